@@ -1,0 +1,125 @@
+"""Pins the CPU oracle (oracle/dense_ref.py) to the golden vectors captured from the reference
+(oracle/gen_golden.py).  Runs anywhere (no GPU)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, params_of
+from oracle import dense_ref as R
+
+TOL = dict(rtol=1e-5, atol=1e-5)
+
+
+def T(a):
+    return torch.tensor(a)
+
+
+def check_grads(g, p):
+    for k, t in p.items():
+        if "g." + k in g:
+            got = t.grad if t.grad is not None else torch.zeros_like(t)
+            np.testing.assert_allclose(got.numpy(), g["g." + k], err_msg=k, **TOL)
+
+
+@pytest.mark.parametrize("tag", ["sum_norm_bias", "self_nonorm_nobias", "weighted_norm_bias"])
+def test_graphconv(tag):
+    g = load_golden("graphconv_" + tag)
+    p = params_of(g, requires_grad=True)
+    x = T(g["x"]).requires_grad_(True)
+    y = R.graph_conv(x, T(g["adj"]), p["weight"], p.get("bias"), bool(g["add_self"]), bool(g["normalize"]))
+    np.testing.assert_allclose(y.detach().numpy(), g["y"], **TOL)
+    (y * T(g["gy"])).sum().backward()
+    np.testing.assert_allclose(x.grad.numpy(), g["gx"], **TOL)
+    check_grads(g, p)
+
+
+@pytest.mark.parametrize("tag", ["b5", "b1"])
+def test_bn_slots(tag):
+    g = load_golden("apply_bn_" + tag)
+    x = T(g["x"]).requires_grad_(True)
+    y = R.bn_slots(x)
+    np.testing.assert_allclose(y.detach().numpy(), g["y"], rtol=1e-4, atol=1e-5)
+    (y * T(g["gy"])).sum().backward()
+    np.testing.assert_allclose(x.grad.numpy(), g["gx"], rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("tag", ["cls_bn_l3", "emb_bn_l3", "pre_nobn_l2", "cls_bn_l4_b1"])
+def test_gcn_encoder(tag):
+    g = load_golden("gcn_encoder_" + tag)
+    p = params_of(g, requires_grad=True)
+    a, b = R.gcn_encoder(p, T(g["x"]), T(g["adj"]), bn=bool(g["bn"]), final_dim=str(g["final_dim"]))
+    np.testing.assert_allclose(a.detach().numpy(), g["out_a"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(b.detach().numpy(), g["out_b"], rtol=1e-4, atol=1e-5)
+    ((a * T(g["ga"])).sum() + (b * T(g["gb"])).sum()).backward()
+    for k, t in p.items():
+        if "g." + k in g:
+            got = t.grad if t.grad is not None else torch.zeros_like(t)
+            np.testing.assert_allclose(got.numpy(), g["g." + k], err_msg=k, rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("tag", ["p1", "p2", "p1_nomask"])
+def test_diffpool_encoder(tag):
+    g = load_golden("diffpool_" + tag)
+    p = params_of(g, requires_grad=True)
+    npool = int(g["cfg"][6])
+    bnn = g["sizes"] if int(g["masked"]) else None
+    a, b, s = R.diffpool_encoder(p, T(g["x"]), T(g["adj"]), bnn, npool, assign_x=T(g["x"]),
+                                 final_dim=str(g["final_dim"]), return_assign=True)
+    np.testing.assert_allclose(a.detach().numpy(), g["out_a"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(b.detach().numpy(), g["out_b"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(s.detach().numpy(), g["assign_last"], rtol=1e-4, atol=1e-5)
+    ((a * T(g["ga"])).sum() + (b * T(g["gb"])).sum()).backward()
+    for k, t in p.items():
+        if "g." + k in g:
+            got = t.grad if t.grad is not None else torch.zeros_like(t)
+            np.testing.assert_allclose(got.numpy(), g["g." + k], err_msg=k, rtol=2e-3, atol=2e-4)
+
+
+def test_diffpool_contract():
+    g = load_golden("diffpool_contract")
+    s, z, adj = (T(g[k]).requires_grad_(True) for k in ("s", "z", "adj"))
+    xo, ao = R.diffpool_contract(s, z, adj)
+    np.testing.assert_allclose(xo.detach().numpy(), g["x_out"], **TOL)
+    np.testing.assert_allclose(ao.detach().numpy(), g["adj_out"], **TOL)
+    ((xo * T(g["gx"])).sum() + (ao * T(g["ga"])).sum()).backward()
+    np.testing.assert_allclose(s.grad.numpy(), g["gs"], **TOL)
+    np.testing.assert_allclose(z.grad.numpy(), g["gz"], **TOL)
+    np.testing.assert_allclose(adj.grad.numpy(), g["gadj"], **TOL)
+
+
+@pytest.mark.parametrize("tag", ["b1_concat", "b1_raw", "b2_concat"])
+def test_gat_head(tag):
+    g = load_golden("gat_head_" + tag)
+    p = params_of(g, requires_grad=True)
+    x = T(g["x"]).requires_grad_(True)
+    y = R.gat_head(x, T(g["adj"]), p["w"], p["a"], concat=bool(g["concat"]))
+    np.testing.assert_allclose(y.detach().numpy(), g["y"], **TOL)
+    (y * T(g["gy"])).sum().backward()
+    np.testing.assert_allclose(x.grad.numpy(), g["gx"], rtol=1e-4, atol=1e-5)
+    check_grads(g, p)
+
+
+@pytest.mark.parametrize("tag", ["concat_h3", "mean_h2"])
+def test_gat_layer(tag):
+    g = load_golden("gat_layer_" + tag)
+    p = {"L." + k: v for k, v in params_of(g, requires_grad=True).items()}
+    x = T(g["x"]).requires_grad_(True)
+    y = R.gat_layer(p, "L", x, T(g["adj"]), concat=bool(g["concat"]))
+    np.testing.assert_allclose(y.detach().numpy(), g["y"], **TOL)
+    (y * T(g["gy"])).sum().backward()
+    np.testing.assert_allclose(x.grad.numpy(), g["gx"], rtol=1e-4, atol=1e-5)
+    for k, t in p.items():
+        np.testing.assert_allclose(t.grad.numpy(), g["g." + k[2:]], err_msg=k, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["l2", "l3"])
+def test_gat_encoder(tag):
+    g = load_golden("gat_encoder_" + tag)
+    p = params_of(g, requires_grad=True)
+    a, b = R.gat_encoder(p, T(g["x"]), T(g["adj"]), final_dim=str(g["final_dim"]))
+    np.testing.assert_allclose(a.detach().numpy(), g["out_a"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(b.detach().numpy(), g["out_b"], rtol=1e-4, atol=1e-5)
+    ((a * T(g["ga"])).sum() + (b * T(g["gb"])).sum()).backward()
+    for k, t in p.items():
+        if "g." + k in g and t.grad is not None:
+            np.testing.assert_allclose(t.grad.numpy(), g["g." + k], err_msg=k, rtol=1e-3, atol=1e-4)
