@@ -1,0 +1,147 @@
+/* libtsgnn_hip — C ABI of the MI355X (gfx950) message-passing / aggregation hot path.
+ *
+ * The reference (manhtuando97/two-stage-gnn) is pure Python and has no FFI; its boundary for this
+ * path is the nn.Module surface of Code/sage+gat+diffpool/encoders.py, encoders_GAT.py and
+ * Code/sag/layers.py.  This header is what a ctypes binding on the reference side binds (see
+ * INTEGRATION.md); every entry point names the reference lines whose arithmetic it replaces.
+ *
+ * Conventions (all entry points):
+ *   - plain device pointers + sizes; no torch types; caller owns every buffer;
+ *   - fp32 values, int32 indices unless stated (int64 only where PyG's edge_index is consumed);
+ *   - returns 0 on success, <0 on error (TSGNN_E*); never throws, never allocates, never
+ *     synchronises, launches on `stream` (graph-capturable);
+ *   - re-entrant, no global state: one process per GPU is safe.
+ */
+#ifndef TSGNN_H
+#define TSGNN_H
+#include <stdint.h>
+
+/* == hipStream_t (HIP declares it as `struct ihipStream_t*`); spelled out so that plain C callers
+ * (gcc, cgo, ctypes generators) need no HIP headers. */
+typedef struct ihipStream_t* tsgnn_stream_t;
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TSGNN_ABI_VERSION 1
+int tsgnn_abi_version(void);
+const char* tsgnn_strerror(int code);
+
+/* ---------------------------------------------------------------- graph ingest (graph_build.hip) */
+
+/* ints of scratch needed by tsgnn_exclusive_scan_i32 / tsgnn_csr_transpose for n items */
+int tsgnn_scan_workspace_ints(int64_t n, int64_t* ws_ints);
+/* out[0..n] = exclusive prefix sums of in[0..n-1] (out[n] = total) */
+int tsgnn_exclusive_scan_i32(const int* in, int64_t n, int* out, int* ws, tsgnn_stream_t stream);
+
+/* row -> graph id / slot-within-graph for rows laid out graph after graph (graph_ptr[B+1]).
+ * Replaces the implicit (b, n) indexing of the padded [B,Nmax,*] tensors (graph_sampler.py:102-114)
+ * and GcnEncoderGraph.construct_mask's python loop (encoders.py:121-132). */
+int tsgnn_row_maps(const int* graph_ptr, int B, int64_t n_rows, int* row_graph, int* row_slot,
+                   tsgnn_stream_t stream);
+
+/* dense padded adjacency adj[B,Nmax,Nmax] (train.py:114) -> CSR over rows r = graph_ptr[b]+n,
+ * columns ascending, values kept (normalised adjacencies stay weighted).
+ * pass 1: row_cnt[r] = nnz of adj[b,n,0:size_b];  (scan row_cnt -> rowptr);  pass 2: fill. */
+int tsgnn_dense_adj_count(const float* adj, int B, int nmax, const int* graph_ptr, const int* row_graph,
+                          int64_t n_rows, int* row_cnt, tsgnn_stream_t stream);
+int tsgnn_dense_adj_fill(const float* adj, int B, int nmax, const int* graph_ptr, const int* row_graph,
+                         int64_t n_rows, const int* rowptr, int* col, float* val, tsgnn_stream_t stream);
+
+/* COO edge list (PyG edge_index rows, int64; Code/sag/network.py:31) -> CSR grouped by `key`
+ * (key = edge_index[1] = target for message passing).  Stable: entries of a row keep edge order;
+ * eid[p] = original edge id.  bad_flag != 0 afterwards if any key was out of range. */
+int tsgnn_coo_count(const int64_t* key, int64_t E, int64_t n_rows, int* cnt, int* bad_flag,
+                    tsgnn_stream_t stream);
+int tsgnn_coo_fill(const int64_t* key, const int64_t* other, int64_t E, int64_t n_rows, const int* rowptr,
+                   int* cursor, int* col, int* eid, tsgnn_stream_t stream);
+
+/* CSR transpose (A^T for dX = A^T dY); rows of the result sorted by column; src_e[p] = source entry */
+int tsgnn_csr_transpose(const int* rowptr, const int* col, const float* val, int64_t n_rows, int64_t n_cols,
+                        int64_t nnz, int* rowptr_t, int* col_t, float* val_t, int* src_e, int* cnt_ws,
+                        int* scan_ws, tsgnn_stream_t stream);
+
+/* ---------------------------------------------------------------- aggregation (aggregate.hip) */
+
+/* y[i,:] (+)= sum_e val[e] * act(x[col[e],:]) + (self_w[i] + self_scalar) * act(x[i,:])
+ *   val == NULL: unit weights;  act = relu if relu_in else identity.
+ * Replaces torch.matmul(adj, x) [+ x] of GraphConv.forward (encoders.py:33-35) and the scatter-add
+ * propagate of PyG GCNConv / SAGEConv / GraphConv (Code/sag/network.py:34, layers.py:18).
+ * Backward of the same op = this call on the transposed CSR. */
+int tsgnn_csr_spmm_f32(const int* rowptr, const int* col, const float* val, const float* self_w,
+                       const float* x, int64_t ldx, float* y, int64_t ldy, int64_t n_rows, int feat,
+                       float self_scalar, int relu_in, int accumulate, tsgnn_stream_t stream);
+
+/* PyG gcn_norm (add remaining self loops of weight self_fill, symmetric D^-1/2 (A+I) D^-1/2):
+ * dinv[i], val_out[e] = dinv[i]*val[e]*dinv[col[e]], self_w[i] = dinv[i]^2*self_fill (0 if the row
+ * already has a self loop).  Call site: GCNConv in Code/sag/network.py:19-23, layers.py:12. */
+int tsgnn_gcn_norm_f32(const int* rowptr, const int* col, const float* val, int64_t n_rows, float self_fill,
+                       float* dinv, float* val_out, float* self_w, tsgnn_stream_t stream);
+
+/* ---------------------------------------------------------------- dense transform (gemm.hip, linear.hip) */
+
+/* C[z] (+)= alpha * op(A[z]) . op(B[z]); element (m,k) of op(A) at A + m*sam + k*sak (transposes are
+ * strides).  batch: strided (stride_*) or ragged via seg_ptr (ragged = 1: K dimension covers rows
+ * [seg_ptr[z], seg_ptr[z+1]) of both operands; ragged = 2: the M dimension of A and C; max_seg =
+ * longest segment).  fp32 MFMA.  Replaces torch.matmul(y, W) (encoders.py:36), h = x[0] @ w
+ * (encoders_GAT.py:32) and DiffPool's S^T Z / S^T A S (encoders.py:374-375) incl. their backward. */
+int tsgnn_gemm_f32(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn, float* C,
+                   int64_t scm, int64_t scn, int M, int N, int K, int batch, int64_t stride_a, int64_t stride_b,
+                   int64_t stride_c, const int* seg_ptr, int ragged, int max_seg, float alpha, int accumulate,
+                   tsgnn_stream_t stream);
+/* split-K plan + product for weight gradients dW = Z^T dU (K = number of graph rows); partial slabs are
+ * summed in a fixed order (bitwise reproducible, no float atomics). C dense row-major [M,N]. */
+int tsgnn_gemm_splitk_plan(int M, int N, int K, int* ksplit, int64_t* ws_floats);
+int tsgnn_gemm_splitk_f32(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn,
+                          float* C, int M, int N, int K, int ksplit, float* ws, int accumulate,
+                          tsgnn_stream_t stream);
+/* out[f] (+)= sum_r x[r,f] (bias gradients); ws >= ceil(rows/512)*F floats */
+int tsgnn_colsum_f32(const float* x, int64_t ld, int64_t rows, int F, float* out, float* ws, int accumulate,
+                     tsgnn_stream_t stream);
+
+/* v = normalize(z.W + bias, p=2, dim=1, eps=1e-12) (normalize=0: plain affine); rinv[r] = 1/max(|u_r|,eps).
+ * GraphConv.forward lines encoders.py:36-40 as one kernel.  N <= 256. */
+int tsgnn_linear_l2norm_f32(const float* z, int64_t ldz, const float* w, int64_t ldw, const float* bias, float* v,
+                            int64_t ldv, float* rinv, int64_t rows, int K, int N, int normalize,
+                            tsgnn_stream_t stream);
+/* backward of the row normalisation: du = rinv * (dv - v (v.dv)) */
+int tsgnn_l2norm_bwd_f32(const float* v, int64_t ldv, const float* dv, int64_t lddv, const float* rinv, float* du,
+                         int64_t lddu, int64_t rows, int F, tsgnn_stream_t stream);
+
+/* ---------------------------------------------------------------- slot batch-norm + readout (bn_readout.hip) */
+
+/* Rows: [0,n_real) real nodes graph after graph; [n_real, n_real+n_ghost) one "ghost" row per node slot
+ * standing for the reference's padded rows of that slot (n_ghost = nmax, multiplicity B - slot_count[n])
+ * or n_ghost = 0 (padded layout: every row is materialised).
+ * y = (act(v) - mean[slot]) * rstd[slot], act = relu if relu; bn = 0: y = act(v).
+ * Replaces self.act + apply_bn (encoders.py:179-181, 134-138): fresh BatchNorm1d(Nmax) per call. */
+int tsgnn_bn_slots_fwd_f32(const int* graph_ptr, const int* slot_count, const int* row_slot, int B, int nmax,
+                           int64_t n_real, int n_ghost, const float* v, int64_t ldv, int F, int relu, int bn,
+                           float* mean, float* rstd, float* y, int64_t ldy, tsgnn_stream_t stream);
+int tsgnn_bn_slots_bwd_f32(const int* graph_ptr, const int* slot_count, const int* row_slot, int B, int nmax,
+                           int64_t n_real, int n_ghost, const float* v, int64_t ldv, const float* dy, int64_t lddy, int F,
+                           int relu, int bn, const float* mean, const float* rstd, float* m1, float* m2, float* dv,
+                           int64_t lddv, tsgnn_stream_t stream);
+
+/* out[b,f] = max over the nmax node slots of graph b (ghost rows included, trap T5), arg = winning row.
+ * Replaces torch.max(x, dim=1) (encoders.py:183,190,197,353,383). packed_ws: B*F uint64 scratch. */
+int tsgnn_readout_max_fwd_f32(const int* graph_ptr, const int* slot_count, int B, int nmax, int64_t n_real, int n_ghost,
+                              const float* x, int64_t ldx, int F, int relu, unsigned long long* packed_ws, float* out,
+                              int64_t ldo, int* arg, tsgnn_stream_t stream);
+/* dx[arg[b,f], f] += dout[b,f] (dx pre-initialised by the caller) */
+int tsgnn_readout_max_bwd_f32(const float* dout, int64_t ldo, const int* arg, int B, int F, const float* x, int64_t ldx_in,
+                              int relu, int64_t n_real, float* dx, int64_t ldx, tsgnn_stream_t stream);
+
+/* padded [B,nmax,F] (graph_sampler.py:110-114) <-> packed rows */
+int tsgnn_pack_rows_f32(const float* src, int nmax, int F, const int* row_graph, const int* row_slot, int64_t n_real,
+                        float* dst, int64_t ld, tsgnn_stream_t stream);
+int tsgnn_unpack_rows_f32(const int* graph_ptr, int B, int nmax, int64_t n_real, int n_ghost, const float* src, int64_t ld,
+                          int F, float fill, float* dst, tsgnn_stream_t stream);
+int tsgnn_unpack_rows_bwd_ghost_f32(const int* graph_ptr, int B, int nmax, int64_t n_real, const float* ddst, int F,
+                                    float* dsrc, int64_t ld, tsgnn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSGNN_H */

@@ -1,0 +1,94 @@
+"""GPU parity of the drop-in encoders against the golden vectors captured from the reference
+(tests/golden, made by oracle/gen_golden.py) and against the CPU oracle at larger sizes."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, params_of
+from oracle import dense_ref as R
+from util_graphs import dense_batch, dd_like_sizes
+
+pytestmark = pytest.mark.gpu
+
+
+def load_state(module, g):
+    sd = {k[2:]: torch.tensor(v) for k, v in g.items() if k.startswith("p.")}
+    module.load_state_dict(sd, strict=True)
+    return module.cuda()
+
+
+def check_param_grads(module, g, rtol, atol):
+    for k, p in module.named_parameters():
+        ref = g["g." + k]
+        got = p.grad.cpu().numpy() if p.grad is not None else np.zeros_like(ref)
+        np.testing.assert_allclose(got, ref, rtol=rtol, atol=atol, err_msg=k)
+
+
+@pytest.mark.parametrize("tag", ["sum_norm_bias", "self_nonorm_nobias", "weighted_norm_bias"])
+@pytest.mark.parametrize("path", ["dense_small", "csr_padded"])
+def test_graphconv_golden(tag, path, monkeypatch):
+    from two_stage_gnn_amd import dense_encoders as E
+    g = load_golden("graphconv_" + tag)
+    if path == "csr_padded":
+        monkeypatch.setattr(E, "DENSE_ADJ_MAX_NODES", 0)
+    m = E.GraphConv(g["x"].shape[2], g["y"].shape[2], add_self=bool(g["add_self"]),
+                    normalize_embedding=bool(g["normalize"]), bias=("p.bias" in g))
+    load_state(m, g)
+    x = torch.tensor(g["x"]).cuda().requires_grad_(True)
+    y = m(x, torch.tensor(g["adj"]).cuda())
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g["y"], rtol=1e-4, atol=1e-5)
+    (y * torch.tensor(g["gy"]).cuda()).sum().backward()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g["gx"], rtol=1e-4, atol=1e-5)
+    check_param_grads(m, g, 1e-4, 1e-5)
+
+
+@pytest.mark.parametrize("tag", ["cls_bn_l3", "emb_bn_l3", "pre_nobn_l2", "cls_bn_l4_b1"])
+@pytest.mark.parametrize("layout", ["packed", "padded"])
+def test_gcn_encoder_golden(tag, layout):
+    from two_stage_gnn_amd import dense_encoders as E
+    g = load_golden("gcn_encoder_" + tag)
+    fin, hid, emb, lab = (int(v) for v in g["dims"])
+
+    class A:
+        bias = True
+    m = E.GcnEncoderGraph(fin, hid, emb, lab, int(g["num_layers"]), bn=bool(g["bn"]), args=A(),
+                          final_dim=str(g["final_dim"]))
+    load_state(m, g)
+    x, adj = torch.tensor(g["x"]).cuda(), torch.tensor(g["adj"]).cuda()
+    a, b = m(x, adj, g["sizes"] if layout == "packed" else None)
+    np.testing.assert_allclose(a.detach().cpu().numpy(), g["out_a"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(b.detach().cpu().numpy(), g["out_b"], rtol=1e-4, atol=1e-5)
+    ((a * torch.tensor(g["ga"]).cuda()).sum() + (b * torch.tensor(g["gb"]).cuda()).sum()).backward()
+    check_param_grads(m, g, 2e-3, 2e-4)
+
+
+@pytest.mark.parametrize("B,nmax,nbar,fin,hid", [(8, 160, 60, 89, 128), (4, 400, 269, 89, 128)])
+def test_gcn_encoder_vs_oracle_dd_shape(B, nmax, nbar, fin, hid):
+    """DD-shaped batches (README.md:39: avg 269 nodes / 676 edges, 89 node labels), 3 layers h=128:
+    HIP packed path vs the CPU oracle's dense formulation, outputs and all parameter gradients."""
+    from two_stage_gnn_amd import dense_encoders as E
+    sizes = dd_like_sizes(7, B, nbar=nbar, nmax=nmax)
+    x, adj, sizes = dense_batch(21, B, nmax, fin, sizes=sizes.tolist(), p_edge=2 * 676 / 269 / 269 * (269 / nbar))
+
+    class A:
+        bias = True
+    torch.manual_seed(0)
+    m = E.GcnEncoderGraph(fin, hid, hid, 2, 3, bn=True, args=A(), final_dim="number_classes")
+    with torch.no_grad():
+        for k, p in m.named_parameters():
+            if k.endswith("bias") and "conv" in k:
+                p.copy_(torch.randn_like(p) * 0.2)
+    m = m.cuda()
+    p_ref = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    a_ref, b_ref = R.gcn_encoder(p_ref, x, adj, bn=True, final_dim="number_classes")
+    label = torch.arange(B) % 2
+    torch.nn.functional.cross_entropy(b_ref, label).backward()
+    a, b = m(x.cuda(), adj.cuda(), sizes)
+    torch.testing.assert_close(a.detach().cpu(), a_ref.detach(), rtol=1e-4, atol=1e-4)     # north_star: 1e-4 fp32
+    torch.testing.assert_close(b.detach().cpu(), b_ref.detach(), rtol=1e-4, atol=1e-4)
+    m.loss(b, label.cuda()).backward()
+    for k, p in m.named_parameters():
+        ref = p_ref[k].grad
+        if ref is None:
+            continue
+        torch.testing.assert_close(p.grad.cpu(), ref, rtol=5e-3, atol=1e-5, msg=lambda s, k=k: k + ": " + s)

@@ -1,0 +1,214 @@
+"""GPU parity of the individual HIP kernels (through the C ABI) against the CPU oracle / dense torch math."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, params_of
+from oracle import dense_ref as R
+from util_graphs import dense_batch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def T():
+    import two_stage_gnn_amd  # noqa
+    from two_stage_gnn_amd import message_passing as mp
+    from two_stage_gnn_amd.graph import GraphBatch
+    return mp, GraphBatch
+
+
+def csr_to_dense(g, n):
+    rp = g.rowptr.cpu().numpy(); col = g.col.cpu().numpy()
+    val = g.val.cpu().numpy() if g.val is not None else np.ones(len(col), np.float32)
+    d = np.zeros((n, n), np.float32)
+    for r in range(n):
+        for e in range(rp[r], rp[r + 1]):
+            d[r, col[e]] += val[e]
+    return d
+
+
+@pytest.mark.parametrize("weighted,symmetric", [(False, True), (True, True), (True, False)])
+def test_dense_to_csr_layouts(T, weighted, symmetric):
+    mp, GB = T
+    x, adj, sizes = dense_batch(1, 5, 70, 3, weighted=weighted, symmetric=symmetric)
+    # padded layout: block-diagonal of the padded matrices
+    g = GB.from_dense(adj.cuda(), layout="padded")
+    assert g.total_rows == 5 * 70 and g.n_ghost == 0
+    d = csr_to_dense(g, g.total_rows)
+    for b in range(5):
+        np.testing.assert_array_equal(d[b * 70:(b + 1) * 70, b * 70:(b + 1) * 70], adj[b].numpy())
+    assert d.sum() == pytest.approx(float(adj.sum()), rel=1e-6)
+    # packed layout: real rows only + nmax empty ghost rows
+    g = GB.from_dense(adj.cuda(), sizes=sizes, layout="packed")
+    assert g.n_rows == sizes.sum() and g.n_ghost == 70
+    d = csr_to_dense(g, g.total_rows)
+    o = 0
+    for b, n in enumerate(sizes):
+        np.testing.assert_array_equal(d[o:o + n, o:o + n], adj[b, :n, :n].numpy())
+        o += n
+    assert d[o:].sum() == 0 and d[:, o:].sum() == 0
+    # transpose
+    rp, col, val = g.transposed()
+    class G2: pass
+    g2 = G2(); g2.rowptr, g2.col, g2.val = rp, col, val
+    np.testing.assert_allclose(csr_to_dense(g2, g.total_rows), d.T)
+    sc = g.slot_count.cpu().numpy()
+    np.testing.assert_array_equal(sc, [(sizes > n).sum() for n in range(70)])
+
+
+def test_scan_large(T):
+    mp, GB = T
+    from two_stage_gnn_amd.graph import exclusive_scan
+    for n in [1, 7, 2048, 2049, 100003, 1 << 21]:
+        c = torch.randint(0, 9, (n,), dtype=torch.int32, device="cuda")
+        out = exclusive_scan(c).cpu().numpy()
+        ref = np.concatenate([[0], np.cumsum(c.cpu().numpy())])
+        np.testing.assert_array_equal(out, ref)
+
+
+def test_coo_to_csr(T):
+    mp, GB = T
+    gen = torch.Generator().manual_seed(3)
+    N, E = 200, 1500
+    ei = torch.randint(0, N, (2, E), generator=gen)
+    g = GB.from_edge_index(ei.cuda(), N)
+    rp = g.rowptr.cpu().numpy(); col = g.col.cpu().numpy(); eid = g.eid.cpu().numpy()
+    assert rp[-1] == E
+    for i in range(N):
+        es = np.nonzero(ei[1].numpy() == i)[0]          # stable: original edge order
+        np.testing.assert_array_equal(eid[rp[i]:rp[i + 1]], es)
+        np.testing.assert_array_equal(col[rp[i]:rp[i + 1]], ei[0].numpy()[es])
+    with pytest.raises(IndexError):
+        GB.from_edge_index(torch.tensor([[0, 1], [1, 999]]).cuda(), 10)
+
+
+@pytest.mark.parametrize("F", [1, 3, 8, 48, 64, 89, 92, 128, 200, 256, 320])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_spmm_vs_dense(T, F, weighted):
+    mp, GB = T
+    x, adj, sizes = dense_batch(F + weighted, 6, 90, F, weighted=weighted, p_edge=0.15)
+    g = GB.from_dense(adj.cuda(), layout="padded")
+    if not weighted:
+        g.val = None
+    xr = x.reshape(-1, F).cuda().requires_grad_(True)
+    for add_self in (False, True):
+        y = mp.aggregate(xr, g, add_self=add_self)
+        ref = torch.matmul(adj, x) + (x if add_self else 0)
+        torch.testing.assert_close(y.detach().cpu().reshape(6, 90, F), ref, rtol=1e-5, atol=1e-5)
+    gy = torch.randn(6 * 90, F, generator=torch.Generator().manual_seed(5))
+    y = mp.aggregate(xr, g, add_self=True)
+    (y * gy.cuda()).sum().backward()
+    gref = torch.matmul(adj.transpose(1, 2), gy.reshape(6, 90, F)) + gy.reshape(6, 90, F)
+    torch.testing.assert_close(xr.grad.cpu().reshape(6, 90, F), gref, rtol=1e-5, atol=1e-5)
+
+
+def test_spmm_high_degree_and_nonsymmetric(T):
+    mp, GB = T
+    x, adj, sizes = dense_batch(11, 2, 300, 128, p_edge=0.6, symmetric=False, weighted=True)   # degree ~180 > 64
+    g = GB.from_dense(adj.cuda(), layout="padded")
+    xr = x.reshape(-1, 128).cuda().requires_grad_(True)
+    y = mp.aggregate(xr, g)
+    torch.testing.assert_close(y.detach().cpu().reshape(2, 300, 128), adj @ x, rtol=1e-4, atol=1e-4)
+    gy = torch.randn(600, 128)
+    (y * gy.cuda()).sum().backward()
+    torch.testing.assert_close(xr.grad.cpu().reshape(2, 300, 128), adj.transpose(1, 2) @ gy.reshape(2, 300, 128),
+                               rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("K,N,normalize,bias", [(5, 7, True, True), (89, 128, True, True), (128, 128, True, False),
+                                                 (92, 64, False, True), (33, 200, True, True), (128, 256, True, True),
+                                                 (300, 20, True, True), (7, 1, False, True)])
+def test_linear_l2norm(T, K, N, normalize, bias):
+    mp, GB = T
+    gen = torch.Generator().manual_seed(K * 1000 + N)
+    R_ = 777
+    z = torch.randn(R_, K + (3 if K == 89 else 0), generator=gen)
+    if K == 89:
+        z[:, 89:] = 0
+    w = torch.randn(K, N, generator=gen) * 0.3
+    b = torch.randn(N, generator=gen) if bias else None
+    z[5] = 0                                         # a row whose pre-norm output is exactly the bias
+    zc, wc = z.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    bc = b.clone().requires_grad_(True) if bias else None
+    u = zc[:, :K] @ wc + (bc if bias else 0)
+    ref = torch.nn.functional.normalize(u, p=2, dim=1) if normalize else u
+    zg, wg = z.cuda().requires_grad_(True), w.cuda().requires_grad_(True)
+    bg = b.cuda().requires_grad_(True) if bias else None
+    v = mp.linear_l2norm(zg, wg, bg, normalize=normalize)
+    torch.testing.assert_close(v.detach().cpu(), ref.detach(), rtol=2e-5, atol=2e-5)
+    gy = torch.randn(R_, N, generator=gen)
+    (ref * gy).sum().backward()
+    (v * gy.cuda()).sum().backward()
+    torch.testing.assert_close(zg.grad.cpu()[:, :K], zc.grad[:, :K], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(wg.grad.cpu(), wc.grad, rtol=1e-4, atol=2e-4)
+    if bias:
+        torch.testing.assert_close(bg.grad.cpu(), bc.grad, rtol=1e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("tag", ["b5", "b1"])
+def test_bn_slots_golden(T, tag):
+    mp, GB = T
+    g = load_golden("apply_bn_" + tag)
+    x = torch.tensor(g["x"])
+    B, N, F = x.shape
+    gb = GB.structure_only(np.full(B, N), N, torch.device("cuda"), ghosts=False)
+    xr = x.reshape(B * N, F).cuda().requires_grad_(True)
+    y = mp.bn_slots(xr, gb, relu=False, bn=True)
+    np.testing.assert_allclose(y.detach().cpu().numpy().reshape(B, N, F), g["y"], rtol=1e-4, atol=1e-5)
+    (y * torch.tensor(g["gy"]).reshape(B * N, F).cuda()).sum().backward()
+    np.testing.assert_allclose(xr.grad.cpu().numpy().reshape(B, N, F), g["gx"], rtol=1e-4, atol=2e-5)
+
+
+def test_ghost_rows_equal_padded(T):
+    """packed rows + per-slot ghost representatives == the reference's padded computation
+    (relu + slot BN + max readout incl. ghost rows), forward and backward."""
+    mp, GB = T
+    B, nmax, F = 6, 40, 16
+    sizes = np.array([40, 13, 27, 5, 31, 13])
+    gen = torch.Generator().manual_seed(9)
+    ghost_val = torch.randn(F, generator=gen)                  # what every padded row carries (normalize(bias))
+    xp = ghost_val.expand(B, nmax, F).clone()
+    for b, n in enumerate(sizes):
+        xp[b, :n] = torch.randn(n, F, generator=gen)
+    xp_ref = xp.clone().requires_grad_(True)
+    y = R.bn_slots(torch.relu(xp_ref))
+    out_ref = y.max(dim=1)[0]
+    gout = torch.randn(B, F, generator=gen)
+    gy = torch.randn(B, nmax, F, generator=gen) * (torch.arange(nmax)[None, :, None] < torch.tensor(sizes)[:, None, None])
+    ((out_ref * gout).sum() + (y * gy).sum()).backward()
+
+    g = GB.structure_only(sizes, nmax, torch.device("cuda"), ghosts=True)
+    rows = torch.zeros(g.total_rows, F)
+    o = 0
+    for b, n in enumerate(sizes):
+        rows[o:o + n] = xp[b, :n]; o += n
+    rows[o:] = ghost_val
+    rows = rows.cuda().requires_grad_(True)
+    yr = mp.bn_slots(rows, g, relu=True, bn=True)
+    out = mp.readout_max(yr, g)
+    torch.testing.assert_close(out.detach().cpu(), out_ref.detach(), rtol=1e-4, atol=1e-5)
+    gy_rows = torch.zeros(g.total_rows, F)
+    o = 0
+    for b, n in enumerate(sizes):
+        gy_rows[o:o + n] = gy[b, :n]; o += n
+    ((out * gout.cuda()).sum() + (yr * gy_rows.cuda()).sum()).backward()
+    gr = rows.grad.cpu()
+    o = 0
+    for b, n in enumerate(sizes):
+        torch.testing.assert_close(gr[o:o + n], xp_ref.grad[b, :n], rtol=1e-3, atol=2e-5); o += n
+    # gradient of a ghost representative = sum over the padded copies it stands for
+    gh = torch.zeros(nmax, F)
+    for b, n in enumerate(sizes):
+        gh[n:] += xp_ref.grad[b, n:]
+    torch.testing.assert_close(gr[o:], gh, rtol=1e-3, atol=2e-5)
+
+
+def test_pack_unpack(T):
+    mp, GB = T
+    x, adj, sizes = dense_batch(4, 4, 20, 6)
+    g = GB.from_dense(adj.cuda(), sizes=sizes, layout="packed")
+    xr = mp.pack_rows(x.cuda(), g, ld=8)
+    assert xr.shape == (g.total_rows, 8)
+    back = mp.unpack_rows(xr[:, :6].contiguous(), g)
+    torch.testing.assert_close(back.cpu(), x)

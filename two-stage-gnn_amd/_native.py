@@ -1,0 +1,137 @@
+"""ctypes binding of libtsgnn_hip.so (the C ABI declared in include/tsgnn.h).
+
+The signatures are parsed from the header itself, so header, library and binding cannot drift.
+There is NO fallback: if the library is missing or a symbol is absent this module raises — the
+product path never computes on the CPU (the CPU oracle lives in oracle/ and is test-only).
+"""
+import ctypes
+import os
+import re
+import subprocess
+
+import torch
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG_DIR)
+HEADER = os.path.join(_ROOT, "include", "tsgnn.h")
+CSRC = os.path.join(_PKG_DIR, "csrc")
+LIB_PATH = os.path.join(_PKG_DIR, "libtsgnn_hip.so")
+
+_SCALARS = {"int": ctypes.c_int, "int64_t": ctypes.c_int64, "float": ctypes.c_float,
+            "unsigned": ctypes.c_uint, "unsigned long long": ctypes.c_ulonglong, "uint64_t": ctypes.c_uint64}
+
+
+def parse_header(path=HEADER):
+    """-> {name: (restype, [(ctype, argname), ...])} for every `int|const char* tsgnn_*(...)`."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", " ", src)
+    out = {}
+    for m in re.finditer(r"\b(int|const char\*)\s+(tsgnn_\w+)\s*\(([^)]*)\)\s*;", src):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        params = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = " ".join(a.split())
+                if "*" in a or a.startswith("tsgnn_stream_t"):
+                    params.append((ctypes.c_void_p, a.split()[-1].lstrip("*")))
+                else:
+                    ty = a.split()[:-1]
+                    ty = [t for t in ty if t != "const"]
+                    params.append((_SCALARS[" ".join(ty)], a.split()[-1]))
+        out[name] = (ctypes.c_int if ret == "int" else ctypes.c_char_p, params)
+    return out
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def build(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -> two-stage-gnn_amd/libtsgnn_hip.so (in-tree, travels with gpurun)."""
+    srcs = sources()
+    deps = srcs + [HEADER] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    if (not force and os.path.exists(LIB_PATH)
+            and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps)):
+        return LIB_PATH
+    objs = []
+    procs = []
+    os.makedirs(os.path.join(_PKG_DIR, "build"), exist_ok=True)
+    for s in srcs:
+        o = os.path.join(_PKG_DIR, "build", os.path.basename(s)[:-4] + ".o")
+        objs.append(o)
+        if (not force and os.path.exists(o)
+                and os.path.getmtime(o) >= max(os.path.getmtime(d) for d in [s, HEADER] + [x for x in deps if x.endswith(".h")])):
+            continue
+        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", s, "-o", o]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for s, p in procs:
+        log = p.communicate()[0].decode()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed on %s:\n%s" % (s, log))
+    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n" + r.stdout.decode())
+    global _lib
+    _lib = None
+    return LIB_PATH
+
+
+_lib = None
+_decls = None
+
+
+def lib():
+    global _lib, _decls
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libtsgnn_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "from the repo root. There is no CPU fallback for the product path." % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    _decls = parse_header()
+    for name, (ret, params) in _decls.items():
+        try:
+            fn = getattr(L, name)
+        except AttributeError:
+            raise RuntimeError("libtsgnn_hip.so does not export %s (declared in include/tsgnn.h); rebuild" % name)
+        fn.restype = ret
+        fn.argtypes = [p[0] for p in params]
+    if L.tsgnn_abi_version() != 1:
+        raise RuntimeError("libtsgnn_hip.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+def stream_handle():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _arg(a):
+    if a is None:
+        return None
+    if isinstance(a, torch.Tensor):
+        if not a.is_cuda:
+            raise RuntimeError("tsgnn kernels take device tensors; got a CPU tensor (no CPU fallback)")
+        return a.data_ptr()
+    return a
+
+
+def call(name, *args):
+    """Call tsgnn_<name>(*args, current_stream); tensors -> device pointers, None -> NULL."""
+    L = lib()
+    fn = getattr(L, "tsgnn_" + name)
+    rc = fn(*[_arg(a) for a in args], stream_handle())
+    if rc != 0:
+        raise RuntimeError("tsgnn_%s failed: %s" % (name, L.tsgnn_strerror(rc).decode()))
+
+
+def call_nostream(name, *args):
+    L = lib()
+    rc = getattr(L, "tsgnn_" + name)(*[_arg(a) for a in args])
+    if rc != 0:
+        raise RuntimeError("tsgnn_%s failed: %s" % (name, L.tsgnn_strerror(rc).decode()))

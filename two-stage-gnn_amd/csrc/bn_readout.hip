@@ -1,0 +1,335 @@
+// Per-node-slot batch norm and node-axis max readout of GcnEncoderGraph.
+//
+//  * apply_bn (encoders.py:134-138) builds a FRESH BatchNorm1d(Nmax) per call: channel = node slot n,
+//    statistics over (graph, feature), biased variance, eps 1e-5, gamma=1, beta=0, always batch stats.
+//    Here rows are laid out graph after graph (graph_ptr); slot n of graph b is row graph_ptr[b]+n when
+//    n < size_b.  The padded "ghost" rows of the reference (slots n >= size_b) all carry one value per
+//    slot; they are represented by ONE row per slot (row n_real + n) with multiplicity
+//    ghost_mult[n] = B - slot_count[n]  (DESIGN.md §ghost rows).  ReLU (encoders.py:179) is folded in:
+//    the kernels consume relu(v).
+//  * readout torch.max(x, dim=1) (encoders.py:183,190,197) INCLUDES ghost rows (trap T5): every graph
+//    has exactly nmax candidate slots; ties resolve to the smallest slot (first occurrence).
+#include "common.h"
+#include "../../include/tsgnn.h"
+
+namespace {
+
+constexpr float BN_EPS = 1e-5f;
+
+struct SlotArgs {
+  const int* graph_ptr;      // [B+1]
+  const int* slot_count;     // [nmax] graphs that have slot n (real row)
+  int B, nmax;
+  int64_t n_real;
+  int n_ghost;               // 0 or nmax
+};
+
+__device__ __forceinline__ float act(float v, int relu) { return relu ? fmaxf(v, 0.f) : v; }
+
+// block reduce of two floats over 256 threads
+__device__ __forceinline__ void block_sum2(float& a, float& b, float* lds /*8 floats*/) {
+  a = wave_sum(a); b = wave_sum(b);
+  const int wid = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { lds[wid] = a; lds[4 + wid] = b; }
+  __syncthreads();
+  a = lds[0] + lds[1] + lds[2] + lds[3];
+  b = lds[4] + lds[5] + lds[6] + lds[7];
+}
+
+// one block per slot: two-pass mean / variance over the slot's rows (L2-hot re-read)
+__global__ __launch_bounds__(256) void bn_slot_stats(SlotArgs s, const float* __restrict__ v, int64_t ld, int F,
+                                                     int relu, float* __restrict__ mean, float* __restrict__ rstd) {
+  __shared__ float lds[8];
+  const int n = blockIdx.x;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int have = s.slot_count[n];
+  const float gm = s.n_ghost ? (float)(s.B - have) : 0.f;      // ghost multiplicity
+  const float cnt = ((float)have + gm) * (float)F;
+  const float* grow = v + (s.n_real + n) * ld;
+  float s1 = 0.f, dummy = 0.f;
+  for (int b = wid; b < s.B; b += 4) {
+    const int g0 = s.graph_ptr[b];
+    if (s.graph_ptr[b + 1] - g0 > n) {
+      const float* row = v + (int64_t)(g0 + n) * ld;
+      for (int f = lane; f < F; f += 64) s1 += act(row[f], relu);
+    }
+  }
+  if (wid == 0 && gm > 0.f) for (int f = lane; f < F; f += 64) s1 += gm * act(grow[f], relu);
+  block_sum2(s1, dummy, lds);
+  const float mu = cnt > 0.f ? s1 / cnt : 0.f;
+  float s2 = 0.f;
+  dummy = 0.f;
+  for (int b = wid; b < s.B; b += 4) {
+    const int g0 = s.graph_ptr[b];
+    if (s.graph_ptr[b + 1] - g0 > n) {
+      const float* row = v + (int64_t)(g0 + n) * ld;
+      for (int f = lane; f < F; f += 64) { const float d = act(row[f], relu) - mu; s2 = fmaf(d, d, s2); }
+    }
+  }
+  if (wid == 0 && gm > 0.f) for (int f = lane; f < F; f += 64) { const float d = act(grow[f], relu) - mu; s2 = fmaf(gm * d, d, s2); }
+  block_sum2(s2, dummy, lds);
+  if (threadIdx.x == 0) {
+    const float var = cnt > 0.f ? s2 / cnt : 0.f;
+    mean[n] = mu;
+    rstd[n] = 1.0f / sqrtf(var + BN_EPS);
+  }
+}
+
+// xhat[r,:] = (act(v[r,:]) - mean[slot]) * rstd[slot]; one wave per row
+__global__ __launch_bounds__(256) void bn_slot_apply(const float* __restrict__ v, int64_t ldv, const int* __restrict__ row_slot,
+                                                     int64_t n_real, int64_t rows, int F, int relu,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     float* __restrict__ y, int64_t ldy) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int n = r < n_real ? row_slot[r] : (int)(r - n_real);
+  const float mu = mean ? mean[n] : 0.f, rs = rstd ? rstd[n] : 1.f;
+  for (int f = lane; f < F; f += 64) y[r * ldy + f] = (act(v[r * ldv + f], relu) - mu) * rs;
+}
+
+// backward stats per slot: m1 = sum dy / cnt, m2 = sum dy*xhat / cnt  (ghost rows: plain sums — their
+// dy is already the sum over the copies they stand for)
+__global__ __launch_bounds__(256) void bn_slot_bwd_stats(SlotArgs s, const float* __restrict__ v, int64_t ldv,
+                                                         const float* __restrict__ dy, int64_t lddy, int F, int relu,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         float* __restrict__ m1, float* __restrict__ m2) {
+  __shared__ float lds[8];
+  const int n = blockIdx.x;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int have = s.slot_count[n];
+  const float gm = s.n_ghost ? (float)(s.B - have) : 0.f;
+  const float cnt = ((float)have + gm) * (float)F;
+  const float mu = mean[n], rs = rstd[n];
+  float a = 0.f, c = 0.f;
+  for (int b = wid; b < s.B; b += 4) {
+    const int g0 = s.graph_ptr[b];
+    if (s.graph_ptr[b + 1] - g0 > n) {
+      const int64_t r = g0 + n;
+      for (int f = lane; f < F; f += 64) {
+        const float d = dy[r * lddy + f];
+        a += d;
+        c = fmaf(d, (act(v[r * ldv + f], relu) - mu) * rs, c);
+      }
+    }
+  }
+  if (wid == 0 && s.n_ghost) {
+    const int64_t r = s.n_real + n;
+    for (int f = lane; f < F; f += 64) {
+      const float d = dy[r * lddy + f];
+      a += d;
+      c = fmaf(d, (act(v[r * ldv + f], relu) - mu) * rs, c);
+    }
+  }
+  block_sum2(a, c, lds);
+  if (threadIdx.x == 0) { m1[n] = cnt > 0.f ? a / cnt : 0.f; m2[n] = cnt > 0.f ? c / cnt : 0.f; }
+}
+
+// dv[r,:] = relu'(v) * rstd * (dy - w_r (m1 + xhat m2)),  w_r = 1 (real) or ghost multiplicity
+__global__ __launch_bounds__(256) void bn_slot_bwd_apply(SlotArgs s, const float* __restrict__ v, int64_t ldv,
+                                                         const float* __restrict__ dy, int64_t lddy,
+                                                         const int* __restrict__ row_slot, int64_t rows, int F, int relu,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         const float* __restrict__ m1, const float* __restrict__ m2,
+                                                         float* __restrict__ dv, int64_t lddv) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const bool ghost = r >= s.n_real;
+  const int n = ghost ? (int)(r - s.n_real) : row_slot[r];
+  float w = 1.f, mu = 0.f, rs = 1.f, a1 = 0.f, a2 = 0.f;
+  if (mean) {
+    if (ghost) w = (float)(s.B - s.slot_count[n]);
+    mu = mean[n]; rs = rstd[n]; a1 = m1[n]; a2 = m2[n];
+  }
+  for (int f = lane; f < F; f += 64) {
+    const float x = v[r * ldv + f];
+    const float xh = (act(x, relu) - mu) * rs;
+    float g = rs * (dy[r * lddy + f] - w * (a1 + xh * a2));
+    if (relu && !(x > 0.f)) g = 0.f;
+    dv[r * lddv + f] = g;
+  }
+}
+
+// ---------------------------------------------------------------- max readout over node slots
+// grid (chunks of 64 slots, B); block = 4 waves x 16 slots, lanes over features
+__global__ __launch_bounds__(256) void readout_max_partial(SlotArgs s, const float* __restrict__ x, int64_t ld, int F,
+                                                           int relu, unsigned long long* __restrict__ packed) {
+  extern __shared__ unsigned long long best_lds[];          // [4][FP]
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int g0 = s.graph_ptr[b];
+  const int sz = s.graph_ptr[b + 1] - g0;
+  const int nslots = s.n_ghost ? s.nmax : sz;
+  const int n_lo = blockIdx.x * 64, n_hi = min(nslots, n_lo + 64);
+  const int FP = (F + 63) & ~63;
+  for (int fb = 0; fb < F; fb += 64) {
+    const int f = fb + lane;
+    unsigned long long best = 0ull;
+    if (f < F) {
+      for (int n = n_lo + wid; n < n_hi; n += 4) {
+        const int64_t r = n < sz ? (int64_t)g0 + n : s.n_real + n;
+        const float val = act(x[r * ld + f], relu);
+        const unsigned long long p = ((unsigned long long)f32_ordered(val) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)r);
+        best = p > best ? p : best;
+      }
+    }
+    best_lds[wid * FP + fb + lane] = best;
+  }
+  __syncthreads();
+  for (int f = threadIdx.x; f < F; f += 256) {
+    unsigned long long m = best_lds[f];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) { const unsigned long long o = best_lds[w * FP + f]; m = o > m ? o : m; }
+    if (m) atomicMax(&packed[(int64_t)b * F + f], m);
+  }
+}
+__global__ void readout_max_decode(const unsigned long long* __restrict__ packed, int B, int F, float* __restrict__ out,
+                                   int64_t ldo, int* __restrict__ arg) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)B * F) return;
+  const int b = (int)(i / F), f = (int)(i % F);
+  const unsigned long long p = packed[i];
+  out[(int64_t)b * ldo + f] = p ? ordered_f32((unsigned)(p >> 32)) : 0.f;
+  arg[i] = p ? (int)(0xFFFFFFFFu - (unsigned)(p & 0xFFFFFFFFull)) : -1;
+}
+// dx[arg[b,f], f] += dout[b,f]   (ghost rows can be chosen by several graphs -> atomic)
+__global__ void readout_max_bwd(const float* __restrict__ dout, int64_t ldo, const int* __restrict__ arg, int B, int F,
+                                const float* __restrict__ x, int64_t ldx_in, int relu, int64_t n_real,
+                                float* __restrict__ dx, int64_t ldx) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)B * F) return;
+  const int b = (int)(i / F), f = (int)(i % F);
+  const int r = arg[i];
+  if (r < 0) return;
+  if (relu && !(x[(int64_t)r * ldx_in + f] > 0.f)) return;
+  const float g = dout[(int64_t)b * ldo + f];
+  if (r >= n_real) atomicAdd(&dx[(int64_t)r * ldx + f], g);
+  else dx[(int64_t)r * ldx + f] += g;
+}
+
+// ---------------------------------------------------------------- padded <-> packed rows, ghost masking
+__global__ void pack_rows_kernel(const float* __restrict__ src, int nmax, int F, const int* __restrict__ row_graph,
+                                 const int* __restrict__ row_slot, int64_t n_real, float* __restrict__ dst, int64_t ld) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_real * ld) return;
+  const int64_t r = i / ld;
+  const int f = (int)(i % ld);
+  dst[i] = f < F ? src[((int64_t)row_graph[r] * nmax + row_slot[r]) * F + f] : 0.f;
+}
+// dst[b,n,:] = n < size_b ? src[graph_ptr[b]+n] : (ghost rows ? src[n_real+n] : fill)
+__global__ void unpack_rows_kernel(SlotArgs s, const float* __restrict__ src, int64_t ld, int F, float fill,
+                                   float* __restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)s.B * s.nmax * F) return;
+  const int f = (int)(i % F);
+  const int64_t bn = i / F;
+  const int n = (int)(bn % s.nmax), b = (int)(bn / s.nmax);
+  const int g0 = s.graph_ptr[b], sz = s.graph_ptr[b + 1] - g0;
+  float val = fill;
+  if (n < sz) val = src[(int64_t)(g0 + n) * ld + f];
+  else if (s.n_ghost) val = src[(s.n_real + n) * ld + f];
+  dst[i] = val;
+}
+// gradient of unpack wrt the ghost rows: dsrc[n_real+n, f] = sum_{b: size_b <= n} ddst[b,n,f]
+__global__ void unpack_rows_bwd_ghost(SlotArgs s, const float* __restrict__ ddst, int F, float* __restrict__ dsrc, int64_t ld) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)s.nmax * F) return;
+  const int f = (int)(i % F), n = (int)(i / F);
+  float acc = 0.f;
+  for (int b = 0; b < s.B; ++b)
+    if (s.graph_ptr[b + 1] - s.graph_ptr[b] <= n) acc += ddst[((int64_t)b * s.nmax + n) * F + f];
+  dsrc[(s.n_real + n) * ld + f] = acc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tsgnn_bn_slots_fwd_f32(const int* graph_ptr, const int* slot_count, const int* row_slot, int B, int nmax,
+                           int64_t n_real, int n_ghost, const float* v, int64_t ldv, int F, int relu, int bn,
+                           float* mean, float* rstd, float* y, int64_t ldy, tsgnn_stream_t stream) {
+  if (!graph_ptr || !slot_count || !row_slot || !v || !y || B <= 0 || nmax <= 0 || n_real < 0 || F <= 0 ||
+      ldv < F || ldy < F || (n_ghost != 0 && n_ghost != nmax) || (bn && (!mean || !rstd)))
+    return TSGNN_EINVAL;
+  SlotArgs s{graph_ptr, slot_count, B, nmax, n_real, n_ghost};
+  const int64_t rows = n_real + n_ghost;
+  if (bn) bn_slot_stats<<<nmax, 256, 0, stream>>>(s, v, ldv, F, relu, mean, rstd);
+  if (rows > 0)
+    bn_slot_apply<<<(unsigned)ceil_div64(rows, 4), 256, 0, stream>>>(v, ldv, row_slot, n_real, rows, F, relu,
+                                                                     bn ? mean : nullptr, bn ? rstd : nullptr, y, ldy);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+int tsgnn_bn_slots_bwd_f32(const int* graph_ptr, const int* slot_count, const int* row_slot, int B, int nmax,
+                           int64_t n_real, int n_ghost, const float* v, int64_t ldv, const float* dy, int64_t lddy, int F,
+                           int relu, int bn, const float* mean, const float* rstd, float* m1, float* m2, float* dv,
+                           int64_t lddv, tsgnn_stream_t stream) {
+  if (!graph_ptr || !slot_count || !row_slot || !v || !dy || !dv || B <= 0 || nmax <= 0 || n_real < 0 || F <= 0 ||
+      ldv < F || lddy < F || lddv < F || (n_ghost != 0 && n_ghost != nmax) || (bn && (!mean || !rstd || !m1 || !m2)))
+    return TSGNN_EINVAL;
+  SlotArgs s{graph_ptr, slot_count, B, nmax, n_real, n_ghost};
+  const int64_t rows = n_real + n_ghost;
+  if (bn) bn_slot_bwd_stats<<<nmax, 256, 0, stream>>>(s, v, ldv, dy, lddy, F, relu, mean, rstd, m1, m2);
+  if (rows > 0)
+    bn_slot_bwd_apply<<<(unsigned)ceil_div64(rows, 4), 256, 0, stream>>>(
+        s, v, ldv, dy, lddy, row_slot, rows, F, relu, bn ? mean : nullptr, rstd, m1, m2, dv, lddv);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+int tsgnn_readout_max_fwd_f32(const int* graph_ptr, const int* slot_count, int B, int nmax, int64_t n_real, int n_ghost,
+                              const float* x, int64_t ldx, int F, int relu, unsigned long long* packed_ws, float* out,
+                              int64_t ldo, int* arg, tsgnn_stream_t stream) {
+  if (!graph_ptr || !x || !packed_ws || !out || !arg || B <= 0 || nmax <= 0 || F <= 0 || ldx < F || ldo < F ||
+      (n_ghost != 0 && n_ghost != nmax))
+    return TSGNN_EINVAL;
+  SlotArgs s{graph_ptr, slot_count, B, nmax, n_real, n_ghost};
+  (void)hipMemsetAsync(packed_ws, 0, sizeof(unsigned long long) * (size_t)B * F, stream);
+  const int FP = (F + 63) & ~63;
+  dim3 grid((unsigned)((nmax + 63) / 64), (unsigned)B);
+  readout_max_partial<<<grid, 256, sizeof(unsigned long long) * 4 * FP, stream>>>(s, x, ldx, F, relu, packed_ws);
+  readout_max_decode<<<(unsigned)ceil_div64((int64_t)B * F, 256), 256, 0, stream>>>(packed_ws, B, F, out, ldo, arg);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+int tsgnn_readout_max_bwd_f32(const float* dout, int64_t ldo, const int* arg, int B, int F, const float* x, int64_t ldx_in,
+                              int relu, int64_t n_real, float* dx, int64_t ldx, tsgnn_stream_t stream) {
+  if (!dout || !arg || !dx || B <= 0 || F <= 0 || ldo < F || ldx < F || (relu && !x)) return TSGNN_EINVAL;
+  readout_max_bwd<<<(unsigned)ceil_div64((int64_t)B * F, 256), 256, 0, stream>>>(dout, ldo, arg, B, F, x, ldx_in, relu,
+                                                                                n_real, dx, ldx);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+int tsgnn_pack_rows_f32(const float* src, int nmax, int F, const int* row_graph, const int* row_slot, int64_t n_real,
+                        float* dst, int64_t ld, tsgnn_stream_t stream) {
+  if (!src || !row_graph || !row_slot || !dst || nmax <= 0 || F <= 0 || ld < F || n_real < 0) return TSGNN_EINVAL;
+  if (n_real == 0) return TSGNN_OK;
+  pack_rows_kernel<<<(unsigned)ceil_div64(n_real * ld, 256), 256, 0, stream>>>(src, nmax, F, row_graph, row_slot, n_real, dst, ld);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+int tsgnn_unpack_rows_f32(const int* graph_ptr, int B, int nmax, int64_t n_real, int n_ghost, const float* src, int64_t ld,
+                          int F, float fill, float* dst, tsgnn_stream_t stream) {
+  if (!graph_ptr || !src || !dst || B <= 0 || nmax <= 0 || F <= 0 || ld < F) return TSGNN_EINVAL;
+  SlotArgs s{graph_ptr, nullptr, B, nmax, n_real, n_ghost};
+  unpack_rows_kernel<<<(unsigned)ceil_div64((int64_t)B * nmax * F, 256), 256, 0, stream>>>(s, src, ld, F, fill, dst);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+int tsgnn_unpack_rows_bwd_ghost_f32(const int* graph_ptr, int B, int nmax, int64_t n_real, const float* ddst, int F,
+                                    float* dsrc, int64_t ld, tsgnn_stream_t stream) {
+  if (!graph_ptr || !ddst || !dsrc || B <= 0 || nmax <= 0 || F <= 0 || ld < F) return TSGNN_EINVAL;
+  SlotArgs s{graph_ptr, nullptr, B, nmax, n_real, nmax};
+  unpack_rows_bwd_ghost<<<(unsigned)ceil_div64((int64_t)nmax * F, 256), 256, 0, stream>>>(s, ddst, F, dsrc, ld);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,261 @@
+"""Drop-in modules for the reference's dense-batched encoders (Code/sage+gat+diffpool/encoders.py).
+
+Same class names, constructor signatures, parameter names/shapes (``weight[Fin,Fout]``, ``bias[Fout]``,
+``conv_first`` / ``conv_block`` / ``conv_last`` / ``pred_model`` …, so ``state_dict``s interchange) and call
+signatures as the reference, so its scaffolding (train.py:253-260,121; tripletnet.py:36-38) can construct
+and call them unchanged.  Internally nothing is dense: the adjacency becomes a CSR ``GraphBatch`` and every
+tensor op on the message-passing path is a HIP kernel behind include/tsgnn.h.
+
+Accepted inputs of ``forward(x, adj, batch_num_nodes)``:
+  * the reference's tensors ``x[B,Nmax,F]``, ``adj[B,Nmax,Nmax]`` (dense -> CSR conversion on the GPU), or
+  * a prebuilt ``GraphBatch`` as ``adj`` with ``x`` either padded ``[B,Nmax,F]`` or already in rows.
+"""
+import weakref
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import message_passing as mp
+from .graph import GraphBatch
+
+
+def _default_device():
+    return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+
+
+# dense adj tensor -> GraphBatch cache (the three conv layers of an encoder share one conversion)
+_csr_cache = {}
+
+
+def _batch_from_dense(adj, sizes, layout):
+    key = (adj.data_ptr(), tuple(adj.shape), adj._version, layout,
+           None if sizes is None else tuple(int(s) for s in np.asarray(sizes).reshape(-1)))
+    hit = _csr_cache.get(key)
+    if hit is not None and hit[0]() is adj:
+        return hit[1]
+    g = GraphBatch.from_dense(adj.detach(), sizes=sizes, layout=layout)
+    if len(_csr_cache) > 8:
+        _csr_cache.clear()
+    _csr_cache[key] = (weakref.ref(adj), g)
+    return g
+
+
+DENSE_ADJ_MAX_NODES = 128      # at or below this many nodes per graph a dense batched MFMA product is used
+
+
+class _DenseBmm(torch.autograd.Function):
+    """y[b] = adj[b] @ x[b] (+x) for small / differentiable dense adjacencies (pooled DiffPool levels,
+    encoders.py:375-380): batched fp32 MFMA, gradients to BOTH operands."""
+
+    @staticmethod
+    def forward(ctx, adj, x, add_self):
+        adj = adj.contiguous()
+        x = x.contiguous()
+        B, N, Fd = x.shape
+        y = x.clone() if add_self else torch.empty_like(x)
+        mp.gemm(adj, N, 1, x, Fd, 1, y, Fd, 1, N, Fd, N, batch=B, stride_a=N * N, stride_b=N * Fd, stride_c=N * Fd,
+                accumulate=add_self)
+        ctx.save_for_backward(adj, x)
+        ctx.add_self = add_self
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        adj, x = ctx.saved_tensors
+        dy = dy.contiguous()
+        B, N, Fd = x.shape
+        dadj = dx = None
+        if ctx.needs_input_grad[0]:      # dA[b] = dY[b] x[b]^T
+            dadj = torch.empty_like(adj)
+            mp.gemm(dy, Fd, 1, x, 1, Fd, dadj, N, 1, N, N, Fd, batch=B, stride_a=N * Fd, stride_b=N * Fd, stride_c=N * N)
+        if ctx.needs_input_grad[1]:      # dx[b] = A[b]^T dY[b] (+dY)
+            dx = dy.clone() if ctx.add_self else torch.empty_like(x)
+            mp.gemm(adj, 1, N, dy, Fd, 1, dx, Fd, 1, N, Fd, N, batch=B, stride_a=N * N, stride_b=N * Fd, stride_c=N * Fd,
+                    accumulate=ctx.add_self)
+        return dadj, dx, None
+
+
+class GraphConv(nn.Module):
+    """Drop-in for encoders.py:13-42: y = normalize((adj@x [+x]) @ weight + bias)."""
+
+    def __init__(self, input_dim, output_dim, add_self=False, normalize_embedding=False, dropout=0.0, bias=True):
+        super().__init__()
+        self.add_self = add_self
+        self.dropout = dropout
+        if dropout > 0.001:
+            self.dropout_layer = nn.Dropout(p=dropout)
+        self.normalize_embedding = normalize_embedding
+        self.input_dim = input_dim
+        self.output_dim = output_dim
+        dev = _default_device()
+        self.weight = nn.Parameter(torch.empty(input_dim, output_dim, device=dev))
+        self.bias = nn.Parameter(torch.empty(output_dim, device=dev)) if bias else None
+        # the reference leaves the storage uninitialised until its encoder re-initialises it
+        # (encoders.py:88-92); give a stand-alone layer the same Xavier/zero init
+        nn.init.xavier_uniform_(self.weight.data, gain=nn.init.calculate_gain("relu"))
+        if self.bias is not None:
+            nn.init.constant_(self.bias.data, 0.0)
+
+    # rows in, rows out (the encoders' fast path)
+    def forward_rows(self, x, g):
+        if self.dropout > 0.001:
+            x = self.dropout_layer(x)
+        z = mp.aggregate(x, g, add_self=self.add_self)
+        return mp.linear_l2norm(z, self.weight, self.bias, normalize=self.normalize_embedding)
+
+    def forward(self, x, adj):
+        if isinstance(adj, GraphBatch):
+            if x.dim() == 2:
+                return self.forward_rows(x, adj)
+            return mp.unpack_rows(self.forward_rows(mp.pack_rows(x, adj), adj), adj)
+        if x.dim() != 3 or adj.dim() != 3:
+            raise ValueError("GraphConv expects x[B,N,F] and adj[B,N,N]")
+        B, N, Fin = x.shape
+        if adj.requires_grad or N <= DENSE_ADJ_MAX_NODES:
+            if self.dropout > 0.001:
+                x = self.dropout_layer(x)
+            y = _DenseBmm.apply(adj.float(), x.float(), self.add_self)
+            v = mp.linear_l2norm(y.reshape(B * N, Fin), self.weight, self.bias, normalize=self.normalize_embedding)
+            return v.reshape(B, N, self.output_dim)
+        g = _batch_from_dense(adj, None, "padded")
+        return self.forward_rows(x.contiguous().float().reshape(B * N, Fin), g).reshape(B, N, self.output_dim)
+
+
+class GcnEncoderGraph(nn.Module):
+    """Drop-in for encoders.py:45-229 (the repo's "GraphSage"/base encoder)."""
+
+    def __init__(self, input_dim, hidden_dim, embedding_dim, label_dim, num_layers, pred_hidden_dims=[],
+                 concat=True, bn=True, dropout=0.0, args=None, final_dim="output_dim"):
+        super().__init__()
+        self.concat = concat
+        add_self = not concat
+        self.bn = bn
+        self.num_layers = num_layers
+        self.num_aggs = 1
+        self.final_dim = final_dim
+        self.bias = True
+        if args is not None:
+            self.bias = args.bias
+        self.conv_first, self.conv_block, self.conv_last = self.build_conv_layers(
+            input_dim, hidden_dim, embedding_dim, num_layers, add_self, normalize=True, dropout=dropout)
+        self.act = nn.ReLU()
+        self.label_dim = label_dim
+        self.pred_input_dim = hidden_dim * (num_layers - 1) + embedding_dim if concat else embedding_dim
+        self.pre_pred_model = self.build_pred_layers(self.pred_input_dim, pred_hidden_dims, embedding_dim,
+                                                     num_aggs=self.num_aggs)
+        self.pred_model = self.build_pred_layers(embedding_dim, pred_hidden_dims, label_dim, num_aggs=self.num_aggs)
+        self.map_model = self.build_pred_layers(self.pred_input_dim, pred_hidden_dims, embedding_dim,
+                                                num_aggs=self.num_aggs)
+        self.map2_model = self.build_pred_layers(pred_input_dim=embedding_dim, pred_hidden_dims=[], label_dim=2)
+        self._init_convs()
+        self.to(_default_device())
+
+    def _init_convs(self):
+        for m in self.modules():
+            if isinstance(m, GraphConv):
+                nn.init.xavier_uniform_(m.weight.data, gain=nn.init.calculate_gain("relu"))
+                if m.bias is not None:
+                    nn.init.constant_(m.bias.data, 0.0)
+
+    def build_conv_layers(self, input_dim, hidden_dim, embedding_dim, num_layers, add_self, normalize=False,
+                          dropout=0.0):
+        conv_first = GraphConv(input_dim=input_dim, output_dim=hidden_dim, add_self=add_self,
+                               normalize_embedding=normalize, bias=self.bias)
+        conv_block = nn.ModuleList(
+            [GraphConv(input_dim=hidden_dim, output_dim=hidden_dim, add_self=add_self, normalize_embedding=normalize,
+                       dropout=dropout, bias=self.bias) for _ in range(num_layers - 2)])
+        conv_last = GraphConv(input_dim=hidden_dim, output_dim=embedding_dim, add_self=add_self,
+                              normalize_embedding=normalize, bias=self.bias)
+        return conv_first, conv_block, conv_last
+
+    def build_pred_layers(self, pred_input_dim, pred_hidden_dims, label_dim, num_aggs=1):
+        pred_input_dim = pred_input_dim * num_aggs
+        if len(pred_hidden_dims) == 0:
+            return nn.Linear(pred_input_dim, label_dim)
+        layers = []
+        for pred_dim in pred_hidden_dims:
+            layers.append(nn.Linear(pred_input_dim, pred_dim))
+            layers.append(self.act)
+            pred_input_dim = pred_dim
+        layers.append(nn.Linear(pred_dim, label_dim))
+        return nn.Sequential(*layers)
+
+    def construct_mask(self, max_nodes, batch_num_nodes):
+        """[B, max_nodes, 1] prefix mask (encoders.py:121-132), built without a python loop."""
+        n = torch.as_tensor(np.asarray(batch_num_nodes, dtype=np.int64), device=_default_device())
+        return (torch.arange(max_nodes, device=n.device)[None, :] < n[:, None]).float().unsqueeze(2)
+
+    def apply_bn(self, x):
+        """Per-node-slot batch norm of a padded [B,N,F] tensor (encoders.py:134-138)."""
+        B, N, Fd = x.shape
+        g = GraphBatch.structure_only(np.full(B, N, dtype=np.int64), N, x.device, ghosts=False)
+        return mp.bn_slots(x.contiguous().float().reshape(B * N, Fd), g, relu=False, bn=True).reshape(B, N, Fd)
+
+    # ------------------------------------------------------------------ graph batch plumbing
+    @staticmethod
+    def make_batch(x, adj, batch_num_nodes):
+        """-> (rows, GraphBatch).  With node counts: packed rows + ghost-slot rows; without: padded rows."""
+        if isinstance(adj, GraphBatch):
+            g = adj
+        elif batch_num_nodes is not None:
+            g = _batch_from_dense(adj, np.asarray(batch_num_nodes).reshape(-1), "packed")
+        else:
+            g = _batch_from_dense(adj, None, "padded")
+        if x.dim() == 3:
+            F_in = x.size(2)
+            ld = (F_in + 3) // 4 * 4 if g.layout == "packed" else None      # 16-B rows for the float4 gather
+            x = mp.pack_rows(x, g, ld)
+        return x, g
+
+    def _post(self, v, g):
+        """ReLU then (optionally) slot batch-norm: encoders.py:179-181."""
+        return mp.bn_slots(v, g, relu=True, bn=self.bn)
+
+    def gcn_forward_rows(self, x, g, conv_first, conv_block, conv_last, mask_ghost=False):
+        """gcn_forward (encoders.py:140-167) on rows: per-layer outputs concatenated on the feature axis;
+        ``mask_ghost`` = multiply by the embedding mask (zeroes every ghost row)."""
+        x = self._post(conv_first.forward_rows(x, g), g)
+        x_all = [x]
+        for conv in conv_block:
+            x = self._post(conv.forward_rows(x, g), g)
+            x_all.append(x)
+        x_all.append(conv_last.forward_rows(x, g))
+        t = torch.cat(x_all, dim=1)
+        if mask_ghost and g.n_ghost:
+            t = mp.mask_ghost_rows(t, g)
+        return t
+
+    def readouts_rows(self, x, g):
+        """encoders.py:177-205 up to the concatenated max readout."""
+        x = self._post(self.conv_first.forward_rows(x, g), g)
+        out_all = [mp.readout_max(x, g)]
+        for conv in self.conv_block:
+            x = self._post(conv.forward_rows(x, g), g)
+            out_all.append(mp.readout_max(x, g))
+        x = self.conv_last.forward_rows(x, g)
+        out_all.append(mp.readout_max(x, g))
+        return torch.cat(out_all, dim=1) if self.concat else out_all[-1]
+
+    def _heads(self, output):
+        if self.final_dim == "pretrain":          # 2stg+
+            out = self.map_model(output)
+            return self.map2_model(out), out
+        if self.final_dim != "output_dim":        # original
+            vec = self.pre_pred_model(output)
+            return vec, self.pred_model(vec)
+        return output, self.map_model(output)     # 2stg
+
+    def forward(self, x, adj, batch_num_nodes=None, **kwargs):
+        x, g = self.make_batch(x, adj, batch_num_nodes)
+        return self._heads(self.readouts_rows(x, g))
+
+    def loss(self, pred, label, type="softmax"):
+        if type == "softmax":
+            return F.cross_entropy(pred, label, reduction="mean")
+        if type == "margin":
+            onehot = torch.zeros(pred.size(0), self.label_dim, dtype=torch.long, device=pred.device)
+            onehot.scatter_(1, label.view(-1, 1), 1)
+            return torch.nn.MultiLabelMarginLoss()(pred, onehot)
+        raise ValueError(type)

@@ -1,0 +1,197 @@
+"""Batch-of-graphs container: CSR adjacency in HBM + the row bookkeeping the kernels consume.
+
+Replaces the reference's dense padded ``adj[B,Nmax,Nmax]`` (graph_sampler.py:102-114, shipped
+host->device every step at train.py:114) and PyG's COO ``edge_index`` (Code/sag/network.py:31).
+
+Row layouts
+-----------
+``packed``  rows [0, n_rows) = real nodes only, graph after graph (``graph_ptr``); the padded "ghost"
+            rows of the reference (slots n >= n_b) are represented by ONE row per node slot, rows
+            [n_rows, n_rows + nmax): all ghost rows of a slot carry the same value in the reference,
+            so a single representative with multiplicity ``B - slot_count[n]`` reproduces the
+            reference's per-slot BatchNorm statistics and max readout exactly.
+``padded``  rows = B*Nmax exactly as the reference lays them out, no ghost representatives (used by the
+            drop-in ``GraphConv.forward(x[B,N,F], adj[B,N,N])`` whose output must be padded too).
+Feature matrices have ``total_rows = n_rows + n_ghost`` rows; ghost rows have empty neighbour lists.
+"""
+import numpy as np
+import torch
+
+from . import _native as nat
+
+
+def _i32(n, device):
+    return torch.empty(int(n), dtype=torch.int32, device=device)
+
+
+def _scan_ws(n, device):
+    need = np.zeros(1, dtype=np.int64)
+    nat.call_nostream("scan_workspace_ints", int(n), need.ctypes.data)
+    return _i32(need[0], device)
+
+
+def exclusive_scan(counts):
+    """int32[n] -> int32[n+1] exclusive prefix sums (device)."""
+    n = counts.numel()
+    out = _i32(n + 1, counts.device)
+    nat.call("exclusive_scan_i32", counts, n, out, _scan_ws(n, counts.device))
+    return out
+
+
+class GraphBatch:
+    def __init__(self):
+        self.B = 0
+        self.nmax = 0
+        self.n_rows = 0            # real rows
+        self.n_ghost = 0           # ghost-slot representative rows (nmax when packed, 0 when padded)
+        self.layout = "packed"
+        self.sizes = None          # np.int64[B] rows of each graph in this layout
+        self.graph_ptr = None      # int32[B+1]
+        self.row_graph = None      # int32[n_rows]
+        self.row_slot = None       # int32[n_rows]
+        self.slot_count = None     # int32[nmax]: number of graphs that HAVE slot n
+        self.rowptr = None         # int32[total_rows+1]
+        self.col = None            # int32[nnz]
+        self.val = None            # float32[nnz] or None (unit weights)
+        self.nnz = 0
+        self.symmetric = False
+        self._t = None
+        self.device = None
+
+    @property
+    def total_rows(self):
+        return self.n_rows + self.n_ghost
+
+    # ------------------------------------------------------------------ bookkeeping shared by builders
+    def _set_sizes(self, sizes, nmax, device, ghosts=True):
+        sizes = np.asarray(sizes, dtype=np.int64).reshape(-1)
+        if sizes.size == 0 or (sizes < 0).any() or (sizes > nmax).any():
+            raise ValueError("graph sizes must lie in [0, nmax]")
+        self.B = int(sizes.size)
+        self.nmax = int(nmax)
+        self.sizes = sizes
+        self.n_rows = int(sizes.sum())
+        self.n_ghost = self.nmax if ghosts else 0
+        gp = np.zeros(self.B + 1, dtype=np.int32)
+        np.cumsum(sizes, out=gp[1:])
+        hist = np.bincount(sizes, minlength=self.nmax + 1)
+        slot_count = (self.B - np.cumsum(hist)[: self.nmax]).astype(np.int32)   # graphs with size > n
+        self.device = device
+        self.graph_ptr = torch.from_numpy(gp).to(device, non_blocking=True)
+        self.slot_count = torch.from_numpy(slot_count).to(device, non_blocking=True)
+        self.row_graph = _i32(max(self.n_rows, 1), device)
+        self.row_slot = _i32(max(self.n_rows, 1), device)
+        nat.call("row_maps", self.graph_ptr, self.B, self.n_rows, self.row_graph, self.row_slot)
+
+    # ------------------------------------------------------------------ builders
+    @classmethod
+    def from_dense(cls, adj, sizes=None, layout="packed", assume_symmetric=False):
+        """adj: float32 [B,Nmax,Nmax] on the GPU (the tensor train.py:114 uploads).
+        layout='packed' needs ``sizes`` (= batch_num_nodes) and assumes zero padding outside
+        [:n_b,:n_b] (what GraphSampler produces); layout='padded' keeps all B*Nmax rows."""
+        if adj.dim() != 3 or adj.size(1) != adj.size(2):
+            raise ValueError("adj must be [B,N,N]")
+        adj = adj.contiguous().float()
+        B, nmax = adj.size(0), adj.size(1)
+        g = cls()
+        g.layout = layout
+        if layout == "padded":
+            sizes = np.full(B, nmax, dtype=np.int64)
+        elif sizes is None:
+            raise ValueError("packed layout needs the per-graph node counts")
+        g._set_sizes(sizes, nmax, adj.device, ghosts=(layout != "padded"))
+        if g.B != B:
+            raise ValueError("len(sizes) != batch size of adj")
+        R = g.n_rows
+        cnt = torch.zeros(g.total_rows, dtype=torch.int32, device=adj.device)
+        nat.call("dense_adj_count", adj, B, nmax, g.graph_ptr, g.row_graph, R, cnt)
+        g.rowptr = exclusive_scan(cnt)
+        g.nnz = int(g.rowptr[-1].item())
+        g.col = _i32(max(g.nnz, 1), adj.device)
+        g.val = torch.empty(max(g.nnz, 1), dtype=torch.float32, device=adj.device)
+        nat.call("dense_adj_fill", adj, B, nmax, g.graph_ptr, g.row_graph, R, g.rowptr, g.col, g.val)
+        g.symmetric = bool(assume_symmetric)
+        return g
+
+    @classmethod
+    def from_edge_index(cls, edge_index, num_nodes, sizes=None, nmax=None, assume_symmetric=False, ghosts=False):
+        """edge_index: int64 [2,E] (PyG: row 0 = source j, row 1 = target i).  CSR row = target."""
+        g = cls()
+        g.layout = "packed"
+        dev = edge_index.device
+        num_nodes = int(num_nodes)
+        if sizes is None:
+            sizes = np.array([num_nodes], dtype=np.int64)
+        sizes = np.asarray(sizes, dtype=np.int64)
+        if int(sizes.sum()) != num_nodes:
+            raise ValueError("sizes must sum to num_nodes")
+        g._set_sizes(sizes, int(nmax) if nmax is not None else int(max(1, sizes.max())), dev, ghosts=ghosts)
+        ei = edge_index.contiguous()
+        E = int(ei.size(1))
+        R = num_nodes
+        cnt = torch.zeros(g.total_rows, dtype=torch.int32, device=dev)
+        bad = torch.zeros(1, dtype=torch.int32, device=dev)
+        key, other = ei[1], ei[0]
+        nat.call("coo_count", key, E, R, cnt, bad)
+        g.rowptr = exclusive_scan(cnt)
+        g.nnz = E
+        g.col = _i32(max(E, 1), dev)
+        g.eid = _i32(max(E, 1), dev)
+        nat.call("coo_fill", key, other, E, R, g.rowptr, _i32(max(R, 1), dev), g.col, g.eid)
+        if int(bad.item()) != 0:
+            raise IndexError("edge_index contains node ids outside [0, num_nodes)")
+        g.val = None
+        g.symmetric = bool(assume_symmetric)
+        return g
+
+    @classmethod
+    def structure_only(cls, sizes, nmax, device, ghosts=True):
+        """Row bookkeeping without an adjacency (slot batch-norm / readout of stand-alone tensors)."""
+        g = cls()
+        g.layout = "packed" if ghosts else "padded"
+        g._set_sizes(sizes, nmax, device, ghosts=ghosts)
+        g.rowptr = torch.zeros(g.total_rows + 1, dtype=torch.int32, device=device)
+        g.col = _i32(1, device)
+        g.symmetric = True
+        return g
+
+    @classmethod
+    def from_csr(cls, rowptr, col, val, sizes, nmax, assume_symmetric=True):
+        """CSR-native ingest (synthetic loader / preprocessed datasets): rowptr int32[n_rows + nmax + 1]
+        (the nmax ghost-slot rows are empty: trailing entries repeat nnz), col int32[nnz] in packed row ids."""
+        g = cls()
+        g._set_sizes(sizes, nmax, rowptr.device)
+        if rowptr.numel() != g.total_rows + 1:
+            raise ValueError("rowptr must have n_rows + nmax + 1 entries (empty ghost rows included)")
+        g.rowptr, g.col, g.val = rowptr, col, val
+        g.nnz = int(col.numel())
+        g.symmetric = bool(assume_symmetric)
+        return g
+
+    # ------------------------------------------------------------------ transpose (for dX = A^T dY)
+    def transposed(self, val="graph"):
+        """CSR of A^T (rowptr, col, val) for dX = A^T dY; ``val`` = per-entry weights aligned with
+        self.col (default: the graph's own)."""
+        if isinstance(val, str):
+            val = self.val
+        if self.symmetric:
+            return self.rowptr, self.col, val
+        if self._t is None:
+            R1 = self.total_rows
+            dev = self.device
+            rowptr_t = _i32(R1 + 1, dev)
+            col_t = _i32(max(self.nnz, 1), dev)
+            val_t = torch.empty(max(self.nnz, 1), dtype=torch.float32, device=dev) if self.val is not None else None
+            src_e = _i32(max(self.nnz, 1), dev)
+            nat.call("csr_transpose", self.rowptr, self.col, self.val, R1, R1, self.nnz, rowptr_t, col_t, val_t,
+                     src_e, _i32(R1, dev), _scan_ws(R1, dev))
+            self._t = (rowptr_t, col_t, val_t)
+            self.src_e_t = src_e
+        if val is self.val:
+            return self._t
+        return self._t[0], self._t[1], (val[self.src_e_t.long()] if val is not None else None)
+
+    # ------------------------------------------------------------------ feature (un)packing helpers
+    def new_features(self, feat, zero=False):
+        f = torch.zeros if zero else torch.empty
+        return f(self.total_rows, feat, dtype=torch.float32, device=self.device)

@@ -1,0 +1,290 @@
+"""Differentiable message-passing operators over a GraphBatch (explicit HIP forward AND backward).
+
+Each torch.autograd.Function here is a thin host wrapper around C-ABI kernels of libtsgnn_hip.so
+(include/tsgnn.h).  Feature matrices are fp32 ``[g.n_rows + g.n_ghost, F]`` row-major on the GPU.
+The reference relies on autograd through dense bmm's (encoders.py:30-42); here every backward is a
+hand-written kernel as SURVEY §8(a) requires.
+"""
+import numpy as np
+import torch
+
+from . import _native as nat
+
+
+def _f32(*shape, device, zero=False):
+    return (torch.zeros if zero else torch.empty)(*shape, dtype=torch.float32, device=device)
+
+
+def _check(x, rows=None):
+    if not x.is_cuda:
+        raise RuntimeError("two_stage_gnn_amd operators run on the GPU only (no CPU fallback)")
+    if x.dtype != torch.float32 or x.dim() != 2:
+        raise ValueError("expected a float32 [rows, features] matrix")
+    if rows is not None and x.size(0) != rows:
+        raise ValueError("feature matrix has %d rows, the graph batch has %d" % (x.size(0), rows))
+    return x if x.is_contiguous() else x.contiguous()
+
+
+# ----------------------------------------------------------------------------- aggregation
+def spmm_raw(rowptr, col, val, x, n_rows, self_w=None, self_scalar=0.0, relu_in=False, out=None, accumulate=False):
+    y = out if out is not None else _f32(x.size(0), x.size(1), device=x.device)
+    nat.call("csr_spmm_f32", rowptr, col, val, self_w, x, x.stride(0), y, y.stride(0), int(n_rows), int(x.size(1)),
+             float(self_scalar), int(relu_in), int(accumulate))
+    return y
+
+
+class _Aggregate(torch.autograd.Function):
+    """y = A x (+ x)   — GraphConv.forward lines encoders.py:33-35."""
+
+    @staticmethod
+    def forward(ctx, x, g, add_self, val, self_w):
+        x = _check(x, g.total_rows)
+        ctx.g, ctx.add_self, ctx.val, ctx.self_w = g, add_self, val, self_w
+        return spmm_raw(g.rowptr, g.col, val, x, g.total_rows, self_w=self_w, self_scalar=1.0 if add_self else 0.0)
+
+    @staticmethod
+    def backward(ctx, dy):
+        g = ctx.g
+        dy = _check(dy)
+        rowptr_t, col_t, val_t = g.transposed(ctx.val)
+        dx = spmm_raw(rowptr_t, col_t, val_t, dy, g.total_rows, self_w=ctx.self_w,
+                      self_scalar=1.0 if ctx.add_self else 0.0)
+        return dx, None, None, None, None
+
+
+def aggregate(x, g, add_self=False, val="graph", self_w=None):
+    """Sum-aggregate neighbour rows. ``val``: 'graph' -> g.val (None = unit weights) or an explicit
+    per-entry weight tensor aligned with g.col (e.g. GCN-normalised weights)."""
+    if isinstance(val, str):
+        val = g.val
+    return _Aggregate.apply(x, g, bool(add_self), val, self_w)
+
+
+# ----------------------------------------------------------------------------- transform + L2 normalise
+def gemm(A, sam, sak, B, sbk, sbn, C, scm, scn, M, N, K, batch=1, stride_a=0, stride_b=0, stride_c=0,
+         seg_ptr=None, ragged=0, max_seg=0, alpha=1.0, accumulate=False):
+    nat.call("gemm_f32", A, int(sam), int(sak), B, int(sbk), int(sbn), C, int(scm), int(scn), int(M), int(N), int(K),
+             int(batch), int(stride_a), int(stride_b), int(stride_c), seg_ptr, int(ragged), int(max_seg), float(alpha),
+             int(accumulate))
+
+
+def gemm_tn_splitk(Z, K_in, dU, out=None):
+    """out[K_in, N] = Z[:, :K_in]^T @ dU   (reduction over graph rows, split-K, reproducible)."""
+    R, N = dU.size(0), dU.size(1)
+    plan = np.zeros(1, dtype=np.int32)
+    need = np.zeros(1, dtype=np.int64)
+    nat.call_nostream("gemm_splitk_plan", int(K_in), int(N), int(R), plan.ctypes.data, need.ctypes.data)
+    ws = _f32(max(int(need[0]), 1), device=dU.device)
+    out = out if out is not None else _f32(K_in, N, device=dU.device)
+    nat.call("gemm_splitk_f32", Z, 1, Z.stride(0), dU, dU.stride(0), 1, out, int(K_in), int(N), int(R), int(plan[0]),
+             ws, 0)
+    return out
+
+
+def colsum(x):
+    R, F = x.size(0), x.size(1)
+    out = _f32(F, device=x.device)
+    ws = _f32(max(1, (R + 511) // 512) * F, device=x.device)
+    nat.call("colsum_f32", x, x.stride(0), int(R), int(F), out, ws, 0)
+    return out
+
+
+class _LinearL2Norm(torch.autograd.Function):
+    """v = normalize(z W + b)  — encoders.py:36-40."""
+
+    @staticmethod
+    def forward(ctx, z, weight, bias, normalize):
+        z = _check(z)
+        w = weight.contiguous()
+        K, N = w.size(0), w.size(1)
+        if z.size(1) < K:
+            raise ValueError("input has %d features, weight expects %d" % (z.size(1), K))
+        R = z.size(0)
+        v = _f32(R, N, device=z.device)
+        rinv = _f32(R, device=z.device) if normalize else None
+        nat.call("linear_l2norm_f32", z, z.stride(0), w, w.stride(0), bias, v, v.stride(0), rinv, R, K, N,
+                 int(normalize))
+        ctx.save_for_backward(z, w, v if normalize else None, rinv)
+        ctx.has_bias = bias is not None
+        ctx.normalize = normalize
+        return v
+
+    @staticmethod
+    def backward(ctx, dv):
+        z, w, v, rinv = ctx.saved_tensors
+        dv = _check(dv)
+        R, N, K = dv.size(0), w.size(1), w.size(0)
+        if ctx.normalize:
+            du = torch.empty_like(dv)
+            nat.call("l2norm_bwd_f32", v, v.stride(0), dv, dv.stride(0), rinv, du, du.stride(0), R, N)
+        else:
+            du = dv
+        dz = dw = db = None
+        if ctx.needs_input_grad[0]:
+            ldz = z.size(1)
+            dz = _f32(R, ldz, device=dv.device, zero=(ldz > K))
+            gemm(du, du.stride(0), 1, w, 1, w.stride(0), dz, dz.stride(0), 1, R, K, N)      # dZ = dU W^T
+        if ctx.needs_input_grad[1]:
+            dw = gemm_tn_splitk(z, K, du)                                                    # dW = Z^T dU
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(du)
+        return dz, dw, db, None
+
+
+def linear_l2norm(z, weight, bias=None, normalize=True):
+    return _LinearL2Norm.apply(z, weight, bias, bool(normalize))
+
+
+# ----------------------------------------------------------------------------- ReLU + per-slot batch norm
+class _BnSlots(torch.autograd.Function):
+    """y = bn_over_slots(relu(v))  — encoders.py:179-181 with apply_bn :134-138 (trap T2)."""
+
+    @staticmethod
+    def forward(ctx, v, g, relu, bn):
+        v = _check(v, g.total_rows)
+        F = v.size(1)
+        dev = v.device
+        mean = _f32(g.nmax, device=dev) if bn else None
+        rstd = _f32(g.nmax, device=dev) if bn else None
+        y = torch.empty_like(v)
+        nat.call("bn_slots_fwd_f32", g.graph_ptr, g.slot_count, g.row_slot, g.B, g.nmax, g.n_rows, g.n_ghost, v,
+                 v.stride(0), F, int(relu), int(bn), mean, rstd, y, y.stride(0))
+        ctx.g, ctx.relu, ctx.bn = g, relu, bn
+        ctx.save_for_backward(v, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        v, mean, rstd = ctx.saved_tensors
+        g = ctx.g
+        dy = _check(dy)
+        F = v.size(1)
+        m1 = _f32(g.nmax, device=v.device) if ctx.bn else None
+        m2 = _f32(g.nmax, device=v.device) if ctx.bn else None
+        dv = torch.empty_like(v)
+        nat.call("bn_slots_bwd_f32", g.graph_ptr, g.slot_count, g.row_slot, g.B, g.nmax, g.n_rows, g.n_ghost, v,
+                 v.stride(0), dy, dy.stride(0), F, int(ctx.relu), int(ctx.bn), mean, rstd, m1, m2, dv, dv.stride(0))
+        return dv, None, None, None
+
+
+def bn_slots(v, g, relu=True, bn=True):
+    return _BnSlots.apply(v, g, bool(relu), bool(bn))
+
+
+# ----------------------------------------------------------------------------- max readout over node slots
+class _ReadoutMax(torch.autograd.Function):
+    """out[b] = max over ALL nmax node slots of graph b (ghost rows included) — encoders.py:183 (trap T5)."""
+
+    @staticmethod
+    def forward(ctx, x, g):
+        x = _check(x, g.total_rows)
+        F = x.size(1)
+        out = _f32(g.B, F, device=x.device)
+        arg = torch.empty(g.B, F, dtype=torch.int32, device=x.device)
+        ws = torch.empty(g.B * F, dtype=torch.int64, device=x.device)
+        nat.call("readout_max_fwd_f32", g.graph_ptr, g.slot_count, g.B, g.nmax, g.n_rows, g.n_ghost, x, x.stride(0),
+                 F, 0, ws, out, out.stride(0), arg)
+        ctx.g = g
+        ctx.rows = x.size(0)
+        ctx.save_for_backward(arg)
+        ctx.mark_non_differentiable(arg)
+        return out, arg
+
+    @staticmethod
+    def backward(ctx, dout, _darg):
+        (arg,) = ctx.saved_tensors
+        g = ctx.g
+        dout = dout.contiguous()
+        F = dout.size(1)
+        dx = _f32(ctx.rows, F, device=dout.device, zero=True)
+        nat.call("readout_max_bwd_f32", dout, dout.stride(0), arg, g.B, F, None, 0, 0, g.n_rows, dx, dx.stride(0))
+        return dx, None
+
+
+def readout_max(x, g, return_arg=False):
+    out, arg = _ReadoutMax.apply(x, g)
+    return (out, arg) if return_arg else out
+
+
+# ----------------------------------------------------------------------------- padded <-> packed rows
+class _PackRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xp, g, ld):
+        if not xp.is_cuda:
+            raise RuntimeError("two_stage_gnn_amd operators run on the GPU only (no CPU fallback)")
+        xp = xp.contiguous().float()
+        B, nmax, F = xp.shape
+        if B != g.B or nmax != g.nmax:
+            raise ValueError("padded features [%d,%d,*] do not match the graph batch [%d,%d]" % (B, nmax, g.B, g.nmax))
+        out = _f32(g.total_rows, ld, device=xp.device, zero=True)       # ghost rows = zero padding
+        nat.call("pack_rows_f32", xp, nmax, F, g.row_graph, g.row_slot, g.n_rows, out, out.stride(0))
+        ctx.g, ctx.F = g, F
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        g = ctx.g
+        dout = _check(dout)
+        dxp = _f32(g.B, g.nmax, ctx.F, device=dout.device)
+        nat.call("unpack_rows_f32", g.graph_ptr, g.B, g.nmax, g.n_rows, 0, dout, dout.stride(0), ctx.F, 0.0, dxp)
+        return dxp, None, None
+
+
+def pack_rows(x_padded, g, ld=None):
+    """[B,Nmax,F] (graph_sampler.py:110-114 layout) -> rows of the batch; ld >= F pads columns with zeros."""
+    F = x_padded.size(2)
+    if g.layout == "padded":
+        if ld not in (None, F):
+            raise ValueError("padded layout keeps the feature width")
+        x = x_padded.contiguous().float().reshape(g.B * g.nmax, F)
+        return x
+    return _PackRows.apply(x_padded, g, F if ld is None else int(ld))
+
+
+class _UnpackRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, g, fill):
+        x = _check(x, g.total_rows)
+        F = x.size(1)
+        out = _f32(g.B, g.nmax, F, device=x.device)
+        nat.call("unpack_rows_f32", g.graph_ptr, g.B, g.nmax, g.n_rows, g.n_ghost, x, x.stride(0), F, float(fill), out)
+        ctx.g, ctx.F = g, F
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        g = ctx.g
+        dout = dout.contiguous()
+        dx = _f32(g.total_rows, ctx.F, device=dout.device, zero=True)
+        nat.call("pack_rows_f32", dout, g.nmax, ctx.F, g.row_graph, g.row_slot, g.n_rows, dx, dx.stride(0))
+        if g.n_ghost:
+            nat.call("unpack_rows_bwd_ghost_f32", g.graph_ptr, g.B, g.nmax, g.n_rows, dout, ctx.F, dx, dx.stride(0))
+        return dx, None, None
+
+
+def unpack_rows(x, g, fill=0.0):
+    """rows of the batch -> [B,Nmax,F] padded tensor (ghost slots take the ghost rows' values)."""
+    if g.layout == "padded":
+        return x.reshape(g.B, g.nmax, x.size(1))
+    return _UnpackRows.apply(x, g, fill)
+
+
+class _MaskGhost(torch.autograd.Function):
+    """x * embedding_mask (encoders.py:165-166): zero every ghost row, pass real rows through."""
+
+    @staticmethod
+    def forward(ctx, x, n_real):
+        y = x.clone()
+        y[n_real:].zero_()
+        ctx.n_real = n_real
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        d = dy.clone()
+        d[ctx.n_real:].zero_()
+        return d, None
+
+
+def mask_ghost_rows(x, g):
+    return _MaskGhost.apply(x, g.n_rows) if g.n_ghost else x
