@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): graphs/sec, forward+backward(+all-reduce+clip+Adam) of the
+3-layer h=128 GraphSage-style encoder (GcnEncoderGraph, `--method=base`) on DD-shaped synthetic batches
+of 32 graphs per GPU, on 1/2/4/8 MI355X, plus the HBM-roofline fraction of the dominant aggregation
+kernel and the reference's dense formulation timed on the host CPU.
+
+  python bench.py --gpus 1 --steps 200 --warmup 20
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+One JSON line on stdout (rank 0).  A "step" = one optimiser step on one batch per rank: forward, CE loss,
+backward, gradient bucket (+RCCL all-reduce when N>1), clip_grad_norm(2.0), Adam — exactly the body of the
+reference's loop (train.py:110-131) minus the host->device copies (inputs are resident in HBM).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md:36
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=32, help="graphs per GPU (BASELINE: 32)")
+    ap.add_argument("--shape", default="DD")
+    ap.add_argument("--nmax", type=int, default=1000, help="padded size of the reference (--max_nodes default)")
+    ap.add_argument("--hidden", type=int, default=128)
+    ap.add_argument("--layers", type=int, default=3)
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=0, help="0 = auto-size the sample to ~15 s")
+    ap.add_argument("--sweep", action="store_true", help="also print the aggregation-kernel batch-size sweep (stderr)")
+    return ap.parse_args()
+
+
+def hip_event_ms(fn, iters, stream):
+    """average ms per call of fn() measured with HIP events recorded on `stream`."""
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(iters):
+        fn()
+    e1.record(stream)
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def aggregation_probe(g, feat, iters=300):
+    """The dominant HBM kernel of the step (tsgnn_csr_spmm_f32 at F = hidden) launched back to back on the
+    step's own CSR / buffers; duration from HIP events on the launching stream."""
+    from two_stage_gnn_amd import message_passing as mp
+    from two_stage_gnn_amd.synthetic import aggregation_bytes
+    x = torch.randn(g.total_rows, feat, device="cuda")
+    y = torch.empty_like(x)
+    s = torch.cuda.current_stream()
+    fn = lambda: mp.spmm_raw(g.rowptr, g.col, g.val, x, g.total_rows, out=y)
+    for _ in range(20):
+        fn()
+    torch.cuda.synchronize()
+    # the burst is replayed from a hipGraph so the host's ~8 us per ctypes launch does not pace it
+    burst = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(burst, stream=s):
+        for _ in range(iters):
+            fn()
+    burst.replay()
+    torch.cuda.synchronize()
+    ms = min(hip_event_ms(burst.replay, 1, s) for _ in range(5)) / iters
+    nbytes = aggregation_bytes(g.total_rows, g.nnz, feat, weighted=g.val is not None)
+    return ms, nbytes
+
+
+def cpu_baseline(hb, hidden, layers, steps, state):
+    """The reference's dense formulation (adj[B,Nmax,Nmax] @ x, encoders.py:30-42,169-217) restated by the
+    CPU oracle, fwd + CE + bwd + clip + Adam, on this host's cores — test infrastructure used as the checker /
+    baseline only (never on the product path)."""
+    from oracle import dense_ref as R
+    from two_stage_gnn_amd.synthetic import to_dense
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(cores, int(os.environ.get("TSGNN_CPU_THREADS", 16)))     # the GPU box's CPU share per GPU is 16
+    torch.set_num_threads(cores)
+    x, adj = to_dense(hb)
+    label = torch.from_numpy(hb["label"])
+    p = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in state.items()}
+    opt = torch.optim.Adam(list(p.values()), lr=1e-3)
+
+    def one():
+        opt.zero_grad()
+        _, ypred = R.gcn_encoder(p, x, adj, bn=True, final_dim="number_classes")
+        loss = torch.nn.functional.cross_entropy(ypred, label)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(list(p.values()), 2.0)
+        opt.step()
+
+    one()
+    t0 = time.perf_counter(); one(); t1 = time.perf_counter()
+    if steps <= 0:
+        steps = int(max(3, min(200, 15.0 / max(t1 - t0, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": len(hb["sizes"]) / dt, "unit": "graphs/s", "cores": cores, "kind": "port",
+            "sample": "%d steps of the same %d-graph batch, dense adj@x formulation at Nmax=%d (%.1f ms/step)"
+                      % (steps, len(hb["sizes"]), hb["nmax"], dt * 1e3)}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != a.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from two_stage_gnn_amd import dense_encoders as E
+    from two_stage_gnn_amd import synthetic
+    from two_stage_gnn_amd.data_parallel import FlatTrainer
+
+    class Args:
+        bias = True
+    torch.manual_seed(1234)                                   # identical initial weights on every rank
+    fin = synthetic.SHAPES[a.shape][2]
+    model = E.GcnEncoderGraph(fin, a.hidden, a.hidden, 2, a.layers, bn=True, args=Args(), final_dim="number_classes").to(dev)
+    init_state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    hb = synthetic.host_batch(seed=rank, B=a.batch, shape=a.shape, nmax=a.nmax)      # per-rank batch (weak scaling)
+    g, x, label = synthetic.to_device(hb, dev)
+    trainer = FlatTrainer(model, lr=1e-3, clip=2.0)
+
+    def fwd_bwd():
+        trainer.zero_grad()
+        _, ypred = model(x, g)
+        loss = model.loss(ypred, label)
+        loss.backward()
+        trainer.gather_grads()
+        return loss
+
+    use_graph = not a.no_graph
+    stream = torch.cuda.Stream()
+    graph_fb = graph_opt = None
+    with torch.cuda.stream(stream):
+        for _ in range(3):                                     # allocator / lazy-init warm-up before capture
+            fwd_bwd(); trainer.all_reduce(); trainer.apply()
+        torch.cuda.synchronize()
+        if use_graph:
+            # fwd+bwd+bucket and clip+Adam are captured as two hipGraphs; the RCCL all-reduce is issued
+            # between them on the same stream (a single-GPU run replays both back to back).
+            graph_fb = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph_fb, stream=stream):
+                fwd_bwd()
+            graph_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph_opt, stream=stream):
+                trainer.apply()
+
+        def step():
+            if use_graph:
+                graph_fb.replay(); trainer.all_reduce(); graph_opt.replay()
+            else:
+                fwd_bwd(); trainer.all_reduce(); trainer.apply()
+
+        for _ in range(a.warmup):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+        out = None
+        if rank == 0:
+            ms_step = elapsed / a.steps * 1e3
+            agg_ms, agg_bytes = aggregation_probe(g, a.hidden)
+            achieved = agg_bytes / (agg_ms * 1e-3) / 1e9
+            out = {
+                "metric": "graphs/sec fwd+bwd, DD batch=32 SAGE-3L h=128",
+                "value": world * a.batch * a.steps / elapsed, "unit": "graphs/s",
+                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "%s-shaped synthetic graphs (avg %d nodes / %d edges, F_in=%d), batch=%d per GPU, "
+                                       "GcnEncoderGraph (GraphSage 'base') %d layers h=%d, Nmax=%d, slot-BN, CE loss, "
+                                       "clip 2.0 + Adam" % (a.shape, *synthetic.SHAPES[a.shape], a.batch, a.layers, a.hidden, a.nmax),
+                           "global_batch": world * a.batch, "parallelism": "dp%d" % world,
+                           "launch": "hipGraph replay" if use_graph else "eager",
+                           "rows": int(g.n_rows), "edges_directed": int(g.nnz)},
+                "roofline": {"bound": "hbm", "kernel": "spmm_vec4<32,false,false> (tsgnn_csr_spmm_f32, F=%d)" % a.hidden,
+                             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                             "traffic": None, "bytes_per_launch": agg_bytes, "us_per_launch": agg_ms * 1e3},
+            }
+    if rank == 0:
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(hb, a.hidden, a.layers, a.cpu_steps, init_state)
+        else:
+            out["cpu_baseline"] = None
+        if a.sweep:
+            with torch.cuda.stream(stream):
+                for B in (32, 256, 2048, 16384):
+                    hs = synthetic.host_batch(seed=100 + B, B=B, shape=a.shape, nmax=a.nmax)
+                    gs, _, _ = synthetic.to_device(hs, dev)
+                    ms, nb = aggregation_probe(gs, a.hidden, iters=50 if B > 2048 else 200)
+                    print("sweep B=%d rows=%d: %.2f us, %.0f GB/s (%.1f%% of 8 TB/s)" % (B, gs.n_rows, ms * 1e3, nb / ms / 1e6,
+                                                                                       nb / ms / 1e6 / HBM_PEAK_GBS * 100), file=sys.stderr)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

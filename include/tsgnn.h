@@ -141,6 +141,16 @@ int tsgnn_unpack_rows_f32(const int* graph_ptr, int B, int nmax, int64_t n_real,
 int tsgnn_unpack_rows_bwd_ghost_f32(const int* graph_ptr, int B, int nmax, int64_t n_real, const float* ddst, int F,
                                     float* dsrc, int64_t ld, tsgnn_stream_t stream);
 
+/* ---------------------------------------------------------------- optimiser on a flat buffer (optim.hip) */
+
+/* clip_grad_norm(max_norm) + Adam.step() of the reference loop (train.py:128-129) on one flat fp32
+ * parameter / gradient buffer (the buffer RCCL all-reduces): grad is first scaled by grad_scale
+ * (1/world_size).  state: 3 floats {step, grad_norm, applied scale} (zeroed before the first step);
+ * ws >= 256 floats. */
+int tsgnn_clip_adam_step_f32(float* param, const float* grad, float* m, float* v, int64_t n, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, float max_norm, float grad_scale, float* state,
+                             float* ws, tsgnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

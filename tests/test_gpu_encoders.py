@@ -91,4 +91,9 @@ def test_gcn_encoder_vs_oracle_dd_shape(B, nmax, nbar, fin, hid):
         ref = p_ref[k].grad
         if ref is None:
             continue
-        torch.testing.assert_close(p.grad.cpu(), ref, rtol=5e-3, atol=1e-5, msg=lambda s, k=k: k + ": " + s)
+        # gradients are piecewise (relu / max-readout winners can flip on 1-ulp differences between the CPU
+        # and GPU summation orders), so compare at the scale of the tensor instead of element-relative
+        err = (p.grad.cpu() - ref).abs().max().item()
+        assert err <= 2e-3 * ref.abs().max().item() + 1e-7, (k, err, ref.abs().max().item())
+        rel_l2 = ((p.grad.cpu() - ref).norm() / (ref.norm() + 1e-12)).item()
+        assert rel_l2 < 1e-3, (k, rel_l2)

@@ -1,0 +1,73 @@
+// Optimiser step of the reference's training loop on ONE flat fp32 buffer (train.py:128-129:
+// nn.utils.clip_grad_norm(model.parameters(), clip) then Adam.step()), so that the data-parallel
+// all-reduce (one RCCL call on the same flat gradient buffer) and the update are 1 + 2 launches per
+// step instead of ~10 launches per parameter tensor.  Graph-replay safe: the step counter lives in
+// device memory.
+#include "common.h"
+#include "../../include/tsgnn.h"
+
+namespace {
+
+constexpr int NPART = 256;
+
+__global__ __launch_bounds__(256) void sqnorm_partial(const float* __restrict__ g, int64_t n, float* __restrict__ part) {
+  __shared__ float lds[4];
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s = fmaf(g[i], g[i], s);
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
+}
+// state[0] = step count (float), state[1] = total grad norm of the last step, state[2] = clip coefficient
+__global__ __launch_bounds__(256) void sqnorm_final(const float* __restrict__ part, int nparts, float grad_scale, float max_norm,
+                                                    float* __restrict__ state) {
+  __shared__ float lds[4];
+  float s = threadIdx.x < nparts ? part[threadIdx.x] : 0.f;
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float norm = sqrtf(lds[0] + lds[1] + lds[2] + lds[3]) * grad_scale;
+    float coef = 1.f;
+    if (max_norm > 0.f) coef = fminf(max_norm / (norm + 1e-6f), 1.f);
+    state[0] += 1.f;
+    state[1] = norm;
+    state[2] = coef * grad_scale;
+  }
+}
+__global__ void adam_update(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            int64_t n, float lr, float b1, float b2, float eps, float wd, const float* __restrict__ state) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float step = state[0], scale = state[2];
+  const float bc1 = 1.f - powf(b1, step), bc2 = 1.f - powf(b2, step);
+  float gi = g[i] * scale;
+  if (wd != 0.f) gi = fmaf(wd, p[i], gi);
+  const float mi = fmaf(b1, m[i], (1.f - b1) * gi);
+  const float vi = fmaf(b2, v[i], (1.f - b2) * gi * gi);
+  m[i] = mi; v[i] = vi;
+  const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+  p[i] -= (lr / bc1) * (mi / denom);
+}
+
+}  // namespace
+
+extern "C" {
+
+/* One optimiser step on flat buffers: g *= grad_scale (1/world after the all-reduce), clip to max_norm
+ * (<=0: off), Adam.  ws >= 256 floats; state = 3 floats {step, grad_norm, applied scale}, zero before step 1. */
+int tsgnn_clip_adam_step_f32(float* param, const float* grad, float* m, float* v, int64_t n, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, float max_norm, float grad_scale, float* state,
+                             float* ws, tsgnn_stream_t stream) {
+  if (!param || !grad || !m || !v || !state || !ws || n <= 0) return TSGNN_EINVAL;
+  int nb = (int)ceil_div64(n, 256 * 8);
+  if (nb > NPART) nb = NPART;
+  sqnorm_partial<<<nb, 256, 0, stream>>>(grad, n, ws);
+  sqnorm_final<<<1, 256, 0, stream>>>(ws, nb, grad_scale, max_norm, state);
+  adam_update<<<(unsigned)ceil_div64(n, 256), 256, 0, stream>>>(param, grad, m, v, n, lr, beta1, beta2, eps, weight_decay, state);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,77 @@
+"""Data-parallel training step: one process per GPU, independent mini-batches of graphs per rank, ONE
+RCCL all-reduce per step on a single flat fp32 gradient buffer over xGMI, then a fused clip+Adam.
+
+The reference is single-process (train.py:509 pins one device, no torch.distributed anywhere); this is
+the new capability BASELINE.json's north_star asks for.  Graphs never share edges, so
+there is no feature exchange between ranks: the gradient all-reduce is the only collective.  The model
+is tiny (SAGE-3L h=128 on DD: ~61 k parameters = 0.25 MB), so the collective is latency-bound: one
+bucket, one call.  Slot batch-norm statistics stay local to each rank's batch (= the reference run on
+each shard).
+"""
+import torch
+import torch.distributed as dist
+
+from . import _native as nat
+
+
+class FlatTrainer:
+    """Owns flat parameter / gradient / Adam-moment buffers; model parameters become views of the flat
+    parameter buffer, so the HIP optimiser kernel updates the model in place."""
+
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip=2.0, group=None):
+        self.model = model
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        dev = self.params[0].device
+        self.numel = sum(p.numel() for p in self.params)
+        self.flat_param = torch.empty(self.numel, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        off = 0
+        self.views = []
+        for p in self.params:
+            n = p.numel()
+            self.flat_param[off:off + n].copy_(p.data.reshape(-1))
+            p.data = self.flat_param[off:off + n].view_as(p.data)
+            self.views.append((off, n))
+            off += n
+        self.lr, self.betas, self.eps, self.wd, self.clip = lr, betas, eps, weight_decay, clip
+        self.on_gpu = dev.type == "cuda"
+        self.exp_avg = torch.zeros_like(self.flat_param)
+        self.exp_avg_sq = torch.zeros_like(self.flat_param)
+        self.state = torch.zeros(3, dtype=torch.float32, device=dev)      # step, grad norm, applied scale
+        self.ws = torch.empty(256, dtype=torch.float32, device=dev)
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None
+
+    def gather_grads(self):
+        """per-parameter gradients -> the flat bucket (one concatenation kernel)."""
+        parts = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params]
+        torch.cat(parts, out=self.flat_grad)
+        return self.flat_grad
+
+    def all_reduce(self):
+        """SUM over ranks on the flat bucket; the 1/world factor is applied inside the optimiser kernel."""
+        if self.world > 1:
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+
+    def apply(self):
+        scale = 1.0 / self.world
+        if not self.on_gpu:
+            raise RuntimeError("FlatTrainer.apply runs the HIP optimiser kernel; parameters must live on the GPU "
+                               "(no CPU fallback)")
+        nat.call("clip_adam_step_f32", self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.numel,
+                 float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd),
+                 float(self.clip), float(scale), self.state, self.ws)
+
+    def step(self, loss_fn):
+        """loss_fn() -> scalar loss.  fwd + bwd + all-reduce + clip + Adam."""
+        self.zero_grad()
+        loss = loss_fn()
+        loss.backward()
+        self.gather_grads()
+        self.all_reduce()
+        self.apply()
+        return loss
