@@ -151,6 +151,42 @@ int tsgnn_clip_adam_step_f32(float* param, const float* grad, float* m, float* v
                              float beta2, float eps, float weight_decay, float max_norm, float grad_scale, float* state,
                              float* ws, tsgnn_stream_t stream);
 
+/* ---------------------------------------------------------------- edge-softmax attention (attention.hip) */
+
+/* s[r,h] = <x[r, head h], a[h]>  — the two per-node scalars a1.h_i / a2.h_j that replace the reference's
+ * [N,N,2F] pair tensor (encoders_GAT.py:35-36). */
+int tsgnn_node_scores_f32(const float* x, int64_t ldx, int64_t rows, int H, int Fh, const float* a, int64_t lda, float* s,
+                          tsgnn_stream_t stream);
+/* alpha[e,h] = softmax over the entries e of CSR row g of LeakyReLU(s_grp[g,h] + s_oth[col[e],h]).
+ * Reference DGATHead (encoders_GAT.py:36-41, softmax over dim=1 = per column, trap T3): call on A^T with
+ * s_grp = a2.h, s_oth = a1.h.  PyG GATConv: call on A (rows = targets).  mod > 0: node index = id % mod. */
+int tsgnn_edge_softmax_fwd_f32(const int* rowptr, const int* col, int64_t rows, int H, const float* s_grp, const float* s_oth,
+                               int mod, float slope, float* alpha, tsgnn_stream_t stream);
+int tsgnn_edge_softmax_bwd_f32(const int* rowptr, const int* col, int64_t rows, int H, const float* s_grp, const float* s_oth,
+                               int mod, float slope, const float* alpha, const float* dalpha, float* dt, float* ds_grp,
+                               tsgnn_stream_t stream);
+/* per-entry values between a CSR and its transpose: gather dst[p] = src[perm[p]] / scatter dst[perm[p]] = src[p] */
+int tsgnn_edge_permute_f32(const float* src, const int* perm, int64_t n, int H, int scatter, float* dst, tsgnn_stream_t stream);
+/* out[r,h] = sum of val[e,h] over the entries of row r */
+int tsgnn_csr_row_sum_f32(const int* rowptr, const float* val, int64_t rows, int H, float* out, tsgnn_stream_t stream);
+/* y[r, head h] = sum_e alpha[e,h] * x[col[e], head h]   (h_prime = attention @ h, encoders_GAT.py:43) */
+int tsgnn_csr_spmm_heads_f32(const int* rowptr, const int* col, const float* alpha, int H, int Fh, const float* x, int64_t ldx,
+                             int mod, float* y, int64_t ldy, int64_t rows, tsgnn_stream_t stream);
+/* dalpha[e,h] = <dy[row(e), head h], x[col[e], head h]>  (sampled dense-dense product) */
+int tsgnn_csr_sddmm_heads_f32(const int* rowptr, const int* col, int H, int Fh, const float* dy, int64_t lddy, const float* x,
+                              int64_t ldx, int mod, float* dalpha, int64_t rows, tsgnn_stream_t stream);
+/* out[s,c] = scale * sum_{r in segment s} w[r, c/Fh] * x[r,c]  (w NULL = 1; seg_ptr NULL = one segment of `rows`).
+ * Also PyG global_mean_pool / global_add_pool (Code/sag/network.py:36). */
+int tsgnn_segment_wsum_f32(const float* x, int64_t ldx, const float* w, int H, int Fh, const int* seg_ptr, int nseg, int64_t rows,
+                           float scale, float* out, int64_t ldo, tsgnn_stream_t stream);
+/* y[r,c] += scale * w[r,c/Fh] * (a ? a[(c/Fh)*lda + c%Fh] : u[(r / rows_per_seg)*ldu + c])   (w NULL = 1) */
+int tsgnn_broadcast_add_f32(float* y, int64_t ldy, int64_t rows, int H, int Fh, const float* w, const float* a, int64_t lda,
+                            const float* u, int64_t ldu, int rows_per_seg, float scale, tsgnn_stream_t stream);
+/* ELU (encoders_GAT.py:47) / mean over heads then ELU (:78-83) */
+int tsgnn_elu_heads_fwd_f32(const float* x, int64_t rows, int H, int Fh, int mean_heads, int apply_elu, float* y, tsgnn_stream_t stream);
+int tsgnn_elu_heads_bwd_f32(const float* x, const float* dy, int64_t rows, int H, int Fh, int mean_heads, int apply_elu, float* dx,
+                            tsgnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Per-kernel micro-benchmark on the DD b32 shapes (hipGraph-captured bursts, HIP events)."""
+import os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from two_stage_gnn_amd import message_passing as mp, synthetic, _native as nat
+from two_stage_gnn_amd.graph import GraphBatch
+
+
+def burst_us(fn, iters=200):
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=s):
+            for _ in range(iters):
+                fn()
+        gr.replay(); torch.cuda.synchronize()
+        best = 1e9
+        for _ in range(5):
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(s); gr.replay(); e1.record(s); e1.synchronize()
+            best = min(best, e0.elapsed_time(e1) / iters * 1e3)
+    return best
+
+
+def main():
+    B = int(os.environ.get("B", 32)); H = 128
+    hb = synthetic.host_batch(0, B, "DD", 1000)
+    g, x, label = synthetic.to_device(hb, torch.device("cuda"))
+    R = g.total_rows
+    print("rows", R, "nnz", g.nnz)
+    X = torch.randn(R, H, device="cuda"); Y = torch.empty_like(X)
+    W = torch.randn(H, H, device="cuda") * 0.1; b = torch.randn(H, device="cuda")
+    rinv = torch.empty(R, device="cuda")
+    res = {}
+    res["empty(memset 4B)"] = burst_us(lambda: rinv[:1].zero_())
+    res["spmm F=128"] = burst_us(lambda: mp.spmm_raw(g.rowptr, g.col, None, X, R, out=Y))
+    res["spmm F=92"] = burst_us(lambda: mp.spmm_raw(g.rowptr, g.col, None, x, R, out=torch.empty_like(x)))
+    res["linear_l2norm 128x128"] = burst_us(lambda: nat.call("linear_l2norm_f32", X, H, W, H, b, Y, H, rinv, R, H, H, 1))
+    dz = torch.empty_like(X)
+    res["gemm dZ=dU.W^T"] = burst_us(lambda: mp.gemm(X, H, 1, W, 1, H, dz, H, 1, R, H, H))
+    res["gemm dW splitk"] = burst_us(lambda: mp.gemm_tn_splitk(X, H, Y))
+    res["colsum"] = burst_us(lambda: mp.colsum(X))
+    mean = torch.empty(g.nmax, device="cuda"); rstd = torch.empty(g.nmax, device="cuda")
+    res["bn_slots fwd (stats+apply)"] = burst_us(lambda: nat.call("bn_slots_fwd_f32", g.graph_ptr, g.slot_count, g.row_slot, g.B, g.nmax, g.n_rows, g.n_ghost, X, H, H, 1, 1, mean, rstd, Y, H))
+    m1 = torch.empty(g.nmax, device="cuda"); m2 = torch.empty(g.nmax, device="cuda")
+    res["bn_slots bwd (stats+apply)"] = burst_us(lambda: nat.call("bn_slots_bwd_f32", g.graph_ptr, g.slot_count, g.row_slot, g.B, g.nmax, g.n_rows, g.n_ghost, X, H, Y, H, H, 1, 1, mean, rstd, m1, m2, dz, H))
+    out = torch.empty(g.B, H, device="cuda"); arg = torch.empty(g.B, H, dtype=torch.int32, device="cuda"); ws = torch.empty(g.B * H, dtype=torch.int64, device="cuda")
+    res["readout fwd (memset+partial+decode)"] = burst_us(lambda: nat.call("readout_max_fwd_f32", g.graph_ptr, g.slot_count, g.B, g.nmax, g.n_rows, g.n_ghost, X, H, H, 0, ws, out, H, arg))
+    res["l2norm_bwd"] = burst_us(lambda: nat.call("l2norm_bwd_f32", X, H, Y, H, rinv, dz, H, R, H))
+    res["torch.mm 9151x128x128 (rocBLAS ref)"] = burst_us(lambda: torch.mm(X, W, out=Y))
+    res["torch.mm X^T.Y (rocBLAS ref)"] = burst_us(lambda: torch.mm(X.t(), Y))
+    for k, v in res.items():
+        print("%-40s %8.2f us" % (k, v))
+
+
+if __name__ == "__main__":
+    main()

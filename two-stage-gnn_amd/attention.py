@@ -1,0 +1,141 @@
+"""Edge-softmax attention aggregation (forward + explicit backward) over a GraphBatch.
+
+Two normalisation modes, same kernels (csrc/attention.hip):
+  * ``by_column=True``  — the reference's DGATHead (encoders_GAT.py:29-49): softmax over the ROW index i
+    for every column j (trap T3); columns without any edge become uniform 1/N and add (1/N)*h_j to every
+    row of their graph (the -9e15 mask makes an all-masked column's softmax uniform, :38-41).
+  * ``by_column=False`` — standard per-target softmax (PyG GATConv).
+"""
+import torch
+
+from . import _native as nat
+
+
+def _f32(*shape, device, zero=False):
+    return (torch.zeros if zero else torch.empty)(*shape, dtype=torch.float32, device=device)
+
+
+def node_scores(h, a, H, Fh):
+    s = _f32(h.size(0), H, device=h.device)
+    nat.call("node_scores_f32", h, h.stride(0), h.size(0), H, Fh, a, a.stride(0), s)
+    return s
+
+
+def segment_wsum(x, w, H, Fh, seg_ptr, nseg, scale=1.0):
+    out = _f32(nseg, H * Fh, device=x.device)
+    nat.call("segment_wsum_f32", x, x.stride(0), w, H, Fh, seg_ptr, nseg, x.size(0), float(scale), out, out.stride(0))
+    return out
+
+
+class _AttentionAggregate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, a_row, a_col, g, H, slope, by_column, uniform_isolated):
+        """h [R, H*Fh]; a_row / a_col [H, Fh]: vectors dotted with the ROW node i / COLUMN node j of entry (i,j).
+        returns pre-activation out[i] = sum_j alpha_ij h_j (+ uniform term)."""
+        h = h.contiguous()
+        a_row = a_row.contiguous()
+        a_col = a_col.contiguous()
+        R, C = h.shape
+        Fh = C // H
+        dev = h.device
+        s_row = node_scores(h, a_row, H, Fh)
+        s_col = node_scores(h, a_col, H, Fh)
+        nnz = max(g.nnz, 1)
+        rp_t, col_t, src_e_t = g.transpose_map() if by_column else (None, None, None)
+        if by_column:
+            # groups = columns j = rows of A^T;  alpha_G lives on A^T's entries, then is permuted onto A's
+            alpha_g = _f32(nnz, H, device=dev)
+            nat.call("edge_softmax_fwd_f32", rp_t, col_t, R, H, s_col, s_row, 0, float(slope), alpha_g)
+            alpha = _f32(nnz, H, device=dev)
+            nat.call("edge_permute_f32", alpha_g, src_e_t, g.nnz, H, 1, alpha)
+        else:
+            alpha_g = None
+            alpha = _f32(nnz, H, device=dev)
+            nat.call("edge_softmax_fwd_f32", g.rowptr, g.col, R, H, s_row, s_col, 0, float(slope), alpha)
+        out = _f32(R, C, device=dev)
+        nat.call("csr_spmm_heads_f32", g.rowptr, g.col, alpha, H, Fh, h, h.stride(0), 0, out, out.stride(0), R)
+        iso = None
+        if uniform_isolated:
+            # columns with no edge: softmax of an all-masked column is uniform 1/N over the N rows of the graph
+            deg_t = (rp_t[1:] - rp_t[:-1])
+            iso = (deg_t == 0).to(torch.float32).unsqueeze(1).expand(R, H).contiguous()
+            N = g.nmax
+            u = segment_wsum(h, iso, H, Fh, g.graph_ptr, g.B, scale=1.0 / N)
+            nat.call("broadcast_add_f32", out, out.stride(0), R, H, Fh, None, None, 0, u, u.stride(0), N, 1.0)
+        ctx.g, ctx.H, ctx.Fh, ctx.slope, ctx.by_column = g, H, Fh, slope, by_column
+        ctx.save_for_backward(h, a_row, a_col, s_row, s_col, alpha, alpha_g, iso)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        h, a_row, a_col, s_row, s_col, alpha, alpha_g, iso = ctx.saved_tensors
+        g, H, Fh, slope = ctx.g, ctx.H, ctx.Fh, ctx.slope
+        dout = dout.contiguous()
+        R, C = h.shape
+        dev = h.device
+        nnz = max(g.nnz, 1)
+        rp_t, col_t, src_e_t = g.transpose_map()
+        dalpha = _f32(nnz, H, device=dev)
+        nat.call("csr_sddmm_heads_f32", g.rowptr, g.col, H, Fh, dout, dout.stride(0), h, h.stride(0), 0, dalpha, R)
+        dh = _f32(R, C, device=dev)
+        ds_row = _f32(R, H, device=dev)
+        ds_col = _f32(R, H, device=dev)
+        if ctx.by_column:
+            dalpha_g = _f32(nnz, H, device=dev)
+            nat.call("edge_permute_f32", dalpha, src_e_t, g.nnz, H, 0, dalpha_g)
+            dt_g = _f32(nnz, H, device=dev)
+            nat.call("edge_softmax_bwd_f32", rp_t, col_t, R, H, s_col, s_row, 0, float(slope), alpha_g, dalpha_g, dt_g, ds_col)
+            dt = _f32(nnz, H, device=dev)
+            nat.call("edge_permute_f32", dt_g, src_e_t, g.nnz, H, 1, dt)
+            nat.call("csr_row_sum_f32", g.rowptr, dt, R, H, ds_row)
+            alpha_t = alpha_g
+        else:
+            dt = _f32(nnz, H, device=dev)
+            nat.call("edge_softmax_bwd_f32", g.rowptr, g.col, R, H, s_row, s_col, 0, float(slope), alpha, dalpha, dt, ds_row)
+            dt_t = _f32(nnz, H, device=dev)
+            nat.call("edge_permute_f32", dt, src_e_t, g.nnz, H, 0, dt_t)
+            nat.call("csr_row_sum_f32", rp_t, dt_t, R, H, ds_col)
+            alpha_t = _f32(nnz, H, device=dev)
+            nat.call("edge_permute_f32", alpha, src_e_t, g.nnz, H, 0, alpha_t)
+        # dh_j = sum_i alpha_ij dout_i  (transposed aggregation)  + ds_row (x) a_row + ds_col (x) a_col
+        nat.call("csr_spmm_heads_f32", rp_t, col_t, alpha_t, H, Fh, dout, dout.stride(0), 0, dh, dh.stride(0), R)
+        nat.call("broadcast_add_f32", dh, dh.stride(0), R, H, Fh, ds_row, a_row, a_row.stride(0), None, 0, 0, 1.0)
+        nat.call("broadcast_add_f32", dh, dh.stride(0), R, H, Fh, ds_col, a_col, a_col.stride(0), None, 0, 0, 1.0)
+        if iso is not None:
+            N = g.nmax
+            du = segment_wsum(dout, None, H, Fh, g.graph_ptr, g.B, scale=1.0)
+            nat.call("broadcast_add_f32", dh, dh.stride(0), R, H, Fh, iso, None, 0, du, du.stride(0), N, 1.0 / N)
+        da_row = segment_wsum(h, ds_row, H, Fh, None, 1).view(H, Fh)
+        da_col = segment_wsum(h, ds_col, H, Fh, None, 1).view(H, Fh)
+        return dh, da_row, da_col, None, None, None, None, None
+
+
+def attention_aggregate(h, a_row, a_col, g, heads, slope=0.2, by_column=True, uniform_isolated=True):
+    return _AttentionAggregate.apply(h, a_row, a_col, g, int(heads), float(slope), bool(by_column), bool(uniform_isolated))
+
+
+class _EluHeads(torch.autograd.Function):
+    """ELU per head (concat) or mean over heads (+ELU)  — encoders_GAT.py:47 / :78-83."""
+
+    @staticmethod
+    def forward(ctx, x, H, mean_heads, apply_elu):
+        x = x.contiguous()
+        R, C = x.shape
+        Fh = C // H
+        y = _f32(R, Fh if mean_heads else C, device=x.device)
+        nat.call("elu_heads_fwd_f32", x, R, H, Fh, int(mean_heads), int(apply_elu), y)
+        ctx.save_for_backward(x)
+        ctx.cfg = (H, Fh, mean_heads, apply_elu)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        H, Fh, mean_heads, apply_elu = ctx.cfg
+        dx = torch.empty_like(x)
+        nat.call("elu_heads_bwd_f32", x, dy.contiguous(), x.size(0), H, Fh, int(mean_heads), int(apply_elu), dx)
+        return dx, None, None, None
+
+
+def elu_heads(x, heads, mean_heads, apply_elu):
+    return _EluHeads.apply(x, int(heads), bool(mean_heads), bool(apply_elu))

@@ -1,0 +1,339 @@
+// Edge-softmax attention (SURVEY §8 a6/a7 and GATConv of a15) without ever materialising the
+// reference's [N,N,2F] pair tensor (encoders_GAT.py:35) or its dense [N,N] attention matrix.
+//
+//   score of entry e in softmax group g (a CSR row):  t = s_grp[g,h] + s_oth[col[e] % mod, h]
+//   alpha[e,h] = softmax over the group's entries of LeakyReLU(t)
+//
+// Reference DGATHead (encoders_GAT.py:36-43): softmax(dim=1) normalises over the ROW index i for each
+// column j (trap T3) -> groups are the rows of A^T, s_grp = a2.h_j, s_oth = a1.h_i; the aggregation
+// out_i = sum_j alpha_ij h_j then runs on A with the permuted alphas.  PyG GATConv: groups are the
+// target rows of A, s_grp = att_r.h_i, s_oth = att_l.h_j, same-CSR aggregation.
+// One sub-wave lane group per CSR row; per-node scalars only in the softmax pass (HBM-light), feature
+// rows are gathered once, by the head-weighted SpMM.
+#include "common.h"
+#include "../../include/tsgnn.h"
+
+namespace {
+
+__device__ __forceinline__ float lrelu(float t, float slope) { return t > 0.f ? t : slope * t; }
+
+// per-node scalars s[r,h] = sum_f x[r, h*Fh + f] * a[h*lda + f]    (a1.h_i / a2.h_j for every head)
+__global__ __launch_bounds__(256) void node_scores_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows, int H, int Fh,
+                                                          const float* __restrict__ a, int64_t lda, float* __restrict__ s) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  for (int h = 0; h < H; ++h) {
+    float acc = 0.f;
+    for (int f = lane; f < Fh; f += 64) acc = fmaf(x[r * ldx + (int64_t)h * Fh + f], a[(int64_t)h * lda + f], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) s[r * H + h] = acc;
+  }
+}
+
+// thread per (row, head): numerically-stable softmax over the row's entries
+__global__ void edge_softmax_fwd_kernel(const int* __restrict__ rowptr, const int* __restrict__ col, int64_t rows, int H,
+                                        const float* __restrict__ s_grp, const float* __restrict__ s_oth, int mod, float slope,
+                                        float* __restrict__ alpha) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * H) return;
+  const int64_t g = i / H;
+  const int h = (int)(i % H);
+  const int e0 = rowptr[g], e1 = rowptr[g + 1];
+  if (e0 == e1) return;
+  const float sg = s_grp[(mod ? g % mod : g) * H + h];
+  float m = -INFINITY;
+  for (int e = e0; e < e1; ++e) {
+    const int64_t c = mod ? col[e] % mod : col[e];
+    m = fmaxf(m, lrelu(sg + s_oth[c * H + h], slope));
+  }
+  float d = 0.f;
+  for (int e = e0; e < e1; ++e) {
+    const int64_t c = mod ? col[e] % mod : col[e];
+    const float p = expf(lrelu(sg + s_oth[c * H + h], slope) - m);
+    alpha[(int64_t)e * H + h] = p;
+    d += p;
+  }
+  const float inv = 1.f / d;
+  for (int e = e0; e < e1; ++e) alpha[(int64_t)e * H + h] *= inv;
+}
+
+// softmax + LeakyReLU backward inside a group:  dt[e] = alpha (dalpha - sum alpha dalpha) * lrelu'(t)
+// also ds_grp[g,h] = sum_e dt[e,h]
+__global__ void edge_softmax_bwd_kernel(const int* __restrict__ rowptr, const int* __restrict__ col, int64_t rows, int H,
+                                        const float* __restrict__ s_grp, const float* __restrict__ s_oth, int mod, float slope,
+                                        const float* __restrict__ alpha, const float* __restrict__ dalpha,
+                                        float* __restrict__ dt, float* __restrict__ ds_grp) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * H) return;
+  const int64_t g = i / H;
+  const int h = (int)(i % H);
+  const int e0 = rowptr[g], e1 = rowptr[g + 1];
+  float c = 0.f;
+  for (int e = e0; e < e1; ++e) c = fmaf(alpha[(int64_t)e * H + h], dalpha[(int64_t)e * H + h], c);
+  const float sg = (e0 < e1) ? s_grp[(mod ? g % mod : g) * H + h] : 0.f;
+  float acc = 0.f;
+  for (int e = e0; e < e1; ++e) {
+    const int64_t cc = mod ? col[e] % mod : col[e];
+    const float t = sg + s_oth[cc * H + h];
+    const float v = alpha[(int64_t)e * H + h] * (dalpha[(int64_t)e * H + h] - c) * (t > 0.f ? 1.f : slope);
+    dt[(int64_t)e * H + h] = v;
+    acc += v;
+  }
+  ds_grp[i] = acc;
+}
+
+// out[p, :] = src[perm[p], :]   (edge-value permutation between a CSR and its transpose)
+__global__ void gather_rows_small(const float* __restrict__ src, const int* __restrict__ perm, int64_t n, int H, float* __restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * H) return;
+  dst[i] = src[(int64_t)perm[i / H] * H + (i % H)];
+}
+__global__ void scatter_rows_small(const float* __restrict__ src, const int* __restrict__ perm, int64_t n, int H, float* __restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * H) return;
+  dst[(int64_t)perm[i / H] * H + (i % H)] = src[i];
+}
+// out[r, h] = sum over the row's entries of val[e, h]
+__global__ void csr_row_sum_kernel(const int* __restrict__ rowptr, const float* __restrict__ val, int64_t rows, int H, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * H) return;
+  const int64_t r = i / H;
+  const int h = (int)(i % H);
+  float acc = 0.f;
+  for (int e = rowptr[r]; e < rowptr[r + 1]; ++e) acc += val[(int64_t)e * H + h];
+  out[i] = acc;
+}
+
+// head-weighted aggregation: y[r, h*Fh+f] = sum_e alpha[e,h] * x[col[e] % mod, h*Fh+f];  one wave per row
+__global__ __launch_bounds__(256) void spmm_heads_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                         const float* __restrict__ alpha, int H, int Fh,
+                                                         const float* __restrict__ x, int64_t ldx, int mod,
+                                                         float* __restrict__ y, int64_t ldy, int64_t rows, unsigned nblk) {
+  const unsigned lb = xcd_remap(blockIdx.x, nblk);
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)lb * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int F = H * Fh;
+  const int e0 = rowptr[r], e1 = rowptr[r + 1];
+  for (int fb = 0; fb < F; fb += 64) {
+    const int f = fb + lane;
+    const bool live = f < F;
+    const int h = live ? f / Fh : 0;
+    float acc = 0.f;
+    for (int eb = e0; eb < e1; eb += 64) {
+      const int me = eb + lane;
+      const int cj = (me < e1) ? (mod ? col[me] % mod : col[me]) : 0;
+      const int cnt = min(64, e1 - eb);
+      for (int k = 0; k < cnt; ++k) {
+        const int j = __shfl(cj, k, 64);
+        if (live) acc = fmaf(alpha[(int64_t)(eb + k) * H + h], x[(int64_t)j * ldx + f], acc);
+      }
+    }
+    if (live) y[r * ldy + f] = acc;
+  }
+}
+
+// SDDMM: dalpha[e,h] = dot(dy[r, head h], x[col[e] % mod, head h]) for every entry e of row r; one wave per row
+__global__ __launch_bounds__(256) void sddmm_heads_kernel(const int* __restrict__ rowptr, const int* __restrict__ col, int H, int Fh,
+                                                          const float* __restrict__ dy, int64_t lddy, const float* __restrict__ x,
+                                                          int64_t ldx, int mod, float* __restrict__ dalpha, int64_t rows) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int e0 = rowptr[r], e1 = rowptr[r + 1];
+  for (int e = e0; e < e1; ++e) {
+    const int64_t j = mod ? col[e] % mod : col[e];
+    for (int h = 0; h < H; ++h) {
+      float acc = 0.f;
+      for (int f = lane; f < Fh; f += 64) acc = fmaf(dy[r * lddy + (int64_t)h * Fh + f], x[j * ldx + (int64_t)h * Fh + f], acc);
+      acc = wave_sum(acc);
+      if (lane == 0) dalpha[(int64_t)e * H + h] = acc;
+    }
+  }
+}
+
+// out[s, c] = sum_{r in segment s} w[r, c / Fh] * x[r, c]   (w nullable = 1).  grid (ceil(C/64), S); two row-lanes... one
+// block per (64-column strip, segment): 4 waves stride over the segment's rows, LDS combine (fixed order).
+__global__ __launch_bounds__(256) void segment_wsum_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ w, int H,
+                                                           int Fh, const int* __restrict__ seg_ptr, int64_t rows_if_one, int C,
+                                                           float scale, float* __restrict__ out, int64_t ldo) {
+  __shared__ float lds[4][64];
+  const int s = blockIdx.y;
+  const int64_t r0 = seg_ptr ? seg_ptr[s] : 0, r1 = seg_ptr ? seg_ptr[s + 1] : rows_if_one;
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  float acc = 0.f;
+  if (c < C) {
+    const int h = c / Fh;
+    for (int64_t r = r0 + rl; r < r1; r += 4) acc = fmaf(w ? w[r * H + h] : 1.f, x[r * ldx + c], acc);
+  }
+  lds[rl][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (rl == 0 && c < C) out[(int64_t)s * ldo + c] = scale * (lds[0][threadIdx.x] + lds[1][threadIdx.x] + lds[2][threadIdx.x] + lds[3][threadIdx.x]);
+}
+
+// y[r, c] (+)= alpha * w[r, c/Fh] * v[seg(r)?, c] ... generic rank-1 style broadcast add:
+//   mode 0: y[r,c] += w[r, c/Fh] * a[(c/Fh)*lda + c%Fh]         (ds (x) a  terms of dh)
+//   mode 1: y[r,c] += w[r, c/Fh] * u[seg_of_row(r), c]           (uniform term; w nullable = 1)
+__global__ void broadcast_add_kernel(float* __restrict__ y, int64_t ldy, int64_t rows, int H, int Fh, const float* __restrict__ w,
+                                     const float* __restrict__ a, int64_t lda, const float* __restrict__ u, int64_t ldu,
+                                     int rows_per_seg, float scale) {
+  const int C = H * Fh;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * C) return;
+  const int64_t r = i / C;
+  const int c = (int)(i % C), h = c / Fh;
+  const float wv = w ? w[r * H + h] : 1.f;
+  float add;
+  if (a) add = wv * a[(int64_t)h * lda + (c - h * Fh)];
+  else add = wv * u[(r / rows_per_seg) * ldu + c];
+  y[r * ldy + c] += scale * add;
+}
+
+// ELU forward / backward (encoders_GAT.py:47,83), optional mean over heads first (concat=False, :78-83)
+__global__ void elu_heads_fwd_kernel(const float* __restrict__ x, int64_t rows, int H, int Fh, int mean_heads, int apply_elu,
+                                     float* __restrict__ y) {
+  const int Co = mean_heads ? Fh : H * Fh;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * Co) return;
+  const int64_t r = i / Co;
+  const int c = (int)(i % Co);
+  float v;
+  if (mean_heads) {
+    v = 0.f;
+    for (int h = 0; h < H; ++h) v += x[r * (int64_t)(H * Fh) + (int64_t)h * Fh + c];
+    v /= (float)H;
+  } else v = x[i];
+  y[i] = (apply_elu && v <= 0.f) ? expm1f(v) : v;
+}
+__global__ void elu_heads_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, int64_t rows, int H, int Fh,
+                                     int mean_heads, int apply_elu, float* __restrict__ dx) {
+  const int C = H * Fh;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * C) return;
+  const int64_t r = i / C;
+  const int c = (int)(i % C);
+  if (mean_heads) {
+    const int f = c % Fh;
+    float v = 0.f;
+    for (int h = 0; h < H; ++h) v += x[r * (int64_t)C + (int64_t)h * Fh + f];
+    v /= (float)H;
+    const float g = dy[r * Fh + f] * ((apply_elu && v <= 0.f) ? expf(v) : 1.f);
+    dx[i] = g / (float)H;
+  } else {
+    const float v = x[i];
+    dx[i] = dy[i] * ((apply_elu && v <= 0.f) ? expf(v) : 1.f);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int tsgnn_node_scores_f32(const float* x, int64_t ldx, int64_t rows, int H, int Fh, const float* a, int64_t lda, float* s,
+                          tsgnn_stream_t stream) {
+  if (!x || !a || !s || rows < 0 || H <= 0 || Fh <= 0 || ldx < (int64_t)H * Fh) return TSGNN_EINVAL;
+  if (rows == 0) return TSGNN_OK;
+  node_scores_kernel<<<(unsigned)ceil_div64(rows, 4), 256, 0, stream>>>(x, ldx, rows, H, Fh, a, lda, s);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+int tsgnn_edge_softmax_fwd_f32(const int* rowptr, const int* col, int64_t rows, int H, const float* s_grp, const float* s_oth,
+                               int mod, float slope, float* alpha, tsgnn_stream_t stream) {
+  if (!rowptr || !s_grp || !s_oth || !alpha || rows < 0 || H <= 0 || mod < 0) return TSGNN_EINVAL;
+  if (rows == 0) return TSGNN_OK;
+  edge_softmax_fwd_kernel<<<(unsigned)ceil_div64(rows * H, 256), 256, 0, stream>>>(rowptr, col, rows, H, s_grp, s_oth, mod, slope, alpha);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+int tsgnn_edge_softmax_bwd_f32(const int* rowptr, const int* col, int64_t rows, int H, const float* s_grp, const float* s_oth,
+                               int mod, float slope, const float* alpha, const float* dalpha, float* dt, float* ds_grp,
+                               tsgnn_stream_t stream) {
+  if (!rowptr || !s_grp || !s_oth || !alpha || !dalpha || !dt || !ds_grp || rows < 0 || H <= 0 || mod < 0) return TSGNN_EINVAL;
+  if (rows == 0) return TSGNN_OK;
+  edge_softmax_bwd_kernel<<<(unsigned)ceil_div64(rows * H, 256), 256, 0, stream>>>(rowptr, col, rows, H, s_grp, s_oth, mod, slope,
+                                                                                  alpha, dalpha, dt, ds_grp);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+int tsgnn_edge_permute_f32(const float* src, const int* perm, int64_t n, int H, int scatter, float* dst, tsgnn_stream_t stream) {
+  if (!src || !perm || !dst || n < 0 || H <= 0) return TSGNN_EINVAL;
+  if (n == 0) return TSGNN_OK;
+  if (scatter) scatter_rows_small<<<(unsigned)ceil_div64(n * H, 256), 256, 0, stream>>>(src, perm, n, H, dst);
+  else gather_rows_small<<<(unsigned)ceil_div64(n * H, 256), 256, 0, stream>>>(src, perm, n, H, dst);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+int tsgnn_csr_row_sum_f32(const int* rowptr, const float* val, int64_t rows, int H, float* out, tsgnn_stream_t stream) {
+  if (!rowptr || !val || !out || rows < 0 || H <= 0) return TSGNN_EINVAL;
+  if (rows == 0) return TSGNN_OK;
+  csr_row_sum_kernel<<<(unsigned)ceil_div64(rows * H, 256), 256, 0, stream>>>(rowptr, val, rows, H, out);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+int tsgnn_csr_spmm_heads_f32(const int* rowptr, const int* col, const float* alpha, int H, int Fh, const float* x, int64_t ldx,
+                             int mod, float* y, int64_t ldy, int64_t rows, tsgnn_stream_t stream) {
+  if (!rowptr || !alpha || !x || !y || rows < 0 || H <= 0 || Fh <= 0 || mod < 0 || ldx < (int64_t)H * Fh || ldy < (int64_t)H * Fh)
+    return TSGNN_EINVAL;
+  if (rows == 0) return TSGNN_OK;
+  const unsigned nblk = (unsigned)ceil_div64(rows, 4);
+  spmm_heads_kernel<<<nblk, 256, 0, stream>>>(rowptr, col, alpha, H, Fh, x, ldx, mod, y, ldy, rows, nblk);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+int tsgnn_csr_sddmm_heads_f32(const int* rowptr, const int* col, int H, int Fh, const float* dy, int64_t lddy, const float* x,
+                              int64_t ldx, int mod, float* dalpha, int64_t rows, tsgnn_stream_t stream) {
+  if (!rowptr || !dy || !x || !dalpha || rows < 0 || H <= 0 || Fh <= 0 || mod < 0) return TSGNN_EINVAL;
+  if (rows == 0) return TSGNN_OK;
+  sddmm_heads_kernel<<<(unsigned)ceil_div64(rows, 4), 256, 0, stream>>>(rowptr, col, H, Fh, dy, lddy, x, ldx, mod, dalpha, rows);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+int tsgnn_segment_wsum_f32(const float* x, int64_t ldx, const float* w, int H, int Fh, const int* seg_ptr, int nseg, int64_t rows,
+                           float scale, float* out, int64_t ldo, tsgnn_stream_t stream) {
+  if (!x || !out || H <= 0 || Fh <= 0 || nseg <= 0 || rows < 0 || ldx < (int64_t)H * Fh || ldo < (int64_t)H * Fh) return TSGNN_EINVAL;
+  if (!seg_ptr && nseg != 1) return TSGNN_EINVAL;
+  const int C = H * Fh;
+  dim3 grid((unsigned)((C + 63) / 64), (unsigned)nseg);
+  segment_wsum_kernel<<<grid, 256, 0, stream>>>(x, ldx, w, H, Fh, seg_ptr, rows, C, scale, out, ldo);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+int tsgnn_broadcast_add_f32(float* y, int64_t ldy, int64_t rows, int H, int Fh, const float* w, const float* a, int64_t lda,
+                            const float* u, int64_t ldu, int rows_per_seg, float scale, tsgnn_stream_t stream) {
+  if (!y || rows < 0 || H <= 0 || Fh <= 0 || ((a == nullptr) == (u == nullptr)) || (u && rows_per_seg <= 0)) return TSGNN_EINVAL;
+  if (rows == 0) return TSGNN_OK;
+  broadcast_add_kernel<<<(unsigned)ceil_div64(rows * H * Fh, 256), 256, 0, stream>>>(y, ldy, rows, H, Fh, w, a, lda, u, ldu,
+                                                                                    rows_per_seg, scale);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+int tsgnn_elu_heads_fwd_f32(const float* x, int64_t rows, int H, int Fh, int mean_heads, int apply_elu, float* y, tsgnn_stream_t stream) {
+  if (!x || !y || rows < 0 || H <= 0 || Fh <= 0) return TSGNN_EINVAL;
+  if (rows == 0) return TSGNN_OK;
+  const int Co = mean_heads ? Fh : H * Fh;
+  elu_heads_fwd_kernel<<<(unsigned)ceil_div64(rows * Co, 256), 256, 0, stream>>>(x, rows, H, Fh, mean_heads, apply_elu, y);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+int tsgnn_elu_heads_bwd_f32(const float* x, const float* dy, int64_t rows, int H, int Fh, int mean_heads, int apply_elu, float* dx,
+                            tsgnn_stream_t stream) {
+  if (!x || !dy || !dx || rows < 0 || H <= 0 || Fh <= 0) return TSGNN_EINVAL;
+  if (rows == 0) return TSGNN_OK;
+  elu_heads_bwd_kernel<<<(unsigned)ceil_div64(rows * H * Fh, 256), 256, 0, stream>>>(x, dy, rows, H, Fh, mean_heads, apply_elu, dx);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,157 @@
+"""Drop-in modules for the reference's dense GAT (Code/sage+gat+diffpool/encoders_GAT.py:11-209).
+
+Same class names / ctor signatures / parameter names (``w[Fin,Fout]``, ``a[2*Fout,1]``, heads registered as
+``attention_{i}``) so state_dicts interchange; the O(N^2 F) pair tensor and dense attention matrix are
+replaced by per-edge kernels (attention.py).  Bug-compatible with the reference where it is runnable:
+  * softmax over dim=1 = per source column (T3), all-masked columns uniform 1/N;
+  * ``input[0]``: every graph of a batch uses graph 0's features (T4) — meaningful at B=1 only;
+  * DGATLayer's ctor in the reference dies on an undefined name (encoders_GAT.py:65); the loop it guards
+    would re-initialise nothing, so it is simply omitted here.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import attention as att
+from . import message_passing as mp
+from .dense_encoders import GraphConv, _batch_from_dense, _default_device
+from .graph import GraphBatch
+
+
+def _padded_batch(adj):
+    return adj if isinstance(adj, GraphBatch) else _batch_from_dense(adj, None, "padded")
+
+
+def _rows_of_graph0(x, g):
+    """the reference uses input[0] for every graph (encoders_GAT.py:32): rows of graph 0, repeated."""
+    if x.dim() == 3:
+        x0 = x[0]
+    else:
+        x0 = x[: g.nmax]
+    return x0.contiguous().float()
+
+
+class DGATHead(nn.Module):
+    def __init__(self, input_dim, output_dim, add_self=False, dropout=0.0, neg_input_slope=0.2, concat=True):
+        super().__init__()
+        self.dropout = dropout
+        self.input_dim = input_dim
+        self.output_dim = output_dim
+        self.leakyRELU_neg_input_slope = neg_input_slope
+        self.concat = concat
+        dev = _default_device()
+        self.w = nn.Parameter(torch.zeros(input_dim, output_dim, device=dev))
+        nn.init.xavier_uniform_(self.w.data, gain=1.414)
+        self.a = nn.Parameter(torch.zeros(2 * output_dim, 1, device=dev))
+        nn.init.xavier_uniform_(self.a.data, gain=1.414)
+
+    def forward(self, input, adj):
+        return _gat_heads_forward([self], input, adj, concat_heads=True, elu=self.concat)
+
+
+def _gat_heads_forward(heads, x, adj, concat_heads, elu):
+    """all heads of a layer in one pass: h = x0 [W_0|W_1|...], one edge-softmax / aggregation launch set."""
+    g = _padded_batch(adj)
+    B, N = g.B, g.nmax
+    H = len(heads)
+    Fo = heads[0].output_dim
+    slope = heads[0].leakyRELU_neg_input_slope
+    x0 = _rows_of_graph0(x, g)                                             # [N, Fin]
+    W = torch.cat([hd.w for hd in heads], dim=1) if H > 1 else heads[0].w   # [Fin, H*Fo]
+    h = mp.linear_l2norm(x0, W, None, normalize=False)                      # [N, H*Fo]
+    if B > 1:
+        h = h.unsqueeze(0).expand(B, N, H * Fo).reshape(B * N, H * Fo)       # T4: graph 0's features everywhere
+    a_row = torch.stack([hd.a[:Fo, 0] for hd in heads])                     # a1 . h_i   (row index i)
+    a_col = torch.stack([hd.a[Fo:, 0] for hd in heads])                     # a2 . h_j   (column index j)
+    pre = att.attention_aggregate(h, a_row, a_col, g, H, slope, by_column=True, uniform_isolated=True)
+    p = heads[0].dropout
+    if p > 0 and heads[0].training:
+        raise NotImplementedError("attention dropout > 0 is not on the benchmarked path (reference default 0.0)")
+    out = att.elu_heads(pre, H, mean_heads=not concat_heads, apply_elu=elu)
+    return out.reshape(B, N, -1)
+
+
+class DGATLayer(nn.Module):
+    def __init__(self, input_dim, output_dim, dropout=0.0, neg_input_slope=0.2, n_heads=4, concat=True):
+        super().__init__()
+        self.dropout = dropout
+        self.concat = concat
+        self.n_heads = n_heads
+        self.attentions = [DGATHead(input_dim, output_dim, dropout=dropout, neg_input_slope=neg_input_slope,
+                                    concat=self.concat) for _ in range(n_heads)]
+        for i, attention in enumerate(self.attentions):
+            self.add_module("attention_{}".format(i), attention)
+
+    def forward(self, x, adj):
+        if self.dropout > 0 and self.training:
+            x = F.dropout(x, self.dropout, training=True)
+        # concat: per-head ELU then concatenation (:75); otherwise mean over heads then ELU (:78-83)
+        return _gat_heads_forward(self.attentions, x, adj, concat_heads=self.concat, elu=True)
+
+
+class DGATEncoderGraph(nn.Module):
+    def __init__(self, input_dim, hidden_dim, embedding_dim, label_dim, args, num_layers=2, num_heads=[2, 2],
+                 pred_hidden_dims=[], neg_input_slopes=[0.2, 0.2], dropouts=[0.0, 0.0], final_dim="output_dim", concat=True):
+        super().__init__()
+        self.dropout = dropouts
+        self.bias = True
+        self.num_layers = num_layers
+        self.num_aggs = 1
+        self.final_dim = final_dim
+        self.label_dim = label_dim
+        self.conv_first, self.conv_block, self.conv_last = self.build_conv_layers(
+            input_dim, hidden_dim, embedding_dim, num_layers, num_heads, neg_input_slopes, dropouts)
+        self.pred_input_dim = embedding_dim
+        self.pred_model = self.build_pred_layers(self.pred_input_dim, label_dim, num_aggs=self.num_aggs)
+        self.map_model = self.build_pred_layers(self.pred_input_dim, embedding_dim, num_aggs=self.num_aggs)
+        self.map2_model = torch.nn.Identity()
+        self.to(_default_device())
+
+    def build_conv_layers(self, input_dim, hidden_dim, embedding_dim, num_layers, num_heads, neg_input_slopes, dropouts):
+        conv_first = DGATLayer(input_dim=input_dim, output_dim=hidden_dim, n_heads=num_heads[0], dropout=dropouts[0], concat=True)
+        if num_layers >= 3:
+            conv_block = nn.ModuleList(
+                [DGATLayer(input_dim=hidden_dim * num_heads[i - 1], output_dim=hidden_dim, n_heads=num_heads[i],
+                           dropout=dropouts[i], concat=True) for i in range(1, num_layers - 1)])
+        else:
+            conv_block = None
+        conv_last = DGATLayer(input_dim=hidden_dim * num_heads[-1], output_dim=embedding_dim, n_heads=num_heads[-1],
+                              dropout=dropouts[-1], concat=False)
+        return conv_first, conv_block, conv_last
+
+    def build_assign_conv_layers(self, input_dim, hidden_dim, embedding_dim, num_layers, add_self, normalize=False, dropout=0.0):
+        conv_first = GraphConv(input_dim=input_dim, output_dim=hidden_dim, add_self=add_self, normalize_embedding=normalize)
+        conv_block = nn.ModuleList([GraphConv(input_dim=hidden_dim, output_dim=hidden_dim, add_self=add_self,
+                                              normalize_embedding=normalize, dropout=dropout) for _ in range(num_layers - 2)])
+        conv_last = GraphConv(input_dim=hidden_dim, output_dim=embedding_dim, add_self=add_self, normalize_embedding=normalize)
+        return conv_first, conv_block, conv_last
+
+    def build_pred_layers(self, pred_input_dim, label_dim, num_aggs=1):
+        return nn.Linear(pred_input_dim * num_aggs, label_dim)
+
+    def gcn_forward(self, x, adj, conv_first, conv_block, conv_last):
+        g = _padded_batch(adj)
+        x = conv_first(x, g)
+        if conv_block is not None:
+            for layer in conv_block:
+                x = layer(x, g)
+        return conv_last(x, g)
+
+    def forward(self, x, adj, batch_num_nodes=None, **kwargs):
+        g = _padded_batch(adj)
+        x = self.gcn_forward(x, g, self.conv_first, self.conv_block, self.conv_last)       # [B,N,E]
+        B, N, E = x.shape
+        x = mp.readout_max(x.reshape(B * N, E), g)                                          # max over ALL padded rows (:189)
+        if self.final_dim != "output_dim":
+            return x, self.map2_model(self.pred_model(x))
+        return x, self.map2_model(self.map_model(x))
+
+    def loss(self, pred, label, type="softmax"):
+        if type == "softmax":
+            return F.cross_entropy(pred, label, reduction="mean")
+        if type == "margin":
+            onehot = torch.zeros(pred.size(0), self.label_dim, dtype=torch.long, device=pred.device)
+            onehot.scatter_(1, label.view(-1, 1), 1)
+            return torch.nn.MultiLabelMarginLoss()(pred, onehot)
+        raise ValueError(type)

@@ -169,13 +169,7 @@ class GraphBatch:
         return g
 
     # ------------------------------------------------------------------ transpose (for dX = A^T dY)
-    def transposed(self, val="graph"):
-        """CSR of A^T (rowptr, col, val) for dX = A^T dY; ``val`` = per-entry weights aligned with
-        self.col (default: the graph's own)."""
-        if isinstance(val, str):
-            val = self.val
-        if self.symmetric:
-            return self.rowptr, self.col, val
+    def _ensure_transpose(self):
         if self._t is None:
             R1 = self.total_rows
             dev = self.device
@@ -184,12 +178,28 @@ class GraphBatch:
             val_t = torch.empty(max(self.nnz, 1), dtype=torch.float32, device=dev) if self.val is not None else None
             src_e = _i32(max(self.nnz, 1), dev)
             nat.call("csr_transpose", self.rowptr, self.col, self.val, R1, R1, self.nnz, rowptr_t, col_t, val_t,
-                     src_e, _i32(R1, dev), _scan_ws(R1, dev))
+                     src_e, _i32(max(R1, 1), dev), _scan_ws(R1, dev))
             self._t = (rowptr_t, col_t, val_t)
             self.src_e_t = src_e
+        return self._t
+
+    def transpose_map(self):
+        """explicit CSR of A^T plus src_e_t[p] = entry of A that transposed entry p came from
+        (always computed, even for symmetric graphs: edge-softmax needs the entry pairing)."""
+        rp, col, _ = self._ensure_transpose()
+        return rp, col, self.src_e_t
+
+    def transposed(self, val="graph"):
+        """CSR of A^T (rowptr, col, val) for dX = A^T dY; ``val`` = per-entry weights aligned with
+        self.col (default: the graph's own).  Symmetric graphs (with symmetric weights) reuse A."""
+        if isinstance(val, str):
+            val = self.val
+        if self.symmetric:
+            return self.rowptr, self.col, val
+        t = self._ensure_transpose()
         if val is self.val:
-            return self._t
-        return self._t[0], self._t[1], (val[self.src_e_t.long()] if val is not None else None)
+            return t
+        return t[0], t[1], (val[self.src_e_t.long()] if val is not None else None)
 
     # ------------------------------------------------------------------ feature (un)packing helpers
     def new_features(self, feat, zero=False):
