@@ -175,10 +175,10 @@ int tsgnn_csr_spmm_heads_f32(const int* rowptr, const int* col, const float* alp
 /* dalpha[e,h] = <dy[row(e), head h], x[col[e], head h]>  (sampled dense-dense product) */
 int tsgnn_csr_sddmm_heads_f32(const int* rowptr, const int* col, int H, int Fh, const float* dy, int64_t lddy, const float* x,
                               int64_t ldx, int mod, float* dalpha, int64_t rows, tsgnn_stream_t stream);
-/* out[s,c] = scale * sum_{r in segment s} w[r, c/Fh] * x[r,c]  (w NULL = 1; seg_ptr NULL = one segment of `rows`).
- * Also PyG global_mean_pool / global_add_pool (Code/sag/network.py:36). */
+/* out[s,c] = scale * sum_{r in segment s} w[r, c/Fh] * x[r,c]  (w NULL = 1; seg_ptr NULL = one segment of `rows`;
+ * mean != 0 divides by the segment length).  Also PyG global_mean_pool (Code/sag/network.py:36). */
 int tsgnn_segment_wsum_f32(const float* x, int64_t ldx, const float* w, int H, int Fh, const int* seg_ptr, int nseg, int64_t rows,
-                           float scale, float* out, int64_t ldo, tsgnn_stream_t stream);
+                           float scale, int mean, float* out, int64_t ldo, tsgnn_stream_t stream);
 /* y[r,c] += scale * w[r,c/Fh] * (a ? a[(c/Fh)*lda + c%Fh] : u[(r / rows_per_seg)*ldu + c])   (w NULL = 1) */
 int tsgnn_broadcast_add_f32(float* y, int64_t ldy, int64_t rows, int H, int Fh, const float* w, const float* a, int64_t lda,
                             const float* u, int64_t ldu, int rows_per_seg, float scale, tsgnn_stream_t stream);
@@ -186,6 +186,32 @@ int tsgnn_broadcast_add_f32(float* y, int64_t ldy, int64_t rows, int H, int Fh, 
 int tsgnn_elu_heads_fwd_f32(const float* x, int64_t rows, int H, int Fh, int mean_heads, int apply_elu, float* y, tsgnn_stream_t stream);
 int tsgnn_elu_heads_bwd_f32(const float* x, const float* dy, int64_t rows, int H, int Fh, int mean_heads, int apply_elu, float* dx,
                             tsgnn_stream_t stream);
+
+/* ---------------------------------------------------------------- SAGPool path (pooling.hip) */
+
+/* PyG topk(score, ratio, batch) (call site Code/sag/layers.py:20): for every graph b keep its
+ * k_b = k_ptr[b+1]-k_ptr[b] highest-scoring nodes, descending; ties -> smaller node id.
+ * perm[k_ptr[b] + t] = global node id.  Graphs of more than tsgnn_topk_max_segment() nodes are unsupported. */
+int tsgnn_topk_max_segment(void);
+int tsgnn_topk_segments_f32(const float* score, const int* graph_ptr, const int* k_ptr, int B, int max_seg, int* perm,
+                            tsgnn_stream_t stream);
+/* out[p,:] = x[perm[p],:] * tanh(score[perm[p]])  (Code/sag/layers.py:21); use_tanh = 0: gate = score */
+int tsgnn_gather_gate_fwd_f32(const float* x, int64_t ldx, const float* score, const int* perm, int64_t K, int F, int use_tanh,
+                              float* out, int64_t ldo, tsgnn_stream_t stream);
+int tsgnn_gather_gate_bwd_f32(const float* x, int64_t ldx, const float* score, const int* perm, int64_t K, int F, int use_tanh,
+                              const float* dout, int64_t ldo, float* dx, int64_t lddx, float* dscore, tsgnn_stream_t stream);
+/* PyG filter_adj (Code/sag/layers.py:23-24): relabel by perm, keep edges with both ends kept, original order.
+ * mark -> (caller: exclusive scan of flag -> pos) -> compact. edge ids int64 as in PyG's edge_index. */
+int tsgnn_filter_edges_mark(const int* perm, int64_t K, int64_t N, const int64_t* src, const int64_t* dst, int64_t E,
+                            int* new_id, int* flag, tsgnn_stream_t stream);
+int tsgnn_filter_edges_compact(const int64_t* src, const int64_t* dst, int64_t E, const int* new_id, const int* flag,
+                               const int* pos, int64_t* out_src, int64_t* out_dst, int64_t* kept_eid, tsgnn_stream_t stream);
+int tsgnn_relu_fwd_f32(const float* x, int64_t n, float* y, tsgnn_stream_t stream);
+int tsgnn_relu_bwd_f32(const float* y, const float* dy, int64_t n, float* dx, tsgnn_stream_t stream);
+/* nn.Softmax(dim=-1) over the assignment logits (encoders.py:369) */
+int tsgnn_row_softmax_fwd_f32(const float* x, int64_t ldx, int64_t rows, int C, float* y, int64_t ldy, tsgnn_stream_t stream);
+int tsgnn_row_softmax_bwd_f32(const float* y, int64_t ldy, const float* dy, int64_t lddy, int64_t rows, int C, float* dx,
+                              int64_t lddx, tsgnn_stream_t stream);
 
 #ifdef __cplusplus
 }

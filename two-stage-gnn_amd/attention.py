@@ -21,9 +21,10 @@ def node_scores(h, a, H, Fh):
     return s
 
 
-def segment_wsum(x, w, H, Fh, seg_ptr, nseg, scale=1.0):
+def segment_wsum(x, w, H, Fh, seg_ptr, nseg, scale=1.0, mean=False):
     out = _f32(nseg, H * Fh, device=x.device)
-    nat.call("segment_wsum_f32", x, x.stride(0), w, H, Fh, seg_ptr, nseg, x.size(0), float(scale), out, out.stride(0))
+    nat.call("segment_wsum_f32", x, x.stride(0), w, H, Fh, seg_ptr, nseg, x.size(0), float(scale), int(mean), out,
+             out.stride(0))
     return out
 
 

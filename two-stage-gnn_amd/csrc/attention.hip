@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void sddmm_heads_kernel(const int* __restrict_
 // block per (64-column strip, segment): 4 waves stride over the segment's rows, LDS combine (fixed order).
 __global__ __launch_bounds__(256) void segment_wsum_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ w, int H,
                                                            int Fh, const int* __restrict__ seg_ptr, int64_t rows_if_one, int C,
-                                                           float scale, float* __restrict__ out, int64_t ldo) {
+                                                           float scale, int mean, float* __restrict__ out, int64_t ldo) {
   __shared__ float lds[4][64];
   const int s = blockIdx.y;
   const int64_t r0 = seg_ptr ? seg_ptr[s] : 0, r1 = seg_ptr ? seg_ptr[s + 1] : rows_if_one;
@@ -170,7 +170,11 @@ __global__ __launch_bounds__(256) void segment_wsum_kernel(const float* __restri
   }
   lds[rl][threadIdx.x & 63] = acc;
   __syncthreads();
-  if (rl == 0 && c < C) out[(int64_t)s * ldo + c] = scale * (lds[0][threadIdx.x] + lds[1][threadIdx.x] + lds[2][threadIdx.x] + lds[3][threadIdx.x]);
+  if (rl == 0 && c < C) {
+    float sc = scale;
+    if (mean) sc = (r1 > r0) ? scale / (float)(r1 - r0) : 0.f;
+    out[(int64_t)s * ldo + c] = sc * (lds[0][threadIdx.x] + lds[1][threadIdx.x] + lds[2][threadIdx.x] + lds[3][threadIdx.x]);
+  }
 }
 
 // y[r, c] (+)= alpha * w[r, c/Fh] * v[seg(r)?, c] ... generic rank-1 style broadcast add:
@@ -298,12 +302,12 @@ int tsgnn_csr_sddmm_heads_f32(const int* rowptr, const int* col, int H, int Fh, 
 }
 
 int tsgnn_segment_wsum_f32(const float* x, int64_t ldx, const float* w, int H, int Fh, const int* seg_ptr, int nseg, int64_t rows,
-                           float scale, float* out, int64_t ldo, tsgnn_stream_t stream) {
+                           float scale, int mean, float* out, int64_t ldo, tsgnn_stream_t stream) {
   if (!x || !out || H <= 0 || Fh <= 0 || nseg <= 0 || rows < 0 || ldx < (int64_t)H * Fh || ldo < (int64_t)H * Fh) return TSGNN_EINVAL;
   if (!seg_ptr && nseg != 1) return TSGNN_EINVAL;
   const int C = H * Fh;
   dim3 grid((unsigned)((C + 63) / 64), (unsigned)nseg);
-  segment_wsum_kernel<<<grid, 256, 0, stream>>>(x, ldx, w, H, Fh, seg_ptr, rows, C, scale, out, ldo);
+  segment_wsum_kernel<<<grid, 256, 0, stream>>>(x, ldx, w, H, Fh, seg_ptr, rows, C, scale, mean, out, ldo);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }

@@ -259,3 +259,116 @@ class GcnEncoderGraph(nn.Module):
             onehot.scatter_(1, label.view(-1, 1), 1)
             return torch.nn.MultiLabelMarginLoss()(pred, onehot)
         raise ValueError(type)
+
+
+class SoftPoolingGcnEncoder(GcnEncoderGraph):
+    """Drop-in for encoders.py:236-441 (DiffPool).  Level 0 runs on the CSR rows of the input graphs; the
+    assignment contraction X' = S^T Z, A' = S^T A S (encoders.py:374-375) is SpMM + ragged batched fp32-MFMA
+    GEMMs; pooled levels (dense, differentiable adjacency) use strided batched MFMA GEMMs."""
+
+    def __init__(self, max_num_nodes, input_dim, hidden_dim, embedding_dim, label_dim, num_layers, assign_hidden_dim,
+                 assign_ratio=0.25, assign_num_layers=-1, num_pooling=1, pred_hidden_dims=[], concat=True, bn=True,
+                 dropout=0.0, linkpred=True, assign_input_dim=-1, args=None, final_dim="output_dim"):
+        # the reference forwards neither bn nor dropout to the base ctor (encoders.py:249-250): bn stays True
+        super().__init__(input_dim, hidden_dim, embedding_dim, label_dim, num_layers, pred_hidden_dims=pred_hidden_dims,
+                         concat=concat, args=args)
+        add_self = not concat
+        self.num_pooling = num_pooling
+        self.linkpred = linkpred
+        self.assign_ent = True
+        self.final_dim = final_dim
+        self.conv_first_after_pool = nn.ModuleList()
+        self.conv_block_after_pool = nn.ModuleList()
+        self.conv_last_after_pool = nn.ModuleList()
+        for _ in range(num_pooling):
+            c1, cb, cl = self.build_conv_layers(self.pred_input_dim, hidden_dim, embedding_dim, num_layers, add_self,
+                                                normalize=True, dropout=dropout)
+            self.conv_first_after_pool.append(c1)
+            self.conv_block_after_pool.append(cb)
+            self.conv_last_after_pool.append(cl)
+        if assign_num_layers == -1:
+            assign_num_layers = num_layers
+        if assign_input_dim == -1:
+            assign_input_dim = input_dim
+        self.assign_conv_first_modules = nn.ModuleList()
+        self.assign_conv_block_modules = nn.ModuleList()
+        self.assign_conv_last_modules = nn.ModuleList()
+        self.assign_pred_modules = nn.ModuleList()
+        assign_dim = int(max_num_nodes * assign_ratio)
+        for _ in range(num_pooling):
+            a1, ab, al = self.build_conv_layers(assign_input_dim, assign_hidden_dim, assign_dim, assign_num_layers, add_self,
+                                                normalize=True)
+            assign_pred_input_dim = assign_hidden_dim * (num_layers - 1) + assign_dim if concat else assign_dim
+            self.assign_pred_modules.append(self.build_pred_layers(assign_pred_input_dim, [], assign_dim, num_aggs=1))
+            assign_input_dim = self.pred_input_dim
+            assign_dim = int(assign_dim * assign_ratio)
+            self.assign_conv_first_modules.append(a1)
+            self.assign_conv_block_modules.append(ab)
+            self.assign_conv_last_modules.append(al)
+        self.pre_pred_model = self.build_pred_layers(self.pred_input_dim * (num_pooling + 1), pred_hidden_dims, embedding_dim,
+                                                     num_aggs=self.num_aggs)
+        self.pred_model = self.build_pred_layers(embedding_dim, pred_hidden_dims, label_dim, num_aggs=self.num_aggs)
+        self.map_model = self.build_pred_layers(self.pred_input_dim * (num_pooling + 1), pred_hidden_dims, embedding_dim,
+                                                num_aggs=self.num_aggs)
+        self.map2_model = self.build_pred_layers(pred_input_dim=embedding_dim, pred_hidden_dims=[], label_dim=2)
+        self._init_convs()
+        self.to(_default_device())
+
+    # gcn_forward on dense pooled tensors x[B,K,F], adj[B,K,K] (encoders.py:378-380; mask is None there)
+    def gcn_forward_dense(self, x, adj, conv_first, conv_block, conv_last):
+        B, K, _ = x.shape
+        g = GraphBatch.structure_only(np.full(B, K, dtype=np.int64), K, x.device, ghosts=False)
+
+        def post(v):
+            return mp.bn_slots(v.reshape(B * K, -1), g, relu=True, bn=self.bn).reshape(B, K, -1)
+        x = post(conv_first(x, adj))
+        x_all = [x]
+        for conv in conv_block:
+            x = post(conv(x, adj))
+            x_all.append(x)
+        x_all.append(conv_last(x, adj))
+        return torch.cat(x_all, dim=2), g
+
+    def forward(self, x, adj, batch_num_nodes, **kwargs):
+        from . import diffpool as dp
+        from .pyg import linear
+        x_a = kwargs["assign_x"] if "assign_x" in kwargs else x
+        same_input = x_a is x
+        masked = batch_num_nodes is not None
+        x, g = self.make_batch(x, adj, batch_num_nodes)             # packed rows (+ghost reps) if masked, else padded
+        x_a = x if same_input else (mp.pack_rows(x_a, g, (x_a.size(2) + 3) // 4 * 4 if g.layout == "packed" else None)
+                                    if x_a.dim() == 3 else x_a)
+        emb = self.gcn_forward_rows(x, g, self.conv_first, self.conv_block, self.conv_last, mask_ghost=masked)
+        out_all = [mp.readout_max(emb, g)]
+        dense_x = dense_adj = None
+        for i in range(self.num_pooling):
+            lin = self.assign_pred_modules[i]
+            if i == 0:
+                a = self.gcn_forward_rows(x_a, g, self.assign_conv_first_modules[0], self.assign_conv_block_modules[0],
+                                          self.assign_conv_last_modules[0], mask_ghost=masked)
+                s = dp.row_softmax(linear(a, lin.weight.t(), lin.bias))                       # encoders.py:369
+                if masked:
+                    s = mp.mask_ghost_rows(s, g)                                              # :371
+                self.assign_tensor = s
+                dense_x, dense_adj = dp.diffpool_contract_rows(s, emb, g)                     # :374-375
+            else:
+                a, _ = self.gcn_forward_dense(dense_x, dense_adj, self.assign_conv_first_modules[i],
+                                              self.assign_conv_block_modules[i], self.assign_conv_last_modules[i])
+                Bq, Kq, Cq = a.shape
+                s = dp.row_softmax(linear(a.reshape(Bq * Kq, Cq), lin.weight.t(), lin.bias)).reshape(Bq, Kq, -1)
+                self.assign_tensor = s
+                dense_x, dense_adj = dp.diffpool_contract_dense(s, emb_dense, dense_adj)
+            emb_dense, gd = self.gcn_forward_dense(dense_x, dense_adj, self.conv_first_after_pool[i],
+                                                   self.conv_block_after_pool[i], self.conv_last_after_pool[i])
+            Bq, Kq, Cq = emb_dense.shape
+            out_all.append(mp.readout_max(emb_dense.reshape(Bq * Kq, Cq), gd))
+            dense_x = dense_x  # x_a = x for the next level (encoders.py:376)
+        output = torch.cat(out_all, dim=1) if self.concat else out_all[-1]
+        return self._heads(output)
+
+    def loss(self, pred, label, adj=None, batch_num_nodes=None, adj_hop=1):
+        loss = super().loss(pred, label)
+        if self.linkpred:
+            raise NotImplementedError("link-prediction side loss (encoders.py:416-440) is a 'next' row (SURVEY §8 f4); "
+                                      "the reference default is linkpred=False (train.py:472)")
+        return loss

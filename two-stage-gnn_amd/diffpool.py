@@ -1,0 +1,136 @@
+"""DiffPool assignment softmax and the S^T.Z / S^T.A.S contractions (encoders.py:365-376) on
+fp32 MFMA (v_mfma_f32_32x32x2_f32 via tsgnn_gemm_f32), forward and explicit backward.
+
+Level-1 contraction works on the ROWS of a GraphBatch: A is sparse there (99.5 % zeros on DD), so
+A.S is one SpMM and both S^T.(.) products are ragged batched GEMMs over each graph's row range — the
+reference's dense [B,N,N] @ [B,N,K] bmm is never formed.  Pooled levels (adjacency already dense and small)
+use strided batched GEMMs.
+"""
+import torch
+
+from . import _native as nat
+from . import message_passing as mp
+
+
+def _f32(*shape, device, zero=False):
+    return (torch.zeros if zero else torch.empty)(*shape, dtype=torch.float32, device=device)
+
+
+class _RowSoftmax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        nat.call("row_softmax_fwd_f32", x, x.stride(0), x.size(0), x.size(1), y, y.stride(0))
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(y)
+        nat.call("row_softmax_bwd_f32", y, y.stride(0), dy, dy.stride(0), y.size(0), y.size(1), dx, dx.stride(0))
+        return dx
+
+
+def row_softmax(x2d):
+    """nn.Softmax(dim=-1) of a [rows, K] matrix (encoders.py:369)."""
+    return _RowSoftmax.apply(x2d)
+
+
+# ----------------------------------------------------------------------------- strided batched matmul
+def _bmm_raw(a, b, ta, tb):
+    """c[z] = op(a[z]) @ op(b[z]) for contiguous 3-D a, b."""
+    B = a.size(0)
+    M, K = (a.size(2), a.size(1)) if ta else (a.size(1), a.size(2))
+    N = b.size(1) if tb else b.size(2)
+    c = _f32(B, M, N, device=a.device)
+    sam, sak = (1, a.size(2)) if ta else (a.size(2), 1)
+    sbk, sbn = (1, b.size(2)) if tb else (b.size(2), 1)
+    mp.gemm(a, sam, sak, b, sbk, sbn, c, N, 1, M, N, K, batch=B, stride_a=a.size(1) * a.size(2),
+            stride_b=b.size(1) * b.size(2), stride_c=M * N)
+    return c
+
+
+class _Bmm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, ta, tb):
+        a, b = a.contiguous(), b.contiguous()
+        ctx.save_for_backward(a, b)
+        ctx.t = (ta, tb)
+        return _bmm_raw(a, b, ta, tb)
+
+    @staticmethod
+    def backward(ctx, dc):
+        a, b = ctx.saved_tensors
+        ta, tb = ctx.t
+        dc = dc.contiguous()
+        da = db = None
+        if ctx.needs_input_grad[0]:
+            # C = op(A) op(B):  d op(A) = dC op(B)^T ; dA = (d op(A))^T if ta
+            da = _bmm_raw(b, dc, tb, True) if ta else _bmm_raw(dc, b, False, not tb)
+        if ctx.needs_input_grad[1]:
+            db = _bmm_raw(dc, a, True, ta) if tb else _bmm_raw(a, dc, not ta, False)
+        return da, db, None, None
+
+
+def bmm(a, b, trans_a=False, trans_b=False):
+    return _Bmm.apply(a, b, bool(trans_a), bool(trans_b))
+
+
+def diffpool_contract_dense(s, z, adj):
+    """encoders.py:374-375 on dense [B,N,*] tensors: (S^T Z, S^T A S)."""
+    return bmm(s, z, trans_a=True), bmm(bmm(s, adj, trans_a=True), s)
+
+
+# ----------------------------------------------------------------------------- ragged (row-layout) contraction
+def _ragged_tn(S, X, g):
+    """out[b] = S[rows_b]^T @ X[rows_b]  -> [B, K, F]   (K-ragged batched GEMM)."""
+    K, F = S.size(1), X.size(1)
+    out = _f32(g.B, K, F, device=S.device)
+    mp.gemm(S, 1, S.stride(0), X, X.stride(0), 1, out, F, 1, K, F, 0, batch=g.B, stride_c=K * F, seg_ptr=g.graph_ptr,
+            ragged=1, max_seg=int(g.sizes.max()))
+    return out
+
+
+def _ragged_nn(X, Y, g, trans_y, out_cols, rows):
+    """out[rows_b] = X[rows_b] @ op(Y[b])   (M-ragged batched GEMM); rows outside every graph stay zero."""
+    Kd = X.size(1)
+    out = _f32(rows, out_cols, device=X.device, zero=True)
+    sbk, sbn = (1, Y.size(2)) if trans_y else (Y.size(2), 1)
+    mp.gemm(X, X.stride(0), 1, Y, sbk, sbn, out, out.stride(0), 1, 0, out_cols, Kd, batch=g.B,
+            stride_b=Y.size(1) * Y.size(2), seg_ptr=g.graph_ptr, ragged=2, max_seg=int(g.sizes.max()))
+    return out
+
+
+class _ContractRows(torch.autograd.Function):
+    """X'[b] = S_b^T Z_b ;  A'[b] = S_b^T (A S)_b   over the real rows of every graph."""
+
+    @staticmethod
+    def forward(ctx, S, Z, g):
+        S, Z = S.contiguous(), Z.contiguous()
+        AS = mp.spmm_raw(g.rowptr, g.col, g.val, S, g.total_rows)
+        xo = _ragged_tn(S, Z, g)
+        ao = _ragged_tn(S, AS, g)
+        ctx.g = g
+        ctx.save_for_backward(S, Z, AS)
+        return xo, ao
+
+    @staticmethod
+    def backward(ctx, dxo, dao):
+        S, Z, AS = ctx.saved_tensors
+        g = ctx.g
+        dxo, dao = dxo.contiguous(), dao.contiguous()
+        R, K, F = S.size(0), S.size(1), Z.size(1)
+        dZ = _ragged_nn(S, dxo, g, False, F, R)                     # dZ_b = S_b dX'_b
+        dS = _ragged_nn(Z, dxo, g, True, K, R)                      # S^T Z     : dS_b  = Z_b dX'_b^T
+        dS = dS + _ragged_nn(AS, dao, g, True, K, R)                # S^T (AS)  : dS_b += (AS)_b dA'_b^T
+        dAS = _ragged_nn(S, dao, g, False, K, R)                    #             d(AS)_b = S_b dA'_b
+        rp, col, val = g.transposed()
+        dS = dS + mp.spmm_raw(rp, col, val, dAS, g.total_rows)      # AS = A S  : dS += A^T d(AS)
+        return dS, dZ, None
+
+
+def diffpool_contract_rows(S, Z, g):
+    return _ContractRows.apply(S, Z, g)

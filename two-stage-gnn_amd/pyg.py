@@ -1,0 +1,381 @@
+"""torch_geometric-named operators on the hot path, backed by the HIP kernels.
+
+(A) what Code/sag actually calls: ``GCNConv``, ``topk``, ``filter_adj``, ``global_max_pool``,
+    ``global_mean_pool`` (Code/sag/network.py:2-4, layers.py:1-2) — signatures, parameter names
+    (``weight[in,out]``, ``bias``; PyG 1.6.x layout) and return conventions preserved;
+(B) the operators BASELINE.json's north_star names: ``SAGEConv``, ``GATConv``, ``SAGPooling``,
+    ``dense_diff_pool`` (plus PyG's ``GraphConv``, SAGPooling's default scorer).
+Inputs are PyG's: ``x[N,F]`` fp32, ``edge_index[2,E]`` int64 (row 0 = source, row 1 = target), ``batch[N]``.
+The COO list is converted to CSR (grouped by target) on the GPU once per distinct edge_index tensor.
+"""
+import math
+import weakref
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _native as nat
+from . import attention as att
+from . import message_passing as mp
+from .graph import GraphBatch, exclusive_scan
+
+
+def _default_device():
+    return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+
+
+def _f32(*shape, device, zero=False):
+    return (torch.zeros if zero else torch.empty)(*shape, dtype=torch.float32, device=device)
+
+
+_graph_cache = {}
+
+
+def graph_of(edge_index, num_nodes):
+    """CSR (rows = targets) of a PyG edge list, cached per edge_index tensor."""
+    if not edge_index.is_cuda:
+        raise RuntimeError("two_stage_gnn_amd operators run on the GPU only (no CPU fallback)")
+    key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, int(num_nodes))
+    hit = _graph_cache.get(key)
+    if hit is not None and hit[0]() is edge_index:
+        return hit[1]
+    g = GraphBatch.from_edge_index(edge_index, num_nodes, ghosts=False)
+    if len(_graph_cache) > 16:
+        _graph_cache.clear()
+    _graph_cache[key] = (weakref.ref(edge_index), g)
+    return g
+
+
+def _segments(batch, num_nodes, device):
+    """batch[N] (sorted graph ids, PyG convention) -> (sizes np.int64[B], graph_ptr int32[B+1] on device)."""
+    if batch is None:
+        sizes = np.array([num_nodes], dtype=np.int64)
+    else:
+        sizes = torch.bincount(batch).cpu().numpy().astype(np.int64)
+    gp = np.zeros(len(sizes) + 1, dtype=np.int32)
+    np.cumsum(sizes, out=gp[1:])
+    return sizes, torch.from_numpy(gp).to(device)
+
+
+# ----------------------------------------------------------------------------- small element-wise ops
+class _Relu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        nat.call("relu_fwd_f32", x, x.numel(), y)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dx = torch.empty_like(y)
+        nat.call("relu_bwd_f32", y, dy.contiguous(), y.numel(), dx)
+        return dx
+
+
+def relu(x):
+    return _Relu.apply(x)
+
+
+class _BiasAdd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, bias):
+        y = x.clone()
+        nat.call("broadcast_add_f32", y, y.stride(0), y.size(0), 1, y.size(1), None, bias, bias.numel(), None, 0, 0, 1.0)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        return dy, mp.colsum(dy)
+
+
+def bias_add(x, bias):
+    return x if bias is None else _BiasAdd.apply(x, bias)
+
+
+def linear(x, weight_in_out, bias=None):
+    """x @ W (+ b) with W stored [in, out] — the fp32 MFMA kernel."""
+    return mp.linear_l2norm(x, weight_in_out, bias, normalize=False)
+
+
+# ----------------------------------------------------------------------------- GCNConv (a11)
+def _gcn_norm(g):
+    cache = getattr(g, "_gcn", None)
+    if cache is None:
+        R = g.total_rows
+        dinv = _f32(R, device=g.device)
+        val = _f32(max(g.nnz, 1), device=g.device)
+        self_w = _f32(R, device=g.device)
+        nat.call("gcn_norm_f32", g.rowptr, g.col, g.val, R, 1.0, dinv, val, self_w)
+        cache = g._gcn = (val, self_w)
+    return cache
+
+
+class GCNConv(nn.Module):
+    """out = D^-1/2 (A+I) D^-1/2 (x W) + b — PyG GCNConv as called at Code/sag/network.py:19-23, layers.py:12."""
+
+    def __init__(self, in_channels, out_channels, improved=False, cached=False, bias=True, **kwargs):
+        super().__init__()
+        if improved:
+            raise NotImplementedError("improved=True is not used by the reference")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        dev = _default_device()
+        self.weight = nn.Parameter(torch.empty(in_channels, out_channels, device=dev))
+        self.bias = nn.Parameter(torch.empty(out_channels, device=dev)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        stdv = math.sqrt(6.0 / (self.weight.size(0) + self.weight.size(1)))        # PyG glorot
+        self.weight.data.uniform_(-stdv, stdv)
+        if self.bias is not None:
+            self.bias.data.zero_()
+
+    def forward(self, x, edge_index, edge_weight=None):
+        if edge_weight is not None:
+            raise NotImplementedError("edge_weight is never passed by the reference (network.py:34)")
+        g = edge_index if isinstance(edge_index, GraphBatch) else graph_of(edge_index, x.size(0))
+        val, self_w = _gcn_norm(g)
+        xw = linear(x, self.weight)
+        return bias_add(mp.aggregate(xw, g, val=val, self_w=self_w), self.bias)
+
+
+# ----------------------------------------------------------------------------- topk / filter_adj (a12, a13)
+def topk(x, ratio, batch, min_score=None):
+    """PyG topk (layers.py:20): per graph the ceil(ratio*n) best nodes, descending.  Returns int64 perm."""
+    if min_score is not None:
+        raise NotImplementedError("min_score is not used by the reference")
+    score = x.contiguous().float().view(-1)
+    N = score.numel()
+    sizes, gp = _segments(batch, N, score.device)
+    k = np.ceil(np.float32(ratio) * sizes.astype(np.float32)).astype(np.int64)      # float32, as PyG computes it
+    k = np.minimum(k, sizes)
+    kp = np.zeros(len(k) + 1, dtype=np.int32)
+    np.cumsum(k, out=kp[1:])
+    perm = torch.empty(max(int(kp[-1]), 1), dtype=torch.int32, device=score.device)
+    nat.call("topk_segments_f32", score, gp, torch.from_numpy(kp).to(score.device), len(sizes), int(sizes.max()), perm)
+    return perm[: int(kp[-1])].long()
+
+
+def filter_adj(edge_index, edge_attr, perm, num_nodes=None):
+    """PyG filter_adj (layers.py:23-24): relabel nodes by perm, drop edges that lost an end."""
+    N = int(num_nodes) if num_nodes is not None else int(edge_index.max().item()) + 1
+    dev = edge_index.device
+    ei = edge_index.contiguous()
+    E = int(ei.size(1))
+    p32 = perm.to(torch.int32).contiguous()
+    new_id = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
+    flag = torch.zeros(max(E, 1), dtype=torch.int32, device=dev)
+    nat.call("filter_edges_mark", p32, p32.numel(), N, ei[0], ei[1], E, new_id, flag)
+    pos = exclusive_scan(flag[:E] if E else flag[:0])
+    E2 = int(pos[-1].item())
+    out = torch.empty(2, E2, dtype=torch.int64, device=dev)
+    kept = torch.empty(max(E2, 1), dtype=torch.int64, device=dev)
+    nat.call("filter_edges_compact", ei[0], ei[1], E, new_id, flag, pos, out[0], out[1], kept)
+    if edge_attr is not None:
+        edge_attr = edge_attr[kept[:E2]]
+    return out, edge_attr
+
+
+# ----------------------------------------------------------------------------- readouts (a14)
+class _SegmentMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gp, B):
+        x = x.contiguous()
+        ctx.save_for_backward(gp)
+        ctx.shape = x.shape
+        return att.segment_wsum(x, None, 1, x.size(1), gp, B, mean=True)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (gp,) = ctx.saved_tensors
+        R, F = ctx.shape
+        dx = _f32(R, F, device=dout.device, zero=True)
+        sizes = (gp[1:] - gp[:-1]).to(torch.float32).clamp(min=1).unsqueeze(1)
+        scaled = (dout / sizes).contiguous()
+        # dx[r,:] += dout[seg(r),:] / n_seg : ragged broadcast through the row->graph map
+        rows = torch.repeat_interleave(torch.arange(gp.numel() - 1, device=gp.device), (gp[1:] - gp[:-1]).long())
+        dx = scaled[rows]
+        return dx, None, None
+
+
+def _pool_struct(x, batch, size):
+    sizes, gp = _segments(batch, x.size(0), x.device)
+    B = len(sizes) if size is None else int(size)
+    return sizes, gp, B
+
+
+def global_mean_pool(x, batch, size=None):
+    sizes, gp, B = _pool_struct(x, batch, size)
+    return _SegmentMean.apply(x, gp, B)
+
+
+def global_max_pool(x, batch, size=None):
+    sizes, gp, B = _pool_struct(x, batch, size)
+    g = GraphBatch.structure_only(sizes, int(max(1, sizes.max())), x.device, ghosts=False)
+    return mp.readout_max(x, g)
+
+
+# ----------------------------------------------------------------------------- gated gather of the kept nodes
+class _GatherGate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, score, perm32, use_tanh):
+        x = x.contiguous()
+        score = score.contiguous()
+        K, F = perm32.numel(), x.size(1)
+        out = _f32(K, F, device=x.device)
+        nat.call("gather_gate_fwd_f32", x, x.stride(0), score, perm32, K, F, int(use_tanh), out, out.stride(0))
+        ctx.save_for_backward(x, score, perm32)
+        ctx.use_tanh = use_tanh
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, score, perm32 = ctx.saved_tensors
+        dout = dout.contiguous()
+        K, F = perm32.numel(), x.size(1)
+        dx = torch.zeros_like(x)
+        ds = torch.zeros_like(score)
+        nat.call("gather_gate_bwd_f32", x, x.stride(0), score, perm32, K, F, int(ctx.use_tanh), dout, dout.stride(0), dx,
+                 dx.stride(0), ds)
+        return dx, ds, None, None
+
+
+def gather_gate(x, score, perm, use_tanh=True):
+    """x[perm] * tanh(score[perm]).view(-1,1)  (Code/sag/layers.py:21) as one kernel."""
+    return _GatherGate.apply(x, score, perm.to(torch.int32).contiguous(), bool(use_tanh))
+
+
+# ----------------------------------------------------------------------------- north_star-named operators (a15)
+class _MeanAggregate(torch.autograd.Function):
+    """mean_{j in N(i)} x_j with the 1/deg weights generated on the fly as per-entry CSR values."""
+
+    @staticmethod
+    def forward(ctx, x, g):
+        deg = (g.rowptr[1:] - g.rowptr[:-1]).clamp(min=1).to(torch.float32)
+        w = torch.repeat_interleave(1.0 / deg, (g.rowptr[1:] - g.rowptr[:-1]).long())
+        if w.numel() == 0:
+            w = _f32(1, device=x.device)
+        ctx.g, ctx.w = g, w
+        return mp.spmm_raw(g.rowptr, g.col, w, x.contiguous(), g.total_rows)
+
+    @staticmethod
+    def backward(ctx, dy):
+        g = ctx.g
+        rp, col, wt = g.transposed(ctx.w)
+        return mp.spmm_raw(rp, col, wt, dy.contiguous(), g.total_rows), None
+
+
+class SAGEConv(nn.Module):
+    """PyG SAGEConv (mean aggregator): lin_l(mean_j x_j) + lin_r(x_i).  No call site in the reference."""
+
+    def __init__(self, in_channels, out_channels, normalize=False, bias=True, **kwargs):
+        super().__init__()
+        self.normalize = normalize
+        dev = _default_device()
+        self.lin_l = nn.Linear(in_channels, out_channels, bias=bias).to(dev)
+        self.lin_r = nn.Linear(in_channels, out_channels, bias=False).to(dev)
+
+    def forward(self, x, edge_index):
+        g = edge_index if isinstance(edge_index, GraphBatch) else graph_of(edge_index, x.size(0))
+        agg = _MeanAggregate.apply(x, g)
+        out = linear(agg, self.lin_l.weight.t(), self.lin_l.bias) + linear(x, self.lin_r.weight.t())
+        if self.normalize:
+            out = mp.linear_l2norm(out, torch.eye(out.size(1), device=out.device), None, normalize=True)
+        return out
+
+
+class GraphConv(nn.Module):
+    """PyG GraphConv: lin_l(sum_j x_j) + lin_r(x_i) — SAGPooling's default scorer."""
+
+    def __init__(self, in_channels, out_channels, aggr="add", bias=True, **kwargs):
+        super().__init__()
+        dev = _default_device()
+        self.lin_l = nn.Linear(in_channels, out_channels, bias=bias).to(dev)
+        self.lin_r = nn.Linear(in_channels, out_channels, bias=False).to(dev)
+
+    def forward(self, x, edge_index, edge_weight=None):
+        g = edge_index if isinstance(edge_index, GraphBatch) else graph_of(edge_index, x.size(0))
+        agg = mp.aggregate(x, g)
+        return linear(agg, self.lin_l.weight.t(), self.lin_l.bias) + linear(x, self.lin_r.weight.t())
+
+
+class GATConv(nn.Module):
+    """PyG GATConv: per-TARGET edge softmax (standard GAT), self loops added, heads concatenated/averaged."""
+
+    def __init__(self, in_channels, out_channels, heads=1, concat=True, negative_slope=0.2, dropout=0.0, bias=True, **kwargs):
+        super().__init__()
+        self.heads, self.out_channels, self.concat, self.negative_slope = heads, out_channels, concat, negative_slope
+        if dropout:
+            raise NotImplementedError("attention dropout is not on the benchmarked path")
+        dev = _default_device()
+        self.lin_l = nn.Linear(in_channels, heads * out_channels, bias=False).to(dev)
+        self.att_l = nn.Parameter(torch.empty(1, heads, out_channels, device=dev))
+        self.att_r = nn.Parameter(torch.empty(1, heads, out_channels, device=dev))
+        self.bias = nn.Parameter(torch.zeros(heads * out_channels if concat else out_channels, device=dev)) if bias else None
+        nn.init.xavier_uniform_(self.lin_l.weight)
+        nn.init.xavier_uniform_(self.att_l)
+        nn.init.xavier_uniform_(self.att_r)
+
+    def forward(self, x, edge_index):
+        n = x.size(0)
+        keep = edge_index[0] != edge_index[1]                       # remove_self_loops + add_self_loops
+        loop = torch.arange(n, device=edge_index.device)
+        ei = torch.cat([edge_index[:, keep], torch.stack([loop, loop])], dim=1)
+        g = GraphBatch.from_edge_index(ei, n, ghosts=False)
+        h = linear(x, self.lin_l.weight.t())
+        # entry (i = target row, j = source col): score = att_r.h_i + att_l.h_j, softmax over the row
+        pre = att.attention_aggregate(h, self.att_r.view(self.heads, -1), self.att_l.view(self.heads, -1), g, self.heads,
+                                      self.negative_slope, by_column=False, uniform_isolated=False)
+        out = pre if self.concat else att.elu_heads(pre, self.heads, mean_heads=True, apply_elu=False)
+        return bias_add(out, self.bias)
+
+
+class SAGPooling(nn.Module):
+    """PyG SAGPooling: score = tanh(GNN(x)), top-k on the score, x[perm]*score[perm]."""
+
+    def __init__(self, in_channels, ratio=0.5, GNN=GraphConv, min_score=None, multiplier=1, nonlinearity=torch.tanh, **kwargs):
+        super().__init__()
+        if min_score is not None:
+            raise NotImplementedError("min_score")
+        self.in_channels, self.ratio, self.multiplier, self.nonlinearity = in_channels, ratio, multiplier, nonlinearity
+        self.gnn = GNN(in_channels, 1, **kwargs)
+
+    def forward(self, x, edge_index, edge_attr=None, batch=None, attn=None):
+        if batch is None:
+            batch = edge_index.new_zeros(x.size(0))
+        attn = x if attn is None else attn
+        raw = self.gnn(attn, edge_index).view(-1)
+        perm = topk(raw, self.ratio, batch)                           # tanh is monotone: same selection as PyG
+        if self.nonlinearity is torch.tanh:
+            xo = gather_gate(x, raw, perm, use_tanh=True)
+            score_perm = torch.tanh(raw[perm])
+        else:
+            score = self.nonlinearity(raw)
+            xo = x[perm] * score[perm].view(-1, 1)
+            score_perm = score[perm]
+        if self.multiplier != 1:
+            xo = self.multiplier * xo
+        ei, edge_attr = filter_adj(edge_index, edge_attr, perm, num_nodes=raw.numel())
+        return xo, ei, edge_attr, batch[perm], perm, score_perm
+
+
+def dense_diff_pool(x, adj, s, mask=None, eps=1e-15):
+    """PyG dense_diff_pool: (s^T x, s^T adj s, link loss, entropy loss); contractions on fp32 MFMA."""
+    from .diffpool import bmm, diffpool_contract_dense, row_softmax
+    x = x.unsqueeze(0) if x.dim() == 2 else x
+    adj = adj.unsqueeze(0) if adj.dim() == 2 else adj
+    s = s.unsqueeze(0) if s.dim() == 2 else s
+    B, N, K = s.shape
+    s = row_softmax(s.reshape(B * N, K)).reshape(B, N, K)
+    if mask is not None:
+        m = mask.view(B, N, 1).to(x.dtype)
+        x, s = x * m, s * m
+    out, out_adj = diffpool_contract_dense(s, x, adj)
+    sst = bmm(s, s, trans_b=True)
+    link = torch.norm(adj - sst, p=2) / adj.numel()
+    ent = (-s * torch.log(s + eps)).sum(dim=-1).mean()
+    return out, out_adj, link, ent

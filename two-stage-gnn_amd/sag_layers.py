@@ -1,0 +1,68 @@
+"""Drop-in for Code/sag/layers.py (SAGPool) and Code/sag/network.py (Net) on the HIP kernels.
+
+Same constructor signatures, submodule names (``score_layer``, ``conv1..3``, ``pool1..3``, ``lin1..3``) and
+return tuples as the reference, so ``latest.pth`` state_dicts (Code/sag/train.py:201-212) interchange.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import pyg
+from .pyg import GCNConv, filter_adj, global_max_pool as gmp, global_mean_pool as gap, topk
+
+
+class SAGPool(nn.Module):
+    def __init__(self, in_channels, ratio=0.8, Conv=GCNConv, non_linearity=torch.tanh):
+        super().__init__()
+        self.in_channels = in_channels
+        self.ratio = ratio
+        self.score_layer = Conv(in_channels, 1)
+        self.non_linearity = non_linearity
+
+    def forward(self, x, edge_index, edge_attr=None, batch=None):
+        if batch is None:
+            batch = edge_index.new_zeros(x.size(0))                      # layers.py:15-16
+        score = self.score_layer(x, edge_index).view(-1)                 # :18  (squeeze)
+        perm = topk(score, self.ratio, batch)                            # :20
+        if self.non_linearity is torch.tanh:
+            x = pyg.gather_gate(x, score, perm, use_tanh=True)           # :21 fused gather * tanh gate
+        else:
+            x = x[perm] * self.non_linearity(score[perm]).view(-1, 1)
+        batch = batch[perm]                                              # :22
+        edge_index, edge_attr = filter_adj(edge_index, edge_attr, perm, num_nodes=score.size(0))   # :23-24
+        return x, edge_index, edge_attr, batch, perm
+
+
+class Net(nn.Module):
+    """Code/sag/network.py:9-53.  ``use_batch=False`` reproduces the reference, which throws data.batch away
+    (network.py:32, trap T6: a mini-batch is pooled as ONE graph); ``use_batch=True`` gives PyG's per-graph
+    semantics."""
+
+    def __init__(self, num_features, nhid, num_classes, pooling_ratio, dropout_ratio, use_batch=False):
+        super().__init__()
+        self.num_features, self.nhid, self.num_classes = num_features, nhid, num_classes
+        self.pooling_ratio, self.dropout_ratio, self.use_batch = pooling_ratio, dropout_ratio, use_batch
+        self.conv1 = GCNConv(self.num_features, self.nhid)
+        self.pool1 = SAGPool(self.nhid, ratio=self.pooling_ratio)
+        self.conv2 = GCNConv(self.nhid, self.nhid)
+        self.pool2 = SAGPool(self.nhid, ratio=self.pooling_ratio)
+        self.conv3 = GCNConv(self.nhid, self.nhid)
+        self.pool3 = SAGPool(self.nhid, ratio=self.pooling_ratio)
+        dev = pyg._default_device()
+        self.lin1 = nn.Linear(self.nhid * 2, self.nhid).to(dev)
+        self.lin2 = nn.Linear(self.nhid, self.nhid // 2).to(dev)
+        self.lin3 = nn.Linear(self.nhid // 2, self.num_classes).to(dev)
+
+    def forward(self, data):
+        x, edge_index = data.x, data.edge_index
+        batch = getattr(data, "batch", None) if self.use_batch else None
+        outs = []
+        for conv, pool in ((self.conv1, self.pool1), (self.conv2, self.pool2), (self.conv3, self.pool3)):
+            x = pyg.relu(conv(x, edge_index))
+            x, edge_index, _, batch, _ = pool(x, edge_index, None, batch)
+            outs.append(torch.cat([gmp(x, batch), gap(x, batch)], dim=1))
+        x = outs[0] + outs[1] + outs[2]
+        x = F.relu(self.lin1(x))
+        x = F.dropout(x, p=self.dropout_ratio, training=self.training)
+        x = F.relu(self.lin2(x))
+        return F.log_softmax(self.lin3(x), dim=-1)
