@@ -1,0 +1,183 @@
+"""Data-parallel path: flat gradient bucket + one all-reduce + one optimiser step.
+CPU: world_size-2 gloo processes exercise the bucket/collective logic (the HIP optimiser kernel is replaced
+by its host arithmetic in a TEST subclass — the product's apply() refuses to run off-GPU).
+GPU: two gloo ranks sharing cuda:0 run the real HIP step and must agree with the average of the per-rank
+gradients and stay bit-identical to each other."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp_
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _host_apply(tr, scale):
+    g = tr.flat_grad * scale
+    norm = g.norm()
+    coef = torch.clamp(tr.clip / (norm + 1e-6), max=1.0) if tr.clip > 0 else torch.tensor(1.0)
+    g = g * coef
+    tr.state[0] += 1
+    step = float(tr.state[0])
+    b1, b2 = tr.betas
+    tr.exp_avg.mul_(b1).add_(g, alpha=1 - b1)
+    tr.exp_avg_sq.mul_(b2).addcmul_(g, g, value=1 - b2)
+    denom = tr.exp_avg_sq.sqrt() / (1 - b2 ** step) ** 0.5 + tr.eps
+    tr.flat_param.addcdiv_(tr.exp_avg, denom, value=-tr.lr / (1 - b1 ** step))
+
+
+def _cpu_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from two_stage_gnn_amd.data_parallel import FlatTrainer
+
+    class HostTrainer(FlatTrainer):
+        def apply(self):
+            _host_apply(self, 1.0 / self.world)
+
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 2))
+    tr = HostTrainer(model, lr=1e-2, clip=2.0)
+    assert tr.world == world
+    gen = torch.Generator().manual_seed(100 + rank)
+    x, y = torch.randn(8, 6, generator=gen), torch.randint(0, 2, (8,), generator=gen)
+    local = None
+    for _ in range(3):
+        tr.zero_grad()
+        loss = torch.nn.functional.cross_entropy(model(x), y)
+        loss.backward()
+        tr.gather_grads()
+        if local is None:
+            local = tr.flat_grad.clone()
+        tr.all_reduce()
+        tr.apply()
+    q.put((rank, local.numpy(), tr.flat_param.detach().numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_bucket_allreduce_gloo_world2():
+    ctx = mp_.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_cpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # replicas stay identical after every all-reduced step
+    np.testing.assert_array_equal(res[0][2], res[1][2])
+    # and equal a single process that averages the two local gradients itself
+    sys.path.insert(0, ROOT)
+    from two_stage_gnn_amd.data_parallel import FlatTrainer
+
+    class HostTrainer(FlatTrainer):
+        def apply(self):
+            _host_apply(self, 0.5)
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 2))
+    tr = HostTrainer(model, lr=1e-2, clip=2.0)
+    data = []
+    for r in range(2):
+        gen = torch.Generator().manual_seed(100 + r)
+        data.append((torch.randn(8, 6, generator=gen), torch.randint(0, 2, (8,), generator=gen)))
+    for _ in range(3):
+        total = torch.zeros_like(tr.flat_grad)
+        for x, y in data:
+            tr.zero_grad()
+            torch.nn.functional.cross_entropy(model(x), y).backward()
+            total += tr.gather_grads()
+        tr.flat_grad.copy_(total)
+        tr.apply()
+    np.testing.assert_allclose(tr.flat_param.detach().numpy(), res[0][2], rtol=1e-6, atol=1e-7)
+
+
+def test_flat_trainer_views_alias_parameters():
+    sys.path.insert(0, ROOT)
+    from two_stage_gnn_amd.data_parallel import FlatTrainer
+    m = torch.nn.Linear(3, 2)
+    tr = FlatTrainer(m)
+    assert tr.numel == 8
+    tr.flat_param.fill_(1.5)
+    assert float(m.weight[0, 0]) == 1.5 and float(m.bias[1]) == 1.5
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        tr.apply()
+
+
+# ----------------------------------------------------------------------------------------------- GPU
+def _gpu_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from two_stage_gnn_amd import dense_encoders as E, synthetic
+    from two_stage_gnn_amd.data_parallel import FlatTrainer
+
+    class A:
+        bias = True
+    torch.manual_seed(7)
+    model = E.GcnEncoderGraph(7, 16, 16, 2, 3, bn=True, args=A(), final_dim="number_classes").cuda()
+    tr = FlatTrainer(model, lr=1e-3, clip=2.0)
+    hb = synthetic.host_batch(seed=rank, B=6, shape="MUTAG", nmax=40)
+    g, x, label = synthetic.to_device(hb, torch.device("cuda"))
+    local = None
+    for _ in range(2):
+        tr.zero_grad()
+        _, yp = model(x, g)
+        model.loss(yp, label).backward()
+        tr.gather_grads()
+        if local is None:
+            local = tr.flat_grad.clone()
+        tr.all_reduce()
+        if _ == 0:
+            reduced = tr.flat_grad.clone()
+        tr.apply()
+    q.put((rank, local.cpu().numpy(), reduced.cpu().numpy(), tr.flat_param.detach().cpu().numpy(), tr.state.cpu().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_hip_step_on_one_gpu():
+    ctx = mp_.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    np.testing.assert_allclose(res[0][2], res[0][1] + res[1][1], rtol=1e-6, atol=1e-7)     # SUM over ranks
+    np.testing.assert_array_equal(res[0][2], res[1][2])
+    np.testing.assert_array_equal(res[0][3], res[1][3])                                    # replicas identical
+    assert res[0][4][0] == 2.0                                                             # two optimiser steps
+
+
+@pytest.mark.gpu
+def test_hip_clip_adam_matches_torch():
+    sys.path.insert(0, ROOT)
+    from two_stage_gnn_amd.data_parallel import FlatTrainer
+    torch.manual_seed(0)
+    m1 = torch.nn.Sequential(torch.nn.Linear(20, 30), torch.nn.Linear(30, 3)).cuda()
+    m2 = torch.nn.Sequential(torch.nn.Linear(20, 30), torch.nn.Linear(30, 3)).cuda()
+    m2.load_state_dict(m1.state_dict())
+    tr = FlatTrainer(m1, lr=1e-3, clip=0.5)
+    opt = torch.optim.Adam(m2.parameters(), lr=1e-3)
+    x, y = torch.randn(16, 20).cuda() * 3, torch.randint(0, 3, (16,)).cuda()
+    for _ in range(5):
+        tr.step(lambda: torch.nn.functional.cross_entropy(m1(x), y))
+        opt.zero_grad()
+        torch.nn.functional.cross_entropy(m2(x), y).backward()
+        torch.nn.utils.clip_grad_norm_(m2.parameters(), 0.5)
+        opt.step()
+    for a, b in zip(m1.parameters(), m2.parameters()):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
