@@ -128,7 +128,7 @@ def _gpu_worker(rank, world, port, q):
     hb = synthetic.host_batch(seed=rank, B=6, shape="MUTAG", nmax=40)
     g, x, label = synthetic.to_device(hb, torch.device("cuda"))
     local = None
-    for _ in range(2):
+    for it in range(2):
         tr.zero_grad()
         _, yp = model(x, g)
         model.loss(yp, label).backward()
@@ -136,7 +136,7 @@ def _gpu_worker(rank, world, port, q):
         if local is None:
             local = tr.flat_grad.clone()
         tr.all_reduce()
-        if _ == 0:
+        if it == 0:
             reduced = tr.flat_grad.clone()
         tr.apply()
     q.put((rank, local.cpu().numpy(), reduced.cpu().numpy(), tr.flat_param.detach().cpu().numpy(), tr.state.cpu().numpy()))
@@ -152,7 +152,7 @@ def test_two_ranks_hip_step_on_one_gpu():
     procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    res = sorted([q.get(timeout=90) for _ in range(2)], key=lambda t: t[0])
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
