@@ -65,7 +65,12 @@ def aggregation_probe(g, feat, iters=300):
     x = torch.randn(g.total_rows, feat, device="cuda")
     y = torch.empty_like(x)
     s = torch.cuda.current_stream()
-    fn = lambda: mp.spmm_raw(g.rowptr, g.col, g.val, x, g.total_rows, out=y)
+    use_ell = g.val is None and mp.ell_ok(x)
+    if use_ell:
+        g.ell()
+        fn = lambda: mp.spmm_ell(g, x, out=y)               # what the step's aggregate() launches
+    else:
+        fn = lambda: mp.spmm_raw(g.rowptr, g.col, g.val, x, g.total_rows, out=y)
     for _ in range(20):
         fn()
     torch.cuda.synchronize()

@@ -73,6 +73,17 @@ int tsgnn_csr_spmm_f32(const int* rowptr, const int* col, const float* val, cons
                        const float* x, int64_t ldx, float* y, int64_t ldy, int64_t n_rows, int feat,
                        float self_scalar, int relu_in, int accumulate, tsgnn_stream_t stream);
 
+/* Fixed-width (ELL) view of a CSR for low-degree graphs: ell[r][k] = k-th neighbour of row r or -1 (W in {4,8,16});
+ * tail_cnt[r] = entries beyond W (kept in a CSR tail: scan tail_cnt -> tail_ptr, then tsgnn_csr_tail_fill).
+ * tsgnn_ell_spmm_f32: y = A_ell.x (+ self_scalar*x) — same sums, same order as tsgnn_csr_spmm_f32 on the first W
+ * entries of every row, without the rowptr->col dependent hop; finish overflow rows with
+ * tsgnn_csr_spmm_f32(tail_ptr, tail_col, ..., accumulate=1).  feat % 4 == 0, feat <= 256. */
+int tsgnn_csr_to_ell(const int* rowptr, const int* col, int64_t n_rows, int W, int* ell, int* tail_cnt, tsgnn_stream_t stream);
+int tsgnn_csr_tail_fill(const int* rowptr, const int* col, const int* tail_ptr, int64_t n_rows, int W, int* tail_col,
+                        tsgnn_stream_t stream);
+int tsgnn_ell_spmm_f32(const int* ell, int W, const float* x, int64_t ldx, float* y, int64_t ldy, int64_t n_rows, int feat,
+                       float self_scalar, tsgnn_stream_t stream);
+
 /* PyG gcn_norm (add remaining self loops of weight self_fill, symmetric D^-1/2 (A+I) D^-1/2):
  * dinv[i], val_out[e] = dinv[i]*val[e]*dinv[col[e]], self_w[i] = dinv[i]^2*self_fill (0 if the row
  * already has a self loop).  Call site: GCNConv in Code/sag/network.py:19-23, layers.py:12. */
@@ -105,6 +116,14 @@ int tsgnn_colsum_f32(const float* x, int64_t ld, int64_t rows, int F, float* out
 int tsgnn_linear_l2norm_f32(const float* z, int64_t ldz, const float* w, int64_t ldw, const float* bias, float* v,
                             int64_t ldv, float* rinv, int64_t rows, int K, int N, int normalize,
                             tsgnn_stream_t stream);
+/* Row-panel variant of the same product (16-byte global loads, register prefetch, ds_read_b128 A fragments):
+ * c = a[rows,K] . b  with b = B[K,N] (trans_b = 0) or b = W[N,K] used transposed (trans_b = 1: dZ = dU . W^T),
+ * optional + bias and row L2 normalise.  tsgnn_rowgemm_supported() tells whether the operands qualify
+ * (16-byte aligned rows, N <= 256); callers fall back to tsgnn_linear_l2norm_f32 / tsgnn_gemm_f32 otherwise. */
+int tsgnn_rowgemm_supported(const float* a, int64_t lda, const float* b, int64_t ldb, const float* c, int64_t ldc, int K, int N,
+                            int trans_b);
+int tsgnn_rowgemm_f32(const float* a, int64_t lda, const float* b, int64_t ldb, int trans_b, const float* bias, float* c,
+                      int64_t ldc, float* rinv, int64_t rows, int K, int N, int normalize, tsgnn_stream_t stream);
 /* backward of the row normalisation: du = rinv * (dv - v (v.dv)) */
 int tsgnn_l2norm_bwd_f32(const float* v, int64_t ldv, const float* dv, int64_t lddv, const float* rinv, float* du,
                          int64_t lddu, int64_t rows, int F, tsgnn_stream_t stream);

@@ -212,3 +212,25 @@ def test_pack_unpack(T):
     assert xr.shape == (g.total_rows, 8)
     back = mp.unpack_rows(xr[:, :6].contiguous(), g)
     torch.testing.assert_close(back.cpu(), x)
+
+
+@pytest.mark.parametrize("F,p_edge", [(128, 0.05), (64, 0.02), (92, 0.1), (256, 0.3)])
+def test_ell_fast_path_equals_csr(T, F, p_edge):
+    """fixed-width index table (+ CSR tail when a row has more than 16 neighbours) == CSR kernel"""
+    mp, GB = T
+    x, adj, sizes = dense_batch(int(F + 100 * p_edge), 5, 80, F, p_edge=p_edge)
+    g = GB.from_dense(adj.cuda(), sizes=sizes, layout="packed")
+    g.val = None
+    xr = torch.zeros(g.total_rows, F)
+    o = 0
+    for b, n in enumerate(sizes):
+        xr[o:o + n] = x[b, :n]; o += n
+    xr = xr.cuda()
+    ell, W, tail = g.ell()
+    assert (tail is not None) == (p_edge >= 0.3)
+    y_csr = mp.spmm_raw(g.rowptr, g.col, None, xr, g.total_rows)
+    y_ell = mp.spmm_ell(g, xr)
+    if tail is None:
+        assert torch.equal(y_csr, y_ell)                       # same summation order: bitwise equal
+    else:
+        torch.testing.assert_close(y_ell, y_csr, rtol=1e-5, atol=1e-5)

@@ -19,32 +19,67 @@
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// ---- cross-lane reductions on DPP (no LDS-crossbar round trips): quad_perm xor1 / xor2, row_half_mirror,
+// row_mirror give every lane its 16-lane row total; rows are combined through v_readlane (SGPR broadcast).
+// All 64 lanes of the wave must be active.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+__device__ __forceinline__ float lane_f32(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_f32<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_f32<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_f32<0x141>(v);   // row_half_mirror
+  v += dpp_f32<0x140>(v);   // row_mirror
   return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_f32<0xB1>(v));
+  v = fmaxf(v, dpp_f32<0x4E>(v));
+  v = fmaxf(v, dpp_f32<0x141>(v));
+  v = fmaxf(v, dpp_f32<0x140>(v));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v = row16_sum(v);
+  return (lane_f32(v, 0) + lane_f32(v, 16)) + (lane_f32(v, 32) + lane_f32(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = row16_max(v);
+  return fmaxf(fmaxf(lane_f32(v, 0), lane_f32(v, 16)), fmaxf(lane_f32(v, 32), lane_f32(v, 48)));
 }
 __device__ __forceinline__ int wave_sum_i(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_i32<0xB1>(v);
+  v += dpp_i32<0x4E>(v);
+  v += dpp_i32<0x141>(v);
+  v += dpp_i32<0x140>(v);
+  return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+         __builtin_amdgcn_readlane(v, 48);
 }
-// reduction inside an aligned power-of-two lane group of width G (<= 64)
+// reduction inside an aligned power-of-two lane group of width G (<= 64); every lane of the group gets the result
 template <int G>
 __device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  if (G >= 2) v += dpp_f32<0xB1>(v);
+  if (G >= 4) v += dpp_f32<0x4E>(v);
+  if (G >= 8) v += dpp_f32<0x141>(v);
+  if (G >= 16) v += dpp_f32<0x140>(v);
+  if (G >= 32) v += __shfl_xor(v, 16, 64);
+  if (G >= 64) v += __shfl_xor(v, 32, 64);
   return v;
 }
 template <int G>
 __device__ __forceinline__ float group_max(float v) {
-#pragma unroll
-  for (int o = G / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  if (G >= 2) v = fmaxf(v, dpp_f32<0xB1>(v));
+  if (G >= 4) v = fmaxf(v, dpp_f32<0x4E>(v));
+  if (G >= 8) v = fmaxf(v, dpp_f32<0x141>(v));
+  if (G >= 16) v = fmaxf(v, dpp_f32<0x140>(v));
+  if (G >= 32) v = fmaxf(v, __shfl_xor(v, 16, 64));
+  if (G >= 64) v = fmaxf(v, __shfl_xor(v, 32, 64));
   return v;
 }
 

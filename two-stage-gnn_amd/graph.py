@@ -168,6 +168,29 @@ class GraphBatch:
         g.symmetric = bool(assume_symmetric)
         return g
 
+    # ------------------------------------------------------------------ fixed-width (ELL) view
+    def ell(self):
+        """(ell_col int32[R,W], W, tail) for the unit-weight aggregation fast path, or None when the graph is
+        weighted.  tail = (tail_ptr, tail_col) CSR of the entries beyond W per row, or None."""
+        if self.val is not None:
+            return None
+        if getattr(self, "_ell", None) is None:
+            R = self.total_rows
+            deg = self.rowptr[1:] - self.rowptr[:-1]
+            maxdeg = int(deg.max().item()) if R > 0 else 0
+            W = 4 if maxdeg <= 4 else (8 if maxdeg <= 8 else 16)
+            ell = _i32(max(R * W, 1), self.device)
+            tail_cnt = torch.zeros(R, dtype=torch.int32, device=self.device) if maxdeg > W else None
+            nat.call("csr_to_ell", self.rowptr, self.col, R, W, ell, tail_cnt)
+            tail = None
+            if tail_cnt is not None:
+                tail_ptr = exclusive_scan(tail_cnt)
+                tail_col = _i32(max(int(tail_ptr[-1].item()), 1), self.device)
+                nat.call("csr_tail_fill", self.rowptr, self.col, tail_ptr, R, W, tail_col)
+                tail = (tail_ptr, tail_col)
+            self._ell = (ell, W, tail)
+        return self._ell
+
     # ------------------------------------------------------------------ transpose (for dX = A^T dY)
     def _ensure_transpose(self):
         if self._t is None:

@@ -33,6 +33,21 @@ def spmm_raw(rowptr, col, val, x, n_rows, self_w=None, self_scalar=0.0, relu_in=
     return y
 
 
+def ell_ok(x):
+    F = x.size(1)
+    return F % 4 == 0 and F <= 256 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
+
+
+def spmm_ell(g, x, self_scalar=0.0, out=None):
+    """unit-weight aggregation through the fixed-width index table (+ CSR tail for rows with > W neighbours)."""
+    ell, W, tail = g.ell()
+    y = out if out is not None else _f32(x.size(0), x.size(1), device=x.device)
+    nat.call("ell_spmm_f32", ell, W, x, x.stride(0), y, y.stride(0), g.total_rows, int(x.size(1)), float(self_scalar))
+    if tail is not None:
+        spmm_raw(tail[0], tail[1], None, x, g.total_rows, out=y, accumulate=True)
+    return y
+
+
 class _Aggregate(torch.autograd.Function):
     """y = A x (+ x)   — GraphConv.forward lines encoders.py:33-35."""
 
@@ -40,12 +55,17 @@ class _Aggregate(torch.autograd.Function):
     def forward(ctx, x, g, add_self, val, self_w):
         x = _check(x, g.total_rows)
         ctx.g, ctx.add_self, ctx.val, ctx.self_w = g, add_self, val, self_w
+        ctx.fast = val is None and self_w is None and g.val is None and ell_ok(x)
+        if ctx.fast:
+            return spmm_ell(g, x, 1.0 if add_self else 0.0)
         return spmm_raw(g.rowptr, g.col, val, x, g.total_rows, self_w=self_w, self_scalar=1.0 if add_self else 0.0)
 
     @staticmethod
     def backward(ctx, dy):
         g = ctx.g
         dy = _check(dy)
+        if ctx.fast and g.symmetric and ell_ok(dy):
+            return spmm_ell(g, dy, 1.0 if ctx.add_self else 0.0), None, None, None, None
         rowptr_t, col_t, val_t = g.transposed(ctx.val)
         dx = spmm_raw(rowptr_t, col_t, val_t, dy, g.total_rows, self_w=ctx.self_w,
                       self_scalar=1.0 if ctx.add_self else 0.0)
@@ -89,6 +109,11 @@ def colsum(x):
     return out
 
 
+def rowgemm_ok(a, lda, b, ldb, K, N, trans_b):
+    return bool(nat.lib().tsgnn_rowgemm_supported(a.data_ptr(), int(lda), b.data_ptr(), int(ldb), None, 0, int(K), int(N),
+                                                  int(trans_b)))
+
+
 class _LinearL2Norm(torch.autograd.Function):
     """v = normalize(z W + b)  — encoders.py:36-40."""
 
@@ -102,8 +127,11 @@ class _LinearL2Norm(torch.autograd.Function):
         R = z.size(0)
         v = _f32(R, N, device=z.device)
         rinv = _f32(R, device=z.device) if normalize else None
-        nat.call("linear_l2norm_f32", z, z.stride(0), w, w.stride(0), bias, v, v.stride(0), rinv, R, K, N,
-                 int(normalize))
+        if rowgemm_ok(z, z.stride(0), w, w.stride(0), K, N, False):
+            nat.call("rowgemm_f32", z, z.stride(0), w, w.stride(0), 0, bias, v, v.stride(0), rinv, R, K, N, int(normalize))
+        else:
+            nat.call("linear_l2norm_f32", z, z.stride(0), w, w.stride(0), bias, v, v.stride(0), rinv, R, K, N,
+                     int(normalize))
         ctx.save_for_backward(z, w, v if normalize else None, rinv)
         ctx.has_bias = bias is not None
         ctx.normalize = normalize
@@ -123,7 +151,10 @@ class _LinearL2Norm(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             ldz = z.size(1)
             dz = _f32(R, ldz, device=dv.device, zero=(ldz > K))
-            gemm(du, du.stride(0), 1, w, 1, w.stride(0), dz, dz.stride(0), 1, R, K, N)      # dZ = dU W^T
+            if rowgemm_ok(du, du.stride(0), w, w.stride(0), N, K, True):                     # dZ = dU W^T
+                nat.call("rowgemm_f32", du, du.stride(0), w, w.stride(0), 1, None, dz, dz.stride(0), None, R, N, K, 0)
+            else:
+                gemm(du, du.stride(0), 1, w, 1, w.stride(0), dz, dz.stride(0), 1, R, K, N)
         if ctx.needs_input_grad[1]:
             dw = gemm_tn_splitk(z, K, du)                                                    # dW = Z^T dU
         if ctx.has_bias and ctx.needs_input_grad[2]:
