@@ -107,6 +107,13 @@ int tsgnn_gemm_splitk_plan(int M, int N, int K, int* ksplit, int64_t* ws_floats)
 int tsgnn_gemm_splitk_f32(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn,
                           float* C, int M, int N, int K, int ksplit, float* ws, int accumulate,
                           tsgnn_stream_t stream);
+/* Weight + bias gradient of the GraphConv transform in one pass over the rows (backward of encoders.py:36-38):
+ * dw[K_in,N] = z[:, :K_in]^T . du,  db[N] = colsum(du) (nullable).  Row slabs -> fixed-order reduce (reproducible).
+ * K_in, N <= 128, 16-byte rows; tsgnn_linear_wgrad_plan returns nslab = 0 for unsupported shapes. */
+int tsgnn_linear_wgrad_plan(int64_t rows, int K_in, int N, int64_t ldz, int64_t lddu, int* nslab, int64_t* rows_per_slab,
+                            int64_t* ws_floats);
+int tsgnn_linear_wgrad_f32(const float* z, int64_t ldz, const float* du, int64_t lddu, int64_t rows, int K_in, int N, int nslab,
+                           int64_t rows_per_slab, float* ws, float* dw, float* db, tsgnn_stream_t stream);
 /* out[f] (+)= sum_r x[r,f] (bias gradients); ws >= ceil(rows/512)*F floats */
 int tsgnn_colsum_f32(const float* x, int64_t ld, int64_t rows, int F, float* out, float* ws, int accumulate,
                      tsgnn_stream_t stream);

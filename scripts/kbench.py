@@ -48,6 +48,7 @@ def main():
     res["rowgemm dZ (trans)"] = burst_us(lambda: nat.call("rowgemm_f32", X, H, W, H, 1, None, dz, H, None, R, H, H, 0))
     res["gemm dZ=dU.W^T"] = burst_us(lambda: mp.gemm(X, H, 1, W, 1, H, dz, H, 1, R, H, H))
     res["gemm dW splitk"] = burst_us(lambda: mp.gemm_tn_splitk(X, H, Y))
+    res["linear_wgrad (dW+db)"] = burst_us(lambda: mp.linear_wgrad(X, H, Y, True))
     res["colsum"] = burst_us(lambda: mp.colsum(X))
     mean = torch.empty(g.nmax, device="cuda"); rstd = torch.empty(g.nmax, device="cuda")
     res["bn_slots fwd (stats+apply)"] = burst_us(lambda: nat.call("bn_slots_fwd_f32", g.graph_ptr, g.slot_count, g.row_slot, g.B, g.nmax, g.n_rows, g.n_ghost, X, H, H, 1, 1, mean, rstd, Y, H))

@@ -133,6 +133,145 @@ __global__ __launch_bounds__(256) void colsum_partial(const float* __restrict__ 
   if (rl == 0 && f < F) part[(int64_t)blockIdx.y * F + f] = lds[0][threadIdx.x] + lds[1][threadIdx.x] + lds[2][threadIdx.x] + lds[3][threadIdx.x];
 }
 
+
+// ---------------------------------------------------------------- weight gradient over row slabs
+// dW[K_in, N] = Z[:, :K_in]^T . dU   and   db[N] = colsum(dU)   (backward of encoders.py:36-38).
+// The reduction runs over the graph rows (thousands+), the output is tiny, so each workgroup owns a SLAB of
+// rows and produces a full [K_in+1, N] partial (row K_in = bias partial) from coalesced 16-byte row loads;
+// both MFMA operands are natural row-major LDS tiles (lane i reads consecutive floats: conflict-free).
+// Slabs are summed in fixed order by tn_rows_reduce (bitwise reproducible, no float atomics).
+constexpr int TN_CH = 32;            // rows per staged chunk
+
+struct TnArgs {
+  const float* z; int64_t ldz;
+  const float* du; int64_t lddu;
+  int64_t rows, rows_per_slab;
+  int K_in, N;
+  float* slabs;                      // [nslab][K_in + 1][N]
+};
+
+template <int MT, int NTt>
+__global__ __launch_bounds__(256) void gemm_tn_rows_kernel(TnArgs g) {
+  constexpr int KP = 32 * MT, NP = 32 * NTt;
+  constexpr int TILES = MT * NTt, TPW = (TILES + 3) / 4;
+  constexpr int ZV = (TN_CH * KP) / (256 * 4), UV = (TN_CH * NP) / (256 * 4);   // float4 per thread per chunk
+  __shared__ __attribute__((aligned(16))) float Zs[TN_CH * KP];
+  __shared__ __attribute__((aligned(16))) float Us[TN_CH * NP];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int64_t r0 = (int64_t)blockIdx.x * g.rows_per_slab;
+  const int64_t r1 = min(g.rows, r0 + g.rows_per_slab);
+  f32x16 acc[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float dbacc = 0.f;
+  float4 rz[ZV], ru[UV];
+  auto load_chunk = [&](int64_t rb) {
+#pragma unroll
+    for (int q = 0; q < ZV; ++q) {
+      const int idx = q * 256 + tid, m = idx / (KP / 4), c4 = idx % (KP / 4);
+      const bool ok = rb + m < r1 && 4 * c4 < g.K_in;
+      rz[q] = *reinterpret_cast<const float4*>(ok ? g.z + (rb + m) * g.ldz + 4 * c4 : g.z);
+      if (!ok) rz[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int q = 0; q < UV; ++q) {
+      const int idx = q * 256 + tid, m = idx / (NP / 4), c4 = idx % (NP / 4);
+      const bool ok = rb + m < r1 && 4 * c4 < g.N;
+      ru[q] = *reinterpret_cast<const float4*>(ok ? g.du + (rb + m) * g.lddu + 4 * c4 : g.du);
+      if (!ok) ru[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int q = 0; q < ZV; ++q) {
+      const int idx = q * 256 + tid, m = idx / (KP / 4), c4 = idx % (KP / 4);
+      float4 v = rz[q];
+      const int nv = g.K_in - 4 * c4;                 // columns >= K_in (row padding of Z) contribute nothing
+      if (nv < 4) v.w = 0.f;
+      if (nv < 3) v.z = 0.f;
+      if (nv < 2) v.y = 0.f;
+      if (nv < 1) v.x = 0.f;
+      *reinterpret_cast<float4*>(Zs + m * KP + 4 * c4) = v;
+    }
+#pragma unroll
+    for (int q = 0; q < UV; ++q) {
+      const int idx = q * 256 + tid, m = idx / (NP / 4), c4 = idx % (NP / 4);
+      *reinterpret_cast<float4*>(Us + m * NP + 4 * c4) = ru[q];
+    }
+  };
+  if (r0 < r1) {
+    load_chunk(r0);
+    for (int64_t rb = r0; rb < r1; rb += TN_CH) {
+      store_chunk();
+      __syncthreads();
+      if (rb + TN_CH < r1) load_chunk(rb + TN_CH);     // next chunk flies under the MFMAs
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) {
+        const int tile = wid + 4 * t;
+        if (tile < TILES) {
+          const int tm = tile / NTt, tn = tile % NTt;
+          const float* ap = Zs + h * KP + tm * 32 + i;   // A[m][k] = Z[row k][m]
+          const float* bp = Us + h * NP + tn * 32 + i;   // B[k][j] = dU[row k][j]
+#pragma unroll
+          for (int s2 = 0; s2 < TN_CH; s2 += 2)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[s2 * KP], bp[s2 * NP], acc[t], 0, 0, 0);
+        }
+      }
+      if (tid < NP) {
+#pragma unroll 8
+        for (int m = 0; m < TN_CH; ++m) dbacc += Us[m * NP + tid];
+      }
+      __syncthreads();
+    }
+  }
+  float* slab = g.slabs + (int64_t)blockIdx.x * (g.K_in + 1) * g.N;
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int tile = wid + 4 * t;
+    if (tile < TILES) {
+      const int tm = tile / NTt, tn = tile % NTt;
+      const int cn = tn * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int cm = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (cm < g.K_in && cn < g.N) slab[(int64_t)cm * g.N + cn] = acc[t][r];
+      }
+    }
+  }
+  if (tid < g.N) slab[(int64_t)g.K_in * g.N + tid] = dbacc;
+}
+
+// out[e] = sum_s slabs[s][e]; e < K_in*N -> dW, else -> db.  64 outputs x 4 slab groups per block.
+__global__ __launch_bounds__(256) void tn_rows_reduce(const float* __restrict__ slabs, int nslab, int64_t per_slab, int64_t n_w,
+                                                      float* __restrict__ dw, float* __restrict__ db) {
+  __shared__ float lds[4][64];
+  const int e_l = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int64_t e = (int64_t)blockIdx.x * 64 + e_l;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (e < per_slab) {
+    const int per = (nslab + 3) / 4;
+    const int s0 = grp * per, s1 = min(nslab, s0 + per);
+    int s = s0;
+    for (; s + 4 <= s1; s += 4) {
+      a0 += slabs[(int64_t)s * per_slab + e];
+      a1 += slabs[(int64_t)(s + 1) * per_slab + e];
+      a2 += slabs[(int64_t)(s + 2) * per_slab + e];
+      a3 += slabs[(int64_t)(s + 3) * per_slab + e];
+    }
+    for (; s < s1; ++s) a0 += slabs[(int64_t)s * per_slab + e];
+  }
+  lds[grp][e_l] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (grp == 0 && e < per_slab) {
+    const float v = (lds[0][e_l] + lds[1][e_l]) + (lds[2][e_l] + lds[3][e_l]);
+    if (e < n_w) dw[e] = v;
+    else if (db) db[e - n_w] = v;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -182,6 +321,44 @@ int tsgnn_gemm_splitk_f32(const float* A, int64_t sam, int64_t sak, const float*
     const int64_t n = (int64_t)M * N;
     splitk_reduce_kernel<<<(unsigned)ceil_div64(n, 256), 256, 0, stream>>>(ws, ksplit, n, n, C, accumulate);
   }
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+
+/* plan: number of row slabs and workspace floats for tsgnn_linear_wgrad_f32 (0 slabs = shape unsupported) */
+int tsgnn_linear_wgrad_plan(int64_t rows, int K_in, int N, int64_t ldz, int64_t lddu, int* nslab, int64_t* rows_per_slab,
+                            int64_t* ws_floats) {
+  if (!nslab || !rows_per_slab || !ws_floats || rows < 0) return TSGNN_EINVAL;
+  *nslab = 0; *rows_per_slab = 0; *ws_floats = 0;
+  if (K_in <= 0 || N <= 0 || K_in > 128 || N > 128 || (ldz % 4) || (lddu % 4) || (N % 4)) return TSGNN_OK;
+  int64_t rps = 64;
+  while (ceil_div64(rows, rps) > 512) rps *= 2;
+  *rows_per_slab = rps;
+  *nslab = (int)(rows > 0 ? ceil_div64(rows, rps) : 1);
+  *ws_floats = (int64_t)(*nslab) * (K_in + 1) * N;
+  return TSGNN_OK;
+}
+
+/* dW[K_in,N] = z[:, :K_in]^T . du ; db[N] = colsum(du) (db nullable).  Plan with tsgnn_linear_wgrad_plan. */
+int tsgnn_linear_wgrad_f32(const float* z, int64_t ldz, const float* du, int64_t lddu, int64_t rows, int K_in, int N, int nslab,
+                           int64_t rows_per_slab, float* ws, float* dw, float* db, tsgnn_stream_t stream) {
+  if (!z || !du || !ws || !dw || rows < 0 || nslab <= 0 || rows_per_slab <= 0 || K_in <= 0 || N <= 0) return TSGNN_EINVAL;
+  if (K_in > 128 || N > 128 || (ldz % 4) || (lddu % 4) || (N % 4) || (reinterpret_cast<uintptr_t>(z) & 15) ||
+      (reinterpret_cast<uintptr_t>(du) & 15))
+    return TSGNN_EUNSUPPORTED;
+  TnArgs g{z, ldz, du, lddu, rows, rows_per_slab, K_in, N, ws};
+  const int mt = (K_in + 31) / 32, nt = (N + 31) / 32;
+#define TSGNN_TN(M_, N_) gemm_tn_rows_kernel<M_, N_><<<nslab, 256, 0, stream>>>(g)
+  switch (mt * 10 + nt) {
+    case 11: TSGNN_TN(1, 1); break; case 12: TSGNN_TN(1, 2); break; case 13: TSGNN_TN(1, 3); break; case 14: TSGNN_TN(1, 4); break;
+    case 21: TSGNN_TN(2, 1); break; case 22: TSGNN_TN(2, 2); break; case 23: TSGNN_TN(2, 3); break; case 24: TSGNN_TN(2, 4); break;
+    case 31: TSGNN_TN(3, 1); break; case 32: TSGNN_TN(3, 2); break; case 33: TSGNN_TN(3, 3); break; case 34: TSGNN_TN(3, 4); break;
+    case 41: TSGNN_TN(4, 1); break; case 42: TSGNN_TN(4, 2); break; case 43: TSGNN_TN(4, 3); break; default: TSGNN_TN(4, 4); break;
+  }
+#undef TSGNN_TN
+  const int64_t per_slab = (int64_t)(K_in + 1) * N;
+  tn_rows_reduce<<<(unsigned)ceil_div64(per_slab, 64), 256, 0, stream>>>(ws, nslab, per_slab, (int64_t)K_in * N, dw, db);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }

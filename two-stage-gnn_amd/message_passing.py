@@ -101,6 +101,24 @@ def gemm_tn_splitk(Z, K_in, dU, out=None):
     return out
 
 
+def linear_wgrad(z, K_in, du, want_db):
+    """(dW[K_in,N], db[N] or None) in one pass over the rows; falls back to split-K GEMM + column sums."""
+    R, N = du.size(0), du.size(1)
+    nslab = np.zeros(1, dtype=np.int32)
+    rps = np.zeros(1, dtype=np.int64)
+    need = np.zeros(1, dtype=np.int64)
+    nat.call_nostream("linear_wgrad_plan", int(R), int(K_in), int(N), int(z.stride(0)), int(du.stride(0)), nslab.ctypes.data,
+                      rps.ctypes.data, need.ctypes.data)
+    if int(nslab[0]) > 0 and z.data_ptr() % 16 == 0 and du.data_ptr() % 16 == 0:
+        ws = _f32(int(need[0]), device=du.device)
+        dw = _f32(K_in, N, device=du.device)
+        db = _f32(N, device=du.device) if want_db else None
+        nat.call("linear_wgrad_f32", z, z.stride(0), du, du.stride(0), R, int(K_in), int(N), int(nslab[0]), int(rps[0]), ws,
+                 dw, db)
+        return dw, db
+    return gemm_tn_splitk(z, K_in, du), (colsum(du) if want_db else None)
+
+
 def colsum(x):
     R, F = x.size(0), x.size(1)
     out = _f32(F, device=x.device)
@@ -155,9 +173,10 @@ class _LinearL2Norm(torch.autograd.Function):
                 nat.call("rowgemm_f32", du, du.stride(0), w, w.stride(0), 1, None, dz, dz.stride(0), None, R, N, K, 0)
             else:
                 gemm(du, du.stride(0), 1, w, 1, w.stride(0), dz, dz.stride(0), 1, R, K, N)
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            dw = gemm_tn_splitk(z, K, du)                                                    # dW = Z^T dU
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+            dw, db = linear_wgrad(z, K, du, want_db)                                         # dW = Z^T dU (+ db)
+        elif want_db:
             db = colsum(du)
         return dz, dw, db, None
 
