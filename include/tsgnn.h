@@ -239,6 +239,28 @@ int tsgnn_row_softmax_fwd_f32(const float* x, int64_t ldx, int64_t rows, int C, 
 int tsgnn_row_softmax_bwd_f32(const float* y, int64_t ldy, const float* dy, int64_t lddy, int64_t rows, int C, float* dx,
                               int64_t lddx, tsgnn_stream_t stream);
 
+/* ---------------------------------------------------------------- fused slot kernels of the GraphSage stack (sage_fused.hip) */
+
+/* 1 if (B graphs, F features) is covered by the fused slot kernels (B <= 128, F % 4 == 0, F <= 128) */
+int tsgnn_slot_fused_supported(int B, int F);
+/* y = slot_bn(relu(v)) with the statistics computed in the same pass (one workgroup per node slot keeps the slot's
+ * rows of all graphs in registers).  Same result as tsgnn_bn_slots_fwd_f32 (encoders.py:179-181,134-138). */
+int tsgnn_slot_bn_fwd_f32(const int* graph_ptr, const int* slot_count, int B, int nmax, int64_t n_real, int n_ghost,
+                          const float* v, int64_t ldv, int F, int relu, float* mean, float* rstd, float* y, int64_t ldy,
+                          tsgnn_stream_t stream);
+/* One-pass backward of [max readout (dout, arg) + next layer's dxs (nullable)] -> slot BN -> ReLU -> row L2 normalise:
+ * du = gradient w.r.t. the pre-normalise GraphConv output (feeds tsgnn_linear_wgrad_f32 / tsgnn_rowgemm_f32). */
+int tsgnn_slot_post_bwd_f32(const int* graph_ptr, const int* slot_count, int B, int nmax, int64_t n_real, int n_ghost,
+                            const float* v, int64_t ldv, const float* dxs, int64_t lddxs, const float* dout, int64_t ldo,
+                            const int* arg, int F, int relu, int bn, const float* mean, const float* rstd, const float* rinv,
+                            float* du, int64_t lddu, tsgnn_stream_t stream);
+/* max readout (encoders.py:183): partial maxima of one layer into packed[B*F] (zeroed by the caller), then ONE decode
+ * for all L layers: out[b, l*Fh + f], arg in packed order (layers 0..L-2 are Fh wide, the last Fl). */
+int tsgnn_readout_partial_f32(const int* graph_ptr, int B, int nmax, int64_t n_real, int n_ghost, const float* x, int64_t ldx, int F,
+                              unsigned long long* packed, tsgnn_stream_t stream);
+int tsgnn_readout_decode_layers_f32(const unsigned long long* packed, int B, int L, int Fh, int Fl, float* out, int64_t ldo, int* arg,
+                                    tsgnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -44,8 +44,10 @@ def test_graphconv_golden(tag, path, monkeypatch):
 
 @pytest.mark.parametrize("tag", ["cls_bn_l3", "emb_bn_l3", "pre_nobn_l2", "cls_bn_l4_b1"])
 @pytest.mark.parametrize("layout", ["packed", "padded"])
-def test_gcn_encoder_golden(tag, layout):
+@pytest.mark.parametrize("fused", [True, False])
+def test_gcn_encoder_golden(tag, layout, fused, monkeypatch):
     from two_stage_gnn_amd import dense_encoders as E
+    monkeypatch.setattr(E, "FUSED_STACK", fused)
     g = load_golden("gcn_encoder_" + tag)
     fin, hid, emb, lab = (int(v) for v in g["dims"])
 
@@ -62,7 +64,8 @@ def test_gcn_encoder_golden(tag, layout):
     check_param_grads(m, g, 2e-3, 2e-4)
 
 
-@pytest.mark.parametrize("B,nmax,nbar,fin,hid", [(8, 160, 60, 89, 128), (4, 400, 269, 89, 128)])
+@pytest.mark.parametrize("B,nmax,nbar,fin,hid", [(8, 160, 60, 89, 128), (4, 400, 269, 89, 128), (40, 200, 60, 7, 64),
+                                                 (100, 64, 20, 3, 32)])
 def test_gcn_encoder_vs_oracle_dd_shape(B, nmax, nbar, fin, hid):
     """DD-shaped batches (README.md:39: avg 269 nodes / 676 edges, 89 node labels), 3 layers h=128:
     HIP packed path vs the CPU oracle's dense formulation, outputs and all parameter gradients."""

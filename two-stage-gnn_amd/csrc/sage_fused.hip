@@ -1,0 +1,377 @@
+// Fused per-node-slot kernels of the GraphSage-style encoder stack (encoders.py:177-205):
+//
+//   slot_bn_fwd : ReLU + slot batch-norm (statistics AND normalisation) in ONE pass — a workgroup owns slot n and
+//                 keeps the slot's candidate rows of all graphs in registers (B <= 256/TPR graphs), so the
+//                 statistics are exact two-pass (mean, then centred variance) without re-reading memory.
+//   slot_post_bwd: backward of [max-readout scatter] + [slot batch-norm] + [ReLU] + [row L2-normalise] in one
+//                 pass: dU for the `.W` GEMMs comes out directly.
+//   readout_partial4 / readout_decode_layers: max readout with 16-byte loads; one decode for all layers.
+//
+// "Candidate (b, n)" = the real row graph_ptr[b]+n when n < size_b, else the ghost row n_real+n that stands for
+// the reference's padded row.  Each ghost-using graph is one copy of the ghost row, so the
+// reference's multiplicities fall out of the per-graph loop with no special weights.
+#include "common.h"
+#include "../../include/tsgnn.h"
+
+namespace {
+
+constexpr float BN_EPS = 1e-5f;
+
+struct SlotArgs {
+  const int* graph_ptr;
+  const int* slot_count;
+  int B, nmax;
+  int64_t n_real;
+  int n_ghost;
+};
+
+__device__ __forceinline__ void block_sum2(float& a, float& b, float* lds /*8*/) {
+  a = wave_sum(a); b = wave_sum(b);
+  const int wid = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { lds[wid] = a; lds[4 + wid] = b; }
+  __syncthreads();
+  a = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+  b = (lds[4] + lds[5]) + (lds[6] + lds[7]);
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// ---------------------------------------------------------------------------------------------- forward
+template <int TPR, int NV>
+__global__ __launch_bounds__(256) void slot_bn_fwd(SlotArgs s, const float* __restrict__ v, int64_t ldv, int F4, int relu,
+                                                   float* __restrict__ mean, float* __restrict__ rstd,
+                                                   float* __restrict__ y, int64_t ldy) {
+  __shared__ float red[8];
+  __shared__ int first_ghost;
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int b = tid / TPR, c = tid % TPR;
+  if (tid == 0) first_ghost = 0x7fffffff;
+  __syncthreads();
+  int64_t row = -1;
+  bool ghost = false;
+  if (b < s.B) {
+    const int g0 = s.graph_ptr[b], sz = s.graph_ptr[b + 1] - g0;
+    if (n < sz) row = (int64_t)g0 + n;
+    else if (s.n_ghost) { row = s.n_real + n; ghost = true; }
+  }
+  if (ghost && c == 0) atomicMin(&first_ghost, b);
+  float4 x[NV];
+  float s1 = 0.f, dummy = 0.f;
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+    const int c4 = c + TPR * q;
+    x[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row >= 0 && c4 < F4) {
+      x[q] = ld4(v + row * ldv + 4 * c4);
+      if (relu) { x[q].x = fmaxf(x[q].x, 0.f); x[q].y = fmaxf(x[q].y, 0.f); x[q].z = fmaxf(x[q].z, 0.f); x[q].w = fmaxf(x[q].w, 0.f); }
+      s1 += (x[q].x + x[q].y) + (x[q].z + x[q].w);
+    }
+  }
+  const int have = s.slot_count[n];
+  const float cnt = (float)(s.n_ghost ? s.B : have) * (float)(4 * F4);
+  block_sum2(s1, dummy, red);
+  const float mu = cnt > 0.f ? s1 / cnt : 0.f;
+  float s2 = 0.f;
+  dummy = 0.f;
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+    const int c4 = c + TPR * q;
+    if (row >= 0 && c4 < F4) {
+      const float a = x[q].x - mu, bb = x[q].y - mu, cc = x[q].z - mu, d = x[q].w - mu;
+      s2 += (a * a + bb * bb) + (cc * cc + d * d);
+    }
+  }
+  block_sum2(s2, dummy, red);
+  const float rs = 1.0f / sqrtf((cnt > 0.f ? s2 / cnt : 0.f) + BN_EPS);
+  if (tid == 0) { mean[n] = mu; rstd[n] = rs; }
+  const bool writer = row >= 0 && (!ghost || b == first_ghost);      // first_ghost is final: block_sum2 synchronised
+  if (writer) {
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      const int c4 = c + TPR * q;
+      if (c4 < F4) st4(y + row * ldy + 4 * c4, make_float4((x[q].x - mu) * rs, (x[q].y - mu) * rs, (x[q].z - mu) * rs, (x[q].w - mu) * rs));
+    }
+  }
+  // a ghost row that no graph uses (every graph has this slot) is never read for its value, but keep it defined
+  if (s.n_ghost && have == s.B && b == 0) {
+    const int64_t gr = s.n_real + n;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      const int c4 = c + TPR * q;
+      if (c4 < F4) st4(y + gr * ldy + 4 * c4, make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- backward
+// dy(b,n,f) = dxs[row] (real rows; a ghost row's dxs — already a sum over its copies — is taken by the first copy)
+//           + (arg[b,f] == row ? dout[b,f] : 0)                       [max-readout winner of graph b]
+// BN:   dv = rstd (dy - m1 - xhat m2) ; ReLU mask ; ghost copies summed in graph order ;
+// L2:   du = rinv (dv - v <v,dv>)   (rinv = 1e12 marks the clamped norm: du = rinv dv)
+template <int TPR, int NV>
+__global__ __launch_bounds__(256) void slot_post_bwd(SlotArgs s, const float* __restrict__ v, int64_t ldv,
+                                                     const float* __restrict__ dxs, int64_t lddxs,
+                                                     const float* __restrict__ dout, int64_t ldo, const int* __restrict__ arg,
+                                                     int F4, int relu, int bn, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const float* __restrict__ rinv,
+                                                     float* __restrict__ du, int64_t lddu) {
+  constexpr int GPB = 256 / TPR;
+  // all LDS in ONE dynamic array (16-byte aligned base for the float4 ghost accumulators, Guideline 17)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int F = 4 * F4;
+  float* gacc = smem;                                                // [GPB][F] ghost copies' dv (only with ghost rows)
+  float* red = smem + (s.n_ghost ? GPB * F : 0);                     // 8 floats
+  int& first_ghost = *reinterpret_cast<int*>(red + 8);
+  unsigned char* is_ghost = reinterpret_cast<unsigned char*>(red + 12);   // GPB bytes
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int b = tid / TPR, c = tid % TPR;
+  if (tid == 0) first_ghost = 0x7fffffff;
+  __syncthreads();
+  int64_t row = -1;
+  bool ghost = false;
+  if (b < s.B) {
+    const int g0 = s.graph_ptr[b], sz = s.graph_ptr[b + 1] - g0;
+    if (n < sz) row = (int64_t)g0 + n;
+    else if (s.n_ghost) { row = s.n_real + n; ghost = true; }
+  }
+  if (c == 0) is_ghost[b] = ghost ? 1 : 0;
+  if (ghost && c == 0) atomicMin(&first_ghost, b);
+  __syncthreads();
+  const bool fg = ghost && b == first_ghost;
+  const float mu = bn ? mean[n] : 0.f, rs = bn ? rstd[n] : 1.f;
+  float4 vv[NV], dy[NV];
+  float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+    const int c4 = c + TPR * q;
+    vv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    dy[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row >= 0 && c4 < F4) {
+      vv[q] = ld4(v + row * ldv + 4 * c4);
+      if (dxs && (!ghost || fg)) dy[q] = ld4(dxs + row * lddxs + 4 * c4);
+      const int4 w = *reinterpret_cast<const int4*>(arg + (int64_t)b * F + 4 * c4);
+      const float4 g = ld4(dout + (int64_t)b * ldo + 4 * c4);
+      const int r32 = (int)row;
+      if (w.x == r32) dy[q].x += g.x;
+      if (w.y == r32) dy[q].y += g.y;
+      if (w.z == r32) dy[q].z += g.z;
+      if (w.w == r32) dy[q].w += g.w;
+      if (bn) {
+        const float xa = ((relu ? fmaxf(vv[q].x, 0.f) : vv[q].x) - mu) * rs, xb = ((relu ? fmaxf(vv[q].y, 0.f) : vv[q].y) - mu) * rs;
+        const float xc = ((relu ? fmaxf(vv[q].z, 0.f) : vv[q].z) - mu) * rs, xd = ((relu ? fmaxf(vv[q].w, 0.f) : vv[q].w) - mu) * rs;
+        a1 += (dy[q].x + dy[q].y) + (dy[q].z + dy[q].w);
+        a2 += (dy[q].x * xa + dy[q].y * xb) + (dy[q].z * xc + dy[q].w * xd);
+      }
+    }
+  }
+  float m1 = 0.f, m2 = 0.f;
+  if (bn) {
+    const int have = s.slot_count[n];
+    const float cnt = (float)(s.n_ghost ? s.B : have) * (float)F;
+    block_sum2(a1, a2, red);
+    m1 = cnt > 0.f ? a1 / cnt : 0.f;
+    m2 = cnt > 0.f ? a2 / cnt : 0.f;
+  }
+  // dv per candidate
+  float4 dv[NV];
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+    const float e[4] = {vv[q].x, vv[q].y, vv[q].z, vv[q].w};
+    const float d[4] = {dy[q].x, dy[q].y, dy[q].z, dy[q].w};
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float g = d[k];
+      if (bn) {
+        const float xh = ((relu ? fmaxf(e[k], 0.f) : e[k]) - mu) * rs;
+        g = rs * (d[k] - m1 - xh * m2);
+      }
+      if (relu && !(e[k] > 0.f)) g = 0.f;
+      o[k] = (row >= 0) ? g : 0.f;
+    }
+    dv[q] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+  // ghost copies -> LDS, summed in graph order by the first ghost group
+  if (s.n_ghost) {
+    if (ghost) {
+#pragma unroll
+      for (int q = 0; q < NV; ++q) {
+        const int c4 = c + TPR * q;
+        if (c4 < F4) st4(gacc + (int64_t)b * F + 4 * c4, dv[q]);
+      }
+    }
+    __syncthreads();
+    if (fg) {
+#pragma unroll
+      for (int q = 0; q < NV; ++q) {
+        const int c4 = c + TPR * q;
+        if (c4 < F4) {
+          float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+          for (int gb = 0; gb < s.B; ++gb) {
+            if (is_ghost[gb]) {
+              const float4 t = ld4(gacc + (int64_t)gb * F + 4 * c4);
+              acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+            }
+          }
+          dv[q] = acc;
+        }
+      }
+    }
+  }
+  // row L2-normalise backward (real rows, and the ghost row by its first copy)
+  const bool writer = row >= 0 && (!ghost || fg);
+  float dot = 0.f;
+#pragma unroll
+  for (int q = 0; q < NV; ++q) dot += (vv[q].x * dv[q].x + vv[q].y * dv[q].y) + (vv[q].z * dv[q].z + vv[q].w * dv[q].w);
+  dot = group_sum<TPR>(dot);
+  if (writer) {
+    const float ri = rinv[row];
+    if (ri >= 0.999e12f) dot = 0.f;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      const int c4 = c + TPR * q;
+      if (c4 < F4)
+        st4(du + row * lddu + 4 * c4, make_float4(ri * (dv[q].x - vv[q].x * dot), ri * (dv[q].y - vv[q].y * dot),
+                                                   ri * (dv[q].z - vv[q].z * dot), ri * (dv[q].w - vv[q].w * dot)));
+    }
+  }
+  if (s.n_ghost && s.slot_count[n] == s.B && b == 0) {           // unused ghost row: zero gradient
+    const int64_t gr = s.n_real + n;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      const int c4 = c + TPR * q;
+      if (c4 < F4) st4(du + gr * lddu + 4 * c4, make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- readout
+__device__ __forceinline__ unsigned long long pack_max(float val, unsigned r) {
+  return ((unsigned long long)f32_ordered(val) << 32) | (unsigned long long)(0xFFFFFFFFu - r);
+}
+// grid (ceil(nslots/64), B); block = (256/G) row lanes x G float4 lanes (G = 32: F <= 128)
+template <int G>
+__global__ __launch_bounds__(256) void readout_partial4(SlotArgs s, const float* __restrict__ x, int64_t ld, int F4,
+                                                        unsigned long long* __restrict__ packed) {
+  constexpr int RL = 256 / G;
+  __shared__ unsigned long long best[RL][4 * G];
+  const int b = blockIdx.y;
+  const int c4 = threadIdx.x % G, rl = threadIdx.x / G;
+  const int g0 = s.graph_ptr[b], sz = s.graph_ptr[b + 1] - g0;
+  const int nslots = s.n_ghost ? s.nmax : sz;
+  const int n_lo = blockIdx.x * 64, n_hi = min(nslots, n_lo + 64);
+  unsigned long long m0 = 0ull, m1 = 0ull, m2 = 0ull, m3 = 0ull;
+  if (c4 < F4) {
+    for (int n = n_lo + rl; n < n_hi; n += RL) {
+      const int64_t r = n < sz ? (int64_t)g0 + n : s.n_real + n;
+      const float4 t = ld4(x + r * ld + 4 * c4);
+      const unsigned long long p0 = pack_max(t.x, (unsigned)r), p1 = pack_max(t.y, (unsigned)r), p2 = pack_max(t.z, (unsigned)r),
+                               p3 = pack_max(t.w, (unsigned)r);
+      m0 = p0 > m0 ? p0 : m0; m1 = p1 > m1 ? p1 : m1; m2 = p2 > m2 ? p2 : m2; m3 = p3 > m3 ? p3 : m3;
+    }
+  }
+  best[rl][4 * c4 + 0] = m0; best[rl][4 * c4 + 1] = m1; best[rl][4 * c4 + 2] = m2; best[rl][4 * c4 + 3] = m3;
+  __syncthreads();
+  const int F = 4 * F4;
+  for (int f = threadIdx.x; f < F; f += 256) {
+    unsigned long long m = best[0][f];
+#pragma unroll
+    for (int w = 1; w < RL; ++w) { const unsigned long long o = best[w][f]; m = o > m ? o : m; }
+    if (m) atomicMax(&packed[(int64_t)b * F + f], m);
+  }
+}
+// packed: layers 0..L-2 hold B*Fh entries each, the last layer B*Fl; out[b, off_l + f]; arg in the packed layout
+__global__ void readout_decode_layers(const unsigned long long* __restrict__ packed, int B, int L, int Fh, int Fl,
+                                      float* __restrict__ out, int64_t ldo, int* __restrict__ arg) {
+  const int64_t total = (int64_t)B * ((int64_t)(L - 1) * Fh + Fl);
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int64_t per_h = (int64_t)B * Fh;
+  int l;
+  int64_t j;
+  if (i < per_h * (L - 1)) { l = (int)(i / per_h); j = i % per_h; }
+  else { l = L - 1; j = i - per_h * (L - 1); }
+  const int Fw = (l == L - 1) ? Fl : Fh;
+  const int b = (int)(j / Fw), f = (int)(j % Fw);
+  const unsigned long long p = packed[i];
+  out[(int64_t)b * ldo + (int64_t)l * Fh + f] = p ? ordered_f32((unsigned)(p >> 32)) : 0.f;
+  arg[i] = p ? (int)(0xFFFFFFFFu - (unsigned)(p & 0xFFFFFFFFull)) : -1;
+}
+
+}  // namespace
+
+extern "C" {
+
+/* 0 if the fused slot kernels do not cover (B, F): callers use tsgnn_bn_slots_* / tsgnn_readout_max_* instead */
+int tsgnn_slot_fused_supported(int B, int F) {
+  if (B <= 0 || F <= 0 || (F % 4) || F > 128) return 0;
+  return B <= 128;
+}
+
+#define TSGNN_SLOT_DISPATCH(KERNEL, ...)                                                          \
+  do {                                                                                            \
+    const int F4_ = F / 4;                                                                        \
+    if (B <= 32) {                                                                                \
+      if (F4_ <= 8) KERNEL<8, 1> __VA_ARGS__; else if (F4_ <= 16) KERNEL<8, 2> __VA_ARGS__; else KERNEL<8, 4> __VA_ARGS__; \
+    } else if (B <= 64) {                                                                         \
+      if (F4_ <= 8) KERNEL<4, 2> __VA_ARGS__; else if (F4_ <= 16) KERNEL<4, 4> __VA_ARGS__; else KERNEL<4, 8> __VA_ARGS__; \
+    } else {                                                                                      \
+      if (F4_ <= 8) KERNEL<2, 4> __VA_ARGS__; else if (F4_ <= 16) KERNEL<2, 8> __VA_ARGS__; else KERNEL<2, 16> __VA_ARGS__; \
+    }                                                                                             \
+  } while (0)
+
+int tsgnn_slot_bn_fwd_f32(const int* graph_ptr, const int* slot_count, int B, int nmax, int64_t n_real, int n_ghost,
+                          const float* v, int64_t ldv, int F, int relu, float* mean, float* rstd, float* y, int64_t ldy,
+                          tsgnn_stream_t stream) {
+  if (!graph_ptr || !slot_count || !v || !mean || !rstd || !y || nmax <= 0 || (n_ghost != 0 && n_ghost != nmax) || ldv < F || ldy < F ||
+      (ldv % 4) || (ldy % 4))
+    return TSGNN_EINVAL;
+  if (!tsgnn_slot_fused_supported(B, F)) return TSGNN_EUNSUPPORTED;
+  SlotArgs s{graph_ptr, slot_count, B, nmax, n_real, n_ghost};
+  TSGNN_SLOT_DISPATCH(slot_bn_fwd, <<<nmax, 256, 0, stream>>>(s, v, ldv, F / 4, relu, mean, rstd, y, ldy));
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+int tsgnn_slot_post_bwd_f32(const int* graph_ptr, const int* slot_count, int B, int nmax, int64_t n_real, int n_ghost,
+                            const float* v, int64_t ldv, const float* dxs, int64_t lddxs, const float* dout, int64_t ldo,
+                            const int* arg, int F, int relu, int bn, const float* mean, const float* rstd, const float* rinv,
+                            float* du, int64_t lddu, tsgnn_stream_t stream) {
+  if (!graph_ptr || !slot_count || !v || !dout || !arg || !rinv || !du || nmax <= 0 || (n_ghost != 0 && n_ghost != nmax) ||
+      (bn && (!mean || !rstd)) || ldv < F || lddu < F || (ldv % 4) || (lddu % 4) || (ldo % 4) || (dxs && (lddxs % 4)))
+    return TSGNN_EINVAL;
+  if (!tsgnn_slot_fused_supported(B, F)) return TSGNN_EUNSUPPORTED;
+  SlotArgs s{graph_ptr, slot_count, B, nmax, n_real, n_ghost};
+  const int gpb = B <= 32 ? 32 : (B <= 64 ? 64 : 128);
+  const size_t lds = sizeof(float) * ((n_ghost ? (size_t)gpb * F : 0) + 12) + gpb;
+  TSGNN_SLOT_DISPATCH(slot_post_bwd, <<<nmax, 256, lds, stream>>>(s, v, ldv, dxs, lddxs, dout, ldo, arg, F / 4, relu, bn, mean, rstd,
+                                                                 rinv, du, lddu));
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+/* partial max of one layer into packed[B*F] (zeroed by the caller once per step for all layers) */
+int tsgnn_readout_partial_f32(const int* graph_ptr, int B, int nmax, int64_t n_real, int n_ghost, const float* x, int64_t ldx, int F,
+                              unsigned long long* packed, tsgnn_stream_t stream) {
+  if (!graph_ptr || !x || !packed || B <= 0 || nmax <= 0 || F <= 0 || (F % 4) || F > 128 || ldx < F || (ldx % 4) ||
+      (n_ghost != 0 && n_ghost != nmax))
+    return TSGNN_EINVAL;
+  SlotArgs s{graph_ptr, nullptr, B, nmax, n_real, n_ghost};
+  dim3 grid((unsigned)((nmax + 63) / 64), (unsigned)B);
+  readout_partial4<32><<<grid, 256, 0, stream>>>(s, x, ldx, F / 4, packed);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+int tsgnn_readout_decode_layers_f32(const unsigned long long* packed, int B, int L, int Fh, int Fl, float* out, int64_t ldo, int* arg,
+                                    tsgnn_stream_t stream) {
+  if (!packed || !out || !arg || B <= 0 || L <= 0 || Fh <= 0 || Fl <= 0) return TSGNN_EINVAL;
+  const int64_t total = (int64_t)B * ((int64_t)(L - 1) * Fh + Fl);
+  readout_decode_layers<<<(unsigned)ceil_div64(total, 256), 256, 0, stream>>>(packed, B, L, Fh, Fl, out, ldo, arg);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+}  // extern "C"

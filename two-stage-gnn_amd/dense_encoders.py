@@ -42,6 +42,7 @@ def _batch_from_dense(adj, sizes, layout):
     return g
 
 
+FUSED_STACK = True             # GcnEncoderGraph: run the conv stack as one fused autograd node when it qualifies
 DENSE_ADJ_MAX_NODES = 128      # at or below this many nodes per graph a dense batched MFMA product is used
 
 
@@ -229,6 +230,12 @@ class GcnEncoderGraph(nn.Module):
 
     def readouts_rows(self, x, g):
         """encoders.py:177-205 up to the concatenated max readout."""
+        from . import sage_stack
+        convs = [self.conv_first] + list(self.conv_block) + [self.conv_last]
+        if self.concat and FUSED_STACK and sage_stack.eligible(g, convs, self.bn, x) and \
+                bool(mp.nat.lib().tsgnn_slot_fused_supported(g.B, convs[0].output_dim)) and \
+                bool(mp.nat.lib().tsgnn_slot_fused_supported(g.B, convs[-1].output_dim)):
+            return sage_stack.sage_stack_readouts(x, g, convs)
         x = self._post(self.conv_first.forward_rows(x, g), g)
         out_all = [mp.readout_max(x, g)]
         for conv in self.conv_block:

@@ -1,0 +1,133 @@
+"""The GraphSage-style conv stack of GcnEncoderGraph (encoders.py:177-205) as ONE autograd node with a minimal
+launch sequence (the b=32 shape is launch-latency bound):
+
+  per layer:   aggregate (ELL/CSR SpMM) -> transform+bias+L2-normalise (fp32 MFMA) -> [ReLU + slot-BN fused] -> max-readout partial
+  once:        zero the packed readout buffer, decode all layers' readouts into the concatenated [B, sum F] output
+  backward:    per layer ONE kernel for readout-scatter + BN + ReLU + normalise backward, ONE pass for dW+db, the dZ GEMM
+               and the transposed aggregation.
+
+Used when the batch qualifies (slot-BN on, sum aggregation without self term, <= 128 graphs, widths <= 128); any other
+configuration runs the operator-by-operator path in dense_encoders.py — same kernels' results, more launches.
+"""
+import torch
+
+from . import _native as nat
+from . import message_passing as mp
+
+
+def eligible(g, convs, bn, x):
+    if not bn or g.B > 128 or len(convs) < 2:
+        return False
+    hid = convs[0].output_dim
+    for i, c in enumerate(convs):
+        if c.add_self or not c.normalize_embedding or c.dropout > 0.001:
+            return False
+        if c.output_dim % 4 or c.output_dim > 128:
+            return False
+        if i < len(convs) - 1 and c.output_dim != hid:
+            return False
+    return x.dim() == 2 and x.size(1) % 4 == 0 and x.is_cuda and x.stride(0) % 4 == 0
+
+
+def _aggregate_raw(g, x, transposed=False):
+    if g.val is None and mp.ell_ok(x) and (not transposed or g.symmetric):
+        return mp.spmm_ell(g, x)
+    rp, col, val = g.transposed() if transposed else (g.rowptr, g.col, g.val)
+    return mp.spmm_raw(rp, col, val, x, g.total_rows)
+
+
+class _SageStack(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x0, g, has_bias, *params):
+        L = len(params) // 2
+        Ws = [params[2 * l].contiguous() for l in range(L)]
+        bs = [params[2 * l + 1] if has_bias else None for l in range(L)]
+        dev = x0.device
+        R, B = g.total_rows, g.B
+        Fh, Fl = Ws[0].size(1), Ws[-1].size(1)
+        total = B * ((L - 1) * Fh + Fl)
+        packed = torch.zeros(total, dtype=torch.int64, device=dev)
+        x = mp._check(x0, R)
+        saved = []
+        off = 0
+        for l in range(L):
+            K, N = Ws[l].size(0), Ws[l].size(1)
+            z = _aggregate_raw(g, x)
+            v = torch.empty(R, N, dtype=torch.float32, device=dev)
+            rinv = torch.empty(R, dtype=torch.float32, device=dev)
+            if mp.rowgemm_ok(z, z.stride(0), Ws[l], Ws[l].stride(0), K, N, False):
+                nat.call("rowgemm_f32", z, z.stride(0), Ws[l], Ws[l].stride(0), 0, bs[l], v, v.stride(0), rinv, R, K, N, 1)
+            else:
+                nat.call("linear_l2norm_f32", z, z.stride(0), Ws[l], Ws[l].stride(0), bs[l], v, v.stride(0), rinv, R, K, N, 1)
+            pk = packed[off:off + B * N]
+            if l < L - 1:
+                mean = torch.empty(g.nmax, dtype=torch.float32, device=dev)
+                rstd = torch.empty(g.nmax, dtype=torch.float32, device=dev)
+                y = torch.empty_like(v)
+                nat.call("slot_bn_fwd_f32", g.graph_ptr, g.slot_count, B, g.nmax, g.n_rows, g.n_ghost, v, v.stride(0), N, 1,
+                         mean, rstd, y, y.stride(0))
+                nat.call("readout_partial_f32", g.graph_ptr, B, g.nmax, g.n_rows, g.n_ghost, y, y.stride(0), N, pk)
+                x = y
+            else:
+                mean = rstd = None
+                nat.call("readout_partial_f32", g.graph_ptr, B, g.nmax, g.n_rows, g.n_ghost, v, v.stride(0), N, pk)
+            saved.append((z, v, rinv, mean, rstd))
+            off += B * N
+        out = torch.empty(B, (L - 1) * Fh + Fl, dtype=torch.float32, device=dev)
+        arg = torch.empty(total, dtype=torch.int32, device=dev)
+        nat.call("readout_decode_layers_f32", packed, B, L, Fh, Fl, out, out.stride(0), arg)
+        ctx.g, ctx.L, ctx.has_bias, ctx.dims = g, L, has_bias, (Fh, Fl)
+        ctx.Ws, ctx.saved, ctx.arg = Ws, saved, arg
+        ctx.x0_ld = x.size(1) if L == 0 else x0.size(1)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        g, L = ctx.g, ctx.L
+        Fh, Fl = ctx.dims
+        dout = dout.contiguous()
+        dev = dout.device
+        R, B = g.total_rows, g.B
+        grads = [None] * (2 * L)
+        dxs = None
+        dx0 = None
+        for l in range(L - 1, -1, -1):
+            z, v, rinv, mean, rstd = ctx.saved[l]
+            W = ctx.Ws[l]
+            K, N = W.size(0), W.size(1)
+            last = l == L - 1
+            du = torch.empty(R, N, dtype=torch.float32, device=dev)
+            dsl = dout[:, l * Fh:l * Fh + N]
+            argl = ctx.arg[l * B * Fh:l * B * Fh + B * N]
+            nat.call("slot_post_bwd_f32", g.graph_ptr, g.slot_count, B, g.nmax, g.n_rows, g.n_ghost, v, v.stride(0), dxs,
+                     dxs.stride(0) if dxs is not None else 0, dsl, dout.stride(0), argl, N, 0 if last else 1, 0 if last else 1,
+                     mean, rstd, rinv, du, du.stride(0))
+            want_w = ctx.needs_input_grad[3 + 2 * l]
+            want_b = ctx.has_bias and ctx.needs_input_grad[4 + 2 * l]
+            if want_w:
+                dw, db = mp.linear_wgrad(z, K, du, want_b)
+                grads[2 * l], grads[2 * l + 1] = dw, db
+            elif want_b:
+                grads[2 * l + 1] = mp.colsum(du)
+            need_dx = l > 0 or ctx.needs_input_grad[0]
+            if need_dx:
+                ldz = z.size(1)
+                dz = torch.zeros(R, ldz, dtype=torch.float32, device=dev) if ldz > K else torch.empty(R, ldz, dtype=torch.float32, device=dev)
+                if mp.rowgemm_ok(du, du.stride(0), W, W.stride(0), N, K, True):
+                    nat.call("rowgemm_f32", du, du.stride(0), W, W.stride(0), 1, None, dz, dz.stride(0), None, R, N, K, 0)
+                else:
+                    mp.gemm(du, du.stride(0), 1, W, 1, W.stride(0), dz, dz.stride(0), 1, R, K, N)
+                dxs = _aggregate_raw(g, dz, transposed=True)
+                if l == 0:
+                    dx0 = dxs
+        return (dx0, None, None) + tuple(grads)
+
+
+def sage_stack_readouts(x, g, convs):
+    """concatenated max readouts [B, hidden*(L-1)+embedding] of the conv stack (encoders.py:177-203)."""
+    has_bias = convs[0].bias is not None
+    params = []
+    for c in convs:
+        params.append(c.weight)
+        params.append(c.bias if has_bias else c.weight.new_zeros(1))
+    return _SageStack.apply(x, g, has_bias, *params)
