@@ -63,5 +63,34 @@ def main():
         print("%-40s %8.2f us" % (k, v))
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not os.environ.get("EXTRA"):
     main()
+
+
+def extra():
+    """launch-overhead probes: alternating DIFFERENT trivial kernels, and the fused-stack kernels"""
+    dev = torch.device("cuda")
+    a = torch.zeros(256, device=dev); b = torch.zeros(256, device=dev)
+    def alt():
+        a.zero_(); nat.call("relu_fwd_f32", a, 256, b); b.add_(1.0); nat.call("relu_bwd_f32", a, b, 256, a)
+    print("%-40s %8.2f us per kernel" % ("4 different trivial kernels alternating", burst_us(alt, 50) / 4))
+    big = torch.zeros(9151 * 128, device=dev); big2 = torch.zeros_like(big)
+    def alt_big():
+        nat.call("relu_fwd_f32", big, big.numel(), big2); nat.call("relu_bwd_f32", big2, big, big.numel(), big)
+    print("%-40s %8.2f us per kernel" % ("2 kernels alternating, 4.7 MB in/out each", burst_us(alt_big, 50) / 2))
+    hb = synthetic.host_batch(0, 32, "DD", 1000)
+    g, x, label = synthetic.to_device(hb, dev)
+    R, H = g.total_rows, 128
+    V = torch.randn(R, H, device=dev); Y = torch.empty_like(V); mean = torch.empty(g.nmax, device=dev); rstd = torch.empty(g.nmax, device=dev)
+    print("%-40s %8.2f us" % ("slot_bn_fwd", burst_us(lambda: nat.call("slot_bn_fwd_f32", g.graph_ptr, g.slot_count, g.B, g.nmax, g.n_rows, g.n_ghost, V, H, H, 1, mean, rstd, Y, H))))
+    packed = torch.zeros(g.B * H, dtype=torch.int64, device=dev)
+    print("%-40s %8.2f us" % ("readout_partial", burst_us(lambda: nat.call("readout_partial_f32", g.graph_ptr, g.B, g.nmax, g.n_rows, g.n_ghost, Y, H, H, packed))))
+    out = torch.empty(g.B, H, device=dev); arg = torch.empty(g.B * H, dtype=torch.int32, device=dev)
+    nat.call("readout_decode_layers_f32", packed, g.B, 1, H, H, out, H, arg)
+    rinv = torch.ones(R, device=dev); du = torch.empty_like(V); dxs = torch.randn(R, H, device=dev); dout = torch.randn(g.B, H, device=dev)
+    print("%-40s %8.2f us" % ("slot_post_bwd (bn)", burst_us(lambda: nat.call("slot_post_bwd_f32", g.graph_ptr, g.slot_count, g.B, g.nmax, g.n_rows, g.n_ghost, V, H, dxs, H, dout, H, arg, H, 1, 1, mean, rstd, rinv, du, H))))
+    print("%-40s %8.2f us" % ("slot_post_bwd (last, no dxs)", burst_us(lambda: nat.call("slot_post_bwd_f32", g.graph_ptr, g.slot_count, g.B, g.nmax, g.n_rows, g.n_ghost, V, H, None, 0, dout, H, arg, H, 0, 0, None, None, rinv, du, H))))
+
+
+if os.environ.get("EXTRA"):
+    extra()

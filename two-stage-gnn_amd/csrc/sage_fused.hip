@@ -193,7 +193,8 @@ __global__ __launch_bounds__(256) void slot_post_bwd(SlotArgs s, const float* __
     }
     dv[q] = make_float4(o[0], o[1], o[2], o[3]);
   }
-  // ghost copies -> LDS, summed in graph order by the first ghost group
+  // ghost copies -> LDS; ALL threads reduce them (feature f = tid % F, interleaved graph ranges, fixed order),
+  // then the first ghost group picks up the totals
   if (s.n_ghost) {
     if (ghost) {
 #pragma unroll
@@ -203,19 +204,27 @@ __global__ __launch_bounds__(256) void slot_post_bwd(SlotArgs s, const float* __
       }
     }
     __syncthreads();
+    const int parts = 256 / F > 0 ? 256 / F : 1;                     // F <= 128 -> parts >= 2
+    const int f = tid % F, part = tid / F;
+    float acc = 0.f;
+    if (part < parts) {
+      for (int gb = part; gb < s.B; gb += parts)
+        if (is_ghost[gb]) acc += gacc[(int64_t)gb * F + f];
+    }
+    __syncthreads();                                                  // everyone done reading gacc
+    if (part < parts) gacc[part * F + f] = acc;                       // rows 0..parts-1 of gacc now hold the partials
+    __syncthreads();
     if (fg) {
 #pragma unroll
       for (int q = 0; q < NV; ++q) {
         const int c4 = c + TPR * q;
         if (c4 < F4) {
-          float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-          for (int gb = 0; gb < s.B; ++gb) {
-            if (is_ghost[gb]) {
-              const float4 t = ld4(gacc + (int64_t)gb * F + 4 * c4);
-              acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
-            }
+          float4 t = ld4(gacc + 4 * c4);
+          for (int p = 1; p < parts; ++p) {
+            const float4 u = ld4(gacc + (int64_t)p * F + 4 * c4);
+            t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
           }
-          dv[q] = acc;
+          dv[q] = t;
         }
       }
     }
