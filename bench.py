@@ -65,7 +65,7 @@ def aggregation_probe(g, feat, iters=300):
     x = torch.randn(g.total_rows, feat, device="cuda")
     y = torch.empty_like(x)
     s = torch.cuda.current_stream()
-    use_ell = g.val is None and mp.ell_ok(x)
+    use_ell = g.val is None and mp.ell_ok(x) and g.total_rows <= mp.ELL_MAX_ROWS
     if use_ell:
         g.ell()
         fn = lambda: mp.spmm_ell(g, x, out=y)               # what the step's aggregate() launches
@@ -83,6 +83,9 @@ def aggregation_probe(g, feat, iters=300):
     torch.cuda.synchronize()
     ms = min(hip_event_ms(burst.replay, 1, s) for _ in range(5)) / iters
     nbytes = aggregation_bytes(g.total_rows, g.nnz, feat, weighted=g.val is not None)
+    aggregation_probe.kernel = ("spmm_ell_vec4<32,16> (tsgnn_ell_spmm_f32" if use_ell else
+                                ("spmm_vec4_rb<32,4,false> (tsgnn_csr_spmm_f32" if g.total_rows >= 262144 else
+                                 "spmm_vec4<32,false,false> (tsgnn_csr_spmm_f32")) + ", F=%d)" % feat
     return ms, nbytes
 
 
@@ -213,7 +216,7 @@ def main():
                            "global_batch": world * a.batch, "parallelism": "dp%d" % world,
                            "launch": "hipGraph replay" if use_graph else "eager",
                            "rows": int(g.n_rows), "edges_directed": int(g.nnz)},
-                "roofline": {"bound": "hbm", "kernel": "spmm_vec4<32,false,false> (tsgnn_csr_spmm_f32, F=%d)" % a.hidden,
+                "roofline": {"bound": "hbm", "kernel": aggregation_probe.kernel,
                              "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                              "traffic": None, "bytes_per_launch": agg_bytes, "us_per_launch": agg_ms * 1e3},
             }
@@ -223,11 +226,15 @@ def main():
         else:
             out["cpu_baseline"] = None
         if a.sweep:
+            out["roofline"]["sweep"] = []
             with torch.cuda.stream(stream):
                 for B in (32, 256, 2048, 16384):
                     hs = synthetic.host_batch(seed=100 + B, B=B, shape=a.shape, nmax=a.nmax)
                     gs, _, _ = synthetic.to_device(hs, dev)
                     ms, nb = aggregation_probe(gs, a.hidden, iters=50 if B > 2048 else 200)
+                    out["roofline"]["sweep"].append({"graphs": B, "rows": int(gs.total_rows), "us_per_launch": ms * 1e3,
+                                                     "achieved": nb / ms / 1e6, "frac": nb / ms / 1e6 / HBM_PEAK_GBS,
+                                                     "kernel": aggregation_probe.kernel})
                     print("sweep B=%d rows=%d: %.2f us, %.0f GB/s (%.1f%% of 8 TB/s)" % (B, gs.n_rows, ms * 1e3, nb / ms / 1e6,
                                                                                        nb / ms / 1e6 / HBM_PEAK_GBS * 100), file=sys.stderr)
         print(json.dumps(out))

@@ -33,6 +33,9 @@ def spmm_raw(rowptr, col, val, x, n_rows, self_w=None, self_scalar=0.0, relu_in=
     return y
 
 
+ELL_MAX_ROWS = 16384      # the fixed-width table only pays while the batch is cache-resident and launch-bound
+
+
 def ell_ok(x):
     F = x.size(1)
     return F % 4 == 0 and F <= 256 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
@@ -55,7 +58,7 @@ class _Aggregate(torch.autograd.Function):
     def forward(ctx, x, g, add_self, val, self_w):
         x = _check(x, g.total_rows)
         ctx.g, ctx.add_self, ctx.val, ctx.self_w = g, add_self, val, self_w
-        ctx.fast = val is None and self_w is None and g.val is None and ell_ok(x)
+        ctx.fast = val is None and self_w is None and g.val is None and ell_ok(x) and g.total_rows <= ELL_MAX_ROWS
         if ctx.fast:
             return spmm_ell(g, x, 1.0 if add_self else 0.0)
         return spmm_raw(g.rowptr, g.col, val, x, g.total_rows, self_w=self_w, self_scalar=1.0 if add_self else 0.0)

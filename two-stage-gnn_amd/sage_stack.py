@@ -30,7 +30,7 @@ def eligible(g, convs, bn, x):
 
 
 def _aggregate_raw(g, x, transposed=False):
-    if g.val is None and mp.ell_ok(x) and (not transposed or g.symmetric):
+    if g.val is None and mp.ell_ok(x) and g.total_rows <= mp.ELL_MAX_ROWS and (not transposed or g.symmetric):
         return mp.spmm_ell(g, x)
     rp, col, val = g.transposed() if transposed else (g.rowptr, g.col, g.val)
     return mp.spmm_raw(rp, col, val, x, g.total_rows)
