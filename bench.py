@@ -205,6 +205,13 @@ def main():
             ms_step = elapsed / a.steps * 1e3
             agg_ms, agg_bytes = aggregation_probe(g, a.hidden)
             achieved = agg_bytes / (agg_ms * 1e-3) / 1e9
+            traffic = None          # PMC-measured HBM bytes per launch of the same kernel/shape (scripts/pmc_traffic.*)
+            try:
+                tr = json.load(open(os.path.join(ROOT, "profiles", "r01", "agg_traffic.json")))
+                if a.shape == "DD" and a.batch == 32 and a.hidden == 128 and int(g.total_rows) == 9151:
+                    traffic = tr["dd_b32_rows9151_f128"]["traffic_bytes_per_launch"]
+            except (OSError, KeyError, ValueError):
+                pass
             out = {
                 "metric": "graphs/sec fwd+bwd, DD batch=32 SAGE-3L h=128",
                 "value": world * a.batch * a.steps / elapsed, "unit": "graphs/s",
@@ -218,7 +225,7 @@ def main():
                            "rows": int(g.n_rows), "edges_directed": int(g.nnz)},
                 "roofline": {"bound": "hbm", "kernel": aggregation_probe.kernel,
                              "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                             "traffic": None, "bytes_per_launch": agg_bytes, "us_per_launch": agg_ms * 1e3},
+                             "traffic": traffic, "bytes_per_launch": agg_bytes, "us_per_launch": agg_ms * 1e3},
             }
     if rank == 0:
         if not a.no_cpu_baseline and world == 1:
