@@ -169,6 +169,10 @@ int tsgnn_unpack_rows_bwd_ghost_f32(const int* graph_ptr, int B, int nmax, int64
 
 /* ---------------------------------------------------------------- optimiser on a flat buffer (optim.hip) */
 
+/* loss = mean_b CE(logits[b,:], label[b]) and dlogits = d loss / d logits in one launch
+ * (model.loss -> F.cross_entropy, encoders.py:221-224; labels int64 as the reference passes them). */
+int tsgnn_softmax_ce_f32(const float* logits, int64_t ld, const int64_t* label, int B, int C, float* loss, float* dlogits,
+                         tsgnn_stream_t stream);
 /* clip_grad_norm(max_norm) + Adam.step() of the reference loop (train.py:128-129) on one flat fp32
  * parameter / gradient buffer (the buffer RCCL all-reduces): grad is first scaled by grad_scale
  * (1/world_size).  state: 3 floats {step, grad_norm, applied scale} (zeroed before the first step);

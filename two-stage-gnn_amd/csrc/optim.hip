@@ -51,9 +51,42 @@ __global__ void adam_update(float* __restrict__ p, const float* __restrict__ g, 
   p[i] -= (lr / bc1) * (mi / denom);
 }
 
+
+// softmax cross-entropy (mean over rows) with its gradient in the same pass: model.loss() of the reference
+// (F.cross_entropy, encoders.py:221-224).  One thread per row (few classes), block reduction of the loss.
+__global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict__ logits, int64_t ld, const int64_t* __restrict__ label,
+                                                         int B, int C, float* __restrict__ loss, float* __restrict__ dlogits) {
+  __shared__ float lds[4];
+  float part = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const float* row = logits + (int64_t)b * ld;
+    float m = -INFINITY;
+    for (int c = 0; c < C; ++c) m = fmaxf(m, row[c]);
+    float d = 0.f;
+    for (int c = 0; c < C; ++c) d += expf(row[c] - m);
+    const int y = (int)label[b];
+    const float logz = m + logf(d);
+    part += logz - row[y];
+    const float invB = 1.f / (float)B;
+    for (int c = 0; c < C; ++c) dlogits[(int64_t)b * C + c] = (expf(row[c] - logz) - (c == y ? 1.f : 0.f)) * invB;
+  }
+  part = wave_sum(part);
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = part;
+  __syncthreads();
+  if (threadIdx.x == 0) *loss = ((lds[0] + lds[1]) + (lds[2] + lds[3])) / (float)B;
+}
+
 }  // namespace
 
 extern "C" {
+
+int tsgnn_softmax_ce_f32(const float* logits, int64_t ld, const int64_t* label, int B, int C, float* loss, float* dlogits,
+                         tsgnn_stream_t stream) {
+  if (!logits || !label || !loss || !dlogits || B <= 0 || C <= 0 || ld < C) return TSGNN_EINVAL;
+  softmax_ce_kernel<<<1, 256, 0, stream>>>(logits, ld, label, B, C, loss, dlogits);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
 
 /* One optimiser step on flat buffers: g *= grad_scale (1/world after the all-reduce), clip to max_norm
  * (<=0: off), Adam.  ws >= 256 floats; state = 3 floats {step, grad_norm, applied scale}, zero before step 1. */

@@ -195,6 +195,7 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs g) {
 }
 
 
+
 template <int NT, bool TRANS_B>
 void launch_rowgemm(const RowGemmArgs& g, hipStream_t s) {
   constexpr int NP = 32 * NT;

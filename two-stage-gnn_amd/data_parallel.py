@@ -39,6 +39,7 @@ class FlatTrainer:
         self.exp_avg_sq = torch.zeros_like(self.flat_param)
         self.state = torch.zeros(3, dtype=torch.float32, device=dev)      # step, grad norm, applied scale
         self.ws = torch.empty(256, dtype=torch.float32, device=dev)
+        self._zeros = [torch.zeros_like(p).reshape(-1) for p in self.params]     # stand-ins for parameters without a gradient
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
@@ -48,7 +49,7 @@ class FlatTrainer:
 
     def gather_grads(self):
         """per-parameter gradients -> the flat bucket (one concatenation kernel)."""
-        parts = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params]
+        parts = [(p.grad.reshape(-1) if p.grad is not None else z) for p, z in zip(self.params, self._zeros)]
         torch.cat(parts, out=self.flat_grad)
         return self.flat_grad
 

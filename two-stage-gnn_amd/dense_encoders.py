@@ -260,7 +260,7 @@ class GcnEncoderGraph(nn.Module):
 
     def loss(self, pred, label, type="softmax"):
         if type == "softmax":
-            return F.cross_entropy(pred, label, reduction="mean")
+            return mp.cross_entropy(pred, label)
         if type == "margin":
             onehot = torch.zeros(pred.size(0), self.label_dim, dtype=torch.long, device=pred.device)
             onehot.scatter_(1, label.view(-1, 1), 1)

@@ -341,3 +341,29 @@ class _MaskGhost(torch.autograd.Function):
 
 def mask_ghost_rows(x, g):
     return _MaskGhost.apply(x, g.n_rows) if g.n_ghost else x
+
+
+# ----------------------------------------------------------------------------- loss
+class _SoftmaxCE(torch.autograd.Function):
+    """F.cross_entropy(pred, label) (encoders.py:221-224) with the logits gradient produced in the same launch."""
+
+    @staticmethod
+    def forward(ctx, logits, label):
+        logits = logits.contiguous().float()
+        B, C = logits.shape
+        loss = _f32(1, device=logits.device)
+        dlogits = _f32(B, C, device=logits.device)
+        nat.call("softmax_ce_f32", logits, logits.stride(0), label.contiguous(), B, C, loss, dlogits)
+        ctx.save_for_backward(dlogits)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dlogits,) = ctx.saved_tensors
+        return dlogits * g, None
+
+
+def cross_entropy(logits, label):
+    if logits.is_cuda and label.dtype == torch.int64:
+        return _SoftmaxCE.apply(logits, label)
+    return torch.nn.functional.cross_entropy(logits, label, reduction="mean")

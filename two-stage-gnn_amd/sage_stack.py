@@ -29,6 +29,17 @@ def eligible(g, convs, bn, x):
     return x.dim() == 2 and x.size(1) % 4 == 0 and x.is_cuda and x.stride(0) % 4 == 0
 
 
+OVERLAP = False         # (measured slower under hipGraph replay: 308 vs 266 us/step) run work that is off the critical path (readout partials, weight gradients) on a side stream
+_side = {}
+
+
+def _side_stream(dev):
+    st = _side.get(dev)
+    if st is None:
+        st = _side[dev] = torch.cuda.Stream(device=dev)
+    return st
+
+
 def _aggregate_raw(g, x, transposed=False):
     if g.val is None and mp.ell_ok(x) and g.total_rows <= mp.ELL_MAX_ROWS and (not transposed or g.symmetric):
         return mp.spmm_ell(g, x)
@@ -50,6 +61,11 @@ class _SageStack(torch.autograd.Function):
         x = mp._check(x0, R)
         saved = []
         off = 0
+        main = torch.cuda.current_stream()
+        side = _side_stream(dev) if OVERLAP else main
+        keep = []
+        if OVERLAP:
+            side.wait_stream(main)                          # packed zeroed before any partial lands
         for l in range(L):
             K, N = Ws[l].size(0), Ws[l].size(1)
             z = _aggregate_raw(g, x)
@@ -66,10 +82,16 @@ class _SageStack(torch.autograd.Function):
                 y = torch.empty_like(v)
                 nat.call("slot_bn_fwd_f32", g.graph_ptr, g.slot_count, B, g.nmax, g.n_rows, g.n_ghost, v, v.stride(0), N, 1,
                          mean, rstd, y, y.stride(0))
-                nat.call("readout_partial_f32", g.graph_ptr, B, g.nmax, g.n_rows, g.n_ghost, y, y.stride(0), N, pk)
+                if OVERLAP:
+                    side.wait_stream(main)
+                with torch.cuda.stream(side):               # the next layer only needs y: readout runs beside it
+                    nat.call("readout_partial_f32", g.graph_ptr, B, g.nmax, g.n_rows, g.n_ghost, y, y.stride(0), N, pk)
+                keep.append(y)
                 x = y
             else:
                 mean = rstd = None
+                if OVERLAP:
+                    main.wait_stream(side)                  # join: all partials done before the decode
                 nat.call("readout_partial_f32", g.graph_ptr, B, g.nmax, g.n_rows, g.n_ghost, v, v.stride(0), N, pk)
             saved.append((z, v, rinv, mean, rstd))
             off += B * N
@@ -91,6 +113,9 @@ class _SageStack(torch.autograd.Function):
         grads = [None] * (2 * L)
         dxs = None
         dx0 = None
+        main = torch.cuda.current_stream()
+        side = _side_stream(dev) if OVERLAP else main
+        keep = []
         for l in range(L - 1, -1, -1):
             z, v, rinv, mean, rstd = ctx.saved[l]
             W = ctx.Ws[l]
@@ -104,11 +129,15 @@ class _SageStack(torch.autograd.Function):
                      mean, rstd, rinv, du, du.stride(0))
             want_w = ctx.needs_input_grad[3 + 2 * l]
             want_b = ctx.has_bias and ctx.needs_input_grad[4 + 2 * l]
-            if want_w:
-                dw, db = mp.linear_wgrad(z, K, du, want_b)
-                grads[2 * l], grads[2 * l + 1] = dw, db
-            elif want_b:
-                grads[2 * l + 1] = mp.colsum(du)
+            if OVERLAP:
+                side.wait_stream(main)                      # du ready
+            with torch.cuda.stream(side):                   # weight/bias gradients are off the dX critical path
+                if want_w:
+                    dw, db = mp.linear_wgrad(z, K, du, want_b)
+                    grads[2 * l], grads[2 * l + 1] = dw, db
+                elif want_b:
+                    grads[2 * l + 1] = mp.colsum(du)
+            keep.append(du)
             need_dx = l > 0 or ctx.needs_input_grad[0]
             if need_dx:
                 ldz = z.size(1)
@@ -120,6 +149,9 @@ class _SageStack(torch.autograd.Function):
                 dxs = _aggregate_raw(g, dz, transposed=True)
                 if l == 0:
                     dx0 = dxs
+        if OVERLAP:
+            main.wait_stream(side)                          # join before the gradients are consumed
+        del keep
         return (dx0, None, None) + tuple(grads)
 
 
