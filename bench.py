@@ -132,10 +132,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != a.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % max(ndev, 1)            # one GPU per rank on the 8-GPU node; TSGNN_DIST_BACKEND=gloo lets
+    torch.cuda.set_device(dev_index)                 # several ranks share one GPU for a functional rehearsal
+    dev = torch.device("cuda", dev_index)
+    backend = os.environ.get("TSGNN_DIST_BACKEND", "nccl")
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)       # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
 
     from two_stage_gnn_amd import dense_encoders as E
     from two_stage_gnn_amd import synthetic
@@ -172,11 +178,16 @@ def main():
         if use_graph:
             # fwd+bwd+bucket and clip+Adam are captured as two hipGraphs; the RCCL all-reduce is issued
             # between them on the same stream (a single-GPU run replays both back to back).
+            if world > 1:
+                dist.barrier()                                 # no collective in flight while capturing
+                torch.cuda.synchronize()
+            # thread_local: the RCCL watchdog thread may touch the HIP runtime while this thread captures
+            mode = {"capture_error_mode": "thread_local"} if world > 1 else {}
             graph_fb = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph_fb, stream=stream):
+            with torch.cuda.graph(graph_fb, stream=stream, **mode):
                 fwd_bwd()
             graph_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph_opt, stream=stream):
+            with torch.cuda.graph(graph_opt, stream=stream, **mode):
                 trainer.apply()
 
         def step():
