@@ -174,7 +174,8 @@ def filter_adj(edge_index, edge_attr, perm, num_nodes=None):
     E2 = int(pos[-1].item())
     out = torch.empty(2, E2, dtype=torch.int64, device=dev)
     kept = torch.empty(max(E2, 1), dtype=torch.int64, device=dev)
-    nat.call("filter_edges_compact", ei[0], ei[1], E, new_id, flag, pos, out[0], out[1], kept)
+    if E2 > 0:
+        nat.call("filter_edges_compact", ei[0], ei[1], E, new_id, flag, pos, out[0], out[1], kept)
     if edge_attr is not None:
         edge_attr = edge_attr[kept[:E2]]
     return out, edge_attr
