@@ -161,6 +161,9 @@ __global__ __launch_bounds__(256) void gemm_tn_rows_kernel(TnArgs g) {
   const int i = lane & 31, h = lane >> 5;
   const int64_t r0 = (int64_t)blockIdx.x * g.rows_per_slab;
   const int64_t r1 = min(g.rows, r0 + g.rows_per_slab);
+  // gridDim.y blocks share a slab: block y owns output tiles t with t % gridDim.y == y (MFMA work and waves per CU
+  // scale with gridDim.y; the dU chunk is staged by every block, Z by all of them too — both are L2 hits)
+  const int ny = gridDim.y, by = blockIdx.y;
   f32x16 acc[TPW];
 #pragma unroll
   for (int t = 0; t < TPW; ++t)
@@ -210,8 +213,8 @@ __global__ __launch_bounds__(256) void gemm_tn_rows_kernel(TnArgs g) {
       if (rb + TN_CH < r1) load_chunk(rb + TN_CH);     // next chunk flies under the MFMAs
 #pragma unroll
       for (int t = 0; t < TPW; ++t) {
-        const int tile = wid + 4 * t;
-        if (tile < TILES) {
+        const int tile = (wid + 4 * t) * ny + by;
+        if (wid + 4 * t < (TILES + ny - 1) / ny && tile < TILES) {
           const int tm = tile / NTt, tn = tile % NTt;
           const float* ap = Zs + h * KP + tm * 32 + i;   // A[m][k] = Z[row k][m]
           const float* bp = Us + h * NP + tn * 32 + i;   // B[k][j] = dU[row k][j]
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(256) void gemm_tn_rows_kernel(TnArgs g) {
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[s2 * KP], bp[s2 * NP], acc[t], 0, 0, 0);
         }
       }
-      if (tid < NP) {
+      if (by == 0 && tid < NP) {
 #pragma unroll 8
         for (int m = 0; m < TN_CH; ++m) dbacc += Us[m * NP + tid];
       }
@@ -230,8 +233,8 @@ __global__ __launch_bounds__(256) void gemm_tn_rows_kernel(TnArgs g) {
   float* slab = g.slabs + (int64_t)blockIdx.x * (g.K_in + 1) * g.N;
 #pragma unroll
   for (int t = 0; t < TPW; ++t) {
-    const int tile = wid + 4 * t;
-    if (tile < TILES) {
+    const int tile = (wid + 4 * t) * ny + by;
+    if (wid + 4 * t < (TILES + ny - 1) / ny && tile < TILES) {
       const int tm = tile / NTt, tn = tile % NTt;
       const int cn = tn * 32 + (lane & 31);
 #pragma unroll
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(256) void gemm_tn_rows_kernel(TnArgs g) {
       }
     }
   }
-  if (tid < g.N) slab[(int64_t)g.K_in * g.N + tid] = dbacc;
+  if (by == 0 && tid < g.N) slab[(int64_t)g.K_in * g.N + tid] = dbacc;
 }
 
 // out[e] = sum_s slabs[s][e]; e < K_in*N -> dW, else -> db.  64 outputs x 4 slab groups per block.
@@ -349,7 +352,10 @@ int tsgnn_linear_wgrad_f32(const float* z, int64_t ldz, const float* du, int64_t
     return TSGNN_EUNSUPPORTED;
   TnArgs g{z, ldz, du, lddu, rows, rows_per_slab, K_in, N, ws};
   const int mt = (K_in + 31) / 32, nt = (N + 31) / 32;
-#define TSGNN_TN(M_, N_) gemm_tn_rows_kernel<M_, N_><<<nslab, 256, 0, stream>>>(g)
+  const int tiles = mt * nt;
+  const unsigned ny = (tiles >= 8 && nslab < 512) ? 2u : 1u;      // two blocks per slab when there is enough tile work
+  const dim3 grid_tn((unsigned)nslab, ny);
+#define TSGNN_TN(M_, N_) gemm_tn_rows_kernel<M_, N_><<<grid_tn, 256, 0, stream>>>(g)
   switch (mt * 10 + nt) {
     case 11: TSGNN_TN(1, 1); break; case 12: TSGNN_TN(1, 2); break; case 13: TSGNN_TN(1, 3); break; case 14: TSGNN_TN(1, 4); break;
     case 21: TSGNN_TN(2, 1); break; case 22: TSGNN_TN(2, 2); break; case 23: TSGNN_TN(2, 3); break; case 24: TSGNN_TN(2, 4); break;
