@@ -114,6 +114,11 @@ int tsgnn_linear_wgrad_plan(int64_t rows, int K_in, int N, int64_t ldz, int64_t 
                             int64_t* ws_floats);
 int tsgnn_linear_wgrad_f32(const float* z, int64_t ldz, const float* du, int64_t lddu, int64_t rows, int K_in, int N, int nslab,
                            int64_t rows_per_slab, float* ws, float* dw, float* db, tsgnn_stream_t stream);
+/* Ragged batched out[b][K,N] = s[rows_b,:K]^T . x[rows_b,:N] — DiffPool's S^T Z and S^T (A S) (encoders.py:374-375) over
+ * the row ranges of the graphs: graph b owns slabs [seg_slab_ptr[b], seg_slab_ptr[b+1]); slab t covers rows
+ * [slab_row_ptr[t], slab_row_ptr[t+1]).  ws >= nslab*(K+1)*N floats.  ceil(K/32)*ceil(N/32) <= 16. */
+int tsgnn_ragged_tn_f32(const float* s_mat, int64_t lds_, const float* x, int64_t ldx, int K, int N, const int* slab_row_ptr,
+                        int nslab, const int* seg_slab_ptr, int nseg, float* ws, float* out, tsgnn_stream_t stream);
 /* out[f] (+)= sum_r x[r,f] (bias gradients); ws >= ceil(rows/512)*F floats */
 int tsgnn_colsum_f32(const float* x, int64_t ld, int64_t rows, int F, float* out, float* ws, int accumulate,
                      tsgnn_stream_t stream);

@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Secondary BASELINE.json configs (not the bench line): fwd+bwd time of each model family on its synthetic shape,
+plus the DiffPool contraction's MFMA utilisation (flops / time / 157.3 TF fp32-MFMA peak)."""
+import os, sys, time
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from two_stage_gnn_amd import dense_encoders as E, gat_encoders as G, sag_layers as S, synthetic, diffpool as dp, message_passing as mp
+from two_stage_gnn_amd.graph import GraphBatch
+
+
+def timeit(fn, iters=30, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record(); e1.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3     # us
+
+
+class A:
+    bias = True
+
+dev = torch.device("cuda")
+torch.manual_seed(0)
+
+# config 2: PROTEINS SAGE 3-layer h=128 batch 64
+hb = synthetic.host_batch(1, 64, "PROTEINS", 620)
+g, x, label = synthetic.to_device(hb, dev)
+m = E.GcnEncoderGraph(3, 128, 128, 2, 3, bn=True, args=A(), final_dim="number_classes").to(dev)
+def step_sage():
+    m.zero_grad(set_to_none=True); m.loss(m(x, g)[1], label).backward()
+t = timeit(step_sage)
+print("cfg2 PROTEINS SAGE-3L h128 b64 (Nmax 620): %.0f us/step eager, %.0f graphs/s" % (t, 64 / t * 1e6))
+
+# config 3: DD GAT 2-layer 4-head h=64, batch 32 graphs = 32 sequential B=1 forwards (the reference's GAT batch size is 1)
+hb1 = synthetic.host_batch(2, 1, "DD", 1000)
+x1, adj1 = synthetic.to_dense(hb1)
+gat = G.DGATEncoderGraph(89, 64, 64, 2, None, num_layers=2, num_heads=[4, 4], final_dim="number_classes").to(dev)
+x1, adj1 = x1.to(dev), adj1.to(dev)
+gpad = GraphBatch.from_dense(adj1, layout="padded"); gpad.transpose_map()
+lab1 = torch.tensor([1], device=dev)
+def step_gat():
+    gat.zero_grad(set_to_none=True); gat.loss(gat(x1, gpad)[1], lab1).backward()
+t = timeit(step_gat)
+print("cfg3 DD GAT-2L 4 heads h64, one graph per step (Nmax 1000): %.0f us/step eager, %.0f graphs/s" % (t, 1 / t * 1e6))
+
+# config 4: IMDB-B SAGPool ratio .5 h=128 batch 128 (PyG per-graph semantics)
+hb4 = synthetic.host_batch(3, 128, "IMDB-BINARY", 136)
+sizes = hb4["sizes"]; rp = hb4["rowptr"][: int(sizes.sum()) + 1]; col = hb4["col"]
+dst = np.repeat(np.arange(int(sizes.sum())), np.diff(rp))
+ei = torch.from_numpy(np.stack([col.astype(np.int64), dst.astype(np.int64)])).to(dev)
+class D: pass
+d = D(); d.x = torch.ones(int(sizes.sum()), 1, device=dev); d.edge_index = ei
+d.batch = torch.repeat_interleave(torch.arange(128), torch.from_numpy(sizes)).to(dev)
+net = S.Net(1, 128, 2, 0.5, 0.5, use_batch=True).to(dev).train()
+lab4 = torch.from_numpy(hb4["label"]).to(dev)
+def step_sag():
+    net.zero_grad(set_to_none=True); torch.nn.functional.nll_loss(net(d), lab4).backward()
+t = timeit(step_sag, iters=10, warm=3)
+print("cfg4 IMDB-B SAGPool(0.5) h128 b128: %.0f us/step eager (host syncs for k / E'), %.0f graphs/s" % (t, 128 / t * 1e6))
+
+# config 5: DD DiffPool 64 -> 8, h=64, batch 16, Nmax 512
+hb5 = synthetic.host_batch(4, 16, "DD", 512)
+g5, x5, lab5 = synthetic.to_device(hb5, dev)
+dpm = E.SoftPoolingGcnEncoder(512, 89, 64, 64, 2, 3, 64, assign_ratio=0.125, num_pooling=2, bn=True, linkpred=False, args=A(),
+                              assign_input_dim=89, final_dim="number_classes").to(dev)
+def step_dp():
+    dpm.zero_grad(set_to_none=True); dpm.loss(dpm(x5, g5, hb5["sizes"], assign_x=x5)[1], lab5).backward()
+t = timeit(step_dp, iters=10, warm=3)
+print("cfg5 DD DiffPool 512->64->8 h64 b16: %.0f us/step eager, %.0f graphs/s" % (t, 16 / t * 1e6))
+# the contraction alone, level 1 (S [rows,64], Z [rows,192]) + level 2 dense
+Sm = torch.softmax(torch.randn(g5.total_rows, 64, device=dev), -1); Sm[g5.n_rows:] = 0
+Z = torch.randn(g5.total_rows, 192, device=dev)
+gr = torch.cuda.CUDAGraph(); st = torch.cuda.Stream()
+with torch.cuda.stream(st):
+    for _ in range(3):
+        dp.diffpool_contract_rows(Sm, Z, g5)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(gr, stream=st):
+        for _ in range(20):
+            xo, ao = dp.diffpool_contract_rows(Sm, Z, g5)
+    gr.replay(); torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record(st); gr.replay(); e1.record(st); e1.synchronize()
+    us = e0.elapsed_time(e1) / 20 * 1e3
+nb = hb5["sizes"].astype(np.float64)
+dense_flops = 16 * (2 * 512 * 512 * 64 + 2 * 64 * 512 * 64 + 2 * 64 * 512 * 192)          # reference's padded bmm's, level 1
+sparse_flops = 2 * g5.nnz * 64 + float((2 * 64 * nb * 64 + 2 * 64 * nb * 192).sum())    # what is executed: SpMM + ragged GEMMs
+print("cfg5 level-1 contraction X'=S^T Z, A'=S^T A S (3 launches): %.1f us ; executed %.1f MFLOP -> %.1f TF (%.1f%% of 157.3 TF fp32 MFMA); "
+      "reference-equivalent dense work %.1f MFLOP -> %.1f TF-equivalent (%.0f%%)"
+      % (us, sparse_flops / 1e6, sparse_flops / us / 1e6, sparse_flops / us / 1e6 / 157.3 * 100, dense_flops / 1e6,
+         dense_flops / us / 1e6, dense_flops / us / 1e6 / 157.3 * 100))

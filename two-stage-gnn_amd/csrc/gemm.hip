@@ -148,6 +148,7 @@ struct TnArgs {
   int64_t rows, rows_per_slab;
   int K_in, N;
   float* slabs;                      // [nslab][K_in + 1][N]
+  const int* slab_row_ptr;           // nullable: slab s covers rows [slab_row_ptr[s], slab_row_ptr[s+1]) (ragged, per graph)
 };
 
 template <int MT, int NTt>
@@ -159,8 +160,8 @@ __global__ __launch_bounds__(256) void gemm_tn_rows_kernel(TnArgs g) {
   __shared__ __attribute__((aligned(16))) float Us[TN_CH * NP];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int i = lane & 31, h = lane >> 5;
-  const int64_t r0 = (int64_t)blockIdx.x * g.rows_per_slab;
-  const int64_t r1 = min(g.rows, r0 + g.rows_per_slab);
+  const int64_t r0 = g.slab_row_ptr ? (int64_t)g.slab_row_ptr[blockIdx.x] : (int64_t)blockIdx.x * g.rows_per_slab;
+  const int64_t r1 = g.slab_row_ptr ? (int64_t)g.slab_row_ptr[blockIdx.x + 1] : min(g.rows, r0 + g.rows_per_slab);
   // gridDim.y blocks share a slab: block y owns output tiles t with t % gridDim.y == y (MFMA work and waves per CU
   // scale with gridDim.y; the dU chunk is staged by every block, Z by all of them too — both are L2 hits)
   const int ny = gridDim.y, by = blockIdx.y;
@@ -249,14 +250,19 @@ __global__ __launch_bounds__(256) void gemm_tn_rows_kernel(TnArgs g) {
 
 // out[e] = sum_s slabs[s][e]; e < K_in*N -> dW, else -> db.  64 outputs x 4 slab groups per block.
 __global__ __launch_bounds__(256) void tn_rows_reduce(const float* __restrict__ slabs, int nslab, int64_t per_slab, int64_t n_w,
-                                                      float* __restrict__ dw, float* __restrict__ db) {
+                                                      float* __restrict__ dw, float* __restrict__ db,
+                                                      const int* __restrict__ seg_slab_ptr) {
   __shared__ float lds[4][64];
   const int e_l = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int64_t e = (int64_t)blockIdx.x * 64 + e_l;
+  // blockIdx.y = segment (graph): sums only that segment's slabs into dw[seg]
+  const int sb = seg_slab_ptr ? seg_slab_ptr[blockIdx.y] : 0;
+  const int se = seg_slab_ptr ? seg_slab_ptr[blockIdx.y + 1] : nslab;
+  dw += (int64_t)blockIdx.y * n_w;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   if (e < per_slab) {
-    const int per = (nslab + 3) / 4;
-    const int s0 = grp * per, s1 = min(nslab, s0 + per);
+    const int per = (se - sb + 3) / 4;
+    const int s0 = sb + grp * per, s1 = min(se, s0 + per);
     int s = s0;
     for (; s + 4 <= s1; s += 4) {
       a0 += slabs[(int64_t)s * per_slab + e];
@@ -350,7 +356,7 @@ int tsgnn_linear_wgrad_f32(const float* z, int64_t ldz, const float* du, int64_t
   if (K_in > 128 || N > 128 || (ldz % 4) || (lddu % 4) || (N % 4) || (reinterpret_cast<uintptr_t>(z) & 15) ||
       (reinterpret_cast<uintptr_t>(du) & 15))
     return TSGNN_EUNSUPPORTED;
-  TnArgs g{z, ldz, du, lddu, rows, rows_per_slab, K_in, N, ws};
+  TnArgs g{z, ldz, du, lddu, rows, rows_per_slab, K_in, N, ws, nullptr};
   const int mt = (K_in + 31) / 32, nt = (N + 31) / 32;
   const int tiles = mt * nt;
   const unsigned ny = (tiles >= 8 && nslab < 512) ? 2u : 1u;      // two blocks per slab when there is enough tile work
@@ -364,7 +370,38 @@ int tsgnn_linear_wgrad_f32(const float* z, int64_t ldz, const float* du, int64_t
   }
 #undef TSGNN_TN
   const int64_t per_slab = (int64_t)(K_in + 1) * N;
-  tn_rows_reduce<<<(unsigned)ceil_div64(per_slab, 64), 256, 0, stream>>>(ws, nslab, per_slab, (int64_t)K_in * N, dw, db);
+  tn_rows_reduce<<<(unsigned)ceil_div64(per_slab, 64), 256, 0, stream>>>(ws, nslab, per_slab, (int64_t)K_in * N, dw, db, nullptr);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+/* Ragged batched  out[b][K,N] = S[rows_b, :K]^T . X[rows_b, :N]  (DiffPool's S^T Z and S^T (A S), encoders.py:374-375):
+ * every graph is cut into row slabs (slab_row_ptr[nslab+1], graph b owns slabs [seg_slab_ptr[b], seg_slab_ptr[b+1])),
+ * each slab is one workgroup of MFMA work, slabs are summed per graph in fixed order.  ceil(K/32)*ceil(N/32) <= 16. */
+int tsgnn_ragged_tn_f32(const float* s_mat, int64_t lds_, const float* x, int64_t ldx, int K, int N, const int* slab_row_ptr,
+                        int nslab, const int* seg_slab_ptr, int nseg, float* ws, float* out, tsgnn_stream_t stream) {
+  if (!s_mat || !x || !slab_row_ptr || !seg_slab_ptr || !ws || !out || K <= 0 || N <= 0 || nslab <= 0 || nseg <= 0) return TSGNN_EINVAL;
+  const int mt = (K + 31) / 32, nt = (N + 31) / 32;
+  if (mt * nt > 16 || mt > 4 || nt > 8 || (lds_ % 4) || (ldx % 4) || (N % 4) || (reinterpret_cast<uintptr_t>(s_mat) & 15) ||
+      (reinterpret_cast<uintptr_t>(x) & 15))
+    return TSGNN_EUNSUPPORTED;
+  TnArgs g{s_mat, lds_, x, ldx, 0, 0, K, N, ws, slab_row_ptr};
+  const unsigned ny = (mt * nt >= 8) ? 2u : 1u;
+  const dim3 grid((unsigned)nslab, ny);
+#define TSGNN_RT(M_, N_) gemm_tn_rows_kernel<M_, N_><<<grid, 256, 0, stream>>>(g)
+  switch (mt * 10 + nt) {
+    case 11: TSGNN_RT(1, 1); break; case 12: TSGNN_RT(1, 2); break; case 13: TSGNN_RT(1, 3); break; case 14: TSGNN_RT(1, 4); break;
+    case 15: TSGNN_RT(1, 5); break; case 16: TSGNN_RT(1, 6); break; case 17: TSGNN_RT(1, 7); break; case 18: TSGNN_RT(1, 8); break;
+    case 21: TSGNN_RT(2, 1); break; case 22: TSGNN_RT(2, 2); break; case 23: TSGNN_RT(2, 3); break; case 24: TSGNN_RT(2, 4); break;
+    case 25: TSGNN_RT(2, 5); break; case 26: TSGNN_RT(2, 6); break; case 27: TSGNN_RT(2, 7); break; case 28: TSGNN_RT(2, 8); break;
+    case 31: TSGNN_RT(3, 1); break; case 32: TSGNN_RT(3, 2); break; case 33: TSGNN_RT(3, 3); break; case 34: TSGNN_RT(3, 4); break;
+    case 35: TSGNN_RT(3, 5); break;
+    case 41: TSGNN_RT(4, 1); break; case 42: TSGNN_RT(4, 2); break; case 43: TSGNN_RT(4, 3); break; default: TSGNN_RT(4, 4); break;
+  }
+#undef TSGNN_RT
+  const int64_t per_slab = (int64_t)(K + 1) * N;
+  dim3 rgrid((unsigned)ceil_div64((int64_t)K * N, 64), (unsigned)nseg);
+  tn_rows_reduce<<<rgrid, 256, 0, stream>>>(ws, nslab, per_slab, (int64_t)K * N, out, nullptr, seg_slab_ptr);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }

@@ -89,6 +89,13 @@ def _ragged_tn(S, X, g):
     """out[b] = S[rows_b]^T @ X[rows_b]  -> [B, K, F]   (K-ragged batched GEMM)."""
     K, F = S.size(1), X.size(1)
     out = _f32(g.B, K, F, device=S.device)
+    tiles = ((K + 31) // 32) * ((F + 31) // 32)
+    if (tiles <= 16 and K <= 128 and F <= 256 and F % 4 == 0 and S.stride(0) % 4 == 0 and X.stride(0) % 4 == 0
+            and S.data_ptr() % 16 == 0 and X.data_ptr() % 16 == 0 and g.n_rows > 0):
+        srp, ssp, nslab = g.row_slabs()
+        ws = _f32(nslab * (K + 1) * F, device=S.device)
+        nat.call("ragged_tn_f32", S, S.stride(0), X, X.stride(0), K, F, srp, nslab, ssp, g.B, ws, out)
+        return out
     mp.gemm(S, 1, S.stride(0), X, X.stride(0), 1, out, F, 1, K, F, 0, batch=g.B, stride_c=K * F, seg_ptr=g.graph_ptr,
             ragged=1, max_seg=int(g.sizes.max()))
     return out

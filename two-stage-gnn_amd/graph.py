@@ -168,6 +168,37 @@ class GraphBatch:
         g.symmetric = bool(assume_symmetric)
         return g
 
+    # ------------------------------------------------------------------ row slabs per graph (ragged contractions)
+    def row_slabs(self, rows_per_slab=64):
+        """(slab_row_ptr int32[nslab+1], seg_slab_ptr int32[B+1], nslab): every graph's real rows cut into slabs of at
+        most ``rows_per_slab`` rows (one workgroup of MFMA work each)."""
+        cache = getattr(self, "_slabs", None)
+        if cache is None or cache[3] != rows_per_slab:
+            starts, seg = [], [0]
+            off = 0
+            for n in self.sizes:
+                n = int(n)
+                for r in range(0, n, rows_per_slab):
+                    starts.append(off + r)
+                seg.append(len(starts))
+                off += n
+            # a graph without rows still needs a (possibly empty) entry: its segment is simply empty
+            srp = np.asarray(starts + [off], dtype=np.int32)
+            # slab t ends where the next starts, except at graph ends: build explicit ends
+            ends = []
+            off = 0
+            for n in self.sizes:
+                n = int(n)
+                for r in range(0, n, rows_per_slab):
+                    ends.append(off + min(n, r + rows_per_slab))
+                off += n
+            # the kernel reads [ptr[t], ptr[t+1]): consecutive slabs are contiguous inside a graph and graphs are
+            # contiguous too, so starts + [total] is exactly the boundary list
+            assert all(e == s2 for e, s2 in zip(ends, list(srp[1:])))
+            cache = self._slabs = (torch.from_numpy(srp).to(self.device),
+                                   torch.from_numpy(np.asarray(seg, dtype=np.int32)).to(self.device), len(starts), rows_per_slab)
+        return cache[0], cache[1], cache[2]
+
     # ------------------------------------------------------------------ fixed-width (ELL) view
     def ell(self):
         """(ell_col int32[R,W], W, tail) for the unit-weight aggregation fast path, or None when the graph is
