@@ -1,0 +1,106 @@
+"""TU reader + CSR-native collate.  CPU: the vectorised reader against a networkx
+restatement of load_data.read_graphfile's rules (load_data.py:12-126).  GPU: collate -> encoder == dense path."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+def write_tu(tmp, name, seed=0, n_graphs=7):
+    rng = np.random.default_rng(seed)
+    d = os.path.join(tmp, name)
+    os.makedirs(d, exist_ok=True)
+    indic, edges, nlab, glab = [], [], [], []
+    nid = 1
+    for g in range(1, n_graphs + 1):
+        n = int(rng.integers(3, 12))
+        ids = list(range(nid, nid + n))
+        nid += n
+        indic += [g] * n
+        nlab += [int(rng.integers(1, 5)) for _ in ids]
+        glab.append([7, -1, 3][g % 3])                       # non-consecutive labels, renumbered by first appearance
+        m = int(rng.integers(1, 2 * n))
+        for _ in range(m):
+            u, v = rng.choice(ids, 2)
+            edges.append((int(u), int(v)))                  # may contain duplicates and self loops; some nodes stay isolated
+            if rng.random() < 0.5:
+                edges.append((int(v), int(u)))
+    pre = os.path.join(d, name)
+    open(pre + "_graph_indicator.txt", "w").write("\n".join(map(str, indic)) + "\n")
+    open(pre + "_graph_labels.txt", "w").write("\n".join(map(str, glab)) + "\n")
+    open(pre + "_node_labels.txt", "w").write("\n".join(map(str, nlab)) + "\n")
+    open(pre + "_A.txt", "w").write("\n".join("%d, %d" % e for e in edges) + "\n")
+    return indic, edges, nlab, glab
+
+
+def nx_reference(indic, edges, nlab, glab, max_nodes):
+    """the reference's construction rules, restated with networkx (load_data.py:72-121)."""
+    import networkx as nx
+    label_vals = []
+    for v in glab:
+        if v not in label_vals:
+            label_vals.append(v)
+    adj_list = {i: [] for i in range(1, len(glab) + 1)}
+    for e0, e1 in edges:
+        adj_list[indic[e0 - 1]].append((e0, e1))
+    out = []
+    k = max(nlab)
+    for i in range(1, len(glab) + 1):
+        G = nx.from_edgelist(adj_list[i])
+        if max_nodes is not None and G.number_of_nodes() > max_nodes:
+            continue
+        nodes = list(G.nodes)
+        A = np.asarray(nx.to_numpy_array(G, nodelist=nodes)) if nodes else np.zeros((0, 0))
+        onehot = np.zeros((len(nodes), k), dtype=np.float32)
+        for r, u in enumerate(nodes):
+            onehot[r, nlab[u - 1] - 1] = 1
+        out.append((A, onehot, label_vals.index(glab[i - 1])))
+    return out
+
+
+@pytest.mark.parametrize("max_nodes", [None, 8])
+def test_reader_matches_networkx_rules(tmp_path, max_nodes):
+    from two_stage_gnn_amd.tu_data import read_tu
+    raw = write_tu(str(tmp_path), "TOY", seed=3)
+    ds = read_tu(str(tmp_path), "TOY", max_nodes=max_nodes)
+    ref = nx_reference(*raw, max_nodes=max_nodes)
+    assert len(ds) == len(ref)
+    feats = ds.features("node-label")
+    for i, (A, onehot, lab) in enumerate(ref):
+        n = A.shape[0]
+        assert ds.sizes[i] == n
+        np.testing.assert_array_equal(ds.dense(i, max(n, 1))[:n, :n], (A > 0).astype(np.float32))
+        np.testing.assert_array_equal(feats[ds.graph_ptr[i]:ds.graph_ptr[i + 1]], onehot)
+        assert ds.graph_label[i] == lab
+
+
+@pytest.mark.gpu
+def test_collate_equals_dense_path(tmp_path):
+    from oracle import dense_ref as R
+    from two_stage_gnn_amd import dense_encoders as E
+    from two_stage_gnn_amd.tu_data import read_tu
+    write_tu(str(tmp_path), "TOY", seed=5, n_graphs=9)
+    ds = read_tu(str(tmp_path), "TOY")
+    nmax = ds.max_num_nodes()
+    feats = ds.features("node-label")
+    idx = [0, 3, 4, 8]
+    g, x, y = ds.collate(idx, nmax, feats, torch.device("cuda"))
+    # the reference's dense tensors of the same mini-batch
+    B, F = len(idx), feats.shape[1]
+    adj = torch.zeros(B, nmax, nmax); xd = torch.zeros(B, nmax, F)
+    for k, i in enumerate(idx):
+        n = int(ds.sizes[i])
+        adj[k] = torch.from_numpy(ds.dense(i, nmax))
+        xd[k, :n] = torch.from_numpy(feats[ds.graph_ptr[i]:ds.graph_ptr[i + 1]])
+
+    class A:
+        bias = True
+    torch.manual_seed(0)
+    m = E.GcnEncoderGraph(F, 8, 8, 3, 3, bn=True, args=A(), final_dim="number_classes").cuda()
+    a, b = m(x, g)
+    p = {k2: v.detach().cpu() for k2, v in m.state_dict().items()}
+    a_ref, b_ref = R.gcn_encoder(p, xd, adj, bn=True, final_dim="number_classes")
+    torch.testing.assert_close(a.cpu(), a_ref, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(b.cpu(), b_ref, rtol=1e-4, atol=1e-4)
+    assert y.tolist() == ds.graph_label[idx].tolist()
