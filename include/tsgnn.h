@@ -114,6 +114,12 @@ int tsgnn_linear_wgrad_plan(int64_t rows, int K_in, int N, int64_t ldz, int64_t 
                             int64_t* ws_floats);
 int tsgnn_linear_wgrad_f32(const float* z, int64_t ldz, const float* du, int64_t lddu, int64_t rows, int K_in, int N, int nslab,
                            int64_t rows_per_slab, float* ws, float* dw, float* db, tsgnn_stream_t stream);
+/* dw == NULL above leaves the slabs in ws; this reduces up to four such slab sets (all layers of one backward pass) in ONE
+ * launch.  Unused sets: ws == NULL. */
+int tsgnn_wgrad_reduce_multi_f32(const float* ws0, int nslab0, int K0, int N0, float* dw0, float* db0, const float* ws1, int nslab1,
+                                 int K1, int N1, float* dw1, float* db1, const float* ws2, int nslab2, int K2, int N2, float* dw2,
+                                 float* db2, const float* ws3, int nslab3, int K3, int N3, float* dw3, float* db3,
+                                 tsgnn_stream_t stream);
 /* Ragged batched out[b][K,N] = s[rows_b,:K]^T . x[rows_b,:N] — DiffPool's S^T Z and S^T (A S) (encoders.py:374-375) over
  * the row ranges of the graphs: graph b owns slabs [seg_slab_ptr[b], seg_slab_ptr[b+1]); slab t covers rows
  * [slab_row_ptr[t], slab_row_ptr[t+1]).  ws >= nslab*(K+1)*N floats.  ceil(K/32)*ceil(N/32) <= 16. */
@@ -269,6 +275,17 @@ int tsgnn_readout_partial_f32(const int* graph_ptr, int B, int nmax, int64_t n_r
                               unsigned long long* packed, tsgnn_stream_t stream);
 int tsgnn_readout_decode_layers_f32(const unsigned long long* packed, int B, int L, int Fh, int Fl, float* out, int64_t ldo, int* arg,
                                     tsgnn_stream_t stream);
+
+/* ---------------------------------------------------------------- graph-level head (head.hip) */
+
+/* vec = W1 out + b1 ; y = W2 vec + b2  — the two chained nn.Linear after the readout (pre_pred_model -> pred_model,
+ * or map_model -> map2_model; encoders.py:207-217).  W1 [E,P], W2 [C,E] as nn.Linear stores them.  P % 4 == 0. */
+int tsgnn_head2_fwd_f32(const float* out, int64_t ldo, const float* w1, const float* b1, const float* w2, const float* b2, int B, int P,
+                        int E, int C, float* vec, float* y, tsgnn_stream_t stream);
+/* backward: dvt = dvec (nullable) + W2^T dy ; dout = W1^T dvt ; dW1 = dvt^T out ; db1 ; dW2 = dy^T vec ; db2 */
+int tsgnn_head2_bwd_f32(const float* out, int64_t ldo, const float* vec, const float* dy, const float* dvec, const float* w1,
+                        const float* w2, int B, int P, int E, int C, float* dvt, float* dout, int64_t lddo, float* dw1, float* db1,
+                        float* dw2, float* db2, tsgnn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -48,6 +48,7 @@ def test_graphconv_golden(tag, path, monkeypatch):
 def test_gcn_encoder_golden(tag, layout, fused, monkeypatch):
     from two_stage_gnn_amd import dense_encoders as E
     monkeypatch.setattr(E, "FUSED_STACK", fused)
+    monkeypatch.setattr(E, "FUSED_HEAD", fused)
     g = load_golden("gcn_encoder_" + tag)
     fin, hid, emb, lab = (int(v) for v in g["dims"])
 

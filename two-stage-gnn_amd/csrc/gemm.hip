@@ -281,6 +281,40 @@ __global__ __launch_bounds__(256) void tn_rows_reduce(const float* __restrict__ 
   }
 }
 
+
+struct ReduceSet { const float* slabs; int nslab; int64_t per_slab; int64_t n_w; float* dw; float* db; int64_t first_block; };
+struct ReduceMulti { ReduceSet s[4]; int n; };
+// several independent slab sets (the layers of one backward pass) reduced by ONE launch
+__global__ __launch_bounds__(256) void tn_rows_reduce_multi(ReduceMulti m) {
+  __shared__ float lds[4][64];
+  int k = 0;
+#pragma unroll
+  for (int t = 1; t < 4; ++t) if (t < m.n && (int64_t)blockIdx.x >= m.s[t].first_block) k = t;
+  const ReduceSet r = m.s[k];
+  const int e_l = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int64_t e = ((int64_t)blockIdx.x - r.first_block) * 64 + e_l;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (e < r.per_slab) {
+    const int per = (r.nslab + 3) / 4;
+    const int s0 = grp * per, s1 = min(r.nslab, s0 + per);
+    int s = s0;
+    for (; s + 4 <= s1; s += 4) {
+      a0 += r.slabs[(int64_t)s * r.per_slab + e];
+      a1 += r.slabs[(int64_t)(s + 1) * r.per_slab + e];
+      a2 += r.slabs[(int64_t)(s + 2) * r.per_slab + e];
+      a3 += r.slabs[(int64_t)(s + 3) * r.per_slab + e];
+    }
+    for (; s < s1; ++s) a0 += r.slabs[(int64_t)s * r.per_slab + e];
+  }
+  lds[grp][e_l] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (grp == 0 && e < r.per_slab) {
+    const float v = (lds[0][e_l] + lds[1][e_l]) + (lds[2][e_l] + lds[3][e_l]);
+    if (e < r.n_w) r.dw[e] = v;
+    else if (r.db) r.db[e - r.n_w] = v;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -349,10 +383,39 @@ int tsgnn_linear_wgrad_plan(int64_t rows, int K_in, int N, int64_t ldz, int64_t 
   return TSGNN_OK;
 }
 
-/* dW[K_in,N] = z[:, :K_in]^T . du ; db[N] = colsum(du) (db nullable).  Plan with tsgnn_linear_wgrad_plan. */
+/* reduce up to four slab sets (written by tsgnn_linear_wgrad_f32 with dw == NULL) in ONE launch: the weight gradients of all
+ * layers of a backward pass.  Unused sets: ws == NULL. */
+int tsgnn_wgrad_reduce_multi_f32(const float* ws0, int nslab0, int K0, int N0, float* dw0, float* db0, const float* ws1, int nslab1,
+                                 int K1, int N1, float* dw1, float* db1, const float* ws2, int nslab2, int K2, int N2, float* dw2,
+                                 float* db2, const float* ws3, int nslab3, int K3, int N3, float* dw3, float* db3,
+                                 tsgnn_stream_t stream) {
+  const float* ws[4] = {ws0, ws1, ws2, ws3};
+  const int ns[4] = {nslab0, nslab1, nslab2, nslab3}, Ks[4] = {K0, K1, K2, K3}, Ns[4] = {N0, N1, N2, N3};
+  float* dws[4] = {dw0, dw1, dw2, dw3};
+  float* dbs[4] = {db0, db1, db2, db3};
+  ReduceMulti m;
+  m.n = 0;
+  int64_t blocks = 0;
+  for (int t = 0; t < 4; ++t) {
+    if (!ws[t]) continue;
+    if (ns[t] <= 0 || Ks[t] <= 0 || Ns[t] <= 0 || !dws[t]) return TSGNN_EINVAL;
+    const int64_t per_slab = (int64_t)(Ks[t] + 1) * Ns[t];
+    m.s[m.n] = ReduceSet{ws[t], ns[t], per_slab, (int64_t)Ks[t] * Ns[t], dws[t], dbs[t], blocks};
+    blocks += ceil_div64(per_slab, 64);
+    ++m.n;
+  }
+  if (m.n == 0) return TSGNN_OK;
+  for (int t = m.n; t < 4; ++t) m.s[t] = m.s[0];
+  tn_rows_reduce_multi<<<(unsigned)blocks, 256, 0, stream>>>(m);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+/* dW[K_in,N] = z[:, :K_in]^T . du ; db[N] = colsum(du) (db nullable).  Plan with tsgnn_linear_wgrad_plan.
+ * dw == NULL: only the slabs are produced (reduce them later with tsgnn_wgrad_reduce_multi_f32). */
 int tsgnn_linear_wgrad_f32(const float* z, int64_t ldz, const float* du, int64_t lddu, int64_t rows, int K_in, int N, int nslab,
                            int64_t rows_per_slab, float* ws, float* dw, float* db, tsgnn_stream_t stream) {
-  if (!z || !du || !ws || !dw || rows < 0 || nslab <= 0 || rows_per_slab <= 0 || K_in <= 0 || N <= 0) return TSGNN_EINVAL;
+  if (!z || !du || !ws || rows < 0 || nslab <= 0 || rows_per_slab <= 0 || K_in <= 0 || N <= 0) return TSGNN_EINVAL;
   if (K_in > 128 || N > 128 || (ldz % 4) || (lddu % 4) || (N % 4) || (reinterpret_cast<uintptr_t>(z) & 15) ||
       (reinterpret_cast<uintptr_t>(du) & 15))
     return TSGNN_EUNSUPPORTED;
@@ -370,7 +433,7 @@ int tsgnn_linear_wgrad_f32(const float* z, int64_t ldz, const float* du, int64_t
   }
 #undef TSGNN_TN
   const int64_t per_slab = (int64_t)(K_in + 1) * N;
-  tn_rows_reduce<<<(unsigned)ceil_div64(per_slab, 64), 256, 0, stream>>>(ws, nslab, per_slab, (int64_t)K_in * N, dw, db, nullptr);
+  if (dw) tn_rows_reduce<<<(unsigned)ceil_div64(per_slab, 64), 256, 0, stream>>>(ws, nslab, per_slab, (int64_t)K_in * N, dw, db, nullptr);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }

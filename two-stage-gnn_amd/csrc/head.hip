@@ -1,0 +1,178 @@
+// Graph-level prediction head of the encoders (encoders.py:207-217 / :396-406): two chained nn.Linear on the
+// concatenated readout [B, P]  ->  vec [B, E]  ->  y [B, C],  forward and backward in 1 + 2 launches instead of the
+// ~8 library launches (2 addmm, 4 mm, 2 bias reductions) a B = 32 batch spends most of its time dispatching.
+// Shapes are tiny (B <= a few hundred rows): one workgroup per graph row, weights streamed from L2 with 16-byte loads.
+#include "common.h"
+#include "../../include/tsgnn.h"
+
+namespace {
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// block b: vec[b,:] = W1 out[b,:] + b1 ; y[b,:] = W2 vec[b,:] + b2        (W1 [E,P], W2 [C,E] row-major = nn.Linear.weight)
+constexpr int HW = 16;   // waves per row block (1024 threads): one batch of 8 weight rows per wave covers E = 128
+
+__global__ __launch_bounds__(64 * HW) void head2_fwd_kernel(const float* __restrict__ out, int64_t ldo, const float* __restrict__ w1,
+                                                        const float* __restrict__ b1, const float* __restrict__ w2,
+                                                        const float* __restrict__ b2, int P, int E, int C,
+                                                        float* __restrict__ vec, float* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* xs = smem;                 // [P]
+  float* vs = smem + ((P + 3) & ~3);  // [E]
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  for (int k = tid; k < P; k += 64 * HW) xs[k] = out[(int64_t)b * ldo + k];
+  __syncthreads();
+  const int P4 = P >> 2;
+  // each wave owns rows j = wid, wid+4, ...; eight rows are in flight per iteration (independent 16-byte loads),
+  // their dot products are reduced together
+  for (int j0 = wid; j0 < E; j0 += 8 * HW) {
+    float acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+    for (int k4 = lane; k4 < P4; k4 += 64) {
+      const float4 x = *reinterpret_cast<const float4*>(xs + 4 * k4);
+      float4 w[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int j = j0 + HW * u;
+        w[u] = ld4(w1 + (int64_t)(j < E ? j : 0) * P + 4 * k4);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] += (w[u].x * x.x + w[u].y * x.y) + (w[u].z * x.z + w[u].w * x.w);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int j = j0 + HW * u;
+      const float r = wave_sum(acc[u]);
+      if (lane == 0 && j < E) { const float v = r + (b1 ? b1[j] : 0.f); vs[j] = v; vec[(int64_t)b * E + j] = v; }
+    }
+  }
+  __syncthreads();
+  for (int c = wid; c < C; c += HW) {
+    float acc = 0.f;
+    for (int j = lane; j < E; j += 64) acc = fmaf(w2[(int64_t)c * E + j], vs[j], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) y[(int64_t)b * C + c] = acc + (b2 ? b2[c] : 0.f);
+  }
+}
+
+// block b: dvt[b,:] = dvec[b,:] + W2^T dy[b,:] ;  dout[b,:] = W1^T dvt[b,:]
+__global__ __launch_bounds__(64 * HW) void head2_bwd_rows_kernel(const float* __restrict__ dy, const float* __restrict__ dvec,
+                                                             const float* __restrict__ w1, const float* __restrict__ w2, int P,
+                                                             int E, int C, float* __restrict__ dvt, float* __restrict__ dout,
+                                                             int64_t ldo) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* ds = smem;                          // [E] dvt row
+  float* part = smem + ((E + 3) & ~3);       // [HW][P] partial dout
+  const int b = blockIdx.x, tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+  for (int j = tid; j < E; j += 64 * HW) {
+    float acc = dvec ? dvec[(int64_t)b * E + j] : 0.f;
+    for (int c = 0; c < C; ++c) acc = fmaf(dy[(int64_t)b * C + c], w2[(int64_t)c * E + j], acc);
+    ds[j] = acc;
+    dvt[(int64_t)b * E + j] = acc;
+  }
+  __syncthreads();
+  // each wave takes every 4th row j of W1 and accumulates its contribution to all P columns
+  const int P4 = P >> 2;
+  for (int k4 = lane; k4 < P4 + ((P & 3) ? 1 : 0); k4 += 64) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k4 < P4) {
+      for (int j = wid; j < E; j += HW) {
+        const float4 w = ld4(w1 + (int64_t)j * P + 4 * k4);
+        const float d = ds[j];
+        acc.x = fmaf(d, w.x, acc.x); acc.y = fmaf(d, w.y, acc.y); acc.z = fmaf(d, w.z, acc.z); acc.w = fmaf(d, w.w, acc.w);
+      }
+      *reinterpret_cast<float4*>(part + wid * ((P + 3) & ~3) + 4 * k4) = acc;
+    } else {
+      for (int k = 4 * P4; k < P; ++k) {
+        float a = 0.f;
+        for (int j = wid; j < E; j += HW) a = fmaf(ds[j], w1[(int64_t)j * P + k], a);
+        part[wid * ((P + 3) & ~3) + k] = a;
+      }
+    }
+  }
+  __syncthreads();
+  const int PP = (P + 3) & ~3;
+  for (int k = tid; k < P; k += 64 * HW) {
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < HW; ++w) a += part[w * PP + k];
+    dout[(int64_t)b * ldo + k] = a;
+  }
+}
+
+// weights: block jb owns rows j = 4*jb .. 4*jb+3 of dW1 (+ db1); the last block also produces dW2, db2
+__global__ __launch_bounds__(256) void head2_bwd_weights_kernel(const float* __restrict__ out, int64_t ldo, const float* __restrict__ vec,
+                                                                const float* __restrict__ dvt, const float* __restrict__ dy, int B, int P,
+                                                                int E, int C, float* __restrict__ dw1, float* __restrict__ db1,
+                                                                float* __restrict__ dw2, float* __restrict__ db2) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [B][4] dvt slice
+  const int tid = threadIdx.x;
+  const int nj = (E + 3) / 4;
+  if ((int)blockIdx.x < nj) {
+    const int j0 = 4 * blockIdx.x;
+    for (int i = tid; i < B * 4; i += 256) {
+      const int bb = i >> 2, jj = j0 + (i & 3);
+      smem[i] = jj < E ? dvt[(int64_t)bb * E + jj] : 0.f;
+    }
+    __syncthreads();
+    for (int k = tid; k < P; k += 256) {
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      for (int bb = 0; bb < B; ++bb) {
+        const float x = out[(int64_t)bb * ldo + k];
+        a0 = fmaf(smem[4 * bb + 0], x, a0); a1 = fmaf(smem[4 * bb + 1], x, a1);
+        a2 = fmaf(smem[4 * bb + 2], x, a2); a3 = fmaf(smem[4 * bb + 3], x, a3);
+      }
+      if (j0 + 0 < E) dw1[(int64_t)(j0 + 0) * P + k] = a0;
+      if (j0 + 1 < E) dw1[(int64_t)(j0 + 1) * P + k] = a1;
+      if (j0 + 2 < E) dw1[(int64_t)(j0 + 2) * P + k] = a2;
+      if (j0 + 3 < E) dw1[(int64_t)(j0 + 3) * P + k] = a3;
+    }
+    if (db1 && tid < 4 && j0 + tid < E) {
+      float a = 0.f;
+      for (int bb = 0; bb < B; ++bb) a += smem[4 * bb + tid];
+      db1[j0 + tid] = a;
+    }
+  } else {
+    for (int i = tid; i < C * E; i += 256) {
+      const int c = i / E, j = i % E;
+      float a = 0.f;
+      for (int bb = 0; bb < B; ++bb) a = fmaf(dy[(int64_t)bb * C + c], vec[(int64_t)bb * E + j], a);
+      dw2[i] = a;
+    }
+    if (db2) for (int c = tid; c < C; c += 256) {
+      float a = 0.f;
+      for (int bb = 0; bb < B; ++bb) a += dy[(int64_t)bb * C + c];
+      db2[c] = a;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int tsgnn_head2_fwd_f32(const float* out, int64_t ldo, const float* w1, const float* b1, const float* w2, const float* b2, int B, int P,
+                        int E, int C, float* vec, float* y, tsgnn_stream_t stream) {
+  if (!out || !w1 || !w2 || !vec || !y || B <= 0 || P <= 0 || E <= 0 || C <= 0 || ldo < P) return TSGNN_EINVAL;
+  if ((P % 4) || P > 4096 || E > 4096 || (reinterpret_cast<uintptr_t>(w1) & 15)) return TSGNN_EUNSUPPORTED;
+  const size_t lds = sizeof(float) * (size_t)(((P + 3) & ~3) + E);
+  head2_fwd_kernel<<<B, 64 * HW, lds, stream>>>(out, ldo, w1, b1, w2, b2, P, E, C, vec, y);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+int tsgnn_head2_bwd_f32(const float* out, int64_t ldo, const float* vec, const float* dy, const float* dvec, const float* w1,
+                        const float* w2, int B, int P, int E, int C, float* dvt, float* dout, int64_t lddo, float* dw1, float* db1,
+                        float* dw2, float* db2, tsgnn_stream_t stream) {
+  if (!out || !vec || !dy || !w1 || !w2 || !dvt || !dout || !dw1 || !dw2 || B <= 0 || P <= 0 || E <= 0 || C <= 0) return TSGNN_EINVAL;
+  if ((P % 4) || P > 2048 || E > 4096 || B > 1024 || (reinterpret_cast<uintptr_t>(w1) & 15)) return TSGNN_EUNSUPPORTED;
+  const size_t lds_rows = sizeof(float) * (size_t)(((E + 3) & ~3) + HW * ((P + 3) & ~3));
+  head2_bwd_rows_kernel<<<B, 64 * HW, lds_rows, stream>>>(dy, dvec, w1, w2, P, E, C, dvt, dout, lddo);
+  head2_bwd_weights_kernel<<<(E + 3) / 4 + 1, 256, sizeof(float) * 4 * (size_t)B, stream>>>(out, ldo, vec, dvt, dy, B, P, E, C, dw1, db1,
+                                                                                           dw2, db2);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+}  // extern "C"

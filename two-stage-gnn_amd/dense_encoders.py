@@ -42,6 +42,7 @@ def _batch_from_dense(adj, sizes, layout):
     return g
 
 
+FUSED_HEAD = True              # the two chained nn.Linear after the readout as one HIP launch (+2 backward)
 FUSED_STACK = True             # GcnEncoderGraph: run the conv stack as one fused autograd node when it qualifies
 DENSE_ADJ_MAX_NODES = 128      # at or below this many nodes per graph a dense batched MFMA product is used
 
@@ -247,9 +248,14 @@ class GcnEncoderGraph(nn.Module):
 
     def _heads(self, output):
         if self.final_dim == "pretrain":          # 2stg+
+            if FUSED_HEAD and mp.head2_ok(output, self.map_model, self.map2_model):
+                out, ypred = mp.head2(output, self.map_model, self.map2_model)
+                return ypred, out
             out = self.map_model(output)
             return self.map2_model(out), out
         if self.final_dim != "output_dim":        # original
+            if FUSED_HEAD and mp.head2_ok(output, self.pre_pred_model, self.pred_model):
+                return mp.head2(output, self.pre_pred_model, self.pred_model)
             vec = self.pre_pred_model(output)
             return vec, self.pred_model(vec)
         return output, self.map_model(output)     # 2stg

@@ -104,6 +104,34 @@ def gemm_tn_splitk(Z, K_in, dU, out=None):
     return out
 
 
+def linear_wgrad_slabs(z, K_in, du):
+    """slab partials of (dW, db) without the reduction; returns (ws, nslab) or None when the shape is unsupported."""
+    R, N = du.size(0), du.size(1)
+    nslab = np.zeros(1, dtype=np.int32)
+    rps = np.zeros(1, dtype=np.int64)
+    need = np.zeros(1, dtype=np.int64)
+    nat.call_nostream("linear_wgrad_plan", int(R), int(K_in), int(N), int(z.stride(0)), int(du.stride(0)), nslab.ctypes.data,
+                      rps.ctypes.data, need.ctypes.data)
+    if int(nslab[0]) <= 0 or z.data_ptr() % 16 or du.data_ptr() % 16:
+        return None
+    ws = _f32(int(need[0]), device=du.device)
+    nat.call("linear_wgrad_f32", z, z.stride(0), du, du.stride(0), R, int(K_in), int(N), int(nslab[0]), int(rps[0]), ws, None, None)
+    return ws, int(nslab[0])
+
+
+def wgrad_reduce_multi(sets):
+    """sets: list of (ws, nslab, K, N, dw, db-or-None), at most 4 per launch."""
+    for i in range(0, len(sets), 4):
+        args = []
+        for t in range(4):
+            if i + t < len(sets):
+                ws, nslab, K, N, dw, db = sets[i + t]
+                args += [ws, int(nslab), int(K), int(N), dw, db]
+            else:
+                args += [None, 0, 0, 0, None, None]
+        nat.call("wgrad_reduce_multi_f32", *args)
+
+
 def linear_wgrad(z, K_in, du, want_db):
     """(dW[K_in,N], db[N] or None) in one pass over the rows; falls back to split-K GEMM + column sums."""
     R, N = du.size(0), du.size(1)
@@ -367,3 +395,48 @@ def cross_entropy(logits, label):
     if logits.is_cuda and label.dtype == torch.int64:
         return _SoftmaxCE.apply(logits, label)
     return torch.nn.functional.cross_entropy(logits, label, reduction="mean")
+
+
+# ----------------------------------------------------------------------------- graph-level head
+class _Head2(torch.autograd.Function):
+    """(vec, y) = (W1 out + b1, W2 vec + b2): the chained nn.Linear pair after the readout, 1 + 2 launches."""
+
+    @staticmethod
+    def forward(ctx, out, w1, b1, w2, b2):
+        out = out.contiguous()
+        w1c, w2c = w1.contiguous(), w2.contiguous()
+        B, P = out.shape
+        E, C = w1c.size(0), w2c.size(0)
+        vec = _f32(B, E, device=out.device)
+        y = _f32(B, C, device=out.device)
+        nat.call("head2_fwd_f32", out, out.stride(0), w1c, b1, w2c, b2, B, P, E, C, vec, y)
+        ctx.save_for_backward(out, w1c, w2c, vec)
+        ctx.has_b = (b1 is not None, b2 is not None)
+        return vec, y
+
+    @staticmethod
+    def backward(ctx, dvec, dy):
+        out, w1, w2, vec = ctx.saved_tensors
+        B, P = out.shape
+        E, C = w1.size(0), w2.size(0)
+        dev = out.device
+        dy = dy.contiguous() if dy is not None else torch.zeros(B, C, device=dev)
+        dvec = dvec.contiguous() if dvec is not None else None
+        dvt = _f32(B, E, device=dev)
+        dout = _f32(B, P, device=dev)
+        dw1, dw2 = _f32(E, P, device=dev), _f32(C, E, device=dev)
+        db1 = _f32(E, device=dev) if ctx.has_b[0] else None
+        db2 = _f32(C, device=dev) if ctx.has_b[1] else None
+        nat.call("head2_bwd_f32", out, out.stride(0), vec, dy, dvec, w1, w2, B, P, E, C, dvt, dout, dout.stride(0), dw1, db1, dw2, db2)
+        return dout, dw1, db1, dw2, db2
+
+
+def head2_ok(out, lin1, lin2):
+    return (out.is_cuda and isinstance(lin1, torch.nn.Linear) and isinstance(lin2, torch.nn.Linear) and out.dim() == 2
+            and out.size(1) % 4 == 0 and out.size(1) <= 2048 and lin1.out_features <= 4096 and out.size(0) <= 1024
+            and lin1.weight.data_ptr() % 16 == 0)
+
+
+def head2(out, lin1, lin2):
+    """lin2(lin1(out)) returning (lin1 output, lin2 output)."""
+    return _Head2.apply(out, lin1.weight, lin1.bias, lin2.weight, lin2.bias)

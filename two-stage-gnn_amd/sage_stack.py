@@ -116,6 +116,7 @@ class _SageStack(torch.autograd.Function):
         main = torch.cuda.current_stream()
         side = _side_stream(dev) if OVERLAP else main
         keep = []
+        pending = []
         for l in range(L - 1, -1, -1):
             z, v, rinv, mean, rstd = ctx.saved[l]
             W = ctx.Ws[l]
@@ -133,7 +134,13 @@ class _SageStack(torch.autograd.Function):
                 side.wait_stream(main)                      # du ready
             with torch.cuda.stream(side):                   # weight/bias gradients are off the dX critical path
                 if want_w:
-                    dw, db = mp.linear_wgrad(z, K, du, want_b)
+                    sl = mp.linear_wgrad_slabs(z, K, du)
+                    if sl is not None:                      # slabs now, ONE reduction for all layers at the end
+                        dw = torch.empty(K, N, dtype=torch.float32, device=dev)
+                        db = torch.empty(N, dtype=torch.float32, device=dev) if want_b else None
+                        pending.append((sl[0], sl[1], K, N, dw, db))
+                    else:
+                        dw, db = mp.linear_wgrad(z, K, du, want_b)
                     grads[2 * l], grads[2 * l + 1] = dw, db
                 elif want_b:
                     grads[2 * l + 1] = mp.colsum(du)
@@ -149,6 +156,9 @@ class _SageStack(torch.autograd.Function):
                 dxs = _aggregate_raw(g, dz, transposed=True)
                 if l == 0:
                     dx0 = dxs
+        if pending:
+            with torch.cuda.stream(side):
+                mp.wgrad_reduce_multi(pending)
         if OVERLAP:
             main.wait_stream(side)                          # join before the gradients are consumed
         del keep
