@@ -259,10 +259,11 @@ int tsgnn_row_softmax_bwd_f32(const float* y, int64_t ldy, const float* dy, int6
 /* 1 if (B graphs, F features) is covered by the fused slot kernels (B <= 128, F % 4 == 0, F <= 128) */
 int tsgnn_slot_fused_supported(int B, int F);
 /* y = slot_bn(relu(v)) with the statistics computed in the same pass (one workgroup per node slot keeps the slot's
- * rows of all graphs in registers).  Same result as tsgnn_bn_slots_fwd_f32 (encoders.py:179-181,134-138). */
+ * rows of all graphs in registers).  Same result as tsgnn_bn_slots_fwd_f32 (encoders.py:179-181,134-138).
+ * zero_ptr (nullable): zero_n 64-bit words cleared on the side (the stack's packed max-readout buffer). */
 int tsgnn_slot_bn_fwd_f32(const int* graph_ptr, const int* slot_count, int B, int nmax, int64_t n_real, int n_ghost,
                           const float* v, int64_t ldv, int F, int relu, float* mean, float* rstd, float* y, int64_t ldy,
-                          tsgnn_stream_t stream);
+                          unsigned long long* zero_ptr, int64_t zero_n, tsgnn_stream_t stream);
 /* One-pass backward of [max readout (dout, arg) + next layer's dxs (nullable)] -> slot BN -> ReLU -> row L2 normalise:
  * du = gradient w.r.t. the pre-normalise GraphConv output (feeds tsgnn_linear_wgrad_f32 / tsgnn_rowgemm_f32). */
 int tsgnn_slot_post_bwd_f32(const int* graph_ptr, const int* slot_count, int B, int nmax, int64_t n_real, int n_ghost,

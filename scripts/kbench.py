@@ -82,7 +82,7 @@ def extra():
     g, x, label = synthetic.to_device(hb, dev)
     R, H = g.total_rows, 128
     V = torch.randn(R, H, device=dev); Y = torch.empty_like(V); mean = torch.empty(g.nmax, device=dev); rstd = torch.empty(g.nmax, device=dev)
-    print("%-40s %8.2f us" % ("slot_bn_fwd", burst_us(lambda: nat.call("slot_bn_fwd_f32", g.graph_ptr, g.slot_count, g.B, g.nmax, g.n_rows, g.n_ghost, V, H, H, 1, mean, rstd, Y, H))))
+    print("%-40s %8.2f us" % ("slot_bn_fwd", burst_us(lambda: nat.call("slot_bn_fwd_f32", g.graph_ptr, g.slot_count, g.B, g.nmax, g.n_rows, g.n_ghost, V, H, H, 1, mean, rstd, Y, H, None, 0))))
     packed = torch.zeros(g.B * H, dtype=torch.int64, device=dev)
     print("%-40s %8.2f us" % ("readout_partial", burst_us(lambda: nat.call("readout_partial_f32", g.graph_ptr, g.B, g.nmax, g.n_rows, g.n_ghost, Y, H, H, packed))))
     out = torch.empty(g.B, H, device=dev); arg = torch.empty(g.B * H, dtype=torch.int32, device=dev)

@@ -42,11 +42,14 @@ __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<floa
 template <int TPR, int NV>
 __global__ __launch_bounds__(256) void slot_bn_fwd(SlotArgs s, const float* __restrict__ v, int64_t ldv, int F4, int relu,
                                                    float* __restrict__ mean, float* __restrict__ rstd,
-                                                   float* __restrict__ y, int64_t ldy) {
+                                                   float* __restrict__ y, int64_t ldy,
+                                                   unsigned long long* __restrict__ zero_ptr, int64_t zero_n) {
   __shared__ float red[8];
   __shared__ int first_ghost;
   const int n = blockIdx.x, tid = threadIdx.x;
   const int b = tid / TPR, c = tid % TPR;
+  // optional: clear the packed max-readout buffer of the whole stack (consumed only by later launches)
+  for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < zero_n; i += (int64_t)gridDim.x * 256) zero_ptr[i] = 0ull;
   if (tid == 0) first_ghost = 0x7fffffff;
   __syncthreads();
   int64_t row = -1;
@@ -333,13 +336,13 @@ int tsgnn_slot_fused_supported(int B, int F) {
 
 int tsgnn_slot_bn_fwd_f32(const int* graph_ptr, const int* slot_count, int B, int nmax, int64_t n_real, int n_ghost,
                           const float* v, int64_t ldv, int F, int relu, float* mean, float* rstd, float* y, int64_t ldy,
-                          tsgnn_stream_t stream) {
+                          unsigned long long* zero_ptr, int64_t zero_n, tsgnn_stream_t stream) {
   if (!graph_ptr || !slot_count || !v || !mean || !rstd || !y || nmax <= 0 || (n_ghost != 0 && n_ghost != nmax) || ldv < F || ldy < F ||
       (ldv % 4) || (ldy % 4))
     return TSGNN_EINVAL;
   if (!tsgnn_slot_fused_supported(B, F)) return TSGNN_EUNSUPPORTED;
   SlotArgs s{graph_ptr, slot_count, B, nmax, n_real, n_ghost};
-  TSGNN_SLOT_DISPATCH(slot_bn_fwd, <<<nmax, 256, 0, stream>>>(s, v, ldv, F / 4, relu, mean, rstd, y, ldy));
+  TSGNN_SLOT_DISPATCH(slot_bn_fwd, <<<nmax, 256, 0, stream>>>(s, v, ldv, F / 4, relu, mean, rstd, y, ldy, zero_ptr, zero_ptr ? zero_n : 0));
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }

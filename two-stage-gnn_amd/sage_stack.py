@@ -57,7 +57,7 @@ class _SageStack(torch.autograd.Function):
         R, B = g.total_rows, g.B
         Fh, Fl = Ws[0].size(1), Ws[-1].size(1)
         total = B * ((L - 1) * Fh + Fl)
-        packed = torch.zeros(total, dtype=torch.int64, device=dev)
+        packed = torch.empty(total, dtype=torch.int64, device=dev)      # cleared by the first slot_bn_fwd launch
         x = mp._check(x0, R)
         saved = []
         off = 0
@@ -81,7 +81,7 @@ class _SageStack(torch.autograd.Function):
                 rstd = torch.empty(g.nmax, dtype=torch.float32, device=dev)
                 y = torch.empty_like(v)
                 nat.call("slot_bn_fwd_f32", g.graph_ptr, g.slot_count, B, g.nmax, g.n_rows, g.n_ghost, v, v.stride(0), N, 1,
-                         mean, rstd, y, y.stride(0))
+                         mean, rstd, y, y.stride(0), packed if l == 0 else None, total)
                 if OVERLAP:
                     side.wait_stream(main)
                 with torch.cuda.stream(side):               # the next layer only needs y: readout runs beside it
