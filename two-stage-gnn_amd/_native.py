@@ -89,6 +89,10 @@ def lib():
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
+        import shutil
+        if shutil.which("hipcc"):
+            build()                      # compiling the product is not a fallback: the HIP path is still the only path
+    if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             "libtsgnn_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "from the repo root. There is no CPU fallback for the product path." % LIB_PATH)
