@@ -161,6 +161,13 @@ int tsgnn_bn_slots_bwd_f32(const int* graph_ptr, const int* slot_count, const in
                            int relu, int bn, const float* mean, const float* rstd, float* m1, float* m2, float* dv,
                            int64_t lddv, tsgnn_stream_t stream);
 
+/* Per-graph statistics: the same ReLU + apply_bn when every graph is normalised as if it were alone in its batch (B = 1,
+ * how tripletnet.py:36-38 calls the encoder): a per-row layer norm over the features, biased variance, eps 1e-5. */
+int tsgnn_row_ln_fwd_f32(const float* v, int64_t ldv, int64_t rows, int F, int relu, float* mean, float* rstd, float* y, int64_t ldy,
+                         tsgnn_stream_t stream);
+int tsgnn_row_ln_bwd_f32(const float* v, int64_t ldv, const float* dy, int64_t lddy, int64_t rows, int F, int relu, const float* mean,
+                         const float* rstd, float* dv, int64_t lddv, tsgnn_stream_t stream);
+
 /* out[b,f] = max over the nmax node slots of graph b (ghost rows included, trap T5), arg = winning row.
  * Replaces torch.max(x, dim=1) (encoders.py:183,190,197,353,383). packed_ws: B*F uint64 scratch. */
 int tsgnn_readout_max_fwd_f32(const int* graph_ptr, const int* slot_count, int B, int nmax, int64_t n_real, int n_ghost,

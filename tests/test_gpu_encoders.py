@@ -246,3 +246,57 @@ def test_diffpool_dd_config_vs_oracle():
         gpu_err = (p.grad.cpu().double() - ref64).abs().max().item()
         mag = ref64.abs().max().item()
         assert gpu_err <= max(10 * cpu_err, 2e-3 * mag + 1e-9), (k, gpu_err, cpu_err, mag)
+
+
+# ----------------------------------------------------------------------------- triplet step (tripletnet.py)
+class _G:                       # stand-in for the networkx graphs cross_val.split_train_val prepares (cross_val.py:158-184)
+    def __init__(self, adj, feats, n):
+        self.graph = {"adj": adj, "feats": feats, "num_nodes": n, "assign_feats": feats}
+
+
+@pytest.mark.parametrize("kind", ["base", "diffpool"])
+def test_triplet_batched_equals_three_b1_forwards(kind):
+    from two_stage_gnn_amd import dense_encoders as E
+    from two_stage_gnn_amd.triplet import tripletnet
+    nmax, fin = 24, 6
+    x, adj, sizes = dense_batch(41, 3, nmax, fin, sizes=[24, 11, 17], p_edge=0.2)
+
+    class A:
+        bias = True
+    torch.manual_seed(4)
+    if kind == "base":
+        m = E.GcnEncoderGraph(fin, 8, 8, 2, 3, bn=True, args=A(), final_dim="output_dim")
+    else:
+        m = E.SoftPoolingGcnEncoder(nmax, fin, 8, 8, 2, 3, 8, assign_ratio=0.25, num_pooling=1, bn=True, linkpred=False, args=A(),
+                                    assign_input_dim=fin, final_dim="output_dim")
+    with torch.no_grad():
+        for k, p in m.named_parameters():
+            if "conv" in k and k.endswith("bias"):
+                p.copy_(torch.randn_like(p) * 0.3)
+    m = m.cuda()
+    p_ref = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    embeds = []
+    for b in range(3):                                             # the reference: three separate B = 1 forwards
+        if kind == "base":
+            _, e = R.gcn_encoder(p_ref, x[b:b + 1], adj[b:b + 1], bn=True, final_dim="output_dim")
+        else:
+            _, e = R.diffpool_encoder(p_ref, x[b:b + 1], adj[b:b + 1], sizes[b:b + 1], 1, assign_x=x[b:b + 1], final_dim="output_dim")
+        embeds.append(e)
+    dp_ref = torch.nn.functional.pairwise_distance(embeds[0], embeds[1], 2)
+    dn_ref = torch.nn.functional.pairwise_distance(embeds[0], embeds[2], 2)
+    loss_ref = torch.nn.MarginRankingLoss(margin=1.0)(dp_ref, dn_ref, torch.tensor([-1.0]))
+    loss_ref.backward()
+    net = tripletnet(m)
+    gs = [_G(adj[b].numpy(), x[b].numpy(), int(sizes[b])) for b in range(3)]
+    dp, dn, ea, ep, en = net(*gs)
+    torch.testing.assert_close(dp.cpu(), dp_ref.detach(), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(dn.cpu(), dn_ref.detach(), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(ea.cpu(), embeds[0].detach(), rtol=1e-4, atol=1e-4)
+    loss = torch.nn.MarginRankingLoss(margin=1.0)(dp, dn, torch.tensor([-1.0]).cuda())
+    loss.backward()
+    for k, p in m.named_parameters():
+        ref = p_ref[k].grad
+        if ref is None or p.grad is None:
+            continue
+        err = (p.grad.cpu() - ref).abs().max().item()
+        assert err <= 5e-3 * ref.abs().max().item() + 1e-6, (k, err, ref.abs().max().item())

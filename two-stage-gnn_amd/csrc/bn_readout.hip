@@ -152,6 +152,46 @@ __global__ __launch_bounds__(256) void bn_slot_bwd_apply(SlotArgs s, const float
   }
 }
 
+// ---------------------------------------------------------------- per-graph statistics (B = 1 semantics, batched)
+// With ONE graph per forward (the 2stg / 2stg+ triplet settings call the encoder at B = 1, tripletnet.py:36-38) the
+// slot batch-norm degenerates to a per-row layer norm over the features (trap T2).  Row mode lets anchor / positive /
+// negative (or any number of graphs) share one launch while each keeps its own B = 1 statistics.  One wave per row.
+__global__ __launch_bounds__(256) void row_ln_fwd(const float* __restrict__ v, int64_t ldv, int64_t rows, int F, int relu,
+                                                  float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ y, int64_t ldy) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  float s1 = 0.f;
+  for (int f = lane; f < F; f += 64) s1 += act(v[r * ldv + f], relu);
+  const float mu = wave_sum(s1) / (float)F;
+  float s2 = 0.f;
+  for (int f = lane; f < F; f += 64) { const float d = act(v[r * ldv + f], relu) - mu; s2 = fmaf(d, d, s2); }
+  const float rs = 1.0f / sqrtf(wave_sum(s2) / (float)F + BN_EPS);
+  for (int f = lane; f < F; f += 64) y[r * ldy + f] = (act(v[r * ldv + f], relu) - mu) * rs;
+  if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
+}
+__global__ __launch_bounds__(256) void row_ln_bwd(const float* __restrict__ v, int64_t ldv, const float* __restrict__ dy, int64_t lddy,
+                                                  int64_t rows, int F, int relu, const float* __restrict__ mean,
+                                                  const float* __restrict__ rstd, float* __restrict__ dv, int64_t lddv) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float mu = mean[r], rs = rstd[r];
+  float a = 0.f, c = 0.f;
+  for (int f = lane; f < F; f += 64) {
+    const float d = dy[r * lddy + f];
+    a += d;
+    c = fmaf(d, (act(v[r * ldv + f], relu) - mu) * rs, c);
+  }
+  const float m1 = wave_sum(a) / (float)F, m2 = wave_sum(c) / (float)F;
+  for (int f = lane; f < F; f += 64) {
+    const float x = v[r * ldv + f];
+    float g = rs * (dy[r * lddy + f] - m1 - (act(x, relu) - mu) * rs * m2);
+    if (relu && !(x > 0.f)) g = 0.f;
+    dv[r * lddv + f] = g;
+  }
+}
+
 // ---------------------------------------------------------------- max readout over node slots
 // grid (chunks of 64 slots, B); block = 4 waves x 16 slots, lanes over features
 __global__ __launch_bounds__(256) void readout_max_partial(SlotArgs s, const float* __restrict__ x, int64_t ld, int F,
@@ -276,6 +316,24 @@ int tsgnn_bn_slots_bwd_f32(const int* graph_ptr, const int* slot_count, const in
   if (rows > 0)
     bn_slot_bwd_apply<<<(unsigned)ceil_div64(rows, 4), 256, 0, stream>>>(
         s, v, ldv, dy, lddy, row_slot, rows, F, relu, bn ? mean : nullptr, rstd, m1, m2, dv, lddv);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+int tsgnn_row_ln_fwd_f32(const float* v, int64_t ldv, int64_t rows, int F, int relu, float* mean, float* rstd, float* y, int64_t ldy,
+                         tsgnn_stream_t stream) {
+  if (!v || !mean || !rstd || !y || rows < 0 || F <= 0 || ldv < F || ldy < F) return TSGNN_EINVAL;
+  if (rows == 0) return TSGNN_OK;
+  row_ln_fwd<<<(unsigned)ceil_div64(rows, 4), 256, 0, stream>>>(v, ldv, rows, F, relu, mean, rstd, y, ldy);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+int tsgnn_row_ln_bwd_f32(const float* v, int64_t ldv, const float* dy, int64_t lddy, int64_t rows, int F, int relu, const float* mean,
+                         const float* rstd, float* dv, int64_t lddv, tsgnn_stream_t stream) {
+  if (!v || !dy || !mean || !rstd || !dv || rows < 0 || F <= 0 || ldv < F || lddy < F || lddv < F) return TSGNN_EINVAL;
+  if (rows == 0) return TSGNN_OK;
+  row_ln_bwd<<<(unsigned)ceil_div64(rows, 4), 256, 0, stream>>>(v, ldv, dy, lddy, rows, F, relu, mean, rstd, dv, lddv);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }

@@ -151,6 +151,8 @@ class GcnEncoderGraph(nn.Module):
         self.map_model = self.build_pred_layers(self.pred_input_dim, pred_hidden_dims, embedding_dim,
                                                 num_aggs=self.num_aggs)
         self.map2_model = self.build_pred_layers(pred_input_dim=embedding_dim, pred_hidden_dims=[], label_dim=2)
+        # True: each graph of a batch is normalised with the statistics it would have at B = 1 (triplet settings)
+        self.per_graph_bn = False
         self._init_convs()
         self.to(_default_device())
 
@@ -213,7 +215,7 @@ class GcnEncoderGraph(nn.Module):
 
     def _post(self, v, g):
         """ReLU then (optionally) slot batch-norm: encoders.py:179-181."""
-        return mp.bn_slots(v, g, relu=True, bn=self.bn)
+        return mp.bn_slots(v, g, relu=True, bn=self.bn, per_graph=self.per_graph_bn)
 
     def gcn_forward_rows(self, x, g, conv_first, conv_block, conv_last, mask_ghost=False):
         """gcn_forward (encoders.py:140-167) on rows: per-layer outputs concatenated on the feature axis;
@@ -233,7 +235,7 @@ class GcnEncoderGraph(nn.Module):
         """encoders.py:177-205 up to the concatenated max readout."""
         from . import sage_stack
         convs = [self.conv_first] + list(self.conv_block) + [self.conv_last]
-        if self.concat and FUSED_STACK and sage_stack.eligible(g, convs, self.bn, x) and \
+        if self.concat and FUSED_STACK and not self.per_graph_bn and sage_stack.eligible(g, convs, self.bn, x) and \
                 bool(mp.nat.lib().tsgnn_slot_fused_supported(g.B, convs[0].output_dim)) and \
                 bool(mp.nat.lib().tsgnn_slot_fused_supported(g.B, convs[-1].output_dim)):
             return sage_stack.sage_stack_readouts(x, g, convs)
@@ -333,7 +335,7 @@ class SoftPoolingGcnEncoder(GcnEncoderGraph):
         g = GraphBatch.structure_only(np.full(B, K, dtype=np.int64), K, x.device, ghosts=False)
 
         def post(v):
-            return mp.bn_slots(v.reshape(B * K, -1), g, relu=True, bn=self.bn).reshape(B, K, -1)
+            return mp.bn_slots(v.reshape(B * K, -1), g, relu=True, bn=self.bn, per_graph=self.per_graph_bn).reshape(B, K, -1)
         x = post(conv_first(x, adj))
         x_all = [x]
         for conv in conv_block:

@@ -248,7 +248,33 @@ class _BnSlots(torch.autograd.Function):
         return dv, None, None, None
 
 
-def bn_slots(v, g, relu=True, bn=True):
+class _RowLn(torch.autograd.Function):
+    """ReLU + apply_bn with per-graph (B = 1) statistics = per-row layer norm (tripletnet.py:36-38 semantics, batched)."""
+
+    @staticmethod
+    def forward(ctx, v, relu):
+        v = _check(v)
+        R, F = v.shape
+        mean, rstd = _f32(R, device=v.device), _f32(R, device=v.device)
+        y = torch.empty_like(v)
+        nat.call("row_ln_fwd_f32", v, v.stride(0), R, F, int(relu), mean, rstd, y, y.stride(0))
+        ctx.relu = relu
+        ctx.save_for_backward(v, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        v, mean, rstd = ctx.saved_tensors
+        dy = _check(dy)
+        dv = torch.empty_like(v)
+        nat.call("row_ln_bwd_f32", v, v.stride(0), dy, dy.stride(0), v.size(0), v.size(1), int(ctx.relu), mean, rstd, dv, dv.stride(0))
+        return dv, None
+
+
+def bn_slots(v, g, relu=True, bn=True, per_graph=False):
+    """per_graph=True: every graph keeps the statistics it would have alone in its batch (B = 1)."""
+    if per_graph and bn:
+        return _RowLn.apply(v, bool(relu))
     return _BnSlots.apply(v, g, bool(relu), bool(bn))
 
 
