@@ -176,8 +176,8 @@ def main():
             fwd_bwd(); trainer.all_reduce(); trainer.apply()
         torch.cuda.synchronize()
         if use_graph:
-            # fwd+bwd+bucket and clip+Adam are captured as two hipGraphs; the RCCL all-reduce is issued
-            # between them on the same stream (a single-GPU run replays both back to back).
+            # N > 1: fwd+bwd+bucket and clip+Adam are two hipGraphs with the RCCL all-reduce issued between them on the
+            # same stream; N = 1: one hipGraph for the whole step.
             if world > 1:
                 dist.barrier()                                 # no collective in flight while capturing
                 torch.cuda.synchronize()
@@ -186,12 +186,17 @@ def main():
             graph_fb = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph_fb, stream=stream, **mode):
                 fwd_bwd()
-            graph_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph_opt, stream=stream, **mode):
-                trainer.apply()
+                if world == 1:
+                    trainer.apply()                            # single GPU: no collective, the whole step is one graph
+            if world > 1:
+                graph_opt = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph_opt, stream=stream, **mode):
+                    trainer.apply()
 
         def step():
-            if use_graph:
+            if use_graph and world == 1:
+                graph_fb.replay()
+            elif use_graph:
                 graph_fb.replay(); trainer.all_reduce(); graph_opt.replay()
             else:
                 fwd_bwd(); trainer.all_reduce(); trainer.apply()
