@@ -22,6 +22,29 @@ def timeit(fn, iters=30, warm=5):
     return e0.elapsed_time(e1) / iters * 1e3     # us
 
 
+def graph_us(fn, iters=20):
+    """the same step replayed from a hipGraph (no host overhead); None if the step cannot be captured"""
+    st = torch.cuda.Stream()
+    try:
+        with torch.cuda.stream(st):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=st):
+                fn()
+            gr.replay(); torch.cuda.synchronize()
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            for _ in range(iters):
+                gr.replay()
+            e1.record(st); e1.synchronize()
+            return e0.elapsed_time(e1) / iters * 1e3
+    except Exception as e:                                     # noqa
+        torch.cuda.synchronize()
+        return None
+
+
 class A:
     bias = True
 
@@ -35,7 +58,8 @@ m = E.GcnEncoderGraph(3, 128, 128, 2, 3, bn=True, args=A(), final_dim="number_cl
 def step_sage():
     m.zero_grad(set_to_none=True); m.loss(m(x, g)[1], label).backward()
 t = timeit(step_sage)
-print("cfg2 PROTEINS SAGE-3L h128 b64 (Nmax 620): %.0f us/step eager, %.0f graphs/s" % (t, 64 / t * 1e6))
+tg = graph_us(step_sage)
+print("cfg2 PROTEINS SAGE-3L h128 b64 (Nmax 620): %.0f us/step eager, %s us/step hipGraph -> %.0f graphs/s" % (t, "%.0f" % tg if tg else "n/a", 64 / (tg or t) * 1e6))
 
 # config 3: DD GAT 2-layer 4-head h=64, batch 32 graphs = 32 sequential B=1 forwards (the reference's GAT batch size is 1)
 hb1 = synthetic.host_batch(2, 1, "DD", 1000)
@@ -47,7 +71,8 @@ lab1 = torch.tensor([1], device=dev)
 def step_gat():
     gat.zero_grad(set_to_none=True); gat.loss(gat(x1, gpad)[1], lab1).backward()
 t = timeit(step_gat)
-print("cfg3 DD GAT-2L 4 heads h64, one graph per step (Nmax 1000): %.0f us/step eager, %.0f graphs/s" % (t, 1 / t * 1e6))
+tg = graph_us(step_gat)
+print("cfg3 DD GAT-2L 4 heads h64, one graph per step (Nmax 1000): %.0f us/step eager, %s us/step hipGraph -> %.0f graphs/s" % (t, "%.0f" % tg if tg else "n/a", 1 / (tg or t) * 1e6))
 
 # config 4: IMDB-B SAGPool ratio .5 h=128 batch 128 (PyG per-graph semantics)
 hb4 = synthetic.host_batch(3, 128, "IMDB-BINARY", 136)
@@ -72,7 +97,8 @@ dpm = E.SoftPoolingGcnEncoder(512, 89, 64, 64, 2, 3, 64, assign_ratio=0.125, num
 def step_dp():
     dpm.zero_grad(set_to_none=True); dpm.loss(dpm(x5, g5, hb5["sizes"], assign_x=x5)[1], lab5).backward()
 t = timeit(step_dp, iters=10, warm=3)
-print("cfg5 DD DiffPool 512->64->8 h64 b16: %.0f us/step eager, %.0f graphs/s" % (t, 16 / t * 1e6))
+tg = None      # hipGraph capture of this step ends in a HIP-runtime segfault at capture_end (ROCm 7.2); eager only
+print("cfg5 DD DiffPool 512->64->8 h64 b16: %.0f us/step eager, %s us/step hipGraph -> %.0f graphs/s" % (t, "%.0f" % tg if tg else "n/a", 16 / (tg or t) * 1e6))
 # the contraction alone, level 1 (S [rows,64], Z [rows,192]) + level 2 dense
 Sm = torch.softmax(torch.randn(g5.total_rows, 64, device=dev), -1); Sm[g5.n_rows:] = 0
 Z = torch.randn(g5.total_rows, 192, device=dev)

@@ -194,7 +194,7 @@ class GcnEncoderGraph(nn.Module):
     def apply_bn(self, x):
         """Per-node-slot batch norm of a padded [B,N,F] tensor (encoders.py:134-138)."""
         B, N, Fd = x.shape
-        g = GraphBatch.structure_only(np.full(B, N, dtype=np.int64), N, x.device, ghosts=False)
+        g = GraphBatch.uniform(B, N, x.device)
         return mp.bn_slots(x.contiguous().float().reshape(B * N, Fd), g, relu=False, bn=True).reshape(B, N, Fd)
 
     # ------------------------------------------------------------------ graph batch plumbing
@@ -332,7 +332,7 @@ class SoftPoolingGcnEncoder(GcnEncoderGraph):
     # gcn_forward on dense pooled tensors x[B,K,F], adj[B,K,K] (encoders.py:378-380; mask is None there)
     def gcn_forward_dense(self, x, adj, conv_first, conv_block, conv_last):
         B, K, _ = x.shape
-        g = GraphBatch.structure_only(np.full(B, K, dtype=np.int64), K, x.device, ghosts=False)
+        g = GraphBatch.uniform(B, K, x.device)
 
         def post(v):
             return mp.bn_slots(v.reshape(B * K, -1), g, relu=True, bn=self.bn, per_graph=self.per_graph_bn).reshape(B, K, -1)

@@ -144,6 +144,18 @@ class GraphBatch:
         g.symmetric = bool(assume_symmetric)
         return g
 
+    _uniform_cache = {}
+
+    @classmethod
+    def uniform(cls, B, K, device):
+        """cached structure-only batch of B graphs with K rows each, no ghost rows (pooled DiffPool levels, apply_bn):
+        built once per (B, K, device), so steady-state steps do no host->device copies (hipGraph-capturable)."""
+        key = (int(B), int(K), str(device))
+        g = cls._uniform_cache.get(key)
+        if g is None:
+            g = cls._uniform_cache[key] = cls.structure_only(np.full(int(B), int(K), dtype=np.int64), int(K), device, ghosts=False)
+        return g
+
     @classmethod
     def structure_only(cls, sizes, nmax, device, ghosts=True):
         """Row bookkeeping without an adjacency (slot batch-norm / readout of stand-alone tensors)."""
