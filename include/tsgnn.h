@@ -224,9 +224,10 @@ int tsgnn_csr_spmm_heads_f32(const int* rowptr, const int* col, const float* alp
 int tsgnn_csr_sddmm_heads_f32(const int* rowptr, const int* col, int H, int Fh, const float* dy, int64_t lddy, const float* x,
                               int64_t ldx, int mod, float* dalpha, int64_t rows, tsgnn_stream_t stream);
 /* out[s,c] = scale * sum_{r in segment s} w[r, c/Fh] * x[r,c]  (w NULL = 1; seg_ptr NULL = one segment of `rows`;
- * mean != 0 divides by the segment length).  Also PyG global_mean_pool (Code/sag/network.py:36). */
+ * mean != 0 divides by the segment length; max_seg = longest segment).  ws >= ceil(max_seg/128)*nseg*H*Fh floats.
+ * Also PyG global_mean_pool (Code/sag/network.py:36). */
 int tsgnn_segment_wsum_f32(const float* x, int64_t ldx, const float* w, int H, int Fh, const int* seg_ptr, int nseg, int64_t rows,
-                           float scale, int mean, float* out, int64_t ldo, tsgnn_stream_t stream);
+                           int64_t max_seg, float scale, int mean, float* ws, float* out, int64_t ldo, tsgnn_stream_t stream);
 /* y[r,c] += scale * w[r,c/Fh] * (a ? a[(c/Fh)*lda + c%Fh] : u[(r / rows_per_seg)*ldu + c])   (w NULL = 1) */
 int tsgnn_broadcast_add_f32(float* y, int64_t ldy, int64_t rows, int H, int Fh, const float* w, const float* a, int64_t lda,
                             const float* u, int64_t ldu, int rows_per_seg, float scale, tsgnn_stream_t stream);

@@ -21,9 +21,13 @@ def node_scores(h, a, H, Fh):
     return s
 
 
-def segment_wsum(x, w, H, Fh, seg_ptr, nseg, scale=1.0, mean=False):
+def segment_wsum(x, w, H, Fh, seg_ptr, nseg, scale=1.0, mean=False, max_seg=None):
+    """max_seg: longest segment (host int); defaults to all rows (always a valid bound)."""
     out = _f32(nseg, H * Fh, device=x.device)
-    nat.call("segment_wsum_f32", x, x.stride(0), w, H, Fh, seg_ptr, nseg, x.size(0), float(scale), int(mean), out,
+    max_seg = int(x.size(0) if max_seg is None else max_seg)
+    nchunk = max(1, (max_seg + 127) // 128)
+    ws = _f32(nchunk * nseg * H * Fh, device=x.device)
+    nat.call("segment_wsum_f32", x, x.stride(0), w, H, Fh, seg_ptr, nseg, x.size(0), max_seg, float(scale), int(mean), ws, out,
              out.stride(0))
     return out
 
@@ -61,7 +65,7 @@ class _AttentionAggregate(torch.autograd.Function):
             deg_t = (rp_t[1:] - rp_t[:-1])
             iso = (deg_t == 0).to(torch.float32).unsqueeze(1).expand(R, H).contiguous()
             N = g.nmax
-            u = segment_wsum(h, iso, H, Fh, g.graph_ptr, g.B, scale=1.0 / N)
+            u = segment_wsum(h, iso, H, Fh, g.graph_ptr, g.B, scale=1.0 / N, max_seg=int(g.sizes.max()))
             nat.call("broadcast_add_f32", out, out.stride(0), R, H, Fh, None, None, 0, u, u.stride(0), N, 1.0)
         ctx.g, ctx.H, ctx.Fh, ctx.slope, ctx.by_column = g, H, Fh, slope, by_column
         ctx.save_for_backward(h, a_row, a_col, s_row, s_col, alpha, alpha_g, iso)
@@ -104,7 +108,7 @@ class _AttentionAggregate(torch.autograd.Function):
         nat.call("broadcast_add_f32", dh, dh.stride(0), R, H, Fh, ds_col, a_col, a_col.stride(0), None, 0, 0, 1.0)
         if iso is not None:
             N = g.nmax
-            du = segment_wsum(dout, None, H, Fh, g.graph_ptr, g.B, scale=1.0)
+            du = segment_wsum(dout, None, H, Fh, g.graph_ptr, g.B, scale=1.0, max_seg=int(g.sizes.max()))
             nat.call("broadcast_add_f32", dh, dh.stride(0), R, H, Fh, iso, None, 0, du, du.stride(0), N, 1.0 / N)
         da_row = segment_wsum(h, ds_row, H, Fh, None, 1).view(H, Fh)
         da_col = segment_wsum(h, ds_col, H, Fh, None, 1).view(H, Fh)

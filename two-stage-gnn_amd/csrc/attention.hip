@@ -153,28 +153,52 @@ __global__ __launch_bounds__(256) void sddmm_heads_kernel(const int* __restrict_
   }
 }
 
-// out[s, c] = sum_{r in segment s} w[r, c / Fh] * x[r, c]   (w nullable = 1).  grid (ceil(C/64), S); two row-lanes... one
-// block per (64-column strip, segment): 4 waves stride over the segment's rows, LDS combine (fixed order).
+// out[s, c] = scale * sum_{r in segment s} w[r, c / Fh] * x[r, c]   (w nullable = 1; mean: / segment length).
+// Two levels so that one long segment (all rows of a 1000-node graph) still fills the chip: grid (ceil(C/64), S, chunks of
+// 128 rows) writes partials, segment_wsum_final adds the chunks in fixed order (reproducible, no float atomics).
+constexpr int SEG_CHUNK = 128;
 __global__ __launch_bounds__(256) void segment_wsum_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ w, int H,
                                                            int Fh, const int* __restrict__ seg_ptr, int64_t rows_if_one, int C,
-                                                           float scale, int mean, float* __restrict__ out, int64_t ldo) {
+                                                           float* __restrict__ part, int nseg) {
   __shared__ float lds[4][64];
   const int s = blockIdx.y;
-  const int64_t r0 = seg_ptr ? seg_ptr[s] : 0, r1 = seg_ptr ? seg_ptr[s + 1] : rows_if_one;
+  const int64_t s0 = seg_ptr ? seg_ptr[s] : 0, s1 = seg_ptr ? seg_ptr[s + 1] : rows_if_one;
+  const int64_t r0 = s0 + (int64_t)blockIdx.z * SEG_CHUNK, r1 = min(s1, r0 + SEG_CHUNK);
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int rl = threadIdx.x >> 6;
   float acc = 0.f;
-  if (c < C) {
+  if (c < C && r0 < r1) {
     const int h = c / Fh;
-    for (int64_t r = r0 + rl; r < r1; r += 4) acc = fmaf(w ? w[r * H + h] : 1.f, x[r * ldx + c], acc);
+    for (int64_t rb = r0 + rl; rb < r1; rb += 32) {       // eight independent row loads in flight per thread
+      float xv[8], wv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t r = rb + 4 * u;
+        const bool ok = r < r1;
+        xv[u] = ok ? x[r * ldx + c] : 0.f;
+        wv[u] = ok ? (w ? w[r * H + h] : 1.f) : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = fmaf(wv[u], xv[u], acc);
+    }
   }
   lds[rl][threadIdx.x & 63] = acc;
   __syncthreads();
-  if (rl == 0 && c < C) {
-    float sc = scale;
-    if (mean) sc = (r1 > r0) ? scale / (float)(r1 - r0) : 0.f;
-    out[(int64_t)s * ldo + c] = sc * (lds[0][threadIdx.x] + lds[1][threadIdx.x] + lds[2][threadIdx.x] + lds[3][threadIdx.x]);
-  }
+  if (rl == 0 && c < C)
+    part[((int64_t)blockIdx.z * nseg + s) * C + c] = (lds[0][threadIdx.x] + lds[1][threadIdx.x]) + (lds[2][threadIdx.x] + lds[3][threadIdx.x]);
+}
+__global__ void segment_wsum_final(const float* __restrict__ part, int nchunk, int nseg, int C, const int* __restrict__ seg_ptr,
+                                   int64_t rows_if_one, float scale, int mean, float* __restrict__ out, int64_t ldo) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)nseg * C) return;
+  const int s = (int)(i / C), c = (int)(i % C);
+  const int64_t len = seg_ptr ? (int64_t)(seg_ptr[s + 1] - seg_ptr[s]) : rows_if_one;
+  const int used = (int)((len + SEG_CHUNK - 1) / SEG_CHUNK);
+  float acc = 0.f;
+  for (int k = 0; k < used && k < nchunk; ++k) acc += part[((int64_t)k * nseg + s) * C + c];
+  float sc = scale;
+  if (mean) sc = len > 0 ? scale / (float)len : 0.f;
+  out[(int64_t)s * ldo + c] = sc * acc;
 }
 
 // y[r, c] (+)= alpha * w[r, c/Fh] * v[seg(r)?, c] ... generic rank-1 style broadcast add:
@@ -302,12 +326,16 @@ int tsgnn_csr_sddmm_heads_f32(const int* rowptr, const int* col, int H, int Fh, 
 }
 
 int tsgnn_segment_wsum_f32(const float* x, int64_t ldx, const float* w, int H, int Fh, const int* seg_ptr, int nseg, int64_t rows,
-                           float scale, int mean, float* out, int64_t ldo, tsgnn_stream_t stream) {
-  if (!x || !out || H <= 0 || Fh <= 0 || nseg <= 0 || rows < 0 || ldx < (int64_t)H * Fh || ldo < (int64_t)H * Fh) return TSGNN_EINVAL;
+                           int64_t max_seg, float scale, int mean, float* ws, float* out, int64_t ldo, tsgnn_stream_t stream) {
+  if (!x || !out || !ws || H <= 0 || Fh <= 0 || nseg <= 0 || rows < 0 || max_seg < 0 || ldx < (int64_t)H * Fh || ldo < (int64_t)H * Fh)
+    return TSGNN_EINVAL;
   if (!seg_ptr && nseg != 1) return TSGNN_EINVAL;
   const int C = H * Fh;
-  dim3 grid((unsigned)((C + 63) / 64), (unsigned)nseg);
-  segment_wsum_kernel<<<grid, 256, 0, stream>>>(x, ldx, w, H, Fh, seg_ptr, rows, C, scale, mean, out, ldo);
+  const int64_t longest = seg_ptr ? max_seg : rows;
+  const int nchunk = (int)(longest > 0 ? ceil_div64(longest, SEG_CHUNK) : 1);
+  dim3 grid((unsigned)((C + 63) / 64), (unsigned)nseg, (unsigned)nchunk);
+  segment_wsum_kernel<<<grid, 256, 0, stream>>>(x, ldx, w, H, Fh, seg_ptr, rows, C, ws, nseg);
+  segment_wsum_final<<<(unsigned)ceil_div64((int64_t)nseg * C, 256), 256, 0, stream>>>(ws, nchunk, nseg, C, seg_ptr, rows, scale, mean, out, ldo);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }

@@ -184,11 +184,11 @@ def filter_adj(edge_index, edge_attr, perm, num_nodes=None):
 # ----------------------------------------------------------------------------- readouts (a14)
 class _SegmentMean(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gp, B):
+    def forward(ctx, x, gp, B, ctx_max_seg):
         x = x.contiguous()
         ctx.save_for_backward(gp)
         ctx.shape = x.shape
-        return att.segment_wsum(x, None, 1, x.size(1), gp, B, mean=True)
+        return att.segment_wsum(x, None, 1, x.size(1), gp, B, mean=True, max_seg=ctx_max_seg)
 
     @staticmethod
     def backward(ctx, dout):
@@ -200,7 +200,7 @@ class _SegmentMean(torch.autograd.Function):
         # dx[r,:] += dout[seg(r),:] / n_seg : ragged broadcast through the row->graph map
         rows = torch.repeat_interleave(torch.arange(gp.numel() - 1, device=gp.device), (gp[1:] - gp[:-1]).long())
         dx = scaled[rows]
-        return dx, None, None
+        return dx, None, None, None
 
 
 def _pool_struct(x, batch, size):
@@ -211,7 +211,7 @@ def _pool_struct(x, batch, size):
 
 def global_mean_pool(x, batch, size=None):
     sizes, gp, B = _pool_struct(x, batch, size)
-    return _SegmentMean.apply(x, gp, B)
+    return _SegmentMean.apply(x, gp, B, int(sizes.max()) if len(sizes) else 0)
 
 
 def global_max_pool(x, batch, size=None):
