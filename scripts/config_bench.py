@@ -15,16 +15,16 @@ def timeit(fn, iters=30, warm=5):
         fn()
     torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-    e0.record()
+    e0.record(torch.cuda.current_stream())
     for _ in range(iters):
         fn()
-    e1.record(); e1.synchronize()
+    e1.record(torch.cuda.current_stream()); e1.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3     # us
 
 
 def graph_us(fn, iters=20):
     """the same step replayed from a hipGraph (no host overhead); None if the step cannot be captured"""
-    st = torch.cuda.Stream()
+    st = torch.cuda.current_stream()      # the script's one side stream: autograd's AccumulateGrad nodes live on it too
     try:
         with torch.cuda.stream(st):
             for _ in range(3):
@@ -50,6 +50,10 @@ class A:
 
 dev = torch.device("cuda")
 torch.manual_seed(0)
+# everything (eager timing and captures) runs on ONE side stream: capturing a step whose AccumulateGrad nodes were created on
+# another stream ends in a segfault inside torch's capture_end (stream-mismatch warning of torch.autograd.graph)
+_S = torch.cuda.Stream()
+torch.cuda.set_stream(_S)
 
 # config 2: PROTEINS SAGE 3-layer h=128 batch 64
 hb = synthetic.host_batch(1, 64, "PROTEINS", 620)
@@ -97,12 +101,12 @@ dpm = E.SoftPoolingGcnEncoder(512, 89, 64, 64, 2, 3, 64, assign_ratio=0.125, num
 def step_dp():
     dpm.zero_grad(set_to_none=True); dpm.loss(dpm(x5, g5, hb5["sizes"], assign_x=x5)[1], lab5).backward()
 t = timeit(step_dp, iters=10, warm=3)
-tg = None      # hipGraph capture of this step ends in a HIP-runtime segfault at capture_end (ROCm 7.2); eager only
+tg = graph_us(step_dp)
 print("cfg5 DD DiffPool 512->64->8 h64 b16: %.0f us/step eager, %s us/step hipGraph -> %.0f graphs/s" % (t, "%.0f" % tg if tg else "n/a", 16 / (tg or t) * 1e6))
 # the contraction alone, level 1 (S [rows,64], Z [rows,192]) + level 2 dense
 Sm = torch.softmax(torch.randn(g5.total_rows, 64, device=dev), -1); Sm[g5.n_rows:] = 0
 Z = torch.randn(g5.total_rows, 192, device=dev)
-gr = torch.cuda.CUDAGraph(); st = torch.cuda.Stream()
+gr = torch.cuda.CUDAGraph(); st = torch.cuda.current_stream()
 with torch.cuda.stream(st):
     for _ in range(3):
         dp.diffpool_contract_rows(Sm, Z, g5)

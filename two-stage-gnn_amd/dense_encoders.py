@@ -377,7 +377,6 @@ class SoftPoolingGcnEncoder(GcnEncoderGraph):
                                                    self.conv_block_after_pool[i], self.conv_last_after_pool[i])
             Bq, Kq, Cq = emb_dense.shape
             out_all.append(mp.readout_max(emb_dense.reshape(Bq * Kq, Cq), gd))
-            dense_x = dense_x  # x_a = x for the next level (encoders.py:376)
         output = torch.cat(out_all, dim=1) if self.concat else out_all[-1]
         return self._heads(output)
 

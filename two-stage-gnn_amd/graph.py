@@ -190,23 +190,12 @@ class GraphBatch:
             off = 0
             for n in self.sizes:
                 n = int(n)
-                for r in range(0, n, rows_per_slab):
-                    starts.append(off + r)
+                starts.extend(range(off, off + n, rows_per_slab))
                 seg.append(len(starts))
                 off += n
-            # a graph without rows still needs a (possibly empty) entry: its segment is simply empty
+            # consecutive slabs are contiguous inside a graph and graphs are contiguous too, so the slab starts followed
+            # by the total row count are exactly the [begin, end) boundaries the kernel reads
             srp = np.asarray(starts + [off], dtype=np.int32)
-            # slab t ends where the next starts, except at graph ends: build explicit ends
-            ends = []
-            off = 0
-            for n in self.sizes:
-                n = int(n)
-                for r in range(0, n, rows_per_slab):
-                    ends.append(off + min(n, r + rows_per_slab))
-                off += n
-            # the kernel reads [ptr[t], ptr[t+1]): consecutive slabs are contiguous inside a graph and graphs are
-            # contiguous too, so starts + [total] is exactly the boundary list
-            assert all(e == s2 for e, s2 in zip(ends, list(srp[1:])))
             cache = self._slabs = (torch.from_numpy(srp).to(self.device),
                                    torch.from_numpy(np.asarray(seg, dtype=np.int32)).to(self.device), len(starts), rows_per_slab)
         return cache[0], cache[1], cache[2]
