@@ -137,7 +137,14 @@ def main():
     torch.cuda.set_device(dev_index)                 # several ranks share one GPU for a functional rehearsal
     dev = torch.device("cuda", dev_index)
     backend = os.environ.get("TSGNN_DIST_BACKEND", "nccl")
-    if world > 1:
+    # TSGNN_FORCE_DIST=1 takes the N > 1 code path (process group, two hipGraphs around the RCCL all-reduce) with a single
+    # rank: the rehearsal of the multi-GPU path that fits a one-GPU box.
+    multi = world > 1 or os.environ.get("TSGNN_FORCE_DIST") == "1"
+    if multi:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)       # RCCL over xGMI
         else:
@@ -159,6 +166,7 @@ def main():
     hb = synthetic.host_batch(seed=rank, B=a.batch, shape=a.shape, nmax=a.nmax)      # per-rank batch (weak scaling)
     g, x, label = synthetic.to_device(hb, dev)
     trainer = FlatTrainer(model, lr=1e-3, clip=2.0)
+    trainer.always_reduce = multi
 
     def fwd_bwd():
         trainer.zero_grad()
@@ -178,23 +186,23 @@ def main():
         if use_graph:
             # N > 1: fwd+bwd+bucket and clip+Adam are two hipGraphs with the RCCL all-reduce issued between them on the
             # same stream; N = 1: one hipGraph for the whole step.
-            if world > 1:
+            if multi:
                 dist.barrier()                                 # no collective in flight while capturing
                 torch.cuda.synchronize()
             # thread_local: the RCCL watchdog thread may touch the HIP runtime while this thread captures
-            mode = {"capture_error_mode": "thread_local"} if world > 1 else {}
+            mode = {"capture_error_mode": "thread_local"} if multi else {}
             graph_fb = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph_fb, stream=stream, **mode):
                 fwd_bwd()
-                if world == 1:
+                if not multi:
                     trainer.apply()                            # single GPU: no collective, the whole step is one graph
-            if world > 1:
+            if multi:
                 graph_opt = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph_opt, stream=stream, **mode):
                     trainer.apply()
 
         def step():
-            if use_graph and world == 1:
+            if use_graph and not multi:
                 graph_fb.replay()
             elif use_graph:
                 graph_fb.replay(); trainer.all_reduce(); graph_opt.replay()
@@ -204,19 +212,19 @@ def main():
         for _ in range(a.warmup):
             step()
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(a.steps):
             step()
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        if world > 1:
+        if multi:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -265,7 +273,7 @@ def main():
                     print("sweep B=%d rows=%d: %.2f us, %.0f GB/s (%.1f%% of 8 TB/s)" % (B, gs.n_rows, ms * 1e3, nb / ms / 1e6,
                                                                                        nb / ms / 1e6 / HBM_PEAK_GBS * 100), file=sys.stderr)
         print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -42,6 +42,7 @@ class FlatTrainer:
         self._zeros = [torch.zeros_like(p).reshape(-1) for p in self.params]     # stand-ins for parameters without a gradient
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.always_reduce = False          # issue the collective even in a one-rank group (single-GPU rehearsal of the N > 1 path)
 
     def zero_grad(self):
         for p in self.params:
@@ -55,7 +56,7 @@ class FlatTrainer:
 
     def all_reduce(self):
         """SUM over ranks on the flat bucket; the 1/world factor is applied inside the optimiser kernel."""
-        if self.world > 1:
+        if self.world > 1 or self.always_reduce:
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
 
     def apply(self):
