@@ -172,7 +172,7 @@ def main():
         trainer.zero_grad()
         _, ypred = model(x, g)
         loss = model.loss(ypred, label)
-        loss.backward()
+        trainer.backward(loss)
         trainer.gather_grads()
         return loss
 

@@ -181,3 +181,54 @@ def test_hip_clip_adam_matches_torch():
         opt.step()
     for a, b in zip(m1.parameters(), m2.parameters()):
         torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_direct_gradient_placement_equals_concatenated_bucket():
+    """gradients written in place by the fused backward nodes (GradSink) == autograd tensors concatenated afterwards,
+    also when seeded with the cached unit scalar, and for a parameter outside every fused node."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from two_stage_gnn_amd import dense_encoders as E, synthetic, message_passing as mp
+    from two_stage_gnn_amd.data_parallel import FlatTrainer
+
+    class A:
+        bias = True
+
+    class WithExtra(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.enc = E.GcnEncoderGraph(7, 16, 16, 2, 3, bn=True, args=A(), final_dim="number_classes")
+            self.temperature = torch.nn.Parameter(torch.tensor([1.3]))      # plain torch op: stays on the autograd path
+            self.unused = torch.nn.Parameter(torch.ones(5))                  # never receives a gradient
+
+        def forward(self, x, g):
+            return self.enc(x, g)[1] * self.temperature
+
+    dev = torch.device("cuda")
+    hb = synthetic.host_batch(seed=3, B=6, shape="MUTAG", nmax=40)
+    g, x, label = synthetic.to_device(hb, dev)
+    results = []
+    for direct in (False, True):
+        torch.manual_seed(11)
+        model = WithExtra().to(dev)
+        tr = FlatTrainer(model, lr=1e-3, clip=2.0, direct_grads=direct)
+        grads = []
+        for it in range(3):
+            tr.zero_grad()
+            loss = model.enc.loss(model(x, g), label)
+            if direct:
+                tr.backward(loss)
+            else:
+                loss.backward()
+            tr.gather_grads()
+            assert mp.GRAD_SINK is None
+            grads.append(tr.flat_grad.clone())
+            tr.apply()
+        if direct:
+            assert len(tr.sink.written) >= 4                                 # conv and head parameters landed in place
+        results.append((grads, tr.flat_param.clone()))
+    for a, b in zip(results[0][0], results[1][0]):
+        torch.testing.assert_close(a, b, rtol=0, atol=0)
+    torch.testing.assert_close(results[0][1], results[1][1], rtol=0, atol=0)
+    assert float(results[1][0][0].abs().sum()) > 0

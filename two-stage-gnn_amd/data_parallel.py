@@ -12,13 +12,14 @@ import torch
 import torch.distributed as dist
 
 from . import _native as nat
+from . import message_passing as mp
 
 
 class FlatTrainer:
     """Owns flat parameter / gradient / Adam-moment buffers; model parameters become views of the flat
     parameter buffer, so the HIP optimiser kernel updates the model in place."""
 
-    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip=2.0, group=None):
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip=2.0, group=None, direct_grads=True):
         self.model = model
         self.params = [p for p in model.parameters() if p.requires_grad]
         dev = self.params[0].device
@@ -42,16 +43,53 @@ class FlatTrainer:
         self._zeros = [torch.zeros_like(p).reshape(-1) for p in self.params]     # stand-ins for parameters without a gradient
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        # direct_grads: between zero_grad() and gather_grads() the fused backward nodes write parameter gradients straight
+        # into their slice of flat_grad (message_passing.GradSink); requires ONE backward per step in which every
+        # parameter feeds at most one fused node (true for the encoders here; tripletnet batches its three forwards).
+        self.sink = None
+        self._dirty = set()                 # parameter indices whose slice of flat_grad may be non-zero (it starts all zero)
+        if direct_grads and self.on_gpu:
+            self.sink = mp.GradSink()
+            for p, (o, n) in zip(self.params, self.views):
+                self.sink.views[p.data_ptr()] = self.flat_grad[o:o + n].view_as(p.data)
         self.always_reduce = False          # issue the collective even in a one-rank group (single-GPU rehearsal of the N > 1 path)
 
     def zero_grad(self):
         for p in self.params:
             p.grad = None
+        if self.sink is not None:
+            self.sink.written.clear()
+            mp.GRAD_SINK = self.sink
+
+    def backward(self, loss):
+        """loss.backward() seeded with the cached unit scalar (no fill launch, no multiply by 1 in the loss node)."""
+        loss.backward(gradient=mp.unit_seed(loss.device) if loss.is_cuda and loss.dim() == 0 else None)
 
     def gather_grads(self):
-        """per-parameter gradients -> the flat bucket (one concatenation kernel)."""
-        parts = [(p.grad.reshape(-1) if p.grad is not None else z) for p, z in zip(self.params, self._zeros)]
-        torch.cat(parts, out=self.flat_grad)
+        """per-parameter gradients -> the flat bucket: nothing to do for slices the backward nodes wrote in place; one
+        concatenation kernel when none were; a copy / clear per remaining parameter otherwise."""
+        written = ()
+        if self.sink is not None:
+            mp.GRAD_SINK = None
+            written = self.sink.written
+        if not written:
+            parts = [(p.grad.reshape(-1) if p.grad is not None else z) for p, z in zip(self.params, self._zeros)]
+            torch.cat(parts, out=self.flat_grad)
+            self._dirty = {i for i, p in enumerate(self.params) if p.grad is not None}
+            return self.flat_grad
+        for i, (p, (o, n)) in enumerate(zip(self.params, self.views)):
+            direct = p.data_ptr() in written
+            if p.grad is not None:
+                if direct:
+                    self.flat_grad[o:o + n].add_(p.grad.reshape(-1))       # used by a sink node AND an ordinary op
+                else:
+                    self.flat_grad[o:o + n].copy_(p.grad.reshape(-1))
+                self._dirty.add(i)
+            elif direct:
+                self._dirty.add(i)
+            elif i in self._dirty:                                          # no gradient this step, stale values from an earlier one
+                self.flat_grad[o:o + n].zero_()
+                self._dirty.discard(i)
         return self.flat_grad
 
     def all_reduce(self):
@@ -72,7 +110,7 @@ class FlatTrainer:
         """loss_fn() -> scalar loss.  fwd + bwd + all-reduce + clip + Adam."""
         self.zero_grad()
         loss = loss_fn()
-        loss.backward()
+        self.backward(loss)
         self.gather_grads()
         self.all_reduce()
         self.apply()

@@ -397,6 +397,45 @@ def mask_ghost_rows(x, g):
     return _MaskGhost.apply(x, g.n_rows) if g.n_ghost else x
 
 
+# ----------------------------------------------------------------------------- gradient sink / unit seed
+class GradSink:
+    """Lets the fused backward nodes write a parameter's gradient straight into its slice of a flat bucket
+    (data_parallel.FlatTrainer) instead of handing autograd a fresh tensor that is concatenated afterwards.  A node that
+    used the sink returns None for that parameter; ``written`` records which slices were produced this step."""
+
+    def __init__(self):
+        self.views = {}             # parameter data_ptr -> view of the flat gradient buffer, shaped like the parameter
+        self.written = set()
+
+    def take(self, param, shape):
+        v = self.views.get(param.data_ptr())
+        if v is None or tuple(v.shape) != tuple(shape):
+            return None
+        self.written.add(param.data_ptr())
+        return v
+
+
+GRAD_SINK = None                    # installed by FlatTrainer between zero_grad() and gather_grads()
+_unit = {}
+
+
+def _sink_or_new(param, shape, device):
+    """(buffer, came_from_sink)"""
+    v = GRAD_SINK.take(param, shape) if (GRAD_SINK is not None and param is not None) else None
+    if v is not None:
+        return v, True
+    return _f32(*shape, device=device), False
+
+
+def unit_seed(device):
+    """cached scalar 1.0 to seed ``loss.backward(gradient=unit_seed(dev))``: no fill launch, and the fused loss node
+    recognises the object and skips the multiply by 1."""
+    t = _unit.get(device)
+    if t is None:
+        t = _unit[device] = torch.ones((), dtype=torch.float32, device=device)
+    return t
+
+
 # ----------------------------------------------------------------------------- loss
 class _SoftmaxCE(torch.autograd.Function):
     """F.cross_entropy(pred, label) (encoders.py:221-224) with the logits gradient produced in the same launch."""
@@ -414,6 +453,8 @@ class _SoftmaxCE(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dlogits,) = ctx.saved_tensors
+        if g is _unit.get(g.device):                        # seeded with unit_seed(): d loss = 1 by construction
+            return dlogits, None
         return dlogits * g, None
 
 
@@ -438,6 +479,8 @@ class _Head2(torch.autograd.Function):
         nat.call("head2_fwd_f32", out, out.stride(0), w1c, b1, w2c, b2, B, P, E, C, vec, y)
         ctx.save_for_backward(out, w1c, w2c, vec)
         ctx.has_b = (b1 is not None, b2 is not None)
+        ctx.params = (w1, b1, w2, b2)
+        ctx.set_materialize_grads(False)                    # an unused output must not cost a zero-fill launch
         return vec, y
 
     @staticmethod
@@ -446,15 +489,19 @@ class _Head2(torch.autograd.Function):
         B, P = out.shape
         E, C = w1.size(0), w2.size(0)
         dev = out.device
+        if dy is None and dvec is None:
+            return None, None, None, None, None
         dy = dy.contiguous() if dy is not None else torch.zeros(B, C, device=dev)
         dvec = dvec.contiguous() if dvec is not None else None
         dvt = _f32(B, E, device=dev)
         dout = _f32(B, P, device=dev)
-        dw1, dw2 = _f32(E, P, device=dev), _f32(C, E, device=dev)
-        db1 = _f32(E, device=dev) if ctx.has_b[0] else None
-        db2 = _f32(C, device=dev) if ctx.has_b[1] else None
+        pw1, pb1, pw2, pb2 = ctx.params
+        dw1, s1 = _sink_or_new(pw1, (E, P), dev)
+        dw2, s2 = _sink_or_new(pw2, (C, E), dev)
+        db1, s3 = _sink_or_new(pb1, (E,), dev) if ctx.has_b[0] else (None, False)
+        db2, s4 = _sink_or_new(pb2, (C,), dev) if ctx.has_b[1] else (None, False)
         nat.call("head2_bwd_f32", out, out.stride(0), vec, dy, dvec, w1, w2, B, P, E, C, dvt, dout, dout.stride(0), dw1, db1, dw2, db2)
-        return dout, dw1, db1, dw2, db2
+        return dout, None if s1 else dw1, None if s3 else db1, None if s2 else dw2, None if s4 else db2
 
 
 def head2_ok(out, lin1, lin2):

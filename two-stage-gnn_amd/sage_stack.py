@@ -100,6 +100,7 @@ class _SageStack(torch.autograd.Function):
         nat.call("readout_decode_layers_f32", packed, B, L, Fh, Fl, out, out.stride(0), arg)
         ctx.g, ctx.L, ctx.has_bias, ctx.dims = g, L, has_bias, (Fh, Fl)
         ctx.Ws, ctx.saved, ctx.arg = Ws, saved, arg
+        ctx.params = params
         ctx.x0_ld = x.size(1) if L == 0 else x0.size(1)
         return out
 
@@ -136,9 +137,10 @@ class _SageStack(torch.autograd.Function):
                 if want_w:
                     sl = mp.linear_wgrad_slabs(z, K, du)
                     if sl is not None:                      # slabs now, ONE reduction for all layers at the end
-                        dw = torch.empty(K, N, dtype=torch.float32, device=dev)
-                        db = torch.empty(N, dtype=torch.float32, device=dev) if want_b else None
+                        dw, sw = mp._sink_or_new(ctx.params[2 * l], (K, N), dev)     # straight into the flat bucket if one is installed
+                        db, sb = mp._sink_or_new(ctx.params[2 * l + 1], (N,), dev) if want_b else (None, False)
                         pending.append((sl[0], sl[1], K, N, dw, db))
+                        dw, db = (None if sw else dw), (None if sb else db)
                     else:
                         dw, db = mp.linear_wgrad(z, K, du, want_b)
                     grads[2 * l], grads[2 * l + 1] = dw, db
