@@ -61,6 +61,23 @@ __device__ __forceinline__ int wave_sum_i(int v) {
   return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
          __builtin_amdgcn_readlane(v, 48);
 }
+// Transposing reduction: every lane holds s[0..15]; lane l returns the sum of s[l & 15] over the 16 lanes of its DPP
+// row.  Each step halves the values a lane carries (keep one half, hand the other half to the partner), so the whole
+// thing is 15 DPP adds + 30 selects instead of 64 DPP adds.  Partner order row_mirror (l^15), row_half_mirror (l^7),
+// quad xor 2, quad xor 1: each partner agrees on the bits already used and differs in the bit selected on.
+__device__ __forceinline__ float row16_sum_transpose(const float (&s)[16]) {
+  const unsigned l = threadIdx.x;
+  const bool b3 = l & 8u, b2 = l & 4u, b1 = l & 2u, b0 = l & 1u;
+  float a8[8], a4[4], a2[2];
+#pragma unroll
+  for (int p = 0; p < 8; ++p) a8[p] = (b3 ? s[p + 8] : s[p]) + dpp_f32<0x140>(b3 ? s[p] : s[p + 8]);
+#pragma unroll
+  for (int p = 0; p < 4; ++p) a4[p] = (b2 ? a8[p + 4] : a8[p]) + dpp_f32<0x141>(b2 ? a8[p] : a8[p + 4]);
+#pragma unroll
+  for (int p = 0; p < 2; ++p) a2[p] = (b1 ? a4[p + 2] : a4[p]) + dpp_f32<0x4E>(b1 ? a4[p] : a4[p + 2]);
+  return (b0 ? a2[1] : a2[0]) + dpp_f32<0xB1>(b0 ? a2[0] : a2[1]);
+}
+
 // reduction inside an aligned power-of-two lane group of width G (<= 64); every lane of the group gets the result
 template <int G>
 __device__ __forceinline__ float group_sum(float v) {

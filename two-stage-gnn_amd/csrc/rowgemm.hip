@@ -5,14 +5,18 @@
 //   optional epilogue: + bias, row L2 normalise (F.normalize eps 1e-12, encoders.py:38-40), rinv out
 //
 // R is the number of graph rows (thousands to millions), K and N are feature widths (<= 256).
-// One 256-thread block owns 32 rows x all N columns.  K is consumed in 32-wide chunks staged through
-// LDS with 16-byte global loads and a register prefetch of the next chunk (loads fly under the MFMAs).
+// One 256-thread block owns 32 rows x all N columns.  K is consumed in 32-wide chunks through a software
+// pipeline (16-byte global loads two chunks ahead -> registers -> two LDS stages -> operand registers one chunk
+// ahead -> MFMA chain; one barrier per chunk).
 // A fragments are read as ds_read_b128 from a [32][K+4] image: the K order inside an MFMA group is
 // permuted (half h of the wave takes k = 8u+4h+c) so one 16-byte read feeds four v_mfma_f32_32x32x2_f32;
 // with the +4 padding every 16-lane read group touches 64 distinct banks.  B fragments are ds_read_b32
-// of 32 consecutive floats (conflict-free).  Exact fp32 (k-ordered fma chains).
+// of 32 consecutive floats (conflict-free); for B = W^T the W chunk keeps its [n][k] layout in LDS and is read
+// with the same 16-byte fragment pattern as A.  The bias / L2-normalise epilogue works on the accumulators in
+// registers (row sums of squares: DPP over 32 lanes, then 4 waves through LDS).  fp32 MFMA throughout.
 #include "common.h"
 #include "../../include/tsgnn.h"
+#include <type_traits>
 
 namespace {
 
@@ -31,74 +35,130 @@ struct RowGemmArgs {
   int normalize;
 };
 
+// developer instrumentation (scripts/trace_rowgemm.hip builds this file with -DTSGNN_TRACE): per-wave s_memtime stamps
+#ifdef TSGNN_TRACE
+__device__ long long g_trace[4096 * 16];
+#define TR(slot) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) g_trace[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define TR(slot) do { } while (0)
+#endif
+
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
 template <int NT, bool TRANS_B>
 __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs g) {
   constexpr int NP = 32 * NT;
   constexpr int TPW = (NT + 3) / 4;
-  constexpr int LDB_S = TRANS_B ? NP + 1 : NP;
-  constexpr int BV = (KC * NP) / (256 * 4);            // float4 of B per thread per chunk (= NT)
+  constexpr int BV = NT;                               // float4 of B per thread per chunk (KC * NP / 1024)
+  constexpr int A_FLOATS = 32 * LDA_S;
+  constexpr int B_FLOATS = TRANS_B ? NP * LDA_S : KC * NP;
+  constexpr int STAGE = A_FLOATS + B_FLOATS;           // one of the two LDS stages
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;                                    // [32][LDA_S]
-  float* Bs = smem + 32 * LDA_S;                       // [KC][LDB_S]
-  float* Cs = smem;                                    // epilogue tile [32][NP+1], aliases As/Bs
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int i = lane & 31, h = lane >> 5;
   const int64_t m0 = (int64_t)blockIdx.x * 32;
+  TR(0);
 
-  // staging maps ------------------------------------------------------------------------------
-  const int am = tid >> 3, ak4 = tid & 7;              // A: row am, floats 4*ak4..+3 of the chunk
-  const int64_t arow = m0 + am;
-  float4 ra;
-  float4 rb[BV];
-  // loads are unconditional (clamped addresses) so nothing waits on them before the MFMAs; validity
-  // masks are applied when the registers are written to LDS.
-  int a_valid = 0;                                     // number of valid floats of ra (0..4)
-  unsigned b_valid = 0;                                // bit q: rb[q] valid
-  auto load_chunk = [&](int k0) {
+  // staging maps (computed once) ------------------------------------------------------------------
+  // A: thread -> row am, floats 4*ak4..+3 of the chunk.  B: float4 q of the thread -> (k, n4) or (n, k4).
+  // Loads are unconditional from clamped (always mapped) addresses; validity is applied when the registers
+  // are written to LDS, so nothing waits on a load before the MFMAs of the current chunk.
+  const int am = tid >> 3, ak4 = tid & 7;
+  const bool a_row_ok = (m0 + am) < g.rows;
+  const float* ap = g.a + (a_row_ok ? (m0 + am) : 0) * g.lda + 4 * ak4;
+  const float* bp[BV];
+  int b_k[BV];                                         // k (or first k of the float4) inside the chunk
+  int b_lds[BV];
+  bool b_nok[BV];
+#pragma unroll
+  for (int q = 0; q < BV; ++q) {
+    const int idx = q * 256 + tid;
+    if (!TRANS_B) {
+      const int k = idx / (NP / 4), n4 = idx % (NP / 4);
+      b_nok[q] = 4 * n4 < g.N;                         // N % 4 == 0 on this path
+      bp[q] = g.b + (int64_t)k * g.ldb + (b_nok[q] ? 4 * n4 : 0);
+      b_k[q] = k;
+      b_lds[q] = k * NP + 4 * n4;
+    } else {
+      const int n = idx / (KC / 4), k4 = idx % (KC / 4);
+      b_nok[q] = n < g.N;                              // K % 4 == 0 on this path
+      bp[q] = g.b + (int64_t)(b_nok[q] ? n : 0) * g.ldb + 4 * k4;
+      b_k[q] = 4 * k4;
+      b_lds[q] = n * LDA_S + 4 * k4;
+    }
+  }
+  struct Staged {                                      // one K chunk on its way global -> registers -> LDS
+    float4 ra;
+    float4 rb[BV];
+    int a_valid;                                       // number of valid floats of ra (0..4)
+    unsigned b_valid;                                  // bit q: rb[q] valid
+    bool plain;                                        // uniform: no masking needed
+  };
+  const bool panel_full = (m0 + 32) <= g.rows && g.N == NP;   // uniform: every row and column of the panel exists
+  auto fetch = [&](Staged& s, int k0) {                // G(c): global -> registers
+    s.plain = panel_full && (k0 + KC) <= g.K;
+    s.a_valid = 0;
+    s.b_valid = 0;
+    if (s.plain) {
+      s.ra = ldg4(ap + k0);
+#pragma unroll
+      for (int q = 0; q < BV; ++q) s.rb[q] = ldg4(TRANS_B ? bp[q] + k0 : bp[q] + (int64_t)k0 * g.ldb);
+      return;
+    }
     const int gk = k0 + 4 * ak4;
-    const bool ok = arow < g.rows && gk < g.K;
-    a_valid = ok ? min(4, g.K - gk) : 0;
-    ra = ldg4(ok ? g.a + arow * g.lda + gk : g.a);
-    b_valid = 0;
+    const bool ok = a_row_ok && gk < g.K;
+    s.a_valid = ok ? min(4, g.K - gk) : 0;
+    s.ra = ldg4(gk < g.K ? ap + k0 : ap - 4 * ak4);
 #pragma unroll
     for (int q = 0; q < BV; ++q) {
-      const int idx = q * 256 + tid;
-      bool okb;
-      const float* p;
-      if (!TRANS_B) {
-        const int k = idx / (NP / 4), n4 = idx % (NP / 4);
-        okb = (k0 + k) < g.K && 4 * n4 < g.N;          // N % 4 == 0 on this path
-        p = g.b + (int64_t)(k0 + k) * g.ldb + 4 * n4;
-      } else {
-        const int n = idx / (KC / 4), k4 = idx % (KC / 4);
-        okb = n < g.N && (k0 + 4 * k4) < g.K;          // K % 4 == 0 on this path
-        p = g.b + (int64_t)n * g.ldb + k0 + 4 * k4;
-      }
-      rb[q] = ldg4(okb ? p : g.b);
-      b_valid |= okb ? (1u << q) : 0u;
+      const bool kok = (k0 + b_k[q]) < g.K;
+      if (!TRANS_B) s.rb[q] = ldg4(kok ? bp[q] + (int64_t)k0 * g.ldb : bp[q] - (int64_t)b_k[q] * g.ldb);
+      else s.rb[q] = ldg4(kok ? bp[q] + k0 : bp[q] - b_k[q]);
+      s.b_valid |= (kok && b_nok[q]) ? (1u << q) : 0u;
     }
   };
-  auto store_chunk = [&]() {
-    float4 va = ra;
-    if (a_valid < 4) va.w = 0.f;
-    if (a_valid < 3) va.z = 0.f;
-    if (a_valid < 2) va.y = 0.f;
-    if (a_valid < 1) va.x = 0.f;
-    *reinterpret_cast<float4*>(As + am * LDA_S + 4 * ak4) = va;
+  auto commit = [&](const Staged& s, float* st) {      // S(c): registers -> LDS stage
+    if (s.plain) {
+      *reinterpret_cast<float4*>(st + am * LDA_S + 4 * ak4) = s.ra;
 #pragma unroll
-    for (int q = 0; q < BV; ++q) {
-      const int idx = q * 256 + tid;
-      const float4 vb = ((b_valid >> q) & 1u) ? rb[q] : make_float4(0.f, 0.f, 0.f, 0.f);
-      if (!TRANS_B) {
-        const int k = idx / (NP / 4), n4 = idx % (NP / 4);
-        *reinterpret_cast<float4*>(Bs + k * LDB_S + 4 * n4) = vb;
+      for (int q = 0; q < BV; ++q) *reinterpret_cast<float4*>(st + A_FLOATS + b_lds[q]) = s.rb[q];
+      return;
+    }
+    float4 va = s.ra;
+    if (s.a_valid < 4) va.w = 0.f;
+    if (s.a_valid < 3) va.z = 0.f;
+    if (s.a_valid < 2) va.y = 0.f;
+    if (s.a_valid < 1) va.x = 0.f;
+    *reinterpret_cast<float4*>(st + am * LDA_S + 4 * ak4) = va;
+#pragma unroll
+    for (int q = 0; q < BV; ++q)
+      *reinterpret_cast<float4*>(st + A_FLOATS + b_lds[q]) = ((s.b_valid >> q) & 1u) ? s.rb[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  auto frags = [&](const float* st, float (&af)[KC / 2], float (&bf)[TPW][KC / 2]) {   // R(c): LDS -> MFMA operands
+    const float* As = st;
+    const float* Bs = st + A_FLOATS;
+#pragma unroll
+    for (int u = 0; u < KC / 8; ++u) {
+      const float4 v = *reinterpret_cast<const float4*>(As + i * LDA_S + 8 * u + 4 * h);
+      af[4 * u] = v.x; af[4 * u + 1] = v.y; af[4 * u + 2] = v.z; af[4 * u + 3] = v.w;
+    }
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      const int tile = wid + 4 * t;
+      if (4 * (t + 1) <= NT || tile < NT) {             // compile-time true for full groups of 4 tiles
+#pragma unroll
+        for (int u = 0; u < KC / 8; ++u) {
+          if (!TRANS_B) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) bf[t][4 * u + c] = Bs[(8 * u + 4 * h + c) * NP + tile * 32 + i];
+          } else {                                      // W row n = output column: same 16-byte fragment read as A
+            const float4 v = *reinterpret_cast<const float4*>(Bs + (tile * 32 + i) * LDA_S + 8 * u + 4 * h);
+            bf[t][4 * u] = v.x; bf[t][4 * u + 1] = v.y; bf[t][4 * u + 2] = v.z; bf[t][4 * u + 3] = v.w;
+          }
+        }
       } else {
-        const int n = idx / (KC / 4), k4 = idx % (KC / 4);
-        Bs[(4 * k4 + 0) * LDB_S + n] = vb.x;
-        Bs[(4 * k4 + 1) * LDB_S + n] = vb.y;
-        Bs[(4 * k4 + 2) * LDB_S + n] = vb.z;
-        Bs[(4 * k4 + 3) * LDB_S + n] = vb.w;
+#pragma unroll
+        for (int j = 0; j < KC / 2; ++j) bf[t][j] = 0.f;
       }
     }
   };
@@ -107,101 +167,145 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs g) {
 #pragma unroll
   for (int t = 0; t < TPW; ++t)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  const int i = lane & 31, h = lane >> 5;
-  load_chunk(0);
-  store_chunk();
+  // Software pipeline over the K chunks c = 0, 1, ...:  G(c) global->registers, S(c) registers->LDS stage c&1,
+  // R(c) LDS->operand registers, M(c) the MFMA chain.  Iteration c runs  R(c+1) | M(c) | S(c+2) | G(c+4)  and ends on
+  // the only barrier: operands of the next chunk are already in registers when M(c) finishes, and a chunk's global
+  // loads have two iterations to land.  Stage c&1 is rewritten in iteration c, one barrier after its readers R(c).
+  // NS register staging sets: with 4 (widths <= 128) the first four chunks are all in flight before any MFMA.
+  constexpr int NS = NT <= 4 ? 4 : 2;
+  Staged st[NS];
+#pragma unroll
+  for (int c = 0; c < NS; ++c)
+    if (c == 0 || c * KC < g.K) fetch(st[c], c * KC);
+  float bias_v[TPW];                                   // fetched now, used in the epilogue
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int cn = (wid + 4 * t) * 32 + i;
+    bias_v[t] = (g.bias && (wid + 4 * t) < NT && cn < g.N) ? g.bias[cn] : 0.f;
+  }
+  TR(1);
+  commit(st[0], smem);
+  if (KC < g.K) commit(st[1], smem + STAGE);
   __syncthreads();
-  for (int k0 = 0; k0 < g.K; k0 += KC) {
-    const bool more = (k0 + KC) < g.K;
-    if (more) load_chunk(k0 + KC);                     // in flight under the MFMAs below
+  TR(2);
+  float fa[2][KC / 2], fb[2][TPW][KC / 2];
+  frags(smem, fa[0], fb[0]);
+  if (NS == 2) {
+    if (2 * KC < g.K) fetch(st[0], 2 * KC);
+    if (3 * KC < g.K) fetch(st[1], 3 * KC);
+  }
+  auto body = [&](auto ci_, int c) {
+    constexpr int CI = decltype(ci_)::value;           // c mod 4, compile time: register sets are picked statically
+    constexpr int P = CI & 1;
+    const int k0 = c * KC;
+    if (k0 + KC < g.K) frags(smem + (P ^ 1) * STAGE, fa[P ^ 1], fb[P ^ 1]);
+    if (NS == 4 && c >= 0 && k0 + 4 * KC < g.K) fetch(st[CI % NS], k0 + 4 * KC);
+    __builtin_amdgcn_sched_barrier(0);                 // the scheduler would sink the LDS reads to their uses
 #pragma unroll
-    for (int u = 0; u < KC / 8; ++u) {
-      const float4 af = *reinterpret_cast<const float4*>(As + i * LDA_S + 8 * u + 4 * h);
-      const float av[4] = {af.x, af.y, af.z, af.w};
+    for (int j = 0; j < 8; ++j) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[P][j], fb[P][0][j], acc[0], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (k0 + 2 * KC < g.K) commit(st[(CI + 2) % NS], smem + P * STAGE);
+    if (NS == 2 && k0 + 4 * KC < g.K) fetch(st[CI % NS], k0 + 4 * KC);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int t = 0; t < TPW; ++t) {
-        const int tile = wid + 4 * t;
-        if (4 * (t + 1) <= NT || tile < NT) {           // compile-time true for full groups of 4 tiles
-          const float* bp = Bs + (8 * u + 4 * h) * LDB_S + tile * 32 + i;
+    for (int j = 8; j < KC / 2; ++j) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[P][j], fb[P][0][j], acc[0], 0, 0, 0);
 #pragma unroll
-          for (int c = 0; c < 4; ++c)
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c], bp[c * LDB_S], acc[t], 0, 0, 0);
-        }
+    for (int t = 1; t < TPW; ++t) {
+      if (4 * (t + 1) <= NT || (wid + 4 * t) < NT) {
+#pragma unroll
+        for (int j = 0; j < KC / 2; ++j) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[P][j], fb[P][t][j], acc[t], 0, 0, 0);
       }
     }
+    TR(3 + 2 * min(c, 3));
     __syncthreads();
-    if (more) {
-      store_chunk();
-      __syncthreads();
-    }
+    TR(4 + 2 * min(c, 3));
+  };
+  for (int c = 0; c * KC < g.K; c += 4) {
+    body(std::integral_constant<int, 0>{}, c);
+    if ((c + 1) * KC < g.K) body(std::integral_constant<int, 1>{}, c + 1);
+    if ((c + 2) * KC < g.K) body(std::integral_constant<int, 2>{}, c + 2);
+    if ((c + 3) * KC < g.K) body(std::integral_constant<int, 3>{}, c + 3);
   }
 
-  if (!g.normalize && !g.bias) {
-    // plain product: accumulators straight to global (32 lanes = 128 contiguous bytes per row)
+  // epilogue in registers: lane (i, h) of tile `wid + 4t` holds C[(r&3) + 8(r>>2) + 4h][tile*32 + i] in acc[t][r].
+  float scale[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) scale[r] = 1.f;
+  if (g.bias || g.normalize) {
+    float ss[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ss[r] = 0.f;
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
       const int tile = wid + 4 * t;
-      if (tile < NT) {
-        const int cn = tile * 32 + (lane & 31);
+      const int cn = tile * 32 + i;
+      const bool okc = tile < NT && cn < g.N;
+      const float bv = bias_v[t];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t gm = m0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          if (gm < g.rows && cn < g.N) g.c[gm * g.ldc + cn] = acc[t][r];
-        }
+      for (int r = 0; r < 16; ++r) {
+        const float v = okc ? acc[t][r] + bv : 0.f;
+        acc[t][r] = v;
+        ss[r] = fmaf(v, v, ss[r]);
       }
     }
-    return;
+    if (g.normalize) {
+      // row sums of squares: transposing DPP reduction inside each 16-lane row (lane l ends with row r = l & 15 of its
+      // half), the two rows of a half through one bpermute, the four waves (column tiles) through LDS; then each wave
+      // turns the 32 totals into 1/max(|u|, eps) with one v_rsq per lane and hands them out through LDS.
+      float* red = smem + 2 * STAGE;                   // [32 rows][4 waves]
+      float* inv = red + 128 + wid * 32;               // per wave [32 rows]
+      float tot = row16_sum_transpose(ss);
+      tot += __shfl_xor(tot, 16, 64);
+      TR(11);
+      if ((lane & 16) == 0) {
+        const int r = lane & 15;
+        red[((r & 3) + 8 * (r >> 2) + 4 * h) * 4 + wid] = tot;
+      }
+      __syncthreads();
+      TR(12);
+      if (lane < 32) {
+        const float4 p = *reinterpret_cast<const float4*>(red + lane * 4);
+        const float rs = fminf(__builtin_amdgcn_rsqf((p.x + p.y) + (p.z + p.w)), 1.0f / NORM_EPS);
+        inv[lane] = rs;
+        if (g.rinv && wid == 0 && (m0 + lane) < g.rows) g.rinv[m0 + lane] = rs;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(inv + 8 * q + 4 * h);
+        scale[4 * q] = v.x; scale[4 * q + 1] = v.y; scale[4 * q + 2] = v.z; scale[4 * q + 3] = v.w;
+      }
+      TR(14);
+    }
   }
-  constexpr int LDC_S = NP + 1;
+  const bool full = panel_full;                        // uniform: no per-element predicates on the common path
 #pragma unroll
   for (int t = 0; t < TPW; ++t) {
     const int tile = wid + 4 * t;
     if (tile < NT) {
-      const int cn = tile * 32 + (lane & 31);
-      const float bv = (g.bias && cn < g.N) ? g.bias[cn] : 0.f;
+      const int cn = tile * 32 + i;
+      float* cp = g.c + (m0 + 4 * h) * g.ldc + cn;
+      if (full) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int cm = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        Cs[cm * LDC_S + cn] = acc[t][r] + bv;
+        for (int r = 0; r < 16; ++r) cp[(int64_t)((r & 3) + 8 * (r >> 2)) * g.ldc] = acc[t][r] * scale[r];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t gm = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (gm < g.rows && cn < g.N) cp[(int64_t)((r & 3) + 8 * (r >> 2)) * g.ldc] = acc[t][r] * scale[r];
+        }
       }
     }
   }
-  __syncthreads();
-  for (int m = wid; m < 32; m += 4) {
-    const int64_t gm = m0 + m;
-    if (gm >= g.rows) break;
-    float u[(NP + 63) / 64];
-    float ss = 0.f;
-#pragma unroll
-    for (int j = 0; j < (NP + 63) / 64; ++j) {
-      const int c = lane + 64 * j;
-      u[j] = (c < g.N) ? Cs[m * LDC_S + c] : 0.f;
-      ss = fmaf(u[j], u[j], ss);
-    }
-    float denom = 1.f;
-    if (g.normalize) {
-      ss = wave_sum(ss);
-      denom = fmaxf(sqrtf(ss), NORM_EPS);
-    }
-#pragma unroll
-    for (int j = 0; j < (NP + 63) / 64; ++j) {
-      const int c = lane + 64 * j;
-      if (c < g.N) g.c[gm * g.ldc + c] = g.normalize ? u[j] / denom : u[j];
-    }
-    if (g.rinv && lane == 0) g.rinv[gm] = 1.0f / denom;
-  }
+  TR(13);
 }
-
-
 
 template <int NT, bool TRANS_B>
 void launch_rowgemm(const RowGemmArgs& g, hipStream_t s) {
   constexpr int NP = 32 * NT;
-  constexpr int LDB_S = TRANS_B ? NP + 1 : NP;
-  const size_t ab = 32 * LDA_S + KC * LDB_S, c = 32 * (NP + 1);
-  const size_t lds = sizeof(float) * (ab > c ? ab : c);
+  const size_t lds = sizeof(float) * (2 * (32 * LDA_S + (TRANS_B ? NP * LDA_S : KC * NP)) + 128 + 4 * 32);
   rowgemm_kernel<NT, TRANS_B><<<(unsigned)ceil_div64(g.rows, 32), 256, lds, s>>>(g);
 }
 
