@@ -109,11 +109,13 @@ int tsgnn_gemm_splitk_f32(const float* A, int64_t sam, int64_t sak, const float*
                           tsgnn_stream_t stream);
 /* Weight + bias gradient of the GraphConv transform in one pass over the rows (backward of encoders.py:36-38):
  * dw[K_in,N] = z[:, :K_in]^T . du,  db[N] = colsum(du) (nullable).  Row slabs -> fixed-order reduce (reproducible).
- * K_in, N <= 128, 16-byte rows; tsgnn_linear_wgrad_plan returns nslab = 0 for unsupported shapes. */
+ * K_in, N <= 128, 16-byte rows; tsgnn_linear_wgrad_plan returns nslab = 0 for unsupported shapes.
+ * bias_only_rows: rows [rows, rows + bias_only_rows) of du add to db but not to dw (the ghost rows of a packed batch:
+ * their z is identically zero, so they are left out of the product). */
 int tsgnn_linear_wgrad_plan(int64_t rows, int K_in, int N, int64_t ldz, int64_t lddu, int* nslab, int64_t* rows_per_slab,
                             int64_t* ws_floats);
 int tsgnn_linear_wgrad_f32(const float* z, int64_t ldz, const float* du, int64_t lddu, int64_t rows, int K_in, int N, int nslab,
-                           int64_t rows_per_slab, float* ws, float* dw, float* db, tsgnn_stream_t stream);
+                           int64_t rows_per_slab, int64_t bias_only_rows, float* ws, float* dw, float* db, tsgnn_stream_t stream);
 /* dw == NULL above leaves the slabs in ws; this reduces up to four such slab sets (all layers of one backward pass) in ONE
  * launch.  Unused sets: ws == NULL. */
 int tsgnn_wgrad_reduce_multi_f32(const float* ws0, int nslab0, int K0, int N0, float* dw0, float* db0, const float* ws1, int nslab1,
@@ -137,11 +139,15 @@ int tsgnn_linear_l2norm_f32(const float* z, int64_t ldz, const float* w, int64_t
 /* Row-panel variant of the same product (16-byte global loads, register prefetch, ds_read_b128 A fragments):
  * c = a[rows,K] . b  with b = B[K,N] (trans_b = 0) or b = W[N,K] used transposed (trans_b = 1: dZ = dU . W^T),
  * optional + bias and row L2 normalise.  tsgnn_rowgemm_supported() tells whether the operands qualify
- * (16-byte aligned rows, N <= 256); callers fall back to tsgnn_linear_l2norm_f32 / tsgnn_gemm_f32 otherwise. */
+ * (16-byte aligned rows, N <= 256); callers fall back to tsgnn_linear_l2norm_f32 / tsgnn_gemm_f32 otherwise.
+ * fill_rows: rows [rows, rows + fill_rows) of c (and rinv) receive the epilogue of an all-zero input row, i.e. the
+ * (normalised) bias, without going through the product: the ghost rows of a packed batch aggregate nothing
+ * (ghost rows), so their GraphConv output is that constant.  Needs N % 4 == 0 and 16-byte aligned c rows. */
 int tsgnn_rowgemm_supported(const float* a, int64_t lda, const float* b, int64_t ldb, const float* c, int64_t ldc, int K, int N,
                             int trans_b);
 int tsgnn_rowgemm_f32(const float* a, int64_t lda, const float* b, int64_t ldb, int trans_b, const float* bias, float* c,
-                      int64_t ldc, float* rinv, int64_t rows, int K, int N, int normalize, tsgnn_stream_t stream);
+                      int64_t ldc, float* rinv, int64_t rows, int K, int N, int normalize, int64_t fill_rows,
+                      tsgnn_stream_t stream);
 /* backward of the row normalisation: du = rinv * (dv - v (v.dv)) */
 int tsgnn_l2norm_bwd_f32(const float* v, int64_t ldv, const float* dv, int64_t lddv, const float* rinv, float* du,
                          int64_t lddu, int64_t rows, int F, tsgnn_stream_t stream);

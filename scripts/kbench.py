@@ -42,10 +42,10 @@ def main():
     g.ell()
     res["spmm ELL F=128"] = burst_us(lambda: mp.spmm_ell(g, X, out=Y))
     res["spmm F=92"] = burst_us(lambda: mp.spmm_raw(g.rowptr, g.col, None, x, R, out=torch.empty_like(x)))
-    res["linear_l2norm 128x128"] = burst_us(lambda: nat.call("linear_l2norm_f32", X, H, W, H, b, Y, H, rinv, R, H, H, 1))
-    res["rowgemm fwd 128x128 norm"] = burst_us(lambda: nat.call("rowgemm_f32", X, H, W, H, 0, b, Y, H, rinv, R, H, H, 1))
+    res["linear_l2norm 128x128"] = burst_us(lambda: nat.call("linear_l2norm_f32", X, H, W, H, b, Y, H, rinv, R, H, H, 1, 0))
+    res["rowgemm fwd 128x128 norm"] = burst_us(lambda: nat.call("rowgemm_f32", X, H, W, H, 0, b, Y, H, rinv, R, H, H, 1, 0))
     dz = torch.empty_like(X)
-    res["rowgemm dZ (trans)"] = burst_us(lambda: nat.call("rowgemm_f32", X, H, W, H, 1, None, dz, H, None, R, H, H, 0))
+    res["rowgemm dZ (trans)"] = burst_us(lambda: nat.call("rowgemm_f32", X, H, W, H, 1, None, dz, H, None, R, H, H, 0, 0))
     res["gemm dZ=dU.W^T"] = burst_us(lambda: mp.gemm(X, H, 1, W, 1, H, dz, H, 1, R, H, H))
     res["gemm dW splitk"] = burst_us(lambda: mp.gemm_tn_splitk(X, H, Y))
     res["linear_wgrad (dW+db)"] = burst_us(lambda: mp.linear_wgrad(X, H, Y, True))

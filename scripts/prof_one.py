@@ -14,7 +14,7 @@ X = torch.randn(R, H, device="cuda"); Y = torch.empty_like(X)
 W = torch.randn(H, H, device="cuda") * 0.1; b = torch.randn(H, device="cuda"); rinv = torch.empty(R, device="cuda")
 for _ in range(int(os.environ.get("N", 30))):
     if which == "rowgemm":
-        nat.call("rowgemm_f32", X, H, W, H, 0, b, Y, H, rinv, R, H, H, 1)
+        nat.call("rowgemm_f32", X, H, W, H, 0, b, Y, H, rinv, R, H, H, 1, 0)
     elif which == "spmm":
         mp.spmm_raw(g.rowptr, g.col, None, X, R, out=Y)
     elif which == "ell":

@@ -1,6 +1,7 @@
 // Developer harness: per-wave phase timeline of rowgemm_kernel (s_memtime stamps), built as
 //   hipcc --offload-arch=gfx950 -O3 -DTSGNN_TRACE scripts/trace_rowgemm.hip -o gpurun_out/trace_rowgemm
 #include "../two-stage-gnn_amd/csrc/rowgemm.hip"
+#include "trace_util.h"
 #include <cstdio>
 #include <vector>
 #include <algorithm>
@@ -19,31 +20,19 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int trans = 0; trans < 2; ++trans) {
     for (int it = 0; it < 20; ++it)
-      tsgnn_rowgemm_f32(a, K, b, N, trans, trans ? nullptr : bias, c, N, trans ? nullptr : rinv, R, K, N, trans ? 0 : 1, s);
+      tsgnn_rowgemm_f32(a, K, b, N, trans, trans ? nullptr : bias, c, N, trans ? nullptr : rinv, R, K, N, trans ? 0 : 1, 0, s);
     hipStreamSynchronize(s);
     hipEventRecord(e0, s);
     for (int it = 0; it < 200; ++it)
-      tsgnn_rowgemm_f32(a, K, b, N, trans, trans ? nullptr : bias, c, N, trans ? nullptr : rinv, R, K, N, trans ? 0 : 1, s);
+      tsgnn_rowgemm_f32(a, K, b, N, trans, trans ? nullptr : bias, c, N, trans ? nullptr : rinv, R, K, N, trans ? 0 : 1, 0, s);
     hipEventRecord(e1, s); hipStreamSynchronize(s);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     std::vector<long long> t(4096 * 16);
     hipMemcpyFromSymbol(t.data(), HIP_SYMBOL(g_trace), t.size() * 8);
     const int nb = (int)std::min<int64_t>((R + 31) / 32, 1024);
     printf("trans_b=%d  %.2f us per launch (back-to-back, incl. trace stores)\n", trans, ms * 1000 / 200);
-    long long gmin = t[0], gmax = 0;
-    for (int w = 0; w < nb * 4; ++w) { gmin = std::min(gmin, t[w * 16]); gmax = std::max(gmax, t[w * 16 + (trans ? 10 : 13)]); }
-    printf("  kernel span (first wave start -> last wave end): %lld ticks\n", gmax - gmin);
-    const int last = trans ? 10 : 14;
-    double avg[16] = {0};
-    for (int w = 0; w < nb * 4; ++w)
-      for (int k = 0; k <= last; ++k) avg[k] += (double)(t[w * 16 + k] - t[w * 16]);
-    printf("  mean ticks since wave start: ");
-    for (int k = 0; k <= last; ++k) printf("[%d]%.0f ", k, avg[k] / (nb * 4));
-    printf("\n  wave start offsets (ticks after first wave), percentiles: ");
-    std::vector<long long> st;
-    for (int w = 0; w < nb * 4; ++w) st.push_back(t[w * 16] - gmin);
-    std::sort(st.begin(), st.end());
-    printf("p0=%lld p50=%lld p90=%lld p100=%lld\n", st[0], st[st.size() / 2], st[st.size() * 9 / 10], st.back());
+    const int last = trans ? 10 : 13;
+    trace_report(t, nb, last);
     for (int w : {0, 1, 400, 1143})
       if (w < nb * 4) { printf("  wave %d:", w); for (int k = 0; k <= last; ++k) printf(" %lld", t[w * 16 + k] - t[w * 16]); printf("\n"); }
   }

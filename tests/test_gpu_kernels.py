@@ -258,3 +258,28 @@ def test_row_batched_gather_large(T, F, weighted):
     y_b = y_b + X[half:]
     torch.testing.assert_close(y_big[:half], y_a[:half], rtol=0, atol=0)
     torch.testing.assert_close(y_big[half:], y_b, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("normalize,bias", [(True, True), (True, False), (False, True)])
+def test_rowgemm_fill_rows_equal_zero_input_rows(T, normalize, bias):
+    """rows handed to the filler block (ghost rows: all-zero input) == the same rows pushed through the product."""
+    mp, GB = T
+    from two_stage_gnn_amd import _native as nat
+    gen = torch.Generator().manual_seed(5)
+    R_, nfill, K, N = 1000, 77, 128, 128
+    z = torch.randn(R_ + nfill, K, generator=gen)
+    z[R_:] = 0
+    w = (torch.randn(K, N, generator=gen) * 0.2).cuda()
+    b = torch.randn(N, generator=gen).cuda() if bias else None
+    zg = z.cuda()
+    outs = []
+    for fill in (0, nfill):
+        v = torch.full((R_ + nfill, N), float("nan"), device="cuda")
+        rinv = torch.full((R_ + nfill,), float("nan"), device="cuda")
+        nat.call("rowgemm_f32", zg, K, w, N, 0, b, v, N, rinv, R_ + nfill - fill, K, N, int(normalize), fill)
+        torch.cuda.synchronize()
+        outs.append((v.cpu(), rinv.cpu()))
+    torch.testing.assert_close(outs[1][0], outs[0][0], rtol=1e-6, atol=1e-7)
+    if normalize:
+        torch.testing.assert_close(outs[1][1], outs[0][1], rtol=1e-6, atol=0)
+    assert not torch.isnan(outs[1][0]).any()

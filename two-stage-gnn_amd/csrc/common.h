@@ -17,6 +17,19 @@
     if (e__ != hipSuccess) return TSGNN_ELAUNCH;          \
   } while (0)
 
+// developer instrumentation (scripts/trace_*.hip build a kernel file with -DTSGNN_TRACE): per-wave s_memtime stamps,
+// 16 slots per wave, first 1024 blocks x 4 waves.  Compiled out of the library.
+#ifdef TSGNN_TRACE
+__device__ long long g_trace[4096 * 16];
+#define TR_SLOT_(slot) g_trace[((blockIdx.x + gridDim.x * blockIdx.y) * 4 + (threadIdx.x >> 6)) * 16 + (slot)]
+#define TR_ON_ ((threadIdx.x & 63) == 0 && (blockIdx.x + gridDim.x * blockIdx.y) < 1024)
+#define TR(slot) do { if (TR_ON_) { TR_SLOT_(slot) = __builtin_readcyclecounter(); if ((slot) == 0) TR_SLOT_(14) = wall_clock64(); } } while (0)
+#define TR_END() do { if (TR_ON_) TR_SLOT_(15) = wall_clock64(); } while (0)   /* 100 MHz, common to the whole device */
+#else
+#define TR(slot) do { } while (0)
+#define TR_END() do { } while (0)
+#endif
+
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // ---- cross-lane reductions on DPP (no LDS-crossbar round trips): quad_perm xor1 / xor2, row_half_mirror,

@@ -14,6 +14,7 @@
 // Tile: 64x64 per 256-thread block (4 waves, 2x2, one 32x32 MFMA tile each), K chunk 32, operands
 // staged through LDS with +1 padding (conflict-free ds_read_b32 for both fragment shapes).
 #include "common.h"
+#include <type_traits>
 #include "../../include/tsgnn.h"
 
 namespace {
@@ -142,6 +143,8 @@ __global__ __launch_bounds__(256) void colsum_partial(const float* __restrict__ 
 // Slabs are summed in fixed order by tn_rows_reduce (bitwise reproducible, no float atomics).
 constexpr int TN_CH = 32;            // rows per staged chunk
 
+__device__ __forceinline__ int64_t ceil_div_dev(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
 struct TnArgs {
   const float* z; int64_t ldz;
   const float* du; int64_t lddu;
@@ -149,103 +152,224 @@ struct TnArgs {
   int K_in, N;
   float* slabs;                      // [nslab][K_in + 1][N]
   const int* slab_row_ptr;           // nullable: slab s covers rows [slab_row_ptr[s], slab_row_ptr[s+1]) (ragged, per graph)
+  int64_t bias_only_rows;            // rows after `rows` whose dU counts for the bias partial only
 };
 
-template <int MT, int NTt>
+template <int MT, int NTt, int NY>
 __global__ __launch_bounds__(256) void gemm_tn_rows_kernel(TnArgs g) {
   constexpr int KP = 32 * MT, NP = 32 * NTt;
-  constexpr int TILES = MT * NTt, TPW = (TILES + 3) / 4;
-  constexpr int ZV = (TN_CH * KP) / (256 * 4), UV = (TN_CH * NP) / (256 * 4);   // float4 per thread per chunk
-  __shared__ __attribute__((aligned(16))) float Zs[TN_CH * KP];
-  __shared__ __attribute__((aligned(16))) float Us[TN_CH * NP];
+  constexpr int TILES = MT * NTt;
+  constexpr bool COLW = NTt == 4;                      // wave w owns output column tile w: one dU fragment set per chunk
+  // NY (= gridDim.y) blocks share a slab.  Tiles per wave is what sizes the register file: arch + accumulation VGPRs
+  // must stay <= 256 so that two blocks fit a CU (a grid a little over 256 blocks must not need a second round).
+  constexpr int TPW = COLW ? (MT + NY - 1) / NY : ((TILES + NY - 1) / NY + 3) / 4;
+  constexpr int ZV = MT, UV = NTt;                     // float4 per thread per chunk (TN_CH * KP / 1024, TN_CH * NP / 1024)
+  constexpr int STAGE = TN_CH * (KP + NP);
+  extern __shared__ __attribute__((aligned(16))) float tn_smem[];   // two stages of [Z chunk | dU chunk]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int i = lane & 31, h = lane >> 5;
   const int64_t r0 = g.slab_row_ptr ? (int64_t)g.slab_row_ptr[blockIdx.x] : (int64_t)blockIdx.x * g.rows_per_slab;
   const int64_t r1 = g.slab_row_ptr ? (int64_t)g.slab_row_ptr[blockIdx.x + 1] : min(g.rows, r0 + g.rows_per_slab);
-  // gridDim.y blocks share a slab: block y owns output tiles t with t % gridDim.y == y (MFMA work and waves per CU
-  // scale with gridDim.y; the dU chunk is staged by every block, Z by all of them too — both are L2 hits)
-  const int ny = gridDim.y, by = blockIdx.y;
+  // gridDim.y blocks share a slab and split its output tiles (every block stages the whole chunk: L2 hits)
+  constexpr int ny = NY;
+  const int by = blockIdx.y;
+  TR(0);
+  int tm_[TPW], tn_[TPW];
+  bool tok[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    if (COLW) {
+      tm_[t] = by + t * ny; tn_[t] = wid; tok[t] = tm_[t] < MT;
+    } else {
+      const int f = (wid + 4 * t) * ny + by;
+      tok[t] = (wid + 4 * t) < (TILES + ny - 1) / ny && f < TILES;
+      tm_[t] = f / NTt; tn_[t] = f % NTt;
+    }
+  }
   f32x16 acc[TPW];
 #pragma unroll
   for (int t = 0; t < TPW; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   float dbacc = 0.f;
-  float4 rz[ZV], ru[UV];
-  auto load_chunk = [&](int64_t rb) {
+
+  // staging maps: thread -> (row m of the chunk, float4 column c4), fixed for the whole slab
+  const float* zp[ZV];
+  const float* up[UV];
+  int zm[ZV], um[UV], znv[ZV];
+  bool ucol[UV];
+#pragma unroll
+  for (int q = 0; q < ZV; ++q) {
+    const int idx = q * 256 + tid, m = idx / (KP / 4), c4 = idx % (KP / 4);
+    zm[q] = m;
+    znv[q] = min(4, max(0, g.K_in - 4 * c4));            // valid floats of this float4 (row padding of Z contributes nothing)
+    zp[q] = g.z + (r0 + m) * g.ldz + (znv[q] > 0 ? 4 * c4 : 0);
+  }
+#pragma unroll
+  for (int q = 0; q < UV; ++q) {
+    const int idx = q * 256 + tid, m = idx / (NP / 4), c4 = idx % (NP / 4);
+    um[q] = m;
+    ucol[q] = 4 * c4 < g.N;
+    up[q] = g.du + (r0 + m) * g.lddu + (ucol[q] ? 4 * c4 : 0);
+  }
+  // two register staging sets: chunk c travels in set c & 1; the first two chunks of a slab are both in flight before
+  // any MFMA, later ones are fetched two iterations ahead.  Row validity is applied at commit time so that nothing
+  // waits on a load while the MFMAs run; loads never leave the matrix.
+  float4 rz[2][ZV], ru[2][UV];
+  unsigned zrow[2] = {0, 0}, urow[2] = {0, 0};         // bit q: the row of rz[.][q] / ru[.][q] exists
+  auto fetch = [&](auto set_, int64_t off) {
+    constexpr int S = decltype(set_)::value;
+    zrow[S] = 0; urow[S] = 0;
 #pragma unroll
     for (int q = 0; q < ZV; ++q) {
-      const int idx = q * 256 + tid, m = idx / (KP / 4), c4 = idx % (KP / 4);
-      const bool ok = rb + m < r1 && 4 * c4 < g.K_in;
-      rz[q] = *reinterpret_cast<const float4*>(ok ? g.z + (rb + m) * g.ldz + 4 * c4 : g.z);
-      if (!ok) rz[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool ok = r0 + off + zm[q] < r1;
+      rz[S][q] = *reinterpret_cast<const float4*>(ok ? zp[q] + off * g.ldz : g.z);
+      zrow[S] |= ok ? (1u << q) : 0u;
     }
 #pragma unroll
     for (int q = 0; q < UV; ++q) {
-      const int idx = q * 256 + tid, m = idx / (NP / 4), c4 = idx % (NP / 4);
-      const bool ok = rb + m < r1 && 4 * c4 < g.N;
-      ru[q] = *reinterpret_cast<const float4*>(ok ? g.du + (rb + m) * g.lddu + 4 * c4 : g.du);
-      if (!ok) ru[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool ok = r0 + off + um[q] < r1;
+      ru[S][q] = *reinterpret_cast<const float4*>(ok ? up[q] + off * g.lddu : g.du);
+      urow[S] |= ok ? (1u << q) : 0u;
     }
   };
-  auto store_chunk = [&]() {
+  auto commit = [&](auto set_, float* st) {
+    constexpr int S = decltype(set_)::value;
 #pragma unroll
     for (int q = 0; q < ZV; ++q) {
-      const int idx = q * 256 + tid, m = idx / (KP / 4), c4 = idx % (KP / 4);
-      float4 v = rz[q];
-      const int nv = g.K_in - 4 * c4;                 // columns >= K_in (row padding of Z) contribute nothing
+      const int idx = q * 256 + tid;
+      float4 v = rz[S][q];
+      const int nv = ((zrow[S] >> q) & 1u) ? znv[q] : 0;
       if (nv < 4) v.w = 0.f;
       if (nv < 3) v.z = 0.f;
       if (nv < 2) v.y = 0.f;
       if (nv < 1) v.x = 0.f;
-      *reinterpret_cast<float4*>(Zs + m * KP + 4 * c4) = v;
+      *reinterpret_cast<float4*>(st + 4 * idx) = v;      // [m][KP] row-major == idx order
     }
 #pragma unroll
     for (int q = 0; q < UV; ++q) {
-      const int idx = q * 256 + tid, m = idx / (NP / 4), c4 = idx % (NP / 4);
-      *reinterpret_cast<float4*>(Us + m * NP + 4 * c4) = ru[q];
+      const int idx = q * 256 + tid;
+      *reinterpret_cast<float4*>(st + TN_CH * KP + 4 * idx) =
+          (ucol[q] && ((urow[S] >> q) & 1u)) ? ru[S][q] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  if (r0 < r1) {
-    load_chunk(r0);
-    for (int64_t rb = r0; rb < r1; rb += TN_CH) {
-      store_chunk();
-      __syncthreads();
-      if (rb + TN_CH < r1) load_chunk(rb + TN_CH);     // next chunk flies under the MFMAs
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+
+  // iteration c (stage / set parity P = c & 1):  operands of chunk c from LDS stage P | MFMAs | fetch chunk c+2 into
+  // set P | commit chunk c+1 (set P^1) into stage P^1 | barrier
+  auto body = [&](auto par_, int64_t off, int cidx) {
+    constexpr int P = decltype(par_)::value;
+    const float* Zs = tn_smem + P * STAGE;
+    const float* Us = Zs + TN_CH * KP;
+    TR(2 + 3 * min(cidx, 2));
+    // operands of the whole chunk into registers first (A[m][k] = Z[row k][m], B[k][j] = dU[row k][j]; lane i reads
+    // consecutive floats: conflict-free)
+    float bfr[COLW ? 1 : TPW][TN_CH / 2];
+    float afr[TPW][TN_CH / 2];
 #pragma unroll
-      for (int t = 0; t < TPW; ++t) {
-        const int tile = (wid + 4 * t) * ny + by;
-        if (wid + 4 * t < (TILES + ny - 1) / ny && tile < TILES) {
-          const int tm = tile / NTt, tn = tile % NTt;
-          const float* ap = Zs + h * KP + tm * 32 + i;   // A[m][k] = Z[row k][m]
-          const float* bp = Us + h * NP + tn * 32 + i;   // B[k][j] = dU[row k][j]
+    for (int t = 0; t < TPW; ++t) {
+      if (t == 0 || tok[t]) {                            // uniform per wave
+        if (!COLW || t == 0) {
 #pragma unroll
-          for (int s2 = 0; s2 < TN_CH; s2 += 2)
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[s2 * KP], bp[s2 * NP], acc[t], 0, 0, 0);
+          for (int s2 = 0; s2 < TN_CH / 2; ++s2) bfr[COLW ? 0 : t][s2] = Us[(2 * s2 + h) * NP + tn_[t] * 32 + i];
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < TN_CH / 2; ++s2) afr[t][s2] = Zs[(2 * s2 + h) * KP + (tok[t] ? tm_[t] : 0) * 32 + i];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);                 // keep the LDS reads above the MFMA chains
+    // a short last chunk runs only the MFMA groups (4 steps = 8 rows) that hold rows; the rest of the stage is zero
+    const int nsteps = (int)min<int64_t>(TN_CH / 2, (r1 - r0 - off + 1) / 2);
+#pragma unroll
+    for (int s4 = 0; s4 < TN_CH / 2; s4 += 4) {
+      if (s4 < nsteps) {
+#pragma unroll
+        for (int s2 = s4; s2 < s4 + 4; ++s2)
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[0][s2], bfr[0][s2], acc[0], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (r0 + off + 2 * TN_CH < r1) fetch(par_, off + 2 * TN_CH);
+    if (COLW) {                                        // bias gradient: column sums straight from the dU fragments
+#pragma unroll
+      for (int s2 = 0; s2 < TN_CH / 2; ++s2) dbacc += bfr[0][s2];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 1; t < TPW; ++t) {
+      if (tok[t]) {
+#pragma unroll
+        for (int s4 = 0; s4 < TN_CH / 2; s4 += 4) {
+          if (s4 < nsteps) {
+#pragma unroll
+            for (int s2 = s4; s2 < s4 + 4; ++s2)
+              acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[t][s2], bfr[COLW ? 0 : t][s2], acc[t], 0, 0, 0);
+          }
         }
       }
-      if (by == 0 && tid < NP) {
+    }
+    TR(3 + 3 * min(cidx, 2));
+    if (!COLW && by == 0 && tid < NP) {
 #pragma unroll 8
-        for (int m = 0; m < TN_CH; ++m) dbacc += Us[m * NP + tid];
-      }
-      __syncthreads();
+      for (int m = 0; m < TN_CH; ++m) dbacc += Us[m * NP + tid];
+    }
+    if (r0 + off + TN_CH < r1) commit(std::integral_constant<int, P ^ 1>{}, tn_smem + (P ^ 1) * STAGE);
+    __syncthreads();
+    TR(4 + 3 * min(cidx, 2));
+  };
+  if (r0 < r1) {
+    fetch(S0{}, 0);
+    if (r0 + TN_CH < r1) fetch(S1{}, TN_CH);
+    TR(1);
+    commit(S0{}, tn_smem);
+    __syncthreads();
+    int cidx = 0;
+    for (int64_t off = 0; r0 + off < r1; off += 2 * TN_CH, cidx += 2) {
+      body(S0{}, off, cidx);
+      if (r0 + off + TN_CH < r1) body(S1{}, off + TN_CH, cidx + 1);
     }
   }
+  TR(11);
   float* slab = g.slabs + (int64_t)blockIdx.x * (g.K_in + 1) * g.N;
+  const bool full = g.K_in == KP && g.N == NP;          // uniform: no per-element predicates
 #pragma unroll
   for (int t = 0; t < TPW; ++t) {
-    const int tile = (wid + 4 * t) * ny + by;
-    if (wid + 4 * t < (TILES + ny - 1) / ny && tile < TILES) {
-      const int tm = tile / NTt, tn = tile % NTt;
-      const int cn = tn * 32 + (lane & 31);
+    if (tok[t]) {
+      const int cn = tn_[t] * 32 + i;
+      float* sp = slab + (int64_t)(tm_[t] * 32 + 4 * h) * g.N + cn;
+      if (full) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int cm = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (cm < g.K_in && cn < g.N) slab[(int64_t)cm * g.N + cn] = acc[t][r];
+        for (int r = 0; r < 16; ++r) sp[((r & 3) + 8 * (r >> 2)) * g.N] = acc[t][r];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int cm = tm_[t] * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (cm < g.K_in && cn < g.N) sp[((r & 3) + 8 * (r >> 2)) * g.N] = acc[t][r];
+        }
       }
     }
   }
-  if (by == 0 && tid < g.N) slab[(int64_t)g.K_in * g.N + tid] = dbacc;
+  if (by == 0 && g.bias_only_rows > 0) {                // this slab's share of the rows that only feed the bias gradient
+    const int64_t per = ceil_div_dev(g.bias_only_rows, (int64_t)gridDim.x);
+    const int64_t e0 = g.rows + (int64_t)blockIdx.x * per, e1 = min(g.rows + g.bias_only_rows, e0 + per);
+    if (COLW) {
+      if (wid * 32 + i < g.N)
+        for (int64_t e = e0 + h; e < e1; e += 2) dbacc += g.du[e * g.lddu + wid * 32 + i];
+    } else if (tid < g.N) {
+      for (int64_t e = e0; e < e1; ++e) dbacc += g.du[e * g.lddu + tid];
+    }
+  }
+  if (by == 0) {
+    if (COLW) {
+      const float v = dbacc + __shfl_xor(dbacc, 32, 64);   // rows of parity h=0 and h=1
+      if (lane < 32 && wid * 32 + i < g.N) slab[(int64_t)g.K_in * g.N + wid * 32 + i] = v;
+    } else if (tid < g.N) {
+      slab[(int64_t)g.K_in * g.N + tid] = dbacc;
+    }
+  }
+  TR(12);
+  TR_END();
 }
 
 // out[e] = sum_s slabs[s][e]; e < K_in*N -> dW, else -> db.  64 outputs x 4 slab groups per block.
@@ -375,8 +499,19 @@ int tsgnn_linear_wgrad_plan(int64_t rows, int K_in, int N, int64_t ldz, int64_t 
   if (!nslab || !rows_per_slab || !ws_floats || rows < 0) return TSGNN_EINVAL;
   *nslab = 0; *rows_per_slab = 0; *ws_floats = 0;
   if (K_in <= 0 || N <= 0 || K_in > 128 || N > 128 || (ldz % 4) || (lddu % 4) || (N % 4)) return TSGNN_OK;
-  int64_t rps = 64;
-  while (ceil_div64(rows, rps) > 512) rps *= 2;
+  // one round of equal blocks: (slabs x blocks per slab) = number of CUs.  A grid a little over the CU count would
+  // put two blocks on some CUs, and those decide the kernel time (measured: 286 blocks 9.9 us, 256 blocks 6.5 us).
+  static int ncu = 0;
+  if (ncu == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
+    else ncu = 256;
+  }
+  const int tiles = ((K_in + 31) / 32) * ((N + 31) / 32);
+  const int per_slab_blocks = tiles >= 8 ? 2 : 1;
+  int64_t rps = ceil_div64(rows > 0 ? rows : 1, ncu / per_slab_blocks);
+  rps = ((rps + 7) / 8) * 8;
+  if (rps < 16) rps = 16;
   *rows_per_slab = rps;
   *nslab = (int)(rows > 0 ? ceil_div64(rows, rps) : 1);
   *ws_floats = (int64_t)(*nslab) * (K_in + 1) * N;
@@ -414,17 +549,18 @@ int tsgnn_wgrad_reduce_multi_f32(const float* ws0, int nslab0, int K0, int N0, f
 /* dW[K_in,N] = z[:, :K_in]^T . du ; db[N] = colsum(du) (db nullable).  Plan with tsgnn_linear_wgrad_plan.
  * dw == NULL: only the slabs are produced (reduce them later with tsgnn_wgrad_reduce_multi_f32). */
 int tsgnn_linear_wgrad_f32(const float* z, int64_t ldz, const float* du, int64_t lddu, int64_t rows, int K_in, int N, int nslab,
-                           int64_t rows_per_slab, float* ws, float* dw, float* db, tsgnn_stream_t stream) {
-  if (!z || !du || !ws || rows < 0 || nslab <= 0 || rows_per_slab <= 0 || K_in <= 0 || N <= 0) return TSGNN_EINVAL;
+                           int64_t rows_per_slab, int64_t bias_only_rows, float* ws, float* dw, float* db, tsgnn_stream_t stream) {
+  if (!z || !du || !ws || rows < 0 || nslab <= 0 || rows_per_slab <= 0 || K_in <= 0 || N <= 0 || bias_only_rows < 0) return TSGNN_EINVAL;
   if (K_in > 128 || N > 128 || (ldz % 4) || (lddu % 4) || (N % 4) || (reinterpret_cast<uintptr_t>(z) & 15) ||
       (reinterpret_cast<uintptr_t>(du) & 15))
     return TSGNN_EUNSUPPORTED;
-  TnArgs g{z, ldz, du, lddu, rows, rows_per_slab, K_in, N, ws, nullptr};
+  TnArgs g{z, ldz, du, lddu, rows, rows_per_slab, K_in, N, ws, nullptr, bias_only_rows};
   const int mt = (K_in + 31) / 32, nt = (N + 31) / 32;
   const int tiles = mt * nt;
   const unsigned ny = (tiles >= 8 && nslab < 512) ? 2u : 1u;      // two blocks per slab when there is enough tile work
   const dim3 grid_tn((unsigned)nslab, ny);
-#define TSGNN_TN(M_, N_) gemm_tn_rows_kernel<M_, N_><<<grid_tn, 256, 0, stream>>>(g)
+#define TSGNN_TN(M_, N_) do { if (ny == 2) gemm_tn_rows_kernel<M_, N_, 2><<<grid_tn, 256, 2 * TN_CH * 32 * (M_ + N_) * sizeof(float), stream>>>(g); \
+    else gemm_tn_rows_kernel<M_, N_, 1><<<grid_tn, 256, 2 * TN_CH * 32 * (M_ + N_) * sizeof(float), stream>>>(g); } while (0)
   switch (mt * 10 + nt) {
     case 11: TSGNN_TN(1, 1); break; case 12: TSGNN_TN(1, 2); break; case 13: TSGNN_TN(1, 3); break; case 14: TSGNN_TN(1, 4); break;
     case 21: TSGNN_TN(2, 1); break; case 22: TSGNN_TN(2, 2); break; case 23: TSGNN_TN(2, 3); break; case 24: TSGNN_TN(2, 4); break;
@@ -448,10 +584,11 @@ int tsgnn_ragged_tn_f32(const float* s_mat, int64_t lds_, const float* x, int64_
   if (mt * nt > 16 || mt > 4 || nt > 8 || (lds_ % 4) || (ldx % 4) || (N % 4) || (reinterpret_cast<uintptr_t>(s_mat) & 15) ||
       (reinterpret_cast<uintptr_t>(x) & 15))
     return TSGNN_EUNSUPPORTED;
-  TnArgs g{s_mat, lds_, x, ldx, 0, 0, K, N, ws, slab_row_ptr};
+  TnArgs g{s_mat, lds_, x, ldx, 0, 0, K, N, ws, slab_row_ptr, 0};
   const unsigned ny = (mt * nt >= 8) ? 2u : 1u;
   const dim3 grid((unsigned)nslab, ny);
-#define TSGNN_RT(M_, N_) gemm_tn_rows_kernel<M_, N_><<<grid, 256, 0, stream>>>(g)
+#define TSGNN_RT(M_, N_) do { if (ny == 2) gemm_tn_rows_kernel<M_, N_, 2><<<grid, 256, 2 * TN_CH * 32 * (M_ + N_) * sizeof(float), stream>>>(g); \
+    else gemm_tn_rows_kernel<M_, N_, 1><<<grid, 256, 2 * TN_CH * 32 * (M_ + N_) * sizeof(float), stream>>>(g); } while (0)
   switch (mt * 10 + nt) {
     case 11: TSGNN_RT(1, 1); break; case 12: TSGNN_RT(1, 2); break; case 13: TSGNN_RT(1, 3); break; case 14: TSGNN_RT(1, 4); break;
     case 15: TSGNN_RT(1, 5); break; case 16: TSGNN_RT(1, 6); break; case 17: TSGNN_RT(1, 7); break; case 18: TSGNN_RT(1, 8); break;

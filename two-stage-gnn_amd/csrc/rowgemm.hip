@@ -33,15 +33,8 @@ struct RowGemmArgs {
   float* rinv;
   int64_t rows; int K; int N;
   int normalize;
+  int64_t fill_rows;                  // rows after `rows` that get the epilogue of a zero input row
 };
-
-// developer instrumentation (scripts/trace_rowgemm.hip builds this file with -DTSGNN_TRACE): per-wave s_memtime stamps
-#ifdef TSGNN_TRACE
-__device__ long long g_trace[4096 * 16];
-#define TR(slot) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) g_trace[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (slot)] = __builtin_readcyclecounter(); } while (0)
-#else
-#define TR(slot) do { } while (0)
-#endif
 
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
@@ -58,6 +51,28 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs g) {
   const int i = lane & 31, h = lane >> 5;
   const int64_t m0 = (int64_t)blockIdx.x * 32;
   TR(0);
+  if (m0 >= g.rows) {
+    // filler block (launched after the panels when fill_rows > 0): every fill row = [normalised] bias
+    __shared__ float fred[4];
+    const int N4 = g.N / 4, rpp = 256 / N4;              // rows per pass
+    const int c4 = tid % N4, rsub = tid / N4;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g.bias && rsub < rpp) bv = ldg4(g.bias + 4 * c4);
+    float ss = rsub == 0 ? (bv.x * bv.x + bv.y * bv.y) + (bv.z * bv.z + bv.w * bv.w) : 0.f;
+    ss = wave_sum(ss);
+    if (lane == 0) fred[wid] = ss;
+    __syncthreads();
+    float sc = 1.f;
+    if (g.normalize) sc = fminf(__builtin_amdgcn_rsqf((fred[0] + fred[1]) + (fred[2] + fred[3])), 1.0f / NORM_EPS);
+    const float4 out = make_float4(bv.x * sc, bv.y * sc, bv.z * sc, bv.w * sc);
+    if (rsub < rpp) {
+      for (int64_t r = rsub; r < g.fill_rows; r += rpp) {
+        *reinterpret_cast<float4*>(g.c + (g.rows + r) * g.ldc + 4 * c4) = out;
+        if (g.rinv && c4 == 0) g.rinv[g.rows + r] = sc;
+      }
+    }
+    return;
+  }
 
   // staging maps (computed once) ------------------------------------------------------------------
   // A: thread -> row am, floats 4*ak4..+3 of the chunk.  B: float4 q of the thread -> (k, n4) or (n, k4).
@@ -277,7 +292,6 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs g) {
         const float4 v = *reinterpret_cast<const float4*>(inv + 8 * q + 4 * h);
         scale[4 * q] = v.x; scale[4 * q + 1] = v.y; scale[4 * q + 2] = v.z; scale[4 * q + 3] = v.w;
       }
-      TR(14);
     }
   }
   const bool full = panel_full;                        // uniform: no per-element predicates on the common path
@@ -300,13 +314,14 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs g) {
     }
   }
   TR(13);
+  TR_END();
 }
 
 template <int NT, bool TRANS_B>
 void launch_rowgemm(const RowGemmArgs& g, hipStream_t s) {
   constexpr int NP = 32 * NT;
   const size_t lds = sizeof(float) * (2 * (32 * LDA_S + (TRANS_B ? NP * LDA_S : KC * NP)) + 128 + 4 * 32);
-  rowgemm_kernel<NT, TRANS_B><<<(unsigned)ceil_div64(g.rows, 32), 256, lds, s>>>(g);
+  rowgemm_kernel<NT, TRANS_B><<<(unsigned)(ceil_div64(g.rows, 32) + (g.fill_rows > 0 ? 1 : 0)), 256, lds, s>>>(g);
 }
 
 template <bool TRANS_B>
@@ -340,11 +355,15 @@ int tsgnn_rowgemm_supported(const float* a, int64_t lda, const float* b, int64_t
 }
 
 int tsgnn_rowgemm_f32(const float* a, int64_t lda, const float* b, int64_t ldb, int trans_b, const float* bias, float* c,
-                      int64_t ldc, float* rinv, int64_t rows, int K, int N, int normalize, tsgnn_stream_t stream) {
-  if (!a || !b || !c || rows < 0 || K <= 0 || N <= 0 || lda < K || ldc < N) return TSGNN_EINVAL;
+                      int64_t ldc, float* rinv, int64_t rows, int K, int N, int normalize, int64_t fill_rows,
+                      tsgnn_stream_t stream) {
+  if (!a || !b || !c || rows < 0 || fill_rows < 0 || K <= 0 || N <= 0 || lda < K || ldc < N) return TSGNN_EINVAL;
   if (!tsgnn_rowgemm_supported(a, lda, b, ldb, c, ldc, K, N, trans_b)) return TSGNN_EUNSUPPORTED;
-  if (rows == 0) return TSGNN_OK;
-  RowGemmArgs g{a, lda, b, ldb, bias, c, ldc, rinv, rows, K, N, normalize};
+  if (fill_rows > 0 && ((N % 4) || (ldc % 4) || (reinterpret_cast<uintptr_t>(c) & 15) ||
+                        (bias && (reinterpret_cast<uintptr_t>(bias) & 15))))
+    return TSGNN_EUNSUPPORTED;
+  if (rows == 0 && fill_rows == 0) return TSGNN_OK;
+  RowGemmArgs g{a, lda, b, ldb, bias, c, ldc, rinv, rows, K, N, normalize, fill_rows};
   if (trans_b) dispatch_rowgemm<true>(g, stream);
   else dispatch_rowgemm<false>(g, stream);
   TSGNN_CHECK_LAUNCH();

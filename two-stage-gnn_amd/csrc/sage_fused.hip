@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void slot_bn_fwd(SlotArgs s, const float* __re
 }
 
 // ---------------------------------------------------------------------------------------------- backward
-// dy(b,n,f) = dxs[row] (real rows; a ghost row's dxs — already a sum over its copies — is taken by the first copy)
+// dy(b,n,f) = dxs[row] (real rows; a ghost row has no edges, so no gradient reaches it through the aggregation)
 //           + (arg[b,f] == row ? dout[b,f] : 0)                       [max-readout winner of graph b]
 // BN:   dv = rstd (dy - m1 - xhat m2) ; ReLU mask ; ghost copies summed in graph order ;
 // L2:   du = rinv (dv - v <v,dv>)   (rinv = 1e12 marks the clamped norm: du = rinv dv)
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void slot_post_bwd(SlotArgs s, const float* __
     dy[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (row >= 0 && c4 < F4) {
       vv[q] = ld4(v + row * ldv + 4 * c4);
-      if (dxs && (!ghost || fg)) dy[q] = ld4(dxs + row * lddxs + 4 * c4);
+      if (dxs && !ghost) dy[q] = ld4(dxs + row * lddxs + 4 * c4);   // nothing aggregates from a ghost row: its dxs is 0
       const int4 w = *reinterpret_cast<const int4*>(arg + (int64_t)b * F + 4 * c4);
       const float4 g = ld4(dout + (int64_t)b * ldo + 4 * c4);
       const int r32 = (int)row;

@@ -41,13 +41,15 @@ def ell_ok(x):
     return F % 4 == 0 and F <= 256 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
 
 
-def spmm_ell(g, x, self_scalar=0.0, out=None):
-    """unit-weight aggregation through the fixed-width index table (+ CSR tail for rows with > W neighbours)."""
+def spmm_ell(g, x, self_scalar=0.0, out=None, rows=None):
+    """unit-weight aggregation through the fixed-width index table (+ CSR tail for rows with > W neighbours).
+    ``rows``: only the first ``rows`` output rows are produced (the caller never reads the others)."""
     ell, W, tail = g.ell()
     y = out if out is not None else _f32(x.size(0), x.size(1), device=x.device)
-    nat.call("ell_spmm_f32", ell, W, x, x.stride(0), y, y.stride(0), g.total_rows, int(x.size(1)), float(self_scalar))
+    n = g.total_rows if rows is None else int(rows)
+    nat.call("ell_spmm_f32", ell, W, x, x.stride(0), y, y.stride(0), n, int(x.size(1)), float(self_scalar))
     if tail is not None:
-        spmm_raw(tail[0], tail[1], None, x, g.total_rows, out=y, accumulate=True)
+        spmm_raw(tail[0], tail[1], None, x, n, out=y, accumulate=True)
     return y
 
 
@@ -104,9 +106,10 @@ def gemm_tn_splitk(Z, K_in, dU, out=None):
     return out
 
 
-def linear_wgrad_slabs(z, K_in, du):
-    """slab partials of (dW, db) without the reduction; returns (ws, nslab) or None when the shape is unsupported."""
-    R, N = du.size(0), du.size(1)
+def linear_wgrad_slabs(z, K_in, du, bias_only_rows=0):
+    """slab partials of (dW, db) without the reduction; returns (ws, nslab) or None when the shape is unsupported.
+    The last ``bias_only_rows`` rows of du feed db only (ghost rows: their z is zero)."""
+    R, N = du.size(0) - int(bias_only_rows), du.size(1)
     nslab = np.zeros(1, dtype=np.int32)
     rps = np.zeros(1, dtype=np.int64)
     need = np.zeros(1, dtype=np.int64)
@@ -115,7 +118,8 @@ def linear_wgrad_slabs(z, K_in, du):
     if int(nslab[0]) <= 0 or z.data_ptr() % 16 or du.data_ptr() % 16:
         return None
     ws = _f32(int(need[0]), device=du.device)
-    nat.call("linear_wgrad_f32", z, z.stride(0), du, du.stride(0), R, int(K_in), int(N), int(nslab[0]), int(rps[0]), ws, None, None)
+    nat.call("linear_wgrad_f32", z, z.stride(0), du, du.stride(0), R, int(K_in), int(N), int(nslab[0]), int(rps[0]),
+             int(bias_only_rows), ws, None, None)
     return ws, int(nslab[0])
 
 
@@ -144,7 +148,7 @@ def linear_wgrad(z, K_in, du, want_db):
         ws = _f32(int(need[0]), device=du.device)
         dw = _f32(K_in, N, device=du.device)
         db = _f32(N, device=du.device) if want_db else None
-        nat.call("linear_wgrad_f32", z, z.stride(0), du, du.stride(0), R, int(K_in), int(N), int(nslab[0]), int(rps[0]), ws,
+        nat.call("linear_wgrad_f32", z, z.stride(0), du, du.stride(0), R, int(K_in), int(N), int(nslab[0]), int(rps[0]), 0, ws,
                  dw, db)
         return dw, db
     return gemm_tn_splitk(z, K_in, du), (colsum(du) if want_db else None)
@@ -177,7 +181,7 @@ class _LinearL2Norm(torch.autograd.Function):
         v = _f32(R, N, device=z.device)
         rinv = _f32(R, device=z.device) if normalize else None
         if rowgemm_ok(z, z.stride(0), w, w.stride(0), K, N, False):
-            nat.call("rowgemm_f32", z, z.stride(0), w, w.stride(0), 0, bias, v, v.stride(0), rinv, R, K, N, int(normalize))
+            nat.call("rowgemm_f32", z, z.stride(0), w, w.stride(0), 0, bias, v, v.stride(0), rinv, R, K, N, int(normalize), 0)
         else:
             nat.call("linear_l2norm_f32", z, z.stride(0), w, w.stride(0), bias, v, v.stride(0), rinv, R, K, N,
                      int(normalize))
@@ -201,7 +205,7 @@ class _LinearL2Norm(torch.autograd.Function):
             ldz = z.size(1)
             dz = _f32(R, ldz, device=dv.device, zero=(ldz > K))
             if rowgemm_ok(du, du.stride(0), w, w.stride(0), N, K, True):                     # dZ = dU W^T
-                nat.call("rowgemm_f32", du, du.stride(0), w, w.stride(0), 1, None, dz, dz.stride(0), None, R, N, K, 0)
+                nat.call("rowgemm_f32", du, du.stride(0), w, w.stride(0), 1, None, dz, dz.stride(0), None, R, N, K, 0, 0)
             else:
                 gemm(du, du.stride(0), 1, w, 1, w.stride(0), dz, dz.stride(0), 1, R, K, N)
         want_db = ctx.has_bias and ctx.needs_input_grad[2]

@@ -40,11 +40,14 @@ def _side_stream(dev):
     return st
 
 
-def _aggregate_raw(g, x, transposed=False):
+def _aggregate_raw(g, x, transposed=False, rows=None):
+    """rows: produce only the first `rows` output rows (ghost rows aggregate nothing and, on the fused path, nobody reads
+    their aggregate: the products leave them out)."""
+    n = g.total_rows if rows is None else rows
     if g.val is None and mp.ell_ok(x) and g.total_rows <= mp.ELL_MAX_ROWS and (not transposed or g.symmetric):
-        return mp.spmm_ell(g, x)
+        return mp.spmm_ell(g, x, rows=n)
     rp, col, val = g.transposed() if transposed else (g.rowptr, g.col, g.val)
-    return mp.spmm_raw(rp, col, val, x, g.total_rows)
+    return mp.spmm_raw(rp, col, val, x, n)
 
 
 class _SageStack(torch.autograd.Function):
@@ -68,12 +71,25 @@ class _SageStack(torch.autograd.Function):
             side.wait_stream(main)                          # packed zeroed before any partial lands
         for l in range(L):
             K, N = Ws[l].size(0), Ws[l].size(1)
-            z = _aggregate_raw(g, x)
             v = torch.empty(R, N, dtype=torch.float32, device=dev)
             rinv = torch.empty(R, dtype=torch.float32, device=dev)
-            if mp.rowgemm_ok(z, z.stride(0), Ws[l], Ws[l].stride(0), K, N, False):
-                nat.call("rowgemm_f32", z, z.stride(0), Ws[l], Ws[l].stride(0), 0, bs[l], v, v.stride(0), rinv, R, K, N, 1)
+            # Ghost rows aggregate nothing (z = 0): their output is the normalised bias, written by a filler block, and
+            # their z is neither produced nor read (255 row panels + 1 filler = one block per CU on the DD batch).
+            lean = (g.n_ghost > 0 and x.stride(0) % 4 == 0 and K % 4 == 0 and N % 4 == 0 and Ws[l].data_ptr() % 16 == 0
+                    and (bs[l] is None or bs[l].data_ptr() % 16 == 0))
+            z = _aggregate_raw(g, x, rows=g.n_rows if lean else None)
+            if lean and mp.rowgemm_ok(z, z.stride(0), Ws[l], Ws[l].stride(0), K, N, False):
+                nat.call("rowgemm_f32", z, z.stride(0), Ws[l], Ws[l].stride(0), 0, bs[l], v, v.stride(0), rinv, g.n_rows, K, N, 1,
+                         g.n_ghost)
+            elif mp.rowgemm_ok(z, z.stride(0), Ws[l], Ws[l].stride(0), K, N, False):
+                if lean:
+                    z[g.n_rows:].zero_()
+                    lean = False
+                nat.call("rowgemm_f32", z, z.stride(0), Ws[l], Ws[l].stride(0), 0, bs[l], v, v.stride(0), rinv, R, K, N, 1, 0)
             else:
+                if lean:
+                    z[g.n_rows:].zero_()
+                    lean = False
                 nat.call("linear_l2norm_f32", z, z.stride(0), Ws[l], Ws[l].stride(0), bs[l], v, v.stride(0), rinv, R, K, N, 1)
             pk = packed[off:off + B * N]
             if l < L - 1:
@@ -93,7 +109,7 @@ class _SageStack(torch.autograd.Function):
                 if OVERLAP:
                     main.wait_stream(side)                  # join: all partials done before the decode
                 nat.call("readout_partial_f32", g.graph_ptr, B, g.nmax, g.n_rows, g.n_ghost, v, v.stride(0), N, pk)
-            saved.append((z, v, rinv, mean, rstd))
+            saved.append((z, v, rinv, mean, rstd, lean))
             off += B * N
         out = torch.empty(B, (L - 1) * Fh + Fl, dtype=torch.float32, device=dev)
         arg = torch.empty(total, dtype=torch.int32, device=dev)
@@ -119,7 +135,7 @@ class _SageStack(torch.autograd.Function):
         keep = []
         pending = []
         for l in range(L - 1, -1, -1):
-            z, v, rinv, mean, rstd = ctx.saved[l]
+            z, v, rinv, mean, rstd, lean = ctx.saved[l]
             W = ctx.Ws[l]
             K, N = W.size(0), W.size(1)
             last = l == L - 1
@@ -135,13 +151,15 @@ class _SageStack(torch.autograd.Function):
                 side.wait_stream(main)                      # du ready
             with torch.cuda.stream(side):                   # weight/bias gradients are off the dX critical path
                 if want_w:
-                    sl = mp.linear_wgrad_slabs(z, K, du)
+                    sl = mp.linear_wgrad_slabs(z, K, du, bias_only_rows=g.n_ghost if lean else 0)
                     if sl is not None:                      # slabs now, ONE reduction for all layers at the end
                         dw, sw = mp._sink_or_new(ctx.params[2 * l], (K, N), dev)     # straight into the flat bucket if one is installed
                         db, sb = mp._sink_or_new(ctx.params[2 * l + 1], (N,), dev) if want_b else (None, False)
                         pending.append((sl[0], sl[1], K, N, dw, db))
                         dw, db = (None if sw else dw), (None if sb else db)
                     else:
+                        if lean:
+                            z[g.n_rows:].zero_()
                         dw, db = mp.linear_wgrad(z, K, du, want_b)
                     grads[2 * l], grads[2 * l + 1] = dw, db
                 elif want_b:
@@ -152,10 +170,12 @@ class _SageStack(torch.autograd.Function):
                 ldz = z.size(1)
                 dz = torch.zeros(R, ldz, dtype=torch.float32, device=dev) if ldz > K else torch.empty(R, ldz, dtype=torch.float32, device=dev)
                 if mp.rowgemm_ok(du, du.stride(0), W, W.stride(0), N, K, True):
-                    nat.call("rowgemm_f32", du, du.stride(0), W, W.stride(0), 1, None, dz, dz.stride(0), None, R, N, K, 0)
+                    # ghost rows have no edges: their dz is never gathered, so only the real rows go through the product
+                    nat.call("rowgemm_f32", du, du.stride(0), W, W.stride(0), 1, None, dz, dz.stride(0), None, g.n_rows, N, K, 0, 0)
                 else:
                     mp.gemm(du, du.stride(0), 1, W, 1, W.stride(0), dz, dz.stride(0), 1, R, K, N)
-                dxs = _aggregate_raw(g, dz, transposed=True)
+                # ... and nothing reads the ghost rows of the aggregated gradient (slot_post_bwd takes 0 for them)
+                dxs = _aggregate_raw(g, dz, transposed=True, rows=g.n_rows if (l > 0 and g.n_ghost) else None)
                 if l == 0:
                     dx0 = dxs
         if pending:
