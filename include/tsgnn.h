@@ -199,8 +199,9 @@ int tsgnn_softmax_ce_f32(const float* logits, int64_t ld, const int64_t* label, 
                          tsgnn_stream_t stream);
 /* clip_grad_norm(max_norm) + Adam.step() of the reference loop (train.py:128-129) on one flat fp32
  * parameter / gradient buffer (the buffer RCCL all-reduces): grad is first scaled by grad_scale
- * (1/world_size).  state: 3 floats {step, grad_norm, applied scale} (zeroed before the first step);
- * ws >= 256 floats. */
+ * (1/world_size).  state: 4 floats {step, grad_norm, applied scale, barrier-timeout flag} (zeroed before the first
+ * step); ws >= 258 floats, 8-byte aligned, zeroed once (its tail holds the arrival counter of the one-launch variant
+ * used for n <= 262,144: norm and update separated by a device-wide barrier of <= 256 resident blocks). */
 int tsgnn_clip_adam_step_f32(float* param, const float* grad, float* m, float* v, int64_t n, float lr, float beta1,
                              float beta2, float eps, float weight_decay, float max_norm, float grad_scale, float* state,
                              float* ws, tsgnn_stream_t stream);
@@ -297,9 +298,9 @@ int tsgnn_readout_decode_layers_f32(const unsigned long long* packed, int B, int
  * or map_model -> map2_model; encoders.py:207-217).  W1 [E,P], W2 [C,E] as nn.Linear stores them.  P % 4 == 0. */
 int tsgnn_head2_fwd_f32(const float* out, int64_t ldo, const float* w1, const float* b1, const float* w2, const float* b2, int B, int P,
                         int E, int C, float* vec, float* y, tsgnn_stream_t stream);
-/* backward: dvt = dvec (nullable) + W2^T dy ; dout = W1^T dvt ; dW1 = dvt^T out ; db1 ; dW2 = dy^T vec ; db2 */
+/* backward in one launch: dvt = dvec (nullable) + W2^T dy (internal) ; dout = W1^T dvt ; dW1 = dvt^T out ; db1 ; dW2 = dy^T vec ; db2 */
 int tsgnn_head2_bwd_f32(const float* out, int64_t ldo, const float* vec, const float* dy, const float* dvec, const float* w1,
-                        const float* w2, int B, int P, int E, int C, float* dvt, float* dout, int64_t lddo, float* dw1, float* db1,
+                        const float* w2, int B, int P, int E, int C, float* dout, int64_t lddo, float* dw1, float* db1,
                         float* dw2, float* db2, tsgnn_stream_t stream);
 
 #ifdef __cplusplus

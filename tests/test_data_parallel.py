@@ -181,6 +181,30 @@ def test_hip_clip_adam_matches_torch():
         opt.step()
     for a, b in zip(m1.parameters(), m2.parameters()):
         torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+    assert float(tr.state[0]) == 5.0 and float(tr.state[3]) == 0.0          # five steps, the device-wide barrier never timed out
+
+
+@pytest.mark.gpu
+def test_hip_clip_adam_large_model_three_launch_path():
+    """more than 262,144 parameters: separate norm / final / update launches, same arithmetic."""
+    sys.path.insert(0, ROOT)
+    from two_stage_gnn_amd.data_parallel import FlatTrainer
+    torch.manual_seed(1)
+    m1 = torch.nn.Linear(600, 500).cuda()
+    m2 = torch.nn.Linear(600, 500).cuda()
+    m2.load_state_dict(m1.state_dict())
+    tr = FlatTrainer(m1, lr=1e-3, clip=1.0)
+    assert tr.numel > 262144
+    opt = torch.optim.Adam(m2.parameters(), lr=1e-3)
+    x, y = torch.randn(8, 600).cuda(), torch.randint(0, 500, (8,)).cuda()
+    for _ in range(3):
+        tr.step(lambda: torch.nn.functional.cross_entropy(m1(x), y))
+        opt.zero_grad()
+        torch.nn.functional.cross_entropy(m2(x), y).backward()
+        torch.nn.utils.clip_grad_norm_(m2.parameters(), 1.0)
+        opt.step()
+    for a, b in zip(m1.parameters(), m2.parameters()):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
 
 
 @pytest.mark.gpu

@@ -1,5 +1,5 @@
 // Graph-level prediction head of the encoders (encoders.py:207-217 / :396-406): two chained nn.Linear on the
-// concatenated readout [B, P]  ->  vec [B, E]  ->  y [B, C],  forward and backward in 1 + 2 launches instead of the
+// concatenated readout [B, P]  ->  vec [B, E]  ->  y [B, C],  forward and backward in 1 + 1 launches instead of the
 // ~8 library launches (2 addmm, 4 mm, 2 bias reductions) a B = 32 batch spends most of its time dispatching.
 // Shapes are tiny (B <= a few hundred rows): one workgroup per graph row, weights streamed from L2 with 16-byte loads.
 #include "common.h"
@@ -56,20 +56,19 @@ __global__ __launch_bounds__(64 * HW) void head2_fwd_kernel(const float* __restr
   }
 }
 
-// block b: dvt[b,:] = dvec[b,:] + W2^T dy[b,:] ;  dout[b,:] = W1^T dvt[b,:]
-__global__ __launch_bounds__(64 * HW) void head2_bwd_rows_kernel(const float* __restrict__ dy, const float* __restrict__ dvec,
-                                                             const float* __restrict__ w1, const float* __restrict__ w2, int P,
-                                                             int E, int C, float* __restrict__ dvt, float* __restrict__ dout,
-                                                             int64_t ldo) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+// Backward in ONE launch.  Blocks [0, B): block b computes dvt[b,:] = dvec[b,:] + W2^T dy[b,:] and dout[b,:] = W1^T dvt[b,:].
+// Blocks [B, B + ceil(E/4)]: the weight gradients; they rebuild the four dvt columns they need from dy, dvec and W2
+// (C fused multiply-adds per value) instead of waiting for the row blocks, so nothing orders the two groups.
+__device__ __forceinline__ void head2_bwd_rows(float* smem, int b, const float* __restrict__ dy, const float* __restrict__ dvec,
+                                               const float* __restrict__ w1, const float* __restrict__ w2, int P, int E, int C,
+                                               float* __restrict__ dout, int64_t ldo) {
   float* ds = smem;                          // [E] dvt row
   float* part = smem + ((E + 3) & ~3);       // [HW][P] partial dout
-  const int b = blockIdx.x, tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
   for (int j = tid; j < E; j += 64 * HW) {
     float acc = dvec ? dvec[(int64_t)b * E + j] : 0.f;
     for (int c = 0; c < C; ++c) acc = fmaf(dy[(int64_t)b * C + c], w2[(int64_t)c * E + j], acc);
     ds[j] = acc;
-    dvt[(int64_t)b * E + j] = acc;
   }
   __syncthreads();
   // each wave takes every 4th row j of W1 and accumulates its contribution to all P columns
@@ -101,22 +100,27 @@ __global__ __launch_bounds__(64 * HW) void head2_bwd_rows_kernel(const float* __
   }
 }
 
-// weights: block jb owns rows j = 4*jb .. 4*jb+3 of dW1 (+ db1); the last block also produces dW2, db2
-__global__ __launch_bounds__(256) void head2_bwd_weights_kernel(const float* __restrict__ out, int64_t ldo, const float* __restrict__ vec,
-                                                                const float* __restrict__ dvt, const float* __restrict__ dy, int B, int P,
-                                                                int E, int C, float* __restrict__ dw1, float* __restrict__ db1,
-                                                                float* __restrict__ dw2, float* __restrict__ db2) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];   // [B][4] dvt slice
-  const int tid = threadIdx.x;
+// weights: block jb owns rows j = 4*jb .. 4*jb+3 of dW1 (+ db1); the last block produces dW2, db2
+__device__ __forceinline__ void head2_bwd_weights(float* smem /* [B][4] dvt slice */, int jb, const float* __restrict__ out, int64_t ldo,
+                                                  const float* __restrict__ vec, const float* __restrict__ dy,
+                                                  const float* __restrict__ dvec, const float* __restrict__ w2, int B, int P, int E,
+                                                  int C, float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dw2,
+                                                  float* __restrict__ db2) {
+  const int tid = threadIdx.x, NTH = 64 * HW;
   const int nj = (E + 3) / 4;
-  if ((int)blockIdx.x < nj) {
-    const int j0 = 4 * blockIdx.x;
-    for (int i = tid; i < B * 4; i += 256) {
+  if (jb < nj) {
+    const int j0 = 4 * jb;
+    for (int i = tid; i < B * 4; i += NTH) {
       const int bb = i >> 2, jj = j0 + (i & 3);
-      smem[i] = jj < E ? dvt[(int64_t)bb * E + jj] : 0.f;
+      float a = 0.f;
+      if (jj < E) {
+        a = dvec ? dvec[(int64_t)bb * E + jj] : 0.f;
+        for (int c = 0; c < C; ++c) a = fmaf(dy[(int64_t)bb * C + c], w2[(int64_t)c * E + jj], a);   // same order as the row blocks
+      }
+      smem[i] = a;
     }
     __syncthreads();
-    for (int k = tid; k < P; k += 256) {
+    for (int k = tid; k < P; k += NTH) {
       float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
       for (int bb = 0; bb < B; ++bb) {
         const float x = out[(int64_t)bb * ldo + k];
@@ -134,18 +138,28 @@ __global__ __launch_bounds__(256) void head2_bwd_weights_kernel(const float* __r
       db1[j0 + tid] = a;
     }
   } else {
-    for (int i = tid; i < C * E; i += 256) {
+    for (int i = tid; i < C * E; i += NTH) {
       const int c = i / E, j = i % E;
       float a = 0.f;
       for (int bb = 0; bb < B; ++bb) a = fmaf(dy[(int64_t)bb * C + c], vec[(int64_t)bb * E + j], a);
       dw2[i] = a;
     }
-    if (db2) for (int c = tid; c < C; c += 256) {
+    if (db2) for (int c = tid; c < C; c += NTH) {
       float a = 0.f;
       for (int bb = 0; bb < B; ++bb) a += dy[(int64_t)bb * C + c];
       db2[c] = a;
     }
   }
+}
+
+__global__ __launch_bounds__(64 * HW) void head2_bwd_kernel(const float* __restrict__ out, int64_t ldo, const float* __restrict__ vec,
+                                                        const float* __restrict__ dy, const float* __restrict__ dvec,
+                                                        const float* __restrict__ w1, const float* __restrict__ w2, int B, int P, int E,
+                                                        int C, float* __restrict__ dout, int64_t lddo, float* __restrict__ dw1,
+                                                        float* __restrict__ db1, float* __restrict__ dw2, float* __restrict__ db2) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if ((int)blockIdx.x < B) head2_bwd_rows(smem, blockIdx.x, dy, dvec, w1, w2, P, E, C, dout, lddo);
+  else head2_bwd_weights(smem, (int)blockIdx.x - B, out, ldo, vec, dy, dvec, w2, B, P, E, C, dw1, db1, dw2, db2);
 }
 
 }  // namespace
@@ -163,14 +177,14 @@ int tsgnn_head2_fwd_f32(const float* out, int64_t ldo, const float* w1, const fl
 }
 
 int tsgnn_head2_bwd_f32(const float* out, int64_t ldo, const float* vec, const float* dy, const float* dvec, const float* w1,
-                        const float* w2, int B, int P, int E, int C, float* dvt, float* dout, int64_t lddo, float* dw1, float* db1,
+                        const float* w2, int B, int P, int E, int C, float* dout, int64_t lddo, float* dw1, float* db1,
                         float* dw2, float* db2, tsgnn_stream_t stream) {
-  if (!out || !vec || !dy || !w1 || !w2 || !dvt || !dout || !dw1 || !dw2 || B <= 0 || P <= 0 || E <= 0 || C <= 0) return TSGNN_EINVAL;
+  if (!out || !vec || !dy || !w1 || !w2 || !dout || !dw1 || !dw2 || B <= 0 || P <= 0 || E <= 0 || C <= 0) return TSGNN_EINVAL;
   if ((P % 4) || P > 2048 || E > 4096 || B > 1024 || (reinterpret_cast<uintptr_t>(w1) & 15)) return TSGNN_EUNSUPPORTED;
-  const size_t lds_rows = sizeof(float) * (size_t)(((E + 3) & ~3) + HW * ((P + 3) & ~3));
-  head2_bwd_rows_kernel<<<B, 64 * HW, lds_rows, stream>>>(dy, dvec, w1, w2, P, E, C, dvt, dout, lddo);
-  head2_bwd_weights_kernel<<<(E + 3) / 4 + 1, 256, sizeof(float) * 4 * (size_t)B, stream>>>(out, ldo, vec, dvt, dy, B, P, E, C, dw1, db1,
-                                                                                           dw2, db2);
+  size_t lds = sizeof(float) * (size_t)(((E + 3) & ~3) + HW * ((P + 3) & ~3));
+  if (lds < sizeof(float) * 4 * (size_t)B) lds = sizeof(float) * 4 * (size_t)B;
+  head2_bwd_kernel<<<B + (E + 3) / 4 + 1, 64 * HW, lds, stream>>>(out, ldo, vec, dy, dvec, w1, w2, B, P, E, C, dout, lddo, dw1, db1, dw2,
+                                                                db2);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }

@@ -1,7 +1,7 @@
 // Optimiser step of the reference's training loop on ONE flat fp32 buffer (train.py:128-129:
 // nn.utils.clip_grad_norm(model.parameters(), clip) then Adam.step()), so that the data-parallel
-// all-reduce (one RCCL call on the same flat gradient buffer) and the update are 1 + 2 launches per
-// step instead of ~10 launches per parameter tensor.  Graph-replay safe: the step counter lives in
+// all-reduce (one RCCL call on the same flat gradient buffer) and the update are 1 + 1 launches per
+// step (1 + 3 for models over 262,144 parameters) instead of ~10 launches per parameter tensor.  Graph-replay safe: the step counter lives in
 // device memory.
 #include "common.h"
 #include "../../include/tsgnn.h"
@@ -52,6 +52,78 @@ __global__ void adam_update(float* __restrict__ p, const float* __restrict__ g, 
 }
 
 
+// One-launch variant for small models: the grid is at most one block per CU (all blocks resident), so the blocks can
+// meet at a device-wide barrier between the norm and the update.  Block k owns elements [k*256*CV, (k+1)*256*CV):
+//   partial sum of squares -> part[k] -> arrive (release) -> wait for everyone (acquire, bounded spin) ->
+//   every block adds the partials in the same fixed order -> clip coefficient -> Adam on its own elements.
+// `sync` is a monotonically increasing 64-bit arrival counter (never reset: launch t waits for (t+1)*gridDim.x).
+// A wait that exceeds its bound (blocks not co-resident: cannot happen with <= #CU tiny blocks on an idle queue) gives
+// up, reports through state[3] and skips the update instead of hanging the device.
+constexpr int CV = 4;               // elements per thread
+constexpr int COOP_MAX_BLOCKS = 256;
+__global__ __launch_bounds__(256) void clip_adam_coop(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                      float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
+                                                      float wd, float max_norm, float grad_scale, float* __restrict__ state,
+                                                      float* __restrict__ part, unsigned long long* __restrict__ sync) {
+  __shared__ float lds[4];
+  __shared__ int ok_s;
+  const int tid = threadIdx.x, nb = gridDim.x;
+  const int64_t base = ((int64_t)blockIdx.x * 256 + tid) * CV;
+  float gv[CV];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < CV; ++c) {
+    gv[c] = (base + c) < n ? g[base + c] : 0.f;
+    s = fmaf(gv[c], gv[c], s);
+  }
+  const float step = state[0] + 1.f;                   // read before anyone can have updated it (block 0 does, after the barrier)
+  s = wave_sum(s);
+  if ((tid & 63) == 0) lds[tid >> 6] = s;
+  __syncthreads();
+  if (tid == 0) {
+    __hip_atomic_store(part + blockIdx.x, (lds[0] + lds[1]) + (lds[2] + lds[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long ticket = __hip_atomic_fetch_add(sync, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long target = (ticket / (unsigned long long)nb + 1ull) * (unsigned long long)nb;
+    int ok = 0;
+    for (int spin = 0; spin < (1 << 20); ++spin) {
+      if (__hip_atomic_load(sync, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = 1; break; }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    ok_s = ok;
+  }
+  __syncthreads();
+  if (!ok_s) {
+    if (tid == 0) state[3] = 1.f;
+    return;
+  }
+  float t = 0.f;
+  for (int k = tid; k < nb; k += 256) t += __hip_atomic_load(part + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // nb <= 256: one each
+  t = wave_sum(t);
+  __syncthreads();
+  if ((tid & 63) == 0) lds[tid >> 6] = t;
+  __syncthreads();
+  const float norm = sqrtf((lds[0] + lds[1]) + (lds[2] + lds[3])) * grad_scale;
+  float coef = 1.f;
+  if (max_norm > 0.f) coef = fminf(max_norm / (norm + 1e-6f), 1.f);
+  const float scale = coef * grad_scale;
+  if (blockIdx.x == 0 && tid == 0) { state[0] = step; state[1] = norm; state[2] = scale; }
+  const float bc1 = 1.f - powf(b1, step), bc2 = 1.f - powf(b2, step);
+#pragma unroll
+  for (int c = 0; c < CV; ++c) {
+    const int64_t i = base + c;
+    if (i < n) {
+      float gi = gv[c] * scale;
+      if (wd != 0.f) gi = fmaf(wd, p[i], gi);
+      const float mi = fmaf(b1, m[i], (1.f - b1) * gi);
+      const float vi = fmaf(b2, v[i], (1.f - b2) * gi * gi);
+      m[i] = mi; v[i] = vi;
+      const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+      p[i] -= (lr / bc1) * (mi / denom);
+    }
+  }
+}
+
+
 // softmax cross-entropy (mean over rows) with its gradient in the same pass: model.loss() of the reference
 // (F.cross_entropy, encoders.py:221-224).  One thread per row (few classes), block reduction of the loss.
 __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict__ logits, int64_t ld, const int64_t* __restrict__ label,
@@ -89,11 +161,21 @@ int tsgnn_softmax_ce_f32(const float* logits, int64_t ld, const int64_t* label, 
 }
 
 /* One optimiser step on flat buffers: g *= grad_scale (1/world after the all-reduce), clip to max_norm
- * (<=0: off), Adam.  ws >= 256 floats; state = 3 floats {step, grad_norm, applied scale}, zero before step 1. */
+ * (<=0: off), Adam.  ws >= 258 floats, 8-byte aligned, zeroed once before the first step (its last two words are the
+ * barrier counter of the one-launch variant); state = 4 floats {step, grad_norm, applied scale, barrier timeout flag},
+ * zero before step 1.  n <= 262,144: ONE launch (device-wide barrier between norm and update); larger: three. */
 int tsgnn_clip_adam_step_f32(float* param, const float* grad, float* m, float* v, int64_t n, float lr, float beta1,
                              float beta2, float eps, float weight_decay, float max_norm, float grad_scale, float* state,
                              float* ws, tsgnn_stream_t stream) {
   if (!param || !grad || !m || !v || !state || !ws || n <= 0) return TSGNN_EINVAL;
+  if (reinterpret_cast<uintptr_t>(ws) & 7) return TSGNN_EINVAL;
+  if (n <= (int64_t)COOP_MAX_BLOCKS * 256 * CV) {
+    const int nbc = (int)ceil_div64(n, 256 * CV);
+    clip_adam_coop<<<nbc, 256, 0, stream>>>(param, grad, m, v, n, lr, beta1, beta2, eps, weight_decay, max_norm, grad_scale, state, ws,
+                                            reinterpret_cast<unsigned long long*>(ws + 256));
+    TSGNN_CHECK_LAUNCH();
+    return TSGNN_OK;
+  }
   int nb = (int)ceil_div64(n, 256 * 8);
   if (nb > NPART) nb = NPART;
   sqnorm_partial<<<nb, 256, 0, stream>>>(grad, n, ws);

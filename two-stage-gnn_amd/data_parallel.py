@@ -38,8 +38,8 @@ class FlatTrainer:
         self.on_gpu = dev.type == "cuda"
         self.exp_avg = torch.zeros_like(self.flat_param)
         self.exp_avg_sq = torch.zeros_like(self.flat_param)
-        self.state = torch.zeros(3, dtype=torch.float32, device=dev)      # step, grad norm, applied scale
-        self.ws = torch.empty(256, dtype=torch.float32, device=dev)
+        self.state = torch.zeros(4, dtype=torch.float32, device=dev)      # step, grad norm, applied scale, barrier-timeout flag
+        self.ws = torch.zeros(264, dtype=torch.float32, device=dev)       # norm partials + the optimiser kernel's arrival counter
         self._zeros = [torch.zeros_like(p).reshape(-1) for p in self.params]     # stand-ins for parameters without a gradient
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1

@@ -42,7 +42,7 @@ def _batch_from_dense(adj, sizes, layout):
     return g
 
 
-FUSED_HEAD = True              # the two chained nn.Linear after the readout as one HIP launch (+2 backward)
+FUSED_HEAD = True              # the two chained nn.Linear after the readout as one HIP launch (+1 backward)
 FUSED_STACK = True             # GcnEncoderGraph: run the conv stack as one fused autograd node when it qualifies
 DENSE_ADJ_MAX_NODES = 128      # at or below this many nodes per graph a dense batched MFMA product is used
 

@@ -470,7 +470,7 @@ def cross_entropy(logits, label):
 
 # ----------------------------------------------------------------------------- graph-level head
 class _Head2(torch.autograd.Function):
-    """(vec, y) = (W1 out + b1, W2 vec + b2): the chained nn.Linear pair after the readout, 1 + 2 launches."""
+    """(vec, y) = (W1 out + b1, W2 vec + b2): the chained nn.Linear pair after the readout, 1 + 1 launches."""
 
     @staticmethod
     def forward(ctx, out, w1, b1, w2, b2):
@@ -497,14 +497,13 @@ class _Head2(torch.autograd.Function):
             return None, None, None, None, None
         dy = dy.contiguous() if dy is not None else torch.zeros(B, C, device=dev)
         dvec = dvec.contiguous() if dvec is not None else None
-        dvt = _f32(B, E, device=dev)
         dout = _f32(B, P, device=dev)
         pw1, pb1, pw2, pb2 = ctx.params
         dw1, s1 = _sink_or_new(pw1, (E, P), dev)
         dw2, s2 = _sink_or_new(pw2, (C, E), dev)
         db1, s3 = _sink_or_new(pb1, (E,), dev) if ctx.has_b[0] else (None, False)
         db2, s4 = _sink_or_new(pb2, (C,), dev) if ctx.has_b[1] else (None, False)
-        nat.call("head2_bwd_f32", out, out.stride(0), vec, dy, dvec, w1, w2, B, P, E, C, dvt, dout, dout.stride(0), dw1, db1, dw2, db2)
+        nat.call("head2_bwd_f32", out, out.stride(0), vec, dy, dvec, w1, w2, B, P, E, C, dout, dout.stride(0), dw1, db1, dw2, db2)
         return dout, None if s1 else dw1, None if s3 else db1, None if s2 else dw2, None if s4 else db2
 
 
