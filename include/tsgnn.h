@@ -148,6 +148,16 @@ int tsgnn_rowgemm_supported(const float* a, int64_t lda, const float* b, int64_t
 int tsgnn_rowgemm_f32(const float* a, int64_t lda, const float* b, int64_t ldb, int trans_b, const float* bias, float* c,
                       int64_t ldc, float* rinv, int64_t rows, int K, int N, int normalize, int64_t fill_rows,
                       tsgnn_stream_t stream);
+/* Aggregation fused into the product (GraphConv.forward lines encoders.py:33-40 in one launch; and its input gradient
+ * dX = (A dU) W^T for a symmetric A): the A operand of tsgnn_rowgemm_f32 is replaced by
+ *   z[r,:] = sum_k x[ell[r*ell_w + k], :K]      (ell = fixed-width neighbour table of tsgnn_csr_to_ell, entries < 0 skipped,
+ *                                               ell_w in {4, 8, 16}; rows with a CSR tail are NOT handled here),
+ * gathered chunk by chunk while it is staged for the MFMAs.  zout (nullable) receives z for rows [0, rows) (the weight
+ * gradient needs it; its columns [K, roundup4(K)) get the aggregated row padding of x, which must be finite).  N <= 128;
+ * everything else as tsgnn_rowgemm_f32. */
+int tsgnn_gather_rowgemm_f32(const int* ell, int ell_w, const float* x, int64_t ldx, const float* b, int64_t ldb, int trans_b,
+                             const float* bias, float* c, int64_t ldc, float* rinv, float* zout, int64_t ldz, int64_t rows, int K,
+                             int N, int normalize, int64_t fill_rows, tsgnn_stream_t stream);
 /* backward of the row normalisation: du = rinv * (dv - v (v.dv)) */
 int tsgnn_l2norm_bwd_f32(const float* v, int64_t ldv, const float* dv, int64_t lddv, const float* rinv, float* du,
                          int64_t lddu, int64_t rows, int F, tsgnn_stream_t stream);

@@ -16,15 +16,30 @@ int main(int argc, char** argv) {
   hipMemcpy(a, h.data(), R * K * 4, hipMemcpyHostToDevice);
   hipMemcpy(b, h.data(), K * N * 4, hipMemcpyHostToDevice);
   hipMemcpy(bias, h.data(), N * 4, hipMemcpyHostToDevice);
+  // synthetic neighbour table: degree 2..8 (avg 5) inside a +-300 row window (DD-like locality), width 16
+  std::vector<int> hell(R * 16, -1);
+  for (int64_t r = 0; r < R; ++r) {
+    const int deg = 2 + (int)((r * 2654435761u >> 7) % 7);
+    for (int k = 0; k < deg; ++k) {
+      long long j = r + (long long)(((r * 40503u + k * 9973u) >> 3) % 600) - 300;
+      hell[r * 16 + k] = (int)std::min<long long>(std::max<long long>(j, 0), R - 1);
+    }
+  }
+  int* ell; hipMalloc(&ell, R * 16 * 4); hipMemcpy(ell, hell.data(), R * 16 * 4, hipMemcpyHostToDevice);
+  float* zout; hipMalloc(&zout, R * K * 4);
+  const bool gather = argc > 2 && atoi(argv[2]) != 0;
   hipStream_t s; hipStreamCreate(&s);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int trans = 0; trans < 2; ++trans) {
-    for (int it = 0; it < 20; ++it)
-      tsgnn_rowgemm_f32(a, K, b, N, trans, trans ? nullptr : bias, c, N, trans ? nullptr : rinv, R, K, N, trans ? 0 : 1, 0, s);
+    auto run = [&]() {
+      if (gather) tsgnn_gather_rowgemm_f32(ell, 16, a, K, b, N, trans, trans ? nullptr : bias, c, N, trans ? nullptr : rinv,
+                                           trans ? nullptr : zout, K, R, K, N, trans ? 0 : 1, 0, s);
+      else tsgnn_rowgemm_f32(a, K, b, N, trans, trans ? nullptr : bias, c, N, trans ? nullptr : rinv, R, K, N, trans ? 0 : 1, 0, s);
+    };
+    for (int it = 0; it < 20; ++it) run();
     hipStreamSynchronize(s);
     hipEventRecord(e0, s);
-    for (int it = 0; it < 200; ++it)
-      tsgnn_rowgemm_f32(a, K, b, N, trans, trans ? nullptr : bias, c, N, trans ? nullptr : rinv, R, K, N, trans ? 0 : 1, 0, s);
+    for (int it = 0; it < 200; ++it) run();
     hipEventRecord(e1, s); hipStreamSynchronize(s);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     std::vector<long long> t(4096 * 16);

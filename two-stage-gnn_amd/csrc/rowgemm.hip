@@ -34,11 +34,18 @@ struct RowGemmArgs {
   int64_t rows; int K; int N;
   int normalize;
   int64_t fill_rows;                  // rows after `rows` that get the epilogue of a zero input row
+  // GATHER variant: the A operand is the unit-weight aggregation  A[r,:] = sum_k a[ell[r*ell_w + k], :]  (entries < 0
+  // skipped), built chunk by chunk while it is staged; zout (nullable) receives it (the weight gradient needs it).
+  const int* ell; int ell_w;
+  float* zout; int64_t ldz;
 };
 
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
-template <int NT, bool TRANS_B>
+constexpr int GN = 8;                 // neighbour rows per output row that are gathered in one go (the rest, rare, follow)
+constexpr int LDA_F = 128 + 4;        // row stride of the gathered full-K A panel (K <= 128; +4: conflict-free 16-byte reads)
+
+template <int NT, bool TRANS_B, bool GATHER>
 __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs g) {
   constexpr int NP = 32 * NT;
   constexpr int TPW = (NT + 3) / 4;
@@ -80,7 +87,7 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs g) {
   // are written to LDS, so nothing waits on a load before the MFMAs of the current chunk.
   const int am = tid >> 3, ak4 = tid & 7;
   const bool a_row_ok = (m0 + am) < g.rows;
-  const float* ap = g.a + (a_row_ok ? (m0 + am) : 0) * g.lda + 4 * ak4;
+  const float* ap = g.a + ((a_row_ok && !GATHER) ? (m0 + am) : 0) * g.lda + 4 * ak4;
   const float* bp[BV];
   int b_k[BV];                                         // k (or first k of the float4) inside the chunk
   int b_lds[BV];
@@ -114,6 +121,17 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs g) {
     s.plain = panel_full && (k0 + KC) <= g.K;
     s.a_valid = 0;
     s.b_valid = 0;
+    if (GATHER) {                                      // the A panel is already in LDS: only B travels
+#pragma unroll
+      for (int q = 0; q < BV; ++q) {
+        const bool kok = (k0 + b_k[q]) < g.K;
+        if (!TRANS_B) s.rb[q] = ldg4(kok ? bp[q] + (int64_t)k0 * g.ldb : bp[q] - (int64_t)b_k[q] * g.ldb);
+        else s.rb[q] = ldg4(kok ? bp[q] + k0 : bp[q] - b_k[q]);
+        s.b_valid |= (kok && b_nok[q]) ? (1u << q) : 0u;
+      }
+      s.plain = false;
+      return;
+    }
     if (s.plain) {
       s.ra = ldg4(ap + k0);
 #pragma unroll
@@ -133,6 +151,12 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs g) {
     }
   };
   auto commit = [&](const Staged& s, float* st) {      // S(c): registers -> LDS stage
+    if (GATHER) {
+#pragma unroll
+      for (int q = 0; q < BV; ++q)
+        *reinterpret_cast<float4*>(st + A_FLOATS + b_lds[q]) = ((s.b_valid >> q) & 1u) ? s.rb[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+      return;
+    }
     if (s.plain) {
       *reinterpret_cast<float4*>(st + am * LDA_S + 4 * ak4) = s.ra;
 #pragma unroll
@@ -149,12 +173,14 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs g) {
     for (int q = 0; q < BV; ++q)
       *reinterpret_cast<float4*>(st + A_FLOATS + b_lds[q]) = ((s.b_valid >> q) & 1u) ? s.rb[q] : make_float4(0.f, 0.f, 0.f, 0.f);
   };
-  auto frags = [&](const float* st, float (&af)[KC / 2], float (&bf)[TPW][KC / 2]) {   // R(c): LDS -> MFMA operands
-    const float* As = st;
+  float* Apanel = smem + 2 * STAGE + 256;              // GATHER: the whole aggregated panel [32][LDA_F], built in the prologue
+  auto frags = [&](const float* st, int k0, float (&af)[KC / 2], float (&bf)[TPW][KC / 2]) {   // R(c): LDS -> MFMA operands
+    const float* As = GATHER ? Apanel + k0 : st;
+    constexpr int lda_s = GATHER ? LDA_F : LDA_S;
     const float* Bs = st + A_FLOATS;
 #pragma unroll
     for (int u = 0; u < KC / 8; ++u) {
-      const float4 v = *reinterpret_cast<const float4*>(As + i * LDA_S + 8 * u + 4 * h);
+      const float4 v = *reinterpret_cast<const float4*>(As + i * lda_s + 8 * u + 4 * h);
       af[4 * u] = v.x; af[4 * u + 1] = v.y; af[4 * u + 2] = v.z; af[4 * u + 3] = v.w;
     }
 #pragma unroll
@@ -189,11 +215,58 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs g) {
   // the only barrier: operands of the next chunk are already in registers when M(c) finishes, and a chunk's global
   // loads have two iterations to land.  Stage c&1 is rewritten in iteration c, one barrier after its readers R(c).
   // NS register staging sets: with 4 (widths <= 128) the first four chunks are all in flight before any MFMA.
-  constexpr int NS = NT <= 4 ? 4 : 2;
+  constexpr int NS = (NT <= 4 && !GATHER) ? 4 : 2;    // (the gather prologue needs the registers for the neighbour rows)
   Staged st[NS];
+  int ids[4][GN];                                      // GATHER: neighbour ids first (head of the dependent chain), the W
+  if (GATHER) {                                        // fetches below fill their latency
+    const int rsub = tid >> 5;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int64_t row = m0 + 8 * p + rsub;
+#pragma unroll
+      for (int q = 0; q < GN / 4; ++q) {
+        int4 v = make_int4(-1, -1, -1, -1);
+        if (row < g.rows && 4 * q < g.ell_w) v = *reinterpret_cast<const int4*>(g.ell + row * g.ell_w + 4 * q);
+        ids[p][4 * q] = v.x; ids[p][4 * q + 1] = v.y; ids[p][4 * q + 2] = v.z; ids[p][4 * q + 3] = v.w;
+      }
+    }
+  }
 #pragma unroll
   for (int c = 0; c < NS; ++c)
     if (c == 0 || c * KC < g.K) fetch(st[c], c * KC);
+  if (GATHER) {
+    // A panel = aggregated rows.  Row-major like the stand-alone aggregation kernel: 32 lanes per row (one float4 column
+    // each), 8 rows per pass, 4 passes; the first GN neighbour rows of all four passes are in flight together
+    // (one index round trip + one row round trip for the whole panel), longer lists (rare) are finished afterwards.
+    const int c4 = tid & 31, rsub = tid >> 5;
+    const bool colok = 4 * c4 < g.K;                   // a float4 that straddles K is taken whole: B's rows >= K are zero in
+                                                       // LDS and the row padding of x is finite (zero) by the layout rule
+    float4 nbv[4][GN];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int k = 0; k < GN; ++k) {
+        nbv[p][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (colok && ids[p][k] >= 0) nbv[p][k] = ldg4(g.a + (int64_t)ids[p][k] * g.lda + 4 * c4);
+      }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int64_t row = m0 + 8 * p + rsub;
+      float4 va = nbv[p][0];
+#pragma unroll
+      for (int k = 1; k < GN; ++k) { va.x += nbv[p][k].x; va.y += nbv[p][k].y; va.z += nbv[p][k].z; va.w += nbv[p][k].w; }
+      if (colok && g.ell_w > GN && ids[p][GN - 1] >= 0) {      // the table fills from the left: maybe more than GN neighbours
+        for (int k = GN; k < g.ell_w; ++k) {
+          const int j = g.ell[row * g.ell_w + k];
+          if (j < 0) break;
+          const float4 t = ldg4(g.a + (int64_t)j * g.lda + 4 * c4);
+          va.x += t.x; va.y += t.y; va.z += t.z; va.w += t.w;
+        }
+      }
+      if (4 * c4 < LDA_F - 4) *reinterpret_cast<float4*>(Apanel + (8 * p + rsub) * LDA_F + 4 * c4) = va;   // zeros beyond K / rows
+      if (g.zout && colok && row < g.rows) *reinterpret_cast<float4*>(g.zout + row * g.ldz + 4 * c4) = va;
+    }
+  }
   float bias_v[TPW];                                   // fetched now, used in the epilogue
 #pragma unroll
   for (int t = 0; t < TPW; ++t) {
@@ -206,7 +279,7 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs g) {
   __syncthreads();
   TR(2);
   float fa[2][KC / 2], fb[2][TPW][KC / 2];
-  frags(smem, fa[0], fb[0]);
+  frags(smem, 0, fa[0], fb[0]);
   if (NS == 2) {
     if (2 * KC < g.K) fetch(st[0], 2 * KC);
     if (3 * KC < g.K) fetch(st[1], 3 * KC);
@@ -215,7 +288,7 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs g) {
     constexpr int CI = decltype(ci_)::value;           // c mod 4, compile time: register sets are picked statically
     constexpr int P = CI & 1;
     const int k0 = c * KC;
-    if (k0 + KC < g.K) frags(smem + (P ^ 1) * STAGE, fa[P ^ 1], fb[P ^ 1]);
+    if (k0 + KC < g.K) frags(smem + (P ^ 1) * STAGE, k0 + KC, fa[P ^ 1], fb[P ^ 1]);
     if (NS == 4 && c >= 0 && k0 + 4 * KC < g.K) fetch(st[CI % NS], k0 + 4 * KC);
     __builtin_amdgcn_sched_barrier(0);                 // the scheduler would sink the LDS reads to their uses
 #pragma unroll
@@ -317,24 +390,30 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs g) {
   TR_END();
 }
 
-template <int NT, bool TRANS_B>
+template <int NT, bool TRANS_B, bool GATHER>
 void launch_rowgemm(const RowGemmArgs& g, hipStream_t s) {
   constexpr int NP = 32 * NT;
-  const size_t lds = sizeof(float) * (2 * (32 * LDA_S + (TRANS_B ? NP * LDA_S : KC * NP)) + 128 + 4 * 32);
-  rowgemm_kernel<NT, TRANS_B><<<(unsigned)(ceil_div64(g.rows, 32) + (g.fill_rows > 0 ? 1 : 0)), 256, lds, s>>>(g);
+  const size_t lds = sizeof(float) * (2 * (32 * LDA_S + (TRANS_B ? NP * LDA_S : KC * NP)) + 128 + 4 * 32 + (GATHER ? 32 * LDA_F : 0));
+  rowgemm_kernel<NT, TRANS_B, GATHER><<<(unsigned)(ceil_div64(g.rows, 32) + (g.fill_rows > 0 ? 1 : 0)), 256, lds, s>>>(g);
 }
 
-template <bool TRANS_B>
+template <bool TRANS_B, bool GATHER>
 void dispatch_rowgemm(const RowGemmArgs& g, hipStream_t s) {
   switch ((g.N + 31) / 32) {
-    case 1: launch_rowgemm<1, TRANS_B>(g, s); break;
-    case 2: launch_rowgemm<2, TRANS_B>(g, s); break;
-    case 3: launch_rowgemm<3, TRANS_B>(g, s); break;
-    case 4: launch_rowgemm<4, TRANS_B>(g, s); break;
-    case 5: launch_rowgemm<5, TRANS_B>(g, s); break;
-    case 6: launch_rowgemm<6, TRANS_B>(g, s); break;
-    case 7: launch_rowgemm<7, TRANS_B>(g, s); break;
-    default: launch_rowgemm<8, TRANS_B>(g, s); break;
+    case 1: launch_rowgemm<1, TRANS_B, GATHER>(g, s); break;
+    case 2: launch_rowgemm<2, TRANS_B, GATHER>(g, s); break;
+    case 3: launch_rowgemm<3, TRANS_B, GATHER>(g, s); break;
+    case 4: launch_rowgemm<4, TRANS_B, GATHER>(g, s); break;
+    default:
+      if constexpr (!GATHER) {                           // the gather variant is built for widths <= 128
+        switch ((g.N + 31) / 32) {
+          case 5: launch_rowgemm<5, TRANS_B, false>(g, s); break;
+          case 6: launch_rowgemm<6, TRANS_B, false>(g, s); break;
+          case 7: launch_rowgemm<7, TRANS_B, false>(g, s); break;
+          default: launch_rowgemm<8, TRANS_B, false>(g, s); break;
+        }
+      }
+      break;
   }
 }
 
@@ -363,9 +442,28 @@ int tsgnn_rowgemm_f32(const float* a, int64_t lda, const float* b, int64_t ldb, 
                         (bias && (reinterpret_cast<uintptr_t>(bias) & 15))))
     return TSGNN_EUNSUPPORTED;
   if (rows == 0 && fill_rows == 0) return TSGNN_OK;
-  RowGemmArgs g{a, lda, b, ldb, bias, c, ldc, rinv, rows, K, N, normalize, fill_rows};
-  if (trans_b) dispatch_rowgemm<true>(g, stream);
-  else dispatch_rowgemm<false>(g, stream);
+  RowGemmArgs g{a, lda, b, ldb, bias, c, ldc, rinv, rows, K, N, normalize, fill_rows, nullptr, 0, nullptr, 0};
+  if (trans_b) dispatch_rowgemm<true, false>(g, stream);
+  else dispatch_rowgemm<false, false>(g, stream);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+int tsgnn_gather_rowgemm_f32(const int* ell, int ell_w, const float* x, int64_t ldx, const float* b, int64_t ldb, int trans_b,
+                             const float* bias, float* c, int64_t ldc, float* rinv, float* zout, int64_t ldz, int64_t rows, int K,
+                             int N, int normalize, int64_t fill_rows, tsgnn_stream_t stream) {
+  if (!ell || !x || !b || !c || rows < 0 || fill_rows < 0 || K <= 0 || N <= 0 || ldx < K || ldc < N) return TSGNN_EINVAL;
+  if (ell_w != 4 && ell_w != 8 && ell_w != 16) return TSGNN_EUNSUPPORTED;
+  if (!tsgnn_rowgemm_supported(x, ldx, b, ldb, c, ldc, K, N, trans_b) || N > 128 || K > 128 || (reinterpret_cast<uintptr_t>(ell) & 15))
+    return TSGNN_EUNSUPPORTED;
+  if (zout && ((ldz % 4) || ldz < K || (reinterpret_cast<uintptr_t>(zout) & 15))) return TSGNN_EUNSUPPORTED;
+  if (fill_rows > 0 && ((N % 4) || (ldc % 4) || (reinterpret_cast<uintptr_t>(c) & 15) ||
+                        (bias && (reinterpret_cast<uintptr_t>(bias) & 15))))
+    return TSGNN_EUNSUPPORTED;
+  if (rows == 0 && fill_rows == 0) return TSGNN_OK;
+  RowGemmArgs g{x, ldx, b, ldb, bias, c, ldc, rinv, rows, K, N, normalize, fill_rows, ell, ell_w, zout, ldz};
+  if (trans_b) dispatch_rowgemm<true, true>(g, stream);
+  else dispatch_rowgemm<false, true>(g, stream);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }

@@ -50,6 +50,17 @@ def _aggregate_raw(g, x, transposed=False, rows=None):
     return mp.spmm_raw(rp, col, val, x, n)
 
 
+import os
+
+GATHER_FUSED = os.environ.get("TSGNN_GATHER_FUSED", "1") != "0"     # aggregate inside the `.W` product when the neighbour table has no CSR tail
+
+
+def _gather_ok(g, x):
+    if not GATHER_FUSED or g.val is not None or not mp.ell_ok(x) or g.total_rows > mp.ELL_MAX_ROWS:
+        return False
+    return g.ell()[2] is None
+
+
 class _SageStack(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x0, g, has_bias, *params):
@@ -75,22 +86,29 @@ class _SageStack(torch.autograd.Function):
             rinv = torch.empty(R, dtype=torch.float32, device=dev)
             # Ghost rows aggregate nothing (z = 0): their output is the normalised bias, written by a filler block, and
             # their z is neither produced nor read (255 row panels + 1 filler = one block per CU on the DD batch).
-            lean = (g.n_ghost > 0 and x.stride(0) % 4 == 0 and K % 4 == 0 and N % 4 == 0 and Ws[l].data_ptr() % 16 == 0
+            lean = (g.n_ghost > 0 and x.stride(0) % 4 == 0 and N % 4 == 0 and Ws[l].data_ptr() % 16 == 0
                     and (bs[l] is None or bs[l].data_ptr() % 16 == 0))
-            z = _aggregate_raw(g, x, rows=g.n_rows if lean else None)
-            if lean and mp.rowgemm_ok(z, z.stride(0), Ws[l], Ws[l].stride(0), K, N, False):
-                nat.call("rowgemm_f32", z, z.stride(0), Ws[l], Ws[l].stride(0), 0, bs[l], v, v.stride(0), rinv, g.n_rows, K, N, 1,
-                         g.n_ghost)
-            elif mp.rowgemm_ok(z, z.stride(0), Ws[l], Ws[l].stride(0), K, N, False):
-                if lean:
-                    z[g.n_rows:].zero_()
-                    lean = False
-                nat.call("rowgemm_f32", z, z.stride(0), Ws[l], Ws[l].stride(0), 0, bs[l], v, v.stride(0), rinv, R, K, N, 1, 0)
+            if lean and N <= 128 and _gather_ok(g, x) and mp.rowgemm_ok(x, x.stride(0), Ws[l], Ws[l].stride(0), K, N, False):
+                # aggregation fused into the product: the neighbour rows are summed while the A panel is staged
+                ell, ell_w, _ = g.ell()
+                z = torch.empty(R, x.size(1), dtype=torch.float32, device=dev)
+                nat.call("gather_rowgemm_f32", ell, ell_w, x, x.stride(0), Ws[l], Ws[l].stride(0), 0, bs[l], v, v.stride(0), rinv,
+                         z, z.stride(0), g.n_rows, K, N, 1, g.n_ghost)
             else:
-                if lean:
-                    z[g.n_rows:].zero_()
-                    lean = False
-                nat.call("linear_l2norm_f32", z, z.stride(0), Ws[l], Ws[l].stride(0), bs[l], v, v.stride(0), rinv, R, K, N, 1)
+                z = _aggregate_raw(g, x, rows=g.n_rows if lean else None)
+                if lean and mp.rowgemm_ok(z, z.stride(0), Ws[l], Ws[l].stride(0), K, N, False):
+                    nat.call("rowgemm_f32", z, z.stride(0), Ws[l], Ws[l].stride(0), 0, bs[l], v, v.stride(0), rinv, g.n_rows, K, N, 1,
+                             g.n_ghost)
+                elif mp.rowgemm_ok(z, z.stride(0), Ws[l], Ws[l].stride(0), K, N, False):
+                    if lean:
+                        z[g.n_rows:].zero_()
+                        lean = False
+                    nat.call("rowgemm_f32", z, z.stride(0), Ws[l], Ws[l].stride(0), 0, bs[l], v, v.stride(0), rinv, R, K, N, 1, 0)
+                else:
+                    if lean:
+                        z[g.n_rows:].zero_()
+                        lean = False
+                    nat.call("linear_l2norm_f32", z, z.stride(0), Ws[l], Ws[l].stride(0), bs[l], v, v.stride(0), rinv, R, K, N, 1)
             pk = packed[off:off + B * N]
             if l < L - 1:
                 mean = torch.empty(g.nmax, dtype=torch.float32, device=dev)
@@ -168,14 +186,22 @@ class _SageStack(torch.autograd.Function):
             need_dx = l > 0 or ctx.needs_input_grad[0]
             if need_dx:
                 ldz = z.size(1)
-                dz = torch.zeros(R, ldz, dtype=torch.float32, device=dev) if ldz > K else torch.empty(R, ldz, dtype=torch.float32, device=dev)
-                if mp.rowgemm_ok(du, du.stride(0), W, W.stride(0), N, K, True):
-                    # ghost rows have no edges: their dz is never gathered, so only the real rows go through the product
-                    nat.call("rowgemm_f32", du, du.stride(0), W, W.stride(0), 1, None, dz, dz.stride(0), None, g.n_rows, N, K, 0, 0)
+                if (l > 0 and g.n_ghost > 0 and g.symmetric and ldz == K and K <= 128 and _gather_ok(g, du)
+                        and mp.rowgemm_ok(du, du.stride(0), W, W.stride(0), N, K, True)):
+                    # dX = A^T (dU W^T) = (A dU) W^T for a symmetric A: the same fused gather + product; only real rows
+                    ell, ell_w, _ = g.ell()
+                    dxs = torch.empty(R, ldz, dtype=torch.float32, device=dev)
+                    nat.call("gather_rowgemm_f32", ell, ell_w, du, du.stride(0), W, W.stride(0), 1, None, dxs, dxs.stride(0), None,
+                             None, 0, g.n_rows, N, K, 0, 0)
                 else:
-                    mp.gemm(du, du.stride(0), 1, W, 1, W.stride(0), dz, dz.stride(0), 1, R, K, N)
-                # ... and nothing reads the ghost rows of the aggregated gradient (slot_post_bwd takes 0 for them)
-                dxs = _aggregate_raw(g, dz, transposed=True, rows=g.n_rows if (l > 0 and g.n_ghost) else None)
+                    dz = torch.zeros(R, ldz, dtype=torch.float32, device=dev) if ldz > K else torch.empty(R, ldz, dtype=torch.float32, device=dev)
+                    if mp.rowgemm_ok(du, du.stride(0), W, W.stride(0), N, K, True):
+                        # ghost rows have no edges: their dz is never gathered, so only the real rows go through the product
+                        nat.call("rowgemm_f32", du, du.stride(0), W, W.stride(0), 1, None, dz, dz.stride(0), None, g.n_rows, N, K, 0, 0)
+                    else:
+                        mp.gemm(du, du.stride(0), 1, W, 1, W.stride(0), dz, dz.stride(0), 1, R, K, N)
+                    # ... and nothing reads the ghost rows of the aggregated gradient (slot_post_bwd takes 0 for them)
+                    dxs = _aggregate_raw(g, dz, transposed=True, rows=g.n_rows if (l > 0 and g.n_ghost) else None)
                 if l == 0:
                     dx0 = dxs
         if pending:
