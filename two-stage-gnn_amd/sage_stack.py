@@ -73,6 +73,16 @@ class _SageStack(torch.autograd.Function):
         total = B * ((L - 1) * Fh + Fl)
         packed = torch.empty(total, dtype=torch.int64, device=dev)      # cleared by the first slot_bn_fwd launch
         x = mp._check(x0, R)
+        # Ghost slots actually needed.  Every graph's padded rows at slots >= the largest graph are bitwise identical in
+        # every layer (same bias row, same statistics), the max readout breaks ties towards the smallest row, and nothing
+        # aggregates from a ghost row: only slots [0, max_size] can influence an output or a gradient.  The slot kernels,
+        # the filler and the bias gradient therefore run on  gs = min(nmax, max_size + 1)  ghost rows (half of nmax on DD).
+        gs = g.n_ghost
+        if g.n_ghost > 0 and x.stride(0) % 4 == 0 and all(
+                Ws[l].size(1) % 4 == 0 and Ws[l].data_ptr() % 16 == 0 and (bs[l] is None or bs[l].data_ptr() % 16 == 0)
+                for l in range(L)):
+            gs = min(g.nmax, int(g.sizes.max()) + 1)
+        sn, sg = (gs, gs) if g.n_ghost else (g.nmax, 0)      # (slots, ghost rows) handed to the slot kernels
         saved = []
         off = 0
         main = torch.cuda.current_stream()
@@ -93,12 +103,12 @@ class _SageStack(torch.autograd.Function):
                 ell, ell_w, _ = g.ell()
                 z = torch.empty(R, x.size(1), dtype=torch.float32, device=dev)
                 nat.call("gather_rowgemm_f32", ell, ell_w, x, x.stride(0), Ws[l], Ws[l].stride(0), 0, bs[l], v, v.stride(0), rinv,
-                         z, z.stride(0), g.n_rows, K, N, 1, g.n_ghost)
+                         z, z.stride(0), g.n_rows, K, N, 1, gs)
             else:
                 z = _aggregate_raw(g, x, rows=g.n_rows if lean else None)
                 if lean and mp.rowgemm_ok(z, z.stride(0), Ws[l], Ws[l].stride(0), K, N, False):
                     nat.call("rowgemm_f32", z, z.stride(0), Ws[l], Ws[l].stride(0), 0, bs[l], v, v.stride(0), rinv, g.n_rows, K, N, 1,
-                             g.n_ghost)
+                             gs)
                 elif mp.rowgemm_ok(z, z.stride(0), Ws[l], Ws[l].stride(0), K, N, False):
                     if lean:
                         z[g.n_rows:].zero_()
@@ -114,25 +124,26 @@ class _SageStack(torch.autograd.Function):
                 mean = torch.empty(g.nmax, dtype=torch.float32, device=dev)
                 rstd = torch.empty(g.nmax, dtype=torch.float32, device=dev)
                 y = torch.empty_like(v)
-                nat.call("slot_bn_fwd_f32", g.graph_ptr, g.slot_count, B, g.nmax, g.n_rows, g.n_ghost, v, v.stride(0), N, 1,
+                nat.call("slot_bn_fwd_f32", g.graph_ptr, g.slot_count, B, sn, g.n_rows, sg, v, v.stride(0), N, 1,
                          mean, rstd, y, y.stride(0), packed if l == 0 else None, total)
                 if OVERLAP:
                     side.wait_stream(main)
                 with torch.cuda.stream(side):               # the next layer only needs y: readout runs beside it
-                    nat.call("readout_partial_f32", g.graph_ptr, B, g.nmax, g.n_rows, g.n_ghost, y, y.stride(0), N, pk)
+                    nat.call("readout_partial_f32", g.graph_ptr, B, sn, g.n_rows, sg, y, y.stride(0), N, pk)
                 keep.append(y)
                 x = y
             else:
                 mean = rstd = None
                 if OVERLAP:
                     main.wait_stream(side)                  # join: all partials done before the decode
-                nat.call("readout_partial_f32", g.graph_ptr, B, g.nmax, g.n_rows, g.n_ghost, v, v.stride(0), N, pk)
+                nat.call("readout_partial_f32", g.graph_ptr, B, sn, g.n_rows, sg, v, v.stride(0), N, pk)
             saved.append((z, v, rinv, mean, rstd, lean))
             off += B * N
         out = torch.empty(B, (L - 1) * Fh + Fl, dtype=torch.float32, device=dev)
         arg = torch.empty(total, dtype=torch.int32, device=dev)
         nat.call("readout_decode_layers_f32", packed, B, L, Fh, Fl, out, out.stride(0), arg)
         ctx.g, ctx.L, ctx.has_bias, ctx.dims = g, L, has_bias, (Fh, Fl)
+        ctx.slots = (sn, sg)
         ctx.Ws, ctx.saved, ctx.arg = Ws, saved, arg
         ctx.params = params
         ctx.x0_ld = x.size(1) if L == 0 else x0.size(1)
@@ -145,6 +156,7 @@ class _SageStack(torch.autograd.Function):
         dout = dout.contiguous()
         dev = dout.device
         R, B = g.total_rows, g.B
+        sn, sg = ctx.slots
         grads = [None] * (2 * L)
         dxs = None
         dx0 = None
@@ -160,7 +172,7 @@ class _SageStack(torch.autograd.Function):
             du = torch.empty(R, N, dtype=torch.float32, device=dev)
             dsl = dout[:, l * Fh:l * Fh + N]
             argl = ctx.arg[l * B * Fh:l * B * Fh + B * N]
-            nat.call("slot_post_bwd_f32", g.graph_ptr, g.slot_count, B, g.nmax, g.n_rows, g.n_ghost, v, v.stride(0), dxs,
+            nat.call("slot_post_bwd_f32", g.graph_ptr, g.slot_count, B, sn, g.n_rows, sg, v, v.stride(0), dxs,
                      dxs.stride(0) if dxs is not None else 0, dsl, dout.stride(0), argl, N, 0 if last else 1, 0 if last else 1,
                      mean, rstd, rinv, du, du.stride(0))
             want_w = ctx.needs_input_grad[3 + 2 * l]
@@ -169,7 +181,9 @@ class _SageStack(torch.autograd.Function):
                 side.wait_stream(main)                      # du ready
             with torch.cuda.stream(side):                   # weight/bias gradients are off the dX critical path
                 if want_w:
-                    sl = mp.linear_wgrad_slabs(z, K, du, bias_only_rows=g.n_ghost if lean else 0)
+                    if not lean and sg < g.n_ghost:
+                        du[g.n_rows + sg:].zero_()          # rows no slot kernel wrote
+                    sl = mp.linear_wgrad_slabs(z, K, du[:g.n_rows + sg] if lean else du, bias_only_rows=sg if lean else 0)
                     if sl is not None:                      # slabs now, ONE reduction for all layers at the end
                         dw, sw = mp._sink_or_new(ctx.params[2 * l], (K, N), dev)     # straight into the flat bucket if one is installed
                         db, sb = mp._sink_or_new(ctx.params[2 * l + 1], (N,), dev) if want_b else (None, False)
@@ -178,9 +192,12 @@ class _SageStack(torch.autograd.Function):
                     else:
                         if lean:
                             z[g.n_rows:].zero_()
+                            du[g.n_rows + sg:].zero_()
                         dw, db = mp.linear_wgrad(z, K, du, want_b)
                     grads[2 * l], grads[2 * l + 1] = dw, db
                 elif want_b:
+                    if sg < g.n_ghost:
+                        du[g.n_rows + sg:].zero_()
                     grads[2 * l + 1] = mp.colsum(du)
             keep.append(du)
             need_dx = l > 0 or ctx.needs_input_grad[0]
