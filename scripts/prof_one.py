@@ -19,4 +19,11 @@ for _ in range(int(os.environ.get("N", 30))):
         mp.spmm_raw(g.rowptr, g.col, None, X, R, out=Y)
     elif which == "ell":
         mp.spmm_ell(g, X, out=Y)
+    elif which == "gather":                 # aggregation fused into the product, as the step's forward layers launch it
+        ell, ell_w, tail = g.ell()
+        assert tail is None
+        Z = getattr(sys.modules[__name__], "_Z", None)
+        if Z is None:
+            Z = sys.modules[__name__]._Z = torch.empty_like(X)
+        nat.call("gather_rowgemm_f32", ell, ell_w, X, H, W, H, 0, b, Y, H, rinv, Z, H, g.n_rows, H, H, 1, g.n_ghost)
 torch.cuda.synchronize()

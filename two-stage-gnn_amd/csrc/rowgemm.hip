@@ -56,7 +56,11 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int i = lane & 31, h = lane >> 5;
-  const int64_t m0 = (int64_t)blockIdx.x * 32;
+  // XCD-aware panel order: blocks b, b+8, ... share an XCD (and its L2); give each XCD one contiguous run of panels so
+  // that the neighbour rows gathered by adjacent panels (same graph) are fetched into one L2 only.  The filler block
+  // (last) keeps its index.
+  const unsigned npanels = (unsigned)((g.rows + 31) / 32);
+  const int64_t m0 = (blockIdx.x < npanels ? (int64_t)xcd_remap(blockIdx.x, npanels) : (int64_t)blockIdx.x) * 32;
   TR(0);
   if (m0 >= g.rows) {
     // filler block (launched after the panels when fill_rows > 0): every fill row = [normalised] bias
