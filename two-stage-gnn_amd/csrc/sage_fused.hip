@@ -124,13 +124,26 @@ __global__ __launch_bounds__(256) void slot_post_bwd(SlotArgs s, const float* __
   // all LDS in ONE dynamic array (16-byte aligned base for the float4 ghost accumulators, Guideline 17)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int F = 4 * F4;
-  float* gacc = smem;                                                // [GPB][F] ghost copies' dv (only with ghost rows)
-  float* red = smem + (s.n_ghost ? GPB * F : 0);                     // 8 floats
+  float* gacc = smem;                                                // [4 waves][F] ghost-copy sums (only with ghost rows)
+  float* red = smem + (s.n_ghost ? 4 * F : 0);                       // 8 floats
   int& first_ghost = *reinterpret_cast<int*>(red + 8);
-  unsigned char* is_ghost = reinterpret_cast<unsigned char*>(red + 12);   // GPB bytes
   const int n = blockIdx.x, tid = threadIdx.x;
   const int b = tid / TPR, c = tid % TPR;
+  TR(0);
   if (tid == 0) first_ghost = 0x7fffffff;
+  // the readout winners and their gradients depend on (graph, column) only: issued first, they fly while the row is resolved
+  int4 wq[NV];
+  float4 gq[NV];
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+    const int c4 = c + TPR * q;
+    wq[q] = make_int4(-1, -1, -1, -1);
+    gq[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (b < s.B && c4 < F4) {
+      wq[q] = *reinterpret_cast<const int4*>(arg + (int64_t)b * F + 4 * c4);
+      gq[q] = ld4(dout + (int64_t)b * ldo + 4 * c4);
+    }
+  }
   __syncthreads();
   int64_t row = -1;
   bool ghost = false;
@@ -139,10 +152,11 @@ __global__ __launch_bounds__(256) void slot_post_bwd(SlotArgs s, const float* __
     if (n < sz) row = (int64_t)g0 + n;
     else if (s.n_ghost) { row = s.n_real + n; ghost = true; }
   }
-  if (c == 0) is_ghost[b] = ghost ? 1 : 0;
+  TR(1);
   if (ghost && c == 0) atomicMin(&first_ghost, b);
   __syncthreads();
   const bool fg = ghost && b == first_ghost;
+  const bool any_ghost = first_ghost != 0x7fffffff;               // uniform
   const float mu = bn ? mean[n] : 0.f, rs = bn ? rstd[n] : 1.f;
   float4 vv[NV], dy[NV];
   float a1 = 0.f, a2 = 0.f;
@@ -154,8 +168,8 @@ __global__ __launch_bounds__(256) void slot_post_bwd(SlotArgs s, const float* __
     if (row >= 0 && c4 < F4) {
       vv[q] = ld4(v + row * ldv + 4 * c4);
       if (dxs && !ghost) dy[q] = ld4(dxs + row * lddxs + 4 * c4);   // nothing aggregates from a ghost row: its dxs is 0
-      const int4 w = *reinterpret_cast<const int4*>(arg + (int64_t)b * F + 4 * c4);
-      const float4 g = ld4(dout + (int64_t)b * ldo + 4 * c4);
+      const int4 w = wq[q];
+      const float4 g = gq[q];
       const int r32 = (int)row;
       if (w.x == r32) dy[q].x += g.x;
       if (w.y == r32) dy[q].y += g.y;
@@ -169,6 +183,7 @@ __global__ __launch_bounds__(256) void slot_post_bwd(SlotArgs s, const float* __
       }
     }
   }
+  TR(2);
   float m1 = 0.f, m2 = 0.f;
   if (bn) {
     const int have = s.slot_count[n];
@@ -177,6 +192,7 @@ __global__ __launch_bounds__(256) void slot_post_bwd(SlotArgs s, const float* __
     m1 = cnt > 0.f ? a1 / cnt : 0.f;
     m2 = cnt > 0.f ? a2 / cnt : 0.f;
   }
+  TR(3);
   // dv per candidate
   float4 dv[NV];
 #pragma unroll
@@ -196,42 +212,43 @@ __global__ __launch_bounds__(256) void slot_post_bwd(SlotArgs s, const float* __
     }
     dv[q] = make_float4(o[0], o[1], o[2], o[3]);
   }
-  // ghost copies -> LDS; ALL threads reduce them (feature f = tid % F, interleaved graph ranges, fixed order),
-  // then the first ghost group picks up the totals
-  if (s.n_ghost) {
-    if (ghost) {
+  TR(4);
+  // ghost copies of this slot are summed: across the graphs of a wave with lane exchanges (lanes TPR apart hold the same
+  // columns of consecutive graphs), across the four waves through 4 x F floats of LDS; the first ghost copy takes the total
+  if (s.n_ghost && any_ghost) {
+    float4 gs[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) gs[q] = ghost ? dv[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int d = TPR; d < 64; d <<= 1) {
+#pragma unroll
+      for (int q = 0; q < NV; ++q) {
+        gs[q].x += __shfl_xor(gs[q].x, d, 64); gs[q].y += __shfl_xor(gs[q].y, d, 64);
+        gs[q].z += __shfl_xor(gs[q].z, d, 64); gs[q].w += __shfl_xor(gs[q].w, d, 64);
+      }
+    }
+    const int lane = tid & 63, wid = tid >> 6;
+    if (lane < TPR) {
 #pragma unroll
       for (int q = 0; q < NV; ++q) {
         const int c4 = c + TPR * q;
-        if (c4 < F4) st4(gacc + (int64_t)b * F + 4 * c4, dv[q]);
+        if (c4 < F4) st4(gacc + wid * F + 4 * c4, gs[q]);
       }
     }
-    __syncthreads();
-    const int parts = 256 / F > 0 ? 256 / F : 1;                     // F <= 128 -> parts >= 2
-    const int f = tid % F, part = tid / F;
-    float acc = 0.f;
-    if (part < parts) {
-      for (int gb = part; gb < s.B; gb += parts)
-        if (is_ghost[gb]) acc += gacc[(int64_t)gb * F + f];
-    }
-    __syncthreads();                                                  // everyone done reading gacc
-    if (part < parts) gacc[part * F + f] = acc;                       // rows 0..parts-1 of gacc now hold the partials
     __syncthreads();
     if (fg) {
 #pragma unroll
       for (int q = 0; q < NV; ++q) {
         const int c4 = c + TPR * q;
         if (c4 < F4) {
-          float4 t = ld4(gacc + 4 * c4);
-          for (int p = 1; p < parts; ++p) {
-            const float4 u = ld4(gacc + (int64_t)p * F + 4 * c4);
-            t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
-          }
-          dv[q] = t;
+          const float4 t0 = ld4(gacc + 4 * c4), t1 = ld4(gacc + F + 4 * c4), t2 = ld4(gacc + 2 * F + 4 * c4), t3 = ld4(gacc + 3 * F + 4 * c4);
+          dv[q] = make_float4((t0.x + t1.x) + (t2.x + t3.x), (t0.y + t1.y) + (t2.y + t3.y), (t0.z + t1.z) + (t2.z + t3.z),
+                              (t0.w + t1.w) + (t2.w + t3.w));
         }
       }
     }
   }
+  TR(5);
   // row L2-normalise backward (real rows, and the ghost row by its first copy)
   const bool writer = row >= 0 && (!ghost || fg);
   float dot = 0.f;
@@ -257,6 +274,8 @@ __global__ __launch_bounds__(256) void slot_post_bwd(SlotArgs s, const float* __
       if (c4 < F4) st4(du + gr * lddu + 4 * c4, make_float4(0.f, 0.f, 0.f, 0.f));
     }
   }
+  TR(6);
+  TR_END();
 }
 
 // ---------------------------------------------------------------------------------------------- readout
@@ -356,8 +375,7 @@ int tsgnn_slot_post_bwd_f32(const int* graph_ptr, const int* slot_count, int B, 
     return TSGNN_EINVAL;
   if (!tsgnn_slot_fused_supported(B, F)) return TSGNN_EUNSUPPORTED;
   SlotArgs s{graph_ptr, slot_count, B, nmax, n_real, n_ghost};
-  const int gpb = B <= 32 ? 32 : (B <= 64 ? 64 : 128);
-  const size_t lds = sizeof(float) * ((n_ghost ? (size_t)gpb * F : 0) + 12) + gpb;
+  const size_t lds = sizeof(float) * ((n_ghost ? (size_t)4 * F : 0) + 12);
   TSGNN_SLOT_DISPATCH(slot_post_bwd, <<<nmax, 256, lds, stream>>>(s, v, ldv, dxs, lddxs, dout, ldo, arg, F / 4, relu, bn, mean, rstd,
                                                                  rinv, du, lddu));
   TSGNN_CHECK_LAUNCH();
