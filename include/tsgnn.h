@@ -158,6 +158,13 @@ int tsgnn_rowgemm_f32(const float* a, int64_t lda, const float* b, int64_t ldb, 
 int tsgnn_gather_rowgemm_f32(const int* ell, int ell_w, const float* x, int64_t ldx, const float* b, int64_t ldb, int trans_b,
                              const float* bias, float* c, int64_t ldc, float* rinv, float* zout, int64_t ldz, int64_t rows, int K,
                              int N, int normalize, int64_t fill_rows, tsgnn_stream_t stream);
+/* Backward of a hidden 128 -> 128 GraphConv layer's GEMM-shaped halves in ONE launch (both consume du): the weight / bias
+ * gradient slabs of tsgnn_linear_wgrad_f32 (dw == NULL form: reduce ws later with tsgnn_wgrad_reduce_multi_f32; plan with
+ * tsgnn_linear_wgrad_plan(rows, 128, 128, ...)) and dxs = (A du) w^T of tsgnn_gather_rowgemm_f32 (trans_b = 1, symmetric A).
+ * A CU hosts one block of each grid, so the two run side by side instead of back to back. */
+int tsgnn_sage_layer_bwd_f32(const int* ell, int ell_w, const float* du, int64_t lddu, const float* w, int64_t ldw, float* dxs,
+                             int64_t lddxs, const float* z, int64_t ldz, int64_t rows, int nslab, int64_t rows_per_slab,
+                             int64_t bias_only_rows, float* ws, tsgnn_stream_t stream);
 /* backward of the row normalisation: du = rinv * (dv - v (v.dv)) */
 int tsgnn_l2norm_bwd_f32(const float* v, int64_t ldv, const float* dv, int64_t lddv, const float* rinv, float* du,
                          int64_t lddu, int64_t rows, int F, tsgnn_stream_t stream);

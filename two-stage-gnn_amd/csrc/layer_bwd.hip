@@ -1,0 +1,45 @@
+// One launch for the two independent GEMM-shaped halves of a hidden GraphConv layer's backward (both consume dU):
+//
+//   weight / bias gradient slabs   dW_s = Z_s^T dU_s , db_s = colsum(dU_s)              (tn_rows_body, gemm.hip)
+//   input gradient                 dX   = (A dU) W^T   for a symmetric A               (rowgemm_body GATHER, rowgemm.hip)
+//
+// Each is a grid of <= #CU latency-bound blocks with one wave per SIMD; launched together, a CU hosts one block of each
+// (registers 214+32 and 220+16 per lane, LDS 64 + 67 KB) and the two MFMA streams interleave, instead of running back to
+// back with a kernel boundary between them.  Blocks [0, n_tn) are the slab blocks, the rest the row panels.
+#include "common.h"
+#include "../../include/tsgnn.h"
+#include "rowgemm_body.h"
+#include "tn_rows_body.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void sage_layer_bwd_kernel(RowGemmArgs ga, TnArgs gt, unsigned n_tn, unsigned nslab) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (blockIdx.x < n_tn) tn_rows_body<4, 4, 2>(gt, smem, blockIdx.x % nslab, blockIdx.x / nslab, nslab);
+  else rowgemm_body<4, true, true>(ga, smem, blockIdx.x - n_tn);
+}
+
+}  // namespace
+
+extern "C" {
+
+int tsgnn_sage_layer_bwd_f32(const int* ell, int ell_w, const float* du, int64_t lddu, const float* w, int64_t ldw, float* dxs,
+                             int64_t lddxs, const float* z, int64_t ldz, int64_t rows, int nslab, int64_t rows_per_slab,
+                             int64_t bias_only_rows, float* ws, tsgnn_stream_t stream) {
+  if (!ell || !du || !w || !dxs || !z || !ws || rows <= 0 || nslab <= 0 || rows_per_slab <= 0 || bias_only_rows < 0) return TSGNN_EINVAL;
+  if (ell_w != 4 && ell_w != 8 && ell_w != 16) return TSGNN_EUNSUPPORTED;
+  const uintptr_t al = reinterpret_cast<uintptr_t>(ell) | reinterpret_cast<uintptr_t>(du) | reinterpret_cast<uintptr_t>(w) |
+                       reinterpret_cast<uintptr_t>(dxs) | reinterpret_cast<uintptr_t>(z);
+  if ((al & 15) || (lddu % 4) || (ldw % 4) || (lddxs % 4) || (ldz % 4) || lddu < 128 || ldw < 128 || lddxs < 128 || ldz < 128)
+    return TSGNN_EUNSUPPORTED;
+  // dX = (A dU) W^T : a = dU (gathered), b = W [K_in = 128, N_out = 128] used transposed, reduction over N_out
+  RowGemmArgs ga{du, lddu, w, ldw, nullptr, dxs, lddxs, nullptr, rows, 128, 128, 0, 0, ell, ell_w, nullptr, 0};
+  TnArgs gt{z, ldz, du, lddu, rows, rows_per_slab, 128, 128, ws, nullptr, bias_only_rows};
+  const unsigned n_tn = 2u * (unsigned)nslab, n_pan = (unsigned)ceil_div64(rows, 32);
+  constexpr size_t la = rowgemm_lds_bytes<4, true, true>(), lt = tn_rows_lds_bytes<4, 4>();
+  sage_layer_bwd_kernel<<<n_tn + n_pan, 256, la > lt ? la : lt, stream>>>(ga, gt, n_tn, (unsigned)nslab);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+}  // extern "C"

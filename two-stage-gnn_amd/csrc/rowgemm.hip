@@ -16,388 +16,20 @@
 // registers (row sums of squares: DPP over 32 lanes, then 4 waves through LDS).  fp32 MFMA throughout.
 #include "common.h"
 #include "../../include/tsgnn.h"
-#include <type_traits>
+
+#include "rowgemm_body.h"
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int KC = 32;
-constexpr int LDA_S = KC + 4;
-constexpr float NORM_EPS = 1e-12f;
-
-struct RowGemmArgs {
-  const float* a; int64_t lda;
-  const float* b; int64_t ldb;        // B[K][N] row-major, or (TRANS_B) W[N][K] row-major
-  const float* bias;
-  float* c; int64_t ldc;
-  float* rinv;
-  int64_t rows; int K; int N;
-  int normalize;
-  int64_t fill_rows;                  // rows after `rows` that get the epilogue of a zero input row
-  // GATHER variant: the A operand is the unit-weight aggregation  A[r,:] = sum_k a[ell[r*ell_w + k], :]  (entries < 0
-  // skipped), built chunk by chunk while it is staged; zout (nullable) receives it (the weight gradient needs it).
-  const int* ell; int ell_w;
-  float* zout; int64_t ldz;
-};
-
-__device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-
-constexpr int GN = 8;                 // neighbour rows per output row that are gathered in one go (the rest, rare, follow)
-constexpr int LDA_F = 128 + 4;        // row stride of the gathered full-K A panel (K <= 128; +4: conflict-free 16-byte reads)
-
 template <int NT, bool TRANS_B, bool GATHER>
 __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs g) {
-  constexpr int NP = 32 * NT;
-  constexpr int TPW = (NT + 3) / 4;
-  constexpr int BV = NT;                               // float4 of B per thread per chunk (KC * NP / 1024)
-  constexpr int A_FLOATS = 32 * LDA_S;
-  constexpr int B_FLOATS = TRANS_B ? NP * LDA_S : KC * NP;
-  constexpr int STAGE = A_FLOATS + B_FLOATS;           // one of the two LDS stages
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int i = lane & 31, h = lane >> 5;
-  // XCD-aware panel order: blocks b, b+8, ... share an XCD (and its L2); give each XCD one contiguous run of panels so
-  // that the neighbour rows gathered by adjacent panels (same graph) are fetched into one L2 only.  The filler block
-  // (last) keeps its index.
-  const unsigned npanels = (unsigned)((g.rows + 31) / 32);
-  const int64_t m0 = (blockIdx.x < npanels ? (int64_t)xcd_remap(blockIdx.x, npanels) : (int64_t)blockIdx.x) * 32;
-  TR(0);
-  if (m0 >= g.rows) {
-    // filler block (launched after the panels when fill_rows > 0): every fill row = [normalised] bias
-    __shared__ float fred[4];
-    const int N4 = g.N / 4, rpp = 256 / N4;              // rows per pass
-    const int c4 = tid % N4, rsub = tid / N4;
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (g.bias && rsub < rpp) bv = ldg4(g.bias + 4 * c4);
-    float ss = rsub == 0 ? (bv.x * bv.x + bv.y * bv.y) + (bv.z * bv.z + bv.w * bv.w) : 0.f;
-    ss = wave_sum(ss);
-    if (lane == 0) fred[wid] = ss;
-    __syncthreads();
-    float sc = 1.f;
-    if (g.normalize) sc = fminf(__builtin_amdgcn_rsqf((fred[0] + fred[1]) + (fred[2] + fred[3])), 1.0f / NORM_EPS);
-    const float4 out = make_float4(bv.x * sc, bv.y * sc, bv.z * sc, bv.w * sc);
-    if (rsub < rpp) {
-      for (int64_t r = rsub; r < g.fill_rows; r += rpp) {
-        *reinterpret_cast<float4*>(g.c + (g.rows + r) * g.ldc + 4 * c4) = out;
-        if (g.rinv && c4 == 0) g.rinv[g.rows + r] = sc;
-      }
-    }
-    return;
-  }
-
-  // staging maps (computed once) ------------------------------------------------------------------
-  // A: thread -> row am, floats 4*ak4..+3 of the chunk.  B: float4 q of the thread -> (k, n4) or (n, k4).
-  // Loads are unconditional from clamped (always mapped) addresses; validity is applied when the registers
-  // are written to LDS, so nothing waits on a load before the MFMAs of the current chunk.
-  const int am = tid >> 3, ak4 = tid & 7;
-  const bool a_row_ok = (m0 + am) < g.rows;
-  const float* ap = g.a + ((a_row_ok && !GATHER) ? (m0 + am) : 0) * g.lda + 4 * ak4;
-  const float* bp[BV];
-  int b_k[BV];                                         // k (or first k of the float4) inside the chunk
-  int b_lds[BV];
-  bool b_nok[BV];
-#pragma unroll
-  for (int q = 0; q < BV; ++q) {
-    const int idx = q * 256 + tid;
-    if (!TRANS_B) {
-      const int k = idx / (NP / 4), n4 = idx % (NP / 4);
-      b_nok[q] = 4 * n4 < g.N;                         // N % 4 == 0 on this path
-      bp[q] = g.b + (int64_t)k * g.ldb + (b_nok[q] ? 4 * n4 : 0);
-      b_k[q] = k;
-      b_lds[q] = k * NP + 4 * n4;
-    } else {
-      const int n = idx / (KC / 4), k4 = idx % (KC / 4);
-      b_nok[q] = n < g.N;                              // K % 4 == 0 on this path
-      bp[q] = g.b + (int64_t)(b_nok[q] ? n : 0) * g.ldb + 4 * k4;
-      b_k[q] = 4 * k4;
-      b_lds[q] = n * LDA_S + 4 * k4;
-    }
-  }
-  struct Staged {                                      // one K chunk on its way global -> registers -> LDS
-    float4 ra;
-    float4 rb[BV];
-    int a_valid;                                       // number of valid floats of ra (0..4)
-    unsigned b_valid;                                  // bit q: rb[q] valid
-    bool plain;                                        // uniform: no masking needed
-  };
-  const bool panel_full = (m0 + 32) <= g.rows && g.N == NP;   // uniform: every row and column of the panel exists
-  auto fetch = [&](Staged& s, int k0) {                // G(c): global -> registers
-    s.plain = panel_full && (k0 + KC) <= g.K;
-    s.a_valid = 0;
-    s.b_valid = 0;
-    if (GATHER) {                                      // the A panel is already in LDS: only B travels
-#pragma unroll
-      for (int q = 0; q < BV; ++q) {
-        const bool kok = (k0 + b_k[q]) < g.K;
-        if (!TRANS_B) s.rb[q] = ldg4(kok ? bp[q] + (int64_t)k0 * g.ldb : bp[q] - (int64_t)b_k[q] * g.ldb);
-        else s.rb[q] = ldg4(kok ? bp[q] + k0 : bp[q] - b_k[q]);
-        s.b_valid |= (kok && b_nok[q]) ? (1u << q) : 0u;
-      }
-      s.plain = false;
-      return;
-    }
-    if (s.plain) {
-      s.ra = ldg4(ap + k0);
-#pragma unroll
-      for (int q = 0; q < BV; ++q) s.rb[q] = ldg4(TRANS_B ? bp[q] + k0 : bp[q] + (int64_t)k0 * g.ldb);
-      return;
-    }
-    const int gk = k0 + 4 * ak4;
-    const bool ok = a_row_ok && gk < g.K;
-    s.a_valid = ok ? min(4, g.K - gk) : 0;
-    s.ra = ldg4(gk < g.K ? ap + k0 : ap - 4 * ak4);
-#pragma unroll
-    for (int q = 0; q < BV; ++q) {
-      const bool kok = (k0 + b_k[q]) < g.K;
-      if (!TRANS_B) s.rb[q] = ldg4(kok ? bp[q] + (int64_t)k0 * g.ldb : bp[q] - (int64_t)b_k[q] * g.ldb);
-      else s.rb[q] = ldg4(kok ? bp[q] + k0 : bp[q] - b_k[q]);
-      s.b_valid |= (kok && b_nok[q]) ? (1u << q) : 0u;
-    }
-  };
-  auto commit = [&](const Staged& s, float* st) {      // S(c): registers -> LDS stage
-    if (GATHER) {
-#pragma unroll
-      for (int q = 0; q < BV; ++q)
-        *reinterpret_cast<float4*>(st + A_FLOATS + b_lds[q]) = ((s.b_valid >> q) & 1u) ? s.rb[q] : make_float4(0.f, 0.f, 0.f, 0.f);
-      return;
-    }
-    if (s.plain) {
-      *reinterpret_cast<float4*>(st + am * LDA_S + 4 * ak4) = s.ra;
-#pragma unroll
-      for (int q = 0; q < BV; ++q) *reinterpret_cast<float4*>(st + A_FLOATS + b_lds[q]) = s.rb[q];
-      return;
-    }
-    float4 va = s.ra;
-    if (s.a_valid < 4) va.w = 0.f;
-    if (s.a_valid < 3) va.z = 0.f;
-    if (s.a_valid < 2) va.y = 0.f;
-    if (s.a_valid < 1) va.x = 0.f;
-    *reinterpret_cast<float4*>(st + am * LDA_S + 4 * ak4) = va;
-#pragma unroll
-    for (int q = 0; q < BV; ++q)
-      *reinterpret_cast<float4*>(st + A_FLOATS + b_lds[q]) = ((s.b_valid >> q) & 1u) ? s.rb[q] : make_float4(0.f, 0.f, 0.f, 0.f);
-  };
-  float* Apanel = smem + 2 * STAGE + 256;              // GATHER: the whole aggregated panel [32][LDA_F], built in the prologue
-  auto frags = [&](const float* st, int k0, float (&af)[KC / 2], float (&bf)[TPW][KC / 2]) {   // R(c): LDS -> MFMA operands
-    const float* As = GATHER ? Apanel + k0 : st;
-    constexpr int lda_s = GATHER ? LDA_F : LDA_S;
-    const float* Bs = st + A_FLOATS;
-#pragma unroll
-    for (int u = 0; u < KC / 8; ++u) {
-      const float4 v = *reinterpret_cast<const float4*>(As + i * lda_s + 8 * u + 4 * h);
-      af[4 * u] = v.x; af[4 * u + 1] = v.y; af[4 * u + 2] = v.z; af[4 * u + 3] = v.w;
-    }
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-      const int tile = wid + 4 * t;
-      if (4 * (t + 1) <= NT || tile < NT) {             // compile-time true for full groups of 4 tiles
-#pragma unroll
-        for (int u = 0; u < KC / 8; ++u) {
-          if (!TRANS_B) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) bf[t][4 * u + c] = Bs[(8 * u + 4 * h + c) * NP + tile * 32 + i];
-          } else {                                      // W row n = output column: same 16-byte fragment read as A
-            const float4 v = *reinterpret_cast<const float4*>(Bs + (tile * 32 + i) * LDA_S + 8 * u + 4 * h);
-            bf[t][4 * u] = v.x; bf[t][4 * u + 1] = v.y; bf[t][4 * u + 2] = v.z; bf[t][4 * u + 3] = v.w;
-          }
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < KC / 2; ++j) bf[t][j] = 0.f;
-      }
-    }
-  };
-
-  f32x16 acc[TPW];
-#pragma unroll
-  for (int t = 0; t < TPW; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
-  // Software pipeline over the K chunks c = 0, 1, ...:  G(c) global->registers, S(c) registers->LDS stage c&1,
-  // R(c) LDS->operand registers, M(c) the MFMA chain.  Iteration c runs  R(c+1) | M(c) | S(c+2) | G(c+4)  and ends on
-  // the only barrier: operands of the next chunk are already in registers when M(c) finishes, and a chunk's global
-  // loads have two iterations to land.  Stage c&1 is rewritten in iteration c, one barrier after its readers R(c).
-  // NS register staging sets: with 4 (widths <= 128) the first four chunks are all in flight before any MFMA.
-  constexpr int NS = (NT <= 4 && !GATHER) ? 4 : 2;    // (the gather prologue needs the registers for the neighbour rows)
-  Staged st[NS];
-  int ids[4][GN];                                      // GATHER: neighbour ids first (head of the dependent chain), the W
-  if (GATHER) {                                        // fetches below fill their latency
-    const int rsub = tid >> 5;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int64_t row = m0 + 8 * p + rsub;
-#pragma unroll
-      for (int q = 0; q < GN / 4; ++q) {
-        int4 v = make_int4(-1, -1, -1, -1);
-        if (row < g.rows && 4 * q < g.ell_w) v = *reinterpret_cast<const int4*>(g.ell + row * g.ell_w + 4 * q);
-        ids[p][4 * q] = v.x; ids[p][4 * q + 1] = v.y; ids[p][4 * q + 2] = v.z; ids[p][4 * q + 3] = v.w;
-      }
-    }
-  }
-#pragma unroll
-  for (int c = 0; c < NS; ++c)
-    if (c == 0 || c * KC < g.K) fetch(st[c], c * KC);
-  if (GATHER) {
-    // A panel = aggregated rows.  Row-major like the stand-alone aggregation kernel: 32 lanes per row (one float4 column
-    // each), 8 rows per pass, 4 passes; the first GN neighbour rows of all four passes are in flight together
-    // (one index round trip + one row round trip for the whole panel), longer lists (rare) are finished afterwards.
-    const int c4 = tid & 31, rsub = tid >> 5;
-    const bool colok = 4 * c4 < g.K;                   // a float4 that straddles K is taken whole: B's rows >= K are zero in
-                                                       // LDS and the row padding of x is finite (zero) by the layout rule
-    float4 nbv[4][GN];
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-#pragma unroll
-      for (int k = 0; k < GN; ++k) {
-        nbv[p][k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (colok && ids[p][k] >= 0) nbv[p][k] = ldg4(g.a + (int64_t)ids[p][k] * g.lda + 4 * c4);
-      }
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int64_t row = m0 + 8 * p + rsub;
-      float4 va = nbv[p][0];
-#pragma unroll
-      for (int k = 1; k < GN; ++k) { va.x += nbv[p][k].x; va.y += nbv[p][k].y; va.z += nbv[p][k].z; va.w += nbv[p][k].w; }
-      if (colok && g.ell_w > GN && ids[p][GN - 1] >= 0) {      // the table fills from the left: maybe more than GN neighbours
-        for (int k = GN; k < g.ell_w; ++k) {
-          const int j = g.ell[row * g.ell_w + k];
-          if (j < 0) break;
-          const float4 t = ldg4(g.a + (int64_t)j * g.lda + 4 * c4);
-          va.x += t.x; va.y += t.y; va.z += t.z; va.w += t.w;
-        }
-      }
-      if (4 * c4 < LDA_F - 4) *reinterpret_cast<float4*>(Apanel + (8 * p + rsub) * LDA_F + 4 * c4) = va;   // zeros beyond K / rows
-      if (g.zout && colok && row < g.rows) *reinterpret_cast<float4*>(g.zout + row * g.ldz + 4 * c4) = va;
-    }
-  }
-  float bias_v[TPW];                                   // fetched now, used in the epilogue
-#pragma unroll
-  for (int t = 0; t < TPW; ++t) {
-    const int cn = (wid + 4 * t) * 32 + i;
-    bias_v[t] = (g.bias && (wid + 4 * t) < NT && cn < g.N) ? g.bias[cn] : 0.f;
-  }
-  TR(1);
-  commit(st[0], smem);
-  if (KC < g.K) commit(st[1], smem + STAGE);
-  __syncthreads();
-  TR(2);
-  float fa[2][KC / 2], fb[2][TPW][KC / 2];
-  frags(smem, 0, fa[0], fb[0]);
-  if (NS == 2) {
-    if (2 * KC < g.K) fetch(st[0], 2 * KC);
-    if (3 * KC < g.K) fetch(st[1], 3 * KC);
-  }
-  auto body = [&](auto ci_, int c) {
-    constexpr int CI = decltype(ci_)::value;           // c mod 4, compile time: register sets are picked statically
-    constexpr int P = CI & 1;
-    const int k0 = c * KC;
-    if (k0 + KC < g.K) frags(smem + (P ^ 1) * STAGE, k0 + KC, fa[P ^ 1], fb[P ^ 1]);
-    if (NS == 4 && c >= 0 && k0 + 4 * KC < g.K) fetch(st[CI % NS], k0 + 4 * KC);
-    __builtin_amdgcn_sched_barrier(0);                 // the scheduler would sink the LDS reads to their uses
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[P][j], fb[P][0][j], acc[0], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (k0 + 2 * KC < g.K) commit(st[(CI + 2) % NS], smem + P * STAGE);
-    if (NS == 2 && k0 + 4 * KC < g.K) fetch(st[CI % NS], k0 + 4 * KC);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = 8; j < KC / 2; ++j) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[P][j], fb[P][0][j], acc[0], 0, 0, 0);
-#pragma unroll
-    for (int t = 1; t < TPW; ++t) {
-      if (4 * (t + 1) <= NT || (wid + 4 * t) < NT) {
-#pragma unroll
-        for (int j = 0; j < KC / 2; ++j) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[P][j], fb[P][t][j], acc[t], 0, 0, 0);
-      }
-    }
-    TR(3 + 2 * min(c, 3));
-    __syncthreads();
-    TR(4 + 2 * min(c, 3));
-  };
-  for (int c = 0; c * KC < g.K; c += 4) {
-    body(std::integral_constant<int, 0>{}, c);
-    if ((c + 1) * KC < g.K) body(std::integral_constant<int, 1>{}, c + 1);
-    if ((c + 2) * KC < g.K) body(std::integral_constant<int, 2>{}, c + 2);
-    if ((c + 3) * KC < g.K) body(std::integral_constant<int, 3>{}, c + 3);
-  }
-
-  // epilogue in registers: lane (i, h) of tile `wid + 4t` holds C[(r&3) + 8(r>>2) + 4h][tile*32 + i] in acc[t][r].
-  float scale[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) scale[r] = 1.f;
-  if (g.bias || g.normalize) {
-    float ss[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) ss[r] = 0.f;
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-      const int tile = wid + 4 * t;
-      const int cn = tile * 32 + i;
-      const bool okc = tile < NT && cn < g.N;
-      const float bv = bias_v[t];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float v = okc ? acc[t][r] + bv : 0.f;
-        acc[t][r] = v;
-        ss[r] = fmaf(v, v, ss[r]);
-      }
-    }
-    if (g.normalize) {
-      // row sums of squares: transposing DPP reduction inside each 16-lane row (lane l ends with row r = l & 15 of its
-      // half), the two rows of a half through one bpermute, the four waves (column tiles) through LDS; then each wave
-      // turns the 32 totals into 1/max(|u|, eps) with one v_rsq per lane and hands them out through LDS.
-      float* red = smem + 2 * STAGE;                   // [32 rows][4 waves]
-      float* inv = red + 128 + wid * 32;               // per wave [32 rows]
-      float tot = row16_sum_transpose(ss);
-      tot += __shfl_xor(tot, 16, 64);
-      TR(11);
-      if ((lane & 16) == 0) {
-        const int r = lane & 15;
-        red[((r & 3) + 8 * (r >> 2) + 4 * h) * 4 + wid] = tot;
-      }
-      __syncthreads();
-      TR(12);
-      if (lane < 32) {
-        const float4 p = *reinterpret_cast<const float4*>(red + lane * 4);
-        const float rs = fminf(__builtin_amdgcn_rsqf((p.x + p.y) + (p.z + p.w)), 1.0f / NORM_EPS);
-        inv[lane] = rs;
-        if (g.rinv && wid == 0 && (m0 + lane) < g.rows) g.rinv[m0 + lane] = rs;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 v = *reinterpret_cast<const float4*>(inv + 8 * q + 4 * h);
-        scale[4 * q] = v.x; scale[4 * q + 1] = v.y; scale[4 * q + 2] = v.z; scale[4 * q + 3] = v.w;
-      }
-    }
-  }
-  const bool full = panel_full;                        // uniform: no per-element predicates on the common path
-#pragma unroll
-  for (int t = 0; t < TPW; ++t) {
-    const int tile = wid + 4 * t;
-    if (tile < NT) {
-      const int cn = tile * 32 + i;
-      float* cp = g.c + (m0 + 4 * h) * g.ldc + cn;
-      if (full) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) cp[(int64_t)((r & 3) + 8 * (r >> 2)) * g.ldc] = acc[t][r] * scale[r];
-      } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t gm = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          if (gm < g.rows && cn < g.N) cp[(int64_t)((r & 3) + 8 * (r >> 2)) * g.ldc] = acc[t][r] * scale[r];
-        }
-      }
-    }
-  }
-  TR(13);
-  TR_END();
+  rowgemm_body<NT, TRANS_B, GATHER>(g, smem, blockIdx.x);
 }
 
 template <int NT, bool TRANS_B, bool GATHER>
 void launch_rowgemm(const RowGemmArgs& g, hipStream_t s) {
-  constexpr int NP = 32 * NT;
-  const size_t lds = sizeof(float) * (2 * (32 * LDA_S + (TRANS_B ? NP * LDA_S : KC * NP)) + 128 + 4 * 32 + (GATHER ? 32 * LDA_F : 0));
+  const size_t lds = rowgemm_lds_bytes<NT, TRANS_B, GATHER>();
   rowgemm_kernel<NT, TRANS_B, GATHER><<<(unsigned)(ceil_div64(g.rows, 32) + (g.fill_rows > 0 ? 1 : 0)), 256, lds, s>>>(g);
 }
 

@@ -106,6 +106,16 @@ def gemm_tn_splitk(Z, K_in, dU, out=None):
     return out
 
 
+def wgrad_plan(rows, K_in, N, ldz, lddu):
+    """(nslab, rows_per_slab, workspace floats) of the weight-gradient slab kernel; nslab = 0: shape unsupported."""
+    nslab = np.zeros(1, dtype=np.int32)
+    rps = np.zeros(1, dtype=np.int64)
+    need = np.zeros(1, dtype=np.int64)
+    nat.call_nostream("linear_wgrad_plan", int(rows), int(K_in), int(N), int(ldz), int(lddu), nslab.ctypes.data, rps.ctypes.data,
+                      need.ctypes.data)
+    return int(nslab[0]), int(rps[0]), int(need[0])
+
+
 def linear_wgrad_slabs(z, K_in, du, bias_only_rows=0):
     """slab partials of (dW, db) without the reduction; returns (ws, nslab) or None when the shape is unsupported.
     The last ``bias_only_rows`` rows of du feed db only (ghost rows: their z is zero)."""

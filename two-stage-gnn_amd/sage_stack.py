@@ -52,6 +52,7 @@ def _aggregate_raw(g, x, transposed=False, rows=None):
 
 import os
 
+MERGED_BWD = os.environ.get("TSGNN_MERGED_BWD", "1") != "0"        # weight-gradient slabs + input-gradient product in one launch
 GATHER_FUSED = os.environ.get("TSGNN_GATHER_FUSED", "1") != "0"     # aggregate inside the `.W` product when the neighbour table has no CSR tail
 
 
@@ -177,6 +178,26 @@ class _SageStack(torch.autograd.Function):
                      mean, rstd, rinv, du, du.stride(0))
             want_w = ctx.needs_input_grad[3 + 2 * l]
             want_b = ctx.has_bias and ctx.needs_input_grad[4 + 2 * l]
+            merged = False
+            if (MERGED_BWD and want_w and lean and l > 0 and K == 128 and N == 128 and g.symmetric and z.size(1) == K
+                    and _gather_ok(g, du) and z.data_ptr() % 16 == 0 and du.data_ptr() % 16 == 0 and W.data_ptr() % 16 == 0
+                    and W.stride(0) % 4 == 0):
+                nslab, rps, need = mp.wgrad_plan(g.n_rows, K, N, z.stride(0), du.stride(0))
+                if 0 < nslab < 512:
+                    # weight-gradient slabs and dX = (A dU) W^T side by side in one launch (both only need dU)
+                    ell, ell_w, _ = g.ell()
+                    ws = torch.empty(need, dtype=torch.float32, device=dev)
+                    dxs = torch.empty(R, K, dtype=torch.float32, device=dev)
+                    nat.call("sage_layer_bwd_f32", ell, ell_w, du, du.stride(0), W, W.stride(0), dxs, dxs.stride(0), z, z.stride(0),
+                             g.n_rows, nslab, rps, sg, ws)
+                    dw, sw = mp._sink_or_new(ctx.params[2 * l], (K, N), dev)
+                    db, sb = mp._sink_or_new(ctx.params[2 * l + 1], (N,), dev) if want_b else (None, False)
+                    pending.append((ws, nslab, K, N, dw, db))
+                    grads[2 * l], grads[2 * l + 1] = (None if sw else dw), (None if sb else db)
+                    keep.append(du)
+                    merged = True
+            if merged:
+                continue
             if OVERLAP:
                 side.wait_stream(main)                      # du ready
             with torch.cuda.stream(side):                   # weight/bias gradients are off the dX critical path
