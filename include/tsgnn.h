@@ -158,6 +158,12 @@ int tsgnn_rowgemm_f32(const float* a, int64_t lda, const float* b, int64_t ldb, 
 int tsgnn_gather_rowgemm_f32(const int* ell, int ell_w, const float* x, int64_t ldx, const float* b, int64_t ldb, int trans_b,
                              const float* bias, float* c, int64_t ldc, float* rinv, float* zout, int64_t ldz, int64_t rows, int K,
                              int N, int normalize, int64_t fill_rows, tsgnn_stream_t stream);
+/* Forward of a hidden 128 -> 128 GraphConv layer in ONE launch together with the max-readout partial of its INPUT x (the
+ * previous layer's output; both only read x): tsgnn_gather_rowgemm_f32(normalize = 1, fill_rows) + tsgnn_readout_partial_f32
+ * over x into packed[B*128] (layout and ghost-row rule as there; n_real = rows). */
+int tsgnn_sage_layer_fwd_f32(const int* ell, int ell_w, const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias,
+                             float* v, int64_t ldv, float* rinv, float* zout, int64_t ldz, int64_t rows, int K, int64_t fill_rows,
+                             const int* graph_ptr, int B, int nslots, int n_ghost, unsigned long long* packed, tsgnn_stream_t stream);
 /* Backward of a hidden 128 -> 128 GraphConv layer's GEMM-shaped halves in ONE launch (both consume du): the weight / bias
  * gradient slabs of tsgnn_linear_wgrad_f32 (dw == NULL form: reduce ws later with tsgnn_wgrad_reduce_multi_f32; plan with
  * tsgnn_linear_wgrad_plan(rows, 128, 128, ...)) and dxs = (A du) w^T of tsgnn_gather_rowgemm_f32 (trans_b = 1, symmetric A).

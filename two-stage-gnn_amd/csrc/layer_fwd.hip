@@ -1,0 +1,52 @@
+// One launch for a hidden GraphConv layer's forward product and the max-readout partial of its INPUT (both only read x,
+// the previous layer's output):
+//
+//   v = normalise((A x) W + b), z = A x            (rowgemm_body GATHER, rowgemm.hip; ghost rows by the filler block)
+//   packed[b, f] = max over the slots of graph b   (readout_partial_body, sage_fused.hip)
+//
+// The readout blocks are short and ride along on the CUs that each host one latency-bound row-panel block.
+#include "common.h"
+#include "../../include/tsgnn.h"
+#include "rowgemm_body.h"
+#include "readout_body.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void sage_layer_fwd_kernel(RowGemmArgs ga, SlotArgs sa, unsigned n_gemm, unsigned ro_gx, int F4,
+                                                             unsigned long long* __restrict__ packed) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (blockIdx.x < n_gemm) {
+    rowgemm_body<4, false, true>(ga, smem, blockIdx.x);
+  } else {
+    const unsigned r = blockIdx.x - n_gemm;
+    readout_partial_body<32>(sa, ga.a, ga.lda, F4, packed, r % ro_gx, r / ro_gx, reinterpret_cast<unsigned long long*>(smem));
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int tsgnn_sage_layer_fwd_f32(const int* ell, int ell_w, const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias,
+                             float* v, int64_t ldv, float* rinv, float* zout, int64_t ldz, int64_t rows, int K, int64_t fill_rows,
+                             const int* graph_ptr, int B, int nslots, int n_ghost, unsigned long long* packed, tsgnn_stream_t stream) {
+  if (!ell || !x || !w || !v || !rinv || !graph_ptr || !packed || rows <= 0 || fill_rows < 0 || K <= 0 || B <= 0 || nslots <= 0 ||
+      (n_ghost != 0 && n_ghost != nslots))
+    return TSGNN_EINVAL;
+  if (ell_w != 4 && ell_w != 8 && ell_w != 16) return TSGNN_EUNSUPPORTED;
+  const uintptr_t al = reinterpret_cast<uintptr_t>(ell) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w) |
+                       reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(zout) | reinterpret_cast<uintptr_t>(bias);
+  if ((al & 15) || K != 128 || (ldx % 4) || (ldw % 4) || (ldv % 4) || (zout && (ldz % 4 || ldz < K)) || ldx < K || ldw < 128 || ldv < 128)
+    return TSGNN_EUNSUPPORTED;            /* x is also read as the [rows, 128] readout operand: hidden layers only */
+  RowGemmArgs ga{x, ldx, w, ldw, bias, v, ldv, rinv, rows, K, 128, 1, fill_rows, ell, ell_w, zout, ldz};
+  SlotArgs sa{graph_ptr, nullptr, B, nslots, rows, n_ghost};
+  const unsigned n_gemm = (unsigned)ceil_div64(rows, 32) + (fill_rows > 0 ? 1u : 0u);
+  const unsigned ro_gx = (unsigned)((nslots + 63) / 64);
+  size_t lds = rowgemm_lds_bytes<4, false, true>();
+  if (lds < 8 * 128 * sizeof(unsigned long long)) lds = 8 * 128 * sizeof(unsigned long long);
+  sage_layer_fwd_kernel<<<n_gemm + ro_gx * (unsigned)B, 256, lds, stream>>>(ga, sa, n_gemm, ro_gx, K / 4, packed);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,53 @@
+// Body of the per-layer max-readout partial kernel (see sage_fused.hip), as a device function so that it can share a
+// launch with the next layer's product (layer_fwd.hip).
+#pragma once
+#include "common.h"
+
+namespace {
+
+struct SlotArgs {
+  const int* graph_ptr;
+  const int* slot_count;
+  int B, nmax;
+  int64_t n_real;
+  int n_ghost;
+};
+
+// ---------------------------------------------------------------------------------------------- readout
+__device__ __forceinline__ unsigned long long pack_max(float val, unsigned r) {
+  return ((unsigned long long)f32_ordered(val) << 32) | (unsigned long long)(0xFFFFFFFFu - r);
+}
+// grid (ceil(nslots/64), B); block = (256/G) row lanes x G float4 lanes (G = 32: F <= 128)
+template <int G>
+__device__ __forceinline__ void readout_partial_body(const SlotArgs& s, const float* __restrict__ x, int64_t ld, int F4,
+                                                     unsigned long long* __restrict__ packed, unsigned bx, unsigned by,
+                                                     unsigned long long* best_mem /* [256/G][4*G] */) {
+  constexpr int RL = 256 / G;
+  unsigned long long (*best)[4 * G] = reinterpret_cast<unsigned long long (*)[4 * G]>(best_mem);
+  const int b = (int)by;
+  const int c4 = threadIdx.x % G, rl = threadIdx.x / G;
+  const int g0 = s.graph_ptr[b], sz = s.graph_ptr[b + 1] - g0;
+  const int nslots = s.n_ghost ? s.nmax : sz;
+  const int n_lo = (int)bx * 64, n_hi = min(nslots, n_lo + 64);
+  unsigned long long m0 = 0ull, m1 = 0ull, m2 = 0ull, m3 = 0ull;
+  if (c4 < F4) {
+    for (int n = n_lo + rl; n < n_hi; n += RL) {
+      const int64_t r = n < sz ? (int64_t)g0 + n : s.n_real + n;
+      const float4 t = *reinterpret_cast<const float4*>(x + r * ld + 4 * c4);
+      const unsigned long long p0 = pack_max(t.x, (unsigned)r), p1 = pack_max(t.y, (unsigned)r), p2 = pack_max(t.z, (unsigned)r),
+                               p3 = pack_max(t.w, (unsigned)r);
+      m0 = p0 > m0 ? p0 : m0; m1 = p1 > m1 ? p1 : m1; m2 = p2 > m2 ? p2 : m2; m3 = p3 > m3 ? p3 : m3;
+    }
+  }
+  best[rl][4 * c4 + 0] = m0; best[rl][4 * c4 + 1] = m1; best[rl][4 * c4 + 2] = m2; best[rl][4 * c4 + 3] = m3;
+  __syncthreads();
+  const int F = 4 * F4;
+  for (int f = threadIdx.x; f < F; f += 256) {
+    unsigned long long m = best[0][f];
+#pragma unroll
+    for (int w = 1; w < RL; ++w) { const unsigned long long o = best[w][f]; m = o > m ? o : m; }
+    if (m) atomicMax(&packed[(int64_t)b * F + f], m);
+  }
+}
+
+}  // namespace

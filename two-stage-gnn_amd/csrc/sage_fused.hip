@@ -12,18 +12,12 @@
 // reference's multiplicities fall out of the per-graph loop with no special weights.
 #include "common.h"
 #include "../../include/tsgnn.h"
+#include "readout_body.h"
 
 namespace {
 
 constexpr float BN_EPS = 1e-5f;
 
-struct SlotArgs {
-  const int* graph_ptr;
-  const int* slot_count;
-  int B, nmax;
-  int64_t n_real;
-  int n_ghost;
-};
 
 __device__ __forceinline__ void block_sum2(float& a, float& b, float* lds /*8*/) {
   a = wave_sum(a); b = wave_sum(b);
@@ -279,39 +273,12 @@ __global__ __launch_bounds__(256) void slot_post_bwd(SlotArgs s, const float* __
 }
 
 // ---------------------------------------------------------------------------------------------- readout
-__device__ __forceinline__ unsigned long long pack_max(float val, unsigned r) {
-  return ((unsigned long long)f32_ordered(val) << 32) | (unsigned long long)(0xFFFFFFFFu - r);
-}
-// grid (ceil(nslots/64), B); block = (256/G) row lanes x G float4 lanes (G = 32: F <= 128)
+// grid (ceil(nslots/64), B); block = (256/G) row lanes x G float4 lanes (G = 32: F <= 128); body in readout_body.h
 template <int G>
 __global__ __launch_bounds__(256) void readout_partial4(SlotArgs s, const float* __restrict__ x, int64_t ld, int F4,
                                                         unsigned long long* __restrict__ packed) {
-  constexpr int RL = 256 / G;
-  __shared__ unsigned long long best[RL][4 * G];
-  const int b = blockIdx.y;
-  const int c4 = threadIdx.x % G, rl = threadIdx.x / G;
-  const int g0 = s.graph_ptr[b], sz = s.graph_ptr[b + 1] - g0;
-  const int nslots = s.n_ghost ? s.nmax : sz;
-  const int n_lo = blockIdx.x * 64, n_hi = min(nslots, n_lo + 64);
-  unsigned long long m0 = 0ull, m1 = 0ull, m2 = 0ull, m3 = 0ull;
-  if (c4 < F4) {
-    for (int n = n_lo + rl; n < n_hi; n += RL) {
-      const int64_t r = n < sz ? (int64_t)g0 + n : s.n_real + n;
-      const float4 t = ld4(x + r * ld + 4 * c4);
-      const unsigned long long p0 = pack_max(t.x, (unsigned)r), p1 = pack_max(t.y, (unsigned)r), p2 = pack_max(t.z, (unsigned)r),
-                               p3 = pack_max(t.w, (unsigned)r);
-      m0 = p0 > m0 ? p0 : m0; m1 = p1 > m1 ? p1 : m1; m2 = p2 > m2 ? p2 : m2; m3 = p3 > m3 ? p3 : m3;
-    }
-  }
-  best[rl][4 * c4 + 0] = m0; best[rl][4 * c4 + 1] = m1; best[rl][4 * c4 + 2] = m2; best[rl][4 * c4 + 3] = m3;
-  __syncthreads();
-  const int F = 4 * F4;
-  for (int f = threadIdx.x; f < F; f += 256) {
-    unsigned long long m = best[0][f];
-#pragma unroll
-    for (int w = 1; w < RL; ++w) { const unsigned long long o = best[w][f]; m = o > m ? o : m; }
-    if (m) atomicMax(&packed[(int64_t)b * F + f], m);
-  }
+  __shared__ unsigned long long best[256 / G][4 * G];
+  readout_partial_body<G>(s, x, ld, F4, packed, blockIdx.x, blockIdx.y, &best[0][0]);
 }
 // packed: layers 0..L-2 hold B*Fh entries each, the last layer B*Fl; out[b, off_l + f]; arg in the packed layout
 __global__ void readout_decode_layers(const unsigned long long* __restrict__ packed, int B, int L, int Fh, int Fl,

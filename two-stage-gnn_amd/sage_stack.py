@@ -52,6 +52,7 @@ def _aggregate_raw(g, x, transposed=False, rows=None):
 
 import os
 
+MERGED_FWD = os.environ.get("TSGNN_MERGED_FWD", "1") != "0"        # a layer's product + the readout partial of its input in one launch
 MERGED_BWD = os.environ.get("TSGNN_MERGED_BWD", "1") != "0"        # weight-gradient slabs + input-gradient product in one launch
 GATHER_FUSED = os.environ.get("TSGNN_GATHER_FUSED", "1") != "0"     # aggregate inside the `.W` product when the neighbour table has no CSR tail
 
@@ -60,6 +61,12 @@ def _gather_ok(g, x):
     if not GATHER_FUSED or g.val is not None or not mp.ell_ok(x) or g.total_rows > mp.ELL_MAX_ROWS:
         return False
     return g.ell()[2] is None
+
+
+def _flush_readout(g, B, sn, sg, pending):
+    if pending is not None:
+        y, pk = pending
+        nat.call("readout_partial_f32", g.graph_ptr, B, sn, g.n_rows, sg, y, y.stride(0), y.size(1), pk)
 
 
 class _SageStack(torch.autograd.Function):
@@ -86,6 +93,7 @@ class _SageStack(torch.autograd.Function):
         sn, sg = (gs, gs) if g.n_ghost else (g.nmax, 0)      # (slots, ghost rows) handed to the slot kernels
         saved = []
         off = 0
+        pending_ro = None
         main = torch.cuda.current_stream()
         side = _side_stream(dev) if OVERLAP else main
         keep = []
@@ -99,13 +107,26 @@ class _SageStack(torch.autograd.Function):
             # their z is neither produced nor read (255 row panels + 1 filler = one block per CU on the DD batch).
             lean = (g.n_ghost > 0 and x.stride(0) % 4 == 0 and N % 4 == 0 and Ws[l].data_ptr() % 16 == 0
                     and (bs[l] is None or bs[l].data_ptr() % 16 == 0))
-            if lean and N <= 128 and _gather_ok(g, x) and mp.rowgemm_ok(x, x.stride(0), Ws[l], Ws[l].stride(0), K, N, False):
+            fused = lean and N <= 128 and _gather_ok(g, x) and mp.rowgemm_ok(x, x.stride(0), Ws[l], Ws[l].stride(0), K, N, False)
+            if (fused and MERGED_FWD and pending_ro is not None and K == 128 and N == 128 and x.size(1) == 128
+                    and Ws[l].stride(0) % 4 == 0):
+                # this layer's product and the max-readout partial of its input (the previous layer's output) in one launch
+                ell, ell_w, _ = g.ell()
+                z = torch.empty(R, x.size(1), dtype=torch.float32, device=dev)
+                nat.call("sage_layer_fwd_f32", ell, ell_w, x, x.stride(0), Ws[l], Ws[l].stride(0), bs[l], v, v.stride(0), rinv,
+                         z, z.stride(0), g.n_rows, K, gs, g.graph_ptr, B, sn, sg, pending_ro[1])
+                pending_ro = None
+            elif fused:
+                _flush_readout(g, B, sn, sg, pending_ro)
+                pending_ro = None
                 # aggregation fused into the product: the neighbour rows are summed while the A panel is staged
                 ell, ell_w, _ = g.ell()
                 z = torch.empty(R, x.size(1), dtype=torch.float32, device=dev)
                 nat.call("gather_rowgemm_f32", ell, ell_w, x, x.stride(0), Ws[l], Ws[l].stride(0), 0, bs[l], v, v.stride(0), rinv,
                          z, z.stride(0), g.n_rows, K, N, 1, gs)
             else:
+                _flush_readout(g, B, sn, sg, pending_ro)
+                pending_ro = None
                 z = _aggregate_raw(g, x, rows=g.n_rows if lean else None)
                 if lean and mp.rowgemm_ok(z, z.stride(0), Ws[l], Ws[l].stride(0), K, N, False):
                     nat.call("rowgemm_f32", z, z.stride(0), Ws[l], Ws[l].stride(0), 0, bs[l], v, v.stride(0), rinv, g.n_rows, K, N, 1,
@@ -127,10 +148,7 @@ class _SageStack(torch.autograd.Function):
                 y = torch.empty_like(v)
                 nat.call("slot_bn_fwd_f32", g.graph_ptr, g.slot_count, B, sn, g.n_rows, sg, v, v.stride(0), N, 1,
                          mean, rstd, y, y.stride(0), packed if l == 0 else None, total)
-                if OVERLAP:
-                    side.wait_stream(main)
-                with torch.cuda.stream(side):               # the next layer only needs y: readout runs beside it
-                    nat.call("readout_partial_f32", g.graph_ptr, B, sn, g.n_rows, sg, y, y.stride(0), N, pk)
+                pending_ro = (y, pk)                        # rides along with the next layer's product (or is flushed before it)
                 keep.append(y)
                 x = y
             else:
