@@ -77,6 +77,12 @@ __global__ __launch_bounds__(256) void clip_adam_coop(float* __restrict__ p, con
     s = fmaf(gv[c], gv[c], s);
   }
   const float step = state[0] + 1.f;                   // read before anyone can have updated it (block 0 does, after the barrier)
+  float pv[CV], mv[CV], vv[CV];                        // the update's operands travel while the blocks meet
+#pragma unroll
+  for (int c = 0; c < CV; ++c) {
+    const bool ok = (base + c) < n;
+    pv[c] = ok ? p[base + c] : 0.f; mv[c] = ok ? m[base + c] : 0.f; vv[c] = ok ? v[base + c] : 0.f;
+  }
   s = wave_sum(s);
   if ((tid & 63) == 0) lds[tid >> 6] = s;
   __syncthreads();
@@ -87,7 +93,7 @@ __global__ __launch_bounds__(256) void clip_adam_coop(float* __restrict__ p, con
     int ok = 0;
     for (int spin = 0; spin < (1 << 20); ++spin) {
       if (__hip_atomic_load(sync, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = 1; break; }
-      __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_s_sleep(1);
     }
     ok_s = ok;
   }
@@ -113,12 +119,12 @@ __global__ __launch_bounds__(256) void clip_adam_coop(float* __restrict__ p, con
     const int64_t i = base + c;
     if (i < n) {
       float gi = gv[c] * scale;
-      if (wd != 0.f) gi = fmaf(wd, p[i], gi);
-      const float mi = fmaf(b1, m[i], (1.f - b1) * gi);
-      const float vi = fmaf(b2, v[i], (1.f - b2) * gi * gi);
+      if (wd != 0.f) gi = fmaf(wd, pv[c], gi);
+      const float mi = fmaf(b1, mv[c], (1.f - b1) * gi);
+      const float vi = fmaf(b2, vv[c], (1.f - b2) * gi * gi);
       m[i] = mi; v[i] = vi;
       const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
-      p[i] -= (lr / bc1) * (mi / denom);
+      p[i] = pv[c] - (lr / bc1) * (mi / denom);
     }
   }
 }
