@@ -321,6 +321,14 @@ int tsgnn_readout_decode_layers_f32(const unsigned long long* packed, int B, int
  * or map_model -> map2_model; encoders.py:207-217).  W1 [E,P], W2 [C,E] as nn.Linear stores them.  P % 4 == 0. */
 int tsgnn_head2_fwd_f32(const float* out, int64_t ldo, const float* w1, const float* b1, const float* w2, const float* b2, int B, int P,
                         int E, int C, float* vec, float* y, tsgnn_stream_t stream);
+/* Tail of the GraphSage stack in ONE launch (block b = graph b): decode layers 0..L-2 of the packed max readout (layout of
+ * tsgnn_readout_partial_f32 / tsgnn_readout_decode_layers_f32), take the last layer's max readout by scanning graph b's rows
+ * of v_last directly (its first ghost row stands for all of them: the last layer has no slot batch-norm), write
+ * out[B, (L-1)*Fh + Fl] and arg, then the head vec = W1 out + b1, y = W2 vec + b2 (encoders.py:183-217). */
+int tsgnn_readout_head_fwd_f32(const unsigned long long* packed, int B, int L, int Fh, int Fl, const float* v_last, int64_t ldv,
+                               const int* graph_ptr, int64_t n_real, int nslots, int n_ghost, float* out, int64_t ldo, int* arg,
+                               const float* w1, const float* b1, const float* w2, const float* b2, int E, int C, float* vec, float* y,
+                               tsgnn_stream_t stream);
 /* backward in one launch: dvt = dvec (nullable) + W2^T dy (internal) ; dout = W1^T dvt ; dW1 = dvt^T out ; db1 ; dW2 = dy^T vec ; db2 */
 int tsgnn_head2_bwd_f32(const float* out, int64_t ldo, const float* vec, const float* dy, const float* dvec, const float* w1,
                         const float* w2, int B, int P, int E, int C, float* dout, int64_t lddo, float* dw1, float* db1,

@@ -4,6 +4,7 @@
 // Shapes are tiny (B <= a few hundred rows): one workgroup per graph row, weights streamed from L2 with 16-byte loads.
 #include "common.h"
 #include "../../include/tsgnn.h"
+#include "readout_body.h"
 
 namespace {
 
@@ -12,18 +13,13 @@ __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast
 // block b: vec[b,:] = W1 out[b,:] + b1 ; y[b,:] = W2 vec[b,:] + b2        (W1 [E,P], W2 [C,E] row-major = nn.Linear.weight)
 constexpr int HW = 16;   // waves per row block (1024 threads): one batch of 8 weight rows per wave covers E = 128
 
-__global__ __launch_bounds__(64 * HW) void head2_fwd_kernel(const float* __restrict__ out, int64_t ldo, const float* __restrict__ w1,
-                                                        const float* __restrict__ b1, const float* __restrict__ w2,
-                                                        const float* __restrict__ b2, int P, int E, int C,
-                                                        float* __restrict__ vec, float* __restrict__ y) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* xs = smem;                 // [P]
-  float* vs = smem + ((P + 3) & ~3);  // [E]
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  for (int k = tid; k < P; k += 64 * HW) xs[k] = out[(int64_t)b * ldo + k];
-  __syncthreads();
+// shared tail: xs[P] (the readout row of graph b) is in LDS; vec[b,:] = W1 xs + b1 ; y[b,:] = W2 vec[b,:] + b2
+__device__ __forceinline__ void head2_fwd_tail(const float* xs, float* vs, int b, const float* __restrict__ w1,
+                                               const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
+                                               int P, int E, int C, float* __restrict__ vec, float* __restrict__ y) {
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int P4 = P >> 2;
-  // each wave owns rows j = wid, wid+4, ...; eight rows are in flight per iteration (independent 16-byte loads),
+  // each wave owns rows j = wid, wid+16, ...; eight rows are in flight per iteration (independent 16-byte loads),
   // their dot products are reduced together
   for (int j0 = wid; j0 < E; j0 += 8 * HW) {
     float acc[8];
@@ -54,6 +50,90 @@ __global__ __launch_bounds__(64 * HW) void head2_fwd_kernel(const float* __restr
     acc = wave_sum(acc);
     if (lane == 0) y[(int64_t)b * C + c] = acc + (b2 ? b2[c] : 0.f);
   }
+}
+
+__global__ __launch_bounds__(64 * HW) void head2_fwd_kernel(const float* __restrict__ out, int64_t ldo, const float* __restrict__ w1,
+                                                        const float* __restrict__ b1, const float* __restrict__ w2,
+                                                        const float* __restrict__ b2, int P, int E, int C,
+                                                        float* __restrict__ vec, float* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* xs = smem;                 // [P]
+  float* vs = smem + ((P + 3) & ~3);  // [E]
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int k = tid; k < P; k += 64 * HW) xs[k] = out[(int64_t)b * ldo + k];
+  __syncthreads();
+  head2_fwd_tail(xs, vs, b, w1, b1, w2, b2, P, E, C, vec, y);
+}
+
+// The GraphSage stack's tail in ONE launch: block b finishes graph b's concatenated max readout and runs the head on it.
+//   layers 0 .. L-2 : decode the packed (value, ~row) maxima the per-layer partial kernels accumulated;
+//   last layer      : scan graph b's rows of v_last directly (32 row lanes x 32 float4 lanes; first ghost row = all ghost
+//                     rows of the un-normalised last layer) - no partial launch, no atomics for that layer;
+//   then vec = W1 out + b1, y = W2 vec + b2.   out[b, :] and arg (winning rows, packed-layout order) are kept for backward.
+struct ReadoutHeadArgs {
+  const unsigned long long* packed; int B, L, Fh, Fl;
+  const float* v_last; int64_t ldv;
+  const int* graph_ptr; int64_t n_real; int nslots; int n_ghost;
+  float* out; int64_t ldo; int* arg;
+};
+__global__ __launch_bounds__(64 * HW) void readout_head_fwd_kernel(ReadoutHeadArgs a, const float* __restrict__ w1,
+                                                               const float* __restrict__ b1, const float* __restrict__ w2,
+                                                               const float* __restrict__ b2, int P, int E, int C,
+                                                               float* __restrict__ vec, float* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* xs = smem;                                                   // [P]
+  float* vs = smem + ((P + 3) & ~3);                                  // [E]
+  unsigned long long* best = reinterpret_cast<unsigned long long*>(smem + ((P + 3) & ~3) + ((E + 3) & ~3));   // [32][Fl]
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int PH = (a.L - 1) * a.Fh;
+  for (int k = tid; k < PH; k += 64 * HW) {
+    const int l = k / a.Fh, f = k % a.Fh;
+    const int64_t i = (int64_t)l * a.B * a.Fh + (int64_t)b * a.Fh + f;
+    const unsigned long long p = a.packed[i];
+    const float val = p ? ordered_f32((unsigned)(p >> 32)) : 0.f;
+    xs[k] = val;
+    a.out[(int64_t)b * a.ldo + k] = val;
+    a.arg[i] = p ? (int)(0xFFFFFFFFu - (unsigned)(p & 0xFFFFFFFFull)) : -1;
+  }
+  {
+    const int c4 = tid & 31, rl = tid >> 5, F4 = a.Fl >> 2;
+    const int g0 = a.graph_ptr[b], sz = a.graph_ptr[b + 1] - g0;
+    unsigned long long m0 = 0ull, m1 = 0ull, m2 = 0ull, m3 = 0ull;
+    if (c4 < F4) {
+      const int nrows = sz + ((a.n_ghost && sz < a.nslots) ? 1 : 0);   // + the first ghost row (the others equal it)
+      // four rows in flight per lane (independent 16-byte loads), maxima folded afterwards
+      for (int n0 = rl; n0 < nrows; n0 += 8 * HW) {
+        float4 t[4];
+        int64_t r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int n = n0 + 2 * HW * u;
+          r[u] = n < sz ? (int64_t)g0 + n : a.n_real + n;
+          t[u] = n < nrows ? ld4(a.v_last + r[u] * a.ldv + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (n0 + 2 * HW * u < nrows) {
+            const unsigned long long p0 = pack_max(t[u].x, (unsigned)r[u]), p1 = pack_max(t[u].y, (unsigned)r[u]),
+                                     p2 = pack_max(t[u].z, (unsigned)r[u]), p3 = pack_max(t[u].w, (unsigned)r[u]);
+            m0 = p0 > m0 ? p0 : m0; m1 = p1 > m1 ? p1 : m1; m2 = p2 > m2 ? p2 : m2; m3 = p3 > m3 ? p3 : m3;
+          }
+        }
+      }
+      best[rl * a.Fl + 4 * c4 + 0] = m0; best[rl * a.Fl + 4 * c4 + 1] = m1; best[rl * a.Fl + 4 * c4 + 2] = m2; best[rl * a.Fl + 4 * c4 + 3] = m3;
+    }
+    __syncthreads();
+    for (int f = tid; f < a.Fl; f += 64 * HW) {
+      unsigned long long m = best[f];
+      for (int w = 1; w < 2 * HW; ++w) { const unsigned long long o = best[w * a.Fl + f]; m = o > m ? o : m; }
+      const float val = m ? ordered_f32((unsigned)(m >> 32)) : 0.f;
+      xs[PH + f] = val;
+      a.out[(int64_t)b * a.ldo + PH + f] = val;
+      a.arg[(int64_t)(a.L - 1) * a.B * a.Fh + (int64_t)b * a.Fl + f] = m ? (int)(0xFFFFFFFFu - (unsigned)(m & 0xFFFFFFFFull)) : -1;
+    }
+  }
+  __syncthreads();
+  head2_fwd_tail(xs, vs, b, w1, b1, w2, b2, P, E, C, vec, y);
 }
 
 // Backward in ONE launch.  Blocks [0, B): block b computes dvt[b,:] = dvec[b,:] + W2^T dy[b,:] and dout[b,:] = W1^T dvt[b,:].
@@ -172,6 +252,24 @@ int tsgnn_head2_fwd_f32(const float* out, int64_t ldo, const float* w1, const fl
   if ((P % 4) || P > 4096 || E > 4096 || (reinterpret_cast<uintptr_t>(w1) & 15)) return TSGNN_EUNSUPPORTED;
   const size_t lds = sizeof(float) * (size_t)(((P + 3) & ~3) + E);
   head2_fwd_kernel<<<B, 64 * HW, lds, stream>>>(out, ldo, w1, b1, w2, b2, P, E, C, vec, y);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+int tsgnn_readout_head_fwd_f32(const unsigned long long* packed, int B, int L, int Fh, int Fl, const float* v_last, int64_t ldv,
+                               const int* graph_ptr, int64_t n_real, int nslots, int n_ghost, float* out, int64_t ldo, int* arg,
+                               const float* w1, const float* b1, const float* w2, const float* b2, int E, int C, float* vec, float* y,
+                               tsgnn_stream_t stream) {
+  if (!packed || !v_last || !graph_ptr || !out || !arg || !w1 || !w2 || !vec || !y || B <= 0 || L <= 0 || Fh <= 0 || Fl <= 0 ||
+      E <= 0 || C <= 0 || nslots <= 0 || (n_ghost != 0 && n_ghost != nslots))
+    return TSGNN_EINVAL;
+  const int P = (L - 1) * Fh + Fl;
+  if ((P % 4) || P > 4096 || E > 4096 || (Fl % 4) || Fl > 128 || (ldv % 4) || ldo < P || (reinterpret_cast<uintptr_t>(w1) & 15) ||
+      (reinterpret_cast<uintptr_t>(v_last) & 15))
+    return TSGNN_EUNSUPPORTED;
+  ReadoutHeadArgs a{packed, B, L, Fh, Fl, v_last, ldv, graph_ptr, n_real, nslots, n_ghost, out, ldo, arg};
+  const size_t lds = sizeof(float) * (size_t)(((P + 3) & ~3) + ((E + 3) & ~3)) + sizeof(unsigned long long) * (size_t)(2 * HW) * Fl;
+  readout_head_fwd_kernel<<<B, 64 * HW, lds, stream>>>(a, w1, b1, w2, b2, P, E, C, vec, y);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }

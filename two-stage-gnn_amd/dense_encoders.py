@@ -262,8 +262,23 @@ class GcnEncoderGraph(nn.Module):
             return vec, self.pred_model(vec)
         return output, self.map_model(output)     # 2stg
 
+    def _stack_fusable(self, x, g):
+        from . import sage_stack
+        convs = [self.conv_first] + list(self.conv_block) + [self.conv_last]
+        ok = (self.concat and FUSED_STACK and not self.per_graph_bn and sage_stack.eligible(g, convs, self.bn, x)
+              and bool(mp.nat.lib().tsgnn_slot_fused_supported(g.B, convs[0].output_dim))
+              and bool(mp.nat.lib().tsgnn_slot_fused_supported(g.B, convs[-1].output_dim)))
+        return ok, convs
+
     def forward(self, x, adj, batch_num_nodes=None, **kwargs):
         x, g = self.make_batch(x, adj, batch_num_nodes)
+        if FUSED_HEAD and type(self) is GcnEncoderGraph and self.final_dim != "output_dim":
+            from . import sage_stack
+            ok, convs = self._stack_fusable(x, g)
+            lin1, lin2 = (self.map_model, self.map2_model) if self.final_dim == "pretrain" else (self.pre_pred_model, self.pred_model)
+            if ok and sage_stack.head_ok(g, convs, lin1, lin2):
+                vec, y = sage_stack.sage_stack_head(x, g, convs, lin1, lin2)       # stack + readout tail + head: one autograd node
+                return (y, vec) if self.final_dim == "pretrain" else (vec, y)
         return self._heads(self.readouts_rows(x, g))
 
     def loss(self, pred, label, type="softmax"):

@@ -52,6 +52,7 @@ def _aggregate_raw(g, x, transposed=False, rows=None):
 
 import os
 
+FUSED_TAIL = os.environ.get("TSGNN_FUSED_TAIL", "1") != "0"        # last readout + decode + the two Linear layers in one launch
 MERGED_FWD = os.environ.get("TSGNN_MERGED_FWD", "1") != "0"        # a layer's product + the readout partial of its input in one launch
 MERGED_BWD = os.environ.get("TSGNN_MERGED_BWD", "1") != "0"        # weight-gradient slabs + input-gradient product in one launch
 GATHER_FUSED = os.environ.get("TSGNN_GATHER_FUSED", "1") != "0"     # aggregate inside the `.W` product when the neighbour table has no CSR tail
@@ -70,8 +71,14 @@ def _flush_readout(g, B, sn, sg, pending):
 
 
 class _SageStack(torch.autograd.Function):
+    """forward(x0, g, has_bias, n_head, *conv params[, w1, b1, w2, b2]).  n_head = 0: returns the concatenated readout
+    [B, P].  n_head = 4: the two chained nn.Linear after the readout (encoders.py:207-217) are part of the node: the last
+    layer's readout, the decode of the earlier layers and the head run as ONE launch and (vec, y) are returned."""
+
     @staticmethod
-    def forward(ctx, x0, g, has_bias, *params):
+    def forward(ctx, x0, g, has_bias, n_head, *params):
+        head = params[len(params) - n_head:] if n_head else None
+        params = params[:len(params) - n_head] if n_head else params
         L = len(params) // 2
         Ws = [params[2 * l].contiguous() for l in range(L)]
         bs = [params[2 * l + 1] if has_bias else None for l in range(L)]
@@ -155,26 +162,59 @@ class _SageStack(torch.autograd.Function):
                 mean = rstd = None
                 if OVERLAP:
                     main.wait_stream(side)                  # join: all partials done before the decode
-                nat.call("readout_partial_f32", g.graph_ptr, B, sn, g.n_rows, sg, v, v.stride(0), N, pk)
+                if head is None:
+                    nat.call("readout_partial_f32", g.graph_ptr, B, sn, g.n_rows, sg, v, v.stride(0), N, pk)
             saved.append((z, v, rinv, mean, rstd, lean))
             off += B * N
         out = torch.empty(B, (L - 1) * Fh + Fl, dtype=torch.float32, device=dev)
         arg = torch.empty(total, dtype=torch.int32, device=dev)
-        nat.call("readout_decode_layers_f32", packed, B, L, Fh, Fl, out, out.stride(0), arg)
         ctx.g, ctx.L, ctx.has_bias, ctx.dims = g, L, has_bias, (Fh, Fl)
         ctx.slots = (sn, sg)
         ctx.Ws, ctx.saved, ctx.arg = Ws, saved, arg
         ctx.params = params
         ctx.x0_ld = x.size(1) if L == 0 else x0.size(1)
-        return out
+        ctx.head = None
+        if head is None:
+            nat.call("readout_decode_layers_f32", packed, B, L, Fh, Fl, out, out.stride(0), arg)
+            return out
+        # last layer's readout (straight from its rows) + decode of the earlier layers + both Linear layers: one launch
+        w1, b1, w2, b2 = head
+        w1c, w2c = w1.contiguous(), w2.contiguous()
+        E, C = w1c.size(0), w2c.size(0)
+        vec = torch.empty(B, E, dtype=torch.float32, device=dev)
+        y = torch.empty(B, C, dtype=torch.float32, device=dev)
+        v_last = saved[-1][1]
+        nat.call("readout_head_fwd_f32", packed, B, L, Fh, Fl, v_last, v_last.stride(0), g.graph_ptr, g.n_rows, sn, sg, out,
+                 out.stride(0), arg, w1c, b1, w2c, b2, E, C, vec, y)
+        ctx.head = (out, vec, w1c, w2c, head)
+        ctx.set_materialize_grads(False)
+        return vec, y
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, *gouts):
         g, L = ctx.g, ctx.L
         Fh, Fl = ctx.dims
-        dout = dout.contiguous()
-        dev = dout.device
         R, B = g.total_rows, g.B
+        head_grads = ()
+        if ctx.head is None:
+            dout = gouts[0].contiguous()
+            dev = dout.device
+        else:
+            out, vec, w1c, w2c, (pw1, pb1, pw2, pb2) = ctx.head
+            dvec, dy = gouts
+            dev = out.device
+            P, E, C = out.size(1), w1c.size(0), w2c.size(0)
+            if dy is None and dvec is None:
+                return (None,) * (4 + 2 * L + 4)
+            dy = dy.contiguous() if dy is not None else torch.zeros(B, C, device=dev)
+            dvec = dvec.contiguous() if dvec is not None else None
+            dout = torch.empty(B, P, dtype=torch.float32, device=dev)
+            dw1, s1 = mp._sink_or_new(pw1, (E, P), dev)
+            dw2, s2 = mp._sink_or_new(pw2, (C, E), dev)
+            db1, s3 = mp._sink_or_new(pb1, (E,), dev) if pb1 is not None else (None, False)
+            db2, s4 = mp._sink_or_new(pb2, (C,), dev) if pb2 is not None else (None, False)
+            nat.call("head2_bwd_f32", out, out.stride(0), vec, dy, dvec, w1c, w2c, B, P, E, C, dout, dout.stride(0), dw1, db1, dw2, db2)
+            head_grads = (None if s1 else dw1, None if s3 else db1, None if s2 else dw2, None if s4 else db2)
         sn, sg = ctx.slots
         grads = [None] * (2 * L)
         dxs = None
@@ -194,8 +234,8 @@ class _SageStack(torch.autograd.Function):
             nat.call("slot_post_bwd_f32", g.graph_ptr, g.slot_count, B, sn, g.n_rows, sg, v, v.stride(0), dxs,
                      dxs.stride(0) if dxs is not None else 0, dsl, dout.stride(0), argl, N, 0 if last else 1, 0 if last else 1,
                      mean, rstd, rinv, du, du.stride(0))
-            want_w = ctx.needs_input_grad[3 + 2 * l]
-            want_b = ctx.has_bias and ctx.needs_input_grad[4 + 2 * l]
+            want_w = ctx.needs_input_grad[4 + 2 * l]
+            want_b = ctx.has_bias and ctx.needs_input_grad[5 + 2 * l]
             merged = False
             if (MERGED_BWD and want_w and lean and l > 0 and K == 128 and N == 128 and g.symmetric and z.size(1) == K
                     and _gather_ok(g, du) and z.data_ptr() % 16 == 0 and du.data_ptr() % 16 == 0 and W.data_ptr() % 16 == 0
@@ -266,7 +306,7 @@ class _SageStack(torch.autograd.Function):
         if OVERLAP:
             main.wait_stream(side)                          # join before the gradients are consumed
         del keep
-        return (dx0, None, None) + tuple(grads)
+        return (dx0, None, None, None) + tuple(grads) + head_grads
 
 
 def sage_stack_readouts(x, g, convs):
@@ -276,4 +316,23 @@ def sage_stack_readouts(x, g, convs):
     for c in convs:
         params.append(c.weight)
         params.append(c.bias if has_bias else c.weight.new_zeros(1))
-    return _SageStack.apply(x, g, has_bias, *params)
+    return _SageStack.apply(x, g, has_bias, 0, *params)
+
+
+def head_ok(g, convs, lin1, lin2):
+    """the fused readout + head tail covers these shapes (else: sage_stack_readouts + message_passing.head2)"""
+    P = sum(c.output_dim for c in convs)
+    Fl = convs[-1].output_dim
+    return (FUSED_TAIL and isinstance(lin1, torch.nn.Linear) and isinstance(lin2, torch.nn.Linear) and P % 4 == 0 and P <= 2048
+            and Fl % 4 == 0 and Fl <= 128 and lin1.out_features <= 4096 and g.B <= 1024 and lin1.in_features == P
+            and lin1.weight.data_ptr() % 16 == 0)
+
+
+def sage_stack_head(x, g, convs, lin1, lin2):
+    """(lin1(readout), lin2(lin1(readout))) with the readout tail and the head fused into the stack node."""
+    has_bias = convs[0].bias is not None
+    params = []
+    for c in convs:
+        params.append(c.weight)
+        params.append(c.bias if has_bias else c.weight.new_zeros(1))
+    return _SageStack.apply(x, g, has_bias, 4, *params, lin1.weight, lin1.bias, lin2.weight, lin2.bias)
