@@ -300,3 +300,80 @@ def test_triplet_batched_equals_three_b1_forwards(kind):
             continue
         err = (p.grad.cpu() - ref).abs().max().item()
         assert err <= 5e-3 * ref.abs().max().item() + 1e-6, (k, err, ref.abs().max().item())
+
+
+# ----------------------------------------------------------------------------- fused GraphSage stack: launch-fusion variants
+def _stack_run(B, nmax, sizes, fin, hid, p_edge, flags, seed=5):
+    from two_stage_gnn_amd import dense_encoders as E, sage_stack as S
+    x, adj, sizes = dense_batch(seed, B, nmax, fin, sizes=sizes, p_edge=p_edge)
+
+    class A:
+        bias = True
+    torch.manual_seed(1)
+    m = E.GcnEncoderGraph(fin, hid, hid, 2, 3, bn=True, args=A(), final_dim="number_classes")
+    with torch.no_grad():
+        for k, p in m.named_parameters():
+            if k.endswith("bias") and "conv" in k:
+                p.copy_(torch.randn_like(p) * 0.2)
+    m = m.cuda()
+    old = {k: getattr(S, k) for k in flags}
+    try:
+        for k, v in flags.items():
+            setattr(S, k, v)
+        a, b = m(x.cuda(), adj.cuda(), sizes)
+        label = (torch.arange(B) % 2).cuda()
+        m.loss(b, label).backward()
+    finally:
+        for k, v in old.items():
+            setattr(S, k, v)
+    grads = {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters() if p.grad is not None}
+    return a.detach().cpu(), b.detach().cpu(), grads, (m, x, adj, sizes)
+
+
+ALL_ON = dict(GATHER_FUSED=True, MERGED_FWD=True, MERGED_BWD=True, FUSED_TAIL=True)
+
+
+@pytest.mark.parametrize("off", ["GATHER_FUSED", "MERGED_FWD", "MERGED_BWD", "FUSED_TAIL"])
+def test_stack_fusion_variants_agree(off):
+    """every launch fusion of the GraphSage stack (aggregation inside the product, product + readout partial, slabs + dX,
+    readout tail + head) gives the results of the launch sequence it replaces"""
+    sizes = dd_like_sizes(3, 6, nbar=70, nmax=150).tolist()
+    ref = _stack_run(6, 150, sizes, 89, 128, 0.06, ALL_ON)
+    alt = _stack_run(6, 150, sizes, 89, 128, 0.06, dict(ALL_ON, **{off: False}))
+    torch.testing.assert_close(alt[0], ref[0], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(alt[1], ref[1], rtol=1e-5, atol=1e-5)
+    assert alt[2].keys() == ref[2].keys()
+    for k in ref[2]:
+        scale = ref[2][k].abs().max().item() + 1e-12
+        assert (alt[2][k] - ref[2][k]).abs().max().item() <= 2e-4 * scale, k
+
+
+@pytest.mark.parametrize("case", ["full_graph", "equal_sizes", "single_graph", "high_degree"])
+def test_stack_edge_shapes_vs_oracle(case):
+    """shapes that steer the fused stack onto its other branches: a graph that fills every slot (no ghost slot can be
+    dropped), equal sizes, one graph, neighbour lists longer than the fixed-width table (CSR tail: no fused gather)"""
+    from two_stage_gnn_amd.graph import GraphBatch
+    if case == "full_graph":
+        B, nmax, sizes, p = 5, 96, [96, 40, 61, 17, 80], 0.08
+    elif case == "equal_sizes":
+        B, nmax, sizes, p = 4, 120, [50, 50, 50, 50], 0.1
+    elif case == "single_graph":
+        B, nmax, sizes, p = 1, 200, [137], 0.05
+    else:
+        B, nmax, sizes, p = 3, 100, [90, 75, 60], 0.35
+    a, b, grads, (m, x, adj, sizes_np) = _stack_run(B, nmax, sizes, 89, 128, p, ALL_ON, seed=9)
+    if case == "high_degree":
+        g = GraphBatch.from_dense(adj.cuda(), sizes=sizes_np, layout="packed")
+        g.val = None
+        assert g.ell()[2] is not None                     # the CSR tail exists: fallback branches are the ones tested
+    p_ref = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    a_ref, b_ref = R.gcn_encoder(p_ref, x, adj, bn=True, final_dim="number_classes")
+    torch.nn.functional.cross_entropy(b_ref, torch.arange(B) % 2).backward()
+    torch.testing.assert_close(a, a_ref.detach(), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(b, b_ref.detach(), rtol=1e-4, atol=1e-4)
+    for k, gr in grads.items():
+        ref = p_ref[k].grad
+        if ref is None:
+            continue
+        assert (gr - ref).abs().max().item() <= 2e-3 * ref.abs().max().item() + 1e-7, k
+        assert ((gr - ref).norm() / (ref.norm() + 1e-12)).item() < 1e-3, k
