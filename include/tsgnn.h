@@ -117,11 +117,13 @@ int tsgnn_linear_wgrad_plan(int64_t rows, int K_in, int N, int64_t ldz, int64_t 
 int tsgnn_linear_wgrad_f32(const float* z, int64_t ldz, const float* du, int64_t lddu, int64_t rows, int K_in, int N, int nslab,
                            int64_t rows_per_slab, int64_t bias_only_rows, float* ws, float* dw, float* db, tsgnn_stream_t stream);
 /* dw == NULL above leaves the slabs in ws; this reduces up to four such slab sets (all layers of one backward pass) in ONE
- * launch.  Unused sets: ws == NULL. */
+ * launch.  Unused sets: ws == NULL.  normparts (nullable): block k of the launch (sum over sets of ceil((K+1)*N/64) blocks)
+ * stores the sum of squares of the gradient entries it wrote; step_state (nullable): step_state[0] += 1 (both feed
+ * tsgnn_adam_from_partials_f32). */
 int tsgnn_wgrad_reduce_multi_f32(const float* ws0, int nslab0, int K0, int N0, float* dw0, float* db0, const float* ws1, int nslab1,
                                  int K1, int N1, float* dw1, float* db1, const float* ws2, int nslab2, int K2, int N2, float* dw2,
                                  float* db2, const float* ws3, int nslab3, int K3, int N3, float* dw3, float* db3,
-                                 tsgnn_stream_t stream);
+                                 float* normparts, float* step_state, tsgnn_stream_t stream);
 /* Ragged batched out[b][K,N] = s[rows_b,:K]^T . x[rows_b,:N] — DiffPool's S^T Z and S^T (A S) (encoders.py:374-375) over
  * the row ranges of the graphs: graph b owns slabs [seg_slab_ptr[b], seg_slab_ptr[b+1]); slab t covers rows
  * [slab_row_ptr[t], slab_row_ptr[t+1]).  ws >= nslab*(K+1)*N floats.  ceil(K/32)*ceil(N/32) <= 16. */
@@ -220,6 +222,12 @@ int tsgnn_unpack_rows_bwd_ghost_f32(const int* graph_ptr, int B, int nmax, int64
  * (model.loss -> F.cross_entropy, encoders.py:221-224; labels int64 as the reference passes them). */
 int tsgnn_softmax_ce_f32(const float* logits, int64_t ld, const int64_t* label, int B, int C, float* loss, float* dlogits,
                          tsgnn_stream_t stream);
+/* Same optimiser step when the gradient producers already left shares of |grad|^2 in parts[0..nparts) (normparts of
+ * tsgnn_wgrad_reduce_multi_f32 / tsgnn_head2_bwd_f32) and advanced state[0]: one launch, no device-wide barrier.  Single GPU
+ * only (after an all-reduce the local shares no longer describe the gradient). */
+int tsgnn_adam_from_partials_f32(float* param, const float* grad, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                                 float eps, float weight_decay, float max_norm, float* state, const float* parts, int nparts,
+                                 tsgnn_stream_t stream);
 /* clip_grad_norm(max_norm) + Adam.step() of the reference loop (train.py:128-129) on one flat fp32
  * parameter / gradient buffer (the buffer RCCL all-reduces): grad is first scaled by grad_scale
  * (1/world_size).  state: 4 floats {step, grad_norm, applied scale, barrier-timeout flag} (zeroed before the first
@@ -329,10 +337,11 @@ int tsgnn_readout_head_fwd_f32(const unsigned long long* packed, int B, int L, i
                                const int* graph_ptr, int64_t n_real, int nslots, int n_ghost, float* out, int64_t ldo, int* arg,
                                const float* w1, const float* b1, const float* w2, const float* b2, int E, int C, float* vec, float* y,
                                tsgnn_stream_t stream);
-/* backward in one launch: dvt = dvec (nullable) + W2^T dy (internal) ; dout = W1^T dvt ; dW1 = dvt^T out ; db1 ; dW2 = dy^T vec ; db2 */
+/* backward in one launch: dvt = dvec (nullable) + W2^T dy (internal) ; dout = W1^T dvt ; dW1 = dvt^T out ; db1 ; dW2 = dy^T vec ; db2.
+ * normparts (nullable, ceil(E/4) + 1 floats): per weight block, the sum of squares of the gradient entries it wrote. */
 int tsgnn_head2_bwd_f32(const float* out, int64_t ldo, const float* vec, const float* dy, const float* dvec, const float* w1,
                         const float* w2, int B, int P, int E, int C, float* dout, int64_t lddo, float* dw1, float* db1,
-                        float* dw2, float* db2, tsgnn_stream_t stream);
+                        float* dw2, float* db2, float* normparts, tsgnn_stream_t stream);
 
 #ifdef __cplusplus
 }

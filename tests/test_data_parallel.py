@@ -256,3 +256,36 @@ def test_direct_gradient_placement_equals_concatenated_bucket():
         torch.testing.assert_close(a, b, rtol=0, atol=0)
     torch.testing.assert_close(results[0][1], results[1][1], rtol=0, atol=0)
     assert float(results[1][0][0].abs().sum()) > 0
+
+
+@pytest.mark.gpu
+def test_barrier_free_optimiser_equals_three_stage_path():
+    """all gradients produced in place with their |grad|^2 shares -> tsgnn_adam_from_partials_f32; must match the generic
+    norm -> clip -> Adam path (direct_grads=False) step for step"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from two_stage_gnn_amd import dense_encoders as E, synthetic
+    from two_stage_gnn_amd.data_parallel import FlatTrainer
+
+    class A:
+        bias = True
+    dev = torch.device("cuda")
+    hb = synthetic.host_batch(seed=4, B=8, shape="DD", nmax=500)
+    g, x, label = synthetic.to_device(hb, dev)
+    finals = []
+    for direct in (False, True):
+        torch.manual_seed(3)
+        model = E.GcnEncoderGraph(89, 128, 128, 2, 3, bn=True, args=A(), final_dim="number_classes").to(dev)
+        tr = FlatTrainer(model, lr=1e-2, clip=0.05, direct_grads=direct)        # a clip that bites: the norm matters
+        for it in range(4):
+            tr.zero_grad()
+            loss = model.loss(model(x, g)[1], label)
+            tr.backward(loss) if direct else loss.backward()
+            tr.gather_grads()
+            if direct:
+                assert tr._norm_ready, "expected the barrier-free path on a fully fused model"
+            tr.apply()
+        finals.append((tr.flat_param.clone(), tr.state.clone()))
+    assert float(finals[0][1][0]) == 4.0 and float(finals[1][1][0]) == 4.0
+    torch.testing.assert_close(finals[1][1][1], finals[0][1][1], rtol=1e-5, atol=0)          # gradient norm of the last step
+    torch.testing.assert_close(finals[1][0], finals[0][0], rtol=1e-4, atol=1e-6)

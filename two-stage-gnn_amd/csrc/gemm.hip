@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void tn_rows_reduce(const float* __restrict__ 
 
 
 struct ReduceSet { const float* slabs; int nslab; int64_t per_slab; int64_t n_w; float* dw; float* db; int64_t first_block; };
-struct ReduceMulti { ReduceSet s[4]; int n; };
+struct ReduceMulti { ReduceSet s[4]; int n; float* normparts; float* step_state; };
 // several independent slab sets (the layers of one backward pass) reduced by ONE launch
 __global__ __launch_bounds__(256) void tn_rows_reduce_multi(ReduceMulti m) {
   __shared__ float lds[4][64];
@@ -203,10 +203,18 @@ __global__ __launch_bounds__(256) void tn_rows_reduce_multi(ReduceMulti m) {
   }
   lds[grp][e_l] = (a0 + a1) + (a2 + a3);
   __syncthreads();
-  if (grp == 0 && e < r.per_slab) {
-    const float v = (lds[0][e_l] + lds[1][e_l]) + (lds[2][e_l] + lds[3][e_l]);
-    if (e < r.n_w) r.dw[e] = v;
-    else if (r.db) r.db[e - r.n_w] = v;
+  if (grp == 0) {                                        // wave 0: one element per lane
+    float sq = 0.f;
+    if (e < r.per_slab) {
+      const float v = (lds[0][e_l] + lds[1][e_l]) + (lds[2][e_l] + lds[3][e_l]);
+      if (e < r.n_w) { r.dw[e] = v; sq = v * v; }
+      else if (r.db) { r.db[e - r.n_w] = v; sq = v * v; }
+    }
+    if (m.normparts) {                                   // this block's share of |grad|^2 (summed in fixed order by the optimiser)
+      sq = wave_sum(sq);
+      if (e_l == 0) m.normparts[blockIdx.x] = sq;
+    }
+    if (m.step_state && blockIdx.x == 0 && e_l == 0) m.step_state[0] += 1.f;   // optimiser step counter, ahead of the update kernel
   }
 }
 
@@ -294,7 +302,7 @@ int tsgnn_linear_wgrad_plan(int64_t rows, int K_in, int N, int64_t ldz, int64_t 
 int tsgnn_wgrad_reduce_multi_f32(const float* ws0, int nslab0, int K0, int N0, float* dw0, float* db0, const float* ws1, int nslab1,
                                  int K1, int N1, float* dw1, float* db1, const float* ws2, int nslab2, int K2, int N2, float* dw2,
                                  float* db2, const float* ws3, int nslab3, int K3, int N3, float* dw3, float* db3,
-                                 tsgnn_stream_t stream) {
+                                 float* normparts, float* step_state, tsgnn_stream_t stream) {
   const float* ws[4] = {ws0, ws1, ws2, ws3};
   const int ns[4] = {nslab0, nslab1, nslab2, nslab3}, Ks[4] = {K0, K1, K2, K3}, Ns[4] = {N0, N1, N2, N3};
   float* dws[4] = {dw0, dw1, dw2, dw3};
@@ -312,6 +320,8 @@ int tsgnn_wgrad_reduce_multi_f32(const float* ws0, int nslab0, int K0, int N0, f
   }
   if (m.n == 0) return TSGNN_OK;
   for (int t = m.n; t < 4; ++t) m.s[t] = m.s[0];
+  m.normparts = normparts;
+  m.step_state = step_state;
   tn_rows_reduce_multi<<<(unsigned)blocks, 256, 0, stream>>>(m);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;

@@ -185,9 +185,10 @@ __device__ __forceinline__ void head2_bwd_weights(float* smem /* [B][4] dvt slic
                                                   const float* __restrict__ vec, const float* __restrict__ dy,
                                                   const float* __restrict__ dvec, const float* __restrict__ w2, int B, int P, int E,
                                                   int C, float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dw2,
-                                                  float* __restrict__ db2) {
+                                                  float* __restrict__ db2, float* __restrict__ normparts) {
   const int tid = threadIdx.x, NTH = 64 * HW;
   const int nj = (E + 3) / 4;
+  float sq = 0.f;                                        // |gradient written by this thread|^2
   if (jb < nj) {
     const int j0 = 4 * jb;
     for (int i = tid; i < B * 4; i += NTH) {
@@ -207,15 +208,16 @@ __device__ __forceinline__ void head2_bwd_weights(float* smem /* [B][4] dvt slic
         a0 = fmaf(smem[4 * bb + 0], x, a0); a1 = fmaf(smem[4 * bb + 1], x, a1);
         a2 = fmaf(smem[4 * bb + 2], x, a2); a3 = fmaf(smem[4 * bb + 3], x, a3);
       }
-      if (j0 + 0 < E) dw1[(int64_t)(j0 + 0) * P + k] = a0;
-      if (j0 + 1 < E) dw1[(int64_t)(j0 + 1) * P + k] = a1;
-      if (j0 + 2 < E) dw1[(int64_t)(j0 + 2) * P + k] = a2;
-      if (j0 + 3 < E) dw1[(int64_t)(j0 + 3) * P + k] = a3;
+      if (j0 + 0 < E) { dw1[(int64_t)(j0 + 0) * P + k] = a0; sq = fmaf(a0, a0, sq); }
+      if (j0 + 1 < E) { dw1[(int64_t)(j0 + 1) * P + k] = a1; sq = fmaf(a1, a1, sq); }
+      if (j0 + 2 < E) { dw1[(int64_t)(j0 + 2) * P + k] = a2; sq = fmaf(a2, a2, sq); }
+      if (j0 + 3 < E) { dw1[(int64_t)(j0 + 3) * P + k] = a3; sq = fmaf(a3, a3, sq); }
     }
     if (db1 && tid < 4 && j0 + tid < E) {
       float a = 0.f;
       for (int bb = 0; bb < B; ++bb) a += smem[4 * bb + tid];
       db1[j0 + tid] = a;
+      sq = fmaf(a, a, sq);
     }
   } else {
     for (int i = tid; i < C * E; i += NTH) {
@@ -223,11 +225,24 @@ __device__ __forceinline__ void head2_bwd_weights(float* smem /* [B][4] dvt slic
       float a = 0.f;
       for (int bb = 0; bb < B; ++bb) a = fmaf(dy[(int64_t)bb * C + c], vec[(int64_t)bb * E + j], a);
       dw2[i] = a;
+      sq = fmaf(a, a, sq);
     }
     if (db2) for (int c = tid; c < C; c += NTH) {
       float a = 0.f;
       for (int bb = 0; bb < B; ++bb) a += dy[(int64_t)bb * C + c];
       db2[c] = a;
+      sq = fmaf(a, a, sq);
+    }
+  }
+  if (normparts) {                                       // block total in a fixed order: waves through LDS
+    sq = wave_sum(sq);
+    __syncthreads();
+    if ((tid & 63) == 0) smem[tid >> 6] = sq;
+    __syncthreads();
+    if (tid == 0) {
+      float t = 0.f;
+      for (int w = 0; w < HW; ++w) t += smem[w];
+      normparts[jb] = t;
     }
   }
 }
@@ -236,10 +251,11 @@ __global__ __launch_bounds__(64 * HW) void head2_bwd_kernel(const float* __restr
                                                         const float* __restrict__ dy, const float* __restrict__ dvec,
                                                         const float* __restrict__ w1, const float* __restrict__ w2, int B, int P, int E,
                                                         int C, float* __restrict__ dout, int64_t lddo, float* __restrict__ dw1,
-                                                        float* __restrict__ db1, float* __restrict__ dw2, float* __restrict__ db2) {
+                                                        float* __restrict__ db1, float* __restrict__ dw2, float* __restrict__ db2,
+                                                        float* __restrict__ normparts) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if ((int)blockIdx.x < B) head2_bwd_rows(smem, blockIdx.x, dy, dvec, w1, w2, P, E, C, dout, lddo);
-  else head2_bwd_weights(smem, (int)blockIdx.x - B, out, ldo, vec, dy, dvec, w2, B, P, E, C, dw1, db1, dw2, db2);
+  else head2_bwd_weights(smem, (int)blockIdx.x - B, out, ldo, vec, dy, dvec, w2, B, P, E, C, dw1, db1, dw2, db2, normparts);
 }
 
 }  // namespace
@@ -276,13 +292,13 @@ int tsgnn_readout_head_fwd_f32(const unsigned long long* packed, int B, int L, i
 
 int tsgnn_head2_bwd_f32(const float* out, int64_t ldo, const float* vec, const float* dy, const float* dvec, const float* w1,
                         const float* w2, int B, int P, int E, int C, float* dout, int64_t lddo, float* dw1, float* db1,
-                        float* dw2, float* db2, tsgnn_stream_t stream) {
+                        float* dw2, float* db2, float* normparts, tsgnn_stream_t stream) {
   if (!out || !vec || !dy || !w1 || !w2 || !dout || !dw1 || !dw2 || B <= 0 || P <= 0 || E <= 0 || C <= 0) return TSGNN_EINVAL;
   if ((P % 4) || P > 2048 || E > 4096 || B > 1024 || (reinterpret_cast<uintptr_t>(w1) & 15)) return TSGNN_EUNSUPPORTED;
   size_t lds = sizeof(float) * (size_t)(((E + 3) & ~3) + HW * ((P + 3) & ~3));
-  if (lds < sizeof(float) * 4 * (size_t)B) lds = sizeof(float) * 4 * (size_t)B;
+  if (lds < sizeof(float) * (4 * (size_t)B + HW)) lds = sizeof(float) * (4 * (size_t)B + HW);
   head2_bwd_kernel<<<B + (E + 3) / 4 + 1, 64 * HW, lds, stream>>>(out, ldo, vec, dy, dvec, w1, w2, B, P, E, C, dout, lddo, dw1, db1, dw2,
-                                                                db2);
+                                                                db2, normparts);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }

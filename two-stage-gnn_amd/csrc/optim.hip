@@ -130,6 +130,49 @@ __global__ __launch_bounds__(256) void clip_adam_coop(float* __restrict__ p, con
 }
 
 
+// Barrier-free variant for a single GPU: the kernels that PRODUCE the gradients (tn_rows_reduce_multi, head2_bwd) already
+// left their share of |grad|^2 in parts[0..nparts) and bumped the step counter, so every block can finish the norm itself
+// (same fixed-order sum everywhere) and go straight to the update.
+__global__ __launch_bounds__(256) void adam_from_partials(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                          float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
+                                                          float wd, float max_norm, float* __restrict__ state,
+                                                          const float* __restrict__ parts, int nparts) {
+  __shared__ float lds[4];
+  const int tid = threadIdx.x;
+  const int64_t base = ((int64_t)blockIdx.x * 256 + tid) * CV;
+  float gv[CV], pv[CV], mv[CV], vv[CV];
+#pragma unroll
+  for (int c = 0; c < CV; ++c) {
+    const bool ok = (base + c) < n;
+    gv[c] = ok ? g[base + c] : 0.f; pv[c] = ok ? p[base + c] : 0.f; mv[c] = ok ? m[base + c] : 0.f; vv[c] = ok ? v[base + c] : 0.f;
+  }
+  float t = 0.f;
+  for (int k = tid; k < nparts; k += 256) t += parts[k];
+  t = wave_sum(t);
+  if ((tid & 63) == 0) lds[tid >> 6] = t;
+  __syncthreads();
+  const float norm = sqrtf((lds[0] + lds[1]) + (lds[2] + lds[3]));
+  float coef = 1.f;
+  if (max_norm > 0.f) coef = fminf(max_norm / (norm + 1e-6f), 1.f);
+  const float step = state[0];                           // already counts this step (the gradient reduction bumped it)
+  if (blockIdx.x == 0 && tid == 0) { state[1] = norm; state[2] = coef; }
+  const float bc1 = 1.f - powf(b1, step), bc2 = 1.f - powf(b2, step);
+#pragma unroll
+  for (int c = 0; c < CV; ++c) {
+    const int64_t i = base + c;
+    if (i < n) {
+      float gi = gv[c] * coef;
+      if (wd != 0.f) gi = fmaf(wd, pv[c], gi);
+      const float mi = fmaf(b1, mv[c], (1.f - b1) * gi);
+      const float vi = fmaf(b2, vv[c], (1.f - b2) * gi * gi);
+      m[i] = mi; v[i] = vi;
+      const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+      p[i] = pv[c] - (lr / bc1) * (mi / denom);
+    }
+  }
+}
+
+
 // softmax cross-entropy (mean over rows) with its gradient in the same pass: model.loss() of the reference
 // (F.cross_entropy, encoders.py:221-224).  One thread per row (few classes), block reduction of the loss.
 __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict__ logits, int64_t ld, const int64_t* __restrict__ label,
@@ -162,6 +205,19 @@ int tsgnn_softmax_ce_f32(const float* logits, int64_t ld, const int64_t* label, 
                          tsgnn_stream_t stream) {
   if (!logits || !label || !loss || !dlogits || B <= 0 || C <= 0 || ld < C) return TSGNN_EINVAL;
   softmax_ce_kernel<<<1, 256, 0, stream>>>(logits, ld, label, B, C, loss, dlogits);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+/* Single-GPU optimiser step whose gradient norm was prepared by the gradient producers: parts[0..nparts) hold shares of
+ * |grad|^2 (tsgnn_wgrad_reduce_multi_f32 / tsgnn_head2_bwd_f32 normparts) and state[0] was already advanced by
+ * tsgnn_wgrad_reduce_multi_f32(step_state).  One launch, no device-wide barrier. */
+int tsgnn_adam_from_partials_f32(float* param, const float* grad, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                                 float eps, float weight_decay, float max_norm, float* state, const float* parts, int nparts,
+                                 tsgnn_stream_t stream) {
+  if (!param || !grad || !m || !v || !state || !parts || n <= 0 || nparts <= 0) return TSGNN_EINVAL;
+  adam_from_partials<<<(unsigned)ceil_div64(n, 256 * CV), 256, 0, stream>>>(param, grad, m, v, n, lr, beta1, beta2, eps, weight_decay,
+                                                                           max_norm, state, parts, nparts);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }

@@ -52,13 +52,18 @@ class FlatTrainer:
             self.sink = mp.GradSink()
             for p, (o, n) in zip(self.params, self.views):
                 self.sink.views[p.data_ptr()] = self.flat_grad[o:o + n].view_as(p.data)
+            self.sink.norm_parts = torch.zeros(4096, dtype=torch.float32, device=dev)
+            self.sink.step_state = self.state
         self.always_reduce = False          # issue the collective even in a one-rank group (single-GPU rehearsal of the N > 1 path)
 
     def zero_grad(self):
         for p in self.params:
             p.grad = None
+        self._norm_ready = False
         if self.sink is not None:
             self.sink.written.clear()
+            self.sink.reset_norm()
+            self.sink.norm_enabled = self.world == 1 and not self.always_reduce     # local shares only describe a local gradient
             mp.GRAD_SINK = self.sink
 
     def backward(self, loss):
@@ -72,6 +77,10 @@ class FlatTrainer:
         if self.sink is not None:
             mp.GRAD_SINK = None
             written = self.sink.written
+            # barrier-free optimiser: every gradient of this step was written in place by a producer that also left its
+            # share of |grad|^2 and the step counter was advanced; nothing arrived through autograd; single GPU
+            self._norm_ready = (bool(written) and self.sink.stepped and written == self.sink.normed
+                                and all(p.grad is None for p in self.params) and self.world == 1 and not self.always_reduce)
         if not written:
             parts = [(p.grad.reshape(-1) if p.grad is not None else z) for p, z in zip(self.params, self._zeros)]
             torch.cat(parts, out=self.flat_grad)
@@ -102,6 +111,13 @@ class FlatTrainer:
         if not self.on_gpu:
             raise RuntimeError("FlatTrainer.apply runs the HIP optimiser kernel; parameters must live on the GPU "
                                "(no CPU fallback)")
+        if getattr(self, "_norm_ready", False):
+            nat.call("adam_from_partials_f32", self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.numel,
+                     float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd), float(self.clip),
+                     self.state, self.sink.norm_parts, int(self.sink.norm_used))
+            return
+        if self.sink is not None and self.sink.stepped:
+            self.state[0] -= 1.0                        # the gradient reduction advanced the counter for the barrier-free path
         nat.call("clip_adam_step_f32", self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.numel,
                  float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd),
                  float(self.clip), float(scale), self.state, self.ws)

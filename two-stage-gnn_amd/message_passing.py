@@ -133,17 +133,24 @@ def linear_wgrad_slabs(z, K_in, du, bias_only_rows=0):
     return ws, int(nslab[0])
 
 
-def wgrad_reduce_multi(sets):
-    """sets: list of (ws, nslab, K, N, dw, db-or-None), at most 4 per launch."""
+def wgrad_reduce_multi(sets, norm_sink=None):
+    """sets: list of (ws, nslab, K, N, dw, db-or-None), at most 4 per launch.  norm_sink: a GradSink whose optimiser wants the
+    |grad|^2 shares of these gradients (and its step counter advanced) from this launch."""
     for i in range(0, len(sets), 4):
         args = []
+        nblk = 0
         for t in range(4):
             if i + t < len(sets):
                 ws, nslab, K, N, dw, db = sets[i + t]
                 args += [ws, int(nslab), int(K), int(N), dw, db]
+                nblk += ((K + 1) * N + 63) // 64
             else:
                 args += [None, 0, 0, 0, None, None]
-        nat.call("wgrad_reduce_multi_f32", *args)
+        parts = norm_sink.norm_slots(nblk) if norm_sink is not None else None
+        step = norm_sink.step_state if (norm_sink is not None and parts is not None and i == 0) else None
+        nat.call("wgrad_reduce_multi_f32", *args, parts, step)
+        if norm_sink is not None and parts is not None:
+            norm_sink.stepped = norm_sink.stepped or step is not None
 
 
 def linear_wgrad(z, K_in, du, want_db):
@@ -420,6 +427,23 @@ class GradSink:
     def __init__(self):
         self.views = {}             # parameter data_ptr -> view of the flat gradient buffer, shaped like the parameter
         self.written = set()
+        # optional: the producers also leave shares of |grad|^2 (and advance the step counter) for a barrier-free optimiser
+        self.norm_parts = None      # float32[capacity]
+        self.step_state = None
+        self.norm_enabled = False   # set per step by the trainer (single GPU only)
+        self.reset_norm()
+
+    def reset_norm(self):
+        self.norm_used = 0
+        self.normed = set()         # parameters whose |grad|^2 is accounted for in norm_parts[:norm_used]
+        self.stepped = False
+
+    def norm_slots(self, n):
+        if not self.norm_enabled or self.norm_parts is None or self.norm_used + n > self.norm_parts.numel():
+            return None
+        v = self.norm_parts[self.norm_used:self.norm_used + n]
+        self.norm_used += n
+        return v
 
     def take(self, param, shape):
         v = self.views.get(param.data_ptr())
@@ -513,8 +537,22 @@ class _Head2(torch.autograd.Function):
         dw2, s2 = _sink_or_new(pw2, (C, E), dev)
         db1, s3 = _sink_or_new(pb1, (E,), dev) if ctx.has_b[0] else (None, False)
         db2, s4 = _sink_or_new(pb2, (C,), dev) if ctx.has_b[1] else (None, False)
-        nat.call("head2_bwd_f32", out, out.stride(0), vec, dy, dvec, w1, w2, B, P, E, C, dout, dout.stride(0), dw1, db1, dw2, db2)
+        parts = head_norm_slots((s1, s2, s3, s4), ctx.has_b, (pw1, pb1, pw2, pb2), E)
+        nat.call("head2_bwd_f32", out, out.stride(0), vec, dy, dvec, w1, w2, B, P, E, C, dout, dout.stride(0), dw1, db1, dw2, db2, parts)
         return dout, None if s1 else dw1, None if s3 else db1, None if s2 else dw2, None if s4 else db2
+
+
+def head_norm_slots(sunk, has_b, params, E):
+    """|grad|^2 shares of the head's gradients for the installed sink's optimiser, when ALL of them went to the sink"""
+    s1, s2, s3, s4 = sunk
+    if GRAD_SINK is None or not (s1 and s2 and (s3 or not has_b[0]) and (s4 or not has_b[1])):
+        return None
+    parts = GRAD_SINK.norm_slots((E + 3) // 4 + 1)
+    if parts is not None:
+        for p_ in params:
+            if p_ is not None:
+                GRAD_SINK.normed.add(p_.data_ptr())
+    return parts
 
 
 def head2_ok(out, lin1, lin2):

@@ -213,7 +213,9 @@ class _SageStack(torch.autograd.Function):
             dw2, s2 = mp._sink_or_new(pw2, (C, E), dev)
             db1, s3 = mp._sink_or_new(pb1, (E,), dev) if pb1 is not None else (None, False)
             db2, s4 = mp._sink_or_new(pb2, (C,), dev) if pb2 is not None else (None, False)
-            nat.call("head2_bwd_f32", out, out.stride(0), vec, dy, dvec, w1c, w2c, B, P, E, C, dout, dout.stride(0), dw1, db1, dw2, db2)
+            parts = mp.head_norm_slots((s1, s2, s3, s4), (pb1 is not None, pb2 is not None), (pw1, pb1, pw2, pb2), E)
+            nat.call("head2_bwd_f32", out, out.stride(0), vec, dy, dvec, w1c, w2c, B, P, E, C, dout, dout.stride(0), dw1, db1, dw2, db2,
+                     parts)
             head_grads = (None if s1 else dw1, None if s3 else db1, None if s2 else dw2, None if s4 else db2)
         sn, sg = ctx.slots
         grads = [None] * (2 * L)
@@ -223,6 +225,7 @@ class _SageStack(torch.autograd.Function):
         side = _side_stream(dev) if OVERLAP else main
         keep = []
         pending = []
+        pend_sunk, pend_layers = [], []
         for l in range(L - 1, -1, -1):
             z, v, rinv, mean, rstd, lean = ctx.saved[l]
             W = ctx.Ws[l]
@@ -251,6 +254,7 @@ class _SageStack(torch.autograd.Function):
                     dw, sw = mp._sink_or_new(ctx.params[2 * l], (K, N), dev)
                     db, sb = mp._sink_or_new(ctx.params[2 * l + 1], (N,), dev) if want_b else (None, False)
                     pending.append((ws, nslab, K, N, dw, db))
+                    pend_sunk.append(sw and (sb or not want_b)); pend_layers.append(l)
                     grads[2 * l], grads[2 * l + 1] = (None if sw else dw), (None if sb else db)
                     keep.append(du)
                     merged = True
@@ -267,6 +271,7 @@ class _SageStack(torch.autograd.Function):
                         dw, sw = mp._sink_or_new(ctx.params[2 * l], (K, N), dev)     # straight into the flat bucket if one is installed
                         db, sb = mp._sink_or_new(ctx.params[2 * l + 1], (N,), dev) if want_b else (None, False)
                         pending.append((sl[0], sl[1], K, N, dw, db))
+                        pend_sunk.append(sw and (sb or not want_b)); pend_layers.append(l)
                         dw, db = (None if sw else dw), (None if sb else db)
                     else:
                         if lean:
@@ -302,7 +307,14 @@ class _SageStack(torch.autograd.Function):
                     dx0 = dxs
         if pending:
             with torch.cuda.stream(side):
-                mp.wgrad_reduce_multi(pending)
+                sink = mp.GRAD_SINK
+                all_sunk = sink is not None and len(pending) <= 4 and all(pend_sunk)
+                mp.wgrad_reduce_multi(pending, norm_sink=sink if all_sunk else None)
+                if all_sunk and sink.stepped:
+                    for l_ in pend_layers:
+                        sink.normed.add(ctx.params[2 * l_].data_ptr())
+                        if ctx.has_bias:
+                            sink.normed.add(ctx.params[2 * l_ + 1].data_ptr())
         if OVERLAP:
             main.wait_stream(side)                          # join before the gradients are consumed
         del keep
