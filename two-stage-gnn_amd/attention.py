@@ -32,6 +32,16 @@ def segment_wsum(x, w, H, Fh, seg_ptr, nseg, scale=1.0, mean=False, max_seg=None
     return out
 
 
+def _isolated_columns(g, rp_t, R, H):
+    """[R, H] indicator of columns without any edge; depends on the graph only, cached on it"""
+    cache = g.__dict__.setdefault("_iso_cols", {})
+    iso = cache.get(H)
+    if iso is None:
+        deg_t = rp_t[1:] - rp_t[:-1]
+        iso = cache[H] = (deg_t == 0).to(torch.float32).unsqueeze(1).expand(R, H).contiguous()
+    return iso
+
+
 class _AttentionAggregate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, a_row, a_col, g, H, slope, by_column, uniform_isolated):
@@ -62,8 +72,7 @@ class _AttentionAggregate(torch.autograd.Function):
         iso = None
         if uniform_isolated:
             # columns with no edge: softmax of an all-masked column is uniform 1/N over the N rows of the graph
-            deg_t = (rp_t[1:] - rp_t[:-1])
-            iso = (deg_t == 0).to(torch.float32).unsqueeze(1).expand(R, H).contiguous()
+            iso = _isolated_columns(g, rp_t, R, H)
             N = g.nmax
             u = segment_wsum(h, iso, H, Fh, g.graph_ptr, g.B, scale=1.0 / N, max_seg=int(g.sizes.max()))
             nat.call("broadcast_add_f32", out, out.stride(0), R, H, Fh, None, None, 0, u, u.stride(0), N, 1.0)

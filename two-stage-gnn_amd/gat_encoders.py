@@ -50,6 +50,49 @@ class DGATHead(nn.Module):
         return _gat_heads_forward([self], input, adj, concat_heads=True, elu=self.concat)
 
 
+class _CatHeadWeights(torch.autograd.Function):
+    """[W_0 | W_1 | ...] of a layer's heads.  The autograd of torch.cat hands every head a strided column slice that
+    AccumulateGrad then clones one by one; here the backward splits the fused gradient into ONE [H, Fin, Fo] buffer (a single
+    launch) and returns its contiguous per-head slices."""
+
+    @staticmethod
+    def forward(ctx, *ws):
+        ctx.shape = (len(ws), ws[0].size(0), ws[0].size(1))
+        return torch.cat(ws, dim=1) if len(ws) > 1 else ws[0].contiguous()
+
+    @staticmethod
+    def backward(ctx, dW):
+        H, Fin, Fo = ctx.shape
+        if H == 1:
+            return (dW,)
+        g = dW.reshape(Fin, H, Fo).permute(1, 0, 2).contiguous()          # one copy kernel for all heads
+        return tuple(g[h] for h in range(H))
+
+
+class _StackHeadVectors(torch.autograd.Function):
+    """a_h [2*Fo, 1] of every head -> (a_row [H, Fo], a_col [H, Fo]) (encoders_GAT.py:34-36: a1 . h_i + a2 . h_j), with a
+    backward that builds all heads' gradients in one launch."""
+
+    @staticmethod
+    def forward(ctx, *as_):
+        H, Fo = len(as_), as_[0].size(0) // 2
+        if H > 1:
+            A = torch.cat(as_, dim=1).reshape(2, Fo, H).permute(0, 2, 1).contiguous()          # [2, H, Fo]: both halves contiguous
+        else:
+            A = as_[0].reshape(2, 1, Fo)
+        ctx.shape = (H, Fo)
+        return A[0], A[1]
+
+    @staticmethod
+    def backward(ctx, da_row, da_col):
+        H, Fo = ctx.shape
+        z = None
+        if da_row is None or da_col is None:
+            z = torch.zeros(H, Fo, dtype=torch.float32, device=(da_row if da_row is not None else da_col).device)
+        G = torch.cat([da_row if da_row is not None else z, da_col if da_col is not None else z], dim=1)   # [H, 2*Fo]
+        return tuple(G[h].reshape(2 * Fo, 1) for h in range(H))
+
+
 def _gat_heads_forward(heads, x, adj, concat_heads, elu):
     """all heads of a layer in one pass: h = x0 [W_0|W_1|...], one edge-softmax / aggregation launch set."""
     g = _padded_batch(adj)
@@ -58,12 +101,13 @@ def _gat_heads_forward(heads, x, adj, concat_heads, elu):
     Fo = heads[0].output_dim
     slope = heads[0].leakyRELU_neg_input_slope
     x0 = _rows_of_graph0(x, g)                                             # [N, Fin]
-    W = torch.cat([hd.w for hd in heads], dim=1) if H > 1 else heads[0].w   # [Fin, H*Fo]
+    if x0.size(1) % 4 and not x0.requires_grad:
+        x0 = F.pad(x0, (0, 4 - x0.size(1) % 4))                            # 16-byte rows: the MFMA row-panel product applies
+    W = _CatHeadWeights.apply(*[hd.w for hd in heads])                      # [Fin, H*Fo]
     h = mp.linear_l2norm(x0, W, None, normalize=False)                      # [N, H*Fo]
     if B > 1:
         h = h.unsqueeze(0).expand(B, N, H * Fo).reshape(B * N, H * Fo)       # T4: graph 0's features everywhere
-    a_row = torch.stack([hd.a[:Fo, 0] for hd in heads])                     # a1 . h_i   (row index i)
-    a_col = torch.stack([hd.a[Fo:, 0] for hd in heads])                     # a2 . h_j   (column index j)
+    a_row, a_col = _StackHeadVectors.apply(*[hd.a for hd in heads])        # a1 . h_i (row index i), a2 . h_j (column index j)
     pre = att.attention_aggregate(h, a_row, a_col, g, H, slope, by_column=True, uniform_isolated=True)
     p = heads[0].dropout
     if p > 0 and heads[0].training:
@@ -149,7 +193,7 @@ class DGATEncoderGraph(nn.Module):
 
     def loss(self, pred, label, type="softmax"):
         if type == "softmax":
-            return F.cross_entropy(pred, label, reduction="mean")
+            return mp.cross_entropy(pred, label)
         if type == "margin":
             onehot = torch.zeros(pred.size(0), self.label_dim, dtype=torch.long, device=pred.device)
             onehot.scatter_(1, label.view(-1, 1), 1)
