@@ -134,6 +134,87 @@ __global__ __launch_bounds__(256) void spmm_heads_kernel(const int* __restrict__
   }
 }
 
+// float4 variants (Fh % 4 == 0, F = H*Fh <= 256, 16-byte rows): lane l of a row's lane group owns features 4l..4l+3 (one head,
+// since Fh % 4 == 0), G = F/4 lanes per row (64 / G rows per wave), edges in batches of 8 with independent 16-byte loads.
+template <int G>
+__global__ __launch_bounds__(256) void spmm_heads_vec4(const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                       const float* __restrict__ alpha, int H, int Fh, const float* __restrict__ x,
+                                                       int64_t ldx, int mod, float* __restrict__ y, int64_t ldy, int64_t rows, int nvec) {
+  const int lig = threadIdx.x % G;
+  const int64_t r = (int64_t)blockIdx.x * (256 / G) + threadIdx.x / G;
+  if (r >= rows) return;
+  const bool live = lig < nvec;
+  const int h = live ? (4 * lig) / Fh : 0;
+  const int64_t co = live ? 4 * lig : 0;
+  const int e0 = rowptr[r], e1 = rowptr[r + 1];
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int eb = e0; eb < e1; eb += 8) {
+    float4 v[8];
+    float a[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int e = eb + k;
+      v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      a[k] = 0.f;
+      if (e < e1) {
+        const int j = mod ? col[e] % mod : col[e];
+        v[k] = *reinterpret_cast<const float4*>(x + (int64_t)j * ldx + co);
+        a[k] = alpha[(int64_t)e * H + h];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      acc.x = fmaf(a[k], v[k].x, acc.x); acc.y = fmaf(a[k], v[k].y, acc.y);
+      acc.z = fmaf(a[k], v[k].z, acc.z); acc.w = fmaf(a[k], v[k].w, acc.w);
+    }
+  }
+  if (live) *reinterpret_cast<float4*>(y + r * ldy + co) = acc;
+}
+
+// SDDMM, float4: the Fh/4 lanes of a head reduce their partial dot products with DPP inside a 16-lane row
+// (Fh/4 in {1,2,4,8,16}); one lane per head writes dalpha[e, h]
+template <int G>
+__global__ __launch_bounds__(256) void sddmm_heads_vec4(const int* __restrict__ rowptr, const int* __restrict__ col, int H, int Fh,
+                                                        const float* __restrict__ dy, int64_t lddy, const float* __restrict__ x,
+                                                        int64_t ldx, int mod, float* __restrict__ dalpha, int64_t rows, int nvec) {
+  const int lig = threadIdx.x % G;
+  const int64_t r0 = (int64_t)blockIdx.x * (256 / G) + threadIdx.x / G;
+  const bool rok = r0 < rows;                           // whole waves stay active: the DPP reductions need every lane
+  const int64_t r = rok ? r0 : 0;
+  const bool live = lig < nvec;
+  const int lph = Fh / 4;                               // lanes per head
+  const int h = live ? lig / lph : 0;
+  const int64_t co = live ? 4 * lig : 0;
+  const int e0 = rok ? rowptr[r] : 0, e1 = rok ? rowptr[r + 1] : 0;
+  const float4 d = live ? *reinterpret_cast<const float4*>(dy + r * lddy + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+  int emax = e1 - e0;                                   // uniform trip count over the wave
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) emax = max(emax, __shfl_xor(emax, o, 64));
+  for (int eb = 0; eb < emax; eb += 4) {
+    float p[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int e = e0 + eb + k;
+      p[k] = 0.f;
+      if (e < e1 && live) {
+        const int j = mod ? col[e] % mod : col[e];
+        const float4 v = *reinterpret_cast<const float4*>(x + (int64_t)j * ldx + co);
+        p[k] = (d.x * v.x + d.y * v.y) + (d.z * v.z + d.w * v.w);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float t = p[k];
+      if (lph >= 2) t += dpp_f32<0xB1>(t);
+      if (lph >= 4) t += dpp_f32<0x4E>(t);
+      if (lph >= 8) t += dpp_f32<0x141>(t);              // row_half_mirror: with the two quad steps = all 8 lanes
+      if (lph >= 16) t += dpp_f32<0x140>(t);             // row_mirror: all 16 lanes
+      const int e = e0 + eb + k;
+      if (live && e < e1 && (lig % lph) == 0) dalpha[(int64_t)e * H + h] = t;
+    }
+  }
+}
+
 // SDDMM: dalpha[e,h] = dot(dy[r, head h], x[col[e] % mod, head h]) for every entry e of row r; one wave per row
 __global__ __launch_bounds__(256) void sddmm_heads_kernel(const int* __restrict__ rowptr, const int* __restrict__ col, int H, int Fh,
                                                           const float* __restrict__ dy, int64_t lddy, const float* __restrict__ x,
@@ -310,6 +391,15 @@ int tsgnn_csr_spmm_heads_f32(const int* rowptr, const int* col, const float* alp
   if (!rowptr || !alpha || !x || !y || rows < 0 || H <= 0 || Fh <= 0 || mod < 0 || ldx < (int64_t)H * Fh || ldy < (int64_t)H * Fh)
     return TSGNN_EINVAL;
   if (rows == 0) return TSGNN_OK;
+  const int F = H * Fh;
+  if ((Fh % 4) == 0 && F <= 256 && (ldx % 4) == 0 && (ldy % 4) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0) {
+    const int nvec = F / 4;
+    if (nvec <= 16) spmm_heads_vec4<16><<<(unsigned)ceil_div64(rows, 16), 256, 0, stream>>>(rowptr, col, alpha, H, Fh, x, ldx, mod, y, ldy, rows, nvec);
+    else if (nvec <= 32) spmm_heads_vec4<32><<<(unsigned)ceil_div64(rows, 8), 256, 0, stream>>>(rowptr, col, alpha, H, Fh, x, ldx, mod, y, ldy, rows, nvec);
+    else spmm_heads_vec4<64><<<(unsigned)ceil_div64(rows, 4), 256, 0, stream>>>(rowptr, col, alpha, H, Fh, x, ldx, mod, y, ldy, rows, nvec);
+    TSGNN_CHECK_LAUNCH();
+    return TSGNN_OK;
+  }
   const unsigned nblk = (unsigned)ceil_div64(rows, 4);
   spmm_heads_kernel<<<nblk, 256, 0, stream>>>(rowptr, col, alpha, H, Fh, x, ldx, mod, y, ldy, rows, nblk);
   TSGNN_CHECK_LAUNCH();
@@ -320,6 +410,17 @@ int tsgnn_csr_sddmm_heads_f32(const int* rowptr, const int* col, int H, int Fh, 
                               int64_t ldx, int mod, float* dalpha, int64_t rows, tsgnn_stream_t stream) {
   if (!rowptr || !dy || !x || !dalpha || rows < 0 || H <= 0 || Fh <= 0 || mod < 0) return TSGNN_EINVAL;
   if (rows == 0) return TSGNN_OK;
+  const int F = H * Fh, lph = Fh / 4;
+  if ((Fh % 4) == 0 && F <= 256 && (lph == 1 || lph == 2 || lph == 4 || lph == 8 || lph == 16) && (ldx % 4) == 0 && (lddy % 4) == 0 &&
+      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0) {
+    const int nvec = F / 4;
+    // lane groups of G lanes start at multiples of G >= 16, so a head's lanes never straddle a 16-lane DPP row
+    if (nvec <= 16) sddmm_heads_vec4<16><<<(unsigned)ceil_div64(rows, 16), 256, 0, stream>>>(rowptr, col, H, Fh, dy, lddy, x, ldx, mod, dalpha, rows, nvec);
+    else if (nvec <= 32) sddmm_heads_vec4<32><<<(unsigned)ceil_div64(rows, 8), 256, 0, stream>>>(rowptr, col, H, Fh, dy, lddy, x, ldx, mod, dalpha, rows, nvec);
+    else sddmm_heads_vec4<64><<<(unsigned)ceil_div64(rows, 4), 256, 0, stream>>>(rowptr, col, H, Fh, dy, lddy, x, ldx, mod, dalpha, rows, nvec);
+    TSGNN_CHECK_LAUNCH();
+    return TSGNN_OK;
+  }
   sddmm_heads_kernel<<<(unsigned)ceil_div64(rows, 4), 256, 0, stream>>>(rowptr, col, H, Fh, dy, lddy, x, ldx, mod, dalpha, rows);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
