@@ -107,7 +107,8 @@ def fused_layer_probe(g, feat, iters=300):
     v = torch.empty_like(x); z = torch.empty_like(x); rinv = torch.empty(R, device="cuda")
     gs = min(g.nmax, int(g.sizes.max()) + 1) if g.n_ghost else 0
     s = torch.cuda.current_stream()
-    fn = lambda: nat.call("gather_rowgemm_f32", ell, ell_w, x, feat, w, feat, 0, b, v, feat, rinv, z, feat, g.n_rows, feat, feat, 1, gs)
+    tp, tc = tail if tail is not None else (None, None)
+    fn = lambda: nat.call("gather_rowgemm_f32", ell, ell_w, tp, tc, x, feat, w, feat, 0, b, v, feat, rinv, z, feat, g.n_rows, feat, feat, 1, gs)
     for _ in range(20):
         fn()
     torch.cuda.synchronize()

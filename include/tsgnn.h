@@ -153,24 +153,25 @@ int tsgnn_rowgemm_f32(const float* a, int64_t lda, const float* b, int64_t ldb, 
 /* Aggregation fused into the product (GraphConv.forward lines encoders.py:33-40 in one launch; and its input gradient
  * dX = (A dU) W^T for a symmetric A): the A operand of tsgnn_rowgemm_f32 is replaced by
  *   z[r,:] = sum_k x[ell[r*ell_w + k], :K]      (ell = fixed-width neighbour table of tsgnn_csr_to_ell, entries < 0 skipped,
- *                                               ell_w in {4, 8, 16}; rows with a CSR tail are NOT handled here),
+ *                                               ell_w in {4, 8, 16}) + the rows' CSR tail (tail_ptr[rows+1], tail_col; both
+ *                                               NULL when no list is longer than ell_w: tsgnn_csr_tail_fill),
  * gathered chunk by chunk while it is staged for the MFMAs.  zout (nullable) receives z for rows [0, rows) (the weight
  * gradient needs it; its columns [K, roundup4(K)) get the aggregated row padding of x, which must be finite).  N <= 128;
  * everything else as tsgnn_rowgemm_f32. */
-int tsgnn_gather_rowgemm_f32(const int* ell, int ell_w, const float* x, int64_t ldx, const float* b, int64_t ldb, int trans_b,
+int tsgnn_gather_rowgemm_f32(const int* ell, int ell_w, const int* tail_ptr, const int* tail_col, const float* x, int64_t ldx, const float* b, int64_t ldb, int trans_b,
                              const float* bias, float* c, int64_t ldc, float* rinv, float* zout, int64_t ldz, int64_t rows, int K,
                              int N, int normalize, int64_t fill_rows, tsgnn_stream_t stream);
 /* Forward of a hidden 128 -> 128 GraphConv layer in ONE launch together with the max-readout partial of its INPUT x (the
  * previous layer's output; both only read x): tsgnn_gather_rowgemm_f32(normalize = 1, fill_rows) + tsgnn_readout_partial_f32
  * over x into packed[B*128] (layout and ghost-row rule as there; n_real = rows). */
-int tsgnn_sage_layer_fwd_f32(const int* ell, int ell_w, const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias,
+int tsgnn_sage_layer_fwd_f32(const int* ell, int ell_w, const int* tail_ptr, const int* tail_col, const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias,
                              float* v, int64_t ldv, float* rinv, float* zout, int64_t ldz, int64_t rows, int K, int64_t fill_rows,
                              const int* graph_ptr, int B, int nslots, int n_ghost, unsigned long long* packed, tsgnn_stream_t stream);
 /* Backward of a hidden 128 -> 128 GraphConv layer's GEMM-shaped halves in ONE launch (both consume du): the weight / bias
  * gradient slabs of tsgnn_linear_wgrad_f32 (dw == NULL form: reduce ws later with tsgnn_wgrad_reduce_multi_f32; plan with
  * tsgnn_linear_wgrad_plan(rows, 128, 128, ...)) and dxs = (A du) w^T of tsgnn_gather_rowgemm_f32 (trans_b = 1, symmetric A).
  * A CU hosts one block of each grid, so the two run side by side instead of back to back. */
-int tsgnn_sage_layer_bwd_f32(const int* ell, int ell_w, const float* du, int64_t lddu, const float* w, int64_t ldw, float* dxs,
+int tsgnn_sage_layer_bwd_f32(const int* ell, int ell_w, const int* tail_ptr, const int* tail_col, const float* du, int64_t lddu, const float* w, int64_t ldw, float* dxs,
                              int64_t lddxs, const float* z, int64_t ldz, int64_t rows, int nslab, int64_t rows_per_slab,
                              int64_t bias_only_rows, float* ws, tsgnn_stream_t stream);
 /* backward of the row normalisation: du = rinv * (dv - v (v.dv)) */

@@ -32,7 +32,7 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int trans = 0; trans < 2; ++trans) {
     auto run = [&]() {
-      if (gather) tsgnn_gather_rowgemm_f32(ell, 16, a, K, b, N, trans, trans ? nullptr : bias, c, N, trans ? nullptr : rinv,
+      if (gather) tsgnn_gather_rowgemm_f32(ell, 16, nullptr, nullptr, a, K, b, N, trans, trans ? nullptr : bias, c, N, trans ? nullptr : rinv,
                                            trans ? nullptr : zout, K, R, K, N, trans ? 0 : 1, 0, s);
       else tsgnn_rowgemm_f32(a, K, b, N, trans, trans ? nullptr : bias, c, N, trans ? nullptr : rinv, R, K, N, trans ? 0 : 1, 0, s);
     };

@@ -286,17 +286,19 @@ def test_rowgemm_fill_rows_equal_zero_input_rows(T, normalize, bias):
 
 
 @pytest.mark.parametrize("K,ld,N,trans_b,p_edge", [(128, 128, 128, False, 0.05), (89, 92, 128, False, 0.1), (128, 128, 64, False, 0.1),
-                                                    (128, 128, 128, True, 0.1), (64, 64, 128, True, 0.05)])
+                                                    (128, 128, 128, True, 0.1), (64, 64, 128, True, 0.05),
+                                                    (128, 128, 128, False, 0.4), (128, 128, 128, True, 0.4)])
 def test_gather_rowgemm_equals_aggregate_then_product(T, K, ld, N, trans_b, p_edge):
     """aggregation fused into the `.W` product (neighbour rows summed while the A panel is staged) == spmm then rowgemm,
-    incl. rows with more neighbours than the register-staged eight, a partial last panel, a padded K and ghost fill rows."""
+    incl. rows with more neighbours than the register-staged eight or than the table (CSR tail), a partial last panel, a
+    padded K and ghost fill rows."""
     mp, GB = T
     from two_stage_gnn_amd import _native as nat
     x, adj, sizes = dense_batch(77 + K + N, 6, 70, ld, p_edge=p_edge)
     g = GB.from_dense(adj.cuda(), sizes=sizes, layout="packed")
     g.val = None
     ell, W, tail = g.ell()
-    assert tail is None
+    assert (tail is not None) == (p_edge >= 0.3)          # the dense cases continue in the CSR tail (lists longer than 16)
     deg = (g.rowptr[1:] - g.rowptr[:-1])
     assert int(deg.max()) > 8 or p_edge < 0.1
     R_ = g.total_rows
@@ -321,7 +323,7 @@ def test_gather_rowgemm_equals_aggregate_then_product(T, K, ld, N, trans_b, p_ed
              0 if trans_b else 1, 0)
     v = torch.full((R_, nn_), float("nan"), device="cuda"); rinv = torch.full((R_,), float("nan"), device="cuda")
     z = torch.full((R_, ld), float("nan"), device="cuda")
-    nat.call("gather_rowgemm_f32", ell, W, xr, ld, w, w.stride(0), int(trans_b), bias, v, nn_, None if trans_b else rinv,
+    nat.call("gather_rowgemm_f32", ell, W, tail[0] if tail is not None else None, tail[1] if tail is not None else None, xr, ld, w, w.stride(0), int(trans_b), bias, v, nn_, None if trans_b else rinv,
              None if trans_b else z, ld, nreal, kk, nn_, 0 if trans_b else 1, 0 if trans_b else nghost)
     torch.cuda.synchronize()
     rows = R_ if not trans_b else nreal
@@ -329,4 +331,4 @@ def test_gather_rowgemm_equals_aggregate_then_product(T, K, ld, N, trans_b, p_ed
     if not trans_b:
         torch.testing.assert_close(rinv, rinv_ref, rtol=2e-5, atol=0)
         kp = (K + 3) // 4 * 4
-        torch.testing.assert_close(z[:nreal, :kp], z_ref[:nreal, :kp], rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(z[:nreal, :kp], z_ref[:nreal, :kp], rtol=1e-5, atol=1e-5)       # summation order differs

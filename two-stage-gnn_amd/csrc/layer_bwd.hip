@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void sage_layer_bwd_kernel(RowGemmArgs ga, TnA
 
 extern "C" {
 
-int tsgnn_sage_layer_bwd_f32(const int* ell, int ell_w, const float* du, int64_t lddu, const float* w, int64_t ldw, float* dxs,
+int tsgnn_sage_layer_bwd_f32(const int* ell, int ell_w, const int* tail_ptr, const int* tail_col, const float* du, int64_t lddu, const float* w, int64_t ldw, float* dxs,
                              int64_t lddxs, const float* z, int64_t ldz, int64_t rows, int nslab, int64_t rows_per_slab,
                              int64_t bias_only_rows, float* ws, tsgnn_stream_t stream) {
   if (!ell || !du || !w || !dxs || !z || !ws || rows <= 0 || nslab <= 0 || rows_per_slab <= 0 || bias_only_rows < 0) return TSGNN_EINVAL;
@@ -33,7 +33,8 @@ int tsgnn_sage_layer_bwd_f32(const int* ell, int ell_w, const float* du, int64_t
   if ((al & 15) || (lddu % 4) || (ldw % 4) || (lddxs % 4) || (ldz % 4) || lddu < 128 || ldw < 128 || lddxs < 128 || ldz < 128)
     return TSGNN_EUNSUPPORTED;
   // dX = (A dU) W^T : a = dU (gathered), b = W [K_in = 128, N_out = 128] used transposed, reduction over N_out
-  RowGemmArgs ga{du, lddu, w, ldw, nullptr, dxs, lddxs, nullptr, rows, 128, 128, 0, 0, ell, ell_w, nullptr, 0};
+  if ((tail_ptr == nullptr) != (tail_col == nullptr)) return TSGNN_EINVAL;
+  RowGemmArgs ga{du, lddu, w, ldw, nullptr, dxs, lddxs, nullptr, rows, 128, 128, 0, 0, ell, ell_w, nullptr, 0, tail_ptr, tail_col};
   TnArgs gt{z, ldz, du, lddu, rows, rows_per_slab, 128, 128, ws, nullptr, bias_only_rows};
   const unsigned n_tn = 2u * (unsigned)nslab, n_pan = (unsigned)ceil_div64(rows, 32);
   constexpr size_t la = rowgemm_lds_bytes<4, true, true>(), lt = tn_rows_lds_bytes<4, 4>();

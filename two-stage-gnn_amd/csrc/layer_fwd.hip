@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void sage_layer_fwd_kernel(RowGemmArgs ga, Slo
 
 extern "C" {
 
-int tsgnn_sage_layer_fwd_f32(const int* ell, int ell_w, const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias,
+int tsgnn_sage_layer_fwd_f32(const int* ell, int ell_w, const int* tail_ptr, const int* tail_col, const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias,
                              float* v, int64_t ldv, float* rinv, float* zout, int64_t ldz, int64_t rows, int K, int64_t fill_rows,
                              const int* graph_ptr, int B, int nslots, int n_ghost, unsigned long long* packed, tsgnn_stream_t stream) {
   if (!ell || !x || !w || !v || !rinv || !graph_ptr || !packed || rows <= 0 || fill_rows < 0 || K <= 0 || B <= 0 || nslots <= 0 ||
@@ -38,7 +38,8 @@ int tsgnn_sage_layer_fwd_f32(const int* ell, int ell_w, const float* x, int64_t 
                        reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(zout) | reinterpret_cast<uintptr_t>(bias);
   if ((al & 15) || K != 128 || (ldx % 4) || (ldw % 4) || (ldv % 4) || (zout && (ldz % 4 || ldz < K)) || ldx < K || ldw < 128 || ldv < 128)
     return TSGNN_EUNSUPPORTED;            /* x is also read as the [rows, 128] readout operand: hidden layers only */
-  RowGemmArgs ga{x, ldx, w, ldw, bias, v, ldv, rinv, rows, K, 128, 1, fill_rows, ell, ell_w, zout, ldz};
+  if ((tail_ptr == nullptr) != (tail_col == nullptr)) return TSGNN_EINVAL;
+  RowGemmArgs ga{x, ldx, w, ldw, bias, v, ldv, rinv, rows, K, 128, 1, fill_rows, ell, ell_w, zout, ldz, tail_ptr, tail_col};
   SlotArgs sa{graph_ptr, nullptr, B, nslots, rows, n_ghost};
   const unsigned n_gemm = (unsigned)ceil_div64(rows, 32) + (fill_rows > 0 ? 1u : 0u);
   const unsigned ro_gx = (unsigned)((nslots + 63) / 64);

@@ -85,7 +85,7 @@ int tsgnn_rowgemm_f32(const float* a, int64_t lda, const float* b, int64_t ldb, 
   return TSGNN_OK;
 }
 
-int tsgnn_gather_rowgemm_f32(const int* ell, int ell_w, const float* x, int64_t ldx, const float* b, int64_t ldb, int trans_b,
+int tsgnn_gather_rowgemm_f32(const int* ell, int ell_w, const int* tail_ptr, const int* tail_col, const float* x, int64_t ldx, const float* b, int64_t ldb, int trans_b,
                              const float* bias, float* c, int64_t ldc, float* rinv, float* zout, int64_t ldz, int64_t rows, int K,
                              int N, int normalize, int64_t fill_rows, tsgnn_stream_t stream) {
   if (!ell || !x || !b || !c || rows < 0 || fill_rows < 0 || K <= 0 || N <= 0 || ldx < K || ldc < N) return TSGNN_EINVAL;
@@ -97,7 +97,8 @@ int tsgnn_gather_rowgemm_f32(const int* ell, int ell_w, const float* x, int64_t 
                         (bias && (reinterpret_cast<uintptr_t>(bias) & 15))))
     return TSGNN_EUNSUPPORTED;
   if (rows == 0 && fill_rows == 0) return TSGNN_OK;
-  RowGemmArgs g{x, ldx, b, ldb, bias, c, ldc, rinv, rows, K, N, normalize, fill_rows, ell, ell_w, zout, ldz};
+  if ((tail_ptr == nullptr) != (tail_col == nullptr)) return TSGNN_EINVAL;
+  RowGemmArgs g{x, ldx, b, ldb, bias, c, ldc, rinv, rows, K, N, normalize, fill_rows, ell, ell_w, zout, ldz, tail_ptr, tail_col};
   if (trans_b) dispatch_rowgemm<true, true>(g, stream);
   else dispatch_rowgemm<false, true>(g, stream);
   TSGNN_CHECK_LAUNCH();

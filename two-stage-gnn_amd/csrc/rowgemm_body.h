@@ -26,6 +26,7 @@ struct RowGemmArgs {
   // skipped), built chunk by chunk while it is staged; zout (nullable) receives it (the weight gradient needs it).
   const int* ell; int ell_w;
   float* zout; int64_t ldz;
+  const int* tail_ptr; const int* tail_col;   // nullable: CSR of the neighbours beyond ell_w (rows with longer lists)
 };
 
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -251,6 +252,12 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem, 
           const int j = g.ell[row * g.ell_w + k];
           if (j < 0) break;
           const float4 t = ldg4(g.a + (int64_t)j * g.lda + 4 * c4);
+          va.x += t.x; va.y += t.y; va.z += t.z; va.w += t.w;
+        }
+      }
+      if (colok && g.tail_ptr && row < g.rows && ids[p][GN - 1] >= 0) {   // lists longer than the table continue in the CSR tail
+        for (int e = g.tail_ptr[row]; e < g.tail_ptr[row + 1]; ++e) {
+          const float4 t = ldg4(g.a + (int64_t)g.tail_col[e] * g.lda + 4 * c4);
           va.x += t.x; va.y += t.y; va.z += t.z; va.w += t.w;
         }
       }

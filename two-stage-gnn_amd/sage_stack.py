@@ -55,13 +55,14 @@ import os
 FUSED_TAIL = os.environ.get("TSGNN_FUSED_TAIL", "1") != "0"        # last readout + decode + the two Linear layers in one launch
 MERGED_FWD = os.environ.get("TSGNN_MERGED_FWD", "1") != "0"        # a layer's product + the readout partial of its input in one launch
 MERGED_BWD = os.environ.get("TSGNN_MERGED_BWD", "1") != "0"        # weight-gradient slabs + input-gradient product in one launch
+GATHER_MAX_ROWS = int(os.environ.get("TSGNN_GATHER_MAX_ROWS", 65536))   # above: stand-alone row-batched aggregation + lean product
 GATHER_FUSED = os.environ.get("TSGNN_GATHER_FUSED", "1") != "0"     # aggregate inside the `.W` product when the neighbour table has no CSR tail
 
 
 def _gather_ok(g, x):
-    if not GATHER_FUSED or g.val is not None or not mp.ell_ok(x) or g.total_rows > mp.ELL_MAX_ROWS:
+    if not GATHER_FUSED or g.val is not None or not mp.ell_ok(x) or g.total_rows > GATHER_MAX_ROWS:
         return False
-    return g.ell()[2] is None
+    return True
 
 
 def _flush_readout(g, B, sn, sg, pending):
@@ -118,18 +119,20 @@ class _SageStack(torch.autograd.Function):
             if (fused and MERGED_FWD and pending_ro is not None and K == 128 and N == 128 and x.size(1) == 128
                     and Ws[l].stride(0) % 4 == 0):
                 # this layer's product and the max-readout partial of its input (the previous layer's output) in one launch
-                ell, ell_w, _ = g.ell()
+                ell, ell_w, tail = g.ell()
+                tp, tc = tail if tail is not None else (None, None)
                 z = torch.empty(R, x.size(1), dtype=torch.float32, device=dev)
-                nat.call("sage_layer_fwd_f32", ell, ell_w, x, x.stride(0), Ws[l], Ws[l].stride(0), bs[l], v, v.stride(0), rinv,
+                nat.call("sage_layer_fwd_f32", ell, ell_w, tp, tc, x, x.stride(0), Ws[l], Ws[l].stride(0), bs[l], v, v.stride(0), rinv,
                          z, z.stride(0), g.n_rows, K, gs, g.graph_ptr, B, sn, sg, pending_ro[1])
                 pending_ro = None
             elif fused:
                 _flush_readout(g, B, sn, sg, pending_ro)
                 pending_ro = None
                 # aggregation fused into the product: the neighbour rows are summed while the A panel is staged
-                ell, ell_w, _ = g.ell()
+                ell, ell_w, tail = g.ell()
+                tp, tc = tail if tail is not None else (None, None)
                 z = torch.empty(R, x.size(1), dtype=torch.float32, device=dev)
-                nat.call("gather_rowgemm_f32", ell, ell_w, x, x.stride(0), Ws[l], Ws[l].stride(0), 0, bs[l], v, v.stride(0), rinv,
+                nat.call("gather_rowgemm_f32", ell, ell_w, tp, tc, x, x.stride(0), Ws[l], Ws[l].stride(0), 0, bs[l], v, v.stride(0), rinv,
                          z, z.stride(0), g.n_rows, K, N, 1, gs)
             else:
                 _flush_readout(g, B, sn, sg, pending_ro)
@@ -246,10 +249,11 @@ class _SageStack(torch.autograd.Function):
                 nslab, rps, need = mp.wgrad_plan(g.n_rows, K, N, z.stride(0), du.stride(0))
                 if 0 < nslab < 512:
                     # weight-gradient slabs and dX = (A dU) W^T side by side in one launch (both only need dU)
-                    ell, ell_w, _ = g.ell()
+                    ell, ell_w, tail = g.ell()
+                    tp, tc = tail if tail is not None else (None, None)
                     ws = torch.empty(need, dtype=torch.float32, device=dev)
                     dxs = torch.empty(R, K, dtype=torch.float32, device=dev)
-                    nat.call("sage_layer_bwd_f32", ell, ell_w, du, du.stride(0), W, W.stride(0), dxs, dxs.stride(0), z, z.stride(0),
+                    nat.call("sage_layer_bwd_f32", ell, ell_w, tp, tc, du, du.stride(0), W, W.stride(0), dxs, dxs.stride(0), z, z.stride(0),
                              g.n_rows, nslab, rps, sg, ws)
                     dw, sw = mp._sink_or_new(ctx.params[2 * l], (K, N), dev)
                     db, sb = mp._sink_or_new(ctx.params[2 * l + 1], (N,), dev) if want_b else (None, False)
@@ -290,9 +294,10 @@ class _SageStack(torch.autograd.Function):
                 if (l > 0 and g.n_ghost > 0 and g.symmetric and ldz == K and K <= 128 and _gather_ok(g, du)
                         and mp.rowgemm_ok(du, du.stride(0), W, W.stride(0), N, K, True)):
                     # dX = A^T (dU W^T) = (A dU) W^T for a symmetric A: the same fused gather + product; only real rows
-                    ell, ell_w, _ = g.ell()
+                    ell, ell_w, tail = g.ell()
+                    tp, tc = tail if tail is not None else (None, None)
                     dxs = torch.empty(R, ldz, dtype=torch.float32, device=dev)
-                    nat.call("gather_rowgemm_f32", ell, ell_w, du, du.stride(0), W, W.stride(0), 1, None, dxs, dxs.stride(0), None,
+                    nat.call("gather_rowgemm_f32", ell, ell_w, tp, tc, du, du.stride(0), W, W.stride(0), 1, None, dxs, dxs.stride(0), None,
                              None, 0, g.n_rows, N, K, 0, 0)
                 else:
                     dz = torch.zeros(R, ldz, dtype=torch.float32, device=dev) if ldz > K else torch.empty(R, ldz, dtype=torch.float32, device=dev)
