@@ -163,6 +163,11 @@ def cpu_baseline(hb, hidden, layers, steps, state):
 
 def main():
     a = parse()
+    # stdout carries exactly ONE JSON line: libraries that write banners to fd 1 (RCCL prints its version block there at
+    # communicator creation) are pointed at stderr until the line is printed
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -188,7 +193,7 @@ def main():
 
     from two_stage_gnn_amd import dense_encoders as E
     from two_stage_gnn_amd import synthetic
-    from two_stage_gnn_amd.data_parallel import FlatTrainer
+    from two_stage_gnn_amd.data_parallel import FlatTrainer, GraphedStep
     from two_stage_gnn_amd import sage_stack
     if a.no_overlap:
         sage_stack.OVERLAP = False
@@ -204,47 +209,13 @@ def main():
     trainer = FlatTrainer(model, lr=1e-3, clip=2.0)
     trainer.always_reduce = multi
 
-    def fwd_bwd():
-        trainer.zero_grad()
-        _, ypred = model(x, g)
-        loss = model.loss(ypred, label)
-        trainer.backward(loss)
-        trainer.gather_grads()
-        return loss
-
     use_graph = not a.no_graph
-    stream = torch.cuda.Stream()
-    graph_fb = graph_opt = None
+    # N > 1: fwd+bwd+bucket and clip+Adam are two hipGraphs with the RCCL all-reduce issued between them on the same stream;
+    # N = 1: one hipGraph for the whole step (data_parallel.GraphedStep)
+    gstep = GraphedStep(trainer, lambda: model.loss(model(x, g)[1], label), warmup=3, use_graph=use_graph)
+    stream = gstep.stream
+    step = gstep.step
     with torch.cuda.stream(stream):
-        for _ in range(3):                                     # allocator / lazy-init warm-up before capture
-            fwd_bwd(); trainer.all_reduce(); trainer.apply()
-        torch.cuda.synchronize()
-        if use_graph:
-            # N > 1: fwd+bwd+bucket and clip+Adam are two hipGraphs with the RCCL all-reduce issued between them on the
-            # same stream; N = 1: one hipGraph for the whole step.
-            if multi:
-                dist.barrier()                                 # no collective in flight while capturing
-                torch.cuda.synchronize()
-            # thread_local: the RCCL watchdog thread may touch the HIP runtime while this thread captures
-            mode = {"capture_error_mode": "thread_local"} if multi else {}
-            graph_fb = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph_fb, stream=stream, **mode):
-                fwd_bwd()
-                if not multi:
-                    trainer.apply()                            # single GPU: no collective, the whole step is one graph
-            if multi:
-                graph_opt = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph_opt, stream=stream, **mode):
-                    trainer.apply()
-
-        def step():
-            if use_graph and not multi:
-                graph_fb.replay()
-            elif use_graph:
-                graph_fb.replay(); trainer.all_reduce(); graph_opt.replay()
-            else:
-                fwd_bwd(); trainer.all_reduce(); trainer.apply()
-
         for _ in range(a.warmup):
             step()
         torch.cuda.synchronize()
@@ -326,7 +297,10 @@ def main():
                                                      "kernel": aggregation_probe.kernel})
                     print("sweep B=%d rows=%d: %.2f us, %.0f GB/s (%.1f%% of 8 TB/s)" % (B, gs.n_rows, ms * 1e3, nb / ms / 1e6,
                                                                                        nb / ms / 1e6 / HBM_PEAK_GBS * 100), file=sys.stderr)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if multi:
         dist.barrier()
         dist.destroy_process_group()

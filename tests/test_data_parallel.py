@@ -289,3 +289,31 @@ def test_barrier_free_optimiser_equals_three_stage_path():
     assert float(finals[0][1][0]) == 4.0 and float(finals[1][1][0]) == 4.0
     torch.testing.assert_close(finals[1][1][1], finals[0][1][1], rtol=1e-5, atol=0)          # gradient norm of the last step
     torch.testing.assert_close(finals[1][0], finals[0][0], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_graphed_step_replays_the_eager_step():
+    """GraphedStep (one hipGraph per optimiser step) == the same steps launched eagerly"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from two_stage_gnn_amd import dense_encoders as E, synthetic
+    from two_stage_gnn_amd.data_parallel import FlatTrainer, GraphedStep
+
+    class A:
+        bias = True
+    dev = torch.device("cuda")
+    hb = synthetic.host_batch(seed=6, B=8, shape="DD", nmax=400)
+    g, x, label = synthetic.to_device(hb, dev)
+    out = []
+    for graphed in (False, True):
+        torch.manual_seed(5)
+        model = E.GcnEncoderGraph(89, 128, 128, 2, 3, bn=True, args=A(), final_dim="number_classes").to(dev)
+        tr = FlatTrainer(model, lr=1e-2, clip=2.0)
+        gs = GraphedStep(tr, lambda: model.loss(model(x, g)[1], label), warmup=2, use_graph=graphed)
+        for _ in range(3):
+            gs.step()
+        torch.cuda.synchronize()
+        out.append((tr.flat_param.clone(), float(tr.state[0]), float(gs.loss.detach())))
+    assert out[0][1] == out[1][1] == 5.0                       # 2 warm-up + 3 steps
+    torch.testing.assert_close(out[1][0], out[0][0], rtol=0, atol=0)
+    assert out[0][2] == out[1][2]

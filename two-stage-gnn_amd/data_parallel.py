@@ -131,3 +131,60 @@ class FlatTrainer:
         self.all_reduce()
         self.apply()
         return loss
+
+
+class GraphedStep:
+    """One optimiser step on FIXED device buffers, replayed from hipGraphs (the b = 32 step is launch-bound: 16 launches).
+
+        gs = GraphedStep(trainer, lambda: model.loss(model(x, g)[1], label))   # captures on its own stream
+        for _ in range(steps): gs.step()                                        # refill x / label in place between steps
+
+    Single GPU: forward + backward + gradient bucket + optimiser are ONE graph.  With a process group (world > 1 or
+    trainer.always_reduce) the RCCL all-reduce cannot live inside the capture here, so the step is two graphs
+    (forward/backward/bucket, optimiser) with ``trainer.all_reduce()`` issued between them on the same stream; the captures
+    use ``capture_error_mode="thread_local"`` because the RCCL watchdog thread touches the HIP runtime concurrently.
+    ``use_graph=False`` runs the same sequence eagerly (debugging)."""
+
+    def __init__(self, trainer, loss_fn, warmup=3, use_graph=True, stream=None):
+        self.trainer, self.loss_fn, self.use_graph = trainer, loss_fn, use_graph
+        self.multi = trainer.world > 1 or trainer.always_reduce
+        self.stream = stream if stream is not None else torch.cuda.Stream()
+        self.loss = None
+        self._fb = self._opt = None
+        with torch.cuda.stream(self.stream):
+            for _ in range(warmup):                                # allocator / lazy-init warm-up on the capture stream
+                self._fwd_bwd(); trainer.all_reduce(); trainer.apply()
+            torch.cuda.synchronize()
+            if not use_graph:
+                return
+            if self.multi and dist.is_initialized():
+                dist.barrier(group=trainer.group)                  # no collective in flight while capturing
+                torch.cuda.synchronize()
+            mode = {"capture_error_mode": "thread_local"} if self.multi else {}
+            self._fb = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._fb, stream=self.stream, **mode):
+                self._fwd_bwd()
+                if not self.multi:
+                    trainer.apply()
+            if self.multi:
+                self._opt = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._opt, stream=self.stream, **mode):
+                    trainer.apply()
+
+    def _fwd_bwd(self):
+        tr = self.trainer
+        tr.zero_grad()
+        self.loss = self.loss_fn()
+        tr.backward(self.loss)
+        tr.gather_grads()
+
+    def step(self):
+        """enqueue one step on self.stream (returns immediately; self.loss is the device scalar of the last step)"""
+        with torch.cuda.stream(self.stream):
+            if not self.use_graph:
+                self._fwd_bwd(); self.trainer.all_reduce(); self.trainer.apply()
+            elif not self.multi:
+                self._fb.replay()
+            else:
+                self._fb.replay(); self.trainer.all_reduce(); self._opt.replay()
+        return self.loss
