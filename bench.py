@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=0, help="0 = auto-size the sample to ~15 s")
-    ap.add_argument("--no-overlap", action="store_true", help="keep the fused stack on one stream")
+    ap.add_argument("--no-overlap", action="store_true", help="accepted for compatibility: the stack always runs on one stream")
     ap.add_argument("--sweep", action="store_true", help="also print the aggregation-kernel batch-size sweep (stderr)")
     return ap.parse_args()
 
@@ -195,8 +195,6 @@ def main():
     from two_stage_gnn_amd import synthetic
     from two_stage_gnn_amd.data_parallel import FlatTrainer, GraphedStep
     from two_stage_gnn_amd import sage_stack
-    if a.no_overlap:
-        sage_stack.OVERLAP = False
 
     class Args:
         bias = True

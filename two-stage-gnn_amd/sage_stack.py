@@ -1,13 +1,20 @@
-"""The GraphSage-style conv stack of GcnEncoderGraph (encoders.py:177-205) as ONE autograd node with a minimal
-launch sequence (the b=32 shape is launch-latency bound):
+"""The GraphSage-style conv stack of GcnEncoderGraph (encoders.py:177-217) as ONE autograd node with a minimal launch
+sequence (the b = 32 shape is bound by launch boundaries and per-kernel latency chains).
 
-  per layer:   aggregate (ELL/CSR SpMM) -> transform+bias+L2-normalise (fp32 MFMA) -> [ReLU + slot-BN fused] -> max-readout partial
-  once:        zero the packed readout buffer, decode all layers' readouts into the concatenated [B, sum F] output
-  backward:    per layer ONE kernel for readout-scatter + BN + ReLU + normalise backward, ONE pass for dW+db, the dZ GEMM
-               and the transposed aggregation.
+  forward, layer 0   : gather_rowgemm (aggregate + .W + bias + L2 normalise; z kept for dW)  -> slot_bn_fwd (ReLU + slot BN)
+  forward, layer l>0 : sage_layer_fwd (the same product || max-readout partial of the layer's input)  [-> slot_bn_fwd]
+  forward, tail      : readout_head_fwd (last layer's readout from its rows + decode of the others + both nn.Linear), or
+                       readout_partial + readout_decode_layers when the head is not part of the node
+  backward           : [head2_bwd ->] per layer slot_post_bwd (readout scatter + BN + ReLU + normalise backward -> dU), then
+                       sage_layer_bwd (dW/db slabs || dX = (A dU) W^T) for hidden layers / linear_wgrad slabs for layer 0,
+                       ONE slab reduction for all layers (straight into the trainer's flat gradient bucket when installed)
+
+Ghost rows: they aggregate nothing, so the products skip them and a filler block writes their constant output;
+only the ghost slots up to the largest graph can influence anything, so the slot kernels run on those.
 
 Used when the batch qualifies (slot-BN on, sum aggregation without self term, <= 128 graphs, widths <= 128); any other
-configuration runs the operator-by-operator path in dense_encoders.py — same kernels' results, more launches.
+configuration runs the operator-by-operator path in dense_encoders.py: same results, more launches.  Every fusion has a switch
+(environment / module attribute) that selects the launch sequence it replaces.
 """
 import torch
 
@@ -27,17 +34,6 @@ def eligible(g, convs, bn, x):
         if i < len(convs) - 1 and c.output_dim != hid:
             return False
     return x.dim() == 2 and x.size(1) % 4 == 0 and x.is_cuda and x.stride(0) % 4 == 0
-
-
-OVERLAP = False         # (measured slower under hipGraph replay: 308 vs 266 us/step) run work that is off the critical path (readout partials, weight gradients) on a side stream
-_side = {}
-
-
-def _side_stream(dev):
-    st = _side.get(dev)
-    if st is None:
-        st = _side[dev] = torch.cuda.Stream(device=dev)
-    return st
 
 
 def _aggregate_raw(g, x, transposed=False, rows=None):
@@ -102,11 +98,7 @@ class _SageStack(torch.autograd.Function):
         saved = []
         off = 0
         pending_ro = None
-        main = torch.cuda.current_stream()
-        side = _side_stream(dev) if OVERLAP else main
         keep = []
-        if OVERLAP:
-            side.wait_stream(main)                          # packed zeroed before any partial lands
         for l in range(L):
             K, N = Ws[l].size(0), Ws[l].size(1)
             v = torch.empty(R, N, dtype=torch.float32, device=dev)
@@ -163,8 +155,6 @@ class _SageStack(torch.autograd.Function):
                 x = y
             else:
                 mean = rstd = None
-                if OVERLAP:
-                    main.wait_stream(side)                  # join: all partials done before the decode
                 if head is None:
                     nat.call("readout_partial_f32", g.graph_ptr, B, sn, g.n_rows, sg, v, v.stride(0), N, pk)
             saved.append((z, v, rinv, mean, rstd, lean))
@@ -224,8 +214,6 @@ class _SageStack(torch.autograd.Function):
         grads = [None] * (2 * L)
         dxs = None
         dx0 = None
-        main = torch.cuda.current_stream()
-        side = _side_stream(dev) if OVERLAP else main
         keep = []
         pending = []
         pend_sunk, pend_layers = [], []
@@ -264,29 +252,26 @@ class _SageStack(torch.autograd.Function):
                     merged = True
             if merged:
                 continue
-            if OVERLAP:
-                side.wait_stream(main)                      # du ready
-            with torch.cuda.stream(side):                   # weight/bias gradients are off the dX critical path
-                if want_w:
-                    if not lean and sg < g.n_ghost:
-                        du[g.n_rows + sg:].zero_()          # rows no slot kernel wrote
-                    sl = mp.linear_wgrad_slabs(z, K, du[:g.n_rows + sg] if lean else du, bias_only_rows=sg if lean else 0)
-                    if sl is not None:                      # slabs now, ONE reduction for all layers at the end
-                        dw, sw = mp._sink_or_new(ctx.params[2 * l], (K, N), dev)     # straight into the flat bucket if one is installed
-                        db, sb = mp._sink_or_new(ctx.params[2 * l + 1], (N,), dev) if want_b else (None, False)
-                        pending.append((sl[0], sl[1], K, N, dw, db))
-                        pend_sunk.append(sw and (sb or not want_b)); pend_layers.append(l)
-                        dw, db = (None if sw else dw), (None if sb else db)
-                    else:
-                        if lean:
-                            z[g.n_rows:].zero_()
-                            du[g.n_rows + sg:].zero_()
-                        dw, db = mp.linear_wgrad(z, K, du, want_b)
-                    grads[2 * l], grads[2 * l + 1] = dw, db
-                elif want_b:
-                    if sg < g.n_ghost:
+            if want_w:
+                if not lean and sg < g.n_ghost:
+                    du[g.n_rows + sg:].zero_()          # rows no slot kernel wrote
+                sl = mp.linear_wgrad_slabs(z, K, du[:g.n_rows + sg] if lean else du, bias_only_rows=sg if lean else 0)
+                if sl is not None:                      # slabs now, ONE reduction for all layers at the end
+                    dw, sw = mp._sink_or_new(ctx.params[2 * l], (K, N), dev)     # straight into the flat bucket if one is installed
+                    db, sb = mp._sink_or_new(ctx.params[2 * l + 1], (N,), dev) if want_b else (None, False)
+                    pending.append((sl[0], sl[1], K, N, dw, db))
+                    pend_sunk.append(sw and (sb or not want_b)); pend_layers.append(l)
+                    dw, db = (None if sw else dw), (None if sb else db)
+                else:
+                    if lean:
+                        z[g.n_rows:].zero_()
                         du[g.n_rows + sg:].zero_()
-                    grads[2 * l + 1] = mp.colsum(du)
+                    dw, db = mp.linear_wgrad(z, K, du, want_b)
+                grads[2 * l], grads[2 * l + 1] = dw, db
+            elif want_b:
+                if sg < g.n_ghost:
+                    du[g.n_rows + sg:].zero_()
+                grads[2 * l + 1] = mp.colsum(du)
             keep.append(du)
             need_dx = l > 0 or ctx.needs_input_grad[0]
             if need_dx:
@@ -311,17 +296,14 @@ class _SageStack(torch.autograd.Function):
                 if l == 0:
                     dx0 = dxs
         if pending:
-            with torch.cuda.stream(side):
-                sink = mp.GRAD_SINK
-                all_sunk = sink is not None and len(pending) <= 4 and all(pend_sunk)
-                mp.wgrad_reduce_multi(pending, norm_sink=sink if all_sunk else None)
-                if all_sunk and sink.stepped:
-                    for l_ in pend_layers:
-                        sink.normed.add(ctx.params[2 * l_].data_ptr())
-                        if ctx.has_bias:
-                            sink.normed.add(ctx.params[2 * l_ + 1].data_ptr())
-        if OVERLAP:
-            main.wait_stream(side)                          # join before the gradients are consumed
+            sink = mp.GRAD_SINK
+            all_sunk = sink is not None and len(pending) <= 4 and all(pend_sunk)
+            mp.wgrad_reduce_multi(pending, norm_sink=sink if all_sunk else None)
+            if all_sunk and sink.stepped:
+                for l_ in pend_layers:
+                    sink.normed.add(ctx.params[2 * l_].data_ptr())
+                    if ctx.has_bias:
+                        sink.normed.add(ctx.params[2 * l_ + 1].data_ptr())
         del keep
         return (dx0, None, None, None) + tuple(grads) + head_grads
 
