@@ -19,31 +19,40 @@ namespace {
 constexpr float BN_EPS = 1e-5f;
 
 
-__device__ __forceinline__ void block_sum2(float& a, float& b, float* lds /*8*/) {
+template <int NW>                                        // NW waves per block (4, 8 or 16)
+__device__ __forceinline__ void block_sum2(float& a, float& b, float* lds /* 2*NW */) {
   a = wave_sum(a); b = wave_sum(b);
   const int wid = threadIdx.x >> 6;
   __syncthreads();
-  if ((threadIdx.x & 63) == 0) { lds[wid] = a; lds[4 + wid] = b; }
+  if ((threadIdx.x & 63) == 0) { lds[wid] = a; lds[NW + wid] = b; }
   __syncthreads();
-  a = (lds[0] + lds[1]) + (lds[2] + lds[3]);
-  b = (lds[4] + lds[5]) + (lds[6] + lds[7]);
+  float ta = 0.f, tb = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; w += 4) {                      // fixed order
+    ta += (lds[w] + lds[w + 1]) + (lds[w + 2] + lds[w + 3]);
+    tb += (lds[NW + w] + lds[NW + w + 1]) + (lds[NW + w + 2] + lds[NW + w + 3]);
+  }
+  a = ta; b = tb;
 }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
 // ---------------------------------------------------------------------------------------------- forward
-template <int TPR, int NV>
-__global__ __launch_bounds__(256) void slot_bn_fwd(SlotArgs s, const float* __restrict__ v, int64_t ldv, int F4, int relu,
+// BT threads per block = TPR threads per graph x up to BT/TPR graphs (B <= 32: 256, <= 64: 512, <= 128: 1024 threads, so that a
+// thread never owns more than NV <= 4 float4 of a row: short dependency chains, <= 80 registers)
+template <int TPR, int NV, int BT>
+__global__ __launch_bounds__(BT) void slot_bn_fwd(SlotArgs s, const float* __restrict__ v, int64_t ldv, int F4, int relu,
                                                    float* __restrict__ mean, float* __restrict__ rstd,
                                                    float* __restrict__ y, int64_t ldy,
                                                    unsigned long long* __restrict__ zero_ptr, int64_t zero_n) {
-  __shared__ float red[8];
+  constexpr int NW = BT / 64;
+  __shared__ float red[2 * NW];
   __shared__ int first_ghost;
   const int n = blockIdx.x, tid = threadIdx.x;
   const int b = tid / TPR, c = tid % TPR;
   // optional: clear the packed max-readout buffer of the whole stack (consumed only by later launches)
-  for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < zero_n; i += (int64_t)gridDim.x * 256) zero_ptr[i] = 0ull;
+  for (int64_t i = (int64_t)blockIdx.x * BT + tid; i < zero_n; i += (int64_t)gridDim.x * BT) zero_ptr[i] = 0ull;
   if (tid == 0) first_ghost = 0x7fffffff;
   __syncthreads();
   int64_t row = -1;
@@ -68,7 +77,7 @@ __global__ __launch_bounds__(256) void slot_bn_fwd(SlotArgs s, const float* __re
   }
   const int have = s.slot_count[n];
   const float cnt = (float)(s.n_ghost ? s.B : have) * (float)(4 * F4);
-  block_sum2(s1, dummy, red);
+  block_sum2<NW>(s1, dummy, red);
   const float mu = cnt > 0.f ? s1 / cnt : 0.f;
   float s2 = 0.f;
   dummy = 0.f;
@@ -80,7 +89,7 @@ __global__ __launch_bounds__(256) void slot_bn_fwd(SlotArgs s, const float* __re
       s2 += (a * a + bb * bb) + (cc * cc + d * d);
     }
   }
-  block_sum2(s2, dummy, red);
+  block_sum2<NW>(s2, dummy, red);
   const float rs = 1.0f / sqrtf((cnt > 0.f ? s2 / cnt : 0.f) + BN_EPS);
   if (tid == 0) { mean[n] = mu; rstd[n] = rs; }
   const bool writer = row >= 0 && (!ghost || b == first_ghost);      // first_ghost is final: block_sum2 synchronised
@@ -107,20 +116,20 @@ __global__ __launch_bounds__(256) void slot_bn_fwd(SlotArgs s, const float* __re
 //           + (arg[b,f] == row ? dout[b,f] : 0)                       [max-readout winner of graph b]
 // BN:   dv = rstd (dy - m1 - xhat m2) ; ReLU mask ; ghost copies summed in graph order ;
 // L2:   du = rinv (dv - v <v,dv>)   (rinv = 1e12 marks the clamped norm: du = rinv dv)
-template <int TPR, int NV>
-__global__ __launch_bounds__(256) void slot_post_bwd(SlotArgs s, const float* __restrict__ v, int64_t ldv,
+template <int TPR, int NV, int BT>
+__global__ __launch_bounds__(BT) void slot_post_bwd(SlotArgs s, const float* __restrict__ v, int64_t ldv,
                                                      const float* __restrict__ dxs, int64_t lddxs,
                                                      const float* __restrict__ dout, int64_t ldo, const int* __restrict__ arg,
                                                      int F4, int relu, int bn, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ rinv,
                                                      float* __restrict__ du, int64_t lddu) {
-  constexpr int GPB = 256 / TPR;
+  constexpr int NW = BT / 64;
   // all LDS in ONE dynamic array (16-byte aligned base for the float4 ghost accumulators, Guideline 17)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int F = 4 * F4;
-  float* gacc = smem;                                                // [4 waves][F] ghost-copy sums (only with ghost rows)
-  float* red = smem + (s.n_ghost ? 4 * F : 0);                       // 8 floats
-  int& first_ghost = *reinterpret_cast<int*>(red + 8);
+  float* gacc = smem;                                                // [NW waves][F] ghost-copy sums (only with ghost rows)
+  float* red = smem + (s.n_ghost ? NW * F : 0);                      // 2 * NW floats
+  int& first_ghost = *reinterpret_cast<int*>(red + 2 * NW);
   const int n = blockIdx.x, tid = threadIdx.x;
   const int b = tid / TPR, c = tid % TPR;
   TR(0);
@@ -182,7 +191,7 @@ __global__ __launch_bounds__(256) void slot_post_bwd(SlotArgs s, const float* __
   if (bn) {
     const int have = s.slot_count[n];
     const float cnt = (float)(s.n_ghost ? s.B : have) * (float)F;
-    block_sum2(a1, a2, red);
+    block_sum2<NW>(a1, a2, red);
     m1 = cnt > 0.f ? a1 / cnt : 0.f;
     m2 = cnt > 0.f ? a2 / cnt : 0.f;
   }
@@ -235,9 +244,15 @@ __global__ __launch_bounds__(256) void slot_post_bwd(SlotArgs s, const float* __
       for (int q = 0; q < NV; ++q) {
         const int c4 = c + TPR * q;
         if (c4 < F4) {
-          const float4 t0 = ld4(gacc + 4 * c4), t1 = ld4(gacc + F + 4 * c4), t2 = ld4(gacc + 2 * F + 4 * c4), t3 = ld4(gacc + 3 * F + 4 * c4);
-          dv[q] = make_float4((t0.x + t1.x) + (t2.x + t3.x), (t0.y + t1.y) + (t2.y + t3.y), (t0.z + t1.z) + (t2.z + t3.z),
-                              (t0.w + t1.w) + (t2.w + t3.w));
+          float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int w = 0; w < NW; w += 4) {                            // fixed order
+            const float4 t0 = ld4(gacc + (w + 0) * F + 4 * c4), t1 = ld4(gacc + (w + 1) * F + 4 * c4),
+                         t2 = ld4(gacc + (w + 2) * F + 4 * c4), t3 = ld4(gacc + (w + 3) * F + 4 * c4);
+            t.x += (t0.x + t1.x) + (t2.x + t3.x); t.y += (t0.y + t1.y) + (t2.y + t3.y);
+            t.z += (t0.z + t1.z) + (t2.z + t3.z); t.w += (t0.w + t1.w) + (t2.w + t3.w);
+          }
+          dv[q] = t;
         }
       }
     }
@@ -308,16 +323,23 @@ int tsgnn_slot_fused_supported(int B, int F) {
   return B <= 128;
 }
 
-#define TSGNN_SLOT_DISPATCH(KERNEL, ...)                                                          \
-  do {                                                                                            \
-    const int F4_ = F / 4;                                                                        \
-    if (B <= 32) {                                                                                \
-      if (F4_ <= 8) KERNEL<8, 1> __VA_ARGS__; else if (F4_ <= 16) KERNEL<8, 2> __VA_ARGS__; else KERNEL<8, 4> __VA_ARGS__; \
-    } else if (B <= 64) {                                                                         \
-      if (F4_ <= 8) KERNEL<4, 2> __VA_ARGS__; else if (F4_ <= 16) KERNEL<4, 4> __VA_ARGS__; else KERNEL<4, 8> __VA_ARGS__; \
-    } else {                                                                                      \
-      if (F4_ <= 8) KERNEL<2, 4> __VA_ARGS__; else if (F4_ <= 16) KERNEL<2, 8> __VA_ARGS__; else KERNEL<2, 16> __VA_ARGS__; \
-    }                                                                                             \
+// (TPR threads per graph row, NV float4 per thread, block threads): F/4 = TPR * NV lanes-worth of columns per row
+#define TSGNN_SLOT_DISPATCH(KERNEL, GRID, LDS, ...)                                                                     \
+  do {                                                                                                                   \
+    const int F4_ = F / 4;                                                                                               \
+    if (B <= 32) {                                                                                                       \
+      if (F4_ <= 8) KERNEL<8, 1, 256><<<GRID, 256, LDS, stream>>> __VA_ARGS__;                                            \
+      else if (F4_ <= 16) KERNEL<8, 2, 256><<<GRID, 256, LDS, stream>>> __VA_ARGS__;                                      \
+      else KERNEL<8, 4, 256><<<GRID, 256, LDS, stream>>> __VA_ARGS__;                                                     \
+    } else if (B <= 64) {                                                                                                \
+      if (F4_ <= 8) KERNEL<8, 1, 512><<<GRID, 512, LDS, stream>>> __VA_ARGS__;                                            \
+      else if (F4_ <= 16) KERNEL<8, 2, 512><<<GRID, 512, LDS, stream>>> __VA_ARGS__;                                      \
+      else KERNEL<8, 4, 512><<<GRID, 512, LDS, stream>>> __VA_ARGS__;                                                     \
+    } else {                                                                                                             \
+      if (F4_ <= 8) KERNEL<8, 1, 1024><<<GRID, 1024, LDS, stream>>> __VA_ARGS__;                                          \
+      else if (F4_ <= 16) KERNEL<8, 2, 1024><<<GRID, 1024, LDS, stream>>> __VA_ARGS__;                                    \
+      else KERNEL<8, 4, 1024><<<GRID, 1024, LDS, stream>>> __VA_ARGS__;                                                   \
+    }                                                                                                                    \
   } while (0)
 
 int tsgnn_slot_bn_fwd_f32(const int* graph_ptr, const int* slot_count, int B, int nmax, int64_t n_real, int n_ghost,
@@ -328,7 +350,7 @@ int tsgnn_slot_bn_fwd_f32(const int* graph_ptr, const int* slot_count, int B, in
     return TSGNN_EINVAL;
   if (!tsgnn_slot_fused_supported(B, F)) return TSGNN_EUNSUPPORTED;
   SlotArgs s{graph_ptr, slot_count, B, nmax, n_real, n_ghost};
-  TSGNN_SLOT_DISPATCH(slot_bn_fwd, <<<nmax, 256, 0, stream>>>(s, v, ldv, F / 4, relu, mean, rstd, y, ldy, zero_ptr, zero_ptr ? zero_n : 0));
+  TSGNN_SLOT_DISPATCH(slot_bn_fwd, nmax, 0, (s, v, ldv, F / 4, relu, mean, rstd, y, ldy, zero_ptr, zero_ptr ? zero_n : 0));
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }
@@ -342,9 +364,9 @@ int tsgnn_slot_post_bwd_f32(const int* graph_ptr, const int* slot_count, int B, 
     return TSGNN_EINVAL;
   if (!tsgnn_slot_fused_supported(B, F)) return TSGNN_EUNSUPPORTED;
   SlotArgs s{graph_ptr, slot_count, B, nmax, n_real, n_ghost};
-  const size_t lds = sizeof(float) * ((n_ghost ? (size_t)4 * F : 0) + 12);
-  TSGNN_SLOT_DISPATCH(slot_post_bwd, <<<nmax, 256, lds, stream>>>(s, v, ldv, dxs, lddxs, dout, ldo, arg, F / 4, relu, bn, mean, rstd,
-                                                                 rinv, du, lddu));
+  const int nw = B <= 32 ? 4 : (B <= 64 ? 8 : 16);
+  const size_t lds = sizeof(float) * ((n_ghost ? (size_t)nw * F : 0) + 2 * nw + 4);
+  TSGNN_SLOT_DISPATCH(slot_post_bwd, nmax, lds, (s, v, ldv, dxs, lddxs, dout, ldo, arg, F / 4, relu, bn, mean, rstd, rinv, du, lddu));
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }
