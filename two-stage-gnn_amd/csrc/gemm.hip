@@ -70,31 +70,58 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 
   const bool a_k_fast = (g.sak == 1);                    // which index is contiguous in memory
   const bool b_n_fast = (g.sbn == 1);
-  for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    // stage A tile [BM][BK] and B tile [BK][BN]; thread mapping follows the unit stride
+  // register-staged software pipeline: the next K chunk's global loads are issued before the MFMAs of the current one
+  constexpr int AV = (BM * BK) / 256, BV = (BK * BN) / 256;
+  float ra[AV], rb[BV];
+  auto fetch = [&](int k0) {
 #pragma unroll
-    for (int it = 0; it < (BM * BK) / 256; ++it) {
+    for (int it = 0; it < AV; ++it) {
       const int idx = it * 256 + tid;
       int m, k;
       if (a_k_fast) { m = idx / BK; k = idx % BK; } else { k = idx / BM; m = idx % BM; }
       const int gm = m0 + m, gk = k0 + k;
-      As[m * LDA_S + k] = (gm < M && gk < kend) ? A[(int64_t)gm * g.sam + (int64_t)gk * g.sak] : 0.f;
+      ra[it] = (gm < M && gk < kend) ? A[(int64_t)gm * g.sam + (int64_t)gk * g.sak] : 0.f;
     }
 #pragma unroll
-    for (int it = 0; it < (BK * BN) / 256; ++it) {
+    for (int it = 0; it < BV; ++it) {
       const int idx = it * 256 + tid;
       int k, n;
       if (b_n_fast) { k = idx / BN; n = idx % BN; } else { n = idx / BK; k = idx % BK; }
       const int gk = k0 + k, gn = n0 + n;
-      Bs[k * LDB_S + n] = (gk < kend && gn < g.N) ? B[(int64_t)gk * g.sbk + (int64_t)gn * g.sbn] : 0.f;
+      rb[it] = (gk < kend && gn < g.N) ? B[(int64_t)gk * g.sbk + (int64_t)gn * g.sbn] : 0.f;
     }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int it = 0; it < AV; ++it) {
+      const int idx = it * 256 + tid;
+      int m, k;
+      if (a_k_fast) { m = idx / BK; k = idx % BK; } else { k = idx / BM; m = idx % BM; }
+      As[m * LDA_S + k] = ra[it];
+    }
+#pragma unroll
+    for (int it = 0; it < BV; ++it) {
+      const int idx = it * 256 + tid;
+      int k, n;
+      if (b_n_fast) { k = idx / BN; n = idx % BN; } else { n = idx / BK; k = idx % BK; }
+      Bs[k * LDB_S + n] = rb[it];
+    }
+  };
+  if (kbeg < kend) fetch(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    commit();
     __syncthreads();
     const int i = lane & 31, h = lane >> 5;
     const float* ap = As + (wr * 32 + i) * LDA_S + h;
     const float* bp = Bs + h * LDB_S + wc * 32 + i;
+    float af[BK / 2], bf[BK / 2];
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[kk], bp[kk * LDB_S], acc, 0, 0, 0);
+    for (int kk = 0; kk < BK; kk += 2) { af[kk / 2] = ap[kk]; bf[kk / 2] = bp[kk * LDB_S]; }
+    __builtin_amdgcn_sched_barrier(0);                   // fragment reads stay ahead of the MFMA chain
+    if (k0 + BK < kend) fetch(k0 + BK);                  // in flight under the MFMAs
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < BK / 2; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j], bf[j], acc, 0, 0, 0);
     __syncthreads();
   }
   // C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)

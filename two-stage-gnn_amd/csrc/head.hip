@@ -203,7 +203,18 @@ __device__ __forceinline__ void head2_bwd_weights(float* smem /* [B][4] dvt slic
     __syncthreads();
     for (int k = tid; k < P; k += NTH) {
       float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-      for (int bb = 0; bb < B; ++bb) {
+      int bb = 0;
+      for (; bb + 8 <= B; bb += 8) {                     // eight rows in flight (independent loads), same summation order
+        float x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = out[(int64_t)(bb + u) * ldo + k];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const float4 d = *reinterpret_cast<const float4*>(smem + 4 * (bb + u));
+          a0 = fmaf(d.x, x[u], a0); a1 = fmaf(d.y, x[u], a1); a2 = fmaf(d.z, x[u], a2); a3 = fmaf(d.w, x[u], a3);
+        }
+      }
+      for (; bb < B; ++bb) {
         const float x = out[(int64_t)bb * ldo + k];
         a0 = fmaf(smem[4 * bb + 0], x, a0); a1 = fmaf(smem[4 * bb + 1], x, a1);
         a2 = fmaf(smem[4 * bb + 2], x, a2); a3 = fmaf(smem[4 * bb + 3], x, a3);
