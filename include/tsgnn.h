@@ -129,7 +129,7 @@ int tsgnn_wgrad_reduce_multi_f32(const float* ws0, int nslab0, int K0, int N0, f
  * [slab_row_ptr[t], slab_row_ptr[t+1]).  ws >= nslab*(K+1)*N floats.  ceil(K/32)*ceil(N/32) <= 16. */
 int tsgnn_ragged_tn_f32(const float* s_mat, int64_t lds_, const float* x, int64_t ldx, int K, int N, const int* slab_row_ptr,
                         int nslab, const int* seg_slab_ptr, int nseg, float* ws, float* out, tsgnn_stream_t stream);
-/* out[f] (+)= sum_r x[r,f] (bias gradients); ws >= ceil(rows/512)*F floats */
+/* out[f] (+)= sum_r x[r,f] (bias gradients); ws >= ceil(rows/128)*F floats */
 int tsgnn_colsum_f32(const float* x, int64_t ld, int64_t rows, int F, float* out, float* ws, int accumulate,
                      tsgnn_stream_t stream);
 

@@ -157,7 +157,16 @@ __global__ __launch_bounds__(256) void colsum_partial(const float* __restrict__ 
   const int rl = threadIdx.x >> 6;
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
   float s = 0.f;
-  if (f < F) for (int64_t r = r0 + rl; r < r1; r += 4) s += x[r * ld + f];
+  if (f < F) {
+    int64_t r = r0 + rl;
+    for (; r + 28 < r1; r += 32) {                       // eight independent loads in flight, fixed summation order
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = x[(r + 4 * u) * ld + f];
+      s += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+    }
+    for (; r < r1; r += 4) s += x[r * ld + f];
+  }
   lds[rl][threadIdx.x & 63] = s;
   __syncthreads();
   if (rl == 0 && f < F) part[(int64_t)blockIdx.y * F + f] = lds[0][threadIdx.x] + lds[1][threadIdx.x] + lds[2][threadIdx.x] + lds[3][threadIdx.x];
@@ -418,7 +427,7 @@ int tsgnn_ragged_tn_f32(const float* s_mat, int64_t lds_, const float* x, int64_
 int tsgnn_colsum_f32(const float* x, int64_t ld, int64_t rows, int F, float* out, float* ws, int accumulate,
                      tsgnn_stream_t stream) {
   if (!x || !out || !ws || rows < 0 || F <= 0 || ld < F) return TSGNN_EINVAL;
-  const int64_t rpc = 512;
+  const int64_t rpc = rows > 65536 ? 512 : 128;          // short chunks: a bias gradient is a latency chain, not a stream
   const int nchunk = (int)(rows > 0 ? ceil_div64(rows, rpc) : 1);
   dim3 grid((unsigned)((F + 63) / 64), (unsigned)nchunk);
   colsum_partial<<<grid, 256, 0, stream>>>(x, ld, rows, F, rpc, ws);

@@ -174,7 +174,7 @@ def linear_wgrad(z, K_in, du, want_db):
 def colsum(x):
     R, F = x.size(0), x.size(1)
     out = _f32(F, device=x.device)
-    ws = _f32(max(1, (R + 511) // 512) * F, device=x.device)
+    ws = _f32(max(1, (R + 127) // 128) * F, device=x.device)
     nat.call("colsum_f32", x, x.stride(0), int(R), int(F), out, ws, 0)
     return out
 
