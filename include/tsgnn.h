@@ -311,12 +311,13 @@ int tsgnn_slot_fused_supported(int B, int F);
 int tsgnn_slot_bn_fwd_f32(const int* graph_ptr, const int* slot_count, int B, int nmax, int64_t n_real, int n_ghost,
                           const float* v, int64_t ldv, int F, int relu, float* mean, float* rstd, float* y, int64_t ldy,
                           unsigned long long* zero_ptr, int64_t zero_n, tsgnn_stream_t stream);
-/* One-pass backward of [max readout (dout, arg) + next layer's dxs (nullable)] -> slot BN -> ReLU -> row L2 normalise:
+/* One-pass backward of [max readout (dout, arg; both NULL: none) + next layer's dxs (nullable) + a gradient dxs2 (nullable)
+ * that reaches this layer's output rows directly (node-level outputs)] -> slot BN -> ReLU -> row L2 normalise:
  * du = gradient w.r.t. the pre-normalise GraphConv output (feeds tsgnn_linear_wgrad_f32 / tsgnn_rowgemm_f32). */
 int tsgnn_slot_post_bwd_f32(const int* graph_ptr, const int* slot_count, int B, int nmax, int64_t n_real, int n_ghost,
-                            const float* v, int64_t ldv, const float* dxs, int64_t lddxs, const float* dout, int64_t ldo,
-                            const int* arg, int F, int relu, int bn, const float* mean, const float* rstd, const float* rinv,
-                            float* du, int64_t lddu, tsgnn_stream_t stream);
+                            const float* v, int64_t ldv, const float* dxs, int64_t lddxs, const float* dxs2, int64_t lddxs2,
+                            const float* dout, int64_t ldo, const int* arg, int F, int relu, int bn, const float* mean,
+                            const float* rstd, const float* rinv, float* du, int64_t lddu, tsgnn_stream_t stream);
 /* max readout (encoders.py:183): partial maxima of one layer into packed[B*F] (zeroed by the caller), then ONE decode
  * for all L layers: out[b, l*Fh + f], arg in packed order (layers 0..L-2 are Fh wide, the last Fl). */
 int tsgnn_readout_partial_f32(const int* graph_ptr, int B, int nmax, int64_t n_real, int n_ghost, const float* x, int64_t ldx, int F,

@@ -29,7 +29,7 @@ int main() {
   (void)hipMemcpy(rstd, h.data() + 5000, nslots * 4, hipMemcpyHostToDevice); (void)hipMemcpy(rinv, h.data() + 9000, R * 4, hipMemcpyHostToDevice);
   hipStream_t s; (void)hipStreamCreate(&s);
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-  auto run = [&]() { tsgnn_slot_post_bwd_f32(d_gp, d_sc, B, nslots, n_real, nslots, v, F, dxs, F, dout, F, d_arg, F, 1, 1, mean, rstd, rinv, du, F, s); };
+  auto run = [&]() { tsgnn_slot_post_bwd_f32(d_gp, d_sc, B, nslots, n_real, nslots, v, F, dxs, F, nullptr, 0, dout, F, d_arg, F, 1, 1, mean, rstd, rinv, du, F, s); };
   for (int it = 0; it < 20; ++it) run();
   (void)hipStreamSynchronize(s);
   (void)hipEventRecord(e0, s);

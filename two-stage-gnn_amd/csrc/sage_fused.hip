@@ -112,13 +112,14 @@ __global__ __launch_bounds__(BT) void slot_bn_fwd(SlotArgs s, const float* __res
 }
 
 // ---------------------------------------------------------------------------------------------- backward
-// dy(b,n,f) = dxs[row] (real rows; a ghost row has no edges, so no gradient reaches it through the aggregation)
+// dy(b,n,f) = dxs[row] + dxs2[row] (real rows; a ghost row has no edges, so no gradient reaches it through the aggregation)
 //           + (arg[b,f] == row ? dout[b,f] : 0)                       [max-readout winner of graph b]
 // BN:   dv = rstd (dy - m1 - xhat m2) ; ReLU mask ; ghost copies summed in graph order ;
 // L2:   du = rinv (dv - v <v,dv>)   (rinv = 1e12 marks the clamped norm: du = rinv dv)
 template <int TPR, int NV, int BT>
 __global__ __launch_bounds__(BT) void slot_post_bwd(SlotArgs s, const float* __restrict__ v, int64_t ldv,
                                                      const float* __restrict__ dxs, int64_t lddxs,
+                                                     const float* __restrict__ dxs2, int64_t lddxs2,
                                                      const float* __restrict__ dout, int64_t ldo, const int* __restrict__ arg,
                                                      int F4, int relu, int bn, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ rinv,
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(BT) void slot_post_bwd(SlotArgs s, const float* __r
     const int c4 = c + TPR * q;
     wq[q] = make_int4(-1, -1, -1, -1);
     gq[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (b < s.B && c4 < F4) {
+    if (arg && b < s.B && c4 < F4) {                        // arg == NULL: this layer has no readout
       wq[q] = *reinterpret_cast<const int4*>(arg + (int64_t)b * F + 4 * c4);
       gq[q] = ld4(dout + (int64_t)b * ldo + 4 * c4);
     }
@@ -171,6 +172,10 @@ __global__ __launch_bounds__(BT) void slot_post_bwd(SlotArgs s, const float* __r
     if (row >= 0 && c4 < F4) {
       vv[q] = ld4(v + row * ldv + 4 * c4);
       if (dxs && !ghost) dy[q] = ld4(dxs + row * lddxs + 4 * c4);   // nothing aggregates from a ghost row: its dxs is 0
+      if (dxs2 && !ghost) {                               // gradient that reaches this layer's output directly (node-level outputs;
+        const float4 t = ld4(dxs2 + row * lddxs2 + 4 * c4);   // ghost rows are masked out of those)
+        dy[q].x += t.x; dy[q].y += t.y; dy[q].z += t.z; dy[q].w += t.w;
+      }
       const int4 w = wq[q];
       const float4 g = gq[q];
       const int r32 = (int)row;
@@ -356,17 +361,18 @@ int tsgnn_slot_bn_fwd_f32(const int* graph_ptr, const int* slot_count, int B, in
 }
 
 int tsgnn_slot_post_bwd_f32(const int* graph_ptr, const int* slot_count, int B, int nmax, int64_t n_real, int n_ghost,
-                            const float* v, int64_t ldv, const float* dxs, int64_t lddxs, const float* dout, int64_t ldo,
-                            const int* arg, int F, int relu, int bn, const float* mean, const float* rstd, const float* rinv,
-                            float* du, int64_t lddu, tsgnn_stream_t stream) {
-  if (!graph_ptr || !slot_count || !v || !dout || !arg || !rinv || !du || nmax <= 0 || (n_ghost != 0 && n_ghost != nmax) ||
-      (bn && (!mean || !rstd)) || ldv < F || lddu < F || (ldv % 4) || (lddu % 4) || (ldo % 4) || (dxs && (lddxs % 4)))
+                            const float* v, int64_t ldv, const float* dxs, int64_t lddxs, const float* dxs2, int64_t lddxs2,
+                            const float* dout, int64_t ldo, const int* arg, int F, int relu, int bn, const float* mean,
+                            const float* rstd, const float* rinv, float* du, int64_t lddu, tsgnn_stream_t stream) {
+  if (!graph_ptr || !slot_count || !v || ((dout == nullptr) != (arg == nullptr)) || !rinv || !du || nmax <= 0 ||
+      (n_ghost != 0 && n_ghost != nmax) || (bn && (!mean || !rstd)) || ldv < F || lddu < F || (ldv % 4) || (lddu % 4) ||
+      (arg && (ldo % 4)) || (dxs && (lddxs % 4)) || (dxs2 && (lddxs2 % 4)))
     return TSGNN_EINVAL;
   if (!tsgnn_slot_fused_supported(B, F)) return TSGNN_EUNSUPPORTED;
   SlotArgs s{graph_ptr, slot_count, B, nmax, n_real, n_ghost};
   const int nw = B <= 32 ? 4 : (B <= 64 ? 8 : 16);
   const size_t lds = sizeof(float) * ((n_ghost ? (size_t)nw * F : 0) + 2 * nw + 4);
-  TSGNN_SLOT_DISPATCH(slot_post_bwd, nmax, lds, (s, v, ldv, dxs, lddxs, dout, ldo, arg, F / 4, relu, bn, mean, rstd, rinv, du, lddu));
+  TSGNN_SLOT_DISPATCH(slot_post_bwd, nmax, lds, (s, v, ldv, dxs, lddxs, dxs2, lddxs2, dout, ldo, arg, F / 4, relu, bn, mean, rstd, rinv, du, lddu));
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }

@@ -220,6 +220,13 @@ class GcnEncoderGraph(nn.Module):
     def gcn_forward_rows(self, x, g, conv_first, conv_block, conv_last, mask_ghost=False):
         """gcn_forward (encoders.py:140-167) on rows: per-layer outputs concatenated on the feature axis;
         ``mask_ghost`` = multiply by the embedding mask (zeroes every ghost row)."""
+        if FUSED_STACK and not self.per_graph_bn and (mask_ghost or not g.n_ghost):
+            from . import sage_stack
+            convs = [conv_first] + list(conv_block) + [conv_last]
+            if (sage_stack.eligible(g, convs, self.bn, x)
+                    and bool(mp.nat.lib().tsgnn_slot_fused_supported(g.B, convs[0].output_dim))
+                    and bool(mp.nat.lib().tsgnn_slot_fused_supported(g.B, convs[-1].output_dim))):
+                return sage_stack.sage_stack_nodes(x, g, convs, mask_ghost)     # one autograd node, layers write into the cat
         x = self._post(conv_first.forward_rows(x, g), g)
         x_all = [x]
         for conv in conv_block:

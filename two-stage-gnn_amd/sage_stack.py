@@ -68,12 +68,14 @@ def _flush_readout(g, B, sn, sg, pending):
 
 
 class _SageStack(torch.autograd.Function):
-    """forward(x0, g, has_bias, n_head, *conv params[, w1, b1, w2, b2]).  n_head = 0: returns the concatenated readout
+    """forward(x0, g, has_bias, n_head, nodes, *conv params[, w1, b1, w2, b2]).  n_head = 0: returns the concatenated readout
     [B, P].  n_head = 4: the two chained nn.Linear after the readout (encoders.py:207-217) are part of the node: the last
-    layer's readout, the decode of the earlier layers and the head run as ONE launch and (vec, y) are returned."""
+    layer's readout, the decode of the earlier layers and the head run as ONE launch and (vec, y) are returned.
+    nodes = 1 / 2: no readouts; returns the per-layer NODE features concatenated on the feature axis [R, P] (gcn_forward,
+    encoders.py:140-167), 2 = ghost rows zeroed (the embedding mask); layers write straight into the concatenated buffer."""
 
     @staticmethod
-    def forward(ctx, x0, g, has_bias, n_head, *params):
+    def forward(ctx, x0, g, has_bias, n_head, nodes, *params):
         head = params[len(params) - n_head:] if n_head else None
         params = params[:len(params) - n_head] if n_head else params
         L = len(params) // 2
@@ -83,7 +85,8 @@ class _SageStack(torch.autograd.Function):
         R, B = g.total_rows, g.B
         Fh, Fl = Ws[0].size(1), Ws[-1].size(1)
         total = B * ((L - 1) * Fh + Fl)
-        packed = torch.empty(total, dtype=torch.int64, device=dev)      # cleared by the first slot_bn_fwd launch
+        packed = torch.empty(total, dtype=torch.int64, device=dev) if not nodes else None   # cleared by the first slot_bn_fwd launch
+        cat = torch.empty(R, (L - 1) * Fh + Fl, dtype=torch.float32, device=dev) if nodes else None
         x = mp._check(x0, R)
         # Ghost slots actually needed.  Every graph's padded rows at slots >= the largest graph are bitwise identical in
         # every layer (same bias row, same statistics), the max readout breaks ties towards the smallest row, and nothing
@@ -94,6 +97,8 @@ class _SageStack(torch.autograd.Function):
                 Ws[l].size(1) % 4 == 0 and Ws[l].data_ptr() % 16 == 0 and (bs[l] is None or bs[l].data_ptr() % 16 == 0)
                 for l in range(L)):
             gs = min(g.nmax, int(g.sizes.max()) + 1)
+        if nodes == 1:
+            gs = g.n_ghost                                   # unmasked node output: every ghost row is part of the result
         sn, sg = (gs, gs) if g.n_ghost else (g.nmax, 0)      # (slots, ghost rows) handed to the slot kernels
         saved = []
         off = 0
@@ -101,7 +106,10 @@ class _SageStack(torch.autograd.Function):
         keep = []
         for l in range(L):
             K, N = Ws[l].size(0), Ws[l].size(1)
-            v = torch.empty(R, N, dtype=torch.float32, device=dev)
+            if nodes and l == L - 1:
+                v = cat[:, (L - 1) * Fh:]                    # the last layer's output IS its block of the concatenation
+            else:
+                v = torch.empty(R, N, dtype=torch.float32, device=dev)
             rinv = torch.empty(R, dtype=torch.float32, device=dev)
             # Ghost rows aggregate nothing (z = 0): their output is the normalised bias, written by a filler block, and
             # their z is neither produced nor read (255 row panels + 1 filler = one block per CU on the DD batch).
@@ -143,22 +151,33 @@ class _SageStack(torch.autograd.Function):
                         z[g.n_rows:].zero_()
                         lean = False
                     nat.call("linear_l2norm_f32", z, z.stride(0), Ws[l], Ws[l].stride(0), bs[l], v, v.stride(0), rinv, R, K, N, 1)
-            pk = packed[off:off + B * N]
+            pk = packed[off:off + B * N] if not nodes else None
             if l < L - 1:
                 mean = torch.empty(g.nmax, dtype=torch.float32, device=dev)
                 rstd = torch.empty(g.nmax, dtype=torch.float32, device=dev)
-                y = torch.empty_like(v)
+                y = torch.empty_like(v) if not nodes else cat[:, l * Fh:(l + 1) * Fh]
                 nat.call("slot_bn_fwd_f32", g.graph_ptr, g.slot_count, B, sn, g.n_rows, sg, v, v.stride(0), N, 1,
-                         mean, rstd, y, y.stride(0), packed if l == 0 else None, total)
-                pending_ro = (y, pk)                        # rides along with the next layer's product (or is flushed before it)
+                         mean, rstd, y, y.stride(0), packed if (l == 0 and not nodes) else None, total)
+                if not nodes:
+                    pending_ro = (y, pk)                    # rides along with the next layer's product (or is flushed before it)
                 keep.append(y)
                 x = y
             else:
                 mean = rstd = None
-                if head is None:
+                if head is None and not nodes:
                     nat.call("readout_partial_f32", g.graph_ptr, B, sn, g.n_rows, sg, v, v.stride(0), N, pk)
             saved.append((z, v, rinv, mean, rstd, lean))
             off += B * N
+        ctx.nodes = nodes
+        if nodes:
+            if nodes == 2 and g.n_ghost:
+                cat[g.n_rows:].zero_()                       # embedding mask: ghost rows of the node output are zero
+            ctx.g, ctx.L, ctx.has_bias, ctx.dims = g, L, has_bias, (Fh, Fl)
+            ctx.slots = (sn, sg)
+            ctx.Ws, ctx.saved, ctx.arg = Ws, saved, None
+            ctx.params = params
+            ctx.head = None
+            return cat
         out = torch.empty(B, (L - 1) * Fh + Fl, dtype=torch.float32, device=dev)
         arg = torch.empty(total, dtype=torch.int32, device=dev)
         ctx.g, ctx.L, ctx.has_bias, ctx.dims = g, L, has_bias, (Fh, Fl)
@@ -198,7 +217,7 @@ class _SageStack(torch.autograd.Function):
             dev = out.device
             P, E, C = out.size(1), w1c.size(0), w2c.size(0)
             if dy is None and dvec is None:
-                return (None,) * (4 + 2 * L + 4)
+                return (None,) * (5 + 2 * L + 4)
             dy = dy.contiguous() if dy is not None else torch.zeros(B, C, device=dev)
             dvec = dvec.contiguous() if dvec is not None else None
             dout = torch.empty(B, P, dtype=torch.float32, device=dev)
@@ -223,13 +242,19 @@ class _SageStack(torch.autograd.Function):
             K, N = W.size(0), W.size(1)
             last = l == L - 1
             du = torch.empty(R, N, dtype=torch.float32, device=dev)
-            dsl = dout[:, l * Fh:l * Fh + N]
-            argl = ctx.arg[l * B * Fh:l * B * Fh + B * N]
+            if ctx.nodes:
+                dsl = argl = None
+                dnode = dout[:, l * Fh:l * Fh + N]           # gradient of this layer's block of the node output
+            else:
+                dsl = dout[:, l * Fh:l * Fh + N]
+                argl = ctx.arg[l * B * Fh:l * B * Fh + B * N]
+                dnode = None
             nat.call("slot_post_bwd_f32", g.graph_ptr, g.slot_count, B, sn, g.n_rows, sg, v, v.stride(0), dxs,
-                     dxs.stride(0) if dxs is not None else 0, dsl, dout.stride(0), argl, N, 0 if last else 1, 0 if last else 1,
-                     mean, rstd, rinv, du, du.stride(0))
-            want_w = ctx.needs_input_grad[4 + 2 * l]
-            want_b = ctx.has_bias and ctx.needs_input_grad[5 + 2 * l]
+                     dxs.stride(0) if dxs is not None else 0, dnode, dnode.stride(0) if dnode is not None else 0, dsl,
+                     dout.stride(0) if dsl is not None else 0, argl, N, 0 if last else 1, 0 if last else 1, mean, rstd, rinv, du,
+                     du.stride(0))
+            want_w = ctx.needs_input_grad[5 + 2 * l]
+            want_b = ctx.has_bias and ctx.needs_input_grad[6 + 2 * l]
             merged = False
             if (MERGED_BWD and want_w and lean and l > 0 and K == 128 and N == 128 and g.symmetric and z.size(1) == K
                     and _gather_ok(g, du) and z.data_ptr() % 16 == 0 and du.data_ptr() % 16 == 0 and W.data_ptr() % 16 == 0
@@ -305,7 +330,7 @@ class _SageStack(torch.autograd.Function):
                     if ctx.has_bias:
                         sink.normed.add(ctx.params[2 * l_ + 1].data_ptr())
         del keep
-        return (dx0, None, None, None) + tuple(grads) + head_grads
+        return (dx0, None, None, None, None) + tuple(grads) + head_grads
 
 
 def sage_stack_readouts(x, g, convs):
@@ -315,7 +340,17 @@ def sage_stack_readouts(x, g, convs):
     for c in convs:
         params.append(c.weight)
         params.append(c.bias if has_bias else c.weight.new_zeros(1))
-    return _SageStack.apply(x, g, has_bias, 0, *params)
+    return _SageStack.apply(x, g, has_bias, 0, 0, *params)
+
+
+def sage_stack_nodes(x, g, convs, mask_ghost):
+    """per-layer node features concatenated on the feature axis [R, sum F] (gcn_forward, encoders.py:140-167)."""
+    has_bias = convs[0].bias is not None
+    params = []
+    for c in convs:
+        params.append(c.weight)
+        params.append(c.bias if has_bias else c.weight.new_zeros(1))
+    return _SageStack.apply(x, g, has_bias, 0, 2 if (mask_ghost and g.n_ghost) else 1, *params)
 
 
 def head_ok(g, convs, lin1, lin2):
@@ -334,4 +369,4 @@ def sage_stack_head(x, g, convs, lin1, lin2):
     for c in convs:
         params.append(c.weight)
         params.append(c.bias if has_bias else c.weight.new_zeros(1))
-    return _SageStack.apply(x, g, has_bias, 4, *params, lin1.weight, lin1.bias, lin2.weight, lin2.bias)
+    return _SageStack.apply(x, g, has_bias, 4, 0, *params, lin1.weight, lin1.bias, lin2.weight, lin2.bias)
