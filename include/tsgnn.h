@@ -279,10 +279,11 @@ int tsgnn_elu_heads_bwd_f32(const float* x, const float* dy, int64_t rows, int H
 
 /* PyG topk(score, ratio, batch) (call site Code/sag/layers.py:20): for every graph b keep its
  * k_b = k_ptr[b+1]-k_ptr[b] highest-scoring nodes, descending; ties -> smaller node id.
- * perm[k_ptr[b] + t] = global node id.  Graphs of more than tsgnn_topk_max_segment() nodes are unsupported. */
+ * perm[k_ptr[b] + t] = global node id.  new_id (nullable, one int per node): filter_adj's relabelling map, new_id[node] =
+ * its position in perm or -1 when dropped.  Graphs of more than tsgnn_topk_max_segment() nodes are unsupported. */
 int tsgnn_topk_max_segment(void);
 int tsgnn_topk_segments_f32(const float* score, const int* graph_ptr, const int* k_ptr, int B, int max_seg, int* perm,
-                            tsgnn_stream_t stream);
+                            int* new_id, tsgnn_stream_t stream);
 /* out[p,:] = x[perm[p],:] * tanh(score[perm[p]])  (Code/sag/layers.py:21); use_tanh = 0: gate = score */
 int tsgnn_gather_gate_fwd_f32(const float* x, int64_t ldx, const float* score, const int* perm, int64_t K, int F, int use_tanh,
                               float* out, int64_t ldo, tsgnn_stream_t stream);
@@ -294,6 +295,48 @@ int tsgnn_filter_edges_mark(const int* perm, int64_t K, int64_t N, const int64_t
                             int* new_id, int* flag, tsgnn_stream_t stream);
 int tsgnn_filter_edges_compact(const int64_t* src, const int64_t* dst, int64_t E, const int* new_id, const int* flag,
                                const int* pos, int64_t* out_src, int64_t* out_dst, int64_t* kept_eid, tsgnn_stream_t stream);
+/* ---- sync-free SAGPool level (sagpool.hip): the filtered adjacency stays a CSR whose entry count lives on the device.
+ * PyG gcn_norm for unit edge weights as per-row coefficients (GCNConv call sites Code/sag/network.py:19-23, layers.py:12):
+ * dinv[i] = (deg_i + 1)^-1/2, self_w[i] = dinv[i]^2 (an existing self loop is kept instead: +0, self_w = 0). */
+int tsgnn_gcn_coef_f32(const int* rowptr, const int* col, int64_t n_rows, float* dinv, float* self_w, tsgnn_stream_t stream);
+/* out[i] = dinv[i] * sum_{j in N(i)} dinv[j] * x'[j] + self_w[i] * x'[i] (+ bias),  x' = relu_in ? relu(x) : x
+ * = (D^-1/2 (A+I) D^-1/2 x')[i].  y (nullable) receives out; w_dot (nullable): t[i] = <out[i], w_dot> (+ *dot_bias) — the
+ * GCNConv(C -> 1) score layer of SAGPool (layers.py:18) without materialising its input transform.  Symmetric A: the same
+ * call is the backward (A^T = A). */
+int tsgnn_gcn_propagate_f32(const int* rowptr, const int* col, const float* dinv, const float* self_w, const float* x,
+                            int64_t ldx, int relu_in, const float* bias, const float* w_dot, const float* dot_bias, float* y,
+                            int64_t ldy, float* t, int64_t n_rows, int feat, tsgnn_stream_t stream);
+/* 1 when the fused level kernels below accept feature width F (F % 4 == 0, F <= 256) */
+int tsgnn_sag_supported(int F);
+/* kept rows (layers.py:21): xp[p,:] = relu?(y[perm[p],:]) * tanh(score[perm[p]]); cnt[p] = kept neighbours of perm[p].
+ * y = xp = NULL: count only (the transposed adjacency of a non-symmetric graph). */
+int tsgnn_sag_pool_gather_f32(const float* y, int64_t ldy, const float* score, const int* perm, const int* new_id,
+                              const int* rowptr, const int* col, int64_t K, int F, int relu_in, float* xp, int64_t ldo, int* cnt,
+                              tsgnn_stream_t stream);
+/* out[b, :F] (+)= max over the rows of graph b, out[b, F:2F] (+)= their mean (gmp || gap, network.py:36,40,44);
+ * arg[b, f] = row holding the max (ties -> smallest row) */
+int tsgnn_sag_readout_f32(const float* xp, int64_t ld, const int* graph_ptr, int B, int F, int accumulate, float* out, int64_t ldo,
+                          int* arg, tsgnn_stream_t stream);
+/* filter_adj on CSR (layers.py:23-24): new row p = old row perm[p], entries = kept neighbours relabelled by new_id, original
+ * order; rowptr_new = exclusive scan of tsgnn_sag_pool_gather_f32's cnt.  dinv_new/self_w_new (nullable pair): the next
+ * level's tsgnn_gcn_coef_f32 output. */
+int tsgnn_csr_filter_fill(const int* rowptr, const int* col, const int* perm, const int* new_id, int64_t K, const int* rowptr_new,
+                          int* col_new, float* dinv_new, float* self_w_new, tsgnn_stream_t stream);
+/* one-launch exclusive scan for short arrays (n <= 2^20): out[0..n], out[n] = total */
+int tsgnn_scan_short_i32(const int* in, int64_t n, int* out, tsgnn_stream_t stream);
+/* backward of gather + readouts per OLD row r (p = new_id[r]): kept: dtot = dxp[p] (nullable) + dread[b, F:2F] / k_b +
+ * [arg[b,:] == p] dread[b, :F]; dyb[r] = dtot * gate; dscore[r] = (1 - gate^2) <dtot, relu?(y[r])>.  dropped: zeros. */
+int tsgnn_sag_pool_bwd_f32(const float* y, int64_t ldy, const float* score, const int* new_id, const int* row_graph_new,
+                           const int* graph_ptr_new, const int* arg, const float* dxp, int64_t lddxp, const float* dread,
+                           int64_t lddr, int64_t N, int F, int relu_in, float* dyb, int64_t lddy, float* dscore,
+                           tsgnn_stream_t stream);
+/* dyb[r] <- (dyb[r] + dt[r] * w_s) * [y[r] > 0] with dt = A^ dscore (score layer backward folded in);
+ * dws = sum_r dt[r] * relu(y[r]), dbs = sum_r dscore[r] (fixed-order block partials in `part`: tsgnn_sag_du_blocks(N, F)
+ * rows of F + 4 floats; `ticket`: one zero-initialised unsigned the kernel leaves at zero). */
+int tsgnn_sag_du_blocks(int64_t N, int F);
+int tsgnn_sag_du_f32(const int* rowptr, const int* col, const float* dinv, const float* self_w, const float* dscore, const float* y,
+                     int64_t ldy, const float* w_s, float* dyb, int64_t lddy, int64_t N, int F, float* part, unsigned* ticket,
+                     float* dws, float* dbs, tsgnn_stream_t stream);
 int tsgnn_relu_fwd_f32(const float* x, int64_t n, float* y, tsgnn_stream_t stream);
 int tsgnn_relu_bwd_f32(const float* y, const float* dy, int64_t n, float* dx, tsgnn_stream_t stream);
 /* nn.Softmax(dim=-1) over the assignment logits (encoders.py:369) */

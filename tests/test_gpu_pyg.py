@@ -102,17 +102,21 @@ def test_topk_large_segment_and_limits():
         pyg.topk(torch.randn(20000).cuda(), 0.5, None)
 
 
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("sym", [True, False])
 @pytest.mark.parametrize("use_batch", [False, True])
-def test_sagpool_net_vs_oracle(use_batch):
-    """Code/sag Net: 3 x [GCNConv -> ReLU -> SAGPool -> gmp||gap], IMDB-B-like mini-batch."""
+def test_sagpool_net_vs_oracle(use_batch, sym, fused):
+    """Code/sag Net: 3 x [GCNConv -> ReLU -> SAGPool -> gmp||gap], IMDB-B-like mini-batch; the sync-free fused node and the
+    level-by-level composition of the drop-ins, on symmetric and directed edge lists."""
     from two_stage_gnn_amd import sag_layers as S
     sizes = [20, 12, 31, 20, 9, 25]
     n = sum(sizes)
     batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
-    ei = rand_graph(11, n, 700, True, sizes)
+    ei = rand_graph(11, n, 700, sym, sizes)
     x = tie_free(12, n, 5)
     torch.manual_seed(3)
-    net = S.Net(5, 32, 2, 0.5, 0.5, use_batch=use_batch).cuda().eval()
+    net = S.Net(5, 32, 2, 0.5, 0.5, use_batch=use_batch, fused=fused).cuda().eval()
+    assert net._fused_ok() == fused
     with torch.no_grad():
         for k, p in net.named_parameters():
             if k.endswith("bias"):
@@ -134,6 +138,112 @@ def test_sagpool_net_vs_oracle(use_batch):
             continue
         err = (p.grad.cpu() - r).abs().max().item()
         assert err <= 2e-3 * r.abs().max().item() + 1e-6, (k, err)
+
+
+def _csr_rows(rowptr, col, n):
+    rp = rowptr.cpu().numpy()
+    c = col.cpu().numpy()
+    return [c[rp[i]:rp[i + 1]].tolist() for i in range(n)]
+
+
+def test_sag_level_kernels_vs_oracle():
+    """the device-side pieces of one sync-free level against the PyG restatement: normalised propagation, top-k with the
+    relabelling map, CSR filtering (= filter_adj), next-level coefficients, gated gather, max||mean readout"""
+    from two_stage_gnn_amd import _native as nat, sag_stack as SS
+    from two_stage_gnn_amd.graph import GraphBatch
+    sizes = [17, 1, 40, 8, 33, 64]
+    n = sum(sizes)
+    batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
+    ei = rand_graph(21, n, 500, True, sizes)
+    g = GraphBatch.from_edge_index(ei.cuda(), n, ghosts=False)
+    dinv, self_w = SS.gcn_coef(g)
+    for F in (1, 7, 32, 100):
+        x = tie_free(22 + F, n, F)
+        ref = P.gcn_conv(x, ei, torch.eye(F), None)
+        got, _ = SS.propagate(g.rowptr, g.col, dinv, self_w, x.cuda(), n)
+        torch.testing.assert_close(got.cpu(), ref, rtol=1e-5, atol=1e-6)
+    # score-layer mode: (A^ relu(y)) . w + b
+    y, w, b = tie_free(30, n, 32), tie_free(31, 32), tie_free(32, 1)
+    ref = P.gcn_conv(torch.relu(y), ei, w.view(-1, 1), b).view(-1)
+    _, got = SS.propagate(g.rowptr, g.col, dinv, self_w, y.cuda(), n, relu_in=True, w_dot=w.cuda(), dot_bias=b.cuda(), want_y=False)
+    torch.testing.assert_close(got.cpu(), ref, rtol=1e-5, atol=1e-5)
+    # pooling
+    score = tie_free(33, n)
+    plan = SS.SagPlan.get(sizes, 0.5, torch.device("cuda"), depth=2)
+    L, Ln = plan.levels[0], plan.levels[1]
+    K = Ln.N
+    perm = torch.empty(K, dtype=torch.int32, device="cuda"); new_id = torch.empty(n, dtype=torch.int32, device="cuda")
+    nat.call("topk_segments_f32", score.cuda(), L.gp, Ln.gp, L.B, L.max_seg, perm, new_id)
+    ref_perm = P.topk(score, 0.5, batch)
+    np.testing.assert_array_equal(perm.cpu().numpy(), ref_perm.numpy())
+    inv = torch.full((n,), -1, dtype=torch.int64); inv[ref_perm] = torch.arange(K)
+    np.testing.assert_array_equal(new_id.cpu().numpy(), inv.numpy())
+    xp = torch.empty(K, 32, device="cuda"); cnt = torch.empty(K, dtype=torch.int32, device="cuda")
+    nat.call("sag_pool_gather_f32", y.cuda(), 32, score.cuda(), perm, new_id, g.rowptr, g.col, K, 32, 1, xp, 32, cnt)
+    torch.testing.assert_close(xp.cpu(), torch.relu(y)[ref_perm] * torch.tanh(score[ref_perm]).view(-1, 1), rtol=1e-6, atol=1e-6)
+    rp_n = torch.empty(K + 1, dtype=torch.int32, device="cuda"); col_n = torch.full((ei.size(1),), -7, dtype=torch.int32, device="cuda")
+    dinv_n = torch.empty(K, device="cuda"); sw_n = torch.empty(K, device="cuda")
+    nat.call("scan_short_i32", cnt, K, rp_n)
+    nat.call("csr_filter_fill", g.rowptr, g.col, perm, new_id, K, rp_n, col_n, dinv_n, sw_n)
+    ref_ei = P.filter_adj(ei, ref_perm, n)
+    assert int(rp_n[-1]) == ref_ei.size(1)
+    g_ref = GraphBatch.from_edge_index(ref_ei.cuda(), K, ghosts=False)
+    assert _csr_rows(rp_n, col_n, K) == _csr_rows(g_ref.rowptr, g_ref.col, K)      # filter_adj keeps the edge order
+    d_ref, s_ref = SS.gcn_coef(g_ref)
+    torch.testing.assert_close(dinv_n, d_ref, rtol=0, atol=0)
+    torch.testing.assert_close(sw_n, s_ref, rtol=0, atol=0)
+    out = torch.empty(L.B, 64, device="cuda"); arg = torch.empty(L.B, 32, dtype=torch.int32, device="cuda")
+    nat.call("sag_readout_f32", xp, 32, Ln.gp, L.B, 32, 0, out, 64, arg)
+    b2 = batch[ref_perm]
+    ref_out = torch.cat([P.global_max_pool(xp.cpu(), b2, L.B), P.global_mean_pool(xp.cpu(), b2, L.B)], 1)
+    torch.testing.assert_close(out.cpu(), ref_out, rtol=1e-6, atol=1e-6)
+    nat.call("sag_readout_f32", xp, 32, Ln.gp, L.B, 32, 1, out, 64, arg)
+    torch.testing.assert_close(out.cpu(), 2 * ref_out, rtol=1e-6, atol=1e-6)
+    # scan across the single-block tile boundary
+    c = torch.randint(0, 9, (9001,), dtype=torch.int32)
+    o = torch.empty(9002, dtype=torch.int32, device="cuda")
+    nat.call("scan_short_i32", c.cuda(), 9001, o)
+    np.testing.assert_array_equal(o.cpu().numpy(), np.concatenate([[0], np.cumsum(c.numpy())]))
+
+
+def test_sag_step_replays_from_a_hipgraph():
+    """the fused SAGPool step has no host round trip: fwd + bwd captured once, replayed on new features"""
+    from two_stage_gnn_amd import sag_layers as S
+    sizes = [20, 12, 31, 20, 9, 25, 14, 40]
+    n = sum(sizes)
+    batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes)).cuda()
+    ei = rand_graph(41, n, 900, True, sizes).cuda()
+    torch.manual_seed(5)
+    net = S.Net(4, 64, 2, 0.5, 0.0, use_batch=True).cuda().train()
+    lab = (torch.arange(len(sizes)) % 2).cuda()
+
+    class D:
+        pass
+    d = D(); d.x, d.edge_index, d.batch = tie_free(42, n, 4).cuda(), ei, batch
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        def step():
+            net.zero_grad(set_to_none=True)
+            out = net(d)
+            torch.nn.functional.nll_loss(out, lab).backward()
+            return out
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=st):
+            out_g = step()
+        grads_g = {k: p.grad for k, p in net.named_parameters()}
+        d.x.copy_(tie_free(43, n, 4).cuda())
+        gr.replay()
+        torch.cuda.synchronize()
+        got_out = out_g.clone()
+        got = {k: v.clone() for k, v in grads_g.items()}
+        ref_out = step()
+        torch.cuda.synchronize()
+    torch.testing.assert_close(got_out, ref_out.detach(), rtol=0, atol=0)
+    for k, p in net.named_parameters():
+        torch.testing.assert_close(got[k], p.grad, rtol=0, atol=0)
 
 
 def test_sage_graph_gat_conv_sagpooling():

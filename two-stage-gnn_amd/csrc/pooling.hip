@@ -16,13 +16,14 @@ constexpr int TOPK_THREADS = 1024;
 
 __global__ __launch_bounds__(TOPK_THREADS) void topk_segments_kernel(const float* __restrict__ score,
                                                                     const int* __restrict__ graph_ptr,
-                                                                    const int* __restrict__ k_ptr, int* __restrict__ perm) {
+                                                                    const int* __restrict__ k_ptr, int* __restrict__ perm,
+                                                                    int* __restrict__ new_id) {
   extern __shared__ unsigned long long keys[];
   const int b = blockIdx.x;
   const int g0 = graph_ptr[b];
   const int n = graph_ptr[b + 1] - g0;
   const int k0 = k_ptr[b], k = k_ptr[b + 1] - k0;
-  if (n <= 0 || k <= 0) return;
+  if (n <= 0) return;
   int np = 1;
   while (np < n) np <<= 1;
   for (int i = threadIdx.x; i < np; i += TOPK_THREADS) {
@@ -43,8 +44,11 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_segments_kernel(const float
       __syncthreads();
     }
   }
-  for (int i = threadIdx.x; i < k; i += TOPK_THREADS)
-    perm[k0 + i] = g0 + (int)(0xFFFFFFFFu - (unsigned)(keys[i] & 0xFFFFFFFFull));
+  for (int i = threadIdx.x; i < n; i += TOPK_THREADS) {
+    const int node = g0 + (int)(0xFFFFFFFFu - (unsigned)(keys[i] & 0xFFFFFFFFull));
+    if (i < k) perm[k0 + i] = node;
+    if (new_id != nullptr) new_id[node] = (i < k) ? k0 + i : -1;      // filter_adj's relabelling map, -1 = dropped
+  }
 }
 
 // out[p,:] = x[perm[p],:] * gate(score[perm[p]]),  gate = tanh (Code/sag/layers.py:21)
@@ -144,7 +148,7 @@ extern "C" {
 int tsgnn_topk_max_segment(void) { return TOPK_MAX_SEG; }
 
 int tsgnn_topk_segments_f32(const float* score, const int* graph_ptr, const int* k_ptr, int B, int max_seg, int* perm,
-                            tsgnn_stream_t stream) {
+                            int* new_id, tsgnn_stream_t stream) {
   if (!score || !graph_ptr || !k_ptr || !perm || B <= 0 || max_seg < 0) return TSGNN_EINVAL;
   if (max_seg > TOPK_MAX_SEG) return TSGNN_EUNSUPPORTED;
   if (max_seg == 0) return TSGNN_OK;
@@ -153,7 +157,7 @@ int tsgnn_topk_segments_f32(const float* score, const int* graph_ptr, const int*
   const size_t lds = sizeof(unsigned long long) * (size_t)np;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topk_segments_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  topk_segments_kernel<<<B, TOPK_THREADS, lds, stream>>>(score, graph_ptr, k_ptr, perm);
+  topk_segments_kernel<<<B, TOPK_THREADS, lds, stream>>>(score, graph_ptr, k_ptr, perm, new_id);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }

@@ -1,0 +1,538 @@
+// SAGPool level, sync-free: GCN propagation with the symmetric normalisation generated from
+// per-row coefficients, per-graph top-k selection output consumed on the device, CSR -> CSR edge filtering, gated
+// gather, max||mean readout, and the explicit backward of all of it.
+//
+// Replaces, per level of Code/sag/network.py:33-44,
+//     x = relu(conv(x, edge_index)); x, edge_index, _, batch, _ = pool(x, edge_index, None, batch)   (layers.py:14-25)
+//     x_l = cat([gmp(x, batch), gap(x, batch)])
+// where PyG's topk / filter_adj return tensors whose SIZES depend on the data (k is host-computable from the graph
+// sizes; E' is not).  Here the filtered adjacency stays a CSR whose row count is host-known and whose entry count
+// lives in rowptr'[K] on the device, so a level needs no host round trip and the step is hipGraph-capturable.
+//
+// GCN normalisation (PyG gcn_norm, unit edge weights): A^ = D^-1/2 (A + I) D^-1/2 is never materialised per entry:
+//     (A^ x)_i = dinv_i * sum_{j in N(i)} dinv_j x_j + self_w_i x_i,   self_w_i = dinv_i^2 (0 if i has a self loop)
+// HBM/L2-bound gathers: one lane group of G lanes per row, float4 per lane, neighbour indices and their dinv fetched
+// with one coalesced load and broadcast with wave shuffles.  No atomics on data (bitwise reproducible).
+#include "common.h"
+#include "../../include/tsgnn.h"
+
+namespace {
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 relu4(float4 v) {
+  return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+}
+__device__ __forceinline__ void fma4(float4& a, float w, float4 v) {
+  a.x = fmaf(w, v.x, a.x); a.y = fmaf(w, v.y, a.y); a.z = fmaf(w, v.z, a.z); a.w = fmaf(w, v.w, a.w);
+}
+__device__ __forceinline__ float dot4(float4 a, float4 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w))); }
+
+// ---------------------------------------------------------------- dinv / self_w of gcn_norm (unit weights)
+__global__ void gcn_coef_kernel(const int* __restrict__ rowptr, const int* __restrict__ col, int64_t n,
+                                float* __restrict__ dinv, float* __restrict__ self_w) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int e0 = rowptr[i], e1 = rowptr[i + 1];
+  bool has_self = false;                                   // add_remaining_self_loops keeps an existing self loop
+  for (int e = e0; e < e1; ++e) has_self |= (col[e] == (int)i);
+  const float d = (float)(e1 - e0) + (has_self ? 0.f : 1.f);
+  const float di = 1.0f / sqrtf(d);
+  dinv[i] = di;
+  self_w[i] = has_self ? 0.f : di * di;
+}
+
+struct PropArgs {
+  const int* rowptr;
+  const int* col;
+  const float* dinv;
+  const float* self_w;
+  const float* x;
+  int64_t ldx;
+  const float* bias;       // nullable, added after the aggregation
+  const float* w_dot;      // nullable: t[row] = <out[row], w_dot> (+ *dot_bias)
+  const float* dot_bias;   // nullable (1 float)
+  float* y;                // nullable: skip the store (dot-only mode)
+  int64_t ldy;
+  float* t;
+  int64_t n_rows;
+  int feat;
+  int relu_in;             // gather relu(x) instead of x
+};
+
+template <int G>
+__global__ __launch_bounds__(256) void gcn_propagate_vec4(PropArgs a, unsigned nblk) {
+  constexpr int RPB = 256 / G;
+  const unsigned lb = xcd_remap(blockIdx.x, nblk);
+  const int lig = threadIdx.x & (G - 1);
+  const int64_t row = (int64_t)lb * RPB + threadIdx.x / G;
+  if (row >= a.n_rows) return;                              // group-uniform
+  const int nvec = a.feat >> 2;
+  const bool live = lig < nvec;
+  const int64_t co = live ? 4 * lig : 0;
+  const int e0 = a.rowptr[row], e1 = a.rowptr[row + 1];
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int eb = e0; eb < e1; eb += G) {
+    const int me = eb + lig;
+    const int cj = (me < e1) ? a.col[me] : 0;
+    const float dj = (me < e1) ? a.dinv[cj] : 0.f;
+    const int cnt = min(G, e1 - eb);
+    int k = 0;
+    for (; k + 4 <= cnt; k += 4) {
+      const int j0 = __shfl(cj, k, G), j1 = __shfl(cj, k + 1, G), j2 = __shfl(cj, k + 2, G), j3 = __shfl(cj, k + 3, G);
+      float4 v0 = ld4(a.x + (int64_t)j0 * a.ldx + co);
+      float4 v1 = ld4(a.x + (int64_t)j1 * a.ldx + co);
+      float4 v2 = ld4(a.x + (int64_t)j2 * a.ldx + co);
+      float4 v3 = ld4(a.x + (int64_t)j3 * a.ldx + co);
+      if (a.relu_in) { v0 = relu4(v0); v1 = relu4(v1); v2 = relu4(v2); v3 = relu4(v3); }
+      fma4(acc, __shfl(dj, k, G), v0); fma4(acc, __shfl(dj, k + 1, G), v1);
+      fma4(acc, __shfl(dj, k + 2, G), v2); fma4(acc, __shfl(dj, k + 3, G), v3);
+    }
+    for (; k < cnt; ++k) {
+      const int j = __shfl(cj, k, G);
+      float4 v = ld4(a.x + (int64_t)j * a.ldx + co);
+      if (a.relu_in) v = relu4(v);
+      fma4(acc, __shfl(dj, k, G), v);
+    }
+  }
+  const float di = a.dinv[row], sw = a.self_w[row];
+  float4 xs = ld4(a.x + row * a.ldx + co);
+  if (a.relu_in) xs = relu4(xs);
+  float4 o = make_float4(fmaf(di, acc.x, sw * xs.x), fmaf(di, acc.y, sw * xs.y), fmaf(di, acc.z, sw * xs.z), fmaf(di, acc.w, sw * xs.w));
+  if (a.bias != nullptr) {
+    const float4 b = ld4(a.bias + co);
+    o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
+  }
+  if (a.y != nullptr && live) *reinterpret_cast<float4*>(a.y + row * a.ldy + co) = o;
+  if (a.w_dot != nullptr) {
+    float d = live ? dot4(o, ld4(a.w_dot + co)) : 0.f;
+    d = group_sum<G>(d);
+    if (lig == 0) a.t[row] = d + (a.dot_bias ? a.dot_bias[0] : 0.f);
+  }
+}
+
+// any feature width / leading dimension (F = 1 input of IMDB-B, the raw 89-wide DD labels): one wave per row
+__global__ __launch_bounds__(256) void gcn_propagate_generic(PropArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.n_rows) return;
+  const int e0 = a.rowptr[row], e1 = a.rowptr[row + 1];
+  const float di = a.dinv[row], sw = a.self_w[row];
+  float dot = 0.f;
+  for (int fb = 0; fb < a.feat; fb += 64) {                // wave-uniform trip count
+    const int f = fb + lane;
+    const bool live = f < a.feat;
+    const int fo = live ? f : 0;
+    float acc = 0.f;
+    for (int eb = e0; eb < e1; eb += 64) {
+      const int me = eb + lane;
+      const int cj = (me < e1) ? a.col[me] : 0;
+      const float dj = (me < e1) ? a.dinv[cj] : 0.f;
+      const int cnt = min(64, e1 - eb);
+      for (int k = 0; k < cnt; ++k) {
+        const int j = __shfl(cj, k, 64);
+        float v = a.x[(int64_t)j * a.ldx + fo];
+        if (a.relu_in) v = fmaxf(v, 0.f);
+        acc = fmaf(__shfl(dj, k, 64), v, acc);
+      }
+    }
+    float xs = a.x[row * a.ldx + fo];
+    if (a.relu_in) xs = fmaxf(xs, 0.f);
+    float o = fmaf(di, acc, sw * xs);
+    if (a.bias != nullptr) o += a.bias[fo];
+    if (a.y != nullptr && live) a.y[row * a.ldy + f] = o;
+    if (a.w_dot != nullptr && live) dot = fmaf(o, a.w_dot[f], dot);
+  }
+  if (a.w_dot != nullptr) {
+    dot = wave_sum(dot);
+    if (lane == 0) a.t[row] = dot + (a.dot_bias ? a.dot_bias[0] : 0.f);
+  }
+}
+
+// ---------------------------------------------------------------- kept rows: gated gather + kept-neighbour count
+// xp[p,:] = relu?(y[perm[p],:]) * tanh(score[perm[p]])  (layers.py:21) ; cnt[p] = #neighbours of perm[p] that are kept
+template <int G>
+__global__ __launch_bounds__(256) void sag_pool_gather(const float* __restrict__ y, int64_t ldy, const float* __restrict__ score,
+                                                       const int* __restrict__ perm, const int* __restrict__ new_id,
+                                                       const int* __restrict__ rowptr, const int* __restrict__ col, int64_t K,
+                                                       int F, int relu_in, float* __restrict__ xp, int64_t ldo,
+                                                       int* __restrict__ cnt) {
+  constexpr int RPB = 256 / G;
+  const int lig = threadIdx.x & (G - 1);
+  const int64_t p = (int64_t)blockIdx.x * RPB + threadIdx.x / G;
+  if (p >= K) return;
+  const int r = perm[p];
+  const float gate = tanhf(score[r]);
+  const int nvec = F >> 2;
+  if (y != nullptr && lig < nvec) {                         // y == nullptr: count only (the transposed adjacency)
+    float4 v = ld4(y + (int64_t)r * ldy + 4 * lig);
+    if (relu_in) v = relu4(v);
+    *reinterpret_cast<float4*>(xp + p * ldo + 4 * lig) = make_float4(v.x * gate, v.y * gate, v.z * gate, v.w * gate);
+  }
+  float c = 0.f;                                            // exact: degrees are far below 2^24
+  for (int e = rowptr[r] + lig; e < rowptr[r + 1]; e += G) c += (new_id[col[e]] >= 0) ? 1.f : 0.f;
+  c = group_sum<G>(c);
+  if (lig == 0) cnt[p] = (int)c;
+}
+
+// out[b, f] (+)= max_p xp[p, f] ; out[b, F + f] (+)= mean_p xp[p, f]  over the rows of graph b (network.py:36,40,44);
+// arg[b, f] = the row that holds the max (ties -> smallest row).  grid (B, ceil(F / 64)), 64 columns x 4 row lanes.
+__global__ __launch_bounds__(256) void sag_readout_kernel(const float* __restrict__ xp, int64_t ld, const int* __restrict__ gp, int F,
+                                                          int accumulate, float* __restrict__ out, int64_t ldo,
+                                                          int* __restrict__ arg) {
+  __shared__ float s_m[4][64];
+  __shared__ float s_s[4][64];
+  __shared__ int s_a[4][64];
+  const int b = blockIdx.x, c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int f = blockIdx.y * 64 + c;
+  const int p0 = gp[b], p1 = gp[b + 1];
+  float m = -INFINITY, s = 0.f;
+  int am = p0;
+  if (f < F) {
+    for (int p = p0 + rl; p < p1; p += 4) {
+      const float v = xp[(int64_t)p * ld + f];
+      if (v > m) { m = v; am = p; }
+      s += v;
+    }
+  }
+  s_m[rl][c] = m; s_s[rl][c] = s; s_a[rl][c] = am;
+  __syncthreads();
+  if (rl != 0 || f >= F) return;
+#pragma unroll
+  for (int q = 1; q < 4; ++q) {
+    const float v = s_m[q][c];
+    const int a = s_a[q][c];
+    if (v > m || (v == m && a < am)) { m = v; am = a; }
+    s += s_s[q][c];
+  }
+  const float mean = s / (float)max(p1 - p0, 1);
+  float* o = out + (int64_t)b * ldo;
+  if (accumulate) { o[f] += m; o[F + f] += mean; }
+  else { o[f] = m; o[F + f] = mean; }
+  arg[(int64_t)b * F + f] = am;
+}
+
+// ---------------------------------------------------------------- filter_adj on CSR (layers.py:23-24)
+// new row p = old row perm[p]; its entries = the kept neighbours, relabelled, original order.  One wave per new row,
+// ballot + popcount ranks.  Also emits the next level's gcn_norm coefficients (the new degree is known here).
+__global__ __launch_bounds__(256) void csr_filter_fill_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                              const int* __restrict__ perm, const int* __restrict__ new_id, int64_t K,
+                                                              const int* __restrict__ rowptr_new, int* __restrict__ col_new,
+                                                              float* __restrict__ dinv_new, float* __restrict__ self_w_new) {
+  const int lane = threadIdx.x & 63;
+  const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= K) return;
+  const int r = perm[p];
+  const int e0 = rowptr[r], e1 = rowptr[r + 1];
+  int out = rowptr_new[p];
+  bool has_self = false;
+  for (int base = e0; base < e1; base += 64) {
+    const int e = base + lane;
+    const int nid = (e < e1) ? new_id[col[e]] : -1;
+    const bool keep = nid >= 0;
+    const unsigned long long mask = __ballot(keep);
+    if (keep) {
+      col_new[out + __popcll(mask & ((1ull << lane) - 1ull))] = nid;
+      has_self |= (nid == (int)p);
+    }
+    out += __popcll(mask);
+  }
+  const bool any_self = __ballot(has_self) != 0ull;
+  if (lane == 0 && dinv_new != nullptr) {
+    const float d = (float)(out - rowptr_new[p]) + (any_self ? 0.f : 1.f);
+    const float di = 1.0f / sqrtf(d);
+    dinv_new[p] = di;
+    self_w_new[p] = any_self ? 0.f : di * di;
+  }
+}
+
+// ---------------------------------------------------------------- backward of gather + readout, per OLD row
+// kept row r (p = new_id[r] >= 0, graph b):  dtot = dxp[p] + dread[b, F:2F] / k_b + [arg[b,:] == p] dread[b, :F]
+//   dyb[r] = dtot * gate      (gradient w.r.t. relu(y)[r] through the gated gather)
+//   dscore[r] = (1 - gate^2) <dtot, relu(y)[r]>
+// dropped row: dyb[r] = 0, dscore[r] = 0.
+template <int G>
+__global__ __launch_bounds__(256) void sag_pool_bwd(const float* __restrict__ y, int64_t ldy, const float* __restrict__ score,
+                                                    const int* __restrict__ new_id, const int* __restrict__ row_graph_new,
+                                                    const int* __restrict__ gp_new, const int* __restrict__ arg,
+                                                    const float* __restrict__ dxp, int64_t lddxp, const float* __restrict__ dread,
+                                                    int64_t lddr, int64_t N, int F, int relu_in, float* __restrict__ dyb,
+                                                    int64_t lddy, float* __restrict__ dscore) {
+  constexpr int RPB = 256 / G;
+  const int lig = threadIdx.x & (G - 1);
+  const int64_t r = (int64_t)blockIdx.x * RPB + threadIdx.x / G;
+  if (r >= N) return;
+  const int nvec = F >> 2;
+  const bool live = lig < nvec;
+  const int co = live ? 4 * lig : 0;
+  const int p = new_id[r];
+  float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+  float ds = 0.f;
+  if (p >= 0) {                                             // group-uniform
+    const int b = row_graph_new[p];
+    const float inv_k = 1.0f / (float)max(gp_new[b + 1] - gp_new[b], 1);
+    float4 d = dxp ? ld4(dxp + (int64_t)p * lddxp + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 dm = ld4(dread + (int64_t)b * lddr + F + co);
+    const float4 dx = ld4(dread + (int64_t)b * lddr + co);
+    const int4 am = *reinterpret_cast<const int4*>(arg + (int64_t)b * F + co);
+    d.x += dm.x * inv_k + (am.x == p ? dx.x : 0.f);
+    d.y += dm.y * inv_k + (am.y == p ? dx.y : 0.f);
+    d.z += dm.z * inv_k + (am.z == p ? dx.z : 0.f);
+    d.w += dm.w * inv_k + (am.w == p ? dx.w : 0.f);
+    const float gate = tanhf(score[r]);
+    float4 v = ld4(y + r * ldy + co);
+    if (relu_in) v = relu4(v);
+    float dot = live ? dot4(d, v) : 0.f;
+    dot = group_sum<G>(dot);
+    ds = dot * (1.f - gate * gate);
+    g = make_float4(d.x * gate, d.y * gate, d.z * gate, d.w * gate);
+  }
+  if (live) *reinterpret_cast<float4*>(dyb + r * lddy + co) = g;
+  if (lig == 0) dscore[r] = ds;
+}
+
+// du[r] = (dyb[r] + dt[r] * w_s) * [y_pre[r] > 0],  dt = A^ dscore (the score layer's propagate, transposed = itself)
+// + fixed-order partial sums of  dw_s = sum_r dt[r] * relu(y_pre[r])  and  db_s = sum_r dscore[r];  the last block to
+// finish adds the partials up in block order (deterministic) and resets the ticket.
+template <int G>
+__global__ __launch_bounds__(256) void sag_du_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                     const float* __restrict__ dinv, const float* __restrict__ self_w,
+                                                     const float* __restrict__ dscore, const float* __restrict__ y, int64_t ldy,
+                                                     const float* __restrict__ w_s, float* __restrict__ dyb, int64_t lddy, int64_t N,
+                                                     int F, float* __restrict__ part, unsigned* __restrict__ ticket,
+                                                     float* __restrict__ dws, float* __restrict__ dbs) {
+  constexpr int RPB = 256 / G;
+  __shared__ float4 s_part[256];
+  __shared__ float s_ds[256];
+  __shared__ bool s_last;
+  const int lig = threadIdx.x & (G - 1), grp = threadIdx.x / G;
+  const int nvec = F >> 2;
+  const bool live = lig < nvec;
+  const int co = live ? 4 * lig : 0;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float dsum = 0.f;
+  for (int64_t r = (int64_t)blockIdx.x * RPB + grp; r < N; r += (int64_t)gridDim.x * RPB) {   // group-uniform
+    float t = 0.f;
+    const int e1 = rowptr[r + 1];
+    for (int e = rowptr[r] + lig; e < e1; e += G) {
+      const int j = col[e];
+      t = fmaf(dinv[j], dscore[j], t);
+    }
+    t = group_sum<G>(t);
+    const float dsr = dscore[r];
+    const float dt = fmaf(dinv[r], t, self_w[r] * dsr);
+    const float4 v = ld4(y + r * ldy + co);
+    const float4 w = ld4(w_s + co);
+    float4 d = ld4(dyb + r * lddy + co);
+    d.x = v.x > 0.f ? fmaf(dt, w.x, d.x) : 0.f;
+    d.y = v.y > 0.f ? fmaf(dt, w.y, d.y) : 0.f;
+    d.z = v.z > 0.f ? fmaf(dt, w.z, d.z) : 0.f;
+    d.w = v.w > 0.f ? fmaf(dt, w.w, d.w) : 0.f;
+    if (live) *reinterpret_cast<float4*>(dyb + r * lddy + co) = d;
+    fma4(acc, dt, relu4(v));
+    if (lig == 0) dsum += dsr;
+  }
+  s_part[threadIdx.x] = acc;
+  s_ds[threadIdx.x] = (lig == 0) ? dsum : 0.f;
+  __syncthreads();
+  // block partial: thread c < nvec sums the RPB groups' column vectors in group order
+  if ((int)threadIdx.x < nvec) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = 0; q < RPB; ++q) {
+      const float4 v = s_part[q * G + threadIdx.x];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *reinterpret_cast<float4*>(part + (int64_t)blockIdx.x * (F + 4) + 4 * threadIdx.x) = s;
+  }
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int q = 0; q < RPB; ++q) s += s_ds[q * G];
+    part[(int64_t)blockIdx.x * (F + 4) + F] = s;
+  }
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = (atomicAdd(ticket, 1u) == gridDim.x - 1);
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  for (int f = threadIdx.x; f <= F; f += 256) {
+    float s = 0.f;
+    for (unsigned q = 0; q < gridDim.x; ++q) s += part[(int64_t)q * (F + 4) + f];
+    if (f < F) dws[f] = s;
+    else dbs[0] = s;
+  }
+  if (threadIdx.x == 0) *ticket = 0u;
+}
+
+// single-launch scan of a short array (the per-row counts of one pooled level)
+__global__ __launch_bounds__(1024) void scan_short_kernel(const int* __restrict__ in, int n, int* __restrict__ out) {
+  __shared__ int wsum[16];
+  __shared__ int carry_s;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += 4096) {
+    const int i0 = base + threadIdx.x * 4;
+    int v[4];
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[k] = (i0 + k < n) ? in[i0 + k] : 0; s += v[k]; }
+    int inc = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += t;
+    }
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    int wbase = carry_s, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      const int x = wsum[w];
+      if (w < wid) wbase += x;
+      tot += x;
+    }
+    int ex = wbase + inc - s;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (i0 + k < n) out[i0 + k] = ex;
+      ex += v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s += tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[n] = carry_s;
+}
+
+template <int G>
+void launch_prop(const PropArgs& a, hipStream_t s) {
+  const unsigned nblk = (unsigned)ceil_div64(a.n_rows, 256 / G);
+  gcn_propagate_vec4<G><<<nblk, 256, 0, s>>>(a, nblk);
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+inline int group_of(int F) { const int nv = F / 4; return nv <= 8 ? 8 : nv <= 16 ? 16 : nv <= 32 ? 32 : 64; }
+
+}  // namespace
+
+extern "C" {
+
+int tsgnn_gcn_coef_f32(const int* rowptr, const int* col, int64_t n_rows, float* dinv, float* self_w, tsgnn_stream_t stream) {
+  if (n_rows < 0 || !rowptr || !dinv || !self_w) return TSGNN_EINVAL;
+  if (n_rows == 0) return TSGNN_OK;
+  gcn_coef_kernel<<<(unsigned)ceil_div64(n_rows, 256), 256, 0, stream>>>(rowptr, col, n_rows, dinv, self_w);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+int tsgnn_gcn_propagate_f32(const int* rowptr, const int* col, const float* dinv, const float* self_w, const float* x,
+                            int64_t ldx, int relu_in, const float* bias, const float* w_dot, const float* dot_bias, float* y,
+                            int64_t ldy, float* t, int64_t n_rows, int feat, tsgnn_stream_t stream) {
+  if (n_rows < 0 || feat <= 0 || !rowptr || !dinv || !self_w || !x || ldx < feat) return TSGNN_EINVAL;
+  if (!y && !w_dot) return TSGNN_EINVAL;
+  if (y && ldy < feat) return TSGNN_EINVAL;
+  if (w_dot && !t) return TSGNN_EINVAL;
+  if (n_rows == 0) return TSGNN_OK;
+  PropArgs a{rowptr, col, dinv, self_w, x, ldx, bias, w_dot, dot_bias, y, ldy, t, n_rows, feat, relu_in};
+  const bool vec_ok = feat % 4 == 0 && feat <= 256 && ldx % 4 == 0 && aligned16(x) && (!y || (ldy % 4 == 0 && aligned16(y))) &&
+                      (!bias || aligned16(bias)) && (!w_dot || aligned16(w_dot));
+  if (vec_ok) {
+    switch (group_of(feat)) {
+      case 8: launch_prop<8>(a, stream); break;
+      case 16: launch_prop<16>(a, stream); break;
+      case 32: launch_prop<32>(a, stream); break;
+      default: launch_prop<64>(a, stream); break;
+    }
+  } else {
+    gcn_propagate_generic<<<(unsigned)ceil_div64(n_rows, 4), 256, 0, stream>>>(a);
+  }
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+#define SAG_DISPATCH(F, CALL)            \
+  switch (group_of(F)) {                 \
+    case 8: { constexpr int G = 8; CALL; } break;   \
+    case 16: { constexpr int G = 16; CALL; } break; \
+    case 32: { constexpr int G = 32; CALL; } break; \
+    default: { constexpr int G = 64; CALL; } break; \
+  }
+
+int tsgnn_sag_supported(int F) { return (F > 0 && F % 4 == 0 && F <= 256) ? 1 : 0; }
+
+int tsgnn_sag_pool_gather_f32(const float* y, int64_t ldy, const float* score, const int* perm, const int* new_id,
+                              const int* rowptr, const int* col, int64_t K, int F, int relu_in, float* xp, int64_t ldo, int* cnt,
+                              tsgnn_stream_t stream) {
+  if (K < 0 || !score || !perm || !new_id || !rowptr || !cnt || ((y == nullptr) != (xp == nullptr))) return TSGNN_EINVAL;
+  if (!tsgnn_sag_supported(F)) return TSGNN_EUNSUPPORTED;
+  if (y && (ldy % 4 || ldo % 4 || !aligned16(y) || !aligned16(xp) || ldy < F || ldo < F)) return TSGNN_EUNSUPPORTED;
+  if (K == 0) return TSGNN_OK;
+  SAG_DISPATCH(F, (sag_pool_gather<G><<<(unsigned)ceil_div64(K, 256 / G), 256, 0, stream>>>(y, ldy, score, perm, new_id, rowptr, col, K,
+                                                                                            F, relu_in, xp, ldo, cnt)));
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+int tsgnn_sag_readout_f32(const float* xp, int64_t ld, const int* graph_ptr, int B, int F, int accumulate, float* out, int64_t ldo,
+                          int* arg, tsgnn_stream_t stream) {
+  if (B <= 0 || F <= 0 || !xp || !graph_ptr || !out || !arg || ld < F || ldo < 2 * F) return TSGNN_EINVAL;
+  sag_readout_kernel<<<dim3((unsigned)B, (unsigned)((F + 63) / 64)), 256, 0, stream>>>(xp, ld, graph_ptr, F, accumulate, out, ldo, arg);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+int tsgnn_csr_filter_fill(const int* rowptr, const int* col, const int* perm, const int* new_id, int64_t K, const int* rowptr_new,
+                          int* col_new, float* dinv_new, float* self_w_new, tsgnn_stream_t stream) {
+  if (K < 0 || !rowptr || !perm || !new_id || !rowptr_new || !col_new) return TSGNN_EINVAL;
+  if ((dinv_new == nullptr) != (self_w_new == nullptr)) return TSGNN_EINVAL;
+  if (K == 0) return TSGNN_OK;
+  csr_filter_fill_kernel<<<(unsigned)ceil_div64(K, 4), 256, 0, stream>>>(rowptr, col, perm, new_id, K, rowptr_new, col_new, dinv_new,
+                                                                        self_w_new);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+int tsgnn_scan_short_i32(const int* in, int64_t n, int* out, tsgnn_stream_t stream) {
+  if (n < 0 || n > (1 << 20) || !out || (n > 0 && !in)) return TSGNN_EINVAL;
+  scan_short_kernel<<<1, 1024, 0, stream>>>(in, (int)n, out);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+int tsgnn_sag_pool_bwd_f32(const float* y, int64_t ldy, const float* score, const int* new_id, const int* row_graph_new,
+                           const int* graph_ptr_new, const int* arg, const float* dxp, int64_t lddxp, const float* dread,
+                           int64_t lddr, int64_t N, int F, int relu_in, float* dyb, int64_t lddy, float* dscore,
+                           tsgnn_stream_t stream) {
+  if (N < 0 || !y || !score || !new_id || !row_graph_new || !graph_ptr_new || !arg || !dread || !dyb || !dscore) return TSGNN_EINVAL;
+  if (!tsgnn_sag_supported(F) || ldy % 4 || lddy % 4 || lddr % 4 || (dxp && (lddxp % 4 || !aligned16(dxp))) || !aligned16(y) ||
+      !aligned16(dyb) || !aligned16(dread) || !aligned16(arg))
+    return TSGNN_EUNSUPPORTED;
+  if (N == 0) return TSGNN_OK;
+  SAG_DISPATCH(F, (sag_pool_bwd<G><<<(unsigned)ceil_div64(N, 256 / G), 256, 0, stream>>>(y, ldy, score, new_id, row_graph_new,
+                                                                                         graph_ptr_new, arg, dxp, lddxp, dread, lddr, N,
+                                                                                         F, relu_in, dyb, lddy, dscore)));
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+/* blocks of the du kernel for N rows of F features (= rows of the partial-sum workspace, each F + 4 floats) */
+int tsgnn_sag_du_blocks(int64_t N, int F) {
+  if (N <= 0 || !tsgnn_sag_supported(F)) return 0;
+  const int64_t nb = ceil_div64(N, 256 / group_of(F));
+  return (int)(nb < 256 ? nb : 256);
+}
+
+int tsgnn_sag_du_f32(const int* rowptr, const int* col, const float* dinv, const float* self_w, const float* dscore, const float* y,
+                     int64_t ldy, const float* w_s, float* dyb, int64_t lddy, int64_t N, int F, float* part, unsigned* ticket,
+                     float* dws, float* dbs, tsgnn_stream_t stream) {
+  if (N <= 0 || !rowptr || !dinv || !self_w || !dscore || !y || !w_s || !dyb || !part || !ticket || !dws || !dbs) return TSGNN_EINVAL;
+  if (!tsgnn_sag_supported(F) || ldy % 4 || lddy % 4 || !aligned16(y) || !aligned16(dyb) || !aligned16(w_s) || !aligned16(part))
+    return TSGNN_EUNSUPPORTED;
+  const unsigned nb = (unsigned)tsgnn_sag_du_blocks(N, F);
+  SAG_DISPATCH(F, (sag_du_kernel<G><<<nb, 256, 0, stream>>>(rowptr, col, dinv, self_w, dscore, y, ldy, w_s, dyb, lddy, N, F, part, ticket,
+                                                            dws, dbs)));
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+}  // extern "C"

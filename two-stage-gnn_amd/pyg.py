@@ -32,27 +32,52 @@ def _f32(*shape, device, zero=False):
 _graph_cache = {}
 
 
-def graph_of(edge_index, num_nodes):
-    """CSR (rows = targets) of a PyG edge list, cached per edge_index tensor."""
+def graph_of(edge_index, num_nodes, check_symmetry=False):
+    """CSR (rows = targets) of a PyG edge list, cached per edge_index tensor.  ``check_symmetry``: also find out (once per
+    edge list, at ingest) whether every edge has its reverse — all TU datasets do —, in which case backward passes reuse
+    the CSR instead of building its transpose."""
     if not edge_index.is_cuda:
         raise RuntimeError("two_stage_gnn_amd operators run on the GPU only (no CPU fallback)")
     key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, int(num_nodes))
     hit = _graph_cache.get(key)
     if hit is not None and hit[0]() is edge_index:
-        return hit[1]
+        g = hit[1]
+        if check_symmetry and not getattr(g, "_sym_checked", False):
+            _check_symmetry(g, edge_index, num_nodes)
+        return g
     g = GraphBatch.from_edge_index(edge_index, num_nodes, ghosts=False)
+    if check_symmetry:
+        _check_symmetry(g, edge_index, num_nodes)
     if len(_graph_cache) > 16:
         _graph_cache.clear()
     _graph_cache[key] = (weakref.ref(edge_index), g)
     return g
 
 
+def _check_symmetry(g, edge_index, num_nodes):
+    n = int(num_nodes)
+    fwd = torch.sort(edge_index[0] * n + edge_index[1]).values
+    rev = torch.sort(edge_index[1] * n + edge_index[0]).values
+    g.symmetric = bool(torch.equal(fwd, rev))                 # one host sync per distinct edge list (ingest, not the step)
+    g._sym_checked = True
+
+
+def segment_sizes(batch, num_nodes):
+    """np.int64[B] graph sizes of PyG's ``batch`` vector (sorted graph ids); cached on the tensor object, so a mini-batch
+    pays the host round trip once (a CSR-native collate can set ``batch._tsgnn_sizes`` itself and pay none)."""
+    if batch is None:
+        return np.array([int(num_nodes)], dtype=np.int64)
+    hit = getattr(batch, "_tsgnn_sizes", None)
+    if hit is not None and hit[0] == batch._version:
+        return hit[1]
+    sizes = torch.bincount(batch).cpu().numpy().astype(np.int64)
+    batch._tsgnn_sizes = (batch._version, sizes)
+    return sizes
+
+
 def _segments(batch, num_nodes, device):
     """batch[N] (sorted graph ids, PyG convention) -> (sizes np.int64[B], graph_ptr int32[B+1] on device)."""
-    if batch is None:
-        sizes = np.array([num_nodes], dtype=np.int64)
-    else:
-        sizes = torch.bincount(batch).cpu().numpy().astype(np.int64)
+    sizes = segment_sizes(batch, num_nodes)
     gp = np.zeros(len(sizes) + 1, dtype=np.int32)
     np.cumsum(sizes, out=gp[1:])
     return sizes, torch.from_numpy(gp).to(device)
@@ -156,7 +181,7 @@ def topk(x, ratio, batch, min_score=None):
     kp = np.zeros(len(k) + 1, dtype=np.int32)
     np.cumsum(k, out=kp[1:])
     perm = torch.empty(max(int(kp[-1]), 1), dtype=torch.int32, device=score.device)
-    nat.call("topk_segments_f32", score, gp, torch.from_numpy(kp).to(score.device), len(sizes), int(sizes.max()), perm)
+    nat.call("topk_segments_f32", score, gp, torch.from_numpy(kp).to(score.device), len(sizes), int(sizes.max()), perm, None)
     return perm[: int(kp[-1])].long()
 
 

@@ -36,12 +36,15 @@ class SAGPool(nn.Module):
 class Net(nn.Module):
     """Code/sag/network.py:9-53.  ``use_batch=False`` reproduces the reference, which throws data.batch away
     (network.py:32, trap T6: a mini-batch is pooled as ONE graph); ``use_batch=True`` gives PyG's per-graph
-    semantics."""
+    semantics.  ``fused=True`` (default) runs the three conv -> pool -> readout levels as the sync-free ``sag_stack`` node
+    (hipGraph-capturable); ``fused=False`` composes the PyG-named drop-ins level by level as the reference does (three
+    host round trips per level for the data-dependent tensor sizes)."""
 
-    def __init__(self, num_features, nhid, num_classes, pooling_ratio, dropout_ratio, use_batch=False):
+    def __init__(self, num_features, nhid, num_classes, pooling_ratio, dropout_ratio, use_batch=False, fused=True):
         super().__init__()
         self.num_features, self.nhid, self.num_classes = num_features, nhid, num_classes
         self.pooling_ratio, self.dropout_ratio, self.use_batch = pooling_ratio, dropout_ratio, use_batch
+        self.fused = fused
         self.conv1 = GCNConv(self.num_features, self.nhid)
         self.pool1 = SAGPool(self.nhid, ratio=self.pooling_ratio)
         self.conv2 = GCNConv(self.nhid, self.nhid)
@@ -53,7 +56,32 @@ class Net(nn.Module):
         self.lin2 = nn.Linear(self.nhid, self.nhid // 2).to(dev)
         self.lin3 = nn.Linear(self.nhid // 2, self.num_classes).to(dev)
 
+    def _fused_ok(self):
+        from . import sag_stack
+        pools = (self.pool1, self.pool2, self.pool3)
+        return (self.fused and sag_stack.supported(self.nhid) and all(p.non_linearity is torch.tanh for p in pools)
+                and all(isinstance(p.score_layer, GCNConv) and p.score_layer.bias is not None for p in pools)
+                and all(c.bias is not None for c in (self.conv1, self.conv2, self.conv3)))
+
+    def _forward_fused(self, data):
+        from . import sag_stack
+        x = data.x
+        g = data.edge_index if isinstance(data.edge_index, pyg.GraphBatch) else pyg.graph_of(data.edge_index, x.size(0), check_symmetry=True)
+        batch = getattr(data, "batch", None) if self.use_batch else None
+        sizes = pyg.segment_sizes(batch, x.size(0))
+        plan = sag_stack.SagPlan.get(sizes, self.pooling_ratio, x.device, depth=3)
+        params = []
+        for conv, pool in ((self.conv1, self.pool1), (self.conv2, self.pool2), (self.conv3, self.pool3)):
+            params += [conv.weight, conv.bias, pool.score_layer.weight, pool.score_layer.bias]
+        return sag_stack.sag_stack(x, g, plan, params)
+
     def forward(self, data):
+        if self._fused_ok():
+            x = self._forward_fused(data)                                # network.py:33-46 in one node
+            x = F.relu(self.lin1(x))
+            x = F.dropout(x, p=self.dropout_ratio, training=self.training)
+            x = F.relu(self.lin2(x))
+            return F.log_softmax(self.lin3(x), dim=-1)
         x, edge_index = data.x, data.edge_index
         batch = getattr(data, "batch", None) if self.use_batch else None
         outs = []

@@ -1,0 +1,226 @@
+"""The three conv -> SAGPool -> readout levels of Code/sag/network.py:33-44 as ONE autograd node with no host round trip.
+
+PyG's ``topk`` / ``filter_adj`` (layers.py:20-24) return tensors whose sizes depend on the data, so the reference path
+(and the composable drop-ins in ``pyg.py``) synchronise with the host three times per level.  Two facts remove that:
+  * k_b = ceil(ratio * n_b) depends on the graph SIZES only, so every level's row count, graph pointer and row -> graph
+    map are host-known before the step starts (``SagPlan``, cached per mini-batch structure);
+  * the filtered adjacency is only ever consumed by the next level's kernels, so it stays a CSR whose entry count lives
+    in ``rowptr'[K]`` on the device (``tsgnn_csr_filter_fill``).
+A step is therefore capturable in a hipGraph.  Per level (csrc/sagpool.hip):
+  forward   agg = A^ x            (gcn_propagate; A^ = D^-1/2 (A+I) D^-1/2 from per-row coefficients)
+            y   = agg W + b       (fp32 MFMA row-panel product; (A^ x) W = A^ (x W), GCNConv network.py:34)
+            s   = (A^ relu(y)) w_s + b_s   (score layer GCNConv(C -> 1), layers.py:18, without its [N,1] intermediate)
+            perm, new_id = topk(s)         (one workgroup per graph, LDS bitonic sort)
+            xp  = relu(y)[perm] * tanh(s[perm]) ; cnt = kept neighbours      (layers.py:21)
+            out += [max || mean](xp)       (network.py:36,40,44 and the sum :46)
+            A'  = filter(A)                (scan of cnt + fill; also the next level's coefficients)
+  backward  pool_bwd -> du (score layer folded in) -> dW, db in one pass -> dagg = du W^T -> dx = A^ dagg
+ReLU is applied by the consumers of ``y`` (it is stored pre-activation), so no activation tensor is written.
+"""
+import numpy as np
+import torch
+
+from . import _native as nat
+from . import message_passing as mp
+
+_f32 = mp._f32
+
+
+def _i32(*shape, device):
+    return torch.empty(*shape, dtype=torch.int32, device=device)
+
+
+class _Level:
+    __slots__ = ("B", "N", "sizes", "gp", "row_graph", "max_seg", "batch_vec")
+
+
+class SagPlan:
+    """Host-known structure of a SAGPool pipeline over one mini-batch: rows, graph pointers and row -> graph maps of
+    the input level and of every pooled level.  Built once per (sizes, ratio) and cached: steady-state steps upload
+    nothing."""
+
+    _cache = {}
+
+    def __init__(self, sizes, ratio, device, depth):
+        sizes = np.asarray(sizes, dtype=np.int64).reshape(-1)
+        if sizes.size == 0 or (sizes < 1).any():
+            raise ValueError("every graph needs at least one node")
+        self.ratio, self.depth, self.device = float(ratio), int(depth), device
+        self.levels = []
+        for _ in range(depth + 1):
+            L = _Level()
+            L.B, L.N, L.sizes, L.max_seg = int(sizes.size), int(sizes.sum()), sizes, int(sizes.max())
+            gp = np.zeros(L.B + 1, dtype=np.int32)
+            np.cumsum(sizes, out=gp[1:])
+            L.gp = torch.from_numpy(gp).to(device)
+            L.row_graph = torch.from_numpy(np.repeat(np.arange(L.B, dtype=np.int32), sizes)).to(device)
+            L.batch_vec = None
+            self.levels.append(L)
+            k = np.ceil(np.float32(ratio) * sizes.astype(np.float32)).astype(np.int64)      # float32, as PyG's topk computes it
+            sizes = np.minimum(k, sizes)
+        if self.levels[0].max_seg > int(nat.lib().tsgnn_topk_max_segment()):
+            raise RuntimeError("graphs of more than %d nodes are not supported by the LDS top-k" % nat.lib().tsgnn_topk_max_segment())
+
+    @classmethod
+    def get(cls, sizes, ratio, device, depth=3):
+        sizes = np.asarray(sizes, dtype=np.int64).reshape(-1)
+        key = (sizes.tobytes(), float(ratio), str(device), int(depth))
+        plan = cls._cache.get(key)
+        if plan is None:
+            if len(cls._cache) > 64:
+                cls._cache.clear()
+            plan = cls._cache[key] = cls(sizes, ratio, device, depth)
+        return plan
+
+
+_tickets = {}
+
+
+def _ticket(device):
+    t = _tickets.get(str(device))
+    if t is None:
+        t = _tickets[str(device)] = torch.zeros(1, dtype=torch.int32, device=device)
+    return t
+
+
+def gcn_coef(g):
+    """(dinv, self_w) of PyG gcn_norm for the unit-weight graph g, cached on it."""
+    c = getattr(g, "_gcn_coef", None)
+    if c is None:
+        R = g.total_rows
+        dinv, self_w = _f32(R, device=g.device), _f32(R, device=g.device)
+        nat.call("gcn_coef_f32", g.rowptr, g.col, R, dinv, self_w)
+        c = g._gcn_coef = (dinv, self_w)
+    return c
+
+
+def propagate(rowptr, col, dinv, self_w, x, n_rows, relu_in=False, bias=None, w_dot=None, dot_bias=None, want_y=True):
+    """A^ x (+ bias) and / or its dot with w_dot; see tsgnn_gcn_propagate_f32."""
+    F = x.size(1)
+    y = _f32(n_rows, F, device=x.device) if want_y else None
+    t = _f32(n_rows, device=x.device) if w_dot is not None else None
+    nat.call("gcn_propagate_f32", rowptr, col, dinv, self_w, x, x.stride(0), int(relu_in), bias, w_dot, dot_bias, y,
+             y.stride(0) if want_y else 0, t, int(n_rows), int(F))
+    return y, t
+
+
+def _linear(z, w, bias):
+    """z @ w + bias, w stored [in, out]"""
+    R, K, N = z.size(0), w.size(0), w.size(1)
+    v = _f32(R, N, device=z.device)
+    if mp.rowgemm_ok(z, z.stride(0), w, w.stride(0), K, N, False):
+        nat.call("rowgemm_f32", z, z.stride(0), w, w.stride(0), 0, bias, v, v.stride(0), None, R, K, N, 0, 0)
+    else:
+        nat.call("linear_l2norm_f32", z, z.stride(0), w, w.stride(0), bias, v, v.stride(0), None, R, K, N, 0)
+    return v
+
+
+def _linear_t(du, w):
+    """du @ w^T, w stored [in, out] -> [rows, in]"""
+    R, K, N = du.size(0), w.size(0), w.size(1)
+    dz = _f32(R, K, device=du.device)
+    if mp.rowgemm_ok(du, du.stride(0), w, w.stride(0), N, K, True):
+        nat.call("rowgemm_f32", du, du.stride(0), w, w.stride(0), 1, None, dz, dz.stride(0), None, R, N, K, 0, 0)
+    else:
+        mp.gemm(du, du.stride(0), 1, w, 1, w.stride(0), dz, dz.stride(0), 1, R, K, N)
+    return dz
+
+
+def supported(hidden):
+    return bool(nat.lib().tsgnn_sag_supported(int(hidden)))
+
+
+class _SagStack(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, g, plan, *params):
+        depth = plan.depth
+        if len(params) != 4 * depth:
+            raise ValueError("expected (weight, bias, score weight, score bias) per level")
+        if plan.levels[0].N != g.total_rows or x.size(0) != g.total_rows:
+            raise ValueError("plan, graph and features disagree on the number of nodes")
+        if g.val is not None:
+            raise NotImplementedError("edge weights are never passed by the reference (network.py:34)")
+        dev = x.device
+        x = x.contiguous().float()
+        H = params[0].size(1)
+        B = plan.levels[0].B
+        rowptr, col = g.rowptr, g.col
+        dinv, self_w = gcn_coef(g)
+        sym = bool(g.symmetric)
+        rowptr_t, col_t = (rowptr, col) if sym else g.transposed(None)[:2]
+        nnz_bound = max(int(col.numel()), 1)
+        read = _f32(B, 2 * H, device=dev)
+        saved = []
+        xin = x
+        for l in range(depth):
+            L, Ln = plan.levels[l], plan.levels[l + 1]
+            N, K = L.N, Ln.N
+            W, b, ws, bs = params[4 * l: 4 * l + 4]
+            W = W.contiguous()
+            wsv = ws.contiguous().view(-1)
+            agg, _ = propagate(rowptr, col, dinv, self_w, xin, N)
+            y = _linear(agg, W, b)
+            _, score = propagate(rowptr, col, dinv, self_w, y, N, relu_in=True, w_dot=wsv, dot_bias=bs, want_y=False)
+            perm, new_id = _i32(max(K, 1), device=dev), _i32(max(N, 1), device=dev)
+            nat.call("topk_segments_f32", score, L.gp, Ln.gp, B, L.max_seg, perm, new_id)
+            xp, cnt = _f32(K, H, device=dev), _i32(max(K, 1), device=dev)
+            nat.call("sag_pool_gather_f32", y, y.stride(0), score, perm, new_id, rowptr, col, K, H, 1, xp, xp.stride(0), cnt)
+            arg = _i32(B, H, device=dev)
+            nat.call("sag_readout_f32", xp, xp.stride(0), Ln.gp, B, H, int(l > 0), read, read.stride(0), arg)
+            saved.append((xin, agg, y, score, new_id, arg, rowptr, col, rowptr_t, col_t, dinv, self_w, W, wsv))
+            if l + 1 < depth:                                   # the adjacency after the last pool is never used
+                rp_n, col_n = _i32(K + 1, device=dev), _i32(nnz_bound, device=dev)
+                dinv_n, self_w_n = _f32(K, device=dev), _f32(K, device=dev)
+                nat.call("scan_short_i32", cnt, K, rp_n)
+                nat.call("csr_filter_fill", rowptr, col, perm, new_id, K, rp_n, col_n, dinv_n, self_w_n)
+                if sym:
+                    rp_tn, col_tn = rp_n, col_n
+                else:
+                    cnt_t = _i32(max(K, 1), device=dev)
+                    nat.call("sag_pool_gather_f32", None, 0, score, perm, new_id, rowptr_t, col_t, K, H, 0, None, 0, cnt_t)
+                    rp_tn, col_tn = _i32(K + 1, device=dev), _i32(nnz_bound, device=dev)
+                    nat.call("scan_short_i32", cnt_t, K, rp_tn)
+                    nat.call("csr_filter_fill", rowptr_t, col_t, perm, new_id, K, rp_tn, col_tn, None, None)
+                rowptr, col, rowptr_t, col_t, dinv, self_w = rp_n, col_n, rp_tn, col_tn, dinv_n, self_w_n
+            xin = xp
+        ctx.plan, ctx.saved_levels, ctx.H = plan, saved, H
+        ctx.x_needs_grad = x.requires_grad
+        return read
+
+    @staticmethod
+    def backward(ctx, dread):
+        plan, H = ctx.plan, ctx.H
+        depth = plan.depth
+        dread = dread.contiguous()
+        dev = dread.device
+        grads = [None] * (4 * depth)
+        dxp = None
+        dx = None
+        for l in range(depth - 1, -1, -1):
+            L, Ln = plan.levels[l], plan.levels[l + 1]
+            N = L.N
+            xin, agg, y, score, new_id, arg, rowptr, col, rowptr_t, col_t, dinv, self_w, W, wsv = ctx.saved_levels[l]
+            dyb, dscore = _f32(N, H, device=dev), _f32(N, device=dev)
+            nat.call("sag_pool_bwd_f32", y, y.stride(0), score, new_id, Ln.row_graph, Ln.gp, arg, dxp,
+                     dxp.stride(0) if dxp is not None else 0, dread, dread.stride(0), N, H, 1, dyb, dyb.stride(0), dscore)
+            nb = int(nat.lib().tsgnn_sag_du_blocks(N, H))
+            part, dws, dbs = _f32(nb * (H + 4), device=dev), _f32(H, device=dev), _f32(1, device=dev)
+            # dt = A^T dscore: the score layer's propagate transposed
+            nat.call("sag_du_f32", rowptr_t, col_t, dinv, self_w, dscore, y, y.stride(0), wsv, dyb, dyb.stride(0), N, H, part,
+                     _ticket(dev), dws, dbs)
+            dW, db = mp.linear_wgrad(agg, agg.size(1), dyb, True)
+            grads[4 * l: 4 * l + 4] = [dW, db, dws.view(-1, 1), dbs]
+            if l > 0 or ctx.x_needs_grad:
+                dagg = _linear_t(dyb, W)
+                dxin, _ = propagate(rowptr_t, col_t, dinv, self_w, dagg, N)
+                if l > 0:
+                    dxp = dxin
+                else:
+                    dx = dxin
+        return (dx, None, None, *grads)
+
+
+def sag_stack(x, g, plan, params):
+    """readout[B, 2H] = sum over the levels of [gmp || gap] (network.py:36-46).  params: per level
+    (conv weight [in, H], conv bias [H], score weight [H, 1], score bias [1])."""
+    return _SagStack.apply(x, g, plan, *params)
