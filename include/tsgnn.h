@@ -332,11 +332,11 @@ int tsgnn_sag_pool_bwd_f32(const float* y, int64_t ldy, const float* score, cons
                            tsgnn_stream_t stream);
 /* dyb[r] <- (dyb[r] + dt[r] * w_s) * [y[r] > 0] with dt = A^ dscore (score layer backward folded in);
  * dws = sum_r dt[r] * relu(y[r]), dbs = sum_r dscore[r] (fixed-order block partials in `part`: tsgnn_sag_du_blocks(N, F)
- * rows of F + 4 floats; `ticket`: one zero-initialised unsigned the kernel leaves at zero). */
+ * rows of F + 4 floats, summed by a second one-block launch). */
 int tsgnn_sag_du_blocks(int64_t N, int F);
 int tsgnn_sag_du_f32(const int* rowptr, const int* col, const float* dinv, const float* self_w, const float* dscore, const float* y,
-                     int64_t ldy, const float* w_s, float* dyb, int64_t lddy, int64_t N, int F, float* part, unsigned* ticket,
-                     float* dws, float* dbs, tsgnn_stream_t stream);
+                     int64_t ldy, const float* w_s, float* dyb, int64_t lddy, int64_t N, int F, float* part, float* dws, float* dbs,
+                     tsgnn_stream_t stream);
 int tsgnn_relu_fwd_f32(const float* x, int64_t n, float* y, tsgnn_stream_t stream);
 int tsgnn_relu_bwd_f32(const float* y, const float* dy, int64_t n, float* dx, tsgnn_stream_t stream);
 /* nn.Softmax(dim=-1) over the assignment logits (encoders.py:369) */

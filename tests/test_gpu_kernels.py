@@ -332,3 +332,21 @@ def test_gather_rowgemm_equals_aggregate_then_product(T, K, ld, N, trans_b, p_ed
         torch.testing.assert_close(rinv, rinv_ref, rtol=2e-5, atol=0)
         kp = (K + 3) // 4 * 4
         torch.testing.assert_close(z[:nreal, :kp], z_ref[:nreal, :kp], rtol=1e-5, atol=1e-5)       # summation order differs
+
+
+@pytest.mark.parametrize("R,K,N", [(128, 256, 128), (128, 128, 64), (128, 64, 2), (37, 50, 7)])
+def test_linear_oi_matches_torch_linear(R, K, N):
+    """x W^T + b with W in torch.nn.Linear's [out, in] layout (the SAGPool head, network.py:25-27,48-51)"""
+    from two_stage_gnn_amd import message_passing as mp
+    g = torch.Generator().manual_seed(R + K + N)
+    x, w, b = torch.randn(R, K, generator=g), torch.randn(N, K, generator=g) * 0.1, torch.randn(N, generator=g)
+    gy = torch.randn(R, N, generator=g)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = torch.nn.functional.linear(xr, wr, br)
+    (ref * gy).sum().backward()
+    xg, wg, bg = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    out = mp.linear_oi(xg, wg, bg)
+    (out * gy.cuda()).sum().backward()
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-4)
+    for a, c in ((xg, xr), (wg, wr), (bg, br)):
+        torch.testing.assert_close(a.grad.cpu(), c.grad, rtol=1e-4, atol=1e-4)

@@ -291,19 +291,18 @@ __global__ __launch_bounds__(256) void sag_pool_bwd(const float* __restrict__ y,
 }
 
 // du[r] = (dyb[r] + dt[r] * w_s) * [y_pre[r] > 0],  dt = A^ dscore (the score layer's propagate, transposed = itself)
-// + fixed-order partial sums of  dw_s = sum_r dt[r] * relu(y_pre[r])  and  db_s = sum_r dscore[r];  the last block to
-// finish adds the partials up in block order (deterministic) and resets the ticket.
+// + per-block partial sums of  dw_s = sum_r dt[r] * relu(y_pre[r])  and  db_s = sum_r dscore[r]  (block b -> part[b, 0:F] and
+// part[b, F]); sag_du_reduce adds them up in a fixed order.  (A last-block-done reduction inside this kernel was measured
+// at 22 us per launch: the device-scope release fence of 256 blocks costs more than a 3 us launch.)
 template <int G>
 __global__ __launch_bounds__(256) void sag_du_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
                                                      const float* __restrict__ dinv, const float* __restrict__ self_w,
                                                      const float* __restrict__ dscore, const float* __restrict__ y, int64_t ldy,
                                                      const float* __restrict__ w_s, float* __restrict__ dyb, int64_t lddy, int64_t N,
-                                                     int F, float* __restrict__ part, unsigned* __restrict__ ticket,
-                                                     float* __restrict__ dws, float* __restrict__ dbs) {
+                                                     int F, float* __restrict__ part) {
   constexpr int RPB = 256 / G;
   __shared__ float4 s_part[256];
   __shared__ float s_ds[256];
-  __shared__ bool s_last;
   const int lig = threadIdx.x & (G - 1), grp = threadIdx.x / G;
   const int nvec = F >> 2;
   const bool live = lig < nvec;
@@ -348,19 +347,38 @@ __global__ __launch_bounds__(256) void sag_du_kernel(const int* __restrict__ row
     for (int q = 0; q < RPB; ++q) s += s_ds[q * G];
     part[(int64_t)blockIdx.x * (F + 4) + F] = s;
   }
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) s_last = (atomicAdd(ticket, 1u) == gridDim.x - 1);
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();
-  for (int f = threadIdx.x; f <= F; f += 256) {
-    float s = 0.f;
-    for (unsigned q = 0; q < gridDim.x; ++q) s += part[(int64_t)q * (F + 4) + f];
-    if (f < F) dws[f] = s;
-    else dbs[0] = s;
+}
+
+
+// dws[0:F], dbs[0] = column sums of part[nb, F + 4]: 8 slices of blocks per float4 column, then the slices in order
+__global__ __launch_bounds__(256) void sag_du_reduce(const float* __restrict__ part, int nb, int F, float* __restrict__ dws,
+                                                     float* __restrict__ dbs) {
+  __shared__ float4 s_part[256];
+  const int nvec = F >> 2;
+  const int c4 = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  for (int cb = 0; cb < nvec + 1; cb += 32) {                       // column nvec = the db_s partial (lane .x)
+    const int c = cb + c4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c <= nvec) {
+#pragma unroll 4
+      for (int q = sl; q < nb; q += 8) {
+        const float4 v = *reinterpret_cast<const float4*>(part + (int64_t)q * (F + 4) + 4 * c);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+    }
+    __syncthreads();
+    s_part[threadIdx.x] = s;
+    __syncthreads();
+    if (sl == 0 && c <= nvec) {
+#pragma unroll
+      for (int q = 1; q < 8; ++q) {
+        const float4 v = s_part[q * 32 + c4];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      if (c < nvec) *reinterpret_cast<float4*>(dws + 4 * c) = s;
+      else dbs[0] = s.x;
+    }
   }
-  if (threadIdx.x == 0) *ticket = 0u;
 }
 
 // single-launch scan of a short array (the per-row counts of one pooled level)
@@ -523,14 +541,14 @@ int tsgnn_sag_du_blocks(int64_t N, int F) {
 }
 
 int tsgnn_sag_du_f32(const int* rowptr, const int* col, const float* dinv, const float* self_w, const float* dscore, const float* y,
-                     int64_t ldy, const float* w_s, float* dyb, int64_t lddy, int64_t N, int F, float* part, unsigned* ticket,
-                     float* dws, float* dbs, tsgnn_stream_t stream) {
-  if (N <= 0 || !rowptr || !dinv || !self_w || !dscore || !y || !w_s || !dyb || !part || !ticket || !dws || !dbs) return TSGNN_EINVAL;
+                     int64_t ldy, const float* w_s, float* dyb, int64_t lddy, int64_t N, int F, float* part, float* dws, float* dbs,
+                     tsgnn_stream_t stream) {
+  if (N <= 0 || !rowptr || !dinv || !self_w || !dscore || !y || !w_s || !dyb || !part || !dws || !dbs) return TSGNN_EINVAL;
   if (!tsgnn_sag_supported(F) || ldy % 4 || lddy % 4 || !aligned16(y) || !aligned16(dyb) || !aligned16(w_s) || !aligned16(part))
     return TSGNN_EUNSUPPORTED;
   const unsigned nb = (unsigned)tsgnn_sag_du_blocks(N, F);
-  SAG_DISPATCH(F, (sag_du_kernel<G><<<nb, 256, 0, stream>>>(rowptr, col, dinv, self_w, dscore, y, ldy, w_s, dyb, lddy, N, F, part, ticket,
-                                                            dws, dbs)));
+  SAG_DISPATCH(F, (sag_du_kernel<G><<<nb, 256, 0, stream>>>(rowptr, col, dinv, self_w, dscore, y, ldy, w_s, dyb, lddy, N, F, part)));
+  sag_du_reduce<<<1, 256, 0, stream>>>(part, (int)nb, F, dws, dbs);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }

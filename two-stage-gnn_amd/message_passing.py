@@ -237,6 +237,52 @@ def linear_l2norm(z, weight, bias=None, normalize=True):
     return _LinearL2Norm.apply(z, weight, bias, bool(normalize))
 
 
+class _LinearOI(torch.autograd.Function):
+    """y = x W^T + b with W stored [out, in] (torch.nn.Linear's layout) on the fp32 MFMA row-panel kernels: no transposed
+    copy of the weight, dW and db from one pass over the rows."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = _check(x)
+        w = weight.contiguous()
+        N, K = w.size(0), w.size(1)
+        R = x.size(0)
+        y = _f32(R, N, device=x.device)
+        if rowgemm_ok(x, x.stride(0), w, w.stride(0), K, N, True):
+            nat.call("rowgemm_f32", x, x.stride(0), w, w.stride(0), 1, bias, y, y.stride(0), None, R, K, N, 0, 0)
+        else:
+            gemm(x, x.stride(0), 1, w, 1, w.stride(0), y, y.stride(0), 1, R, N, K)
+            if bias is not None:
+                nat.call("broadcast_add_f32", y, y.stride(0), R, 1, N, None, bias, N, None, 0, 0, 1.0)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _check(dy)
+        R, N, K = dy.size(0), w.size(0), w.size(1)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _f32(R, K, device=dy.device)
+            if rowgemm_ok(dy, dy.stride(0), w, w.stride(0), N, K, False):                   # dX = dY W
+                nat.call("rowgemm_f32", dy, dy.stride(0), w, w.stride(0), 0, None, dx, dx.stride(0), None, R, N, K, 0, 0)
+            else:
+                gemm(dy, dy.stride(0), 1, w, w.stride(0), 1, dx, dx.stride(0), 1, R, K, N)
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1]:
+            dwt, db = linear_wgrad(x, K, dy, want_db)                                        # (dW)^T = X^T dY [in, out]
+            dw = dwt.t()
+        elif want_db:
+            db = colsum(dy)
+        return dx, dw, db
+
+
+def linear_oi(x, weight, bias=None):
+    return _LinearOI.apply(x, weight, bias)
+
+
 # ----------------------------------------------------------------------------- ReLU + per-slot batch norm
 class _BnSlots(torch.autograd.Function):
     """y = bn_over_slots(relu(v))  — encoders.py:179-181 with apply_bn :134-138 (trap T2)."""

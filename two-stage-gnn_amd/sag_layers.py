@@ -7,6 +7,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import message_passing as mp
 from . import pyg
 from .pyg import GCNConv, filter_adj, global_max_pool as gmp, global_mean_pool as gap, topk
 
@@ -78,10 +79,10 @@ class Net(nn.Module):
     def forward(self, data):
         if self._fused_ok():
             x = self._forward_fused(data)                                # network.py:33-46 in one node
-            x = F.relu(self.lin1(x))
+            x = pyg.relu(mp.linear_oi(x, self.lin1.weight, self.lin1.bias))
             x = F.dropout(x, p=self.dropout_ratio, training=self.training)
-            x = F.relu(self.lin2(x))
-            return F.log_softmax(self.lin3(x), dim=-1)
+            x = pyg.relu(mp.linear_oi(x, self.lin2.weight, self.lin2.bias))
+            return F.log_softmax(mp.linear_oi(x, self.lin3.weight, self.lin3.bias), dim=-1)
         x, edge_index = data.x, data.edge_index
         batch = getattr(data, "batch", None) if self.use_batch else None
         outs = []

@@ -73,16 +73,6 @@ class SagPlan:
         return plan
 
 
-_tickets = {}
-
-
-def _ticket(device):
-    t = _tickets.get(str(device))
-    if t is None:
-        t = _tickets[str(device)] = torch.zeros(1, dtype=torch.int32, device=device)
-    return t
-
-
 def gcn_coef(g):
     """(dinv, self_w) of PyG gcn_norm for the unit-weight graph g, cached on it."""
     c = getattr(g, "_gcn_coef", None)
@@ -207,7 +197,7 @@ class _SagStack(torch.autograd.Function):
             part, dws, dbs = _f32(nb * (H + 4), device=dev), _f32(H, device=dev), _f32(1, device=dev)
             # dt = A^T dscore: the score layer's propagate transposed
             nat.call("sag_du_f32", rowptr_t, col_t, dinv, self_w, dscore, y, y.stride(0), wsv, dyb, dyb.stride(0), N, H, part,
-                     _ticket(dev), dws, dbs)
+                     dws, dbs)
             dW, db = mp.linear_wgrad(agg, agg.size(1), dyb, True)
             grads[4 * l: 4 * l + 4] = [dW, db, dws.view(-1, 1), dbs]
             if l > 0 or ctx.x_needs_grad:
