@@ -173,6 +173,35 @@ def test_gat_dd_graph_vs_oracle():
         assert err <= 2e-3 * ref.abs().max().item() + 1e-7, (k, err, ref.abs().max().item())
 
 
+def test_gat_batched_equals_independent_b1_forwards():
+    """per_graph_features=True: ONE block-diagonal forward of B DD-sized graphs = B reference forwards at B = 1 (the
+    reference's GAT batch size) — outputs per graph, gradients summed over the graphs"""
+    from two_stage_gnn_amd import gat_encoders as G
+    B, nmax = 4, 320
+    x, adj, sizes = dense_batch(6, B, nmax, 89, sizes=[269, 120, 320, 33], p_edge=2 * 676 / 269 / 269)
+    torch.manual_seed(2)
+    m = G.DGATEncoderGraph(89, 64, 64, 2, None, num_layers=2, num_heads=[4, 4], final_dim="number_classes",
+                           per_graph_features=True).cuda()
+    p_ref = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    label = torch.tensor([1, 0, 0, 1])
+    refs_a, refs_b, loss_ref = [], [], 0.0
+    for b in range(B):
+        a_ref, b_ref = R.gat_encoder(p_ref, x[b:b + 1], adj[b:b + 1], final_dim="number_classes")
+        refs_a.append(a_ref); refs_b.append(b_ref)
+        loss_ref = loss_ref + torch.nn.functional.cross_entropy(b_ref, label[b:b + 1])
+    loss_ref.backward()
+    a, bb = m(x.cuda(), adj.cuda(), sizes)
+    torch.testing.assert_close(a.detach().cpu(), torch.cat(refs_a).detach(), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(bb.detach().cpu(), torch.cat(refs_b).detach(), rtol=1e-4, atol=1e-4)
+    (m.loss(bb, label.cuda()) * B).backward()                              # mean over graphs * B = sum of the B = 1 losses
+    for k, p in m.named_parameters():
+        ref = p_ref[k].grad
+        if ref is None:
+            continue
+        err = (p.grad.cpu() - ref).abs().max().item()
+        assert err <= 2e-3 * ref.abs().max().item() + 1e-7, (k, err, ref.abs().max().item())
+
+
 # ----------------------------------------------------------------------------- DiffPool (encoders.py:236-406)
 def test_diffpool_contract_golden():
     from two_stage_gnn_amd import diffpool as dp

@@ -7,6 +7,9 @@ replaced by per-edge kernels (attention.py).  Bug-compatible with the reference 
   * ``input[0]``: every graph of a batch uses graph 0's features (T4) — meaningful at B=1 only;
   * DGATLayer's ctor in the reference dies on an undefined name (encoders_GAT.py:65); the loop it guards
     would re-initialise nothing, so it is simply omitted here.
+``DGATEncoderGraph(..., per_graph_features=True)`` (extension, default off) gives every graph of a batch its OWN
+features: one batched forward then equals B independent B = 1 reference forwards (the reference's GAT batch size,
+train.py:480) in outputs and summed gradients, and the per-edge kernels run once on the block-diagonal batch.
 """
 import numpy as np
 import torch
@@ -33,6 +36,8 @@ def _rows_of_graph0(x, g):
 
 
 class DGATHead(nn.Module):
+    per_graph_features = False          # False: encoders_GAT.py:32's input[0] for every graph (T4)
+
     def __init__(self, input_dim, output_dim, add_self=False, dropout=0.0, neg_input_slope=0.2, concat=True):
         super().__init__()
         self.dropout = dropout
@@ -100,12 +105,13 @@ def _gat_heads_forward(heads, x, adj, concat_heads, elu):
     H = len(heads)
     Fo = heads[0].output_dim
     slope = heads[0].leakyRELU_neg_input_slope
-    x0 = _rows_of_graph0(x, g)                                             # [N, Fin]
+    own = heads[0].per_graph_features and B > 1
+    x0 = x.reshape(B * N, -1).contiguous().float() if own else _rows_of_graph0(x, g)     # [N, Fin] ([B*N, Fin] per-graph)
     if x0.size(1) % 4 and not x0.requires_grad:
         x0 = F.pad(x0, (0, 4 - x0.size(1) % 4))                            # 16-byte rows: the MFMA row-panel product applies
     W = _CatHeadWeights.apply(*[hd.w for hd in heads])                      # [Fin, H*Fo]
     h = mp.linear_l2norm(x0, W, None, normalize=False)                      # [N, H*Fo]
-    if B > 1:
+    if B > 1 and not own:
         h = h.unsqueeze(0).expand(B, N, H * Fo).reshape(B * N, H * Fo)       # T4: graph 0's features everywhere
     a_row, a_col = _StackHeadVectors.apply(*[hd.a for hd in heads])        # a1 . h_i (row index i), a2 . h_j (column index j)
     pre = att.attention_aggregate(h, a_row, a_col, g, H, slope, by_column=True, uniform_isolated=True)
@@ -136,7 +142,8 @@ class DGATLayer(nn.Module):
 
 class DGATEncoderGraph(nn.Module):
     def __init__(self, input_dim, hidden_dim, embedding_dim, label_dim, args, num_layers=2, num_heads=[2, 2],
-                 pred_hidden_dims=[], neg_input_slopes=[0.2, 0.2], dropouts=[0.0, 0.0], final_dim="output_dim", concat=True):
+                 pred_hidden_dims=[], neg_input_slopes=[0.2, 0.2], dropouts=[0.0, 0.0], final_dim="output_dim", concat=True,
+                 per_graph_features=False):
         super().__init__()
         self.dropout = dropouts
         self.bias = True
@@ -150,6 +157,9 @@ class DGATEncoderGraph(nn.Module):
         self.pred_model = self.build_pred_layers(self.pred_input_dim, label_dim, num_aggs=self.num_aggs)
         self.map_model = self.build_pred_layers(self.pred_input_dim, embedding_dim, num_aggs=self.num_aggs)
         self.map2_model = torch.nn.Identity()
+        for m in self.modules():
+            if isinstance(m, DGATHead):
+                m.per_graph_features = bool(per_graph_features)
         self.to(_default_device())
 
     def build_conv_layers(self, input_dim, hidden_dim, embedding_dim, num_layers, num_heads, neg_input_slopes, dropouts):
