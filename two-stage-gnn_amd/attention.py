@@ -68,14 +68,17 @@ class _AttentionAggregate(torch.autograd.Function):
             alpha = _f32(nnz, H, device=dev)
             nat.call("edge_softmax_fwd_f32", g.rowptr, g.col, R, H, s_row, s_col, 0, float(slope), alpha)
         out = _f32(R, C, device=dev)
-        nat.call("csr_spmm_heads_f32", g.rowptr, g.col, alpha, H, Fh, h, h.stride(0), 0, out, out.stride(0), R)
         iso = None
         if uniform_isolated:
-            # columns with no edge: softmax of an all-masked column is uniform 1/N over the N rows of the graph
+            # columns with no edge: softmax of an all-masked column is uniform 1/N over the N rows of the graph; the
+            # per-graph sum u is added to every row in the aggregation's epilogue
             iso = _isolated_columns(g, rp_t, R, H)
             N = g.nmax
             u = segment_wsum(h, iso, H, Fh, g.graph_ptr, g.B, scale=1.0 / N, max_seg=int(g.sizes.max()))
-            nat.call("broadcast_add_f32", out, out.stride(0), R, H, Fh, None, None, 0, u, u.stride(0), N, 1.0)
+            nat.call("csr_spmm_heads_epi_f32", g.rowptr, g.col, alpha, H, Fh, h, h.stride(0), 0, out, out.stride(0), R,
+                     None, None, 0, None, None, 0, u, u.stride(0), None, N, 1.0)
+        else:
+            nat.call("csr_spmm_heads_f32", g.rowptr, g.col, alpha, H, Fh, h, h.stride(0), 0, out, out.stride(0), R)
         ctx.g, ctx.H, ctx.Fh, ctx.slope, ctx.by_column = g, H, Fh, slope, by_column
         ctx.save_for_backward(h, a_row, a_col, s_row, s_col, alpha, alpha_g, iso)
         return out
@@ -112,13 +115,13 @@ class _AttentionAggregate(torch.autograd.Function):
             alpha_t = _f32(nnz, H, device=dev)
             nat.call("edge_permute_f32", alpha, src_e_t, g.nnz, H, 0, alpha_t)
         # dh_j = sum_i alpha_ij dout_i  (transposed aggregation)  + ds_row (x) a_row + ds_col (x) a_col
-        nat.call("csr_spmm_heads_f32", rp_t, col_t, alpha_t, H, Fh, dout, dout.stride(0), 0, dh, dh.stride(0), R)
-        nat.call("broadcast_add_f32", dh, dh.stride(0), R, H, Fh, ds_row, a_row, a_row.stride(0), None, 0, 0, 1.0)
-        nat.call("broadcast_add_f32", dh, dh.stride(0), R, H, Fh, ds_col, a_col, a_col.stride(0), None, 0, 0, 1.0)
+        # (the three element-wise terms ride in the aggregation's epilogue: one pass over dh instead of four)
+        du, N = None, max(g.nmax, 1)
         if iso is not None:
-            N = g.nmax
             du = segment_wsum(dout, None, H, Fh, g.graph_ptr, g.B, scale=1.0, max_seg=int(g.sizes.max()))
-            nat.call("broadcast_add_f32", dh, dh.stride(0), R, H, Fh, iso, None, 0, du, du.stride(0), N, 1.0 / N)
+        nat.call("csr_spmm_heads_epi_f32", rp_t, col_t, alpha_t, H, Fh, dout, dout.stride(0), 0, dh, dh.stride(0), R,
+                 ds_row, a_row, a_row.stride(0), ds_col, a_col, a_col.stride(0), du, du.stride(0) if du is not None else 0,
+                 iso, N, 1.0 / N)
         da_row = segment_wsum(h, ds_row, H, Fh, None, 1).view(H, Fh)
         da_col = segment_wsum(h, ds_col, H, Fh, None, 1).view(H, Fh)
         return dh, da_row, da_col, None, None, None, None, None

@@ -105,11 +105,27 @@ __global__ void csr_row_sum_kernel(const int* __restrict__ rowptr, const float* 
   out[i] = acc;
 }
 
+// optional epilogue of the head-weighted aggregation (folds the element-wise passes that used to follow it):
+//   y[r, h*Fh+f] += w1[r,h] * a1[h,f] + w2[r,h] * a2[h,f] + uscale * (uw ? uw[r,h] : 1) * u[r / rows_per_seg, h*Fh+f]
+// (score-gradient outer products ds (x) a of dh, and the uniform 1/N term of all-masked softmax columns)
+struct HeadsEpi {
+  const float* w1; const float* a1; int64_t lda1;
+  const float* w2; const float* a2; int64_t lda2;
+  const float* u; int64_t ldu; const float* uw; int rows_per_seg; float uscale;
+};
+__device__ __forceinline__ float heads_epi(const HeadsEpi& e, int64_t r, int H, int Fh, int h, int f /*within head*/) {
+  float add = 0.f;
+  if (e.w1) add = fmaf(e.w1[r * H + h], e.a1[(int64_t)h * e.lda1 + f], add);
+  if (e.w2) add = fmaf(e.w2[r * H + h], e.a2[(int64_t)h * e.lda2 + f], add);
+  if (e.u) add = fmaf(e.uscale * (e.uw ? e.uw[r * H + h] : 1.f), e.u[(r / e.rows_per_seg) * e.ldu + (int64_t)h * Fh + f], add);
+  return add;
+}
+
 // head-weighted aggregation: y[r, h*Fh+f] = sum_e alpha[e,h] * x[col[e] % mod, h*Fh+f];  one wave per row
 __global__ __launch_bounds__(256) void spmm_heads_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
                                                          const float* __restrict__ alpha, int H, int Fh,
                                                          const float* __restrict__ x, int64_t ldx, int mod,
-                                                         float* __restrict__ y, int64_t ldy, int64_t rows, unsigned nblk) {
+                                                         float* __restrict__ y, int64_t ldy, int64_t rows, unsigned nblk, HeadsEpi epi) {
   const unsigned lb = xcd_remap(blockIdx.x, nblk);
   const int lane = threadIdx.x & 63;
   const int64_t r = (int64_t)lb * 4 + (threadIdx.x >> 6);
@@ -130,7 +146,7 @@ __global__ __launch_bounds__(256) void spmm_heads_kernel(const int* __restrict__
         if (live) acc = fmaf(alpha[(int64_t)(eb + k) * H + h], x[(int64_t)j * ldx + f], acc);
       }
     }
-    if (live) y[r * ldy + f] = acc;
+    if (live) y[r * ldy + f] = acc + heads_epi(epi, r, H, Fh, h, f - h * Fh);
   }
 }
 
@@ -139,7 +155,8 @@ __global__ __launch_bounds__(256) void spmm_heads_kernel(const int* __restrict__
 template <int G>
 __global__ __launch_bounds__(256) void spmm_heads_vec4(const int* __restrict__ rowptr, const int* __restrict__ col,
                                                        const float* __restrict__ alpha, int H, int Fh, const float* __restrict__ x,
-                                                       int64_t ldx, int mod, float* __restrict__ y, int64_t ldy, int64_t rows, int nvec) {
+                                                       int64_t ldx, int mod, float* __restrict__ y, int64_t ldy, int64_t rows, int nvec,
+                                                       HeadsEpi epi) {
   const int lig = threadIdx.x % G;
   const int64_t r = (int64_t)blockIdx.x * (256 / G) + threadIdx.x / G;
   if (r >= rows) return;
@@ -168,7 +185,12 @@ __global__ __launch_bounds__(256) void spmm_heads_vec4(const int* __restrict__ r
       acc.z = fmaf(a[k], v[k].z, acc.z); acc.w = fmaf(a[k], v[k].w, acc.w);
     }
   }
-  if (live) *reinterpret_cast<float4*>(y + r * ldy + co) = acc;
+  if (live) {
+    const int f0 = (int)co - h * Fh;
+    acc.x += heads_epi(epi, r, H, Fh, h, f0); acc.y += heads_epi(epi, r, H, Fh, h, f0 + 1);
+    acc.z += heads_epi(epi, r, H, Fh, h, f0 + 2); acc.w += heads_epi(epi, r, H, Fh, h, f0 + 3);
+    *reinterpret_cast<float4*>(y + r * ldy + co) = acc;
+  }
 }
 
 // SDDMM, float4: the Fh/4 lanes of a head reduce their partial dot products with DPP inside a 16-lane row
@@ -268,15 +290,24 @@ __global__ __launch_bounds__(256) void segment_wsum_kernel(const float* __restri
   if (rl == 0 && c < C)
     part[((int64_t)blockIdx.z * nseg + s) * C + c] = (lds[0][threadIdx.x] + lds[1][threadIdx.x]) + (lds[2][threadIdx.x] + lds[3][threadIdx.x]);
 }
-__global__ void segment_wsum_final(const float* __restrict__ part, int nchunk, int nseg, int C, const int* __restrict__ seg_ptr,
-                                   int64_t rows_if_one, float scale, int mean, float* __restrict__ out, int64_t ldo) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (int64_t)nseg * C) return;
-  const int s = (int)(i / C), c = (int)(i % C);
+// grid (ceil(C / 64), nseg), 64 columns x 16 chunk lanes: lane q adds chunks q, q + 16, ... (a 32,000-row segment has 250
+// chunks: one thread per output summed them in a 32 us latency chain), then the 16 lanes are added in order.
+__global__ __launch_bounds__(1024) void segment_wsum_final(const float* __restrict__ part, int nchunk, int nseg, int C,
+                                                           const int* __restrict__ seg_ptr, int64_t rows_if_one, float scale, int mean,
+                                                           float* __restrict__ out, int64_t ldo) {
+  __shared__ float lds[16][64];
+  const int s = blockIdx.y, cl = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   const int64_t len = seg_ptr ? (int64_t)(seg_ptr[s + 1] - seg_ptr[s]) : rows_if_one;
-  const int used = (int)((len + SEG_CHUNK - 1) / SEG_CHUNK);
+  const int used = min((int)((len + SEG_CHUNK - 1) / SEG_CHUNK), nchunk);
   float acc = 0.f;
-  for (int k = 0; k < used && k < nchunk; ++k) acc += part[((int64_t)k * nseg + s) * C + c];
+  if (c < C)
+    for (int k = q; k < used; k += 16) acc += part[((int64_t)k * nseg + s) * C + c];
+  lds[q][cl] = acc;
+  __syncthreads();
+  if (q != 0 || c >= C) return;
+#pragma unroll
+  for (int k = 1; k < 16; ++k) acc += lds[k][cl];
   float sc = scale;
   if (mean) sc = len > 0 ? scale / (float)len : 0.f;
   out[(int64_t)s * ldo + c] = sc * acc;
@@ -386,24 +417,39 @@ int tsgnn_csr_row_sum_f32(const int* rowptr, const float* val, int64_t rows, int
   return TSGNN_OK;
 }
 
-int tsgnn_csr_spmm_heads_f32(const int* rowptr, const int* col, const float* alpha, int H, int Fh, const float* x, int64_t ldx,
-                             int mod, float* y, int64_t ldy, int64_t rows, tsgnn_stream_t stream) {
+static int spmm_heads_launch(const int* rowptr, const int* col, const float* alpha, int H, int Fh, const float* x, int64_t ldx,
+                             int mod, float* y, int64_t ldy, int64_t rows, const HeadsEpi& epi, tsgnn_stream_t stream) {
   if (!rowptr || !alpha || !x || !y || rows < 0 || H <= 0 || Fh <= 0 || mod < 0 || ldx < (int64_t)H * Fh || ldy < (int64_t)H * Fh)
     return TSGNN_EINVAL;
   if (rows == 0) return TSGNN_OK;
   const int F = H * Fh;
   if ((Fh % 4) == 0 && F <= 256 && (ldx % 4) == 0 && (ldy % 4) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0) {
     const int nvec = F / 4;
-    if (nvec <= 16) spmm_heads_vec4<16><<<(unsigned)ceil_div64(rows, 16), 256, 0, stream>>>(rowptr, col, alpha, H, Fh, x, ldx, mod, y, ldy, rows, nvec);
-    else if (nvec <= 32) spmm_heads_vec4<32><<<(unsigned)ceil_div64(rows, 8), 256, 0, stream>>>(rowptr, col, alpha, H, Fh, x, ldx, mod, y, ldy, rows, nvec);
-    else spmm_heads_vec4<64><<<(unsigned)ceil_div64(rows, 4), 256, 0, stream>>>(rowptr, col, alpha, H, Fh, x, ldx, mod, y, ldy, rows, nvec);
+    if (nvec <= 16) spmm_heads_vec4<16><<<(unsigned)ceil_div64(rows, 16), 256, 0, stream>>>(rowptr, col, alpha, H, Fh, x, ldx, mod, y, ldy, rows, nvec, epi);
+    else if (nvec <= 32) spmm_heads_vec4<32><<<(unsigned)ceil_div64(rows, 8), 256, 0, stream>>>(rowptr, col, alpha, H, Fh, x, ldx, mod, y, ldy, rows, nvec, epi);
+    else spmm_heads_vec4<64><<<(unsigned)ceil_div64(rows, 4), 256, 0, stream>>>(rowptr, col, alpha, H, Fh, x, ldx, mod, y, ldy, rows, nvec, epi);
     TSGNN_CHECK_LAUNCH();
     return TSGNN_OK;
   }
   const unsigned nblk = (unsigned)ceil_div64(rows, 4);
-  spmm_heads_kernel<<<nblk, 256, 0, stream>>>(rowptr, col, alpha, H, Fh, x, ldx, mod, y, ldy, rows, nblk);
+  spmm_heads_kernel<<<nblk, 256, 0, stream>>>(rowptr, col, alpha, H, Fh, x, ldx, mod, y, ldy, rows, nblk, epi);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
+}
+
+int tsgnn_csr_spmm_heads_f32(const int* rowptr, const int* col, const float* alpha, int H, int Fh, const float* x, int64_t ldx,
+                             int mod, float* y, int64_t ldy, int64_t rows, tsgnn_stream_t stream) {
+  HeadsEpi epi{};
+  return spmm_heads_launch(rowptr, col, alpha, H, Fh, x, ldx, mod, y, ldy, rows, epi, stream);
+}
+
+int tsgnn_csr_spmm_heads_epi_f32(const int* rowptr, const int* col, const float* alpha, int H, int Fh, const float* x, int64_t ldx,
+                                 int mod, float* y, int64_t ldy, int64_t rows, const float* w1, const float* a1, int64_t lda1,
+                                 const float* w2, const float* a2, int64_t lda2, const float* u, int64_t ldu, const float* uw,
+                                 int rows_per_seg, float uscale, tsgnn_stream_t stream) {
+  if ((w1 && !a1) || (w2 && !a2) || (u && rows_per_seg <= 0)) return TSGNN_EINVAL;
+  HeadsEpi epi{w1, a1, lda1, w2, a2, lda2, u, ldu, uw, rows_per_seg, uscale};
+  return spmm_heads_launch(rowptr, col, alpha, H, Fh, x, ldx, mod, y, ldy, rows, epi, stream);
 }
 
 int tsgnn_csr_sddmm_heads_f32(const int* rowptr, const int* col, int H, int Fh, const float* dy, int64_t lddy, const float* x,
@@ -436,7 +482,7 @@ int tsgnn_segment_wsum_f32(const float* x, int64_t ldx, const float* w, int H, i
   const int nchunk = (int)(longest > 0 ? ceil_div64(longest, SEG_CHUNK) : 1);
   dim3 grid((unsigned)((C + 63) / 64), (unsigned)nseg, (unsigned)nchunk);
   segment_wsum_kernel<<<grid, 256, 0, stream>>>(x, ldx, w, H, Fh, seg_ptr, rows, C, ws, nseg);
-  segment_wsum_final<<<(unsigned)ceil_div64((int64_t)nseg * C, 256), 256, 0, stream>>>(ws, nchunk, nseg, C, seg_ptr, rows, scale, mean, out, ldo);
+  segment_wsum_final<<<dim3((unsigned)((C + 63) / 64), (unsigned)nseg), 1024, 0, stream>>>(ws, nchunk, nseg, C, seg_ptr, rows, scale, mean, out, ldo);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }
