@@ -283,6 +283,22 @@ int tsgnn_elu_heads_fwd_f32(const float* x, int64_t rows, int H, int Fh, int mea
 int tsgnn_elu_heads_bwd_f32(const float* x, const float* dy, int64_t rows, int H, int Fh, int mean_heads, int apply_elu, float* dx,
                             tsgnn_stream_t stream);
 
+/* ---------------------------------------------------------------- DiffPool link-prediction side loss (linkpred.hip) */
+
+/* encoders.py:416-440 for adj_hop = 1, value and gradient in one pass, no [B,N,N] tensor:
+ *   loss = inv_entries * sum_b sum_{i,j in graph b} BCE(min((S S^T)_ij, clamp), a_ij),  eps = 1e-7
+ * S[rows, K] (K <= 128): assignment rows of the batch, graph b = rows [graph_ptr[b], graph_ptr[b+1]) (the reference's
+ * adj_mask: only pairs inside a graph's real rows count); slabs: every graph's rows cut into pieces of at most
+ * tsgnn_linkpred_tile_rows() rows (slab_row_ptr[nslab+1], slab_graph[nslab]); (rowptr, col, val) the adjacency (val NULL =
+ * unit), (rowptr_t, col_t, val_t) its transpose or NULLs when it is symmetric.  dS[rows, K] = d loss / d S (rows outside
+ * every slab are left untouched: zero them); part: nslab + 2 * ceil(rows / 4) floats of scratch; loss: 1 float.
+ * clamp: the reference passes an UNINITIALISED one-element tensor (:424); 1.0 is the value it presumably meant. */
+int tsgnn_linkpred_tile_rows(void);
+int tsgnn_linkpred_loss_f32(const float* S, int64_t lds, int K, int64_t rows, const int* slab_row_ptr, const int* slab_graph,
+                            int nslab, const int* graph_ptr, const int* rowptr, const int* col, const float* val,
+                            const int* rowptr_t, const int* col_t, const float* val_t, float clamp, float inv_entries, float* dS,
+                            int64_t ldd, float* part, float* loss, tsgnn_stream_t stream);
+
 /* ---------------------------------------------------------------- SAGPool path (pooling.hip) */
 
 /* PyG topk(score, ratio, batch) (call site Code/sag/layers.py:20): for every graph b keep its

@@ -204,3 +204,21 @@ def gat_encoder(p, x, adj, final_dim="output_dim"):
     if final_dim != "output_dim":
         return x, _linear(p, "pred_model", x)
     return x, _linear(p, "map_model", x)
+
+
+def diffpool_link_loss(s, adj, batch_num_nodes=None, clamp=1.0, eps=1e-7):
+    """SoftPoolingGcnEncoder.loss's link-prediction term, encoders.py:416-438 (adj_hop = 1).  s: the assignment tensor
+    [B, N, K] (masked rows already zero, :371), adj [B, N, N].  The reference clamps with ``torch.Tensor(1)`` (:424), an
+    UNINITIALISED value: it is a parameter here (parity of this term is pinned by the source lines, not by a vector)."""
+    pred = torch.minimum(s @ s.transpose(1, 2), torch.tensor(float(clamp)))                 # :418-424
+    ll = -adj * torch.log(pred + eps) - (1 - adj) * torch.log(1 - pred + eps)                # :428
+    B, N = adj.size(0), adj.size(1)
+    if batch_num_nodes is None:
+        entries = N * N * B                                                                 # :430
+    else:
+        entries = float(sum(int(n) * int(n) for n in batch_num_nodes))                      # :433
+        m = torch.zeros(B, N, 1)
+        for b, n in enumerate(batch_num_nodes):
+            m[b, :int(n)] = 1
+        ll = ll * (m @ m.transpose(1, 2))                                                    # :434-436
+    return ll.sum() / float(entries)                                                        # :438

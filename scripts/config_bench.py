@@ -138,6 +138,14 @@ with torch.cuda.stream(st):
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record(st); gr.replay(); e1.record(st); e1.synchronize()
     us = e0.elapsed_time(e1) / 20 * 1e3
+# f4: link-prediction side loss (value + dS) on the level-1 assignment of the same batch
+Sl = Sm.clone().requires_grad_(True)
+def step_lp():
+    Sl.grad = None; dp.link_pred_loss(Sl, g5).backward()
+tl = graph_us(step_lp) or timeit(step_lp)
+pairs = float((hb5["sizes"].astype(np.float64) ** 2).sum())
+print("f4 link-pred loss + gradient, DD b16 K=64 (%.2f M row pairs, no [B,N,N] tensor): %.1f us -> %.1f GFLOP/s of pair products"
+      % (pairs / 1e6, tl, 4 * pairs * 64 / tl / 1e3))
 nb = hb5["sizes"].astype(np.float64)
 dense_flops = 16 * (2 * 512 * 512 * 64 + 2 * 64 * 512 * 64 + 2 * 64 * 512 * 192)          # reference's padded bmm's, level 1
 sparse_flops = 2 * g5.nnz * 64 + float((2 * 64 * nb * 64 + 2 * 64 * nb * 192).sum())    # what is executed: SpMM + ragged GEMMs

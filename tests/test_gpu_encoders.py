@@ -277,6 +277,84 @@ def test_diffpool_dd_config_vs_oracle():
         assert gpu_err <= max(10 * cpu_err, 2e-3 * mag + 1e-9), (k, gpu_err, cpu_err, mag)
 
 
+@pytest.mark.parametrize("masked", [True, False])
+@pytest.mark.parametrize("sym", [True, False])
+def test_link_pred_loss_vs_oracle(masked, sym):
+    """f4: the link-prediction side loss (encoders.py:416-438) on packed assignment rows + CSR against the dense
+    restatement — value and d loss / d S; directed and weighted adjacencies, ragged graph sizes, clamp below 1"""
+    from two_stage_gnn_amd import diffpool as dp
+    from two_stage_gnn_amd import message_passing as mp
+    from two_stage_gnn_amd.graph import GraphBatch
+    B, nmax, K = 5, 96, 24
+    x, adj, sizes = dense_batch(41, B, nmax, 3, sizes=[96, 33, 1, 64, 70], p_edge=0.08)
+    gen = torch.Generator().manual_seed(7)
+    if not sym:
+        adj = adj * (torch.rand(adj.shape, generator=gen) < 0.6).float() * (0.5 + torch.rand(adj.shape, generator=gen))
+    s = torch.softmax(torch.randn(B, nmax, K, generator=gen) * 2, dim=-1)
+    if masked:
+        for b, n in enumerate(sizes):
+            s[b, int(n):] = 0
+    for clamp in (1.0, 0.3):
+        sr = s.clone().requires_grad_(True)
+        ref = R.diffpool_link_loss(sr, adj, sizes if masked else None, clamp=clamp)
+        ref.backward()
+        g = GraphBatch.from_dense(adj.cuda(), sizes if masked else None, layout="packed" if masked else "padded",
+                                  assume_symmetric=sym)
+        sp = (mp.pack_rows(s.cuda(), g) if masked else s.cuda().reshape(B * nmax, K)).detach().requires_grad_(True)
+        got = dp.link_pred_loss(sp, g, clamp=clamp, masked=masked)
+        torch.testing.assert_close(got.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-6)
+        (got * 3.0).backward()
+        gs = mp.unpack_rows(sp.grad, g).cpu() if masked else sp.grad.reshape(B, nmax, K).cpu()
+        if masked:
+            for b, n in enumerate(sizes):
+                gs[b, int(n):] = 0                      # padded rows: not part of the packed problem
+                sr.grad[b, int(n):] = 0
+        torch.testing.assert_close(gs, 3.0 * sr.grad, rtol=2e-4, atol=1e-6)
+
+
+def test_diffpool_linkpred_encoder_vs_oracle():
+    """SoftPoolingGcnEncoder(linkpred=True, num_pooling=1): CE + link loss and all parameter gradients vs the oracle;
+    num_pooling=2 reproduces the reference's failure (trap T7)"""
+    from two_stage_gnn_amd import dense_encoders as E
+    B, nmax, fin, hid = 4, 128, 12, 32
+    sizes = dd_like_sizes(5, B, nbar=70, nmax=nmax)
+    x, adj, sizes = dense_batch(35, B, nmax, fin, sizes=sizes.tolist(), p_edge=0.06)
+
+    class A:
+        bias = True
+    torch.manual_seed(4)
+    m = E.SoftPoolingGcnEncoder(nmax, fin, hid, hid, 2, 3, hid, assign_ratio=0.25, num_pooling=1, bn=True, linkpred=True,
+                                args=A(), assign_input_dim=fin, final_dim="number_classes")
+    p_ref = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    _, b_ref, s_ref = R.diffpool_encoder(p_ref, x, adj, sizes, 1, assign_x=x, final_dim="number_classes", return_assign=True)
+    label = torch.arange(B) % 2
+    link_ref = R.diffpool_link_loss(s_ref, adj, sizes)
+    loss_ref = torch.nn.functional.cross_entropy(b_ref, label) + link_ref
+    loss_ref.backward()
+    _, b = m(x.cuda(), adj.cuda(), sizes, assign_x=x.cuda())
+    loss = m.loss(b, label.cuda(), adj.cuda(), sizes)
+    torch.testing.assert_close(m.link_loss.detach().cpu(), link_ref.detach(), rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(loss.detach().cpu(), loss_ref.detach(), rtol=1e-4, atol=1e-5)
+    loss.backward()
+    p64 = {k: v.detach().double().requires_grad_(True) for k, v in p_ref.items()}
+    _, b64, s64 = R.diffpool_encoder(p64, x.double(), adj.double(), sizes, 1, assign_x=x.double(), final_dim="number_classes",
+                                     return_assign=True)
+    (torch.nn.functional.cross_entropy(b64, label) + R.diffpool_link_loss(s64, adj.double(), sizes)).backward()
+    for k, p in m.named_parameters():
+        ref32, ref64 = p_ref[k].grad, p64[k].grad
+        if ref32 is None or p.grad is None:
+            continue
+        cpu_err = (ref32.double() - ref64).abs().max().item()
+        gpu_err = (p.grad.cpu().double() - ref64).abs().max().item()
+        mag = ref64.abs().max().item()
+        assert gpu_err <= max(10 * cpu_err, 2e-3 * mag + 1e-9), (k, gpu_err, cpu_err, mag)
+    m2 = E.SoftPoolingGcnEncoder(nmax, fin, hid, hid, 2, 3, hid, assign_ratio=0.25, num_pooling=2, bn=True, linkpred=True,
+                                 args=A(), assign_input_dim=fin, final_dim="number_classes")
+    _, b2 = m2(x.cuda(), adj.cuda(), sizes, assign_x=x.cuda())
+    with pytest.raises(RuntimeError, match="num_pooling"):
+        m2.loss(b2, label.cuda(), adj.cuda(), sizes)
+
+
 # ----------------------------------------------------------------------------- triplet step (tripletnet.py)
 class _G:                       # stand-in for the networkx graphs cross_val.split_train_val prepares (cross_val.py:158-184)
     def __init__(self, adj, feats, n):

@@ -1,0 +1,179 @@
+// DiffPool link-prediction side loss (encoders.py:416-440), value AND gradient in one pass, without the
+// [B, N, N] tensors the reference builds (pred_adj = S S^T, the element-wise BCE, the mask product):
+//
+//   L = 1/num_entries * sum_b sum_{i,j < n_b} [ -a_ij log(p_ij + eps) - (1 - a_ij) log(1 - p_ij + eps) ],  p = min(S S^T, clamp)
+//     = 1/num_entries * [ sum_pairs f0(p_ij)  +  sum_{(i,j) in E} a_ij (f1(p_ij) - f0(p_ij)) ]
+//   f0(p) = -log(1 - p + eps),  f1(p) = -log(p + eps)                    (the BCE is linear in a_ij)
+//
+// The first sum runs over all row pairs of each graph and needs no adjacency: row tiles of S are staged in LDS, the
+// P tile and dL/dP tile live in registers / LDS only, and dS_i = 2 sum_j g0(p_ij) s_j is accumulated tile by tile
+// (P is symmetric).  The second sum is an SDDMM over the CSR entries.  Rows of S are the packed rows of a GraphBatch
+// (ghost rows excluded = the reference's adj_mask, encoders.py:433-436) or all padded rows (batch_num_nodes=None, :430).
+// The reference clamps with an UNINITIALISED tensor (`torch.min(pred_adj, torch.Tensor(1).cuda())`, :424); `clamp` is a
+// parameter here, 1.0 (the value the DiffPool authors' later code uses) by default — see DESIGN.md.
+// FMA work (K <= 128 assignment columns, n_b^2 K flops per graph): an auxiliary loss, not a GEMM worth MFMA tiles.
+#include "common.h"
+#include "../../include/tsgnn.h"
+
+namespace {
+
+constexpr int LP_TILE = 32;
+constexpr int LP_KMAX = 128;
+constexpr float LP_EPS = 1e-7f;          // encoders.py:413
+
+__device__ __forceinline__ float lp_clamp(float p, float clamp, float& gate) {
+  // torch.min(p, c): gradient 1 where p < c, 1/2 on ties, 0 above
+  gate = p < clamp ? 1.f : (p == clamp ? 0.5f : 0.f);
+  return fminf(p, clamp);
+}
+
+// one block per 32-row slab of one graph; loops over the graph's row tiles
+__global__ __launch_bounds__(256) void linkpred_pairs_kernel(const float* __restrict__ S, int64_t lds_, int K,
+                                                             const int* __restrict__ slab_row_ptr, const int* __restrict__ slab_graph,
+                                                             const int* __restrict__ graph_ptr, float clamp, float inv_entries,
+                                                             float* __restrict__ dS, int64_t ldd, float* __restrict__ part) {
+  __shared__ float s_i[LP_TILE][LP_KMAX + 1];
+  __shared__ float s_j[LP_TILE][LP_KMAX + 1];
+  __shared__ float s_g[LP_TILE][LP_TILE + 1];
+  __shared__ float s_red[4];
+  const int slab = blockIdx.x;
+  const int i0 = slab_row_ptr[slab], i1 = slab_row_ptr[slab + 1];
+  const int b = slab_graph[slab];
+  const int g0 = graph_ptr[b], g1 = graph_ptr[b + 1];
+  const int tid = threadIdx.x;
+  for (int t = tid; t < LP_TILE * K; t += 256) {
+    const int r = t / K, k = t - r * K;
+    s_i[r][k] = (i0 + r < i1) ? S[(int64_t)(i0 + r) * lds_ + k] : 0.f;
+  }
+  const int ti = tid >> 3, tj = tid & 7;          // P tile: thread (row ti, columns tj, tj + 8, tj + 16, tj + 24)
+  const int kq = tid & 7;                         // dS accumulation: thread (row ti, k = kq, kq + 8, ...)
+  float acc[LP_KMAX / 8];
+#pragma unroll
+  for (int q = 0; q < LP_KMAX / 8; ++q) acc[q] = 0.f;
+  float loss = 0.f;
+  for (int j0 = g0; j0 < g1; j0 += LP_TILE) {
+    __syncthreads();
+    for (int t = tid; t < LP_TILE * K; t += 256) {
+      const int r = t / K, k = t - r * K;
+      s_j[r][k] = (j0 + r < g1) ? S[(int64_t)(j0 + r) * lds_ + k] : 0.f;
+    }
+    __syncthreads();
+    float p[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < K; ++k) {
+      const float a = s_i[ti][k];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) p[u] = fmaf(a, s_j[tj + 8 * u][k], p[u]);
+    }
+    const bool vi = i0 + ti < i1;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool v = vi && (j0 + tj + 8 * u < g1);
+      float gate;
+      const float pc = lp_clamp(p[u], clamp, gate);
+      const float om = 1.f - pc + LP_EPS;
+      if (v) loss -= logf(om);
+      s_g[ti][tj + 8 * u] = v ? gate / om : 0.f;                       // d f0 / d p
+    }
+    __syncthreads();
+    for (int j = 0; j < LP_TILE; ++j) {
+      const float gij = s_g[ti][j];
+#pragma unroll
+      for (int q = 0; q < LP_KMAX / 8; ++q)
+        if (kq + 8 * q < K) acc[q] = fmaf(gij, s_j[j][kq + 8 * q], acc[q]);
+    }
+  }
+  if (i0 + ti < i1) {
+#pragma unroll
+    for (int q = 0; q < LP_KMAX / 8; ++q)
+      if (kq + 8 * q < K) dS[(int64_t)(i0 + ti) * ldd + kq + 8 * q] = 2.f * inv_entries * acc[q];
+  }
+  loss = wave_sum(loss);
+  if ((tid & 63) == 0) s_red[tid >> 6] = loss;
+  __syncthreads();
+  if (tid == 0) part[slab] = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) * inv_entries;
+}
+
+// edge corrections, one wave per row i: entries (i, j) of the CSR (and of its transpose when A is not symmetric):
+//   loss += a_ij (f1 - f0)(p_ij);  dS_i += sym_factor * a_ij (f1 - f0)'(p_ij) s_j
+__global__ __launch_bounds__(256) void linkpred_edges_kernel(const float* __restrict__ S, int64_t lds_, int K,
+                                                             const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                             const float* __restrict__ val, int64_t rows, float clamp,
+                                                             float inv_entries, float grad_factor, int count_loss,
+                                                             float* __restrict__ dS, int64_t ldd, float* __restrict__ part) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  __shared__ float s_red[4];
+  float loss = 0.f;
+  if (i < rows) {
+    const float a0 = lane < K ? S[i * lds_ + lane] : 0.f;
+    const float a1 = lane + 64 < K ? S[i * lds_ + lane + 64] : 0.f;
+    float d0 = 0.f, d1 = 0.f;
+    for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+      const int64_t j = col[e];
+      const float b0 = lane < K ? S[j * lds_ + lane] : 0.f;
+      const float b1 = lane + 64 < K ? S[j * lds_ + lane + 64] : 0.f;
+      const float p = wave_sum(fmaf(a0, b0, a1 * b1));
+      float gate;
+      const float pc = lp_clamp(p, clamp, gate);
+      const float a = val ? val[e] : 1.f;
+      const float om = 1.f - pc + LP_EPS, pp = pc + LP_EPS;
+      loss += a * (logf(om) - logf(pp));                               // f1 - f0
+      const float gc = a * gate * (-1.f / pp - 1.f / om) * grad_factor * inv_entries;
+      d0 = fmaf(gc, b0, d0);
+      d1 = fmaf(gc, b1, d1);
+    }
+    if (lane < K) dS[i * ldd + lane] += d0;
+    if (lane + 64 < K) dS[i * ldd + lane + 64] += d1;
+  }
+  if (lane == 0) s_red[threadIdx.x >> 6] = (i < rows && count_loss) ? loss * inv_entries : 0.f;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
+// loss[0] = sum of the partials, fixed order
+__global__ __launch_bounds__(256) void linkpred_sum_kernel(const float* __restrict__ part, int n, float* __restrict__ loss) {
+  __shared__ float s[256];
+  float a = 0.f;
+  for (int k = threadIdx.x; k < n; k += 256) a += part[k];
+  s[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = s[0];
+}
+
+}  // namespace
+
+extern "C" {
+
+int tsgnn_linkpred_tile_rows(void) { return LP_TILE; }
+
+int tsgnn_linkpred_loss_f32(const float* S, int64_t lds, int K, int64_t rows, const int* slab_row_ptr, const int* slab_graph,
+                            int nslab, const int* graph_ptr, const int* rowptr, const int* col, const float* val,
+                            const int* rowptr_t, const int* col_t, const float* val_t, float clamp, float inv_entries, float* dS,
+                            int64_t ldd, float* part, float* loss, tsgnn_stream_t stream) {
+  if (!S || !slab_row_ptr || !slab_graph || !graph_ptr || !rowptr || !dS || !part || !loss || nslab <= 0 || rows <= 0 || K <= 0 ||
+      lds < K || ldd < K)
+    return TSGNN_EINVAL;
+  if (K > LP_KMAX) return TSGNN_EUNSUPPORTED;
+  if ((rowptr_t == nullptr) != (col_t == nullptr)) return TSGNN_EINVAL;
+  const unsigned eblk = (unsigned)ceil_div64(rows, 4);
+  linkpred_pairs_kernel<<<(unsigned)nslab, 256, 0, stream>>>(S, lds, K, slab_row_ptr, slab_graph, graph_ptr, clamp, inv_entries, dS, ldd,
+                                                            part);
+  // symmetric adjacency: entry (i,j) and its mirror give row i the same term twice
+  linkpred_edges_kernel<<<eblk, 256, 0, stream>>>(S, lds, K, rowptr, col, val, rows, clamp, inv_entries, rowptr_t ? 1.f : 2.f, 1, dS,
+                                                  ldd, part + nslab);
+  int nparts = nslab + (int)eblk;
+  if (rowptr_t) {
+    linkpred_edges_kernel<<<eblk, 256, 0, stream>>>(S, lds, K, rowptr_t, col_t, val_t, rows, clamp, inv_entries, 1.f, 0, dS, ldd,
+                                                    part + nparts);
+    nparts += (int)eblk;
+  }
+  linkpred_sum_kernel<<<1, 256, 0, stream>>>(part, nparts, loss);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+}  // extern "C"

@@ -387,6 +387,7 @@ class SoftPoolingGcnEncoder(GcnEncoderGraph):
                 if masked:
                     s = mp.mask_ghost_rows(s, g)                                              # :371
                 self.assign_tensor = s
+                self._link_graph, self._link_masked = g, masked
                 dense_x, dense_adj = dp.diffpool_contract_rows(s, emb, g)                     # :374-375
             else:
                 a, _ = self.gcn_forward_dense(dense_x, dense_adj, self.assign_conv_first_modules[i],
@@ -402,9 +403,22 @@ class SoftPoolingGcnEncoder(GcnEncoderGraph):
         output = torch.cat(out_all, dim=1) if self.concat else out_all[-1]
         return self._heads(output)
 
+    linkpred_clamp = 1.0        # the reference clamps pred_adj with an UNINITIALISED tensor (encoders.py:424); see DESIGN.md
+
     def loss(self, pred, label, adj=None, batch_num_nodes=None, adj_hop=1):
+        """CE (+ the link-prediction side loss of encoders.py:416-440 when ``linkpred``).  ``adj`` / ``batch_num_nodes`` are
+        accepted for signature compatibility; the adjacency and the mask used are those of the forward's batch."""
         loss = super().loss(pred, label)
         if self.linkpred:
-            raise NotImplementedError("link-prediction side loss (encoders.py:416-440) is a 'next' row (SURVEY §8 f4); "
-                                      "the reference default is linkpred=False (train.py:472)")
+            from . import diffpool as dp
+            if adj_hop != 1:
+                raise NotImplementedError("adj_hop > 1 (powers of S S^T) is never used by the reference (train.py:130)")
+            if self.num_pooling != 1:
+                # trap T7: the reference multiplies the LAST level's assignment with the ORIGINAL adjacency (:418,428)
+                raise RuntimeError("link-prediction loss with num_pooling >= 2: the last assignment tensor [B, %d, .] does not "
+                                   "match the input adjacency (the reference fails with a shape error here too)"
+                                   % self.assign_tensor.size(-2))
+            self.link_loss = dp.link_pred_loss(self.assign_tensor, self._link_graph, self.linkpred_clamp,
+                                               masked=self._link_masked)
+            return loss + self.link_loss
         return loss

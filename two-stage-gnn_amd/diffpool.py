@@ -141,3 +141,48 @@ class _ContractRows(torch.autograd.Function):
 
 def diffpool_contract_rows(S, Z, g):
     return _ContractRows.apply(S, Z, g)
+
+
+# ----------------------------------------------------------------------------- link-prediction side loss (f4)
+class _LinkPredLoss(torch.autograd.Function):
+    """encoders.py:416-440 (adj_hop = 1): value and d loss / d S from one launch set (csrc/linkpred.hip)."""
+
+    @staticmethod
+    def forward(ctx, s, g, clamp, masked):
+        import numpy as np
+        s = s.contiguous()
+        K = s.size(1)
+        rows = g.n_rows
+        tile = int(nat.lib().tsgnn_linkpred_tile_rows())
+        cache = getattr(g, "_lp_slabs", None)
+        if cache is None:
+            srp, seg, nslab = g.row_slabs(tile)
+            counts = np.diff(seg.cpu().numpy())
+            slab_graph = torch.from_numpy(np.repeat(np.arange(g.B, dtype=np.int32), counts)).to(g.device)
+            cache = g._lp_slabs = (srp, slab_graph, nslab)
+            g._slabs = None                                   # row_slabs caches one slab size: leave it to its other users
+        srp, slab_graph, nslab = cache
+        sizes = g.sizes.astype(np.float64)
+        entries = float((sizes * sizes).sum()) if masked else float(g.nmax) * g.nmax * g.B
+        ds = _f32(s.size(0), K, device=s.device, zero=(s.size(0) > rows))
+        part = _f32(nslab + 2 * ((rows + 3) // 4), device=s.device)
+        loss = _f32(1, device=s.device)
+        if g.symmetric:
+            rp_t = col_t = val_t = None
+        else:
+            rp_t, col_t, val_t = g.transposed()
+        nat.call("linkpred_loss_f32", s, s.stride(0), K, rows, srp, slab_graph, nslab, g.graph_ptr, g.rowptr, g.col, g.val,
+                 rp_t, col_t, val_t, float(clamp), 1.0 / entries, ds, ds.stride(0), part, loss)
+        ctx.save_for_backward(ds)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, dl):
+        (ds,) = ctx.saved_tensors
+        return ds * dl, None, None, None
+
+
+def link_pred_loss(s, g, clamp=1.0, masked=True):
+    """DiffPool's link-prediction side loss on the packed assignment rows s[total_rows, K] of GraphBatch g
+    (ghost rows carry zeros and are outside every graph: the reference's adj_mask)."""
+    return _LinkPredLoss.apply(s, g, float(clamp), bool(masked))
