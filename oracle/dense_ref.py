@@ -23,7 +23,13 @@ MASK_NEG = -9e15    # encoders_GAT.py:38
 def graph_conv(x, adj, weight, bias=None, add_self=False, normalize=False):
     """GraphConv.forward, encoders.py:30-42 (dropout omitted: p=0 on every hot-path config).
     SUM aggregation, optional +x, @W, +b, row-wise L2 normalise (F.normalize eps=1e-12)."""
-    y = torch.matmul(adj, x)                      # :33
+    if adj.is_sparse:
+        # the same product with the padded batch's block-diagonal adjacency held as ONE sparse [B*Nmax, B*Nmax] matrix
+        # (bench.py's second CPU line: what a sparse CPU implementation of the reference would execute)
+        B, N, Fi = x.shape
+        y = torch.sparse.mm(adj, x.reshape(B * N, Fi)).reshape(B, N, Fi)
+    else:
+        y = torch.matmul(adj, x)                  # :33
     if add_self:
         y = y + x                                 # :35
     y = torch.matmul(y, weight)                   # :36

@@ -123,3 +123,17 @@ def test_gat_encoder(tag):
     for k, t in p.items():
         if "g." + k in g and t.grad is not None:
             np.testing.assert_allclose(t.grad.numpy(), g["g." + k], err_msg=k, rtol=1e-3, atol=1e-4)
+
+
+def test_sparse_aggregation_variant_equals_dense():
+    """bench.py's second CPU line feeds the oracle a block-diagonal sparse adjacency: same numbers as the dense product"""
+    g = torch.Generator().manual_seed(0)
+    B, N, F = 3, 20, 5
+    adj = (torch.rand(B, N, N, generator=g) < 0.2).float()
+    x = torch.randn(B, N, F, generator=g)
+    w, b = torch.randn(F, 7, generator=g), torch.randn(7, generator=g)
+    bi, ri, ci = adj.nonzero(as_tuple=True)
+    sp = torch.sparse_coo_tensor(torch.stack([bi * N + ri, bi * N + ci]), adj[bi, ri, ci], (B * N, B * N)).coalesce()
+    for add_self in (False, True):
+        torch.testing.assert_close(R.graph_conv(x, sp, w, b, add_self=add_self, normalize=True),
+                                   R.graph_conv(x, adj, w, b, add_self=add_self, normalize=True), rtol=1e-5, atol=1e-6)
