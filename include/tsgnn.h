@@ -291,13 +291,15 @@ int tsgnn_elu_heads_bwd_f32(const float* x, const float* dy, int64_t rows, int H
  * adj_mask: only pairs inside a graph's real rows count); slabs: every graph's rows cut into pieces of at most
  * tsgnn_linkpred_tile_rows() rows (slab_row_ptr[nslab+1], slab_graph[nslab]); (rowptr, col, val) the adjacency (val NULL =
  * unit), (rowptr_t, col_t, val_t) its transpose or NULLs when it is symmetric.  dS[rows, K] = d loss / d S (rows outside
- * every slab are left untouched: zero them); part: nslab + 2 * ceil(rows / 4) floats of scratch; loss: 1 float.
+ * every slab are left untouched: zero them); ws: tsgnn_linkpred_chunks() * rows * ldd floats (per-chunk partial gradients,
+ * every row of every slab is written); part: tsgnn_linkpred_chunks() * nslab + 2 * ceil(rows / 4) floats; loss: 1 float.
  * clamp: the reference passes an UNINITIALISED one-element tensor (:424); 1.0 is the value it presumably meant. */
 int tsgnn_linkpred_tile_rows(void);
+int tsgnn_linkpred_chunks(void);
 int tsgnn_linkpred_loss_f32(const float* S, int64_t lds, int K, int64_t rows, const int* slab_row_ptr, const int* slab_graph,
                             int nslab, const int* graph_ptr, const int* rowptr, const int* col, const float* val,
                             const int* rowptr_t, const int* col_t, const float* val_t, float clamp, float inv_entries, float* dS,
-                            int64_t ldd, float* part, float* loss, tsgnn_stream_t stream);
+                            int64_t ldd, float* ws, float* part, float* loss, tsgnn_stream_t stream);
 
 /* ---------------------------------------------------------------- SAGPool path (pooling.hip) */
 

@@ -103,7 +103,7 @@ def test_flat_trainer_views_alias_parameters():
     from two_stage_gnn_amd.data_parallel import FlatTrainer
     m = torch.nn.Linear(3, 2)
     tr = FlatTrainer(m)
-    assert tr.numel == 8
+    assert tr.numel == 10 and tr.views == [(0, 6), (8, 2)]          # parameters start on 16-byte boundaries of the flat buffer
     tr.flat_param.fill_(1.5)
     assert float(m.weight[0, 0]) == 1.5 and float(m.bias[1]) == 1.5
     with pytest.raises(RuntimeError, match="no CPU fallback"):

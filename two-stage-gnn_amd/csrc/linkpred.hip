@@ -27,42 +27,53 @@ __device__ __forceinline__ float lp_clamp(float p, float clamp, float& gate) {
   return fminf(p, clamp);
 }
 
-// one block per 32-row slab of one graph; loops over the graph's row tiles
+// one block per 32-row slab of one graph; loops over the graph's row tiles.  LDS rows are 132 floats apart (16-byte
+// aligned, 4 banks per row step): every fragment read is a conflict-free ds_read_b128 — with one block per CU the kernel
+// is bound by LDS round trips, so reads are wide and batched (the first version, one b32 read per FMA, ran 5x slower).
+constexpr int LP_LD = LP_KMAX + 4;
+constexpr int LP_NY = 4;                 // column-tile chunks per row slab (grid.y): 4 blocks per CU hide each other's LDS / L2 round trips
 __global__ __launch_bounds__(256) void linkpred_pairs_kernel(const float* __restrict__ S, int64_t lds_, int K,
                                                              const int* __restrict__ slab_row_ptr, const int* __restrict__ slab_graph,
                                                              const int* __restrict__ graph_ptr, float clamp, float inv_entries,
-                                                             float* __restrict__ dS, int64_t ldd, float* __restrict__ part) {
-  __shared__ float s_i[LP_TILE][LP_KMAX + 1];
-  __shared__ float s_j[LP_TILE][LP_KMAX + 1];
-  __shared__ float s_g[LP_TILE][LP_TILE + 1];
+                                                             float* __restrict__ dSp, int64_t ldd, int64_t rows,
+                                                             float* __restrict__ part) {
+  __shared__ __attribute__((aligned(16))) float s_i[LP_TILE][LP_LD];
+  __shared__ __attribute__((aligned(16))) float s_j[LP_TILE][LP_LD];
+  __shared__ __attribute__((aligned(16))) float s_g[LP_TILE][LP_TILE + 4];
   __shared__ float s_red[4];
   const int slab = blockIdx.x;
   const int i0 = slab_row_ptr[slab], i1 = slab_row_ptr[slab + 1];
   const int b = slab_graph[slab];
   const int g0 = graph_ptr[b], g1 = graph_ptr[b + 1];
   const int tid = threadIdx.x;
-  for (int t = tid; t < LP_TILE * K; t += 256) {
-    const int r = t / K, k = t - r * K;
-    s_i[r][k] = (i0 + r < i1) ? S[(int64_t)(i0 + r) * lds_ + k] : 0.f;
+  const int K4 = (K + 3) & ~3;                    // columns [K, K4) are zero in LDS
+  const int nk4 = K4 >> 2;
+  for (int t = tid; t < LP_TILE * K4; t += 256) {
+    const int r = t / K4, k = t - r * K4;
+    s_i[r][k] = (i0 + r < i1 && k < K) ? S[(int64_t)(i0 + r) * lds_ + k] : 0.f;
   }
   const int ti = tid >> 3, tj = tid & 7;          // P tile: thread (row ti, columns tj, tj + 8, tj + 16, tj + 24)
-  const int kq = tid & 7;                         // dS accumulation: thread (row ti, k = kq, kq + 8, ...)
-  float acc[LP_KMAX / 8];
+  const int kq = tid & 7;                         // dS accumulation: thread (row ti, k = 4 kq .. 4 kq + 3 (+ 32 q))
+  float4 acc[LP_KMAX / 32];
 #pragma unroll
-  for (int q = 0; q < LP_KMAX / 8; ++q) acc[q] = 0.f;
+  for (int q = 0; q < LP_KMAX / 32; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
   float loss = 0.f;
-  for (int j0 = g0; j0 < g1; j0 += LP_TILE) {
+  for (int j0 = g0 + (int)blockIdx.y * LP_TILE; j0 < g1; j0 += LP_TILE * LP_NY) {      // this block's share of the column tiles
     __syncthreads();
-    for (int t = tid; t < LP_TILE * K; t += 256) {
-      const int r = t / K, k = t - r * K;
-      s_j[r][k] = (j0 + r < g1) ? S[(int64_t)(j0 + r) * lds_ + k] : 0.f;
+    for (int t = tid; t < LP_TILE * K4; t += 256) {
+      const int r = t / K4, k = t - r * K4;
+      s_j[r][k] = (j0 + r < g1 && k < K) ? S[(int64_t)(j0 + r) * lds_ + k] : 0.f;
     }
     __syncthreads();
     float p[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < K; ++k) {
-      const float a = s_i[ti][k];
+#pragma unroll 4
+    for (int k4 = 0; k4 < nk4; ++k4) {
+      const float4 a = *reinterpret_cast<const float4*>(&s_i[ti][4 * k4]);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) p[u] = fmaf(a, s_j[tj + 8 * u][k], p[u]);
+      for (int u = 0; u < 4; ++u) {
+        const float4 c = *reinterpret_cast<const float4*>(&s_j[tj + 8 * u][4 * k4]);
+        p[u] = fmaf(a.x, c.x, fmaf(a.y, c.y, fmaf(a.z, c.z, fmaf(a.w, c.w, p[u]))));
+      }
     }
     const bool vi = i0 + ti < i1;
 #pragma unroll
@@ -75,22 +86,39 @@ __global__ __launch_bounds__(256) void linkpred_pairs_kernel(const float* __rest
       s_g[ti][tj + 8 * u] = v ? gate / om : 0.f;                       // d f0 / d p
     }
     __syncthreads();
-    for (int j = 0; j < LP_TILE; ++j) {
-      const float gij = s_g[ti][j];
+#pragma unroll 2
+    for (int j4 = 0; j4 < LP_TILE / 4; ++j4) {
+      const float4 g4 = *reinterpret_cast<const float4*>(&s_g[ti][4 * j4]);
+      const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
 #pragma unroll
-      for (int q = 0; q < LP_KMAX / 8; ++q)
-        if (kq + 8 * q < K) acc[q] = fmaf(gij, s_j[j][kq + 8 * q], acc[q]);
+      for (int jj = 0; jj < 4; ++jj) {
+#pragma unroll
+        for (int q = 0; q < LP_KMAX / 32; ++q) {
+          if (4 * kq + 32 * q < K4) {
+            const float4 c = *reinterpret_cast<const float4*>(&s_j[4 * j4 + jj][4 * kq + 32 * q]);
+            acc[q].x = fmaf(gv[jj], c.x, acc[q].x); acc[q].y = fmaf(gv[jj], c.y, acc[q].y);
+            acc[q].z = fmaf(gv[jj], c.z, acc[q].z); acc[q].w = fmaf(gv[jj], c.w, acc[q].w);
+          }
+        }
+      }
     }
   }
   if (i0 + ti < i1) {
+    const float sc = 2.f * inv_entries;
 #pragma unroll
-    for (int q = 0; q < LP_KMAX / 8; ++q)
-      if (kq + 8 * q < K) dS[(int64_t)(i0 + ti) * ldd + kq + 8 * q] = 2.f * inv_entries * acc[q];
+    for (int q = 0; q < LP_KMAX / 32; ++q) {
+      const int k = 4 * kq + 32 * q;
+      float* d = dSp + ((int64_t)blockIdx.y * rows + (i0 + ti)) * ldd + k;
+      if (k < K) d[0] = sc * acc[q].x;
+      if (k + 1 < K) d[1] = sc * acc[q].y;
+      if (k + 2 < K) d[2] = sc * acc[q].z;
+      if (k + 3 < K) d[3] = sc * acc[q].w;
+    }
   }
   loss = wave_sum(loss);
   if ((tid & 63) == 0) s_red[tid >> 6] = loss;
   __syncthreads();
-  if (tid == 0) part[slab] = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) * inv_entries;
+  if (tid == 0) part[slab * LP_NY + blockIdx.y] = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) * inv_entries;
 }
 
 // edge corrections, one wave per row i: entries (i, j) of the CSR (and of its transpose when A is not symmetric):
@@ -99,6 +127,7 @@ __global__ __launch_bounds__(256) void linkpred_edges_kernel(const float* __rest
                                                              const int* __restrict__ rowptr, const int* __restrict__ col,
                                                              const float* __restrict__ val, int64_t rows, float clamp,
                                                              float inv_entries, float grad_factor, int count_loss,
+                                                             const float* __restrict__ dSp /*nullable: LP_NY partials to start from*/,
                                                              float* __restrict__ dS, int64_t ldd, float* __restrict__ part) {
   const int lane = threadIdx.x & 63;
   const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -122,8 +151,19 @@ __global__ __launch_bounds__(256) void linkpred_edges_kernel(const float* __rest
       d0 = fmaf(gc, b0, d0);
       d1 = fmaf(gc, b1, d1);
     }
-    if (lane < K) dS[i * ldd + lane] += d0;
-    if (lane + 64 < K) dS[i * ldd + lane + 64] += d1;
+    float o0 = 0.f, o1 = 0.f;
+    if (dSp != nullptr) {
+#pragma unroll
+      for (int y = 0; y < LP_NY; ++y) {
+        if (lane < K) o0 += dSp[((int64_t)y * rows + i) * ldd + lane];
+        if (lane + 64 < K) o1 += dSp[((int64_t)y * rows + i) * ldd + lane + 64];
+      }
+    } else {
+      if (lane < K) o0 = dS[i * ldd + lane];
+      if (lane + 64 < K) o1 = dS[i * ldd + lane + 64];
+    }
+    if (lane < K) dS[i * ldd + lane] = o0 + d0;
+    if (lane + 64 < K) dS[i * ldd + lane + 64] = o1 + d1;
   }
   if (lane == 0) s_red[threadIdx.x >> 6] = (i < rows && count_loss) ? loss * inv_entries : 0.f;
   __syncthreads();
@@ -149,26 +189,27 @@ __global__ __launch_bounds__(256) void linkpred_sum_kernel(const float* __restri
 extern "C" {
 
 int tsgnn_linkpred_tile_rows(void) { return LP_TILE; }
+int tsgnn_linkpred_chunks(void) { return LP_NY; }
 
 int tsgnn_linkpred_loss_f32(const float* S, int64_t lds, int K, int64_t rows, const int* slab_row_ptr, const int* slab_graph,
                             int nslab, const int* graph_ptr, const int* rowptr, const int* col, const float* val,
                             const int* rowptr_t, const int* col_t, const float* val_t, float clamp, float inv_entries, float* dS,
-                            int64_t ldd, float* part, float* loss, tsgnn_stream_t stream) {
-  if (!S || !slab_row_ptr || !slab_graph || !graph_ptr || !rowptr || !dS || !part || !loss || nslab <= 0 || rows <= 0 || K <= 0 ||
+                            int64_t ldd, float* ws, float* part, float* loss, tsgnn_stream_t stream) {
+  if (!S || !slab_row_ptr || !slab_graph || !graph_ptr || !rowptr || !dS || !ws || !part || !loss || nslab <= 0 || rows <= 0 || K <= 0 ||
       lds < K || ldd < K)
     return TSGNN_EINVAL;
   if (K > LP_KMAX) return TSGNN_EUNSUPPORTED;
   if ((rowptr_t == nullptr) != (col_t == nullptr)) return TSGNN_EINVAL;
   const unsigned eblk = (unsigned)ceil_div64(rows, 4);
-  linkpred_pairs_kernel<<<(unsigned)nslab, 256, 0, stream>>>(S, lds, K, slab_row_ptr, slab_graph, graph_ptr, clamp, inv_entries, dS, ldd,
-                                                            part);
+  linkpred_pairs_kernel<<<dim3((unsigned)nslab, LP_NY), 256, 0, stream>>>(S, lds, K, slab_row_ptr, slab_graph, graph_ptr, clamp,
+                                                                         inv_entries, ws, ldd, rows, part);
   // symmetric adjacency: entry (i,j) and its mirror give row i the same term twice
-  linkpred_edges_kernel<<<eblk, 256, 0, stream>>>(S, lds, K, rowptr, col, val, rows, clamp, inv_entries, rowptr_t ? 1.f : 2.f, 1, dS,
-                                                  ldd, part + nslab);
-  int nparts = nslab + (int)eblk;
+  linkpred_edges_kernel<<<eblk, 256, 0, stream>>>(S, lds, K, rowptr, col, val, rows, clamp, inv_entries, rowptr_t ? 1.f : 2.f, 1, ws, dS,
+                                                  ldd, part + nslab * LP_NY);
+  int nparts = nslab * LP_NY + (int)eblk;
   if (rowptr_t) {
-    linkpred_edges_kernel<<<eblk, 256, 0, stream>>>(S, lds, K, rowptr_t, col_t, val_t, rows, clamp, inv_entries, 1.f, 0, dS, ldd,
-                                                    part + nparts);
+    linkpred_edges_kernel<<<eblk, 256, 0, stream>>>(S, lds, K, rowptr_t, col_t, val_t, rows, clamp, inv_entries, 1.f, 0, nullptr, dS,
+                                                    ldd, part + nparts);
     nparts += (int)eblk;
   }
   linkpred_sum_kernel<<<1, 256, 0, stream>>>(part, nparts, loss);

@@ -23,17 +23,24 @@ class FlatTrainer:
         self.model = model
         self.params = [p for p in model.parameters() if p.requires_grad]
         dev = self.params[0].device
-        self.numel = sum(p.numel() for p in self.params)
-        self.flat_param = torch.empty(self.numel, dtype=torch.float32, device=dev)
-        self.flat_grad = torch.zeros(self.numel, dtype=torch.float32, device=dev)
-        off = 0
+        # every parameter starts on a 16-byte boundary of the flat buffer (the float4 / MFMA kernels read weights with 16-byte
+        # loads; a 1-element bias would otherwise misalign everything behind it).  The few padding floats stay zero in the
+        # parameter, gradient and moment buffers, so the norm, the all-reduce and Adam are unaffected by them.
         self.views = []
+        self._pads = []
+        off = 0
         for p in self.params:
-            n = p.numel()
-            self.flat_param[off:off + n].copy_(p.data.reshape(-1))
-            p.data = self.flat_param[off:off + n].view_as(p.data)
-            self.views.append((off, n))
-            off += n
+            pad = (-off) % 4
+            self._pads.append(pad)
+            off += pad
+            self.views.append((off, p.numel()))
+            off += p.numel()
+        self.numel = off
+        self.flat_param = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        for p, (o, n) in zip(self.params, self.views):
+            self.flat_param[o:o + n].copy_(p.data.reshape(-1))
+            p.data = self.flat_param[o:o + n].view_as(p.data)
         self.lr, self.betas, self.eps, self.wd, self.clip = lr, betas, eps, weight_decay, clip
         self.on_gpu = dev.type == "cuda"
         self.exp_avg = torch.zeros_like(self.flat_param)
@@ -41,6 +48,7 @@ class FlatTrainer:
         self.state = torch.zeros(4, dtype=torch.float32, device=dev)      # step, grad norm, applied scale, barrier-timeout flag
         self.ws = torch.zeros(264, dtype=torch.float32, device=dev)       # norm partials + the optimiser kernel's arrival counter
         self._zeros = [torch.zeros_like(p).reshape(-1) for p in self.params]     # stand-ins for parameters without a gradient
+        self._pad_zeros = [torch.zeros(k, dtype=torch.float32, device=dev) if k else None for k in self._pads]
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         # direct_grads: between zero_grad() and gather_grads() the fused backward nodes write parameter gradients straight
@@ -82,7 +90,11 @@ class FlatTrainer:
             self._norm_ready = (bool(written) and self.sink.stepped and written == self.sink.normed
                                 and all(p.grad is None for p in self.params) and self.world == 1 and not self.always_reduce)
         if not written:
-            parts = [(p.grad.reshape(-1) if p.grad is not None else z) for p, z in zip(self.params, self._zeros)]
+            parts = []
+            for p, z, pz in zip(self.params, self._zeros, self._pad_zeros):
+                if pz is not None:
+                    parts.append(pz)
+                parts.append(p.grad.reshape(-1) if p.grad is not None else z)
             torch.cat(parts, out=self.flat_grad)
             self._dirty = {i for i, p in enumerate(self.params) if p.grad is not None}
             return self.flat_grad

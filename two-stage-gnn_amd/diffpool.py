@@ -165,14 +165,16 @@ class _LinkPredLoss(torch.autograd.Function):
         sizes = g.sizes.astype(np.float64)
         entries = float((sizes * sizes).sum()) if masked else float(g.nmax) * g.nmax * g.B
         ds = _f32(s.size(0), K, device=s.device, zero=(s.size(0) > rows))
-        part = _f32(nslab + 2 * ((rows + 3) // 4), device=s.device)
+        ny = int(nat.lib().tsgnn_linkpred_chunks())
+        ws = _f32(ny * rows * K, device=s.device)
+        part = _f32(ny * nslab + 2 * ((rows + 3) // 4), device=s.device)
         loss = _f32(1, device=s.device)
         if g.symmetric:
             rp_t = col_t = val_t = None
         else:
             rp_t, col_t, val_t = g.transposed()
         nat.call("linkpred_loss_f32", s, s.stride(0), K, rows, srp, slab_graph, nslab, g.graph_ptr, g.rowptr, g.col, g.val,
-                 rp_t, col_t, val_t, float(clamp), 1.0 / entries, ds, ds.stride(0), part, loss)
+                 rp_t, col_t, val_t, float(clamp), 1.0 / entries, ds, ds.stride(0), ws, part, loss)
         ctx.save_for_backward(ds)
         return loss.view(())
 

@@ -116,6 +116,11 @@ def _linear_t(du, w):
     return dz
 
 
+def _al16(t):
+    """the float4 kernels read the small parameter vectors with 16-byte loads: a view at an odd offset is copied"""
+    return t if t.data_ptr() % 16 == 0 else t.clone()
+
+
 def supported(hidden):
     return bool(nat.lib().tsgnn_sag_supported(int(hidden)))
 
@@ -146,8 +151,8 @@ class _SagStack(torch.autograd.Function):
             L, Ln = plan.levels[l], plan.levels[l + 1]
             N, K = L.N, Ln.N
             W, b, ws, bs = params[4 * l: 4 * l + 4]
-            W = W.contiguous()
-            wsv = ws.contiguous().view(-1)
+            W, b = _al16(W.contiguous()), _al16(b.contiguous())
+            wsv = _al16(ws.contiguous().view(-1))
             agg, _ = propagate(rowptr, col, dinv, self_w, xin, N)
             y = _linear(agg, W, b)
             _, score = propagate(rowptr, col, dinv, self_w, y, N, relu_in=True, w_dot=wsv, dot_bias=bs, want_y=False)
