@@ -8,8 +8,8 @@ dev = torch.device("cuda"); torch.manual_seed(0)
 hb32 = synthetic.host_batch(2, 32, "DD", 1000)
 x32, adj32 = synthetic.to_dense(hb32)
 gat32 = G.DGATEncoderGraph(89, 64, 64, 2, None, num_layers=2, num_heads=[4, 4], final_dim="number_classes", per_graph_features=True).to(dev)
-x32 = x32.to(dev)
-g32 = GraphBatch.from_dense(adj32.to(dev), layout="padded"); g32.transpose_map()
+adj32d = adj32.to(dev)
+x32, g32 = gat32.packed_batch(x32.to(dev), adj32d, hb32["sizes"])
 lab32 = torch.from_numpy(hb32["label"]).to(dev)
 for _ in range(20):
     gat32.zero_grad(set_to_none=True); gat32.loss(gat32(x32, g32)[1], lab32).backward()

@@ -173,12 +173,15 @@ def test_gat_dd_graph_vs_oracle():
         assert err <= 2e-3 * ref.abs().max().item() + 1e-7, (k, err, ref.abs().max().item())
 
 
-def test_gat_batched_equals_independent_b1_forwards():
+@pytest.mark.parametrize("packed", [True, False])
+def test_gat_batched_equals_independent_b1_forwards(packed):
     """per_graph_features=True: ONE block-diagonal forward of B DD-sized graphs = B reference forwards at B = 1 (the
-    reference's GAT batch size) — outputs per graph, gradients summed over the graphs"""
+    reference's GAT batch size) — outputs per graph, gradients summed over the graphs.  packed: n_b real rows + one ghost
+    representative per graph (a graph that fills all Nmax slots and graphs with isolated nodes included); else all padded rows."""
     from two_stage_gnn_amd import gat_encoders as G
     B, nmax = 4, 320
     x, adj, sizes = dense_batch(6, B, nmax, 89, sizes=[269, 120, 320, 33], p_edge=2 * 676 / 269 / 269)
+    adj[1, 5, :] = 0; adj[1, :, 5] = 0                                     # an isolated real node (a uniform 1/N column)
     torch.manual_seed(2)
     m = G.DGATEncoderGraph(89, 64, 64, 2, None, num_layers=2, num_heads=[4, 4], final_dim="number_classes",
                            per_graph_features=True).cuda()
@@ -190,7 +193,7 @@ def test_gat_batched_equals_independent_b1_forwards():
         refs_a.append(a_ref); refs_b.append(b_ref)
         loss_ref = loss_ref + torch.nn.functional.cross_entropy(b_ref, label[b:b + 1])
     loss_ref.backward()
-    a, bb = m(x.cuda(), adj.cuda(), sizes)
+    a, bb = m(x.cuda(), adj.cuda(), sizes if packed else None)
     torch.testing.assert_close(a.detach().cpu(), torch.cat(refs_a).detach(), rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(bb.detach().cpu(), torch.cat(refs_b).detach(), rtol=1e-4, atol=1e-4)
     (m.loss(bb, label.cuda()) * B).backward()                              # mean over graphs * B = sum of the B = 1 losses

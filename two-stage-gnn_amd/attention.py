@@ -32,13 +32,22 @@ def segment_wsum(x, w, H, Fh, seg_ptr, nseg, scale=1.0, mean=False, max_seg=None
     return out
 
 
+def _row_seg(g):
+    """row -> graph map for ragged batches (None: every graph has g.nmax rows, the kernels divide)"""
+    return g.row_graph if getattr(g, "row_mult", None) is not None else None
+
+
 def _isolated_columns(g, rp_t, R, H):
     """[R, H] indicator of columns without any edge; depends on the graph only, cached on it"""
     cache = g.__dict__.setdefault("_iso_cols", {})
     iso = cache.get(H)
     if iso is None:
         deg_t = rp_t[1:] - rp_t[:-1]
-        iso = cache[H] = (deg_t == 0).to(torch.float32).unsqueeze(1).expand(R, H).contiguous()
+        w = (deg_t == 0).to(torch.float32)
+        mult = getattr(g, "row_mult", None)
+        if mult is not None:
+            w = w * mult                  # a ghost representative stands for Nmax - n_b identical all-masked columns
+        iso = cache[H] = w.unsqueeze(1).expand(R, H).contiguous()
     return iso
 
 
@@ -76,7 +85,7 @@ class _AttentionAggregate(torch.autograd.Function):
             N = g.nmax
             u = segment_wsum(h, iso, H, Fh, g.graph_ptr, g.B, scale=1.0 / N, max_seg=int(g.sizes.max()))
             nat.call("csr_spmm_heads_epi_f32", g.rowptr, g.col, alpha, H, Fh, h, h.stride(0), 0, out, out.stride(0), R,
-                     None, None, 0, None, None, 0, u, u.stride(0), None, N, 1.0)
+                     None, None, 0, None, None, 0, u, u.stride(0), None, N, _row_seg(g), 1.0)
         else:
             nat.call("csr_spmm_heads_f32", g.rowptr, g.col, alpha, H, Fh, h, h.stride(0), 0, out, out.stride(0), R)
         ctx.g, ctx.H, ctx.Fh, ctx.slope, ctx.by_column = g, H, Fh, slope, by_column
@@ -121,7 +130,7 @@ class _AttentionAggregate(torch.autograd.Function):
             du = segment_wsum(dout, None, H, Fh, g.graph_ptr, g.B, scale=1.0, max_seg=int(g.sizes.max()))
         nat.call("csr_spmm_heads_epi_f32", rp_t, col_t, alpha_t, H, Fh, dout, dout.stride(0), 0, dh, dh.stride(0), R,
                  ds_row, a_row, a_row.stride(0), ds_col, a_col, a_col.stride(0), du, du.stride(0) if du is not None else 0,
-                 iso, N, 1.0 / N)
+                 iso, N, _row_seg(g), 1.0 / N)
         da_row = segment_wsum(h, ds_row, H, Fh, None, 1).view(H, Fh)
         da_col = segment_wsum(h, ds_col, H, Fh, None, 1).view(H, Fh)
         return dh, da_row, da_col, None, None, None, None, None

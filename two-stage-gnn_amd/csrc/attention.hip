@@ -112,12 +112,13 @@ struct HeadsEpi {
   const float* w1; const float* a1; int64_t lda1;
   const float* w2; const float* a2; int64_t lda2;
   const float* u; int64_t ldu; const float* uw; int rows_per_seg; float uscale;
+  const int* row_seg;      // nullable: segment (graph) of every row for ragged batches; else r / rows_per_seg
 };
 __device__ __forceinline__ float heads_epi(const HeadsEpi& e, int64_t r, int H, int Fh, int h, int f /*within head*/) {
   float add = 0.f;
   if (e.w1) add = fmaf(e.w1[r * H + h], e.a1[(int64_t)h * e.lda1 + f], add);
   if (e.w2) add = fmaf(e.w2[r * H + h], e.a2[(int64_t)h * e.lda2 + f], add);
-  if (e.u) add = fmaf(e.uscale * (e.uw ? e.uw[r * H + h] : 1.f), e.u[(r / e.rows_per_seg) * e.ldu + (int64_t)h * Fh + f], add);
+  if (e.u) add = fmaf(e.uscale * (e.uw ? e.uw[r * H + h] : 1.f), e.u[(e.row_seg ? (int64_t)e.row_seg[r] : r / e.rows_per_seg) * e.ldu + (int64_t)h * Fh + f], add);
   return add;
 }
 
@@ -446,9 +447,9 @@ int tsgnn_csr_spmm_heads_f32(const int* rowptr, const int* col, const float* alp
 int tsgnn_csr_spmm_heads_epi_f32(const int* rowptr, const int* col, const float* alpha, int H, int Fh, const float* x, int64_t ldx,
                                  int mod, float* y, int64_t ldy, int64_t rows, const float* w1, const float* a1, int64_t lda1,
                                  const float* w2, const float* a2, int64_t lda2, const float* u, int64_t ldu, const float* uw,
-                                 int rows_per_seg, float uscale, tsgnn_stream_t stream) {
-  if ((w1 && !a1) || (w2 && !a2) || (u && rows_per_seg <= 0)) return TSGNN_EINVAL;
-  HeadsEpi epi{w1, a1, lda1, w2, a2, lda2, u, ldu, uw, rows_per_seg, uscale};
+                                 int rows_per_seg, const int* row_seg, float uscale, tsgnn_stream_t stream) {
+  if ((w1 && !a1) || (w2 && !a2) || (u && rows_per_seg <= 0 && !row_seg)) return TSGNN_EINVAL;
+  HeadsEpi epi{w1, a1, lda1, w2, a2, lda2, u, ldu, uw, rows_per_seg, uscale, row_seg};
   return spmm_heads_launch(rowptr, col, alpha, H, Fh, x, ldx, mod, y, ldy, rows, epi, stream);
 }
 

@@ -9,8 +9,14 @@ replaced by per-edge kernels (attention.py).  Bug-compatible with the reference 
     would re-initialise nothing, so it is simply omitted here.
 ``DGATEncoderGraph(..., per_graph_features=True)`` (extension, default off) gives every graph of a batch its OWN
 features: one batched forward then equals B independent B = 1 reference forwards (the reference's GAT batch size,
-train.py:480) in outputs and summed gradients, and the per-edge kernels run once on the block-diagonal batch.
+train.py:480) in outputs and summed gradients, and the per-edge kernels run once on the block-diagonal batch.  With
+``batch_num_nodes`` that batch is packed: n_b real rows per graph plus ONE representative of its Nmax - n_b padded rows
+(``GraphBatch.from_dense_ghost1``) — padded rows have no edges and there are no per-slot statistics in this model, so
+they are identical in every layer; as all-masked softmax columns they add (Nmax - n_b) / Nmax * h_ghost to every row
+of their graph, which is the only place their multiplicity enters (forward weight and backward scale).
 """
+import weakref
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -20,6 +26,9 @@ from . import attention as att
 from . import message_passing as mp
 from .dense_encoders import GraphConv, _batch_from_dense, _default_device
 from .graph import GraphBatch
+
+
+_ghost1_cache = {}
 
 
 def _padded_batch(adj):
@@ -105,8 +114,14 @@ def _gat_heads_forward(heads, x, adj, concat_heads, elu):
     H = len(heads)
     Fo = heads[0].output_dim
     slope = heads[0].leakyRELU_neg_input_slope
-    own = heads[0].per_graph_features and B > 1
-    x0 = x.reshape(B * N, -1).contiguous().float() if own else _rows_of_graph0(x, g)     # [N, Fin] ([B*N, Fin] per-graph)
+    ragged = getattr(g, "row_mult", None) is not None          # packed rows + one ghost representative per graph
+    if ragged and not heads[0].per_graph_features:
+        raise ValueError("the packed GAT batch needs per_graph_features=True")
+    own = ragged or (heads[0].per_graph_features and B > 1)
+    if ragged:
+        x0 = x.contiguous().float()                            # [rows, Fin]
+    else:
+        x0 = x.reshape(B * N, -1).contiguous().float() if own else _rows_of_graph0(x, g)  # [N, Fin] ([B*N, Fin] per-graph)
     if x0.size(1) % 4 and not x0.requires_grad:
         x0 = F.pad(x0, (0, 4 - x0.size(1) % 4))                            # 16-byte rows: the MFMA row-panel product applies
     W = _CatHeadWeights.apply(*[hd.w for hd in heads])                      # [Fin, H*Fo]
@@ -119,7 +134,7 @@ def _gat_heads_forward(heads, x, adj, concat_heads, elu):
     if p > 0 and heads[0].training:
         raise NotImplementedError("attention dropout > 0 is not on the benchmarked path (reference default 0.0)")
     out = att.elu_heads(pre, H, mean_heads=not concat_heads, apply_elu=elu)
-    return out.reshape(B, N, -1)
+    return out if ragged else out.reshape(B, N, -1)
 
 
 class DGATLayer(nn.Module):
@@ -192,11 +207,32 @@ class DGATEncoderGraph(nn.Module):
                 x = layer(x, g)
         return conv_last(x, g)
 
+    def packed_batch(self, x, adj, batch_num_nodes):
+        """(rows, GraphBatch) of the packed block-diagonal batch (per_graph_features mode): dense adj [B,Nmax,Nmax] -> CSR
+        over n_b + 1 rows per graph, cached per adj tensor; x [B,Nmax,F] -> those rows."""
+        sizes = np.asarray(batch_num_nodes, dtype=np.int64).reshape(-1)
+        key = (adj.data_ptr(), tuple(adj.shape), adj._version, tuple(int(v) for v in sizes))
+        hit = _ghost1_cache.get(key)
+        if hit is not None and hit[0]() is adj:
+            g = hit[1]
+        else:
+            g = GraphBatch.from_dense_ghost1(adj.detach(), sizes)
+            g.transpose_map()
+            if len(_ghost1_cache) > 8:
+                _ghost1_cache.clear()
+            _ghost1_cache[key] = (weakref.ref(adj), g)
+        F_in = x.size(2)
+        return mp.pack_rows(x, g, (F_in + 3) // 4 * 4), g
+
     def forward(self, x, adj, batch_num_nodes=None, **kwargs):
+        if self.conv_first.attentions[0].per_graph_features and batch_num_nodes is not None and not isinstance(adj, GraphBatch) \
+                and adj.size(0) > 1:
+            x, adj = self.packed_batch(x, adj, batch_num_nodes)
         g = _padded_batch(adj)
-        x = self.gcn_forward(x, g, self.conv_first, self.conv_block, self.conv_last)       # [B,N,E]
-        B, N, E = x.shape
-        x = mp.readout_max(x.reshape(B * N, E), g)                                          # max over ALL padded rows (:189)
+        x = self.gcn_forward(x, g, self.conv_first, self.conv_block, self.conv_last)       # [B,N,E] ([rows,E] packed)
+        if x.dim() == 3:
+            x = x.reshape(g.B * g.nmax, x.size(2))
+        x = mp.readout_max(x, g)                                                            # max over ALL padded rows (:189)
         if self.final_dim != "output_dim":
             return x, self.map2_model(self.pred_model(x))
         return x, self.map2_model(self.map_model(x))

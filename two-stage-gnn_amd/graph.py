@@ -85,7 +85,26 @@ class GraphBatch:
 
     # ------------------------------------------------------------------ builders
     @classmethod
-    def from_dense(cls, adj, sizes=None, layout="packed", assume_symmetric=False):
+    def from_dense_ghost1(cls, adj, sizes, assume_symmetric=False):
+        """Packed rows with ONE ghost representative per graph (the row right after its n_b real rows, multiplicity
+        ``row_mult = Nmax - n_b``; graphs that fill all Nmax slots get none).  For models without per-slot statistics (the
+        GAT encoder): all padded rows of one graph carry the same value in every layer, so one row stands for them
+        (DESIGN.md §4d).  ``g.real_sizes`` keeps n_b; ``g.sizes`` counts the representative."""
+        sizes = np.asarray(sizes, dtype=np.int64).reshape(-1)
+        nmax = adj.size(1)
+        if (sizes > nmax).any() or (sizes < 0).any():
+            raise ValueError("graph sizes must lie in [0, nmax]")
+        has_ghost = sizes < nmax
+        g = cls.from_dense(adj, sizes + has_ghost, layout="packed", assume_symmetric=assume_symmetric, ghosts=False)
+        mult = np.ones(g.n_rows, dtype=np.float32)
+        ends = np.cumsum(sizes + has_ghost) - 1
+        mult[ends[has_ghost]] = (nmax - sizes[has_ghost]).astype(np.float32)
+        g.row_mult = torch.from_numpy(mult).to(adj.device)
+        g.real_sizes = sizes
+        return g
+
+    @classmethod
+    def from_dense(cls, adj, sizes=None, layout="packed", assume_symmetric=False, ghosts=None):
         """adj: float32 [B,Nmax,Nmax] on the GPU (the tensor train.py:114 uploads).
         layout='packed' needs ``sizes`` (= batch_num_nodes) and assumes zero padding outside
         [:n_b,:n_b] (what GraphSampler produces); layout='padded' keeps all B*Nmax rows."""
@@ -99,7 +118,7 @@ class GraphBatch:
             sizes = np.full(B, nmax, dtype=np.int64)
         elif sizes is None:
             raise ValueError("packed layout needs the per-graph node counts")
-        g._set_sizes(sizes, nmax, adj.device, ghosts=(layout != "padded"))
+        g._set_sizes(sizes, nmax, adj.device, ghosts=(layout != "padded") if ghosts is None else bool(ghosts))
         if g.B != B:
             raise ValueError("len(sizes) != batch size of adj")
         R = g.n_rows
