@@ -284,6 +284,22 @@ int tsgnn_elu_heads_fwd_f32(const float* x, int64_t rows, int H, int Fh, int mea
 int tsgnn_elu_heads_bwd_f32(const float* x, const float* dy, int64_t rows, int H, int Fh, int mean_heads, int apply_elu, float* dx,
                             tsgnn_stream_t stream);
 
+/* ---------------------------------------------------------------- SAGPool graph-level head (mlp_head.hip) */
+
+/* Code/sag/network.py:48-53 in one launch: a1 = relu(x W1^T + b1) * keep * keep_scale (dropout mask keep[B, D1] of 0 / 1,
+ * NULL = no dropout), a2 = relu(a1 W2^T + b2), logp = log_softmax(a2 W3^T + b3).  W* in nn.Linear's [out, in] layout,
+ * x[B, D0].  a1, a2 are kept for the backward.  D0 % 4 == 0, D1 % 4 == 0, C <= 16, 16-byte aligned W1 / W2. */
+int tsgnn_mlp3_supported(int B, int D0, int D1, int D2, int C);
+int tsgnn_mlp3_fwd_f32(const float* x, int64_t ldx, const float* w1, const float* b1, const float* keep, float keep_scale, const float* w2,
+                       const float* b2, const float* w3, const float* b3, int B, int D0, int D1, int D2, int C, float* a1, float* a2,
+                       float* logp, tsgnn_stream_t stream);
+/* its backward in one launch ([dW1 tiles | dW2 tiles | dW3 | dX rows] blocks, each recomputing dlogits -> dz2 in LDS);
+ * dlogp[B, C] = gradient w.r.t. logp; dx nullable. */
+int tsgnn_mlp3_bwd_f32(const float* x, int64_t ldx, const float* w1, const float* w2, const float* w3, const float* a1,
+                       const float* a2, const float* logp, const float* dlogp, float keep_scale, int B, int D0, int D1, int D2, int C,
+                       float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3, float* dx, int64_t lddx,
+                       tsgnn_stream_t stream);
+
 /* ---------------------------------------------------------------- DiffPool link-prediction side loss (linkpred.hip) */
 
 /* encoders.py:416-440 for adj_hop = 1, value and gradient in one pass, no [B,N,N] tensor:

@@ -350,3 +350,35 @@ def test_linear_oi_matches_torch_linear(R, K, N):
     torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-4)
     for a, c in ((xg, xr), (wg, wr), (bg, br)):
         torch.testing.assert_close(a.grad.cpu(), c.grad, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("B,D0,D1,D2,C,p", [(128, 256, 128, 64, 2, 0.5), (6, 64, 32, 16, 2, 0.0), (37, 128, 60, 30, 5, 0.3)])
+def test_mlp3_head_matches_torch(B, D0, D1, D2, C, p):
+    """the SAGPool head (network.py:48-53) fused into one launch per direction, against torch's own ops with the same mask"""
+    from two_stage_gnn_amd import message_passing as mp
+    torch.manual_seed(B + D1)
+    lins = [torch.nn.Linear(D0, D1), torch.nn.Linear(D1, D2), torch.nn.Linear(D2, C)]
+    ref_lins = [torch.nn.Linear(D0, D1), torch.nn.Linear(D1, D2), torch.nn.Linear(D2, C)]
+    for a, b in zip(lins, ref_lins):
+        b.load_state_dict(a.state_dict())
+    lins = [m.cuda() for m in lins]
+    assert mp.mlp3_ok(torch.empty(B, D0, device="cuda"), *lins)
+    x = torch.randn(B, D0)
+    keep = torch.empty(B, D1).bernoulli_(1.0 - p) if p > 0 else None
+    scale = 1.0 / (1.0 - p)
+    xr = x.clone().requires_grad_(True)
+    h = torch.relu(ref_lins[0](xr))
+    if keep is not None:
+        h = h * keep * scale
+    ref = torch.log_softmax(ref_lins[2](torch.relu(ref_lins[1](h))), dim=-1)
+    gy = torch.randn(B, C)
+    (ref * gy).sum().backward()
+    xg = x.cuda().requires_grad_(True)
+    out = mp._Mlp3LogSoftmax.apply(xg, lins[0].weight, lins[0].bias, lins[1].weight, lins[1].bias, lins[2].weight, lins[2].bias,
+                                   keep.cuda() if keep is not None else None, scale)
+    (out * gy.cuda()).sum().backward()
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(xg.grad.cpu(), xr.grad, rtol=1e-4, atol=1e-5)
+    for a, b in zip(lins, ref_lins):
+        torch.testing.assert_close(a.weight.grad.cpu(), b.weight.grad, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(a.bias.grad.cpu(), b.bias.grad, rtol=1e-4, atol=1e-5)

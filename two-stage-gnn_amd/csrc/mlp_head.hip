@@ -1,0 +1,282 @@
+// Graph-level head of the SAGPool model (Code/sag/network.py:25-27,48-53):
+//     x = relu(lin1(x)); x = dropout(x); x = relu(lin2(x)); x = log_softmax(lin3(x))
+// forward and backward in 1 + 1 launches instead of ~25 library launches (3 addmm + 6 mm + bias reductions + the
+// element-wise passes between them), for the small row counts of a graph-level head (B = graphs per batch).
+// The dropout keep-mask (0 / 1 per element, scaled by keep_scale = 1/(1-p) here) is an input: the random stream stays the
+// framework's own.
+//   forward : one workgroup per graph row; weights streamed from L2 with 16-byte loads, a wave owns eight output
+//             rows at a time and reduces their dot products with DPP.
+//   backward: ONE launch of four block kinds, each recomputing the tiny upstream chain it needs
+//             (dlogits -> dz2 [B, D2] in LDS) instead of exchanging it through HBM with another launch:
+//               [dW1 tile ‖ dW2 tile ‖ dW3 ‖ dX rows]
+//             weight gradients are plain sums over the B rows in row order (no atomics, reproducible).
+#include "common.h"
+#include "../../include/tsgnn.h"
+
+namespace {
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+constexpr int MH_WAVES = 16;   // forward: 1024 threads per row
+
+// vs[j] = act(W[j,:] . xs + bias[j]) for j < E   (W [E, P] row-major, P % 4 == 0, xs in LDS)
+template <bool RELU>
+__device__ __forceinline__ void dense_row(const float* xs, int P, const float* __restrict__ w, const float* __restrict__ bias, int E,
+                                          float* vs) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int P4 = P >> 2;
+  for (int j0 = wid; j0 < E; j0 += 8 * MH_WAVES) {
+    float acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+    for (int k4 = lane; k4 < P4; k4 += 64) {
+      const float4 x = *reinterpret_cast<const float4*>(xs + 4 * k4);
+      float4 wv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int j = j0 + MH_WAVES * u;
+        wv[u] = ld4(w + (int64_t)(j < E ? j : 0) * P + 4 * k4);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] += (wv[u].x * x.x + wv[u].y * x.y) + (wv[u].z * x.z + wv[u].w * x.w);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int j = j0 + MH_WAVES * u;
+      const float r = wave_sum(acc[u]);
+      if (lane == 0 && j < E) {
+        const float v = r + (bias ? bias[j] : 0.f);
+        vs[j] = RELU ? fmaxf(v, 0.f) : v;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(64 * MH_WAVES) void mlp3_fwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ w1,
+                                                                 const float* __restrict__ b1, const float* __restrict__ keep,
+                                                                 float keep_scale, const float* __restrict__ w2, const float* __restrict__ b2,
+                                                                 const float* __restrict__ w3, const float* __restrict__ b3, int D0,
+                                                                 int D1, int D2, int C, float* __restrict__ a1, float* __restrict__ a2,
+                                                                 float* __restrict__ logp) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* xs = smem;                              // [D0]
+  float* v1 = xs + D0;                           // [D1]
+  float* v2 = v1 + ((D1 + 3) & ~3);              // [D2]
+  float* lg = v2 + ((D2 + 3) & ~3);              // [C]
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  for (int k = tid; k < D0; k += 64 * MH_WAVES) xs[k] = x[(int64_t)b * ldx + k];
+  __syncthreads();
+  dense_row<true>(xs, D0, w1, b1, D1, v1);
+  __syncthreads();
+  for (int j = tid; j < D1; j += 64 * MH_WAVES) {
+    const float v = v1[j] * (keep ? keep[(int64_t)b * D1 + j] * keep_scale : 1.f);   // dropout after the ReLU (network.py:48-49)
+    v1[j] = v;
+    a1[(int64_t)b * D1 + j] = v;
+  }
+  __syncthreads();
+  dense_row<true>(v1, D1, w2, b2, D2, v2);
+  __syncthreads();
+  for (int j = tid; j < D2; j += 64 * MH_WAVES) a2[(int64_t)b * D2 + j] = v2[j];
+  for (int c = wid; c < C; c += MH_WAVES) {
+    float acc = 0.f;
+    for (int j = lane; j < D2; j += 64) acc = fmaf(w3[(int64_t)c * D2 + j], v2[j], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) lg[c] = acc + (b3 ? b3[c] : 0.f);
+  }
+  __syncthreads();
+  if (tid < C) {
+    float m = -INFINITY;
+    for (int c = 0; c < C; ++c) m = fmaxf(m, lg[c]);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += expf(lg[c] - m);
+    logp[(int64_t)b * C + tid] = lg[tid] - m - logf(s);
+  }
+}
+
+struct Mlp3Bwd {
+  const float* x; int64_t ldx;
+  const float* w1; const float* w2; const float* w3;
+  const float* a1; const float* a2; const float* logp; const float* dlogp;
+  float keep_scale;                      // 1/(1-p) (1 without dropout): d a1 / d z1 = keep_scale * [a1 > 0]
+  int B, D0, D1, D2, C;
+  float* dw1; float* db1; float* dw2; float* db2; float* dw3; float* db3; float* dx; int64_t lddx;
+  int nW1, nW2;                          // block kinds: [0, nW1) dW1 tiles, [nW1, nW1+nW2) dW2 tiles, one dW3 block, then dX rows
+};
+
+constexpr int MB_TILE = 8;               // weight rows per tile block
+constexpr int MB_ROWS = 4;               // batch rows per dX block
+
+// dz2[r, k] = [a2 > 0] * sum_c dlogits[r, c] W3[c, k],  dlogits = dlogp - softmax * sum_c dlogp   for rows [r0, r1)
+__device__ __forceinline__ void mlp3_dz2(const Mlp3Bwd& p, int r0, int r1, float* dlg /*[rows][C]*/, float* dz2 /*[rows][D2+1]*/) {
+  const int tid = threadIdx.x, nr = r1 - r0;
+  for (int r = tid; r < nr; r += 256) {
+    float s = 0.f;
+    for (int c = 0; c < p.C; ++c) s += p.dlogp[(int64_t)(r0 + r) * p.C + c];
+    for (int c = 0; c < p.C; ++c)
+      dlg[r * p.C + c] = p.dlogp[(int64_t)(r0 + r) * p.C + c] - expf(p.logp[(int64_t)(r0 + r) * p.C + c]) * s;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < nr * p.D2; idx += 256) {
+    const int r = idx / p.D2, k = idx - r * p.D2;
+    float v = 0.f;
+    for (int c = 0; c < p.C; ++c) v = fmaf(dlg[r * p.C + c], p.w3[(int64_t)c * p.D2 + k], v);
+    dz2[r * (p.D2 + 1) + k] = p.a2[(int64_t)(r0 + r) * p.D2 + k] > 0.f ? v : 0.f;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void mlp3_bwd_kernel(Mlp3Bwd p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const int bid = blockIdx.x;
+  const int B = p.B, D0 = p.D0, D1 = p.D1, D2 = p.D2, C = p.C;
+  if (bid < p.nW1 + p.nW2 + 1) {
+    float* dlg = smem;                                   // [B][C]
+    float* dz2 = dlg + ((B * C + 3) & ~3);               // [B][D2+1]
+    float* t8 = dz2 + B * (D2 + 1);                      // [B][8]   (dW1 blocks: the dz1 tile)
+    mlp3_dz2(p, 0, B, dlg, dz2);
+    if (bid < p.nW1) {
+      // ---- dW1[o, :] for o in the tile: dz1[b, o] = gate * sum_k dz2[b, k] W2[k, o]
+      const int o0 = bid * MB_TILE;
+      for (int idx = tid; idx < B * MB_TILE; idx += 256) {
+        const int b = idx / MB_TILE, u = idx - b * MB_TILE;
+        const int o = o0 + u;
+        float v = 0.f;
+        if (o < D1) {
+          for (int k = 0; k < D2; ++k) v = fmaf(dz2[b * (D2 + 1) + k], p.w2[(int64_t)k * D1 + o], v);
+          v = p.a1[(int64_t)b * D1 + o] > 0.f ? v * p.keep_scale : 0.f;
+        }
+        t8[b * MB_TILE + u] = v;
+      }
+      __syncthreads();
+      for (int i = tid; i < D0; i += 256) {
+        float acc[MB_TILE];
+#pragma unroll
+        for (int u = 0; u < MB_TILE; ++u) acc[u] = 0.f;
+        for (int b = 0; b < B; ++b) {
+          const float xv = p.x[(int64_t)b * p.ldx + i];
+#pragma unroll
+          for (int u = 0; u < MB_TILE; ++u) acc[u] = fmaf(t8[b * MB_TILE + u], xv, acc[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < MB_TILE; ++u)
+          if (o0 + u < D1) p.dw1[(int64_t)(o0 + u) * D0 + i] = acc[u];
+      }
+      if (tid < MB_TILE && o0 + tid < D1) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += t8[b * MB_TILE + tid];
+        p.db1[o0 + tid] = s;
+      }
+    } else if (bid < p.nW1 + p.nW2) {
+      // ---- dW2[k, :] for k in the tile: sum_b dz2[b, k] a1[b, :]
+      const int k0 = (bid - p.nW1) * MB_TILE;
+      for (int o = tid; o < D1; o += 256) {
+        float acc[MB_TILE];
+#pragma unroll
+        for (int u = 0; u < MB_TILE; ++u) acc[u] = 0.f;
+        for (int b = 0; b < B; ++b) {
+          const float av = p.a1[(int64_t)b * D1 + o];
+#pragma unroll
+          for (int u = 0; u < MB_TILE; ++u) acc[u] = fmaf(k0 + u < D2 ? dz2[b * (D2 + 1) + k0 + u] : 0.f, av, acc[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < MB_TILE; ++u)
+          if (k0 + u < D2) p.dw2[(int64_t)(k0 + u) * D1 + o] = acc[u];
+      }
+      if (tid < MB_TILE && k0 + tid < D2) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += dz2[b * (D2 + 1) + k0 + tid];
+        p.db2[k0 + tid] = s;
+      }
+    } else {
+      // ---- dW3[c, k] = sum_b dlogits[b, c] a2[b, k],  db3[c] = sum_b dlogits[b, c]
+      for (int idx = tid; idx < C * D2; idx += 256) {
+        const int c = idx / D2, k = idx - c * D2;
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s = fmaf(dlg[b * C + c], p.a2[(int64_t)b * D2 + k], s);
+        p.dw3[idx] = s;
+      }
+      if (tid < C) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += dlg[b * C + tid];
+        p.db3[tid] = s;
+      }
+    }
+    return;
+  }
+  // ---- dX rows: dz2 -> dz1 (all D1 columns) -> dx = dz1 W1
+  if (p.dx == nullptr) return;
+  const int r0 = (bid - (p.nW1 + p.nW2 + 1)) * MB_ROWS, r1 = min(B, r0 + MB_ROWS), nr = r1 - r0;
+  float* dlg = smem;                                     // [4][C]
+  float* dz2 = dlg + ((MB_ROWS * C + 3) & ~3);           // [4][D2+1]
+  float* dz1 = dz2 + MB_ROWS * (D2 + 1);                 // [4][D1]
+  mlp3_dz2(p, r0, r1, dlg, dz2);
+  for (int idx = tid; idx < nr * D1; idx += 256) {
+    const int r = idx / D1, o = idx - r * D1;
+    float v = 0.f;
+    for (int k = 0; k < D2; ++k) v = fmaf(dz2[r * (D2 + 1) + k], p.w2[(int64_t)k * D1 + o], v);
+    dz1[r * D1 + o] = p.a1[(int64_t)(r0 + r) * D1 + o] > 0.f ? v * p.keep_scale : 0.f;
+  }
+  __syncthreads();
+  for (int i = tid; i < D0; i += 256) {
+    float acc[MB_ROWS] = {0.f, 0.f, 0.f, 0.f};
+    for (int o = 0; o < D1; ++o) {
+      const float wv = p.w1[(int64_t)o * D0 + i];
+#pragma unroll
+      for (int r = 0; r < MB_ROWS; ++r) acc[r] = fmaf(r < nr ? dz1[r * D1 + o] : 0.f, wv, acc[r]);
+    }
+    for (int r = 0; r < nr; ++r) p.dx[(int64_t)(r0 + r) * p.lddx + i] = acc[r];
+  }
+}
+
+inline size_t bwd_lds_bytes(int B, int D1, int D2, int C) {
+  const size_t wblk = (size_t)((B * C + 3) & ~3) + (size_t)B * (D2 + 1) + (size_t)B * MB_TILE;
+  const size_t rblk = (size_t)((MB_ROWS * C + 3) & ~3) + (size_t)MB_ROWS * (D2 + 1) + (size_t)MB_ROWS * D1;
+  return sizeof(float) * (wblk > rblk ? wblk : rblk);
+}
+
+}  // namespace
+
+extern "C" {
+
+/* 1 when the fused head accepts the shape: D0 % 4 == 0 (16-byte weight rows), D1 % 4 == 0, C <= 16, and the backward's
+ * per-block copy of dz2[B, D2] fits LDS */
+int tsgnn_mlp3_supported(int B, int D0, int D1, int D2, int C) {
+  if (B <= 0 || D0 <= 0 || D1 <= 0 || D2 <= 0 || C <= 0 || C > 16 || D0 % 4 || D1 % 4 || D0 > 4096 || D1 > 2048 || D2 > 1024) return 0;
+  return bwd_lds_bytes(B, D1, D2, C) <= 96 * 1024 ? 1 : 0;
+}
+
+int tsgnn_mlp3_fwd_f32(const float* x, int64_t ldx, const float* w1, const float* b1, const float* keep, float keep_scale, const float* w2,
+                       const float* b2, const float* w3, const float* b3, int B, int D0, int D1, int D2, int C, float* a1, float* a2,
+                       float* logp, tsgnn_stream_t stream) {
+  if (!x || !w1 || !w2 || !w3 || !a1 || !a2 || !logp || ldx < D0) return TSGNN_EINVAL;
+  if (!tsgnn_mlp3_supported(B, D0, D1, D2, C) || (reinterpret_cast<uintptr_t>(w1) & 15) || (reinterpret_cast<uintptr_t>(w2) & 15))
+    return TSGNN_EUNSUPPORTED;
+  const size_t lds = sizeof(float) * ((size_t)D0 + ((D1 + 3) & ~3) + ((D2 + 3) & ~3) + C);
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp3_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  mlp3_fwd_kernel<<<(unsigned)B, 64 * MH_WAVES, lds, stream>>>(x, ldx, w1, b1, keep, keep_scale, w2, b2, w3, b3, D0, D1, D2, C, a1, a2, logp);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+int tsgnn_mlp3_bwd_f32(const float* x, int64_t ldx, const float* w1, const float* w2, const float* w3, const float* a1,
+                       const float* a2, const float* logp, const float* dlogp, float keep_scale, int B, int D0, int D1, int D2, int C,
+                       float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3, float* dx, int64_t lddx,
+                       tsgnn_stream_t stream) {
+  if (!x || !w1 || !w2 || !w3 || !a1 || !a2 || !logp || !dlogp || !dw1 || !db1 || !dw2 || !db2 || !dw3 || !db3 || ldx < D0 ||
+      (dx && lddx < D0))
+    return TSGNN_EINVAL;
+  if (!tsgnn_mlp3_supported(B, D0, D1, D2, C)) return TSGNN_EUNSUPPORTED;
+  Mlp3Bwd p{x, ldx, w1, w2, w3, a1, a2, logp, dlogp, keep_scale, B, D0, D1, D2, C, dw1, db1, dw2, db2, dw3, db3, dx, lddx,
+            (D1 + MB_TILE - 1) / MB_TILE, (D2 + MB_TILE - 1) / MB_TILE};
+  const unsigned nblk = (unsigned)(p.nW1 + p.nW2 + 1 + (dx ? (B + MB_ROWS - 1) / MB_ROWS : 0));
+  const size_t lds = bwd_lds_bytes(B, D1, D2, C);
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp3_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  mlp3_bwd_kernel<<<nblk, 256, lds, stream>>>(p);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+}  // extern "C"

@@ -283,6 +283,52 @@ def linear_oi(x, weight, bias=None):
     return _LinearOI.apply(x, weight, bias)
 
 
+class _Mlp3LogSoftmax(torch.autograd.Function):
+    """log_softmax(lin3(relu(lin2(dropout(relu(lin1(x))))))) — Code/sag/network.py:48-53 — forward and backward in one launch each"""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, w3, b3, keep, keep_scale):
+        x = _check(x)
+        w1, w2, w3 = w1.contiguous(), w2.contiguous(), w3.contiguous()
+        B, D0, D1, D2, C = x.size(0), w1.size(1), w1.size(0), w2.size(0), w3.size(0)
+        a1, a2, logp = _f32(B, D1, device=x.device), _f32(B, D2, device=x.device), _f32(B, C, device=x.device)
+        nat.call("mlp3_fwd_f32", x, x.stride(0), w1, b1, keep, float(keep_scale), w2, b2, w3, b3, B, D0, D1, D2, C, a1, a2, logp)
+        ctx.save_for_backward(x, w1, w2, w3, a1, a2, logp)
+        ctx.keep_scale = float(keep_scale) if keep is not None else 1.0
+        ctx.has_b = (b1 is not None, b2 is not None, b3 is not None)
+        return logp
+
+    @staticmethod
+    def backward(ctx, dlogp):
+        x, w1, w2, w3, a1, a2, logp = ctx.saved_tensors
+        dlogp = dlogp.contiguous()
+        dev = x.device
+        B, D0, D1, D2, C = x.size(0), w1.size(1), w1.size(0), w2.size(0), w3.size(0)
+        dw1, db1 = _f32(D1, D0, device=dev), _f32(D1, device=dev)
+        dw2, db2 = _f32(D2, D1, device=dev), _f32(D2, device=dev)
+        dw3, db3 = _f32(C, D2, device=dev), _f32(C, device=dev)
+        dx = _f32(B, D0, device=dev) if ctx.needs_input_grad[0] else None
+        nat.call("mlp3_bwd_f32", x, x.stride(0), w1, w2, w3, a1, a2, logp, dlogp, ctx.keep_scale, B, D0, D1, D2, C,
+                 dw1, db1, dw2, db2, dw3, db3, dx, D0)
+        hb = ctx.has_b
+        return dx, dw1, db1 if hb[0] else None, dw2, db2 if hb[1] else None, dw3, db3 if hb[2] else None, None, None
+
+
+def mlp3_ok(x, lin1, lin2, lin3):
+    return bool(x.is_cuda and x.dim() == 2 and lin1.weight.data_ptr() % 16 == 0 and lin2.weight.data_ptr() % 16 == 0
+                and nat.lib().tsgnn_mlp3_supported(int(x.size(0)), int(lin1.in_features), int(lin1.out_features),
+                                                   int(lin2.out_features), int(lin3.out_features)))
+
+
+def mlp3_log_softmax(x, lin1, lin2, lin3, p=0.0, training=False):
+    """the SAGPool head on three nn.Linear modules; the dropout mask comes from torch's generator (one bernoulli launch)"""
+    keep, scale = None, 1.0
+    if training and p > 0.0:
+        keep = torch.empty(x.size(0), lin1.out_features, dtype=torch.float32, device=x.device).bernoulli_(1.0 - p)
+        scale = 1.0 / (1.0 - p)
+    return _Mlp3LogSoftmax.apply(x, lin1.weight, lin1.bias, lin2.weight, lin2.bias, lin3.weight, lin3.bias, keep, scale)
+
+
 # ----------------------------------------------------------------------------- ReLU + per-slot batch norm
 class _BnSlots(torch.autograd.Function):
     """y = bn_over_slots(relu(v))  — encoders.py:179-181 with apply_bn :134-138 (trap T2)."""

@@ -79,6 +79,8 @@ class Net(nn.Module):
     def forward(self, data):
         if self._fused_ok():
             x = self._forward_fused(data)                                # network.py:33-46 in one node
+            if mp.mlp3_ok(x, self.lin1, self.lin2, self.lin3):
+                return mp.mlp3_log_softmax(x, self.lin1, self.lin2, self.lin3, self.dropout_ratio, self.training)   # :48-53
             x = pyg.relu(mp.linear_oi(x, self.lin1.weight, self.lin1.bias))
             x = F.dropout(x, p=self.dropout_ratio, training=self.training)
             x = pyg.relu(mp.linear_oi(x, self.lin2.weight, self.lin2.bias))
