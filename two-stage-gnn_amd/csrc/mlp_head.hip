@@ -103,12 +103,14 @@ struct Mlp3Bwd {
   int nW1, nW2;                          // block kinds: [0, nW1) dW1 tiles, [nW1, nW1+nW2) dW2 tiles, one dW3 block, then dX rows
 };
 
-constexpr int MB_TILE = 8;               // weight rows per tile block
+constexpr int MB_TILE = 2;               // weight rows per tile block
 constexpr int MB_ROWS = 4;               // batch rows per dX block
 
 // dz2[r, k] = [a2 > 0] * sum_c dlogits[r, c] W3[c, k],  dlogits = dlogp - softmax * sum_c dlogp   for rows [r0, r1)
-__device__ __forceinline__ void mlp3_dz2(const Mlp3Bwd& p, int r0, int r1, float* dlg /*[rows][C]*/, float* dz2 /*[rows][D2+1]*/) {
+__device__ __forceinline__ void mlp3_dz2(const Mlp3Bwd& p, int r0, int r1, float* dlg /*[rows][C]*/, float* w3s /*[C][D2]*/,
+                                         float* dz2 /*[rows][D2+1]*/) {
   const int tid = threadIdx.x, nr = r1 - r0;
+  for (int idx = tid; idx < p.C * p.D2; idx += 256) w3s[idx] = p.w3[idx];     // W3 once into LDS (it was re-read per element)
   for (int r = tid; r < nr; r += 256) {
     float s = 0.f;
     for (int c = 0; c < p.C; ++c) s += p.dlogp[(int64_t)(r0 + r) * p.C + c];
@@ -116,11 +118,26 @@ __device__ __forceinline__ void mlp3_dz2(const Mlp3Bwd& p, int r0, int r1, float
       dlg[r * p.C + c] = p.dlogp[(int64_t)(r0 + r) * p.C + c] - expf(p.logp[(int64_t)(r0 + r) * p.C + c]) * s;
   }
   __syncthreads();
-  for (int idx = tid; idx < nr * p.D2; idx += 256) {
-    const int r = idx / p.D2, k = idx - r * p.D2;
-    float v = 0.f;
-    for (int c = 0; c < p.C; ++c) v = fmaf(dlg[r * p.C + c], p.w3[(int64_t)c * p.D2 + k], v);
-    dz2[r * (p.D2 + 1) + k] = p.a2[(int64_t)(r0 + r) * p.D2 + k] > 0.f ? v : 0.f;
+  // the a2 loads of different elements are independent: issue them eight at a time (one load per trip was a chain of 32
+  // L2 round trips in every weight-tile block)
+  const int total = nr * p.D2;
+  for (int base = tid; base < total; base += 256 * 8) {
+    float av[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + 256 * u;
+      av[u] = idx < total ? p.a2[(int64_t)r0 * p.D2 + idx] : 0.f;          // a2 rows are dense: [r0 + r][k] = r0 * D2 + idx
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + 256 * u;
+      if (idx < total) {
+        const int r = idx / p.D2, k = idx - r * p.D2;
+        float v = 0.f;
+        for (int c = 0; c < p.C; ++c) v = fmaf(dlg[r * p.C + c], w3s[c * p.D2 + k], v);
+        dz2[r * (p.D2 + 1) + k] = av[u] > 0.f ? v : 0.f;
+      }
+    }
   }
   __syncthreads();
 }
@@ -132,18 +149,26 @@ __global__ __launch_bounds__(256) void mlp3_bwd_kernel(Mlp3Bwd p) {
   const int B = p.B, D0 = p.D0, D1 = p.D1, D2 = p.D2, C = p.C;
   if (bid < p.nW1 + p.nW2 + 1) {
     float* dlg = smem;                                   // [B][C]
-    float* dz2 = dlg + ((B * C + 3) & ~3);               // [B][D2+1]
-    float* t8 = dz2 + B * (D2 + 1);                      // [B][8]   (dW1 blocks: the dz1 tile)
-    mlp3_dz2(p, 0, B, dlg, dz2);
+    float* w3s = dlg + ((B * C + 3) & ~3);               // [C][D2]
+    float* dz2 = w3s + ((C * D2 + 3) & ~3);              // [B][D2+1]
+    float* t8 = dz2 + B * (D2 + 1);                      // [B][MB_TILE]   (dW1 blocks: the dz1 tile)
+    mlp3_dz2(p, 0, B, dlg, w3s, dz2);
     if (bid < p.nW1) {
       // ---- dW1[o, :] for o in the tile: dz1[b, o] = gate * sum_k dz2[b, k] W2[k, o]
       const int o0 = bid * MB_TILE;
+      float* w2t = t8 + B * MB_TILE;                     // [D2][MB_TILE]: this tile's columns of W2 (one cooperative fetch; the
+      for (int idx = tid; idx < D2 * MB_TILE; idx += 256) {   // dependent per-k global loads of a first version cost 30 us)
+        const int k = idx / MB_TILE, u = idx - k * MB_TILE;
+        w2t[idx] = o0 + u < D1 ? p.w2[(int64_t)k * D1 + o0 + u] : 0.f;
+      }
+      __syncthreads();
       for (int idx = tid; idx < B * MB_TILE; idx += 256) {
         const int b = idx / MB_TILE, u = idx - b * MB_TILE;
         const int o = o0 + u;
         float v = 0.f;
         if (o < D1) {
-          for (int k = 0; k < D2; ++k) v = fmaf(dz2[b * (D2 + 1) + k], p.w2[(int64_t)k * D1 + o], v);
+#pragma unroll 8
+          for (int k = 0; k < D2; ++k) v = fmaf(dz2[b * (D2 + 1) + k], w2t[k * MB_TILE + u], v);
           v = p.a1[(int64_t)b * D1 + o] > 0.f ? v * p.keep_scale : 0.f;
         }
         t8[b * MB_TILE + u] = v;
@@ -153,7 +178,8 @@ __global__ __launch_bounds__(256) void mlp3_bwd_kernel(Mlp3Bwd p) {
         float acc[MB_TILE];
 #pragma unroll
         for (int u = 0; u < MB_TILE; ++u) acc[u] = 0.f;
-        for (int b = 0; b < B; ++b) {
+#pragma unroll 32
+        for (int b = 0; b < B; ++b) {                      // independent coalesced loads, 32 in flight
           const float xv = p.x[(int64_t)b * p.ldx + i];
 #pragma unroll
           for (int u = 0; u < MB_TILE; ++u) acc[u] = fmaf(t8[b * MB_TILE + u], xv, acc[u]);
@@ -174,6 +200,7 @@ __global__ __launch_bounds__(256) void mlp3_bwd_kernel(Mlp3Bwd p) {
         float acc[MB_TILE];
 #pragma unroll
         for (int u = 0; u < MB_TILE; ++u) acc[u] = 0.f;
+#pragma unroll 32
         for (int b = 0; b < B; ++b) {
           const float av = p.a1[(int64_t)b * D1 + o];
 #pragma unroll
@@ -193,6 +220,7 @@ __global__ __launch_bounds__(256) void mlp3_bwd_kernel(Mlp3Bwd p) {
       for (int idx = tid; idx < C * D2; idx += 256) {
         const int c = idx / D2, k = idx - c * D2;
         float s = 0.f;
+#pragma unroll 16
         for (int b = 0; b < B; ++b) s = fmaf(dlg[b * C + c], p.a2[(int64_t)b * D2 + k], s);
         p.dw3[idx] = s;
       }
@@ -208,18 +236,21 @@ __global__ __launch_bounds__(256) void mlp3_bwd_kernel(Mlp3Bwd p) {
   if (p.dx == nullptr) return;
   const int r0 = (bid - (p.nW1 + p.nW2 + 1)) * MB_ROWS, r1 = min(B, r0 + MB_ROWS), nr = r1 - r0;
   float* dlg = smem;                                     // [4][C]
-  float* dz2 = dlg + ((MB_ROWS * C + 3) & ~3);           // [4][D2+1]
+  float* w3s = dlg + ((MB_ROWS * C + 3) & ~3);           // [C][D2]
+  float* dz2 = w3s + ((C * D2 + 3) & ~3);                // [4][D2+1]
   float* dz1 = dz2 + MB_ROWS * (D2 + 1);                 // [4][D1]
-  mlp3_dz2(p, r0, r1, dlg, dz2);
+  mlp3_dz2(p, r0, r1, dlg, w3s, dz2);
   for (int idx = tid; idx < nr * D1; idx += 256) {
     const int r = idx / D1, o = idx - r * D1;
     float v = 0.f;
-    for (int k = 0; k < D2; ++k) v = fmaf(dz2[r * (D2 + 1) + k], p.w2[(int64_t)k * D1 + o], v);
+#pragma unroll 16
+    for (int k = 0; k < D2; ++k) v = fmaf(dz2[r * (D2 + 1) + k], p.w2[(int64_t)k * D1 + o], v);       // coalesced over o
     dz1[r * D1 + o] = p.a1[(int64_t)(r0 + r) * D1 + o] > 0.f ? v * p.keep_scale : 0.f;
   }
   __syncthreads();
   for (int i = tid; i < D0; i += 256) {
     float acc[MB_ROWS] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 16
     for (int o = 0; o < D1; ++o) {
       const float wv = p.w1[(int64_t)o * D0 + i];
 #pragma unroll
@@ -230,8 +261,9 @@ __global__ __launch_bounds__(256) void mlp3_bwd_kernel(Mlp3Bwd p) {
 }
 
 inline size_t bwd_lds_bytes(int B, int D1, int D2, int C) {
-  const size_t wblk = (size_t)((B * C + 3) & ~3) + (size_t)B * (D2 + 1) + (size_t)B * MB_TILE;
-  const size_t rblk = (size_t)((MB_ROWS * C + 3) & ~3) + (size_t)MB_ROWS * (D2 + 1) + (size_t)MB_ROWS * D1;
+  const size_t w3 = (size_t)((C * D2 + 3) & ~3);
+  const size_t wblk = w3 + (size_t)((B * C + 3) & ~3) + (size_t)B * (D2 + 1) + (size_t)B * MB_TILE + (size_t)D2 * MB_TILE;
+  const size_t rblk = w3 + (size_t)((MB_ROWS * C + 3) & ~3) + (size_t)MB_ROWS * (D2 + 1) + (size_t)MB_ROWS * D1;
   return sizeof(float) * (wblk > rblk ? wblk : rblk);
 }
 
