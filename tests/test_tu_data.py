@@ -104,3 +104,24 @@ def test_collate_equals_dense_path(tmp_path):
     torch.testing.assert_close(a.cpu(), a_ref, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(b.cpu(), b_ref, rtol=1e-4, atol=1e-4)
     assert y.tolist() == ds.graph_label[idx].tolist()
+
+
+def test_sag_plan_sizes_follow_pyg_topk():
+    """host-known structure of the sync-free SAGPool levels: k_b = ceil(ratio * n_b) in float32 as PyG's topk computes it,
+    graph pointers and row -> graph maps per level (device-independent: built here on the CPU)"""
+    import numpy as np
+    import torch
+    from oracle import pyg_ref as P
+    from two_stage_gnn_amd.sag_stack import SagPlan
+    sizes = [20, 1, 7, 136, 3, 64]
+    for ratio in (0.5, 0.8, 0.25):
+        plan = SagPlan.get(sizes, ratio, torch.device("cpu"), depth=3)
+        cur = np.asarray(sizes)
+        for lvl in plan.levels:
+            assert lvl.N == int(cur.sum()) and lvl.B == len(sizes) and lvl.max_seg == int(cur.max())
+            np.testing.assert_array_equal(lvl.gp.numpy(), np.concatenate([[0], np.cumsum(cur)]))
+            np.testing.assert_array_equal(lvl.row_graph.numpy(), np.repeat(np.arange(len(sizes)), cur))
+            batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.from_numpy(cur))
+            perm = P.topk(torch.arange(int(cur.sum()), dtype=torch.float32), ratio, batch)     # the oracle's per-graph k
+            cur = np.bincount(batch[perm].numpy(), minlength=len(sizes))
+    assert SagPlan.get(sizes, 0.5, torch.device("cpu"), depth=3) is SagPlan.get(list(sizes), 0.5, torch.device("cpu"), depth=3)

@@ -30,6 +30,7 @@ def _f32(*shape, device, zero=False):
 
 
 _graph_cache = {}
+_gat_graph_cache = {}
 
 
 def graph_of(edge_index, num_nodes, check_symmetry=False):
@@ -276,23 +277,18 @@ def gather_gate(x, score, perm, use_tanh=True):
 
 
 # ----------------------------------------------------------------------------- north_star-named operators (a15)
-class _MeanAggregate(torch.autograd.Function):
-    """mean_{j in N(i)} x_j with the 1/deg weights generated on the fly as per-entry CSR values."""
+def _inv_degree(g):
+    """1 / max(in-degree, 1) per row, cached on the graph"""
+    inv = getattr(g, "_inv_deg", None)
+    if inv is None:
+        inv = g._inv_deg = (1.0 / (g.rowptr[1:] - g.rowptr[:-1]).clamp(min=1).to(torch.float32)).unsqueeze(1)
+    return inv
 
-    @staticmethod
-    def forward(ctx, x, g):
-        deg = (g.rowptr[1:] - g.rowptr[:-1]).clamp(min=1).to(torch.float32)
-        w = torch.repeat_interleave(1.0 / deg, (g.rowptr[1:] - g.rowptr[:-1]).long())
-        if w.numel() == 0:
-            w = _f32(1, device=x.device)
-        ctx.g, ctx.w = g, w
-        return mp.spmm_raw(g.rowptr, g.col, w, x.contiguous(), g.total_rows)
 
-    @staticmethod
-    def backward(ctx, dy):
-        g = ctx.g
-        rp, col, wt = g.transposed(ctx.w)
-        return mp.spmm_raw(rp, col, wt, dy.contiguous(), g.total_rows), None
+def _mean_aggregate(x, g):
+    """mean_{j in N(i)} x_j = (A x)_i / deg_i: the unit-weight aggregation kernel (fixed-width index table while the batch is
+    cache-resident) followed by a row scale; its backward is A^T (dy / deg) through the same operator.  No host round trip."""
+    return mp.aggregate(x, g, val=None) * _inv_degree(g)
 
 
 class SAGEConv(nn.Module):
@@ -307,7 +303,7 @@ class SAGEConv(nn.Module):
 
     def forward(self, x, edge_index):
         g = edge_index if isinstance(edge_index, GraphBatch) else graph_of(edge_index, x.size(0))
-        agg = _MeanAggregate.apply(x, g)
+        agg = _mean_aggregate(x, g)
         out = linear(agg, self.lin_l.weight.t(), self.lin_l.bias) + linear(x, self.lin_r.weight.t())
         if self.normalize:
             out = mp.linear_l2norm(out, torch.eye(out.size(1), device=out.device), None, normalize=True)
@@ -346,12 +342,27 @@ class GATConv(nn.Module):
         nn.init.xavier_uniform_(self.att_l)
         nn.init.xavier_uniform_(self.att_r)
 
-    def forward(self, x, edge_index):
-        n = x.size(0)
-        keep = edge_index[0] != edge_index[1]                       # remove_self_loops + add_self_loops
+    @staticmethod
+    def _loop_graph(edge_index, n):
+        """remove_self_loops + add_self_loops, as a CSR cached per edge_index tensor (the boolean compaction and the COO
+        ingest each cost a host round trip: once per edge list, not per forward)"""
+        key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, int(n))
+        hit = _gat_graph_cache.get(key)
+        if hit is not None and hit[0]() is edge_index:
+            return hit[1]
+        keep = edge_index[0] != edge_index[1]
         loop = torch.arange(n, device=edge_index.device)
         ei = torch.cat([edge_index[:, keep], torch.stack([loop, loop])], dim=1)
         g = GraphBatch.from_edge_index(ei, n, ghosts=False)
+        g.transpose_map()
+        if len(_gat_graph_cache) > 16:
+            _gat_graph_cache.clear()
+        _gat_graph_cache[key] = (weakref.ref(edge_index), g)
+        return g
+
+    def forward(self, x, edge_index):
+        n = x.size(0)
+        g = self._loop_graph(edge_index, n)
         h = linear(x, self.lin_l.weight.t())
         # entry (i = target row, j = source col): score = att_r.h_i + att_l.h_j, softmax over the row
         pre = att.attention_aggregate(h, self.att_r.view(self.heads, -1), self.att_l.view(self.heads, -1), g, self.heads,
