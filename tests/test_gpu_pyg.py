@@ -206,6 +206,37 @@ def test_sag_level_kernels_vs_oracle():
     np.testing.assert_array_equal(o.cpu().numpy(), np.concatenate([[0], np.cumsum(c.numpy())]))
 
 
+@pytest.mark.parametrize("F", [64, 128])
+def test_gcn_propagate_row_batched_large(F):
+    """>= 262,144 rows take the row-batched gather (4 rows per lane group): same result as an index_add formulation,
+    plain, with relu on the gathered rows + bias, and in score (dot) mode; ragged tail of rows included"""
+    from two_stage_gnn_amd import _native as nat
+    n, deg = 262144 + 37, 3
+    g = torch.Generator(device="cuda").manual_seed(5)
+    cnt = torch.randint(0, 2 * deg + 1, (n,), generator=g, device="cuda", dtype=torch.int32)
+    cnt[-1] = 0; cnt[7] = 70                                           # an empty last row, a row longer than a lane group
+    rowptr = torch.zeros(n + 1, dtype=torch.int32, device="cuda"); rowptr[1:] = torch.cumsum(cnt, 0)
+    nnz = int(rowptr[-1])
+    col = torch.randint(0, n, (nnz,), generator=g, device="cuda", dtype=torch.int32)
+    dinv = torch.rand(n, generator=g, device="cuda") + 0.5
+    self_w = torch.rand(n, generator=g, device="cuda")
+    x = torch.randn(n, F, generator=g, device="cuda")
+    bias = torch.randn(F, generator=g, device="cuda"); w = torch.randn(F, generator=g, device="cuda"); b0 = torch.randn(1, generator=g, device="cuda")
+    rows = torch.repeat_interleave(torch.arange(n, device="cuda"), cnt.long())
+
+    def ref(relu):
+        xs = torch.relu(x) if relu else x
+        acc = torch.zeros(n, F, device="cuda").index_add_(0, rows, dinv[col.long()].unsqueeze(1) * xs[col.long()])
+        return dinv.unsqueeze(1) * acc + self_w.unsqueeze(1) * xs
+    y = torch.empty_like(x); t = torch.empty(n, device="cuda")
+    nat.call("gcn_propagate_f32", rowptr, col, dinv, self_w, x, F, 0, None, None, None, y, F, None, n, F)
+    torch.testing.assert_close(y, ref(False), rtol=1e-4, atol=1e-4)
+    nat.call("gcn_propagate_f32", rowptr, col, dinv, self_w, x, F, 1, bias, w, b0, y, F, t, n, F)
+    r = ref(True) + bias
+    torch.testing.assert_close(y, r, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(t, r @ w + b0, rtol=1e-4, atol=1e-3)
+
+
 def test_sag_step_replays_from_a_hipgraph():
     """the fused SAGPool step has no host round trip: fwd + bwd captured once, replayed on new features"""
     from two_stage_gnn_amd import sag_layers as S

@@ -110,6 +110,76 @@ __global__ __launch_bounds__(256) void gcn_propagate_vec4(PropArgs a, unsigned n
   }
 }
 
+// Row-batched variant for batches that no longer fit the caches (>= 262,144 rows): a lane group owns RB consecutive rows,
+// ONE rowptr fetch and ONE coalesced index (+ dinv) fetch cover all their neighbours and the feature rows are gathered eight
+// at a time — ~RB x fewer dependent hops per row (the one-row-per-group kernel is latency- rather than bandwidth-bound there:
+// 0.33 of the HBM spec at 2,048 DD graphs).  Per-row summation order is unchanged (bitwise equal to gcn_propagate_vec4).
+template <int G, int RB>
+__global__ __launch_bounds__(256) void gcn_propagate_vec4_rb(PropArgs a, unsigned nblk) {
+  constexpr int GROUPS = 256 / G;
+  const unsigned lb = xcd_remap(blockIdx.x, nblk);
+  const int lig = threadIdx.x & (G - 1);
+  const int64_t row0 = ((int64_t)lb * GROUPS + threadIdx.x / G) * RB;
+  if (row0 >= a.n_rows) return;
+  const int nvec = a.feat >> 2;
+  const bool live = lig < nvec;
+  const int64_t co = live ? 4 * lig : 0;
+  const int64_t rr = min(row0 + lig, a.n_rows);
+  const int rp = (lig <= RB) ? a.rowptr[rr] : 0;
+  int eb[RB + 1];
+#pragma unroll
+  for (int k = 0; k <= RB; ++k) eb[k] = __shfl(rp, k, G);
+  float4 acc[RB];
+#pragma unroll
+  for (int k = 0; k < RB; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int base = eb[0]; base < eb[RB]; base += G) {
+    const int me = base + lig;
+    const int cj = (me < eb[RB]) ? a.col[me] : 0;
+    const float dj = (me < eb[RB]) ? a.dinv[cj] : 0.f;
+    const int cnt = min(G, eb[RB] - base);
+    for (int k = 0; k < cnt; k += 8) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int j = __shfl(cj, (k + u) & (G - 1), G);
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k + u < cnt) v[u] = ld4(a.x + (int64_t)j * a.ldx + co);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (k + u < cnt) {
+          const int e = base + k + u;
+          const float w = __shfl(dj, (k + u) & (G - 1), G);
+          const float4 vv = a.relu_in ? relu4(v[u]) : v[u];
+#pragma unroll
+          for (int r = 0; r < RB; ++r)
+            if (e >= eb[r] && e < eb[r + 1]) fma4(acc[r], w, vv);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    const int64_t row = row0 + r;
+    if (row >= a.n_rows) break;                          // group-uniform
+    const float di = a.dinv[row], sw = a.self_w[row];
+    float4 xs = ld4(a.x + row * a.ldx + co);
+    if (a.relu_in) xs = relu4(xs);
+    float4 o = make_float4(fmaf(di, acc[r].x, sw * xs.x), fmaf(di, acc[r].y, sw * xs.y), fmaf(di, acc[r].z, sw * xs.z),
+                           fmaf(di, acc[r].w, sw * xs.w));
+    if (a.bias != nullptr) {
+      const float4 b = ld4(a.bias + co);
+      o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
+    }
+    if (a.y != nullptr && live) *reinterpret_cast<float4*>(a.y + row * a.ldy + co) = o;
+    if (a.w_dot != nullptr) {
+      float d = live ? dot4(o, ld4(a.w_dot + co)) : 0.f;
+      d = group_sum<G>(d);
+      if (lig == 0) a.t[row] = d + (a.dot_bias ? a.dot_bias[0] : 0.f);
+    }
+  }
+}
+
 // any feature width / leading dimension (F = 1 input of IMDB-B, the raw 89-wide DD labels): one wave per row
 __global__ __launch_bounds__(256) void gcn_propagate_generic(PropArgs a) {
   const int lane = threadIdx.x & 63;
@@ -428,6 +498,8 @@ void launch_prop(const PropArgs& a, hipStream_t s) {
   gcn_propagate_vec4<G><<<nblk, 256, 0, s>>>(a, nblk);
 }
 
+constexpr int64_t PROP_RB_MIN_ROWS = 262144;   // below this the batch is cache-resident: one row per lane group wins
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 inline int group_of(int F) { const int nv = F / 4; return nv <= 8 ? 8 : nv <= 16 ? 16 : nv <= 32 ? 32 : 64; }
 
@@ -454,7 +526,15 @@ int tsgnn_gcn_propagate_f32(const int* rowptr, const int* col, const float* dinv
   PropArgs a{rowptr, col, dinv, self_w, x, ldx, bias, w_dot, dot_bias, y, ldy, t, n_rows, feat, relu_in};
   const bool vec_ok = feat % 4 == 0 && feat <= 256 && ldx % 4 == 0 && aligned16(x) && (!y || (ldy % 4 == 0 && aligned16(y))) &&
                       (!bias || aligned16(bias)) && (!w_dot || aligned16(w_dot));
-  if (vec_ok) {
+  if (vec_ok && n_rows >= PROP_RB_MIN_ROWS && (group_of(feat) == 16 || group_of(feat) == 32)) {
+    if (group_of(feat) == 16) {
+      const unsigned nblk = (unsigned)ceil_div64(n_rows, (256 / 16) * 4);
+      gcn_propagate_vec4_rb<16, 4><<<nblk, 256, 0, stream>>>(a, nblk);
+    } else {
+      const unsigned nblk = (unsigned)ceil_div64(n_rows, (256 / 32) * 4);
+      gcn_propagate_vec4_rb<32, 4><<<nblk, 256, 0, stream>>>(a, nblk);
+    }
+  } else if (vec_ok) {
     switch (group_of(feat)) {
       case 8: launch_prop<8>(a, stream); break;
       case 16: launch_prop<16>(a, stream); break;
