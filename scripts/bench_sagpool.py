@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""BASELINE config 4: IMDB-B-shaped SAGPool (ratio 0.5) + GCNConv h=128, batch 128 per GPU, data-parallel with one RCCL
+gradient all-reduce per step.  Same launch contract and JSON line as bench.py (which stays on the headline metric):
+
+  python scripts/bench_sagpool.py --steps 200
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P scripts/bench_sagpool.py --gpus N
+
+A step = forward (three sync-free conv -> SAGPool -> readout levels + the fused head), nll loss, backward, gradient bucket
+(+ all-reduce at N > 1), clip 2.0 + Adam, replayed from hipGraphs; inputs resident in HBM."""
+import argparse, json, os, sys, time
+import numpy as np
+import torch
+import torch.distributed as dist
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1); ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20); ap.add_argument("--batch", type=int, default=128)
+    a = ap.parse_args()
+    sys.stdout.flush(); real_stdout = os.dup(1); os.dup2(2, 1)          # RCCL prints its banner on fd 1
+    rank, local_rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index); dev = torch.device("cuda", dev_index)
+    multi = world > 1
+    if multi:
+        backend = os.environ.get("TSGNN_DIST_BACKEND", "nccl")
+        dist.init_process_group("nccl", device_id=dev) if backend == "nccl" else dist.init_process_group(backend)
+    from two_stage_gnn_amd import sag_layers as S, synthetic
+    from two_stage_gnn_amd.data_parallel import FlatTrainer, GraphedStep
+    torch.manual_seed(1234)                                             # identical initial weights on every rank
+    net = S.Net(1, 128, 2, 0.5, 0.5, use_batch=True).to(dev).train()
+    hb = synthetic.host_batch(seed=rank, B=a.batch, shape="IMDB-BINARY", nmax=136)       # per-rank batch (weak scaling)
+    sizes = hb["sizes"]; n = int(sizes.sum())
+    rp = hb["rowptr"][: n + 1]
+    dst = np.repeat(np.arange(n), np.diff(rp))
+    class D: pass
+    d = D(); d.x = torch.ones(n, 1, device=dev)                          # IMDB-B has no node features (constant input)
+    d.edge_index = torch.from_numpy(np.stack([hb["col"].astype(np.int64), dst.astype(np.int64)])).to(dev)
+    d.batch = torch.repeat_interleave(torch.arange(a.batch), torch.from_numpy(sizes)).to(dev)
+    label = torch.from_numpy(hb["label"]).to(dev)
+    tr = FlatTrainer(net, lr=5e-4, clip=2.0)
+    gs = GraphedStep(tr, lambda: torch.nn.functional.nll_loss(net(d), label), warmup=3)
+    for _ in range(a.warmup):
+        gs.step()
+    torch.cuda.synchronize()
+    if multi:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        gs.step()
+    torch.cuda.synchronize()
+    if multi:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    if multi:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    el = float(el.item())
+    if rank == 0:
+        out = {"metric": "graphs/sec fwd+bwd, IMDB-B SAGPool(0.5) + GCNConv h=128, batch=128 per GPU", "value": world * a.batch * a.steps / el,
+               "unit": "graphs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "IMDB-B-shaped synthetic graphs (avg 20 nodes / 97 edges, constant input), batch=%d per GPU, "
+                                      "Net: 3 x [GCNConv -> SAGPool(0.5) -> gmp||gap] + 3 Linear, nll loss, clip 2.0 + Adam" % a.batch,
+                          "global_batch": world * a.batch, "parallelism": "dp%d" % world, "launch": "hipGraph replay",
+                          "rows": n, "edges_directed": int(len(hb["col"])), "loss": float(gs.loss.detach())}}
+        os.dup2(real_stdout, 1); print(json.dumps(out), flush=True); os.dup2(2, 1)
+    if multi:
+        dist.barrier(); dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
