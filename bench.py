@@ -271,7 +271,7 @@ def main():
                 gbs = f_bytes / (f_ms * 1e-3) / 1e9
                 mf, hf = tf / MFMA_F32_PEAK_TF, gbs / HBM_PEAK_GBS
                 roofline = {"bound": "mfma" if mf >= hf else "hbm",
-                            "kernel": "rowgemm_kernel<4,false,true> (tsgnn_gather_rowgemm_f32: aggregation + .W + bias + L2 normalise, K=N=%d)" % a.hidden,
+                            "kernel": "rowgemm_gather_ks2_kernel<4,false> (tsgnn_gather_rowgemm_f32: aggregation + .W + bias + L2 normalise, K=N=%d)" % a.hidden,
                             "achieved": tf if mf >= hf else gbs, "peak": MFMA_F32_PEAK_TF if mf >= hf else HBM_PEAK_GBS,
                             "unit": "TFLOP/s" if mf >= hf else "GB/s", "frac": max(mf, hf),
                             "traffic": tr.get("dd_b32_gather_rowgemm_k128_n128", {}).get("traffic_bytes_per_launch"),

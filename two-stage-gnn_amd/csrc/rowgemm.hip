@@ -17,9 +17,15 @@
 #include "common.h"
 #include "../../include/tsgnn.h"
 
+#include <cstdlib>
 #include "rowgemm_body.h"
 
 namespace {
+
+inline bool rowgemm_ks2_enabled() {                      // TSGNN_ROWGEMM_KS2=0 selects the one-group kernel (A/B measurements)
+  static const bool on = [] { const char* e = getenv("TSGNN_ROWGEMM_KS2"); return !(e && e[0] == '0'); }();
+  return on;
+}
 
 template <int NT, bool TRANS_B, bool GATHER>
 __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs g) {
@@ -27,10 +33,31 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs g) {
   rowgemm_body<NT, TRANS_B, GATHER>(g, smem, blockIdx.x);
 }
 
+// split-K variant: two groups of four waves per row panel (rowgemm_body.h, KS = 2)
+template <int NT, bool TRANS_B>
+__global__ __launch_bounds__(512) void rowgemm_gather_ks2_kernel(RowGemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  rowgemm_body<NT, TRANS_B, true, 2>(g, smem, blockIdx.x);
+}
+
 template <int NT, bool TRANS_B, bool GATHER>
 void launch_rowgemm(const RowGemmArgs& g, hipStream_t s) {
+  const unsigned nblk = (unsigned)(ceil_div64(g.rows, 32) + (g.fill_rows > 0 ? 1 : 0));
+  if constexpr (GATHER && NT <= 4) {
+    if (g.K > KC && rowgemm_ks2_enabled()) {
+      constexpr size_t lds2 = rowgemm_lds_bytes<NT, TRANS_B, true, 2>();
+      static bool attr = false;
+      if (!attr && lds2 > 64 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rowgemm_gather_ks2_kernel<NT, TRANS_B>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        attr = true;
+      }
+      rowgemm_gather_ks2_kernel<NT, TRANS_B><<<nblk, 512, lds2, s>>>(g);
+      return;
+    }
+  }
   const size_t lds = rowgemm_lds_bytes<NT, TRANS_B, GATHER>();
-  rowgemm_kernel<NT, TRANS_B, GATHER><<<(unsigned)(ceil_div64(g.rows, 32) + (g.fill_rows > 0 ? 1 : 0)), 256, lds, s>>>(g);
+  rowgemm_kernel<NT, TRANS_B, GATHER><<<nblk, 256, lds, s>>>(g);
 }
 
 template <bool TRANS_B, bool GATHER>

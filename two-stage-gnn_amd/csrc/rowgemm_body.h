@@ -32,18 +32,38 @@ struct RowGemmArgs {
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
 constexpr int GN = 8;                 // neighbour rows per output row that are gathered in one go (the rest, rare, follow)
-constexpr int LDA_F = 128 + 4;        // row stride of the gathered full-K A panel (K <= 128; +4: conflict-free 16-byte reads)
+constexpr int LDA_F = 128;            // row stride of the gathered full-K A panel (K <= 128).  No padding: float4 column c of row r
+                                      // lives at column c ^ (r & 7), which spreads eight rows over the 32 banks (conflict-free
+                                      // 16-byte fragment reads) and keeps the split-K kernel at 80 KiB = two blocks per CU
 
-template <int NT, bool TRANS_B, bool GATHER>
-__device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem, unsigned bid) {
+// KS = 2 (GATHER, NT <= 4, K > KC): 512 threads, the K range is split between two groups of four waves.  A block of the
+// KS = 1 kernel keeps ONE wave per SIMD busy with a chain of dependent phases (index trip -> row gather -> K loop ->
+// epilogue), so a CU idles through every memory wait; with two wave groups the gather prologue is shared by twice the
+// lanes (half the rows per lane), each group runs half of the K chunks on its own LDS stages while the other group's
+// waits are covered, and group 1 hands its accumulators to group 0 through LDS before the (unchanged) epilogue.
+template <int NT, bool TRANS_B, bool GATHER, int KS = 1>
+__device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem_all, unsigned bid) {
+  static_assert(KS == 1 || (KS == 2 && GATHER && NT <= 4), "the split-K variant is built for the gather kernel, widths <= 128");
   constexpr int NP = 32 * NT;
   constexpr int TPW = (NT + 3) / 4;
   constexpr int BV = NT;                               // float4 of B per thread per chunk (KC * NP / 1024)
-  constexpr int A_FLOATS = 32 * LDA_S;
+  constexpr int A_FLOATS = GATHER ? 0 : 32 * LDA_S;   // GATHER: the A operand is the gathered panel, no A stage
   constexpr int B_FLOATS = TRANS_B ? NP * LDA_S : KC * NP;
   constexpr int STAGE = A_FLOATS + B_FLOATS;           // one of the two LDS stages
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid_all = threadIdx.x;
+  const int grp = KS == 2 ? (tid_all >> 8) : 0;          // wave group (uniform per wave)
+  const int tid = KS == 2 ? (tid_all & 255) : tid_all, lane = tid & 63, wid = tid >> 6;
   const int i = lane & 31, h = lane >> 5;
+  // K split: both groups run the same number of chunk iterations (Kc, the barriers match); Kv = what is valid of it
+  const int Kc = KS == 1 ? g.K : ((g.K + 2 * KC - 1) / (2 * KC)) * KC;
+  const int kb = grp * Kc;
+  const int Kv = KS == 1 ? g.K : min(g.K - kb, Kc);
+  constexpr int GRP = (KS == 2 && 2 * STAGE < 4096 + 256) ? 4096 + 256 : 2 * STAGE;   // LDS floats per wave group
+  float* smem = smem_all + grp * GRP;                    // this group's two stages
+  // common to the block: the gathered panel, and 256 floats of epilogue scratch (KS = 2: inside group 1's idle stages,
+  // after the accumulator exchange buffer)
+  float* Apanel = smem_all + KS * GRP + (KS == 2 ? 0 : 256);
+  float* scratch = KS == 2 ? smem_all + GRP + 4096 : smem_all + 2 * STAGE;
   // XCD-aware panel order: blocks b, b+8, ... share an XCD (and its L2); give each XCD one contiguous run of panels so
   // that the neighbour rows gathered by adjacent panels (same graph) are fetched into one L2 only.  The filler block
   // (last) keeps its index.
@@ -52,7 +72,8 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem, 
   TR(0);
   if (m0 >= g.rows) {
     // filler block (launched after the panels when fill_rows > 0): every fill row = [normalised] bias
-    __shared__ float fred[4];
+    if (KS == 2 && grp == 1) return;
+    float* fred = smem_all;
     const int N4 = g.N / 4, rpp = 256 / N4;              // rows per pass
     const int c4 = tid % N4, rsub = tid / N4;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -79,7 +100,7 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem, 
   // are written to LDS, so nothing waits on a load before the MFMAs of the current chunk.
   const int am = tid >> 3, ak4 = tid & 7;
   const bool a_row_ok = (m0 + am) < g.rows;
-  const float* ap = g.a + ((a_row_ok && !GATHER) ? (m0 + am) : 0) * g.lda + 4 * ak4;
+  const float* ap = g.a + ((a_row_ok && !GATHER) ? (m0 + am) : 0) * g.lda + 4 * ak4 + (GATHER ? 0 : kb);
   const float* bp[BV];
   int b_k[BV];                                         // k (or first k of the float4) inside the chunk
   int b_lds[BV];
@@ -90,13 +111,13 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem, 
     if (!TRANS_B) {
       const int k = idx / (NP / 4), n4 = idx % (NP / 4);
       b_nok[q] = 4 * n4 < g.N;                         // N % 4 == 0 on this path
-      bp[q] = g.b + (int64_t)k * g.ldb + (b_nok[q] ? 4 * n4 : 0);
+      bp[q] = g.b + (int64_t)(k + kb) * g.ldb + (b_nok[q] ? 4 * n4 : 0);
       b_k[q] = k;
       b_lds[q] = k * NP + 4 * n4;
     } else {
       const int n = idx / (KC / 4), k4 = idx % (KC / 4);
       b_nok[q] = n < g.N;                              // K % 4 == 0 on this path
-      bp[q] = g.b + (int64_t)(b_nok[q] ? n : 0) * g.ldb + 4 * k4;
+      bp[q] = g.b + (int64_t)(b_nok[q] ? n : 0) * g.ldb + 4 * k4 + kb;
       b_k[q] = 4 * k4;
       b_lds[q] = n * LDA_S + 4 * k4;
     }
@@ -110,13 +131,13 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem, 
   };
   const bool panel_full = (m0 + 32) <= g.rows && g.N == NP;   // uniform: every row and column of the panel exists
   auto fetch = [&](Staged& s, int k0) {                // G(c): global -> registers
-    s.plain = panel_full && (k0 + KC) <= g.K;
+    s.plain = panel_full && (k0 + KC) <= Kv;
     s.a_valid = 0;
     s.b_valid = 0;
     if (GATHER) {                                      // the A panel is already in LDS: only B travels
 #pragma unroll
       for (int q = 0; q < BV; ++q) {
-        const bool kok = (k0 + b_k[q]) < g.K;
+        const bool kok = (k0 + b_k[q]) < Kv;
         if (!TRANS_B) s.rb[q] = ldg4(kok ? bp[q] + (int64_t)k0 * g.ldb : bp[q] - (int64_t)b_k[q] * g.ldb);
         else s.rb[q] = ldg4(kok ? bp[q] + k0 : bp[q] - b_k[q]);
         s.b_valid |= (kok && b_nok[q]) ? (1u << q) : 0u;
@@ -131,12 +152,12 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem, 
       return;
     }
     const int gk = k0 + 4 * ak4;
-    const bool ok = a_row_ok && gk < g.K;
-    s.a_valid = ok ? min(4, g.K - gk) : 0;
-    s.ra = ldg4(gk < g.K ? ap + k0 : ap - 4 * ak4);
+    const bool ok = a_row_ok && gk < Kv;
+    s.a_valid = ok ? min(4, Kv - gk) : 0;
+    s.ra = ldg4(gk < Kv ? ap + k0 : ap - 4 * ak4);
 #pragma unroll
     for (int q = 0; q < BV; ++q) {
-      const bool kok = (k0 + b_k[q]) < g.K;
+      const bool kok = (k0 + b_k[q]) < Kv;
       if (!TRANS_B) s.rb[q] = ldg4(kok ? bp[q] + (int64_t)k0 * g.ldb : bp[q] - (int64_t)b_k[q] * g.ldb);
       else s.rb[q] = ldg4(kok ? bp[q] + k0 : bp[q] - b_k[q]);
       s.b_valid |= (kok && b_nok[q]) ? (1u << q) : 0u;
@@ -165,14 +186,15 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem, 
     for (int q = 0; q < BV; ++q)
       *reinterpret_cast<float4*>(st + A_FLOATS + b_lds[q]) = ((s.b_valid >> q) & 1u) ? s.rb[q] : make_float4(0.f, 0.f, 0.f, 0.f);
   };
-  float* Apanel = smem + 2 * STAGE + 256;              // GATHER: the whole aggregated panel [32][LDA_F], built in the prologue
   auto frags = [&](const float* st, int k0, float (&af)[KC / 2], float (&bf)[TPW][KC / 2]) {   // R(c): LDS -> MFMA operands
-    const float* As = GATHER ? Apanel + k0 : st;
+    const float* As = GATHER ? Apanel : st;
     constexpr int lda_s = GATHER ? LDA_F : LDA_S;
+    const int kq = GATHER ? (kb + k0) >> 2 : 0;          // first float4 column of the chunk in the panel (multiple of 8)
     const float* Bs = st + A_FLOATS;
 #pragma unroll
     for (int u = 0; u < KC / 8; ++u) {
-      const float4 v = *reinterpret_cast<const float4*>(As + i * lda_s + 8 * u + 4 * h);
+      const float4 v = GATHER ? *reinterpret_cast<const float4*>(As + i * lda_s + 4 * ((kq + 2 * u + h) ^ (i & 7)))
+                              : *reinterpret_cast<const float4*>(As + i * lda_s + 8 * u + 4 * h);
       af[4 * u] = v.x; af[4 * u + 1] = v.y; af[4 * u + 2] = v.z; af[4 * u + 3] = v.w;
     }
 #pragma unroll
@@ -209,12 +231,13 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem, 
   // NS register staging sets: with 4 (widths <= 128) the first four chunks are all in flight before any MFMA.
   constexpr int NS = (NT <= 4 && !GATHER) ? 4 : 2;    // (the gather prologue needs the registers for the neighbour rows)
   Staged st[NS];
-  int ids[4][GN];                                      // GATHER: neighbour ids first (head of the dependent chain), the W
+  constexpr int NPASS = 4 / KS;                        // gather passes of 8 * KS rows
+  int ids[NPASS][GN];                                  // GATHER: neighbour ids first (head of the dependent chain), the W
   if (GATHER) {                                        // fetches below fill their latency
-    const int rsub = tid >> 5;
+    const int rsub = tid_all >> 5;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int64_t row = m0 + 8 * p + rsub;
+    for (int p = 0; p < NPASS; ++p) {
+      const int64_t row = m0 + 8 * KS * p + rsub;
 #pragma unroll
       for (int q = 0; q < GN / 4; ++q) {
         int4 v = make_int4(-1, -1, -1, -1);
@@ -225,25 +248,25 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem, 
   }
 #pragma unroll
   for (int c = 0; c < NS; ++c)
-    if (c == 0 || c * KC < g.K) fetch(st[c], c * KC);
+    if (c == 0 || c * KC < Kc) fetch(st[c], c * KC);
   if (GATHER) {
     // A panel = aggregated rows.  Row-major like the stand-alone aggregation kernel: 32 lanes per row (one float4 column
     // each), 8 rows per pass, 4 passes; the first GN neighbour rows of all four passes are in flight together
     // (one index round trip + one row round trip for the whole panel), longer lists (rare) are finished afterwards.
-    const int c4 = tid & 31, rsub = tid >> 5;
+    const int c4 = tid_all & 31, rsub = tid_all >> 5;
     const bool colok = 4 * c4 < g.K;                   // a float4 that straddles K is taken whole: B's rows >= K are zero in
                                                        // LDS and the row padding of x is finite (zero) by the layout rule
-    float4 nbv[4][GN];
+    float4 nbv[NPASS][GN];
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
+    for (int p = 0; p < NPASS; ++p)
 #pragma unroll
       for (int k = 0; k < GN; ++k) {
         nbv[p][k] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (colok && ids[p][k] >= 0) nbv[p][k] = ldg4(g.a + (int64_t)ids[p][k] * g.lda + 4 * c4);
       }
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int64_t row = m0 + 8 * p + rsub;
+    for (int p = 0; p < NPASS; ++p) {
+      const int64_t row = m0 + 8 * KS * p + rsub;
       float4 va = nbv[p][0];
 #pragma unroll
       for (int k = 1; k < GN; ++k) { va.x += nbv[p][k].x; va.y += nbv[p][k].y; va.z += nbv[p][k].z; va.w += nbv[p][k].w; }
@@ -261,7 +284,10 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem, 
           va.x += t.x; va.y += t.y; va.z += t.z; va.w += t.w;
         }
       }
-      if (4 * c4 < LDA_F - 4) *reinterpret_cast<float4*>(Apanel + (8 * p + rsub) * LDA_F + 4 * c4) = va;   // zeros beyond K / rows
+      {                                                  // zeros beyond K / rows; swizzled column (see LDA_F)
+        const int pr = 8 * KS * p + rsub;
+        *reinterpret_cast<float4*>(Apanel + pr * LDA_F + 4 * (c4 ^ (pr & 7))) = va;
+      }
       if (g.zout && colok && row < g.rows) *reinterpret_cast<float4*>(g.zout + row * g.ldz + 4 * c4) = va;
     }
   }
@@ -273,27 +299,27 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem, 
   }
   TR(1);
   commit(st[0], smem);
-  if (KC < g.K) commit(st[1], smem + STAGE);
+  if (KC < Kc) commit(st[1], smem + STAGE);
   __syncthreads();
   TR(2);
   float fa[2][KC / 2], fb[2][TPW][KC / 2];
   frags(smem, 0, fa[0], fb[0]);
   if (NS == 2) {
-    if (2 * KC < g.K) fetch(st[0], 2 * KC);
-    if (3 * KC < g.K) fetch(st[1], 3 * KC);
+    if (2 * KC < Kc) fetch(st[0], 2 * KC);
+    if (3 * KC < Kc) fetch(st[1], 3 * KC);
   }
   auto body = [&](auto ci_, int c) {
     constexpr int CI = decltype(ci_)::value;           // c mod 4, compile time: register sets are picked statically
     constexpr int P = CI & 1;
     const int k0 = c * KC;
-    if (k0 + KC < g.K) frags(smem + (P ^ 1) * STAGE, k0 + KC, fa[P ^ 1], fb[P ^ 1]);
-    if (NS == 4 && c >= 0 && k0 + 4 * KC < g.K) fetch(st[CI % NS], k0 + 4 * KC);
+    if (k0 + KC < Kc) frags(smem + (P ^ 1) * STAGE, k0 + KC, fa[P ^ 1], fb[P ^ 1]);
+    if (NS == 4 && c >= 0 && k0 + 4 * KC < Kc) fetch(st[CI % NS], k0 + 4 * KC);
     __builtin_amdgcn_sched_barrier(0);                 // the scheduler would sink the LDS reads to their uses
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[P][j], fb[P][0][j], acc[0], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    if (k0 + 2 * KC < g.K) commit(st[(CI + 2) % NS], smem + P * STAGE);
-    if (NS == 2 && k0 + 4 * KC < g.K) fetch(st[CI % NS], k0 + 4 * KC);
+    if (k0 + 2 * KC < Kc) commit(st[(CI + 2) % NS], smem + P * STAGE);
+    if (NS == 2 && k0 + 4 * KC < Kc) fetch(st[CI % NS], k0 + 4 * KC);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 8; j < KC / 2; ++j) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[P][j], fb[P][0][j], acc[0], 0, 0, 0);
@@ -308,11 +334,23 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem, 
     __syncthreads();
     TR(4 + 2 * min(c, 3));
   };
-  for (int c = 0; c * KC < g.K; c += 4) {
+  for (int c = 0; c * KC < Kc; c += 4) {
     body(std::integral_constant<int, 0>{}, c);
-    if ((c + 1) * KC < g.K) body(std::integral_constant<int, 1>{}, c + 1);
-    if ((c + 2) * KC < g.K) body(std::integral_constant<int, 2>{}, c + 2);
-    if ((c + 3) * KC < g.K) body(std::integral_constant<int, 3>{}, c + 3);
+    if ((c + 1) * KC < Kc) body(std::integral_constant<int, 1>{}, c + 1);
+    if ((c + 2) * KC < Kc) body(std::integral_constant<int, 2>{}, c + 2);
+    if ((c + 3) * KC < Kc) body(std::integral_constant<int, 3>{}, c + 3);
+  }
+  if (KS == 2) {
+    // group 1 hands its partial sums over through its own (now idle) stages and retires; group 0 finishes the panel
+    float* xch = smem_all + GRP;                       // 4 waves x 16 registers x 64 lanes = 16 KiB, inside group 1's region
+    if (grp == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xch[(wid * 16 + r) * 64 + lane] = acc[0][r];
+    }
+    __syncthreads();
+    if (grp == 1) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][r] += xch[(wid * 16 + r) * 64 + lane];
   }
 
   // epilogue in registers: lane (i, h) of tile `wid + 4t` holds C[(r&3) + 8(r>>2) + 4h][tile*32 + i] in acc[t][r].
@@ -340,7 +378,7 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem, 
       // row sums of squares: transposing DPP reduction inside each 16-lane row (lane l ends with row r = l & 15 of its
       // half), the two rows of a half through one bpermute, the four waves (column tiles) through LDS; then each wave
       // turns the 32 totals into 1/max(|u|, eps) with one v_rsq per lane and hands them out through LDS.
-      float* red = smem + 2 * STAGE;                   // [32 rows][4 waves]
+      float* red = scratch;                            // [32 rows][4 waves]
       float* inv = red + 128 + wid * 32;               // per wave [32 rows]
       float tot = row16_sum_transpose(ss);
       tot += __shfl_xor(tot, 16, 64);
@@ -389,10 +427,12 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem, 
 }
 
 
-template <int NT, bool TRANS_B, bool GATHER>
+template <int NT, bool TRANS_B, bool GATHER, int KS = 1>
 constexpr size_t rowgemm_lds_bytes() {
   constexpr int NP = 32 * NT;
-  return sizeof(float) * (2 * (32 * LDA_S + (TRANS_B ? NP * LDA_S : KC * NP)) + 128 + 4 * 32 + (GATHER ? 32 * LDA_F : 0));
+  constexpr int STAGE2 = 2 * ((GATHER ? 0 : 32 * LDA_S) + (TRANS_B ? NP * LDA_S : KC * NP));
+  constexpr int GRP = (KS == 2 && STAGE2 < 4096 + 256) ? 4096 + 256 : STAGE2;
+  return sizeof(float) * (KS * GRP + (KS == 2 ? 0 : 128 + 4 * 32) + (GATHER ? 32 * LDA_F : 0));
 }
 
 }  // namespace
