@@ -16,7 +16,7 @@ for tag, fd, wd in (("dd_b32_rows9151_f128", "pmc_f", "pmc_w"), ("dd_b2048_f128"
                 "hbm_read_bytes": 2 * fetch * 1024, "hbm_write_bytes": write * 1024,
                 "traffic_bytes_per_launch": 2 * fetch * 1024 + write * 1024}
 if glob.glob("gpurun_out/pmc_gf/*/*_counter_collection.csv"):
-    fetch, write = med("pmc_gf", "FETCH_SIZE", "rowgemm_kernel"), med("pmc_gw", "WRITE_SIZE", "rowgemm_kernel")
+    fetch, write = med("pmc_gf", "FETCH_SIZE", "rowgemm_"), med("pmc_gw", "WRITE_SIZE", "rowgemm_")      # the gather kernel (rowgemm_gather_ks2_kernel)
     out["dd_b32_gather_rowgemm_k128_n128"] = {"FETCH_SIZE_KiB_raw": fetch, "WRITE_SIZE_KiB_raw": write,
                                               "hbm_read_bytes": 2 * fetch * 1024, "hbm_write_bytes": write * 1024,
                                               "traffic_bytes_per_launch": 2 * fetch * 1024 + write * 1024}
