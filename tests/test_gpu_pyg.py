@@ -140,6 +140,57 @@ def test_sagpool_net_vs_oracle(use_batch, sym, fused):
         assert err <= 2e-3 * r.abs().max().item() + 1e-6, (k, err)
 
 
+@pytest.mark.parametrize("case", ["ratio1", "singletons", "isolated", "odd_width"])
+def test_sagpool_net_edge_cases(case):
+    """edge cases of the sync-free SAGPool levels against the oracle: ratio 1.0 (nothing dropped, the filter is the identity
+    up to the top-k order), one-node graphs (k = 1 at every level), nodes without any edge, and a hidden width the float4
+    kernels do not take (the model then composes the drop-ins level by level)"""
+    from two_stage_gnn_amd import sag_layers as S
+    ratio, nhid = 0.5, 32
+    sizes = [20, 12, 31, 20, 9, 25]
+    if case == "ratio1":
+        ratio = 1.0
+    elif case == "singletons":
+        sizes = [1, 7, 1, 1, 16, 2]
+    elif case == "odd_width":
+        nhid = 30
+    n = sum(sizes)
+    batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
+    ei = rand_graph(51, n, 500, True, sizes)
+    if case == "singletons":                         # rand_graph gives one-node graphs a self pair that it then removes
+        keep = (ei[0] != ei[1])
+        ei = ei[:, keep]
+    if case == "isolated":
+        drop = torch.tensor([0, 5, 33, n - 1])
+        keep = ~(torch.isin(ei[0], drop) | torch.isin(ei[1], drop))
+        ei = ei[:, keep]
+    x = tie_free(52, n, 6)
+    torch.manual_seed(8)
+    net = S.Net(6, nhid, 3, ratio, 0.5, use_batch=True).cuda().eval()
+    assert net._fused_ok() == (case != "odd_width")
+    with torch.no_grad():
+        for k, p in net.named_parameters():
+            if k.endswith("bias"):
+                p.copy_(torch.randn_like(p) * 0.1)
+    p_ref = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+
+    class D:
+        pass
+    d = D(); d.x, d.edge_index, d.batch = x.cuda(), ei.cuda(), batch.cuda()
+    out = net(d)
+    ref = P.sag_net(p_ref, x, ei, ratio, batch)
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-4)
+    gy = tie_free(53, *ref.shape)
+    (ref * gy).sum().backward()
+    (out * gy.cuda()).sum().backward()
+    for k, p in net.named_parameters():
+        r = p_ref[k].grad
+        if r is None:
+            continue
+        err = (p.grad.cpu() - r).abs().max().item()
+        assert err <= 2e-3 * r.abs().max().item() + 1e-6, (case, k, err)
+
+
 def _csr_rows(rowptr, col, n):
     rp = rowptr.cpu().numpy()
     c = col.cpu().numpy()
