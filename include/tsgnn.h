@@ -356,6 +356,15 @@ int tsgnn_sag_supported(int F);
 int tsgnn_sag_pool_gather_f32(const float* y, int64_t ldy, const float* score, const int* perm, const int* new_id,
                               const int* rowptr, const int* col, int64_t K, int F, int relu_in, float* xp, int64_t ldo, int* cnt,
                               tsgnn_stream_t stream);
+/* One launch per level for everything between the conv output y (pre-activation) and the pooled rows, for graphs of at most
+ * tsgnn_sag_pool_graph_max_nodes() nodes (one workgroup per graph, intermediate results in LDS): the score layer
+ * score = A^ (relu(y) w_s) + b_s (layers.py:18), top-k with the relabelling map (perm, new_id as tsgnn_topk_segments_f32),
+ * xp / cnt as tsgnn_sag_pool_gather_f32(relu_in = 1), out / arg as tsgnn_sag_readout_f32. */
+int tsgnn_sag_pool_graph_max_nodes(void);
+int tsgnn_sag_pool_graph_f32(const float* y, int64_t ldy, const int* rowptr, const int* col, const float* dinv, const float* self_w,
+                             const float* w_s, const float* b_s, const int* graph_ptr, const int* graph_ptr_new, int B, int max_seg,
+                             int F, float* score, int* perm, int* new_id, float* xp, int64_t ldo, int* cnt, float* out, int64_t ldout,
+                             int* arg, int accumulate, tsgnn_stream_t stream);
 /* out[b, :F] (+)= max over the rows of graph b, out[b, F:2F] (+)= their mean (gmp || gap, network.py:36,40,44);
  * arg[b, f] = row holding the max (ties -> smallest row) */
 int tsgnn_sag_readout_f32(const float* xp, int64_t ld, const int* graph_ptr, int B, int F, int accumulate, float* out, int64_t ldo,

@@ -140,7 +140,7 @@ def test_sagpool_net_vs_oracle(use_batch, sym, fused):
         assert err <= 2e-3 * r.abs().max().item() + 1e-6, (k, err)
 
 
-@pytest.mark.parametrize("case", ["ratio1", "singletons", "isolated", "odd_width"])
+@pytest.mark.parametrize("case", ["ratio1", "singletons", "isolated", "odd_width", "large_graph"])
 def test_sagpool_net_edge_cases(case):
     """edge cases of the sync-free SAGPool levels against the oracle: ratio 1.0 (nothing dropped, the filter is the identity
     up to the top-k order), one-node graphs (k = 1 at every level), nodes without any edge, and a hidden width the float4
@@ -154,9 +154,11 @@ def test_sagpool_net_edge_cases(case):
         sizes = [1, 7, 1, 1, 16, 2]
     elif case == "odd_width":
         nhid = 30
+    elif case == "large_graph":                      # > 1,024 nodes: the per-graph kernel's bitonic branch (rank count below)
+        sizes = [1500, 40, 9]
     n = sum(sizes)
     batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
-    ei = rand_graph(51, n, 500, True, sizes)
+    ei = rand_graph(51, n, 500 if case != "large_graph" else 6000, True, sizes)
     if case == "singletons":                         # rand_graph gives one-node graphs a self pair that it then removes
         keep = (ei[0] != ei[1])
         ei = ei[:, keep]

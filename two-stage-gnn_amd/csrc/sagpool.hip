@@ -281,6 +281,174 @@ __global__ __launch_bounds__(256) void sag_readout_kernel(const float* __restric
   arg[(int64_t)b * F + f] = am;
 }
 
+// ---------------------------------------------------------------- one workgroup per graph: score -> top-k -> gather -> readout
+// Everything between the conv output y and the pooled level touches ONE graph's rows only (the score layer's neighbours,
+// the top-k segment, the kept rows, the readout), so for graphs of up to 4,096 nodes a single 1,024-thread workgroup does
+//   t_j = relu(y_j) . w_s                      (lane group per row, DPP reduction)                         -> LDS
+//   s_i = dinv_i sum_j dinv_j t_j + self_w_i t_i + b_s   (the GCNConv(C -> 1) score layer, layers.py:18)   -> score, sort keys
+//   bitonic sort of (score, ~index) keys in LDS (descending, ties -> smaller node id)                       -> perm, new_id
+//   xp[p] = relu(y[perm[p]]) * tanh(s)  (layers.py:21),  max || mean readout of the kept rows (network.py:36)
+//   cnt[p] = kept neighbours of perm[p]  (input of the CSR filter's scan)
+// in one launch instead of four (score propagate, top-k, gather, readout), with the relabelling map and the scores staying
+// in LDS between the phases.
+constexpr int PG_THREADS = 1024;
+constexpr int PG_MAX_NODES = 4096;
+constexpr int PG_RGROUPS = 8;            // lane groups that run the gather / readout phase
+constexpr int PG_RANK_MAX = 1024;        // up to this many (padded) nodes the top-k order comes from a rank count instead of a bitonic sort
+
+struct PoolGraphArgs {
+  const float* y; int64_t ldy;
+  const int* rowptr; const int* col; const float* dinv; const float* self_w;
+  const float* w_s; const float* b_s;
+  const int* gp; const int* gp_new;
+  float* score; int* perm; int* new_id;
+  float* xp; int64_t ldo; int* cnt;
+  float* out; int64_t ldout; int* arg; int accumulate;
+  int F;
+};
+
+template <int G>
+__global__ __launch_bounds__(PG_THREADS) void sag_pool_graph_kernel(PoolGraphArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long pg_smem[];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int g0 = a.gp[b], n = a.gp[b + 1] - g0;
+  const int k0 = a.gp_new[b], k = a.gp_new[b + 1] - k0;
+  if (n <= 0) return;
+  int np = 1;
+  while (np < n) np <<= 1;
+  unsigned long long* keys = pg_smem;                                   // [np]
+  float* t = reinterpret_cast<float*>(keys + np);                       // [np]
+  int* nid = reinterpret_cast<int*>(t + np);                            // [np]
+  float* rmax = reinterpret_cast<float*>(nid + np);                     // [PG_RGROUPS][F]
+  float* rsum = rmax + PG_RGROUPS * a.F;                                // [PG_RGROUPS][F]
+  int* rarg = reinterpret_cast<int*>(rsum + PG_RGROUPS * a.F);          // [PG_RGROUPS][F]
+  constexpr int NG = PG_THREADS / G;
+  const int lig = tid & (G - 1), grp = tid / G;
+  const int nvec = a.F >> 2;
+  const bool live = lig < nvec;
+  const int co = live ? 4 * lig : 0;
+  const float4 wv = live ? ld4(a.w_s + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+  // (1) t_j = relu(y_j) . w_s
+  for (int j = grp; j < n; j += NG) {
+    float d = live ? dot4(relu4(ld4(a.y + (int64_t)(g0 + j) * a.ldy + co)), wv) : 0.f;
+    d = group_sum<G>(d);
+    if (lig == 0) t[j] = d;
+  }
+  __syncthreads();
+  // (2) scores and sort keys
+  const float bs = a.b_s ? a.b_s[0] : 0.f;
+  for (int j = tid; j < np; j += PG_THREADS) {
+    unsigned long long key = 0ull;                                      // padding sorts last
+    if (j < n) {
+      const int r = g0 + j;
+      float acc = 0.f;
+      for (int e = a.rowptr[r]; e < a.rowptr[r + 1]; ++e) {
+        const int c = a.col[e];
+        if ((unsigned)(c - g0) < (unsigned)n) acc = fmaf(a.dinv[c], t[c - g0], acc);   // graphs of a batch are disjoint (PyG collate)
+      }
+      const float sc = fmaf(a.dinv[r], acc, a.self_w[r] * t[j]) + bs;
+      a.score[r] = sc;
+      key = ((unsigned long long)f32_ordered(sc) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)j);
+    }
+    keys[j] = key;
+  }
+  __syncthreads();
+  // (3) sort, descending.  Small graphs (the common case: <= 1,024 nodes) by rank: thread i counts the keys above key i
+  // (LDS broadcast reads, no barrier per step — a bitonic network on 256 keys is 36 barriers of a 16-wave block) and drops
+  // its key at that position of a second array; keys are unique (they carry the node index).
+  if (np <= PG_RANK_MAX) {
+    unsigned long long* sorted = reinterpret_cast<unsigned long long*>(rarg + PG_RGROUPS * a.F);     // [np]
+    for (int i = tid; i < np; i += PG_THREADS) {
+      const unsigned long long mine = keys[i];
+      int rank = 0;
+      if (i < n) {
+#pragma unroll 8
+        for (int j = 0; j < n; ++j) rank += keys[j] > mine ? 1 : 0;
+        sorted[rank] = mine;
+      } else {
+        sorted[i] = 0ull;                                                // padding keeps its place behind the n real keys
+      }
+    }
+    __syncthreads();
+    keys = sorted;
+  } else {
+    for (int size = 2; size <= np; size <<= 1) {
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        for (int q = tid; q < (np >> 1); q += PG_THREADS) {
+          const int lo = 2 * q - (q & (stride - 1));
+          const int hi = lo + stride;
+          const bool desc = ((lo & size) == 0);
+          const unsigned long long x = keys[lo], z = keys[hi];
+          if ((x < z) == desc) { keys[lo] = z; keys[hi] = x; }
+        }
+        __syncthreads();
+      }
+    }
+  }
+  // (4) perm and the relabelling map
+  for (int i = tid; i < n; i += PG_THREADS) {
+    const int j = (int)(0xFFFFFFFFu - (unsigned)(keys[i] & 0xFFFFFFFFull));
+    const int id = i < k ? k0 + i : -1;
+    if (i < k) a.perm[k0 + i] = g0 + j;
+    nid[j] = id;
+    a.new_id[g0 + j] = id;
+  }
+  __syncthreads();
+  // (5) gated gather of the kept rows + their max || mean readout  (PG_RGROUPS lane groups; ties of the max -> smallest row)
+  if (grp < PG_RGROUPS) {
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY), s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int4 am = make_int4(k0, k0, k0, k0);
+    for (int p = grp; p < k; p += PG_RGROUPS) {
+      const unsigned long long key = keys[p];
+      const int j = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+      const float gate = tanhf(ordered_f32((unsigned)(key >> 32)));
+      if (live) {
+        float4 v = relu4(ld4(a.y + (int64_t)(g0 + j) * a.ldy + co));
+        v = make_float4(v.x * gate, v.y * gate, v.z * gate, v.w * gate);
+        *reinterpret_cast<float4*>(a.xp + (int64_t)(k0 + p) * a.ldo + co) = v;
+        if (v.x > m.x) { m.x = v.x; am.x = k0 + p; }
+        if (v.y > m.y) { m.y = v.y; am.y = k0 + p; }
+        if (v.z > m.z) { m.z = v.z; am.z = k0 + p; }
+        if (v.w > m.w) { m.w = v.w; am.w = k0 + p; }
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+    }
+    if (live) {
+      *reinterpret_cast<float4*>(rmax + grp * a.F + co) = m;
+      *reinterpret_cast<float4*>(rsum + grp * a.F + co) = s;
+      *reinterpret_cast<int4*>(rarg + grp * a.F + co) = am;
+    }
+  }
+  // (6) kept neighbours of every kept row (the CSR filter's counts)
+  for (int p = tid; p < k; p += PG_THREADS) {
+    const int j = (int)(0xFFFFFFFFu - (unsigned)(keys[p] & 0xFFFFFFFFull));
+    const int r = g0 + j;
+    int c = 0;
+    for (int e = a.rowptr[r]; e < a.rowptr[r + 1]; ++e) {
+      const int cj = a.col[e] - g0;
+      c += ((unsigned)cj < (unsigned)n && nid[cj] >= 0) ? 1 : 0;
+    }
+    a.cnt[k0 + p] = c;
+  }
+  __syncthreads();
+  for (int f = tid; f < a.F; f += PG_THREADS) {
+    float m = rmax[f], s = rsum[f];
+    int am = rarg[f];
+#pragma unroll
+    for (int q = 1; q < PG_RGROUPS; ++q) {
+      const float v = rmax[q * a.F + f];
+      const int z = rarg[q * a.F + f];
+      if (v > m || (v == m && z < am)) { m = v; am = z; }
+      s += rsum[q * a.F + f];
+    }
+    const float mean = s / (float)max(k, 1);
+    float* o = a.out + (int64_t)b * a.ldout;
+    if (a.accumulate) { o[f] += m; o[a.F + f] += mean; }
+    else { o[f] = m; o[a.F + f] = mean; }
+    a.arg[(int64_t)b * a.F + f] = am;
+  }
+}
+
 // ---------------------------------------------------------------- filter_adj on CSR (layers.py:23-24)
 // new row p = old row perm[p]; its entries = the kept neighbours, relabelled, original order.  One wave per new row,
 // ballot + popcount ranks.  Also emits the next level's gcn_norm coefficients (the new degree is known here).
@@ -567,6 +735,41 @@ int tsgnn_sag_pool_gather_f32(const float* y, int64_t ldy, const float* score, c
   if (K == 0) return TSGNN_OK;
   SAG_DISPATCH(F, (sag_pool_gather<G><<<(unsigned)ceil_div64(K, 256 / G), 256, 0, stream>>>(y, ldy, score, perm, new_id, rowptr, col, K,
                                                                                             F, relu_in, xp, ldo, cnt)));
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+int tsgnn_sag_pool_graph_max_nodes(void) { return PG_MAX_NODES; }
+
+int tsgnn_sag_pool_graph_f32(const float* y, int64_t ldy, const int* rowptr, const int* col, const float* dinv, const float* self_w,
+                             const float* w_s, const float* b_s, const int* graph_ptr, const int* graph_ptr_new, int B, int max_seg,
+                             int F, float* score, int* perm, int* new_id, float* xp, int64_t ldo, int* cnt, float* out, int64_t ldout,
+                             int* arg, int accumulate, tsgnn_stream_t stream) {
+  if (!y || !rowptr || !dinv || !self_w || !w_s || !graph_ptr || !graph_ptr_new || !score || !perm || !new_id || !xp || !cnt || !out ||
+      !arg || B <= 0 || max_seg < 0 || ldy < F || ldo < F || ldout < 2 * F)
+    return TSGNN_EINVAL;
+  if (!tsgnn_sag_supported(F) || max_seg > PG_MAX_NODES || ldy % 4 || ldo % 4 || !aligned16(y) || !aligned16(xp) || !aligned16(w_s))
+    return TSGNN_EUNSUPPORTED;
+  if (max_seg == 0) return TSGNN_OK;
+  int np = 1;
+  while (np < max_seg) np <<= 1;
+  const size_t lds = (size_t)np * (8 + 4 + 4) + (size_t)PG_RGROUPS * F * 12 + (np <= PG_RANK_MAX ? (size_t)np * 8 : 0);
+  PoolGraphArgs a{y, ldy, rowptr, col, dinv, self_w, w_s, b_s, graph_ptr, graph_ptr_new, score, perm, new_id, xp, ldo, cnt,
+                  out, ldout, arg, accumulate, F};
+#define PG_LAUNCH(GG)                                                                                                          \
+  do {                                                                                                                         \
+    if (lds > 64 * 1024)                                                                                                       \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sag_pool_graph_kernel<GG>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)lds);                                                                                     \
+    sag_pool_graph_kernel<GG><<<(unsigned)B, PG_THREADS, lds, stream>>>(a);                                                    \
+  } while (0)
+  switch (group_of(F)) {
+    case 8: PG_LAUNCH(8); break;
+    case 16: PG_LAUNCH(16); break;
+    case 32: PG_LAUNCH(32); break;
+    default: PG_LAUNCH(64); break;
+  }
+#undef PG_LAUNCH
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }

@@ -116,6 +116,9 @@ def _linear_t(du, w):
     return dz
 
 
+PER_GRAPH_POOL = True        # level tail (score -> top-k -> gather -> readout) as one workgroup per graph when graphs are small
+
+
 def _al16(t):
     """the float4 kernels read the small parameter vectors with 16-byte loads: a view at an odd offset is copied"""
     return t if t.data_ptr() % 16 == 0 else t.clone()
@@ -145,6 +148,7 @@ class _SagStack(torch.autograd.Function):
         rowptr_t, col_t = (rowptr, col) if sym else g.transposed(None)[:2]
         nnz_bound = max(int(col.numel()), 1)
         read = _f32(B, 2 * H, device=dev)
+        pool_graph_max = int(nat.lib().tsgnn_sag_pool_graph_max_nodes())
         saved = []
         xin = x
         for l in range(depth):
@@ -155,13 +159,19 @@ class _SagStack(torch.autograd.Function):
             wsv = _al16(ws.contiguous().view(-1))
             agg, _ = propagate(rowptr, col, dinv, self_w, xin, N)
             y = _linear(agg, W, b)
-            _, score = propagate(rowptr, col, dinv, self_w, y, N, relu_in=True, w_dot=wsv, dot_bias=bs, want_y=False)
             perm, new_id = _i32(max(K, 1), device=dev), _i32(max(N, 1), device=dev)
-            nat.call("topk_segments_f32", score, L.gp, Ln.gp, B, L.max_seg, perm, new_id)
             xp, cnt = _f32(K, H, device=dev), _i32(max(K, 1), device=dev)
-            nat.call("sag_pool_gather_f32", y, y.stride(0), score, perm, new_id, rowptr, col, K, H, 1, xp, xp.stride(0), cnt)
             arg = _i32(B, H, device=dev)
-            nat.call("sag_readout_f32", xp, xp.stride(0), Ln.gp, B, H, int(l > 0), read, read.stride(0), arg)
+            if L.max_seg <= pool_graph_max and PER_GRAPH_POOL:
+                # score layer, top-k, gated gather, readout and the filter's counts: one workgroup per graph, one launch
+                score = _f32(N, device=dev)
+                nat.call("sag_pool_graph_f32", y, y.stride(0), rowptr, col, dinv, self_w, wsv, bs, L.gp, Ln.gp, B, L.max_seg, H,
+                         score, perm, new_id, xp, xp.stride(0), cnt, read, read.stride(0), arg, int(l > 0))
+            else:
+                _, score = propagate(rowptr, col, dinv, self_w, y, N, relu_in=True, w_dot=wsv, dot_bias=bs, want_y=False)
+                nat.call("topk_segments_f32", score, L.gp, Ln.gp, B, L.max_seg, perm, new_id)
+                nat.call("sag_pool_gather_f32", y, y.stride(0), score, perm, new_id, rowptr, col, K, H, 1, xp, xp.stride(0), cnt)
+                nat.call("sag_readout_f32", xp, xp.stride(0), Ln.gp, B, H, int(l > 0), read, read.stride(0), arg)
             saved.append((xin, agg, y, score, new_id, arg, rowptr, col, rowptr_t, col_t, dinv, self_w, W, wsv))
             if l + 1 < depth:                                   # the adjacency after the last pool is never used
                 rp_n, col_n = _i32(K + 1, device=dev), _i32(nnz_bound, device=dev)
