@@ -26,4 +26,8 @@ for _ in range(int(os.environ.get("N", 30))):
         if Z is None:
             Z = sys.modules[__name__]._Z = torch.empty_like(X)
         nat.call("gather_rowgemm_f32", ell, ell_w, None, None, X, H, W, H, 0, b, Y, H, rinv, Z, H, g.n_rows, H, H, 1, g.n_ghost)
+    elif which == "prop":                   # GCN-normalised aggregation of the SAGPool path (tsgnn_gcn_propagate_f32)
+        from two_stage_gnn_amd import sag_stack as SS
+        dinv, self_w = SS.gcn_coef(g)
+        nat.call("gcn_propagate_f32", g.rowptr, g.col, dinv, self_w, X, H, 0, None, None, None, Y, H, None, g.n_rows, H)
 torch.cuda.synchronize()
