@@ -43,6 +43,7 @@ def _batch_from_dense(adj, sizes, layout):
 
 
 FUSED_HEAD = True              # the two chained nn.Linear after the readout as one HIP launch (+1 backward)
+FUSED_DENSE_POST = True       # pooled DiffPool levels: transform + normalise + ReLU + slot BN as one node
 FUSED_STACK = True             # GcnEncoderGraph: run the conv stack as one fused autograd node when it qualifies
 DENSE_ADJ_MAX_NODES = 128      # at or below this many nodes per graph a dense batched MFMA product is used
 
@@ -358,10 +359,19 @@ class SoftPoolingGcnEncoder(GcnEncoderGraph):
 
         def post(v):
             return mp.bn_slots(v.reshape(B * K, -1), g, relu=True, bn=self.bn, per_graph=self.per_graph_bn).reshape(B, K, -1)
-        x = post(conv_first(x, adj))
+
+        def hidden(conv, x):
+            # transform + normalise + ReLU + slot BN as one node (one launch for the BN forward, one for the backward of
+            # BN + ReLU + normalise) when the fused slot kernels take the shape; else the composed ops
+            if (FUSED_DENSE_POST and self.bn and not self.per_graph_bn and conv.normalize_embedding and conv.dropout <= 0.001
+                    and mp.linear_norm_bn_ok(g, conv.output_dim)):
+                y = _DenseBmm.apply(adj.float(), x.float(), conv.add_self)
+                return mp.linear_norm_bn(y.reshape(B * K, -1), conv.weight, conv.bias, g).reshape(B, K, -1)
+            return post(conv(x, adj))
+        x = hidden(conv_first, x)
         x_all = [x]
         for conv in conv_block:
-            x = post(conv(x, adj))
+            x = hidden(conv, x)
             x_all.append(x)
         x_all.append(conv_last(x, adj))
         return torch.cat(x_all, dim=2), g

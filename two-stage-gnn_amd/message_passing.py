@@ -361,6 +361,65 @@ class _BnSlots(torch.autograd.Function):
         return dv, None, None, None
 
 
+class _LinearNormBn(torch.autograd.Function):
+    """y = slot_bn(relu(normalize(z W + b))) — a hidden GraphConv's transform and the ReLU + apply_bn that follow it
+    (encoders.py:36-40,179-181) as one node on the fused slot kernels: BN statistics and normalisation in one launch forward,
+    BN + ReLU + L2-normalise backward in one launch (instead of stats / apply, stats / apply and the normalise backward)."""
+
+    @staticmethod
+    def forward(ctx, z, weight, bias, g):
+        z = _check(z)
+        w = weight.contiguous()
+        K, N = w.size(0), w.size(1)
+        R = z.size(0)
+        dev = z.device
+        v, rinv = _f32(R, N, device=dev), _f32(R, device=dev)
+        if rowgemm_ok(z, z.stride(0), w, w.stride(0), K, N, False):
+            nat.call("rowgemm_f32", z, z.stride(0), w, w.stride(0), 0, bias, v, v.stride(0), rinv, R, K, N, 1, 0)
+        else:
+            nat.call("linear_l2norm_f32", z, z.stride(0), w, w.stride(0), bias, v, v.stride(0), rinv, R, K, N, 1)
+        mean, rstd = _f32(g.nmax, device=dev), _f32(g.nmax, device=dev)
+        y = torch.empty_like(v)
+        nat.call("slot_bn_fwd_f32", g.graph_ptr, g.slot_count, g.B, g.nmax, g.n_rows, g.n_ghost, v, v.stride(0), N, 1, mean, rstd,
+                 y, y.stride(0), None, 0)
+        ctx.save_for_backward(z, w, v, rinv, mean, rstd)
+        ctx.g, ctx.has_bias = g, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        z, w, v, rinv, mean, rstd = ctx.saved_tensors
+        g = ctx.g
+        dy = _check(dy)
+        R, N, K = dy.size(0), w.size(1), w.size(0)
+        du = torch.empty_like(v)
+        nat.call("slot_post_bwd_f32", g.graph_ptr, g.slot_count, g.B, g.nmax, g.n_rows, g.n_ghost, v, v.stride(0), dy, dy.stride(0),
+                 None, 0, None, 0, None, N, 1, 1, mean, rstd, rinv, du, du.stride(0))
+        dz = dw = db = None
+        if ctx.needs_input_grad[0]:
+            ldz = z.size(1)
+            dz = _f32(R, ldz, device=dy.device, zero=(ldz > K))
+            if rowgemm_ok(du, du.stride(0), w, w.stride(0), N, K, True):
+                nat.call("rowgemm_f32", du, du.stride(0), w, w.stride(0), 1, None, dz, dz.stride(0), None, R, N, K, 0, 0)
+            else:
+                gemm(du, du.stride(0), 1, w, 1, w.stride(0), dz, dz.stride(0), 1, R, K, N)
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1]:
+            dw, db = linear_wgrad(z, K, du, want_db)
+        elif want_db:
+            db = colsum(du)
+        return dz, dw, db, None
+
+
+def linear_norm_bn_ok(g, n_out):
+    """the fused slot kernels take this batch (no ghost rows needed: they handle both layouts)"""
+    return bool(nat.lib().tsgnn_slot_fused_supported(int(g.B), int(n_out)))
+
+
+def linear_norm_bn(z, weight, bias, g):
+    return _LinearNormBn.apply(z, weight, bias, g)
+
+
 class _RowLn(torch.autograd.Function):
     """ReLU + apply_bn with per-graph (B = 1) statistics = per-row layer norm (tripletnet.py:36-38 semantics, batched)."""
 
