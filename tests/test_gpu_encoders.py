@@ -103,6 +103,37 @@ def test_gcn_encoder_vs_oracle_dd_shape(B, nmax, nbar, fin, hid):
         assert rel_l2 < 1e-3, (k, rel_l2)
 
 
+@pytest.mark.parametrize("shape,B,nmax,layers,hid", [("MUTAG", 32, 40, 2, 64), ("PROTEINS", 64, 620, 3, 128)])
+def test_baseline_config_batches_vs_oracle(shape, B, nmax, layers, hid):
+    """BASELINE.json configs 1 and 2 on the bench's own synthetic generator (CSR-native ingest, the path bench.py and
+    scripts/config_bench.py run): MUTAG 2-layer h=64 batch 32, PROTEINS 3-layer h=128 batch 64 — outputs and gradients vs the
+    oracle's dense formulation on the same graphs"""
+    from two_stage_gnn_amd import dense_encoders as E, synthetic
+    hb = synthetic.host_batch(11, B, shape, nmax)
+    g, xrows, label = synthetic.to_device(hb, torch.device("cuda"))
+    x, adj = synthetic.to_dense(hb)
+    fin = hb["fin"]
+
+    class A:
+        bias = True
+    torch.manual_seed(0)
+    m = E.GcnEncoderGraph(fin, hid, hid, 2, layers, bn=True, args=A(), final_dim="number_classes").cuda()
+    p_ref = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    a_ref, b_ref = R.gcn_encoder(p_ref, x, adj, bn=True, final_dim="number_classes")
+    lab = torch.from_numpy(hb["label"])
+    torch.nn.functional.cross_entropy(b_ref, lab).backward()
+    a, b = m(xrows, g)
+    torch.testing.assert_close(a.detach().cpu(), a_ref.detach(), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(b.detach().cpu(), b_ref.detach(), rtol=1e-4, atol=1e-4)
+    m.loss(b, label).backward()
+    for k, p in m.named_parameters():
+        ref = p_ref[k].grad
+        if ref is None:
+            continue
+        err = (p.grad.cpu() - ref).abs().max().item()
+        assert err <= 2e-3 * ref.abs().max().item() + 1e-7, (k, err, ref.abs().max().item())
+
+
 # ----------------------------------------------------------------------------- GAT (encoders_GAT.py)
 @pytest.mark.parametrize("tag", ["b1_concat", "b1_raw", "b2_concat"])
 def test_gat_head_golden(tag):
