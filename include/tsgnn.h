@@ -244,6 +244,9 @@ int tsgnn_clip_adam_step_f32(float* param, const float* grad, float* m, float* v
  * [N,N,2F] pair tensor (encoders_GAT.py:35-36). */
 int tsgnn_node_scores_f32(const float* x, int64_t ldx, int64_t rows, int H, int Fh, const float* a, int64_t lda, float* s,
                           tsgnn_stream_t stream);
+/* both score vectors of a head in one pass over the rows: s1 = x . a1, s2 = x . a2 (encoders_GAT.py:34-36) */
+int tsgnn_node_scores2_f32(const float* x, int64_t ldx, int64_t rows, int H, int Fh, const float* a1, int64_t lda1, float* s1,
+                           const float* a2, int64_t lda2, float* s2, tsgnn_stream_t stream);
 /* alpha[e,h] = softmax over the entries e of CSR row g of LeakyReLU(s_grp[g,h] + s_oth[col[e],h]).
  * Reference DGATHead (encoders_GAT.py:36-41, softmax over dim=1 = per column, trap T3): call on A^T with
  * s_grp = a2.h, s_oth = a1.h.  PyG GATConv: call on A (rows = targets).  mod > 0: node index = id % mod. */
@@ -276,6 +279,11 @@ int tsgnn_csr_sddmm_heads_f32(const int* rowptr, const int* col, int H, int Fh, 
  * Also PyG global_mean_pool (Code/sag/network.py:36). */
 int tsgnn_segment_wsum_f32(const float* x, int64_t ldx, const float* w, int H, int Fh, const int* seg_ptr, int nseg, int64_t rows,
                            int64_t max_seg, float scale, int mean, float* ws, float* out, int64_t ldo, tsgnn_stream_t stream);
+/* two weighted sums of the same rows in one pass (the gradients of both attention vectors): out1 = sum w1 x, out2 = sum w2 x;
+ * ws: twice the floats tsgnn_segment_wsum_f32 needs */
+int tsgnn_segment_wsum2_f32(const float* x, int64_t ldx, const float* w1, const float* w2, int H, int Fh, const int* seg_ptr, int nseg,
+                            int64_t rows, int64_t max_seg, float scale, float* ws, float* out1, float* out2, int64_t ldo,
+                            tsgnn_stream_t stream);
 /* y[r,c] += scale * w[r,c/Fh] * (a ? a[(c/Fh)*lda + c%Fh] : u[(r / rows_per_seg)*ldu + c])   (w NULL = 1) */
 int tsgnn_broadcast_add_f32(float* y, int64_t ldy, int64_t rows, int H, int Fh, const float* w, const float* a, int64_t lda,
                             const float* u, int64_t ldu, int rows_per_seg, float scale, tsgnn_stream_t stream);

@@ -21,6 +21,22 @@ def node_scores(h, a, H, Fh):
     return s
 
 
+def node_scores2(h, a1, a2, H, Fh):
+    """(h . a1, h . a2) per node and head from one pass over the rows"""
+    s1, s2 = _f32(h.size(0), H, device=h.device), _f32(h.size(0), H, device=h.device)
+    nat.call("node_scores2_f32", h, h.stride(0), h.size(0), H, Fh, a1, a1.stride(0), s1, a2, a2.stride(0), s2)
+    return s1, s2
+
+
+def segment_wsum2(x, w1, w2, H, Fh):
+    """(sum_r w1[r,h] x[r,:], sum_r w2[r,h] x[r,:]) over all rows, x read once"""
+    out1, out2 = _f32(1, H * Fh, device=x.device), _f32(1, H * Fh, device=x.device)
+    nchunk = max(1, (int(x.size(0)) + 127) // 128)
+    ws = _f32(2 * nchunk * H * Fh, device=x.device)
+    nat.call("segment_wsum2_f32", x, x.stride(0), w1, w2, H, Fh, None, 1, x.size(0), int(x.size(0)), 1.0, ws, out1, out2, out1.stride(0))
+    return out1, out2
+
+
 def segment_wsum(x, w, H, Fh, seg_ptr, nseg, scale=1.0, mean=False, max_seg=None):
     """max_seg: longest segment (host int); defaults to all rows (always a valid bound)."""
     out = _f32(nseg, H * Fh, device=x.device)
@@ -62,8 +78,7 @@ class _AttentionAggregate(torch.autograd.Function):
         R, C = h.shape
         Fh = C // H
         dev = h.device
-        s_row = node_scores(h, a_row, H, Fh)
-        s_col = node_scores(h, a_col, H, Fh)
+        s_row, s_col = node_scores2(h, a_row, a_col, H, Fh)
         nnz = max(g.nnz, 1)
         rp_t, col_t, src_e_t = g.transpose_map() if by_column else (None, None, None)
         if by_column:
@@ -131,8 +146,8 @@ class _AttentionAggregate(torch.autograd.Function):
         nat.call("csr_spmm_heads_epi_f32", rp_t, col_t, alpha_t, H, Fh, dout, dout.stride(0), 0, dh, dh.stride(0), R,
                  ds_row, a_row, a_row.stride(0), ds_col, a_col, a_col.stride(0), du, du.stride(0) if du is not None else 0,
                  iso, N, _row_seg(g), 1.0 / N)
-        da_row = segment_wsum(h, ds_row, H, Fh, None, 1).view(H, Fh)
-        da_col = segment_wsum(h, ds_col, H, Fh, None, 1).view(H, Fh)
+        da_row, da_col = segment_wsum2(h, ds_row, ds_col, H, Fh)
+        da_row, da_col = da_row.view(H, Fh), da_col.view(H, Fh)
         return dh, da_row, da_col, None, None, None, None, None
 
 

@@ -18,16 +18,26 @@ namespace {
 __device__ __forceinline__ float lrelu(float t, float slope) { return t > 0.f ? t : slope * t; }
 
 // per-node scalars s[r,h] = sum_f x[r, h*Fh + f] * a[h*lda + f]    (a1.h_i / a2.h_j for every head)
+// (a2 / s2 nullable: both score vectors of a GAT head, a1.h_i and a2.h_j, from ONE pass over the rows)
 __global__ __launch_bounds__(256) void node_scores_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows, int H, int Fh,
-                                                          const float* __restrict__ a, int64_t lda, float* __restrict__ s) {
+                                                          const float* __restrict__ a, int64_t lda, float* __restrict__ s,
+                                                          const float* __restrict__ a2, int64_t lda2, float* __restrict__ s2) {
   const int lane = threadIdx.x & 63;
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
   for (int h = 0; h < H; ++h) {
-    float acc = 0.f;
-    for (int f = lane; f < Fh; f += 64) acc = fmaf(x[r * ldx + (int64_t)h * Fh + f], a[(int64_t)h * lda + f], acc);
+    float acc = 0.f, acc2 = 0.f;
+    for (int f = lane; f < Fh; f += 64) {
+      const float xv = x[r * ldx + (int64_t)h * Fh + f];
+      acc = fmaf(xv, a[(int64_t)h * lda + f], acc);
+      if (a2) acc2 = fmaf(xv, a2[(int64_t)h * lda2 + f], acc2);
+    }
     acc = wave_sum(acc);
-    if (lane == 0) s[r * H + h] = acc;
+    if (a2) acc2 = wave_sum(acc2);
+    if (lane == 0) {
+      s[r * H + h] = acc;
+      if (a2) s2[r * H + h] = acc2;
+    }
   }
 }
 
@@ -261,42 +271,52 @@ __global__ __launch_bounds__(256) void sddmm_heads_kernel(const int* __restrict_
 // Two levels so that one long segment (all rows of a 1000-node graph) still fills the chip: grid (ceil(C/64), S, chunks of
 // 128 rows) writes partials, segment_wsum_final adds the chunks in fixed order (reproducible, no float atomics).
 constexpr int SEG_CHUNK = 128;
+// w2 / part2 (nullable pair): a second weighted sum of the same rows in the same pass (x is read once)
 __global__ __launch_bounds__(256) void segment_wsum_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ w, int H,
                                                            int Fh, const int* __restrict__ seg_ptr, int64_t rows_if_one, int C,
-                                                           float* __restrict__ part, int nseg) {
+                                                           float* __restrict__ part, int nseg, const float* __restrict__ w2,
+                                                           float* __restrict__ part2) {
   __shared__ float lds[4][64];
+  __shared__ float lds2[4][64];
   const int s = blockIdx.y;
   const int64_t s0 = seg_ptr ? seg_ptr[s] : 0, s1 = seg_ptr ? seg_ptr[s + 1] : rows_if_one;
   const int64_t r0 = s0 + (int64_t)blockIdx.z * SEG_CHUNK, r1 = min(s1, r0 + SEG_CHUNK);
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int rl = threadIdx.x >> 6;
-  float acc = 0.f;
+  float acc = 0.f, acc2 = 0.f;
   if (c < C && r0 < r1) {
     const int h = c / Fh;
     for (int64_t rb = r0 + rl; rb < r1; rb += 32) {       // eight independent row loads in flight per thread
-      float xv[8], wv[8];
+      float xv[8], wv[8], wv2[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int64_t r = rb + 4 * u;
         const bool ok = r < r1;
         xv[u] = ok ? x[r * ldx + c] : 0.f;
         wv[u] = ok ? (w ? w[r * H + h] : 1.f) : 0.f;
+        wv2[u] = (ok && w2) ? w2[r * H + h] : 0.f;
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) acc = fmaf(wv[u], xv[u], acc);
+      for (int u = 0; u < 8; ++u) { acc = fmaf(wv[u], xv[u], acc); acc2 = fmaf(wv2[u], xv[u], acc2); }
     }
   }
   lds[rl][threadIdx.x & 63] = acc;
+  lds2[rl][threadIdx.x & 63] = acc2;
   __syncthreads();
-  if (rl == 0 && c < C)
+  if (rl == 0 && c < C) {
     part[((int64_t)blockIdx.z * nseg + s) * C + c] = (lds[0][threadIdx.x] + lds[1][threadIdx.x]) + (lds[2][threadIdx.x] + lds[3][threadIdx.x]);
+    if (part2)
+      part2[((int64_t)blockIdx.z * nseg + s) * C + c] = (lds2[0][threadIdx.x] + lds2[1][threadIdx.x]) + (lds2[2][threadIdx.x] + lds2[3][threadIdx.x]);
+  }
 }
 // grid (ceil(C / 64), nseg), 64 columns x 16 chunk lanes: lane q adds chunks q, q + 16, ... (a 32,000-row segment has 250
 // chunks: one thread per output summed them in a 32 us latency chain), then the 16 lanes are added in order.
 __global__ __launch_bounds__(1024) void segment_wsum_final(const float* __restrict__ part, int nchunk, int nseg, int C,
                                                            const int* __restrict__ seg_ptr, int64_t rows_if_one, float scale, int mean,
-                                                           float* __restrict__ out, int64_t ldo) {
+                                                           float* __restrict__ out, int64_t ldo, const float* __restrict__ part2,
+                                                           float* __restrict__ out2) {
   __shared__ float lds[16][64];
+  if (blockIdx.z == 1) { part = part2; out = out2; }             // the second sum of a two-weight call
   const int s = blockIdx.y, cl = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
   const int64_t len = seg_ptr ? (int64_t)(seg_ptr[s + 1] - seg_ptr[s]) : rows_if_one;
@@ -376,7 +396,16 @@ int tsgnn_node_scores_f32(const float* x, int64_t ldx, int64_t rows, int H, int 
                           tsgnn_stream_t stream) {
   if (!x || !a || !s || rows < 0 || H <= 0 || Fh <= 0 || ldx < (int64_t)H * Fh) return TSGNN_EINVAL;
   if (rows == 0) return TSGNN_OK;
-  node_scores_kernel<<<(unsigned)ceil_div64(rows, 4), 256, 0, stream>>>(x, ldx, rows, H, Fh, a, lda, s);
+  node_scores_kernel<<<(unsigned)ceil_div64(rows, 4), 256, 0, stream>>>(x, ldx, rows, H, Fh, a, lda, s, nullptr, 0, nullptr);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+int tsgnn_node_scores2_f32(const float* x, int64_t ldx, int64_t rows, int H, int Fh, const float* a1, int64_t lda1, float* s1,
+                           const float* a2, int64_t lda2, float* s2, tsgnn_stream_t stream) {
+  if (!x || !a1 || !s1 || !a2 || !s2 || rows < 0 || H <= 0 || Fh <= 0 || ldx < (int64_t)H * Fh) return TSGNN_EINVAL;
+  if (rows == 0) return TSGNN_OK;
+  node_scores_kernel<<<(unsigned)ceil_div64(rows, 4), 256, 0, stream>>>(x, ldx, rows, H, Fh, a1, lda1, s1, a2, lda2, s2);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }
@@ -482,8 +511,30 @@ int tsgnn_segment_wsum_f32(const float* x, int64_t ldx, const float* w, int H, i
   const int64_t longest = seg_ptr ? max_seg : rows;
   const int nchunk = (int)(longest > 0 ? ceil_div64(longest, SEG_CHUNK) : 1);
   dim3 grid((unsigned)((C + 63) / 64), (unsigned)nseg, (unsigned)nchunk);
-  segment_wsum_kernel<<<grid, 256, 0, stream>>>(x, ldx, w, H, Fh, seg_ptr, rows, C, ws, nseg);
-  segment_wsum_final<<<dim3((unsigned)((C + 63) / 64), (unsigned)nseg), 1024, 0, stream>>>(ws, nchunk, nseg, C, seg_ptr, rows, scale, mean, out, ldo);
+  segment_wsum_kernel<<<grid, 256, 0, stream>>>(x, ldx, w, H, Fh, seg_ptr, rows, C, ws, nseg, nullptr, nullptr);
+  segment_wsum_final<<<dim3((unsigned)((C + 63) / 64), (unsigned)nseg), 1024, 0, stream>>>(ws, nchunk, nseg, C, seg_ptr, rows, scale, mean, out, ldo,
+                                                                                           nullptr, nullptr);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+/* two weighted sums of the same rows in one pass (x read once): out1 = sum w1 x, out2 = sum w2 x; ws: twice the floats of
+ * tsgnn_segment_wsum_f32 */
+int tsgnn_segment_wsum2_f32(const float* x, int64_t ldx, const float* w1, const float* w2, int H, int Fh, const int* seg_ptr, int nseg,
+                            int64_t rows, int64_t max_seg, float scale, float* ws, float* out1, float* out2, int64_t ldo,
+                            tsgnn_stream_t stream) {
+  if (!x || !w1 || !w2 || !out1 || !out2 || !ws || H <= 0 || Fh <= 0 || nseg <= 0 || rows < 0 || max_seg < 0 || ldx < (int64_t)H * Fh ||
+      ldo < (int64_t)H * Fh)
+    return TSGNN_EINVAL;
+  if (!seg_ptr && nseg != 1) return TSGNN_EINVAL;
+  const int C = H * Fh;
+  const int64_t longest = seg_ptr ? max_seg : rows;
+  const int nchunk = (int)(longest > 0 ? ceil_div64(longest, SEG_CHUNK) : 1);
+  float* ws2 = ws + (size_t)nchunk * nseg * C;
+  dim3 grid((unsigned)((C + 63) / 64), (unsigned)nseg, (unsigned)nchunk);
+  segment_wsum_kernel<<<grid, 256, 0, stream>>>(x, ldx, w1, H, Fh, seg_ptr, rows, C, ws, nseg, w2, ws2);
+  segment_wsum_final<<<dim3((unsigned)((C + 63) / 64), (unsigned)nseg, 2), 1024, 0, stream>>>(ws, nchunk, nseg, C, seg_ptr, rows, scale, 0, out1,
+                                                                                              ldo, ws2, out2);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }

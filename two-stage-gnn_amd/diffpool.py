@@ -159,8 +159,7 @@ class _LinkPredLoss(torch.autograd.Function):
             srp, seg, nslab = g.row_slabs(tile)
             counts = np.diff(seg.cpu().numpy())
             slab_graph = torch.from_numpy(np.repeat(np.arange(g.B, dtype=np.int32), counts)).to(g.device)
-            cache = g._lp_slabs = (srp, slab_graph, nslab)
-            g._slabs = None                                   # row_slabs caches one slab size: leave it to its other users
+            cache = g._lp_slabs = (srp, slab_graph, nslab)     # (row_slabs itself re-cuts when asked for another slab size)
         srp, slab_graph, nslab = cache
         sizes = g.sizes.astype(np.float64)
         entries = float((sizes * sizes).sum()) if masked else float(g.nmax) * g.nmax * g.B
