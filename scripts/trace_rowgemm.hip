@@ -1,5 +1,6 @@
 // Developer harness: per-wave phase timeline of rowgemm_kernel (s_memtime stamps), built as
 //   hipcc --offload-arch=gfx950 -O3 -DTSGNN_TRACE scripts/trace_rowgemm.hip -o gpurun_out/trace_rowgemm
+// (add -DTSGNN_TRACE_WPB=8 for the gather variant: its row panels are 512-thread blocks, waves 4-7 = the second K group)
 #include "../two-stage-gnn_amd/csrc/rowgemm.hip"
 #include "trace_util.h"
 #include <cstdio>
@@ -48,8 +49,8 @@ int main(int argc, char** argv) {
     printf("trans_b=%d  %.2f us per launch (back-to-back, incl. trace stores)\n", trans, ms * 1000 / 200);
     const int last = trans ? 10 : 13;
     trace_report(t, nb, last);
-    for (int w : {0, 1, 400, 1143})
-      if (w < nb * 4) { printf("  wave %d:", w); for (int k = 0; k <= last; ++k) printf(" %lld", t[w * 16 + k] - t[w * 16]); printf("\n"); }
+    for (int w : {0, 1, 4, 5, 400, 404})
+      if (w < nb * TSGNN_TRACE_WPB) { printf("  wave %d:", w); for (int k = 0; k <= last; ++k) printf(" %lld", t[w * 16 + k] - t[w * 16]); printf("\n"); }
   }
   return 0;
 }

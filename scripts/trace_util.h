@@ -6,7 +6,10 @@
 
 // t: [nblocks*4][16] stamps; blocks are dealt round-robin to the 8 XCDs, each XCD has its own counter
 static void trace_report(const std::vector<long long>& t, int nblocks, int last) {
-  const int nw = std::min(nblocks, 1024) * 4;
+#ifndef TSGNN_TRACE_WPB
+#define TSGNN_TRACE_WPB 4
+#endif
+  const int nw = std::min(nblocks, 4096 / TSGNN_TRACE_WPB) * TSGNN_TRACE_WPB;
   double avg[16] = {0};
   for (int w = 0; w < nw; ++w)
     for (int k = 0; k <= last; ++k) avg[k] += (double)(t[w * 16 + k] - t[w * 16]);

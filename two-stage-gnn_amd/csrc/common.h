@@ -20,9 +20,12 @@
 // developer instrumentation (scripts/trace_*.hip build a kernel file with -DTSGNN_TRACE): per-wave s_memtime stamps,
 // 16 slots per wave, first 1024 blocks x 4 waves.  Compiled out of the library.
 #ifdef TSGNN_TRACE
+#ifndef TSGNN_TRACE_WPB
+#define TSGNN_TRACE_WPB 4                 /* waves per block of the traced kernel (8 for the 512-thread split-K row panels) */
+#endif
 __device__ long long g_trace[4096 * 16];
-#define TR_SLOT_(slot) g_trace[((blockIdx.x + gridDim.x * blockIdx.y) * 4 + (threadIdx.x >> 6)) * 16 + (slot)]
-#define TR_ON_ ((threadIdx.x & 63) == 0 && (blockIdx.x + gridDim.x * blockIdx.y) < 1024)
+#define TR_SLOT_(slot) g_trace[((blockIdx.x + gridDim.x * blockIdx.y) * TSGNN_TRACE_WPB + (threadIdx.x >> 6)) * 16 + (slot)]
+#define TR_ON_ ((threadIdx.x & 63) == 0 && (blockIdx.x + gridDim.x * blockIdx.y) < 4096 / TSGNN_TRACE_WPB)
 #define TR(slot) do { if (TR_ON_) { TR_SLOT_(slot) = __builtin_readcyclecounter(); if ((slot) == 0) TR_SLOT_(14) = wall_clock64(); } } while (0)
 #define TR_END() do { if (TR_ON_) TR_SLOT_(15) = wall_clock64(); } while (0)   /* 100 MHz, common to the whole device */
 #else

@@ -348,9 +348,11 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem_a
       for (int r = 0; r < 16; ++r) xch[(wid * 16 + r) * 64 + lane] = acc[0][r];
     }
     __syncthreads();
-    if (grp == 1) return;
+    TR(7);
+    if (grp == 1) { TR_END(); return; }
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[0][r] += xch[(wid * 16 + r) * 64 + lane];
+    TR(8);
   }
 
   // epilogue in registers: lane (i, h) of tile `wid + 4t` holds C[(r&3) + 8(r>>2) + 4h][tile*32 + i] in acc[t][r].
