@@ -331,8 +331,8 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem_a
       }
     }
     TR(3 + 2 * min(c, 3));
-    __syncthreads();
-    TR(4 + 2 * min(c, 3));
+    if (Kc > 2 * KC) __syncthreads();                  // stage reuse only exists beyond two chunks (both were committed before
+    TR(4 + 2 * min(c, 3));                             // the loop): without it the two K groups of a panel run uncoupled
   };
   for (int c = 0; c * KC < Kc; c += 4) {
     body(std::integral_constant<int, 0>{}, c);
