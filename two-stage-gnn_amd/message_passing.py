@@ -168,6 +168,37 @@ def linear_wgrad(z, K_in, du, want_db):
         nat.call("linear_wgrad_f32", z, z.stride(0), du, du.stride(0), R, int(K_in), int(N), int(nslab[0]), int(rps[0]), 0, ws,
                  dw, db)
         return dw, db
+    # wider than one slab pass (<= 128 x 128): the same MFMA slab kernel on 128-wide blocks, ONE fixed-order reduction for all
+    # of them — rows of dW when K_in > 128 (GAT layer 2: 256 -> 64), columns when N > 128 through the transposed product
+    # dW^T = dU^T Z (GAT layer 1: 92 -> 4 x 64).  The split-K fallback below spends 23 + 17 us on the DD batch for either.
+    if z.data_ptr() % 16 == 0 and du.data_ptr() % 16 == 0 and z.stride(0) % 4 == 0 and du.stride(0) % 4 == 0:
+        if K_in > 128 and N <= 128 and N % 4 == 0 and K_in % 4 == 0 and K_in <= 512:
+            dw = _f32(K_in, N, device=du.device)
+            db = _f32(N, device=du.device) if want_db else None
+            sets = []
+            for k0 in range(0, K_in, 128):
+                kc = min(128, K_in - k0)
+                got = linear_wgrad_slabs(z[:, k0:], kc, du)
+                if got is None:
+                    sets = None
+                    break
+                sets.append((got[0], got[1], kc, N, dw[k0:k0 + kc], db if k0 == 0 else None))
+            if sets:
+                wgrad_reduce_multi(sets)
+                return dw, db
+        elif N > 128 and K_in <= 128 and K_in % 4 == 0 and N % 4 == 0 and N <= 512 and z.size(1) >= K_in:
+            dwt = _f32(N, K_in, device=du.device)
+            sets = []
+            for n0 in range(0, N, 128):
+                nc = min(128, N - n0)
+                got = linear_wgrad_slabs(du[:, n0:], nc, z[:, :K_in] if z.size(1) != K_in else z)
+                if got is None:
+                    sets = None
+                    break
+                sets.append((got[0], got[1], nc, K_in, dwt[n0:n0 + nc], None))
+            if sets:
+                wgrad_reduce_multi(sets)
+                return dwt.t(), (colsum(du) if want_db else None)
     return gemm_tn_splitk(z, K_in, du), (colsum(du) if want_db else None)
 
 
