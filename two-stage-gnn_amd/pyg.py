@@ -129,16 +129,33 @@ def linear(x, weight_in_out, bias=None):
 
 
 # ----------------------------------------------------------------------------- GCNConv (a11)
-def _gcn_norm(g):
-    cache = getattr(g, "_gcn", None)
-    if cache is None:
-        R = g.total_rows
-        dinv = _f32(R, device=g.device)
-        val = _f32(max(g.nnz, 1), device=g.device)
-        self_w = _f32(R, device=g.device)
-        nat.call("gcn_norm_f32", g.rowptr, g.col, g.val, R, 1.0, dinv, val, self_w)
-        cache = g._gcn = (val, self_w)
-    return cache
+class _GcnPropagate(torch.autograd.Function):
+    """A^ x = D^-1/2 (A + I) D^-1/2 x from the per-row coefficients of gcn_norm (no per-edge weight tensor):
+    tsgnn_gcn_propagate_f32 forward, the same operator on A^T backward (A^T = A for symmetric edge lists)."""
+
+    @staticmethod
+    def forward(ctx, x, g):
+        from . import sag_stack as ss
+        x = x.contiguous()
+        dinv, self_w = ss.gcn_coef(g)
+        ctx.g = g
+        y, _ = ss.propagate(g.rowptr, g.col, dinv, self_w, x, g.total_rows)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import sag_stack as ss
+        g = ctx.g
+        dinv, self_w = ss.gcn_coef(g)
+        rp_t, col_t = (g.rowptr, g.col) if g.symmetric else g.transposed(None)[:2]
+        dx, _ = ss.propagate(rp_t, col_t, dinv, self_w, dy.contiguous(), g.total_rows)
+        return dx, None
+
+
+def gcn_propagate(x, g):
+    if g.val is not None:
+        raise NotImplementedError("edge weights are never passed by the reference (network.py:34)")
+    return _GcnPropagate.apply(x, g)
 
 
 class GCNConv(nn.Module):
@@ -164,9 +181,8 @@ class GCNConv(nn.Module):
         if edge_weight is not None:
             raise NotImplementedError("edge_weight is never passed by the reference (network.py:34)")
         g = edge_index if isinstance(edge_index, GraphBatch) else graph_of(edge_index, x.size(0))
-        val, self_w = _gcn_norm(g)
         xw = linear(x, self.weight)
-        return bias_add(mp.aggregate(xw, g, val=val, self_w=self_w), self.bias)
+        return bias_add(gcn_propagate(xw, g), self.bias)
 
 
 # ----------------------------------------------------------------------------- topk / filter_adj (a12, a13)
