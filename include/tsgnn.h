@@ -307,6 +307,12 @@ int tsgnn_mlp3_bwd_f32(const float* x, int64_t ldx, const float* w1, const float
                        const float* a2, const float* logp, const float* dlogp, float keep_scale, int B, int D0, int D1, int D2, int C,
                        float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3, float* dx, int64_t lddx,
                        tsgnn_stream_t stream);
+/* the same backward as two short launches (rows: dlogits -> dz2 -> dz1 -> dx once per row; weights: tiles that sum over the
+ * rows); ws: B * (C + D2 + D1) floats of scratch */
+int tsgnn_mlp3_bwd2_f32(const float* x, int64_t ldx, const float* w1, const float* w2, const float* w3, const float* a1,
+                        const float* a2, const float* logp, const float* dlogp, float keep_scale, int B, int D0, int D1, int D2, int C,
+                        float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3, float* dx, int64_t lddx, float* ws,
+                        tsgnn_stream_t stream);
 
 /* ---------------------------------------------------------------- DiffPool link-prediction side loss (linkpred.hip) */
 

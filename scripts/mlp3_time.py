@@ -27,6 +27,9 @@ def t(fn, n=200):
         for _ in range(n // 20): g.replay()
         e1.record(s); e1.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
+ws = torch.empty(B * (C + D2 + D1), device=dev)
+def bwd2(dxt): nat.call("mlp3_bwd2_f32", x, D0, w1, w2, w3, a1, a2, logp, dlogp, 1.0, B, D0, D1, D2, C, dw1, db1, dw2, db2, dw3, db3, dxt, D0, ws)
 print("fwd %.1f us" % t(fwd))
+print("bwd2 (two launches) full %.1f us per pair" % t(lambda: bwd2(dx)))
 print("bwd full %.1f us" % t(lambda: bwd(dx)))
 print("bwd no dx %.1f us" % t(lambda: bwd(None)))

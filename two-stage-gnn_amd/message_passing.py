@@ -314,6 +314,9 @@ def linear_oi(x, weight, bias=None):
     return _LinearOI.apply(x, weight, bias)
 
 
+MLP3_TWO_LAUNCH_BWD = True      # rows kernel + weights kernel (False: the single-launch backward, kept for comparison)
+
+
 class _Mlp3LogSoftmax(torch.autograd.Function):
     """log_softmax(lin3(relu(lin2(dropout(relu(lin1(x))))))) — Code/sag/network.py:48-53 — forward and backward in one launch each"""
 
@@ -339,8 +342,13 @@ class _Mlp3LogSoftmax(torch.autograd.Function):
         dw2, db2 = _f32(D2, D1, device=dev), _f32(D2, device=dev)
         dw3, db3 = _f32(C, D2, device=dev), _f32(C, device=dev)
         dx = _f32(B, D0, device=dev) if ctx.needs_input_grad[0] else None
-        nat.call("mlp3_bwd_f32", x, x.stride(0), w1, w2, w3, a1, a2, logp, dlogp, ctx.keep_scale, B, D0, D1, D2, C,
-                 dw1, db1, dw2, db2, dw3, db3, dx, D0)
+        if MLP3_TWO_LAUNCH_BWD:
+            ws = _f32(B * (C + D2 + D1), device=dev)
+            nat.call("mlp3_bwd2_f32", x, x.stride(0), w1, w2, w3, a1, a2, logp, dlogp, ctx.keep_scale, B, D0, D1, D2, C,
+                     dw1, db1, dw2, db2, dw3, db3, dx, D0, ws)
+        else:
+            nat.call("mlp3_bwd_f32", x, x.stride(0), w1, w2, w3, a1, a2, logp, dlogp, ctx.keep_scale, B, D0, D1, D2, C,
+                     dw1, db1, dw2, db2, dw3, db3, dx, D0)
         hb = ctx.has_b
         return dx, dw1, db1 if hb[0] else None, dw2, db2 if hb[1] else None, dw3, db3 if hb[2] else None, None, None
 
