@@ -342,7 +342,9 @@ __global__ __launch_bounds__(PG_THREADS) void sag_pool_graph_kernel(PoolGraphArg
     if (j < n) {
       const int r = g0 + j;
       float acc = 0.f;
-      for (int e = a.rowptr[r]; e < a.rowptr[r + 1]; ++e) {
+      const int e1 = a.rowptr[r + 1];
+#pragma unroll 8
+      for (int e = a.rowptr[r]; e < e1; ++e) {             // neighbour ids, then their coefficients: two round trips per batch of 8
         const int c = a.col[e];
         if ((unsigned)(c - g0) < (unsigned)n) acc = fmaf(a.dinv[c], t[c - g0], acc);   // graphs of a batch are disjoint (PyG collate)
       }
@@ -424,7 +426,9 @@ __global__ __launch_bounds__(PG_THREADS) void sag_pool_graph_kernel(PoolGraphArg
     const int j = (int)(0xFFFFFFFFu - (unsigned)(keys[p] & 0xFFFFFFFFull));
     const int r = g0 + j;
     int c = 0;
-    for (int e = a.rowptr[r]; e < a.rowptr[r + 1]; ++e) {
+    const int e1 = a.rowptr[r + 1];
+#pragma unroll 8
+    for (int e = a.rowptr[r]; e < e1; ++e) {
       const int cj = a.col[e] - g0;
       c += ((unsigned)cj < (unsigned)n && nid[cj] >= 0) ? 1 : 0;
     }
