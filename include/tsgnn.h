@@ -363,6 +363,11 @@ int tsgnn_gcn_coef_f32(const int* rowptr, const int* col, int64_t n_rows, float*
 int tsgnn_gcn_propagate_f32(const int* rowptr, const int* col, const float* dinv, const float* self_w, const float* x,
                             int64_t ldx, int relu_in, const float* bias, const float* w_dot, const float* dot_bias, float* y,
                             int64_t ldy, float* t, int64_t n_rows, int feat, tsgnn_stream_t stream);
+/* the same with explicit row ends: row r = entries [rowptr[r], rowend[r]) (rowend NULL = rowptr[r+1]) — the CSR the per-graph
+ * pooling kernel writes keeps every graph's entries at its old segment base, with slack between graphs */
+int tsgnn_gcn_propagate_re_f32(const int* rowptr, const int* rowend, const int* col, const float* dinv, const float* self_w,
+                               const float* x, int64_t ldx, int relu_in, const float* bias, const float* w_dot, const float* dot_bias,
+                               float* y, int64_t ldy, float* t, int64_t n_rows, int feat, tsgnn_stream_t stream);
 /* 1 when the fused level kernels below accept feature width F (F % 4 == 0, F <= 256) */
 int tsgnn_sag_supported(int F);
 /* kept rows (layers.py:21): xp[p,:] = relu?(y[perm[p],:]) * tanh(score[perm[p]]); cnt[p] = kept neighbours of perm[p].
@@ -373,12 +378,16 @@ int tsgnn_sag_pool_gather_f32(const float* y, int64_t ldy, const float* score, c
 /* One launch per level for everything between the conv output y (pre-activation) and the pooled rows, for graphs of at most
  * tsgnn_sag_pool_graph_max_nodes() nodes (one workgroup per graph, intermediate results in LDS): the score layer
  * score = A^ (relu(y) w_s) + b_s (layers.py:18), top-k with the relabelling map (perm, new_id as tsgnn_topk_segments_f32),
- * xp / cnt as tsgnn_sag_pool_gather_f32(relu_in = 1), out / arg as tsgnn_sag_readout_f32. */
+ * xp / cnt as tsgnn_sag_pool_gather_f32(relu_in = 1), out / arg as tsgnn_sag_readout_f32.  rowend (nullable): explicit row ends
+ * of the input CSR.  rowptr_new .. self_w_new (all or none): filter_adj done here too — the pooled adjacency goes to col_new
+ * from each graph's old segment base (rows [rowptr_new[p], rowend_new[p]), K entries each) with the next level's
+ * tsgnn_gcn_coef_f32 output, so no scan / fill launches follow. */
 int tsgnn_sag_pool_graph_max_nodes(void);
-int tsgnn_sag_pool_graph_f32(const float* y, int64_t ldy, const int* rowptr, const int* col, const float* dinv, const float* self_w,
-                             const float* w_s, const float* b_s, const int* graph_ptr, const int* graph_ptr_new, int B, int max_seg,
-                             int F, float* score, int* perm, int* new_id, float* xp, int64_t ldo, int* cnt, float* out, int64_t ldout,
-                             int* arg, int accumulate, tsgnn_stream_t stream);
+int tsgnn_sag_pool_graph_f32(const float* y, int64_t ldy, const int* rowptr, const int* rowend, const int* col, const float* dinv,
+                             const float* self_w, const float* w_s, const float* b_s, const int* graph_ptr, const int* graph_ptr_new,
+                             int B, int max_seg, int F, float* score, int* perm, int* new_id, float* xp, int64_t ldo, int* cnt,
+                             float* out, int64_t ldout, int* arg, int accumulate, int* rowptr_new, int* rowend_new, int* col_new,
+                             float* dinv_new, float* self_w_new, tsgnn_stream_t stream);
 /* out[b, :F] (+)= max over the rows of graph b, out[b, F:2F] (+)= their mean (gmp || gap, network.py:36,40,44);
  * arg[b, f] = row holding the max (ties -> smallest row) */
 int tsgnn_sag_readout_f32(const float* xp, int64_t ld, const int* graph_ptr, int B, int F, int accumulate, float* out, int64_t ldo,
@@ -400,7 +409,7 @@ int tsgnn_sag_pool_bwd_f32(const float* y, int64_t ldy, const float* score, cons
  * dws = sum_r dt[r] * relu(y[r]), dbs = sum_r dscore[r] (fixed-order block partials in `part`: tsgnn_sag_du_blocks(N, F)
  * rows of F + 4 floats, summed by a second one-block launch). */
 int tsgnn_sag_du_blocks(int64_t N, int F);
-int tsgnn_sag_du_f32(const int* rowptr, const int* col, const float* dinv, const float* self_w, const float* dscore, const float* y,
+int tsgnn_sag_du_f32(const int* rowptr, const int* rowend, const int* col, const float* dinv, const float* self_w, const float* dscore, const float* y,
                      int64_t ldy, const float* w_s, float* dyb, int64_t lddy, int64_t N, int F, float* part, float* dws, float* dbs,
                      tsgnn_stream_t stream);
 int tsgnn_relu_fwd_f32(const float* x, int64_t n, float* y, tsgnn_stream_t stream);

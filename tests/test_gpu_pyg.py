@@ -252,6 +252,35 @@ def test_sag_level_kernels_vs_oracle():
     torch.testing.assert_close(out.cpu(), ref_out, rtol=1e-6, atol=1e-6)
     nat.call("sag_readout_f32", xp, 32, Ln.gp, L.B, 32, 1, out, 64, arg)
     torch.testing.assert_close(out.cpu(), 2 * ref_out, rtol=1e-6, atol=1e-6)
+    # the same level tail as ONE per-graph launch, CSR filter included (rows with explicit ends at the graphs' old bases)
+    wsc, bsc = tie_free(34, 32), tie_free(35, 1)
+    t_ref = P.gcn_conv(torch.relu(y), ei, wsc.view(-1, 1), bsc).view(-1)
+    perm_r = P.topk(t_ref, 0.5, batch)
+    sc2 = torch.empty(n, device="cuda"); perm2 = torch.empty(K, dtype=torch.int32, device="cuda"); nid2 = torch.empty(n, dtype=torch.int32, device="cuda")
+    xp2 = torch.empty(K, 32, device="cuda"); cnt2 = torch.empty(K, dtype=torch.int32, device="cuda")
+    out2 = torch.empty(L.B, 64, device="cuda"); arg2 = torch.empty(L.B, 32, dtype=torch.int32, device="cuda")
+    rp2 = torch.empty(K, dtype=torch.int32, device="cuda"); re2 = torch.empty(K, dtype=torch.int32, device="cuda")
+    col2 = torch.full((ei.size(1),), -7, dtype=torch.int32, device="cuda")
+    d2 = torch.empty(K, device="cuda"); s2 = torch.empty(K, device="cuda")
+    nat.call("sag_pool_graph_f32", y.cuda(), 32, g.rowptr, None, g.col, dinv, self_w, wsc.cuda(), bsc.cuda(), L.gp, Ln.gp, L.B, L.max_seg, 32,
+             sc2, perm2, nid2, xp2, 32, cnt2, out2, 64, arg2, 0, rp2, re2, col2, d2, s2)
+    torch.testing.assert_close(sc2.cpu(), t_ref, rtol=1e-5, atol=1e-5)
+    np.testing.assert_array_equal(perm2.cpu().numpy(), perm_r.numpy())
+    ei_r = P.filter_adj(ei, perm_r, n)
+    g_r = GraphBatch.from_edge_index(ei_r.cuda(), K, ghosts=False)
+    rp2c, re2c, col2c = rp2.cpu().numpy(), re2.cpu().numpy(), col2.cpu().numpy()
+    assert [col2c[rp2c[i]:re2c[i]].tolist() for i in range(K)] == _csr_rows(g_r.rowptr, g_r.col, K)
+    d_r, s_r = SS.gcn_coef(g_r)
+    torch.testing.assert_close(d2, d_r, rtol=0, atol=0)
+    torch.testing.assert_close(s2, s_r, rtol=0, atol=0)
+    xr2 = torch.relu(y)[perm_r] * torch.tanh(t_ref[perm_r]).view(-1, 1)
+    torch.testing.assert_close(xp2.cpu(), xr2, rtol=1e-5, atol=1e-5)
+    b3 = batch[perm_r]
+    torch.testing.assert_close(out2.cpu(), torch.cat([P.global_max_pool(xr2, b3, L.B), P.global_mean_pool(xr2, b3, L.B)], 1), rtol=1e-5, atol=1e-5)
+    # the filtered CSR with explicit row ends feeds the propagate kernel
+    xk = tie_free(36, K, 32)
+    got, _ = SS.propagate(rp2, col2, d2, s2, xk.cuda(), K, rowend=re2)
+    torch.testing.assert_close(got.cpu(), P.gcn_conv(xk, ei_r, torch.eye(32), None), rtol=1e-5, atol=1e-6)
     # scan across the single-block tile boundary
     c = torch.randint(0, 9, (9001,), dtype=torch.int32)
     o = torch.empty(9002, dtype=torch.int32, device="cuda")

@@ -43,6 +43,8 @@ __global__ void gcn_coef_kernel(const int* __restrict__ rowptr, const int* __res
 
 struct PropArgs {
   const int* rowptr;
+  const int* rowend;       // nullable: row r = entries [rowptr[r], rowend[r]) (graph segments with slack between them, written by
+                           // the per-graph pooling kernel); NULL: the standard [rowptr[r], rowptr[r+1])
   const int* col;
   const float* dinv;
   const float* self_w;
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(256) void gcn_propagate_vec4(PropArgs a, unsigned n
   const int nvec = a.feat >> 2;
   const bool live = lig < nvec;
   const int64_t co = live ? 4 * lig : 0;
-  const int e0 = a.rowptr[row], e1 = a.rowptr[row + 1];
+  const int e0 = a.rowptr[row], e1 = a.rowend ? a.rowend[row] : a.rowptr[row + 1];
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int eb = e0; eb < e1; eb += G) {
     const int me = eb + lig;
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(256) void gcn_propagate_generic(PropArgs a) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= a.n_rows) return;
-  const int e0 = a.rowptr[row], e1 = a.rowptr[row + 1];
+  const int e0 = a.rowptr[row], e1 = a.rowend ? a.rowend[row] : a.rowptr[row + 1];
   const float di = a.dinv[row], sw = a.self_w[row];
   float dot = 0.f;
   for (int fb = 0; fb < a.feat; fb += 64) {                // wave-uniform trip count
@@ -298,13 +300,16 @@ constexpr int PG_RANK_MAX = 1024;        // up to this many (padded) nodes the t
 
 struct PoolGraphArgs {
   const float* y; int64_t ldy;
-  const int* rowptr; const int* col; const float* dinv; const float* self_w;
+  const int* rowptr; const int* rowend; const int* col; const float* dinv; const float* self_w;
   const float* w_s; const float* b_s;
   const int* gp; const int* gp_new;
   float* score; int* perm; int* new_id;
   float* xp; int64_t ldo; int* cnt;
   float* out; int64_t ldout; int* arg; int accumulate;
   int F;
+  // CSR filter inside the kernel (all nullable together): the pooled level's adjacency goes to col_new at the graph's OLD
+  // segment base rowptr[gp[b]] (kept entries never outnumber the old ones), rows [rowptr_new[p], rowend_new[p])
+  int* rowptr_new; int* rowend_new; int* col_new; float* dinv_new; float* self_w_new;
 };
 
 template <int G>
@@ -342,7 +347,7 @@ __global__ __launch_bounds__(PG_THREADS) void sag_pool_graph_kernel(PoolGraphArg
     if (j < n) {
       const int r = g0 + j;
       float acc = 0.f;
-      const int e1 = a.rowptr[r + 1];
+      const int e1 = a.rowend ? a.rowend[r] : a.rowptr[r + 1];
 #pragma unroll 8
       for (int e = a.rowptr[r]; e < e1; ++e) {             // neighbour ids, then their coefficients: two round trips per batch of 8
         const int c = a.col[e];
@@ -421,18 +426,74 @@ __global__ __launch_bounds__(PG_THREADS) void sag_pool_graph_kernel(PoolGraphArg
       *reinterpret_cast<int4*>(rarg + grp * a.F + co) = am;
     }
   }
-  // (6) kept neighbours of every kept row (the CSR filter's counts)
-  for (int p = tid; p < k; p += PG_THREADS) {
-    const int j = (int)(0xFFFFFFFFu - (unsigned)(keys[p] & 0xFFFFFFFFull));
-    const int r = g0 + j;
+  // (6) kept neighbours of every kept row: the CSR filter's counts — and, when asked, the filter itself (layers.py:23-24):
+  // block scan of the counts, rows laid out from the graph's old segment base, entries relabelled in their original order,
+  // and the next level's gcn_norm coefficients
+  int* cl = reinterpret_cast<int*>(t);                                  // [np] counts, then exclusive offsets (t is dead by now)
+  for (int p = tid; p < np; p += PG_THREADS) {
     int c = 0;
-    const int e1 = a.rowptr[r + 1];
+    if (p < k) {
+      const int j = (int)(0xFFFFFFFFu - (unsigned)(keys[p] & 0xFFFFFFFFull));
+      const int r = g0 + j;
+      const int e1 = a.rowend ? a.rowend[r] : a.rowptr[r + 1];
 #pragma unroll 8
-    for (int e = a.rowptr[r]; e < e1; ++e) {
-      const int cj = a.col[e] - g0;
-      c += ((unsigned)cj < (unsigned)n && nid[cj] >= 0) ? 1 : 0;
+      for (int e = a.rowptr[r]; e < e1; ++e) {
+        const int cj = a.col[e] - g0;
+        c += ((unsigned)cj < (unsigned)n && nid[cj] >= 0) ? 1 : 0;
+      }
+      a.cnt[k0 + p] = c;
     }
-    a.cnt[k0 + p] = c;
+    cl[p] = c;
+  }
+  __syncthreads();
+  if (a.col_new != nullptr) {
+    // exclusive scan of cl[0..np): four consecutive counts per thread, wave scan, wave totals through LDS (np <= 4,096)
+    __shared__ int wsum[PG_THREADS / 64];
+    const int lane = tid & 63, wid = tid >> 6;
+    int v[4], sum = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { v[q] = (4 * tid + q < np) ? cl[4 * tid + q] : 0; sum += v[q]; }
+    int inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += up;
+    }
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    int wbase = 0;
+#pragma unroll
+    for (int w = 0; w < PG_THREADS / 64; ++w) wbase += (w < wid) ? wsum[w] : 0;
+    int ex = wbase + inc - sum;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (4 * tid + q < np) cl[4 * tid + q] = ex;
+      ex += v[q];
+    }
+    __syncthreads();
+    const int base = a.rowptr[g0];
+    for (int p = tid; p < k; p += PG_THREADS) {
+      const int j = (int)(0xFFFFFFFFu - (unsigned)(keys[p] & 0xFFFFFFFFull));
+      const int r = g0 + j;
+      const int e1 = a.rowend ? a.rowend[r] : a.rowptr[r + 1];
+      const int o0 = base + cl[p];
+      int o = o0;
+      bool has_self = false;
+      for (int e = a.rowptr[r]; e < e1; ++e) {
+        const int cj = a.col[e] - g0;
+        const int id = ((unsigned)cj < (unsigned)n) ? nid[cj] : -1;
+        if (id >= 0) {
+          a.col_new[o++] = id;
+          has_self |= (id == k0 + p);
+        }
+      }
+      a.rowptr_new[k0 + p] = o0;
+      a.rowend_new[k0 + p] = o;
+      const float d = (float)(o - o0) + (has_self ? 0.f : 1.f);
+      const float di = 1.0f / sqrtf(d);
+      a.dinv_new[k0 + p] = di;
+      a.self_w_new[k0 + p] = has_self ? 0.f : di * di;
+    }
   }
   __syncthreads();
   for (int f = tid; f < a.F; f += PG_THREADS) {
@@ -537,7 +598,8 @@ __global__ __launch_bounds__(256) void sag_pool_bwd(const float* __restrict__ y,
 // part[b, F]); sag_du_reduce adds them up in a fixed order.  (A last-block-done reduction inside this kernel was measured
 // at 22 us per launch: the device-scope release fence of 256 blocks costs more than a 3 us launch.)
 template <int G>
-__global__ __launch_bounds__(256) void sag_du_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
+__global__ __launch_bounds__(256) void sag_du_kernel(const int* __restrict__ rowptr, const int* __restrict__ rowend,
+                                                     const int* __restrict__ col,
                                                      const float* __restrict__ dinv, const float* __restrict__ self_w,
                                                      const float* __restrict__ dscore, const float* __restrict__ y, int64_t ldy,
                                                      const float* __restrict__ w_s, float* __restrict__ dyb, int64_t lddy, int64_t N,
@@ -553,7 +615,7 @@ __global__ __launch_bounds__(256) void sag_du_kernel(const int* __restrict__ row
   float dsum = 0.f;
   for (int64_t r = (int64_t)blockIdx.x * RPB + grp; r < N; r += (int64_t)gridDim.x * RPB) {   // group-uniform
     float t = 0.f;
-    const int e1 = rowptr[r + 1];
+    const int e1 = rowend ? rowend[r] : rowptr[r + 1];
     for (int e = rowptr[r] + lig; e < e1; e += G) {
       const int j = col[e];
       t = fmaf(dinv[j], dscore[j], t);
@@ -690,15 +752,22 @@ int tsgnn_gcn_coef_f32(const int* rowptr, const int* col, int64_t n_rows, float*
 int tsgnn_gcn_propagate_f32(const int* rowptr, const int* col, const float* dinv, const float* self_w, const float* x,
                             int64_t ldx, int relu_in, const float* bias, const float* w_dot, const float* dot_bias, float* y,
                             int64_t ldy, float* t, int64_t n_rows, int feat, tsgnn_stream_t stream) {
+  return tsgnn_gcn_propagate_re_f32(rowptr, nullptr, col, dinv, self_w, x, ldx, relu_in, bias, w_dot, dot_bias, y, ldy, t, n_rows, feat,
+                                    stream);
+}
+
+int tsgnn_gcn_propagate_re_f32(const int* rowptr, const int* rowend, const int* col, const float* dinv, const float* self_w,
+                               const float* x, int64_t ldx, int relu_in, const float* bias, const float* w_dot, const float* dot_bias,
+                               float* y, int64_t ldy, float* t, int64_t n_rows, int feat, tsgnn_stream_t stream) {
   if (n_rows < 0 || feat <= 0 || !rowptr || !dinv || !self_w || !x || ldx < feat) return TSGNN_EINVAL;
   if (!y && !w_dot) return TSGNN_EINVAL;
   if (y && ldy < feat) return TSGNN_EINVAL;
   if (w_dot && !t) return TSGNN_EINVAL;
   if (n_rows == 0) return TSGNN_OK;
-  PropArgs a{rowptr, col, dinv, self_w, x, ldx, bias, w_dot, dot_bias, y, ldy, t, n_rows, feat, relu_in};
+  PropArgs a{rowptr, rowend, col, dinv, self_w, x, ldx, bias, w_dot, dot_bias, y, ldy, t, n_rows, feat, relu_in};
   const bool vec_ok = feat % 4 == 0 && feat <= 256 && ldx % 4 == 0 && aligned16(x) && (!y || (ldy % 4 == 0 && aligned16(y))) &&
                       (!bias || aligned16(bias)) && (!w_dot || aligned16(w_dot));
-  if (vec_ok && n_rows >= PROP_RB_MIN_ROWS && (group_of(feat) == 16 || group_of(feat) == 32)) {
+  if (vec_ok && !rowend && n_rows >= PROP_RB_MIN_ROWS && (group_of(feat) == 16 || group_of(feat) == 32)) {
     if (group_of(feat) == 16) {
       const unsigned nblk = (unsigned)ceil_div64(n_rows, (256 / 16) * 4);
       gcn_propagate_vec4_rb<16, 4><<<nblk, 256, 0, stream>>>(a, nblk);
@@ -745,10 +814,14 @@ int tsgnn_sag_pool_gather_f32(const float* y, int64_t ldy, const float* score, c
 
 int tsgnn_sag_pool_graph_max_nodes(void) { return PG_MAX_NODES; }
 
-int tsgnn_sag_pool_graph_f32(const float* y, int64_t ldy, const int* rowptr, const int* col, const float* dinv, const float* self_w,
-                             const float* w_s, const float* b_s, const int* graph_ptr, const int* graph_ptr_new, int B, int max_seg,
-                             int F, float* score, int* perm, int* new_id, float* xp, int64_t ldo, int* cnt, float* out, int64_t ldout,
-                             int* arg, int accumulate, tsgnn_stream_t stream) {
+int tsgnn_sag_pool_graph_f32(const float* y, int64_t ldy, const int* rowptr, const int* rowend, const int* col, const float* dinv,
+                             const float* self_w, const float* w_s, const float* b_s, const int* graph_ptr, const int* graph_ptr_new,
+                             int B, int max_seg, int F, float* score, int* perm, int* new_id, float* xp, int64_t ldo, int* cnt,
+                             float* out, int64_t ldout, int* arg, int accumulate, int* rowptr_new, int* rowend_new, int* col_new,
+                             float* dinv_new, float* self_w_new, tsgnn_stream_t stream) {
+  if ((col_new != nullptr) != (rowptr_new != nullptr) || (col_new != nullptr) != (rowend_new != nullptr) ||
+      (col_new != nullptr) != (dinv_new != nullptr) || (col_new != nullptr) != (self_w_new != nullptr))
+    return TSGNN_EINVAL;
   if (!y || !rowptr || !dinv || !self_w || !w_s || !graph_ptr || !graph_ptr_new || !score || !perm || !new_id || !xp || !cnt || !out ||
       !arg || B <= 0 || max_seg < 0 || ldy < F || ldo < F || ldout < 2 * F)
     return TSGNN_EINVAL;
@@ -758,8 +831,8 @@ int tsgnn_sag_pool_graph_f32(const float* y, int64_t ldy, const int* rowptr, con
   int np = 1;
   while (np < max_seg) np <<= 1;
   const size_t lds = (size_t)np * (8 + 4 + 4) + (size_t)PG_RGROUPS * F * 12 + (np <= PG_RANK_MAX ? (size_t)np * 8 : 0);
-  PoolGraphArgs a{y, ldy, rowptr, col, dinv, self_w, w_s, b_s, graph_ptr, graph_ptr_new, score, perm, new_id, xp, ldo, cnt,
-                  out, ldout, arg, accumulate, F};
+  PoolGraphArgs a{y, ldy, rowptr, rowend, col, dinv, self_w, w_s, b_s, graph_ptr, graph_ptr_new, score, perm, new_id, xp, ldo, cnt,
+                  out, ldout, arg, accumulate, F, rowptr_new, rowend_new, col_new, dinv_new, self_w_new};
 #define PG_LAUNCH(GG)                                                                                                          \
   do {                                                                                                                         \
     if (lds > 64 * 1024)                                                                                                       \
@@ -827,14 +900,14 @@ int tsgnn_sag_du_blocks(int64_t N, int F) {
   return (int)(nb < 256 ? nb : 256);
 }
 
-int tsgnn_sag_du_f32(const int* rowptr, const int* col, const float* dinv, const float* self_w, const float* dscore, const float* y,
+int tsgnn_sag_du_f32(const int* rowptr, const int* rowend, const int* col, const float* dinv, const float* self_w, const float* dscore, const float* y,
                      int64_t ldy, const float* w_s, float* dyb, int64_t lddy, int64_t N, int F, float* part, float* dws, float* dbs,
                      tsgnn_stream_t stream) {
   if (N <= 0 || !rowptr || !dinv || !self_w || !dscore || !y || !w_s || !dyb || !part || !dws || !dbs) return TSGNN_EINVAL;
   if (!tsgnn_sag_supported(F) || ldy % 4 || lddy % 4 || !aligned16(y) || !aligned16(dyb) || !aligned16(w_s) || !aligned16(part))
     return TSGNN_EUNSUPPORTED;
   const unsigned nb = (unsigned)tsgnn_sag_du_blocks(N, F);
-  SAG_DISPATCH(F, (sag_du_kernel<G><<<nb, 256, 0, stream>>>(rowptr, col, dinv, self_w, dscore, y, ldy, w_s, dyb, lddy, N, F, part)));
+  SAG_DISPATCH(F, (sag_du_kernel<G><<<nb, 256, 0, stream>>>(rowptr, rowend, col, dinv, self_w, dscore, y, ldy, w_s, dyb, lddy, N, F, part)));
   sag_du_reduce<<<1, 256, 0, stream>>>(part, (int)nb, F, dws, dbs);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;

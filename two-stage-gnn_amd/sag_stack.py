@@ -84,12 +84,12 @@ def gcn_coef(g):
     return c
 
 
-def propagate(rowptr, col, dinv, self_w, x, n_rows, relu_in=False, bias=None, w_dot=None, dot_bias=None, want_y=True):
-    """A^ x (+ bias) and / or its dot with w_dot; see tsgnn_gcn_propagate_f32."""
+def propagate(rowptr, col, dinv, self_w, x, n_rows, relu_in=False, bias=None, w_dot=None, dot_bias=None, want_y=True, rowend=None):
+    """A^ x (+ bias) and / or its dot with w_dot; see tsgnn_gcn_propagate_re_f32 (rowend: explicit row ends or None)."""
     F = x.size(1)
     y = _f32(n_rows, F, device=x.device) if want_y else None
     t = _f32(n_rows, device=x.device) if w_dot is not None else None
-    nat.call("gcn_propagate_f32", rowptr, col, dinv, self_w, x, x.stride(0), int(relu_in), bias, w_dot, dot_bias, y,
+    nat.call("gcn_propagate_re_f32", rowptr, rowend, col, dinv, self_w, x, x.stride(0), int(relu_in), bias, w_dot, dot_bias, y,
              y.stride(0) if want_y else 0, t, int(n_rows), int(F))
     return y, t
 
@@ -142,7 +142,7 @@ class _SagStack(torch.autograd.Function):
         x = x.contiguous().float()
         H = params[0].size(1)
         B = plan.levels[0].B
-        rowptr, col = g.rowptr, g.col
+        rowptr, col, rowend = g.rowptr, g.col, None          # rowend: explicit row ends once a level was filtered in-kernel
         dinv, self_w = gcn_coef(g)
         sym = bool(g.symmetric)
         rowptr_t, col_t = (rowptr, col) if sym else g.transposed(None)[:2]
@@ -157,23 +157,36 @@ class _SagStack(torch.autograd.Function):
             W, b, ws, bs = params[4 * l: 4 * l + 4]
             W, b = _al16(W.contiguous()), _al16(b.contiguous())
             wsv = _al16(ws.contiguous().view(-1))
-            agg, _ = propagate(rowptr, col, dinv, self_w, xin, N)
+            agg, _ = propagate(rowptr, col, dinv, self_w, xin, N, rowend=rowend)
             y = _linear(agg, W, b)
             perm, new_id = _i32(max(K, 1), device=dev), _i32(max(N, 1), device=dev)
             xp, cnt = _f32(K, H, device=dev), _i32(max(K, 1), device=dev)
             arg = _i32(B, H, device=dev)
+            fused_filter = False
             if L.max_seg <= pool_graph_max and PER_GRAPH_POOL:
-                # score layer, top-k, gated gather, readout and the filter's counts: one workgroup per graph, one launch
+                # score layer, top-k, gated gather, readout and (symmetric graphs) the CSR filter: one workgroup per graph,
+                # one launch; the pooled adjacency keeps each graph at its old segment base -> explicit row ends
                 score = _f32(N, device=dev)
-                nat.call("sag_pool_graph_f32", y, y.stride(0), rowptr, col, dinv, self_w, wsv, bs, L.gp, Ln.gp, B, L.max_seg, H,
-                         score, perm, new_id, xp, xp.stride(0), cnt, read, read.stride(0), arg, int(l > 0))
+                fused_filter = sym and l + 1 < depth
+                if fused_filter:
+                    rp_n, re_n, col_n = _i32(K, device=dev), _i32(K, device=dev), _i32(nnz_bound, device=dev)
+                    dinv_n, self_w_n = _f32(K, device=dev), _f32(K, device=dev)
+                else:
+                    rp_n = re_n = col_n = dinv_n = self_w_n = None
+                nat.call("sag_pool_graph_f32", y, y.stride(0), rowptr, rowend, col, dinv, self_w, wsv, bs, L.gp, Ln.gp, B, L.max_seg, H,
+                         score, perm, new_id, xp, xp.stride(0), cnt, read, read.stride(0), arg, int(l > 0),
+                         rp_n, re_n, col_n, dinv_n, self_w_n)
             else:
+                if rowend is not None:
+                    raise RuntimeError("explicit row ends only arise from the per-graph kernel, whose size limit applies to every level")
                 _, score = propagate(rowptr, col, dinv, self_w, y, N, relu_in=True, w_dot=wsv, dot_bias=bs, want_y=False)
                 nat.call("topk_segments_f32", score, L.gp, Ln.gp, B, L.max_seg, perm, new_id)
                 nat.call("sag_pool_gather_f32", y, y.stride(0), score, perm, new_id, rowptr, col, K, H, 1, xp, xp.stride(0), cnt)
                 nat.call("sag_readout_f32", xp, xp.stride(0), Ln.gp, B, H, int(l > 0), read, read.stride(0), arg)
-            saved.append((xin, agg, y, score, new_id, arg, rowptr, col, rowptr_t, col_t, dinv, self_w, W, wsv))
-            if l + 1 < depth:                                   # the adjacency after the last pool is never used
+            saved.append((xin, agg, y, score, new_id, arg, rowptr, col, rowptr_t, col_t, dinv, self_w, W, wsv, rowend))
+            if fused_filter:
+                rowptr, col, rowend, rowptr_t, col_t, dinv, self_w = rp_n, col_n, re_n, rp_n, col_n, dinv_n, self_w_n
+            elif l + 1 < depth:                                 # the adjacency after the last pool is never used
                 rp_n, col_n = _i32(K + 1, device=dev), _i32(nnz_bound, device=dev)
                 dinv_n, self_w_n = _f32(K, device=dev), _f32(K, device=dev)
                 nat.call("scan_short_i32", cnt, K, rp_n)
@@ -204,20 +217,20 @@ class _SagStack(torch.autograd.Function):
         for l in range(depth - 1, -1, -1):
             L, Ln = plan.levels[l], plan.levels[l + 1]
             N = L.N
-            xin, agg, y, score, new_id, arg, rowptr, col, rowptr_t, col_t, dinv, self_w, W, wsv = ctx.saved_levels[l]
+            xin, agg, y, score, new_id, arg, rowptr, col, rowptr_t, col_t, dinv, self_w, W, wsv, rowend = ctx.saved_levels[l]
             dyb, dscore = _f32(N, H, device=dev), _f32(N, device=dev)
             nat.call("sag_pool_bwd_f32", y, y.stride(0), score, new_id, Ln.row_graph, Ln.gp, arg, dxp,
                      dxp.stride(0) if dxp is not None else 0, dread, dread.stride(0), N, H, 1, dyb, dyb.stride(0), dscore)
             nb = int(nat.lib().tsgnn_sag_du_blocks(N, H))
             part, dws, dbs = _f32(nb * (H + 4), device=dev), _f32(H, device=dev), _f32(1, device=dev)
             # dt = A^T dscore: the score layer's propagate transposed
-            nat.call("sag_du_f32", rowptr_t, col_t, dinv, self_w, dscore, y, y.stride(0), wsv, dyb, dyb.stride(0), N, H, part,
+            nat.call("sag_du_f32", rowptr_t, rowend, col_t, dinv, self_w, dscore, y, y.stride(0), wsv, dyb, dyb.stride(0), N, H, part,
                      dws, dbs)
             dW, db = mp.linear_wgrad(agg, agg.size(1), dyb, True)
             grads[4 * l: 4 * l + 4] = [dW, db, dws.view(-1, 1), dbs]
             if l > 0 or ctx.x_needs_grad:
                 dagg = _linear_t(dyb, W)
-                dxin, _ = propagate(rowptr_t, col_t, dinv, self_w, dagg, N)
+                dxin, _ = propagate(rowptr_t, col_t, dinv, self_w, dagg, N, rowend=rowend)
                 if l > 0:
                     dxp = dxin
                 else:
