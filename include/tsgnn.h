@@ -405,6 +405,14 @@ int tsgnn_sag_pool_bwd_f32(const float* y, int64_t ldy, const float* score, cons
                            const int* graph_ptr_new, const int* arg, const float* dxp, int64_t lddxp, const float* dread,
                            int64_t lddr, int64_t N, int F, int relu_in, float* dyb, int64_t lddy, float* dscore,
                            tsgnn_stream_t stream);
+/* tsgnn_sag_pool_bwd_f32 + tsgnn_sag_du_f32 as one workgroup per graph (graphs <= tsgnn_sag_pool_graph_max_nodes() nodes,
+ * symmetric adjacency, rowend nullable): du[r] = gradient w.r.t. the pre-activation conv output y[r]; part: B rows of F + 4
+ * floats; dws / dbs as tsgnn_sag_du_f32. */
+int tsgnn_sag_pool_graph_bwd_f32(const float* y, int64_t ldy, const float* score, const int* new_id, const int* graph_ptr,
+                                 const int* graph_ptr_new, const int* arg, const float* dxp, int64_t lddxp, const float* dread,
+                                 int64_t lddr, const int* rowptr, const int* rowend, const int* col, const float* dinv,
+                                 const float* self_w, const float* w_s, int B, int max_seg, int F, float* du, int64_t lddu, float* part,
+                                 float* dws, float* dbs, tsgnn_stream_t stream);
 /* dyb[r] <- (dyb[r] + dt[r] * w_s) * [y[r] > 0] with dt = A^ dscore (score layer backward folded in);
  * dws = sum_r dt[r] * relu(y[r]), dbs = sum_r dscore[r] (fixed-order block partials in `part`: tsgnn_sag_du_blocks(N, F)
  * rows of F + 4 floats, summed by a second one-block launch). */

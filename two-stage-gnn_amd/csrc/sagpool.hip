@@ -685,6 +685,106 @@ __global__ __launch_bounds__(256) void sag_du_reduce(const float* __restrict__ p
   }
 }
 
+// ---------------------------------------------------------------- backward of the level tail, one workgroup per graph
+// pool_bwd -> dt = A^ dscore -> du also touch one graph's rows only: with dscore and dt in LDS the three phases are one launch
+// (sag_pool_bwd + sag_du otherwise), followed by the fixed-order reduction of the per-graph partial sums of dw_s / db_s.
+struct PoolGraphBwdArgs {
+  const float* y; int64_t ldy; const float* score; const int* new_id;
+  const int* gp; const int* gp_new; const int* arg;
+  const float* dxp; int64_t lddxp; const float* dread; int64_t lddr;
+  const int* rowptr; const int* rowend; const int* col; const float* dinv; const float* self_w; const float* w_s;
+  float* du; int64_t lddu; float* part; int F;
+};
+template <int G>
+__global__ __launch_bounds__(PG_THREADS) void sag_pool_graph_bwd_kernel(PoolGraphBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float pb_smem[];
+  constexpr int NG = PG_THREADS / G;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int g0 = a.gp[b], n = a.gp[b + 1] - g0;
+  const int kb = a.gp_new[b + 1] - a.gp_new[b];
+  const int F = a.F, nvec = F >> 2;
+  float* ds = pb_smem;                        // [n] dscore
+  float* dt = ds + ((n + 3) & ~3);            // [n]
+  float* racc = dt + ((n + 3) & ~3);          // [NG][F] partial dw_s
+  const int lig = tid & (G - 1), grp = tid / G;
+  const bool live = lig < nvec;
+  const int co = live ? 4 * lig : 0;
+  const float inv_k = 1.0f / (float)max(kb, 1);
+  float4 dm = make_float4(0.f, 0.f, 0.f, 0.f), dx = dm;
+  int4 am = make_int4(-1, -1, -1, -1);
+  if (live) {
+    dm = ld4(a.dread + (int64_t)b * a.lddr + F + co);
+    dx = ld4(a.dread + (int64_t)b * a.lddr + co);
+    am = *reinterpret_cast<const int4*>(a.arg + (int64_t)b * F + co);
+  }
+  // (A) gradient of the gated gather + readouts per row: du <- dtot * gate (for now), dscore -> LDS
+  for (int j = grp; j < n; j += NG) {
+    const int r = g0 + j;
+    const int p = a.new_id[r];
+    float4 gq = make_float4(0.f, 0.f, 0.f, 0.f);
+    float dsv = 0.f;
+    if (p >= 0) {                                                       // group-uniform
+      float4 d = a.dxp ? ld4(a.dxp + (int64_t)p * a.lddxp + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+      d.x += dm.x * inv_k + (am.x == p ? dx.x : 0.f);
+      d.y += dm.y * inv_k + (am.y == p ? dx.y : 0.f);
+      d.z += dm.z * inv_k + (am.z == p ? dx.z : 0.f);
+      d.w += dm.w * inv_k + (am.w == p ? dx.w : 0.f);
+      const float gate = tanhf(a.score[r]);
+      const float4 v = relu4(ld4(a.y + (int64_t)r * a.ldy + co));
+      float dot = live ? dot4(d, v) : 0.f;
+      dot = group_sum<G>(dot);
+      dsv = dot * (1.f - gate * gate);
+      gq = make_float4(d.x * gate, d.y * gate, d.z * gate, d.w * gate);
+    }
+    if (live) *reinterpret_cast<float4*>(a.du + (int64_t)r * a.lddu + co) = gq;
+    if (lig == 0) ds[j] = dsv;
+  }
+  __syncthreads();
+  // (B) dt = A^ dscore (the score layer's propagate; symmetric adjacency)
+  for (int j = tid; j < n; j += PG_THREADS) {
+    const int r = g0 + j;
+    const int e1 = a.rowend ? a.rowend[r] : a.rowptr[r + 1];
+    float acc = 0.f;
+#pragma unroll 8
+    for (int e = a.rowptr[r]; e < e1; ++e) {
+      const int c = a.col[e];
+      if ((unsigned)(c - g0) < (unsigned)n) acc = fmaf(a.dinv[c], ds[c - g0], acc);
+    }
+    dt[j] = fmaf(a.dinv[r], acc, a.self_w[r] * ds[j]);
+  }
+  __syncthreads();
+  // (C) du = (du + dt w_s) [y > 0]; partial sums of dw_s = sum dt relu(y)
+  const float4 w = live ? ld4(a.w_s + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int j = grp; j < n; j += NG) {
+    const int r = g0 + j;
+    const float t = dt[j];
+    if (live) {
+      const float4 v = ld4(a.y + (int64_t)r * a.ldy + co);
+      float4 d = ld4(a.du + (int64_t)r * a.lddu + co);
+      d.x = v.x > 0.f ? fmaf(t, w.x, d.x) : 0.f;
+      d.y = v.y > 0.f ? fmaf(t, w.y, d.y) : 0.f;
+      d.z = v.z > 0.f ? fmaf(t, w.z, d.z) : 0.f;
+      d.w = v.w > 0.f ? fmaf(t, w.w, d.w) : 0.f;
+      *reinterpret_cast<float4*>(a.du + (int64_t)r * a.lddu + co) = d;
+      fma4(acc, t, relu4(v));
+    }
+  }
+  if (live) *reinterpret_cast<float4*>(racc + grp * F + co) = acc;
+  __syncthreads();
+  // (D) this graph's partial sums, groups in order
+  for (int f = tid; f < F; f += PG_THREADS) {
+    float sum = 0.f;
+    for (int q = 0; q < NG; ++q) sum += racc[q * F + f];
+    a.part[(int64_t)b * (F + 4) + f] = sum;
+  }
+  if (tid == 0) {
+    float sum = 0.f;
+    for (int j = 0; j < n; ++j) sum += ds[j];
+    a.part[(int64_t)b * (F + 4) + F] = sum;
+  }
+}
+
 // single-launch scan of a short array (the per-row counts of one pooled level)
 __global__ __launch_bounds__(1024) void scan_short_kernel(const int* __restrict__ in, int n, int* __restrict__ out) {
   __shared__ int wsum[16];
@@ -889,6 +989,41 @@ int tsgnn_sag_pool_bwd_f32(const float* y, int64_t ldy, const float* score, cons
   SAG_DISPATCH(F, (sag_pool_bwd<G><<<(unsigned)ceil_div64(N, 256 / G), 256, 0, stream>>>(y, ldy, score, new_id, row_graph_new,
                                                                                          graph_ptr_new, arg, dxp, lddxp, dread, lddr, N,
                                                                                          F, relu_in, dyb, lddy, dscore)));
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+int tsgnn_sag_pool_graph_bwd_f32(const float* y, int64_t ldy, const float* score, const int* new_id, const int* graph_ptr,
+                                 const int* graph_ptr_new, const int* arg, const float* dxp, int64_t lddxp, const float* dread,
+                                 int64_t lddr, const int* rowptr, const int* rowend, const int* col, const float* dinv,
+                                 const float* self_w, const float* w_s, int B, int max_seg, int F, float* du, int64_t lddu, float* part,
+                                 float* dws, float* dbs, tsgnn_stream_t stream) {
+  if (!y || !score || !new_id || !graph_ptr || !graph_ptr_new || !arg || !dread || !rowptr || !dinv || !self_w || !w_s || !du || !part ||
+      !dws || !dbs || B <= 0 || max_seg < 0)
+    return TSGNN_EINVAL;
+  if (!tsgnn_sag_supported(F) || max_seg > PG_MAX_NODES || ldy % 4 || lddu % 4 || lddr % 4 || (dxp && (lddxp % 4 || !aligned16(dxp))) ||
+      !aligned16(y) || !aligned16(du) || !aligned16(dread) || !aligned16(arg) || !aligned16(w_s) || !aligned16(part))
+    return TSGNN_EUNSUPPORTED;
+  if (max_seg == 0) return TSGNN_OK;
+  PoolGraphBwdArgs a{y, ldy, score, new_id, graph_ptr, graph_ptr_new, arg, dxp, lddxp, dread, lddr, rowptr, rowend, col, dinv, self_w,
+                     w_s, du, lddu, part, F};
+  const int G_ = group_of(F);
+  const size_t lds = sizeof(float) * (2 * (size_t)((max_seg + 3) & ~3) + (size_t)(PG_THREADS / G_) * F);
+#define PGB_LAUNCH(GG)                                                                                                             \
+  do {                                                                                                                             \
+    if (lds > 64 * 1024)                                                                                                           \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sag_pool_graph_bwd_kernel<GG>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)lds);                                                                                         \
+    sag_pool_graph_bwd_kernel<GG><<<(unsigned)B, PG_THREADS, lds, stream>>>(a);                                                    \
+  } while (0)
+  switch (G_) {
+    case 8: PGB_LAUNCH(8); break;
+    case 16: PGB_LAUNCH(16); break;
+    case 32: PGB_LAUNCH(32); break;
+    default: PGB_LAUNCH(64); break;
+  }
+#undef PGB_LAUNCH
+  sag_du_reduce<<<1, 256, 0, stream>>>(part, B, F, dws, dbs);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }

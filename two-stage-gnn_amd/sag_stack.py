@@ -201,7 +201,7 @@ class _SagStack(torch.autograd.Function):
                     nat.call("csr_filter_fill", rowptr_t, col_t, perm, new_id, K, rp_tn, col_tn, None, None)
                 rowptr, col, rowptr_t, col_t, dinv, self_w = rp_n, col_n, rp_tn, col_tn, dinv_n, self_w_n
             xin = xp
-        ctx.plan, ctx.saved_levels, ctx.H = plan, saved, H
+        ctx.plan, ctx.saved_levels, ctx.H, ctx.sym = plan, saved, H, sym
         ctx.x_needs_grad = x.requires_grad
         return read
 
@@ -212,20 +212,31 @@ class _SagStack(torch.autograd.Function):
         dread = dread.contiguous()
         dev = dread.device
         grads = [None] * (4 * depth)
+        pool_graph_max = int(nat.lib().tsgnn_sag_pool_graph_max_nodes())
+        sym = ctx.sym
         dxp = None
         dx = None
         for l in range(depth - 1, -1, -1):
             L, Ln = plan.levels[l], plan.levels[l + 1]
             N = L.N
             xin, agg, y, score, new_id, arg, rowptr, col, rowptr_t, col_t, dinv, self_w, W, wsv, rowend = ctx.saved_levels[l]
-            dyb, dscore = _f32(N, H, device=dev), _f32(N, device=dev)
-            nat.call("sag_pool_bwd_f32", y, y.stride(0), score, new_id, Ln.row_graph, Ln.gp, arg, dxp,
-                     dxp.stride(0) if dxp is not None else 0, dread, dread.stride(0), N, H, 1, dyb, dyb.stride(0), dscore)
-            nb = int(nat.lib().tsgnn_sag_du_blocks(N, H))
-            part, dws, dbs = _f32(nb * (H + 4), device=dev), _f32(H, device=dev), _f32(1, device=dev)
-            # dt = A^T dscore: the score layer's propagate transposed
-            nat.call("sag_du_f32", rowptr_t, rowend, col_t, dinv, self_w, dscore, y, y.stride(0), wsv, dyb, dyb.stride(0), N, H, part,
-                     dws, dbs)
+            dyb = _f32(N, H, device=dev)
+            dws, dbs = _f32(H, device=dev), _f32(1, device=dev)
+            if sym and L.max_seg <= pool_graph_max and PER_GRAPH_POOL:
+                # pooled-row gradients -> score-layer backward -> du: one workgroup per graph, then the partial-sum reduction
+                part = _f32(L.B * (H + 4), device=dev)
+                nat.call("sag_pool_graph_bwd_f32", y, y.stride(0), score, new_id, L.gp, Ln.gp, arg, dxp,
+                         dxp.stride(0) if dxp is not None else 0, dread, dread.stride(0), rowptr, rowend, col, dinv, self_w, wsv,
+                         L.B, L.max_seg, H, dyb, dyb.stride(0), part, dws, dbs)
+            else:
+                dscore = _f32(N, device=dev)
+                nat.call("sag_pool_bwd_f32", y, y.stride(0), score, new_id, Ln.row_graph, Ln.gp, arg, dxp,
+                         dxp.stride(0) if dxp is not None else 0, dread, dread.stride(0), N, H, 1, dyb, dyb.stride(0), dscore)
+                nb = int(nat.lib().tsgnn_sag_du_blocks(N, H))
+                part = _f32(nb * (H + 4), device=dev)
+                # dt = A^T dscore: the score layer's propagate transposed
+                nat.call("sag_du_f32", rowptr_t, rowend, col_t, dinv, self_w, dscore, y, y.stride(0), wsv, dyb, dyb.stride(0), N, H, part,
+                         dws, dbs)
             dW, db = mp.linear_wgrad(agg, agg.size(1), dyb, True)
             grads[4 * l: 4 * l + 4] = [dW, db, dws.view(-1, 1), dbs]
             if l > 0 or ctx.x_needs_grad:
