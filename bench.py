@@ -218,7 +218,7 @@ def main():
     init_state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     hb = synthetic.host_batch(seed=rank, B=a.batch, shape=a.shape, nmax=a.nmax)      # per-rank batch (weak scaling)
     g, x, label = synthetic.to_device(hb, dev)
-    trainer = FlatTrainer(model, lr=1e-3, clip=2.0)
+    trainer = FlatTrainer(model, lr=1e-3, clip=2.0, defer_loss=True)     # the loss value is written by the head's backward kernel
     trainer.always_reduce = multi
 
     use_graph = not a.no_graph

@@ -470,6 +470,11 @@ int tsgnn_readout_head_fwd_f32(const unsigned long long* packed, int B, int L, i
 int tsgnn_head2_bwd_f32(const float* out, int64_t ldo, const float* vec, const float* dy, const float* dvec, const float* w1,
                         const float* w2, int B, int P, int E, int C, float* dout, int64_t lddo, float* dw1, float* db1,
                         float* dw2, float* db2, float* normparts, tsgnn_stream_t stream);
+/* the same with F.cross_entropy (encoders.py:221-224) folded in: the gradient of mean softmax cross-entropy of the logits
+ * y[B, C] w.r.t. them is rebuilt inside the kernel (B * C values per block in LDS) and the loss value is written to loss[0] */
+int tsgnn_head2_bwd_ce_f32(const float* out, int64_t ldo, const float* vec, const float* y, const int64_t* label, float* loss,
+                           const float* dvec, const float* w1, const float* w2, int B, int P, int E, int C, float* dout, int64_t lddo,
+                           float* dw1, float* db1, float* dw2, float* db2, float* normparts, tsgnn_stream_t stream);
 
 #ifdef __cplusplus
 }

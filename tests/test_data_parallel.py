@@ -317,3 +317,31 @@ def test_graphed_step_replays_the_eager_step():
     assert out[0][1] == out[1][1] == 5.0                       # 2 warm-up + 3 steps
     torch.testing.assert_close(out[1][0], out[0][0], rtol=0, atol=0)
     assert out[0][2] == out[1][2]
+
+
+@pytest.mark.gpu
+def test_deferred_loss_equals_ordinary_step():
+    """FlatTrainer(defer_loss=True): the cross-entropy launches nothing, the head's backward kernel rebuilds its gradient and
+    writes the loss value — same loss and same parameters after the step as the ordinary sequence (bitwise)"""
+    sys.path.insert(0, ROOT)
+    from two_stage_gnn_amd import dense_encoders as E, synthetic
+    from two_stage_gnn_amd.data_parallel import FlatTrainer
+
+    class A:
+        bias = True
+    dev = torch.device("cuda")
+    hb = synthetic.host_batch(seed=5, B=12, shape="DD", nmax=400)
+    g, x, label = synthetic.to_device(hb, dev)
+    outs = []
+    for defer in (False, True):
+        torch.manual_seed(3)
+        m = E.GcnEncoderGraph(89, 128, 128, 2, 3, bn=True, args=A(), final_dim="number_classes").to(dev)
+        tr = FlatTrainer(m, lr=1e-2, clip=2.0, defer_loss=defer)
+        losses = []
+        for _ in range(3):
+            loss = tr.step(lambda: m.loss(m(x, g)[1], label))
+            losses.append(float(loss.detach()))
+        outs.append((losses, tr.flat_param.clone()))
+    assert outs[0][0] == outs[1][0]
+    torch.testing.assert_close(outs[0][1], outs[1][1], rtol=0, atol=0)
+    assert all(0.01 < v < 10.0 for v in outs[1][0])   # real cross-entropy values, not an unwritten buffer

@@ -258,13 +258,42 @@ __device__ __forceinline__ void head2_bwd_weights(float* smem /* [B][4] dvt slic
   }
 }
 
+// ce_label != NULL: dy is not an input — it is the gradient of mean softmax cross-entropy of the logits ce_y[B, C] w.r.t. them
+// (F.cross_entropy, encoders.py:221-224), rebuilt by every block in LDS (B * C values) instead of being produced by a launch
+// of its own between the forward and this kernel; block 0 also writes the loss value.
 __global__ __launch_bounds__(64 * HW) void head2_bwd_kernel(const float* __restrict__ out, int64_t ldo, const float* __restrict__ vec,
                                                         const float* __restrict__ dy, const float* __restrict__ dvec,
                                                         const float* __restrict__ w1, const float* __restrict__ w2, int B, int P, int E,
                                                         int C, float* __restrict__ dout, int64_t lddo, float* __restrict__ dw1,
                                                         float* __restrict__ db1, float* __restrict__ dw2, float* __restrict__ db2,
-                                                        float* __restrict__ normparts) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+                                                        float* __restrict__ normparts, const float* __restrict__ ce_y,
+                                                        const int64_t* __restrict__ ce_label, float* __restrict__ ce_loss) {
+  extern __shared__ __attribute__((aligned(16))) float smem_all[];
+  float* smem = smem_all;
+  if (ce_label != nullptr) {
+    float* dyl = smem_all;                               // [B * C]
+    float* lb = smem_all + ((B * C + 3) & ~3);           // [B] per-graph loss terms
+    smem = lb + ((B + 3) & ~3);
+    const float invB = 1.f / (float)B;
+    for (int b = threadIdx.x; b < B; b += 64 * HW) {
+      const float* row = ce_y + (int64_t)b * C;
+      float m = -INFINITY;
+      for (int c = 0; c < C; ++c) m = fmaxf(m, row[c]);
+      float d = 0.f;
+      for (int c = 0; c < C; ++c) d += expf(row[c] - m);
+      const int yb = (int)ce_label[b];
+      const float logz = m + logf(d);
+      lb[b] = logz - row[yb];
+      for (int c = 0; c < C; ++c) dyl[b * C + c] = (expf(row[c] - logz) - (c == yb ? 1.f : 0.f)) * invB;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      float t = 0.f;
+      for (int b = 0; b < B; ++b) t += lb[b];            // graph order: reproducible
+      ce_loss[0] = t * invB;
+    }
+    dy = dyl;
+  }
   if ((int)blockIdx.x < B) head2_bwd_rows(smem, blockIdx.x, dy, dvec, w1, w2, P, E, C, dout, lddo);
   else head2_bwd_weights(smem, (int)blockIdx.x - B, out, ldo, vec, dy, dvec, w2, B, P, E, C, dw1, db1, dw2, db2, normparts);
 }
@@ -301,17 +330,37 @@ int tsgnn_readout_head_fwd_f32(const unsigned long long* packed, int B, int L, i
   return TSGNN_OK;
 }
 
-int tsgnn_head2_bwd_f32(const float* out, int64_t ldo, const float* vec, const float* dy, const float* dvec, const float* w1,
-                        const float* w2, int B, int P, int E, int C, float* dout, int64_t lddo, float* dw1, float* db1,
-                        float* dw2, float* db2, float* normparts, tsgnn_stream_t stream) {
-  if (!out || !vec || !dy || !w1 || !w2 || !dout || !dw1 || !dw2 || B <= 0 || P <= 0 || E <= 0 || C <= 0) return TSGNN_EINVAL;
+static int head2_bwd_launch(const float* out, int64_t ldo, const float* vec, const float* dy, const float* dvec, const float* w1,
+                            const float* w2, int B, int P, int E, int C, float* dout, int64_t lddo, float* dw1, float* db1,
+                            float* dw2, float* db2, float* normparts, const float* ce_y, const int64_t* ce_label, float* ce_loss,
+                            tsgnn_stream_t stream) {
+  if (!out || !vec || (!dy && !ce_label) || !w1 || !w2 || !dout || !dw1 || !dw2 || B <= 0 || P <= 0 || E <= 0 || C <= 0) return TSGNN_EINVAL;
+  if (ce_label && (!ce_y || !ce_loss)) return TSGNN_EINVAL;
   if ((P % 4) || P > 2048 || E > 4096 || B > 1024 || (reinterpret_cast<uintptr_t>(w1) & 15)) return TSGNN_EUNSUPPORTED;
   size_t lds = sizeof(float) * (size_t)(((E + 3) & ~3) + HW * ((P + 3) & ~3));
   if (lds < sizeof(float) * (4 * (size_t)B + HW)) lds = sizeof(float) * (4 * (size_t)B + HW);
+  if (ce_label) lds += sizeof(float) * (size_t)(((B * C + 3) & ~3) + ((B + 3) & ~3));
   head2_bwd_kernel<<<B + (E + 3) / 4 + 1, 64 * HW, lds, stream>>>(out, ldo, vec, dy, dvec, w1, w2, B, P, E, C, dout, lddo, dw1, db1, dw2,
-                                                                db2, normparts);
+                                                                db2, normparts, ce_y, ce_label, ce_loss);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
+}
+
+int tsgnn_head2_bwd_f32(const float* out, int64_t ldo, const float* vec, const float* dy, const float* dvec, const float* w1,
+                        const float* w2, int B, int P, int E, int C, float* dout, int64_t lddo, float* dw1, float* db1,
+                        float* dw2, float* db2, float* normparts, tsgnn_stream_t stream) {
+  return head2_bwd_launch(out, ldo, vec, dy, dvec, w1, w2, B, P, E, C, dout, lddo, dw1, db1, dw2, db2, normparts, nullptr, nullptr,
+                          nullptr, stream);
+}
+
+/* the same with the loss folded in: dy = d mean-softmax-cross-entropy(y, label) / dy is rebuilt inside the kernel and the loss
+ * value written to loss[0] (F.cross_entropy of encoders.py:221-224 without a launch of its own) */
+int tsgnn_head2_bwd_ce_f32(const float* out, int64_t ldo, const float* vec, const float* y, const int64_t* label, float* loss,
+                           const float* dvec, const float* w1, const float* w2, int B, int P, int E, int C, float* dout, int64_t lddo,
+                           float* dw1, float* db1, float* dw2, float* db2, float* normparts, tsgnn_stream_t stream) {
+  if (!y || !label || !loss) return TSGNN_EINVAL;
+  return head2_bwd_launch(out, ldo, vec, nullptr, dvec, w1, w2, B, P, E, C, dout, lddo, dw1, db1, dw2, db2, normparts, y, label, loss,
+                          stream);
 }
 
 }  // extern "C"

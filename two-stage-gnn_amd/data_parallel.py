@@ -19,8 +19,13 @@ class FlatTrainer:
     """Owns flat parameter / gradient / Adam-moment buffers; model parameters become views of the flat
     parameter buffer, so the HIP optimiser kernel updates the model in place."""
 
-    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip=2.0, group=None, direct_grads=True):
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip=2.0, group=None, direct_grads=True,
+                 defer_loss=False):
         self.model = model
+        # defer_loss: a cross-entropy computed between zero_grad() and backward() on the fused stack's logits launches nothing;
+        # the head's backward kernel rebuilds its gradient and fills in the loss value (one launch less per step).  The loss
+        # tensor then holds its value only after backward() — what step() / GraphedStep return.
+        self.defer_loss = bool(defer_loss)
         self.params = [p for p in model.parameters() if p.requires_grad]
         dev = self.params[0].device
         # every parameter starts on a 16-byte boundary of the flat buffer (the float4 / MFMA kernels read weights with 16-byte
@@ -68,6 +73,7 @@ class FlatTrainer:
         for p in self.params:
             p.grad = None
         self._norm_ready = False
+        mp.CE_DEFER = self.defer_loss and self.on_gpu
         if self.sink is not None:
             self.sink.written.clear()
             self.sink.reset_norm()
@@ -82,6 +88,7 @@ class FlatTrainer:
         """per-parameter gradients -> the flat bucket: nothing to do for slices the backward nodes wrote in place; one
         concatenation kernel when none were; a copy / clear per remaining parameter otherwise."""
         written = ()
+        mp.CE_DEFER = False
         if self.sink is not None:
             mp.GRAD_SINK = None
             written = self.sink.written

@@ -665,14 +665,27 @@ def unit_seed(device):
 
 
 # ----------------------------------------------------------------------------- loss
+CE_DEFER = False        # set by FlatTrainer(defer_loss=True) between zero_grad() and the backward: see _SoftmaxCE
+_deferred_ce = None     # (placeholder gradient, logits, label, loss) handed from _SoftmaxCE.backward to the head node's backward
+
+
 class _SoftmaxCE(torch.autograd.Function):
-    """F.cross_entropy(pred, label) (encoders.py:221-224) with the logits gradient produced in the same launch."""
+    """F.cross_entropy(pred, label) (encoders.py:221-224) with the logits gradient produced in the same launch.
+
+    Deferred mode (trainer option, logits produced by the fused stack + head node): the forward launches nothing and the head's
+    backward kernel rebuilds the logits gradient itself and writes the loss value (tsgnn_head2_bwd_ce_f32) — one launch less
+    per step; the returned loss tensor holds its value once the backward has run."""
 
     @staticmethod
-    def forward(ctx, logits, label):
-        logits = logits.contiguous().float()
+    def forward(ctx, logits, label, defer=False):
         B, C = logits.shape
+        ctx.deferred = bool(defer and logits.is_contiguous() and logits.dtype == torch.float32)
         loss = _f32(1, device=logits.device)
+        if ctx.deferred:
+            ctx.loss = loss
+            ctx.save_for_backward(logits, label.contiguous())
+            return loss[0]
+        logits = logits.contiguous().float()
         dlogits = _f32(B, C, device=logits.device)
         nat.call("softmax_ce_f32", logits, logits.stride(0), label.contiguous(), B, C, loss, dlogits)
         ctx.save_for_backward(dlogits)
@@ -680,15 +693,36 @@ class _SoftmaxCE(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        global _deferred_ce
+        if ctx.deferred:
+            logits, label = ctx.saved_tensors
+            if g is _unit.get(g.device):
+                ph = torch.empty_like(logits)               # never read: the head's backward recognises it and takes over
+                _deferred_ce = (ph, logits, label, ctx.loss)
+                return ph, None, None
+            B, C = logits.shape                             # arbitrary upstream gradient: the ordinary kernel, late
+            dlogits = _f32(B, C, device=logits.device)
+            nat.call("softmax_ce_f32", logits, logits.stride(0), label, B, C, ctx.loss, dlogits)
+            return dlogits * g, None, None
         (dlogits,) = ctx.saved_tensors
         if g is _unit.get(g.device):                        # seeded with unit_seed(): d loss = 1 by construction
-            return dlogits, None
-        return dlogits * g, None
+            return dlogits, None, None
+        return dlogits * g, None, None
+
+
+def take_deferred_ce(dy):
+    """(logits, label, loss) if dy is the placeholder a deferred cross-entropy left for the head's backward, else None"""
+    global _deferred_ce
+    d = _deferred_ce
+    if d is not None and dy is d[0]:
+        _deferred_ce = None
+        return d[1], d[2], d[3]
+    return None
 
 
 def cross_entropy(logits, label):
     if logits.is_cuda and label.dtype == torch.int64:
-        return _SoftmaxCE.apply(logits, label)
+        return _SoftmaxCE.apply(logits, label, bool(CE_DEFER and getattr(logits, "_tsgnn_defer_ce", False)))
     return torch.nn.functional.cross_entropy(logits, label, reduction="mean")
 
 

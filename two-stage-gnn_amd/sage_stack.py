@@ -218,7 +218,9 @@ class _SageStack(torch.autograd.Function):
             P, E, C = out.size(1), w1c.size(0), w2c.size(0)
             if dy is None and dvec is None:
                 return (None,) * (5 + 2 * L + 4)
-            dy = dy.contiguous() if dy is not None else torch.zeros(B, C, device=dev)
+            ce = mp.take_deferred_ce(dy) if dy is not None else None      # deferred cross-entropy: this backward rebuilds dy
+            if ce is None:
+                dy = dy.contiguous() if dy is not None else torch.zeros(B, C, device=dev)
             dvec = dvec.contiguous() if dvec is not None else None
             dout = torch.empty(B, P, dtype=torch.float32, device=dev)
             dw1, s1 = mp._sink_or_new(pw1, (E, P), dev)
@@ -226,8 +228,12 @@ class _SageStack(torch.autograd.Function):
             db1, s3 = mp._sink_or_new(pb1, (E,), dev) if pb1 is not None else (None, False)
             db2, s4 = mp._sink_or_new(pb2, (C,), dev) if pb2 is not None else (None, False)
             parts = mp.head_norm_slots((s1, s2, s3, s4), (pb1 is not None, pb2 is not None), (pw1, pb1, pw2, pb2), E)
-            nat.call("head2_bwd_f32", out, out.stride(0), vec, dy, dvec, w1c, w2c, B, P, E, C, dout, dout.stride(0), dw1, db1, dw2, db2,
-                     parts)
+            if ce is not None:
+                nat.call("head2_bwd_ce_f32", out, out.stride(0), vec, ce[0], ce[1], ce[2], dvec, w1c, w2c, B, P, E, C, dout,
+                         dout.stride(0), dw1, db1, dw2, db2, parts)
+            else:
+                nat.call("head2_bwd_f32", out, out.stride(0), vec, dy, dvec, w1c, w2c, B, P, E, C, dout, dout.stride(0), dw1, db1, dw2,
+                         db2, parts)
             head_grads = (None if s1 else dw1, None if s3 else db1, None if s2 else dw2, None if s4 else db2)
         sn, sg = ctx.slots
         grads = [None] * (2 * L)
@@ -369,4 +375,6 @@ def sage_stack_head(x, g, convs, lin1, lin2):
     for c in convs:
         params.append(c.weight)
         params.append(c.bias if has_bias else c.weight.new_zeros(1))
-    return _SageStack.apply(x, g, has_bias, 4, 0, *params, lin1.weight, lin1.bias, lin2.weight, lin2.bias)
+    vec, y = _SageStack.apply(x, g, has_bias, 4, 0, *params, lin1.weight, lin1.bias, lin2.weight, lin2.bias)
+    y._tsgnn_defer_ce = True          # a cross-entropy on these logits may be folded into this node's backward (mp._SoftmaxCE)
+    return vec, y
