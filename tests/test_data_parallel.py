@@ -344,4 +344,4 @@ def test_deferred_loss_equals_ordinary_step():
         outs.append((losses, tr.flat_param.clone()))
     assert outs[0][0] == outs[1][0]
     torch.testing.assert_close(outs[0][1], outs[1][1], rtol=0, atol=0)
-    assert all(0.01 < v < 10.0 for v in outs[1][0])   # real cross-entropy values, not an unwritten buffer
+    assert all(np.isfinite(v) and v > 0.0 for v in outs[1][0]) and len(set(outs[1][0])) == 3    # written, and changing step to step
