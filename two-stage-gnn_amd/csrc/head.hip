@@ -275,7 +275,9 @@ __global__ __launch_bounds__(64 * HW) void head2_bwd_kernel(const float* __restr
     float* lb = smem_all + ((B * C + 3) & ~3);           // [B] per-graph loss terms
     smem = lb + ((B + 3) & ~3);
     const float invB = 1.f / (float)B;
-    for (int b = threadIdx.x; b < B; b += 64 * HW) {
+    // weight blocks (and block 0, which also writes the loss) need every row's gradient, a row block only its own
+    const bool all_rows = (int)blockIdx.x >= B || blockIdx.x == 0;
+    for (int b = all_rows ? (int)threadIdx.x : (int)blockIdx.x + (int)threadIdx.x * B; b < B; b += 64 * HW) {
       const float* row = ce_y + (int64_t)b * C;
       float m = -INFINITY;
       for (int c = 0; c < C; ++c) m = fmaxf(m, row[c]);
