@@ -1,15 +1,15 @@
 // Graph-level head of the SAGPool model (Code/sag/network.py:25-27,48-53):
 //     x = relu(lin1(x)); x = dropout(x); x = relu(lin2(x)); x = log_softmax(lin3(x))
-// forward and backward in 1 + 1 launches instead of ~25 library launches (3 addmm + 6 mm + bias reductions + the
+// forward and backward in 1 + 2 launches instead of ~25 library launches (3 addmm + 6 mm + bias reductions + the
 // element-wise passes between them), for the small row counts of a graph-level head (B = graphs per batch).
 // The dropout keep-mask (0 / 1 per element, scaled by keep_scale = 1/(1-p) here) is an input: the random stream stays the
 // framework's own.
 //   forward : one workgroup per graph row; weights streamed from L2 with 16-byte loads, a wave owns eight output
 //             rows at a time and reduces their dot products with DPP.
-//   backward: ONE launch of four block kinds, each recomputing the tiny upstream chain it needs
-//             (dlogits -> dz2 [B, D2] in LDS) instead of exchanging it through HBM with another launch:
-//               [dW1 tile ‖ dW2 tile ‖ dW3 ‖ dX rows]
-//             weight gradients are plain sums over the B rows in row order (no atomics, reproducible).
+//   backward: a rows kernel (dlogits -> dz2 -> dz1 -> dX once per row) and a weights kernel ([dW1 tile ‖ dW2 tile ‖ dW3] blocks
+//             summing over the rows with 16-byte loads) — tsgnn_mlp3_bwd2_f32, 14 us; the single-launch variant
+//             (tsgnn_mlp3_bwd_f32: four block kinds, each recomputing dlogits -> dz2 in LDS) is kept for comparison, 21 us.
+//             Weight gradients are plain sums over the B rows in a fixed order (no atomics, reproducible).
 #include "common.h"
 #include "../../include/tsgnn.h"
 

@@ -9,12 +9,16 @@ PyG's ``topk`` / ``filter_adj`` (layers.py:20-24) return tensors whose sizes dep
 A step is therefore capturable in a hipGraph.  Per level (csrc/sagpool.hip):
   forward   agg = A^ x            (gcn_propagate; A^ = D^-1/2 (A+I) D^-1/2 from per-row coefficients)
             y   = agg W + b       (fp32 MFMA row-panel product; (A^ x) W = A^ (x W), GCNConv network.py:34)
-            s   = (A^ relu(y)) w_s + b_s   (score layer GCNConv(C -> 1), layers.py:18, without its [N,1] intermediate)
-            perm, new_id = topk(s)         (one workgroup per graph, LDS bitonic sort)
-            xp  = relu(y)[perm] * tanh(s[perm]) ; cnt = kept neighbours      (layers.py:21)
-            out += [max || mean](xp)       (network.py:36,40,44 and the sum :46)
-            A'  = filter(A)                (scan of cnt + fill; also the next level's coefficients)
-  backward  pool_bwd -> du (score layer folded in) -> dW, db in one pass -> dagg = du W^T -> dx = A^ dagg
+            one workgroup per graph (tsgnn_sag_pool_graph_f32, graphs <= 4,096 nodes; everything below touches one graph):
+              s   = A^ (relu(y) w_s) + b_s      (score layer GCNConv(C -> 1), layers.py:18)
+              perm, new_id = topk(s)            (rank count / LDS bitonic sort, ties -> smaller node id)
+              xp  = relu(y)[perm] * tanh(s[perm])                              (layers.py:21)
+              out += [max || mean](xp)          (network.py:36,40,44 and the sum :46)
+              A'  = filter(A)                   (symmetric graphs: entries from the graph's old segment base, explicit row
+                                                 ends, next level's coefficients; layers.py:23-24)
+            (larger graphs / directed edge lists: the same steps as separate launches + scan + tsgnn_csr_filter_fill)
+  backward  one workgroup per graph: pooled-row gradients -> score layer backward -> du ; reduction of dw_s / db_s partials ;
+            dW, db in one pass ; dagg = du W^T ; dx = A^ dagg
 ReLU is applied by the consumers of ``y`` (it is stored pre-activation), so no activation tensor is written.
 """
 import numpy as np
@@ -31,7 +35,7 @@ def _i32(*shape, device):
 
 
 class _Level:
-    __slots__ = ("B", "N", "sizes", "gp", "row_graph", "max_seg", "batch_vec")
+    __slots__ = ("B", "N", "sizes", "gp", "row_graph", "max_seg")
 
 
 class SagPlan:
@@ -54,7 +58,6 @@ class SagPlan:
             np.cumsum(sizes, out=gp[1:])
             L.gp = torch.from_numpy(gp).to(device)
             L.row_graph = torch.from_numpy(np.repeat(np.arange(L.B, dtype=np.int32), sizes)).to(device)
-            L.batch_vec = None
             self.levels.append(L)
             k = np.ceil(np.float32(ratio) * sizes.astype(np.float32)).astype(np.int64)      # float32, as PyG's topk computes it
             sizes = np.minimum(k, sizes)
