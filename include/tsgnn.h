@@ -313,6 +313,12 @@ int tsgnn_mlp3_bwd2_f32(const float* x, int64_t ldx, const float* w1, const floa
                         const float* a2, const float* logp, const float* dlogp, float keep_scale, int B, int D0, int D1, int D2, int C,
                         float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3, float* dx, int64_t lddx, float* ws,
                         tsgnn_stream_t stream);
+/* the same with F.nll_loss(logp, label) (mean; Code/sag/train.py) folded in: dlogits = (softmax - onehot) / B is formed inside
+ * the rows kernel and the loss value is written to loss[0] by the weights kernel */
+int tsgnn_mlp3_bwd2_nll_f32(const float* x, int64_t ldx, const float* w1, const float* w2, const float* w3, const float* a1,
+                            const float* a2, const float* logp, const int64_t* label, float* loss, float keep_scale, int B, int D0,
+                            int D1, int D2, int C, float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3, float* dx,
+                            int64_t lddx, float* ws, tsgnn_stream_t stream);
 
 /* ---------------------------------------------------------------- DiffPool link-prediction side loss (linkpred.hip) */
 

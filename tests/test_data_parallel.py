@@ -345,3 +345,44 @@ def test_deferred_loss_equals_ordinary_step():
     assert outs[0][0] == outs[1][0]
     torch.testing.assert_close(outs[0][1], outs[1][1], rtol=0, atol=0)
     assert all(np.isfinite(v) and v > 0.0 for v in outs[1][0]) and len(set(outs[1][0])) == 3    # written, and changing step to step
+
+
+@pytest.mark.gpu
+def test_deferred_nll_equals_ordinary_sagpool_step():
+    """SAGPool Net under FlatTrainer(defer_loss=True) with mp.nll_loss: the head's backward forms the nll gradient and writes
+    the loss — same losses and parameters as torch's nll_loss through autograd (dropout off: identical random state)"""
+    sys.path.insert(0, ROOT)
+    from two_stage_gnn_amd import sag_layers as S, message_passing as mp
+    from two_stage_gnn_amd.data_parallel import FlatTrainer
+    dev = torch.device("cuda")
+    sizes = [20, 12, 31, 20, 9, 25, 14, 40]
+    n = sum(sizes)
+    gen = torch.Generator().manual_seed(9)
+    src, dst, off = [], [], 0
+    for nb in sizes:
+        e = torch.randint(0, nb, (2, 3 * nb), generator=gen)
+        e = e[:, e[0] != e[1]] + off
+        src += [e[0], e[1]]; dst += [e[1], e[0]]
+        off += nb
+    code = torch.unique(torch.cat(src) * n + torch.cat(dst))
+    ei = torch.stack([code // n, code % n]).to(dev)
+
+    class D:
+        pass
+    d = D()
+    d.x, d.edge_index = torch.randn(n, 4, generator=gen).to(dev), ei
+    d.batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes)).to(dev)
+    label = (torch.arange(len(sizes)) % 2).to(dev)
+    outs = []
+    for defer in (False, True):
+        torch.manual_seed(11)
+        net = S.Net(4, 64, 2, 0.5, 0.0, use_batch=True).to(dev).train()
+        tr = FlatTrainer(net, lr=1e-2, clip=2.0, defer_loss=defer)
+        losses = []
+        for _ in range(3):
+            loss = tr.step(lambda: mp.nll_loss(net(d), label))
+            losses.append(float(loss.detach()))
+        outs.append((losses, tr.flat_param.clone()))
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=1e-6)
+    torch.testing.assert_close(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-7)
+    assert all(np.isfinite(v) and v > 0.0 for v in outs[1][0]) and len(set(outs[1][0])) == 3

@@ -266,8 +266,10 @@ __global__ __launch_bounds__(256) void mlp3_bwd_kernel(Mlp3Bwd p) {
 // The single launch above makes every weight tile recompute dz2 for all rows behind a chain of dependent phases at one wave per
 // SIMD; two short kernels with the chain done once are faster (measured 21 -> ~9 us for B = 128, 256 -> 128 -> 64 -> 2).
 constexpr int MR_T = 256;
+// nll_label != NULL: dlogp is not an input — it is the gradient of F.nll_loss(logp, label) (mean; Code/sag/train.py) and
+// dlogits = (softmax - onehot) / B is formed directly; the weights kernel's last block then also writes the loss value.
 __global__ __launch_bounds__(MR_T) void mlp3_bwd_rows_kernel(Mlp3Bwd p, float* __restrict__ dlgg, float* __restrict__ dz2g,
-                                                           float* __restrict__ dz1g) {
+                                                           float* __restrict__ dz1g, const int64_t* __restrict__ nll_label) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int D0 = p.D0, D1 = p.D1, D2 = p.D2, C = p.C;
@@ -275,9 +277,14 @@ __global__ __launch_bounds__(MR_T) void mlp3_bwd_rows_kernel(Mlp3Bwd p, float* _
   float* dz2 = dlg + ((C + 3) & ~3);         // [D2]
   float* dz1 = dz2 + ((D2 + 3) & ~3);        // [D1]
   if (tid < C) {
-    float s = 0.f;
-    for (int c = 0; c < C; ++c) s += p.dlogp[(int64_t)b * C + c];
-    const float v = p.dlogp[(int64_t)b * C + tid] - expf(p.logp[(int64_t)b * C + tid]) * s;
+    float v;
+    if (nll_label != nullptr) {
+      v = (expf(p.logp[(int64_t)b * C + tid]) - (tid == (int)nll_label[b] ? 1.f : 0.f)) / (float)p.B;
+    } else {
+      float s = 0.f;
+      for (int c = 0; c < C; ++c) s += p.dlogp[(int64_t)b * C + c];
+      v = p.dlogp[(int64_t)b * C + tid] - expf(p.logp[(int64_t)b * C + tid]) * s;
+    }
     dlg[tid] = v;
     dlgg[(int64_t)b * C + tid] = v;
   }
@@ -310,7 +317,8 @@ __global__ __launch_bounds__(MR_T) void mlp3_bwd_rows_kernel(Mlp3Bwd p, float* _
 
 constexpr int MW_TILE = 4;                   // weight rows per block
 __global__ __launch_bounds__(256) void mlp3_bwd_weights_kernel(Mlp3Bwd p, const float* __restrict__ dlgg, const float* __restrict__ dz2g,
-                                                              const float* __restrict__ dz1g, int nW1, int nW2) {
+                                                              const float* __restrict__ dz1g, int nW1, int nW2,
+                                                              const int64_t* __restrict__ nll_label, float* __restrict__ nll_loss) {
   extern __shared__ __attribute__((aligned(16))) float smem[];      // [B][MW_TILE] operand tile
   const int tid = threadIdx.x, bid = blockIdx.x;
   const int B = p.B, D0 = p.D0, D1 = p.D1, D2 = p.D2, C = p.C;
@@ -425,6 +433,18 @@ __global__ __launch_bounds__(256) void mlp3_bwd_weights_kernel(Mlp3Bwd p, const 
       p.db3[tid] = t;
     }
   }
+  if (nll_label != nullptr) {                                          // loss = -mean_b logp[b, label_b], 256 row lanes then in order
+    __syncthreads();
+    float s = 0.f;
+    for (int b = tid; b < B; b += 256) s -= p.logp[(int64_t)b * C + (int)nll_label[b]];
+    smem[tid] = s;
+    __syncthreads();
+    if (tid == 0) {
+      float t = 0.f;
+      for (int q = 0; q < 256; ++q) t += smem[q];
+      nll_loss[0] = t / (float)B;
+    }
+  }
 }
 
 inline size_t bwd_lds_bytes(int B, int D1, int D2, int C) {
@@ -480,12 +500,12 @@ int tsgnn_mlp3_bwd_f32(const float* x, int64_t ldx, const float* w1, const float
 
 /* the same backward as two short launches (rows: the chain once per row; weights: tiles summing over the rows);
  * ws: B * (C + D2 + D1) floats */
-int tsgnn_mlp3_bwd2_f32(const float* x, int64_t ldx, const float* w1, const float* w2, const float* w3, const float* a1,
-                        const float* a2, const float* logp, const float* dlogp, float keep_scale, int B, int D0, int D1, int D2, int C,
-                        float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3, float* dx, int64_t lddx, float* ws,
-                        tsgnn_stream_t stream) {
-  if (!x || !w1 || !w2 || !w3 || !a1 || !a2 || !logp || !dlogp || !dw1 || !db1 || !dw2 || !db2 || !dw3 || !db3 || !ws || ldx < D0 ||
-      (dx && lddx < D0))
+static int mlp3_bwd2_launch(const float* x, int64_t ldx, const float* w1, const float* w2, const float* w3, const float* a1,
+                            const float* a2, const float* logp, const float* dlogp, float keep_scale, int B, int D0, int D1, int D2, int C,
+                            float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3, float* dx, int64_t lddx, float* ws,
+                            const int64_t* nll_label, float* nll_loss, tsgnn_stream_t stream) {
+  if (!x || !w1 || !w2 || !w3 || !a1 || !a2 || !logp || (!dlogp && !nll_label) || !dw1 || !db1 || !dw2 || !db2 || !dw3 || !db3 || !ws ||
+      ldx < D0 || (dx && lddx < D0) || (nll_label && !nll_loss))
     return TSGNN_EINVAL;
   if (!tsgnn_mlp3_supported(B, D0, D1, D2, C)) return TSGNN_EUNSUPPORTED;
   Mlp3Bwd p{x, ldx, w1, w2, w3, a1, a2, logp, dlogp, keep_scale, B, D0, D1, D2, C, dw1, db1, dw2, db2, dw3, db3, dx, lddx, 0, 0};
@@ -493,15 +513,34 @@ int tsgnn_mlp3_bwd2_f32(const float* x, int64_t ldx, const float* w1, const floa
   float* dz2g = dlgg + (size_t)B * C;
   float* dz1g = dz2g + (size_t)B * D2;
   const size_t lds_r = sizeof(float) * (size_t)(((C + 3) & ~3) + ((D2 + 3) & ~3) + D1);
-  mlp3_bwd_rows_kernel<<<(unsigned)B, MR_T, lds_r, stream>>>(p, dlgg, dz2g, dz1g);
+  mlp3_bwd_rows_kernel<<<(unsigned)B, MR_T, lds_r, stream>>>(p, dlgg, dz2g, dz1g, nll_label);
   const int nW1 = (D1 + MW_TILE - 1) / MW_TILE, nW2 = (D2 + MW_TILE - 1) / MW_TILE;
   size_t lds_w = sizeof(float) * ((size_t)((B * MW_TILE + 3) & ~3) + 4 * (size_t)MW_TILE * (D0 > D1 ? D0 : D1));
   if (lds_w < sizeof(float) * 1024 * (size_t)C) lds_w = sizeof(float) * 1024 * (size_t)C;       // dW3 block: [256 / (D2/4)][C][D2] partials
   if (lds_w > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp3_bwd_weights_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w);
-  mlp3_bwd_weights_kernel<<<(unsigned)(nW1 + nW2 + 1), 256, lds_w, stream>>>(p, dlgg, dz2g, dz1g, nW1, nW2);
+  mlp3_bwd_weights_kernel<<<(unsigned)(nW1 + nW2 + 1), 256, lds_w, stream>>>(p, dlgg, dz2g, dz1g, nW1, nW2, nll_label, nll_loss);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
+}
+
+int tsgnn_mlp3_bwd2_f32(const float* x, int64_t ldx, const float* w1, const float* w2, const float* w3, const float* a1,
+                        const float* a2, const float* logp, const float* dlogp, float keep_scale, int B, int D0, int D1, int D2, int C,
+                        float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3, float* dx, int64_t lddx, float* ws,
+                        tsgnn_stream_t stream) {
+  return mlp3_bwd2_launch(x, ldx, w1, w2, w3, a1, a2, logp, dlogp, keep_scale, B, D0, D1, D2, C, dw1, db1, dw2, db2, dw3, db3, dx, lddx,
+                          ws, nullptr, nullptr, stream);
+}
+
+/* the same with F.nll_loss(logp, label) (mean) folded in: its gradient is formed inside the rows kernel and the loss value is
+ * written to loss[0] by the weights kernel */
+int tsgnn_mlp3_bwd2_nll_f32(const float* x, int64_t ldx, const float* w1, const float* w2, const float* w3, const float* a1,
+                            const float* a2, const float* logp, const int64_t* label, float* loss, float keep_scale, int B, int D0,
+                            int D1, int D2, int C, float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3, float* dx,
+                            int64_t lddx, float* ws, tsgnn_stream_t stream) {
+  if (!label || !loss) return TSGNN_EINVAL;
+  return mlp3_bwd2_launch(x, ldx, w1, w2, w3, a1, a2, logp, nullptr, keep_scale, B, D0, D1, D2, C, dw1, db1, dw2, db2, dw3, db3, dx, lddx,
+                          ws, label, loss, stream);
 }
 
 }  // extern "C"

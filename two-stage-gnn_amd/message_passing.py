@@ -335,14 +335,20 @@ class _Mlp3LogSoftmax(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogp):
         x, w1, w2, w3, a1, a2, logp = ctx.saved_tensors
-        dlogp = dlogp.contiguous()
         dev = x.device
         B, D0, D1, D2, C = x.size(0), w1.size(1), w1.size(0), w2.size(0), w3.size(0)
         dw1, db1 = _f32(D1, D0, device=dev), _f32(D1, device=dev)
         dw2, db2 = _f32(D2, D1, device=dev), _f32(D2, device=dev)
         dw3, db3 = _f32(C, D2, device=dev), _f32(C, device=dev)
         dx = _f32(B, D0, device=dev) if ctx.needs_input_grad[0] else None
-        if MLP3_TWO_LAUNCH_BWD:
+        nll = take_deferred_nll(dlogp)                    # deferred F.nll_loss: this backward forms its gradient and the loss
+        if nll is None:
+            dlogp = dlogp.contiguous()
+        if nll is not None:
+            ws = _f32(B * (C + D2 + D1), device=dev)
+            nat.call("mlp3_bwd2_nll_f32", x, x.stride(0), w1, w2, w3, a1, a2, logp, nll[0], nll[1], ctx.keep_scale, B, D0, D1, D2, C,
+                     dw1, db1, dw2, db2, dw3, db3, dx, D0, ws)
+        elif MLP3_TWO_LAUNCH_BWD:
             ws = _f32(B * (C + D2 + D1), device=dev)
             nat.call("mlp3_bwd2_f32", x, x.stride(0), w1, w2, w3, a1, a2, logp, dlogp, ctx.keep_scale, B, D0, D1, D2, C,
                      dw1, db1, dw2, db2, dw3, db3, dx, D0, ws)
@@ -351,6 +357,52 @@ class _Mlp3LogSoftmax(torch.autograd.Function):
                      dw1, db1, dw2, db2, dw3, db3, dx, D0)
         hb = ctx.has_b
         return dx, dw1, db1 if hb[0] else None, dw2, db2 if hb[1] else None, dw3, db3 if hb[2] else None, None, None
+
+
+_deferred_nll = None
+
+
+class _NllLoss(torch.autograd.Function):
+    """F.nll_loss(logp, label) (mean) on the fused head's output.  Deferred mode (FlatTrainer(defer_loss=True)): nothing is
+    launched here; the head's backward forms dlogits = (softmax - onehot) / B itself and writes the loss value."""
+
+    @staticmethod
+    def forward(ctx, logp, label):
+        loss = _f32(1, device=logp.device)
+        ctx.loss = loss
+        ctx.save_for_backward(logp, label.contiguous())
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        global _deferred_nll
+        logp, label = ctx.saved_tensors
+        if g is _unit.get(g.device):
+            ph = torch.empty_like(logp)
+            _deferred_nll = (ph, label, ctx.loss)
+            return ph, None
+        B = logp.size(0)                                    # arbitrary upstream gradient: plain formulas, late
+        ctx.loss.copy_(-logp.gather(1, label.view(-1, 1)).mean().view(1))
+        d = torch.zeros_like(logp)
+        d.scatter_(1, label.view(-1, 1), -1.0 / B)
+        return d * g, None
+
+
+def take_deferred_nll(dlogp):
+    global _deferred_nll
+    d = _deferred_nll
+    if d is not None and dlogp is d[0]:
+        _deferred_nll = None
+        return d[1], d[2]
+    return None
+
+
+def nll_loss(logp, label):
+    """F.nll_loss(logp, label); folded into the fused head's backward when a FlatTrainer(defer_loss=True) step is running and
+    logp came from mlp3_log_softmax"""
+    if CE_DEFER and getattr(logp, "_tsgnn_defer_nll", False) and label.dtype == torch.int64 and logp.is_contiguous():
+        return _NllLoss.apply(logp, label)
+    return torch.nn.functional.nll_loss(logp, label)
 
 
 def mlp3_ok(x, lin1, lin2, lin3):
@@ -365,7 +417,9 @@ def mlp3_log_softmax(x, lin1, lin2, lin3, p=0.0, training=False):
     if training and p > 0.0:
         keep = torch.empty(x.size(0), lin1.out_features, dtype=torch.float32, device=x.device).bernoulli_(1.0 - p)
         scale = 1.0 / (1.0 - p)
-    return _Mlp3LogSoftmax.apply(x, lin1.weight, lin1.bias, lin2.weight, lin2.bias, lin3.weight, lin3.bias, keep, scale)
+    logp = _Mlp3LogSoftmax.apply(x, lin1.weight, lin1.bias, lin2.weight, lin2.bias, lin3.weight, lin3.bias, keep, scale)
+    logp._tsgnn_defer_nll = True          # mp.nll_loss on this output may be folded into the head's backward
+    return logp
 
 
 # ----------------------------------------------------------------------------- ReLU + per-slot batch norm
