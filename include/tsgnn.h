@@ -259,18 +259,22 @@ int tsgnn_edge_softmax_bwd_f32(const int* rowptr, const int* col, int64_t rows, 
 int tsgnn_edge_permute_f32(const float* src, const int* perm, int64_t n, int H, int scatter, float* dst, tsgnn_stream_t stream);
 /* out[r,h] = sum of val[e,h] over the entries of row r */
 int tsgnn_csr_row_sum_f32(const int* rowptr, const float* val, int64_t rows, int H, float* out, tsgnn_stream_t stream);
+/* the same for values stored in another entry order: entry e's value is val[eperm[e]] */
+int tsgnn_csr_row_sum_perm_f32(const int* rowptr, const float* val, const int* eperm, int64_t rows, int H, float* out,
+                               tsgnn_stream_t stream);
 /* y[r, head h] = sum_e alpha[e,h] * x[col[e], head h]   (h_prime = attention @ h, encoders_GAT.py:43) */
 int tsgnn_csr_spmm_heads_f32(const int* rowptr, const int* col, const float* alpha, int H, int Fh, const float* x, int64_t ldx,
                              int mod, float* y, int64_t ldy, int64_t rows, tsgnn_stream_t stream);
 /* the same aggregation with the element-wise passes that follow it folded into its epilogue:
  * y[r, h*Fh+f] += w1[r,h] * a1[h*lda1+f] + w2[r,h] * a2[h*lda2+f] + uscale * (uw ? uw[r,h] : 1) * u[(r / rows_per_seg)*ldu + h*Fh+f]
  * (each term optional: NULL w1 / w2 / u; row_seg (nullable) names every row's segment for ragged batches and replaces
- * r / rows_per_seg).  Forward: the uniform 1/N contribution of all-masked softmax columns
+ * r / rows_per_seg; eperm (nullable): entry e's weights are alpha[eperm[e]], i.e. alpha is stored in the entry order of the
+ * transposed structure — the column softmax produces it there — and no permuted copy is made).  Forward: the uniform 1/N contribution of all-masked softmax columns
  * (encoders_GAT.py:38-41); backward: dh = A^T-aggregation + ds_row (x) a_row + ds_col (x) a_col + iso * du / N. */
 int tsgnn_csr_spmm_heads_epi_f32(const int* rowptr, const int* col, const float* alpha, int H, int Fh, const float* x, int64_t ldx,
                                  int mod, float* y, int64_t ldy, int64_t rows, const float* w1, const float* a1, int64_t lda1,
                                  const float* w2, const float* a2, int64_t lda2, const float* u, int64_t ldu, const float* uw,
-                                 int rows_per_seg, const int* row_seg, float uscale, tsgnn_stream_t stream);
+                                 int rows_per_seg, const int* row_seg, float uscale, const int* eperm, tsgnn_stream_t stream);
 /* dalpha[e,h] = <dy[row(e), head h], x[col[e], head h]>  (sampled dense-dense product) */
 int tsgnn_csr_sddmm_heads_f32(const int* rowptr, const int* col, int H, int Fh, const float* dy, int64_t lddy, const float* x,
                               int64_t ldx, int mod, float* dalpha, int64_t rows, tsgnn_stream_t stream);

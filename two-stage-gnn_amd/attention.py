@@ -53,6 +53,17 @@ def _row_seg(g):
     return g.row_graph if getattr(g, "row_mult", None) is not None else None
 
 
+def _inverse_entry_map(g, src_e_t):
+    """inv[e] = p with src_e_t[p] = e: where A's entry e sits in A^T's entry order (cached on the graph)"""
+    inv = getattr(g, "_inv_e_t", None)
+    if inv is None:
+        n = src_e_t.numel()
+        inv = torch.empty(n, dtype=torch.int32, device=src_e_t.device)
+        inv[src_e_t.long()] = torch.arange(n, dtype=torch.int32, device=src_e_t.device)
+        g._inv_e_t = inv
+    return inv
+
+
 def _isolated_columns(g, rp_t, R, H):
     """[R, H] indicator of columns without any edge; depends on the graph only, cached on it"""
     cache = g.__dict__.setdefault("_iso_cols", {})
@@ -81,12 +92,14 @@ class _AttentionAggregate(torch.autograd.Function):
         s_row, s_col = node_scores2(h, a_row, a_col, H, Fh)
         nnz = max(g.nnz, 1)
         rp_t, col_t, src_e_t = g.transpose_map() if by_column else (None, None, None)
+        eperm = None
         if by_column:
-            # groups = columns j = rows of A^T;  alpha_G lives on A^T's entries, then is permuted onto A's
+            # groups = columns j = rows of A^T: alpha_G lives on A^T's entries and the aggregation over A's rows reads it
+            # through the entry map (no permuted copy)
             alpha_g = _f32(nnz, H, device=dev)
             nat.call("edge_softmax_fwd_f32", rp_t, col_t, R, H, s_col, s_row, 0, float(slope), alpha_g)
-            alpha = _f32(nnz, H, device=dev)
-            nat.call("edge_permute_f32", alpha_g, src_e_t, g.nnz, H, 1, alpha)
+            alpha = alpha_g
+            eperm = _inverse_entry_map(g, src_e_t)
         else:
             alpha_g = None
             alpha = _f32(nnz, H, device=dev)
@@ -100,7 +113,10 @@ class _AttentionAggregate(torch.autograd.Function):
             N = g.nmax
             u = segment_wsum(h, iso, H, Fh, g.graph_ptr, g.B, scale=1.0 / N, max_seg=int(g.sizes.max()))
             nat.call("csr_spmm_heads_epi_f32", g.rowptr, g.col, alpha, H, Fh, h, h.stride(0), 0, out, out.stride(0), R,
-                     None, None, 0, None, None, 0, u, u.stride(0), None, N, _row_seg(g), 1.0)
+                     None, None, 0, None, None, 0, u, u.stride(0), None, N, _row_seg(g), 1.0, eperm)
+        elif eperm is not None:
+            nat.call("csr_spmm_heads_epi_f32", g.rowptr, g.col, alpha, H, Fh, h, h.stride(0), 0, out, out.stride(0), R,
+                     None, None, 0, None, None, 0, None, 0, None, 1, None, 1.0, eperm)
         else:
             nat.call("csr_spmm_heads_f32", g.rowptr, g.col, alpha, H, Fh, h, h.stride(0), 0, out, out.stride(0), R)
         ctx.g, ctx.H, ctx.Fh, ctx.slope, ctx.by_column = g, H, Fh, slope, by_column
@@ -116,21 +132,21 @@ class _AttentionAggregate(torch.autograd.Function):
         dev = h.device
         nnz = max(g.nnz, 1)
         rp_t, col_t, src_e_t = g.transpose_map()
-        dalpha = _f32(nnz, H, device=dev)
-        nat.call("csr_sddmm_heads_f32", g.rowptr, g.col, H, Fh, dout, dout.stride(0), h, h.stride(0), 0, dalpha, R)
         dh = _f32(R, C, device=dev)
         ds_row = _f32(R, H, device=dev)
         ds_col = _f32(R, H, device=dev)
         if ctx.by_column:
+            # everything stays in A^T's entry order: d alpha_ij = <dout_i, h_j> computed over A^T's rows (operands swapped),
+            # the softmax backward there, and ds_row (a sum over A's rows) read through the entry map — no permuted copies
             dalpha_g = _f32(nnz, H, device=dev)
-            nat.call("edge_permute_f32", dalpha, src_e_t, g.nnz, H, 0, dalpha_g)
+            nat.call("csr_sddmm_heads_f32", rp_t, col_t, H, Fh, h, h.stride(0), dout, dout.stride(0), 0, dalpha_g, R)
             dt_g = _f32(nnz, H, device=dev)
             nat.call("edge_softmax_bwd_f32", rp_t, col_t, R, H, s_col, s_row, 0, float(slope), alpha_g, dalpha_g, dt_g, ds_col)
-            dt = _f32(nnz, H, device=dev)
-            nat.call("edge_permute_f32", dt_g, src_e_t, g.nnz, H, 1, dt)
-            nat.call("csr_row_sum_f32", g.rowptr, dt, R, H, ds_row)
+            nat.call("csr_row_sum_perm_f32", g.rowptr, dt_g, _inverse_entry_map(g, src_e_t), R, H, ds_row)
             alpha_t = alpha_g
         else:
+            dalpha = _f32(nnz, H, device=dev)
+            nat.call("csr_sddmm_heads_f32", g.rowptr, g.col, H, Fh, dout, dout.stride(0), h, h.stride(0), 0, dalpha, R)
             dt = _f32(nnz, H, device=dev)
             nat.call("edge_softmax_bwd_f32", g.rowptr, g.col, R, H, s_row, s_col, 0, float(slope), alpha, dalpha, dt, ds_row)
             dt_t = _f32(nnz, H, device=dev)
@@ -145,7 +161,7 @@ class _AttentionAggregate(torch.autograd.Function):
             du = segment_wsum(dout, None, H, Fh, g.graph_ptr, g.B, scale=1.0, max_seg=int(g.sizes.max()))
         nat.call("csr_spmm_heads_epi_f32", rp_t, col_t, alpha_t, H, Fh, dout, dout.stride(0), 0, dh, dh.stride(0), R,
                  ds_row, a_row, a_row.stride(0), ds_col, a_col, a_col.stride(0), du, du.stride(0) if du is not None else 0,
-                 iso, N, _row_seg(g), 1.0 / N)
+                 iso, N, _row_seg(g), 1.0 / N, None)
         da_row, da_col = segment_wsum2(h, ds_row, ds_col, H, Fh)
         da_row, da_col = da_row.view(H, Fh), da_col.view(H, Fh)
         return dh, da_row, da_col, None, None, None, None, None

@@ -105,13 +105,15 @@ __global__ void scatter_rows_small(const float* __restrict__ src, const int* __r
   dst[(int64_t)perm[i / H] * H + (i % H)] = src[i];
 }
 // out[r, h] = sum over the row's entries of val[e, h]
-__global__ void csr_row_sum_kernel(const int* __restrict__ rowptr, const float* __restrict__ val, int64_t rows, int H, float* __restrict__ out) {
+// eperm (nullable): entry e's value lives at val[eperm[e]] (values stored in the transposed structure's entry order)
+__global__ void csr_row_sum_kernel(const int* __restrict__ rowptr, const float* __restrict__ val, int64_t rows, int H, float* __restrict__ out,
+                                   const int* __restrict__ eperm) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * H) return;
   const int64_t r = i / H;
   const int h = (int)(i % H);
   float acc = 0.f;
-  for (int e = rowptr[r]; e < rowptr[r + 1]; ++e) acc += val[(int64_t)e * H + h];
+  for (int e = rowptr[r]; e < rowptr[r + 1]; ++e) acc += val[(int64_t)(eperm ? eperm[e] : e) * H + h];
   out[i] = acc;
 }
 
@@ -123,6 +125,7 @@ struct HeadsEpi {
   const float* w2; const float* a2; int64_t lda2;
   const float* u; int64_t ldu; const float* uw; int rows_per_seg; float uscale;
   const int* row_seg;      // nullable: segment (graph) of every row for ragged batches; else r / rows_per_seg
+  const int* eperm;        // nullable: entry e's weights live at alpha[eperm[e]] (alpha stored in the transposed entry order)
 };
 __device__ __forceinline__ float heads_epi(const HeadsEpi& e, int64_t r, int H, int Fh, int h, int f /*within head*/) {
   float add = 0.f;
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(256) void spmm_heads_kernel(const int* __restrict__
       const int cnt = min(64, e1 - eb);
       for (int k = 0; k < cnt; ++k) {
         const int j = __shfl(cj, k, 64);
-        if (live) acc = fmaf(alpha[(int64_t)(eb + k) * H + h], x[(int64_t)j * ldx + f], acc);
+        if (live) acc = fmaf(alpha[(int64_t)(epi.eperm ? epi.eperm[eb + k] : eb + k) * H + h], x[(int64_t)j * ldx + f], acc);
       }
     }
     if (live) y[r * ldy + f] = acc + heads_epi(epi, r, H, Fh, h, f - h * Fh);
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(256) void spmm_heads_vec4(const int* __restrict__ r
       if (e < e1) {
         const int j = mod ? col[e] % mod : col[e];
         v[k] = *reinterpret_cast<const float4*>(x + (int64_t)j * ldx + co);
-        a[k] = alpha[(int64_t)e * H + h];
+        a[k] = alpha[(int64_t)(epi.eperm ? epi.eperm[e] : e) * H + h];
       }
     }
 #pragma unroll
@@ -442,7 +445,16 @@ int tsgnn_edge_permute_f32(const float* src, const int* perm, int64_t n, int H, 
 int tsgnn_csr_row_sum_f32(const int* rowptr, const float* val, int64_t rows, int H, float* out, tsgnn_stream_t stream) {
   if (!rowptr || !val || !out || rows < 0 || H <= 0) return TSGNN_EINVAL;
   if (rows == 0) return TSGNN_OK;
-  csr_row_sum_kernel<<<(unsigned)ceil_div64(rows * H, 256), 256, 0, stream>>>(rowptr, val, rows, H, out);
+  csr_row_sum_kernel<<<(unsigned)ceil_div64(rows * H, 256), 256, 0, stream>>>(rowptr, val, rows, H, out, nullptr);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+int tsgnn_csr_row_sum_perm_f32(const int* rowptr, const float* val, const int* eperm, int64_t rows, int H, float* out,
+                               tsgnn_stream_t stream) {
+  if (!rowptr || !val || !eperm || !out || rows < 0 || H <= 0) return TSGNN_EINVAL;
+  if (rows == 0) return TSGNN_OK;
+  csr_row_sum_kernel<<<(unsigned)ceil_div64(rows * H, 256), 256, 0, stream>>>(rowptr, val, rows, H, out, eperm);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }
@@ -476,9 +488,9 @@ int tsgnn_csr_spmm_heads_f32(const int* rowptr, const int* col, const float* alp
 int tsgnn_csr_spmm_heads_epi_f32(const int* rowptr, const int* col, const float* alpha, int H, int Fh, const float* x, int64_t ldx,
                                  int mod, float* y, int64_t ldy, int64_t rows, const float* w1, const float* a1, int64_t lda1,
                                  const float* w2, const float* a2, int64_t lda2, const float* u, int64_t ldu, const float* uw,
-                                 int rows_per_seg, const int* row_seg, float uscale, tsgnn_stream_t stream) {
+                                 int rows_per_seg, const int* row_seg, float uscale, const int* eperm, tsgnn_stream_t stream) {
   if ((w1 && !a1) || (w2 && !a2) || (u && rows_per_seg <= 0 && !row_seg)) return TSGNN_EINVAL;
-  HeadsEpi epi{w1, a1, lda1, w2, a2, lda2, u, ldu, uw, rows_per_seg, uscale, row_seg};
+  HeadsEpi epi{w1, a1, lda1, w2, a2, lda2, u, ldu, uw, rows_per_seg, uscale, row_seg, eperm};
   return spmm_heads_launch(rowptr, col, alpha, H, Fh, x, ldx, mod, y, ldy, rows, epi, stream);
 }
 
