@@ -101,13 +101,16 @@ def _ragged_tn(S, X, g):
     return out
 
 
-def _ragged_nn(X, Y, g, trans_y, out_cols, rows):
-    """out[rows_b] = X[rows_b] @ op(Y[b])   (M-ragged batched GEMM); rows outside every graph stay zero."""
+def _ragged_nn(X, Y, g, trans_y, out_cols, rows, out=None):
+    """out[rows_b] (+)= X[rows_b] @ op(Y[b])   (M-ragged batched GEMM); rows outside every graph stay zero.
+    ``out`` given: the product is accumulated into it (no allocation, no fill, no separate add)."""
     Kd = X.size(1)
-    out = _f32(rows, out_cols, device=X.device, zero=True)
+    acc = out is not None
+    if out is None:
+        out = _f32(rows, out_cols, device=X.device, zero=True)
     sbk, sbn = (1, Y.size(2)) if trans_y else (Y.size(2), 1)
     mp.gemm(X, X.stride(0), 1, Y, sbk, sbn, out, out.stride(0), 1, 0, out_cols, Kd, batch=g.B,
-            stride_b=Y.size(1) * Y.size(2), seg_ptr=g.graph_ptr, ragged=2, max_seg=int(g.sizes.max()))
+            stride_b=Y.size(1) * Y.size(2), seg_ptr=g.graph_ptr, ragged=2, max_seg=int(g.sizes.max()), accumulate=acc)
     return out
 
 
@@ -132,10 +135,10 @@ class _ContractRows(torch.autograd.Function):
         R, K, F = S.size(0), S.size(1), Z.size(1)
         dZ = _ragged_nn(S, dxo, g, False, F, R)                     # dZ_b = S_b dX'_b
         dS = _ragged_nn(Z, dxo, g, True, K, R)                      # S^T Z     : dS_b  = Z_b dX'_b^T
-        dS = dS + _ragged_nn(AS, dao, g, True, K, R)                # S^T (AS)  : dS_b += (AS)_b dA'_b^T
+        _ragged_nn(AS, dao, g, True, K, R, out=dS)                  # S^T (AS)  : dS_b += (AS)_b dA'_b^T   (accumulated in place)
         dAS = _ragged_nn(S, dao, g, False, K, R)                    #             d(AS)_b = S_b dA'_b
         rp, col, val = g.transposed()
-        dS = dS + mp.spmm_raw(rp, col, val, dAS, g.total_rows)      # AS = A S  : dS += A^T d(AS)
+        mp.spmm_raw(rp, col, val, dAS, g.total_rows, out=dS, accumulate=True)     # AS = A S  : dS += A^T d(AS)
         return dS, dZ, None
 
 
