@@ -140,7 +140,7 @@ def test_sagpool_net_vs_oracle(use_batch, sym, fused):
         assert err <= 2e-3 * r.abs().max().item() + 1e-6, (k, err)
 
 
-@pytest.mark.parametrize("case", ["ratio1", "singletons", "isolated", "odd_width", "large_graph"])
+@pytest.mark.parametrize("case", ["ratio1", "singletons", "isolated", "odd_width", "large_graph", "wide256", "narrow8", "width100"])
 def test_sagpool_net_edge_cases(case):
     """edge cases of the sync-free SAGPool levels against the oracle: ratio 1.0 (nothing dropped, the filter is the identity
     up to the top-k order), one-node graphs (k = 1 at every level), nodes without any edge, and a hidden width the float4
@@ -156,6 +156,12 @@ def test_sagpool_net_edge_cases(case):
         nhid = 30
     elif case == "large_graph":                      # > 1,024 nodes: the per-graph kernel's bitonic branch (rank count below)
         sizes = [1500, 40, 9]
+    elif case == "wide256":                          # 64 lanes per row (the other tests run 8 / 16 / 32)
+        nhid = 256
+    elif case == "narrow8":
+        nhid = 8
+    elif case == "width100":                         # 25 float4 columns in a 32-lane group: idle lanes in every group
+        nhid = 100
     n = sum(sizes)
     batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
     ei = rand_graph(51, n, 500 if case != "large_graph" else 6000, True, sizes)
