@@ -288,6 +288,10 @@ int tsgnn_segment_wsum_f32(const float* x, int64_t ldx, const float* w, int H, i
 int tsgnn_segment_wsum2_f32(const float* x, int64_t ldx, const float* w1, const float* w2, int H, int Fh, const int* seg_ptr, int nseg,
                             int64_t rows, int64_t max_seg, float scale, float* ws, float* out1, float* out2, int64_t ldo,
                             tsgnn_stream_t stream);
+/* out[s, :C] = scale * sum over the listed rows of segment s (idx / w entries [seg_ptr[s], seg_ptr[s+1])) of w[e] * x[idx[e], :C]:
+ * the uniform softmax term only involves a graph's few edge-less columns (encoders_GAT.py:38-41) */
+int tsgnn_gather_wsum_f32(const float* x, int64_t ldx, const int* idx, const float* w, const int* seg_ptr, int nseg, int C, float scale,
+                          float* out, int64_t ldo, tsgnn_stream_t stream);
 /* y[r,c] += scale * w[r,c/Fh] * (a ? a[(c/Fh)*lda + c%Fh] : u[(r / rows_per_seg)*ldu + c])   (w NULL = 1) */
 int tsgnn_broadcast_add_f32(float* y, int64_t ldy, int64_t rows, int H, int Fh, const float* w, const float* a, int64_t lda,
                             const float* u, int64_t ldu, int rows_per_seg, float scale, tsgnn_stream_t stream);

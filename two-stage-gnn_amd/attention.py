@@ -64,6 +64,27 @@ def _inverse_entry_map(g, src_e_t):
     return inv
 
 
+def _isolated_list(g, iso):
+    """(row ids, weights, per-graph pointer) of the rows with a non-zero uniform-term weight — a few per graph; built once
+    per graph (one host round trip at graph build time) so that the forward sums those rows only"""
+    c = getattr(g, "_iso_list", None)
+    if c is None:
+        w = iso[:, 0]
+        idx = torch.nonzero(w).view(-1)
+        rows_graph = g.row_graph[: g.n_rows].long() if g.n_ghost == 0 else None
+        if rows_graph is None:                              # per-slot ghost layout: not used with the uniform term
+            rows_graph = torch.div(torch.arange(w.numel(), device=w.device), max(g.nmax, 1), rounding_mode="floor")
+        cnt = torch.bincount(rows_graph[idx], minlength=g.B)
+        ptr = torch.zeros(g.B + 1, dtype=torch.int32, device=w.device)
+        ptr[1:] = torch.cumsum(cnt, 0)
+        n_listed = int(idx.numel())
+        if n_listed == 0 or n_listed > 64 * g.B:            # nothing to list, or so many that the all-rows scan is the better kernel
+            c = g._iso_list = (None,)
+        else:
+            c = g._iso_list = (idx.to(torch.int32).contiguous(), w[idx].contiguous(), ptr)
+    return None if c[0] is None else c
+
+
 def _isolated_columns(g, rp_t, R, H):
     """[R, H] indicator of columns without any edge; depends on the graph only, cached on it"""
     cache = g.__dict__.setdefault("_iso_cols", {})
@@ -111,7 +132,12 @@ class _AttentionAggregate(torch.autograd.Function):
             # per-graph sum u is added to every row in the aggregation's epilogue
             iso = _isolated_columns(g, rp_t, R, H)
             N = g.nmax
-            u = segment_wsum(h, iso, H, Fh, g.graph_ptr, g.B, scale=1.0 / N, max_seg=int(g.sizes.max()))
+            lst = _isolated_list(g, iso)
+            if lst is not None:                                # a few listed rows per graph (packed batch): sum those only
+                u = _f32(g.B, C, device=dev)
+                nat.call("gather_wsum_f32", h, h.stride(0), lst[0], lst[1], lst[2], g.B, C, 1.0 / N, u, u.stride(0))
+            else:                                              # padded batch: most rows are edge-less columns, scan them all
+                u = segment_wsum(h, iso, H, Fh, g.graph_ptr, g.B, scale=1.0 / N, max_seg=int(g.sizes.max()))
             nat.call("csr_spmm_heads_epi_f32", g.rowptr, g.col, alpha, H, Fh, h, h.stride(0), 0, out, out.stride(0), R,
                      None, None, 0, None, None, 0, u, u.stride(0), None, N, _row_seg(g), 1.0, eperm)
         elif eperm is not None:

@@ -337,6 +337,21 @@ __global__ __launch_bounds__(1024) void segment_wsum_final(const float* __restri
   out[(int64_t)s * ldo + c] = sc * acc;
 }
 
+// out[s, c] = scale * sum_{e in [seg_ptr[s], seg_ptr[s+1])} w[e] * x[idx[e], c]: weighted sum of a FEW listed rows per segment (the
+// isolated / padded columns of a graph in the uniform softmax term) without scanning all rows.  One block per segment.
+__global__ __launch_bounds__(256) void gather_wsum_kernel(const float* __restrict__ x, int64_t ldx, const int* __restrict__ idx,
+                                                          const float* __restrict__ w, const int* __restrict__ seg_ptr, int C,
+                                                          float scale, float* __restrict__ out, int64_t ldo) {
+  const int s = blockIdx.x;
+  const int e0 = seg_ptr[s], e1 = seg_ptr[s + 1];
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float acc = 0.f;
+#pragma unroll 4
+    for (int e = e0; e < e1; ++e) acc = fmaf(w[e], x[(int64_t)idx[e] * ldx + c], acc);
+    out[(int64_t)s * ldo + c] = scale * acc;
+  }
+}
+
 // y[r, c] (+)= alpha * w[r, c/Fh] * v[seg(r)?, c] ... generic rank-1 style broadcast add:
 //   mode 0: y[r,c] += w[r, c/Fh] * a[(c/Fh)*lda + c%Fh]         (ds (x) a  terms of dh)
 //   mode 1: y[r,c] += w[r, c/Fh] * u[seg_of_row(r), c]           (uniform term; w nullable = 1)
@@ -547,6 +562,14 @@ int tsgnn_segment_wsum2_f32(const float* x, int64_t ldx, const float* w1, const 
   segment_wsum_kernel<<<grid, 256, 0, stream>>>(x, ldx, w1, H, Fh, seg_ptr, rows, C, ws, nseg, w2, ws2);
   segment_wsum_final<<<dim3((unsigned)((C + 63) / 64), (unsigned)nseg, 2), 1024, 0, stream>>>(ws, nchunk, nseg, C, seg_ptr, rows, scale, 0, out1,
                                                                                               ldo, ws2, out2);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+int tsgnn_gather_wsum_f32(const float* x, int64_t ldx, const int* idx, const float* w, const int* seg_ptr, int nseg, int C, float scale,
+                          float* out, int64_t ldo, tsgnn_stream_t stream) {
+  if (!x || !idx || !w || !seg_ptr || !out || nseg <= 0 || C <= 0 || ldx < C || ldo < C) return TSGNN_EINVAL;
+  gather_wsum_kernel<<<(unsigned)nseg, 256, 0, stream>>>(x, ldx, idx, w, seg_ptr, C, scale, out, ldo);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }
