@@ -199,6 +199,34 @@ def test_sagpool_net_edge_cases(case):
         assert err <= 2e-3 * r.abs().max().item() + 1e-6, (case, k, err)
 
 
+def test_sagpool_fused_equals_composed_on_a_large_batch():
+    """600 graphs per batch: the sync-free node (per-graph kernels with 600 workgroups, 600 partial rows in the reductions, the
+    fused head at B = 600) against the level-by-level composition of the drop-ins, same weights — outputs and gradients"""
+    from two_stage_gnn_amd import sag_layers as S
+    gen = torch.Generator().manual_seed(77)
+    sizes = torch.randint(5, 41, (600,), generator=gen).tolist()
+    n = sum(sizes)
+    batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
+    ei = rand_graph(78, n, 3 * n, True, sizes)
+    x = tie_free(79, n, 3)
+    torch.manual_seed(5)
+    fused = S.Net(3, 64, 2, 0.5, 0.0, use_batch=True).cuda().eval()
+    comp = S.Net(3, 64, 2, 0.5, 0.0, use_batch=True, fused=False).cuda().eval()
+    comp.load_state_dict(fused.state_dict())
+
+    class D:
+        pass
+    d = D(); d.x, d.edge_index, d.batch = x.cuda(), ei.cuda(), batch.cuda()
+    a, b = fused(d), comp(d)
+    torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4)
+    gy = tie_free(80, *a.shape).cuda()
+    (a * gy).sum().backward()
+    (b * gy).sum().backward()
+    for (k, p), (_, q) in zip(fused.named_parameters(), comp.named_parameters()):
+        err = (p.grad - q.grad).abs().max().item()
+        assert err <= 2e-3 * q.grad.abs().max().item() + 1e-6, (k, err)
+
+
 def _csr_rows(rowptr, col, n):
     rp = rowptr.cpu().numpy()
     c = col.cpu().numpy()

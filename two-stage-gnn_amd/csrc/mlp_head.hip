@@ -462,7 +462,9 @@ extern "C" {
  * per-block copy of dz2[B, D2] fits LDS */
 int tsgnn_mlp3_supported(int B, int D0, int D1, int D2, int C) {
   if (B <= 0 || D0 <= 0 || D1 <= 0 || D2 <= 0 || C <= 0 || C > 16 || D0 % 4 || D1 % 4 || D0 > 4096 || D1 > 2048 || D2 > 1024) return 0;
-  return bwd_lds_bytes(B, D1, D2, C) <= 96 * 1024 ? 1 : 0;
+  // the two-launch backward stages a [B][4] operand tile per weight block (the single-launch variant needs dz2[B, D2] in LDS and
+  // reports TSGNN_EUNSUPPORTED itself beyond that)
+  return (size_t)B * 16 + 16 * (size_t)(D0 > D1 ? D0 : D1) * 4 + 4096 * (size_t)C <= 128 * 1024 ? 1 : 0;
 }
 
 int tsgnn_mlp3_fwd_f32(const float* x, int64_t ldx, const float* w1, const float* b1, const float* keep, float keep_scale, const float* w2,
@@ -486,7 +488,7 @@ int tsgnn_mlp3_bwd_f32(const float* x, int64_t ldx, const float* w1, const float
   if (!x || !w1 || !w2 || !w3 || !a1 || !a2 || !logp || !dlogp || !dw1 || !db1 || !dw2 || !db2 || !dw3 || !db3 || ldx < D0 ||
       (dx && lddx < D0))
     return TSGNN_EINVAL;
-  if (!tsgnn_mlp3_supported(B, D0, D1, D2, C)) return TSGNN_EUNSUPPORTED;
+  if (!tsgnn_mlp3_supported(B, D0, D1, D2, C) || bwd_lds_bytes(B, D1, D2, C) > 96 * 1024) return TSGNN_EUNSUPPORTED;
   Mlp3Bwd p{x, ldx, w1, w2, w3, a1, a2, logp, dlogp, keep_scale, B, D0, D1, D2, C, dw1, db1, dw2, db2, dw3, db3, dx, lddx,
             (D1 + MB_TILE - 1) / MB_TILE, (D2 + MB_TILE - 1) / MB_TILE};
   const unsigned nblk = (unsigned)(p.nW1 + p.nW2 + 1 + (dx ? (B + MB_ROWS - 1) / MB_ROWS : 0));
