@@ -353,6 +353,43 @@ def test_gcn_propagate_row_batched_large(F):
     torch.testing.assert_close(t, r @ w + b0, rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("F,ld", [(1, 1), (3, 3), (8, 12)])
+def test_gcn_propagate_narrow_large(F, ld):
+    """>= 32,768 rows of <= 8 columns run one thread per row (the degree / constant input column of a large IMDB batch):
+    same result as the index_add formulation, with explicit row ends, relu + bias and the score (dot) mode"""
+    from two_stage_gnn_amd import _native as nat
+    n = 32768 + 11
+    g = torch.Generator(device="cuda").manual_seed(9)
+    cap = torch.randint(0, 9, (n,), generator=g, device="cuda", dtype=torch.int32)
+    cap[-1] = 0; cap[5] = 150
+    rowptr = torch.zeros(n + 1, dtype=torch.int32, device="cuda"); rowptr[1:] = torch.cumsum(cap, 0)
+    cnt = torch.minimum(cap, torch.randint(0, 9, (n,), generator=g, device="cuda", dtype=torch.int32)); cnt[5] = 150
+    rowend = (rowptr[:-1] + cnt).contiguous()
+    col = torch.randint(0, n, (int(rowptr[-1]),), generator=g, device="cuda", dtype=torch.int32)
+    dinv = torch.rand(n, generator=g, device="cuda") + 0.5
+    self_w = torch.rand(n, generator=g, device="cuda")
+    xb = torch.randn(n, ld, generator=g, device="cuda"); x = xb[:, :F]
+    bias = torch.randn(F, generator=g, device="cuda"); w = torch.randn(F, generator=g, device="cuda"); b0 = torch.randn(1, generator=g, device="cuda")
+    for ends in (None, rowend):
+        c = cap if ends is None else cnt
+        rows = torch.repeat_interleave(torch.arange(n, device="cuda"), c.long())
+        e = (rowptr[:-1].long().repeat_interleave(c.long()) +
+             (torch.arange(int(c.sum()), device="cuda") - (torch.cumsum(c.long(), 0) - c.long()).repeat_interleave(c.long())))
+        cj = col[e].long()
+
+        def ref(relu):
+            xs = torch.relu(x) if relu else x
+            acc = torch.zeros(n, F, device="cuda").index_add_(0, rows, dinv[cj].unsqueeze(1) * xs[cj])
+            return dinv.unsqueeze(1) * acc + self_w.unsqueeze(1) * xs
+        y = torch.empty(n, F, device="cuda"); t = torch.empty(n, device="cuda")
+        nat.call("gcn_propagate_re_f32", rowptr, ends, col, dinv, self_w, xb, ld, 0, None, None, None, y, F, None, n, F)
+        torch.testing.assert_close(y, ref(False), rtol=1e-4, atol=1e-4)
+        nat.call("gcn_propagate_re_f32", rowptr, ends, col, dinv, self_w, xb, ld, 1, bias, w, b0, y, F, t, n, F)
+        r = ref(True) + bias
+        torch.testing.assert_close(y, r, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(t, r @ w + b0, rtol=1e-4, atol=1e-3)
+
+
 def test_sag_step_replays_from_a_hipgraph():
     """the fused SAGPool step has no host round trip: fwd + bwd captured once, replayed on new features"""
     from two_stage_gnn_amd import sag_layers as S

@@ -220,6 +220,47 @@ __global__ __launch_bounds__(256) void gcn_propagate_generic(PropArgs a) {
   }
 }
 
+// narrow inputs of a large batch (the one-column degree / constant feature of the IMDB sets, <= 8 columns): one THREAD per
+// row — a wave per row leaves 63 of 64 lanes idle there (8,192 IMDB-B graphs: 90 us for a 160k x 1 propagate)
+constexpr int PROP_NARROW_MAX = 8;
+constexpr int64_t PROP_NARROW_MIN_ROWS = 32768;
+__global__ __launch_bounds__(256) void gcn_propagate_narrow(PropArgs a) {
+  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (row >= a.n_rows) return;
+  const int e0 = a.rowptr[row], e1 = a.rowend ? a.rowend[row] : a.rowptr[row + 1];
+  float acc[PROP_NARROW_MAX];
+#pragma unroll
+  for (int f = 0; f < PROP_NARROW_MAX; ++f) acc[f] = 0.f;
+#pragma unroll 4
+  for (int e = e0; e < e1; ++e) {
+    const int j = a.col[e];
+    const float dj = a.dinv[j];
+    const float* xr = a.x + (int64_t)j * a.ldx;
+#pragma unroll
+    for (int f = 0; f < PROP_NARROW_MAX; ++f) {
+      if (f < a.feat) {
+        float v = xr[f];
+        if (a.relu_in) v = fmaxf(v, 0.f);
+        acc[f] = fmaf(dj, v, acc[f]);
+      }
+    }
+  }
+  const float di = a.dinv[row], sw = a.self_w[row];
+  float dot = 0.f;
+#pragma unroll
+  for (int f = 0; f < PROP_NARROW_MAX; ++f) {
+    if (f < a.feat) {
+      float xs = a.x[row * a.ldx + f];
+      if (a.relu_in) xs = fmaxf(xs, 0.f);
+      float o = fmaf(di, acc[f], sw * xs);
+      if (a.bias != nullptr) o += a.bias[f];
+      if (a.y != nullptr) a.y[row * a.ldy + f] = o;
+      if (a.w_dot != nullptr) dot = fmaf(o, a.w_dot[f], dot);
+    }
+  }
+  if (a.w_dot != nullptr) a.t[row] = dot + (a.dot_bias ? a.dot_bias[0] : 0.f);
+}
+
 // ---------------------------------------------------------------- kept rows: gated gather + kept-neighbour count
 // xp[p,:] = relu?(y[perm[p],:]) * tanh(score[perm[p]])  (layers.py:21) ; cnt[p] = #neighbours of perm[p] that are kept
 template <int G>
@@ -295,6 +336,7 @@ __global__ __launch_bounds__(256) void sag_readout_kernel(const float* __restric
 // in LDS between the phases.
 constexpr int PG_THREADS = 1024;
 constexpr int PG_MAX_NODES = 4096;
+constexpr int PG_SMALL_NODES = 256;       // batches whose graphs all fit this run the per-graph kernels with 256-thread workgroups
 constexpr int PG_RGROUPS = 8;            // lane groups that run the gather / readout phase
 constexpr int PG_RANK_MAX = 1024;        // up to this many (padded) nodes the top-k order comes from a rank count instead of a bitonic sort
 
@@ -312,8 +354,10 @@ struct PoolGraphArgs {
   int* rowptr_new; int* rowend_new; int* col_new; float* dinv_new; float* self_w_new;
 };
 
-template <int G>
-__global__ __launch_bounds__(PG_THREADS) void sag_pool_graph_kernel(PoolGraphArgs a) {
+// BT threads per workgroup: 1,024 for graphs of up to 4,096 nodes, 256 when no graph of the batch exceeds 256 nodes (TU graphs:
+// four times the resident graphs per CU; at 8,192 IMDB-B graphs per launch 266 -> see profiles)
+template <int G, int BT>
+__global__ __launch_bounds__(BT) void sag_pool_graph_kernel(PoolGraphArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long pg_smem[];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int g0 = a.gp[b], n = a.gp[b + 1] - g0;
@@ -327,7 +371,8 @@ __global__ __launch_bounds__(PG_THREADS) void sag_pool_graph_kernel(PoolGraphArg
   float* rmax = reinterpret_cast<float*>(nid + np);                     // [PG_RGROUPS][F]
   float* rsum = rmax + PG_RGROUPS * a.F;                                // [PG_RGROUPS][F]
   int* rarg = reinterpret_cast<int*>(rsum + PG_RGROUPS * a.F);          // [PG_RGROUPS][F]
-  constexpr int NG = PG_THREADS / G;
+  constexpr int NG = BT / G;
+  constexpr int RG = NG < PG_RGROUPS ? NG : PG_RGROUPS;                 // lane groups of the gather / readout phase (LDS laid out for PG_RGROUPS)
   const int lig = tid & (G - 1), grp = tid / G;
   const int nvec = a.F >> 2;
   const bool live = lig < nvec;
@@ -342,7 +387,7 @@ __global__ __launch_bounds__(PG_THREADS) void sag_pool_graph_kernel(PoolGraphArg
   __syncthreads();
   // (2) scores and sort keys
   const float bs = a.b_s ? a.b_s[0] : 0.f;
-  for (int j = tid; j < np; j += PG_THREADS) {
+  for (int j = tid; j < np; j += BT) {
     unsigned long long key = 0ull;                                      // padding sorts last
     if (j < n) {
       const int r = g0 + j;
@@ -365,7 +410,7 @@ __global__ __launch_bounds__(PG_THREADS) void sag_pool_graph_kernel(PoolGraphArg
   // its key at that position of a second array; keys are unique (they carry the node index).
   if (np <= PG_RANK_MAX) {
     unsigned long long* sorted = reinterpret_cast<unsigned long long*>(rarg + PG_RGROUPS * a.F);     // [np]
-    for (int i = tid; i < np; i += PG_THREADS) {
+    for (int i = tid; i < np; i += BT) {
       const unsigned long long mine = keys[i];
       int rank = 0;
       if (i < n) {
@@ -381,7 +426,7 @@ __global__ __launch_bounds__(PG_THREADS) void sag_pool_graph_kernel(PoolGraphArg
   } else {
     for (int size = 2; size <= np; size <<= 1) {
       for (int stride = size >> 1; stride > 0; stride >>= 1) {
-        for (int q = tid; q < (np >> 1); q += PG_THREADS) {
+        for (int q = tid; q < (np >> 1); q += BT) {
           const int lo = 2 * q - (q & (stride - 1));
           const int hi = lo + stride;
           const bool desc = ((lo & size) == 0);
@@ -393,7 +438,7 @@ __global__ __launch_bounds__(PG_THREADS) void sag_pool_graph_kernel(PoolGraphArg
     }
   }
   // (4) perm and the relabelling map
-  for (int i = tid; i < n; i += PG_THREADS) {
+  for (int i = tid; i < n; i += BT) {
     const int j = (int)(0xFFFFFFFFu - (unsigned)(keys[i] & 0xFFFFFFFFull));
     const int id = i < k ? k0 + i : -1;
     if (i < k) a.perm[k0 + i] = g0 + j;
@@ -402,10 +447,10 @@ __global__ __launch_bounds__(PG_THREADS) void sag_pool_graph_kernel(PoolGraphArg
   }
   __syncthreads();
   // (5) gated gather of the kept rows + their max || mean readout  (PG_RGROUPS lane groups; ties of the max -> smallest row)
-  if (grp < PG_RGROUPS) {
+  if (grp < RG) {
     float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY), s = make_float4(0.f, 0.f, 0.f, 0.f);
     int4 am = make_int4(k0, k0, k0, k0);
-    for (int p = grp; p < k; p += PG_RGROUPS) {
+    for (int p = grp; p < k; p += RG) {
       const unsigned long long key = keys[p];
       const int j = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
       const float gate = tanhf(ordered_f32((unsigned)(key >> 32)));
@@ -430,7 +475,7 @@ __global__ __launch_bounds__(PG_THREADS) void sag_pool_graph_kernel(PoolGraphArg
   // block scan of the counts, rows laid out from the graph's old segment base, entries relabelled in their original order,
   // and the next level's gcn_norm coefficients
   int* cl = reinterpret_cast<int*>(t);                                  // [np] counts, then exclusive offsets (t is dead by now)
-  for (int p = tid; p < np; p += PG_THREADS) {
+  for (int p = tid; p < np; p += BT) {
     int c = 0;
     if (p < k) {
       const int j = (int)(0xFFFFFFFFu - (unsigned)(keys[p] & 0xFFFFFFFFull));
@@ -448,7 +493,7 @@ __global__ __launch_bounds__(PG_THREADS) void sag_pool_graph_kernel(PoolGraphArg
   __syncthreads();
   if (a.col_new != nullptr) {
     // exclusive scan of cl[0..np): four consecutive counts per thread, wave scan, wave totals through LDS (np <= 4,096)
-    __shared__ int wsum[PG_THREADS / 64];
+    __shared__ int wsum[BT / 64];
     const int lane = tid & 63, wid = tid >> 6;
     int v[4], sum = 0;
 #pragma unroll
@@ -463,7 +508,7 @@ __global__ __launch_bounds__(PG_THREADS) void sag_pool_graph_kernel(PoolGraphArg
     __syncthreads();
     int wbase = 0;
 #pragma unroll
-    for (int w = 0; w < PG_THREADS / 64; ++w) wbase += (w < wid) ? wsum[w] : 0;
+    for (int w = 0; w < BT / 64; ++w) wbase += (w < wid) ? wsum[w] : 0;
     int ex = wbase + inc - sum;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -472,7 +517,7 @@ __global__ __launch_bounds__(PG_THREADS) void sag_pool_graph_kernel(PoolGraphArg
     }
     __syncthreads();
     const int base = a.rowptr[g0];
-    for (int p = tid; p < k; p += PG_THREADS) {
+    for (int p = tid; p < k; p += BT) {
       const int j = (int)(0xFFFFFFFFu - (unsigned)(keys[p] & 0xFFFFFFFFull));
       const int r = g0 + j;
       const int e1 = a.rowend ? a.rowend[r] : a.rowptr[r + 1];
@@ -496,11 +541,11 @@ __global__ __launch_bounds__(PG_THREADS) void sag_pool_graph_kernel(PoolGraphArg
     }
   }
   __syncthreads();
-  for (int f = tid; f < a.F; f += PG_THREADS) {
+  for (int f = tid; f < a.F; f += BT) {
     float m = rmax[f], s = rsum[f];
     int am = rarg[f];
 #pragma unroll
-    for (int q = 1; q < PG_RGROUPS; ++q) {
+    for (int q = 1; q < RG; ++q) {
       const float v = rmax[q * a.F + f];
       const int z = rarg[q * a.F + f];
       if (v > m || (v == m && z < am)) { m = v; am = z; }
@@ -655,18 +700,21 @@ __global__ __launch_bounds__(256) void sag_du_kernel(const int* __restrict__ row
 
 
 // dws[0:F], dbs[0] = column sums of part[nb, F + 4]: 8 slices of blocks per float4 column, then the slices in order
-__global__ __launch_bounds__(256) void sag_du_reduce(const float* __restrict__ part, int nb, int F, float* __restrict__ dws,
-                                                     float* __restrict__ dbs) {
+__global__ __launch_bounds__(256) void sag_du_reduce(float* __restrict__ part, int nb, int F, float* __restrict__ dws,
+                                                     float* __restrict__ dbs, int chunk, int stride) {
+  // block i sums rows {q * stride : i * chunk <= q < min(nb, (i + 1) * chunk)} in a fixed order; dws == NULL: the sum goes back
+  // to the block's first row (first stage of the two-stage reduction of a large batch's partials)
   __shared__ float4 s_part[256];
   const int nvec = F >> 2;
   const int c4 = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int q0 = blockIdx.x * chunk, q1 = min(nb, q0 + chunk);
   for (int cb = 0; cb < nvec + 1; cb += 32) {                       // column nvec = the db_s partial (lane .x)
     const int c = cb + c4;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c <= nvec) {
 #pragma unroll 4
-      for (int q = sl; q < nb; q += 8) {
-        const float4 v = *reinterpret_cast<const float4*>(part + (int64_t)q * (F + 4) + 4 * c);
+      for (int q = q0 + sl; q < q1; q += 8) {
+        const float4 v = *reinterpret_cast<const float4*>(part + (int64_t)q * stride * (F + 4) + 4 * c);
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
       }
     }
@@ -679,10 +727,28 @@ __global__ __launch_bounds__(256) void sag_du_reduce(const float* __restrict__ p
         const float4 v = s_part[q * 32 + c4];
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
       }
-      if (c < nvec) *reinterpret_cast<float4*>(dws + 4 * c) = s;
-      else dbs[0] = s.x;
+      if (dws == nullptr) {
+        float* o = part + (int64_t)q0 * stride * (F + 4);
+        if (c < nvec) *reinterpret_cast<float4*>(o + 4 * c) = s;
+        else o[F] = s.x;
+      } else {
+        if (c < nvec) *reinterpret_cast<float4*>(dws + 4 * c) = s;
+        else dbs[0] = s.x;
+      }
     }
   }
+}
+
+constexpr int DU_REDUCE_CHUNK = 64;
+// fixed-order sum of nb partial rows: one block up to 256 rows, two stages above (8,192 rows by one block: 150 us)
+inline void launch_du_reduce(float* part, int nb, int F, float* dws, float* dbs, hipStream_t stream) {
+  if (nb <= 256) {
+    sag_du_reduce<<<1, 256, 0, stream>>>(part, nb, F, dws, dbs, nb, 1);
+    return;
+  }
+  const int nb2 = (nb + DU_REDUCE_CHUNK - 1) / DU_REDUCE_CHUNK;
+  sag_du_reduce<<<(unsigned)nb2, 256, 0, stream>>>(part, nb, F, nullptr, nullptr, DU_REDUCE_CHUNK, 1);
+  sag_du_reduce<<<1, 256, 0, stream>>>(part, nb2, F, dws, dbs, nb2, DU_REDUCE_CHUNK);
 }
 
 // ---------------------------------------------------------------- backward of the level tail, one workgroup per graph
@@ -695,10 +761,10 @@ struct PoolGraphBwdArgs {
   const int* rowptr; const int* rowend; const int* col; const float* dinv; const float* self_w; const float* w_s;
   float* du; int64_t lddu; float* part; int F;
 };
-template <int G>
-__global__ __launch_bounds__(PG_THREADS) void sag_pool_graph_bwd_kernel(PoolGraphBwdArgs a) {
+template <int G, int BT>
+__global__ __launch_bounds__(BT) void sag_pool_graph_bwd_kernel(PoolGraphBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float pb_smem[];
-  constexpr int NG = PG_THREADS / G;
+  constexpr int NG = BT / G;
   const int b = blockIdx.x, tid = threadIdx.x;
   const int g0 = a.gp[b], n = a.gp[b + 1] - g0;
   const int kb = a.gp_new[b + 1] - a.gp_new[b];
@@ -741,7 +807,7 @@ __global__ __launch_bounds__(PG_THREADS) void sag_pool_graph_bwd_kernel(PoolGrap
   }
   __syncthreads();
   // (B) dt = A^ dscore (the score layer's propagate; symmetric adjacency)
-  for (int j = tid; j < n; j += PG_THREADS) {
+  for (int j = tid; j < n; j += BT) {
     const int r = g0 + j;
     const int e1 = a.rowend ? a.rowend[r] : a.rowptr[r + 1];
     float acc = 0.f;
@@ -773,7 +839,7 @@ __global__ __launch_bounds__(PG_THREADS) void sag_pool_graph_bwd_kernel(PoolGrap
   if (live) *reinterpret_cast<float4*>(racc + grp * F + co) = acc;
   __syncthreads();
   // (D) this graph's partial sums, groups in order
-  for (int f = tid; f < F; f += PG_THREADS) {
+  for (int f = tid; f < F; f += BT) {
     float sum = 0.f;
     for (int q = 0; q < NG; ++q) sum += racc[q * F + f];
     a.part[(int64_t)b * (F + 4) + f] = sum;
@@ -882,6 +948,8 @@ int tsgnn_gcn_propagate_re_f32(const int* rowptr, const int* rowend, const int* 
       case 32: launch_prop<32>(a, stream); break;
       default: launch_prop<64>(a, stream); break;
     }
+  } else if (feat <= PROP_NARROW_MAX && n_rows >= PROP_NARROW_MIN_ROWS) {
+    gcn_propagate_narrow<<<(unsigned)ceil_div64(n_rows, 256), 256, 0, stream>>>(a);
   } else {
     gcn_propagate_generic<<<(unsigned)ceil_div64(n_rows, 4), 256, 0, stream>>>(a);
   }
@@ -935,10 +1003,14 @@ int tsgnn_sag_pool_graph_f32(const float* y, int64_t ldy, const int* rowptr, con
                   out, ldout, arg, accumulate, F, rowptr_new, rowend_new, col_new, dinv_new, self_w_new};
 #define PG_LAUNCH(GG)                                                                                                          \
   do {                                                                                                                         \
-    if (lds > 64 * 1024)                                                                                                       \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sag_pool_graph_kernel<GG>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                (int)lds);                                                                                     \
-    sag_pool_graph_kernel<GG><<<(unsigned)B, PG_THREADS, lds, stream>>>(a);                                                    \
+    if (max_seg <= PG_SMALL_NODES) {                                                                                           \
+      sag_pool_graph_kernel<GG, 256><<<(unsigned)B, 256, lds, stream>>>(a);                                                    \
+    } else {                                                                                                                   \
+      if (lds > 64 * 1024)                                                                                                     \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sag_pool_graph_kernel<GG, PG_THREADS>),                        \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                       \
+      sag_pool_graph_kernel<GG, PG_THREADS><<<(unsigned)B, PG_THREADS, lds, stream>>>(a);                                      \
+    }                                                                                                                          \
   } while (0)
   switch (group_of(F)) {
     case 8: PG_LAUNCH(8); break;
@@ -1008,13 +1080,18 @@ int tsgnn_sag_pool_graph_bwd_f32(const float* y, int64_t ldy, const float* score
   PoolGraphBwdArgs a{y, ldy, score, new_id, graph_ptr, graph_ptr_new, arg, dxp, lddxp, dread, lddr, rowptr, rowend, col, dinv, self_w,
                      w_s, du, lddu, part, F};
   const int G_ = group_of(F);
-  const size_t lds = sizeof(float) * (2 * (size_t)((max_seg + 3) & ~3) + (size_t)(PG_THREADS / G_) * F);
+  const int bt = max_seg <= PG_SMALL_NODES ? 256 : PG_THREADS;
+  const size_t lds = sizeof(float) * (2 * (size_t)((max_seg + 3) & ~3) + (size_t)(bt / G_) * F);
 #define PGB_LAUNCH(GG)                                                                                                             \
   do {                                                                                                                             \
-    if (lds > 64 * 1024)                                                                                                           \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sag_pool_graph_bwd_kernel<GG>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                (int)lds);                                                                                         \
-    sag_pool_graph_bwd_kernel<GG><<<(unsigned)B, PG_THREADS, lds, stream>>>(a);                                                    \
+    if (bt == 256) {                                                                                                               \
+      sag_pool_graph_bwd_kernel<GG, 256><<<(unsigned)B, 256, lds, stream>>>(a);                                                    \
+    } else {                                                                                                                       \
+      if (lds > 64 * 1024)                                                                                                         \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sag_pool_graph_bwd_kernel<GG, PG_THREADS>),                        \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                           \
+      sag_pool_graph_bwd_kernel<GG, PG_THREADS><<<(unsigned)B, PG_THREADS, lds, stream>>>(a);                                      \
+    }                                                                                                                              \
   } while (0)
   switch (G_) {
     case 8: PGB_LAUNCH(8); break;
@@ -1023,7 +1100,7 @@ int tsgnn_sag_pool_graph_bwd_f32(const float* y, int64_t ldy, const float* score
     default: PGB_LAUNCH(64); break;
   }
 #undef PGB_LAUNCH
-  sag_du_reduce<<<1, 256, 0, stream>>>(part, B, F, dws, dbs);
+  launch_du_reduce(part, (int)B, F, dws, dbs, stream);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }
@@ -1043,7 +1120,7 @@ int tsgnn_sag_du_f32(const int* rowptr, const int* rowend, const int* col, const
     return TSGNN_EUNSUPPORTED;
   const unsigned nb = (unsigned)tsgnn_sag_du_blocks(N, F);
   SAG_DISPATCH(F, (sag_du_kernel<G><<<nb, 256, 0, stream>>>(rowptr, rowend, col, dinv, self_w, dscore, y, ldy, w_s, dyb, lddy, N, F, part)));
-  sag_du_reduce<<<1, 256, 0, stream>>>(part, (int)nb, F, dws, dbs);
+  launch_du_reduce(part, (int)nb, F, dws, dbs, stream);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }
