@@ -311,6 +311,41 @@ def test_diffpool_dd_config_vs_oracle():
         assert gpu_err <= max(10 * cpu_err, 2e-3 * mag + 1e-9), (k, gpu_err, cpu_err, mag)
 
 
+@pytest.mark.parametrize("B,K,fin,hid,last", [(16, 64, 192, 64, 64), (16, 8, 192, 64, 8), (5, 20, 12, 32, 16)])
+def test_dense_gcn_stack_equals_composed_layers(B, K, fin, hid, last, monkeypatch):
+    """a pooled DiffPool level's GCN stack as one autograd node (layers write into the concatenation, adjacency gradient
+    accumulated by the batched products) against the per-layer composition: outputs, dx, dA and every parameter gradient"""
+    from two_stage_gnn_amd import dense_encoders as E
+
+    class A:
+        bias = True
+    torch.manual_seed(11)
+    m = E.SoftPoolingGcnEncoder(64, 12, hid, last, 2, 3, hid, assign_ratio=0.25, num_pooling=1, bn=True, linkpred=False, args=A(),
+                                assign_input_dim=12, final_dim="number_classes")
+    c1, cb, cl = m.build_conv_layers(fin, hid, last, 3, False, normalize=True, dropout=0.0)
+    cb = torch.nn.ModuleList(cb)
+    for mod in [c1, cl] + list(cb):
+        mod.cuda()
+        torch.nn.init.normal_(mod.bias.data, std=0.1)
+    gen = torch.Generator().manual_seed(12)
+    x0 = torch.randn(B, K, fin, generator=gen).cuda()
+    a0 = torch.rand(B, K, K, generator=gen).cuda()
+    gy = torch.randn(B, K, 2 * hid + last, generator=gen).cuda()
+    res = []
+    for fused in (True, False):
+        monkeypatch.setattr(E, "FUSED_DENSE_STACK", fused)
+        x, a = x0.clone().requires_grad_(True), a0.clone().requires_grad_(True)
+        for mod in [c1, cl] + list(cb):
+            mod.zero_grad(set_to_none=True)
+        y, _ = m.gcn_forward_dense(x, a, c1, cb, cl)
+        (y * gy).sum().backward()
+        res.append([y.detach(), x.grad, a.grad] + [p.grad.clone() for mod in [c1] + list(cb) + [cl] for p in mod.parameters()])
+    assert res[0][0].shape == (B, K, 2 * hid + last)
+    for f, c in zip(res[0], res[1]):
+        scale = c.abs().max().item() + 1e-12
+        assert (f - c).abs().max().item() <= 2e-4 * scale
+
+
 @pytest.mark.parametrize("masked", [True, False])
 @pytest.mark.parametrize("sym", [True, False])
 def test_link_pred_loss_vs_oracle(masked, sym):

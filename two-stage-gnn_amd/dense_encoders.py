@@ -44,6 +44,7 @@ def _batch_from_dense(adj, sizes, layout):
 
 FUSED_HEAD = True              # the two chained nn.Linear after the readout as one HIP launch (+1 backward)
 FUSED_DENSE_POST = True       # pooled DiffPool levels: transform + normalise + ReLU + slot BN as one node
+FUSED_DENSE_STACK = True    # pooled DiffPool levels: the whole GCN stack as one autograd node (dense_stack.py)
 FUSED_STACK = True             # GcnEncoderGraph: run the conv stack as one fused autograd node when it qualifies
 DENSE_ADJ_MAX_NODES = 128      # at or below this many nodes per graph a dense batched MFMA product is used
 
@@ -356,6 +357,11 @@ class SoftPoolingGcnEncoder(GcnEncoderGraph):
     def gcn_forward_dense(self, x, adj, conv_first, conv_block, conv_last):
         B, K, _ = x.shape
         g = GraphBatch.uniform(B, K, x.device)
+        if FUSED_DENSE_STACK:
+            from . import dense_stack
+            convs = [conv_first] + list(conv_block) + [conv_last]
+            if dense_stack.eligible(x, adj, g, convs, self.bn, self.per_graph_bn):
+                return dense_stack.dense_gcn_stack(x, adj, g, convs), g       # one autograd node, layers write into the cat
 
         def post(v):
             return mp.bn_slots(v.reshape(B * K, -1), g, relu=True, bn=self.bn, per_graph=self.per_graph_bn).reshape(B, K, -1)
