@@ -440,6 +440,12 @@ int tsgnn_relu_bwd_f32(const float* y, const float* dy, int64_t n, float* dx, ts
 int tsgnn_row_softmax_fwd_f32(const float* x, int64_t ldx, int64_t rows, int C, float* y, int64_t ldy, tsgnn_stream_t stream);
 int tsgnn_row_softmax_bwd_f32(const float* y, int64_t ldy, const float* dy, int64_t lddy, int64_t rows, int C, float* dx,
                               int64_t lddx, tsgnn_stream_t stream);
+/* the same with the embedding mask of encoders.py:370-371 folded in: rows >= zero_from (the ghost rows of a packed batch)
+ * get y = 0 forward and dx = 0 backward */
+int tsgnn_row_softmax_masked_fwd_f32(const float* x, int64_t ldx, int64_t rows, int C, float* y, int64_t ldy, int64_t zero_from,
+                                     tsgnn_stream_t stream);
+int tsgnn_row_softmax_masked_bwd_f32(const float* y, int64_t ldy, const float* dy, int64_t lddy, int64_t rows, int C, float* dx,
+                                     int64_t lddx, int64_t zero_from, tsgnn_stream_t stream);
 
 /* ---------------------------------------------------------------- fused slot kernels of the GraphSage stack (sage_fused.hip) */
 

@@ -13,9 +13,8 @@ def step():
     dpm.zero_grad(set_to_none=True); dpm.loss(dpm(x5, g5, hb5["sizes"], assign_x=x5)[1], lab5).backward()
 for _ in range(3): step()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
     step(); torch.cuda.synchronize()
-rows = [e for e in prof.key_averages(group_by_stack_n=6) if e.key.startswith("aten::") and e.device_time_total > 0 and e.self_device_time_total > 0]
-rows.sort(key=lambda e: -e.count)
-for e in rows:
-    print("%-28s x%-3d %6.1f us  | %s" % (e.key, e.count, e.self_device_time_total, " <- ".join(s.split("/")[-1] for s in e.stack[:6])))
+for e in prof.events():
+    if e.name.startswith("aten::") and e.self_device_time_total > 0:
+        print("%-16s %5.1f us  %s" % (e.name, e.self_device_time_total, e.input_shapes))

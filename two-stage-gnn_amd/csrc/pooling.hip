@@ -117,11 +117,16 @@ __global__ void relu_bwd_kernel(const float* __restrict__ y, const float* __rest
 }
 
 // row softmax (DiffPool assignment, nn.Softmax(dim=-1), encoders.py:369) with optional row mask; one wave per row
+// rows >= zero_from are written as zeros (the assignment rows of ghost nodes: "* embedding_mask", encoders.py:371)
 __global__ __launch_bounds__(256) void row_softmax_fwd(const float* __restrict__ x, int64_t ldx, int64_t rows, int C,
-                                                       float* __restrict__ y, int64_t ldy) {
+                                                       float* __restrict__ y, int64_t ldy, int64_t zero_from) {
   const int lane = threadIdx.x & 63;
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
+  if (r >= zero_from) {
+    for (int c = lane; c < C; c += 64) y[r * ldy + c] = 0.f;
+    return;
+  }
   float m = -INFINITY;
   for (int c = lane; c < C; c += 64) m = fmaxf(m, x[r * ldx + c]);
   m = wave_max(m);
@@ -131,10 +136,15 @@ __global__ __launch_bounds__(256) void row_softmax_fwd(const float* __restrict__
   for (int c = lane; c < C; c += 64) y[r * ldy + c] = expf(x[r * ldx + c] - m) / d;
 }
 __global__ __launch_bounds__(256) void row_softmax_bwd(const float* __restrict__ y, int64_t ldy, const float* __restrict__ dy,
-                                                       int64_t lddy, int64_t rows, int C, float* __restrict__ dx, int64_t lddx) {
+                                                       int64_t lddy, int64_t rows, int C, float* __restrict__ dx, int64_t lddx,
+                                                       int64_t zero_from) {
   const int lane = threadIdx.x & 63;
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
+  if (r >= zero_from) {
+    for (int c = lane; c < C; c += 64) dx[r * lddx + c] = 0.f;
+    return;
+  }
   float dot = 0.f;
   for (int c = lane; c < C; c += 64) dot = fmaf(y[r * ldy + c], dy[r * lddy + c], dot);
   dot = wave_sum(dot);
@@ -215,17 +225,25 @@ int tsgnn_relu_bwd_f32(const float* y, const float* dy, int64_t n, float* dx, ts
 }
 
 int tsgnn_row_softmax_fwd_f32(const float* x, int64_t ldx, int64_t rows, int C, float* y, int64_t ldy, tsgnn_stream_t stream) {
-  if (!x || !y || rows < 0 || C <= 0 || ldx < C || ldy < C) return TSGNN_EINVAL;
+  return tsgnn_row_softmax_masked_fwd_f32(x, ldx, rows, C, y, ldy, rows, stream);
+}
+int tsgnn_row_softmax_masked_fwd_f32(const float* x, int64_t ldx, int64_t rows, int C, float* y, int64_t ldy, int64_t zero_from,
+                                     tsgnn_stream_t stream) {
+  if (!x || !y || rows < 0 || C <= 0 || ldx < C || ldy < C || zero_from < 0) return TSGNN_EINVAL;
   if (rows == 0) return TSGNN_OK;
-  row_softmax_fwd<<<(unsigned)ceil_div64(rows, 4), 256, 0, stream>>>(x, ldx, rows, C, y, ldy);
+  row_softmax_fwd<<<(unsigned)ceil_div64(rows, 4), 256, 0, stream>>>(x, ldx, rows, C, y, ldy, zero_from);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }
 int tsgnn_row_softmax_bwd_f32(const float* y, int64_t ldy, const float* dy, int64_t lddy, int64_t rows, int C, float* dx,
                               int64_t lddx, tsgnn_stream_t stream) {
-  if (!y || !dy || !dx || rows < 0 || C <= 0) return TSGNN_EINVAL;
+  return tsgnn_row_softmax_masked_bwd_f32(y, ldy, dy, lddy, rows, C, dx, lddx, rows, stream);
+}
+int tsgnn_row_softmax_masked_bwd_f32(const float* y, int64_t ldy, const float* dy, int64_t lddy, int64_t rows, int C, float* dx,
+                                     int64_t lddx, int64_t zero_from, tsgnn_stream_t stream) {
+  if (!y || !dy || !dx || rows < 0 || C <= 0 || zero_from < 0) return TSGNN_EINVAL;
   if (rows == 0) return TSGNN_OK;
-  row_softmax_bwd<<<(unsigned)ceil_div64(rows, 4), 256, 0, stream>>>(y, ldy, dy, lddy, rows, C, dx, lddx);
+  row_softmax_bwd<<<(unsigned)ceil_div64(rows, 4), 256, 0, stream>>>(y, ldy, dy, lddy, rows, C, dx, lddx, zero_from);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }

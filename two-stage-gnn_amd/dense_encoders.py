@@ -399,9 +399,8 @@ class SoftPoolingGcnEncoder(GcnEncoderGraph):
             if i == 0:
                 a = self.gcn_forward_rows(x_a, g, self.assign_conv_first_modules[0], self.assign_conv_block_modules[0],
                                           self.assign_conv_last_modules[0], mask_ghost=masked)
-                s = dp.row_softmax(linear(a, lin.weight.t(), lin.bias))                       # encoders.py:369
-                if masked:
-                    s = mp.mask_ghost_rows(s, g)                                              # :371
+                s = dp.row_softmax(mp.linear_oi(a, lin.weight, lin.bias),                    # encoders.py:369
+                                   g.n_rows if (masked and g.n_ghost) else None)              # :371 (ghost rows -> 0)
                 self.assign_tensor = s
                 self._link_graph, self._link_masked = g, masked
                 dense_x, dense_adj = dp.diffpool_contract_rows(s, emb, g)                     # :374-375
@@ -409,7 +408,7 @@ class SoftPoolingGcnEncoder(GcnEncoderGraph):
                 a, _ = self.gcn_forward_dense(dense_x, dense_adj, self.assign_conv_first_modules[i],
                                               self.assign_conv_block_modules[i], self.assign_conv_last_modules[i])
                 Bq, Kq, Cq = a.shape
-                s = dp.row_softmax(linear(a.reshape(Bq * Kq, Cq), lin.weight.t(), lin.bias)).reshape(Bq, Kq, -1)
+                s = dp.row_softmax(mp.linear_oi(a.reshape(Bq * Kq, Cq), lin.weight, lin.bias)).reshape(Bq, Kq, -1)
                 self.assign_tensor = s
                 dense_x, dense_adj = dp.diffpool_contract_dense(s, emb_dense, dense_adj)
             emb_dense, gd = self.gcn_forward_dense(dense_x, dense_adj, self.conv_first_after_pool[i],

@@ -18,11 +18,12 @@ def _f32(*shape, device, zero=False):
 
 class _RowSoftmax(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, zero_from):
         x = x.contiguous()
         y = torch.empty_like(x)
-        nat.call("row_softmax_fwd_f32", x, x.stride(0), x.size(0), x.size(1), y, y.stride(0))
+        nat.call("row_softmax_masked_fwd_f32", x, x.stride(0), x.size(0), x.size(1), y, y.stride(0), zero_from)
         ctx.save_for_backward(y)
+        ctx.zero_from = zero_from
         return y
 
     @staticmethod
@@ -30,26 +31,27 @@ class _RowSoftmax(torch.autograd.Function):
         (y,) = ctx.saved_tensors
         dy = dy.contiguous()
         dx = torch.empty_like(y)
-        nat.call("row_softmax_bwd_f32", y, y.stride(0), dy, dy.stride(0), y.size(0), y.size(1), dx, dx.stride(0))
-        return dx
+        nat.call("row_softmax_masked_bwd_f32", y, y.stride(0), dy, dy.stride(0), y.size(0), y.size(1), dx, dx.stride(0), ctx.zero_from)
+        return dx, None
 
 
-def row_softmax(x2d):
-    """nn.Softmax(dim=-1) of a [rows, K] matrix (encoders.py:369)."""
-    return _RowSoftmax.apply(x2d)
+def row_softmax(x2d, zero_from=None):
+    """nn.Softmax(dim=-1) of a [rows, K] matrix (encoders.py:369); rows >= ``zero_from`` (ghost rows) are zeroed, which is the
+    multiplication by the embedding mask that follows it (:370-371) without a second pass."""
+    return _RowSoftmax.apply(x2d, int(x2d.size(0) if zero_from is None else zero_from))
 
 
 # ----------------------------------------------------------------------------- strided batched matmul
-def _bmm_raw(a, b, ta, tb):
-    """c[z] = op(a[z]) @ op(b[z]) for contiguous 3-D a, b."""
+def _bmm_raw(a, b, ta, tb, out=None):
+    """c[z] = op(a[z]) @ op(b[z]) for contiguous 3-D a, b; ``out`` given: accumulated into it."""
     B = a.size(0)
     M, K = (a.size(2), a.size(1)) if ta else (a.size(1), a.size(2))
     N = b.size(1) if tb else b.size(2)
-    c = _f32(B, M, N, device=a.device)
+    c = out if out is not None else _f32(B, M, N, device=a.device)
     sam, sak = (1, a.size(2)) if ta else (a.size(2), 1)
     sbk, sbn = (1, b.size(2)) if tb else (b.size(2), 1)
     mp.gemm(a, sam, sak, b, sbk, sbn, c, N, 1, M, N, K, batch=B, stride_a=a.size(1) * a.size(2),
-            stride_b=b.size(1) * b.size(2), stride_c=M * N)
+            stride_b=b.size(1) * b.size(2), stride_c=M * N, accumulate=out is not None)
     return c
 
 
@@ -79,9 +81,41 @@ def bmm(a, b, trans_a=False, trans_b=False):
     return _Bmm.apply(a, b, bool(trans_a), bool(trans_b))
 
 
+class _ContractDense(torch.autograd.Function):
+    """(S^T Z, S^T A S) of a pooled level as one node: the three gradient contributions to S are accumulated by the
+    batched products themselves (composed from bmm nodes autograd adds them with two element-wise launches)."""
+
+    @staticmethod
+    def forward(ctx, s, z, adj):
+        s, z, adj = s.contiguous(), z.contiguous(), adj.contiguous()
+        xo = _bmm_raw(s, z, True, False)
+        t = _bmm_raw(s, adj, True, False)                      # S^T A
+        ao = _bmm_raw(t, s, False, False)
+        ctx.save_for_backward(s, z, adj, t)
+        return xo, ao
+
+    @staticmethod
+    def backward(ctx, dxo, dao):
+        s, z, adj, t = ctx.saved_tensors
+        dxo, dao = dxo.contiguous(), dao.contiguous()
+        ns, nz, na = ctx.needs_input_grad
+        ds = dz = dadj = None
+        if nz:
+            dz = _bmm_raw(s, dxo, False, False)                # X' = S^T Z : dZ = S dX'
+        if ns or na:
+            dt = _bmm_raw(dao, s, False, True)                 # A' = T S  : dT = dA' S^T
+        if ns:
+            ds = _bmm_raw(z, dxo, False, True)                 #             dS  = Z dX'^T
+            _bmm_raw(t, dao, True, False, out=ds)              #             dS += T^T dA'
+            _bmm_raw(adj, dt, False, True, out=ds)             # T = S^T A : dS += A dT^T
+        if na:
+            dadj = _bmm_raw(s, dt, False, False)               #             dA  = S dT
+        return ds, dz, dadj
+
+
 def diffpool_contract_dense(s, z, adj):
     """encoders.py:374-375 on dense [B,N,*] tensors: (S^T Z, S^T A S)."""
-    return bmm(s, z, trans_a=True), bmm(bmm(s, adj, trans_a=True), s)
+    return _ContractDense.apply(s, z, adj)
 
 
 # ----------------------------------------------------------------------------- ragged (row-layout) contraction
