@@ -395,13 +395,14 @@ int tsgnn_sag_pool_gather_f32(const float* y, int64_t ldy, const float* score, c
  * xp / cnt as tsgnn_sag_pool_gather_f32(relu_in = 1), out / arg as tsgnn_sag_readout_f32.  rowend (nullable): explicit row ends
  * of the input CSR.  rowptr_new .. self_w_new (all or none): filter_adj done here too — the pooled adjacency goes to col_new
  * from each graph's old segment base (rows [rowptr_new[p], rowend_new[p]), K entries each) with the next level's
- * tsgnn_gcn_coef_f32 output, so no scan / fill launches follow. */
+ * tsgnn_gcn_coef_f32 output, so no scan / fill launches follow.  agg_next (nullable, needs the filter outputs): the NEXT
+ * level's aggregation A^' xp = tsgnn_gcn_propagate_re_f32 on the pooled rows, formed here as well (same arithmetic). */
 int tsgnn_sag_pool_graph_max_nodes(void);
 int tsgnn_sag_pool_graph_f32(const float* y, int64_t ldy, const int* rowptr, const int* rowend, const int* col, const float* dinv,
                              const float* self_w, const float* w_s, const float* b_s, const int* graph_ptr, const int* graph_ptr_new,
                              int B, int max_seg, int F, float* score, int* perm, int* new_id, float* xp, int64_t ldo, int* cnt,
                              float* out, int64_t ldout, int* arg, int accumulate, int* rowptr_new, int* rowend_new, int* col_new,
-                             float* dinv_new, float* self_w_new, tsgnn_stream_t stream);
+                             float* dinv_new, float* self_w_new, float* agg_next, int64_t ldagg, tsgnn_stream_t stream);
 /* out[b, :F] (+)= max over the rows of graph b, out[b, F:2F] (+)= their mean (gmp || gap, network.py:36,40,44);
  * arg[b, f] = row holding the max (ties -> smallest row) */
 int tsgnn_sag_readout_f32(const float* xp, int64_t ld, const int* graph_ptr, int B, int F, int accumulate, float* out, int64_t ldo,
@@ -421,12 +422,16 @@ int tsgnn_sag_pool_bwd_f32(const float* y, int64_t ldy, const float* score, cons
                            tsgnn_stream_t stream);
 /* tsgnn_sag_pool_bwd_f32 + tsgnn_sag_du_f32 as one workgroup per graph (graphs <= tsgnn_sag_pool_graph_max_nodes() nodes,
  * symmetric adjacency, rowend nullable): du[r] = gradient w.r.t. the pre-activation conv output y[r]; part: B rows of F + 4
- * floats; dws / dbs as tsgnn_sag_du_f32. */
+ * floats; dws / dbs as tsgnn_sag_du_f32.  dagg_next (nullable; then dxp must be NULL): the gradient of the NEXT level's
+ * aggregation with that level's CSR (rowptr_n, rowend_n, col_n) and coefficients — dxp = A^' dagg_next is formed per kept row
+ * inside the kernel instead of by a tsgnn_gcn_propagate_re_f32 launch. */
 int tsgnn_sag_pool_graph_bwd_f32(const float* y, int64_t ldy, const float* score, const int* new_id, const int* graph_ptr,
                                  const int* graph_ptr_new, const int* arg, const float* dxp, int64_t lddxp, const float* dread,
                                  int64_t lddr, const int* rowptr, const int* rowend, const int* col, const float* dinv,
                                  const float* self_w, const float* w_s, int B, int max_seg, int F, float* du, int64_t lddu, float* part,
-                                 float* dws, float* dbs, tsgnn_stream_t stream);
+                                 float* dws, float* dbs, const float* dagg_next, int64_t lddagg, const int* rowptr_n,
+                                 const int* rowend_n, const int* col_n, const float* dinv_n, const float* self_w_n,
+                                 tsgnn_stream_t stream);
 /* dyb[r] <- (dyb[r] + dt[r] * w_s) * [y[r] > 0] with dt = A^ dscore (score layer backward folded in);
  * dws = sum_r dt[r] * relu(y[r]), dbs = sum_r dscore[r] (fixed-order block partials in `part`: tsgnn_sag_du_blocks(N, F)
  * rows of F + 4 floats, summed by a second one-block launch). */

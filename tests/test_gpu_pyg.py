@@ -199,10 +199,13 @@ def test_sagpool_net_edge_cases(case):
         assert err <= 2e-3 * r.abs().max().item() + 1e-6, (case, k, err)
 
 
-def test_sagpool_fused_equals_composed_on_a_large_batch():
+@pytest.mark.parametrize("next_prop", [True, False])
+def test_sagpool_fused_equals_composed_on_a_large_batch(next_prop, monkeypatch):
     """600 graphs per batch: the sync-free node (per-graph kernels with 600 workgroups, 600 partial rows in the reductions, the
-    fused head at B = 600) against the level-by-level composition of the drop-ins, same weights — outputs and gradients"""
-    from two_stage_gnn_amd import sag_layers as S
+    fused head at B = 600) against the level-by-level composition of the drop-ins, same weights — outputs and gradients; with
+    the next level's aggregation / gradient propagate inside the per-graph kernels, and as launches of their own"""
+    from two_stage_gnn_amd import sag_layers as S, sag_stack as SS
+    monkeypatch.setattr(SS, "FUSED_NEXT_PROPAGATE", next_prop)
     gen = torch.Generator().manual_seed(77)
     sizes = torch.randint(5, 41, (600,), generator=gen).tolist()
     n = sum(sizes)
@@ -295,9 +298,9 @@ def test_sag_level_kernels_vs_oracle():
     out2 = torch.empty(L.B, 64, device="cuda"); arg2 = torch.empty(L.B, 32, dtype=torch.int32, device="cuda")
     rp2 = torch.empty(K, dtype=torch.int32, device="cuda"); re2 = torch.empty(K, dtype=torch.int32, device="cuda")
     col2 = torch.full((ei.size(1),), -7, dtype=torch.int32, device="cuda")
-    d2 = torch.empty(K, device="cuda"); s2 = torch.empty(K, device="cuda")
+    d2 = torch.empty(K, device="cuda"); s2 = torch.empty(K, device="cuda"); aggn = torch.empty(K, 32, device="cuda")
     nat.call("sag_pool_graph_f32", y.cuda(), 32, g.rowptr, None, g.col, dinv, self_w, wsc.cuda(), bsc.cuda(), L.gp, Ln.gp, L.B, L.max_seg, 32,
-             sc2, perm2, nid2, xp2, 32, cnt2, out2, 64, arg2, 0, rp2, re2, col2, d2, s2)
+             sc2, perm2, nid2, xp2, 32, cnt2, out2, 64, arg2, 0, rp2, re2, col2, d2, s2, aggn, 32)
     torch.testing.assert_close(sc2.cpu(), t_ref, rtol=1e-5, atol=1e-5)
     np.testing.assert_array_equal(perm2.cpu().numpy(), perm_r.numpy())
     ei_r = P.filter_adj(ei, perm_r, n)
@@ -311,6 +314,8 @@ def test_sag_level_kernels_vs_oracle():
     torch.testing.assert_close(xp2.cpu(), xr2, rtol=1e-5, atol=1e-5)
     b3 = batch[perm_r]
     torch.testing.assert_close(out2.cpu(), torch.cat([P.global_max_pool(xr2, b3, L.B), P.global_mean_pool(xr2, b3, L.B)], 1), rtol=1e-5, atol=1e-5)
+    # ... and the next level's aggregation A^' xp from the same launch
+    torch.testing.assert_close(aggn.cpu(), P.gcn_conv(xr2, ei_r, torch.eye(32), None), rtol=1e-5, atol=1e-5)
     # the filtered CSR with explicit row ends feeds the propagate kernel
     xk = tie_free(36, K, 32)
     got, _ = SS.propagate(rp2, col2, d2, s2, xk.cuda(), K, rowend=re2)

@@ -324,6 +324,40 @@ __global__ __launch_bounds__(256) void sag_readout_kernel(const float* __restric
   arg[(int64_t)b * F + f] = am;
 }
 
+// one row of the normalised propagation, computed by a lane group of G (float4 per lane): dinv_r sum_j dinv_j x_j + self_w_r x_r
+// over the row's CSR entries [rowptr[r], rowend[r]) — the arithmetic (and its order) of gcn_propagate_vec4, for use inside the
+// per-graph kernels (the next level's aggregation / the gradient arriving from the next level touch one graph's rows only)
+template <int G>
+__device__ __forceinline__ float4 prop_row(const int* __restrict__ rowptr, const int* __restrict__ rowend, const int* __restrict__ col,
+                                           const float* __restrict__ dinv, const float* __restrict__ self_w,
+                                           const float* __restrict__ x, int64_t ldx, int64_t row, int lig, int64_t co) {
+  const int e0 = rowptr[row], e1 = rowend[row];
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int eb = e0; eb < e1; eb += G) {
+    const int me = eb + lig;
+    const int cj = (me < e1) ? col[me] : 0;
+    const float dj = (me < e1) ? dinv[cj] : 0.f;
+    const int cnt = min(G, e1 - eb);
+    int k = 0;
+    for (; k + 4 <= cnt; k += 4) {
+      const int j0 = __shfl(cj, k, G), j1 = __shfl(cj, k + 1, G), j2 = __shfl(cj, k + 2, G), j3 = __shfl(cj, k + 3, G);
+      const float4 v0 = ld4(x + (int64_t)j0 * ldx + co);
+      const float4 v1 = ld4(x + (int64_t)j1 * ldx + co);
+      const float4 v2 = ld4(x + (int64_t)j2 * ldx + co);
+      const float4 v3 = ld4(x + (int64_t)j3 * ldx + co);
+      fma4(acc, __shfl(dj, k, G), v0); fma4(acc, __shfl(dj, k + 1, G), v1);
+      fma4(acc, __shfl(dj, k + 2, G), v2); fma4(acc, __shfl(dj, k + 3, G), v3);
+    }
+    for (; k < cnt; ++k) {
+      const int j = __shfl(cj, k, G);
+      fma4(acc, __shfl(dj, k, G), ld4(x + (int64_t)j * ldx + co));
+    }
+  }
+  const float di = dinv[row], sw = self_w[row];
+  const float4 xs = ld4(x + row * ldx + co);
+  return make_float4(fmaf(di, acc.x, sw * xs.x), fmaf(di, acc.y, sw * xs.y), fmaf(di, acc.z, sw * xs.z), fmaf(di, acc.w, sw * xs.w));
+}
+
 // ---------------------------------------------------------------- one workgroup per graph: score -> top-k -> gather -> readout
 // Everything between the conv output y and the pooled level touches ONE graph's rows only (the score layer's neighbours,
 // the top-k segment, the kept rows, the readout), so for graphs of up to 4,096 nodes a single 1,024-thread workgroup does
@@ -352,6 +386,8 @@ struct PoolGraphArgs {
   // CSR filter inside the kernel (all nullable together): the pooled level's adjacency goes to col_new at the graph's OLD
   // segment base rowptr[gp[b]] (kept entries never outnumber the old ones), rows [rowptr_new[p], rowend_new[p])
   int* rowptr_new; int* rowend_new; int* col_new; float* dinv_new; float* self_w_new;
+  // with the filter: the NEXT level's aggregation A^' xp (nullable) — one launch less per level (gcn_propagate on the pooled rows)
+  float* agg_next; int64_t ldagg;
 };
 
 // BT threads per workgroup: 1,024 for graphs of up to 4,096 nodes, 256 when no graph of the batch exceeds 256 nodes (TU graphs:
@@ -541,6 +577,12 @@ __global__ __launch_bounds__(BT) void sag_pool_graph_kernel(PoolGraphArgs a) {
     }
   }
   __syncthreads();
+  if (a.agg_next != nullptr) {                              // pooled rows, their CSR and coefficients were written above by this block
+    for (int p = grp; p < k; p += NG) {
+      const float4 o = prop_row<G>(a.rowptr_new, a.rowend_new, a.col_new, a.dinv_new, a.self_w_new, a.xp, a.ldo, k0 + p, lig, co);
+      if (live) *reinterpret_cast<float4*>(a.agg_next + (int64_t)(k0 + p) * a.ldagg + co) = o;
+    }
+  }
   for (int f = tid; f < a.F; f += BT) {
     float m = rmax[f], s = rsum[f];
     int am = rarg[f];
@@ -760,6 +802,10 @@ struct PoolGraphBwdArgs {
   const float* dxp; int64_t lddxp; const float* dread; int64_t lddr;
   const int* rowptr; const int* rowend; const int* col; const float* dinv; const float* self_w; const float* w_s;
   float* du; int64_t lddu; float* part; int F;
+  // instead of dxp: the next level's dagg (gradient of ITS aggregation) and that level's CSR / coefficients — dxp = A^' dagg is
+  // formed per kept row here (symmetric adjacency), one launch less per level
+  const float* dagg_next; int64_t lddagg;
+  const int* rowptr_n; const int* rowend_n; const int* col_n; const float* dinv_n; const float* self_w_n;
 };
 template <int G, int BT>
 __global__ __launch_bounds__(BT) void sag_pool_graph_bwd_kernel(PoolGraphBwdArgs a) {
@@ -790,7 +836,9 @@ __global__ __launch_bounds__(BT) void sag_pool_graph_bwd_kernel(PoolGraphBwdArgs
     float4 gq = make_float4(0.f, 0.f, 0.f, 0.f);
     float dsv = 0.f;
     if (p >= 0) {                                                       // group-uniform
-      float4 d = a.dxp ? ld4(a.dxp + (int64_t)p * a.lddxp + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (a.dagg_next != nullptr) d = prop_row<G>(a.rowptr_n, a.rowend_n, a.col_n, a.dinv_n, a.self_w_n, a.dagg_next, a.lddagg, p, lig, co);
+      else if (a.dxp != nullptr) d = ld4(a.dxp + (int64_t)p * a.lddxp + co);
       d.x += dm.x * inv_k + (am.x == p ? dx.x : 0.f);
       d.y += dm.y * inv_k + (am.y == p ? dx.y : 0.f);
       d.z += dm.z * inv_k + (am.z == p ? dx.z : 0.f);
@@ -986,7 +1034,9 @@ int tsgnn_sag_pool_graph_f32(const float* y, int64_t ldy, const int* rowptr, con
                              const float* self_w, const float* w_s, const float* b_s, const int* graph_ptr, const int* graph_ptr_new,
                              int B, int max_seg, int F, float* score, int* perm, int* new_id, float* xp, int64_t ldo, int* cnt,
                              float* out, int64_t ldout, int* arg, int accumulate, int* rowptr_new, int* rowend_new, int* col_new,
-                             float* dinv_new, float* self_w_new, tsgnn_stream_t stream) {
+                             float* dinv_new, float* self_w_new, float* agg_next, int64_t ldagg, tsgnn_stream_t stream) {
+  if (agg_next && (!col_new || ldagg < F)) return TSGNN_EINVAL;
+  if (agg_next && (ldagg % 4 || !aligned16(agg_next))) return TSGNN_EUNSUPPORTED;
   if ((col_new != nullptr) != (rowptr_new != nullptr) || (col_new != nullptr) != (rowend_new != nullptr) ||
       (col_new != nullptr) != (dinv_new != nullptr) || (col_new != nullptr) != (self_w_new != nullptr))
     return TSGNN_EINVAL;
@@ -1000,7 +1050,7 @@ int tsgnn_sag_pool_graph_f32(const float* y, int64_t ldy, const int* rowptr, con
   while (np < max_seg) np <<= 1;
   const size_t lds = (size_t)np * (8 + 4 + 4) + (size_t)PG_RGROUPS * F * 12 + (np <= PG_RANK_MAX ? (size_t)np * 8 : 0);
   PoolGraphArgs a{y, ldy, rowptr, rowend, col, dinv, self_w, w_s, b_s, graph_ptr, graph_ptr_new, score, perm, new_id, xp, ldo, cnt,
-                  out, ldout, arg, accumulate, F, rowptr_new, rowend_new, col_new, dinv_new, self_w_new};
+                  out, ldout, arg, accumulate, F, rowptr_new, rowend_new, col_new, dinv_new, self_w_new, agg_next, ldagg};
 #define PG_LAUNCH(GG)                                                                                                          \
   do {                                                                                                                         \
     if (max_seg <= PG_SMALL_NODES) {                                                                                           \
@@ -1069,7 +1119,11 @@ int tsgnn_sag_pool_graph_bwd_f32(const float* y, int64_t ldy, const float* score
                                  const int* graph_ptr_new, const int* arg, const float* dxp, int64_t lddxp, const float* dread,
                                  int64_t lddr, const int* rowptr, const int* rowend, const int* col, const float* dinv,
                                  const float* self_w, const float* w_s, int B, int max_seg, int F, float* du, int64_t lddu, float* part,
-                                 float* dws, float* dbs, tsgnn_stream_t stream) {
+                                 float* dws, float* dbs, const float* dagg_next, int64_t lddagg, const int* rowptr_n,
+                                 const int* rowend_n, const int* col_n, const float* dinv_n, const float* self_w_n,
+                                 tsgnn_stream_t stream) {
+  if (dagg_next && (dxp || !rowptr_n || !rowend_n || !col_n || !dinv_n || !self_w_n || lddagg < F)) return TSGNN_EINVAL;
+  if (dagg_next && (lddagg % 4 || !aligned16(dagg_next))) return TSGNN_EUNSUPPORTED;
   if (!y || !score || !new_id || !graph_ptr || !graph_ptr_new || !arg || !dread || !rowptr || !dinv || !self_w || !w_s || !du || !part ||
       !dws || !dbs || B <= 0 || max_seg < 0)
     return TSGNN_EINVAL;
@@ -1078,7 +1132,7 @@ int tsgnn_sag_pool_graph_bwd_f32(const float* y, int64_t ldy, const float* score
     return TSGNN_EUNSUPPORTED;
   if (max_seg == 0) return TSGNN_OK;
   PoolGraphBwdArgs a{y, ldy, score, new_id, graph_ptr, graph_ptr_new, arg, dxp, lddxp, dread, lddr, rowptr, rowend, col, dinv, self_w,
-                     w_s, du, lddu, part, F};
+                     w_s, du, lddu, part, F, dagg_next, lddagg, rowptr_n, rowend_n, col_n, dinv_n, self_w_n};
   const int G_ = group_of(F);
   const int bt = max_seg <= PG_SMALL_NODES ? 256 : PG_THREADS;
   const size_t lds = sizeof(float) * (2 * (size_t)((max_seg + 3) & ~3) + (size_t)(bt / G_) * F);

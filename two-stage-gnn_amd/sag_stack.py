@@ -16,9 +16,10 @@ A step is therefore capturable in a hipGraph.  Per level (csrc/sagpool.hip):
               out += [max || mean](xp)          (network.py:36,40,44 and the sum :46)
               A'  = filter(A)                   (symmetric graphs: entries from the graph's old segment base, explicit row
                                                  ends, next level's coefficients; layers.py:23-24)
+              agg' = A^' xp                     (the NEXT level's aggregation: its rows, CSR and coefficients are this block's)
             (larger graphs / directed edge lists: the same steps as separate launches + scan + tsgnn_csr_filter_fill)
-  backward  one workgroup per graph: pooled-row gradients -> score layer backward -> du ; reduction of dw_s / db_s partials ;
-            dW, db in one pass ; dagg = du W^T ; dx = A^ dagg
+  backward  one workgroup per graph: [dxp = A^' dagg' of the next level per kept row ->] pooled-row gradients -> score layer
+            backward -> du ; reduction of dw_s / db_s partials ; dW, db in one pass ; dagg = du W^T ; level 0: dx = A^ dagg
 ReLU is applied by the consumers of ``y`` (it is stored pre-activation), so no activation tensor is written.
 """
 import numpy as np
@@ -119,7 +120,10 @@ def _linear_t(du, w):
     return dz
 
 
-PER_GRAPH_POOL = True        # level tail (score -> top-k -> gather -> readout) as one workgroup per graph when graphs are small
+PER_GRAPH_POOL = True           # level tail (score -> top-k -> gather -> readout) as one workgroup per graph when graphs are small
+FUSED_NEXT_PROPAGATE = True     # ... which then also forms the next level's aggregation and, backward, takes the next level's
+                                # dagg instead of dxp (A^ applied per kept row in the kernel): two launches less per pooled level
+FUSED_NEXT_PROPAGATE_MAX_GRAPHS = 1024   # a launch-count saving: 207 vs 213 us at 128 graphs, 1.21 vs 1.17 ms at 8,192 (few lane groups per block)
 
 
 def _al16(t):
@@ -154,13 +158,18 @@ class _SagStack(torch.autograd.Function):
         pool_graph_max = int(nat.lib().tsgnn_sag_pool_graph_max_nodes())
         saved = []
         xin = x
+        agg_next = None
         for l in range(depth):
             L, Ln = plan.levels[l], plan.levels[l + 1]
             N, K = L.N, Ln.N
             W, b, ws, bs = params[4 * l: 4 * l + 4]
             W, b = _al16(W.contiguous()), _al16(b.contiguous())
             wsv = _al16(ws.contiguous().view(-1))
-            agg, _ = propagate(rowptr, col, dinv, self_w, xin, N, rowend=rowend)
+            if agg_next is not None:
+                agg = agg_next                                  # formed by the previous level's per-graph kernel
+            else:
+                agg, _ = propagate(rowptr, col, dinv, self_w, xin, N, rowend=rowend)
+            agg_next = None
             y = _linear(agg, W, b)
             perm, new_id = _i32(max(K, 1), device=dev), _i32(max(N, 1), device=dev)
             xp, cnt = _f32(K, H, device=dev), _i32(max(K, 1), device=dev)
@@ -174,11 +183,13 @@ class _SagStack(torch.autograd.Function):
                 if fused_filter:
                     rp_n, re_n, col_n = _i32(K, device=dev), _i32(K, device=dev), _i32(nnz_bound, device=dev)
                     dinv_n, self_w_n = _f32(K, device=dev), _f32(K, device=dev)
+                    if FUSED_NEXT_PROPAGATE and B <= FUSED_NEXT_PROPAGATE_MAX_GRAPHS:
+                        agg_next = _f32(K, H, device=dev)       # the next level's A^ xp, formed by the same launch
                 else:
                     rp_n = re_n = col_n = dinv_n = self_w_n = None
                 nat.call("sag_pool_graph_f32", y, y.stride(0), rowptr, rowend, col, dinv, self_w, wsv, bs, L.gp, Ln.gp, B, L.max_seg, H,
                          score, perm, new_id, xp, xp.stride(0), cnt, read, read.stride(0), arg, int(l > 0),
-                         rp_n, re_n, col_n, dinv_n, self_w_n)
+                         rp_n, re_n, col_n, dinv_n, self_w_n, agg_next, H if agg_next is not None else 0)
             else:
                 if rowend is not None:
                     raise RuntimeError("explicit row ends only arise from the per-graph kernel, whose size limit applies to every level")
@@ -186,7 +197,8 @@ class _SagStack(torch.autograd.Function):
                 nat.call("topk_segments_f32", score, L.gp, Ln.gp, B, L.max_seg, perm, new_id)
                 nat.call("sag_pool_gather_f32", y, y.stride(0), score, perm, new_id, rowptr, col, K, H, 1, xp, xp.stride(0), cnt)
                 nat.call("sag_readout_f32", xp, xp.stride(0), Ln.gp, B, H, int(l > 0), read, read.stride(0), arg)
-            saved.append((xin, agg, y, score, new_id, arg, rowptr, col, rowptr_t, col_t, dinv, self_w, W, wsv, rowend))
+            saved.append((xin, agg, y, score, new_id, arg, rowptr, col, rowptr_t, col_t, dinv, self_w, W, wsv, rowend,
+                          agg_next is not None))
             if fused_filter:
                 rowptr, col, rowend, rowptr_t, col_t, dinv, self_w = rp_n, col_n, re_n, rp_n, col_n, dinv_n, self_w_n
             elif l + 1 < depth:                                 # the adjacency after the last pool is never used
@@ -219,10 +231,11 @@ class _SagStack(torch.autograd.Function):
         sym = ctx.sym
         dxp = None
         dx = None
+        nxt = None          # (dagg, rowptr, rowend, col, dinv, self_w) of level l + 1 when this level's kernel forms dxp itself
         for l in range(depth - 1, -1, -1):
             L, Ln = plan.levels[l], plan.levels[l + 1]
             N = L.N
-            xin, agg, y, score, new_id, arg, rowptr, col, rowptr_t, col_t, dinv, self_w, W, wsv, rowend = ctx.saved_levels[l]
+            xin, agg, y, score, new_id, arg, rowptr, col, rowptr_t, col_t, dinv, self_w, W, wsv, rowend, _ = ctx.saved_levels[l]
             dyb = _f32(N, H, device=dev)
             dws, dbs = _f32(H, device=dev), _f32(1, device=dev)
             if sym and L.max_seg <= pool_graph_max and PER_GRAPH_POOL:
@@ -230,8 +243,11 @@ class _SagStack(torch.autograd.Function):
                 part = _f32(L.B * (H + 4), device=dev)
                 nat.call("sag_pool_graph_bwd_f32", y, y.stride(0), score, new_id, L.gp, Ln.gp, arg, dxp,
                          dxp.stride(0) if dxp is not None else 0, dread, dread.stride(0), rowptr, rowend, col, dinv, self_w, wsv,
-                         L.B, L.max_seg, H, dyb, dyb.stride(0), part, dws, dbs)
+                         L.B, L.max_seg, H, dyb, dyb.stride(0), part, dws, dbs,
+                         *((nxt[0], nxt[0].stride(0)) + nxt[1:] if nxt is not None else (None, 0, None, None, None, None, None)))
             else:
+                if nxt is not None:
+                    raise RuntimeError("the in-kernel gradient propagate belongs to the per-graph backward")
                 dscore = _f32(N, device=dev)
                 nat.call("sag_pool_bwd_f32", y, y.stride(0), score, new_id, Ln.row_graph, Ln.gp, arg, dxp,
                          dxp.stride(0) if dxp is not None else 0, dread, dread.stride(0), N, H, 1, dyb, dyb.stride(0), dscore)
@@ -244,6 +260,12 @@ class _SagStack(torch.autograd.Function):
             grads[4 * l: 4 * l + 4] = [dW, db, dws.view(-1, 1), dbs]
             if l > 0 or ctx.x_needs_grad:
                 dagg = _linear_t(dyb, W)
+                nxt = None
+                if l > 0 and ctx.saved_levels[l - 1][-1]:
+                    # level l - 1 ran the fused per-graph forward (symmetric, filter in-kernel): its backward kernel takes
+                    # dagg and this level's CSR and forms dxp = A^ dagg per kept row itself
+                    nxt, dxp = (dagg, rowptr, rowend, col, dinv, self_w), None
+                    continue
                 dxin, _ = propagate(rowptr_t, col_t, dinv, self_w, dagg, N, rowend=rowend)
                 if l > 0:
                     dxp = dxin
