@@ -399,6 +399,7 @@ __global__ __launch_bounds__(BT) void sag_pool_graph_kernel(PoolGraphArgs a) {
   const int g0 = a.gp[b], n = a.gp[b + 1] - g0;
   const int k0 = a.gp_new[b], k = a.gp_new[b + 1] - k0;
   if (n <= 0) return;
+  TR(0);
   int np = 1;
   while (np < n) np <<= 1;
   unsigned long long* keys = pg_smem;                                   // [np]
@@ -409,38 +410,60 @@ __global__ __launch_bounds__(BT) void sag_pool_graph_kernel(PoolGraphArgs a) {
   int* rarg = reinterpret_cast<int*>(rsum + PG_RGROUPS * a.F);          // [PG_RGROUPS][F]
   constexpr int NG = BT / G;
   constexpr int RG = NG < PG_RGROUPS ? NG : PG_RGROUPS;                 // lane groups of the gather / readout phase (LDS laid out for PG_RGROUPS)
+  // the pooled rows' CSR bounds and coefficients, kept for the next level's aggregation at the end of the kernel
+  int* rpn = reinterpret_cast<int*>(np <= PG_RANK_MAX ? reinterpret_cast<float*>(rarg + PG_RGROUPS * a.F) + 2 * np
+                                                       : reinterpret_cast<float*>(rarg + PG_RGROUPS * a.F));   // [np] row begin
+  int* ren = rpn + np;                                                  // [np] row end
+  float* dvn = reinterpret_cast<float*>(ren + np);                      // [np] dinv'
+  float* swn = dvn + np;                                                // [np] self_w'
   const int lig = tid & (G - 1), grp = tid / G;
   const int nvec = a.F >> 2;
   const bool live = lig < nvec;
   const int co = live ? 4 * lig : 0;
   const float4 wv = live ? ld4(a.w_s + co) : make_float4(0.f, 0.f, 0.f, 0.f);
-  // (1) t_j = relu(y_j) . w_s
-  for (int j = grp; j < n; j += NG) {
-    float d = live ? dot4(relu4(ld4(a.y + (int64_t)(g0 + j) * a.ldy + co)), wv) : 0.f;
-    d = group_sum<G>(d);
-    if (lig == 0) t[j] = d;
+  // (1) t_j = relu(y_j) . w_s   (four rows per lane group in flight: one round trip for up to 4 * NG rows)
+  for (int j0 = grp; j0 < n; j0 += 4 * NG) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = j0 + u * NG;
+      v[u] = (live && j < n) ? ld4(a.y + (int64_t)(g0 + j) * a.ldy + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = j0 + u * NG;
+      const float d = group_sum<G>(dot4(relu4(v[u]), wv));
+      if (lig == 0 && j < n) t[j] = d;
+    }
   }
   __syncthreads();
+  TR(1);
   // (2) scores and sort keys
+  // The walks over the adjacency (here, the kept-neighbour counts and the filter below) give a row to EG = 8 lanes: a TU graph has
+  // tens of nodes and a handful of neighbours per node, so one pass of the block covers the graph and a row costs three dependent
+  // round trips (row pointer -> entries -> coefficients) instead of two per neighbour of a serial walk (traced: 2.5 -> 1.5 us).
+  constexpr int EG = 8;
+  const int sub = tid & (EG - 1), jr = tid / EG;
   const float bs = a.b_s ? a.b_s[0] : 0.f;
-  for (int j = tid; j < np; j += BT) {
+  for (int j = jr; j < np; j += BT / EG) {                  // uniform per lane group
     unsigned long long key = 0ull;                                      // padding sorts last
     if (j < n) {
       const int r = g0 + j;
       float acc = 0.f;
       const int e1 = a.rowend ? a.rowend[r] : a.rowptr[r + 1];
-#pragma unroll 8
-      for (int e = a.rowptr[r]; e < e1; ++e) {             // neighbour ids, then their coefficients: two round trips per batch of 8
+      for (int e = a.rowptr[r] + sub; e < e1; e += EG) {
         const int c = a.col[e];
         if ((unsigned)(c - g0) < (unsigned)n) acc = fmaf(a.dinv[c], t[c - g0], acc);   // graphs of a batch are disjoint (PyG collate)
       }
+      acc = group_sum<EG>(acc);
       const float sc = fmaf(a.dinv[r], acc, a.self_w[r] * t[j]) + bs;
-      a.score[r] = sc;
+      if (sub == 0) a.score[r] = sc;
       key = ((unsigned long long)f32_ordered(sc) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)j);
     }
-    keys[j] = key;
+    if (sub == 0) keys[j] = key;
   }
   __syncthreads();
+  TR(2);
   // (3) sort, descending.  Small graphs (the common case: <= 1,024 nodes) by rank: thread i counts the keys above key i
   // (LDS broadcast reads, no barrier per step — a bitonic network on 256 keys is 36 barriers of a 16-wave block) and drops
   // its key at that position of a second array; keys are unique (they carry the node index).
@@ -473,6 +496,7 @@ __global__ __launch_bounds__(BT) void sag_pool_graph_kernel(PoolGraphArgs a) {
       }
     }
   }
+  TR(3);
   // (4) perm and the relabelling map
   for (int i = tid; i < n; i += BT) {
     const int j = (int)(0xFFFFFFFFu - (unsigned)(keys[i] & 0xFFFFFFFFull));
@@ -482,6 +506,7 @@ __global__ __launch_bounds__(BT) void sag_pool_graph_kernel(PoolGraphArgs a) {
     a.new_id[g0 + j] = id;
   }
   __syncthreads();
+  TR(4);
   // (5) gated gather of the kept rows + their max || mean readout  (PG_RGROUPS lane groups; ties of the max -> smallest row)
   if (grp < RG) {
     float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY), s = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -507,26 +532,29 @@ __global__ __launch_bounds__(BT) void sag_pool_graph_kernel(PoolGraphArgs a) {
       *reinterpret_cast<int4*>(rarg + grp * a.F + co) = am;
     }
   }
+  TR(5);
   // (6) kept neighbours of every kept row: the CSR filter's counts — and, when asked, the filter itself (layers.py:23-24):
   // block scan of the counts, rows laid out from the graph's old segment base, entries relabelled in their original order,
   // and the next level's gcn_norm coefficients
   int* cl = reinterpret_cast<int*>(t);                                  // [np] counts, then exclusive offsets (t is dead by now)
-  for (int p = tid; p < np; p += BT) {
+  for (int p = jr; p < np; p += BT / EG) {
     int c = 0;
     if (p < k) {
       const int j = (int)(0xFFFFFFFFu - (unsigned)(keys[p] & 0xFFFFFFFFull));
       const int r = g0 + j;
       const int e1 = a.rowend ? a.rowend[r] : a.rowptr[r + 1];
-#pragma unroll 8
-      for (int e = a.rowptr[r]; e < e1; ++e) {
+      float cf = 0.f;                                                   // counts <= 4,096: exact in fp32
+      for (int e = a.rowptr[r] + sub; e < e1; e += EG) {
         const int cj = a.col[e] - g0;
-        c += ((unsigned)cj < (unsigned)n && nid[cj] >= 0) ? 1 : 0;
+        cf += ((unsigned)cj < (unsigned)n && nid[cj] >= 0) ? 1.f : 0.f;
       }
-      a.cnt[k0 + p] = c;
+      c = (int)group_sum<EG>(cf);
+      if (sub == 0) a.cnt[k0 + p] = c;
     }
-    cl[p] = c;
+    if (sub == 0) cl[p] = c;
   }
   __syncthreads();
+  TR(6);
   if (a.col_new != nullptr) {
     // exclusive scan of cl[0..np): four consecutive counts per thread, wave scan, wave totals through LDS (np <= 4,096)
     __shared__ int wsum[BT / 64];
@@ -553,36 +581,75 @@ __global__ __launch_bounds__(BT) void sag_pool_graph_kernel(PoolGraphArgs a) {
     }
     __syncthreads();
     const int base = a.rowptr[g0];
-    for (int p = tid; p < k; p += BT) {
+    const int gsh = (tid & 63) & ~(EG - 1);                             // this lane group's bits of a wave ballot
+    for (int p = jr; p < k; p += BT / EG) {                             // uniform per lane group: its lanes vote together
       const int j = (int)(0xFFFFFFFFu - (unsigned)(keys[p] & 0xFFFFFFFFull));
       const int r = g0 + j;
-      const int e1 = a.rowend ? a.rowend[r] : a.rowptr[r + 1];
+      const int e0 = a.rowptr[r], e1 = a.rowend ? a.rowend[r] : a.rowptr[r + 1];
       const int o0 = base + cl[p];
       int o = o0;
       bool has_self = false;
-      for (int e = a.rowptr[r]; e < e1; ++e) {
-        const int cj = a.col[e] - g0;
-        const int id = ((unsigned)cj < (unsigned)n) ? nid[cj] : -1;
+      for (int eb = e0; eb < e1; eb += EG) {                            // EG entries per step, kept ones compacted in order
+        const int e = eb + sub;
+        int id = -1;
+        if (e < e1) {
+          const int cj = a.col[e] - g0;
+          if ((unsigned)cj < (unsigned)n) id = nid[cj];
+        }
+        const unsigned gm = (unsigned)(__ballot(id >= 0) >> gsh) & ((1u << EG) - 1u);
         if (id >= 0) {
-          a.col_new[o++] = id;
+          a.col_new[o + __popc(gm & ((1u << sub) - 1u))] = id;
           has_self |= (id == k0 + p);
         }
+        o += __popc(gm);
       }
-      a.rowptr_new[k0 + p] = o0;
-      a.rowend_new[k0 + p] = o;
-      const float d = (float)(o - o0) + (has_self ? 0.f : 1.f);
-      const float di = 1.0f / sqrtf(d);
-      a.dinv_new[k0 + p] = di;
-      a.self_w_new[k0 + p] = has_self ? 0.f : di * di;
+      has_self = (((unsigned)(__ballot(has_self) >> gsh)) & ((1u << EG) - 1u)) != 0u;
+      if (sub == 0) {
+        a.rowptr_new[k0 + p] = o0;
+        a.rowend_new[k0 + p] = o;
+        const float d = (float)(o - o0) + (has_self ? 0.f : 1.f);
+        const float di = 1.0f / sqrtf(d);
+        a.dinv_new[k0 + p] = di;
+        a.self_w_new[k0 + p] = has_self ? 0.f : di * di;
+        rpn[p] = o0; ren[p] = o; dvn[p] = di; swn[p] = has_self ? 0.f : di * di;
+      }
     }
   }
   __syncthreads();
+  TR(7);
   if (a.agg_next != nullptr) {                              // pooled rows, their CSR and coefficients were written above by this block
+    // prop_row's arithmetic with the row bounds and coefficients from LDS: entries -> pooled rows are the only global hops
     for (int p = grp; p < k; p += NG) {
-      const float4 o = prop_row<G>(a.rowptr_new, a.rowend_new, a.col_new, a.dinv_new, a.self_w_new, a.xp, a.ldo, k0 + p, lig, co);
-      if (live) *reinterpret_cast<float4*>(a.agg_next + (int64_t)(k0 + p) * a.ldagg + co) = o;
+      const int e0 = rpn[p], e1 = ren[p];
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int eb = e0; eb < e1; eb += G) {
+        const int me = eb + lig;
+        const int cj = (me < e1) ? a.col_new[me] : k0;
+        const float dj = (me < e1) ? dvn[cj - k0] : 0.f;
+        const int cnt = min(G, e1 - eb);
+        int q = 0;
+        for (; q + 4 <= cnt; q += 4) {
+          const int j0 = __shfl(cj, q, G), j1 = __shfl(cj, q + 1, G), j2 = __shfl(cj, q + 2, G), j3 = __shfl(cj, q + 3, G);
+          const float4 v0 = ld4(a.xp + (int64_t)j0 * a.ldo + co);
+          const float4 v1 = ld4(a.xp + (int64_t)j1 * a.ldo + co);
+          const float4 v2 = ld4(a.xp + (int64_t)j2 * a.ldo + co);
+          const float4 v3 = ld4(a.xp + (int64_t)j3 * a.ldo + co);
+          fma4(acc, __shfl(dj, q, G), v0); fma4(acc, __shfl(dj, q + 1, G), v1);
+          fma4(acc, __shfl(dj, q + 2, G), v2); fma4(acc, __shfl(dj, q + 3, G), v3);
+        }
+        for (; q < cnt; ++q) {
+          const int j = __shfl(cj, q, G);
+          fma4(acc, __shfl(dj, q, G), ld4(a.xp + (int64_t)j * a.ldo + co));
+        }
+      }
+      const float di = dvn[p], sw = swn[p];
+      const float4 xs = ld4(a.xp + (int64_t)(k0 + p) * a.ldo + co);
+      if (live)
+        *reinterpret_cast<float4*>(a.agg_next + (int64_t)(k0 + p) * a.ldagg + co) =
+            make_float4(fmaf(di, acc.x, sw * xs.x), fmaf(di, acc.y, sw * xs.y), fmaf(di, acc.z, sw * xs.z), fmaf(di, acc.w, sw * xs.w));
     }
   }
+  TR(8);
   for (int f = tid; f < a.F; f += BT) {
     float m = rmax[f], s = rsum[f];
     int am = rarg[f];
@@ -599,6 +666,8 @@ __global__ __launch_bounds__(BT) void sag_pool_graph_kernel(PoolGraphArgs a) {
     else { o[f] = m; o[a.F + f] = mean; }
     a.arg[(int64_t)b * a.F + f] = am;
   }
+  TR(9);
+  TR_END();
 }
 
 // ---------------------------------------------------------------- filter_adj on CSR (layers.py:23-24)
@@ -811,17 +880,23 @@ template <int G, int BT>
 __global__ __launch_bounds__(BT) void sag_pool_graph_bwd_kernel(PoolGraphBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float pb_smem[];
   constexpr int NG = BT / G;
+  constexpr int EG = 8;                       // lanes per row of the adjacency walk (B), as in the forward kernel
   const int b = blockIdx.x, tid = threadIdx.x;
   const int g0 = a.gp[b], n = a.gp[b + 1] - g0;
-  const int kb = a.gp_new[b + 1] - a.gp_new[b];
+  const int k0 = a.gp_new[b], kb = a.gp_new[b + 1] - k0;
   const int F = a.F, nvec = F >> 2;
+  const int n4 = (max(n, 0) + 3) & ~3;
   float* ds = pb_smem;                        // [n] dscore
-  float* dt = ds + ((n + 3) & ~3);            // [n]
-  float* racc = dt + ((n + 3) & ~3);          // [NG][F] partial dw_s
+  float* dt = ds + n4;                        // [n]
+  int* nidl = reinterpret_cast<int*>(dt + n4);   // [n] new id of old row j, -1: dropped
+  int* rowof = nidl + n4;                     // [kb] old row (offset in the graph) of kept row q
+  float* dvn = reinterpret_cast<float*>(rowof + n4);   // [kb] next level's dinv of kept row q
+  float* racc = dvn + n4;                     // [NG][F] partial dw_s
   const int lig = tid & (G - 1), grp = tid / G;
   const bool live = lig < nvec;
   const int co = live ? 4 * lig : 0;
   const float inv_k = 1.0f / (float)max(kb, 1);
+  TR(0);
   float4 dm = make_float4(0.f, 0.f, 0.f, 0.f), dx = dm;
   int4 am = make_int4(-1, -1, -1, -1);
   if (live) {
@@ -829,63 +904,114 @@ __global__ __launch_bounds__(BT) void sag_pool_graph_bwd_kernel(PoolGraphBwdArgs
     dx = ld4(a.dread + (int64_t)b * a.lddr + co);
     am = *reinterpret_cast<const int4*>(a.arg + (int64_t)b * F + co);
   }
-  // (A) gradient of the gated gather + readouts per row: du <- dtot * gate (for now), dscore -> LDS
-  for (int j = grp; j < n; j += NG) {
-    const int r = g0 + j;
-    const int p = a.new_id[r];
-    float4 gq = make_float4(0.f, 0.f, 0.f, 0.f);
-    float dsv = 0.f;
-    if (p >= 0) {                                                       // group-uniform
-      float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (a.dagg_next != nullptr) d = prop_row<G>(a.rowptr_n, a.rowend_n, a.col_n, a.dinv_n, a.self_w_n, a.dagg_next, a.lddagg, p, lig, co);
-      else if (a.dxp != nullptr) d = ld4(a.dxp + (int64_t)p * a.lddxp + co);
-      d.x += dm.x * inv_k + (am.x == p ? dx.x : 0.f);
-      d.y += dm.y * inv_k + (am.y == p ? dx.y : 0.f);
-      d.z += dm.z * inv_k + (am.z == p ? dx.z : 0.f);
-      d.w += dm.w * inv_k + (am.w == p ? dx.w : 0.f);
-      const float gate = tanhf(a.score[r]);
-      const float4 v = relu4(ld4(a.y + (int64_t)r * a.ldy + co));
-      float dot = live ? dot4(d, v) : 0.f;
-      dot = group_sum<G>(dot);
-      dsv = dot * (1.f - gate * gate);
-      gq = make_float4(d.x * gate, d.y * gate, d.z * gate, d.w * gate);
-    }
-    if (live) *reinterpret_cast<float4*>(a.du + (int64_t)r * a.lddu + co) = gq;
-    if (lig == 0) ds[j] = dsv;
-  }
-  __syncthreads();
-  // (B) dt = A^ dscore (the score layer's propagate; symmetric adjacency)
+  // the relabelling map of the graph, its inverse and the kept rows' coefficients: two round trips for the whole graph
   for (int j = tid; j < n; j += BT) {
-    const int r = g0 + j;
-    const int e1 = a.rowend ? a.rowend[r] : a.rowptr[r + 1];
-    float acc = 0.f;
-#pragma unroll 8
-    for (int e = a.rowptr[r]; e < e1; ++e) {
-      const int c = a.col[e];
-      if ((unsigned)(c - g0) < (unsigned)n) acc = fmaf(a.dinv[c], ds[c - g0], acc);
+    const int p = a.new_id[g0 + j];
+    nidl[j] = p;
+    if (p >= 0) {
+      rowof[p - k0] = j;
+      if (a.dagg_next != nullptr) dvn[p - k0] = a.dinv_n[p];
+    } else {
+      ds[j] = 0.f;                                                       // dropped rows carry no score gradient
     }
-    dt[j] = fmaf(a.dinv[r], acc, a.self_w[r] * ds[j]);
   }
   __syncthreads();
-  // (C) du = (du + dt w_s) [y > 0]; partial sums of dw_s = sum dt relu(y)
+  // (A) kept rows only: gradient of the gated gather + readouts (dxp = A^' dagg' formed here when the next level hands over
+  // its dagg), du <- dtot * gate (for now), dscore -> LDS.  Dropped rows have du = 0: (C) does not read them.
+  for (int q = grp; q < kb; q += NG) {
+    const int j = rowof[q], r = g0 + j, p = k0 + q;
+    const float sc = a.score[r];
+    const float4 yv = live ? ld4(a.y + (int64_t)r * a.ldy + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.dagg_next != nullptr) {
+      const int e0 = a.rowptr_n[p], e1 = a.rowend_n[p];
+      const float sw = a.self_w_n[p];
+      const float4 xs = ld4(a.dagg_next + (int64_t)p * a.lddagg + co);
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int eb = e0; eb < e1; eb += G) {                              // prop_row's arithmetic, coefficients from LDS
+        const int me = eb + lig;
+        const int cj = (me < e1) ? a.col_n[me] : k0;
+        const float dj = (me < e1) ? dvn[cj - k0] : 0.f;
+        const int cnt = min(G, e1 - eb);
+        int u = 0;
+        for (; u + 4 <= cnt; u += 4) {
+          const int j0 = __shfl(cj, u, G), j1 = __shfl(cj, u + 1, G), j2 = __shfl(cj, u + 2, G), j3 = __shfl(cj, u + 3, G);
+          const float4 v0 = ld4(a.dagg_next + (int64_t)j0 * a.lddagg + co);
+          const float4 v1 = ld4(a.dagg_next + (int64_t)j1 * a.lddagg + co);
+          const float4 v2 = ld4(a.dagg_next + (int64_t)j2 * a.lddagg + co);
+          const float4 v3 = ld4(a.dagg_next + (int64_t)j3 * a.lddagg + co);
+          fma4(acc, __shfl(dj, u, G), v0); fma4(acc, __shfl(dj, u + 1, G), v1);
+          fma4(acc, __shfl(dj, u + 2, G), v2); fma4(acc, __shfl(dj, u + 3, G), v3);
+        }
+        for (; u < cnt; ++u) {
+          const int jj = __shfl(cj, u, G);
+          fma4(acc, __shfl(dj, u, G), ld4(a.dagg_next + (int64_t)jj * a.lddagg + co));
+        }
+      }
+      const float di = dvn[q];
+      d = make_float4(fmaf(di, acc.x, sw * xs.x), fmaf(di, acc.y, sw * xs.y), fmaf(di, acc.z, sw * xs.z), fmaf(di, acc.w, sw * xs.w));
+    } else if (a.dxp != nullptr) {
+      d = ld4(a.dxp + (int64_t)p * a.lddxp + co);
+    }
+    d.x += dm.x * inv_k + (am.x == p ? dx.x : 0.f);
+    d.y += dm.y * inv_k + (am.y == p ? dx.y : 0.f);
+    d.z += dm.z * inv_k + (am.z == p ? dx.z : 0.f);
+    d.w += dm.w * inv_k + (am.w == p ? dx.w : 0.f);
+    const float gate = tanhf(sc);
+    float dot = live ? dot4(d, relu4(yv)) : 0.f;
+    dot = group_sum<G>(dot);
+    if (live) *reinterpret_cast<float4*>(a.du + (int64_t)r * a.lddu + co) = make_float4(d.x * gate, d.y * gate, d.z * gate, d.w * gate);
+    if (lig == 0) ds[j] = dot * (1.f - gate * gate);
+  }
+  __syncthreads();
+  TR(1);
+  // (B) dt = A^ dscore (the score layer's propagate; symmetric adjacency), EG lanes per row
+  {
+    const int sub = tid & (EG - 1), jr = tid / EG;
+    for (int j = jr; j < n; j += BT / EG) {
+      const int r = g0 + j;
+      const int e1 = a.rowend ? a.rowend[r] : a.rowptr[r + 1];
+      float acc = 0.f;
+      for (int e = a.rowptr[r] + sub; e < e1; e += EG) {
+        const int c = a.col[e];
+        if ((unsigned)(c - g0) < (unsigned)n) acc = fmaf(a.dinv[c], ds[c - g0], acc);
+      }
+      acc = group_sum<EG>(acc);
+      if (sub == 0) dt[j] = fmaf(a.dinv[r], acc, a.self_w[r] * ds[j]);
+    }
+  }
+  __syncthreads();
+  TR(2);
+  // (C) du = (du + dt w_s) [y > 0]; partial sums of dw_s = sum dt relu(y)   (two rows per lane group in flight)
   const float4 w = live ? ld4(a.w_s + co) : make_float4(0.f, 0.f, 0.f, 0.f);
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int j = grp; j < n; j += NG) {
-    const int r = g0 + j;
-    const float t = dt[j];
-    if (live) {
-      const float4 v = ld4(a.y + (int64_t)r * a.ldy + co);
-      float4 d = ld4(a.du + (int64_t)r * a.lddu + co);
-      d.x = v.x > 0.f ? fmaf(t, w.x, d.x) : 0.f;
-      d.y = v.y > 0.f ? fmaf(t, w.y, d.y) : 0.f;
-      d.z = v.z > 0.f ? fmaf(t, w.z, d.z) : 0.f;
-      d.w = v.w > 0.f ? fmaf(t, w.w, d.w) : 0.f;
-      *reinterpret_cast<float4*>(a.du + (int64_t)r * a.lddu + co) = d;
-      fma4(acc, t, relu4(v));
+  for (int j0 = grp; j0 < n; j0 += 2 * NG) {
+    float4 v[2], d[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int j = j0 + u * NG;
+      const bool ok = live && j < n;
+      v[u] = ok ? ld4(a.y + (int64_t)(g0 + j) * a.ldy + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+      d[u] = (ok && nidl[j] >= 0) ? ld4(a.du + (int64_t)(g0 + j) * a.lddu + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int j = j0 + u * NG;
+      if (live && j < n) {
+        const float t = dt[j];
+        float4 o;
+        o.x = v[u].x > 0.f ? fmaf(t, w.x, d[u].x) : 0.f;
+        o.y = v[u].y > 0.f ? fmaf(t, w.y, d[u].y) : 0.f;
+        o.z = v[u].z > 0.f ? fmaf(t, w.z, d[u].z) : 0.f;
+        o.w = v[u].w > 0.f ? fmaf(t, w.w, d[u].w) : 0.f;
+        *reinterpret_cast<float4*>(a.du + (int64_t)(g0 + j) * a.lddu + co) = o;
+        fma4(acc, t, relu4(v[u]));
+      }
     }
   }
   if (live) *reinterpret_cast<float4*>(racc + grp * F + co) = acc;
   __syncthreads();
+  TR(3);
   // (D) this graph's partial sums, groups in order
   for (int f = tid; f < F; f += BT) {
     float sum = 0.f;
@@ -897,6 +1023,8 @@ __global__ __launch_bounds__(BT) void sag_pool_graph_bwd_kernel(PoolGraphBwdArgs
     for (int j = 0; j < n; ++j) sum += ds[j];
     a.part[(int64_t)b * (F + 4) + F] = sum;
   }
+  TR(4);
+  TR_END();
 }
 
 // single-launch scan of a short array (the per-row counts of one pooled level)
@@ -1048,7 +1176,7 @@ int tsgnn_sag_pool_graph_f32(const float* y, int64_t ldy, const int* rowptr, con
   if (max_seg == 0) return TSGNN_OK;
   int np = 1;
   while (np < max_seg) np <<= 1;
-  const size_t lds = (size_t)np * (8 + 4 + 4) + (size_t)PG_RGROUPS * F * 12 + (np <= PG_RANK_MAX ? (size_t)np * 8 : 0);
+  const size_t lds = (size_t)np * (8 + 4 + 4) + (size_t)PG_RGROUPS * F * 12 + (np <= PG_RANK_MAX ? (size_t)np * 8 : 0) + (size_t)np * 16;
   PoolGraphArgs a{y, ldy, rowptr, rowend, col, dinv, self_w, w_s, b_s, graph_ptr, graph_ptr_new, score, perm, new_id, xp, ldo, cnt,
                   out, ldout, arg, accumulate, F, rowptr_new, rowend_new, col_new, dinv_new, self_w_new, agg_next, ldagg};
 #define PG_LAUNCH(GG)                                                                                                          \
@@ -1135,7 +1263,7 @@ int tsgnn_sag_pool_graph_bwd_f32(const float* y, int64_t ldy, const float* score
                      w_s, du, lddu, part, F, dagg_next, lddagg, rowptr_n, rowend_n, col_n, dinv_n, self_w_n};
   const int G_ = group_of(F);
   const int bt = max_seg <= PG_SMALL_NODES ? 256 : PG_THREADS;
-  const size_t lds = sizeof(float) * (2 * (size_t)((max_seg + 3) & ~3) + (size_t)(bt / G_) * F);
+  const size_t lds = sizeof(float) * (5 * (size_t)((max_seg + 3) & ~3) + (size_t)(bt / G_) * F);
 #define PGB_LAUNCH(GG)                                                                                                             \
   do {                                                                                                                             \
     if (bt == 256) {                                                                                                               \
