@@ -236,6 +236,27 @@ def test_ell_fast_path_equals_csr(T, F, p_edge):
         torch.testing.assert_close(y_ell, y_csr, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("rows,K,N,trans_b,bias", [(1000, 92, 256, False, True), (1000, 256, 256, True, False), (1024, 64, 192, True, False),
+                                                    (37, 128, 132, False, True), (4096, 128, 256, False, False)])
+def test_rowgemm_column_split(T, rows, K, N, trans_b, bias):
+    """products without the row epilogue and more than 128 output columns on few row panels run as column blocks of 128
+    (grid.y): same result as the torch product, ragged last block and partial row panel included"""
+    from two_stage_gnn_amd import _native as nat
+    gen = torch.Generator(device="cuda").manual_seed(rows + N)
+    ldk = (K + 3) // 4 * 4
+    a = torch.randn(rows, ldk, generator=gen, device="cuda")
+    w = torch.randn(N, ldk, generator=gen, device="cuda") if trans_b else torch.randn(K, N, generator=gen, device="cuda")
+    b = torch.randn(N, generator=gen, device="cuda") if bias else None
+    c = torch.full((rows, N + 4), 7.0, device="cuda")
+    assert nat.lib().tsgnn_rowgemm_supported(a.data_ptr(), ldk, w.data_ptr(), w.stride(0), None, 0, K, N, int(trans_b))
+    nat.call("rowgemm_f32", a, ldk, w, w.stride(0), int(trans_b), b, c, c.stride(0), None, rows, K, N, 0, 0)
+    ref = a[:, :K].double() @ (w[:, :K].double().t() if trans_b else w.double())
+    if bias:
+        ref = ref + b.double()
+    torch.testing.assert_close(c[:, :N].double(), ref, rtol=1e-4, atol=1e-4)
+    assert bool((c[:, N:] == 7.0).all())                       # nothing written beyond the N columns
+
+
 @pytest.mark.parametrize("F,weighted", [(128, False), (64, True), (92, False)])
 def test_row_batched_gather_large(T, F, weighted):
     """>= 262144 rows switches to the row-batched kernel: must equal the one-row-per-group kernel bitwise."""

@@ -52,6 +52,37 @@ __global__ __launch_bounds__(512) void rowgemm_gather_ks2_kernel(RowGemmArgs g) 
   rowgemm_body<NT, TRANS_B, true, 2>(g, smem, blockIdx.x);
 }
 
+// column-split variant for products WITHOUT the row epilogue (no normalise: rows need not be whole): grid.y column blocks of
+// 32 * NT.  A 1,000-row x 256-column product (GAT projection, DiffPool's dagg = du W^T) is 32 panels on a 256-CU chip whose
+// waves each run two 32 x 32 tiles over the whole K: split in two, twice the CUs work and each wave's MFMA chain is half as long.
+template <int NT, bool TRANS_B>
+__global__ __launch_bounds__(256) void rowgemm_colsplit_kernel(RowGemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int n0 = (int)blockIdx.y * 32 * NT;
+  g.N = min(32 * NT, g.N - n0);
+  g.c += n0;
+  if (g.bias) g.bias += n0;
+  g.b += TRANS_B ? (int64_t)n0 * g.ldb : (int64_t)n0;
+  g.rinv = nullptr;
+  rowgemm_body<NT, TRANS_B, false>(g, smem, blockIdx.x);
+}
+
+inline bool rowgemm_colsplit_enabled() {
+  static const bool on = [] { const char* e = getenv("TSGNN_ROWGEMM_COLSPLIT"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
+template <bool TRANS_B>
+bool try_colsplit(const RowGemmArgs& g, hipStream_t s) {
+  const unsigned nblk = (unsigned)ceil_div64(g.rows, 32);
+  if (g.normalize || g.fill_rows > 0 || g.N <= 128 || (g.N % 4) || nblk == 0 || 2 * nblk > (unsigned)device_cu_count() ||
+      !rowgemm_colsplit_enabled())
+    return false;
+  const size_t lds = rowgemm_lds_bytes<4, TRANS_B, false>();
+  rowgemm_colsplit_kernel<4, TRANS_B><<<dim3(nblk, (unsigned)((g.N + 127) / 128)), 256, lds, s>>>(g);
+  return true;
+}
+
 template <int NT, bool TRANS_B, bool GATHER>
 void launch_rowgemm(const RowGemmArgs& g, hipStream_t s) {
   const unsigned nblk = (unsigned)(ceil_div64(g.rows, 32) + (g.fill_rows > 0 ? 1 : 0));
@@ -121,8 +152,8 @@ int tsgnn_rowgemm_f32(const float* a, int64_t lda, const float* b, int64_t ldb, 
     return TSGNN_EUNSUPPORTED;
   if (rows == 0 && fill_rows == 0) return TSGNN_OK;
   RowGemmArgs g{a, lda, b, ldb, bias, c, ldc, rinv, rows, K, N, normalize, fill_rows, nullptr, 0, nullptr, 0};
-  if (trans_b) dispatch_rowgemm<true, false>(g, stream);
-  else dispatch_rowgemm<false, false>(g, stream);
+  if (trans_b) { if (!try_colsplit<true>(g, stream)) dispatch_rowgemm<true, false>(g, stream); }
+  else { if (!try_colsplit<false>(g, stream)) dispatch_rowgemm<false, false>(g, stream); }
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }
