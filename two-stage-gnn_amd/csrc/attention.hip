@@ -41,56 +41,78 @@ __global__ __launch_bounds__(256) void node_scores_kernel(const float* __restric
   }
 }
 
-// thread per (row, head): numerically-stable softmax over the row's entries
-__global__ void edge_softmax_fwd_kernel(const int* __restrict__ rowptr, const int* __restrict__ col, int64_t rows, int H,
-                                        const float* __restrict__ s_grp, const float* __restrict__ s_oth, int mod, float slope,
-                                        float* __restrict__ alpha) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// EG lanes per (row, head): numerically-stable softmax over the row's entries.  A DD row has ~5 entries: one pass of the lane
+// group covers it with two dependent round trips (entry ids -> their scores); a thread walking the row alone paid those two
+// trips per entry, three times over (max, sum, normalise).  The first entry of every lane stays in registers; rows longer
+// than EG entries take the strided loops.
+constexpr int SM_EG = 8;
+__global__ __launch_bounds__(256) void edge_softmax_fwd_kernel(const int* __restrict__ rowptr, const int* __restrict__ col, int64_t rows,
+                                                               int H, const float* __restrict__ s_grp, const float* __restrict__ s_oth,
+                                                               int mod, float slope, float* __restrict__ alpha) {
+  const int sub = threadIdx.x & (SM_EG - 1);
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / SM_EG;      // (row, head) pair of this lane group
   if (i >= rows * H) return;
   const int64_t g = i / H;
   const int h = (int)(i % H);
   const int e0 = rowptr[g], e1 = rowptr[g + 1];
   if (e0 == e1) return;
   const float sg = s_grp[(mod ? g % mod : g) * H + h];
-  float m = -INFINITY;
-  for (int e = e0; e < e1; ++e) {
+  auto score = [&](int e) {
     const int64_t c = mod ? col[e] % mod : col[e];
-    m = fmaxf(m, lrelu(sg + s_oth[c * H + h], slope));
-  }
-  float d = 0.f;
-  for (int e = e0; e < e1; ++e) {
-    const int64_t c = mod ? col[e] % mod : col[e];
-    const float p = expf(lrelu(sg + s_oth[c * H + h], slope) - m);
-    alpha[(int64_t)e * H + h] = p;
-    d += p;
-  }
+    return lrelu(sg + s_oth[c * H + h], slope);
+  };
+  const int ef = e0 + sub;
+  const bool has = ef < e1;
+  const float tf = has ? score(ef) : -INFINITY;
+  float m = tf;
+  for (int e = ef + SM_EG; e < e1; e += SM_EG) m = fmaxf(m, score(e));
+  m = group_max<SM_EG>(m);
+  const float pf = has ? expf(tf - m) : 0.f;
+  float d = pf;
+  for (int e = ef + SM_EG; e < e1; e += SM_EG) d += expf(score(e) - m);
+  d = group_sum<SM_EG>(d);
   const float inv = 1.f / d;
-  for (int e = e0; e < e1; ++e) alpha[(int64_t)e * H + h] *= inv;
+  if (has) alpha[(int64_t)ef * H + h] = pf * inv;
+  for (int e = ef + SM_EG; e < e1; e += SM_EG) alpha[(int64_t)e * H + h] = expf(score(e) - m) * inv;
 }
 
 // softmax + LeakyReLU backward inside a group:  dt[e] = alpha (dalpha - sum alpha dalpha) * lrelu'(t)
-// also ds_grp[g,h] = sum_e dt[e,h]
-__global__ void edge_softmax_bwd_kernel(const int* __restrict__ rowptr, const int* __restrict__ col, int64_t rows, int H,
-                                        const float* __restrict__ s_grp, const float* __restrict__ s_oth, int mod, float slope,
-                                        const float* __restrict__ alpha, const float* __restrict__ dalpha,
-                                        float* __restrict__ dt, float* __restrict__ ds_grp) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// also ds_grp[g,h] = sum_e dt[e,h]                      (same lane-group layout)
+__global__ __launch_bounds__(256) void edge_softmax_bwd_kernel(const int* __restrict__ rowptr, const int* __restrict__ col, int64_t rows,
+                                                               int H, const float* __restrict__ s_grp, const float* __restrict__ s_oth,
+                                                               int mod, float slope, const float* __restrict__ alpha,
+                                                               const float* __restrict__ dalpha, float* __restrict__ dt,
+                                                               float* __restrict__ ds_grp) {
+  const int sub = threadIdx.x & (SM_EG - 1);
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / SM_EG;
   if (i >= rows * H) return;
   const int64_t g = i / H;
   const int h = (int)(i % H);
   const int e0 = rowptr[g], e1 = rowptr[g + 1];
-  float c = 0.f;
-  for (int e = e0; e < e1; ++e) c = fmaf(alpha[(int64_t)e * H + h], dalpha[(int64_t)e * H + h], c);
+  const int ef = e0 + sub;
+  const bool has = ef < e1;
+  const float af = has ? alpha[(int64_t)ef * H + h] : 0.f, daf = has ? dalpha[(int64_t)ef * H + h] : 0.f;
+  float c = af * daf;
+  for (int e = ef + SM_EG; e < e1; e += SM_EG) c = fmaf(alpha[(int64_t)e * H + h], dalpha[(int64_t)e * H + h], c);
+  c = group_sum<SM_EG>(c);
   const float sg = (e0 < e1) ? s_grp[(mod ? g % mod : g) * H + h] : 0.f;
   float acc = 0.f;
-  for (int e = e0; e < e1; ++e) {
+  if (has) {
+    const int64_t cc = mod ? col[ef] % mod : col[ef];
+    const float t = sg + s_oth[cc * H + h];
+    const float v = af * (daf - c) * (t > 0.f ? 1.f : slope);
+    dt[(int64_t)ef * H + h] = v;
+    acc = v;
+  }
+  for (int e = ef + SM_EG; e < e1; e += SM_EG) {
     const int64_t cc = mod ? col[e] % mod : col[e];
     const float t = sg + s_oth[cc * H + h];
     const float v = alpha[(int64_t)e * H + h] * (dalpha[(int64_t)e * H + h] - c) * (t > 0.f ? 1.f : slope);
     dt[(int64_t)e * H + h] = v;
     acc += v;
   }
-  ds_grp[i] = acc;
+  acc = group_sum<SM_EG>(acc);
+  if (sub == 0) ds_grp[i] = acc;
 }
 
 // out[p, :] = src[perm[p], :]   (edge-value permutation between a CSR and its transpose)
@@ -432,7 +454,7 @@ int tsgnn_edge_softmax_fwd_f32(const int* rowptr, const int* col, int64_t rows, 
                                int mod, float slope, float* alpha, tsgnn_stream_t stream) {
   if (!rowptr || !s_grp || !s_oth || !alpha || rows < 0 || H <= 0 || mod < 0) return TSGNN_EINVAL;
   if (rows == 0) return TSGNN_OK;
-  edge_softmax_fwd_kernel<<<(unsigned)ceil_div64(rows * H, 256), 256, 0, stream>>>(rowptr, col, rows, H, s_grp, s_oth, mod, slope, alpha);
+  edge_softmax_fwd_kernel<<<(unsigned)ceil_div64(rows * H * SM_EG, 256), 256, 0, stream>>>(rowptr, col, rows, H, s_grp, s_oth, mod, slope, alpha);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }
@@ -442,7 +464,7 @@ int tsgnn_edge_softmax_bwd_f32(const int* rowptr, const int* col, int64_t rows, 
                                tsgnn_stream_t stream) {
   if (!rowptr || !s_grp || !s_oth || !alpha || !dalpha || !dt || !ds_grp || rows < 0 || H <= 0 || mod < 0) return TSGNN_EINVAL;
   if (rows == 0) return TSGNN_OK;
-  edge_softmax_bwd_kernel<<<(unsigned)ceil_div64(rows * H, 256), 256, 0, stream>>>(rowptr, col, rows, H, s_grp, s_oth, mod, slope,
+  edge_softmax_bwd_kernel<<<(unsigned)ceil_div64(rows * H * SM_EG, 256), 256, 0, stream>>>(rowptr, col, rows, H, s_grp, s_oth, mod, slope,
                                                                                   alpha, dalpha, dt, ds_grp);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
