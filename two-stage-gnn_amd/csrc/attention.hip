@@ -128,15 +128,19 @@ __global__ void scatter_rows_small(const float* __restrict__ src, const int* __r
 }
 // out[r, h] = sum over the row's entries of val[e, h]
 // eperm (nullable): entry e's value lives at val[eperm[e]] (values stored in the transposed structure's entry order)
-__global__ void csr_row_sum_kernel(const int* __restrict__ rowptr, const float* __restrict__ val, int64_t rows, int H, float* __restrict__ out,
-                                   const int* __restrict__ eperm) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void csr_row_sum_kernel(const int* __restrict__ rowptr, const float* __restrict__ val, int64_t rows, int H,
+                                                          float* __restrict__ out, const int* __restrict__ eperm) {
+  // SM_EG lanes per (row, head), as the edge softmax: entry -> (permuted) value is two dependent round trips per ROW, not per entry
+  const int sub = threadIdx.x & (SM_EG - 1);
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / SM_EG;
   if (i >= rows * H) return;
   const int64_t r = i / H;
   const int h = (int)(i % H);
+  const int e1 = rowptr[r + 1];
   float acc = 0.f;
-  for (int e = rowptr[r]; e < rowptr[r + 1]; ++e) acc += val[(int64_t)(eperm ? eperm[e] : e) * H + h];
-  out[i] = acc;
+  for (int e = rowptr[r] + sub; e < e1; e += SM_EG) acc += val[(int64_t)(eperm ? eperm[e] : e) * H + h];
+  acc = group_sum<SM_EG>(acc);
+  if (sub == 0) out[i] = acc;
 }
 
 // optional epilogue of the head-weighted aggregation (folds the element-wise passes that used to follow it):
@@ -482,7 +486,7 @@ int tsgnn_edge_permute_f32(const float* src, const int* perm, int64_t n, int H, 
 int tsgnn_csr_row_sum_f32(const int* rowptr, const float* val, int64_t rows, int H, float* out, tsgnn_stream_t stream) {
   if (!rowptr || !val || !out || rows < 0 || H <= 0) return TSGNN_EINVAL;
   if (rows == 0) return TSGNN_OK;
-  csr_row_sum_kernel<<<(unsigned)ceil_div64(rows * H, 256), 256, 0, stream>>>(rowptr, val, rows, H, out, nullptr);
+  csr_row_sum_kernel<<<(unsigned)ceil_div64(rows * H * SM_EG, 256), 256, 0, stream>>>(rowptr, val, rows, H, out, nullptr);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }
@@ -491,7 +495,7 @@ int tsgnn_csr_row_sum_perm_f32(const int* rowptr, const float* val, const int* e
                                tsgnn_stream_t stream) {
   if (!rowptr || !val || !eperm || !out || rows < 0 || H <= 0) return TSGNN_EINVAL;
   if (rows == 0) return TSGNN_OK;
-  csr_row_sum_kernel<<<(unsigned)ceil_div64(rows * H, 256), 256, 0, stream>>>(rowptr, val, rows, H, out, eperm);
+  csr_row_sum_kernel<<<(unsigned)ceil_div64(rows * H * SM_EG, 256), 256, 0, stream>>>(rowptr, val, rows, H, out, eperm);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }

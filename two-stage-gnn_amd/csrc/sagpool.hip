@@ -190,6 +190,28 @@ __global__ __launch_bounds__(256) void gcn_propagate_generic(PropArgs a) {
   const int e0 = a.rowptr[row], e1 = a.rowend ? a.rowend[row] : a.rowptr[row + 1];
   const float di = a.dinv[row], sw = a.self_w[row];
   float dot = 0.f;
+  if (a.feat <= 8) {
+    // narrow inputs (the one-column degree / constant feature): lanes over the ENTRIES — with lanes over features one lane
+    // walked the neighbours alone, a dependent round trip each
+    for (int f = 0; f < a.feat; ++f) {
+      float acc = 0.f;
+      for (int e = e0 + lane; e < e1; e += 64) {
+        const int j = a.col[e];
+        float v = a.x[(int64_t)j * a.ldx + f];
+        if (a.relu_in) v = fmaxf(v, 0.f);
+        acc = fmaf(a.dinv[j], v, acc);
+      }
+      acc = wave_sum(acc);
+      float xs = a.x[row * a.ldx + f];
+      if (a.relu_in) xs = fmaxf(xs, 0.f);
+      float o = fmaf(di, acc, sw * xs);
+      if (a.bias != nullptr) o += a.bias[f];
+      if (a.y != nullptr && lane == 0) a.y[row * a.ldy + f] = o;
+      if (a.w_dot != nullptr) dot = fmaf(o, a.w_dot[f], dot);
+    }
+    if (a.w_dot != nullptr && lane == 0) a.t[row] = dot + (a.dot_bias ? a.dot_bias[0] : 0.f);
+    return;
+  }
   for (int fb = 0; fb < a.feat; fb += 64) {                // wave-uniform trip count
     const int f = fb + lane;
     const bool live = f < a.feat;
