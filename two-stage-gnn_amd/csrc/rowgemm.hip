@@ -54,7 +54,9 @@ __global__ __launch_bounds__(512) void rowgemm_gather_ks2_kernel(RowGemmArgs g) 
 
 // column-split variant for products WITHOUT the row epilogue (no normalise: rows need not be whole): grid.y column blocks of
 // 32 * NT.  A 1,000-row x 256-column product (GAT projection, DiffPool's dagg = du W^T) is 32 panels on a 256-CU chip whose
-// waves each run two 32 x 32 tiles over the whole K: split in two, twice the CUs work and each wave's MFMA chain is half as long.
+// waves each run two 32 x 32 tiles over the whole K: split in two, twice the CUs work and each wave's MFMA chain is half as long
+// (16.0 -> 9.5 us).  The one-tile-per-wave body is also the faster one at scale (K = N = 256: 89 vs 76 TF at 131 k rows, 79 vs 72 TF
+// at 555 k; scripts/colsplit_sweep.py), so every such product takes this path.
 template <int NT, bool TRANS_B>
 __global__ __launch_bounds__(256) void rowgemm_colsplit_kernel(RowGemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -72,10 +74,18 @@ inline bool rowgemm_colsplit_enabled() {
   return on;
 }
 
+inline unsigned colsplit_max_panels() {                   // TSGNN_ROWGEMM_COLSPLIT_PANELS=0 disables the column blocks (A/B measurements)
+  static const unsigned n = [] {
+    const char* e = getenv("TSGNN_ROWGEMM_COLSPLIT_PANELS");
+    return e ? (unsigned)atoi(e) : 0xFFFFFFFFu;
+  }();
+  return n;
+}
+
 template <bool TRANS_B>
 bool try_colsplit(const RowGemmArgs& g, hipStream_t s) {
   const unsigned nblk = (unsigned)ceil_div64(g.rows, 32);
-  if (g.normalize || g.fill_rows > 0 || g.N <= 128 || (g.N % 4) || nblk == 0 || 2 * nblk > (unsigned)device_cu_count() ||
+  if (g.normalize || g.fill_rows > 0 || g.N <= 128 || (g.N % 4) || nblk == 0 || nblk > colsplit_max_panels() ||
       !rowgemm_colsplit_enabled())
     return false;
   const size_t lds = rowgemm_lds_bytes<4, TRANS_B, false>();
