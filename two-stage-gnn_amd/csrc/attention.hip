@@ -41,6 +41,51 @@ __global__ __launch_bounds__(256) void node_scores_kernel(const float* __restric
   }
 }
 
+// the same with 16-byte loads: lane l holds floats 4l..4l+3 of the row (all heads at once, H * Fh <= 256), the Fh / 4 lanes of a
+// head reduce with DPP inside their 16-lane row — one load per row instead of H dependent-on-nothing but serial passes
+template <int LPH>
+__global__ __launch_bounds__(256) void node_scores_vec4_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows, int H, int Fh,
+                                                               const float* __restrict__ a, int64_t lda, float* __restrict__ s,
+                                                               const float* __restrict__ a2, int64_t lda2, float* __restrict__ s2) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const bool rok = r0 < rows;                               // whole waves stay active for the DPP reductions
+  const int64_t r = rok ? r0 : 0;
+  const int h = lane / LPH, f = 4 * (lane % LPH);
+  const bool live = h < H;
+  const float4 xv = live ? *reinterpret_cast<const float4*>(x + r * ldx + (int64_t)h * Fh + f) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 av = live ? *reinterpret_cast<const float4*>(a + (int64_t)h * lda + f) : make_float4(0.f, 0.f, 0.f, 0.f);
+  float acc = (xv.x * av.x + xv.y * av.y) + (xv.z * av.z + xv.w * av.w);
+  acc = group_sum<LPH>(acc);
+  float acc2 = 0.f;
+  if (a2) {
+    const float4 bv = live ? *reinterpret_cast<const float4*>(a2 + (int64_t)h * lda2 + f) : make_float4(0.f, 0.f, 0.f, 0.f);
+    acc2 = group_sum<LPH>((xv.x * bv.x + xv.y * bv.y) + (xv.z * bv.z + xv.w * bv.w));
+  }
+  if (rok && live && (lane % LPH) == 0) {
+    s[r * H + h] = acc;
+    if (a2) s2[r * H + h] = acc2;
+  }
+}
+
+inline bool node_scores_vec4_ok(const float* x, int64_t ldx, int H, int Fh, const float* a, int64_t lda, const float* a2, int64_t lda2) {
+  const int lph = Fh / 4;
+  if (Fh % 4 || (lph != 1 && lph != 2 && lph != 4 && lph != 8 && lph != 16) || H * lph > 64) return false;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(a2)) & 15) return false;
+  return ldx % 4 == 0 && lda % 4 == 0 && (!a2 || lda2 % 4 == 0);
+}
+
+template <class... A>
+inline void launch_node_scores_vec4(int lph, unsigned grid, hipStream_t stream, A... args) {
+  switch (lph) {
+    case 1: node_scores_vec4_kernel<1><<<grid, 256, 0, stream>>>(args...); break;
+    case 2: node_scores_vec4_kernel<2><<<grid, 256, 0, stream>>>(args...); break;
+    case 4: node_scores_vec4_kernel<4><<<grid, 256, 0, stream>>>(args...); break;
+    case 8: node_scores_vec4_kernel<8><<<grid, 256, 0, stream>>>(args...); break;
+    default: node_scores_vec4_kernel<16><<<grid, 256, 0, stream>>>(args...); break;
+  }
+}
+
 // EG lanes per (row, head): numerically-stable softmax over the row's entries.  A DD row has ~5 entries: one pass of the lane
 // group covers it with two dependent round trips (entry ids -> their scores); a thread walking the row alone paid those two
 // trips per entry, three times over (max, sum, normalise).  The first entry of every lane stays in registers; rows longer
@@ -397,6 +442,29 @@ __global__ void broadcast_add_kernel(float* __restrict__ y, int64_t ldy, int64_t
 }
 
 // ELU forward / backward (encoders_GAT.py:47,83), optional mean over heads first (concat=False, :78-83)
+// concat heads (no mean over heads): plain element-wise ELU, four elements per thread
+__global__ __launch_bounds__(256) void elu_vec4_fwd_kernel(const float* __restrict__ x, int64_t n4, int apply_elu, float* __restrict__ y) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  float4 v = reinterpret_cast<const float4*>(x)[i];
+  if (apply_elu) {
+    v.x = v.x <= 0.f ? expm1f(v.x) : v.x; v.y = v.y <= 0.f ? expm1f(v.y) : v.y;
+    v.z = v.z <= 0.f ? expm1f(v.z) : v.z; v.w = v.w <= 0.f ? expm1f(v.w) : v.w;
+  }
+  reinterpret_cast<float4*>(y)[i] = v;
+}
+__global__ __launch_bounds__(256) void elu_vec4_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, int64_t n4,
+                                                           int apply_elu, float* __restrict__ dx) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const float4 v = reinterpret_cast<const float4*>(x)[i];
+  float4 g = reinterpret_cast<const float4*>(dy)[i];
+  if (apply_elu) {
+    g.x *= v.x <= 0.f ? expf(v.x) : 1.f; g.y *= v.y <= 0.f ? expf(v.y) : 1.f;
+    g.z *= v.z <= 0.f ? expf(v.z) : 1.f; g.w *= v.w <= 0.f ? expf(v.w) : 1.f;
+  }
+  reinterpret_cast<float4*>(dx)[i] = g;
+}
 __global__ void elu_heads_fwd_kernel(const float* __restrict__ x, int64_t rows, int H, int Fh, int mean_heads, int apply_elu,
                                      float* __restrict__ y) {
   const int Co = mean_heads ? Fh : H * Fh;
@@ -440,7 +508,11 @@ int tsgnn_node_scores_f32(const float* x, int64_t ldx, int64_t rows, int H, int 
                           tsgnn_stream_t stream) {
   if (!x || !a || !s || rows < 0 || H <= 0 || Fh <= 0 || ldx < (int64_t)H * Fh) return TSGNN_EINVAL;
   if (rows == 0) return TSGNN_OK;
-  node_scores_kernel<<<(unsigned)ceil_div64(rows, 4), 256, 0, stream>>>(x, ldx, rows, H, Fh, a, lda, s, nullptr, 0, nullptr);
+  if (node_scores_vec4_ok(x, ldx, H, Fh, a, lda, nullptr, 0))
+    launch_node_scores_vec4(Fh / 4, (unsigned)ceil_div64(rows, 4), stream, x, ldx, rows, H, Fh, a, lda, s, (const float*)nullptr, (int64_t)0,
+                            (float*)nullptr);
+  else
+    node_scores_kernel<<<(unsigned)ceil_div64(rows, 4), 256, 0, stream>>>(x, ldx, rows, H, Fh, a, lda, s, nullptr, 0, nullptr);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }
@@ -449,7 +521,10 @@ int tsgnn_node_scores2_f32(const float* x, int64_t ldx, int64_t rows, int H, int
                            const float* a2, int64_t lda2, float* s2, tsgnn_stream_t stream) {
   if (!x || !a1 || !s1 || !a2 || !s2 || rows < 0 || H <= 0 || Fh <= 0 || ldx < (int64_t)H * Fh) return TSGNN_EINVAL;
   if (rows == 0) return TSGNN_OK;
-  node_scores_kernel<<<(unsigned)ceil_div64(rows, 4), 256, 0, stream>>>(x, ldx, rows, H, Fh, a1, lda1, s1, a2, lda2, s2);
+  if (node_scores_vec4_ok(x, ldx, H, Fh, a1, lda1, a2, lda2))
+    launch_node_scores_vec4(Fh / 4, (unsigned)ceil_div64(rows, 4), stream, x, ldx, rows, H, Fh, a1, lda1, s1, a2, lda2, s2);
+  else
+    node_scores_kernel<<<(unsigned)ceil_div64(rows, 4), 256, 0, stream>>>(x, ldx, rows, H, Fh, a1, lda1, s1, a2, lda2, s2);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }
@@ -614,7 +689,11 @@ int tsgnn_elu_heads_fwd_f32(const float* x, int64_t rows, int H, int Fh, int mea
   if (!x || !y || rows < 0 || H <= 0 || Fh <= 0) return TSGNN_EINVAL;
   if (rows == 0) return TSGNN_OK;
   const int Co = mean_heads ? Fh : H * Fh;
-  elu_heads_fwd_kernel<<<(unsigned)ceil_div64(rows * Co, 256), 256, 0, stream>>>(x, rows, H, Fh, mean_heads, apply_elu, y);
+  const int64_t n = rows * (int64_t)H * Fh;
+  if (!mean_heads && n % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0)
+    elu_vec4_fwd_kernel<<<(unsigned)ceil_div64(n / 4, 256), 256, 0, stream>>>(x, n / 4, apply_elu, y);
+  else
+    elu_heads_fwd_kernel<<<(unsigned)ceil_div64(rows * Co, 256), 256, 0, stream>>>(x, rows, H, Fh, mean_heads, apply_elu, y);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }
@@ -623,7 +702,12 @@ int tsgnn_elu_heads_bwd_f32(const float* x, const float* dy, int64_t rows, int H
                             tsgnn_stream_t stream) {
   if (!x || !dy || !dx || rows < 0 || H <= 0 || Fh <= 0) return TSGNN_EINVAL;
   if (rows == 0) return TSGNN_OK;
-  elu_heads_bwd_kernel<<<(unsigned)ceil_div64(rows * H * Fh, 256), 256, 0, stream>>>(x, dy, rows, H, Fh, mean_heads, apply_elu, dx);
+  const int64_t n = rows * (int64_t)H * Fh;
+  if (!mean_heads && n % 4 == 0 &&
+      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0)
+    elu_vec4_bwd_kernel<<<(unsigned)ceil_div64(n / 4, 256), 256, 0, stream>>>(x, dy, n / 4, apply_elu, dx);
+  else
+    elu_heads_bwd_kernel<<<(unsigned)ceil_div64(rows * H * Fh, 256), 256, 0, stream>>>(x, dy, rows, H, Fh, mean_heads, apply_elu, dx);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }
