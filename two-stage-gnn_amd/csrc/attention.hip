@@ -243,7 +243,8 @@ __global__ __launch_bounds__(256) void spmm_heads_vec4(const int* __restrict__ r
                                                        int64_t ldx, int mod, float* __restrict__ y, int64_t ldy, int64_t rows, int nvec,
                                                        HeadsEpi epi) {
   const int lig = threadIdx.x % G;
-  const int64_t r = (int64_t)blockIdx.x * (256 / G) + threadIdx.x / G;
+  // XCD-aware row order (blocks b, b + 8, ... share an L2): neighbouring rows gather the same x rows
+  const int64_t r = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * (256 / G) + threadIdx.x / G;
   if (r >= rows) return;
   const bool live = lig < nvec;
   const int h = live ? (4 * lig) / Fh : 0;
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(256) void sddmm_heads_vec4(const int* __restrict__ 
                                                         const float* __restrict__ dy, int64_t lddy, const float* __restrict__ x,
                                                         int64_t ldx, int mod, float* __restrict__ dalpha, int64_t rows, int nvec) {
   const int lig = threadIdx.x % G;
-  const int64_t r0 = (int64_t)blockIdx.x * (256 / G) + threadIdx.x / G;
+  const int64_t r0 = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * (256 / G) + threadIdx.x / G;   // XCD-aware row order, as the aggregation
   const bool rok = r0 < rows;                           // whole waves stay active: the DPP reductions need every lane
   const int64_t r = rok ? r0 : 0;
   const bool live = lig < nvec;
