@@ -129,6 +129,12 @@ int tsgnn_wgrad_reduce_multi_f32(const float* ws0, int nslab0, int K0, int N0, f
  * [slab_row_ptr[t], slab_row_ptr[t+1]).  ws >= nslab*(K+1)*N floats.  ceil(K/32)*ceil(N/32) <= 16. */
 int tsgnn_ragged_tn_f32(const float* s_mat, int64_t lds_, const float* x, int64_t ldx, int K, int N, const int* slab_row_ptr,
                         int nslab, const int* seg_slab_ptr, int nseg, float* ws, float* out, tsgnn_stream_t stream);
+/* Weight + bias gradient of a layer with a narrow input (K_in <= 4, e.g. the one-column constant feature of IMDB-B,
+ * network.py:34 with num_features = 1): dwb[(K_in + 1), N], rows 0..K_in-1 = z[:, :K_in]^T du, row K_in = column sums of du,
+ * from one pass over du.  ws: *ws_floats of tsgnn_wgrad_narrow_plan(rows, K_in, N, &ws_floats). */
+int tsgnn_wgrad_narrow_plan(int64_t rows, int K_in, int N, int64_t* ws_floats);
+int tsgnn_wgrad_narrow_f32(const float* z, int64_t ldz, const float* du, int64_t lddu, int64_t rows, int K_in, int N, float* ws,
+                           float* dwb, tsgnn_stream_t stream);
 /* out[f] (+)= sum_r x[r,f] (bias gradients); ws >= ceil(rows/128)*F floats */
 int tsgnn_colsum_f32(const float* x, int64_t ld, int64_t rows, int F, float* out, float* ws, int accumulate,
                      tsgnn_stream_t stream);

@@ -236,6 +236,21 @@ def test_ell_fast_path_equals_csr(T, F, p_edge):
         torch.testing.assert_close(y_ell, y_csr, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("rows,K,N,ldz", [(2629, 1, 128, 1), (70000, 3, 64, 4), (5, 4, 100, 4), (0, 1, 8, 1)])
+def test_linear_wgrad_narrow_input(T, rows, K, N, ldz):
+    """layers with <= 4 input columns (IMDB's single constant feature): dW = z^T du and db = colsum(du) from one pass over du"""
+    mp, _ = T
+    gen = torch.Generator(device="cuda").manual_seed(rows + K)
+    z = torch.randn(max(rows, 1), ldz, generator=gen, device="cuda")[:rows]
+    du = torch.randn(max(rows, 1), N, generator=gen, device="cuda")[:rows]
+    dw, db = mp.linear_wgrad(z, K, du, True)
+    assert dw.shape == (K, N) and db.shape == (N,)
+    torch.testing.assert_close(dw.double(), z[:, :K].double().t() @ du.double(), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(db.double(), du.double().sum(0), rtol=1e-4, atol=1e-4)
+    dw2, db2 = mp.linear_wgrad(z, K, du, False)
+    assert db2 is None and torch.equal(dw2, dw)
+
+
 @pytest.mark.parametrize("rows,K,N,trans_b,bias", [(1000, 92, 256, False, True), (1000, 256, 256, True, False), (1024, 64, 192, True, False),
                                                     (37, 128, 132, False, True), (4096, 128, 256, False, False)])
 def test_rowgemm_column_split(T, rows, K, N, trans_b, bias):

@@ -180,6 +180,50 @@ __global__ __launch_bounds__(256) void colsum_partial(const float* __restrict__ 
 }
 
 
+// weight + bias gradient of a layer with a NARROW input (K_in <= 4: the one-column degree / constant feature of the IMDB sets):
+// dW[k, f] = sum_r z[r, k] du[r, f] and db[f] = sum_r du[r, f] from ONE pass over du — the column-sum kernel with K_in extra
+// weighted accumulators (an MFMA tile would be 1/32 full; the split-K product + its reduction + the column sums were 19 us
+// for a [1 x 128] result).  grid (ceil(F/64), nchunk); partial layout [chunk][K_in + 1][F], summed by splitk_reduce_kernel.
+constexpr int WN_KMAX = 4;
+__global__ __launch_bounds__(256) void wgrad_narrow_partial(const float* __restrict__ z, int64_t ldz, const float* __restrict__ du,
+                                                            int64_t lddu, int64_t rows, int K_in, int F, int64_t rows_per_chunk,
+                                                            float* __restrict__ part) {
+  __shared__ float lds[WN_KMAX + 1][4][64];
+  const int fl = threadIdx.x & 63, f = blockIdx.x * 64 + fl;
+  const int rl = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+  float acc[WN_KMAX + 1];
+#pragma unroll
+  for (int k = 0; k <= WN_KMAX; ++k) acc[k] = 0.f;
+  if (f < F) {
+    for (int64_t rb = r0 + rl; rb < r1; rb += 32) {        // eight rows in flight per thread, fixed summation order
+      float t[8], zz[8][WN_KMAX];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t r = rb + 4 * u;
+        const bool ok = r < r1;
+        t[u] = ok ? du[r * lddu + f] : 0.f;
+#pragma unroll
+        for (int k = 0; k < WN_KMAX; ++k) zz[u][k] = (ok && k < K_in) ? z[r * ldz + k] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+#pragma unroll
+        for (int k = 0; k < WN_KMAX; ++k) acc[k] = fmaf(zz[u][k], t[u], acc[k]);
+        acc[WN_KMAX] += t[u];
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k <= WN_KMAX; ++k) lds[k][rl][fl] = acc[k];
+  __syncthreads();
+  if (rl == 0 && f < F) {
+    float* o = part + (int64_t)blockIdx.y * (K_in + 1) * F;
+    for (int k = 0; k < K_in; ++k) o[(int64_t)k * F + f] = (lds[k][0][fl] + lds[k][1][fl]) + (lds[k][2][fl] + lds[k][3][fl]);
+    o[(int64_t)K_in * F + f] = (lds[WN_KMAX][0][fl] + lds[WN_KMAX][1][fl]) + (lds[WN_KMAX][2][fl] + lds[WN_KMAX][3][fl]);
+  }
+}
+
 template <int MT, int NTt, int NY>
 __global__ __launch_bounds__(256) void gemm_tn_rows_kernel(TnArgs g) {
   extern __shared__ __attribute__((aligned(16))) float tn_smem[];   // two stages of [Z chunk | dU chunk]
@@ -431,6 +475,33 @@ int tsgnn_ragged_tn_f32(const float* s_mat, int64_t lds_, const float* x, int64_
 }
 
 /* out[f] (+)= sum_r x[r,f];  ws >= nchunk*F floats with nchunk = ceil(rows/512) */
+/* floats of workspace for tsgnn_wgrad_narrow_f32 */
+int tsgnn_wgrad_narrow_plan(int64_t rows, int K_in, int N, int64_t* ws_floats) {
+  if (!ws_floats || rows < 0 || K_in <= 0 || N <= 0) return TSGNN_EINVAL;
+  const int64_t rpc = rows > 65536 ? 512 : 128;
+  *ws_floats = (rows > 0 ? ceil_div64(rows, rpc) : 1) * (int64_t)(K_in + 1) * N;
+  return TSGNN_OK;
+}
+
+/* dwb[(K_in + 1), N]: rows 0..K_in-1 = dW = z[:, :K_in]^T du, row K_in = db = column sums of du; K_in <= 4 (narrow inputs) */
+int tsgnn_wgrad_narrow_f32(const float* z, int64_t ldz, const float* du, int64_t lddu, int64_t rows, int K_in, int N, float* ws,
+                           float* dwb, tsgnn_stream_t stream) {
+  if (!dwb || rows < 0 || K_in <= 0 || N <= 0) return TSGNN_EINVAL;
+  if (K_in > WN_KMAX) return TSGNN_EUNSUPPORTED;
+  if (rows == 0) {                                          // no rows: zero gradients (empty tensors have no storage)
+    (void)hipMemsetAsync(dwb, 0, sizeof(float) * (size_t)(K_in + 1) * N, stream);
+    return TSGNN_OK;
+  }
+  if (!z || !du || !ws || ldz < K_in || lddu < N) return TSGNN_EINVAL;
+  const int64_t rpc = rows > 65536 ? 512 : 128;
+  const int nchunk = (int)(rows > 0 ? ceil_div64(rows, rpc) : 1);
+  const int64_t n = (int64_t)(K_in + 1) * N;
+  wgrad_narrow_partial<<<dim3((unsigned)((N + 63) / 64), (unsigned)nchunk), 256, 0, stream>>>(z, ldz, du, lddu, rows, K_in, N, rpc, ws);
+  splitk_reduce_kernel<<<(unsigned)ceil_div64(n, 256), 256, 0, stream>>>(ws, nchunk, n, n, dwb, 0);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
 int tsgnn_colsum_f32(const float* x, int64_t ld, int64_t rows, int F, float* out, float* ws, int accumulate,
                      tsgnn_stream_t stream) {
   if (!x || !out || !ws || rows < 0 || F <= 0 || ld < F) return TSGNN_EINVAL;

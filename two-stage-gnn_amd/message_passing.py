@@ -199,6 +199,13 @@ def linear_wgrad(z, K_in, du, want_db):
             if sets:
                 wgrad_reduce_multi(sets)
                 return dwt.t(), (colsum(du) if want_db else None)
+    if K_in <= 4:                          # narrow input (IMDB's single constant column): dW and db from one pass over du
+        need = np.zeros(1, dtype=np.int64)
+        nat.call_nostream("wgrad_narrow_plan", int(R), int(K_in), int(N), need.ctypes.data)
+        ws = _f32(max(int(need[0]), 1), device=du.device)
+        dwb = _f32(K_in + 1, N, device=du.device)
+        nat.call("wgrad_narrow_f32", z, z.stride(0), du, du.stride(0), int(R), int(K_in), int(N), ws, dwb)
+        return dwb[:K_in], (dwb[K_in] if want_db else None)
     return gemm_tn_splitk(z, K_in, du), (colsum(du) if want_db else None)
 
 
