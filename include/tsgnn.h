@@ -430,7 +430,8 @@ int tsgnn_sag_pool_bwd_f32(const float* y, int64_t ldy, const float* score, cons
  * symmetric adjacency, rowend nullable): du[r] = gradient w.r.t. the pre-activation conv output y[r]; part: B rows of F + 4
  * floats; dws / dbs as tsgnn_sag_du_f32.  dagg_next (nullable; then dxp must be NULL): the gradient of the NEXT level's
  * aggregation with that level's CSR (rowptr_n, rowend_n, col_n) and coefficients — dxp = A^' dagg_next is formed per kept row
- * inside the kernel instead of by a tsgnn_gcn_propagate_re_f32 launch. */
+ * inside the kernel instead of by a tsgnn_gcn_propagate_re_f32 launch.  dws = dbs = NULL: the partial rows are left in `part` for
+ * tsgnn_linear_wgrad_du_f32 (or tsgnn_sag_du_reduce_f32) to add up. */
 int tsgnn_sag_pool_graph_bwd_f32(const float* y, int64_t ldy, const float* score, const int* new_id, const int* graph_ptr,
                                  const int* graph_ptr_new, const int* arg, const float* dxp, int64_t lddxp, const float* dread,
                                  int64_t lddr, const int* rowptr, const int* rowend, const int* col, const float* dinv,
@@ -438,6 +439,13 @@ int tsgnn_sag_pool_graph_bwd_f32(const float* y, int64_t ldy, const float* score
                                  float* dws, float* dbs, const float* dagg_next, int64_t lddagg, const int* rowptr_n,
                                  const int* rowend_n, const int* col_n, const float* dinv_n, const float* self_w_n,
                                  tsgnn_stream_t stream);
+/* fixed-order sum of nb partial rows part[nb][F + 4] (columns 0..F-1: dw_s, column F: db_s) -> dws[F], dbs[1] */
+int tsgnn_sag_du_reduce_f32(float* part, int nb, int F, float* dws, float* dbs, tsgnn_stream_t stream);
+/* tsgnn_linear_wgrad_f32 (dw != NULL) whose reduction launch carries that sum as one extra block (nb <= 256): the conv layer's
+ * weight gradient and the score layer's wait for the same producer, so they share a launch */
+int tsgnn_linear_wgrad_du_f32(const float* z, int64_t ldz, const float* du, int64_t lddu, int64_t rows, int K_in, int N, int nslab,
+                              int64_t rows_per_slab, float* ws, float* dw, float* db, float* part, int nb, int F_du, float* dws,
+                              float* dbs, tsgnn_stream_t stream);
 /* dyb[r] <- (dyb[r] + dt[r] * w_s) * [y[r] > 0] with dt = A^ dscore (score layer backward folded in);
  * dws = sum_r dt[r] * relu(y[r]), dbs = sum_r dscore[r] (fixed-order block partials in `part`: tsgnn_sag_du_blocks(N, F)
  * rows of F + 4 floats, summed by a second one-block launch). */

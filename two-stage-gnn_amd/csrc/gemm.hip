@@ -18,6 +18,7 @@
 #include "../../include/tsgnn.h"
 
 #include "tn_rows_body.h"
+#include "du_reduce_body.h"
 
 namespace {
 
@@ -264,6 +265,41 @@ __global__ __launch_bounds__(256) void tn_rows_reduce(const float* __restrict__ 
 }
 
 
+// tn_rows_reduce with one passenger: the last block adds up the per-graph partial rows of the SAGPool score-layer gradients
+// (du_reduce_body) — both reductions wait for the same producer launch, so they share one launch (4 us per pooled level)
+__global__ __launch_bounds__(256) void tn_rows_reduce_du(const float* __restrict__ slabs, int nslab, int64_t per_slab, int64_t n_w,
+                                                         float* __restrict__ dw, float* __restrict__ db, float* __restrict__ part, int nb,
+                                                         int F_du, float* __restrict__ dws, float* __restrict__ dbs) {
+  __shared__ float4 s_part[256];
+  if (blockIdx.x == gridDim.x - 1) {
+    du_reduce_body(part, nb, F_du, dws, dbs, nb, 1, 0, s_part);
+    return;
+  }
+  float (*lds)[64] = reinterpret_cast<float (*)[64]>(s_part);      // [4][64]
+  const int e_l = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int64_t e = (int64_t)blockIdx.x * 64 + e_l;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (e < per_slab) {                                                 // the arithmetic (and order) of tn_rows_reduce
+    const int per = (nslab + 3) / 4;
+    const int s0 = grp * per, s1 = min(nslab, s0 + per);
+    int s = s0;
+    for (; s + 4 <= s1; s += 4) {
+      a0 += slabs[(int64_t)s * per_slab + e];
+      a1 += slabs[(int64_t)(s + 1) * per_slab + e];
+      a2 += slabs[(int64_t)(s + 2) * per_slab + e];
+      a3 += slabs[(int64_t)(s + 3) * per_slab + e];
+    }
+    for (; s < s1; ++s) a0 += slabs[(int64_t)s * per_slab + e];
+  }
+  lds[grp][e_l] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (grp == 0 && e < per_slab) {
+    const float v = (lds[0][e_l] + lds[1][e_l]) + (lds[2][e_l] + lds[3][e_l]);
+    if (e < n_w) dw[e] = v;
+    else if (db) db[e - n_w] = v;
+  }
+}
+
 struct ReduceSet { const float* slabs; int nslab; int64_t per_slab; int64_t n_w; float* dw; float* db; int64_t first_block; };
 struct ReduceMulti { ReduceSet s[4]; int n; float* normparts; float* step_state; };
 // several independent slab sets (the layers of one backward pass) reduced by ONE launch
@@ -416,8 +452,9 @@ int tsgnn_wgrad_reduce_multi_f32(const float* ws0, int nslab0, int K0, int N0, f
 
 /* dW[K_in,N] = z[:, :K_in]^T . du ; db[N] = colsum(du) (db nullable).  Plan with tsgnn_linear_wgrad_plan.
  * dw == NULL: only the slabs are produced (reduce them later with tsgnn_wgrad_reduce_multi_f32). */
-int tsgnn_linear_wgrad_f32(const float* z, int64_t ldz, const float* du, int64_t lddu, int64_t rows, int K_in, int N, int nslab,
-                           int64_t rows_per_slab, int64_t bias_only_rows, float* ws, float* dw, float* db, tsgnn_stream_t stream) {
+static int linear_wgrad_launch(const float* z, int64_t ldz, const float* du, int64_t lddu, int64_t rows, int K_in, int N, int nslab,
+                               int64_t rows_per_slab, int64_t bias_only_rows, float* ws, float* dw, float* db, float* du_part, int du_nb,
+                               int du_F, float* du_dws, float* du_dbs, tsgnn_stream_t stream) {
   if (!z || !du || !ws || rows < 0 || nslab <= 0 || rows_per_slab <= 0 || K_in <= 0 || N <= 0 || bias_only_rows < 0) return TSGNN_EINVAL;
   if (K_in > 128 || N > 128 || (ldz % 4) || (lddu % 4) || (N % 4) || (reinterpret_cast<uintptr_t>(z) & 15) ||
       (reinterpret_cast<uintptr_t>(du) & 15))
@@ -437,10 +474,32 @@ int tsgnn_linear_wgrad_f32(const float* z, int64_t ldz, const float* du, int64_t
   }
 #undef TSGNN_TN
   const int64_t per_slab = (int64_t)(K_in + 1) * N;
-  if (dw) tn_rows_reduce<<<(unsigned)ceil_div64(per_slab, 64), 256, 0, stream>>>(ws, nslab, per_slab, (int64_t)K_in * N, dw, db, nullptr);
+  if (dw && du_part)
+    tn_rows_reduce_du<<<(unsigned)ceil_div64(per_slab, 64) + 1, 256, 0, stream>>>(ws, nslab, per_slab, (int64_t)K_in * N, dw, db, du_part,
+                                                                                   du_nb, du_F, du_dws, du_dbs);
+  else if (dw)
+    tn_rows_reduce<<<(unsigned)ceil_div64(per_slab, 64), 256, 0, stream>>>(ws, nslab, per_slab, (int64_t)K_in * N, dw, db, nullptr);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }
+
+int tsgnn_linear_wgrad_f32(const float* z, int64_t ldz, const float* du, int64_t lddu, int64_t rows, int K_in, int N, int nslab,
+                           int64_t rows_per_slab, int64_t bias_only_rows, float* ws, float* dw, float* db, tsgnn_stream_t stream) {
+  return linear_wgrad_launch(z, ldz, du, lddu, rows, K_in, N, nslab, rows_per_slab, bias_only_rows, ws, dw, db, nullptr, 0, 0, nullptr,
+                             nullptr, stream);
+}
+
+/* tsgnn_linear_wgrad_f32 (dw != NULL) whose reduction launch also sums the nb <= 256 partial rows part[nb][F_du + 4] that
+ * tsgnn_sag_pool_graph_bwd_f32 (called with dws = dbs = NULL) left behind: dws[F_du], dbs[1]. */
+int tsgnn_linear_wgrad_du_f32(const float* z, int64_t ldz, const float* du, int64_t lddu, int64_t rows, int K_in, int N, int nslab,
+                              int64_t rows_per_slab, float* ws, float* dw, float* db, float* part, int nb, int F_du, float* dws,
+                              float* dbs, tsgnn_stream_t stream) {
+  if (!dw || !part || !dws || !dbs || nb <= 0 || nb > 256 || F_du <= 0 || (F_du % 4) || (reinterpret_cast<uintptr_t>(part) & 15) ||
+      (reinterpret_cast<uintptr_t>(dws) & 15))
+    return TSGNN_EINVAL;
+  return linear_wgrad_launch(z, ldz, du, lddu, rows, K_in, N, nslab, rows_per_slab, 0, ws, dw, db, part, nb, F_du, dws, dbs, stream);
+}
+
 
 /* Ragged batched  out[b][K,N] = S[rows_b, :K]^T . X[rows_b, :N]  (DiffPool's S^T Z and S^T (A S), encoders.py:374-375):
  * every graph is cut into row slabs (slab_row_ptr[nslab+1], graph b owns slabs [seg_slab_ptr[b], seg_slab_ptr[b+1])),

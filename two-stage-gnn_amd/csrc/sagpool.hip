@@ -15,6 +15,7 @@
 // with one coalesced load and broadcast with wave shuffles.  No atomics on data (bitwise reproducible).
 #include "common.h"
 #include "../../include/tsgnn.h"
+#include "du_reduce_body.h"
 
 namespace {
 
@@ -835,41 +836,8 @@ __global__ __launch_bounds__(256) void sag_du_kernel(const int* __restrict__ row
 // dws[0:F], dbs[0] = column sums of part[nb, F + 4]: 8 slices of blocks per float4 column, then the slices in order
 __global__ __launch_bounds__(256) void sag_du_reduce(float* __restrict__ part, int nb, int F, float* __restrict__ dws,
                                                      float* __restrict__ dbs, int chunk, int stride) {
-  // block i sums rows {q * stride : i * chunk <= q < min(nb, (i + 1) * chunk)} in a fixed order; dws == NULL: the sum goes back
-  // to the block's first row (first stage of the two-stage reduction of a large batch's partials)
   __shared__ float4 s_part[256];
-  const int nvec = F >> 2;
-  const int c4 = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  const int q0 = blockIdx.x * chunk, q1 = min(nb, q0 + chunk);
-  for (int cb = 0; cb < nvec + 1; cb += 32) {                       // column nvec = the db_s partial (lane .x)
-    const int c = cb + c4;
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c <= nvec) {
-#pragma unroll 4
-      for (int q = q0 + sl; q < q1; q += 8) {
-        const float4 v = *reinterpret_cast<const float4*>(part + (int64_t)q * stride * (F + 4) + 4 * c);
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-      }
-    }
-    __syncthreads();
-    s_part[threadIdx.x] = s;
-    __syncthreads();
-    if (sl == 0 && c <= nvec) {
-#pragma unroll
-      for (int q = 1; q < 8; ++q) {
-        const float4 v = s_part[q * 32 + c4];
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-      }
-      if (dws == nullptr) {
-        float* o = part + (int64_t)q0 * stride * (F + 4);
-        if (c < nvec) *reinterpret_cast<float4*>(o + 4 * c) = s;
-        else o[F] = s.x;
-      } else {
-        if (c < nvec) *reinterpret_cast<float4*>(dws + 4 * c) = s;
-        else dbs[0] = s.x;
-      }
-    }
-  }
+  du_reduce_body(part, nb, F, dws, dbs, chunk, stride, (int)blockIdx.x, s_part);
 }
 
 constexpr int DU_REDUCE_CHUNK = 64;
@@ -1275,7 +1243,7 @@ int tsgnn_sag_pool_graph_bwd_f32(const float* y, int64_t ldy, const float* score
   if (dagg_next && (dxp || !rowptr_n || !rowend_n || !col_n || !dinv_n || !self_w_n || lddagg < F)) return TSGNN_EINVAL;
   if (dagg_next && (lddagg % 4 || !aligned16(dagg_next))) return TSGNN_EUNSUPPORTED;
   if (!y || !score || !new_id || !graph_ptr || !graph_ptr_new || !arg || !dread || !rowptr || !dinv || !self_w || !w_s || !du || !part ||
-      !dws || !dbs || B <= 0 || max_seg < 0)
+      ((dws == nullptr) != (dbs == nullptr)) || B <= 0 || max_seg < 0)
     return TSGNN_EINVAL;
   if (!tsgnn_sag_supported(F) || max_seg > PG_MAX_NODES || ldy % 4 || lddu % 4 || lddr % 4 || (dxp && (lddxp % 4 || !aligned16(dxp))) ||
       !aligned16(y) || !aligned16(du) || !aligned16(dread) || !aligned16(arg) || !aligned16(w_s) || !aligned16(part))
@@ -1304,7 +1272,16 @@ int tsgnn_sag_pool_graph_bwd_f32(const float* y, int64_t ldy, const float* score
     default: PGB_LAUNCH(64); break;
   }
 #undef PGB_LAUNCH
-  launch_du_reduce(part, (int)B, F, dws, dbs, stream);
+  if (dws != nullptr) launch_du_reduce(part, (int)B, F, dws, dbs, stream);   // NULL: reduced by tsgnn_linear_wgrad_du_f32
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+/* fixed-order sum of nb partial rows part[nb][F + 4] -> dws[F], dbs[1] (what tsgnn_sag_pool_graph_bwd_f32 runs itself unless it
+ * is called with dws = dbs = NULL) */
+int tsgnn_sag_du_reduce_f32(float* part, int nb, int F, float* dws, float* dbs, tsgnn_stream_t stream) {
+  if (!part || !dws || !dbs || nb <= 0 || !tsgnn_sag_supported(F) || !aligned16(part) || !aligned16(dws)) return TSGNN_EINVAL;
+  launch_du_reduce(part, nb, F, dws, dbs, stream);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }

@@ -153,9 +153,26 @@ def wgrad_reduce_multi(sets, norm_sink=None):
             norm_sink.stepped = norm_sink.stepped or step is not None
 
 
-def linear_wgrad(z, K_in, du, want_db):
-    """(dW[K_in,N], db[N] or None) in one pass over the rows; falls back to split-K GEMM + column sums."""
+def linear_wgrad(z, K_in, du, want_db, du_job=None):
+    """(dW[K_in,N], db[N] or None) in one pass over the rows; falls back to split-K GEMM + column sums.
+    du_job = (part, nb, F, dws, dbs): the partial rows tsgnn_sag_pool_graph_bwd_f32 left behind (called with dws = dbs = NULL);
+    their sum rides in this product's reduction launch when the one-pass slab kernel takes the shape, else it is launched here."""
     R, N = du.size(0), du.size(1)
+    if du_job is not None:
+        part, nb, F_du, dws, dbs = du_job
+        nslab = np.zeros(1, dtype=np.int32)
+        rps = np.zeros(1, dtype=np.int64)
+        need = np.zeros(1, dtype=np.int64)
+        nat.call_nostream("linear_wgrad_plan", int(R), int(K_in), int(N), int(z.stride(0)), int(du.stride(0)), nslab.ctypes.data,
+                          rps.ctypes.data, need.ctypes.data)
+        if int(nslab[0]) > 0 and nb <= 256 and z.data_ptr() % 16 == 0 and du.data_ptr() % 16 == 0:
+            ws = _f32(int(need[0]), device=du.device)
+            dw = _f32(K_in, N, device=du.device)
+            db = _f32(N, device=du.device) if want_db else None
+            nat.call("linear_wgrad_du_f32", z, z.stride(0), du, du.stride(0), R, int(K_in), int(N), int(nslab[0]), int(rps[0]), ws,
+                     dw, db, part, int(nb), int(F_du), dws, dbs)
+            return dw, db
+        nat.call("sag_du_reduce_f32", part, int(nb), int(F_du), dws, dbs)
     nslab = np.zeros(1, dtype=np.int32)
     rps = np.zeros(1, dtype=np.int64)
     need = np.zeros(1, dtype=np.int64)

@@ -238,13 +238,15 @@ class _SagStack(torch.autograd.Function):
             xin, agg, y, score, new_id, arg, rowptr, col, rowptr_t, col_t, dinv, self_w, W, wsv, rowend, _ = ctx.saved_levels[l]
             dyb = _f32(N, H, device=dev)
             dws, dbs = _f32(H, device=dev), _f32(1, device=dev)
+            du_job = None
             if sym and L.max_seg <= pool_graph_max and PER_GRAPH_POOL:
                 # pooled-row gradients -> score-layer backward -> du: one workgroup per graph, then the partial-sum reduction
                 part = _f32(L.B * (H + 4), device=dev)
                 nat.call("sag_pool_graph_bwd_f32", y, y.stride(0), score, new_id, L.gp, Ln.gp, arg, dxp,
                          dxp.stride(0) if dxp is not None else 0, dread, dread.stride(0), rowptr, rowend, col, dinv, self_w, wsv,
-                         L.B, L.max_seg, H, dyb, dyb.stride(0), part, dws, dbs,
+                         L.B, L.max_seg, H, dyb, dyb.stride(0), part, None, None,      # partial rows: summed with the dW slabs below
                          *((nxt[0], nxt[0].stride(0)) + nxt[1:] if nxt is not None else (None, 0, None, None, None, None, None)))
+                du_job = (part, L.B, H, dws, dbs)
             else:
                 if nxt is not None:
                     raise RuntimeError("the in-kernel gradient propagate belongs to the per-graph backward")
@@ -256,7 +258,7 @@ class _SagStack(torch.autograd.Function):
                 # dt = A^T dscore: the score layer's propagate transposed
                 nat.call("sag_du_f32", rowptr_t, rowend, col_t, dinv, self_w, dscore, y, y.stride(0), wsv, dyb, dyb.stride(0), N, H, part,
                          dws, dbs)
-            dW, db = mp.linear_wgrad(agg, agg.size(1), dyb, True)
+            dW, db = mp.linear_wgrad(agg, agg.size(1), dyb, True, du_job=du_job)
             grads[4 * l: 4 * l + 4] = [dW, db, dws.view(-1, 1), dbs]
             if l > 0 or ctx.x_needs_grad:
                 dagg = _linear_t(dyb, W)
