@@ -388,6 +388,12 @@ int tsgnn_gcn_propagate_f32(const int* rowptr, const int* col, const float* dinv
 int tsgnn_gcn_propagate_re_f32(const int* rowptr, const int* rowend, const int* col, const float* dinv, const float* self_w,
                                const float* x, int64_t ldx, int relu_in, const float* bias, const float* w_dot, const float* dot_bias,
                                float* y, int64_t ldy, float* t, int64_t n_rows, int feat, tsgnn_stream_t stream);
+/* Narrow inputs (feat <= 8; IMDB-B has one constant column): the aggregation agg = A^ x (as tsgnn_gcn_propagate_re_f32, kept for
+ * the weight gradient) AND GCNConv's transform y = agg . w + bias (w [feat, n_out] row-major; network.py:34) in one launch — at
+ * feat = 1 the transform is an outer product, not worth an MFMA launch of its own. */
+int tsgnn_gcn_propagate_affine_f32(const int* rowptr, const int* rowend, const int* col, const float* dinv, const float* self_w,
+                                   const float* x, int64_t ldx, float* agg, int64_t ldagg, int64_t n_rows, int feat, const float* w,
+                                   int64_t ldw, const float* bias, float* y, int64_t ldy, int n_out, tsgnn_stream_t stream);
 /* 1 when the fused level kernels below accept feature width F (F % 4 == 0, F <= 256) */
 int tsgnn_sag_supported(int F);
 /* kept rows (layers.py:21): xp[p,:] = relu?(y[perm[p],:]) * tanh(score[perm[p]]); cnt[p] = kept neighbours of perm[p].

@@ -60,6 +60,9 @@ struct PropArgs {
   int64_t n_rows;
   int feat;
   int relu_in;             // gather relu(x) instead of x
+  // narrow inputs only (feat <= 8, wave-per-row kernel): the GCNConv transform that follows the aggregation in the same launch,
+  // lin_y[row, :lin_n] = agg[row, :feat] . lin_w[feat, lin_n] + lin_b  (network.py:34 at num_features = 1: an outer product)
+  const float* lin_w; int64_t ldlw; const float* lin_b; float* lin_y; int64_t ldly; int lin_n;
 };
 
 template <int G>
@@ -194,23 +197,38 @@ __global__ __launch_bounds__(256) void gcn_propagate_generic(PropArgs a) {
   if (a.feat <= 8) {
     // narrow inputs (the one-column degree / constant feature): lanes over the ENTRIES — with lanes over features one lane
     // walked the neighbours alone, a dependent round trip each
-    for (int f = 0; f < a.feat; ++f) {
-      float acc = 0.f;
-      for (int e = e0 + lane; e < e1; e += 64) {
-        const int j = a.col[e];
-        float v = a.x[(int64_t)j * a.ldx + f];
-        if (a.relu_in) v = fmaxf(v, 0.f);
-        acc = fmaf(a.dinv[j], v, acc);
+    float ov[8];
+#pragma unroll
+    for (int f = 0; f < 8; ++f) {
+      ov[f] = 0.f;
+      if (f < a.feat) {
+        float acc = 0.f;
+        for (int e = e0 + lane; e < e1; e += 64) {
+          const int j = a.col[e];
+          float v = a.x[(int64_t)j * a.ldx + f];
+          if (a.relu_in) v = fmaxf(v, 0.f);
+          acc = fmaf(a.dinv[j], v, acc);
+        }
+        acc = wave_sum(acc);
+        float xs = a.x[row * a.ldx + f];
+        if (a.relu_in) xs = fmaxf(xs, 0.f);
+        float o = fmaf(di, acc, sw * xs);
+        if (a.bias != nullptr) o += a.bias[f];
+        if (a.y != nullptr && lane == 0) a.y[row * a.ldy + f] = o;
+        if (a.w_dot != nullptr) dot = fmaf(o, a.w_dot[f], dot);
+        ov[f] = o;
       }
-      acc = wave_sum(acc);
-      float xs = a.x[row * a.ldx + f];
-      if (a.relu_in) xs = fmaxf(xs, 0.f);
-      float o = fmaf(di, acc, sw * xs);
-      if (a.bias != nullptr) o += a.bias[f];
-      if (a.y != nullptr && lane == 0) a.y[row * a.ldy + f] = o;
-      if (a.w_dot != nullptr) dot = fmaf(o, a.w_dot[f], dot);
     }
     if (a.w_dot != nullptr && lane == 0) a.t[row] = dot + (a.dot_bias ? a.dot_bias[0] : 0.f);
+    if (a.lin_y != nullptr) {                                // every lane holds the row's aggregate: lanes over the output columns
+      for (int c = lane; c < a.lin_n; c += 64) {
+        float v = a.lin_b ? a.lin_b[c] : 0.f;
+#pragma unroll
+        for (int f = 0; f < 8; ++f)
+          if (f < a.feat) v = fmaf(ov[f], a.lin_w[(int64_t)f * a.ldlw + c], v);
+        a.lin_y[row * a.ldly + c] = v;
+      }
+    }
     return;
   }
   for (int fb = 0; fb < a.feat; fb += 64) {                // wave-uniform trip count
@@ -1119,6 +1137,22 @@ int tsgnn_gcn_propagate_re_f32(const int* rowptr, const int* rowend, const int* 
   } else {
     gcn_propagate_generic<<<(unsigned)ceil_div64(n_rows, 4), 256, 0, stream>>>(a);
   }
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+/* narrow inputs (feat <= 8): agg = A^ x AND y = agg . w + bias (GCNConv's transform, w [feat, n_out] row-major) in one launch */
+int tsgnn_gcn_propagate_affine_f32(const int* rowptr, const int* rowend, const int* col, const float* dinv, const float* self_w,
+                                   const float* x, int64_t ldx, float* agg, int64_t ldagg, int64_t n_rows, int feat, const float* w,
+                                   int64_t ldw, const float* bias, float* y, int64_t ldy, int n_out, tsgnn_stream_t stream) {
+  if (n_rows < 0 || feat <= 0 || n_out <= 0 || !rowptr || !dinv || !self_w || !x || !agg || !w || !y || ldx < feat || ldagg < feat ||
+      ldw < n_out || ldy < n_out)
+    return TSGNN_EINVAL;
+  if (feat > 8) return TSGNN_EUNSUPPORTED;
+  if (n_rows == 0) return TSGNN_OK;
+  PropArgs a{rowptr, rowend, col, dinv, self_w, x, ldx, nullptr, nullptr, nullptr, agg, ldagg, nullptr, n_rows, feat, 0,
+             w, ldw, bias, y, ldy, n_out};
+  gcn_propagate_generic<<<(unsigned)ceil_div64(n_rows, 4), 256, 0, stream>>>(a);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }

@@ -167,10 +167,17 @@ class _SagStack(torch.autograd.Function):
             wsv = _al16(ws.contiguous().view(-1))
             if agg_next is not None:
                 agg = agg_next                                  # formed by the previous level's per-graph kernel
+                y = _linear(agg, W, b)
+            elif xin.size(1) <= 8 and N < 32768:
+                # narrow input (one constant column on the IMDB sets): aggregation and transform in one launch (a launch-count
+                # saving: 162 vs 168 us at 128 graphs; from 32,768 rows on the thread-per-row propagate + MFMA product are faster)
+                agg, y = _f32(N, xin.size(1), device=dev), _f32(N, H, device=dev)
+                nat.call("gcn_propagate_affine_f32", rowptr, rowend, col, dinv, self_w, xin, xin.stride(0), agg, agg.stride(0), N,
+                         xin.size(1), W, W.stride(0), b, y, y.stride(0), H)
             else:
                 agg, _ = propagate(rowptr, col, dinv, self_w, xin, N, rowend=rowend)
+                y = _linear(agg, W, b)
             agg_next = None
-            y = _linear(agg, W, b)
             perm, new_id = _i32(max(K, 1), device=dev), _i32(max(N, 1), device=dev)
             xp, cnt = _f32(K, H, device=dev), _i32(max(K, 1), device=dev)
             arg = _i32(B, H, device=dev)
