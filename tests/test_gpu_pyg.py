@@ -206,6 +206,8 @@ def test_sagpool_fused_equals_composed_on_a_large_batch(next_prop, monkeypatch):
     the next level's aggregation / gradient propagate inside the per-graph kernels, and as launches of their own"""
     from two_stage_gnn_amd import sag_layers as S, sag_stack as SS
     monkeypatch.setattr(SS, "FUSED_NEXT_PROPAGATE", next_prop)
+    if not next_prop:
+        monkeypatch.setattr(SS, "NARROW_FUSED_MAX_ROWS", 0)      # 3 input columns: level 0 as propagate + product launches
     gen = torch.Generator().manual_seed(77)
     sizes = torch.randint(5, 41, (600,), generator=gen).tolist()
     n = sum(sizes)

@@ -123,6 +123,7 @@ def _linear_t(du, w):
 PER_GRAPH_POOL = True           # level tail (score -> top-k -> gather -> readout) as one workgroup per graph when graphs are small
 FUSED_NEXT_PROPAGATE = True     # ... which then also forms the next level's aggregation and, backward, takes the next level's
                                 # dagg instead of dxp (A^ applied per kept row in the kernel): two launches less per pooled level
+NARROW_FUSED_MAX_ROWS = 32768             # level 0 on <= 8 input columns: aggregation + transform in one launch below this many rows
 FUSED_NEXT_PROPAGATE_MAX_GRAPHS = 1024   # a launch-count saving: 207 vs 213 us at 128 graphs, 1.21 vs 1.17 ms at 8,192 (few lane groups per block)
 
 
@@ -168,7 +169,7 @@ class _SagStack(torch.autograd.Function):
             if agg_next is not None:
                 agg = agg_next                                  # formed by the previous level's per-graph kernel
                 y = _linear(agg, W, b)
-            elif xin.size(1) <= 8 and N < 32768:
+            elif xin.size(1) <= 8 and N < NARROW_FUSED_MAX_ROWS:
                 # narrow input (one constant column on the IMDB sets): aggregation and transform in one launch (a launch-count
                 # saving: 162 vs 168 us at 128 graphs; from 32,768 rows on the thread-per-row propagate + MFMA product are faster)
                 agg, y = _f32(N, xin.size(1), device=dev), _f32(N, H, device=dev)
