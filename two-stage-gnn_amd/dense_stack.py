@@ -98,6 +98,7 @@ class _DenseGcnStack(torch.autograd.Function):
         grads = [None] * (2 * L)
         dx_next = None
         first_adj = True
+        slab_sets = []
         for l in range(L - 1, -1, -1):
             N = widths[l]
             fin = Fin if l == 0 else widths[l - 1]
@@ -112,7 +113,14 @@ class _DenseGcnStack(torch.autograd.Function):
                          dsl, total, None, 0, None, N, 1, 1, mean, rstd, rinvs[l], du, N)
             want_w, want_b = ctx.needs_input_grad[3 + 2 * l], ctx.has_bias[l] and ctx.needs_input_grad[4 + 2 * l]
             if want_w:
-                grads[2 * l], grads[2 * l + 1] = mp.linear_wgrad(aggs[l], fin, du, want_b)
+                got = mp.linear_wgrad_slabs(aggs[l], fin, du) if fin <= 128 and N <= 128 else None
+                if got is not None:                      # slab partials now, ONE fixed-order reduction for the whole stack below
+                    dw = _f32(fin, N, device=dev)
+                    db = _f32(N, device=dev) if want_b else None
+                    slab_sets.append((got[0], got[1], fin, N, dw, db))
+                    grads[2 * l], grads[2 * l + 1] = dw, db
+                else:
+                    grads[2 * l], grads[2 * l + 1] = mp.linear_wgrad(aggs[l], fin, du, want_b)
             elif want_b:
                 grads[2 * l + 1] = mp.colsum(du)
             if not (need_adj or need_x or l > 0):
@@ -132,6 +140,8 @@ class _DenseGcnStack(torch.autograd.Function):
                 mp.gemm(adj, 1, K, dagg, fin, 1, dxin, fin, 1, K, fin, K, batch=B, stride_a=K * K, stride_b=K * fin,
                         stride_c=K * fin)
                 dx_next = dxin
+        if slab_sets:
+            mp.wgrad_reduce_multi(slab_sets)
         dx = dx_next.view(B, K, Fin) if need_x else None
         return (dx, dadj, None, *grads)
 
