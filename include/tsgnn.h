@@ -301,6 +301,17 @@ int tsgnn_gather_wsum_f32(const float* x, int64_t ldx, const int* idx, const flo
 /* y[r,c] += scale * w[r,c/Fh] * (a ? a[(c/Fh)*lda + c%Fh] : u[(r / rows_per_seg)*ldu + c])   (w NULL = 1) */
 int tsgnn_broadcast_add_f32(float* y, int64_t ldy, int64_t rows, int H, int Fh, const float* w, const float* a, int64_t lda,
                             const float* u, int64_t ldu, int rows_per_seg, float scale, tsgnn_stream_t stream);
+/* The per-head parameters of a DGATLayer (attention_{i}.w [Fin, Fo], attention_{i}.a [2*Fo, 1]; encoders_GAT.py:22-25,60-62)
+ * <-> the fused operands of the layer, one launch each way: W[Fin, H*Fo] = [w_0 | w_1 | ...], A[2, H, Fo] (A[0]: the halves
+ * that meet h_i, A[1]: those that meet h_j, :34-36); backward gw[H, Fin, Fo], ga[H, 2*Fo] from dW / dA[0] / dA[1] (each
+ * nullable = zero).  H <= tsgnn_pack_heads_max(); unused head pointers NULL. */
+int tsgnn_pack_heads_max(void);
+int tsgnn_pack_heads_f32(const float* w0, const float* w1, const float* w2, const float* w3, const float* w4, const float* w5,
+                         const float* w6, const float* w7, const float* a0, const float* a1, const float* a2, const float* a3,
+                         const float* a4, const float* a5, const float* a6, const float* a7, int H, int Fin, int Fo, float* W, float* A,
+                         tsgnn_stream_t stream);
+int tsgnn_unpack_heads_f32(const float* dW, const float* dA0, const float* dA1, int H, int Fin, int Fo, float* gw, float* ga,
+                           tsgnn_stream_t stream);
 /* ELU (encoders_GAT.py:47) / mean over heads then ELU (:78-83) */
 int tsgnn_elu_heads_fwd_f32(const float* x, int64_t rows, int H, int Fh, int mean_heads, int apply_elu, float* y, tsgnn_stream_t stream);
 int tsgnn_elu_heads_bwd_f32(const float* x, const float* dy, int64_t rows, int H, int Fh, int mean_heads, int apply_elu, float* dx,

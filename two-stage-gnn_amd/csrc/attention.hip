@@ -501,6 +501,42 @@ __global__ void elu_heads_bwd_kernel(const float* __restrict__ x, const float* _
   }
 }
 
+// ---------------------------------------------------------------- parameters of a layer's heads <-> fused operands
+// forward:  W[i, h*Fo + f] = w_h[i, f]   (the [Fin, H*Fo] operand of the projection h = x W, encoders_GAT.py:32)
+//           A[s, h, f]     = a_h[s*Fo + f]   (s = 0: the a1 half that meets h_i, s = 1: the a2 half, :34-36)
+// backward: gw[h, i, f] = dW[i, h*Fo + f];  ga[h, s*Fo + f] = dA_s[h, f]   — one launch each way instead of cat / permute / copy
+// launches per tensor kind (the reference keeps one w and one a per head module: attention_{i}.w / .a)
+constexpr int PACK_HMAX = 8;
+struct HeadPtrs { const float* w[PACK_HMAX]; const float* a[PACK_HMAX]; };
+__global__ __launch_bounds__(256) void pack_heads_kernel(HeadPtrs p, int H, int Fin, int Fo, float* __restrict__ W, float* __restrict__ A) {
+  const int64_t nw = (int64_t)Fin * H * Fo, na = (int64_t)2 * H * Fo;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nw) {
+    const int c = (int)(i % (H * Fo)), r = (int)(i / (H * Fo));
+    const int h = c / Fo, f = c % Fo;
+    W[i] = p.w[h][(int64_t)r * Fo + f];
+  } else if (i < nw + na) {
+    const int64_t j = i - nw;
+    const int f = (int)(j % Fo), h = (int)((j / Fo) % H), sidx = (int)(j / ((int64_t)H * Fo));
+    A[j] = p.a[h][sidx * Fo + f];
+  }
+}
+__global__ __launch_bounds__(256) void unpack_heads_kernel(const float* __restrict__ dW, const float* __restrict__ dA0,
+                                                           const float* __restrict__ dA1, int H, int Fin, int Fo,
+                                                           float* __restrict__ gw, float* __restrict__ ga) {
+  const int64_t nw = (int64_t)Fin * H * Fo, na = (int64_t)2 * H * Fo;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nw) {                                             // i indexes gw[h][r][f]: contiguous stores
+    const int f = (int)(i % Fo), r = (int)((i / Fo) % Fin), h = (int)(i / ((int64_t)Fin * Fo));
+    gw[i] = dW ? dW[(int64_t)r * H * Fo + (int64_t)h * Fo + f] : 0.f;
+  } else if (i < nw + na) {
+    const int64_t j = i - nw;                               // ga[h][s*Fo + f]
+    const int f = (int)(j % Fo), sidx = (int)((j / Fo) % 2), h = (int)(j / (2 * (int64_t)Fo));
+    const float* src = sidx ? dA1 : dA0;
+    ga[j] = src ? src[(int64_t)h * Fo + f] : 0.f;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -709,6 +745,31 @@ int tsgnn_elu_heads_bwd_f32(const float* x, const float* dy, int64_t rows, int H
     elu_vec4_bwd_kernel<<<(unsigned)ceil_div64(n / 4, 256), 256, 0, stream>>>(x, dy, n / 4, apply_elu, dx);
   else
     elu_heads_bwd_kernel<<<(unsigned)ceil_div64(rows * H * Fh, 256), 256, 0, stream>>>(x, dy, rows, H, Fh, mean_heads, apply_elu, dx);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+int tsgnn_pack_heads_max(void) { return PACK_HMAX; }
+
+int tsgnn_pack_heads_f32(const float* w0, const float* w1, const float* w2, const float* w3, const float* w4, const float* w5,
+                         const float* w6, const float* w7, const float* a0, const float* a1, const float* a2, const float* a3,
+                         const float* a4, const float* a5, const float* a6, const float* a7, int H, int Fin, int Fo, float* W, float* A,
+                         tsgnn_stream_t stream) {
+  if (H <= 0 || H > PACK_HMAX || Fin <= 0 || Fo <= 0 || !W || !A) return TSGNN_EINVAL;
+  HeadPtrs p{{w0, w1, w2, w3, w4, w5, w6, w7}, {a0, a1, a2, a3, a4, a5, a6, a7}};
+  for (int h = 0; h < H; ++h)
+    if (!p.w[h] || !p.a[h]) return TSGNN_EINVAL;
+  const int64_t n = (int64_t)Fin * H * Fo + (int64_t)2 * H * Fo;
+  pack_heads_kernel<<<(unsigned)ceil_div64(n, 256), 256, 0, stream>>>(p, H, Fin, Fo, W, A);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+int tsgnn_unpack_heads_f32(const float* dW, const float* dA0, const float* dA1, int H, int Fin, int Fo, float* gw, float* ga,
+                           tsgnn_stream_t stream) {
+  if (H <= 0 || Fin <= 0 || Fo <= 0 || !gw || !ga) return TSGNN_EINVAL;
+  const int64_t n = (int64_t)Fin * H * Fo + (int64_t)2 * H * Fo;
+  unpack_heads_kernel<<<(unsigned)ceil_div64(n, 256), 256, 0, stream>>>(dW, dA0, dA1, H, Fin, Fo, gw, ga);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }

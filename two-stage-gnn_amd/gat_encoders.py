@@ -23,6 +23,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import attention as att
+from . import _native as nat
 from . import message_passing as mp
 from .dense_encoders import GraphConv, _batch_from_dense, _default_device
 from .graph import GraphBatch
@@ -107,6 +108,38 @@ class _StackHeadVectors(torch.autograd.Function):
         return tuple(G[h].reshape(2 * Fo, 1) for h in range(H))
 
 
+class _PackHeads(torch.autograd.Function):
+    """(w_0.., a_0..) of a layer's heads -> (W [Fin, H*Fo], a_row [H, Fo], a_col [H, Fo]) in ONE launch, and all 2H parameter
+    gradients from ONE launch backward (cat / permute / copy per tensor kind otherwise: five launches per layer and step)."""
+
+    @staticmethod
+    def forward(ctx, *params):
+        H = len(params) // 2
+        ws, as_ = params[:H], params[H:]
+        Fin, Fo = ws[0].size(0), ws[0].size(1)
+        dev = ws[0].device
+        W = torch.empty(Fin, H * Fo, dtype=torch.float32, device=dev)
+        A = torch.empty(2, H, Fo, dtype=torch.float32, device=dev)
+        pad = [None] * (8 - H)
+        nat.call("pack_heads_f32", *[w.contiguous() for w in ws], *pad, *[a.contiguous() for a in as_], *pad, H, Fin, Fo, W, A)
+        ctx.shape = (H, Fin, Fo)
+        return W, A[0], A[1]
+
+    @staticmethod
+    def backward(ctx, dW, da_row, da_col):
+        H, Fin, Fo = ctx.shape
+        ref = next(t for t in (dW, da_row, da_col) if t is not None)
+        gw = torch.empty(H, Fin, Fo, dtype=torch.float32, device=ref.device)
+        ga = torch.empty(H, 2 * Fo, dtype=torch.float32, device=ref.device)
+        nat.call("unpack_heads_f32", dW.contiguous() if dW is not None else None,
+                 da_row.contiguous() if da_row is not None else None, da_col.contiguous() if da_col is not None else None,
+                 H, Fin, Fo, gw, ga)
+        return tuple(gw[h] for h in range(H)) + tuple(ga[h].reshape(2 * Fo, 1) for h in range(H))
+
+
+PACK_HEADS = True
+
+
 def _gat_heads_forward(heads, x, adj, concat_heads, elu):
     """all heads of a layer in one pass: h = x0 [W_0|W_1|...], one edge-softmax / aggregation launch set."""
     g = _padded_batch(adj)
@@ -124,11 +157,14 @@ def _gat_heads_forward(heads, x, adj, concat_heads, elu):
         x0 = x.reshape(B * N, -1).contiguous().float() if own else _rows_of_graph0(x, g)  # [N, Fin] ([B*N, Fin] per-graph)
     if x0.size(1) % 4 and not x0.requires_grad:
         x0 = F.pad(x0, (0, 4 - x0.size(1) % 4))                            # 16-byte rows: the MFMA row-panel product applies
-    W = _CatHeadWeights.apply(*[hd.w for hd in heads])                      # [Fin, H*Fo]
+    if PACK_HEADS and 1 < H <= 8 and heads[0].w.is_cuda:
+        W, a_row, a_col = _PackHeads.apply(*[hd.w for hd in heads], *[hd.a for hd in heads])
+    else:
+        W = _CatHeadWeights.apply(*[hd.w for hd in heads])                  # [Fin, H*Fo]
+        a_row, a_col = _StackHeadVectors.apply(*[hd.a for hd in heads])    # a1 . h_i (row index i), a2 . h_j (column index j)
     h = mp.linear_l2norm(x0, W, None, normalize=False)                      # [N, H*Fo]
     if B > 1 and not own:
         h = h.unsqueeze(0).expand(B, N, H * Fo).reshape(B * N, H * Fo)       # T4: graph 0's features everywhere
-    a_row, a_col = _StackHeadVectors.apply(*[hd.a for hd in heads])        # a1 . h_i (row index i), a2 . h_j (column index j)
     pre = att.attention_aggregate(h, a_row, a_col, g, H, slope, by_column=True, uniform_isolated=True)
     p = heads[0].dropout
     if p > 0 and heads[0].training:
