@@ -590,7 +590,8 @@ class _ReadoutMax(torch.autograd.Function):
     def backward(ctx, dout, _darg):
         (arg,) = ctx.saved_tensors
         g = ctx.g
-        dout = dout.contiguous()
+        if dout.stride(1) != 1 or dout.stride(0) < dout.size(1):
+            dout = dout.contiguous()                     # (a column slice of the concatenated readouts' gradient is read in place)
         F = dout.size(1)
         dx = _f32(ctx.rows, F, device=dout.device, zero=True)
         nat.call("readout_max_bwd_f32", dout, dout.stride(0), arg, g.B, F, None, 0, 0, g.n_rows, dx, dx.stride(0))
