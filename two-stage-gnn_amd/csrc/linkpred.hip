@@ -137,19 +137,37 @@ __global__ __launch_bounds__(256) void linkpred_edges_kernel(const float* __rest
     const float a0 = lane < K ? S[i * lds_ + lane] : 0.f;
     const float a1 = lane + 64 < K ? S[i * lds_ + lane + 64] : 0.f;
     float d0 = 0.f, d1 = 0.f;
-    for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
-      const int64_t j = col[e];
-      const float b0 = lane < K ? S[j * lds_ + lane] : 0.f;
-      const float b1 = lane + 64 < K ? S[j * lds_ + lane + 64] : 0.f;
-      const float p = wave_sum(fmaf(a0, b0, a1 * b1));
-      float gate;
-      const float pc = lp_clamp(p, clamp, gate);
-      const float a = val ? val[e] : 1.f;
-      const float om = 1.f - pc + LP_EPS, pp = pc + LP_EPS;
-      loss += a * (logf(om) - logf(pp));                               // f1 - f0
-      const float gc = a * gate * (-1.f / pp - 1.f / om) * grad_factor * inv_entries;
-      d0 = fmaf(gc, b0, d0);
-      d1 = fmaf(gc, b1, d1);
+    const int e0 = rowptr[i], e1 = rowptr[i + 1];
+    for (int eb = e0; eb < e1; eb += 64) {
+      // the row's entries (and weights) with one coalesced load, then the neighbours' rows four at a time: entry -> row was a
+      // dependent pair of round trips per neighbour
+      const int me = eb + lane;
+      const int cj = me < e1 ? col[me] : 0;
+      const float av = me < e1 ? (val ? val[me] : 1.f) : 0.f;
+      const int cnt = min(64, e1 - eb);
+      for (int q0 = 0; q0 < cnt; q0 += 4) {
+        float b0[4], b1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int64_t j = __shfl(cj, min(q0 + u, cnt - 1), 64);
+          b0[u] = (lane < K && q0 + u < cnt) ? S[j * lds_ + lane] : 0.f;
+          b1[u] = (lane + 64 < K && q0 + u < cnt) ? S[j * lds_ + lane + 64] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (q0 + u < cnt) {                                            // wave-uniform
+            const float p = wave_sum(fmaf(a0, b0[u], a1 * b1[u]));
+            float gate;
+            const float pc = lp_clamp(p, clamp, gate);
+            const float a = __shfl(av, q0 + u, 64);
+            const float om = 1.f - pc + LP_EPS, pp = pc + LP_EPS;
+            loss += a * (logf(om) - logf(pp));                           // f1 - f0
+            const float gc = a * gate * (-1.f / pp - 1.f / om) * grad_factor * inv_entries;
+            d0 = fmaf(gc, b0[u], d0);
+            d1 = fmaf(gc, b1[u], d1);
+          }
+        }
+      }
     }
     float o0 = 0.f, o1 = 0.f;
     if (dSp != nullptr) {
