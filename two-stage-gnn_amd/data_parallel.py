@@ -153,7 +153,7 @@ class FlatTrainer:
 
 
 class GraphedStep:
-    """One optimiser step on FIXED device buffers, replayed from hipGraphs (the b = 32 step is launch-bound: 16 launches).
+    """One optimiser step on FIXED device buffers, replayed from hipGraphs (the b = 32 step is launch-bound: 15 launches).
 
         gs = GraphedStep(trainer, lambda: model.loss(model(x, g)[1], label))   # captures on its own stream
         for _ in range(steps): gs.step()                                        # refill x / label in place between steps
