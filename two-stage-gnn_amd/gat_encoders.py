@@ -269,9 +269,10 @@ class DGATEncoderGraph(nn.Module):
         if x.dim() == 3:
             x = x.reshape(g.B * g.nmax, x.size(2))
         x = mp.readout_max(x, g)                                                            # max over ALL padded rows (:189)
-        if self.final_dim != "output_dim":
-            return x, self.map2_model(self.pred_model(x))
-        return x, self.map2_model(self.map_model(x))
+        lin1 = self.pred_model if self.final_dim != "output_dim" else self.map_model
+        if mp.head2_ok(x, lin1, self.map2_model):
+            return x, mp.head2(x, lin1, self.map2_model)[1]                                # both nn.Linear: one launch each way
+        return x, self.map2_model(lin1(x))
 
     def loss(self, pred, label, type="softmax"):
         if type == "softmax":
