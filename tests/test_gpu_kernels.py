@@ -236,6 +236,36 @@ def test_ell_fast_path_equals_csr(T, F, p_edge):
         torch.testing.assert_close(y_ell, y_csr, rtol=1e-5, atol=1e-5)
 
 
+def test_aggregation_properties_at_headline_size(T):
+    """size-independent properties of the aggregation on the full BASELINE batch (DD-shaped, 32 graphs, Nmax 1000, F = 128), where
+    the dense oracle is too slow to be the checker: A 1 = degree (bit-exact: small integers), linearity, symmetry
+    <A x, z> = <x, A z>, and the three kernels that serve this size (CSR rows, fixed-width table, fused into the product)
+    agreeing with each other"""
+    mp, _ = T
+    from two_stage_gnn_amd import synthetic, _native as nat
+    hb = synthetic.host_batch(0, 32, "DD", 1000)
+    g, _, _ = synthetic.to_device(hb, torch.device("cuda"))
+    R, F = g.total_rows, 128
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(R, F, generator=gen, device="cuda"); z = torch.randn(R, F, generator=gen, device="cuda")
+    agg = lambda v: mp.spmm_raw(g.rowptr, g.col, None, v, R)
+    deg = (g.rowptr[1:] - g.rowptr[:-1]).float()
+    assert torch.equal(agg(torch.ones(R, F, device="cuda")), deg.unsqueeze(1).expand(R, F))
+    ax, az = agg(x), agg(z)
+    torch.testing.assert_close(agg(2.5 * x - 0.75 * z), 2.5 * ax - 0.75 * az, rtol=1e-4, atol=1e-4)
+    lhs, rhs = (ax.double() * z.double()).sum(), (x.double() * az.double()).sum()
+    assert abs(float(lhs - rhs)) <= 1e-6 * abs(float(lhs)) + 1e-6                      # TU graphs are undirected: A = A^T
+    if mp.ell_ok(x):
+        ell, W, tail = g.ell()
+        y_ell = mp.spmm_ell(g, x)
+        assert torch.equal(y_ell, ax) if tail is None else torch.allclose(y_ell, ax, rtol=1e-5, atol=1e-5)
+        if tail is None:                                                                # fused into the product: z output = A x
+            w = torch.eye(F, device="cuda"); v = torch.empty(g.n_rows, F, device="cuda"); zo = torch.empty(g.n_rows, F, device="cuda")
+            nat.call("gather_rowgemm_f32", ell, W, None, None, x, F, w, F, 0, None, v, F, None, zo, F, g.n_rows, F, F, 0, 0)
+            torch.testing.assert_close(zo, ax[:g.n_rows], rtol=1e-5, atol=1e-5)
+            torch.testing.assert_close(v, ax[:g.n_rows], rtol=1e-4, atol=1e-4)
+
+
 @pytest.mark.parametrize("rows,K,N,ldz", [(2629, 1, 128, 1), (70000, 3, 64, 4), (5, 4, 100, 4), (0, 1, 8, 1)])
 def test_linear_wgrad_narrow_input(T, rows, K, N, ldz):
     """layers with <= 4 input columns (IMDB's single constant feature): dW = z^T du and db = colsum(du) from one pass over du"""
