@@ -329,6 +329,68 @@ def test_sag_level_kernels_vs_oracle():
     np.testing.assert_array_equal(o.cpu().numpy(), np.concatenate([[0], np.cumsum(c.numpy())]))
 
 
+def test_sag_level_properties_at_baseline_size():
+    """the one-launch level tail on the full BASELINE config-4 batch (IMDB-B-shaped, 128 graphs, H = 128), checked through
+    properties instead of the (slow) python oracle: k = ceil(ratio n) rows per graph, scores non-increasing along perm with ties
+    towards the smaller node, new_id the inverse of perm, xp = relu(y)[perm] * tanh(score[perm]), readout = max || mean of the kept
+    rows, and the filtered adjacency = exactly the kept-kept entries of the input adjacency, relabelled"""
+    import numpy as np
+    from two_stage_gnn_amd import _native as nat, sag_stack as SS, synthetic
+    from two_stage_gnn_amd.graph import GraphBatch
+    hb = synthetic.host_batch(3, 128, "IMDB-BINARY", 136)
+    sizes = hb["sizes"]; n = int(sizes.sum())
+    rp = torch.from_numpy(hb["rowptr"][: n + 1].astype(np.int32)).cuda(); col = torch.from_numpy(hb["col"].astype(np.int32)).cuda()
+    dst = torch.repeat_interleave(torch.arange(n, device="cuda"), (rp[1:] - rp[:-1]).long())
+    g = GraphBatch.from_edge_index(torch.stack([col.long(), dst]), n, ghosts=False)
+    dinv, self_w = SS.gcn_coef(g)
+    plan = SS.SagPlan.get(sizes, 0.5, torch.device("cuda"), depth=2)
+    L, Ln = plan.levels[0], plan.levels[1]
+    K, H = Ln.N, 128
+    assert np.array_equal(Ln.sizes, np.ceil(0.5 * sizes).astype(np.int64))
+    gen = torch.Generator(device="cuda").manual_seed(8)
+    y = torch.randn(n, H, generator=gen, device="cuda"); ws = torch.randn(H, generator=gen, device="cuda"); bs = torch.randn(1, generator=gen, device="cuda")
+    i32 = lambda *s: torch.empty(*s, dtype=torch.int32, device="cuda")
+    score = torch.empty(n, device="cuda"); perm, new_id, cnt = i32(K), i32(n), i32(K)
+    xp = torch.empty(K, H, device="cuda"); out = torch.empty(L.B, 2 * H, device="cuda"); arg = i32(L.B, H)
+    rp_n, re_n, col_n = i32(K), i32(K), torch.full((int(g.col.numel()),), -7, dtype=torch.int32, device="cuda")
+    d_n, s_n = torch.empty(K, device="cuda"), torch.empty(K, device="cuda")
+    nat.call("sag_pool_graph_f32", y, H, g.rowptr, None, g.col, dinv, self_w, ws, bs, L.gp, Ln.gp, L.B, L.max_seg, H, score, perm, new_id, xp, H,
+             cnt, out, 2 * H, arg, 0, rp_n, re_n, col_n, d_n, s_n, None, 0)
+    # score layer = A^ (relu(y) w) + b through the stand-alone propagate kernel
+    _, t_ref = SS.propagate(g.rowptr, g.col, dinv, self_w, y, n, relu_in=True, w_dot=ws, dot_bias=bs, want_y=False)
+    torch.testing.assert_close(score, t_ref, rtol=1e-5, atol=1e-5)
+    permL, row_graph = perm.long(), L.row_graph.long()
+    kept_graph = Ln.row_graph.long()
+    assert torch.equal(row_graph[permL], kept_graph)                                          # kept rows stay in their graph
+    sp = score[permL]
+    same = kept_graph[1:] == kept_graph[:-1]
+    assert bool(((sp[:-1] >= sp[1:]) | ~same).all())                                          # descending inside every graph
+    ties = same & (sp[:-1] == sp[1:])
+    assert bool((permL[:-1][ties] < permL[1:][ties]).all())
+    inv = torch.full((n,), -1, dtype=torch.int32, device="cuda"); inv[permL] = torch.arange(K, dtype=torch.int32, device="cuda")
+    assert torch.equal(new_id, inv)
+    # the smallest kept score of a graph is >= every dropped score of that graph
+    big = torch.full((L.B,), float("inf"), device="cuda").scatter_reduce(0, kept_graph, sp, "amin")
+    dropped = new_id < 0
+    assert bool((score[dropped] <= big[row_graph[dropped]]).all())
+    xr = torch.relu(y)[permL] * torch.tanh(sp).unsqueeze(1)
+    torch.testing.assert_close(xp, xr, rtol=1e-5, atol=1e-6)
+    mx = torch.full((L.B, H), float("-inf"), device="cuda").scatter_reduce(0, kept_graph.unsqueeze(1).expand(K, H), xp, "amax")
+    mean = torch.zeros(L.B, H, device="cuda").index_add_(0, kept_graph, xp) / torch.from_numpy(Ln.sizes).cuda().float().unsqueeze(1)
+    torch.testing.assert_close(out, torch.cat([mx, mean], 1), rtol=1e-5, atol=1e-5)
+    # filtered adjacency: the kept-kept entries, relabelled (as sets of (new row, new col) pairs)
+    src_new, dst_new = new_id.long()[g.col.long()], new_id.long()[dst]
+    keep = (src_new >= 0) & (dst_new >= 0)
+    ref = torch.sort(dst_new[keep] * K + src_new[keep]).values
+    lens = (re_n - rp_n).long()
+    assert int(lens.sum()) == int(keep.sum())
+    rows_new = torch.repeat_interleave(torch.arange(K, device="cuda"), lens)
+    pos = rp_n.long().repeat_interleave(lens) + (torch.arange(int(lens.sum()), device="cuda") - (torch.cumsum(lens, 0) - lens).repeat_interleave(lens))
+    got = torch.sort(rows_new * K + col_n.long()[pos]).values
+    assert torch.equal(got, ref)
+    assert torch.equal(cnt.long(), lens)
+
+
 @pytest.mark.parametrize("F", [64, 128])
 def test_gcn_propagate_row_batched_large(F):
     """>= 262,144 rows take the row-batched gather (4 rows per lane group): same result as an index_add formulation,
