@@ -250,6 +250,40 @@ def test_diffpool_contract_golden():
     np.testing.assert_allclose(adj.grad.cpu().numpy(), g["gadj"], rtol=1e-4, atol=1e-5)
 
 
+def test_diffpool_contraction_properties_at_baseline_size():
+    """level-1 contraction X' = S^T Z, A' = S^T A S on the full BASELINE config-5 batch (DD-shaped, 16 graphs, Nmax 512, 64
+    clusters, Z 192 wide) through properties the dense oracle would need 16 x 512 x 512 products for: rows of S sum to one
+    (ghost rows to zero), so the entries of A'_b add up to the number of edges of graph b and the rows of X'_b to the column sums
+    of Z over its nodes; A' is symmetric because A is; both outputs are linear in Z / bilinear in S"""
+    from two_stage_gnn_amd import diffpool as dp, synthetic
+    hb = synthetic.host_batch(4, 16, "DD", 512)
+    g, _, _ = synthetic.to_device(hb, torch.device("cuda"))
+    R, K, F = g.total_rows, 64, 192
+    gen = torch.Generator(device="cuda").manual_seed(6)
+    S = dp.row_softmax(torch.randn(R, K, generator=gen, device="cuda"), g.n_rows if g.n_ghost else None)
+    Z = torch.randn(R, F, generator=gen, device="cuda")
+    if g.n_ghost:
+        Z[g.n_rows:] = 0
+    torch.testing.assert_close(S[:g.n_rows].sum(1), torch.ones(g.n_rows, device="cuda"), rtol=1e-5, atol=1e-5)
+    assert not g.n_ghost or float(S[g.n_rows:].abs().max()) == 0.0
+    Xo, Ao = dp.diffpool_contract_rows(S, Z, g)
+    assert Xo.shape == (g.B, K, F) and Ao.shape == (g.B, K, K)
+    gp = g.graph_ptr.long()
+    deg = (g.rowptr[1:] - g.rowptr[:-1]).double()[:g.n_rows]
+    rg = torch.repeat_interleave(torch.arange(g.B, device="cuda"), gp[1:] - gp[:-1])
+    edges = torch.zeros(g.B, dtype=torch.float64, device="cuda").index_add_(0, rg, deg)
+    torch.testing.assert_close(Ao.double().sum((1, 2)), edges, rtol=1e-4, atol=1e-3)
+    zsum = torch.zeros(g.B, F, dtype=torch.float64, device="cuda").index_add_(0, rg, Z[:g.n_rows].double())
+    torch.testing.assert_close(Xo.double().sum(1), zsum, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(Ao, Ao.transpose(1, 2), rtol=1e-4, atol=1e-4)
+    Z2 = torch.randn(R, F, generator=gen, device="cuda")
+    if g.n_ghost:
+        Z2[g.n_rows:] = 0
+    X2, _ = dp.diffpool_contract_rows(S, Z2, g)
+    X3, _ = dp.diffpool_contract_rows(S, 2.0 * Z - 0.5 * Z2, g)
+    torch.testing.assert_close(X3, 2.0 * Xo - 0.5 * X2, rtol=1e-4, atol=1e-4)
+
+
 @pytest.mark.parametrize("tag", ["p1", "p2", "p1_nomask"])
 def test_diffpool_encoder_golden(tag):
     from two_stage_gnn_amd import dense_encoders as E
