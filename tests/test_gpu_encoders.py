@@ -250,6 +250,36 @@ def test_diffpool_contract_golden():
     np.testing.assert_allclose(adj.grad.cpu().numpy(), g["gadj"], rtol=1e-4, atol=1e-5)
 
 
+def test_gat_column_softmax_mass_at_baseline_size():
+    """attention aggregation on the full DD-shaped 32-graph batch (packed rows + one ghost representative per graph, 4 heads x
+    64): every COLUMN j of the (column-)softmax of encoders_GAT.py:41-45 hands out exactly one unit of mass — to its neighbours
+    through their softmax weights, or, when all-masked (isolated and padded nodes), as the uniform 1/Nmax over all rows.  With
+    features that are a per-row constant c_r, out_i = sum_j alpha_ij c_j, so the multiplicity-weighted row sum of the output must
+    equal the multiplicity-weighted sum of c over the graph, for every head and whatever the attention vectors are"""
+    import numpy as np
+    from two_stage_gnn_amd import attention as att, synthetic
+    from two_stage_gnn_amd.graph import GraphBatch
+    B, nmax, H, Fo = 32, 1000, 4, 64
+    hb = synthetic.host_batch(2, B, "DD", nmax)
+    _, adj = synthetic.to_dense(hb)
+    g = GraphBatch.from_dense_ghost1(adj.cuda(), hb["sizes"])
+    g.transpose_map()
+    R = g.total_rows
+    gen = torch.Generator(device="cuda").manual_seed(4)
+    a_row = torch.randn(H, Fo, generator=gen, device="cuda"); a_col = torch.randn(H, Fo, generator=gen, device="cuda")
+    c = torch.rand(R, 1, generator=gen, device="cuda") + 0.5
+    h = c.expand(R, H * Fo).contiguous()
+    out = att.attention_aggregate(h, a_row, a_col, g, H, 0.2, by_column=True, uniform_isolated=True)      # [R, H*Fo]
+    assert out.shape == (R, H * Fo)
+    gp = g.graph_ptr.long()
+    rg = torch.repeat_interleave(torch.arange(B, device="cuda"), gp[1:] - gp[:-1])
+    mult = g.row_mult.double()
+    mass = torch.zeros(B, H * Fo, dtype=torch.float64, device="cuda").index_add_(0, rg, out.double()[: g.n_rows] * mult.unsqueeze(1))
+    # sum_i mult_i out_i = sum_j mult_j c_j (column j carries c_j, and a unit of softmax mass)
+    ref = torch.zeros(B, dtype=torch.float64, device="cuda").index_add_(0, rg, (c.double().view(-1)[: g.n_rows] * mult))
+    torch.testing.assert_close(mass, ref.unsqueeze(1).expand(B, H * Fo), rtol=2e-4, atol=1e-3)
+
+
 def test_diffpool_contraction_properties_at_baseline_size():
     """level-1 contraction X' = S^T Z, A' = S^T A S on the full BASELINE config-5 batch (DD-shaped, 16 graphs, Nmax 512, 64
     clusters, Z 192 wide) through properties the dense oracle would need 16 x 512 x 512 products for: rows of S sum to one
