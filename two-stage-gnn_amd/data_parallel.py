@@ -8,6 +8,8 @@ is tiny (SAGE-3L h=128 on DD: ~61 k parameters = 0.25 MB), so the collective is 
 bucket, one call.  Slot batch-norm statistics stay local to each rank's batch (= the reference run on
 each shard).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -170,6 +172,7 @@ class GraphedStep:
         self.stream = stream if stream is not None else torch.cuda.Stream()
         self.loss = None
         self._fb = self._opt = None
+        self.one_graph = False
         with torch.cuda.stream(self.stream):
             for _ in range(warmup):                                # allocator / lazy-init warm-up on the capture stream
                 self._fwd_bwd(); trainer.all_reduce(); trainer.apply()
@@ -180,12 +183,17 @@ class GraphedStep:
                 dist.barrier(group=trainer.group)                  # no collective in flight while capturing
                 torch.cuda.synchronize()
             mode = {"capture_error_mode": "thread_local"} if self.multi else {}
+            # TSGNN_GRAPH_ALLREDUCE=1 (opt-in, to be validated on a multi-GPU box): the collective is captured too and the
+            # N > 1 step is ONE graph; RCCL's all-reduce captures and replays correctly in a one-rank group on this stack
+            self.one_graph = self.multi and os.environ.get("TSGNN_GRAPH_ALLREDUCE") == "1"
             self._fb = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._fb, stream=self.stream, **mode):
                 self._fwd_bwd()
-                if not self.multi:
+                if self.one_graph:
+                    trainer.all_reduce()
+                if not self.multi or self.one_graph:
                     trainer.apply()
-            if self.multi:
+            if self.multi and not self.one_graph:
                 self._opt = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self._opt, stream=self.stream, **mode):
                     trainer.apply()
@@ -202,7 +210,7 @@ class GraphedStep:
         with torch.cuda.stream(self.stream):
             if not self.use_graph:
                 self._fwd_bwd(); self.trainer.all_reduce(); self.trainer.apply()
-            elif not self.multi:
+            elif not self.multi or self.one_graph:
                 self._fb.replay()
             else:
                 self._fb.replay(); self.trainer.all_reduce(); self._opt.replay()
