@@ -237,6 +237,38 @@ __global__ __launch_bounds__(256) void readout_max_partial(SlotArgs s, const flo
     if (m) atomicMax(&packed[(int64_t)b * F + f], m);
   }
 }
+// nmax <= 64 (the pooled DiffPool levels: 64- and 8-node graphs): one chunk per graph, so neither the zeroed packed buffer,
+// nor atomics, nor the decode launch are needed — block b scans graph b's slots, thread per feature, eight slots in flight
+__global__ __launch_bounds__(256) void readout_max_direct(SlotArgs s, const float* __restrict__ x, int64_t ld, int F, int relu,
+                                                          float* __restrict__ out, int64_t ldo, int* __restrict__ arg) {
+  const int b = blockIdx.x;
+  const int g0 = s.graph_ptr[b];
+  const int sz = s.graph_ptr[b + 1] - g0;
+  const int nslots = s.n_ghost ? s.nmax : sz;
+  for (int f = threadIdx.x; f < F; f += 256) {
+    unsigned long long best = 0ull;
+    for (int n0 = 0; n0 < nslots; n0 += 8) {
+      float val[8];
+      int64_t rr[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int n = n0 + u;
+        rr[u] = n < sz ? (int64_t)g0 + n : s.n_real + n;
+        val[u] = n < nslots ? x[rr[u] * ld + f] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (n0 + u < nslots) {
+          const unsigned long long p = ((unsigned long long)f32_ordered(act(val[u], relu)) << 32) |
+                                       (unsigned long long)(0xFFFFFFFFu - (unsigned)rr[u]);
+          best = p > best ? p : best;
+        }
+      }
+    }
+    out[(int64_t)b * ldo + f] = best ? ordered_f32((unsigned)(best >> 32)) : 0.f;
+    arg[(int64_t)b * F + f] = best ? (int)(0xFFFFFFFFu - (unsigned)(best & 0xFFFFFFFFull)) : -1;
+  }
+}
 __global__ void readout_max_decode(const unsigned long long* __restrict__ packed, int B, int F, float* __restrict__ out,
                                    int64_t ldo, int* __restrict__ arg) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -357,6 +389,11 @@ int tsgnn_readout_max_fwd_f32(const int* graph_ptr, const int* slot_count, int B
       (n_ghost != 0 && n_ghost != nmax))
     return TSGNN_EINVAL;
   SlotArgs s{graph_ptr, slot_count, B, nmax, n_real, n_ghost};
+  if (nmax <= 64) {                                        // one chunk per graph: a single launch
+    readout_max_direct<<<(unsigned)B, 256, 0, stream>>>(s, x, ldx, F, relu, out, ldo, arg);
+    TSGNN_CHECK_LAUNCH();
+    return TSGNN_OK;
+  }
   (void)hipMemsetAsync(packed_ws, 0, sizeof(unsigned long long) * (size_t)B * F, stream);
   const int FP = (F + 63) & ~63;
   dim3 grid((unsigned)((nmax + 63) / 64), (unsigned)B);
