@@ -144,6 +144,51 @@ def _gpu_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _rccl_one_rank_worker(port, q):
+    """one-rank RCCL group (RCCL refuses two ranks on one device): the N > 1 step as two hipGraphs around an eager all-reduce,
+    and as ONE hipGraph with the collective captured (TSGNN_GRAPH_ALLREDUCE=1), must leave identical parameters"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    from two_stage_gnn_amd import dense_encoders as E, synthetic
+    from two_stage_gnn_amd.data_parallel import FlatTrainer, GraphedStep
+
+    class A:
+        bias = True
+    hb = synthetic.host_batch(seed=3, B=8, shape="DD", nmax=400)
+    g, x, label = synthetic.to_device(hb, torch.device("cuda"))
+    out = []
+    for one_graph in ("0", "1"):
+        os.environ["TSGNN_GRAPH_ALLREDUCE"] = one_graph
+        torch.manual_seed(5)
+        model = E.GcnEncoderGraph(89, 128, 128, 2, 3, bn=True, args=A(), final_dim="number_classes").cuda()
+        tr = FlatTrainer(model, lr=1e-2, clip=2.0)
+        tr.always_reduce = True
+        gs = GraphedStep(tr, lambda: model.loss(model(x, g)[1], label), warmup=2)
+        assert gs.multi and gs.one_graph == (one_graph == "1")
+        for _ in range(3):
+            gs.step()
+        torch.cuda.synchronize()
+        out.append((tr.flat_param.detach().cpu().numpy(), float(tr.state[0])))
+    q.put(out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_one_graph_allreduce_step_equals_two_graph_step():
+    ctx = mp_.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_one_rank_worker, args=(29500 + (os.getpid() + 977) % 2000, q))
+    p.start()
+    out = q.get(timeout=240)
+    p.join(60)
+    assert p.exitcode == 0
+    assert out[0][1] == out[1][1] == 5.0
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+
+
 @pytest.mark.gpu
 def test_two_ranks_hip_step_on_one_gpu():
     ctx = mp_.get_context("spawn")
