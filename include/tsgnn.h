@@ -237,9 +237,10 @@ int tsgnn_adam_from_partials_f32(float* param, const float* grad, float* m, floa
                                  tsgnn_stream_t stream);
 /* clip_grad_norm(max_norm) + Adam.step() of the reference loop (train.py:128-129) on one flat fp32
  * parameter / gradient buffer (the buffer RCCL all-reduces): grad is first scaled by grad_scale
- * (1/world_size).  state: 4 floats {step, grad_norm, applied scale, barrier-timeout flag} (zeroed before the first
- * step); ws >= 258 floats, 8-byte aligned, zeroed once (its tail holds the arrival counter of the one-launch variant
- * used for n <= 262,144: norm and update separated by a device-wide barrier of <= 256 resident blocks). */
+ * (1/world_size).  state: 4 floats {step, grad_norm, applied scale, reserved (always 0)} (zeroed before the first
+ * step); ws >= 258 floats, 8-byte aligned, zeroed once (word 256 is the sign-off counter of the one-launch variant used
+ * for n <= 131,072: every block sums the norm of the whole gradient itself, so there is NO device-wide barrier, no
+ * co-residency assumption and no partial update; larger n: norm partials, norm, update = three launches). */
 int tsgnn_clip_adam_step_f32(float* param, const float* grad, float* m, float* v, int64_t n, float lr, float beta1,
                              float beta2, float eps, float weight_decay, float max_norm, float grad_scale, float* state,
                              float* ws, tsgnn_stream_t stream);

@@ -39,10 +39,11 @@ def _cpu_worker(rank, world, port, q):
         def apply(self):
             _host_apply(self, 1.0 / self.world)
 
-    torch.manual_seed(0)
+    torch.manual_seed(rank)          # replicas start from DIFFERENT bits: FlatTrainer broadcasts rank 0's parameters
     model = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 2))
     tr = HostTrainer(model, lr=1e-2, clip=2.0)
     assert tr.world == world
+    start = tr.flat_param.detach().clone()
     gen = torch.Generator().manual_seed(100 + rank)
     x, y = torch.randn(8, 6, generator=gen), torch.randint(0, 2, (8,), generator=gen)
     local = None
@@ -55,7 +56,7 @@ def _cpu_worker(rank, world, port, q):
             local = tr.flat_grad.clone()
         tr.all_reduce()
         tr.apply()
-    q.put((rank, local.numpy(), tr.flat_param.detach().numpy().copy()))
+    q.put((rank, local.numpy(), tr.flat_param.detach().numpy().copy(), start.numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -71,7 +72,9 @@ def test_flat_bucket_allreduce_gloo_world2():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    # replicas stay identical after every all-reduced step
+    # the constructor aligned the replicas (rank 1 was initialised from another seed) ...
+    np.testing.assert_array_equal(res[0][3], res[1][3])
+    # ... and they stay identical after every all-reduced step
     np.testing.assert_array_equal(res[0][2], res[1][2])
     # and equal a single process that averages the two local gradients itself
     sys.path.insert(0, ROOT)
@@ -122,7 +125,7 @@ def _gpu_worker(rank, world, port, q):
 
     class A:
         bias = True
-    torch.manual_seed(7)
+    torch.manual_seed(7 + rank)          # different initial bits per rank: the trainer broadcasts rank 0's
     model = E.GcnEncoderGraph(7, 16, 16, 2, 3, bn=True, args=A(), final_dim="number_classes").cuda()
     tr = FlatTrainer(model, lr=1e-3, clip=2.0)
     hb = synthetic.host_batch(seed=rank, B=6, shape="MUTAG", nmax=40)
@@ -139,7 +142,22 @@ def _gpu_worker(rank, world, port, q):
         if it == 0:
             reduced = tr.flat_grad.clone()
         tr.apply()
-    q.put((rank, local.cpu().numpy(), reduced.cpu().numpy(), tr.flat_param.detach().cpu().numpy(), tr.state.cpu().numpy()))
+    # the N > 1 GraphedStep (two hipGraphs around the eagerly issued collective) against the same steps launched eagerly
+    from two_stage_gnn_amd.data_parallel import GraphedStep
+    graphed = []
+    for use_graph in (False, True):
+        torch.manual_seed(21)
+        m2 = E.GcnEncoderGraph(7, 16, 16, 2, 3, bn=True, args=A(), final_dim="number_classes").cuda()
+        t2 = FlatTrainer(m2, lr=1e-2, clip=2.0)
+        before = t2.flat_param.clone()
+        gs = GraphedStep(t2, lambda: m2.loss(m2(x, g)[1], label), warmup=2, use_graph=use_graph)
+        assert gs.multi and not gs.one_graph
+        assert torch.equal(before, t2.flat_param) and float(t2.state[0]) == 0.0      # warm-up left the trainer as it was
+        for _ in range(3):
+            gs.step()
+        torch.cuda.synchronize()
+        graphed.append((t2.flat_param.detach().cpu().numpy(), float(t2.state[0])))
+    q.put((rank, local.cpu().numpy(), reduced.cpu().numpy(), tr.flat_param.detach().cpu().numpy(), tr.state.cpu().numpy(), graphed))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -185,7 +203,7 @@ def test_one_graph_allreduce_step_equals_two_graph_step():
     out = q.get(timeout=240)
     p.join(60)
     assert p.exitcode == 0
-    assert out[0][1] == out[1][1] == 5.0
+    assert out[0][1] == out[1][1] == 3.0
     np.testing.assert_array_equal(out[0][0], out[1][0])
 
 
@@ -197,7 +215,7 @@ def test_two_ranks_hip_step_on_one_gpu():
     procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=90) for _ in range(2)], key=lambda t: t[0])
+    res = sorted([q.get(timeout=240) for _ in range(2)], key=lambda t: t[0])
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -205,6 +223,11 @@ def test_two_ranks_hip_step_on_one_gpu():
     np.testing.assert_array_equal(res[0][2], res[1][2])
     np.testing.assert_array_equal(res[0][3], res[1][3])                                    # replicas identical
     assert res[0][4][0] == 2.0                                                             # two optimiser steps
+    for r in range(2):
+        (p_eager, n_eager), (p_graph, n_graph) = res[r][5]
+        assert n_eager == n_graph == 3.0
+        np.testing.assert_array_equal(p_eager, p_graph)                                    # two-graph step == eager step
+    np.testing.assert_array_equal(res[0][5][1][0], res[1][5][1][0])                        # replicas identical after GraphedStep
 
 
 @pytest.mark.gpu
@@ -226,12 +249,12 @@ def test_hip_clip_adam_matches_torch():
         opt.step()
     for a, b in zip(m1.parameters(), m2.parameters()):
         torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
-    assert float(tr.state[0]) == 5.0 and float(tr.state[3]) == 0.0          # five steps, the device-wide barrier never timed out
+    assert float(tr.state[0]) == 5.0 and float(tr.state[3]) == 0.0          # five steps; the reserved word stays 0 (no barrier, nothing to time out)
 
 
 @pytest.mark.gpu
 def test_hip_clip_adam_large_model_three_launch_path():
-    """more than 262,144 parameters: separate norm / final / update launches, same arithmetic."""
+    """more than 131,072 parameters: separate norm / final / update launches, same arithmetic."""
     sys.path.insert(0, ROOT)
     from two_stage_gnn_amd.data_parallel import FlatTrainer
     torch.manual_seed(1)
@@ -239,7 +262,7 @@ def test_hip_clip_adam_large_model_three_launch_path():
     m2 = torch.nn.Linear(600, 500).cuda()
     m2.load_state_dict(m1.state_dict())
     tr = FlatTrainer(m1, lr=1e-3, clip=1.0)
-    assert tr.numel > 262144
+    assert tr.numel > 131072
     opt = torch.optim.Adam(m2.parameters(), lr=1e-3)
     x, y = torch.randn(8, 600).cuda(), torch.randint(0, 500, (8,)).cuda()
     for _ in range(3):
@@ -359,7 +382,7 @@ def test_graphed_step_replays_the_eager_step():
             gs.step()
         torch.cuda.synchronize()
         out.append((tr.flat_param.clone(), float(tr.state[0]), float(gs.loss.detach())))
-    assert out[0][1] == out[1][1] == 5.0                       # 2 warm-up + 3 steps
+    assert out[0][1] == out[1][1] == 3.0                       # the 2 warm-up steps are undone: 3 steps
     torch.testing.assert_close(out[1][0], out[0][0], rtol=0, atol=0)
     assert out[0][2] == out[1][2]
 
@@ -431,3 +454,77 @@ def test_deferred_nll_equals_ordinary_sagpool_step():
     np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=1e-6)
     torch.testing.assert_close(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-7)
     assert all(np.isfinite(v) and v > 0.0 for v in outs[1][0]) and len(set(outs[1][0])) == 3
+
+
+@pytest.mark.gpu
+def test_parameter_feeding_two_fused_nodes_accumulates():
+    """the fused backward nodes STORE into their slice of the flat bucket, so a parameter used by two fused nodes in
+    one backward (the reference's tripletnet calls one encoder three times, tripletnet.py:36-38) must get the second
+    contribution through autograd: direct placement == plain autograd == the sum of the single-forward gradients."""
+    sys.path.insert(0, ROOT)
+    from two_stage_gnn_amd import dense_encoders as E, synthetic
+    from two_stage_gnn_amd.data_parallel import FlatTrainer
+
+    class A:
+        bias = True
+    dev = torch.device("cuda")
+    batches = [synthetic.to_device(synthetic.host_batch(seed=s_, B=5, shape="DD", nmax=300), dev) for s_ in (1, 2, 3)]
+    flat = {}
+    for direct in (False, True):
+        torch.manual_seed(3)
+        model = E.GcnEncoderGraph(89, 128, 128, 2, 3, bn=True, args=A(), final_dim="number_classes").to(dev)
+        tr = FlatTrainer(model, lr=1e-2, clip=2.0, direct_grads=direct)
+        tr.zero_grad()
+        loss = sum(model.loss(model(x, g)[1], label) for g, x, label in batches)          # three forwards, shared weights
+        loss.backward()
+        tr.gather_grads()
+        if direct:
+            assert tr.sink.reused and not tr._norm_ready          # the |grad|^2 shares of the first producer must not be used
+        flat[direct] = tr.flat_grad.clone()
+        singles = torch.zeros_like(tr.flat_grad)
+        for g, x, label in batches:
+            tr.zero_grad()
+            model.loss(model(x, g)[1], label).backward()
+            singles += tr.gather_grads()
+        flat[("sum", direct)] = singles
+        tr.zero_grad(); tr.gather_grads()
+    scale = float(flat[False].abs().max())
+    assert scale > 0
+    torch.testing.assert_close(flat[True], flat[False], rtol=0, atol=2e-6 * scale)
+    torch.testing.assert_close(flat[True], flat[("sum", True)], rtol=0, atol=2e-6 * scale)
+    torch.testing.assert_close(flat[False], flat[("sum", False)], rtol=0, atol=2e-6 * scale)
+
+
+@pytest.mark.gpu
+def test_selfnorm_optimiser_sizes_and_replay():
+    """the one-launch, barrier-free clip + Adam (every block sums the whole norm) at sizes around its block / vector
+    boundaries, replayed from a hipGraph (the sign-off counter re-arms itself), against torch"""
+    sys.path.insert(0, ROOT)
+    from two_stage_gnn_amd import _native as nat
+    dev = torch.device("cuda")
+    for n in (1, 3, 1023, 1024, 1025, 4099, 61002, 131072):
+        gen = torch.Generator().manual_seed(n)
+        p0 = torch.randn(n, generator=gen).to(dev)
+        grads = [torch.randn(n, generator=gen).to(dev) * (0.01 if n > 5000 else 1.0) for _ in range(3)]
+        ref = p0.clone().requires_grad_(True)
+        opt = torch.optim.Adam([ref], lr=1e-2)
+        p, m, v = p0.clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        state, ws = torch.zeros(4, device=dev), torch.zeros(264, device=dev)
+        gbuf = torch.empty(n, device=dev)
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            graph = torch.cuda.CUDAGraph()
+            gbuf.copy_(grads[0])
+            torch.cuda.synchronize()
+            with torch.cuda.graph(graph, stream=s):
+                nat.call("clip_adam_step_f32", p, gbuf, m, v, n, 1e-2, 0.9, 0.999, 1e-8, 0.0, 0.7, 0.5, state, ws)
+            for gi in grads:
+                gbuf.copy_(gi)
+                graph.replay()
+                ref.grad = gi * 0.5
+                torch.nn.utils.clip_grad_norm_([ref], 0.7)
+                opt.step()
+            torch.cuda.synchronize()
+        assert float(state[0]) == 3.0 and float(state[3]) == 0.0
+        torch.testing.assert_close(float(state[1]), float((grads[-1] * 0.5).norm()), rtol=1e-5, atol=0)
+        torch.testing.assert_close(p, ref.detach(), rtol=2e-5, atol=2e-6)

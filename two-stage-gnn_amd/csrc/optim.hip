@@ -1,7 +1,7 @@
 // Optimiser step of the reference's training loop on ONE flat fp32 buffer (train.py:128-129:
 // nn.utils.clip_grad_norm(model.parameters(), clip) then Adam.step()), so that the data-parallel
 // all-reduce (one RCCL call on the same flat gradient buffer) and the update are 1 + 1 launches per
-// step (1 + 3 for models over 262,144 parameters) instead of ~10 launches per parameter tensor.  Graph-replay safe: the step counter lives in
+// step (1 + 3 for models over 131,072 parameters) instead of ~10 launches per parameter tensor.  Graph-replay safe: the step counter lives in
 // device memory.
 #include "common.h"
 #include "../../include/tsgnn.h"
@@ -52,83 +52,77 @@ __global__ void adam_update(float* __restrict__ p, const float* __restrict__ g, 
 }
 
 
-// One-launch variant for small models: the grid is at most one block per CU (all blocks resident), so the blocks can
-// meet at a device-wide barrier between the norm and the update.  Block k owns elements [k*256*CV, (k+1)*256*CV):
-//   partial sum of squares -> part[k] -> arrive (release) -> wait for everyone (acquire, bounded spin) ->
-//   every block adds the partials in the same fixed order -> clip coefficient -> Adam on its own elements.
-// `sync` is a monotonically increasing 64-bit arrival counter (never reset: launch t waits for (t+1)*gridDim.x).
-// A wait that exceeds its bound (blocks not co-resident: cannot happen with <= #CU tiny blocks on an idle queue) gives
-// up, reports through state[3] and skips the update instead of hanging the device.
+// One-launch variant for small models, WITHOUT a device-wide barrier: every block computes the norm of the WHOLE gradient
+// itself (same fixed order in every block -> the same bits everywhere; the buffer is <= 512 KB and sits in L2 after the
+// all-reduce wrote it), then clips and runs Adam on its own 256*CV elements.  Nothing waits for another block, so there is
+// no co-residency assumption, no spin, no timeout and therefore no way to apply a partial update (round 1's variant met at
+// a bounded spin barrier and could give up half-way).  Redundant reads: nblocks x n x 4 B of L2 traffic (61 k parameters:
+// 60 blocks x 244 KB = 15 MB), a few microseconds of latency instead of a second launch.
 constexpr int CV = 4;               // elements per thread
-constexpr int COOP_MAX_BLOCKS = 256;
-__global__ __launch_bounds__(256) void clip_adam_coop(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                      float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
-                                                      float wd, float max_norm, float grad_scale, float* __restrict__ state,
-                                                      float* __restrict__ part, unsigned long long* __restrict__ sync) {
+constexpr int64_t SELFNORM_MAX_N = 131072;
+__global__ __launch_bounds__(256) void clip_adam_selfnorm(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                          float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
+                                                          float wd, float max_norm, float grad_scale, float* __restrict__ state,
+                                                          unsigned* __restrict__ done) {
   __shared__ float lds[4];
-  __shared__ int ok_s;
-  const int tid = threadIdx.x, nb = gridDim.x;
+  const int tid = threadIdx.x;
   const int64_t base = ((int64_t)blockIdx.x * 256 + tid) * CV;
-  float gv[CV];
-  float s = 0.f;
-#pragma unroll
-  for (int c = 0; c < CV; ++c) {
-    gv[c] = (base + c) < n ? g[base + c] : 0.f;
-    s = fmaf(gv[c], gv[c], s);
-  }
-  const float step = state[0] + 1.f;                   // read before anyone can have updated it (block 0 does, after the barrier)
-  float pv[CV], mv[CV], vv[CV];                        // the update's operands travel while the blocks meet
+  float gv[CV], pv[CV], mv[CV], vv[CV];                // the update's operands travel while the norm is summed
 #pragma unroll
   for (int c = 0; c < CV; ++c) {
     const bool ok = (base + c) < n;
-    pv[c] = ok ? p[base + c] : 0.f; mv[c] = ok ? m[base + c] : 0.f; vv[c] = ok ? v[base + c] : 0.f;
+    gv[c] = ok ? g[base + c] : 0.f; pv[c] = ok ? p[base + c] : 0.f; mv[c] = ok ? m[base + c] : 0.f; vv[c] = ok ? v[base + c] : 0.f;
   }
-  s = wave_sum(s);
+  const float step = state[0] + 1.f;                   // every block reads the OLD counter; whichever block retires last stores
+                                                       // the new one (see the end of the kernel): nobody waits for anybody
+  const float4* __restrict__ g4 = reinterpret_cast<const float4*>(g);
+  const int64_t n4 = n >> 2;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int64_t i = tid;
+  for (; i + 3 * 256 < n4; i += 4 * 256) {             // four independent 16-byte loads in flight per thread
+    const float4 a = g4[i], b = g4[i + 256], c = g4[i + 512], d = g4[i + 768];
+    s0 = fmaf(a.x, a.x, s0); s0 = fmaf(a.y, a.y, s0); s0 = fmaf(a.z, a.z, s0); s0 = fmaf(a.w, a.w, s0);
+    s1 = fmaf(b.x, b.x, s1); s1 = fmaf(b.y, b.y, s1); s1 = fmaf(b.z, b.z, s1); s1 = fmaf(b.w, b.w, s1);
+    s2 = fmaf(c.x, c.x, s2); s2 = fmaf(c.y, c.y, s2); s2 = fmaf(c.z, c.z, s2); s2 = fmaf(c.w, c.w, s2);
+    s3 = fmaf(d.x, d.x, s3); s3 = fmaf(d.y, d.y, s3); s3 = fmaf(d.z, d.z, s3); s3 = fmaf(d.w, d.w, s3);
+  }
+  for (; i < n4; i += 256) {
+    const float4 a = g4[i];
+    s0 = fmaf(a.x, a.x, s0); s0 = fmaf(a.y, a.y, s0); s0 = fmaf(a.z, a.z, s0); s0 = fmaf(a.w, a.w, s0);
+  }
+  for (int64_t k = (n4 << 2) + tid; k < n; k += 256) s1 = fmaf(g[k], g[k], s1);
+  float s = wave_sum((s0 + s1) + (s2 + s3));
   if ((tid & 63) == 0) lds[tid >> 6] = s;
-  __syncthreads();
-  if (tid == 0) {
-    __hip_atomic_store(part + blockIdx.x, (lds[0] + lds[1]) + (lds[2] + lds[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long ticket = __hip_atomic_fetch_add(sync, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long target = (ticket / (unsigned long long)nb + 1ull) * (unsigned long long)nb;
-    int ok = 0;
-    for (int spin = 0; spin < (1 << 20); ++spin) {
-      if (__hip_atomic_load(sync, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = 1; break; }
-      __builtin_amdgcn_s_sleep(1);
-    }
-    ok_s = ok;
-  }
-  __syncthreads();
-  if (!ok_s) {
-    if (tid == 0) state[3] = 1.f;
-    return;
-  }
-  float t = 0.f;
-  for (int k = tid; k < nb; k += 256) t += __hip_atomic_load(part + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // nb <= 256: one each
-  t = wave_sum(t);
-  __syncthreads();
-  if ((tid & 63) == 0) lds[tid >> 6] = t;
   __syncthreads();
   const float norm = sqrtf((lds[0] + lds[1]) + (lds[2] + lds[3])) * grad_scale;
   float coef = 1.f;
   if (max_norm > 0.f) coef = fminf(max_norm / (norm + 1e-6f), 1.f);
   const float scale = coef * grad_scale;
-  if (blockIdx.x == 0 && tid == 0) { state[0] = step; state[1] = norm; state[2] = scale; }
   const float bc1 = 1.f - powf(b1, step), bc2 = 1.f - powf(b2, step);
 #pragma unroll
   for (int c = 0; c < CV; ++c) {
-    const int64_t i = base + c;
-    if (i < n) {
+    const int64_t k = base + c;
+    if (k < n) {
       float gi = gv[c] * scale;
       if (wd != 0.f) gi = fmaf(wd, pv[c], gi);
       const float mi = fmaf(b1, mv[c], (1.f - b1) * gi);
       const float vi = fmaf(b2, vv[c], (1.f - b2) * gi * gi);
-      m[i] = mi; v[i] = vi;
+      m[k] = mi; v[k] = vi;
       const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
-      p[i] = pv[c] - (lr / bc1) * (mi / denom);
+      p[k] = pv[c] - (lr / bc1) * (mi / denom);
+    }
+  }
+  // Step counter: each block has read state[0] by now; it signs off on `done` (release) and the block that finds itself last
+  // (acquire: every other block's read of state[0] happened before) stores the new counter and re-arms `done` for the next
+  // launch / graph replay.  A sign-off, not a barrier: no block ever waits.
+  if (tid == 0) {
+    const unsigned prev = __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == gridDim.x - 1) {
+      __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      state[0] = step; state[1] = norm; state[2] = scale;
     }
   }
 }
-
 
 // Barrier-free variant for a single GPU: the kernels that PRODUCE the gradients (tn_rows_reduce_multi, head2_bwd) already
 // left their share of |grad|^2 in parts[0..nparts) and bumped the step counter, so every block can finish the norm itself
@@ -223,18 +217,18 @@ int tsgnn_adam_from_partials_f32(float* param, const float* grad, float* m, floa
 }
 
 /* One optimiser step on flat buffers: g *= grad_scale (1/world after the all-reduce), clip to max_norm
- * (<=0: off), Adam.  ws >= 258 floats, 8-byte aligned, zeroed once before the first step (its last two words are the
- * barrier counter of the one-launch variant); state = 4 floats {step, grad_norm, applied scale, barrier timeout flag},
- * zero before step 1.  n <= 262,144: ONE launch (device-wide barrier between norm and update); larger: three. */
+ * (<=0: off), Adam.  ws >= 258 floats, 8-byte aligned, zeroed once before the first step (word 256 is the sign-off counter
+ * of the one-launch variant, which re-arms it itself); state = 4 floats {step, grad_norm, applied scale, reserved = 0},
+ * zero before step 1.  n <= 131,072: ONE launch, no device-wide barrier (every block sums the whole norm); larger: three. */
 int tsgnn_clip_adam_step_f32(float* param, const float* grad, float* m, float* v, int64_t n, float lr, float beta1,
                              float beta2, float eps, float weight_decay, float max_norm, float grad_scale, float* state,
                              float* ws, tsgnn_stream_t stream) {
   if (!param || !grad || !m || !v || !state || !ws || n <= 0) return TSGNN_EINVAL;
   if (reinterpret_cast<uintptr_t>(ws) & 7) return TSGNN_EINVAL;
-  if (n <= (int64_t)COOP_MAX_BLOCKS * 256 * CV) {
+  if (n <= SELFNORM_MAX_N) {
     const int nbc = (int)ceil_div64(n, 256 * CV);
-    clip_adam_coop<<<nbc, 256, 0, stream>>>(param, grad, m, v, n, lr, beta1, beta2, eps, weight_decay, max_norm, grad_scale, state, ws,
-                                            reinterpret_cast<unsigned long long*>(ws + 256));
+    clip_adam_selfnorm<<<nbc, 256, 0, stream>>>(param, grad, m, v, n, lr, beta1, beta2, eps, weight_decay, max_norm, grad_scale, state,
+                                                reinterpret_cast<unsigned*>(ws + 256));
     TSGNN_CHECK_LAUNCH();
     return TSGNN_OK;
   }

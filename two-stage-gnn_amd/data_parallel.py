@@ -52,15 +52,19 @@ class FlatTrainer:
         self.on_gpu = dev.type == "cuda"
         self.exp_avg = torch.zeros_like(self.flat_param)
         self.exp_avg_sq = torch.zeros_like(self.flat_param)
-        self.state = torch.zeros(4, dtype=torch.float32, device=dev)      # step, grad norm, applied scale, barrier-timeout flag
-        self.ws = torch.zeros(264, dtype=torch.float32, device=dev)       # norm partials + the optimiser kernel's arrival counter
+        self.state = torch.zeros(4, dtype=torch.float32, device=dev)      # step, grad norm, applied scale, reserved
+        self.ws = torch.zeros(264, dtype=torch.float32, device=dev)       # norm partials + the optimiser kernel's sign-off counter
         self._zeros = [torch.zeros_like(p).reshape(-1) for p in self.params]     # stand-ins for parameters without a gradient
         self._pad_zeros = [torch.zeros(k, dtype=torch.float32, device=dev) if k else None for k in self._pads]
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        if self.world > 1:
+            # replicas must start from the same bits whatever each rank's RNG did before constructing the model (DDP does the same)
+            dist.broadcast(self.flat_param, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         # direct_grads: between zero_grad() and gather_grads() the fused backward nodes write parameter gradients straight
-        # into their slice of flat_grad (message_passing.GradSink); requires ONE backward per step in which every
-        # parameter feeds at most one fused node (true for the encoders here; tripletnet batches its three forwards).
+        # into their slice of flat_grad (message_passing.GradSink).  A slice is handed out once per step: a parameter that
+        # feeds a second fused node (the reference's tripletnet calls one encoder three times) gets its further contributions
+        # through autograd and gather_grads adds them (GradSink.take).
         self.sink = None
         self._dirty = set()                 # parameter indices whose slice of flat_grad may be non-zero (it starts all zero)
         if direct_grads and self.on_gpu:
@@ -96,7 +100,7 @@ class FlatTrainer:
             written = self.sink.written
             # barrier-free optimiser: every gradient of this step was written in place by a producer that also left its
             # share of |grad|^2 and the step counter was advanced; nothing arrived through autograd; single GPU
-            self._norm_ready = (bool(written) and self.sink.stepped and written == self.sink.normed
+            self._norm_ready = (bool(written) and self.sink.stepped and written == self.sink.normed and not self.sink.reused
                                 and all(p.grad is None for p in self.params) and self.world == 1 and not self.always_reduce)
         if not written:
             parts = []
@@ -174,8 +178,15 @@ class GraphedStep:
         self._fb = self._opt = None
         self.one_graph = False
         with torch.cuda.stream(self.stream):
-            for _ in range(warmup):                                # allocator / lazy-init warm-up on the capture stream
+            # allocator / lazy-init warm-up on the capture stream.  The warm-up steps are real optimiser steps on whatever the
+            # input buffers hold, so the trainer's state is put back afterwards: constructing a GraphedStep leaves parameters,
+            # Adam moments and the step counter exactly as it found them.
+            snap = [t.clone() for t in (trainer.flat_param, trainer.exp_avg, trainer.exp_avg_sq, trainer.state)] if warmup else None
+            for _ in range(warmup):
                 self._fwd_bwd(); trainer.all_reduce(); trainer.apply()
+            if snap is not None:
+                for t, s_ in zip((trainer.flat_param, trainer.exp_avg, trainer.exp_avg_sq, trainer.state), snap):
+                    t.copy_(s_)
             torch.cuda.synchronize()
             if not use_graph:
                 return

@@ -706,6 +706,7 @@ class GradSink:
         self.norm_used = 0
         self.normed = set()         # parameters whose |grad|^2 is accounted for in norm_parts[:norm_used]
         self.stepped = False
+        self.reused = False         # a slice was asked for twice this step (see take)
 
     def norm_slots(self, n):
         if not self.norm_enabled or self.norm_parts is None or self.norm_used + n > self.norm_parts.numel():
@@ -715,10 +716,18 @@ class GradSink:
         return v
 
     def take(self, param, shape):
-        v = self.views.get(param.data_ptr())
+        """The parameter's slice of the flat bucket — ONCE per step.  The fused backward kernels store ('=') into the slice, so
+        a parameter that feeds a second fused node in the same backward (tripletnet.py:36-38 calls the shared encoder three
+        times; two forwards of one model under one loss) must not get the slice again: the second node is handed None, returns
+        an ordinary gradient tensor, autograd accumulates it in p.grad and FlatTrainer.gather_grads adds p.grad onto the slice."""
+        key = param.data_ptr()
+        v = self.views.get(key)
         if v is None or tuple(v.shape) != tuple(shape):
             return None
-        self.written.add(param.data_ptr())
+        if key in self.written:
+            self.reused = True          # the |grad|^2 shares the first producer left no longer describe the gradient
+            return None
+        self.written.add(key)
         return v
 
 
