@@ -1,31 +1,42 @@
 #!/usr/bin/env python3
 """Headline benchmark (BASELINE.json): graphs/sec, forward+backward(+all-reduce+clip+Adam) of the
 3-layer h=128 GraphSage-style encoder (GcnEncoderGraph, `--method=base`) on DD-shaped synthetic batches
-of 32 graphs per GPU, on 1/2/4/8 MI355X, plus the HBM-roofline fraction of the dominant aggregation
-kernel and the reference's dense formulation timed on the host CPU.
+of 32 graphs per GPU, on 1/2/4/8 MI355X, plus the roofline of EVERY kernel the timed step launches, the
+aggregation kernel's batch-size sweep and the reference's dense formulation timed on the host CPU.
 
   python bench.py --gpus 1 --steps 200 --warmup 20
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N ...          (WORLD_SIZE unset: starts the N ranks itself as child processes)
 
 One JSON line on stdout (rank 0).  A "step" = one optimiser step on one batch per rank: forward, CE loss,
 backward, gradient bucket (+RCCL all-reduce when N>1), clip_grad_norm(2.0), Adam — exactly the body of the
 reference's loop (train.py:110-131) minus the host->device copies (inputs are resident in HBM).
+
+`roofline` describes the step that was timed:
+  step_kernels   one row per launch group of the step, in launch order: the device kernel the library dispatched (reported by
+                 the library, tsgnn_last_kernel), launches per step, average duration of ONE launch measured with HIP events
+                 around a hipGraph burst of that very launch (same arguments, same buffers the step used: layer 0 runs at its
+                 K = 92, not at a stand-in shape), algorithmic flops and bytes, and the fraction of the fp32-MFMA peak and of
+                 the HBM peak that follows.
+  (top level)    the kernel with the largest per-step total, with the fields the contract names.
+  aggregation_in_fused   SURVEY §8(d)'s aggregation-only bytes / the duration of the fused kernel that contains the aggregation.
+  sweep          the stand-alone aggregation kernel (tsgnn_ell_spmm_f32 / tsgnn_csr_spmm_f32, F = hidden) at
+                 32 / 256 / 2,048 / 16,384 DD graphs (north_star: >= 40 % of the HBM roofline on DD-sized batched graphs).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md:36
+MFMA_F32_PEAK_TF = 157.3       # dense fp32 MFMA, /opt/skills/guides/MI355X_MICROARCH.md:42
+PROFILE_DIR = os.path.join("profiles", "r02")
 
 
 def parse():
@@ -41,13 +52,36 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=0, help="0 = auto-size the sample to ~15 s")
-    ap.add_argument("--no-overlap", action="store_true", help="accepted for compatibility: the stack always runs on one stream")
-    ap.add_argument("--sweep", action="store_true", help="also print the aggregation-kernel batch-size sweep (stderr)")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the aggregation-kernel batch-size sweep")
+    ap.add_argument("--no-kernels", action="store_true", help="skip the per-kernel table of the step (rocprof runs of the bare step)")
+    ap.add_argument("--sweep-sizes", default="32,256,2048,16384")
+    ap.add_argument("--ingest", action="store_true", help="also time the step fed with a NEW host batch every step (collate + "
+                                                          "upload on a copy stream, double-buffered): `ingest` in the JSON line")
     return ap.parse_args()
+
+
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (nothing in this process has
+    touched the GPU yet), forward rank 0's JSON line, exit with the launcher's code.  Never falls back to one GPU."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE)
+    sys.stdout.write(r.stdout.decode())
+    sys.stdout.flush()
+    if r.returncode != 0:
+        sys.stderr.write("bench.py: the %d-rank launch failed (exit %d); no single-GPU number is reported in its place\n"
+                         % (a.gpus, r.returncode))
+    raise SystemExit(r.returncode)
 
 
 def hip_event_ms(fn, iters, stream):
     """average ms per call of fn() measured with HIP events recorded on `stream`."""
+    import torch
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
     e0.record(stream)
@@ -58,10 +92,146 @@ def hip_event_ms(fn, iters, stream):
     return e0.elapsed_time(e1) / iters
 
 
+def burst_ms(fn, iters, stream, repeats=5):
+    """ms per launch of fn() replayed back to back from one hipGraph on `stream` (the host's ~8 us per ctypes launch does not
+    pace it); the best of `repeats` replays."""
+    import torch
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    burst = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(burst, stream=stream):
+        for _ in range(iters):
+            fn()
+    burst.replay()
+    torch.cuda.synchronize()
+    return min(hip_event_ms(burst.replay, 1, stream) for _ in range(repeats)) / iters
+
+
+# ----------------------------------------------------------------------------------------------- the step's kernels
+def _numel(t):
+    return 0 if t is None else int(t.numel())
+
+
+def account(entry, a, nnz):
+    """(flops, algorithmic bytes, what) of one launch of a training-step entry point, from its own arguments.
+    Bytes follow SURVEY §8(d): every operand once (features read once however often they are gathered), indices, row
+    pointers, outputs once; flops count the MFMA products only (2mnk)."""
+    f4 = 4
+    if entry == "gather_rowgemm_f32":
+        rows, K, N, fill = int(a[15]), int(a[16]), int(a[17]), int(a[19])
+        by = f4 * rows * K + 4 * nnz + 4 * (rows + 1) + f4 * rows * N + f4 * K * N + f4 * fill * N
+        by += f4 * rows * K if a[13] is not None else 0          # z (the aggregate) kept for the weight gradient
+        by += f4 * (rows + fill) if a[12] is not None else 0     # rinv
+        return 2.0 * rows * K * N, by, "aggregate + .W + bias + L2 normalise (layer 0), K=%d N=%d" % (K, N)
+    if entry == "sage_layer_fwd_f32":
+        rows, K, gs = int(a[14]), int(a[15]), int(a[16])
+        B = int(a[18])
+        by = (f4 * rows * K + 4 * nnz + 4 * (rows + 1) + 2 * f4 * rows * K + f4 * K * K + f4 * gs * K + f4 * (rows + gs)   # product half
+              + f4 * gs * K + 8 * B * K)                                                                                  # readout half: ghost rows, packed maxima
+        return 2.0 * rows * K * K, by, "[aggregate + .W + bias + normalise || max-readout partial of the layer's input], K=N=%d" % K
+    if entry == "sage_layer_bwd_f32":
+        rows, nslab, sg = int(a[12]), int(a[13]), int(a[15])
+        K = N = 128
+        by = (f4 * (rows + sg) * N + f4 * rows * K + 4 * nnz + 4 * (rows + 1) + f4 * rows * K + f4 * K * N + f4 * nslab * (K + 1) * N)
+        return 4.0 * rows * K * N, by, "[dW/db slabs = z^T dU || dX = (A dU) W^T], K=N=128"
+    if entry == "linear_wgrad_f32":
+        rows, K, N, nslab, bo = int(a[4]), int(a[5]), int(a[6]), int(a[7]), int(a[9])
+        return 2.0 * rows * K * N, f4 * rows * K + f4 * (rows + bo) * N + f4 * nslab * (K + 1) * N, "dW/db slabs of layer 0, K=%d N=%d" % (K, N)
+    if entry == "wgrad_reduce_multi_f32":
+        by = 0
+        for t in range(4):
+            ns, K, N = int(a[6 * t + 1]), int(a[6 * t + 2]), int(a[6 * t + 3])
+            by += f4 * (ns + 1) * (K + 1) * N
+        return 0.0, by, "fixed-order slab sums of all layers' dW/db -> flat bucket, |grad|^2 shares"
+    if entry == "slot_bn_fwd_f32":
+        sn, n, sg, F = int(a[3]), int(a[4]), int(a[5]), int(a[8])
+        return 0.0, 2 * f4 * (n + sg) * F + 8 * int(a[15]) + 8 * sn, "ReLU + per-slot BatchNorm (fresh statistics), F=%d" % F
+    if entry == "slot_post_bwd_f32":
+        n, sg, F = int(a[4]), int(a[5]), int(a[15])
+        nread = 1 + (a[8] is not None) + (a[10] is not None)
+        by = f4 * (n + sg) * F * (nread + 1) + f4 * (n + sg) + (8 * int(a[2]) * F if a[12] is not None else 0)
+        return 0.0, by, "backward of readout scatter + slot BN + ReLU + L2 normalise -> dU, F=%d" % F
+    if entry == "readout_head_fwd_f32":
+        B, L, Fh, Fl, n, sg, E, C = int(a[1]), int(a[2]), int(a[3]), int(a[4]), int(a[8]), int(a[10]), int(a[18]), int(a[19])
+        P = (L - 1) * Fh + Fl
+        return 2.0 * B * (P * E + E * C), f4 * (n + sg) * Fl + 8 * B * (L - 1) * Fh + f4 * (E * P + C * E) + 2 * f4 * B * P, \
+            "last layer's max readout + decode + Linear(%d,%d) + Linear(%d,%d)" % (P, E, E, C)
+    if entry in ("head2_bwd_ce_f32", "head2_bwd_f32"):
+        o = 0 if entry == "head2_bwd_ce_f32" else -1
+        B, P, E, C = int(a[9 + o]), int(a[10 + o]), int(a[11 + o]), int(a[12 + o])
+        return 4.0 * B * (P * E + E * C), 2 * f4 * (E * P + C * E) + 2 * f4 * B * P, "CE loss + head backward (dW1, db1, dW2, db2, d readout)"
+    if entry == "adam_from_partials_f32":
+        n = int(a[4])
+        return 0.0, 7 * f4 * n, "clip + Adam on the flat buffer (norm from the producers' shares)"
+    if entry == "clip_adam_step_f32":
+        n = int(a[4])
+        return 0.0, 7 * f4 * n, "clip_grad_norm + Adam on the flat buffer (every block sums the norm)"
+    if entry == "readout_partial_f32":
+        n, sg, F = int(a[3]), int(a[4]), int(a[7])
+        return 0.0, f4 * (n + sg) * F + 8 * int(a[1]) * F, "max-readout partial"
+    return 0.0, 0, entry
+
+
+def step_kernel_table(gstep, trainer, stream, iters=100):
+    """Record ONE eager step (every launch with its arguments and the kernel the library dispatched), then time each launch on
+    its own as a hipGraph burst with the step's own operands.  The trainer's state is put back afterwards."""
+    import torch
+    from two_stage_gnn_amd import _native as nat
+    snap = [t.clone() for t in (trainer.flat_param, trainer.exp_avg, trainer.exp_avg_sq, trainer.state)]
+    with torch.cuda.stream(stream):
+        torch.cuda.synchronize()
+        nat.trace = []
+        try:
+            gstep._fwd_bwd()            # (no collective here: only rank 0 runs this table)
+            trainer.apply()
+        finally:
+            rec, nat.trace = nat.trace, None
+        torch.cuda.synchronize()
+        rows = []
+        for name, args, kernel in rec:
+            fn = (lambda name=name, args=args: nat.call(name, *args))
+            ms = burst_ms(fn, iters, stream, repeats=3)
+            rows.append((name, args, kernel, ms * 1e3))
+        for t, s_ in zip((trainer.flat_param, trainer.exp_avg, trainer.exp_avg_sq, trainer.state), snap):
+            t.copy_(s_)
+        torch.cuda.synchronize()
+    return rows
+
+
+def summarise_kernels(rows, nnz):
+    """group consecutive / repeated launches of the same kernel with the same accounting into one table row"""
+    table, index = [], {}
+    for name, args, kernel, us in rows:
+        flops, nbytes, what = account(name, args, nnz)
+        key = (kernel or name, what)
+        if key not in index:
+            index[key] = len(table)
+            table.append({"kernel": kernel or ("tsgnn_" + name), "entry": "tsgnn_" + name, "what": what, "launches_per_step": 0,
+                          "us": [], "flops": flops, "bytes": nbytes})
+        r = table[index[key]]
+        r["launches_per_step"] += 1
+        r["us"].append(us)
+    for r in table:
+        us = sum(r["us"]) / len(r["us"])
+        r["us_per_launch"] = us
+        r["us_per_step"] = us * r["launches_per_step"]
+        del r["us"]
+        tf = r["flops"] / (us * 1e-6) / 1e12
+        gbs = r["bytes"] / (us * 1e-6) / 1e9
+        r["tflops"], r["gbs"] = tf, gbs
+        r["frac_mfma"], r["frac_hbm"] = tf / MFMA_F32_PEAK_TF, gbs / HBM_PEAK_GBS
+        r["bound"] = "mfma" if r["frac_mfma"] >= r["frac_hbm"] else "hbm"
+        r["frac"] = max(r["frac_mfma"], r["frac_hbm"])
+    return table
+
+
+# ----------------------------------------------------------------------------------------------- aggregation kernel
 def aggregation_probe(g, feat, iters=300):
-    """The dominant HBM kernel of the step (tsgnn_csr_spmm_f32 at F = hidden) launched back to back on the
-    step's own CSR / buffers; duration from HIP events on the launching stream."""
+    """tsgnn_ell_spmm_f32 / tsgnn_csr_spmm_f32 at F = feat on the batch's own neighbour table; (ms, bytes, kernel)."""
+    import torch
     from two_stage_gnn_amd import message_passing as mp
+    from two_stage_gnn_amd import _native as nat
     from two_stage_gnn_amd.synthetic import aggregation_bytes
     x = torch.randn(g.total_rows, feat, device="cuda")
     y = torch.empty_like(x)
@@ -69,67 +239,33 @@ def aggregation_probe(g, feat, iters=300):
     use_ell = g.val is None and mp.ell_ok(x) and g.total_rows <= mp.ELL_MAX_ROWS
     if use_ell:
         g.ell()
-        fn = lambda: mp.spmm_ell(g, x, out=y)               # what the step's aggregate() launches
+        fn = lambda: mp.spmm_ell(g, x, out=y)               # what aggregate() launches for cache-resident batches
     else:
         fn = lambda: mp.spmm_raw(g.rowptr, g.col, g.val, x, g.total_rows, out=y)
-    for _ in range(20):
-        fn()
-    torch.cuda.synchronize()
-    # the burst is replayed from a hipGraph so the host's ~8 us per ctypes launch does not pace it
-    burst = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(burst, stream=s):
-        for _ in range(iters):
-            fn()
-    burst.replay()
-    torch.cuda.synchronize()
-    ms = min(hip_event_ms(burst.replay, 1, s) for _ in range(5)) / iters
+    fn()
+    kernel = nat.last_kernel()
+    ms = burst_ms(fn, iters, s)
     nbytes = aggregation_bytes(g.total_rows, g.nnz, feat, weighted=g.val is not None)
-    aggregation_probe.kernel = ("spmm_ell_vec4<32,16> (tsgnn_ell_spmm_f32" if use_ell else
-                                ("spmm_vec4_rb<32,4,false> (tsgnn_csr_spmm_f32" if g.total_rows >= 262144 else
-                                 "spmm_vec4<32,false,false> (tsgnn_csr_spmm_f32")) + ", F=%d)" % feat
-    return ms, nbytes
+    return ms, nbytes, "%s (tsgnn_%s, F=%d)" % (kernel, "ell_spmm_f32" if use_ell else "csr_spmm_f32", feat)
 
 
-MFMA_F32_PEAK_TF = 157.3       # dense fp32 MFMA, /opt/skills/guides/MI355X_MICROARCH.md:42
+def load_traffic():
+    """PMC-measured HBM bytes per launch (rocprofv3 --pmc in separate passes, scripts/pmc_traffic.*): a recorded measurement,
+    not taken in this run — labelled as such."""
+    for rel in (os.path.join(PROFILE_DIR, "step_traffic.json"), os.path.join("profiles", "r01", "agg_traffic.json")):
+        try:
+            return json.load(open(os.path.join(ROOT, rel))), rel
+        except (OSError, ValueError):
+            continue
+    return {}, None
 
 
-def fused_layer_probe(g, feat, iters=300):
-    """The dominant kernel of the step when the aggregation is fused into the transform (tsgnn_gather_rowgemm_f32 at
-    K = N = hidden, as layers 1.. of the forward launch it: neighbour gather + .W + bias + L2 normalise, z written for the
-    weight gradient), launched back to back on the step's own neighbour table; HIP events on the launching stream.
-    Returns (ms, flops, algorithmic bytes) per launch."""
-    from two_stage_gnn_amd import _native as nat
-    ell, ell_w, tail = g.ell()
-    R = g.total_rows
-    x = torch.randn(R, feat, device="cuda")
-    w = torch.randn(feat, feat, device="cuda") * 0.1
-    b = torch.randn(feat, device="cuda")
-    v = torch.empty_like(x); z = torch.empty_like(x); rinv = torch.empty(R, device="cuda")
-    gs = min(g.nmax, int(g.sizes.max()) + 1) if g.n_ghost else 0
-    s = torch.cuda.current_stream()
-    tp, tc = tail if tail is not None else (None, None)
-    fn = lambda: nat.call("gather_rowgemm_f32", ell, ell_w, tp, tc, x, feat, w, feat, 0, b, v, feat, rinv, z, feat, g.n_rows, feat, feat, 1, gs)
-    for _ in range(20):
-        fn()
-    torch.cuda.synchronize()
-    burst = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(burst, stream=s):
-        for _ in range(iters):
-            fn()
-    burst.replay()
-    torch.cuda.synchronize()
-    ms = min(hip_event_ms(burst.replay, 1, s) for _ in range(5)) / iters
-    n = int(g.n_rows)
-    flops = 2.0 * n * feat * feat
-    # SURVEY 8(d) aggregation bytes on the real rows (X read once, indices, row pointers) + z and v written + W + rinv
-    nbytes = 4 * n * feat + 4 * int(g.nnz) + 4 * (n + 1) + 2 * 4 * n * feat + 4 * feat * feat + 4 * (n + gs) + 4 * gs * feat
-    return ms, flops, nbytes
-
-
+# ----------------------------------------------------------------------------------------------- CPU baseline
 def cpu_baseline(hb, hidden, layers, steps, state):
     """The reference's dense formulation (adj[B,Nmax,Nmax] @ x, encoders.py:30-42,169-217) restated by the
     CPU oracle, fwd + CE + bwd + clip + Adam, on this host's cores — test infrastructure used as the checker /
     baseline only (never on the product path)."""
+    import torch
     from oracle import dense_ref as R
     from two_stage_gnn_amd.synthetic import to_dense
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -175,8 +311,22 @@ def cpu_baseline(hb, hidden, layers, steps, state):
                                          "padded rows otherwise as the reference (%.1f ms/step)" % (steps_s, dts * 1e3)}}
 
 
+# ----------------------------------------------------------------------------------------------- ingest on the clock
+def ingest_run(a, model, dev, steps, rank):
+    """graphs/s when every step consumes a NEW host batch (f1, train.py:110-119 / graph_sampler.py:102-114): host CSR collate
+    -> pinned staging -> async upload + device-side ELL build on a copy stream, double-buffered against the compute stream."""
+    from two_stage_gnn_amd.ingest import IngestPipeline
+    pipe = IngestPipeline(model, dev, batch=a.batch, shape=a.shape, nmax=a.nmax, seed=1000 + rank)
+    return pipe.run(steps)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(a)                               # before anything touches the GPU; does not return
+    import numpy as np  # noqa: F401
+    import torch
+    import torch.distributed as dist
     # stdout carries exactly ONE JSON line: libraries that write banners to fd 1 (RCCL prints its version block there at
     # communicator creation) are pointed at stderr until the line is printed
     sys.stdout.flush()
@@ -185,14 +335,14 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    if world != a.gpus and world > 1:
+    if world != a.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     ndev = torch.cuda.device_count()
     dev_index = local_rank % max(ndev, 1)            # one GPU per rank on the 8-GPU node; TSGNN_DIST_BACKEND=gloo lets
     torch.cuda.set_device(dev_index)                 # several ranks share one GPU for a functional rehearsal
     dev = torch.device("cuda", dev_index)
     backend = os.environ.get("TSGNN_DIST_BACKEND", "nccl")
-    # TSGNN_FORCE_DIST=1 takes the N > 1 code path (process group, two hipGraphs around the RCCL all-reduce) with a single
+    # TSGNN_FORCE_DIST=1 takes the N > 1 code path (process group, hipGraphs around the RCCL all-reduce) with a single
     # rank: the rehearsal of the multi-GPU path that fits a one-GPU box.
     multi = world > 1 or os.environ.get("TSGNN_FORCE_DIST") == "1"
     if multi:
@@ -208,11 +358,10 @@ def main():
     from two_stage_gnn_amd import dense_encoders as E
     from two_stage_gnn_amd import synthetic
     from two_stage_gnn_amd.data_parallel import FlatTrainer, GraphedStep
-    from two_stage_gnn_amd import sage_stack
 
     class Args:
         bias = True
-    torch.manual_seed(1234)                                   # identical initial weights on every rank
+    torch.manual_seed(1234)                                   # identical initial weights on every rank (and broadcast by the trainer)
     fin = synthetic.SHAPES[a.shape][2]
     model = E.GcnEncoderGraph(fin, a.hidden, a.hidden, 2, a.layers, bn=True, args=Args(), final_dim="number_classes").to(dev)
     init_state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
@@ -222,8 +371,7 @@ def main():
     trainer.always_reduce = multi
 
     use_graph = not a.no_graph
-    # N > 1: fwd+bwd+bucket and clip+Adam are two hipGraphs with the RCCL all-reduce issued between them on the same stream;
-    # N = 1: one hipGraph for the whole step (data_parallel.GraphedStep)
+    # N = 1: one hipGraph for the whole step; N > 1: hipGraphs around the RCCL all-reduce (data_parallel.GraphedStep)
     gstep = GraphedStep(trainer, lambda: model.loss(model(x, g)[1], label), warmup=3, use_graph=use_graph)
     stream = gstep.stream
     step = gstep.step
@@ -247,68 +395,97 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-        out = None
+    out = None
+    if rank == 0:
+        ms_step = elapsed / a.steps * 1e3
+        out = {
+            "metric": "graphs/sec fwd+bwd, DD batch=32 SAGE-3L h=128",
+            "value": world * a.batch * a.steps / elapsed, "unit": "graphs/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s-shaped synthetic graphs (avg %d nodes / %d edges, F_in=%d), batch=%d per GPU, "
+                                   "GcnEncoderGraph (GraphSage 'base') %d layers h=%d, Nmax=%d, slot-BN, CE loss, "
+                                   "clip 2.0 + Adam" % (a.shape, *synthetic.SHAPES[a.shape], a.batch, a.layers, a.hidden, a.nmax),
+                       "global_batch": world * a.batch, "parallelism": "dp%d" % world,
+                       "launch": ("hipGraph replay (%s)" % gstep.describe()) if use_graph else "eager",
+                       "rows": int(g.n_rows), "edges_directed": int(g.nnz)},
+        }
+        roofline = {}
+        traffic, traffic_src = load_traffic()
+        with torch.cuda.stream(stream):
+            if not a.no_kernels:
+                rows = step_kernel_table(gstep, trainer, stream)
+                table = summarise_kernels(rows, int(g.nnz))
+                top = max(table, key=lambda r: r["us_per_step"])
+                tr = traffic.get(top["kernel"], {}) if isinstance(traffic.get(top["kernel"]), dict) else {}
+                roofline = {"bound": top["bound"], "kernel": "%s (%s: %s)" % (top["kernel"], top["entry"], top["what"]),
+                            "achieved": top["tflops"] if top["bound"] == "mfma" else top["gbs"],
+                            "peak": MFMA_F32_PEAK_TF if top["bound"] == "mfma" else HBM_PEAK_GBS,
+                            "unit": "TFLOP/s" if top["bound"] == "mfma" else "GB/s", "frac": top["frac"],
+                            "traffic": tr.get("traffic_bytes_per_launch"),
+                            "traffic_source": (traffic_src + " (rocprofv3 --pmc, separate run; not measured in this process)")
+                            if tr else None,
+                            "flops_per_launch": top["flops"], "bytes_per_launch": top["bytes"], "us_per_launch": top["us_per_launch"],
+                            "launches_per_step": top["launches_per_step"],
+                            "mfma": {"achieved": top["tflops"], "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": top["frac_mfma"]},
+                            "hbm": {"achieved": top["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": top["frac_hbm"]},
+                            "selection": "the kernel with the largest launches x duration in the timed step",
+                            "step_kernels": table,
+                            "step_launches": sum(r["launches_per_step"] for r in table),
+                            "step_kernel_us_sum": sum(r["us_per_step"] for r in table),
+                            "step_flops": sum(r["flops"] * r["launches_per_step"] for r in table),
+                            "step_bytes": sum(r["bytes"] * r["launches_per_step"] for r in table)}
+                roofline["step"] = {"mfma_frac": roofline["step_flops"] / (ms_step * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
+                                    "hbm_frac": roofline["step_bytes"] / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                # the aggregation-only bytes of one pass over the real rows / the fused kernel that contains it
+                n = int(g.n_rows)
+                fused = [r for r in table if r["entry"] in ("tsgnn_sage_layer_fwd_f32", "tsgnn_gather_rowgemm_f32")]
+                agg_in = []
+                for r in fused:
+                    K = a.hidden if r["entry"] == "tsgnn_sage_layer_fwd_f32" else x.size(1)
+                    nb = synthetic.aggregation_bytes(n, int(g.nnz), K)
+                    agg_in.append({"kernel": r["kernel"], "F": K, "aggregation_bytes": nb, "us_per_launch": r["us_per_launch"],
+                                   "achieved": nb / r["us_per_launch"] / 1e3, "unit": "GB/s",
+                                   "frac": nb / r["us_per_launch"] / 1e3 / HBM_PEAK_GBS})
+                roofline["aggregation_in_fused"] = agg_in
+            # the stand-alone aggregation kernel on the step's batch and its batch-size sweep
+            agg_ms, agg_bytes, agg_kernel = aggregation_probe(g, a.hidden)
+            tr = traffic.get("dd_b32_rows9151_f128", {}) if (a.shape == "DD" and a.batch == 32 and a.hidden == 128
+                                                             and int(g.total_rows) == 9151) else {}
+            roofline["aggregation_standalone"] = {
+                "bound": "hbm", "kernel": agg_kernel, "achieved": agg_bytes / agg_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": agg_bytes / agg_ms / 1e6 / HBM_PEAK_GBS, "traffic": tr.get("traffic_bytes_per_launch"),
+                "traffic_source": (traffic_src + " (rocprofv3 --pmc, separate run)") if tr else None,
+                "bytes_per_launch": agg_bytes, "us_per_launch": agg_ms * 1e3,
+                "note": "not launched by the timed step (the step aggregates inside the fused kernels); what non-fused callers run"}
+            if not roofline.get("kernel"):
+                roofline.update({k: roofline["aggregation_standalone"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic")})
+            if not a.no_sweep:
+                sweep = []
+                for B in [int(v) for v in a.sweep_sizes.split(",") if v]:
+                    hs = synthetic.tiled_batch(seed=100 + B, B=B, shape=a.shape, nmax=a.nmax)
+                    gsw = synthetic.structure_to_device(hs, dev)
+                    ms, nb, kern = aggregation_probe(gsw, a.hidden, iters=20 if B > 2048 else (100 if B > 256 else 300))
+                    sweep.append({"graphs": B, "rows": int(gsw.total_rows), "edges_directed": int(gsw.nnz), "bytes_per_launch": nb,
+                                  "us_per_launch": ms * 1e3, "achieved": nb / ms / 1e6, "unit": "GB/s",
+                                  "frac": nb / ms / 1e6 / HBM_PEAK_GBS, "kernel": kern})
+                    print("sweep B=%d rows=%d: %.2f us, %.0f GB/s (%.1f%% of 8 TB/s)  %s"
+                          % (B, gsw.n_rows, ms * 1e3, nb / ms / 1e6, nb / ms / 1e6 / HBM_PEAK_GBS * 100, kern), file=sys.stderr)
+                    del gsw, hs
+                    torch.cuda.empty_cache()
+                roofline["sweep"] = sweep
+                roofline["sweep_note"] = ("stand-alone aggregation, F=%d, DD-shaped graphs; batches above 256 graphs repeat 256 generated "
+                                          "graphs (every copy owns its rows)" % a.hidden)
+        out["roofline"] = roofline
+    if a.ingest:
+        res = ingest_run(a, model, dev, max(a.steps, 50), rank)
         if rank == 0:
-            ms_step = elapsed / a.steps * 1e3
-            agg_ms, agg_bytes = aggregation_probe(g, a.hidden)
-            achieved = agg_bytes / (agg_ms * 1e-3) / 1e9
-            tr = {}                 # PMC-measured HBM bytes per launch of the same kernels/shape (scripts/pmc_traffic.*)
-            try:
-                if a.shape == "DD" and a.batch == 32 and a.hidden == 128 and int(g.total_rows) == 9151:
-                    tr = json.load(open(os.path.join(ROOT, "profiles", "r01", "agg_traffic.json")))
-            except (OSError, ValueError):
-                pass
-            standalone = {"bound": "hbm", "kernel": aggregation_probe.kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                          "frac": achieved / HBM_PEAK_GBS, "traffic": tr.get("dd_b32_rows9151_f128", {}).get("traffic_bytes_per_launch"),
-                          "bytes_per_launch": agg_bytes, "us_per_launch": agg_ms * 1e3}
-            roofline = standalone
-            if sage_stack._gather_ok(g, x.new_empty(1, a.hidden)) and g.n_ghost > 0 and a.hidden <= 128:
-                # the step aggregates inside the transform: that fused kernel is the dominant one; it sits at the ridge of the
-                # two rooflines (20 flop per algorithmic byte vs 19.7 for the chip), so both fractions are given and the larger
-                # one names the bound
-                f_ms, f_flops, f_bytes = fused_layer_probe(g, a.hidden)
-                tf = f_flops / (f_ms * 1e-3) / 1e12
-                gbs = f_bytes / (f_ms * 1e-3) / 1e9
-                mf, hf = tf / MFMA_F32_PEAK_TF, gbs / HBM_PEAK_GBS
-                roofline = {"bound": "mfma" if mf >= hf else "hbm",
-                            "kernel": "rowgemm_gather_ks2_kernel<4,false> (tsgnn_gather_rowgemm_f32: aggregation + .W + bias + L2 normalise, K=N=%d)" % a.hidden,
-                            "achieved": tf if mf >= hf else gbs, "peak": MFMA_F32_PEAK_TF if mf >= hf else HBM_PEAK_GBS,
-                            "unit": "TFLOP/s" if mf >= hf else "GB/s", "frac": max(mf, hf),
-                            "traffic": tr.get("dd_b32_gather_rowgemm_k128_n128", {}).get("traffic_bytes_per_launch"),
-                            "flops_per_launch": f_flops, "bytes_per_launch": f_bytes, "us_per_launch": f_ms * 1e3,
-                            "mfma": {"achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": mf},
-                            "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hf},
-                            "aggregation_standalone": standalone}
-            out = {
-                "metric": "graphs/sec fwd+bwd, DD batch=32 SAGE-3L h=128",
-                "value": world * a.batch * a.steps / elapsed, "unit": "graphs/s",
-                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "config": {"workload": "%s-shaped synthetic graphs (avg %d nodes / %d edges, F_in=%d), batch=%d per GPU, "
-                                       "GcnEncoderGraph (GraphSage 'base') %d layers h=%d, Nmax=%d, slot-BN, CE loss, "
-                                       "clip 2.0 + Adam" % (a.shape, *synthetic.SHAPES[a.shape], a.batch, a.layers, a.hidden, a.nmax),
-                           "global_batch": world * a.batch, "parallelism": "dp%d" % world,
-                           "launch": "hipGraph replay" if use_graph else "eager",
-                           "rows": int(g.n_rows), "edges_directed": int(g.nnz)},
-                "roofline": roofline,
-            }
+            out["ingest"] = res
     if rank == 0:
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(hb, a.hidden, a.layers, a.cpu_steps, init_state)
         else:
             out["cpu_baseline"] = None
-        if a.sweep:
-            out["roofline"]["sweep"] = []
-            with torch.cuda.stream(stream):
-                for B in (32, 256, 2048, 16384):
-                    hs = synthetic.host_batch(seed=100 + B, B=B, shape=a.shape, nmax=a.nmax)
-                    gs, _, _ = synthetic.to_device(hs, dev)
-                    ms, nb = aggregation_probe(gs, a.hidden, iters=50 if B > 2048 else 200)
-                    out["roofline"]["sweep"].append({"graphs": B, "rows": int(gs.total_rows), "us_per_launch": ms * 1e3,
-                                                     "achieved": nb / ms / 1e6, "frac": nb / ms / 1e6 / HBM_PEAK_GBS,
-                                                     "kernel": aggregation_probe.kernel})
-                    print("sweep B=%d rows=%d: %.2f us, %.0f GB/s (%.1f%% of 8 TB/s)" % (B, gs.n_rows, ms * 1e3, nb / ms / 1e6,
-                                                                                       nb / ms / 1e6 / HBM_PEAK_GBS * 100), file=sys.stderr)
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)

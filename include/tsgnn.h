@@ -27,6 +27,10 @@ extern "C" {
 #define TSGNN_ABI_VERSION 1
 int tsgnn_abi_version(void);
 const char* tsgnn_strerror(int code);
+/* Diagnostic: name (template arguments included) of the device kernel that the calling thread's most recent entry-point call
+ * dispatched, "" if that entry point is not annotated.  Thread-local, read-only for the caller; used by bench.py to label
+ * its per-kernel roofline table from the actual dispatch. */
+const char* tsgnn_last_kernel(void);
 
 /* ---------------------------------------------------------------- graph ingest (graph_build.hip) */
 

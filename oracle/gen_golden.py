@@ -10,7 +10,7 @@ source text is written anywhere.
 
 The GPU box has no /root/reference: tests read only the committed fixtures.
 
-Usage:  python oracle/gen_golden.py            (rewrites tests/golden/*.npz)
+Usage:  python oracle/gen_golden.py [encoders] [tu]     (rewrites tests/golden/*.npz; default: both sections)
 """
 import os
 import sys
@@ -218,15 +218,108 @@ def gen_gat(gat, gen):
              dims=np.array([fin, hid, emb, lab]), **sd_np(m), **grads_np(m))
 
 
-def main():
-    enc, gat = _import_reference()
-    gen = torch.Generator().manual_seed(20261003)
-    gen_graphconv(enc, gen)
-    gen_apply_bn(enc, gen)
-    gen_gcn_encoder(enc, gen)
-    gen_diffpool(enc, gen)
-    gen_gat(gat, gen)
+# ----------------------------------------------------------------------------------------------- TU reader (f2)
+def tu_arrays(seed, n_graphs, with_labels, with_attrs):
+    """A small synthetic TU-format dataset as plain arrays: graph indicator, edge lines (may repeat, may be one-directional,
+    may be self loops; some nodes have no edge at all, one graph has no edge), node labels, raw graph labels, attributes."""
+    rng = np.random.default_rng(seed)
+    indic, edges, nlab, glab = [], [], [], []
+    nid = 1
+    for g in range(1, n_graphs + 1):
+        n = int(rng.integers(3, 12))
+        ids = list(range(nid, nid + n))
+        nid += n
+        indic += [g] * n
+        nlab += [int(rng.integers(1, 5)) for _ in ids]
+        glab.append([7, -1, 3][g % 3])                       # non-consecutive labels: renumbered by first appearance
+        m = 0 if g == 4 else int(rng.integers(1, 2 * n))     # graph 4 has nodes but not a single edge line
+        for _ in range(m):
+            u, v = rng.choice(ids, 2)
+            edges.append((int(u), int(v)))
+            if rng.random() < 0.5:
+                edges.append((int(v), int(u)))
+    attrs = np.round(rng.standard_normal((len(indic), 3)), 3).astype(np.float32) if with_attrs else None
+    return (np.asarray(indic, np.int64), np.asarray(edges, np.int64).reshape(-1, 2),
+            np.asarray(nlab, np.int64) if with_labels else None, np.asarray(glab, np.int64), attrs)
+
+
+def write_tu_files(root, name, indic, edges, nlab, glab, attrs):
+    """the five text files of the TU format (the layout load_data.py:17-79 opens) from plain arrays"""
+    d = os.path.join(root, name)
+    os.makedirs(d, exist_ok=True)
+    pre = os.path.join(d, name)
+    with open(pre + "_graph_indicator.txt", "w") as f:
+        f.write("\n".join(str(int(v)) for v in indic) + "\n")
+    with open(pre + "_graph_labels.txt", "w") as f:
+        f.write("\n".join(str(int(v)) for v in glab) + "\n")
+    with open(pre + "_A.txt", "w") as f:
+        f.write("\n".join("%d, %d" % (int(a), int(b)) for a, b in edges) + "\n")
+    if nlab is not None:
+        with open(pre + "_node_labels.txt", "w") as f:
+            f.write("\n".join(str(int(v)) for v in nlab) + "\n")
+    if attrs is not None:
+        with open(pre + "_node_attributes.txt", "w") as f:
+            f.write("\n".join(", ".join("%.3f" % float(x) for x in row) for row in attrs) + "\n")
+
+
+def gen_tu():
+    """Fixtures for the TU reader: the reference's load_data.read_graphfile (load_data.py:12-126) run HERE on small synthetic
+    TU directories.  The only thing neutralised is the version probe float(nx.__version__) (load_data.py:112), which raises
+    on "3.4.2": the module-level string is replaced in this process; both branches of that probe build the same mapping."""
+    import contextlib
+    import io
+    import tempfile
+    import networkx as nx
+    sys.path.insert(0, REF_DIR)
+    nx.__version__ = "3.4"
+    import load_data
+    for tag, seed, with_labels, with_attrs in [("labels_attrs", 3, True, True), ("plain", 11, False, False)]:
+        indic, edges, nlab, glab, attrs = tu_arrays(seed, 8, with_labels, with_attrs)
+        out = {"indic": indic, "edges": edges, "glab": glab}
+        if nlab is not None:
+            out["nlab"] = nlab
+        if attrs is not None:
+            out["attrs"] = attrs
+        with tempfile.TemporaryDirectory() as tmp:
+            write_tu_files(tmp, "TOY", indic, edges, nlab, glab, attrs)
+            for mtag, max_nodes in [("all", None), ("max8", 8)]:
+                with contextlib.redirect_stdout(io.StringIO()):
+                    graphs = load_data.read_graphfile(tmp, "TOY", max_nodes=max_nodes)
+                sizes, adjs, onehots, feats, labels = [], [], [], [], []
+                for G in graphs:
+                    n = G.number_of_nodes()
+                    assert list(G.nodes) == list(range(n))          # relabelled 0..n-1 in insertion order (load_data.py:110-124)
+                    sizes.append(n)
+                    labels.append(int(G.graph["label"]))
+                    A = np.asarray(nx.to_numpy_array(G, nodelist=list(range(n)))) if n else np.zeros((0, 0))
+                    adjs.append(A.astype(np.float32).reshape(-1))
+                    if with_labels and n:
+                        onehots.append(np.asarray([G.nodes[u]["label"] for u in range(n)], dtype=np.float32).reshape(n, -1))
+                    if with_attrs and n:
+                        feats.append(np.asarray([G.nodes[u]["feat"] for u in range(n)], dtype=np.float32).reshape(n, -1))
+                out[mtag + ".sizes"] = np.asarray(sizes, np.int64)
+                out[mtag + ".labels"] = np.asarray(labels, np.int64)
+                out[mtag + ".adj_flat"] = np.concatenate(adjs) if adjs else np.zeros(0, np.float32)
+                if with_labels:
+                    out[mtag + ".onehot"] = np.concatenate(onehots)
+                if with_attrs:
+                    out[mtag + ".feat"] = np.concatenate(feats)
+        save("tu_" + tag, **out)
+
+
+def main(argv):
+    want = set(argv) or {"encoders", "tu"}
+    if "encoders" in want:
+        enc, gat = _import_reference()
+        gen = torch.Generator().manual_seed(20261003)
+        gen_graphconv(enc, gen)
+        gen_apply_bn(enc, gen)
+        gen_gcn_encoder(enc, gen)
+        gen_diffpool(enc, gen)
+        gen_gat(gat, gen)
+    if "tu" in want:
+        gen_tu()
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1:])

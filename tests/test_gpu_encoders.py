@@ -65,6 +65,31 @@ def test_gcn_encoder_golden(tag, layout, fused, monkeypatch):
     check_param_grads(m, g, 2e-3, 2e-4)
 
 
+def assert_grads_arbitrated(named_params, p32, p64, floor=2e-3, handful=8):
+    """Gradient check arbitrated by an fp64 run of the oracle.  Per parameter tensor, with mag = max|fp64|:
+      * max|hip - fp64| <= max(10 * max|cpu32 - fp64|, floor * mag): the HIP result must be as close to the exact gradient as
+        the fp32 CPU oracle is (x10) — the floor only matters for tensors on which fp32 itself is that inexact (piecewise
+        ReLU / arg-max winners flipping on summation order);
+      * at most a handful of entries (or 4x as many as the CPU fp32 run has) may be further than 1e-4 * mag from fp64, so a
+        backward bug that is small against the tensor's largest entry but touches many entries cannot hide under the floor."""
+    checked = 0
+    for k, p in named_params:
+        if p32[k].grad is None or p.grad is None:
+            continue
+        ref32, ref64 = p32[k].grad.double(), p64[k].grad
+        hip = p.grad.detach().cpu().double()
+        mag = ref64.abs().max().item()
+        cpu_abs, gpu_abs = (ref32 - ref64).abs(), (hip - ref64).abs()
+        cpu_err, gpu_err = cpu_abs.max().item(), gpu_abs.max().item()
+        assert gpu_err <= max(10 * cpu_err, floor * mag + 1e-9), (k, gpu_err, cpu_err, mag)
+        n_cpu = int((cpu_abs > 1e-4 * mag + 1e-12).sum())
+        n_gpu = int((gpu_abs > 1e-4 * mag + 1e-12).sum())
+        assert n_gpu <= max(handful, 4 * n_cpu), (k, n_gpu, n_cpu, hip.numel(), gpu_err, mag)
+        checked += 1
+    assert checked > 0
+
+
+
 @pytest.mark.parametrize("B,nmax,nbar,fin,hid", [(8, 160, 60, 89, 128), (4, 400, 269, 89, 128), (40, 200, 60, 7, 64),
                                                  (100, 64, 20, 3, 32)])
 def test_gcn_encoder_vs_oracle_dd_shape(B, nmax, nbar, fin, hid):
@@ -91,16 +116,17 @@ def test_gcn_encoder_vs_oracle_dd_shape(B, nmax, nbar, fin, hid):
     torch.testing.assert_close(a.detach().cpu(), a_ref.detach(), rtol=1e-4, atol=1e-4)     # north_star: 1e-4 fp32
     torch.testing.assert_close(b.detach().cpu(), b_ref.detach(), rtol=1e-4, atol=1e-4)
     m.loss(b, label.cuda()).backward()
+    # gradients are piecewise (ReLU / max-readout winners can flip on 1-ulp differences between the CPU and GPU summation
+    # orders): an fp64 run of the oracle arbitrates
+    p64 = {k: v.detach().double().requires_grad_(True) for k, v in p_ref.items()}
+    _, b64 = R.gcn_encoder(p64, x.double(), adj.double(), bn=True, final_dim="number_classes")
+    torch.nn.functional.cross_entropy(b64, label).backward()
+    assert_grads_arbitrated(m.named_parameters(), p_ref, p64)
     for k, p in m.named_parameters():
         ref = p_ref[k].grad
-        if ref is None:
-            continue
-        # gradients are piecewise (relu / max-readout winners can flip on 1-ulp differences between the CPU
-        # and GPU summation orders), so compare at the scale of the tensor instead of element-relative
-        err = (p.grad.cpu() - ref).abs().max().item()
-        assert err <= 2e-3 * ref.abs().max().item() + 1e-7, (k, err, ref.abs().max().item())
-        rel_l2 = ((p.grad.cpu() - ref).norm() / (ref.norm() + 1e-12)).item()
-        assert rel_l2 < 1e-3, (k, rel_l2)
+        if ref is not None:
+            rel_l2 = ((p.grad.cpu() - ref).norm() / (ref.norm() + 1e-12)).item()
+            assert rel_l2 < 1e-3, (k, rel_l2)
 
 
 @pytest.mark.parametrize("shape,B,nmax,layers,hid", [("MUTAG", 32, 40, 2, 64), ("PROTEINS", 64, 620, 3, 128)])
@@ -126,12 +152,10 @@ def test_baseline_config_batches_vs_oracle(shape, B, nmax, layers, hid):
     torch.testing.assert_close(a.detach().cpu(), a_ref.detach(), rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(b.detach().cpu(), b_ref.detach(), rtol=1e-4, atol=1e-4)
     m.loss(b, label).backward()
-    for k, p in m.named_parameters():
-        ref = p_ref[k].grad
-        if ref is None:
-            continue
-        err = (p.grad.cpu() - ref).abs().max().item()
-        assert err <= 2e-3 * ref.abs().max().item() + 1e-7, (k, err, ref.abs().max().item())
+    p64 = {k: v.detach().double().requires_grad_(True) for k, v in p_ref.items()}
+    _, b64 = R.gcn_encoder(p64, x.double(), adj.double(), bn=True, final_dim="number_classes")
+    torch.nn.functional.cross_entropy(b64, lab).backward()
+    assert_grads_arbitrated(m.named_parameters(), p_ref, p64)
 
 
 # ----------------------------------------------------------------------------- GAT (encoders_GAT.py)
@@ -196,12 +220,10 @@ def test_gat_dd_graph_vs_oracle():
     torch.testing.assert_close(b.detach().cpu(), b_ref.detach(), rtol=1e-4, atol=1e-4)
     torch.nn.functional.cross_entropy(b_ref, torch.tensor([1])).backward()
     m.loss(b, torch.tensor([1]).cuda()).backward()
-    for k, p in m.named_parameters():
-        ref = p_ref[k].grad
-        if ref is None:
-            continue
-        err = (p.grad.cpu() - ref).abs().max().item()
-        assert err <= 2e-3 * ref.abs().max().item() + 1e-7, (k, err, ref.abs().max().item())
+    p64 = {k: v.detach().double().requires_grad_(True) for k, v in p_ref.items()}
+    _, b64 = R.gat_encoder(p64, x.double(), adj.double(), final_dim="number_classes")
+    torch.nn.functional.cross_entropy(b64, torch.tensor([1])).backward()
+    assert_grads_arbitrated(m.named_parameters(), p_ref, p64)
 
 
 @pytest.mark.parametrize("packed", [True, False])

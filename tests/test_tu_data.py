@@ -1,5 +1,7 @@
-"""TU reader + CSR-native collate.  CPU: the vectorised reader against a networkx
-restatement of load_data.read_graphfile's rules (load_data.py:12-126).  GPU: collate -> encoder == dense path."""
+"""TU reader + CSR-native collate.  CPU: the vectorised reader against fixtures produced by the
+REFERENCE's load_data.read_graphfile (load_data.py:12-126; oracle/gen_golden.py `tu` imports it in the build container and
+stores its graphs as arrays in tests/golden/tu_*.npz), and against a networkx restatement of the same rules on further random
+inputs.  GPU: collate -> encoder == dense path."""
 import os
 
 import numpy as np
@@ -57,6 +59,41 @@ def nx_reference(indic, edges, nlab, glab, max_nodes):
             onehot[r, nlab[u - 1] - 1] = 1
         out.append((A, onehot, label_vals.index(glab[i - 1])))
     return out
+
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("tag", ["labels_attrs", "plain"])
+@pytest.mark.parametrize("mtag,max_nodes", [("all", None), ("max8", 8)])
+def test_reader_matches_reference_fixture(tmp_path, tag, mtag, max_nodes):
+    """read_tu == the reference's read_graphfile on the same files: kept graphs, node order (= BatchNorm slot), adjacency
+    (duplicates collapsed, self loops on the diagonal, nodes without an edge dropped, a graph without edges kept with 0 nodes),
+    one-hot node labels, node attributes, graph labels renumbered by first appearance."""
+    from oracle.gen_golden import write_tu_files
+    from two_stage_gnn_amd.tu_data import read_tu
+    d = np.load(os.path.join(GOLDEN, "tu_%s.npz" % tag))
+    write_tu_files(str(tmp_path), "TOY", d["indic"], d["edges"], d["nlab"] if "nlab" in d.files else None, d["glab"],
+                   d["attrs"] if "attrs" in d.files else None)
+    ds = read_tu(str(tmp_path), "TOY", max_nodes=max_nodes)
+    sizes = d[mtag + ".sizes"]
+    np.testing.assert_array_equal(ds.sizes, sizes)
+    np.testing.assert_array_equal(ds.graph_label, d[mtag + ".labels"])
+    flat, off = d[mtag + ".adj_flat"], 0
+    for i, n in enumerate(sizes):
+        n = int(n)
+        np.testing.assert_array_equal(ds.dense(i, max(n, 1))[:n, :n].reshape(-1), (flat[off:off + n * n] > 0).astype(np.float32))
+        off += n * n
+    assert off == flat.size
+    if "nlab" in d.files:
+        np.testing.assert_array_equal(ds.features("node-label"), d[mtag + ".onehot"])
+    else:
+        assert ds.node_label is None
+        np.testing.assert_array_equal(ds.features("node-label", input_dim=5), np.ones((int(sizes.sum()), 5), np.float32))
+    if "attrs" in d.files:
+        np.testing.assert_allclose(ds.features("node-feat"), d[mtag + ".feat"], rtol=0, atol=1e-6)
+    else:
+        assert ds.node_attr is None
 
 
 @pytest.mark.parametrize("max_nodes", [None, 8])

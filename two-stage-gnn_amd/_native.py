@@ -125,6 +125,14 @@ def _arg(a):
     return a
 
 
+trace = None        # measurement hook (bench.py): a list -> every launch appends (entry point, args, dispatched kernel name)
+
+
+def last_kernel():
+    """device kernel (template arguments included) dispatched by this thread's most recent entry-point call"""
+    return lib().tsgnn_last_kernel().decode()
+
+
 def call(name, *args):
     """Call tsgnn_<name>(*args, current_stream); tensors -> device pointers, None -> NULL."""
     L = lib()
@@ -132,6 +140,8 @@ def call(name, *args):
     rc = fn(*[_arg(a) for a in args], stream_handle())
     if rc != 0:
         raise RuntimeError("tsgnn_%s failed: %s" % (name, L.tsgnn_strerror(rc).decode()))
+    if trace is not None:
+        trace.append((name, args, L.tsgnn_last_kernel().decode()))
 
 
 def call_nostream(name, *args):

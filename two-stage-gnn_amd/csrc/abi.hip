@@ -2,7 +2,10 @@
 #include "common.h"
 #include "../../include/tsgnn.h"
 
+thread_local char tsgnn_kname_[160] = "";
+
 extern "C" {
+const char* tsgnn_last_kernel(void) { return tsgnn_kname_; }
 int tsgnn_abi_version(void) { return TSGNN_ABI_VERSION; }
 const char* tsgnn_strerror(int code) {
   switch (code) {

@@ -289,6 +289,7 @@ __global__ void csr_tail_fill(const int* __restrict__ rowptr, const int* __restr
 template <int G>
 void launch_vec4(const SpmmArgs& a, hipStream_t s) {
   const unsigned nblk = (unsigned)ceil_div64(a.n_rows, 256 / G);
+  TSGNN_KNAME("spmm_vec4<%d,%s,%s>", G, a.val ? "true" : "false", a.relu_in ? "true" : "false");
   if (a.val) {
     if (a.relu_in) spmm_vec4<G, true, true><<<nblk, 256, 0, s>>>(a, nblk);
     else spmm_vec4<G, true, false><<<nblk, 256, 0, s>>>(a, nblk);
@@ -345,6 +346,7 @@ int tsgnn_csr_spmm_f32(const int* rowptr, const int* col, const float* val, cons
   } else if (vec_ok && !relu_in && n_rows >= RB_MIN_ROWS && feat / 4 <= 32 && feat / 4 > 8) {
     // large batches: row-batched gather (RB = 4 rows per lane group)
     const int nvec = feat / 4;
+    TSGNN_KNAME("spmm_vec4_rb<%d,4,%s>", nvec <= 16 ? 16 : 32, val ? "true" : "false");
     if (nvec <= 16) {
       const unsigned nblk = (unsigned)ceil_div64(n_rows, (256 / 16) * 4);
       if (val) spmm_vec4_rb<16, 4, true><<<nblk, 256, 0, stream>>>(a, nblk);
@@ -404,6 +406,7 @@ int tsgnn_ell_spmm_f32(const int* ell, int W, const float* x, int64_t ldx, float
 #define TSGNN_ELL(G, WW)                                                                               \
   {                                                                                                    \
     const unsigned nblk = (unsigned)ceil_div64(n_rows, 256 / G);                                       \
+    TSGNN_KNAME("spmm_ell_vec4<%d,%d>", G, WW);                                                        \
     spmm_ell_vec4<G, WW><<<nblk, 256, 0, stream>>>(ell, x, ldx, y, ldy, n_rows, nvec, self_scalar, nblk); \
   }
   if (nvec <= 16) {

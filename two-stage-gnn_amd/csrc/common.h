@@ -33,6 +33,13 @@ __device__ long long g_trace[4096 * 16];
 #define TR_END() do { } while (0)
 #endif
 
+// diagnostic note: the device kernel the last entry point of this thread dispatched (tsgnn_last_kernel(); bench.py reports
+// kernel names from the dispatch instead of hard-coding them).  Annotated at the dispatch sites of the training-step and
+// aggregation entry points; a few dozen nanoseconds of host time per launch.
+#include <cstdio>
+extern thread_local char tsgnn_kname_[160];
+#define TSGNN_KNAME(...) (void)snprintf(tsgnn_kname_, sizeof(tsgnn_kname_), __VA_ARGS__)
+
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // ---- cross-lane reductions on DPP (no LDS-crossbar round trips): quad_perm xor1 / xor2, row_half_mirror,

@@ -445,6 +445,7 @@ int tsgnn_wgrad_reduce_multi_f32(const float* ws0, int nslab0, int K0, int N0, f
   for (int t = m.n; t < 4; ++t) m.s[t] = m.s[0];
   m.normparts = normparts;
   m.step_state = step_state;
+  TSGNN_KNAME("tn_rows_reduce_multi");
   tn_rows_reduce_multi<<<(unsigned)blocks, 256, 0, stream>>>(m);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
@@ -464,6 +465,7 @@ static int linear_wgrad_launch(const float* z, int64_t ldz, const float* du, int
   const int tiles = mt * nt;
   const unsigned ny = (tiles >= 8 && nslab < 512) ? 2u : 1u;      // two blocks per slab when there is enough tile work
   const dim3 grid_tn((unsigned)nslab, ny);
+  TSGNN_KNAME("gemm_tn_rows_kernel<%d,%d,%u>", mt > 4 ? 4 : mt, nt > 4 ? 4 : nt, ny);
 #define TSGNN_TN(M_, N_) do { if (ny == 2) gemm_tn_rows_kernel<M_, N_, 2><<<grid_tn, 256, 2 * TN_CH * 32 * (M_ + N_) * sizeof(float), stream>>>(g); \
     else gemm_tn_rows_kernel<M_, N_, 1><<<grid_tn, 256, 2 * TN_CH * 32 * (M_ + N_) * sizeof(float), stream>>>(g); } while (0)
   switch (mt * 10 + nt) {

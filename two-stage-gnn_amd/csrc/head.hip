@@ -309,6 +309,7 @@ int tsgnn_head2_fwd_f32(const float* out, int64_t ldo, const float* w1, const fl
   if (!out || !w1 || !w2 || !vec || !y || B <= 0 || P <= 0 || E <= 0 || C <= 0 || ldo < P) return TSGNN_EINVAL;
   if ((P % 4) || P > 4096 || E > 4096 || (reinterpret_cast<uintptr_t>(w1) & 15)) return TSGNN_EUNSUPPORTED;
   const size_t lds = sizeof(float) * (size_t)(((P + 3) & ~3) + E);
+  TSGNN_KNAME("head2_fwd_kernel");
   head2_fwd_kernel<<<B, 64 * HW, lds, stream>>>(out, ldo, w1, b1, w2, b2, P, E, C, vec, y);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
@@ -327,6 +328,7 @@ int tsgnn_readout_head_fwd_f32(const unsigned long long* packed, int B, int L, i
     return TSGNN_EUNSUPPORTED;
   ReadoutHeadArgs a{packed, B, L, Fh, Fl, v_last, ldv, graph_ptr, n_real, nslots, n_ghost, out, ldo, arg};
   const size_t lds = sizeof(float) * (size_t)(((P + 3) & ~3) + ((E + 3) & ~3)) + sizeof(unsigned long long) * (size_t)(2 * HW) * Fl;
+  TSGNN_KNAME("readout_head_fwd_kernel");
   readout_head_fwd_kernel<<<B, 64 * HW, lds, stream>>>(a, w1, b1, w2, b2, P, E, C, vec, y);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
@@ -342,6 +344,7 @@ static int head2_bwd_launch(const float* out, int64_t ldo, const float* vec, con
   size_t lds = sizeof(float) * (size_t)(((E + 3) & ~3) + HW * ((P + 3) & ~3));
   if (lds < sizeof(float) * (4 * (size_t)B + HW)) lds = sizeof(float) * (4 * (size_t)B + HW);
   if (ce_label) lds += sizeof(float) * (size_t)(((B * C + 3) & ~3) + ((B + 3) & ~3));
+  TSGNN_KNAME("head2_bwd_kernel");
   head2_bwd_kernel<<<B + (E + 3) / 4 + 1, 64 * HW, lds, stream>>>(out, ldo, vec, dy, dvec, w1, w2, B, P, E, C, dout, lddo, dw1, db1, dw2,
                                                                 db2, normparts, ce_y, ce_label, ce_loss);
   TSGNN_CHECK_LAUNCH();

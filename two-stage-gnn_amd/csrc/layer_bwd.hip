@@ -38,6 +38,7 @@ int tsgnn_sage_layer_bwd_f32(const int* ell, int ell_w, const int* tail_ptr, con
   TnArgs gt{z, ldz, du, lddu, rows, rows_per_slab, 128, 128, ws, nullptr, bias_only_rows};
   const unsigned n_tn = 2u * (unsigned)nslab, n_pan = (unsigned)ceil_div64(rows, 32);
   constexpr size_t la = rowgemm_lds_bytes<4, true, true>(), lt = tn_rows_lds_bytes<4, 4>();
+  TSGNN_KNAME("sage_layer_bwd_kernel");
   sage_layer_bwd_kernel<<<n_tn + n_pan, 256, la > lt ? la : lt, stream>>>(ga, gt, n_tn, (unsigned)nslab);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;

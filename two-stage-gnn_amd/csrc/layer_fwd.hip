@@ -45,6 +45,7 @@ int tsgnn_sage_layer_fwd_f32(const int* ell, int ell_w, const int* tail_ptr, con
   const unsigned ro_gx = (unsigned)((nslots + 63) / 64);
   size_t lds = rowgemm_lds_bytes<4, false, true>();
   if (lds < 8 * 128 * sizeof(unsigned long long)) lds = 8 * 128 * sizeof(unsigned long long);
+  TSGNN_KNAME("sage_layer_fwd_kernel");
   sage_layer_fwd_kernel<<<n_gemm + ro_gx * (unsigned)B, 256, lds, stream>>>(ga, sa, n_gemm, ro_gx, K / 4, packed);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;

@@ -198,6 +198,7 @@ extern "C" {
 int tsgnn_softmax_ce_f32(const float* logits, int64_t ld, const int64_t* label, int B, int C, float* loss, float* dlogits,
                          tsgnn_stream_t stream) {
   if (!logits || !label || !loss || !dlogits || B <= 0 || C <= 0 || ld < C) return TSGNN_EINVAL;
+  TSGNN_KNAME("softmax_ce_kernel");
   softmax_ce_kernel<<<1, 256, 0, stream>>>(logits, ld, label, B, C, loss, dlogits);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
@@ -210,6 +211,7 @@ int tsgnn_adam_from_partials_f32(float* param, const float* grad, float* m, floa
                                  float eps, float weight_decay, float max_norm, float* state, const float* parts, int nparts,
                                  tsgnn_stream_t stream) {
   if (!param || !grad || !m || !v || !state || !parts || n <= 0 || nparts <= 0) return TSGNN_EINVAL;
+  TSGNN_KNAME("adam_from_partials");
   adam_from_partials<<<(unsigned)ceil_div64(n, 256 * CV), 256, 0, stream>>>(param, grad, m, v, n, lr, beta1, beta2, eps, weight_decay,
                                                                            max_norm, state, parts, nparts);
   TSGNN_CHECK_LAUNCH();
@@ -227,6 +229,7 @@ int tsgnn_clip_adam_step_f32(float* param, const float* grad, float* m, float* v
   if (reinterpret_cast<uintptr_t>(ws) & 7) return TSGNN_EINVAL;
   if (n <= SELFNORM_MAX_N) {
     const int nbc = (int)ceil_div64(n, 256 * CV);
+    TSGNN_KNAME("clip_adam_selfnorm");
     clip_adam_selfnorm<<<nbc, 256, 0, stream>>>(param, grad, m, v, n, lr, beta1, beta2, eps, weight_decay, max_norm, grad_scale, state,
                                                 reinterpret_cast<unsigned*>(ws + 256));
     TSGNN_CHECK_LAUNCH();
@@ -234,6 +237,7 @@ int tsgnn_clip_adam_step_f32(float* param, const float* grad, float* m, float* v
   }
   int nb = (int)ceil_div64(n, 256 * 8);
   if (nb > NPART) nb = NPART;
+  TSGNN_KNAME("sqnorm_partial + sqnorm_final + adam_update");
   sqnorm_partial<<<nb, 256, 0, stream>>>(grad, n, ws);
   sqnorm_final<<<1, 256, 0, stream>>>(ws, nb, grad_scale, max_norm, state);
   adam_update<<<(unsigned)ceil_div64(n, 256), 256, 0, stream>>>(param, grad, m, v, n, lr, beta1, beta2, eps, weight_decay, state);

@@ -89,6 +89,7 @@ bool try_colsplit(const RowGemmArgs& g, hipStream_t s) {
       !rowgemm_colsplit_enabled())
     return false;
   const size_t lds = rowgemm_lds_bytes<4, TRANS_B, false>();
+  TSGNN_KNAME("rowgemm_colsplit_kernel<4,%s>", TRANS_B ? "true" : "false");
   rowgemm_colsplit_kernel<4, TRANS_B><<<dim3(nblk, (unsigned)((g.N + 127) / 128)), 256, lds, s>>>(g);
   return true;
 }
@@ -108,11 +109,13 @@ void launch_rowgemm(const RowGemmArgs& g, hipStream_t s) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
         attr = true;
       }
+      TSGNN_KNAME("rowgemm_gather_ks2_kernel<%d,%s>", NT, TRANS_B ? "true" : "false");
       rowgemm_gather_ks2_kernel<NT, TRANS_B><<<nblk, 512, lds2, s>>>(g);
       return;
     }
   }
   const size_t lds = rowgemm_lds_bytes<NT, TRANS_B, GATHER>();
+  TSGNN_KNAME("rowgemm_kernel<%d,%s,%s>", NT, TRANS_B ? "true" : "false", GATHER ? "true" : "false");
   rowgemm_kernel<NT, TRANS_B, GATHER><<<nblk, 256, lds, s>>>(g);
 }
 

@@ -332,6 +332,7 @@ int tsgnn_slot_fused_supported(int B, int F) {
 #define TSGNN_SLOT_DISPATCH(KERNEL, GRID, LDS, ...)                                                                     \
   do {                                                                                                                   \
     const int F4_ = F / 4;                                                                                               \
+    TSGNN_KNAME("%s<8,%d,%d>", #KERNEL, F4_ <= 8 ? 1 : (F4_ <= 16 ? 2 : 4), B <= 32 ? 256 : (B <= 64 ? 512 : 1024));     \
     if (B <= 32) {                                                                                                       \
       if (F4_ <= 8) KERNEL<8, 1, 256><<<GRID, 256, LDS, stream>>> __VA_ARGS__;                                            \
       else if (F4_ <= 16) KERNEL<8, 2, 256><<<GRID, 256, LDS, stream>>> __VA_ARGS__;                                      \
@@ -385,6 +386,7 @@ int tsgnn_readout_partial_f32(const int* graph_ptr, int B, int nmax, int64_t n_r
     return TSGNN_EINVAL;
   SlotArgs s{graph_ptr, nullptr, B, nmax, n_real, n_ghost};
   dim3 grid((unsigned)((nmax + 63) / 64), (unsigned)B);
+  TSGNN_KNAME("readout_partial4<32>");
   readout_partial4<32><<<grid, 256, 0, stream>>>(s, x, ldx, F / 4, packed);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
@@ -394,6 +396,7 @@ int tsgnn_readout_decode_layers_f32(const unsigned long long* packed, int B, int
                                     tsgnn_stream_t stream) {
   if (!packed || !out || !arg || B <= 0 || L <= 0 || Fh <= 0 || Fl <= 0) return TSGNN_EINVAL;
   const int64_t total = (int64_t)B * ((int64_t)(L - 1) * Fh + Fl);
+  TSGNN_KNAME("readout_decode_layers");
   readout_decode_layers<<<(unsigned)ceil_div64(total, 256), 256, 0, stream>>>(packed, B, L, Fh, Fl, out, ldo, arg);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;

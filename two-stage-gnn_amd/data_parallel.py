@@ -209,6 +209,15 @@ class GraphedStep:
                 with torch.cuda.graph(self._opt, stream=self.stream, **mode):
                     trainer.apply()
 
+    def describe(self):
+        if not self.use_graph:
+            return "eager"
+        if not self.multi:
+            return "one graph: forward + backward + bucket + optimiser"
+        if self.one_graph:
+            return "one graph incl. the captured all-reduce"
+        return "two graphs around the eagerly issued all-reduce"
+
     def _fwd_bwd(self):
         tr = self.trainer
         tr.zero_grad()

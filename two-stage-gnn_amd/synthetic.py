@@ -67,6 +67,36 @@ def host_batch(seed, B, shape="DD", nmax=1000, nbar=None, ebar=None, fin=None):
     return {"sizes": sizes, "rowptr": rowptr, "col": col, "x": x, "label": label, "nmax": nmax, "fin": fin}
 
 
+def tiled_batch(seed, B, shape="DD", nmax=1000, unique=256):
+    """A B-graph batch made of ``unique`` generated graphs repeated B/unique times (structure only matters to the caller: the
+    aggregation sweep of bench.py).  Every copy owns its rows, so nothing is shared between copies; generating 16,384 graphs
+    one by one costs ~40 s of host time, tiling 256 of them well under a second."""
+    if B <= unique:
+        return host_batch(seed, B, shape, nmax)
+    if B % unique:
+        raise ValueError("B must be a multiple of %d" % unique)
+    hb = host_batch(seed, unique, shape, nmax)
+    reps = B // unique
+    n = int(hb["sizes"].sum())
+    rp = hb["rowptr"][: n + 1].astype(np.int64)
+    e = int(rp[-1])
+    sizes = np.tile(hb["sizes"], reps)
+    col = (np.tile(hb["col"][:e].astype(np.int64), reps) + np.repeat(np.arange(reps, dtype=np.int64) * n, e)).astype(np.int32)
+    rowptr = np.empty(reps * n + nmax + 1, dtype=np.int64)
+    rowptr[: reps * n] = (np.tile(rp[:-1], reps) + np.repeat(np.arange(reps, dtype=np.int64) * e, n))
+    rowptr[reps * n:] = reps * e
+    if reps * e >= 2 ** 31 or reps * n >= 2 ** 31:
+        raise ValueError("batch too large for int32 indices")
+    return {"sizes": sizes, "rowptr": rowptr.astype(np.int32), "col": col, "x": None, "label": np.tile(hb["label"], reps),
+            "nmax": nmax, "fin": hb["fin"]}
+
+
+def structure_to_device(hb, device):
+    """host batch -> GraphBatch only (no features)"""
+    return GraphBatch.from_csr(torch.from_numpy(hb["rowptr"]).to(device), torch.from_numpy(hb["col"]).to(device), None,
+                               hb["sizes"], hb["nmax"], assume_symmetric=True)
+
+
 def to_device(hb, device):
     """host batch -> (GraphBatch, packed feature rows [N+nmax, ld] with 16-byte rows, labels)."""
     g = GraphBatch.from_csr(torch.from_numpy(hb["rowptr"]).to(device), torch.from_numpy(hb["col"]).to(device), None,
