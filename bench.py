@@ -124,12 +124,15 @@ def account(entry, a, nnz):
         by += f4 * rows * K if a[13] is not None else 0          # z (the aggregate) kept for the weight gradient
         by += f4 * (rows + fill) if a[12] is not None else 0     # rinv
         return 2.0 * rows * K * N, by, "aggregate + .W + bias + L2 normalise (layer 0), K=%d N=%d" % (K, N)
-    if entry == "sage_layer_fwd_f32":
+    if entry in ("sage_layer_fwd_f32", "sage_layer_fwd_ro_f32"):
         rows, K, gs = int(a[14]), int(a[15]), int(a[16])
         B = int(a[18])
+        ro = entry.endswith("_ro_f32") and a[22] is not None
         by = (f4 * rows * K + 4 * nnz + 4 * (rows + 1) + 2 * f4 * rows * K + f4 * K * K + f4 * gs * K + f4 * (rows + gs)   # product half
-              + f4 * gs * K + 8 * B * K)                                                                                  # readout half: ghost rows, packed maxima
-        return 2.0 * rows * K * K, by, "[aggregate + .W + bias + normalise || max-readout partial of the layer's input], K=N=%d" % K
+              + f4 * gs * K + 8 * B * K                                                                                   # readout half: ghost rows, packed maxima
+              + ((8 * B * K + 4 * rows) if ro else 0))                                                                    # own readout: packed maxima, row -> graph
+        return 2.0 * rows * K * K, by, ("[aggregate + .W + bias + normalise%s || max-readout partial of the layer's input], K=N=%d"
+                                        % (" + max readout of the output" if ro else "", K))
     if entry == "sage_layer_bwd_f32":
         rows, nslab, sg = int(a[12]), int(a[13]), int(a[15])
         K = N = 128
@@ -157,6 +160,11 @@ def account(entry, a, nnz):
         P = (L - 1) * Fh + Fl
         return 2.0 * B * (P * E + E * C), f4 * (n + sg) * Fl + 8 * B * (L - 1) * Fh + f4 * (E * P + C * E) + 2 * f4 * B * P, \
             "last layer's max readout + decode + Linear(%d,%d) + Linear(%d,%d)" % (P, E, E, C)
+    if entry == "packed_head_fwd_f32":
+        B, L, Fh, Fl, E, C = int(a[1]), int(a[2]), int(a[3]), int(a[4]), int(a[12]), int(a[13])
+        P = (L - 1) * Fh + Fl
+        return 2.0 * B * (P * E + E * C), 8 * B * P + f4 * (E * P + C * E) + 2 * f4 * B * P, \
+            "decode of all layers' packed maxima + Linear(%d,%d) + Linear(%d,%d)" % (P, E, E, C)
     if entry in ("head2_bwd_ce_f32", "head2_bwd_f32"):
         o = 0 if entry == "head2_bwd_ce_f32" else -1
         B, P, E, C = int(a[9 + o]), int(a[10 + o]), int(a[11 + o]), int(a[12 + o])
@@ -439,10 +447,10 @@ def main():
                                     "hbm_frac": roofline["step_bytes"] / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
                 # the aggregation-only bytes of one pass over the real rows / the fused kernel that contains it
                 n = int(g.n_rows)
-                fused = [r for r in table if r["entry"] in ("tsgnn_sage_layer_fwd_f32", "tsgnn_gather_rowgemm_f32")]
+                fused = [r for r in table if r["entry"] in ("tsgnn_sage_layer_fwd_f32", "tsgnn_sage_layer_fwd_ro_f32", "tsgnn_gather_rowgemm_f32")]
                 agg_in = []
                 for r in fused:
-                    K = a.hidden if r["entry"] == "tsgnn_sage_layer_fwd_f32" else x.size(1)
+                    K = a.hidden if r["entry"].startswith("tsgnn_sage_layer_fwd") else x.size(1)
                     nb = synthetic.aggregation_bytes(n, int(g.nnz), K)
                     agg_in.append({"kernel": r["kernel"], "F": K, "aggregation_bytes": nb, "us_per_launch": r["us_per_launch"],
                                    "achieved": nb / r["us_per_launch"] / 1e3, "unit": "GB/s",

@@ -177,6 +177,14 @@ int tsgnn_gather_rowgemm_f32(const int* ell, int ell_w, const int* tail_ptr, con
 int tsgnn_sage_layer_fwd_f32(const int* ell, int ell_w, const int* tail_ptr, const int* tail_col, const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias,
                              float* v, int64_t ldv, float* rinv, float* zout, int64_t ldz, int64_t rows, int K, int64_t fill_rows,
                              const int* graph_ptr, int B, int nslots, int n_ghost, unsigned long long* packed, tsgnn_stream_t stream);
+/* The same launch when the layer is the LAST of the stack (no slot batch-norm follows, encoders.py:182-183): the product's
+ * epilogue also folds the max readout of the layer's own output v into packed_out[B*128] (packed (ordered value, ~row)
+ * atomicMax; real rows from the row panels, each graph's first ghost row from the filler block), so no pass over v is needed
+ * for it.  packed_out: zeroed by the caller, nullable (= tsgnn_sage_layer_fwd_f32); row_graph[rows] = graph of each row. */
+int tsgnn_sage_layer_fwd_ro_f32(const int* ell, int ell_w, const int* tail_ptr, const int* tail_col, const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias,
+                                float* v, int64_t ldv, float* rinv, float* zout, int64_t ldz, int64_t rows, int K, int64_t fill_rows,
+                                const int* graph_ptr, int B, int nslots, int n_ghost, unsigned long long* packed,
+                                unsigned long long* packed_out, const int* row_graph, tsgnn_stream_t stream);
 /* Backward of a hidden 128 -> 128 GraphConv layer's GEMM-shaped halves in ONE launch (both consume du): the weight / bias
  * gradient slabs of tsgnn_linear_wgrad_f32 (dw == NULL form: reduce ws later with tsgnn_wgrad_reduce_multi_f32; plan with
  * tsgnn_linear_wgrad_plan(rows, 128, 128, ...)) and dxs = (A du) w^T of tsgnn_gather_rowgemm_f32 (trans_b = 1, symmetric A).
@@ -526,6 +534,11 @@ int tsgnn_readout_head_fwd_f32(const unsigned long long* packed, int B, int L, i
                                const int* graph_ptr, int64_t n_real, int nslots, int n_ghost, float* out, int64_t ldo, int* arg,
                                const float* w1, const float* b1, const float* w2, const float* b2, int E, int C, float* vec, float* y,
                                tsgnn_stream_t stream);
+/* The same tail when the LAST layer's readout is already in packed too (tsgnn_sage_layer_fwd_ro_f32): decode all
+ * (L-1)*Fh + Fl packed maxima of each graph into out / arg, then the head.  No pass over node rows.  E <= 128. */
+int tsgnn_packed_head_fwd_f32(const unsigned long long* packed, int B, int L, int Fh, int Fl, float* out, int64_t ldo, int* arg,
+                              const float* w1, const float* b1, const float* w2, const float* b2, int E, int C, float* vec, float* y,
+                              tsgnn_stream_t stream);
 /* backward in one launch: dvt = dvec (nullable) + W2^T dy (internal) ; dout = W1^T dvt ; dW1 = dvt^T out ; db1 ; dW2 = dy^T vec ; db2.
  * normparts (nullable, ceil(E/4) + 1 floats): per weight block, the sum of squares of the gradient entries it wrote. */
 int tsgnn_head2_bwd_f32(const float* out, int64_t ldo, const float* vec, const float* dy, const float* dvec, const float* w1,

@@ -91,7 +91,7 @@ def assert_grads_arbitrated(named_params, p32, p64, floor=2e-3, handful=8):
 
 
 @pytest.mark.parametrize("B,nmax,nbar,fin,hid", [(8, 160, 60, 89, 128), (4, 400, 269, 89, 128), (40, 200, 60, 7, 64),
-                                                 (100, 64, 20, 3, 32)])
+                                                 (100, 64, 20, 3, 32), (48, 64, 12, 7, 128)])
 def test_gcn_encoder_vs_oracle_dd_shape(B, nmax, nbar, fin, hid):
     """DD-shaped batches (README.md:39: avg 269 nodes / 676 edges, 89 node labels), 3 layers h=128:
     HIP packed path vs the CPU oracle's dense formulation, outputs and all parameter gradients."""
@@ -639,3 +639,34 @@ def test_stack_edge_shapes_vs_oracle(case):
             continue
         assert (gr - ref).abs().max().item() <= 2e-3 * ref.abs().max().item() + 1e-7, k
         assert ((gr - ref).norm() / (ref.norm() + 1e-12)).item() < 1e-3, k
+
+
+@pytest.mark.parametrize("B,nmax,nbar", [(6, 300, 120), (48, 64, 12), (3, 40, 33)])
+def test_epilogue_readout_equals_row_scan(B, nmax, nbar, monkeypatch):
+    """the last layer's max readout folded into its product's epilogue (packed atomicMax per panel and graph, ghost rows from
+    the filler block; panels that span one, two or many graphs) == the tail kernel scanning the layer's rows: identical
+    outputs, arg-max winners (through the gradients) and parameters after a step, bit for bit"""
+    from two_stage_gnn_amd import dense_encoders as E, sage_stack
+    sizes = dd_like_sizes(5, B, nbar=nbar, nmax=nmax)
+    x, adj, sizes = dense_batch(9, B, nmax, 12, sizes=sizes.tolist(), p_edge=min(0.5, 5.0 / nbar))
+
+    class A:
+        bias = True
+    res = []
+    for on in (True, False):
+        monkeypatch.setattr(sage_stack, "EPILOGUE_READOUT", on)
+        torch.manual_seed(4)
+        m = E.GcnEncoderGraph(12, 128, 128, 3, 3, bn=True, args=A(), final_dim="number_classes")
+        with torch.no_grad():
+            for k, p in m.named_parameters():
+                if k.endswith("bias") and "conv" in k:
+                    p.copy_(torch.randn_like(p) * 0.3)        # ghost rows (normalised bias) can win the readout
+        m = m.cuda()
+        a, b = m(x.cuda(), adj.cuda(), sizes)
+        m.loss(b, (torch.arange(B) % 3).cuda()).backward()
+        res.append((a.detach().clone(), b.detach().clone(), [p.grad.clone() for p in m.parameters() if p.grad is not None]))
+        assert len(res[-1][2]) >= 8
+    torch.testing.assert_close(res[0][0], res[1][0], rtol=0, atol=0)
+    torch.testing.assert_close(res[0][1], res[1][1], rtol=0, atol=0)
+    for ga, gb in zip(res[0][2], res[1][2]):
+        torch.testing.assert_close(ga, gb, rtol=0, atol=0)

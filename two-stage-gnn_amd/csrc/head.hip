@@ -136,6 +136,103 @@ __global__ __launch_bounds__(64 * HW) void readout_head_fwd_kernel(ReadoutHeadAr
   head2_fwd_tail(xs, vs, b, w1, b1, w2, b2, P, E, C, vec, y);
 }
 
+// The tail when the last layer's readout is already in `packed` (tsgnn_sage_layer_fwd_ro_f32 folded it into the product's
+// epilogue): block b decodes its P packed maxima and runs the head.  Everything the block reads from memory is requested
+// before anything is waited for — the packed words (the only operands that depend on the previous launch) and, behind them,
+// the wave's W1 rows and W2 — so the kernel is ONE memory round trip, an LDS exchange and two short reductions.
+template <int NJ>     // W1 rows per wave held in registers (E <= HW * NJ)
+__global__ __launch_bounds__(64 * HW) void packed_head_fwd_kernel(const unsigned long long* __restrict__ packed, int B, int L, int Fh,
+                                                              int Fl, float* __restrict__ out, int64_t ldo, int* __restrict__ arg,
+                                                              const float* __restrict__ w1, const float* __restrict__ b1,
+                                                              const float* __restrict__ w2, const float* __restrict__ b2, int P, int E,
+                                                              int C, float* __restrict__ vec, float* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* xs = smem;                                  // [P]
+  float* vs = smem + ((P + 3) & ~3);                 // [E]
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int PH = (L - 1) * Fh, P4 = P >> 2;
+  // (1) the packed maxima of this graph: thread k < P (P <= 2048: two per thread)
+  unsigned long long pk[2];
+  int64_t pidx[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int k = tid + u * 64 * HW;
+    int64_t idx = 0;
+    if (k < P) {
+      if (k < PH) { const int l = k / Fh, f = k - l * Fh; idx = (int64_t)l * B * Fh + (int64_t)b * Fh + f; }
+      else idx = (int64_t)(L - 1) * B * Fh + (int64_t)b * Fl + (k - PH);
+    }
+    pidx[u] = idx;
+    pk[u] = k < P ? packed[idx] : 0ull;
+  }
+  // (2) this wave's rows of W1 (j = wid + HW * u), float4 column `lane` and `lane + 64` of each; W2 for the waves that own a class
+  float4 w[NJ][2];
+#pragma unroll
+  for (int u = 0; u < NJ; ++u) {
+    const int j = wid + HW * u;
+    const float* row = w1 + (int64_t)(j < E ? j : 0) * P;
+    w[u][0] = lane < P4 ? ld4(row + 4 * lane) : make_float4(0.f, 0.f, 0.f, 0.f);
+    w[u][1] = lane + 64 < P4 ? ld4(row + 4 * (lane + 64)) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float bj[NJ];
+#pragma unroll
+  for (int u = 0; u < NJ; ++u) { const int j = wid + HW * u; bj[u] = (b1 && j < E) ? b1[j] : 0.f; }
+  float w2v[4];                                      // class `wid`: columns lane, lane + 64, ... of W2 (E <= 256 in registers)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { const int j = lane + 64 * q; w2v[q] = (wid < C && j < E) ? w2[(int64_t)wid * E + j] : 0.f; }
+  const float b2v = (b2 && wid < C) ? b2[wid] : 0.f;
+  // decode -> LDS, out, arg
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int k = tid + u * 64 * HW;
+    if (k < P) {
+      const unsigned long long p = pk[u];
+      const float val = p ? ordered_f32((unsigned)(p >> 32)) : 0.f;
+      xs[k] = val;
+      out[(int64_t)b * ldo + k] = val;
+      arg[pidx[u]] = p ? (int)(0xFFFFFFFFu - (unsigned)(p & 0xFFFFFFFFull)) : -1;
+    }
+  }
+  __syncthreads();
+  {
+    const float4 x0 = lane < P4 ? *reinterpret_cast<const float4*>(xs + 4 * lane) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 x1 = lane + 64 < P4 ? *reinterpret_cast<const float4*>(xs + 4 * (lane + 64)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float acc[NJ];
+#pragma unroll
+    for (int u = 0; u < NJ; ++u)
+      acc[u] = ((w[u][0].x * x0.x + w[u][0].y * x0.y) + (w[u][0].z * x0.z + w[u][0].w * x0.w)) +
+               ((w[u][1].x * x1.x + w[u][1].y * x1.y) + (w[u][1].z * x1.z + w[u][1].w * x1.w));
+    // columns beyond 128 float4 (P > 512) and rows beyond HW * NJ are streamed (not the shapes this kernel is picked for)
+    for (int k4 = lane + 128; k4 < P4; k4 += 64) {
+      const float4 x = *reinterpret_cast<const float4*>(xs + 4 * k4);
+#pragma unroll
+      for (int u = 0; u < NJ; ++u) {
+        const int j = wid + HW * u;
+        const float4 t = ld4(w1 + (int64_t)(j < E ? j : 0) * P + 4 * k4);
+        acc[u] += (t.x * x.x + t.y * x.y) + (t.z * x.z + t.w * x.w);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NJ; ++u) {
+      const int j = wid + HW * u;
+      const float r = wave_sum(acc[u]);
+      if (lane == 0 && j < E) { const float v = r + bj[u]; vs[j] = v; vec[(int64_t)b * E + j] = v; }
+    }
+  }
+  __syncthreads();
+  for (int c = wid; c < C; c += HW) {
+    float acc = 0.f;
+    if (c == wid && E <= 256) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const int j = lane + 64 * q; if (j < E) acc = fmaf(w2v[q], vs[j], acc); }
+    } else {
+      for (int j = lane; j < E; j += 64) acc = fmaf(w2[(int64_t)c * E + j], vs[j], acc);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) y[(int64_t)b * C + c] = acc + ((c == wid) ? b2v : (b2 ? b2[c] : 0.f));
+  }
+}
+
 // Backward in ONE launch.  Blocks [0, B): block b computes dvt[b,:] = dvec[b,:] + W2^T dy[b,:] and dout[b,:] = W1^T dvt[b,:].
 // Blocks [B, B + ceil(E/4)]: the weight gradients; they rebuild the four dvt columns they need from dy, dvec and W2
 // (C fused multiply-adds per value) instead of waiting for the row blocks, so nothing orders the two groups.
@@ -300,6 +397,235 @@ __global__ __launch_bounds__(64 * HW) void head2_bwd_kernel(const float* __restr
   else head2_bwd_weights(smem, (int)blockIdx.x - B, out, ldo, vec, dy, dvec, w2, B, P, E, C, dw1, db1, dw2, db2, normparts);
 }
 
+// ---- second generation of the backward launch: same roles, same arithmetic per output, but every block REQUESTS all of its
+// global operands (logits / labels, W2, its W1 rows or its rows of `out`) before it waits for anything, so a block is one
+// memory round trip followed by LDS phases instead of four or five dependent trips (measured r1: 11.6 us in the step).
+//   row block b   : threads = (row group jg, float4 column k4); group jg owns rows j = jg + G*u of W1; partial sums over the
+//                   groups meet in LDS and are added in group order (fixed order: reproducible).
+//   weight block  : threads = (graph group bg, float4 column k4) over `out`; the four dvt columns of the block sit in LDS.
+constexpr int RB_ROWS = 16;      // W1 rows per thread and batch (row blocks)
+constexpr int WB_ROWS = 4;       // rows of `out` per thread and batch (weight blocks)
+
+struct CeArgs { const float* y; const int64_t* label; float* loss; };
+
+// softmax-CE gradient rows into dyl[B*C] (+ per-graph loss terms lb[B]) — rows: all of them, or only row `only` (row blocks > 0)
+__device__ __forceinline__ void ce_rows(const CeArgs& ce, int B, int C, float* dyl, float* lb, int only) {
+  const float invB = 1.f / (float)B;
+  for (int b = only >= 0 ? only + (int)threadIdx.x * B : (int)threadIdx.x; b < B; b += 64 * HW) {
+    const float* row = ce.y + (int64_t)b * C;
+    float m = -INFINITY;
+    for (int c = 0; c < C; ++c) m = fmaxf(m, row[c]);
+    float d = 0.f;
+    for (int c = 0; c < C; ++c) d += expf(row[c] - m);
+    const int yb = (int)ce.label[b];
+    const float logz = m + logf(d);
+    lb[b] = logz - row[yb];
+    for (int c = 0; c < C; ++c) dyl[b * C + c] = (expf(row[c] - logz) - (c == yb ? 1.f : 0.f)) * invB;
+  }
+}
+
+__global__ __launch_bounds__(64 * HW) void head2_bwd2_kernel(const float* __restrict__ out, int64_t ldo, const float* __restrict__ vec,
+                                                         const float* __restrict__ dy_in, const float* __restrict__ dvec,
+                                                         const float* __restrict__ w1, const float* __restrict__ w2, int B, int P, int E,
+                                                         int C, float* __restrict__ dout, int64_t lddo, float* __restrict__ dw1,
+                                                         float* __restrict__ db1, float* __restrict__ dw2, float* __restrict__ db2,
+                                                         float* __restrict__ normparts, CeArgs ce) {
+  extern __shared__ __attribute__((aligned(16))) float smem_all[];
+  const int tid = threadIdx.x, NTH = 64 * HW;
+  const int P4 = P >> 2, PP = P;                         // P % 4 == 0 on this path
+  const bool has_ce = ce.label != nullptr;
+  float* dyl = smem_all;                                 // [B * C]   (has_ce)
+  float* lb = smem_all + (has_ce ? ((B * C + 3) & ~3) : 0);
+  float* smem = lb + (has_ce ? ((B + 3) & ~3) : 0);      // role-specific region, 16-byte aligned
+  const float* dy = has_ce ? dyl : dy_in;
+  const int nj = (E + 3) / 4;
+
+  if ((int)blockIdx.x < B) {
+    // ------------------------------------------------------------------------------------------------ row block
+    const int b = blockIdx.x;
+    const int G = min(16, NTH / P4);                     // row groups (P4 <= 512: G >= 2)
+    const int jg = tid / P4, k4 = tid - jg * P4;
+    const bool active = jg < G;
+    float* ds = smem;                                    // [E]
+    float* part = smem + ((E + 3) & ~3);                 // [G][PP]
+    // requests: W2 column(s) of thread j, dvec, then the first batch of W1 rows
+    float w2r[4];
+    float dv0 = 0.f;
+    if (tid < E) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) w2r[c] = c < C ? w2[(int64_t)c * E + tid] : 0.f;
+      if (dvec) dv0 = dvec[(int64_t)b * E + tid];
+    }
+    float4 w[RB_ROWS];
+#pragma unroll
+    for (int u = 0; u < RB_ROWS; ++u) {
+      const int j = jg + G * u;
+      w[u] = (active && j < E) ? ld4(w1 + (int64_t)j * P + 4 * k4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (has_ce) {
+      ce_rows(ce, B, C, dyl, lb, b == 0 ? -1 : b);
+      __syncthreads();
+      if (b == 0) {
+        // the loss value, summed exactly as tsgnn_softmax_ce_f32 sums it (thread t: rows t, t + 256, ...; DPP wave sums;
+        // (w0 + w1) + (w2 + w3); / B) so that the deferred and the ordinary loss agree to the bit
+        float* red = lb + ((B + 3) & ~3);                // start of the role region: not in use yet
+        if (tid < 256) {
+          float part = 0.f;
+          for (int q = tid; q < B; q += 256) part += lb[q];
+          part = wave_sum(part);
+          if ((tid & 63) == 0) red[tid >> 6] = part;
+        }
+        __syncthreads();
+        if (tid == 0) ce.loss[0] = ((red[0] + red[1]) + (red[2] + red[3])) / (float)B;
+        __syncthreads();
+      }
+    }
+    for (int j = tid; j < E; j += NTH) {                 // dvt row (same expression and order as the weight blocks)
+      float acc = j == tid ? dv0 : (dvec ? dvec[(int64_t)b * E + j] : 0.f);
+      for (int c = 0; c < C; ++c) acc = fmaf(dy[(int64_t)b * C + c], (j == tid && c < 4) ? w2r[c] : w2[(int64_t)c * E + j], acc);
+      ds[j] = acc;
+    }
+    __syncthreads();
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j0 = 0; j0 < E; j0 += G * RB_ROWS) {
+      if (j0 > 0) {
+#pragma unroll
+        for (int u = 0; u < RB_ROWS; ++u) {
+          const int j = j0 + jg + G * u;
+          w[u] = (active && j < E) ? ld4(w1 + (int64_t)j * P + 4 * k4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < RB_ROWS; ++u) {
+        const int j = j0 + jg + G * u;
+        const float d = (active && j < E) ? ds[j] : 0.f;
+        acc.x = fmaf(d, w[u].x, acc.x); acc.y = fmaf(d, w[u].y, acc.y); acc.z = fmaf(d, w[u].z, acc.z); acc.w = fmaf(d, w[u].w, acc.w);
+      }
+    }
+    if (active) *reinterpret_cast<float4*>(part + jg * PP + 4 * k4) = acc;
+    __syncthreads();
+    for (int k = tid; k < P; k += NTH) {
+      float a = 0.f;
+      for (int q = 0; q < G; ++q) a += part[q * PP + k];
+      dout[(int64_t)b * lddo + k] = a;
+    }
+    return;
+  }
+  // -------------------------------------------------------------------------------------------------- weight blocks
+  const int jb = (int)blockIdx.x - B;
+  float sq = 0.f;                                        // |gradient written by this thread|^2
+  if (jb < nj) {
+    const int j0 = 4 * jb;
+    const int G = max(1, min(8, 768 / P4));              // graph groups: G * 4 * P floats of partial sums (<= 48 KB)
+    const int bg = tid / P4, k4 = tid - bg * P4;
+    const bool active = bg < G;
+    float* dvs = smem;                                   // [B][4] dvt slice
+    float* part = smem + 4 * ((B + 3) & ~3);             // [G][4][PP]
+    // requests: W2 / dvec of the thread's (graph, column) of the slice, the first batch of `out` rows
+    float w2r[4];
+    float dv0 = 0.f;
+    const int sb = tid >> 2, sj = j0 + (tid & 3);
+    if (tid < 4 * B && sj < E) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) w2r[c] = c < C ? w2[(int64_t)c * E + sj] : 0.f;
+      if (dvec) dv0 = dvec[(int64_t)sb * E + sj];
+    }
+    float4 x[WB_ROWS];
+#pragma unroll
+    for (int u = 0; u < WB_ROWS; ++u) {
+      const int bb = bg + G * u;
+      x[u] = (active && bb < B) ? ld4(out + (int64_t)bb * ldo + 4 * k4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (has_ce) { ce_rows(ce, B, C, dyl, lb, -1); __syncthreads(); }
+    for (int i = tid; i < 4 * B; i += NTH) {
+      const int bb = i >> 2, jj = j0 + (i & 3);
+      float a = 0.f;
+      if (jj < E) {
+        a = i == tid ? dv0 : (dvec ? dvec[(int64_t)bb * E + jj] : 0.f);
+        for (int c = 0; c < C; ++c) a = fmaf(dy[(int64_t)bb * C + c], (i == tid && c < 4) ? w2r[c] : w2[(int64_t)c * E + jj], a);
+      }
+      dvs[i] = a;
+    }
+    __syncthreads();
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+    for (int b0 = 0; b0 < B; b0 += G * WB_ROWS) {
+      if (b0 > 0) {
+#pragma unroll
+        for (int u = 0; u < WB_ROWS; ++u) {
+          const int bb = b0 + bg + G * u;
+          x[u] = (active && bb < B) ? ld4(out + (int64_t)bb * ldo + 4 * k4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < WB_ROWS; ++u) {
+        const int bb = b0 + bg + G * u;
+        if (active && bb < B) {
+          const float4 d = *reinterpret_cast<const float4*>(dvs + 4 * bb);
+          a0.x = fmaf(d.x, x[u].x, a0.x); a0.y = fmaf(d.x, x[u].y, a0.y); a0.z = fmaf(d.x, x[u].z, a0.z); a0.w = fmaf(d.x, x[u].w, a0.w);
+          a1.x = fmaf(d.y, x[u].x, a1.x); a1.y = fmaf(d.y, x[u].y, a1.y); a1.z = fmaf(d.y, x[u].z, a1.z); a1.w = fmaf(d.y, x[u].w, a1.w);
+          a2.x = fmaf(d.z, x[u].x, a2.x); a2.y = fmaf(d.z, x[u].y, a2.y); a2.z = fmaf(d.z, x[u].z, a2.z); a2.w = fmaf(d.z, x[u].w, a2.w);
+          a3.x = fmaf(d.w, x[u].x, a3.x); a3.y = fmaf(d.w, x[u].y, a3.y); a3.z = fmaf(d.w, x[u].z, a3.z); a3.w = fmaf(d.w, x[u].w, a3.w);
+        }
+      }
+    }
+    if (active) {
+      float* pp = part + (int64_t)bg * 4 * PP + 4 * k4;
+      *reinterpret_cast<float4*>(pp) = a0; *reinterpret_cast<float4*>(pp + PP) = a1;
+      *reinterpret_cast<float4*>(pp + 2 * PP) = a2; *reinterpret_cast<float4*>(pp + 3 * PP) = a3;
+    }
+    __syncthreads();
+    for (int i = tid; i < 4 * P; i += NTH) {
+      const int jj = i / P, k = i - jj * P;
+      if (j0 + jj < E) {
+        float a = 0.f;
+        for (int q = 0; q < G; ++q) a += part[(q * 4 + jj) * PP + k];      // group order: reproducible
+        dw1[(int64_t)(j0 + jj) * P + k] = a;
+        sq = fmaf(a, a, sq);
+      }
+    }
+    if (db1 && tid < 4 && j0 + tid < E) {
+      float a = 0.f;
+      for (int bb = 0; bb < B; ++bb) a += dvs[4 * bb + tid];
+      db1[j0 + tid] = a;
+      sq = fmaf(a, a, sq);
+    }
+  } else {
+    if (has_ce) { ce_rows(ce, B, C, dyl, lb, -1); __syncthreads(); }
+    for (int i = tid; i < C * E; i += NTH) {
+      const int c = i / E, j = i - c * E;
+      float a = 0.f;
+      int bb = 0;
+      for (; bb + 8 <= B; bb += 8) {                     // eight rows of vec in flight
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = vec[(int64_t)(bb + u) * E + j];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a = fmaf(dy[(int64_t)(bb + u) * C + c], v[u], a);
+      }
+      for (; bb < B; ++bb) a = fmaf(dy[(int64_t)bb * C + c], vec[(int64_t)bb * E + j], a);
+      dw2[i] = a;
+      sq = fmaf(a, a, sq);
+    }
+    if (db2) for (int c = tid; c < C; c += NTH) {
+      float a = 0.f;
+      for (int bb = 0; bb < B; ++bb) a += dy[(int64_t)bb * C + c];
+      db2[c] = a;
+      sq = fmaf(a, a, sq);
+    }
+  }
+  if (normparts) {                                       // block total in a fixed order: waves through LDS
+    sq = wave_sum(sq);
+    __syncthreads();
+    if ((tid & 63) == 0) smem[tid >> 6] = sq;
+    __syncthreads();
+    if (tid == 0) {
+      float t = 0.f;
+      for (int w = 0; w < HW; ++w) t += smem[w];
+      normparts[jb] = t;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -334,6 +660,19 @@ int tsgnn_readout_head_fwd_f32(const unsigned long long* packed, int B, int L, i
   return TSGNN_OK;
 }
 
+int tsgnn_packed_head_fwd_f32(const unsigned long long* packed, int B, int L, int Fh, int Fl, float* out, int64_t ldo, int* arg,
+                              const float* w1, const float* b1, const float* w2, const float* b2, int E, int C, float* vec, float* y,
+                              tsgnn_stream_t stream) {
+  if (!packed || !out || !arg || !w1 || !w2 || !vec || !y || B <= 0 || L <= 0 || Fh <= 0 || Fl <= 0 || E <= 0 || C <= 0) return TSGNN_EINVAL;
+  const int P = (L - 1) * Fh + Fl;
+  if ((P % 4) || P > 2048 || E > 8 * HW || ldo < P || (reinterpret_cast<uintptr_t>(w1) & 15)) return TSGNN_EUNSUPPORTED;
+  const size_t lds = sizeof(float) * (size_t)(((P + 3) & ~3) + ((E + 3) & ~3));
+  TSGNN_KNAME("packed_head_fwd_kernel<8>");
+  packed_head_fwd_kernel<8><<<B, 64 * HW, lds, stream>>>(packed, B, L, Fh, Fl, out, ldo, arg, w1, b1, w2, b2, P, E, C, vec, y);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
 static int head2_bwd_launch(const float* out, int64_t ldo, const float* vec, const float* dy, const float* dvec, const float* w1,
                             const float* w2, int B, int P, int E, int C, float* dout, int64_t lddo, float* dw1, float* db1,
                             float* dw2, float* db2, float* normparts, const float* ce_y, const int64_t* ce_label, float* ce_loss,
@@ -341,6 +680,30 @@ static int head2_bwd_launch(const float* out, int64_t ldo, const float* vec, con
   if (!out || !vec || (!dy && !ce_label) || !w1 || !w2 || !dout || !dw1 || !dw2 || B <= 0 || P <= 0 || E <= 0 || C <= 0) return TSGNN_EINVAL;
   if (ce_label && (!ce_y || !ce_loss)) return TSGNN_EINVAL;
   if ((P % 4) || P > 2048 || E > 4096 || B > 1024 || (reinterpret_cast<uintptr_t>(w1) & 15)) return TSGNN_EUNSUPPORTED;
+  if ((ldo % 4) == 0 && (lddo % 4) == 0 && !((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(dout)) & 15) && (P / 4) <= 512) {
+    // second-generation kernel: all operands requested up front (16-byte rows of `out` required)
+    const int P4 = P / 4;
+    const int Gr = 64 * HW / P4 < 16 ? 64 * HW / P4 : 16;
+    const int Gw = 768 / P4 < 1 ? 1 : (768 / P4 > 8 ? 8 : 768 / P4);
+    size_t role = (size_t)((E + 3) & ~3) + (size_t)Gr * P;
+    const size_t wrole = 4 * (size_t)((B + 3) & ~3) + (size_t)Gw * 4 * P;
+    if (wrole > role) role = wrole;
+    if (role < HW) role = HW;
+    size_t lds2 = sizeof(float) * role;
+    if (ce_label) lds2 += sizeof(float) * (size_t)(((B * C + 3) & ~3) + ((B + 3) & ~3));
+    if (lds2 <= 160 * 1024 - 1024) {
+      static size_t attr_set = 0;
+      if (lds2 > 64 * 1024 && lds2 > attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(head2_bwd2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        attr_set = lds2;
+      }
+      TSGNN_KNAME("head2_bwd2_kernel");
+      head2_bwd2_kernel<<<B + (E + 3) / 4 + 1, 64 * HW, lds2, stream>>>(out, ldo, vec, dy, dvec, w1, w2, B, P, E, C, dout, lddo, dw1, db1, dw2, db2,
+                                                                    normparts, CeArgs{ce_y, ce_label, ce_loss});
+      TSGNN_CHECK_LAUNCH();
+      return TSGNN_OK;
+    }
+  }
   size_t lds = sizeof(float) * (size_t)(((E + 3) & ~3) + HW * ((P + 3) & ~3));
   if (lds < sizeof(float) * (4 * (size_t)B + HW)) lds = sizeof(float) * (4 * (size_t)B + HW);
   if (ce_label) lds += sizeof(float) * (size_t)(((B * C + 3) & ~3) + ((B + 3) & ~3));

@@ -12,11 +12,14 @@
 
 namespace {
 
+// RO: the product's epilogue also folds the max readout of its OWN output into ga.ro_packed (last layer of the stack: no
+// slot batch-norm follows, so the readout is taken on v itself)
+template <bool RO>
 __global__ __launch_bounds__(256) void sage_layer_fwd_kernel(RowGemmArgs ga, SlotArgs sa, unsigned n_gemm, unsigned ro_gx, int F4,
                                                              unsigned long long* __restrict__ packed) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (blockIdx.x < n_gemm) {
-    rowgemm_body<4, false, true>(ga, smem, blockIdx.x);
+    rowgemm_body<4, false, true, 1, RO>(ga, smem, blockIdx.x);
   } else {
     const unsigned r = blockIdx.x - n_gemm;
     readout_partial_body<32>(sa, ga.a, ga.lda, F4, packed, r % ro_gx, r / ro_gx, reinterpret_cast<unsigned long long*>(smem));
@@ -27,11 +30,14 @@ __global__ __launch_bounds__(256) void sage_layer_fwd_kernel(RowGemmArgs ga, Slo
 
 extern "C" {
 
-int tsgnn_sage_layer_fwd_f32(const int* ell, int ell_w, const int* tail_ptr, const int* tail_col, const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias,
-                             float* v, int64_t ldv, float* rinv, float* zout, int64_t ldz, int64_t rows, int K, int64_t fill_rows,
-                             const int* graph_ptr, int B, int nslots, int n_ghost, unsigned long long* packed, tsgnn_stream_t stream) {
+/* packed_out (nullable) [B*128], zeroed by the caller: receives the packed max readout of the layer's own OUTPUT v (real rows
+ * from the product's epilogue, each graph's first ghost row from the filler block); row_graph[rows] = graph of each row. */
+int tsgnn_sage_layer_fwd_ro_f32(const int* ell, int ell_w, const int* tail_ptr, const int* tail_col, const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias,
+                                float* v, int64_t ldv, float* rinv, float* zout, int64_t ldz, int64_t rows, int K, int64_t fill_rows,
+                                const int* graph_ptr, int B, int nslots, int n_ghost, unsigned long long* packed,
+                                unsigned long long* packed_out, const int* row_graph, tsgnn_stream_t stream) {
   if (!ell || !x || !w || !v || !rinv || !graph_ptr || !packed || rows <= 0 || fill_rows < 0 || K <= 0 || B <= 0 || nslots <= 0 ||
-      (n_ghost != 0 && n_ghost != nslots))
+      (n_ghost != 0 && n_ghost != nslots) || (packed_out && !row_graph))
     return TSGNN_EINVAL;
   if (ell_w != 4 && ell_w != 8 && ell_w != 16) return TSGNN_EUNSUPPORTED;
   const uintptr_t al = reinterpret_cast<uintptr_t>(ell) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w) |
@@ -39,16 +45,30 @@ int tsgnn_sage_layer_fwd_f32(const int* ell, int ell_w, const int* tail_ptr, con
   if ((al & 15) || K != 128 || (ldx % 4) || (ldw % 4) || (ldv % 4) || (zout && (ldz % 4 || ldz < K)) || ldx < K || ldw < 128 || ldv < 128)
     return TSGNN_EUNSUPPORTED;            /* x is also read as the [rows, 128] readout operand: hidden layers only */
   if ((tail_ptr == nullptr) != (tail_col == nullptr)) return TSGNN_EINVAL;
-  RowGemmArgs ga{x, ldx, w, ldw, bias, v, ldv, rinv, rows, K, 128, 1, fill_rows, ell, ell_w, zout, ldz, tail_ptr, tail_col};
+  if (packed_out && n_ghost && fill_rows <= 0) return TSGNN_EUNSUPPORTED;   /* the ghost rows' share comes from the filler block */
+  RowGemmArgs ga{x, ldx, w, ldw, bias, v, ldv, rinv, rows, K, 128, 1, fill_rows, ell, ell_w, zout, ldz, tail_ptr, tail_col,
+                 packed_out, graph_ptr, row_graph, B, nslots, n_ghost};
   SlotArgs sa{graph_ptr, nullptr, B, nslots, rows, n_ghost};
   const unsigned n_gemm = (unsigned)ceil_div64(rows, 32) + (fill_rows > 0 ? 1u : 0u);
   const unsigned ro_gx = (unsigned)((nslots + 63) / 64);
   size_t lds = rowgemm_lds_bytes<4, false, true>();
   if (lds < 8 * 128 * sizeof(unsigned long long)) lds = 8 * 128 * sizeof(unsigned long long);
-  TSGNN_KNAME("sage_layer_fwd_kernel");
-  sage_layer_fwd_kernel<<<n_gemm + ro_gx * (unsigned)B, 256, lds, stream>>>(ga, sa, n_gemm, ro_gx, K / 4, packed);
+  if (packed_out) {
+    TSGNN_KNAME("sage_layer_fwd_kernel<true>");
+    sage_layer_fwd_kernel<true><<<n_gemm + ro_gx * (unsigned)B, 256, lds, stream>>>(ga, sa, n_gemm, ro_gx, K / 4, packed);
+  } else {
+    TSGNN_KNAME("sage_layer_fwd_kernel<false>");
+    sage_layer_fwd_kernel<false><<<n_gemm + ro_gx * (unsigned)B, 256, lds, stream>>>(ga, sa, n_gemm, ro_gx, K / 4, packed);
+  }
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
+}
+
+int tsgnn_sage_layer_fwd_f32(const int* ell, int ell_w, const int* tail_ptr, const int* tail_col, const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias,
+                             float* v, int64_t ldv, float* rinv, float* zout, int64_t ldz, int64_t rows, int K, int64_t fill_rows,
+                             const int* graph_ptr, int B, int nslots, int n_ghost, unsigned long long* packed, tsgnn_stream_t stream) {
+  return tsgnn_sage_layer_fwd_ro_f32(ell, ell_w, tail_ptr, tail_col, x, ldx, w, ldw, bias, v, ldv, rinv, zout, ldz, rows, K, fill_rows,
+                                     graph_ptr, B, nslots, n_ghost, packed, nullptr, nullptr, stream);
 }
 
 }  // extern "C"

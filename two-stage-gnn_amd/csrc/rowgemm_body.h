@@ -27,7 +27,17 @@ struct RowGemmArgs {
   const int* ell; int ell_w;
   float* zout; int64_t ldz;
   const int* tail_ptr; const int* tail_col;   // nullable: CSR of the neighbours beyond ell_w (rows with longer lists)
+  // READOUT variant (epilogue): the per-graph column maxima of the OUTPUT rows are folded into ro_packed[B, N] as packed
+  // (ordered value, ~row) 64-bit atomicMax, the arg-max readout of encoders.py:183 without a pass of its own; the filler
+  // block adds every graph's first ghost row (row rows + size_b; all ghost rows of this layer carry the same value).
+  unsigned long long* ro_packed;              // nullable
+  const int* ro_graph_ptr; const int* ro_row_graph;
+  int ro_B, ro_nslots, ro_nghost;
 };
+
+__device__ __forceinline__ unsigned long long rg_pack_max(float val, unsigned r) {      // = pack_max of readout_body.h
+  return ((unsigned long long)f32_ordered(val) << 32) | (unsigned long long)(0xFFFFFFFFu - r);
+}
 
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
@@ -41,9 +51,10 @@ constexpr int LDA_F = 128;            // row stride of the gathered full-K A pan
 // epilogue), so a CU idles through every memory wait; with two wave groups the gather prologue is shared by twice the
 // lanes (half the rows per lane), each group runs half of the K chunks on its own LDS stages while the other group's
 // waits are covered, and group 1 hands its accumulators to group 0 through LDS before the (unchanged) epilogue.
-template <int NT, bool TRANS_B, bool GATHER, int KS = 1>
+template <int NT, bool TRANS_B, bool GATHER, int KS = 1, bool READOUT = false>
 __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem_all, unsigned bid) {
   static_assert(KS == 1 || (KS == 2 && GATHER && NT <= 4), "the split-K variant is built for the gather kernel, widths <= 128");
+  static_assert(!READOUT || (NT <= 4 && KS == 1), "the readout epilogue is built for one column tile per wave");
   constexpr int NP = 32 * NT;
   constexpr int TPW = (NT + 3) / 4;
   constexpr int BV = NT;                               // float4 of B per thread per chunk (KC * NP / 1024)
@@ -90,8 +101,28 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem_a
         *reinterpret_cast<float4*>(g.c + (g.rows + r) * g.ldc + 4 * c4) = out;
         if (g.rinv && c4 == 0) g.rinv[g.rows + r] = sc;
       }
+      if constexpr (READOUT) {
+        if (g.ro_packed && g.ro_nghost) {                // every graph's first ghost row takes part in its readout
+          for (int b = rsub; b < g.ro_B; b += rpp) {
+            const int sz = g.ro_graph_ptr[b + 1] - g.ro_graph_ptr[b];
+            if (sz < g.ro_nslots && sz < g.fill_rows) {
+              const unsigned row = (unsigned)(g.rows + sz);
+              unsigned long long* dst = g.ro_packed + (int64_t)b * g.N + 4 * c4;
+              atomicMax(dst + 0, rg_pack_max(out.x, row)); atomicMax(dst + 1, rg_pack_max(out.y, row));
+              atomicMax(dst + 2, rg_pack_max(out.z, row)); atomicMax(dst + 3, rg_pack_max(out.w, row));
+            }
+          }
+        }
+      }
     }
     return;
+  }
+  int ro_gf = 0, ro_gl = 0;                            // READOUT: first / last graph of this panel (loaded early, used last)
+  if constexpr (READOUT) {
+    if (g.ro_packed) {
+      ro_gf = g.ro_row_graph[m0];
+      ro_gl = g.ro_row_graph[min(m0 + 31, g.rows - 1)];
+    }
   }
 
   // staging maps (computed once) ------------------------------------------------------------------
@@ -421,6 +452,32 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem_a
           const int64_t gm = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
           if (gm < g.rows && cn < g.N) cp[(int64_t)((r & 3) + 8 * (r >> 2)) * g.ldc] = acc[t][r] * scale[r];
         }
+      }
+    }
+  }
+  if constexpr (READOUT) {
+    if (g.ro_packed) {
+      // lane (i, h) of wave `wid` holds column cn of 16 of the panel's rows: fold them per graph, meet the other half of
+      // the wave, one 64-bit atomicMax per (graph, column) and panel.  Values are the stored ones (acc * scale), so the
+      // readout is bitwise what a pass over c would find; ties go to the smallest row (~row in the low word).
+      const int cn = wid * 32 + i;
+      const int64_t last = min(m0 + 31, g.rows - 1);
+      for (int b = ro_gf; b <= ro_gl; ++b) {
+        int64_t lo = m0, hi = last + 1;
+        if (ro_gf != ro_gl) { lo = max(lo, (int64_t)g.ro_graph_ptr[b]); hi = min(hi, (int64_t)g.ro_graph_ptr[b + 1]); }
+        unsigned long long best = 0ull;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t gm = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (gm >= lo && gm < hi) {
+            const unsigned long long p = rg_pack_max(acc[0][r] * scale[r], (unsigned)gm);
+            best = p > best ? p : best;
+          }
+        }
+        const unsigned olo = __shfl_xor((unsigned)(best & 0xFFFFFFFFull), 32, 64), ohi = __shfl_xor((unsigned)(best >> 32), 32, 64);
+        const unsigned long long other = ((unsigned long long)ohi << 32) | olo;
+        best = other > best ? other : best;
+        if (h == 0 && best && cn < g.N) atomicMax(&g.ro_packed[(int64_t)b * g.N + cn], best);
       }
     }
   }

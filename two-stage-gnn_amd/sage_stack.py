@@ -53,6 +53,7 @@ MERGED_FWD = os.environ.get("TSGNN_MERGED_FWD", "1") != "0"        # a layer's p
 MERGED_BWD = os.environ.get("TSGNN_MERGED_BWD", "1") != "0"        # weight-gradient slabs + input-gradient product in one launch
 GATHER_MAX_ROWS = int(os.environ.get("TSGNN_GATHER_MAX_ROWS", 65536))   # above: stand-alone row-batched aggregation + lean product
 GATHER_FUSED = os.environ.get("TSGNN_GATHER_FUSED", "1") != "0"     # aggregate inside the `.W` product when the neighbour table has no CSR tail
+EPILOGUE_READOUT = os.environ.get("TSGNN_EPILOGUE_READOUT", "1") != "0"   # the last layer's max readout in its product's epilogue
 
 
 def _gather_ok(g, x):
@@ -104,6 +105,7 @@ class _SageStack(torch.autograd.Function):
         off = 0
         pending_ro = None
         keep = []
+        last_ro_done = False
         for l in range(L):
             K, N = Ws[l].size(0), Ws[l].size(1)
             if nodes and l == L - 1:
@@ -122,8 +124,16 @@ class _SageStack(torch.autograd.Function):
                 ell, ell_w, tail = g.ell()
                 tp, tc = tail if tail is not None else (None, None)
                 z = torch.empty(R, x.size(1), dtype=torch.float32, device=dev)
-                nat.call("sage_layer_fwd_f32", ell, ell_w, tp, tc, x, x.stride(0), Ws[l], Ws[l].stride(0), bs[l], v, v.stride(0), rinv,
-                         z, z.stride(0), g.n_rows, K, gs, g.graph_ptr, B, sn, sg, pending_ro[1])
+                if EPILOGUE_READOUT and l == L - 1 and not nodes and l > 0 and (not g.n_ghost or gs > 0):
+                    # last layer: no slot batch-norm follows, so its own max readout is folded into the product's epilogue
+                    # (packed was cleared by layer 0's slot_bn_fwd launch): no pass over v for it
+                    nat.call("sage_layer_fwd_ro_f32", ell, ell_w, tp, tc, x, x.stride(0), Ws[l], Ws[l].stride(0), bs[l], v, v.stride(0),
+                             rinv, z, z.stride(0), g.n_rows, K, gs, g.graph_ptr, B, sn, sg, pending_ro[1],
+                             packed[off:off + B * N], g.row_graph)
+                    last_ro_done = True
+                else:
+                    nat.call("sage_layer_fwd_f32", ell, ell_w, tp, tc, x, x.stride(0), Ws[l], Ws[l].stride(0), bs[l], v, v.stride(0), rinv,
+                             z, z.stride(0), g.n_rows, K, gs, g.graph_ptr, B, sn, sg, pending_ro[1])
                 pending_ro = None
             elif fused:
                 _flush_readout(g, B, sn, sg, pending_ro)
@@ -164,7 +174,7 @@ class _SageStack(torch.autograd.Function):
                 x = y
             else:
                 mean = rstd = None
-                if head is None and not nodes:
+                if head is None and not nodes and not last_ro_done:
                     nat.call("readout_partial_f32", g.graph_ptr, B, sn, g.n_rows, sg, v, v.stride(0), N, pk)
             saved.append((z, v, rinv, mean, rstd, lean))
             off += B * N
@@ -196,8 +206,12 @@ class _SageStack(torch.autograd.Function):
         vec = torch.empty(B, E, dtype=torch.float32, device=dev)
         y = torch.empty(B, C, dtype=torch.float32, device=dev)
         v_last = saved[-1][1]
-        nat.call("readout_head_fwd_f32", packed, B, L, Fh, Fl, v_last, v_last.stride(0), g.graph_ptr, g.n_rows, sn, sg, out,
-                 out.stride(0), arg, w1c, b1, w2c, b2, E, C, vec, y)
+        if last_ro_done and E <= 128 and out.size(1) <= 2048:
+            # every layer's maxima are in `packed`: decode + both Linear layers, one memory round trip per block
+            nat.call("packed_head_fwd_f32", packed, B, L, Fh, Fl, out, out.stride(0), arg, w1c, b1, w2c, b2, E, C, vec, y)
+        else:
+            nat.call("readout_head_fwd_f32", packed, B, L, Fh, Fl, v_last, v_last.stride(0), g.graph_ptr, g.n_rows, sn, sg, out,
+                     out.stride(0), arg, w1c, b1, w2c, b2, E, C, vec, y)
         ctx.head = (out, vec, w1c, w2c, head)
         ctx.set_materialize_grads(False)
         return vec, y
