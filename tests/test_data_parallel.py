@@ -164,7 +164,9 @@ def _gpu_worker(rank, world, port, q):
 
 def _rccl_one_rank_worker(port, q):
     """one-rank RCCL group (RCCL refuses two ranks on one device): the N > 1 step as two hipGraphs around an eager all-reduce,
-    and as ONE hipGraph with the collective captured (TSGNN_GRAPH_ALLREDUCE=1), must leave identical parameters"""
+    as ONE hipGraph with the collective captured (TSGNN_GRAPH_ALLREDUCE=1), as the self-checked one-graph step (auto, the
+    default), with the head's gradient bucket all-reduced on a side branch (buckets=2), and eagerly with that overlap, must all
+    leave identical parameters"""
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
@@ -178,17 +180,20 @@ def _rccl_one_rank_worker(port, q):
     hb = synthetic.host_batch(seed=3, B=8, shape="DD", nmax=400)
     g, x, label = synthetic.to_device(hb, torch.device("cuda"))
     out = []
-    for one_graph in ("0", "1"):
+    for one_graph, buckets in (("0", 1), ("1", 1), ("auto", 1), ("1", 2), ("eager", 2)):
         os.environ["TSGNN_GRAPH_ALLREDUCE"] = one_graph
         torch.manual_seed(5)
         model = E.GcnEncoderGraph(89, 128, 128, 2, 3, bn=True, args=A(), final_dim="number_classes").cuda()
-        tr = FlatTrainer(model, lr=1e-2, clip=2.0)
+        tr = FlatTrainer(model, lr=1e-2, clip=2.0, buckets=buckets)
         tr.always_reduce = True
-        gs = GraphedStep(tr, lambda: model.loss(model(x, g)[1], label), warmup=2)
-        assert gs.multi and gs.one_graph == (one_graph == "1")
+        gs = GraphedStep(tr, lambda: model.loss(model(x, g)[1], label), warmup=2, use_graph=one_graph != "eager")
+        assert gs.multi and gs.one_graph == (one_graph in ("1", "auto")), gs.describe()
         for _ in range(3):
             gs.step()
         torch.cuda.synchronize()
+        if buckets == 2:
+            # the head's gradients (the tail of the flat buffer) went through the side-stream all-reduce
+            assert tr._early is not None and tr._early[1] - tr._early[0] >= 128 * 384, tr._early
         out.append((tr.flat_param.detach().cpu().numpy(), float(tr.state[0])))
     q.put(out)
     dist.destroy_process_group()
@@ -203,8 +208,9 @@ def test_one_graph_allreduce_step_equals_two_graph_step():
     out = q.get(timeout=240)
     p.join(60)
     assert p.exitcode == 0
-    assert out[0][1] == out[1][1] == 3.0
-    np.testing.assert_array_equal(out[0][0], out[1][0])
+    for o in out:                                             # two graphs == one graph == checked one graph == 2 buckets == eager
+        assert o[1] == 3.0
+        np.testing.assert_array_equal(out[0][0], o[0])
 
 
 @pytest.mark.gpu
@@ -528,3 +534,51 @@ def test_selfnorm_optimiser_sizes_and_replay():
         assert float(state[0]) == 3.0 and float(state[3]) == 0.0
         torch.testing.assert_close(float(state[1]), float((grads[-1] * 0.5).norm()), rtol=1e-5, atol=0)
         torch.testing.assert_close(p, ref.detach(), rtol=2e-5, atol=2e-6)
+
+
+def _fallback_worker(rank, port, q):
+    """gloo collectives cannot be captured: with TSGNN_ONE_GRAPH_ANY_BACKEND=1 the auto mode tries anyway, the capture is
+    invalidated, and GraphedStep must carry on (fresh stream, two graphs) with the trainer's state intact"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TSGNN_ONE_GRAPH_ANY_BACKEND="1", TSGNN_GRAPH_ALLREDUCE="auto")
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    torch.cuda.set_device(0)
+    from two_stage_gnn_amd import dense_encoders as E, synthetic
+    from two_stage_gnn_amd.data_parallel import FlatTrainer, GraphedStep
+
+    class A:
+        bias = True
+    hb = synthetic.host_batch(seed=rank, B=6, shape="DD", nmax=400)
+    g, x, label = synthetic.to_device(hb, torch.device("cuda"))
+    finals = []
+    for use_graph in (True, False):
+        torch.manual_seed(1)
+        m = E.GcnEncoderGraph(89, 128, 128, 2, 3, bn=True, args=A(), final_dim="number_classes").cuda()
+        tr = FlatTrainer(m, lr=1e-3, clip=2.0)
+        gs = GraphedStep(tr, lambda: m.loss(m(x, g)[1], label), warmup=2, use_graph=use_graph)
+        for _ in range(3):
+            gs.step()
+        torch.cuda.synchronize()
+        finals.append((tr.flat_param.detach().cpu().numpy(), float(tr.state[0]), gs.describe()))
+    q.put((rank, finals))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_failed_collective_capture_falls_back_to_two_graphs():
+    ctx = mp_.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 311) % 2000
+    procs = [ctx.Process(target=_fallback_worker, args=(r, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, ((p_graph, n_graph, note), (p_eager, n_eager, _)) in res:
+        assert "fell back" in note and "two graphs" in note, note
+        assert n_graph == n_eager == 3.0
+        np.testing.assert_array_equal(p_graph, p_eager)            # the fall-back step == the eager step, state untouched by the attempt
+    np.testing.assert_array_equal(res[0][1][0][0], res[1][1][0][0])    # replicas identical

@@ -22,8 +22,13 @@ class FlatTrainer:
     parameter buffer, so the HIP optimiser kernel updates the model in place."""
 
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip=2.0, group=None, direct_grads=True,
-                 defer_loss=False):
+                 defer_loss=False, buckets=None):
         self.model = model
+        # buckets = 2: the gradients that are final EARLY in the backward (the fused stack reports its head's gradients right
+        # after the first backward launch: 49 k of the 94 k floats of the SAGE-3L model) are all-reduced on a side stream while
+        # the rest of the backward runs; the remainder follows in all_reduce().  Takes effect where the collective can overlap:
+        # eager steps and the one-graph step (parallel branch of the hipGraph); the two-graph step keeps one bucket.
+        self.buckets = int(os.environ.get("TSGNN_AR_BUCKETS", 1)) if buckets is None else int(buckets)
         # defer_loss: a cross-entropy computed between zero_grad() and backward() on the fused stack's logits launches nothing;
         # the head's backward kernel rebuilds its gradient and fills in the loss value (one launch less per step).  The loss
         # tensor then holds its value only after backward() — what step() / GraphedStep return.
@@ -74,13 +79,51 @@ class FlatTrainer:
             self.sink.norm_parts = torch.zeros(4096, dtype=torch.float32, device=dev)
             self.sink.step_state = self.state
         self.always_reduce = False          # issue the collective even in a one-rank group (single-GPU rehearsal of the N > 1 path)
+        self._early = None                  # (start, end) of the early bucket, learnt from the first backward that reports one
+        self._early_issued = False
+        self._allow_early = True            # cleared by GraphedStep while it captures the two-graph step
+        self._side = torch.cuda.Stream() if (self.on_gpu and self.buckets > 1) else None
+
+    # ------------------------------------------------------------------ early bucket (overlapped all-reduce)
+    def _reducing(self):
+        return (self.world > 1 or self.always_reduce) and dist.is_available() and dist.is_initialized()
+
+    def _range_of(self, params):
+        """(start, end) of the flat buffer covered by `params` if they form one contiguous run of it (padding included)"""
+        ptrs = {q.data_ptr() for q in params}
+        idx = sorted(i for i, p in enumerate(self.params) if p.data_ptr() in ptrs)
+        if not idx or idx != list(range(idx[0], idx[-1] + 1)):
+            return None
+        start = self.views[idx[0]][0] - self._pads[idx[0]]
+        last = idx[-1]
+        end = self.numel if last == len(self.params) - 1 else self.views[last + 1][0] - self._pads[last + 1]
+        return start, end
+
+    def _on_ready(self, params):
+        """called by a fused backward node right after the launch that finalised the gradients of `params` (on the compute
+        stream, possibly under hipGraph capture): fork, all-reduce their range on the side stream"""
+        if self._early_issued or not self._allow_early or self._side is None or not self._reducing():
+            return
+        rng = self._range_of([p for p in params if p is not None])
+        if rng is None or rng[1] - rng[0] <= 0:
+            return
+        if self._early is None:
+            self._early = rng
+        elif rng != self._early:
+            return
+        self._side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._side):
+            dist.all_reduce(self.flat_grad[rng[0]:rng[1]], op=dist.ReduceOp.SUM, group=self.group)
+        self._early_issued = True
 
     def zero_grad(self):
         for p in self.params:
             p.grad = None
         self._norm_ready = False
+        self._early_issued = False
         mp.CE_DEFER = self.defer_loss and self.on_gpu
         if self.sink is not None:
+            self.sink.ready_cb = self._on_ready if (self._side is not None and self._reducing()) else None
             self.sink.written.clear()
             self.sink.reset_norm()
             self.sink.norm_enabled = self.world == 1 and not self.always_reduce     # local shares only describe a local gradient
@@ -114,7 +157,14 @@ class FlatTrainer:
         for i, (p, (o, n)) in enumerate(zip(self.params, self.views)):
             direct = p.data_ptr() in written
             if p.grad is not None:
-                if direct:
+                if direct and self._early_issued and self._early[0] <= o < self._early[1]:
+                    # this slice is already being summed over the ranks: the late contribution is summed separately (the
+                    # all-reduce is linear) and joins it after the side stream
+                    extra = p.grad.reshape(-1).contiguous()
+                    dist.all_reduce(extra, op=dist.ReduceOp.SUM, group=self.group)
+                    torch.cuda.current_stream().wait_stream(self._side)
+                    self.flat_grad[o:o + n].add_(extra)
+                elif direct:
                     self.flat_grad[o:o + n].add_(p.grad.reshape(-1))       # used by a sink node AND an ordinary op
                 else:
                     self.flat_grad[o:o + n].copy_(p.grad.reshape(-1))
@@ -129,6 +179,13 @@ class FlatTrainer:
     def all_reduce(self):
         """SUM over ranks on the flat bucket; the 1/world factor is applied inside the optimiser kernel."""
         if self.world > 1 or self.always_reduce:
+            if self._early_issued:
+                a, b = self._early
+                for s_, e_ in ((0, a), (b, self.numel)):
+                    if e_ > s_:
+                        dist.all_reduce(self.flat_grad[s_:e_], op=dist.ReduceOp.SUM, group=self.group)
+                torch.cuda.current_stream().wait_stream(self._side)        # join: the optimiser needs both buckets
+                return
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
 
     def apply(self):
@@ -194,29 +251,119 @@ class GraphedStep:
                 dist.barrier(group=trainer.group)                  # no collective in flight while capturing
                 torch.cuda.synchronize()
             mode = {"capture_error_mode": "thread_local"} if self.multi else {}
-            # TSGNN_GRAPH_ALLREDUCE=1 (opt-in, to be validated on a multi-GPU box): the collective is captured too and the
-            # N > 1 step is ONE graph; RCCL's all-reduce captures and replays correctly in a one-rank group on this stack
-            self.one_graph = self.multi and os.environ.get("TSGNN_GRAPH_ALLREDUCE") == "1"
-            self._fb = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._fb, stream=self.stream, **mode):
+            # N > 1: TSGNN_GRAPH_ALLREDUCE = 1: the collective is captured too, the step is ONE graph (no graph boundary either
+            # side of the all-reduce: 0.156 vs 0.1715 ms in the one-rank rehearsal of round 1); 0: two graphs around an eagerly
+            # issued all-reduce; auto (default): capture the one-graph step, CHECK it — one replay from a snapshot must leave
+            # the parameters the eager sequence leaves, on every rank (agreement by an eager MIN all-reduce) — and fall back
+            # to two graphs otherwise.
+            want = os.environ.get("TSGNN_GRAPH_ALLREDUCE", "auto") if self.multi else "0"
+            self.mode_note = ""
+            if want == "auto" and self.multi and dist.is_initialized() and dist.get_backend(trainer.group) != "nccl" \
+                    and os.environ.get("TSGNN_ONE_GRAPH_ANY_BACKEND") != "1":
+                want = "0"                  # gloo moves the data through the host: its collectives cannot be captured
+            broken = False
+            if self.multi and want != "0":
+                ok, broken = self._try_one_graph(mode, verify=(want != "1"))
+                if not ok:
+                    self._fb = None
+                    self.mode_note = " (one-graph step failed its %s: fell back)" % ("capture" if broken else "check")
+                self.one_graph = ok
+            if self._fb is None and not broken:
+                self._capture_two(mode)
+        if broken and want == "1":
+            raise RuntimeError("TSGNN_GRAPH_ALLREDUCE=1: the all-reduce could not be captured into the step's hipGraph; "
+                               "use TSGNN_GRAPH_ALLREDUCE=auto (checked, falls back) or 0 (two graphs)")
+        if broken:
+            # A capture that was invalidated half-way leaves its stream unusable on this stack (every later call on it reports
+            # hipErrorStreamCaptureInvalidated): carry on with a fresh stream.
+            self.stream = torch.cuda.Stream()
+            with torch.cuda.stream(self.stream):
+                for _ in range(4):                                   # the runtime's sticky "last error" is reported once more
+                    try:
+                        torch.cuda.synchronize()
+                        break
+                    except Exception:                                # noqa: BLE001
+                        pass
+                for t, s_ in zip(self._bufs(), self._snap):
+                    t.copy_(s_)
+                torch.cuda.synchronize()
+                self._agree(False)
+                self._capture_two(mode)
+        self._snap = None
+
+    def _bufs(self):
+        tr = self.trainer
+        return tr.flat_param, tr.exp_avg, tr.exp_avg_sq, tr.state
+
+    def _agree(self, ok):
+        """every rank takes the same decision about the one-graph step (eager MIN all-reduce of the local verdicts)"""
+        tr = self.trainer
+        if dist.is_initialized():
+            flag = torch.tensor([1.0 if ok else 0.0], device=tr.flat_param.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=tr.group)
+            ok = bool(flag.item() > 0.5)
+            torch.cuda.synchronize()
+        return ok
+
+    def _capture_two(self, mode):
+        trainer = self.trainer
+        trainer._allow_early = not self.multi                # a fork inside the first of two graphs could not be joined
+        self._fb = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._fb, stream=self.stream, **mode):
+            self._fwd_bwd()
+            if not self.multi:
+                trainer.apply()
+        if self.multi:
+            self._opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._opt, stream=self.stream, **mode):
+                trainer.apply()
+
+    def _try_one_graph(self, mode, verify):
+        """capture forward + backward + bucket + all-reduce + optimiser as ONE graph; verify=True: replay it once from a
+        snapshot and compare with the eager sequence from the same snapshot, agree across ranks.  Leaves the trainer's state as
+        it found it.  -> (installed in self._fb, capture raised: the stream must be abandoned)"""
+        tr = self.trainer
+        bufs = self._bufs()
+        self._snap = snap = [t.clone() for t in bufs]
+        ok = True
+        graph = torch.cuda.CUDAGraph()
+        try:
+            tr._allow_early = True
+            with torch.cuda.graph(graph, stream=self.stream, **mode):
                 self._fwd_bwd()
-                if self.one_graph:
-                    trainer.all_reduce()
-                if not self.multi or self.one_graph:
-                    trainer.apply()
-            if self.multi and not self.one_graph:
-                self._opt = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self._opt, stream=self.stream, **mode):
-                    trainer.apply()
+                tr.all_reduce()
+                tr.apply()
+        except Exception as e:                                  # noqa: BLE001 - any capture failure selects the two-graph step
+            print("GraphedStep: one-graph capture failed (%s: %s)" % (type(e).__name__, str(e).splitlines()[0]), flush=True)
+            return False, True
+        if verify:
+            graph.replay()
+            torch.cuda.synchronize()
+            got = tr.flat_param.clone()
+            for t, s_ in zip(bufs, snap):
+                t.copy_(s_)
+            self._fwd_bwd(); tr.all_reduce(); tr.apply()
+            torch.cuda.synchronize()
+            scale = float(tr.flat_param.abs().max()) + 1e-30
+            ok = bool(torch.isfinite(got).all()) and float((got - tr.flat_param).abs().max()) <= 1e-5 * scale
+        for t, s_ in zip(bufs, snap):
+            t.copy_(s_)
+        torch.cuda.synchronize()
+        if verify:
+            ok = self._agree(ok)
+        if ok:
+            self._fb = graph
+        return ok, False
 
     def describe(self):
         if not self.use_graph:
             return "eager"
         if not self.multi:
             return "one graph: forward + backward + bucket + optimiser"
+        bk = ", early bucket [%d, %d) all-reduced on a side branch" % self.trainer._early if self.trainer._early else ""
         if self.one_graph:
-            return "one graph incl. the captured all-reduce"
-        return "two graphs around the eagerly issued all-reduce"
+            return "one graph incl. the captured all-reduce" + bk
+        return "two graphs around the eagerly issued all-reduce" + getattr(self, "mode_note", "")
 
     def _fwd_bwd(self):
         tr = self.trainer

@@ -700,7 +700,14 @@ class GradSink:
         self.norm_parts = None      # float32[capacity]
         self.step_state = None
         self.norm_enabled = False   # set per step by the trainer (single GPU only)
+        self.ready_cb = None        # trainer hook: called with the parameters whose gradients a launch just finalised
         self.reset_norm()
+
+    def ready(self, params):
+        """a fused backward node reports: the launch just issued on the current stream finalised the gradients of `params`
+        (all of them written through the sink) — lets the data-parallel trainer start their all-reduce early"""
+        if self.ready_cb is not None:
+            self.ready_cb(params)
 
     def reset_norm(self):
         self.norm_used = 0

@@ -249,6 +249,8 @@ class _SageStack(torch.autograd.Function):
                 nat.call("head2_bwd_f32", out, out.stride(0), vec, dy, dvec, w1c, w2c, B, P, E, C, dout, dout.stride(0), dw1, db1, dw2,
                          db2, parts)
             head_grads = (None if s1 else dw1, None if s3 else db1, None if s2 else dw2, None if s4 else db2)
+            if mp.GRAD_SINK is not None and s1 and s2 and (s3 or pb1 is None) and (s4 or pb2 is None):
+                mp.GRAD_SINK.ready((pw1, pb1, pw2, pb2))       # final already: their all-reduce may overlap the conv backward
         sn, sg = ctx.slots
         grads = [None] * (2 * L)
         dxs = None
