@@ -31,13 +31,17 @@ def burst_us(fn, iters):
 st = torch.cuda.Stream()
 with torch.cuda.stream(st):
     for B in (32, 256, 2048, 8192):
-        hb = synthetic.host_batch(100 + B, B, "DD", 1000)
-        g, _, _ = synthetic.to_device(hb, dev)
+        hb = synthetic.tiled_batch(100 + B, B, "DD", 1000)
+        g = synthetic.structure_to_device(hb, dev)
         R, n = g.total_rows, g.n_rows
         X = torch.randn(R, H, device=dev); V = torch.empty_like(X); rinv = torch.empty(R, device=dev)
         W = torch.randn(H, H, device=dev) * 0.1; b = torch.randn(H, device=dev)
         us = burst_us(lambda: nat.call("rowgemm_f32", X, H, W, H, 0, b, V, H, rinv, n, H, H, 1, 0), 100 if B <= 256 else 20)
         flops = 2.0 * n * H * H
         nbytes = 2 * 4 * n * H + 4 * H * H + 4 * n
-        print("rowgemm   B=%5d rows=%8d: %9.2f us  %6.1f TF (%.2f of 157.3)  %6.0f GB/s (%.2f of 8000)" % (
-            B, n, us, flops / us / 1e6, flops / us / 1e6 / 157.3, nbytes / us / 1e3, nbytes / us / 1e3 / 8000))
+        print("rowgemm   B=%5d rows=%8d: %9.2f us  %6.1f TF (%.2f of 157.3)  %6.0f GB/s (%.2f of 8000)  %s" % (
+            B, n, us, flops / us / 1e6, flops / us / 1e6 / 157.3, nbytes / us / 1e3, nbytes / us / 1e3 / 8000, nat.last_kernel()))
+        Wt = W.t().contiguous()
+        us = burst_us(lambda: nat.call("rowgemm_f32", X, H, Wt, H, 1, None, V, H, None, n, H, H, 0, 0), 100 if B <= 256 else 20)
+        print("  dZ=dU.W^T          rows=%8d: %9.2f us  %6.1f TF (%.2f of 157.3)  %s" % (n, us, flops / us / 1e6, flops / us / 1e6 / 157.3,
+                                                                                      nat.last_kernel()))

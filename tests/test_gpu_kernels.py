@@ -448,3 +448,43 @@ def test_mlp3_head_matches_torch(B, D0, D1, D2, C, p):
     for a, b in zip(lins, ref_lins):
         torch.testing.assert_close(a.weight.grad.cpu(), b.weight.grad, rtol=1e-4, atol=1e-5)
         torch.testing.assert_close(a.bias.grad.cpu(), b.bias.grad, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("K,ld,N,trans_b,normalize,fill", [(128, 128, 128, False, 1, 37), (89, 92, 128, False, 1, 0), (128, 128, 64, False, 0, 0),
+                                                            (128, 128, 128, True, 0, 0), (64, 64, 128, True, 0, 0), (40, 40, 96, False, 1, 5)])
+def test_rowgemm_large_batch_kernel_equals_row_panel_kernel(T, K, ld, N, trans_b, normalize, fill):
+    """the B-stationary persistent kernel that tsgnn_rowgemm_f32 dispatches from 49,152 rows (rowgemm_big_body.h: W slice in
+    registers for the whole K, double-buffered A panels, one barrier per panel) against the row-panel kernel: rows are
+    independent, so the same call on two pieces below the threshold must give the same bits — incl. a partial last panel, a
+    padded K, narrow N, the transposed operand, bias + L2 normalise + rinv, ghost fill rows — and a torch product agrees."""
+    from two_stage_gnn_amd import _native as nat
+    R = 50000 + 13                                       # > threshold, partial last panel
+    gen = torch.Generator().manual_seed(5 + K + N)
+    a = torch.zeros(R, ld); a[:, :K] = torch.randn(R, K, generator=gen)
+    a = a.cuda()
+    w = (torch.randn(N, K, generator=gen) if trans_b else torch.randn(K, N, generator=gen)).mul_(0.2).cuda()
+    bias = None if trans_b else torch.randn(N, generator=gen).cuda()
+    out = []
+    for pieces in ([(0, R)], [(0, 32768), (32768, R)]):
+        c = torch.full((R + fill, N), float("nan"), device="cuda")
+        rinv = torch.full((R + fill,), float("nan"), device="cuda") if normalize else None
+        names = []
+        for lo, hi in pieces:
+            last = hi == R
+            nat.call("rowgemm_f32", a[lo:hi], ld, w, w.stride(0), int(trans_b), bias, c[lo:], N, rinv[lo:] if normalize else None, hi - lo, K, N,
+                     normalize, fill if last else 0)
+            names.append(nat.last_kernel())
+        out.append((c, rinv, names))
+    torch.cuda.synchronize()
+    assert out[0][2][0].startswith("rowgemm_big_kernel"), out[0][2]
+    assert all(not n.startswith("rowgemm_big_kernel") for n in out[1][2]), out[1][2]
+    assert not torch.isnan(out[0][0]).any()
+    torch.testing.assert_close(out[0][0], out[1][0], rtol=0, atol=0)
+    if normalize:
+        torch.testing.assert_close(out[0][1], out[1][1], rtol=0, atol=0)
+    ref = a[:, :K] @ (w.t() if trans_b else w)
+    if bias is not None:
+        ref = ref + bias
+    if normalize:
+        ref = torch.nn.functional.normalize(ref, p=2, dim=1)
+    torch.testing.assert_close(out[0][0][:R], ref, rtol=2e-4, atol=2e-4)

@@ -19,6 +19,7 @@
 
 #include <cstdlib>
 #include "rowgemm_body.h"
+#include "rowgemm_big_body.h"
 
 namespace {
 
@@ -80,6 +81,41 @@ inline unsigned colsplit_max_panels() {                   // TSGNN_ROWGEMM_COLSP
     return e ? (unsigned)atoi(e) : 0xFFFFFFFFu;
   }();
   return n;
+}
+
+// Large batches: the B-stationary persistent kernel (rowgemm_big_body.h).  TSGNN_ROWGEMM_BIG_ROWS sets the row count from which it
+// is used (0 disables it; A/B measurements).
+inline int64_t rowgemm_big_min_rows() {
+  static const int64_t n = [] {
+    const char* e = getenv("TSGNN_ROWGEMM_BIG_ROWS");
+    return e ? (int64_t)atoll(e) : (int64_t)49152;
+  }();
+  return n;
+}
+
+template <int U, bool TRANS_B>
+void launch_big(const RowGemmArgs& g, hipStream_t s) {
+  constexpr size_t lds = rowgemm_big_lds_bytes<U, TRANS_B>();
+  static const int bpc = [] {                           // resident blocks per CU (registers decide; LDS allows 4)
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(rowgemm_big_kernel<U, TRANS_B>), 256, lds) != hipSuccess || n < 1) n = 2;
+    return n;
+  }();
+  const unsigned npanels = (unsigned)ceil_div64(g.rows, 32);
+  unsigned grid = (unsigned)device_cu_count() * (unsigned)bpc;
+  if (grid > npanels) grid = npanels;
+  if (grid == 0) grid = 1;
+  TSGNN_KNAME("rowgemm_big_kernel<%d,%s>", U, TRANS_B ? "true" : "false");
+  rowgemm_big_kernel<U, TRANS_B><<<grid, 256, lds, s>>>(g, npanels);
+}
+
+template <bool TRANS_B>
+bool try_big(const RowGemmArgs& g, hipStream_t s) {
+  const int64_t mn = rowgemm_big_min_rows();
+  if (mn <= 0 || g.rows < mn || g.N > 128 || g.K > 128 || (TRANS_B && (g.K % 4)) || (g.N % 4)) return false;
+  if (g.K <= 96) launch_big<12, TRANS_B>(g, s);
+  else launch_big<16, TRANS_B>(g, s);
+  return true;
 }
 
 template <bool TRANS_B>
@@ -165,8 +201,8 @@ int tsgnn_rowgemm_f32(const float* a, int64_t lda, const float* b, int64_t ldb, 
     return TSGNN_EUNSUPPORTED;
   if (rows == 0 && fill_rows == 0) return TSGNN_OK;
   RowGemmArgs g{a, lda, b, ldb, bias, c, ldc, rinv, rows, K, N, normalize, fill_rows, nullptr, 0, nullptr, 0};
-  if (trans_b) { if (!try_colsplit<true>(g, stream)) dispatch_rowgemm<true, false>(g, stream); }
-  else { if (!try_colsplit<false>(g, stream)) dispatch_rowgemm<false, false>(g, stream); }
+  if (trans_b) { if (!try_big<true>(g, stream) && !try_colsplit<true>(g, stream)) dispatch_rowgemm<true, false>(g, stream); }
+  else { if (!try_big<false>(g, stream) && !try_colsplit<false>(g, stream)) dispatch_rowgemm<false, false>(g, stream); }
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }
