@@ -61,6 +61,44 @@ int tsgnn_coo_count(const int64_t* key, int64_t E, int64_t n_rows, int* cnt, int
 int tsgnn_coo_fill(const int64_t* key, const int64_t* other, int64_t E, int64_t n_rows, const int* rowptr,
                    int* cursor, int* col, int* eid, tsgnn_stream_t stream);
 
+/* ---------------------------------------------------------------- mini-batch ingest (ingest.hip)
+ *
+ * A capacity-padded packed batch: rows [0, n) real nodes (n = graph_ptr[B] <= row_cap), rows [n, row_cap) padding (no
+ * edges, row_graph = B: a dummy graph), rows [row_cap, row_cap + nmax) the ghost-slot representatives.  Every launch of the
+ * training step then has the same shape for every batch (one hipGraph serves all steps); what varies lives in ONE device
+ * buffer refreshed by ONE host->device copy.  Replaces GraphSampler.__getitem__ + default collate + the per-step .cuda() of
+ * adj[B,Nmax,Nmax] (graph_sampler.py:102-114, train.py:114-119). */
+
+/* word offsets (4-byte words) of the segments of an ingest buffer: off[0..8] = graph_ptr[B+2], slot_count[nmax],
+ * row_graph[row_cap], row_slot[row_cap], ell[(row_cap+nmax)*ell_w], tail_ptr[row_cap+nmax+1], tail_col[tail_cap],
+ * node_label[row_cap], label (int64[B]); off[9] = total words.  Every segment starts on a 16-byte boundary. */
+int tsgnn_ingest_layout(int B, int nmax, int64_t row_cap, int ell_w, int64_t tail_cap, int64_t* off);
+/* HOST function (no GPU work, no stream): collate graphs ids[0..B) of a dataset held as one CSR over re-labelled nodes
+ * (ds_graph_ptr[G+1], ds_rowptr[N+1], ds_col[nnz] dataset node ids, ds_node_label[N] nullable, ds_graph_label[G]) into
+ * `staging` (host memory, tsgnn_ingest_layout words) in device layout.  out[0..3] = real rows, directed edges, tail entries,
+ * largest graph.  TSGNN_EUNSUPPORTED: a graph over nmax nodes, rows over row_cap, tail over tail_cap. */
+int tsgnn_host_collate_tu(const int64_t* ds_graph_ptr, const int64_t* ds_rowptr, const int64_t* ds_col, const int64_t* ds_node_label,
+                          const int64_t* ds_graph_label, const int64_t* ids, int B, int nmax, int64_t row_cap, int ell_w,
+                          int64_t tail_cap, int32_t* staging, int64_t* out);
+/* x[r, :] = one-hot(label[r]) (r < n_rows), 0 for n_rows <= r < total_rows: the "node-label" input features of
+ * train.py:227-231 built on the device from 4 bytes per node. */
+int tsgnn_onehot_rows_f32(const int* label, int64_t n_rows, int64_t total_rows, int F, float* x, int64_t ldx, tsgnn_stream_t stream);
+
+/* staging -> device (ONE asynchronous copy of `words` 4-byte words; pinned host memory) + tsgnn_onehot_rows_f32, on `stream` */
+int tsgnn_ingest_upload_f32(int32_t* dev, const int32_t* host, int64_t words, const int* node_label_dev, int64_t n_rows, int64_t total_rows,
+                            int F, float* x, int64_t ldx, tsgnn_stream_t stream);
+/* Collate workers: native threads that run tsgnn_host_collate_tu for the batches ahead of the step being enqueued.  submit:
+ * the arguments of tsgnn_host_collate_tu (`ids`, `out` must stay valid until waited for) + after_event (nullable hipEvent_t:
+ * the worker synchronises with it before writing `staging`); wait: blocks, returns the collate's status. */
+typedef struct tsgnn_collate_pool tsgnn_collate_pool;
+int tsgnn_collate_pool_create(int nthreads, tsgnn_collate_pool** pool);
+int tsgnn_collate_pool_submit(tsgnn_collate_pool* pool, const int64_t* ds_graph_ptr, const int64_t* ds_rowptr, const int64_t* ds_col,
+                              const int64_t* ds_node_label, const int64_t* ds_graph_label, const int64_t* ids, int B, int nmax,
+                              int64_t row_cap, int ell_w, int64_t tail_cap, int32_t* staging, int64_t* out, void* after_event,
+                              int64_t* ticket);
+int tsgnn_collate_pool_wait(tsgnn_collate_pool* pool, int64_t ticket);
+int tsgnn_collate_pool_destroy(tsgnn_collate_pool* pool);
+
 /* CSR transpose (A^T for dX = A^T dY); rows of the result sorted by column; src_e[p] = source entry */
 int tsgnn_csr_transpose(const int* rowptr, const int* col, const float* val, int64_t n_rows, int64_t n_cols,
                         int64_t nnz, int* rowptr_t, int* col_t, float* val_t, int* src_e, int* cnt_ws,

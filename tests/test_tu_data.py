@@ -162,3 +162,110 @@ def test_sag_plan_sizes_follow_pyg_topk():
             perm = P.topk(torch.arange(int(cur.sum()), dtype=torch.float32), ratio, batch)     # the oracle's per-graph k
             cur = np.bincount(batch[perm].numpy(), minlength=len(sizes))
     assert SagPlan.get(sizes, 0.5, torch.device("cpu"), depth=3) is SagPlan.get(list(sizes), 0.5, torch.device("cpu"), depth=3)
+
+
+def test_host_collate_device_layout():
+    """tsgnn_host_collate_tu (host C code, no GPU): the capacity-padded batch in device layout — graph pointers (+ the dummy
+    graph of the padding rows), slot counts, row maps, the fixed-width neighbour table with its tail, labels — against numpy on
+    a dataset with rows of more than 16 neighbours, an empty graph, and the error paths"""
+    from two_stage_gnn_amd import ingest
+    from two_stage_gnn_amd.tu_data import TUDataset
+    rng = np.random.default_rng(3)
+    sizes = np.array([5, 0, 40, 12, 23, 1, 30])
+    gp = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    rows, cols = [], []
+    for gi, n in enumerate(sizes):
+        a = (rng.random((n, n)) < (0.7 if gi == 2 else 0.2))
+        a = np.triu(a, 1); a = a | a.T
+        for r in range(n):
+            rows.append(np.flatnonzero(a[r]) + gp[gi])
+    deg = np.array([len(r) for r in rows])
+    assert deg.max() > 16
+    rowptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    col = np.concatenate(rows).astype(np.int64)
+    ds = TUDataset(gp, rowptr, col, np.array([1, 0, 1, 1, 0, 0, 1], dtype=np.int64), rng.integers(0, 9, size=int(gp[-1])).astype(np.int64), None, 9)
+    B, nmax, cap, tcap = 4, 48, 96, 512
+    ids = np.array([2, 1, 4, 0])
+    off = ingest.layout(B, nmax, cap, 16, tcap)
+    st = np.full(off[9], 12345, dtype=np.int32)
+    n, nnz, ntail, largest = ingest.host_collate(ds, ids, B, nmax, cap, st, 16, tcap)
+    bs = sizes[ids]
+    assert n == bs.sum() and largest == 40 and nnz == sum(deg[gp[i]:gp[i + 1]].sum() for i in ids)
+    g_ptr = st[off[0]:off[0] + B + 2]
+    np.testing.assert_array_equal(g_ptr, np.concatenate([[0], np.cumsum(bs), [cap]]))
+    np.testing.assert_array_equal(st[off[1]:off[1] + nmax], [(bs > s).sum() for s in range(nmax)])
+    rg, rs = st[off[2]:off[2] + cap], st[off[3]:off[3] + cap]
+    np.testing.assert_array_equal(rg[:n], np.repeat(np.arange(B), bs))
+    np.testing.assert_array_equal(rs[:n], np.concatenate([np.arange(k) for k in bs]))
+    assert (rg[n:] == B).all()                                              # padding rows: the dummy graph
+    ell = st[off[4]:off[4] + (cap + nmax) * 16].reshape(cap + nmax, 16)
+    tp, tc = st[off[5]:off[5] + cap + nmax + 1], st[off[6]:off[6] + tcap]
+    row = 0
+    for b, i in enumerate(ids):
+        for r in range(gp[i], gp[i + 1]):
+            want = col[rowptr[r]:rowptr[r + 1]] - gp[i] + g_ptr[b]
+            got = np.concatenate([ell[row][ell[row] >= 0], tc[tp[row]:tp[row + 1]]])
+            np.testing.assert_array_equal(got, want)
+            assert (ell[row][:min(len(want), 16)] >= 0).all() and (ell[row][len(want):] == -1).all()
+            row += 1
+    assert row == n and ntail == tp[-1] == sum(max(0, d - 16) for i in ids for d in deg[gp[i]:gp[i + 1]])
+    assert (ell[n:] == -1).all() and (tp[n:] == ntail).all()
+    np.testing.assert_array_equal(st[off[7]:off[7] + n], np.concatenate([ds.node_label[gp[i]:gp[i + 1]] for i in ids]))
+    np.testing.assert_array_equal(st[off[8]:off[8] + 2 * B].view(np.int64), ds.graph_label[ids])
+    # capacity / size errors
+    with pytest.raises(RuntimeError, match="not supported"):
+        ingest.host_collate(ds, ids, B, nmax, 64, st, 16, tcap)               # 75 rows do not fit 64
+    with pytest.raises(RuntimeError, match="not supported"):
+        ingest.host_collate(ds, ids, B, 32, cap, st, 16, tcap)                # a 40-node graph with nmax 32
+    with pytest.raises(RuntimeError, match="not supported"):
+        ingest.host_collate(ds, ids, B, nmax, cap, st, 16, 2)                 # tail capacity
+
+
+@pytest.mark.gpu
+def test_capacity_padded_step_equals_exact_batch():
+    """a mini-batch through the ingest slot (capacity-padded rows, dummy graph, fixed ghost-slot bound, one-hot features from the
+    uploaded labels) trains exactly like the same graphs as an exact packed batch: loss, every gradient, two optimiser steps"""
+    from two_stage_gnn_amd import dense_encoders as E, ingest
+    from two_stage_gnn_amd.data_parallel import FlatTrainer
+    from two_stage_gnn_amd.graph import GraphBatch
+    dev = torch.device("cuda")
+    ds = ingest.synthetic_dataset(seed=9, n_graphs=24, shape="DD", nmax=600)
+    ids = np.array([3, 17, 5, 11, 20, 8])
+    B, nmax, fin = len(ids), 600, ds.num_node_labels
+    n = int(ds.sizes[ids].sum())
+    slot = ingest.CapacityBatch(B, nmax, (n + 200 + 31) // 32 * 32, fin, dev, ghost_slots=int(ds.sizes.max()) + 1)
+    slot.collate(ds, ids)
+    slot.upload(torch.cuda.current_stream())
+    torch.cuda.synchronize()
+    # the same graphs as an exact batch
+    feats = ds.features("node-label")
+    g, x, y = ds.collate(ids, nmax, feats, dev)
+    torch.testing.assert_close(slot.x[:n], x[:n], rtol=0, atol=0)
+    assert float(slot.x[n:].abs().sum()) == 0.0 and torch.equal(slot.label, y)
+
+    class A:
+        bias = True
+    res = []
+    for use_slot in (False, True):
+        torch.manual_seed(2)
+        m = E.GcnEncoderGraph(fin, 128, 128, 2, 3, bn=True, args=A(), final_dim="number_classes").to(dev)
+        with torch.no_grad():
+            for k, p in m.named_parameters():
+                if k.endswith("bias") and "conv" in k:
+                    p.copy_(torch.randn_like(p) * 0.2)
+        tr = FlatTrainer(m, lr=1e-2, clip=2.0)
+        losses, grads = [], None
+        for it in range(2):
+            tr.zero_grad()
+            loss = m.loss(m(slot.x, slot.g)[1], slot.label) if use_slot else m.loss(m(x, g)[1], y)
+            tr.backward(loss)
+            tr.gather_grads()
+            if grads is None:
+                grads = tr.flat_grad.clone()
+            tr.apply()
+            losses.append(float(loss.detach()))
+        res.append((losses, grads, tr.flat_param.clone()))
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=1e-6)
+    scale = float(res[0][1].abs().max())
+    torch.testing.assert_close(res[1][1], res[0][1], rtol=0, atol=2e-5 * scale)
+    torch.testing.assert_close(res[1][2], res[0][2], rtol=1e-4, atol=1e-6)

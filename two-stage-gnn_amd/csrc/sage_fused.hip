@@ -135,6 +135,15 @@ __global__ __launch_bounds__(BT) void slot_post_bwd(SlotArgs s, const float* __r
   const int b = tid / TPR, c = tid % TPR;
   TR(0);
   if (tid == 0) first_ghost = 0x7fffffff;
+  {
+    // capacity-padded batches (ingest.hip): rows [graph_ptr[B], n_real) belong to no graph; nothing below writes their du,
+    // and the weight / bias gradients sum du over all n_real rows: they are zeroed here (no-op for exact batches)
+    const int64_t pad_lo = s.graph_ptr[s.B], npad = s.n_real - pad_lo;
+    for (int64_t i = (int64_t)blockIdx.x * BT + tid; i < npad * F4; i += (int64_t)gridDim.x * BT) {
+      const int64_t r = pad_lo + i / F4;
+      st4(du + r * lddu + 4 * (i % F4), make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+  }
   // the readout winners and their gradients depend on (graph, column) only: issued first, they fly while the row is resolved
   int4 wq[NV];
   float4 gq[NV];

@@ -86,7 +86,9 @@ class _SageStack(torch.autograd.Function):
         R, B = g.total_rows, g.B
         Fh, Fl = Ws[0].size(1), Ws[-1].size(1)
         total = B * ((L - 1) * Fh + Fl)
-        packed = torch.empty(total, dtype=torch.int64, device=dev) if not nodes else None   # cleared by the first slot_bn_fwd launch
+        # cleared by the first slot_bn_fwd launch; Fl spare words behind the last layer's segment take the readout of the dummy
+        # graph that the padding rows of a capacity-padded batch (ingest.py) belong to: never cleared, never read
+        packed = torch.empty(total + Fl, dtype=torch.int64, device=dev) if not nodes else None
         cat = torch.empty(R, (L - 1) * Fh + Fl, dtype=torch.float32, device=dev) if nodes else None
         x = mp._check(x0, R)
         # Ghost slots actually needed.  Every graph's padded rows at slots >= the largest graph are bitwise identical in
@@ -97,7 +99,9 @@ class _SageStack(torch.autograd.Function):
         if g.n_ghost > 0 and x.stride(0) % 4 == 0 and all(
                 Ws[l].size(1) % 4 == 0 and Ws[l].data_ptr() % 16 == 0 and (bs[l] is None or bs[l].data_ptr() % 16 == 0)
                 for l in range(L)):
-            gs = min(g.nmax, int(g.sizes.max()) + 1)
+            # (capacity-padded batches keep one shape for every batch: a fixed bound instead of this batch's largest graph)
+            fixed = getattr(g, "ghost_slots_fixed", None)
+            gs = min(g.nmax, (int(fixed) if fixed is not None else int(g.sizes.max()) + 1))
         if nodes == 1:
             gs = g.n_ghost                                   # unmasked node output: every ghost row is part of the result
         sn, sg = (gs, gs) if g.n_ghost else (g.nmax, 0)      # (slots, ghost rows) handed to the slot kernels
@@ -129,7 +133,7 @@ class _SageStack(torch.autograd.Function):
                     # (packed was cleared by layer 0's slot_bn_fwd launch): no pass over v for it
                     nat.call("sage_layer_fwd_ro_f32", ell, ell_w, tp, tc, x, x.stride(0), Ws[l], Ws[l].stride(0), bs[l], v, v.stride(0),
                              rinv, z, z.stride(0), g.n_rows, K, gs, g.graph_ptr, B, sn, sg, pending_ro[1],
-                             packed[off:off + B * N], g.row_graph)
+                             packed[off:off + (B + 1) * N], g.row_graph)
                     last_ro_done = True
                 else:
                     nat.call("sage_layer_fwd_f32", ell, ell_w, tp, tc, x, x.stride(0), Ws[l], Ws[l].stride(0), bs[l], v, v.stride(0), rinv,
