@@ -19,13 +19,13 @@ import torch.nn.functional as F
 
 
 # ----------------------------------------------------------------------------- GCNConv (a11)
-def gcn_norm(edge_index, num_nodes, edge_weight=None):
-    """add_remaining_self_loops(fill 1) ; deg over targets ; D^-1/2 (A+I) D^-1/2."""
+def gcn_norm(edge_index, num_nodes, edge_weight=None, improved=False):
+    """add_remaining_self_loops(fill 1, or 2 when improved) ; deg over targets ; D^-1/2 (A+I) D^-1/2."""
     row, col = edge_index[0], edge_index[1]
     if edge_weight is None:
         edge_weight = torch.ones(row.numel())
     mask = row != col
-    loop_w = torch.ones(num_nodes)
+    loop_w = torch.full((num_nodes,), 2.0 if improved else 1.0)
     loop_w[row[~mask]] = edge_weight[~mask]                 # existing self loops keep their weight
     loop = torch.arange(num_nodes)
     row = torch.cat([row[mask], loop])
@@ -37,20 +37,28 @@ def gcn_norm(edge_index, num_nodes, edge_weight=None):
     return row, col, dis[row] * w * dis[col]
 
 
-def gcn_conv(x, edge_index, weight, bias=None):
+def gcn_conv(x, edge_index, weight, bias=None, edge_weight=None, improved=False):
     """out = A_hat (x W) + b ; message flows source (edge_index[0]) -> target (edge_index[1])."""
     n = x.size(0)
-    row, col, w = gcn_norm(edge_index, n)
+    row, col, w = gcn_norm(edge_index, n, edge_weight, improved)
     xw = x @ weight
     out = torch.zeros(n, weight.size(1)).index_add_(0, col, xw[row] * w.unsqueeze(1))
     return out + bias if bias is not None else out
 
 
 # ----------------------------------------------------------------------------- topk / filter_adj (a12, a13)
-def topk(score, ratio, batch):
+def topk(score, ratio, batch, min_score=None):
     """per graph keep ceil(ratio*n) highest scores, descending (float32 ceil as PyG computes it);
-    ties -> smaller index (PyG's sort is unstable; fixtures avoid ties)."""
+    ties -> smaller index (PyG's sort is unstable; fixtures avoid ties).  min_score: PyG's threshold mode instead — every
+    node whose score exceeds min(min_score, max of its graph - 1e-7), in node order."""
     B = int(batch.max()) + 1 if batch.numel() else 0
+    if min_score is not None:
+        keep = []
+        for b in range(B):
+            idx = (batch == b).nonzero().view(-1)
+            thr = min(float(min_score), float(score[idx].max()) - 1e-7)
+            keep.append(idx[score[idx] > thr])
+        return torch.cat(keep) if keep else torch.zeros(0, dtype=torch.long)
     perm = []
     for b in range(B):
         idx = (batch == b).nonzero().view(-1)

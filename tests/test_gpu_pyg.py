@@ -61,6 +61,51 @@ def test_gcn_conv(sym):
         torch.testing.assert_close(a.cpu(), c, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("improved,weighted,self_loops", [(True, False, False), (False, True, False), (True, True, True)])
+def test_gcn_conv_edge_weight_and_improved(improved, weighted, self_loops):
+    """PyG GCNConv's options the reference never passes (network.py:34): per-edge weights (existing self loops keep theirs) and
+    improved = self loops of weight 2, forward and backward (x, W, b) against the oracle's gcn_norm"""
+    from two_stage_gnn_amd import pyg
+    n, fin, fout = 200, 12, 16
+    ei = rand_graph(7, n, 700, False)
+    if self_loops:
+        loops = torch.arange(0, n, 7)
+        ei = torch.cat([ei, torch.stack([loops, loops])], dim=1)
+    ew = (0.25 + torch.rand(ei.size(1), generator=torch.Generator().manual_seed(8))) if weighted else None
+    x = tie_free(9, n, fin)
+    m = pyg.GCNConv(fin, fout, improved=improved).cuda()
+    with torch.no_grad():
+        m.bias.copy_(tie_free(10, fout))
+    w, b = m.weight.detach().cpu().requires_grad_(True), m.bias.detach().cpu().requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    ref = P.gcn_conv(xr, ei, w, b, edge_weight=ew, improved=improved)
+    xg = x.cuda().requires_grad_(True)
+    out = m(xg, ei.cuda(), ew.cuda() if ew is not None else None)
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-5)
+    gy = tie_free(11, n, fout)
+    gr = grads((ref * gy).sum(), [xr, w, b])
+    gg = grads((out * gy.cuda()).sum(), [xg, m.weight, m.bias])
+    for a, c in zip(gg, gr):
+        torch.testing.assert_close(a.cpu(), c, rtol=1e-4, atol=1e-4)
+
+
+def test_topk_min_score():
+    """PyG topk's threshold mode (never used by the reference): nodes above min(min_score, graph max - 1e-7), node order"""
+    from two_stage_gnn_amd import pyg
+    sizes = [17, 1, 40, 8, 33]
+    n = sum(sizes)
+    batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
+    score = tie_free(5, n)
+    for ms in (0.0, 0.5, 10.0, -10.0):
+        ref = P.topk(score, 0.5, batch, min_score=ms)
+        got = pyg.topk(score.cuda(), 0.5, batch.cuda(), min_score=ms)
+        np.testing.assert_array_equal(got.cpu().numpy(), ref.numpy())
+    # (a threshold above every score keeps at most each graph's best node: PyG subtracts its 1e-7 tolerance in float32, so a
+    # maximum of magnitude >= 1 is not strictly above it and that graph keeps nothing — reproduced as is)
+    counts = np.bincount(batch[P.topk(score, 0.5, batch, min_score=10.0)].numpy(), minlength=len(sizes))
+    assert (counts <= 1).all()
+
+
 def test_topk_filter_pools():
     from two_stage_gnn_amd import pyg
     sizes = [17, 1, 40, 8, 33]

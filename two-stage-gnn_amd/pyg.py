@@ -152,10 +152,26 @@ class _GcnPropagate(torch.autograd.Function):
         return dx, None
 
 
-def gcn_propagate(x, g):
-    if g.val is not None:
-        raise NotImplementedError("edge weights are never passed by the reference (network.py:34)")
-    return _GcnPropagate.apply(x, g)
+def gcn_propagate(x, g, edge_weight=None, improved=False):
+    """A^ x.  Unit weights, fill 1 (every reference call site, network.py:34, layers.py:18): the per-row-coefficient kernels.
+    ``edge_weight`` (per edge of the edge list the graph was built from, or per CSR entry for a GraphBatch without ``eid``) and
+    ``improved`` (self loops of weight 2) take PyG's general gcn_norm: per-entry normalised weights (tsgnn_gcn_norm_f32) and the
+    weighted aggregation; the weights are data, not parameters (no gradient flows to them)."""
+    if edge_weight is None and not improved and g.val is None:
+        return _GcnPropagate.apply(x, g)
+    val = g.val
+    if edge_weight is not None:
+        if edge_weight.requires_grad:
+            raise NotImplementedError("gradients with respect to edge_weight")
+        w = edge_weight.detach().contiguous().float().view(-1)
+        eid = getattr(g, "eid", None)
+        val = w[eid[: g.nnz].long()] if eid is not None else w          # CSR entry order
+    R = g.total_rows
+    dev = x.device
+    dinv, self_w = torch.empty(R, device=dev), torch.empty(R, device=dev)
+    val_out = torch.empty(max(g.nnz, 1), device=dev)
+    nat.call("gcn_norm_f32", g.rowptr, g.col, val, R, 2.0 if improved else 1.0, dinv, val_out, self_w)
+    return mp.aggregate(x, g, False, val=val_out, self_w=self_w)
 
 
 class GCNConv(nn.Module):
@@ -163,8 +179,7 @@ class GCNConv(nn.Module):
 
     def __init__(self, in_channels, out_channels, improved=False, cached=False, bias=True, **kwargs):
         super().__init__()
-        if improved:
-            raise NotImplementedError("improved=True is not used by the reference")
+        self.improved = bool(improved)
         self.in_channels, self.out_channels = in_channels, out_channels
         dev = _default_device()
         self.weight = nn.Parameter(torch.empty(in_channels, out_channels, device=dev))
@@ -178,18 +193,23 @@ class GCNConv(nn.Module):
             self.bias.data.zero_()
 
     def forward(self, x, edge_index, edge_weight=None):
-        if edge_weight is not None:
-            raise NotImplementedError("edge_weight is never passed by the reference (network.py:34)")
         g = edge_index if isinstance(edge_index, GraphBatch) else graph_of(edge_index, x.size(0))
         xw = linear(x, self.weight)
-        return bias_add(gcn_propagate(xw, g), self.bias)
+        return bias_add(gcn_propagate(xw, g, edge_weight, self.improved), self.bias)
 
 
 # ----------------------------------------------------------------------------- topk / filter_adj (a12, a13)
 def topk(x, ratio, batch, min_score=None):
     """PyG topk (layers.py:20): per graph the ceil(ratio*n) best nodes, descending.  Returns int64 perm."""
     if min_score is not None:
-        raise NotImplementedError("min_score is not used by the reference")
+        # PyG's threshold mode: keep every node whose score exceeds min(min_score, its graph's maximum - 1e-7), in node order
+        # (at least the best node of each graph survives).  Never used by the reference (layers.py:20 passes a ratio).
+        score = x.contiguous().float().view(-1)
+        if batch is None:
+            batch = torch.zeros(score.numel(), dtype=torch.int64, device=score.device)
+        B = int(batch.max().item()) + 1 if batch.numel() else 0
+        smax = torch.full((B,), float("-inf"), device=score.device).scatter_reduce_(0, batch, score, "amax")[batch] - 1e-7
+        return (score > smax.clamp(max=float(min_score))).nonzero(as_tuple=False).view(-1)
     score = x.contiguous().float().view(-1)
     N = score.numel()
     sizes, gp = _segments(batch, N, score.device)
@@ -392,8 +412,7 @@ class SAGPooling(nn.Module):
 
     def __init__(self, in_channels, ratio=0.5, GNN=GraphConv, min_score=None, multiplier=1, nonlinearity=torch.tanh, **kwargs):
         super().__init__()
-        if min_score is not None:
-            raise NotImplementedError("min_score")
+        self.min_score = min_score
         self.in_channels, self.ratio, self.multiplier, self.nonlinearity = in_channels, ratio, multiplier, nonlinearity
         self.gnn = GNN(in_channels, 1, **kwargs)
 
@@ -402,6 +421,18 @@ class SAGPooling(nn.Module):
             batch = edge_index.new_zeros(x.size(0))
         attn = x if attn is None else attn
         raw = self.gnn(attn, edge_index).view(-1)
+        if self.min_score is not None:
+            # PyG's threshold mode: the score is the per-graph softmax of the GNN output, kept nodes are those above min_score
+            B = int(batch.max().item()) + 1
+            mx = torch.full((B,), float("-inf"), device=raw.device).scatter_reduce(0, batch, raw.detach(), "amax")
+            e = torch.exp(raw - mx[batch])
+            score = e / torch.zeros(B, device=raw.device).index_add(0, batch, e)[batch]
+            perm = topk(score, self.ratio, batch, self.min_score)
+            xo = x[perm] * score[perm].view(-1, 1)
+            if self.multiplier != 1:
+                xo = self.multiplier * xo
+            ei, edge_attr = filter_adj(edge_index, edge_attr, perm, num_nodes=raw.numel())
+            return xo, ei, edge_attr, batch[perm], perm, score[perm]
         perm = topk(raw, self.ratio, batch)                           # tanh is monotone: same selection as PyG
         if self.nonlinearity is torch.tanh:
             xo = gather_gate(x, raw, perm, use_tanh=True)
