@@ -87,15 +87,31 @@ int tsgnn_onehot_rows_f32(const int* label, int64_t n_rows, int64_t total_rows, 
 /* staging -> device (ONE asynchronous copy of `words` 4-byte words; pinned host memory) + tsgnn_onehot_rows_f32, on `stream` */
 int tsgnn_ingest_upload_f32(int32_t* dev, const int32_t* host, int64_t words, const int* node_label_dev, int64_t n_rows, int64_t total_rows,
                             int F, float* x, int64_t ldx, tsgnn_stream_t stream);
-/* Collate workers: native threads that run tsgnn_host_collate_tu for the batches ahead of the step being enqueued.  submit:
- * the arguments of tsgnn_host_collate_tu (`ids`, `out` must stay valid until waited for) + after_event (nullable hipEvent_t:
- * the worker synchronises with it before writing `staging`); wait: blocks, returns the collate's status. */
+/* COMPACT staging (about a third of the expanded layout: the CSR, not the table) and the two launches that bring it in from
+ * pinned host memory at the head of the step's own hipGraph — no copy engine, no second stream, no cross-stream events.
+ * Layout: off[0..8] = header{n, nnz, ntail, largest}, graph_ptr[B+2], slot_count[nmax], label (int64[B]), rowptr[row_cap+1],
+ * node_label[row_cap], tail_ptr[row_cap+1], col[edge_cap], tail_col[tail_cap]; off[9] = total words. */
+int tsgnn_ingest_compact_layout(int B, int nmax, int64_t row_cap, int64_t edge_cap, int64_t tail_cap, int64_t* off);
+/* HOST function: tsgnn_host_collate_tu's batch in the compact layout (TSGNN_EUNSUPPORTED also when edges exceed edge_cap) */
+int tsgnn_host_collate_compact(const int64_t* ds_graph_ptr, const int64_t* ds_rowptr, const int64_t* ds_col, const int64_t* ds_node_label,
+                               const int64_t* ds_graph_label, const int64_t* ids, int B, int nmax, int64_t row_cap, int64_t edge_cap,
+                               int ell_w, int64_t tail_cap, int32_t* staging, int64_t* out);
+/* pull (flat copy of the whole staging buffer into its device mirror: graph_ptr, slot_count, label, node_label, tail_col are used
+ * straight out of the mirror at the layout's offsets) and expand (mirror -> row maps, neighbour table, tail pointers, one-hot
+ * feature rows); the expansion reads the sizes from the batch's header, so the captured pair serves every batch. */
+int tsgnn_ingest_pull_expand_f32(const int32_t* host, int32_t* mirror, int B, int nmax, int64_t row_cap, int64_t edge_cap, int ell_w,
+                                 int64_t tail_cap, int32_t* row_graph, int32_t* row_slot, int32_t* ell, int32_t* tail_ptr, int F, float* x,
+                                 int64_t ldx, tsgnn_stream_t stream);
+/* Collate workers: native threads that run the host collate for the batches ahead of the step being enqueued.  submit: the
+ * arguments of tsgnn_host_collate_tu (edge_cap = 0) or tsgnn_host_collate_compact (edge_cap > 0) (`ids`, `out` must stay valid
+ * until waited for) + after_event (nullable hipEvent_t: the worker synchronises with it before writing `staging`); wait: blocks,
+ * returns the collate's status. */
 typedef struct tsgnn_collate_pool tsgnn_collate_pool;
 int tsgnn_collate_pool_create(int nthreads, tsgnn_collate_pool** pool);
 int tsgnn_collate_pool_submit(tsgnn_collate_pool* pool, const int64_t* ds_graph_ptr, const int64_t* ds_rowptr, const int64_t* ds_col,
                               const int64_t* ds_node_label, const int64_t* ds_graph_label, const int64_t* ids, int B, int nmax,
-                              int64_t row_cap, int ell_w, int64_t tail_cap, int32_t* staging, int64_t* out, void* after_event,
-                              int64_t* ticket);
+                              int64_t row_cap, int64_t edge_cap, int ell_w, int64_t tail_cap, int32_t* staging, int64_t* out,
+                              void* after_event, int64_t* ticket);
 int tsgnn_collate_pool_wait(tsgnn_collate_pool* pool, int64_t ticket);
 int tsgnn_collate_pool_destroy(tsgnn_collate_pool* pool);
 

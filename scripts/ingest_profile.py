@@ -1,8 +1,8 @@
-"""where does the host time of one ingest iteration go? (perf_counter around each phase, 300 iterations)"""
+"""where does the time of one ingest iteration go? host phases (perf_counter) and GPU-side variants, 300 iterations each"""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from two_stage_gnn_amd import dense_encoders as E, ingest, synthetic
+from two_stage_gnn_amd import dense_encoders as E, ingest
 from two_stage_gnn_amd.data_parallel import FlatTrainer
 dev = torch.device("cuda")
 class A: bias = True
@@ -34,11 +34,8 @@ for workers in (3, 2, 1, 0):
         else:
             s.collate(ds, ids)
         t = tick("collate/wait", t)
-        pipe.copy.wait_event(s.consumed); t = tick("wait consumed", t)
-        s.upload(pipe.copy); t = tick("upload", t)
-        pipe.compute.wait_event(s.uploaded); t = tick("wait uploaded", t)
         gs.step(); t = tick("replay", t)
-        s.consumed.record(pipe.compute); t = tick("record", t)
+        s.mark_consumed(pipe.compute); t = tick("record", t)
         if pool is not None and k + depth < len(S):
             s.collate_async(pool, ds, S[k + depth])
         t = tick("submit", t)
@@ -48,7 +45,6 @@ for workers in (3, 2, 1, 0):
     print("workers=%d: host loop %.1f us/iter, with GPU drain %.1f us/iter" % (workers, t_host / len(S) * 1e6, t_tot / len(S) * 1e6))
     print("   " + "  ".join("%s %.1f" % (k, v / len(S) * 1e6) for k, v in T.items()))
 
-# ---- which part of the per-step protocol costs GPU time?  (400 iterations each, wall clock incl. drain)
 def timed(fn, n=400):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for k in range(n):
@@ -56,35 +52,7 @@ def timed(fn, n=400):
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n * 1e6
 depth = len(pipe.slots)
-print("replay slot 0 only            %.1f us" % timed(lambda k: pipe.steps[0].step()))
-print("replay alternating slots      %.1f us" % timed(lambda k: pipe.steps[k % depth].step()))
-def with_events(k):
-    s = pipe.slots[k % depth]
-    pipe.copy.wait_event(s.consumed); s.uploaded.record(pipe.copy); pipe.compute.wait_event(s.uploaded)
-    pipe.steps[k % depth].step(); s.consumed.record(pipe.compute)
-print("+ event protocol, no upload   %.1f us" % timed(with_events))
-def with_upload(k):
-    s = pipe.slots[k % depth]
-    pipe.copy.wait_event(s.consumed); s.upload(pipe.copy); pipe.compute.wait_event(s.uploaded)
-    pipe.steps[k % depth].step(); s.consumed.record(pipe.compute)
-print("+ upload of the same staging  %.1f us" % timed(with_upload))
-def upload_only(k):
-    s = pipe.slots[k % depth]
-    s.upload(pipe.copy)
-print("upload only (copy stream)     %.1f us" % timed(upload_only))
-def same_stream(k):
-    s = pipe.slots[k % depth]
-    s.upload(pipe.compute)
-    pipe.steps[k % depth].step()
-print("upload on the compute stream, no events  %.1f us" % timed(same_stream))
-import ctypes
-def copy_only(k):
-    s = pipe.slots[k % depth]
-    with torch.cuda.stream(pipe.copy):
-        s.dev.copy_(s.host, non_blocking=True)
-print("H2D copy only (copy stream)   %.1f us  (%d bytes)" % (timed(copy_only), 4 * pipe.slots[0].words))
-small = torch.zeros(65536, dtype=torch.int32).pin_memory(); smalld = torch.zeros(65536, dtype=torch.int32, device=dev)
-def copy_small(k):
-    with torch.cuda.stream(pipe.copy):
-        smalld.copy_(small, non_blocking=True)
-print("H2D copy of 256 KB            %.1f us" % timed(copy_small))
+print("replay slot 0 only (pull + expand + step, same staged batch)  %.1f us" % timed(lambda k: pipe.steps[0].step()))
+print("replay alternating slots                                      %.1f us" % timed(lambda k: pipe.steps[k % depth].step()))
+with torch.cuda.stream(pipe.compute):
+    print("pull + expand alone                                           %.1f us" % timed(lambda k: pipe.slots[0].pull()))

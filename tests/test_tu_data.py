@@ -233,15 +233,27 @@ def test_capacity_padded_step_equals_exact_batch():
     ids = np.array([3, 17, 5, 11, 20, 8])
     B, nmax, fin = len(ids), 600, ds.num_node_labels
     n = int(ds.sizes[ids].sum())
-    slot = ingest.CapacityBatch(B, nmax, (n + 200 + 31) // 32 * 32, fin, dev, ghost_slots=int(ds.sizes.max()) + 1)
+    nnz = int(sum(ds.rowptr[ds.graph_ptr[i + 1]] - ds.rowptr[ds.graph_ptr[i]] for i in ids))
+    slot = ingest.CapacityBatch(B, nmax, (n + 200 + 31) // 32 * 32, nnz + 500, fin, dev, ghost_slots=int(ds.sizes.max()) + 1)
     slot.collate(ds, ids)
-    slot.upload(torch.cuda.current_stream())
+    slot.pull()
     torch.cuda.synchronize()
+    # the expanded arrays against the exact batch built by the numpy collate
+    assert (slot.rows, slot.edges) == (n, nnz)
     # the same graphs as an exact batch
     feats = ds.features("node-label")
     g, x, y = ds.collate(ids, nmax, feats, dev)
     torch.testing.assert_close(slot.x[:n], x[:n], rtol=0, atol=0)
     assert float(slot.x[n:].abs().sum()) == 0.0 and torch.equal(slot.label, y)
+    ell_ref, W, tail_ref = g.ell()
+    ell_slot = slot.g._ell[0].view(-1, 16)
+    assert W <= 16 and tail_ref is None
+    torch.testing.assert_close(ell_slot[:n, :W], ell_ref.view(-1, W)[:n], rtol=0, atol=0)
+    assert bool((ell_slot[:n, W:] == -1).all()) and bool((ell_slot[n:] == -1).all())
+    assert torch.equal(slot.g.graph_ptr[:B + 1], g.graph_ptr) and int(slot.g.graph_ptr[B + 1]) == slot.row_cap
+    assert torch.equal(slot.g.slot_count[:nmax], g.slot_count)
+    assert torch.equal(slot.g.row_graph[:n], g.row_graph[:n]) and torch.equal(slot.g.row_slot[:n], g.row_slot[:n])
+    assert bool((slot.g.row_graph[n:] == B).all()) and int(slot.g._ell[2][0].abs().sum()) == 0
 
     class A:
         bias = True
@@ -257,6 +269,8 @@ def test_capacity_padded_step_equals_exact_batch():
         losses, grads = [], None
         for it in range(2):
             tr.zero_grad()
+            if use_slot:
+                slot.pull()                                    # (idempotent: the same staged batch again)
             loss = m.loss(m(slot.x, slot.g)[1], slot.label) if use_slot else m.loss(m(x, g)[1], y)
             tr.backward(loss)
             tr.gather_grads()
@@ -269,3 +283,50 @@ def test_capacity_padded_step_equals_exact_batch():
     scale = float(res[0][1].abs().max())
     torch.testing.assert_close(res[1][1], res[0][1], rtol=0, atol=2e-5 * scale)
     torch.testing.assert_close(res[1][2], res[0][2], rtol=1e-4, atol=1e-6)
+
+
+def test_host_collate_compact_layout():
+    """tsgnn_host_collate_compact (host C code): the compact CSR batch the step's own graph pulls — header, graph pointers with
+    the dummy graph, slot counts, shifted row pointers / columns, tail of the rows beyond 16 neighbours, labels; error paths"""
+    from two_stage_gnn_amd import ingest
+    from two_stage_gnn_amd.tu_data import TUDataset
+    rng = np.random.default_rng(4)
+    sizes = np.array([6, 0, 35, 14, 20])
+    gp = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    rows = []
+    for gi, n in enumerate(sizes):
+        a = (rng.random((n, n)) < (0.8 if gi == 2 else 0.25))
+        a = np.triu(a, 1); a = a | a.T
+        rows += [np.flatnonzero(a[r]) + gp[gi] for r in range(n)]
+    deg = np.array([len(r) for r in rows])
+    assert deg.max() > 16
+    rowptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    col = np.concatenate(rows).astype(np.int64)
+    ds = TUDataset(gp, rowptr, col, np.arange(5, dtype=np.int64) % 2, rng.integers(0, 9, size=int(gp[-1])).astype(np.int64), None, 9)
+    B, nmax, cap, ecap, tcap = 3, 40, 96, 2048, 512
+    ids = np.array([2, 4, 0])
+    off = ingest.compact_layout(B, nmax, cap, ecap, tcap)
+    st = np.full(off[9], 777, dtype=np.int32)
+    n, nnz, ntail, largest = ingest.host_collate_compact(ds, ids, B, nmax, cap, ecap, st, 16, tcap)
+    bs = sizes[ids]
+    np.testing.assert_array_equal(st[off[0]:off[0] + 4], [n, nnz, ntail, largest])
+    assert n == bs.sum() and largest == 35
+    g_ptr = st[off[1]:off[1] + B + 2]
+    np.testing.assert_array_equal(g_ptr, np.concatenate([[0], np.cumsum(bs), [cap]]))
+    np.testing.assert_array_equal(st[off[2]:off[2] + nmax], [(bs > s).sum() for s in range(nmax)])
+    np.testing.assert_array_equal(st[off[3]:off[3] + 2 * B].view(np.int64), ds.graph_label[ids])
+    rp, nl, tp = st[off[4]:off[4] + n + 1], st[off[5]:off[5] + n], st[off[6]:off[6] + n + 1]
+    cc, tc = st[off[7]:off[7] + nnz], st[off[8]:off[8] + ntail]
+    row = 0
+    for b, i in enumerate(ids):
+        for r in range(gp[i], gp[i + 1]):
+            want = col[rowptr[r]:rowptr[r + 1]] - gp[i] + g_ptr[b]
+            np.testing.assert_array_equal(cc[rp[row]:rp[row + 1]], want)
+            np.testing.assert_array_equal(tc[tp[row]:tp[row + 1]], want[16:])
+            assert nl[row] == ds.node_label[r]
+            row += 1
+    assert row == n and rp[n] == nnz and tp[n] == ntail
+    for kw in (dict(row_cap=32), dict(edge_cap=64), dict(tail_cap=1), dict(nmax=20)):
+        args = dict(nmax=nmax, row_cap=cap, edge_cap=ecap, tail_cap=tcap); args.update(kw)
+        with pytest.raises(RuntimeError, match="not supported"):
+            ingest.host_collate_compact(ds, ids, B, args["nmax"], args["row_cap"], args["edge_cap"], st, 16, args["tail_cap"])

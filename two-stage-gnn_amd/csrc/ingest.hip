@@ -51,17 +51,214 @@ __global__ __launch_bounds__(256) void onehot_rows_kernel(const int* __restrict_
   if (i >= total_rows * ld4) return;
   const int64_t r = i / ld4;
   const int c = 4 * (int)(i - r * ld4);
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (r < n_rows) {
-    const int l = label[r];
-    if (l >= c && l < c + 4 && l < F) (&v.x)[l - c] = 1.f;
-  }
+  const int l = (r < n_rows) ? label[r] : -1;
+  const bool ok = l >= 0 && l < F;
+  const float4 v = make_float4((ok && l == c) ? 1.f : 0.f, (ok && l == c + 1) ? 1.f : 0.f, (ok && l == c + 2) ? 1.f : 0.f,
+                               (ok && l == c + 3) ? 1.f : 0.f);
   *reinterpret_cast<float4*>(x + r * ldx + c) = v;
+}
+
+
+// ---- second generation (compact staging, pulled by the step's own hipGraph) -----------------------------------------------
+// The host writes a COMPACT batch (CSR, not the expanded table): header {n, nnz, ntail, largest}, graph_ptr[B+2], slot_count[nmax],
+// label int64[B], rowptr[row_cap+1], node_label[row_cap], tail_ptr[row_cap+1], col[edge_cap], tail_col[tail_cap] — about a third
+// of the expanded layout.  Two kernels at the head of the step's hipGraph bring it in: `ingest_pull` copies the pinned host
+// buffer over PCIe (coalesced 16-byte loads) into its device mirror — graph_ptr, slot_count, labels, node labels and the tail
+// columns are used straight out of the mirror —; `ingest_expand` builds row maps, the fixed-width neighbour table and the one-hot
+// feature rows from it.  No copy engine,
+// no second stream, no cross-stream events: the copy-engine -> shader hand-over alone cost more than the whole transfer.
+struct CLayout {
+  int64_t header, graph_ptr, slot_count, label, rowptr, node_label, tail_ptr, col, tail_col, total;
+};
+inline CLayout make_clayout(int B, int nmax, int64_t row_cap, int64_t edge_cap, int64_t tail_cap) {
+  CLayout L;
+  int64_t o = 0;
+  L.header = o; o += 4;
+  L.graph_ptr = o; o += align4(B + 2);
+  L.slot_count = o; o += align4(nmax);
+  L.label = o; o += align4(2 * (int64_t)B);
+  L.rowptr = o; o += align4(row_cap + 1);
+  L.node_label = o; o += align4(row_cap);
+  L.tail_ptr = o; o += align4(row_cap + 1);
+  L.col = o; o += align4(edge_cap);
+  L.tail_col = o; o += align4(tail_cap > 0 ? tail_cap : 1);
+  L.total = o;
+  return L;
+}
+
+// flat copy of the whole staging buffer (capacity sized: ~0.34 MB for 32 DD graphs): no dependence on the batch's header, so
+// every thread's 16-byte loads are in flight at once — one PCIe round trip, then bandwidth
+__global__ __launch_bounds__(256) void ingest_pull_kernel(const int4* __restrict__ host, int4* __restrict__ mirror, int64_t n4) {
+  const int64_t gtid = (int64_t)blockIdx.x * 256 + threadIdx.x, gsize = (int64_t)gridDim.x * 256;
+  int4 v[4];
+  int64_t i = gtid;
+  for (; i + 3 * gsize < n4; i += 4 * gsize) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = host[i + u * gsize];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) mirror[i + u * gsize] = v[u];
+  }
+  for (; i < n4; i += gsize) mirror[i] = host[i];
+}
+
+struct ExpandArgs {
+  const int32_t* mirror; CLayout L;
+  int B, nmax, ell_w, F, ld4; int64_t row_cap;
+  int32_t* row_graph; int32_t* row_slot; int32_t* ell; int32_t* tail_ptr; float* x; int64_t ldx;
+};
+
+// 32 lanes per row, 8 rows per block.  Lane q of a row: q < ell_w/4 writes four entries of the row's neighbour table, q == ell_w/4
+// the row maps and the tail pointer, the lanes after that (looping when a row has more than 32 - ell_w/4 - 1 float4) the one-hot
+// feature row.
+__global__ __launch_bounds__(256) void ingest_expand_kernel(ExpandArgs a) {
+  const int64_t total_rows = a.row_cap + a.nmax;
+  const int64_t r = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+  const int q = threadIdx.x & 31;
+  if (r >= total_rows) return;
+  const int64_t n = a.mirror[a.L.header];
+  const int32_t ntail = a.mirror[a.L.header + 2];
+  const int EQ = a.ell_w / 4;
+  const int l = (r < n) ? a.mirror[a.L.node_label + r] : -1;
+  if (q < EQ) {
+    int4 v = make_int4(-1, -1, -1, -1);
+    if (r < n) {
+      const int32_t* rowptr = a.mirror + a.L.rowptr;
+      const int e0 = rowptr[r], d = rowptr[r + 1] - e0;
+      const int32_t* col = a.mirror + a.L.col + e0;
+      const int k = 4 * q;
+      if (k < d) v.x = col[k];
+      if (k + 1 < d) v.y = col[k + 1];
+      if (k + 2 < d) v.z = col[k + 2];
+      if (k + 3 < d) v.w = col[k + 3];
+    }
+    *reinterpret_cast<int4*>(a.ell + r * a.ell_w + 4 * q) = v;
+  } else if (q == EQ) {
+    if (r < a.row_cap) {
+      int g = a.B, slot = 0;
+      if (r < n) {                                          // binary search: the graph whose row range holds r
+        const int32_t* gp = a.mirror + a.L.graph_ptr;
+        int lo = 0, hi = a.B;                               // gp[lo] <= r < gp[hi]
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (gp[mid] <= r) lo = mid; else hi = mid; }
+        g = lo; slot = (int)(r - gp[lo]);
+      }
+      a.row_graph[r] = g;
+      a.row_slot[r] = slot;
+    }
+    a.tail_ptr[r] = r < n ? a.mirror[a.L.tail_ptr + r] : ntail;
+    if (r == total_rows - 1) a.tail_ptr[total_rows] = ntail;
+  } else {
+    const bool ok = l >= 0 && l < a.F;                      // (no dynamic register indexing: that would go through scratch)
+    for (int c4 = q - EQ - 1; c4 < a.ld4; c4 += 32 - EQ - 1) {
+      const int c = 4 * c4;
+      const float4 v = make_float4((ok && l == c) ? 1.f : 0.f, (ok && l == c + 1) ? 1.f : 0.f, (ok && l == c + 2) ? 1.f : 0.f,
+                                   (ok && l == c + 3) ? 1.f : 0.f);
+      *reinterpret_cast<float4*>(a.x + r * a.ldx + c) = v;
+    }
+  }
 }
 
 }  // namespace
 
 extern "C" {
+
+/* word offsets of the COMPACT staging layout: off[0..8] = header{n, nnz, ntail, largest}, graph_ptr[B+2], slot_count[nmax],
+ * label (int64[B]), rowptr[row_cap+1], node_label[row_cap], tail_ptr[row_cap+1], col[edge_cap], tail_col[tail_cap]; off[9] = total */
+int tsgnn_ingest_compact_layout(int B, int nmax, int64_t row_cap, int64_t edge_cap, int64_t tail_cap, int64_t* off) {
+  if (!off || B <= 0 || nmax <= 0 || row_cap <= 0 || edge_cap <= 0 || tail_cap < 0) return TSGNN_EINVAL;
+  const CLayout L = make_clayout(B, nmax, row_cap, edge_cap, tail_cap);
+  off[0] = L.header; off[1] = L.graph_ptr; off[2] = L.slot_count; off[3] = L.label; off[4] = L.rowptr; off[5] = L.node_label;
+  off[6] = L.tail_ptr; off[7] = L.col; off[8] = L.tail_col; off[9] = L.total;
+  return TSGNN_OK;
+}
+
+/* HOST function: the mini-batch ids[0..B) of a CSR-resident dataset in the compact layout (columns shifted to batch row ids;
+ * tail_ptr / tail_col = the entries beyond the first ell_w of each row).  out[0..3] = rows, directed edges, tail entries,
+ * largest graph (also the header).  TSGNN_EUNSUPPORTED: a graph over nmax nodes, rows over row_cap, edges over edge_cap, tail
+ * over tail_cap. */
+int tsgnn_host_collate_compact(const int64_t* ds_graph_ptr, const int64_t* ds_rowptr, const int64_t* ds_col, const int64_t* ds_node_label,
+                               const int64_t* ds_graph_label, const int64_t* ids, int B, int nmax, int64_t row_cap, int64_t edge_cap,
+                               int ell_w, int64_t tail_cap, int32_t* staging, int64_t* out) {
+  if (!ds_graph_ptr || !ds_rowptr || !ds_col || !ds_graph_label || !ids || !staging || !out || B <= 0 || nmax <= 0 || row_cap <= 0 ||
+      edge_cap <= 0 || (ell_w != 4 && ell_w != 8 && ell_w != 16) || tail_cap < 0)
+    return TSGNN_EINVAL;
+  const CLayout L = make_clayout(B, nmax, row_cap, edge_cap, tail_cap);
+  int32_t* hd = staging + L.header;
+  int32_t* gp = staging + L.graph_ptr;
+  int32_t* sc = staging + L.slot_count;
+  int64_t* lab = reinterpret_cast<int64_t*>(staging + L.label);
+  int32_t* rp = staging + L.rowptr;
+  int32_t* nl = staging + L.node_label;
+  int32_t* tp = staging + L.tail_ptr;
+  int32_t* col = staging + L.col;
+  int32_t* tc = staging + L.tail_col;
+  int64_t n = 0, nnz = 0, ntail = 0, largest = 0;
+  std::memset(sc, 0, sizeof(int32_t) * (size_t)nmax);
+  for (int b = 0; b < B; ++b) {
+    const int64_t a = ds_graph_ptr[ids[b]], e = ds_graph_ptr[ids[b] + 1], sz = e - a;
+    if (sz > nmax || sz < 0 || n + sz > row_cap) return TSGNN_EUNSUPPORTED;
+    const int64_t e_lo = ds_rowptr[a], e_hi = ds_rowptr[e];
+    if (nnz + (e_hi - e_lo) > edge_cap) return TSGNN_EUNSUPPORTED;
+    gp[b] = (int32_t)n;
+    if (sz > 0) sc[sz - 1] += 1;
+    if (sz > largest) largest = sz;
+    const int32_t shift = (int32_t)(n - a);
+    const int64_t eshift = nnz - e_lo;
+    for (int64_t r = 0; r < sz; ++r) {
+      const int64_t e0 = ds_rowptr[a + r], d = ds_rowptr[a + r + 1] - e0;
+      rp[n + r] = (int32_t)(e0 + eshift);
+      nl[n + r] = ds_node_label ? (int32_t)ds_node_label[a + r] : 0;
+      tp[n + r] = (int32_t)ntail;
+      if (d > ell_w) {
+        if (ntail + (d - ell_w) > tail_cap) return TSGNN_EUNSUPPORTED;
+        for (int64_t k = ell_w; k < d; ++k) tc[ntail++] = (int32_t)ds_col[e0 + k] + shift;
+      }
+    }
+    const int64_t* cp = ds_col + e_lo;
+    int32_t* dst = col + nnz;
+    for (int64_t k = 0; k < e_hi - e_lo; ++k) dst[k] = (int32_t)cp[k] + shift;     // one contiguous run per graph: vectorises
+    nnz += e_hi - e_lo;
+    lab[b] = ds_graph_label[ids[b]];
+    n += sz;
+  }
+  rp[n] = (int32_t)nnz;
+  tp[n] = (int32_t)ntail;
+  gp[B] = (int32_t)n;
+  gp[B + 1] = (int32_t)row_cap;
+  {
+    int32_t run = 0;
+    for (int s = nmax - 1; s >= 0; --s) { run += sc[s]; sc[s] = run; }
+  }
+  hd[0] = (int32_t)n; hd[1] = (int32_t)nnz; hd[2] = (int32_t)ntail; hd[3] = (int32_t)largest;
+  out[0] = n; out[1] = nnz; out[2] = ntail; out[3] = largest;
+  return TSGNN_OK;
+}
+
+/* The two launches that bring a compact batch in (graph-capturable, `host` pinned and device-readable): pull host -> mirror
+ * (+ graph_ptr, slot_count, label, node_label, tail_col: plain copies), then expand mirror -> row_graph, row_slot, ell
+ * [(row_cap+nmax) x ell_w], tail_ptr[row_cap+nmax+1], one-hot x [(row_cap+nmax) x ldx] (F classes).  Sizes come from the batch's
+ * own header, so one captured launch pair serves every batch of the slot. */
+int tsgnn_ingest_pull_expand_f32(const int32_t* host, int32_t* mirror, int B, int nmax, int64_t row_cap, int64_t edge_cap, int ell_w,
+                                 int64_t tail_cap, int32_t* row_graph, int32_t* row_slot, int32_t* ell, int32_t* tail_ptr, int F, float* x,
+                                 int64_t ldx, tsgnn_stream_t stream) {
+  if (!host || !mirror || !row_graph || !row_slot || !ell || !tail_ptr || !x || B <= 0 || nmax <= 0 || row_cap <= 0 || edge_cap <= 0 ||
+      tail_cap < 0 || F <= 0)
+    return TSGNN_EINVAL;
+  const int ld4 = (F + 3) / 4;
+  if ((ell_w != 4 && ell_w != 8 && ell_w != 16) || ldx < 4 * ld4 || (ldx % 4)) return TSGNN_EUNSUPPORTED;
+  const uintptr_t al = reinterpret_cast<uintptr_t>(host) | reinterpret_cast<uintptr_t>(mirror) | reinterpret_cast<uintptr_t>(ell) |
+                       reinterpret_cast<uintptr_t>(x);
+  if (al & 15) return TSGNN_EUNSUPPORTED;
+  const CLayout L = make_clayout(B, nmax, row_cap, edge_cap, tail_cap);
+  const int64_t n4 = L.total / 4;                          // every segment is a whole number of 16-byte units
+  TSGNN_KNAME("ingest_pull_kernel + ingest_expand_kernel");
+  unsigned pgrid = (unsigned)ceil_div64(n4, 256 * 2);
+  if (pgrid > 512) pgrid = 512;
+  ingest_pull_kernel<<<pgrid, 256, 0, stream>>>(reinterpret_cast<const int4*>(host), reinterpret_cast<int4*>(mirror), n4);
+  ExpandArgs ea{mirror, L, B, nmax, ell_w, F, ld4, row_cap, row_graph, row_slot, ell, tail_ptr, x, ldx};
+  ingest_expand_kernel<<<(unsigned)ceil_div64(row_cap + nmax, 8), 256, 0, stream>>>(ea);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
 
 /* word offsets (4-byte words) of the segments of an ingest buffer: off[0..8] = graph_ptr[B+2], slot_count[nmax],
  * row_graph[row_cap], row_slot[row_cap], ell[(row_cap+nmax)*ell_w], tail_ptr[row_cap+nmax+1], tail_col[tail_cap],
@@ -175,7 +372,7 @@ int tsgnn_onehot_rows_f32(const int* label, int64_t n_rows, int64_t total_rows, 
 struct tsgnn_collate_pool {
   struct Job {
     const int64_t *gp, *rp, *col, *nl, *gl, *ids;
-    int B, nmax, ell_w; int64_t row_cap, tail_cap; int32_t* staging; int64_t* out; hipEvent_t after;
+    int B, nmax, ell_w; int64_t row_cap, tail_cap, edge_cap; int32_t* staging; int64_t* out; hipEvent_t after;
     int64_t ticket; int rc; bool done;
   };
   std::mutex mu;
@@ -198,8 +395,11 @@ static void collate_worker(tsgnn_collate_pool* p) {
       p->queue.pop_front();
     }
     if (j->after) (void)hipEventSynchronize(j->after);
-    const int rc = tsgnn_host_collate_tu(j->gp, j->rp, j->col, j->nl, j->gl, j->ids, j->B, j->nmax, j->row_cap, j->ell_w, j->tail_cap,
-                                         j->staging, j->out);
+    const int rc = j->edge_cap > 0
+                       ? tsgnn_host_collate_compact(j->gp, j->rp, j->col, j->nl, j->gl, j->ids, j->B, j->nmax, j->row_cap, j->edge_cap,
+                                                    j->ell_w, j->tail_cap, j->staging, j->out)
+                       : tsgnn_host_collate_tu(j->gp, j->rp, j->col, j->nl, j->gl, j->ids, j->B, j->nmax, j->row_cap, j->ell_w,
+                                               j->tail_cap, j->staging, j->out);
     {
       std::lock_guard<std::mutex> lk(p->mu);
       j->rc = rc;
@@ -217,15 +417,16 @@ int tsgnn_collate_pool_create(int nthreads, tsgnn_collate_pool** pool) {
   return TSGNN_OK;
 }
 
-/* queue one tsgnn_host_collate_tu call (same arguments; `ids` and `out` must stay valid until the job was waited for);
+/* queue one tsgnn_host_collate_tu call (edge_cap = 0) or tsgnn_host_collate_compact call (edge_cap > 0) with these arguments
+ * (`ids` and `out` must stay valid until the job was waited for);
  * after_event (nullable hipEvent_t): the worker synchronises with it before it writes `staging`.  *ticket identifies the job. */
 int tsgnn_collate_pool_submit(tsgnn_collate_pool* pool, const int64_t* ds_graph_ptr, const int64_t* ds_rowptr, const int64_t* ds_col,
                               const int64_t* ds_node_label, const int64_t* ds_graph_label, const int64_t* ids, int B, int nmax,
-                              int64_t row_cap, int ell_w, int64_t tail_cap, int32_t* staging, int64_t* out, void* after_event,
-                              int64_t* ticket) {
+                              int64_t row_cap, int64_t edge_cap, int ell_w, int64_t tail_cap, int32_t* staging, int64_t* out,
+                              void* after_event, int64_t* ticket) {
   if (!pool || !ticket) return TSGNN_EINVAL;
   auto* j = new tsgnn_collate_pool::Job{ds_graph_ptr, ds_rowptr, ds_col, ds_node_label, ds_graph_label, ids, B, nmax, ell_w, row_cap,
-                                        tail_cap, staging, out, reinterpret_cast<hipEvent_t>(after_event), 0, 0, false};
+                                        tail_cap, edge_cap, staging, out, reinterpret_cast<hipEvent_t>(after_event), 0, 0, false};
   {
     std::lock_guard<std::mutex> lk(pool->mu);
     j->ticket = pool->next_ticket++;
