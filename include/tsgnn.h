@@ -311,6 +311,22 @@ int tsgnn_clip_adam_step_f32(float* param, const float* grad, float* m, float* v
                              float beta2, float eps, float weight_decay, float max_norm, float grad_scale, float* state,
                              float* ws, tsgnn_stream_t stream);
 
+/* ---------------------------------------------------------------- pooled-level GCN stacks in one launch (dense_stack.hip) */
+
+/* 1 if tsgnn_dense_stack_*_f32 take these shapes: B graphs of K <= 64 nodes, nstack (1 or 2) stacks of L <= 4 layers, input
+ * width fin0 <= 192, hidden width, last-layer widths of the two stacks (<= 128). */
+int tsgnn_dense_stack_supported(int B, int K, int nstack, int L, int fin0, int hidden, int last0, int last1);
+/* GCN stack(s) of a pooled DiffPool level (encoders.py:378-380 -> gcn_forward :140-167, dense adjacency adj[B,K,K], x[B*K, fin0]),
+ * forward / backward as ONE launch each, for up to two stacks that share (x, adj).  Per hidden layer: u = (A x) W + b,
+ * v = u / max(|u|, 1e-12), y = BN_slot(ReLU(v)) (apply_bn, :134-138: fresh statistics over batch and features, eps 1e-5, biased
+ * variance); last layer: v only; out[:, off_l : off_l + n_l] = the layer's output.  The workgroups (16 rows of one graph each,
+ * all resident) meet at a device-wide barrier per hidden layer (per-slot statistics) forward, twice per layer backward; a
+ * barrier that is not completed within its bound raises err[0] (checked by the host at its next synchronisation).
+ * `desc`: host array of 8-byte words (pointers / integers), layout in csrc/dense_stack.hip::ds_unpack, built by
+ * two_stage_gnn_amd/dense_stack.py::_describe. */
+int tsgnn_dense_stack_fwd_f32(const int64_t* desc, tsgnn_stream_t stream);
+int tsgnn_dense_stack_bwd_f32(const int64_t* desc, tsgnn_stream_t stream);
+
 /* ---------------------------------------------------------------- edge-softmax attention (attention.hip) */
 
 /* s[r,h] = <x[r, head h], a[h]>  — the two per-node scalars a1.h_i / a2.h_j that replace the reference's

@@ -417,8 +417,10 @@ def test_dense_gcn_stack_equals_composed_layers(B, K, fin, hid, last, monkeypatc
     x0 = torch.randn(B, K, fin, generator=gen).cuda()
     a0 = torch.rand(B, K, K, generator=gen).cuda()
     gy = torch.randn(B, K, 2 * hid + last, generator=gen).cuda()
+    from two_stage_gnn_amd import dense_stack, message_passing as mp
     res = []
-    for fused in (True, False):
+    for one_launch, fused in ((True, True), (False, True), (False, False)):      # one launch per direction / one node / composed
+        monkeypatch.setattr(dense_stack, "ONE_LAUNCH", one_launch)
         monkeypatch.setattr(E, "FUSED_DENSE_STACK", fused)
         x, a = x0.clone().requires_grad_(True), a0.clone().requires_grad_(True)
         for mod in [c1, cl] + list(cb):
@@ -426,10 +428,53 @@ def test_dense_gcn_stack_equals_composed_layers(B, K, fin, hid, last, monkeypatc
         y, _ = m.gcn_forward_dense(x, a, c1, cb, cl)
         (y * gy).sum().backward()
         res.append([y.detach(), x.grad, a.grad] + [p.grad.clone() for mod in [c1] + list(cb) + [cl] for p in mod.parameters()])
+    mp.check_device_errors()
     assert res[0][0].shape == (B, K, 2 * hid + last)
+    for other in (res[0], res[1]):
+        for f, c in zip(other, res[2]):
+            scale = c.abs().max().item() + 1e-12
+            assert (f - c).abs().max().item() <= 2e-4 * scale
+
+
+@pytest.mark.parametrize("B,K,fin,hid,lasts,need_x", [(16, 64, 192, 64, (64, 8), True), (16, 8, 192, 64, (64, 4), True),
+                                                       (7, 20, 12, 32, (16, 8), False)])
+def test_two_dense_stacks_in_one_launch(B, K, fin, hid, lasts, need_x):
+    """the embedding stack of a pooled level and the next level's assignment stack (same x and adjacency) in ONE launch per
+    direction == the two stacks run one after the other: outputs, dx (summed over the stacks), dA (summed), all parameter grads"""
+    from two_stage_gnn_amd import dense_encoders as E, dense_stack, message_passing as mp
+
+    class A:
+        bias = True
+    torch.manual_seed(21)
+    m = E.SoftPoolingGcnEncoder(64, 12, hid, 16, 2, 3, hid, assign_ratio=0.25, num_pooling=1, bn=True, linkpred=False, args=A(),
+                                assign_input_dim=12, final_dim="number_classes")
+    stacks = []
+    for last in lasts:
+        c1, cb, cl = m.build_conv_layers(fin, hid, last, 3, False, normalize=True, dropout=0.0)
+        convs = [c1] + list(cb) + [cl]
+        for mod in convs:
+            mod.cuda()
+            torch.nn.init.normal_(mod.bias.data, std=0.1)
+        stacks.append(convs)
+    gen = torch.Generator().manual_seed(22)
+    x0 = torch.randn(B, K, fin, generator=gen).cuda()
+    a0 = torch.rand(B, K, K, generator=gen).cuda()
+    gys = [torch.randn(B, K, 2 * hid + last, generator=gen).cuda() for last in lasts]
+    assert dense_stack.one_launch_ok(x0, a0, stacks)
+    res = []
+    for together in (True, False):
+        x, a = x0.clone().requires_grad_(need_x), a0.clone().requires_grad_(True)
+        for convs in stacks:
+            for mod in convs:
+                mod.zero_grad(set_to_none=True)
+        ys = dense_stack.dense_gcn_stacks(x, a, stacks) if together else [dense_stack.dense_gcn_stacks(x, a, [c])[0] for c in stacks]
+        sum((y * gy).sum() for y, gy in zip(ys, gys)).backward()
+        res.append([y.detach() for y in ys] + ([x.grad] if need_x else []) + [a.grad]
+                   + [p.grad.clone() for convs in stacks for mod in convs for p in mod.parameters()])
+    mp.check_device_errors()
     for f, c in zip(res[0], res[1]):
         scale = c.abs().max().item() + 1e-12
-        assert (f - c).abs().max().item() <= 2e-4 * scale
+        assert (f - c).abs().max().item() <= 2e-5 * scale
 
 
 @pytest.mark.parametrize("masked", [True, False])

@@ -245,6 +245,7 @@ class GraphedStep:
                 for t, s_ in zip((trainer.flat_param, trainer.exp_avg, trainer.exp_avg_sq, trainer.state), snap):
                     t.copy_(s_)
             torch.cuda.synchronize()
+            mp.check_device_errors()
             if not use_graph:
                 return
             if self.multi and dist.is_initialized():

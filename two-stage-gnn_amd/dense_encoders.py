@@ -394,6 +394,7 @@ class SoftPoolingGcnEncoder(GcnEncoderGraph):
         emb = self.gcn_forward_rows(x, g, self.conv_first, self.conv_block, self.conv_last, mask_ghost=masked)
         out_all = [mp.readout_max(emb, g)]
         dense_x = dense_adj = None
+        a_next = None
         for i in range(self.num_pooling):
             lin = self.assign_pred_modules[i]
             if i == 0:
@@ -405,14 +406,29 @@ class SoftPoolingGcnEncoder(GcnEncoderGraph):
                 self._link_graph, self._link_masked = g, masked
                 dense_x, dense_adj = dp.diffpool_contract_rows(s, emb, g)                     # :374-375
             else:
-                a, _ = self.gcn_forward_dense(dense_x, dense_adj, self.assign_conv_first_modules[i],
-                                              self.assign_conv_block_modules[i], self.assign_conv_last_modules[i])
+                if a_next is not None:
+                    a = a_next                  # came out of the launch that ran this level's embedding stack
+                else:
+                    a, _ = self.gcn_forward_dense(dense_x, dense_adj, self.assign_conv_first_modules[i],
+                                                  self.assign_conv_block_modules[i], self.assign_conv_last_modules[i])
                 Bq, Kq, Cq = a.shape
                 s = dp.row_softmax(mp.linear_oi(a.reshape(Bq * Kq, Cq), lin.weight, lin.bias)).reshape(Bq, Kq, -1)
                 self.assign_tensor = s
                 dense_x, dense_adj = dp.diffpool_contract_dense(s, emb_dense, dense_adj)
-            emb_dense, gd = self.gcn_forward_dense(dense_x, dense_adj, self.conv_first_after_pool[i],
-                                                   self.conv_block_after_pool[i], self.conv_last_after_pool[i])
+            a_next = None
+            emb_convs = [self.conv_first_after_pool[i]] + list(self.conv_block_after_pool[i]) + [self.conv_last_after_pool[i]]
+            if i + 1 < self.num_pooling and FUSED_DENSE_STACK and self.bn and not self.per_graph_bn:
+                # this level's embedding stack and the NEXT level's assignment stack read the same (x, adjacency): one launch
+                # forward and one backward for both (dense_stack.py)
+                from . import dense_stack
+                asg_convs = ([self.assign_conv_first_modules[i + 1]] + list(self.assign_conv_block_modules[i + 1])
+                             + [self.assign_conv_last_modules[i + 1]])
+                if dense_stack.ONE_LAUNCH and dense_stack.one_launch_ok(dense_x, dense_adj, [emb_convs, asg_convs]):
+                    emb_dense, a_next = dense_stack.dense_gcn_stacks(dense_x, dense_adj, [emb_convs, asg_convs])
+                    gd = GraphBatch.uniform(dense_x.size(0), dense_x.size(1), dense_x.device)
+            if a_next is None:
+                emb_dense, gd = self.gcn_forward_dense(dense_x, dense_adj, self.conv_first_after_pool[i],
+                                                       self.conv_block_after_pool[i], self.conv_last_after_pool[i])
             Bq, Kq, Cq = emb_dense.shape
             out_all.append(mp.readout_max(emb_dense.reshape(Bq * Kq, Cq), gd))
         output = torch.cat(out_all, dim=1) if self.concat else out_all[-1]

@@ -148,7 +148,155 @@ class _DenseGcnStack(torch.autograd.Function):
 
 def dense_gcn_stack(x, adj, g, convs):
     """concatenated layer outputs [B, K, sum(widths)] of conv_first / conv_block / conv_last on the pooled level (x, adj)"""
+    if ONE_LAUNCH and one_launch_ok(x, adj, [convs]):
+        return dense_gcn_stacks(x, adj, [convs])[0]
     params = []
     for c in convs:
         params += [c.weight, c.bias]
     return _DenseGcnStack.apply(x, adj, g, *params)
+
+
+# ----------------------------------------------------------------------------------------------- one launch per direction
+import os
+
+import numpy as np
+
+ONE_LAUNCH = os.environ.get("TSGNN_DENSE_ONE_LAUNCH", "1") != "0"    # pooled-level stacks as one launch forward, one backward
+_MAXL = 4
+_ws = {}
+
+
+def _workspace(dev):
+    """(barrier words, error flag) of the device-wide barriers: zeroed once, re-armed by the kernels themselves"""
+    w = _ws.get(dev)
+    if w is None:
+        w = _ws[dev] = (torch.zeros(32, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.float32, device=dev))
+        mp.DEVICE_ERRORS.append((w[1], "a device-wide barrier of the pooled-level stack kernels (dense_stack.hip) timed out: "
+                                       "its workgroups were not all resident; results of that launch are invalid", w[0]))
+    return w
+
+
+def one_launch_ok(x, adj, stacks):
+    if x.dim() != 3 or adj.dim() != 3 or x.dtype != torch.float32 or adj.dtype != torch.float32 or not x.is_cuda:
+        return False
+    if len(stacks) not in (1, 2) or any(len(c) != len(stacks[0]) for c in stacks):
+        return False
+    B, K, fin0 = x.shape
+    L = len(stacks[0])
+    hid = stacks[0][0].output_dim
+    for convs in stacks:
+        for i, c in enumerate(convs):
+            if c.add_self or not c.normalize_embedding or c.dropout > 0.001:
+                return False
+            if i < L - 1 and c.output_dim != hid:
+                return False
+    lasts = [convs[-1].output_dim for convs in stacks] * 2
+    return bool(nat.lib().tsgnn_dense_stack_supported(int(B), int(K), len(stacks), L, int(fin0), int(hid), int(lasts[0]), int(lasts[1])))
+
+
+def _describe(x2, ldx, fin0, adj, B, K, stacks, stats, ws, bwd=None):
+    """the int64 description of tsgnn_dense_stack_*_f32 (layout: csrc/dense_stack.hip::ds_unpack)"""
+    P = lambda t: 0 if t is None else int(t.data_ptr())
+    d = [P(x2), int(ldx), int(fin0), P(adj), int(B), int(K), len(stacks), P(stats), P(ws[0]), P(ws[1])]
+    if bwd is None:
+        d += [0, 0, 0, 0, 0, 0, 0, 0, 0]
+    else:
+        d += [P(bwd["dagg"]), P(bwd["dxn"]), P(bwd["slabs"]), int(bwd["slab_floats"]), int(bwd["finmax"]), P(bwd["dx"]),
+              int(bwd["lddx"]), P(bwd["dadj"]), P(bwd["dadj_part"])]
+    for si in range(2):
+        if si < len(stacks):
+            st = stacks[si]
+            d += [P(st["out"]), int(st["ldo"]), P(st.get("dout")), int(st.get("lddo", 0)), len(st["layers"])]
+            for li in range(_MAXL):
+                if li < len(st["layers"]):
+                    y = st["layers"][li]
+                    d += [P(y["w"]), int(y["ldw"]), P(y["bias"]), int(y["fin"]), int(y["n"]), int(y["off"]), P(y["agg"]), P(y["v"]),
+                          P(y["rinv"]), P(y["mean"]), P(y["rstd"]), P(y.get("dw")), P(y.get("db")), int(y.get("slab_off", 0))]
+                else:
+                    d += [0] * 14
+        else:
+            d += [0] * (5 + 14 * _MAXL)
+    return np.asarray(d, dtype=np.int64)
+
+
+class _DenseGcnStacks(torch.autograd.Function):
+    """forward(x, adj, nstack, L, *params): params = per stack, per layer (weight, bias).  Returns one concatenated output per
+    stack.  ONE launch forward, ONE backward (tsgnn_dense_stack_fwd_f32 / _bwd_f32)."""
+
+    @staticmethod
+    def forward(ctx, x, adj, nstack, L, *params):
+        B, K, fin0 = x.shape
+        R = B * K
+        dev = x.device
+        x2 = x.contiguous().reshape(R, fin0)
+        adj = adj.contiguous()
+        ws = _workspace(dev)
+        stats = _f32(_MAXL * nstack * R * 2, device=dev)
+        stacks, outs = [], []
+        for si in range(nstack):
+            layers, off, fin = [], 0, fin0
+            widths = [params[(si * L + l) * 2].size(1) for l in range(L)]
+            total = sum(widths)
+            out = _f32(R, total, device=dev)
+            for l in range(L):
+                w = params[(si * L + l) * 2].contiguous()
+                bias = params[(si * L + l) * 2 + 1]
+                n = widths[l]
+                last = l == L - 1
+                layers.append({"w": w, "ldw": w.stride(0), "bias": bias, "fin": fin, "n": n, "off": off,
+                               "agg": _f32(R, fin, device=dev), "v": None if last else _f32(R, n, device=dev),
+                               "rinv": _f32(R, device=dev), "mean": None if last else _f32(K, device=dev),
+                               "rstd": None if last else _f32(K, device=dev)})
+                off += n
+                fin = n
+            stacks.append({"out": out, "ldo": total, "layers": layers})
+            outs.append(out)
+        desc = _describe(x2, fin0, fin0, adj, B, K, stacks, stats, ws)       # (kept alive across the call: the kernel arguments are
+        nat.call("dense_stack_fwd_f32", desc.ctypes.data)                      # read from it on the host at launch)
+        ctx.stacks, ctx.x2, ctx.adj, ctx.dims, ctx.stats, ctx.ws = stacks, x2, adj, (B, K, fin0, nstack, L), stats, ws
+        ctx.params = params
+        return tuple(o.view(B, K, -1) for o in outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        B, K, fin0, nstack, L = ctx.dims
+        R = B * K
+        stacks, x2, adj = ctx.stacks, ctx.x2, ctx.adj
+        dev = x2.device
+        need_x, need_adj = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        finmax = max(max(y["fin"] for y in st["layers"]) for st in stacks)
+        slab = 0
+        grads = []
+        for si, st in enumerate(stacks):
+            d = douts[si]
+            d = torch.zeros(R, st["ldo"], device=dev) if d is None else mp._check(d.reshape(R, st["ldo"]))
+            st["dout"], st["lddo"] = d, d.stride(0)
+        for st in stacks:
+            off = 0
+            for y in st["layers"]:
+                y["slab_off"] = off
+                off += (y["fin"] + 1) * y["n"]
+                y["dw"] = _f32(y["fin"], y["n"], device=dev)
+                y["db"] = _f32(y["n"], device=dev) if y["bias"] is not None else None
+                grads += [y["dw"], y["db"]]
+            slab = max(slab, off)
+        tiles = (K + 15) // 16
+        bwd = {"dagg": _f32(nstack * R * finmax, device=dev), "dxn": _f32(nstack * R * finmax, device=dev),
+               "slabs": _f32(tiles * B * nstack * slab, device=dev), "slab_floats": slab, "finmax": finmax,
+               "dx": _f32(R, fin0, device=dev) if need_x else None, "lddx": fin0,
+               "dadj": _f32(B, K, K, device=dev) if need_adj else None,
+               "dadj_part": _f32(2 * R * K, device=dev) if (need_adj and nstack == 2) else None}
+        desc = _describe(x2, fin0, fin0, adj, B, K, stacks, ctx.stats, ctx.ws, bwd)
+        nat.call("dense_stack_bwd_f32", desc.ctypes.data)
+        dx = bwd["dx"].view(B, K, fin0) if need_x else None
+        return (dx, bwd["dadj"], None, None, *grads)
+
+
+def dense_gcn_stacks(x, adj, stacks):
+    """the GCN stacks `stacks` (1 or 2 lists of GraphConv modules, same depth) on the pooled level (x[B,K,F], adj[B,K,K]):
+    one concatenated output [B, K, sum(widths)] per stack, one launch forward and one backward for all of them"""
+    params = []
+    for convs in stacks:
+        for c in convs:
+            params += [c.weight, c.bias]
+    return _DenseGcnStacks.apply(x, adj, len(stacks), len(stacks[0]), *params)

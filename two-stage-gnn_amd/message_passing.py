@@ -738,6 +738,21 @@ class GradSink:
         return v
 
 
+DEVICE_ERRORS = []                  # (flag tensor, message, state to clear): raised by kernels with a bounded device-wide barrier
+
+
+def check_device_errors():
+    """Synchronises and raises if a kernel reported a failure it could not return through its status (a bounded device-wide
+    barrier that was not completed: the launch's results are invalid).  Called where the host synchronises anyway (end of a
+    GraphedStep's warm-up, test fixtures); call it after any synchronisation point of a long run."""
+    for flag, msg, state in DEVICE_ERRORS:
+        if float(flag.item()) != 0.0:
+            flag.zero_()
+            if state is not None:
+                state.zero_()               # the barrier words of the failed launch: start clean
+            raise RuntimeError(msg)
+
+
 GRAD_SINK = None                    # installed by FlatTrainer between zero_grad() and gather_grads()
 _unit = {}
 
