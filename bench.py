@@ -475,7 +475,12 @@ def main():
                 rows = step_kernel_table(gstep, trainer, stream)
                 table = summarise_kernels(rows, int(g.nnz))
                 top = max(table, key=lambda r: r["us_per_step"])
-                tr = traffic.get(top["kernel"], {}) if isinstance(traffic.get(top["kernel"]), dict) else {}
+                for r_ in table:                                # PMC traffic (recorded measurement) next to the algorithmic bytes
+                    t_ = traffic.get(r_["kernel"].replace(" ", ""))
+                    if isinstance(t_, dict):
+                        r_["traffic"] = t_.get("traffic_bytes_per_launch")
+                tr = traffic.get(top["kernel"].replace(" ", ""), {})
+                tr = tr if isinstance(tr, dict) else {}
                 roofline = {"bound": top["bound"], "kernel": "%s (%s: %s)" % (top["kernel"], top["entry"], top["what"]),
                             "achieved": top["tflops"] if top["bound"] == "mfma" else top["gbs"],
                             "peak": MFMA_F32_PEAK_TF if top["bound"] == "mfma" else HBM_PEAK_GBS,
@@ -508,8 +513,10 @@ def main():
                 roofline["aggregation_in_fused"] = agg_in
             # the stand-alone aggregation kernel on the step's batch and its batch-size sweep
             agg_ms, agg_bytes, agg_kernel = aggregation_probe(g, a.hidden)
-            tr = traffic.get("dd_b32_rows9151_f128", {}) if (a.shape == "DD" and a.batch == 32 and a.hidden == 128
-                                                             and int(g.total_rows) == 9151) else {}
+            tr = {}
+            if a.shape == "DD" and a.batch == 32 and a.hidden == 128 and int(g.total_rows) == 9151:       # the shape the PMC run measured
+                tr = traffic.get(agg_kernel.split(" ")[0].replace(" ", ""), traffic.get("dd_b32_rows9151_f128", {}))
+                tr = tr if isinstance(tr, dict) else {}
             roofline["aggregation_standalone"] = {
                 "bound": "hbm", "kernel": agg_kernel, "achieved": agg_bytes / agg_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": agg_bytes / agg_ms / 1e6 / HBM_PEAK_GBS, "traffic": tr.get("traffic_bytes_per_launch"),
