@@ -175,6 +175,9 @@ def account(entry, a, nnz):
     if entry == "clip_adam_step_f32":
         n = int(a[4])
         return 0.0, 7 * f4 * n, "clip_grad_norm + Adam on the flat buffer (every block sums the norm)"
+    if entry == "readout_l2_bwd_f32":
+        B, n, sg, F = int(a[2]), int(a[3]), int(a[4]), int(a[10])
+        return 0.0, 2 * f4 * (n + sg) * F + f4 * (n + sg) + 4 * n + 8 * B * F, "backward of the last layer's max readout + L2 normalise -> dU (row-parallel), F=%d" % F
     if entry == "readout_partial_f32":
         n, sg, F = int(a[3]), int(a[4]), int(a[7])
         return 0.0, f4 * (n + sg) * F + 8 * int(a[1]) * F, "max-readout partial"

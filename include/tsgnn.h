@@ -583,6 +583,13 @@ int tsgnn_slot_post_bwd_f32(const int* graph_ptr, const int* slot_count, int B, 
                             const float* v, int64_t ldv, const float* dxs, int64_t lddxs, const float* dxs2, int64_t lddxs2,
                             const float* dout, int64_t ldo, const int* arg, int F, int relu, int bn, const float* mean,
                             const float* rstd, const float* rinv, float* du, int64_t lddu, tsgnn_stream_t stream);
+/* The same for the LAST layer of a stack (relu = bn = 0, nothing above it): du from the max-readout gradient alone, one lane
+ * group per row instead of one workgroup per slot.  row_graph[n_real]: graph of every real row (>= B: padding row of a
+ * capacity-padded batch, du = 0); rows [0, n_real + n_ghost_rows) of du are written; a ghost row n_real + n collects the
+ * graphs with exactly n nodes, in graph order. */
+int tsgnn_readout_l2_bwd_f32(const int* graph_ptr, const int* row_graph, int B, int64_t n_real, int n_ghost_rows, const float* v,
+                             int64_t ldv, const float* dout, int64_t ldo, const int* arg, int F, const float* rinv, float* du,
+                             int64_t lddu, tsgnn_stream_t stream);
 /* max readout (encoders.py:183): partial maxima of one layer into packed[B*F] (zeroed by the caller), then ONE decode
  * for all L layers: out[b, l*Fh + f], arg in packed order (layers 0..L-2 are Fh wide, the last Fl). */
 int tsgnn_readout_partial_f32(const int* graph_ptr, int B, int nmax, int64_t n_real, int n_ghost, const float* x, int64_t ldx, int F,

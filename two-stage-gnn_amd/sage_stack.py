@@ -54,6 +54,7 @@ MERGED_BWD = os.environ.get("TSGNN_MERGED_BWD", "1") != "0"        # weight-grad
 GATHER_MAX_ROWS = int(os.environ.get("TSGNN_GATHER_MAX_ROWS", 65536))   # above: stand-alone row-batched aggregation + lean product
 GATHER_FUSED = os.environ.get("TSGNN_GATHER_FUSED", "1") != "0"     # aggregate inside the `.W` product when the neighbour table has no CSR tail
 EPILOGUE_READOUT = os.environ.get("TSGNN_EPILOGUE_READOUT", "1") != "0"   # the last layer's max readout in its product's epilogue
+LAST_LAYER_ROWS = os.environ.get("TSGNN_LAST_LAYER_ROWS", "1") != "0"     # the last layer's dU from a row-parallel kernel
 
 
 def _gather_ok(g, x):
@@ -275,10 +276,16 @@ class _SageStack(torch.autograd.Function):
                 dsl = dout[:, l * Fh:l * Fh + N]
                 argl = ctx.arg[l * B * Fh:l * B * Fh + B * N]
                 dnode = None
-            nat.call("slot_post_bwd_f32", g.graph_ptr, g.slot_count, B, sn, g.n_rows, sg, v, v.stride(0), dxs,
-                     dxs.stride(0) if dxs is not None else 0, dnode, dnode.stride(0) if dnode is not None else 0, dsl,
-                     dout.stride(0) if dsl is not None else 0, argl, N, 0 if last else 1, 0 if last else 1, mean, rstd, rinv, du,
-                     du.stride(0))
+            if (LAST_LAYER_ROWS and last and not ctx.nodes and dxs is None and N % 4 == 0 and N <= 128 and g.n_ghost == g.nmax
+                    and sn == sg and dout.stride(0) % 4 == 0 and dsl.data_ptr() % 16 == 0 and g.row_graph is not None):
+                # the last layer has no batch-norm: its dU is a row-wise function of the readout gradient (no slot structure)
+                nat.call("readout_l2_bwd_f32", g.graph_ptr, g.row_graph, B, g.n_rows, sg, v, v.stride(0), dsl, dout.stride(0), argl, N, rinv,
+                         du, du.stride(0))
+            else:
+                nat.call("slot_post_bwd_f32", g.graph_ptr, g.slot_count, B, sn, g.n_rows, sg, v, v.stride(0), dxs,
+                         dxs.stride(0) if dxs is not None else 0, dnode, dnode.stride(0) if dnode is not None else 0, dsl,
+                         dout.stride(0) if dsl is not None else 0, argl, N, 0 if last else 1, 0 if last else 1, mean, rstd, rinv, du,
+                         du.stride(0))
             want_w = ctx.needs_input_grad[5 + 2 * l]
             want_b = ctx.has_bias and ctx.needs_input_grad[6 + 2 * l]
             merged = False
