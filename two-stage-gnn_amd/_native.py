@@ -47,12 +47,27 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
+HASH_PATH = LIB_PATH + ".srchash"
+
+
+def source_hash():
+    """sha256 over the contents of every source the library is built from (kernels, headers, the C ABI header)"""
+    import hashlib
+    h = hashlib.sha256()
+    for d in sorted(sources() + [HEADER] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]):
+        h.update(os.path.basename(d).encode())
+        h.update(open(d, "rb").read())
+    return h.hexdigest()
+
+
 def build(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 -> two-stage-gnn_amd/libtsgnn_hip.so (in-tree, travels with gpurun)."""
+    """hipcc --offload-arch=gfx950 -> two-stage-gnn_amd/libtsgnn_hip.so (in-tree, travels with gpurun).  The library is reused
+    only if the hash of the sources it was built from (stored beside it) equals the hash of the sources in the tree: a stale
+    binary is rebuilt whatever its time stamp says."""
     srcs = sources()
     deps = srcs + [HEADER] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    if (not force and os.path.exists(LIB_PATH)
-            and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps)):
+    cur = source_hash()
+    if not force and os.path.exists(LIB_PATH) and os.path.exists(HASH_PATH) and open(HASH_PATH).read().strip() == cur:
         return LIB_PATH
     objs = []
     procs = []
@@ -75,6 +90,8 @@ def build(force=False, verbose=False):
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stdout.decode())
+    with open(HASH_PATH, "w") as f:
+        f.write(cur + "\n")
     global _lib
     _lib = None
     return LIB_PATH
@@ -88,10 +105,10 @@ def lib():
     global _lib, _decls
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        import shutil
-        if shutil.which("hipcc"):
-            build()                      # compiling the product is not a fallback: the HIP path is still the only path
+    import shutil
+    if shutil.which("hipcc") and (not os.path.exists(LIB_PATH) or not os.path.exists(HASH_PATH)
+                                  or open(HASH_PATH).read().strip() != source_hash()):
+        build()                          # compiling the product is not a fallback: the HIP path is still the only path
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             "libtsgnn_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
