@@ -293,6 +293,22 @@ __global__ void readout_max_bwd(const float* __restrict__ dout, int64_t ldo, con
   else dx[(int64_t)r * ldx + f] += g;
 }
 
+// the same as a dense pass for batches WITHOUT ghost rows: every element of dx is written (no zero fill beforehand, no atomics):
+// dx[r, f] = (arg[graph(r), f] == r) ? dout[graph(r), f] : 0
+__global__ void readout_max_bwd_rows(const float* __restrict__ dout, int64_t ldo, const int* __restrict__ arg, const int* __restrict__ row_graph,
+                                     int F4, int64_t rows, float* __restrict__ dx, int64_t ldx) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * F4) return;
+  const int64_t r = i / F4;
+  const int c = 4 * (int)(i - r * F4);
+  const int b = row_graph[r];
+  const int4 w = *reinterpret_cast<const int4*>(arg + (int64_t)b * 4 * F4 + c);
+  const float4 g = *reinterpret_cast<const float4*>(dout + (int64_t)b * ldo + c);
+  const int r32 = (int)r;
+  *reinterpret_cast<float4*>(dx + r * ldx + c) = make_float4(w.x == r32 ? g.x : 0.f, w.y == r32 ? g.y : 0.f, w.z == r32 ? g.z : 0.f,
+                                                             w.w == r32 ? g.w : 0.f);
+}
+
 // ---------------------------------------------------------------- padded <-> packed rows, ghost masking
 __global__ void pack_rows_kernel(const float* __restrict__ src, int nmax, int F, const int* __restrict__ row_graph,
                                  const int* __restrict__ row_slot, int64_t n_real, float* __restrict__ dst, int64_t ld) {
@@ -408,6 +424,18 @@ int tsgnn_readout_max_bwd_f32(const float* dout, int64_t ldo, const int* arg, in
   if (!dout || !arg || !dx || B <= 0 || F <= 0 || ldo < F || ldx < F || (relu && !x)) return TSGNN_EINVAL;
   readout_max_bwd<<<(unsigned)ceil_div64((int64_t)B * F, 256), 256, 0, stream>>>(dout, ldo, arg, B, F, x, ldx_in, relu,
                                                                                 n_real, dx, ldx);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+/* backward of the max readout for batches without ghost rows: writes EVERY element of dx[rows, F] (no fill, no atomics) */
+int tsgnn_readout_max_bwd_rows_f32(const float* dout, int64_t ldo, const int* arg, const int* row_graph, int F, int64_t rows, float* dx,
+                                   int64_t ldx, tsgnn_stream_t stream) {
+  if (!dout || !arg || !row_graph || !dx || F <= 0 || rows < 0 || ldo < F || ldx < F) return TSGNN_EINVAL;
+  if ((F % 4) || (ldo % 4) || (ldx % 4) || ((reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(arg) | reinterpret_cast<uintptr_t>(dx)) & 15))
+    return TSGNN_EUNSUPPORTED;
+  if (rows == 0) return TSGNN_OK;
+  readout_max_bwd_rows<<<(unsigned)ceil_div64(rows * (F / 4), 256), 256, 0, stream>>>(dout, ldo, arg, row_graph, F / 4, rows, dx, ldx);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }

@@ -267,6 +267,9 @@ class _DenseGcnStacks(torch.autograd.Function):
         finmax = max(max(y["fin"] for y in st["layers"]) for st in stacks)
         slab = 0
         grads = []
+        # (work on copies of the layer descriptions: a gradient tensor that stayed referenced from ctx would not be "stolen" by
+        # AccumulateGrad but cloned — one copy launch per parameter)
+        stacks = [dict(st, layers=[dict(y) for y in st["layers"]]) for st in stacks]
         for si, st in enumerate(stacks):
             d = douts[si]
             d = torch.zeros(R, st["ldo"], device=dev) if d is None else mp._check(d.reshape(R, st["ldo"]))
@@ -289,7 +292,9 @@ class _DenseGcnStacks(torch.autograd.Function):
         desc = _describe(x2, fin0, fin0, adj, B, K, stacks, ctx.stats, ctx.ws, bwd)
         nat.call("dense_stack_bwd_f32", desc.ctypes.data)
         dx = bwd["dx"].view(B, K, fin0) if need_x else None
-        return (dx, bwd["dadj"], None, None, *grads)
+        dadj = bwd["dadj"]
+        del stacks, bwd, desc
+        return (dx, dadj, None, None, *grads)
 
 
 def dense_gcn_stacks(x, adj, stacks):

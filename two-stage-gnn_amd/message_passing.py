@@ -593,6 +593,11 @@ class _ReadoutMax(torch.autograd.Function):
         if dout.stride(1) != 1 or dout.stride(0) < dout.size(1):
             dout = dout.contiguous()                     # (a column slice of the concatenated readouts' gradient is read in place)
         F = dout.size(1)
+        if (g.n_ghost == 0 and F % 4 == 0 and dout.stride(0) % 4 == 0 and dout.data_ptr() % 16 == 0 and ctx.rows == g.n_rows
+                and g.row_graph is not None):
+            dx = _f32(ctx.rows, F, device=dout.device)              # no ghost rows: one dense pass writes every element
+            nat.call("readout_max_bwd_rows_f32", dout, dout.stride(0), arg, g.row_graph, F, ctx.rows, dx, dx.stride(0))
+            return dx, None
         dx = _f32(ctx.rows, F, device=dout.device, zero=True)
         nat.call("readout_max_bwd_f32", dout, dout.stride(0), arg, g.B, F, None, 0, 0, g.n_rows, dx, dx.stride(0))
         return dx, None
