@@ -182,6 +182,13 @@ int tsgnn_wgrad_reduce_multi_f32(const float* ws0, int nslab0, int K0, int N0, f
                                  int K1, int N1, float* dw1, float* db1, const float* ws2, int nslab2, int K2, int N2, float* dw2,
                                  float* db2, const float* ws3, int nslab3, int K3, int N3, float* dw3, float* db3,
                                  float* normparts, float* step_state, tsgnn_stream_t stream);
+/* dW[K_in, N] = z[:, :K_in]^T . du for K_in, N <= 512 (the GAT projections: 92 x 264, 256 x 264): the slab kernel on 128 x 128
+ * output blocks, every block and slab in ONE launch, then one fixed-order reduction (no float atomics).  Plan first
+ * (nslab = 0: unsupported shape); ws holds ws_floats floats. */
+int tsgnn_wgrad_blocks_plan(int64_t rows, int K_in, int N, int64_t ldz, int64_t lddu, int* nslab, int64_t* rows_per_slab,
+                            int64_t* ws_floats);
+int tsgnn_wgrad_blocks_f32(const float* z, int64_t ldz, const float* du, int64_t lddu, int64_t rows, int K_in, int N, int nslab,
+                           int64_t rows_per_slab, float* ws, float* dw, int64_t lddw, tsgnn_stream_t stream);
 /* Ragged batched out[b][K,N] = s[rows_b,:K]^T . x[rows_b,:N] — DiffPool's S^T Z and S^T (A S) (encoders.py:374-375) over
  * the row ranges of the graphs: graph b owns slabs [seg_slab_ptr[b], seg_slab_ptr[b+1]); slab t covers rows
  * [slab_row_ptr[t], slab_row_ptr[t+1]).  ws >= nslab*(K+1)*N floats.  ceil(K/32)*ceil(N/32) <= 16. */
@@ -399,6 +406,47 @@ int tsgnn_pack_heads_f32(const float* w0, const float* w1, const float* w2, cons
                          tsgnn_stream_t stream);
 int tsgnn_unpack_heads_f32(const float* dW, const float* dA0, const float* dA1, int H, int Fin, int Fo, float* gw, float* ga,
                            tsgnn_stream_t stream);
+
+/* ---- one GAT layer, all heads, fused (csrc/gat_fused.hip).  Replaces DGATHead.forward / DGATLayer.forward
+ * (Code/sage+gat+diffpool/encoders_GAT.py:29-49, 68-84) for batches whose edge-less columns are listed per graph.
+ * hp[rows, ldh] = x . W' with W' = [W_0 | .. | W_{H-1} | W_h a1_h (H columns) | W_h a2_h (H columns) | 0 pad] (Ns columns):
+ * features, then the two attention scalars of every head (:35-36).  See the file header for the data flow. */
+int tsgnn_gat_fused_supported(int H, int Fh);
+/* y[i] = act( sum_j alpha_ij hp[j, :C] + sum_{edge-less j of i's graph} (iso_w / N) hp[j, :C] ), alpha = softmax over dim=1
+ * (column-wise, :41) of the masked LeakyReLU scores; mean_heads: mean over heads before the ELU (:78-83), y is [rows, Fh].
+ * (rowptr, col): A; (rp_t, col_t): A^T.  row_graph nullable (then graph = row / nmax).  iso_*: nullable together; iso_ptr[B + 1].
+ * drop_p > 0: attention dropout (:42), Philox4x32-10 keyed on (seed; i, j, head).
+ * stat[rows, H, 2] (out): (max, 1 / sum of exponentials) of every softmax column, written by a first small launch and read by
+ * the attention kernel here and by the backward. */
+int tsgnn_gat_attn_fwd_f32(const float* hp, int64_t ldh, const int* rowptr, const int* col, const int* rp_t, const int* col_t,
+                           int64_t rows, int H, int Fh, float slope, const int* row_graph, int nmax, const int* iso_idx,
+                           const float* iso_w, const int* iso_ptr, float uscale, int mean_heads, int apply_elu, float drop_p,
+                           uint64_t seed, float* stat, float* y, int64_t ldy, tsgnn_stream_t stream);
+/* backward, column-wise: dhp[:, :C] (features), dhp[:, C+H+h] (d s_col), zero pad columns; per-entry terms t1, t2 [nnz, H] (A^T
+ * entry order) and S [rows, H] for tsgnn_gat_score_rowsum_f32, which writes dhp[:, C+h] (d s_row) and — from the partial sums
+ * dupart[B, tsgnn_gat_bwd_parts(B), C] of dpre over each graph's rows — dh of the listed edge-less columns.  dy, y: the layer's
+ * output gradient and output ([rows, Fh] with mean_heads).  iso_row[rows * iso_row_ld]: per-row weight of the edge-less columns.
+ * With drop_p > 0 the listed columns are completed by the backward itself (every element has its own mask): pass
+ * dupart = NULL to the row-sum kernel. */
+int tsgnn_gat_bwd_parts(int B);
+int tsgnn_gat_attn_bwd_f32(const float* hp, int64_t ldh, const float* y, int64_t ldy, const float* dy, int64_t lddy, const int* rp_t,
+                           const int* col_t, int64_t rows, int H, int Fh, float slope, int mean_heads, int apply_elu,
+                           const int* graph_ptr, int B, const int* iso_idx, const float* iso_w, const int* iso_ptr,
+                           const float* iso_row, int iso_row_ld, float uscale, float drop_p, uint64_t seed, const float* stat,
+                           float* dhp, int Ns, float* t1, float* t2, float* S, float* dupart, tsgnn_stream_t stream);
+/* the dropout multipliers (0 or 1 / (1 - p)) of attention elements (i0 + i, j0 + j) of every head, out[ni, nj, H] — what the two
+ * kernels above apply; lets a test hand the very same mask to the dense oracle */
+int tsgnn_gat_dropout_mult_f32(float drop_p, uint64_t seed, int64_t i0, int64_t ni, int64_t j0, int64_t nj, int H, float* out,
+                               tsgnn_stream_t stream);
+int tsgnn_gat_score_rowsum_f32(const int* rowptr, const int* col, const int* eperm, const float* t1, const float* t2, const float* S,
+                               int64_t rows, int H, float* dhp, int64_t ldh, int C, const float* dupart, int B, const int* iso_idx,
+                               const float* iso_w, const int* iso_ptr, float uscale, tsgnn_stream_t stream);
+/* heads' parameters -> W' (and dW' -> the heads' gradients) for up to 4 layers in ONE launch.  desc lives in HOST memory:
+ * [L, then per layer: H, Fin, Fo, Ns, W' (pack) or dW' (unpack), gw [H, Fin, Fo], ga [H, 2 Fo], w_0..w_7, a_0..a_7]
+ * (tsgnn_gat_pack_desc_words() words per layer; gw / ga are read by the unpack only). */
+int tsgnn_gat_pack_desc_words(void);
+int tsgnn_gat_pack_f32(const int64_t* desc, tsgnn_stream_t stream);
+int tsgnn_gat_unpack_f32(const int64_t* desc, tsgnn_stream_t stream);
 /* ELU (encoders_GAT.py:47) / mean over heads then ELU (:78-83) */
 int tsgnn_elu_heads_fwd_f32(const float* x, int64_t rows, int H, int Fh, int mean_heads, int apply_elu, float* y, tsgnn_stream_t stream);
 int tsgnn_elu_heads_bwd_f32(const float* x, const float* dy, int64_t rows, int H, int Fh, int mean_heads, int apply_elu, float* dx,

@@ -169,26 +169,31 @@ def diffpool_encoder(p, x, adj, batch_num_nodes, num_pooling, assign_x=None, fin
 
 
 # --------------------------------------------------------------------------- GAT (dense, column softmax)
-def gat_head(x, adj, w, a, slope=0.2, concat=True):
+def gat_head(x, adj, w, a, slope=0.2, concat=True, att_mult=None):
     """DGATHead.forward, encoders_GAT.py:29-49.  Uses graph 0's features for every graph (T4);
     softmax(dim=1) of a [B,N,N] tensor normalises over the ROW index i, i.e. per source column j
-    (T3); masked entries are -9e15 so an all-masked column becomes uniform 1/N."""
+    (T3); masked entries are -9e15 so an all-masked column becomes uniform 1/N.
+    att_mult [B,N,N] (optional): F.dropout(attention, p, training=True) of :42 with the multipliers (0 or 1/(1-p)) supplied by the
+    caller — torch's own random stream cannot be reproduced by another implementation, the arithmetic can."""
     h = x[0] @ w                                                  # :32
     fo = w.size(1)
     e = F.leaky_relu((h @ a[:fo]) + (h @ a[fo:]).t(), slope)      # e_ij = a1.h_i + a2.h_j, :35-36
     att = torch.where(adj > 0, e.expand_as(adj), torch.full_like(adj, MASK_NEG))
     att = torch.softmax(att, dim=1)                               # :41
+    if att_mult is not None:
+        att = att * att_mult                                      # :42
     hp = torch.matmul(att, h)                                     # :43
     return F.elu(hp) if concat else hp
 
 
-def gat_layer(p, prefix, x, adj, concat=True, slope=0.2):
-    """DGATLayer.forward, encoders_GAT.py:70-84."""
+def gat_layer(p, prefix, x, adj, concat=True, slope=0.2, att_mult=None):
+    """DGATLayer.forward, encoders_GAT.py:70-84.  att_mult: per head, see gat_head."""
     heads = []
     i = 0
     while "%s.attention_%d.w" % (prefix, i) in p:
         heads.append(gat_head(x, adj, p["%s.attention_%d.w" % (prefix, i)],
-                              p["%s.attention_%d.a" % (prefix, i)], slope, concat))
+                              p["%s.attention_%d.a" % (prefix, i)], slope, concat,
+                              None if att_mult is None else att_mult[i]))
         i += 1
     if concat:
         return torch.cat(heads, dim=2)

@@ -64,9 +64,10 @@ def _inverse_entry_map(g, src_e_t):
     return inv
 
 
-def _isolated_list(g, iso):
+def _isolated_list(g, iso, force=False):
     """(row ids, weights, per-graph pointer) of the rows with a non-zero uniform-term weight — a few per graph; built once
-    per graph (one host round trip at graph build time) so that the forward sums those rows only"""
+    per graph (one host round trip at graph build time) so that the forward sums those rows only.  None: nothing to list, or
+    (unless ``force``) so many that the all-rows scan is the better kernel."""
     c = getattr(g, "_iso_list", None)
     if c is None:
         w = iso[:, 0]
@@ -78,11 +79,15 @@ def _isolated_list(g, iso):
         ptr = torch.zeros(g.B + 1, dtype=torch.int32, device=w.device)
         ptr[1:] = torch.cumsum(cnt, 0)
         n_listed = int(idx.numel())
-        if n_listed == 0 or n_listed > 64 * g.B:            # nothing to list, or so many that the all-rows scan is the better kernel
-            c = g._iso_list = (None,)
-        else:
-            c = g._iso_list = (idx.to(torch.int32).contiguous(), w[idx].contiguous(), ptr)
-    return None if c[0] is None else c
+        c = g._iso_list = (idx.to(torch.int32).contiguous(), w[idx].contiguous(), ptr, n_listed)
+    if c[3] == 0 or (c[3] > 64 * g.B and not force):
+        return None
+    return c[:3]
+
+
+def isolated_count(g):
+    """number of listed edge-less columns (after _isolated_list has run on g)"""
+    return g._iso_list[3]
 
 
 def _isolated_columns(g, rp_t, R, H):

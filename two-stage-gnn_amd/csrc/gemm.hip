@@ -14,6 +14,7 @@
 // Tile: 64x64 per 256-thread block (4 waves, 2x2, one 32x32 MFMA tile each), K chunk 32, operands
 // staged through LDS with +1 padding (conflict-free ds_read_b32 for both fragment shapes).
 #include "common.h"
+#include <cstdlib>
 #include <type_traits>
 #include "../../include/tsgnn.h"
 
@@ -341,6 +342,69 @@ __global__ __launch_bounds__(256) void tn_rows_reduce_multi(ReduceMulti m) {
   }
 }
 
+// ---- blocked weight gradient: dW[K_in, N] for K_in, N up to 512 as 128 x 128 output blocks ("sets"), all of them and all of
+// their row slabs in ONE launch of the slab body (tn_rows_body.h), then ONE fixed-order reduction.  The GAT projections have
+// 92 x 264 and 256 x 264 outputs; one set at a time was a launch per set.
+constexpr int WB_MAXSETS = 16;
+constexpr int64_t WB_SET_FLOATS = 129 * 128;            // per slab: [kc + 1][nc] <= 129 x 128
+struct WgradBlocks {
+  TnArgs g;                                             // z, du, rows, rows_per_slab; K_in / N hold the TOTAL widths
+  int NB, nsets;                                        // column blocks; sets = row blocks x column blocks
+  int64_t set_stride;                                   // floats between the slab arrays of two sets
+};
+template <int NY>
+__global__ __launch_bounds__(256) void wgrad_blocks_kernel(WgradBlocks w) {
+  extern __shared__ __attribute__((aligned(16))) float tn_smem[];
+  const int set = (int)blockIdx.y / NY, by = (int)blockIdx.y % NY;
+  const int kb = set / w.NB, nb = set % w.NB;
+  TnArgs g = w.g;
+  g.z += 128 * kb;
+  g.du += 128 * nb;
+  g.K_in = min(128, w.g.K_in - 128 * kb);
+  g.N = min(128, w.g.N - 128 * nb);
+  g.slabs = w.g.slabs + (int64_t)set * w.set_stride;
+  if (g.N <= 32) tn_rows_body<4, 1, NY>(g, tn_smem, blockIdx.x, by, gridDim.x);     // a narrow last column block (the 2H score columns)
+  else tn_rows_body<4, 4, NY>(g, tn_smem, blockIdx.x, by, gridDim.x);
+}
+struct WgradBlocksReduce {
+  const float* slabs; int nslab; int64_t set_stride;
+  int K_in, N, NB, nsets;
+  float* dw; int64_t lddw;
+  int first_block[WB_MAXSETS + 1];
+};
+__global__ __launch_bounds__(256) void wgrad_blocks_reduce(WgradBlocksReduce r) {
+  __shared__ float lds[4][64];
+  int set = 0;
+#pragma unroll
+  for (int t = 1; t < WB_MAXSETS; ++t) if (t < r.nsets && (int)blockIdx.x >= r.first_block[t]) set = t;
+  const int kb = set / r.NB, nb = set % r.NB;
+  const int kc = min(128, r.K_in - 128 * kb), nc = min(128, r.N - 128 * nb);
+  const int64_t per_slab = (int64_t)(kc + 1) * nc;
+  const float* slabs = r.slabs + (int64_t)set * r.set_stride;
+  const int e_l = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int64_t e = ((int64_t)blockIdx.x - r.first_block[set]) * 64 + e_l;
+  const bool ok = e < (int64_t)kc * nc;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (ok) {                                             // the arithmetic (and order) of tn_rows_reduce
+    const int per = (r.nslab + 3) / 4;
+    const int s0 = grp * per, s1 = min(r.nslab, s0 + per);
+    int s = s0;
+    for (; s + 4 <= s1; s += 4) {
+      a0 += slabs[(int64_t)s * per_slab + e];
+      a1 += slabs[(int64_t)(s + 1) * per_slab + e];
+      a2 += slabs[(int64_t)(s + 2) * per_slab + e];
+      a3 += slabs[(int64_t)(s + 3) * per_slab + e];
+    }
+    for (; s < s1; ++s) a0 += slabs[(int64_t)s * per_slab + e];
+  }
+  lds[grp][e_l] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (grp == 0 && ok) {
+    const int k = (int)(e / nc), n = (int)(e % nc);
+    r.dw[(int64_t)(128 * kb + k) * r.lddw + 128 * nb + n] = (lds[0][e_l] + lds[1][e_l]) + (lds[2][e_l] + lds[3][e_l]);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -571,6 +635,65 @@ int tsgnn_colsum_f32(const float* x, int64_t ld, int64_t rows, int F, float* out
   dim3 grid((unsigned)((F + 63) / 64), (unsigned)nchunk);
   colsum_partial<<<grid, 256, 0, stream>>>(x, ld, rows, F, rpc, ws);
   splitk_reduce_kernel<<<(unsigned)ceil_div64(F, 256), 256, 0, stream>>>(ws, nchunk, F, F, out, accumulate);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+static int wgrad_blocks_cus() {
+  static int ncu = 0;
+  if (ncu == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
+    else ncu = 256;
+  }
+  return ncu;
+}
+
+int tsgnn_wgrad_blocks_plan(int64_t rows, int K_in, int N, int64_t ldz, int64_t lddu, int* nslab, int64_t* rows_per_slab,
+                            int64_t* ws_floats) {
+  if (!nslab || !rows_per_slab || !ws_floats || rows < 0) return TSGNN_EINVAL;
+  *nslab = 0; *rows_per_slab = 0; *ws_floats = 0;
+  if (K_in <= 0 || N <= 0 || K_in > 512 || N > 512 || (ldz % 4) || (lddu % 4) || (N % 4)) return TSGNN_OK;
+  const int nsets = ((K_in + 127) / 128) * ((N + 127) / 128);
+  if (nsets > WB_MAXSETS) return TSGNN_OK;
+  // two workgroups of 64 KB LDS fit a CU: (slabs x sets x 2 blocks per set) ~ 2 x CUs, every block in flight at once
+  static const int per_cu = [] { const char* e = getenv("TSGNN_WGRAD_BLOCKS_PER_CU"); const int v = e ? atoi(e) : 2; return v > 0 ? v : 2; }();
+  int64_t ns = (int64_t)per_cu * wgrad_blocks_cus() / (2 * nsets);
+  if (ns < 1) ns = 1;
+  int64_t rps = ceil_div64(rows > 0 ? rows : 1, ns);
+  rps = ((rps + 31) / 32) * 32;                           // whole staged chunks
+  *rows_per_slab = rps;
+  *nslab = (int)(rows > 0 ? ceil_div64(rows, rps) : 1);
+  *ws_floats = (int64_t)nsets * (*nslab) * WB_SET_FLOATS;
+  return TSGNN_OK;
+}
+
+int tsgnn_wgrad_blocks_f32(const float* z, int64_t ldz, const float* du, int64_t lddu, int64_t rows, int K_in, int N, int nslab,
+                           int64_t rows_per_slab, float* ws, float* dw, int64_t lddw, tsgnn_stream_t stream) {
+  if (!z || !du || !ws || !dw || rows < 0 || nslab <= 0 || rows_per_slab <= 0 || K_in <= 0 || N <= 0 || lddw < N) return TSGNN_EINVAL;
+  if (K_in > 512 || N > 512 || (ldz % 4) || (lddu % 4) || (N % 4) || ldz < ((K_in + 3) / 4) * 4 || lddu < N ||
+      ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(du)) & 15))
+    return TSGNN_EUNSUPPORTED;
+  const int KB = (K_in + 127) / 128, NB = (N + 127) / 128, nsets = KB * NB;
+  if (nsets > WB_MAXSETS || (int64_t)nslab * rows_per_slab < rows) return TSGNN_EINVAL;
+  WgradBlocks w{TnArgs{z, ldz, du, lddu, rows, rows_per_slab, K_in, N, ws, nullptr, 0}, NB, nsets, (int64_t)nslab * WB_SET_FLOATS};
+  static bool attr = false;
+  constexpr size_t lds = 2 * TN_CH * 32 * (4 + 4) * sizeof(float);
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_blocks_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  TSGNN_KNAME("wgrad_blocks_kernel<2>");
+  wgrad_blocks_kernel<2><<<dim3((unsigned)nslab, (unsigned)(2 * nsets)), 256, lds, stream>>>(w);
+  WgradBlocksReduce r{ws, nslab, w.set_stride, K_in, N, NB, nsets, dw, lddw, {0}};
+  int blocks = 0;
+  for (int t = 0; t < nsets; ++t) {
+    r.first_block[t] = blocks;
+    const int kc = K_in - 128 * (t / NB) < 128 ? K_in - 128 * (t / NB) : 128, nc = N - 128 * (t % NB) < 128 ? N - 128 * (t % NB) : 128;
+    blocks += (kc * nc + 63) / 64;
+  }
+  for (int t = nsets; t <= WB_MAXSETS; ++t) r.first_block[t] = blocks;
+  wgrad_blocks_reduce<<<(unsigned)blocks, 256, 0, stream>>>(r);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }

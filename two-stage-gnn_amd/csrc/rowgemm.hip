@@ -67,7 +67,9 @@ __global__ __launch_bounds__(256) void rowgemm_colsplit_kernel(RowGemmArgs g) {
   if (g.bias) g.bias += n0;
   g.b += TRANS_B ? (int64_t)n0 * g.ldb : (int64_t)n0;
   g.rinv = nullptr;
-  rowgemm_body<NT, TRANS_B, false>(g, smem, blockIdx.x);
+  // a narrow last block (the 2H score columns of the packed GAT projection, N = H * Fh + 2H) runs the one-tile body
+  if (!TRANS_B && g.N <= 32) rowgemm_body<1, TRANS_B, false>(g, smem, blockIdx.x);
+  else rowgemm_body<NT, TRANS_B, false>(g, smem, blockIdx.x);
 }
 
 inline bool rowgemm_colsplit_enabled() {
@@ -183,7 +185,7 @@ extern "C" {
 int tsgnn_rowgemm_supported(const float* a, int64_t lda, const float* b, int64_t ldb, const float* c, int64_t ldc, int K, int N,
                             int trans_b) {
   const bool al = ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0;
-  if (!al || (lda % 4) || (ldb % 4) || N > 256 || N <= 0 || K <= 0) return 0;
+  if (!al || (lda % 4) || (ldb % 4) || N > 384 || N <= 0 || K <= 0) return 0;   // 256 < N <= 384: column-split kernel only (no row epilogue)
   if (lda < ((K + 3) / 4) * 4) return 0;
   if (!trans_b && (N % 4)) return 0;
   if (trans_b && (K % 4)) return 0;
@@ -201,8 +203,17 @@ int tsgnn_rowgemm_f32(const float* a, int64_t lda, const float* b, int64_t ldb, 
     return TSGNN_EUNSUPPORTED;
   if (rows == 0 && fill_rows == 0) return TSGNN_OK;
   RowGemmArgs g{a, lda, b, ldb, bias, c, ldc, rinv, rows, K, N, normalize, fill_rows, nullptr, 0, nullptr, 0};
-  if (trans_b) { if (!try_big<true>(g, stream) && !try_colsplit<true>(g, stream)) dispatch_rowgemm<true, false>(g, stream); }
-  else { if (!try_big<false>(g, stream) && !try_colsplit<false>(g, stream)) dispatch_rowgemm<false, false>(g, stream); }
+  if (trans_b) {
+    if (!try_big<true>(g, stream) && !try_colsplit<true>(g, stream)) {
+      if (N > 256) return TSGNN_EUNSUPPORTED;
+      dispatch_rowgemm<true, false>(g, stream);
+    }
+  } else {
+    if (!try_big<false>(g, stream) && !try_colsplit<false>(g, stream)) {
+      if (N > 256) return TSGNN_EUNSUPPORTED;
+      dispatch_rowgemm<false, false>(g, stream);
+    }
+  }
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }

@@ -23,6 +23,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import attention as att
+from . import gat_fused as gf
 from . import _native as nat
 from . import message_passing as mp
 from .dense_encoders import GraphConv, _batch_from_dense, _default_device
@@ -140,8 +141,23 @@ class _PackHeads(torch.autograd.Function):
 PACK_HEADS = True
 
 
-def _gat_heads_forward(heads, x, adj, concat_heads, elu):
-    """all heads of a layer in one pass: h = x0 [W_0|W_1|...], one edge-softmax / aggregation launch set."""
+def _own_features(heads, g):
+    ragged = getattr(g, "row_mult", None) is not None
+    return ragged or (heads[0].per_graph_features and g.B > 1)
+
+
+def _fused_layer_ok(heads, g, rows):
+    """this layer runs on the fused kernels (gat_fused.py): supported head shape, every graph reads its own rows, the batch's
+    edge-less columns can be listed"""
+    if not gf.heads_ok(heads) or not (g.B == 1 or _own_features(heads, g)):
+        return False
+    drop_on = heads[0].dropout > 0 and heads[0].training
+    return gf.batch_ok(g, rows, len(heads), drop_on)
+
+
+def _gat_heads_forward(heads, x, adj, concat_heads, elu, wp=None):
+    """all heads of a layer in one pass: h = x0 [W_0|W_1|...], one edge-softmax / aggregation launch set.
+    wp: this layer's packed operand when the caller packed several layers in one launch (gat_fused.pack_layers)."""
     g = _padded_batch(adj)
     B, N = g.B, g.nmax
     H = len(heads)
@@ -157,6 +173,18 @@ def _gat_heads_forward(heads, x, adj, concat_heads, elu):
         x0 = x.reshape(B * N, -1).contiguous().float() if own else _rows_of_graph0(x, g)  # [N, Fin] ([B*N, Fin] per-graph)
     if x0.size(1) % 4 and not x0.requires_grad:
         x0 = F.pad(x0, (0, 4 - x0.size(1) % 4))                            # 16-byte rows: the MFMA row-panel product applies
+    p = heads[0].dropout
+    drop_on = p > 0 and heads[0].training
+    if (x0.stride(0) % 4 == 0 and x0.data_ptr() % 16 == 0 and x0.size(1) >= heads[0].input_dim
+            and _fused_layer_ok(heads, g, x0.size(0))):
+        if wp is None:
+            (wp,) = gf.pack_layers([heads])
+        y = gf.gat_layer(x0, wp, g, H, Fo, slope, mean_heads=not concat_heads, apply_elu=elu, drop_p=p if drop_on else 0.0,
+                         seed=gf.new_seed() if drop_on else 0)
+        return y if ragged else y.reshape(B, N, -1)
+    if drop_on:
+        raise NotImplementedError("attention dropout > 0 needs the fused layer kernels (gat_fused.py): supported head shape, "
+                                  "per-graph features (or B = 1), un-packed rows")
     if PACK_HEADS and 1 < H <= 8 and heads[0].w.is_cuda:
         W, a_row, a_col = _PackHeads.apply(*[hd.w for hd in heads], *[hd.a for hd in heads])
     else:
@@ -166,9 +194,6 @@ def _gat_heads_forward(heads, x, adj, concat_heads, elu):
     if B > 1 and not own:
         h = h.unsqueeze(0).expand(B, N, H * Fo).reshape(B * N, H * Fo)       # T4: graph 0's features everywhere
     pre = att.attention_aggregate(h, a_row, a_col, g, H, slope, by_column=True, uniform_isolated=True)
-    p = heads[0].dropout
-    if p > 0 and heads[0].training:
-        raise NotImplementedError("attention dropout > 0 is not on the benchmarked path (reference default 0.0)")
     out = att.elu_heads(pre, H, mean_heads=not concat_heads, apply_elu=elu)
     return out if ragged else out.reshape(B, N, -1)
 
@@ -184,11 +209,11 @@ class DGATLayer(nn.Module):
         for i, attention in enumerate(self.attentions):
             self.add_module("attention_{}".format(i), attention)
 
-    def forward(self, x, adj):
+    def forward(self, x, adj, wp=None):
         if self.dropout > 0 and self.training:
             x = F.dropout(x, self.dropout, training=True)
         # concat: per-head ELU then concatenation (:75); otherwise mean over heads then ELU (:78-83)
-        return _gat_heads_forward(self.attentions, x, adj, concat_heads=self.concat, elu=True)
+        return _gat_heads_forward(self.attentions, x, adj, concat_heads=self.concat, elu=True, wp=wp)
 
 
 class DGATEncoderGraph(nn.Module):
@@ -237,11 +262,14 @@ class DGATEncoderGraph(nn.Module):
 
     def gcn_forward(self, x, adj, conv_first, conv_block, conv_last):
         g = _padded_batch(adj)
-        x = conv_first(x, g)
-        if conv_block is not None:
-            for layer in conv_block:
-                x = layer(x, g)
-        return conv_last(x, g)
+        layers = [conv_first] + (list(conv_block) if conv_block is not None else []) + [conv_last]
+        wps = [None] * len(layers)
+        rows = x.size(0) if x.dim() == 2 else (x.size(0) * x.size(1) if _own_features(conv_first.attentions, g) else x.size(1))
+        if len(layers) <= 4 and all(isinstance(l, DGATLayer) and _fused_layer_ok(l.attentions, g, rows) for l in layers):
+            wps = gf.pack_layers([l.attentions for l in layers])        # the parameters of every layer: one launch each way
+        for layer, wp in zip(layers, wps):
+            x = layer(x, g, wp=wp) if isinstance(layer, DGATLayer) else layer(x, g)
+        return x
 
     def packed_batch(self, x, adj, batch_num_nodes):
         """(rows, GraphBatch) of the packed block-diagonal batch (per_graph_features mode): dense adj [B,Nmax,Nmax] -> CSR
@@ -261,8 +289,9 @@ class DGATEncoderGraph(nn.Module):
         return mp.pack_rows(x, g, (F_in + 3) // 4 * 4), g
 
     def forward(self, x, adj, batch_num_nodes=None, **kwargs):
+        drop_on = self.training and any(hd.dropout > 0 for hd in self.modules() if isinstance(hd, DGATHead))
         if self.conv_first.attentions[0].per_graph_features and batch_num_nodes is not None and not isinstance(adj, GraphBatch) \
-                and adj.size(0) > 1:
+                and adj.size(0) > 1 and not drop_on:      # (attention dropout makes a graph's padded rows differ: no packing)
             x, adj = self.packed_batch(x, adj, batch_num_nodes)
         g = _padded_batch(adj)
         x = self.gcn_forward(x, g, self.conv_first, self.conv_block, self.conv_last)       # [B,N,E] ([rows,E] packed)

@@ -1,0 +1,194 @@
+"""One GAT layer (all heads) on the fused kernels of csrc/gat_fused.hip — DGATHead / DGATLayer of
+Code/sage+gat+diffpool/encoders_GAT.py:29-49, 68-84 in two launches forward (packed projection, attention + aggregation +
+ELU) and four backward (column kernel, score row sums, dW' blocks + their reduction, dx), plus ONE pack and ONE unpack launch
+per step for the parameters of all layers.
+
+The heads' (w, a) are packed into W' = [W_0 | .. | W_{H-1} | W_h a1_h | W_h a2_h] so that the projection hp = x W' carries the
+attention scalars a1 . h_i, a2 . h_j (:35-36) as 2H extra columns; their gradients return through dW' and are folded back onto
+(w_h, a_h) by the unpack.  Attention dropout (:42) is a Philox mask regenerated in the backward.
+
+Taken when the kernels support the head shape (tsgnn_gat_fused_supported), every graph has its own features (B == 1 or
+per_graph_features) and the edge-less columns of every graph can be listed (att._isolated_list).  Everything else — the T4
+broadcast of graph 0's features at B > 1, padded batches with hundreds of edge-less columns — stays on the per-op path of
+attention.py."""
+import os
+
+import numpy as np
+import torch
+
+from . import _native as nat
+from . import attention as att
+from . import message_passing as mp
+
+FUSED = os.environ.get("TSGNN_GAT_FUSED", "1") != "0"
+_LMAX, _HMAX = 4, 8
+
+
+def _f32(*shape, device):
+    return torch.empty(*shape, dtype=torch.float32, device=device)
+
+
+def packed_width(H, Fo):
+    return (H * Fo + 2 * H + 3) // 4 * 4
+
+
+def heads_ok(heads):
+    h0 = heads[0]
+    return (FUSED and h0.w.is_cuda and 1 <= len(heads) <= _HMAX and len(heads) * h0.output_dim <= 2048
+            and all(hd.w.data_ptr() % 16 == 0 and hd.w.is_contiguous() for hd in heads)
+            and all(hd.input_dim == h0.input_dim and hd.output_dim == h0.output_dim for hd in heads)
+            and bool(nat.lib().tsgnn_gat_fused_supported(len(heads), int(h0.output_dim))))
+
+
+def batch_ok(g, rows, H, dropout_on):
+    """the edge-less columns of g can be listed for the kernels (or there are none)"""
+    rp_t, _, _ = g.transpose_map()
+    iso = att._isolated_columns(g, rp_t, rows, H)
+    ragged = getattr(g, "row_mult", None) is not None
+    if dropout_on and ragged:
+        return False                       # one representative per graph is exact only while all of its copies stay identical
+    lst = att._isolated_list(g, iso, force=dropout_on)
+    return lst is not None or att.isolated_count(g) == 0
+
+
+def _desc(layers, ptrs):
+    """layers: [(H, Fin, Fo, Ns, w tensors, a tensors)], ptrs: [(wp, gw, ga)] -> host int64 description"""
+    words = int(nat.lib().tsgnn_gat_pack_desc_words())
+    d = np.zeros(1 + len(layers) * words, dtype=np.int64)
+    d[0] = len(layers)
+    for i, ((H, Fin, Fo, Ns, ws, as_), (wp, gw, ga)) in enumerate(zip(layers, ptrs)):
+        o = 1 + i * words
+        d[o:o + 4] = (H, Fin, Fo, Ns)
+        d[o + 4] = wp.data_ptr()
+        d[o + 5] = gw.data_ptr() if gw is not None else 0
+        d[o + 6] = ga.data_ptr() if ga is not None else 0
+        for h in range(H):
+            d[o + 7 + h] = ws[h].data_ptr()
+            d[o + 7 + _HMAX + h] = as_[h].data_ptr()
+    return d
+
+
+class _PackLayers(torch.autograd.Function):
+    """(w_0.., a_0..) of every layer -> the layers' W' in ONE launch; backward: all 2H parameter gradients of all layers from
+    their dW' in ONE launch."""
+
+    @staticmethod
+    def forward(ctx, nheads, *params):
+        layers, k = [], 0
+        for H in nheads:
+            ws = [p.detach().contiguous() for p in params[k:k + H]]
+            as_ = [p.detach().contiguous() for p in params[k + H:k + 2 * H]]
+            k += 2 * H
+            Fin, Fo = int(ws[0].size(0)), int(ws[0].size(1))
+            layers.append((H, Fin, Fo, packed_width(H, Fo), ws, as_))
+        dev = params[0].device
+        outs = [_f32(L[1], L[3], device=dev) for L in layers]
+        d = _desc(layers, [(o, None, None) for o in outs])
+        nat.call("gat_pack_f32", d.ctypes.data)
+        ctx.layers = layers
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dwps):
+        layers = ctx.layers
+        dev = layers[0][4][0].device
+        ptrs, res = [], []
+        for L, dwp in zip(layers, dwps):
+            H, Fin, Fo, Ns = L[:4]
+            if dwp is None:
+                dwp = torch.zeros(Fin, Ns, dtype=torch.float32, device=dev)
+            ptrs.append((dwp.contiguous(), _f32(H, Fin, Fo, device=dev), _f32(H, 2 * Fo, device=dev)))
+        d = _desc(layers, ptrs)
+        nat.call("gat_unpack_f32", d.ctypes.data)
+        for L, (_, gw, ga) in zip(layers, ptrs):
+            H, Fo = L[0], L[2]
+            res += [gw[h] for h in range(H)] + [ga[h].reshape(2 * Fo, 1) for h in range(H)]
+        return (None,) + tuple(res)
+
+
+def pack_layers(layers_heads):
+    """layers_heads: list (<= 4) of lists of DGATHead -> tuple of W' (one per layer)"""
+    params = []
+    for heads in layers_heads:
+        params += [hd.w for hd in heads] + [hd.a for hd in heads]
+    return _PackLayers.apply(tuple(len(h) for h in layers_heads), *params)
+
+
+def wgrad_blocks(z, K_in, du):
+    """dW[K_in, N] = z[:, :K_in]^T du (N = du.size(1) <= 512) in two launches; None if the shape is not taken"""
+    R, N = int(du.size(0)), int(du.size(1))
+    nslab = np.zeros(1, dtype=np.int32)
+    rps = np.zeros(1, dtype=np.int64)
+    need = np.zeros(1, dtype=np.int64)
+    nat.call_nostream("wgrad_blocks_plan", R, int(K_in), N, int(z.stride(0)), int(du.stride(0)), nslab.ctypes.data, rps.ctypes.data,
+                      need.ctypes.data)
+    if int(nslab[0]) <= 0 or z.data_ptr() % 16 or du.data_ptr() % 16:
+        return None
+    ws = _f32(int(need[0]), device=du.device)
+    dw = _f32(int(K_in), N, device=du.device)
+    nat.call("wgrad_blocks_f32", z, z.stride(0), du, du.stride(0), R, int(K_in), N, int(nslab[0]), int(rps[0]), ws, dw, dw.stride(0))
+    return dw
+
+
+class _GatLayer(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, wp, g, H, Fo, slope, mean_heads, apply_elu, drop_p, seed):
+        """x [R, >= Fin] (16-byte rows), wp [Fin, Ns] -> y [R, H*Fo] ([R, Fo] with mean_heads)"""
+        R, Fin, Ns, C = int(x.size(0)), int(wp.size(0)), int(wp.size(1)), H * Fo
+        dev = x.device
+        hp = _f32(R, Ns, device=dev)
+        nat.call("rowgemm_f32", x, x.stride(0), wp, wp.stride(0), 0, None, hp, hp.stride(0), None, R, Fin, Ns, 0, 0)
+        rp_t, col_t, src_e_t = g.transpose_map()
+        iso = att._isolated_columns(g, rp_t, R, H)
+        lst = att._isolated_list(g, iso, force=drop_p > 0.0)
+        y = _f32(R, Fo if mean_heads else C, device=dev)
+        stat = _f32(R, H, 2, device=dev)
+        i_idx, i_w, i_ptr = lst if lst is not None else (None, None, None)
+        nat.call("gat_attn_fwd_f32", hp, hp.stride(0), g.rowptr, g.col, rp_t, col_t, R, H, Fo, float(slope), att._row_seg(g),
+                 int(g.nmax), i_idx, i_w, i_ptr, 1.0 / max(int(g.nmax), 1), int(mean_heads), int(apply_elu), float(drop_p),
+                 int(seed), stat, y, y.stride(0))
+        ctx.cfg = (g, H, Fo, slope, mean_heads, apply_elu, drop_p, seed, Fin)
+        ctx.save_for_backward(x, wp, hp, y, iso, stat)
+        ctx.lst = lst
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wp, hp, y, iso, stat = ctx.saved_tensors
+        g, H, Fo, slope, mean_heads, apply_elu, drop_p, seed, Fin = ctx.cfg
+        lst = ctx.lst
+        R, Ns, C = int(x.size(0)), int(wp.size(1)), H * Fo
+        dev = x.device
+        dy = dy.contiguous()
+        rp_t, col_t, src_e_t = g.transpose_map()
+        nnz = max(int(g.nnz), 1)
+        dhp = _f32(R, Ns, device=dev)
+        t1, t2, S = _f32(nnz, H, device=dev), _f32(nnz, H, device=dev), _f32(R, H, device=dev)
+        i_idx, i_w, i_ptr = lst if lst is not None else (None, None, None)
+        us = 1.0 / max(int(g.nmax), 1)
+        dupart = _f32(int(g.B) * int(nat.lib().tsgnn_gat_bwd_parts(int(g.B))) * C, device=dev) if lst is not None else None
+        nat.call("gat_attn_bwd_f32", hp, hp.stride(0), y, y.stride(0), dy, dy.stride(0), rp_t, col_t, R, H, Fo, float(slope),
+                 int(mean_heads), int(apply_elu), g.graph_ptr, int(g.B), i_idx, i_w, i_ptr, iso if lst is not None else None, H,
+                 us, float(drop_p), int(seed), stat, dhp, Ns, t1, t2, S, dupart)
+        fin = lst is not None and drop_p == 0.0                 # (with dropout the backward completes the listed columns itself)
+        nat.call("gat_score_rowsum_f32", g.rowptr, g.col, att._inverse_entry_map(g, src_e_t), t1, t2, S, R, H, dhp, dhp.stride(0), C,
+                 dupart if fin else None, int(g.B), i_idx if fin else None, i_w if fin else None, i_ptr if fin else None, us)
+        dwp = wgrad_blocks(x, Fin, dhp)
+        if dwp is None:
+            dwp = mp.gemm_tn_splitk(x, Fin, dhp)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _f32(R, int(x.size(1)), device=dev)
+            if x.size(1) > Fin:
+                dx[:, Fin:].zero_()
+            nat.call("rowgemm_f32", dhp, dhp.stride(0), wp, wp.stride(0), 1, None, dx, dx.stride(0), None, R, Ns, Fin, 0, 0)
+        return dx, dwp, None, None, None, None, None, None, None, None
+
+
+def gat_layer(x, wp, g, H, Fo, slope, mean_heads, apply_elu, drop_p=0.0, seed=0):
+    return _GatLayer.apply(x, wp, g, int(H), int(Fo), float(slope), bool(mean_heads), bool(apply_elu), float(drop_p), int(seed))
+
+
+def new_seed():
+    """a fresh 63-bit seed from torch's CPU generator (follows torch.manual_seed; no device round trip)"""
+    return int(torch.empty((), dtype=torch.int64).random_().item())
