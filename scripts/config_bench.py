@@ -73,7 +73,7 @@ x1, adj1 = x1.to(dev), adj1.to(dev)
 gpad = GraphBatch.from_dense(adj1, layout="padded"); gpad.transpose_map()
 lab1 = torch.tensor([1], device=dev)
 def step_gat():
-    gat.zero_grad(set_to_none=True); gat.loss(gat(x1, gpad)[1], lab1).backward()
+    gat.zero_grad(set_to_none=True); gat.loss(gat(x1, adj1, hb1["sizes"])[1], lab1).backward()
 t = timeit(step_gat)
 tg = graph_us(step_gat)
 print("cfg3 DD GAT-2L 4 heads h64, one graph per step (Nmax 1000): %.0f us/step eager, %s us/step hipGraph -> %.0f graphs/s" % (t, "%.0f" % tg if tg else "n/a", 1 / (tg or t) * 1e6))

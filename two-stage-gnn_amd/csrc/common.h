@@ -28,7 +28,10 @@ __device__ long long g_trace[4096 * 16];
 #define TR_ON_ ((threadIdx.x & 63) == 0 && (blockIdx.x + gridDim.x * blockIdx.y) < 4096 / TSGNN_TRACE_WPB)
 #define TR(slot) do { if (TR_ON_) { TR_SLOT_(slot) = __builtin_readcyclecounter(); if ((slot) == 0) TR_SLOT_(14) = wall_clock64(); } } while (0)
 #define TR_END() do { if (TR_ON_) TR_SLOT_(15) = wall_clock64(); } while (0)   /* 100 MHz, common to the whole device */
+/* stamp once the 32-bit value v has ARRIVED (the read makes the wave wait for the load that produces it) */
+#define TR_AFTER(v, slot) do { if (__builtin_amdgcn_readfirstlane(v) != 0x7fffffff) TR(slot); } while (0)
 #else
+#define TR_AFTER(v, slot) do { } while (0)
 #define TR(slot) do { } while (0)
 #define TR_END() do { } while (0)
 #endif

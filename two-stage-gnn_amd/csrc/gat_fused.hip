@@ -115,17 +115,63 @@ __global__ __launch_bounds__(256, GAT_WAVES_PER_SIMD) void gat_attn_fwd_kernel(G
   const int co = live ? 4 * lane : 0;
   const float* __restrict__ hp = a.hp;
   const int64_t ldh = a.ldh;
+  TR(0);
   const int e0 = a.rowptr[r], e1 = a.rowptr[r + 1];
   const int EB = min(8, 64 / H);              // entries per batch: lane p = (entry p / H, head p % H) computes one alpha
   const int pk = lane / H, ph = lane - pk * H;
   const float srow_i = hp[r * ldh + C + ph];
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  // uniform term: the edge-less columns j of this row's graph, alpha_ij = 1/N each (a ghost representative counts Nmax - n_b times)
+  int q0 = 0, q1 = 0;
   if (a.iso_ptr) {
     const int b = a.row_graph ? a.row_graph[r] : (int)(r / a.nmax);
-    const int q0 = a.iso_ptr[b], q1 = a.iso_ptr[b + 1];
-    for (int q = q0; q < q1; q += 4) {
+    q0 = a.iso_ptr[b]; q1 = a.iso_ptr[b + 1];
+  }
+  int jq = 0;
+  float wq = 0.f;
+  if (q0 < q1) { jq = a.iso_idx[q0]; wq = a.iso_w[q0]; }    // (the first listed column: requested with the edge chain)
+  TR(1);
+  for (int eb = e0; eb < e1; eb += EB) {
+    const int cnt = min(EB, e1 - eb);                       // uniform over the wave
+    const bool has = pk < cnt;
+    const int j = a.col[has ? eb + pk : eb];
+    TR_AFTER(j, 2);                                         // column ids arrived
+    float4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {                           // the batch's feature rows: requested before the statistics chain
+      v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k < cnt) {
+        const int jk = __shfl(j, k * H, 64);
+        v[k] = ldg4_(hp + (int64_t)jk * ldh + co);
+      }
+    }
+    const float scol_j = hp[(int64_t)j * ldh + C + H + ph];
+    const float2 st = a.stat[(int64_t)j * H + ph];           // (m, 1 / Z) of column j
+    float alpha = 0.f;
+    if (has) {
+      alpha = __expf(lrelu_(srow_i + scol_j, a.slope) - st.x) * st.y;
+      if (DROP) alpha *= drop_mult(a.drop, (unsigned)r, (unsigned)j, ph);
+    }
+    TR_AFTER(__float_as_int(alpha), 3);                     // statistics and scalars arrived
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (k < cnt) {
+        const float al = __shfl(alpha, k * H + h, 64);
+        acc.x = fmaf(al, v[k].x, acc.x); acc.y = fmaf(al, v[k].y, acc.y);
+        acc.z = fmaf(al, v[k].z, acc.z); acc.w = fmaf(al, v[k].w, acc.w);
+      }
+    }
+  }
+
+  // uniform term: the edge-less columns j of this row's graph, alpha_ij = 1/N each (a ghost representative counts Nmax - n_b times).
+  // Its list pointers are requested before the edge loop (q0, q1 above), its rows after it: the two chains overlap.
+  if (q0 < q1) {                                            // the first listed column (its id came in with the edge chain)
+    const float4 vq = ldg4_(hp + (int64_t)jq * ldh + co);
+    const float wk = (DROP ? drop_mult(a.drop, (unsigned)r, (unsigned)jq, h) : 1.f) * (wq * a.uscale);
+    acc.x = fmaf(wk, vq.x, acc.x); acc.y = fmaf(wk, vq.y, acc.y); acc.z = fmaf(wk, vq.z, acc.z); acc.w = fmaf(wk, vq.w, acc.w);
+  }
+  if (q0 + 1 < q1) {
+    for (int q = q0 + 1; q < q1; q += 4) {
       int jj[4];
       float w[4];
       float4 v[4];
@@ -146,36 +192,7 @@ __global__ __launch_bounds__(256, GAT_WAVES_PER_SIMD) void gat_attn_fwd_kernel(G
     }
   }
 
-  for (int eb = e0; eb < e1; eb += EB) {
-    const int cnt = min(EB, e1 - eb);                       // uniform over the wave
-    const bool has = pk < cnt;
-    const int j = a.col[has ? eb + pk : eb];
-    float4 v[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {                           // the batch's feature rows: requested before the statistics chain
-      v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (k < cnt) {
-        const int jk = __shfl(j, k * H, 64);
-        v[k] = ldg4_(hp + (int64_t)jk * ldh + co);
-      }
-    }
-    const float scol_j = hp[(int64_t)j * ldh + C + H + ph];
-    const float2 st = a.stat[(int64_t)j * H + ph];           // (m, 1 / Z) of column j
-    float alpha = 0.f;
-    if (has) {
-      alpha = __expf(lrelu_(srow_i + scol_j, a.slope) - st.x) * st.y;
-      if (DROP) alpha *= drop_mult(a.drop, (unsigned)r, (unsigned)j, ph);
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      if (k < cnt) {
-        const float al = __shfl(alpha, k * H + h, 64);
-        acc.x = fmaf(al, v[k].x, acc.x); acc.y = fmaf(al, v[k].y, acc.y);
-        acc.z = fmaf(al, v[k].z, acc.z); acc.w = fmaf(al, v[k].w, acc.w);
-      }
-    }
-  }
-
+  TR_AFTER(__float_as_int(acc.x), 4);                       // feature rows arrived, sums done
   if (a.mean_heads) {                                       // (h_0 + h_1 + ...) / H, then ELU (encoders_GAT.py:78-83)
     float4 s = acc;
     for (int k = 1; k < H; ++k) {
@@ -196,6 +213,8 @@ __global__ __launch_bounds__(256, GAT_WAVES_PER_SIMD) void gat_attn_fwd_kernel(G
     }
     if (live) *reinterpret_cast<float4*>(a.y + r * a.ldy + co) = acc;
   }
+  TR(5);
+  TR_END();
 }
 
 // ---------------------------------------------------------------- backward: one wave per column (+ workgroups per graph)
@@ -230,8 +249,13 @@ __device__ __forceinline__ float4 dpre_row(const GatBwd& a, int64_t i, int lane,
     d.x *= elu_grad_y(yv.x); d.y *= elu_grad_y(yv.y); d.z *= elu_grad_y(yv.z); d.w *= elu_grad_y(yv.w);
   }
   if (a.mean_heads) {
-    const float Hf = (float)a.H;
-    d.x /= Hf; d.y /= Hf; d.z /= Hf; d.w /= Hf;
+    if ((a.H & (a.H - 1)) == 0) {                            // 1 / H is exact: the product equals the quotient
+      const float r = 1.f / (float)a.H;
+      d.x *= r; d.y *= r; d.z *= r; d.w *= r;
+    } else {
+      const float Hf = (float)a.H;
+      d.x /= Hf; d.y /= Hf; d.z /= Hf; d.w /= Hf;
+    }
   }
   return d;
 }
@@ -326,6 +350,7 @@ __global__ __launch_bounds__(256, GAT_BWD_WAVES_PER_SIMD) void gat_attn_bwd_kern
   const int64_t j = (int64_t)xcd_remap(blockIdx.x - a.ngraph_blocks, nreg) * 4 + wid;
   if (j >= a.rows) return;
   const float* __restrict__ hp = a.hp;
+  TR(0);
   const int t0 = a.rp_t[j], t1 = a.rp_t[j + 1];
   const float4 hj = live ? ldg4_(hp + j * ldh + co) : make_float4(0.f, 0.f, 0.f, 0.f);
   const float scol = hp[j * ldh + C + H + h];
@@ -338,6 +363,7 @@ __global__ __launch_bounds__(256, GAT_BWD_WAVES_PER_SIMD) void gat_attn_bwd_kern
     int ii[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) ii[k] = a.col_t[min(t0 + k, t1 - 1)];        // the usual column: every entry id in one round trip
+    TR_AFTER(ii[0], 1);                                      // entry ids arrived
     for (int tb = 0; tb < deg; tb += 4) {
       int i4[4];
       float sr[4];
@@ -352,6 +378,7 @@ __global__ __launch_bounds__(256, GAT_BWD_WAVES_PER_SIMD) void gat_attn_bwd_kern
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         if (tb + k < deg) bwd_entry<LPH, DROP>(a, c, hj, dp[k], sr[k], scol, st.x, st.y, i4[k], j, t0 + tb + k, h, writer);
+      TR_AFTER(__float_as_int(c.S), 2 + min(tb / 4, 2));     // a group of four entries done
     }
   }
   const bool listed = a.iso_row && deg == 0 && a.iso_row[j * a.iso_row_ld] != 0.f;     // its dh comes from the graph's sums
@@ -361,6 +388,8 @@ __global__ __launch_bounds__(256, GAT_BWD_WAVES_PER_SIMD) void gat_attn_bwd_kern
     a.dhp[j * ldh + C + H + h] = c.P1 - c.S * c.P2;          // d s_col[j] = sum_i lrelu' alpha (dalpha - S)
   }
   if (lane < a.Ns - C - 2 * H) a.dhp[j * ldh + C + 2 * H + lane] = 0.f;
+  TR(5);
+  TR_END();
 }
 
 // d s_row[i, h] = sum over row i's entries (i, j) of  t1[e] - t2[e] * S[j]   (the per-entry terms live in A^T entry order: eperm)

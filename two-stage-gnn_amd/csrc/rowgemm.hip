@@ -95,26 +95,50 @@ inline int64_t rowgemm_big_min_rows() {
   return n;
 }
 
+// rows from which products WIDER than one 128-column block (the first GAT projection: 92 -> 264) take the B-stationary kernel on
+// column blocks instead of the column-split row-panel kernel (0 disables)
+inline int64_t rowgemm_big_wide_min_rows() {
+  static const int64_t n = [] {
+    const char* e = getenv("TSGNN_ROWGEMM_BIG_WIDE_ROWS");
+    return e ? (int64_t)atoll(e) : (int64_t)2048;
+  }();
+  return n;
+}
+
 template <int U, bool TRANS_B>
 void launch_big(const RowGemmArgs& g, hipStream_t s) {
   constexpr size_t lds = rowgemm_big_lds_bytes<U, TRANS_B>();
   static const int bpc = [] {                           // resident blocks per CU (registers decide; LDS allows 4)
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rowgemm_big_kernel<U, TRANS_B>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(rowgemm_big_kernel<U, TRANS_B>), 256, lds) != hipSuccess || n < 1) n = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(rowgemm_big_kernel<U, TRANS_B>), 256, lds) != hipSuccess || n < 1) n = 1;
     return n;
   }();
   const unsigned npanels = (unsigned)ceil_div64(g.rows, 32);
-  unsigned grid = (unsigned)device_cu_count() * (unsigned)bpc;
+  const unsigned ny = (unsigned)((g.N + 127) / 128);
+  // a last column block of <= 32 columns (the 2H score columns of a packed GAT projection) is light: only one of its waves
+  // has MFMA work.  The heavy blocks share the CUs; the light ones fill in behind them.
+  const unsigned heavy = (unsigned)(g.N / 128 + ((g.N % 128) > 32 ? 1 : 0));
+  unsigned grid = (unsigned)device_cu_count() * (unsigned)bpc / (heavy ? heavy : 1u);
   if (grid > npanels) grid = npanels;
   if (grid == 0) grid = 1;
+  if (ny > 1) {                                         // equal shares: every block the same number of panels (+- 1)
+    const unsigned per = (npanels + grid - 1) / grid;
+    grid = (npanels + per - 1) / per;
+  }
   TSGNN_KNAME("rowgemm_big_kernel<%d,%s>", U, TRANS_B ? "true" : "false");
-  rowgemm_big_kernel<U, TRANS_B><<<grid, 256, lds, s>>>(g, npanels);
+  rowgemm_big_kernel<U, TRANS_B><<<dim3(grid, ny), 256, lds, s>>>(g, npanels);
 }
 
 template <bool TRANS_B>
 bool try_big(const RowGemmArgs& g, hipStream_t s) {
-  const int64_t mn = rowgemm_big_min_rows();
-  if (mn <= 0 || g.rows < mn || g.N > 128 || g.K > 128 || (TRANS_B && (g.K % 4)) || (g.N % 4)) return false;
+  const bool wide = g.N > 128;
+  const int64_t mn = wide ? rowgemm_big_wide_min_rows() : rowgemm_big_min_rows();
+  // K <= 128: the wave's slice of B fits 64 registers.  (Holding K = 256 costs 128 + 38 accumulation registers, one wave per
+  // SIMD: measured 45 us against 28 us of the column-split row-panel kernel on the 8,518 x 256 x 264 GAT projection.)
+  if (mn <= 0 || g.rows < mn || g.N > 384 || g.K > 128 || (TRANS_B && (g.K % 4)) || (g.N % 4)) return false;
+  if (g.N > 128 && (g.normalize || g.fill_rows > 0 || g.rinv)) return false;     // column blocks: no row epilogue
   if (g.K <= 96) launch_big<12, TRANS_B>(g, s);
   else launch_big<16, TRANS_B>(g, s);
   return true;

@@ -27,6 +27,13 @@ namespace {
 template <int U, bool TRANS_B>   // U = groups of 8 k: K <= 8 U
 __global__ __launch_bounds__(256, TSGNN_BIG_MINBLOCKS) void rowgemm_big_kernel(RowGemmArgs g, unsigned npanels) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (gridDim.y > 1) {                       // column blocks of 128 (products without a row epilogue: N up to 384)
+    const int n0 = (int)blockIdx.y * 128;
+    g.N = min(128, g.N - n0);
+    g.c += n0;
+    if (g.bias) g.bias += n0;
+    g.b += TRANS_B ? (int64_t)n0 * g.ldb : (int64_t)n0;
+  }
   constexpr int LDB = 8 * U;                 // floats per LDS row
   constexpr int QV = U / 4;                  // float4 per thread and panel (8 threads per row)
   float* red = smem + 2 * 32 * LDB;          // [2][32 rows][4 waves]
@@ -122,6 +129,7 @@ __global__ __launch_bounds__(256, TSGNN_BIG_MINBLOCKS) void rowgemm_big_kernel(R
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (32 * wid < g.N) {                                  // (a wave without columns only helps staging: narrow column blocks)
     // A fragments four k-groups at a time, the next four requested before the current sixteen MFMAs issue (32 VGPRs instead
     // of 64 for the whole K: the kernel fits three waves per SIMD)
     constexpr int NCH = U / 4;
@@ -143,6 +151,7 @@ __global__ __launch_bounds__(256, TSGNN_BIG_MINBLOCKS) void rowgemm_big_kernel(R
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ch & 1][q].z, bq[4 * u + 2], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ch & 1][q].w, bq[4 * u + 3], acc, 0, 0, 0);
       }
+    }
     }
     // epilogue, part 1 (registers): + bias, partial row sums of squares over this wave's 32 columns
     const int64_t m0 = (int64_t)p * 32;
