@@ -679,6 +679,26 @@ int tsgnn_head2_bwd_ce_f32(const float* out, int64_t ldo, const float* vec, cons
                            const float* dvec, const float* w1, const float* w2, int B, int P, int E, int C, float* dout, int64_t lddo,
                            float* dw1, float* db1, float* dw2, float* db2, float* normparts, tsgnn_stream_t stream);
 
+/* ---- DiffPool contraction of a pooled level (dense per-graph operands small enough for LDS), one workgroup per graph
+ * (csrc/contract.hip).  Replaces the three bmm's of encoders.py:374-375 and their six backward products. */
+int tsgnn_contract_dense_supported(int N, int K, int F);
+/* X'[b] = S_b^T Z_b (xo [B,K,F]), A'[b] = S_b^T A_b S_b (ao [B,K,K]); t [B,K,N] = S^T A is kept for the backward.
+ * s [B,N,K], z [B,N,F], adj [B,N,N], all contiguous. */
+int tsgnn_contract_dense_fwd_f32(const float* s, const float* z, const float* adj, int B, int N, int K, int F, float* xo, float* ao,
+                                 float* t, tsgnn_stream_t stream);
+/* ds [B,N,K], dz [B,N,F], dadj [B,N,N] (each nullable) from dxo [B,K,F], dao [B,K,K] */
+int tsgnn_contract_dense_bwd_f32(const float* s, const float* z, const float* adj, const float* t, const float* dxo, const float* dao,
+                                 int B, int N, int K, int F, float* ds, float* dz, float* dadj, tsgnn_stream_t stream);
+
+/* backward of the ROW-layout (level 1) contraction X'[b] = S_b^T Z_b, A'[b] = S_b^T (A S)_b (diffpool.py::_ContractRows) in one
+ * launch: dZ = S dX', dS = Z dX'^T + (AS) dA'^T, d(AS) = S dA' for the rows of every slab (slab_row_ptr[nslab + 1]: at most 32
+ * consecutive rows of ONE graph per slab; slab_graph[nslab]); rows [zero_from, zero_to) of the outputs are cleared. */
+int tsgnn_contract_rows_bwd_supported(int K, int F);
+int tsgnn_contract_rows_bwd_f32(const float* S, int64_t ldS, const float* Z, int64_t ldZ, const float* AS, int64_t ldAS,
+                                const float* dxo, const float* dao, const int* slab_row_ptr, const int* slab_graph, int nslab, int K,
+                                int F, float* dZ, int64_t lddZ, float* dS, int64_t lddS, float* dAS, int64_t lddAS,
+                                int64_t zero_from, int64_t zero_to, tsgnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

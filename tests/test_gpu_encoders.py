@@ -272,6 +272,73 @@ def test_diffpool_contract_golden():
     np.testing.assert_allclose(adj.grad.cpu().numpy(), g["gadj"], rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("B,N,K,F,need", [(16, 64, 8, 192, (1, 1, 1)), (3, 50, 7, 36, (1, 1, 1)), (5, 8, 2, 192, (1, 0, 1)),
+                                          (2, 100, 30, 64, (0, 1, 0)), (1, 1, 1, 4, (1, 1, 1))])
+def test_contract_dense_fused_equals_batched_products(B, N, K, F, need, monkeypatch):
+    """the one-workgroup-per-graph contraction (csrc/contract.hip) against the batched-GEMM composition it replaces and fp64:
+    both outputs and the gradients of whichever inputs need one"""
+    from two_stage_gnn_amd import diffpool as dp
+    gen = torch.Generator().manual_seed(B * 1000 + N)
+    s0 = torch.softmax(torch.randn(B, N, K, generator=gen), -1)
+    z0, a0 = torch.randn(B, N, F, generator=gen), (torch.rand(B, N, N, generator=gen) < 0.2).float()
+    gx, ga = torch.randn(B, K, F, generator=gen), torch.randn(B, K, K, generator=gen)
+    res = []
+    for fused in (True, False):
+        monkeypatch.setattr(dp, "FUSED_CONTRACT", fused)
+        s, z, a = (t.clone().cuda().requires_grad_(bool(n)) for t, n in zip((s0, z0, a0), need))
+        xo, ao = dp.diffpool_contract_dense(s, z, a)
+        ((xo * gx.cuda()).sum() + (ao * ga.cuda()).sum()).backward()
+        res.append([xo.detach(), ao.detach()] + [t.grad for t in (s, z, a) if t.grad is not None])
+    sd, zd, ad = (t.double().requires_grad_(bool(n)) for t, n in zip((s0, z0, a0), need))
+    x64 = sd.transpose(1, 2) @ zd
+    a64 = sd.transpose(1, 2) @ ad @ sd
+    ((x64 * gx.double()).sum() + (a64 * ga.double()).sum()).backward()
+    ref = [x64.detach(), a64.detach()] + [t.grad for t in (sd, zd, ad) if t.grad is not None]
+    assert len(res[0]) == len(res[1]) == len(ref)
+    for f, c, r in zip(res[0], res[1], ref):
+        scale = r.abs().max().item() + 1e-12
+        assert (f.cpu().double() - r).abs().max().item() <= 2e-5 * scale
+        assert (f - c).abs().max().item() <= 2e-5 * scale
+
+
+@pytest.mark.parametrize("K,F,sizes,nmax", [(64, 192, [96, 33, 1, 64, 70], 96), (8, 36, [5, 40, 17], 40), (24, 4, [31, 32, 33], 40)])
+def test_contract_rows_backward_fused_equals_ragged_products(K, F, sizes, nmax, monkeypatch):
+    """backward of the row-layout contraction as one launch (csrc/contract.hip) against the four ragged products it replaces
+    and against fp64 dense math: ragged graph sizes (slabs of 32 rows with short tails, a one-node graph), ghost rows zero"""
+    from two_stage_gnn_amd import diffpool as dp, message_passing as mp
+    from two_stage_gnn_amd.graph import GraphBatch
+    B = len(sizes)
+    x, adj, sizes = dense_batch(43, B, nmax, 3, sizes=sizes, p_edge=0.1)
+    gen = torch.Generator().manual_seed(9)
+    s0 = torch.softmax(torch.randn(B, nmax, K, generator=gen), -1)
+    z0 = torch.randn(B, nmax, F, generator=gen)
+    for b, n in enumerate(sizes):
+        s0[b, int(n):] = 0; z0[b, int(n):] = 0
+    gx, ga = torch.randn(B, K, F, generator=gen), torch.randn(B, K, K, generator=gen)
+    g = GraphBatch.from_dense(adj.cuda(), sizes, layout="packed")
+    res = []
+    for fused in (True, False):
+        monkeypatch.setattr(dp, "FUSED_CONTRACT", fused)
+        S = mp.pack_rows(s0.cuda(), g).detach().requires_grad_(True)
+        Z = mp.pack_rows(z0.cuda(), g).detach().requires_grad_(True)
+        xo, ao = dp.diffpool_contract_rows(S, Z, g)
+        ((xo * gx.cuda()).sum() + (ao * ga.cuda()).sum()).backward()
+        res.append((xo.detach(), ao.detach(), S.grad.clone(), Z.grad.clone()))
+    sd, zd = s0.double().requires_grad_(True), z0.double().requires_grad_(True)
+    x64 = sd.transpose(1, 2) @ zd
+    a64 = sd.transpose(1, 2) @ adj.double() @ sd
+    ((x64 * gx.double()).sum() + (a64 * ga.double()).sum()).backward()
+    ref = (x64.detach(), a64.detach(), mp.pack_rows(sd.grad.float().cuda(), g).double().cpu(), mp.pack_rows(zd.grad.float().cuda(), g).double().cpu())
+    for i, (f, c, r) in enumerate(zip(res[0], res[1], ref)):
+        scale = r.abs().max().item() + 1e-12
+        fr, cr = f[: g.n_rows] if i >= 2 else f, c[: g.n_rows] if i >= 2 else c
+        rr = r[: g.n_rows] if i >= 2 else r
+        assert (fr.cpu().double() - rr).abs().max().item() <= 3e-5 * scale, i
+        assert (fr - cr).abs().max().item() <= 3e-5 * scale, i
+        if i >= 2:
+            assert float(f[g.n_rows:].abs().max()) == 0.0 if f.size(0) > g.n_rows else True
+
+
 def test_gat_column_softmax_mass_at_baseline_size():
     """attention aggregation on the full DD-shaped 32-graph batch (packed rows + one ghost representative per graph, 4 heads x
     64): every COLUMN j of the (column-)softmax of encoders_GAT.py:41-45 hands out exactly one unit of mass — to its neighbours

@@ -1,0 +1,365 @@
+// DiffPool contraction of a POOLED level (encoders.py:374-375):  X'[b] = S_b^T Z_b,  A'[b] = S_b^T A_b S_b
+// on dense per-graph operands that are tiny (DD cfg 5, second pooling: 64 nodes, 8 clusters, 192 features).
+//
+// As batched GEMM launches this is 3 launches forward and 6 backward of ~7.6 us each for 0.4 MFLOP per graph — launch latency
+// only.  Here ONE workgroup per graph keeps S, Z, A (and T = S^T A) in LDS and produces both outputs; the backward produces
+// dS, dZ, dA from (dX', dA') the same way:
+//     dZ = S dX' ;  dT = dA' S^T ;  dS = Z dX'^T + T^T dA' + A dT^T ;  dA = S dT
+// LDS rows are padded by one float, so that lanes that walk different rows of one operand hit different banks.
+// Sums run over the contracted index in ascending order with fma: fixed order, bitwise reproducible.
+#include "common.h"
+#include "../../include/tsgnn.h"
+
+namespace {
+
+constexpr int CT_THREADS = 512;
+
+struct CtDims {
+  int N, K, F;              // nodes, clusters, features
+  int ldS, ldZ, ldA, ldT;   // padded LDS row lengths: K+1, F+1, N+1, N+1
+};
+__host__ __device__ inline CtDims ct_dims(int N, int K, int F) { return CtDims{N, K, F, K + 1, F + 1, N + 1, N + 1}; }
+// floats of LDS: S, Z, A, T (+ backward: dX', dA', dT)
+inline size_t ct_lds_floats(int N, int K, int F, bool bwd) {
+  size_t n = (size_t)N * (K + 1) + (size_t)N * (F + 1) + (size_t)N * (N + 1) + (size_t)K * (N + 1);
+  if (bwd) n += (size_t)K * (F + 1) + (size_t)K * (K + 1) + (size_t)K * (N + 1);
+  return n;
+}
+
+__device__ __forceinline__ void ct_load(float* dst, int ld, const float* __restrict__ src, int rows, int cols) {
+  for (int i = threadIdx.x; i < rows * cols; i += CT_THREADS) {
+    const int r = i / cols, c = i - r * cols;
+    dst[r * ld + c] = src[i];
+  }
+}
+
+__global__ __launch_bounds__(CT_THREADS) void contract_dense_fwd_kernel(const float* __restrict__ s, const float* __restrict__ z,
+                                                                        const float* __restrict__ adj, int N, int K, int F,
+                                                                        float* __restrict__ xo, float* __restrict__ ao,
+                                                                        float* __restrict__ t_out) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const CtDims d = ct_dims(N, K, F);
+  float* S = sm;
+  float* Z = S + N * d.ldS;
+  float* A = Z + N * d.ldZ;
+  float* T = A + N * d.ldA;
+  const int b = blockIdx.x;
+  ct_load(S, d.ldS, s + (int64_t)b * N * K, N, K);
+  ct_load(Z, d.ldZ, z + (int64_t)b * N * F, N, F);
+  ct_load(A, d.ldA, adj + (int64_t)b * N * N, N, N);
+  __syncthreads();
+  // X' = S^T Z   [K, F]
+  for (int i = threadIdx.x; i < K * F; i += CT_THREADS) {
+    const int k = i / F, f = i - k * F;
+    float acc = 0.f;
+    for (int n = 0; n < N; ++n) acc = fmaf(S[n * d.ldS + k], Z[n * d.ldZ + f], acc);
+    xo[(int64_t)b * K * F + i] = acc;
+  }
+  // T = S^T A   [K, N]
+  for (int i = threadIdx.x; i < K * N; i += CT_THREADS) {
+    const int k = i / N, m = i - k * N;
+    float acc = 0.f;
+    for (int n = 0; n < N; ++n) acc = fmaf(S[n * d.ldS + k], A[n * d.ldA + m], acc);
+    T[k * d.ldT + m] = acc;
+    t_out[(int64_t)b * K * N + i] = acc;
+  }
+  __syncthreads();
+  // A' = T S    [K, K]
+  for (int i = threadIdx.x; i < K * K; i += CT_THREADS) {
+    const int k = i / K, l = i - k * K;
+    float acc = 0.f;
+    for (int m = 0; m < N; ++m) acc = fmaf(T[k * d.ldT + m], S[m * d.ldS + l], acc);
+    ao[(int64_t)b * K * K + i] = acc;
+  }
+}
+
+__global__ __launch_bounds__(CT_THREADS) void contract_dense_bwd_kernel(const float* __restrict__ s, const float* __restrict__ z,
+                                                                        const float* __restrict__ adj, const float* __restrict__ t,
+                                                                        const float* __restrict__ dxo, const float* __restrict__ dao,
+                                                                        int N, int K, int F, float* __restrict__ ds,
+                                                                        float* __restrict__ dz, float* __restrict__ dadj) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const CtDims d = ct_dims(N, K, F);
+  float* S = sm;
+  float* Z = S + N * d.ldS;
+  float* A = Z + N * d.ldZ;
+  float* T = A + N * d.ldA;
+  float* DX = T + K * d.ldT;           // [K][F+1]
+  float* DA = DX + K * d.ldZ;          // [K][K+1]
+  float* DT = DA + K * d.ldS;          // [K][N+1]
+  const int b = blockIdx.x;
+  ct_load(S, d.ldS, s + (int64_t)b * N * K, N, K);
+  ct_load(DX, d.ldZ, dxo + (int64_t)b * K * F, K, F);
+  ct_load(DA, d.ldS, dao + (int64_t)b * K * K, K, K);
+  if (ds) {
+    ct_load(Z, d.ldZ, z + (int64_t)b * N * F, N, F);
+    ct_load(A, d.ldA, adj + (int64_t)b * N * N, N, N);
+    ct_load(T, d.ldT, t + (int64_t)b * K * N, K, N);
+  }
+  __syncthreads();
+  // dT = dA' S^T   [K, N]
+  for (int i = threadIdx.x; i < K * N; i += CT_THREADS) {
+    const int k = i / N, m = i - k * N;
+    float acc = 0.f;
+    for (int l = 0; l < K; ++l) acc = fmaf(DA[k * d.ldS + l], S[m * d.ldS + l], acc);
+    DT[k * d.ldT + m] = acc;
+  }
+  // dZ = S dX'     [N, F]
+  if (dz) {
+    for (int i = threadIdx.x; i < N * F; i += CT_THREADS) {
+      const int n = i / F, f = i - n * F;
+      float acc = 0.f;
+      for (int k = 0; k < K; ++k) acc = fmaf(S[n * d.ldS + k], DX[k * d.ldZ + f], acc);
+      dz[(int64_t)b * N * F + i] = acc;
+    }
+  }
+  __syncthreads();
+  // dS = Z dX'^T + T^T dA' + A dT^T   [N, K]   (the three terms in this order)
+  if (ds) {
+    for (int i = threadIdx.x; i < N * K; i += CT_THREADS) {
+      const int k = i / N, n = i - k * N;                  // n fastest: lanes walk rows of Z / A (padded: conflict-free)
+      float acc = 0.f;
+      for (int f = 0; f < F; ++f) acc = fmaf(Z[n * d.ldZ + f], DX[k * d.ldZ + f], acc);
+      for (int l = 0; l < K; ++l) acc = fmaf(T[l * d.ldT + n], DA[l * d.ldS + k], acc);
+      for (int m = 0; m < N; ++m) acc = fmaf(A[n * d.ldA + m], DT[k * d.ldT + m], acc);
+      ds[(int64_t)b * N * K + (int64_t)n * K + k] = acc;
+    }
+  }
+  // dA = S dT      [N, N]
+  if (dadj) {
+    for (int i = threadIdx.x; i < N * N; i += CT_THREADS) {
+      const int n = i / N, m = i - n * N;
+      float acc = 0.f;
+      for (int k = 0; k < K; ++k) acc = fmaf(S[n * d.ldS + k], DT[k * d.ldT + m], acc);
+      dadj[(int64_t)b * N * N + i] = acc;
+    }
+  }
+}
+
+constexpr size_t CT_LDS_MAX = 150 * 1024;
+
+// ---------------------------------------------------------------- backward of the level-1 (row-layout) contraction
+// X'[b] = S_b^T Z_b, A'[b] = S_b^T (A S)_b over the real rows of graph b (diffpool.py::_ContractRows).  Its backward is three
+// row-ragged products with the per-graph K x F / K x K gradients,
+//     dZ_b = S_b dX'_b ;  dS_b = Z_b dX'_b^T + (AS)_b dA'_b^T ;  d(AS)_b = S_b dA'_b ,
+// four batched-GEMM launches + three zero fills before.  One workgroup per slab of <= 32 rows of one graph holds dX'_b, dA'_b and
+// the slab's rows of S, Z, AS in LDS (odd row strides: both the row-wise and the transposed fragment reads are conflict-free)
+// and runs the 32 x 32 output tiles as fp32 MFMA jobs (v_mfma_f32_32x32x2_f32); the host deals the jobs to the four waves by
+// cost (longest first), e.g. K = 64, F = 192: two dS tiles of depth 256, six dZ and two d(AS) tiles of depth 64 -> 128 MFMAs per
+// wave.  (A first version with scalar FMAs out of LDS took longer than the launches it replaced.)
+// Rows outside every graph (ghost rows) are zeroed by the trailing blocks.
+typedef float ct_f32x16 __attribute__((ext_vector_type(16)));
+constexpr int CR_KMAX = 64, CR_FMAX = 256, CR_MAXJOBS = 8;
+struct CtRows {
+  const float* S; int64_t ldS; const float* Z; int64_t ldZ; const float* AS; int64_t ldAS;
+  const float* dxo; const float* dao;            // [B, K, F], [B, K, K]
+  const int* slab_row_ptr; const int* slab_graph; int nslab;
+  int K, F;
+  float* dZ; int64_t lddZ; float* dS; int64_t lddS; float* dAS; int64_t lddAS;
+  int64_t zero_from, zero_to;                    // rows [zero_from, zero_to) of the three outputs are cleared
+  signed char job[4][CR_MAXJOBS];                // per wave: job codes, -1 ends.  0..7: dZ tile t; 8..9: d(AS) tile; 10..11: dS tile
+};
+
+// acc += A[32 x depth] . B[depth x 32]:  A[i][k] = ap[i * ald + k];  B[k][n] = bp[k * bks + n * bns], columns n >= nvalid are zero
+__device__ __forceinline__ void ct_mfma(ct_f32x16& acc, const float* ap, int ald, const float* bp, int bks, int bns, int depth, int nvalid) {
+  const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
+  const bool nok = i < nvalid;
+  const float* arow = ap + i * ald + h;
+  const float* bcol = bp + (nok ? i : 0) * bns + h * bks;
+  for (int s0 = 0; s0 < depth; s0 += 16) {               // eight MFMA steps per round: operands first, then the chain
+    float av[8], bv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = s0 + 2 * u;
+      av[u] = k < depth ? arow[k] : 0.f;
+      bv[u] = (k < depth && nok) ? bcol[k * bks] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(256) void contract_rows_bwd_kernel(CtRows a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int K = a.K, F = a.F, tid = threadIdx.x;
+  if ((int)blockIdx.x >= a.nslab) {                      // ghost rows: zeros
+    const int zb = (int)blockIdx.x - a.nslab, nzb = (int)gridDim.x - a.nslab;
+    for (int64_t r = a.zero_from + zb; r < a.zero_to; r += nzb) {
+      for (int c = tid; c < F; c += 256) a.dZ[r * a.lddZ + c] = 0.f;
+      for (int c = tid; c < K; c += 256) { a.dS[r * a.lddS + c] = 0.f; a.dAS[r * a.lddAS + c] = 0.f; }
+    }
+    return;
+  }
+  const int ldx = F + 1, lda = K + 1;
+  float* DX = sm;                       // [K][F + 1]
+  float* DA = DX + K * ldx;             // [K][K + 1]
+  float* Sp = DA + K * lda;             // [32][K + 1]
+  float* Zp = Sp + 32 * lda;            // [32][F + 1]
+  float* Ap = Zp + 32 * ldx;            // [32][K + 1]
+  const int r0 = a.slab_row_ptr[blockIdx.x], r1 = a.slab_row_ptr[blockIdx.x + 1];
+  const int nr = r1 - r0;
+  const int b = a.slab_graph[blockIdx.x];
+  const int F4 = F / 4, K4 = K / 4;
+  {
+    const float* gx = a.dxo + (int64_t)b * K * F;
+    for (int i = tid; i < K * F4; i += 256) {
+      const int k = i / F4, c = i - k * F4;
+      const float4 v = *reinterpret_cast<const float4*>(gx + (int64_t)k * F + 4 * c);
+      float* d = DX + k * ldx + 4 * c;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    const float* ga = a.dao + (int64_t)b * K * K;
+    for (int i = tid; i < K * K4; i += 256) {
+      const int k = i / K4, c = i - k * K4;
+      const float4 v = *reinterpret_cast<const float4*>(ga + (int64_t)k * K + 4 * c);
+      float* d = DA + k * lda + 4 * c;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    for (int i = tid; i < 32 * F4; i += 256) {
+      const int r = i / F4, c = i - r * F4;
+      const float4 v = r < nr ? *reinterpret_cast<const float4*>(a.Z + (int64_t)(r0 + r) * a.ldZ + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      float* d = Zp + r * ldx + 4 * c;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    for (int i = tid; i < 32 * K4; i += 256) {
+      const int r = i / K4, c = i - r * K4;
+      const bool ok = r < nr;
+      const float4 v = ok ? *reinterpret_cast<const float4*>(a.S + (int64_t)(r0 + r) * a.ldS + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 w = ok ? *reinterpret_cast<const float4*>(a.AS + (int64_t)(r0 + r) * a.ldAS + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      float* d = Sp + r * lda + 4 * c;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      float* e = Ap + r * lda + 4 * c;
+      e[0] = w.x; e[1] = w.y; e[2] = w.z; e[3] = w.w;
+    }
+  }
+  __syncthreads();
+  const int wid = tid >> 6, lane = tid & 63, i = lane & 31, h = lane >> 5;
+  for (int q = 0; q < CR_MAXJOBS; ++q) {
+    const int code = a.job[wid][q];                      // uniform over the wave
+    if (code < 0) break;
+    ct_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float* out;
+    int64_t ldo;
+    int t, ncols;
+    if (code < 8) {                                      // dZ tile: S . dX'
+      t = code; ncols = F; out = a.dZ; ldo = a.lddZ;
+      ct_mfma(acc, Sp, lda, DX + 32 * t, ldx, 1, K, F - 32 * t);
+    } else if (code < 10) {                              // d(AS) tile: S . dA'
+      t = code - 8; ncols = K; out = a.dAS; ldo = a.lddAS;
+      ct_mfma(acc, Sp, lda, DA + 32 * t, lda, 1, K, K - 32 * t);
+    } else {                                             // dS tile: Z . dX'^T + AS . dA'^T
+      t = code - 10; ncols = K; out = a.dS; ldo = a.lddS;
+      ct_mfma(acc, Zp, ldx, DX + 32 * t * ldx, 1, ldx, F, K - 32 * t);
+      ct_mfma(acc, Ap, lda, DA + 32 * t * lda, 1, lda, K, K - 32 * t);
+    }
+    const int c = 32 * t + i;
+    if (c < ncols) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m < nr) out[(int64_t)(r0 + m) * ldo + c] = acc[r];
+      }
+    }
+  }
+}
+
+inline size_t ct_rows_lds_floats(int K, int F) { return (size_t)K * (F + 1) + (size_t)K * (K + 1) + 32 * (size_t)(K + 1) * 2 + 32 * (size_t)(F + 1); }
+
+// deal the tile jobs to the four waves: longest processing time first
+inline void ct_rows_jobs(int K, int F, signed char (&job)[4][CR_MAXJOBS]) {
+  int codes[12], cost[12], n = 0;
+  for (int t = 0; t * 32 < K; ++t) { codes[n] = 10 + t; cost[n++] = F + K; }
+  for (int t = 0; t * 32 < F; ++t) { codes[n] = t; cost[n++] = K; }
+  for (int t = 0; t * 32 < K; ++t) { codes[n] = 8 + t; cost[n++] = K; }
+  int load[4] = {0, 0, 0, 0}, cnt[4] = {0, 0, 0, 0};
+  for (int w = 0; w < 4; ++w) for (int q = 0; q < CR_MAXJOBS; ++q) job[w][q] = -1;
+  for (int j = 0; j < n; ++j) {                           // (codes are listed in non-increasing cost order already)
+    int best = 0;
+    for (int w = 1; w < 4; ++w) if (load[w] < load[best]) best = w;
+    job[best][cnt[best]++] = (signed char)codes[j];
+    load[best] += cost[j];
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+/* 1 if the one-workgroup-per-graph contraction kernels take (N nodes, K clusters, F features): operands of a graph fit in LDS */
+int tsgnn_contract_dense_supported(int N, int K, int F) {
+  return (N > 0 && K > 0 && F > 0 && N <= 256 && K <= 256 && F <= 1024 && ct_lds_floats(N, K, F, true) * sizeof(float) <= CT_LDS_MAX) ? 1 : 0;
+}
+
+/* X'[b] = S_b^T Z_b (xo [B,K,F]), A'[b] = S_b^T A_b S_b (ao [B,K,K]), T = S^T A (t [B,K,N], kept for the backward);
+ * s [B,N,K], z [B,N,F], adj [B,N,N] contiguous (encoders.py:374-375) */
+int tsgnn_contract_dense_fwd_f32(const float* s, const float* z, const float* adj, int B, int N, int K, int F, float* xo, float* ao,
+                                 float* t, tsgnn_stream_t stream) {
+  if (!s || !z || !adj || !xo || !ao || !t || B < 0) return TSGNN_EINVAL;
+  if (!tsgnn_contract_dense_supported(N, K, F)) return TSGNN_EUNSUPPORTED;
+  if (B == 0) return TSGNN_OK;
+  const size_t lds = ct_lds_floats(N, K, F, false) * sizeof(float);
+  static size_t attr = 0;
+  if (lds > 64 * 1024 && lds > attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(contract_dense_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CT_LDS_MAX);
+    attr = CT_LDS_MAX;
+  }
+  contract_dense_fwd_kernel<<<(unsigned)B, CT_THREADS, lds, stream>>>(s, z, adj, N, K, F, xo, ao, t);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+/* gradients of the pair above: ds [B,N,K], dz [B,N,F], dadj [B,N,N] (each nullable) from dxo [B,K,F], dao [B,K,K] */
+int tsgnn_contract_dense_bwd_f32(const float* s, const float* z, const float* adj, const float* t, const float* dxo, const float* dao,
+                                 int B, int N, int K, int F, float* ds, float* dz, float* dadj, tsgnn_stream_t stream) {
+  if (!s || !dxo || !dao || B < 0 || (ds && (!z || !adj || !t))) return TSGNN_EINVAL;
+  if (!tsgnn_contract_dense_supported(N, K, F)) return TSGNN_EUNSUPPORTED;
+  if (B == 0 || (!ds && !dz && !dadj)) return TSGNN_OK;
+  const size_t lds = ct_lds_floats(N, K, F, true) * sizeof(float);
+  static size_t attr = 0;
+  if (lds > 64 * 1024 && lds > attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(contract_dense_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CT_LDS_MAX);
+    attr = CT_LDS_MAX;
+  }
+  contract_dense_bwd_kernel<<<(unsigned)B, CT_THREADS, lds, stream>>>(s, z, adj, t, dxo, dao, N, K, F, ds, dz, dadj);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+/* 1 if tsgnn_contract_rows_bwd_f32 takes (K clusters, F features): K % 4 == 0, K <= 64, F % 4 == 0, F <= 256 */
+int tsgnn_contract_rows_bwd_supported(int K, int F) {
+  return (K > 0 && F > 0 && K % 4 == 0 && F % 4 == 0 && K <= CR_KMAX && F <= CR_FMAX) ? 1 : 0;
+}
+
+/* backward of the row-layout contraction X'[b] = S_b^T Z_b, A'[b] = S_b^T (AS)_b:  dZ = S dX', dS = Z dX'^T + AS dA'^T,
+ * dAS = S dA' for the rows of every slab (slab_row_ptr[nslab + 1]: <= 32 consecutive rows of ONE graph each, slab_graph[nslab]);
+ * rows [zero_from, zero_to) of the three outputs are cleared.  16-byte aligned rows. */
+int tsgnn_contract_rows_bwd_f32(const float* S, int64_t ldS, const float* Z, int64_t ldZ, const float* AS, int64_t ldAS,
+                                const float* dxo, const float* dao, const int* slab_row_ptr, const int* slab_graph, int nslab, int K,
+                                int F, float* dZ, int64_t lddZ, float* dS, int64_t lddS, float* dAS, int64_t lddAS,
+                                int64_t zero_from, int64_t zero_to, tsgnn_stream_t stream) {
+  if (!S || !Z || !AS || !dxo || !dao || !slab_row_ptr || !slab_graph || !dZ || !dS || !dAS || nslab < 0 || zero_to < zero_from)
+    return TSGNN_EINVAL;
+  if (!tsgnn_contract_rows_bwd_supported(K, F) || (ldS % 4) || (ldZ % 4) || (ldAS % 4) || (lddZ % 4) || (lddAS % 4) || ldS < K ||
+      ldZ < F || ldAS < K || lddZ < F || lddS < K || lddAS < K ||
+      ((reinterpret_cast<uintptr_t>(S) | reinterpret_cast<uintptr_t>(Z) | reinterpret_cast<uintptr_t>(AS) | reinterpret_cast<uintptr_t>(dxo) |
+        reinterpret_cast<uintptr_t>(dao) | reinterpret_cast<uintptr_t>(dZ) | reinterpret_cast<uintptr_t>(dAS)) & 15))
+    return TSGNN_EUNSUPPORTED;
+  const int64_t nz = zero_to - zero_from;
+  const unsigned zblocks = nz > 0 ? (unsigned)(nz < 64 ? nz : 64) : 0u;
+  if (nslab == 0 && zblocks == 0) return TSGNN_OK;
+  const size_t lds = ct_rows_lds_floats(K, F) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(contract_rows_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CT_LDS_MAX);
+    attr = true;
+  }
+  CtRows a{S, ldS, Z, ldZ, AS, ldAS, dxo, dao, slab_row_ptr, slab_graph, nslab, K, F, dZ, lddZ, dS, lddS, dAS, lddAS, zero_from, zero_to, {}};
+  ct_rows_jobs(K, F, a.job);
+  contract_rows_bwd_kernel<<<(unsigned)nslab + zblocks, 256, lds, stream>>>(a);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+}  // extern "C"

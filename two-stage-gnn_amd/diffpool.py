@@ -6,10 +6,15 @@ A.S is one SpMM and both S^T.(.) products are ragged batched GEMMs over each gra
 reference's dense [B,N,N] @ [B,N,K] bmm is never formed.  Pooled levels (adjacency already dense and small)
 use strided batched GEMMs.
 """
+import os
+
 import torch
 
 from . import _native as nat
 from . import message_passing as mp
+
+
+FUSED_CONTRACT = os.environ.get("TSGNN_FUSED_CONTRACT", "1") != "0"     # pooled-level contraction: one launch each way (contract.hip)
 
 
 def _f32(*shape, device, zero=False):
@@ -88,6 +93,13 @@ class _ContractDense(torch.autograd.Function):
     @staticmethod
     def forward(ctx, s, z, adj):
         s, z, adj = s.contiguous(), z.contiguous(), adj.contiguous()
+        B, N, K, F = s.size(0), s.size(1), s.size(2), z.size(2)
+        ctx.fused = bool(FUSED_CONTRACT and s.is_cuda and nat.lib().tsgnn_contract_dense_supported(int(N), int(K), int(F)))
+        if ctx.fused:                                          # one workgroup per graph, operands in LDS: one launch each way
+            xo, ao, t = _f32(B, K, F, device=s.device), _f32(B, K, K, device=s.device), _f32(B, K, N, device=s.device)
+            nat.call("contract_dense_fwd_f32", s, z, adj, B, N, K, F, xo, ao, t)
+            ctx.save_for_backward(s, z, adj, t)
+            return xo, ao
         xo = _bmm_raw(s, z, True, False)
         t = _bmm_raw(s, adj, True, False)                      # S^T A
         ao = _bmm_raw(t, s, False, False)
@@ -100,6 +112,13 @@ class _ContractDense(torch.autograd.Function):
         dxo, dao = dxo.contiguous(), dao.contiguous()
         ns, nz, na = ctx.needs_input_grad
         ds = dz = dadj = None
+        if ctx.fused:
+            B, N, K, F = s.size(0), s.size(1), s.size(2), z.size(2)
+            ds = torch.empty_like(s) if ns else None
+            dz = torch.empty_like(z) if nz else None
+            dadj = torch.empty_like(adj) if na else None
+            nat.call("contract_dense_bwd_f32", s, z, adj, t, dxo, dao, B, N, K, F, ds, dz, dadj)
+            return ds, dz, dadj
         if nz:
             dz = _bmm_raw(s, dxo, False, False)                # X' = S^T Z : dZ = S dX'
         if ns or na:
@@ -148,6 +167,22 @@ def _ragged_nn(X, Y, g, trans_y, out_cols, rows, out=None):
     return out
 
 
+def _slabs32(g):
+    """(slab_row_ptr, slab_graph, nslab) of 32-row slabs, cached on the graph (row_slabs itself caches one slab size only)"""
+    c = getattr(g, "_slabs32", None)
+    if c is None:
+        import numpy as np
+        starts, graphs, off = [], [], 0
+        for b, n in enumerate(g.sizes):
+            n = int(n)
+            for r in range(off, off + n, 32):
+                starts.append(r); graphs.append(b)
+            off += n
+        c = g._slabs32 = (torch.from_numpy(np.asarray(starts + [off], dtype=np.int32)).to(g.device),
+                          torch.from_numpy(np.asarray(graphs if graphs else [0], dtype=np.int32)).to(g.device), len(starts))
+    return c
+
+
 class _ContractRows(torch.autograd.Function):
     """X'[b] = S_b^T Z_b ;  A'[b] = S_b^T (A S)_b   over the real rows of every graph."""
 
@@ -167,6 +202,16 @@ class _ContractRows(torch.autograd.Function):
         g = ctx.g
         dxo, dao = dxo.contiguous(), dao.contiguous()
         R, K, F = S.size(0), S.size(1), Z.size(1)
+        if (FUSED_CONTRACT and S.is_cuda and nat.lib().tsgnn_contract_rows_bwd_supported(int(K), int(F)) and Z.stride(0) % 4 == 0
+                and S.stride(0) % 4 == 0 and all(t.data_ptr() % 16 == 0 for t in (S, Z, AS, dxo, dao))):
+            # the three row-ragged products (+ their zero fills) as one launch: one workgroup per 32-row slab of one graph
+            srp, slab_graph, nslab = _slabs32(g)
+            dZ, dS, dAS = _f32(R, F, device=S.device), _f32(R, K, device=S.device), _f32(R, K, device=S.device)
+            nat.call("contract_rows_bwd_f32", S, S.stride(0), Z, Z.stride(0), AS, AS.stride(0), dxo, dao, srp, slab_graph, nslab, K, F,
+                     dZ, dZ.stride(0), dS, dS.stride(0), dAS, dAS.stride(0), g.n_rows, R)
+            rp, col, val = g.transposed()
+            mp.spmm_raw(rp, col, val, dAS, g.total_rows, out=dS, accumulate=True)     # AS = A S  : dS += A^T d(AS)
+            return dS, dZ, None
         dZ = _ragged_nn(S, dxo, g, False, F, R)                     # dZ_b = S_b dX'_b
         dS = _ragged_nn(Z, dxo, g, True, K, R)                      # S^T Z     : dS_b  = Z_b dX'_b^T
         _ragged_nn(AS, dao, g, True, K, R, out=dS)                  # S^T (AS)  : dS_b += (AS)_b dA'_b^T   (accumulated in place)
