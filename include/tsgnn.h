@@ -287,10 +287,11 @@ int tsgnn_readout_max_fwd_f32(const int* graph_ptr, const int* slot_count, int B
 /* dx[arg[b,f], f] += dout[b,f] (dx pre-initialised by the caller) */
 int tsgnn_readout_max_bwd_f32(const float* dout, int64_t ldo, const int* arg, int B, int F, const float* x, int64_t ldx_in,
                               int relu, int64_t n_real, float* dx, int64_t ldx, tsgnn_stream_t stream);
-/* the same for batches without ghost rows: a dense pass that writes every element of dx[rows, F] (no zero fill, no atomics);
- * row_graph[rows] = graph of each row.  F % 4 == 0, 16-byte rows. */
-int tsgnn_readout_max_bwd_rows_f32(const float* dout, int64_t ldo, const int* arg, const int* row_graph, int F, int64_t rows, float* dx,
-                                   int64_t ldx, tsgnn_stream_t stream);
+/* the same as a dense pass that writes every element of dx[rows_total, F] (no zero fill, no atomics): rows [0, rows) can hold a
+ * maximum (row_graph[rows] = their graphs) — all rows of a batch without ghost rows, or the real rows when the caller discards the
+ * ghost rows' gradient; add (nullable): a second gradient of the same tensor, summed in the same pass.  F % 4 == 0, 16-byte rows. */
+int tsgnn_readout_max_bwd_rows_f32(const float* dout, int64_t ldo, const int* arg, const int* row_graph, int F, int64_t rows,
+                                   int64_t rows_total, const float* add, int64_t ldadd, float* dx, int64_t ldx, tsgnn_stream_t stream);
 
 /* padded [B,nmax,F] (graph_sampler.py:110-114) <-> packed rows */
 int tsgnn_pack_rows_f32(const float* src, int nmax, int F, const int* row_graph, const int* row_slot, int64_t n_real,

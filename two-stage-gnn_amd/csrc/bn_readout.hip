@@ -294,19 +294,25 @@ __global__ void readout_max_bwd(const float* __restrict__ dout, int64_t ldo, con
 }
 
 // the same as a dense pass for batches WITHOUT ghost rows: every element of dx is written (no zero fill beforehand, no atomics):
-// dx[r, f] = (arg[graph(r), f] == r) ? dout[graph(r), f] : 0
+// dx[r, f] = (arg[graph(r), f] == r ? dout[graph(r), f] : 0) + (add ? add[r, f] : 0);  rows [rows, rows_total) (ghost rows whose
+// gradient the caller discards, or none) get add[r, f] or 0.  `add` is the gradient that reaches the same tensor through its
+// other consumer (the DiffPool contraction reads the embeddings the readout reads): one pass instead of fill + scatter + add.
 __global__ void readout_max_bwd_rows(const float* __restrict__ dout, int64_t ldo, const int* __restrict__ arg, const int* __restrict__ row_graph,
-                                     int F4, int64_t rows, float* __restrict__ dx, int64_t ldx) {
+                                     int F4, int64_t rows, int64_t rows_total, const float* __restrict__ add, int64_t ldadd,
+                                     float* __restrict__ dx, int64_t ldx) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= rows * F4) return;
+  if (i >= rows_total * F4) return;
   const int64_t r = i / F4;
   const int c = 4 * (int)(i - r * F4);
-  const int b = row_graph[r];
-  const int4 w = *reinterpret_cast<const int4*>(arg + (int64_t)b * 4 * F4 + c);
-  const float4 g = *reinterpret_cast<const float4*>(dout + (int64_t)b * ldo + c);
-  const int r32 = (int)r;
-  *reinterpret_cast<float4*>(dx + r * ldx + c) = make_float4(w.x == r32 ? g.x : 0.f, w.y == r32 ? g.y : 0.f, w.z == r32 ? g.z : 0.f,
-                                                             w.w == r32 ? g.w : 0.f);
+  float4 o = add ? *reinterpret_cast<const float4*>(add + r * ldadd + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  if (r < rows) {
+    const int b = row_graph[r];
+    const int4 w = *reinterpret_cast<const int4*>(arg + (int64_t)b * 4 * F4 + c);
+    const float4 g = *reinterpret_cast<const float4*>(dout + (int64_t)b * ldo + c);
+    const int r32 = (int)r;
+    o.x += w.x == r32 ? g.x : 0.f; o.y += w.y == r32 ? g.y : 0.f; o.z += w.z == r32 ? g.z : 0.f; o.w += w.w == r32 ? g.w : 0.f;
+  }
+  *reinterpret_cast<float4*>(dx + r * ldx + c) = o;
 }
 
 // ---------------------------------------------------------------- padded <-> packed rows, ghost masking
@@ -428,14 +434,19 @@ int tsgnn_readout_max_bwd_f32(const float* dout, int64_t ldo, const int* arg, in
   return TSGNN_OK;
 }
 
-/* backward of the max readout for batches without ghost rows: writes EVERY element of dx[rows, F] (no fill, no atomics) */
-int tsgnn_readout_max_bwd_rows_f32(const float* dout, int64_t ldo, const int* arg, const int* row_graph, int F, int64_t rows, float* dx,
-                                   int64_t ldx, tsgnn_stream_t stream) {
-  if (!dout || !arg || !row_graph || !dx || F <= 0 || rows < 0 || ldo < F || ldx < F) return TSGNN_EINVAL;
-  if ((F % 4) || (ldo % 4) || (ldx % 4) || ((reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(arg) | reinterpret_cast<uintptr_t>(dx)) & 15))
+/* backward of the max readout as a dense pass: writes EVERY element of dx[rows_total, F] (no fill, no atomics).  rows: the rows
+ * that can hold a maximum (all of them for batches without ghost rows; the real rows when the caller discards the ghost rows'
+ * gradient); add (nullable): a second gradient of the same tensor, summed in the same pass. */
+int tsgnn_readout_max_bwd_rows_f32(const float* dout, int64_t ldo, const int* arg, const int* row_graph, int F, int64_t rows,
+                                   int64_t rows_total, const float* add, int64_t ldadd, float* dx, int64_t ldx, tsgnn_stream_t stream) {
+  if (!dout || !arg || !row_graph || !dx || F <= 0 || rows < 0 || rows_total < rows || ldo < F || ldx < F || (add && ldadd < F))
+    return TSGNN_EINVAL;
+  if ((F % 4) || (ldo % 4) || (ldx % 4) || (add && (ldadd % 4)) ||
+      ((reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(arg) | reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(add)) & 15))
     return TSGNN_EUNSUPPORTED;
-  if (rows == 0) return TSGNN_OK;
-  readout_max_bwd_rows<<<(unsigned)ceil_div64(rows * (F / 4), 256), 256, 0, stream>>>(dout, ldo, arg, row_graph, F / 4, rows, dx, ldx);
+  if (rows_total == 0) return TSGNN_OK;
+  readout_max_bwd_rows<<<(unsigned)ceil_div64(rows_total * (F / 4), 256), 256, 0, stream>>>(dout, ldo, arg, row_graph, F / 4, rows, rows_total,
+                                                                                             add, ldadd, dx, ldx);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }

@@ -45,6 +45,7 @@ def _batch_from_dense(adj, sizes, layout):
 FUSED_HEAD = True              # the two chained nn.Linear after the readout as one HIP launch (+1 backward)
 FUSED_DENSE_POST = True       # pooled DiffPool levels: transform + normalise + ReLU + slot BN as one node
 FUSED_DENSE_STACK = True    # pooled DiffPool levels: the whole GCN stack as one autograd node (dense_stack.py)
+READOUT_PASS = True            # DiffPool: readout backward and the contraction's gradient of the same embeddings in one pass
 FUSED_STACK = True             # GcnEncoderGraph: run the conv stack as one fused autograd node when it qualifies
 DENSE_ADJ_MAX_NODES = 128      # at or below this many nodes per graph a dense batched MFMA product is used
 
@@ -392,7 +393,13 @@ class SoftPoolingGcnEncoder(GcnEncoderGraph):
         x_a = x if same_input else (mp.pack_rows(x_a, g, (x_a.size(2) + 3) // 4 * 4 if g.layout == "packed" else None)
                                     if x_a.dim() == 3 else x_a)
         emb = self.gcn_forward_rows(x, g, self.conv_first, self.conv_block, self.conv_last, mask_ghost=masked)
-        out_all = [mp.readout_max(emb, g)]
+        if self.num_pooling > 0 and READOUT_PASS:
+            # the embeddings feed the readout AND the contraction: one backward pass sums both gradients (mp._ReadoutMax);
+            # masked: the ghost rows of `emb` are constants (zeros), their gradient is discarded by the stack's backward
+            ro, emb = mp.readout_max_pass(emb, g, ghost_unused=bool(masked and g.n_ghost))
+            out_all = [ro]
+        else:
+            out_all = [mp.readout_max(emb, g)]
         dense_x = dense_adj = None
         a_next = None
         for i in range(self.num_pooling):
@@ -430,7 +437,12 @@ class SoftPoolingGcnEncoder(GcnEncoderGraph):
                 emb_dense, gd = self.gcn_forward_dense(dense_x, dense_adj, self.conv_first_after_pool[i],
                                                        self.conv_block_after_pool[i], self.conv_last_after_pool[i])
             Bq, Kq, Cq = emb_dense.shape
-            out_all.append(mp.readout_max(emb_dense.reshape(Bq * Kq, Cq), gd))
+            if i + 1 < self.num_pooling and READOUT_PASS:
+                ro, e2 = mp.readout_max_pass(emb_dense.reshape(Bq * Kq, Cq), gd)
+                emb_dense = e2.reshape(Bq, Kq, Cq)
+                out_all.append(ro)
+            else:
+                out_all.append(mp.readout_max(emb_dense.reshape(Bq * Kq, Cq), gd))
         output = torch.cat(out_all, dim=1) if self.concat else out_all[-1]
         return self._heads(output)
 

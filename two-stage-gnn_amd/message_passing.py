@@ -569,10 +569,14 @@ def bn_slots(v, g, relu=True, bn=True, per_graph=False):
 
 # ----------------------------------------------------------------------------- max readout over node slots
 class _ReadoutMax(torch.autograd.Function):
-    """out[b] = max over ALL nmax node slots of graph b (ghost rows included) — encoders.py:183 (trap T5)."""
+    """out[b] = max over ALL nmax node slots of graph b (ghost rows included) — encoders.py:183 (trap T5).
+    passthrough: also returns x itself as a second differentiable output for the OTHER consumer of the same tensor (DiffPool's
+    contraction reads the embeddings the readout reads): the backward then receives both gradients at once and sums them in the
+    pass that scatters the readout's (no zero fill, no scatter launch of its own, no element-wise add by autograd).
+    ghost_unused: the caller discards the gradient of the ghost rows (masked embeddings) — the dense pass may be used with them."""
 
     @staticmethod
-    def forward(ctx, x, g):
+    def forward(ctx, x, g, passthrough, ghost_unused):
         x = _check(x, g.total_rows)
         F = x.size(1)
         out = _f32(g.B, F, device=x.device)
@@ -582,30 +586,48 @@ class _ReadoutMax(torch.autograd.Function):
                  F, 0, ws, out, out.stride(0), arg)
         ctx.g = g
         ctx.rows = x.size(0)
+        ctx.ghost_unused = bool(ghost_unused)
         ctx.save_for_backward(arg)
         ctx.mark_non_differentiable(arg)
+        ctx.set_materialize_grads(False)
+        if passthrough:
+            return out, arg, x.view_as(x)
         return out, arg
 
     @staticmethod
-    def backward(ctx, dout, _darg):
+    def backward(ctx, dout, _darg, dpass=None):
         (arg,) = ctx.saved_tensors
         g = ctx.g
+        if dout is None:
+            return dpass, None, None, None
         if dout.stride(1) != 1 or dout.stride(0) < dout.size(1):
             dout = dout.contiguous()                     # (a column slice of the concatenated readouts' gradient is read in place)
         F = dout.size(1)
-        if (g.n_ghost == 0 and F % 4 == 0 and dout.stride(0) % 4 == 0 and dout.data_ptr() % 16 == 0 and ctx.rows == g.n_rows
-                and g.row_graph is not None):
-            dx = _f32(ctx.rows, F, device=dout.device)              # no ghost rows: one dense pass writes every element
-            nat.call("readout_max_bwd_rows_f32", dout, dout.stride(0), arg, g.row_graph, F, ctx.rows, dx, dx.stride(0))
-            return dx, None
+        dense_ok = (F % 4 == 0 and dout.stride(0) % 4 == 0 and dout.data_ptr() % 16 == 0 and g.row_graph is not None
+                    and (g.n_ghost == 0 or ctx.ghost_unused) and ctx.rows >= g.n_rows)
+        if dpass is not None and dense_ok:
+            dpass = dpass if (dpass.stride(1) == 1 and dpass.stride(0) % 4 == 0 and dpass.data_ptr() % 16 == 0) else dpass.contiguous()
+        if dense_ok:
+            dx = _f32(ctx.rows, F, device=dout.device)              # one dense pass writes every element
+            nat.call("readout_max_bwd_rows_f32", dout, dout.stride(0), arg, g.row_graph, F, g.n_rows, ctx.rows, dpass,
+                     dpass.stride(0) if dpass is not None else 0, dx, dx.stride(0))
+            return dx, None, None, None
         dx = _f32(ctx.rows, F, device=dout.device, zero=True)
         nat.call("readout_max_bwd_f32", dout, dout.stride(0), arg, g.B, F, None, 0, 0, g.n_rows, dx, dx.stride(0))
-        return dx, None
+        if dpass is not None:
+            dx = dx + dpass
+        return dx, None, None, None
 
 
 def readout_max(x, g, return_arg=False):
-    out, arg = _ReadoutMax.apply(x, g)
+    out, arg = _ReadoutMax.apply(x, g, False, False)
     return (out, arg) if return_arg else out
+
+
+def readout_max_pass(x, g, ghost_unused=False):
+    """(max readout of x, x): the second output is x for its other consumer; see _ReadoutMax"""
+    out, _arg, xp = _ReadoutMax.apply(x, g, True, bool(ghost_unused))
+    return out, xp
 
 
 # ----------------------------------------------------------------------------- padded <-> packed rows
