@@ -26,10 +26,19 @@ inline size_t ct_lds_floats(int N, int K, int F, bool bwd) {
   return n;
 }
 
+// rows x cols contiguous floats -> LDS rows of stride ld.  Eight requests in flight per thread before the first LDS store (a
+// load-then-store loop is one dependent L2 round trip per iteration: 24 trips for a 64 x 192 operand).
 __device__ __forceinline__ void ct_load(float* dst, int ld, const float* __restrict__ src, int rows, int cols) {
-  for (int i = threadIdx.x; i < rows * cols; i += CT_THREADS) {
-    const int r = i / cols, c = i - r * cols;
-    dst[r * ld + c] = src[i];
+  const int total = rows * cols;
+  for (int base = threadIdx.x; base < total; base += 8 * CT_THREADS) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int i = base + u * CT_THREADS; v[u] = i < total ? src[i] : 0.f; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = base + u * CT_THREADS;
+      if (i < total) { const int r = i / cols, c = i - r * cols; dst[r * ld + c] = v[u]; }
+    }
   }
 }
 
@@ -166,16 +175,31 @@ __device__ __forceinline__ void ct_mfma(ct_f32x16& acc, const float* ap, int ald
   const bool nok = i < nvalid;
   const float* arow = ap + i * ald + h;
   const float* bcol = bp + (nok ? i : 0) * bns + h * bks;
-  for (int s0 = 0; s0 < depth; s0 += 16) {               // eight MFMA steps per round: operands first, then the chain
-    float av[8], bv[8];
+  // eight MFMA steps per round; the operands of round n + 1 are requested before the chain of round n issues (one wave per SIMD:
+  // nothing else hides the LDS latency).  Reads are unconditional from clamped addresses and masked afterwards (a predicated
+  // read would be waited for on its own).
+  auto fetch = [&](int s0, float (&av)[8], float (&bv)[8]) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int k = s0 + 2 * u;
-      av[u] = k < depth ? arow[k] : 0.f;
-      bv[u] = (k < depth && nok) ? bcol[k * bks] : 0.f;
+      const int k = s0 + 2 * u, kc = k < depth ? k : 0;
+      const float ta = arow[kc], tb = bcol[kc * bks];
+      av[u] = k < depth ? ta : 0.f;
+      bv[u] = (k < depth && nok) ? tb : 0.f;
     }
+  };
+  float a0[8], b0[8], a1[8], b1[8];
+  fetch(0, a0, b0);
+  for (int s0 = 0; s0 < depth; s0 += 32) {
+    if (s0 + 16 < depth) fetch(s0 + 16, a1, b1);
+    __builtin_amdgcn_sched_barrier(0);                     // (the scheduler would sink the reads below the MFMA chain)
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+    for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b0[u], acc, 0, 0, 0);
+    if (s0 + 16 < depth) {
+      if (s0 + 32 < depth) fetch(s0 + 32, a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b1[u], acc, 0, 0, 0);
+    }
   }
 }
 
@@ -190,6 +214,7 @@ __global__ __launch_bounds__(256) void contract_rows_bwd_kernel(CtRows a) {
     }
     return;
   }
+  TR(0);
   const int ldx = F + 1, lda = K + 1;
   float* DX = sm;                       // [K][F + 1]
   float* DA = DX + K * ldx;             // [K][K + 1]
@@ -201,38 +226,45 @@ __global__ __launch_bounds__(256) void contract_rows_bwd_kernel(CtRows a) {
   const int b = a.slab_graph[blockIdx.x];
   const int F4 = F / 4, K4 = K / 4;
   {
+    // all five operands are requested before the first LDS store: ONE memory round trip for the block's 104 KB (five staged
+    // calls were five dependent trips).  One wave per SIMD here, so the <= 32 float4 per thread are free registers.
+    constexpr int NX = CR_KMAX * (CR_FMAX / 4) / 256, NA = CR_KMAX * (CR_KMAX / 4) / 256, NZ = 32 * (CR_FMAX / 4) / 256, NS = 32 * (CR_KMAX / 4) / 256;
+    float4 vx[NX], va[NA], vz[NZ], vs[NS], vp[NS];
     const float* gx = a.dxo + (int64_t)b * K * F;
-    for (int i = tid; i < K * F4; i += 256) {
-      const int k = i / F4, c = i - k * F4;
-      const float4 v = *reinterpret_cast<const float4*>(gx + (int64_t)k * F + 4 * c);
-      float* d = DX + k * ldx + 4 * c;
-      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-    }
     const float* ga = a.dao + (int64_t)b * K * K;
-    for (int i = tid; i < K * K4; i += 256) {
-      const int k = i / K4, c = i - k * K4;
-      const float4 v = *reinterpret_cast<const float4*>(ga + (int64_t)k * K + 4 * c);
-      float* d = DA + k * lda + 4 * c;
-      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < NX; ++u) { const int i = tid + 256 * u; vx[u] = i < K * F4 ? *reinterpret_cast<const float4*>(gx + 4 * (int64_t)i) : zero4; }
+#pragma unroll
+    for (int u = 0; u < NA; ++u) { const int i = tid + 256 * u; va[u] = i < K * K4 ? *reinterpret_cast<const float4*>(ga + 4 * (int64_t)i) : zero4; }
+#pragma unroll
+    for (int u = 0; u < NZ; ++u) {
+      const int i = tid + 256 * u, r = i / F4, c = i - r * F4;
+      vz[u] = (i < 32 * F4 && r < nr) ? *reinterpret_cast<const float4*>(a.Z + (int64_t)(r0 + r) * a.ldZ + 4 * c) : zero4;
     }
-    for (int i = tid; i < 32 * F4; i += 256) {
-      const int r = i / F4, c = i - r * F4;
-      const float4 v = r < nr ? *reinterpret_cast<const float4*>(a.Z + (int64_t)(r0 + r) * a.ldZ + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
-      float* d = Zp + r * ldx + 4 * c;
-      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+      const int i = tid + 256 * u, r = i / K4, c = i - r * K4;
+      const bool ok = i < 32 * K4 && r < nr;
+      vs[u] = ok ? *reinterpret_cast<const float4*>(a.S + (int64_t)(r0 + r) * a.ldS + 4 * c) : zero4;
+      vp[u] = ok ? *reinterpret_cast<const float4*>(a.AS + (int64_t)(r0 + r) * a.ldAS + 4 * c) : zero4;
     }
-    for (int i = tid; i < 32 * K4; i += 256) {
-      const int r = i / K4, c = i - r * K4;
-      const bool ok = r < nr;
-      const float4 v = ok ? *reinterpret_cast<const float4*>(a.S + (int64_t)(r0 + r) * a.ldS + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
-      const float4 w = ok ? *reinterpret_cast<const float4*>(a.AS + (int64_t)(r0 + r) * a.ldAS + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
-      float* d = Sp + r * lda + 4 * c;
-      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-      float* e = Ap + r * lda + 4 * c;
-      e[0] = w.x; e[1] = w.y; e[2] = w.z; e[3] = w.w;
+    auto put = [](float* d, const float4& v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; };
+#pragma unroll
+    for (int u = 0; u < NX; ++u) { const int i = tid + 256 * u; if (i < K * F4) { const int k = i / F4, c = i - k * F4; put(DX + k * ldx + 4 * c, vx[u]); } }
+#pragma unroll
+    for (int u = 0; u < NA; ++u) { const int i = tid + 256 * u; if (i < K * K4) { const int k = i / K4, c = i - k * K4; put(DA + k * lda + 4 * c, va[u]); } }
+#pragma unroll
+    for (int u = 0; u < NZ; ++u) { const int i = tid + 256 * u; if (i < 32 * F4) { const int r = i / F4, c = i - r * F4; put(Zp + r * ldx + 4 * c, vz[u]); } }
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+      const int i = tid + 256 * u;
+      if (i < 32 * K4) { const int r = i / K4, c = i - r * K4; put(Sp + r * lda + 4 * c, vs[u]); put(Ap + r * lda + 4 * c, vp[u]); }
     }
   }
+  TR(1);
   __syncthreads();
+  TR(2);
   const int wid = tid >> 6, lane = tid & 63, i = lane & 31, h = lane >> 5;
   for (int q = 0; q < CR_MAXJOBS; ++q) {
     const int code = a.job[wid][q];                      // uniform over the wave
@@ -254,6 +286,7 @@ __global__ __launch_bounds__(256) void contract_rows_bwd_kernel(CtRows a) {
       ct_mfma(acc, Zp, ldx, DX + 32 * t * ldx, 1, ldx, F, K - 32 * t);
       ct_mfma(acc, Ap, lda, DA + 32 * t * lda, 1, lda, K, K - 32 * t);
     }
+    TR_AFTER(__float_as_int(acc[0]), 3 + 2 * min(q, 3));
     const int c = 32 * t + i;
     if (c < ncols) {
 #pragma unroll
@@ -262,7 +295,10 @@ __global__ __launch_bounds__(256) void contract_rows_bwd_kernel(CtRows a) {
         if (m < nr) out[(int64_t)(r0 + m) * ldo + c] = acc[r];
       }
     }
+    TR(4 + 2 * min(q, 3));
   }
+  TR(11);
+  TR_END();
 }
 
 inline size_t ct_rows_lds_floats(int K, int F) { return (size_t)K * (F + 1) + (size_t)K * (K + 1) + 32 * (size_t)(K + 1) * 2 + 32 * (size_t)(F + 1); }
