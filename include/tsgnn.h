@@ -700,6 +700,17 @@ int tsgnn_contract_rows_bwd_f32(const float* S, int64_t ldS, const float* Z, int
                                 int F, float* dZ, int64_t lddZ, float* dS, int64_t lddS, float* dAS, int64_t lddAS,
                                 int64_t zero_from, int64_t zero_to, tsgnn_stream_t stream);
 
+/* ---- several independent problems of the GraphConv layer kernels in one launch (csrc/multi.hip): up to two weight-gradient slab
+ * problems (arguments of tsgnn_linear_wgrad_f32, dw = db = NULL) and up to two gather products (arguments of
+ * tsgnn_gather_rowgemm_f32), for the two 64-wide GCN stacks of DiffPool's first level (encoders.py:352-363).  desc (HOST memory):
+ *   [ntn, ng,
+ *    ntn x (z, ldz, du, lddu, rows, K_in, N, nslab, rows_per_slab, bias_only_rows, ws),
+ *    ng  x (ell, ell_w, tail_ptr, tail_col, x, ldx, b, ldb, trans_b, bias, c, ldc, rinv, zout, ldz, rows, K, N, normalize, fill_rows)]
+ * 32 < N <= 64, K, K_in <= 128, problems of one kind share every shape; TSGNN_EUNSUPPORTED otherwise. */
+int tsgnn_sage_multi_tn_words(void);
+int tsgnn_sage_multi_g_words(void);
+int tsgnn_sage_multi_f32(const int64_t* desc, tsgnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

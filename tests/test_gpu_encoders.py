@@ -339,6 +339,43 @@ def test_contract_rows_backward_fused_equals_ragged_products(K, F, sizes, nmax, 
             assert float(f[g.n_rows:].abs().max()) == 0.0 if f.size(0) > g.n_rows else True
 
 
+def test_diffpool_level0_stack_pairs_equal_separate_stacks(monkeypatch):
+    """the two first-level GCN stacks of DiffPool as ONE autograd node with shared launches (sage_stack._SageStackPair,
+    csrc/multi.hip) against the two separate nodes: outputs, loss and every parameter gradient; and the launches really are shared"""
+    from two_stage_gnn_amd import dense_encoders as E, sage_stack, _native as nat
+    B, nmax, fin, hid = 6, 96, 12, 64
+    x, adj, sizes = dense_batch(31, B, nmax, fin, sizes=[96, 33, 5, 64, 70, 50], p_edge=0.08)
+
+    class A:
+        bias = True
+    torch.manual_seed(2)
+    m = E.SoftPoolingGcnEncoder(nmax, fin, hid, hid, 2, 3, hid, assign_ratio=0.25, num_pooling=1, bn=True, linkpred=False, args=A(),
+                                assign_input_dim=fin, final_dim="number_classes").cuda()
+    label = (torch.arange(B) % 2).cuda()
+    res = []
+    for pair in (True, False):
+        monkeypatch.setattr(sage_stack, "PAIR_LAUNCHES", pair)
+        m.zero_grad(set_to_none=True)
+        nat.trace = []
+        try:
+            a, b = m(x.cuda(), adj.cuda(), sizes, assign_x=x.cuda())
+            loss = m.loss(b, label)
+            loss.backward()
+            names = [t[0] for t in nat.trace]
+        finally:
+            nat.trace = None
+        res.append((a.detach(), b.detach(), loss.detach(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}, names))
+    (a1, b1, l1, g1, n1), (a0, b0, l0, g0, n0) = res
+    assert n1.count("sage_multi_f32") >= 2 and n0.count("sage_multi_f32") == 0
+    assert len(n1) < len(n0)
+    torch.testing.assert_close(a1, a0, rtol=2e-5, atol=2e-6)
+    torch.testing.assert_close(b1, b0, rtol=2e-5, atol=2e-6)
+    assert set(g1) == set(g0)
+    for k in g0:
+        err = (g1[k] - g0[k]).abs().max().item()
+        assert err <= 2e-4 * g0[k].abs().max().item() + 1e-8, (k, err)
+
+
 def test_gat_column_softmax_mass_at_baseline_size():
     """attention aggregation on the full DD-shaped 32-graph batch (packed rows + one ghost representative per graph, 4 heads x
     64): every COLUMN j of the (column-)softmax of encoders_GAT.py:41-45 hands out exactly one unit of mass — to its neighbours

@@ -150,8 +150,61 @@ def last_kernel():
     return lib().tsgnn_last_kernel().decode()
 
 
+_defer = None       # a list while launches are being RECORDED instead of issued (deferred(); sage_stack.run_paired merges two records)
+
+
+class deferred:
+    """``with deferred() as q``: every call() / defer() inside is appended to q instead of being executed.  The recorded argument
+    tensors stay referenced by q, so nothing they point to is recycled before run(q) (or a merge of several records) issues them.
+    Only for code whose HOST side does not depend on device results — true of every entry point of this library."""
+
+    def __enter__(self):
+        global _defer
+        self._prev, self.q = _defer, []
+        _defer = self.q
+        return self.q
+
+    def __exit__(self, *exc):
+        global _defer
+        _defer = self._prev
+        return False
+
+
+def defer(fn):
+    """a torch-side operation that must keep its place among recorded launches (executed at once outside deferred())"""
+    if _defer is not None:
+        _defer.append((None, fn))
+    else:
+        fn()
+
+
+def run(q):
+    for name, args in q:
+        if name is None:
+            args()
+        else:
+            call(name, *args)
+
+
+def try_call(name, *args):
+    """like call(), but an argument combination the entry point does not take (TSGNN_EUNSUPPORTED, decided before anything is
+    launched) returns False instead of raising"""
+    L = lib()
+    rc = getattr(L, "tsgnn_" + name)(*[_arg(a) for a in args], stream_handle())
+    if rc == -3:
+        return False
+    if rc != 0:
+        raise RuntimeError("tsgnn_%s failed: %s" % (name, L.tsgnn_strerror(rc).decode()))
+    if trace is not None:
+        trace.append((name, args, L.tsgnn_last_kernel().decode()))
+    return True
+
+
 def call(name, *args):
     """Call tsgnn_<name>(*args, current_stream); tensors -> device pointers, None -> NULL."""
+    if _defer is not None:
+        _defer.append((name, args))
+        return
     L = lib()
     fn = getattr(L, "tsgnn_" + name)
     rc = fn(*[_arg(a) for a in args], stream_handle())

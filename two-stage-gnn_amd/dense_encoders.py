@@ -383,6 +383,21 @@ class SoftPoolingGcnEncoder(GcnEncoderGraph):
         x_all.append(conv_last(x, adj))
         return torch.cat(x_all, dim=2), g
 
+    def _level0_pair_ok(self, x, x_a, g, masked):
+        """both first-level stacks take the fused stack path (gcn_forward_rows) and may share launches"""
+        from . import sage_stack
+        if not (FUSED_STACK and sage_stack.PAIR_LAUNCHES and not self.per_graph_bn and (masked or not g.n_ghost)):
+            return False
+        lib = mp.nat.lib()
+        for xx, convs in ((x, [self.conv_first] + list(self.conv_block) + [self.conv_last]),
+                          (x_a, [self.assign_conv_first_modules[0]] + list(self.assign_conv_block_modules[0])
+                           + [self.assign_conv_last_modules[0]])):
+            if not (torch.is_tensor(xx) and xx.dim() == 2 and sage_stack.eligible(g, convs, self.bn, xx)
+                    and bool(lib.tsgnn_slot_fused_supported(g.B, convs[0].output_dim))
+                    and bool(lib.tsgnn_slot_fused_supported(g.B, convs[-1].output_dim))):
+                return False
+        return True
+
     def forward(self, x, adj, batch_num_nodes, **kwargs):
         from . import diffpool as dp
         from .pyg import linear
@@ -392,7 +407,17 @@ class SoftPoolingGcnEncoder(GcnEncoderGraph):
         x, g = self.make_batch(x, adj, batch_num_nodes)             # packed rows (+ghost reps) if masked, else padded
         x_a = x if same_input else (mp.pack_rows(x_a, g, (x_a.size(2) + 3) // 4 * 4 if g.layout == "packed" else None)
                                     if x_a.dim() == 3 else x_a)
-        emb = self.gcn_forward_rows(x, g, self.conv_first, self.conv_block, self.conv_last, mask_ghost=masked)
+        a0 = None
+        if self.num_pooling > 0 and self._level0_pair_ok(x, x_a, g, masked):
+            # the embedding and the first assignment stack run on the same graph: one autograd node whose launches are shared
+            # pairwise (sage_stack._SageStackPair) — each kernel of one stack alone fills about half of the CUs
+            from . import sage_stack
+            emb, a0 = sage_stack.sage_stack_nodes_pair(
+                x, x_a, g, [self.conv_first] + list(self.conv_block) + [self.conv_last],
+                [self.assign_conv_first_modules[0]] + list(self.assign_conv_block_modules[0]) + [self.assign_conv_last_modules[0]],
+                masked)
+        else:
+            emb = self.gcn_forward_rows(x, g, self.conv_first, self.conv_block, self.conv_last, mask_ghost=masked)
         if self.num_pooling > 0 and READOUT_PASS:
             # the embeddings feed the readout AND the contraction: one backward pass sums both gradients (mp._ReadoutMax);
             # masked: the ghost rows of `emb` are constants (zeros), their gradient is discarded by the stack's backward
@@ -405,8 +430,9 @@ class SoftPoolingGcnEncoder(GcnEncoderGraph):
         for i in range(self.num_pooling):
             lin = self.assign_pred_modules[i]
             if i == 0:
-                a = self.gcn_forward_rows(x_a, g, self.assign_conv_first_modules[0], self.assign_conv_block_modules[0],
-                                          self.assign_conv_last_modules[0], mask_ghost=masked)
+                a = a0 if a0 is not None else self.gcn_forward_rows(
+                    x_a, g, self.assign_conv_first_modules[0], self.assign_conv_block_modules[0],
+                    self.assign_conv_last_modules[0], mask_ghost=masked)
                 s = dp.row_softmax(mp.linear_oi(a, lin.weight, lin.bias),                    # encoders.py:369
                                    g.n_rows if (masked and g.n_ghost) else None)              # :371 (ghost rows -> 0)
                 self.assign_tensor = s

@@ -186,7 +186,7 @@ class _SageStack(torch.autograd.Function):
         ctx.nodes = nodes
         if nodes:
             if nodes == 2 and g.n_ghost:
-                cat[g.n_rows:].zero_()                       # embedding mask: ghost rows of the node output are zero
+                nat.defer(lambda: cat[g.n_rows:].zero_())    # embedding mask: ghost rows of the node output are zero
             ctx.g, ctx.L, ctx.has_bias, ctx.dims = g, L, has_bias, (Fh, Fl)
             ctx.slots = (sn, sg)
             ctx.Ws, ctx.saved, ctx.arg = Ws, saved, None
@@ -384,6 +384,100 @@ def sage_stack_nodes(x, g, convs, mask_ghost):
         params.append(c.weight)
         params.append(c.bias if has_bias else c.weight.new_zeros(1))
     return _SageStack.apply(x, g, has_bias, 0, 2 if (mask_ghost and g.n_ghost) else 1, *params)
+
+
+# ----------------------------------------------------------------------------- two stacks on one graph, launches shared
+PAIR_LAUNCHES = os.environ.get("TSGNN_STACK_PAIRS", "1") != "0"
+
+
+def _multi(tn, gs):
+    """one launch for the recorded argument tuples of <= 2 tsgnn_linear_wgrad_f32 (slab form) and <= 2 tsgnn_gather_rowgemm_f32
+    calls; False when the entry point does not take the combination (csrc/multi.hip)"""
+    import numpy as np
+    words = [len(tn), len(gs)]
+    for a in tn:
+        words += [nat._arg(v) or 0 for v in a[:11]]
+    for a in gs:
+        words += [(nat._arg(v) or 0) if not isinstance(v, bool) else int(v) for v in a[:20]]
+    d = np.asarray(words, dtype=np.int64)
+    return nat.try_call("sage_multi_f32", d.ctypes.data)
+
+
+def _slab_form(rec):
+    return rec[0] == "linear_wgrad_f32" and len(rec[1]) >= 13 and rec[1][11] is None and rec[1][12] is None
+
+
+def run_paired(qa, qb):
+    """issue two launch records of INDEPENDENT computations (nat.deferred) in lockstep; where both are at the same kind of
+    step, the two problems share a launch: gather products pairwise, weight-gradient slabs pairwise and together with the
+    gather products that follow them (all four only read dU).  Any interleaving that keeps each record's order is valid."""
+    i = j = 0
+    while i < len(qa) and j < len(qb):
+        a, b = qa[i], qb[j]
+        if a[0] == b[0] == "gather_rowgemm_f32" and _multi([], [a[1], b[1]]):
+            i += 1; j += 1
+            continue
+        if _slab_form(a) and _slab_form(b):
+            na = qa[i + 1] if i + 1 < len(qa) else (None,)
+            nb = qb[j + 1] if j + 1 < len(qb) else (None,)
+            if na[0] == nb[0] == "gather_rowgemm_f32" and _multi([a[1], b[1]], [na[1], nb[1]]):
+                i += 2; j += 2
+                continue
+            if _multi([a[1], b[1]], []):
+                i += 1; j += 1
+                continue
+        nat.run([a]); nat.run([b])
+        i += 1; j += 1
+    nat.run(qa[i:]); nat.run(qb[j:])
+
+
+class _StackCtx:
+    """what _SageStack.forward / backward need of an autograd context, for the two halves of _SageStackPair"""
+    needs_input_grad = ()
+
+    def set_materialize_grads(self, v):
+        pass
+
+
+class _SageStackPair(torch.autograd.Function):
+    """two _SageStack nodes (node outputs) on the SAME graph whose launches are recorded and issued in pairs (run_paired): the
+    embedding and the assignment stack of DiffPool's first level.  forward(xa, xb, g, has_bias, nodes_a, nodes_b, n_a, *params)."""
+
+    @staticmethod
+    def forward(ctx, xa, xb, g, has_bias, nodes_a, nodes_b, n_a, *params):
+        ca, cb = _StackCtx(), _StackCtx()
+        with nat.deferred() as qa:
+            oa = _SageStack.forward(ca, xa, g, has_bias, 0, nodes_a, *params[:n_a])
+        with nat.deferred() as qb:
+            ob = _SageStack.forward(cb, xb, g, has_bias, 0, nodes_b, *params[n_a:])
+        run_paired(qa, qb)
+        ctx.ca, ctx.cb, ctx.n_a = ca, cb, n_a
+        return oa, ob
+
+    @staticmethod
+    def backward(ctx, da, db):
+        n, n_a = ctx.needs_input_grad, ctx.n_a
+        ctx.ca.needs_input_grad = (n[0], False, False, False, False) + tuple(n[7:7 + n_a])
+        ctx.cb.needs_input_grad = (n[1], False, False, False, False) + tuple(n[7 + n_a:])
+        with nat.deferred() as qa:
+            ga = _SageStack.backward(ctx.ca, da)
+        with nat.deferred() as qb:
+            gb = _SageStack.backward(ctx.cb, db)
+        run_paired(qa, qb)
+        return (ga[0], gb[0], None, None, None, None, None) + tuple(ga[5:]) + tuple(gb[5:])
+
+
+def sage_stack_nodes_pair(xa, xb, g, convs_a, convs_b, mask_ghost):
+    """sage_stack_nodes of two stacks on one graph, launches shared where both are at the same step"""
+    has_bias = convs_a[0].bias is not None
+    if (convs_b[0].bias is not None) != has_bias:
+        return sage_stack_nodes(xa, g, convs_a, mask_ghost), sage_stack_nodes(xb, g, convs_b, mask_ghost)
+    params = []
+    for c in list(convs_a) + list(convs_b):
+        params.append(c.weight)
+        params.append(c.bias if has_bias else c.weight.new_zeros(1))
+    nodes = 2 if (mask_ghost and g.n_ghost) else 1
+    return _SageStackPair.apply(xa, xb, g, has_bias, nodes, nodes, 2 * len(convs_a), *params)
 
 
 def head_ok(g, convs, lin1, lin2):
