@@ -700,6 +700,19 @@ int tsgnn_contract_rows_bwd_f32(const float* S, int64_t ldS, const float* Z, int
                                 int F, float* dZ, int64_t lddZ, float* dS, int64_t lddS, float* dAS, int64_t lddAS,
                                 int64_t zero_from, int64_t zero_to, tsgnn_stream_t stream);
 
+/* paired forms for two stacks that share batch and shapes (grid.y = 2; sage_stack._SageStackPair): tsgnn_slot_bn_fwd_f32 without
+ * the readout-buffer clear, tsgnn_slot_post_bwd_f32 without a readout gradient, and the slab reduction of up to 8 sets described
+ * in HOST memory, desc = [n, n x (ws, nslab, K, N, dw, db)] */
+int tsgnn_slot_bn_fwd_pair_f32(const int* graph_ptr, const int* slot_count, int B, int nmax, int64_t n_real, int n_ghost,
+                               const float* v0, const float* v1, int64_t ldv, int F, int relu, float* mean0, float* mean1, float* rstd0,
+                               float* rstd1, float* y0, float* y1, int64_t ldy, tsgnn_stream_t stream);
+int tsgnn_slot_post_bwd_pair_f32(const int* graph_ptr, const int* slot_count, int B, int nmax, int64_t n_real, int n_ghost,
+                                 const float* v0, const float* v1, int64_t ldv, const float* dxs0, const float* dxs1, int64_t lddxs,
+                                 const float* dxs2_0, const float* dxs2_1, int64_t lddxs2, int F, int relu, int bn, const float* mean0,
+                                 const float* mean1, const float* rstd0, const float* rstd1, const float* rinv0, const float* rinv1,
+                                 float* du0, float* du1, int64_t lddu, tsgnn_stream_t stream);
+int tsgnn_wgrad_reduce_sets_f32(const int64_t* desc, tsgnn_stream_t stream);
+
 /* ---- several independent problems of the GraphConv layer kernels in one launch (csrc/multi.hip): up to two weight-gradient slab
  * problems (arguments of tsgnn_linear_wgrad_f32, dw = db = NULL) and up to two gather products (arguments of
  * tsgnn_gather_rowgemm_f32), for the two 64-wide GCN stacks of DiffPool's first level (encoders.py:352-363).  desc (HOST memory):

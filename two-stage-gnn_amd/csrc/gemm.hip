@@ -302,13 +302,14 @@ __global__ __launch_bounds__(256) void tn_rows_reduce_du(const float* __restrict
 }
 
 struct ReduceSet { const float* slabs; int nslab; int64_t per_slab; int64_t n_w; float* dw; float* db; int64_t first_block; };
-struct ReduceMulti { ReduceSet s[4]; int n; float* normparts; float* step_state; };
+constexpr int RM_SETS = 8;
+struct ReduceMulti { ReduceSet s[RM_SETS]; int n; float* normparts; float* step_state; };
 // several independent slab sets (the layers of one backward pass) reduced by ONE launch
 __global__ __launch_bounds__(256) void tn_rows_reduce_multi(ReduceMulti m) {
   __shared__ float lds[4][64];
   int k = 0;
 #pragma unroll
-  for (int t = 1; t < 4; ++t) if (t < m.n && (int64_t)blockIdx.x >= m.s[t].first_block) k = t;
+  for (int t = 1; t < RM_SETS; ++t) if (t < m.n && (int64_t)blockIdx.x >= m.s[t].first_block) k = t;
   const ReduceSet r = m.s[k];
   const int e_l = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int64_t e = ((int64_t)blockIdx.x - r.first_block) * 64 + e_l;
@@ -506,7 +507,7 @@ int tsgnn_wgrad_reduce_multi_f32(const float* ws0, int nslab0, int K0, int N0, f
     ++m.n;
   }
   if (m.n == 0) return TSGNN_OK;
-  for (int t = m.n; t < 4; ++t) m.s[t] = m.s[0];
+  for (int t = m.n; t < RM_SETS; ++t) m.s[t] = m.s[0];
   m.normparts = normparts;
   m.step_state = step_state;
   TSGNN_KNAME("tn_rows_reduce_multi");
@@ -635,6 +636,36 @@ int tsgnn_colsum_f32(const float* x, int64_t ld, int64_t rows, int F, float* out
   dim3 grid((unsigned)((F + 63) / 64), (unsigned)nchunk);
   colsum_partial<<<grid, 256, 0, stream>>>(x, ld, rows, F, rpc, ws);
   splitk_reduce_kernel<<<(unsigned)ceil_div64(F, 256), 256, 0, stream>>>(ws, nchunk, F, F, out, accumulate);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+/* the same for up to 8 slab sets described in HOST memory: desc = [n, n x (ws, nslab, K, N, dw, db)] (the gradients of two
+ * stacks that share their launches, sage_stack._SageStackPair) */
+int tsgnn_wgrad_reduce_sets_f32(const int64_t* desc, tsgnn_stream_t stream) {
+  if (!desc) return TSGNN_EINVAL;
+  const int n = (int)desc[0];
+  if (n < 0 || n > RM_SETS) return TSGNN_EINVAL;
+  if (n == 0) return TSGNN_OK;
+  ReduceMulti m;
+  m.n = n;
+  int64_t blocks = 0;
+  for (int t = 0; t < n; ++t) {
+    const int64_t* d = desc + 1 + 6 * t;
+    const float* ws = reinterpret_cast<const float*>(d[0]);
+    const int nslab = (int)d[1], K = (int)d[2], N = (int)d[3];
+    float* dw = reinterpret_cast<float*>(d[4]);
+    float* db = reinterpret_cast<float*>(d[5]);
+    if (!ws || !dw || nslab <= 0 || K <= 0 || N <= 0) return TSGNN_EINVAL;
+    const int64_t per_slab = (int64_t)(K + 1) * N;
+    m.s[t] = ReduceSet{ws, nslab, per_slab, (int64_t)K * N, dw, db, blocks};
+    blocks += ceil_div64(per_slab, 64);
+  }
+  for (int t = n; t < RM_SETS; ++t) m.s[t] = m.s[0];
+  m.normparts = nullptr;
+  m.step_state = nullptr;
+  TSGNN_KNAME("tn_rows_reduce_multi");
+  tn_rows_reduce_multi<<<(unsigned)blocks, 256, 0, stream>>>(m);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }

@@ -41,11 +41,17 @@ __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<floa
 // ---------------------------------------------------------------------------------------------- forward
 // BT threads per block = TPR threads per graph x up to BT/TPR graphs (B <= 32: 256, <= 64: 512, <= 128: 1024 threads, so that a
 // thread never owns more than NV <= 4 float4 of a row: short dependency chains, <= 80 registers)
+// second problem of a PAIRED launch (grid.y = 2: two stacks on the same graph and shapes, sage_stack._SageStackPair): the
+// operands that differ; blockIdx.y == 1 works on these
+struct SlotFwdAlt { const float* v; float* mean; float* rstd; float* y; };
+struct SlotBwdAlt { const float* v; const float* dxs; const float* dxs2; const float* mean; const float* rstd; const float* rinv; float* du; };
+
 template <int TPR, int NV, int BT>
 __global__ __launch_bounds__(BT) void slot_bn_fwd(SlotArgs s, const float* __restrict__ v, int64_t ldv, int F4, int relu,
                                                    float* __restrict__ mean, float* __restrict__ rstd,
                                                    float* __restrict__ y, int64_t ldy,
-                                                   unsigned long long* __restrict__ zero_ptr, int64_t zero_n) {
+                                                   unsigned long long* __restrict__ zero_ptr, int64_t zero_n, SlotFwdAlt alt) {
+  if (blockIdx.y) { v = alt.v; mean = alt.mean; rstd = alt.rstd; y = alt.y; zero_n = 0; }
   constexpr int NW = BT / 64;
   __shared__ float red[2 * NW];
   __shared__ int first_ghost;
@@ -123,7 +129,8 @@ __global__ __launch_bounds__(BT) void slot_post_bwd(SlotArgs s, const float* __r
                                                      const float* __restrict__ dout, int64_t ldo, const int* __restrict__ arg,
                                                      int F4, int relu, int bn, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ rinv,
-                                                     float* __restrict__ du, int64_t lddu) {
+                                                     float* __restrict__ du, int64_t lddu, SlotBwdAlt alt) {
+  if (blockIdx.y) { v = alt.v; dxs = alt.dxs; dxs2 = alt.dxs2; mean = alt.mean; rstd = alt.rstd; rinv = alt.rinv; du = alt.du; }
   constexpr int NW = BT / 64;
   // all LDS in ONE dynamic array (16-byte aligned base for the float4 ghost accumulators, Guideline 17)
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -420,7 +427,23 @@ int tsgnn_slot_bn_fwd_f32(const int* graph_ptr, const int* slot_count, int B, in
     return TSGNN_EINVAL;
   if (!tsgnn_slot_fused_supported(B, F)) return TSGNN_EUNSUPPORTED;
   SlotArgs s{graph_ptr, slot_count, B, nmax, n_real, n_ghost};
-  TSGNN_SLOT_DISPATCH(slot_bn_fwd, nmax, 0, (s, v, ldv, F / 4, relu, mean, rstd, y, ldy, zero_ptr, zero_ptr ? zero_n : 0));
+  TSGNN_SLOT_DISPATCH(slot_bn_fwd, nmax, 0, (s, v, ldv, F / 4, relu, mean, rstd, y, ldy, zero_ptr, zero_ptr ? zero_n : 0, SlotFwdAlt{}));
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+/* tsgnn_slot_bn_fwd_f32 for TWO feature matrices on the same batch and shapes in one launch (grid.y = 2) */
+int tsgnn_slot_bn_fwd_pair_f32(const int* graph_ptr, const int* slot_count, int B, int nmax, int64_t n_real, int n_ghost,
+                               const float* v0, const float* v1, int64_t ldv, int F, int relu, float* mean0, float* mean1, float* rstd0,
+                               float* rstd1, float* y0, float* y1, int64_t ldy, tsgnn_stream_t stream) {
+  if (!graph_ptr || !slot_count || !v0 || !v1 || !mean0 || !mean1 || !rstd0 || !rstd1 || !y0 || !y1 || nmax <= 0 ||
+      (n_ghost != 0 && n_ghost != nmax) || ldv < F || ldy < F || (ldv % 4) || (ldy % 4))
+    return TSGNN_EINVAL;
+  if (!tsgnn_slot_fused_supported(B, F)) return TSGNN_EUNSUPPORTED;
+  SlotArgs s{graph_ptr, slot_count, B, nmax, n_real, n_ghost};
+  const unsigned long long* none = nullptr;
+  TSGNN_SLOT_DISPATCH(slot_bn_fwd, dim3((unsigned)nmax, 2), 0,
+                      (s, v0, ldv, F / 4, relu, mean0, rstd0, y0, ldy, const_cast<unsigned long long*>(none), 0, SlotFwdAlt{v1, mean1, rstd1, y1}));
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }
@@ -437,7 +460,32 @@ int tsgnn_slot_post_bwd_f32(const int* graph_ptr, const int* slot_count, int B, 
   SlotArgs s{graph_ptr, slot_count, B, nmax, n_real, n_ghost};
   const int nw = B <= 32 ? 4 : (B <= 64 ? 8 : 16);
   const size_t lds = sizeof(float) * ((n_ghost ? (size_t)nw * F : 0) + 2 * nw + 4);
-  TSGNN_SLOT_DISPATCH(slot_post_bwd, nmax, lds, (s, v, ldv, dxs, lddxs, dxs2, lddxs2, dout, ldo, arg, F / 4, relu, bn, mean, rstd, rinv, du, lddu));
+  TSGNN_SLOT_DISPATCH(slot_post_bwd, nmax, lds, (s, v, ldv, dxs, lddxs, dxs2, lddxs2, dout, ldo, arg, F / 4, relu, bn, mean, rstd, rinv, du, lddu, SlotBwdAlt{}));
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+/* tsgnn_slot_post_bwd_f32 (without a readout gradient) for TWO stacks on the same batch and shapes in one launch (grid.y = 2);
+ * dxs / dxs2 are given for both problems or for neither */
+int tsgnn_slot_post_bwd_pair_f32(const int* graph_ptr, const int* slot_count, int B, int nmax, int64_t n_real, int n_ghost,
+                                 const float* v0, const float* v1, int64_t ldv, const float* dxs0, const float* dxs1, int64_t lddxs,
+                                 const float* dxs2_0, const float* dxs2_1, int64_t lddxs2, int F, int relu, int bn, const float* mean0,
+                                 const float* mean1, const float* rstd0, const float* rstd1, const float* rinv0, const float* rinv1,
+                                 float* du0, float* du1, int64_t lddu, tsgnn_stream_t stream) {
+  if (!graph_ptr || !slot_count || !v0 || !v1 || !rinv0 || !rinv1 || !du0 || !du1 || nmax <= 0 || (n_ghost != 0 && n_ghost != nmax) ||
+      (bn && (!mean0 || !mean1 || !rstd0 || !rstd1)) || ldv < F || lddu < F || (ldv % 4) || (lddu % 4) ||
+      ((dxs0 == nullptr) != (dxs1 == nullptr)) || ((dxs2_0 == nullptr) != (dxs2_1 == nullptr)) || (dxs0 && (lddxs % 4)) ||
+      (dxs2_0 && (lddxs2 % 4)))
+    return TSGNN_EINVAL;
+  if (!tsgnn_slot_fused_supported(B, F)) return TSGNN_EUNSUPPORTED;
+  SlotArgs s{graph_ptr, slot_count, B, nmax, n_real, n_ghost};
+  const int nw = B <= 32 ? 4 : (B <= 64 ? 8 : 16);
+  const size_t lds = sizeof(float) * ((n_ghost ? (size_t)nw * F : 0) + 2 * nw + 4);
+  const float* nof = nullptr;
+  const int* noi = nullptr;
+  TSGNN_SLOT_DISPATCH(slot_post_bwd, dim3((unsigned)nmax, 2), lds,
+                      (s, v0, ldv, dxs0, lddxs, dxs2_0, lddxs2, nof, 0, noi, F / 4, relu, bn, mean0, rstd0, rinv0, du0, lddu,
+                       SlotBwdAlt{v1, dxs1, dxs2_1, mean1, rstd1, rinv1, du1}));
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }

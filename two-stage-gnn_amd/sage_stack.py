@@ -426,9 +426,56 @@ def run_paired(qa, qb):
             if _multi([a[1], b[1]], []):
                 i += 1; j += 1
                 continue
+        if a[0] == b[0] and a[0] in _PAIRED and _PAIRED[a[0]](a[1], b[1]):
+            i += 1; j += 1
+            continue
         nat.run([a]); nat.run([b])
         i += 1; j += 1
     nat.run(qa[i:]); nat.run(qb[j:])
+
+
+def _same(x, y):
+    if torch.is_tensor(x) or torch.is_tensor(y):
+        return torch.is_tensor(x) and torch.is_tensor(y) and x.data_ptr() == y.data_ptr()
+    return x == y
+
+
+def _pair_slot_bn(a, b):
+    # (graph_ptr, slot_count, B, sn, n_rows, sg, v, ldv, N, relu, mean, rstd, y, ldy, zero_ptr, total)
+    if a[14] is not None or b[14] is not None or not all(_same(a[k], b[k]) for k in (0, 1, 2, 3, 4, 5, 7, 8, 9, 13)):
+        return False
+    return nat.try_call("slot_bn_fwd_pair_f32", a[0], a[1], a[2], a[3], a[4], a[5], a[6], b[6], a[7], a[8], a[9], a[10], b[10], a[11], b[11],
+                        a[12], b[12], a[13])
+
+
+def _pair_slot_post_bwd(a, b):
+    # (graph_ptr, slot_count, B, sn, n_rows, sg, v, ldv, dxs, lddxs, dxs2, lddxs2, dout, ldo, arg, N, relu, bn, mean, rstd, rinv, du, lddu)
+    if any(t[12] is not None or t[14] is not None for t in (a, b)):
+        return False
+    if (a[8] is None) != (b[8] is None) or (a[10] is None) != (b[10] is None):
+        return False
+    if not all(_same(a[k], b[k]) for k in (0, 1, 2, 3, 4, 5, 7, 9, 11, 15, 16, 17, 22)):
+        return False
+    return nat.try_call("slot_post_bwd_pair_f32", a[0], a[1], a[2], a[3], a[4], a[5], a[6], b[6], a[7], a[8], b[8], a[9], a[10], b[10], a[11],
+                        a[15], a[16], a[17], a[18], b[18], a[19], b[19], a[20], b[20], a[21], b[21], a[22])
+
+
+def _pair_reduce(a, b):
+    # 4 x (ws, nslab, K, N, dw, db), normparts, step
+    import numpy as np
+    if a[24] is not None or a[25] is not None or b[24] is not None or b[25] is not None:
+        return False
+    sets = [t[6 * k:6 * k + 6] for t in (a, b) for k in range(4) if t[6 * k] is not None]
+    if not sets or len(sets) > 8:
+        return False
+    words = [len(sets)]
+    for st in sets:
+        words += [nat._arg(st[0]), int(st[1]), int(st[2]), int(st[3]), nat._arg(st[4]), nat._arg(st[5]) or 0]
+    d = np.asarray(words, dtype=np.int64)
+    return nat.try_call("wgrad_reduce_sets_f32", d.ctypes.data)
+
+
+_PAIRED = {"slot_bn_fwd_f32": _pair_slot_bn, "slot_post_bwd_f32": _pair_slot_post_bwd, "wgrad_reduce_multi_f32": _pair_reduce}
 
 
 class _StackCtx:
