@@ -7,7 +7,7 @@ for c in SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES SQ_WAIT_ANY; do
 done
 python3 - <<'PY'
 import csv, glob
-for kern in ("gemm_tn_rows", "dense_stack_fwd", "dense_stack_bwd", "gemm_f32_kernel", "rowgemm_gather_ks2"):
+for kern in ("gemm_tn_rows", "dense_stack_fwd", "dense_stack_bwd", "contract_rows_bwd", "contract_dense_bwd", "sage_multi_kernel<2, 2>", "sage_multi_kernel<0, 1>"):
     out = {}
     for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAVES", "SQ_WAIT_ANY"):
         f = glob.glob("gpurun_out/pmc_dp_%s/*/*_counter_collection.csv" % c)[0]
