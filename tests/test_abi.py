@@ -42,3 +42,81 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_new_entry_points_validate_on_the_host():
+    """round-2 entry points reject bad descriptions / shapes before any launch (no GPU needed)"""
+    import numpy as np
+    from two_stage_gnn_amd import _native as nat
+    L = nat.lib()
+    assert L.tsgnn_gat_fused_supported(4, 64) == 1 and L.tsgnn_gat_fused_supported(4, 6) == 0 and L.tsgnn_gat_fused_supported(9, 4) == 0
+    assert L.tsgnn_gat_fused_supported(2, 256) == 0                                   # H * Fh / 4 lanes must fit one wave
+    assert L.tsgnn_contract_dense_supported(64, 8, 192) == 1 and L.tsgnn_contract_dense_supported(512, 64, 192) == 0
+    assert L.tsgnn_contract_rows_bwd_supported(64, 192) == 1 and L.tsgnn_contract_rows_bwd_supported(66, 192) == 0
+    assert L.tsgnn_gat_bwd_parts(32) == 8 and L.tsgnn_gat_bwd_parts(1000) == 1
+    assert L.tsgnn_gat_pack_desc_words() == 23 and L.tsgnn_sage_multi_tn_words() == 11 and L.tsgnn_sage_multi_g_words() == 20
+    bad = np.zeros(64, dtype=np.int64)
+    assert L.tsgnn_gat_pack_f32(bad.ctypes.data, None) == -1                          # zero layers
+    assert L.tsgnn_sage_multi_f32(bad.ctypes.data, None) == -1                        # no problems
+    assert L.tsgnn_wgrad_reduce_sets_f32(None, None) == -1
+    ns, rps, need = np.zeros(1, np.int32), np.zeros(1, np.int64), np.zeros(1, np.int64)
+    assert L.tsgnn_wgrad_blocks_plan(8518, 256, 264, 256, 264, ns.ctypes.data, rps.ctypes.data, need.ctypes.data) == 0
+    assert ns[0] > 0 and ns[0] * rps[0] >= 8518 and rps[0] % 32 == 0 and need[0] == 6 * ns[0] * 129 * 128
+    assert L.tsgnn_wgrad_blocks_plan(100, 600, 264, 600, 264, ns.ctypes.data, rps.ctypes.data, need.ctypes.data) == 0 and ns[0] == 0
+
+
+def test_paired_launch_records_merge_in_order(monkeypatch):
+    """sage_stack.run_paired (host logic): two launch records are issued in lockstep, same-kind steps share a launch, everything
+    else keeps its order inside its own record; an unsupported combination falls back to the two single launches"""
+    import torch
+    from two_stage_gnn_amd import _native as nat, sage_stack
+    issued = []
+    monkeypatch.setattr(nat, "run", lambda q: issued.extend(("single", n, a) for n, a in q))
+    ok = {"multi": True}
+
+    def fake_multi(tn, gs):
+        if not ok["multi"]:
+            return False
+        issued.append(("multi", len(tn), len(gs)))
+        return True
+    monkeypatch.setattr(sage_stack, "_multi", fake_multi)
+    monkeypatch.setattr(nat, "try_call", lambda name, *a: issued.append(("pair", name)) or True)
+    gp = torch.zeros(1)
+
+    def slab(tag):
+        return ("linear_wgrad_f32", (tag,) + (0,) * 10 + (None, None))
+
+    def gather(tag):
+        return ("gather_rowgemm_f32", (tag,) + (0,) * 19)
+
+    def bn(tag):
+        return ("slot_bn_fwd_f32", (gp, gp, 4, 8, 10, 0, tag, 8, 8, 1, None, None, None, 8, None, 0))
+    qa = [gather("a0"), bn("a"), ("readout_x", ("a",)), slab("a1"), gather("a2"), slab("a3")]
+    qb = [gather("b0"), bn("b"), ("other_y", ("b",)), slab("b1"), gather("b2"), slab("b3"), ("tail", ("b",))]
+    sage_stack.run_paired(qa, qb)
+    kinds = [t[0] if t[0] != "single" else t[1] for t in issued]
+    assert kinds == ["multi", "pair", "readout_x", "other_y", "multi", "multi", "tail"]
+    assert issued[0] == ("multi", 0, 2) and issued[4] == ("multi", 2, 2) and issued[5] == ("multi", 2, 0)
+    issued.clear()
+    ok["multi"] = False
+    sage_stack.run_paired([gather("a0"), slab("a1")], [gather("b0"), slab("b1")])
+    assert [t[1] for t in issued] == ["gather_rowgemm_f32", "gather_rowgemm_f32", "linear_wgrad_f32", "linear_wgrad_f32"]
+    assert [t[2][0] for t in issued] == ["a0", "b0", "a1", "b1"]
+
+
+def test_deferred_records_instead_of_launching():
+    from two_stage_gnn_amd import _native as nat
+    ran = []
+    with nat.deferred() as q:
+        nat.call("definitely_not_an_entry_point", 1, 2)          # recorded, not looked up
+        nat.defer(lambda: ran.append("torch-side"))
+        with nat.deferred() as inner:
+            nat.call("inner", 3)
+        assert [n for n, _ in inner] == ["inner"]
+        nat.call("after", 4)
+    assert [n for n, _ in q] == ["definitely_not_an_entry_point", None, "after"] and ran == []
+    assert nat._defer is None
+    q[1][1]()
+    assert ran == ["torch-side"]
+    nat.defer(lambda: ran.append("now"))                          # outside a record: executed at once
+    assert ran[-1] == "now"
