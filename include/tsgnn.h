@@ -498,6 +498,13 @@ int tsgnn_linkpred_loss_f32(const float* S, int64_t lds, int K, int64_t rows, co
                             int nslab, const int* graph_ptr, const int* rowptr, const int* col, const float* val,
                             const int* rowptr_t, const int* col_t, const float* val_t, float clamp, float inv_entries, float* dS,
                             int64_t ldd, float* ws, float* part, float* loss, tsgnn_stream_t stream);
+/* the same with two row operands, p_ij = <X_i, Y_j>, for adj_hop > 1 (encoders.py:419-423: sum_p (S S^T)^p = (S M) S^T):
+ * dX[i] = sum_j (dL/dp_ij) Y_j over the pairs of every graph and the entries (i, j) of the given CSR; the loss value with
+ * count_loss.  A second call with the operands swapped and the transposed CSR gives the other operand's gradient. */
+int tsgnn_linkpred_loss_xy_f32(const float* X, int64_t ldx, const float* Y, int64_t ldy, int K, int64_t rows, const int* slab_row_ptr,
+                               const int* slab_graph, int nslab, const int* graph_ptr, const int* rowptr, const int* col,
+                               const float* val, float clamp, float inv_entries, int count_loss, float* dX, int64_t ldd, float* ws,
+                               float* part, float* loss, tsgnn_stream_t stream);
 
 /* ---------------------------------------------------------------- SAGPool path (pooling.hip) */
 

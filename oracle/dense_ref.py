@@ -217,11 +217,16 @@ def gat_encoder(p, x, adj, final_dim="output_dim"):
     return x, _linear(p, "map_model", x)
 
 
-def diffpool_link_loss(s, adj, batch_num_nodes=None, clamp=1.0, eps=1e-7):
-    """SoftPoolingGcnEncoder.loss's link-prediction term, encoders.py:416-438 (adj_hop = 1).  s: the assignment tensor
+def diffpool_link_loss(s, adj, batch_num_nodes=None, clamp=1.0, eps=1e-7, adj_hop=1):
+    """SoftPoolingGcnEncoder.loss's link-prediction term, encoders.py:416-438 (adj_hop: the powers of S S^T of :419-423).  s: the assignment tensor
     [B, N, K] (masked rows already zero, :371), adj [B, N, N].  The reference clamps with ``torch.Tensor(1)`` (:424), an
     UNINITIALISED value: it is a parameter here (parity of this term is pinned by the source lines, not by a vector)."""
-    pred = torch.minimum(s @ s.transpose(1, 2), torch.tensor(float(clamp)))                 # :418-424
+    pred0 = s @ s.transpose(1, 2)                                                            # :418
+    tmp, pred = pred0, pred0
+    for _ in range(adj_hop - 1):                                                             # :421-423
+        tmp = tmp @ pred0
+        pred = pred + tmp
+    pred = torch.minimum(pred, torch.tensor(float(clamp), dtype=pred.dtype))                # :424
     ll = -adj * torch.log(pred + eps) - (1 - adj) * torch.log(1 - pred + eps)                # :428
     B, N = adj.size(0), adj.size(1)
     if batch_num_nodes is None:

@@ -616,6 +616,43 @@ def test_link_pred_loss_vs_oracle(masked, sym):
         torch.testing.assert_close(gs, 3.0 * sr.grad, rtol=2e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("hop", [2, 3])
+@pytest.mark.parametrize("masked,sym", [(True, True), (True, False), (False, True)])
+def test_link_pred_loss_adj_hop_vs_oracle(hop, masked, sym):
+    """adj_hop > 1 (encoders.py:419-423: pred = sum_p (S S^T)^p, clamped): value and d loss / d S against the dense restatement,
+    fp32 and fp64 (the gradient runs through the K x K polynomial of S^T S)"""
+    from two_stage_gnn_amd import diffpool as dp
+    from two_stage_gnn_amd import message_passing as mp
+    from two_stage_gnn_amd.graph import GraphBatch
+    B, nmax, K = 5, 40, 24
+    x, adj, sizes = dense_batch(45, B, nmax, 3, sizes=[40, 13, 1, 33, 20], p_edge=0.15)
+    gen = torch.Generator().manual_seed(11)
+    if not sym:
+        adj = adj * (torch.rand(adj.shape, generator=gen) < 0.6).float() * (0.5 + torch.rand(adj.shape, generator=gen))
+    s = torch.softmax(torch.randn(B, nmax, K, generator=gen) * 1.5, dim=-1) * 0.6          # (scaled: part of the entries stays below the clamp)
+    if masked:
+        for b, n in enumerate(sizes):
+            s[b, int(n):] = 0
+    sr = s.clone().double().requires_grad_(True)
+    ref = R.diffpool_link_loss(sr, adj.double(), sizes if masked else None, clamp=1.0, adj_hop=hop)
+    ref.backward()
+    frac_clamped = float(((sr.detach() @ sr.detach().transpose(1, 2)) >= 1).float().mean())
+    assert frac_clamped < 0.9
+    g = GraphBatch.from_dense(adj.cuda(), sizes if masked else None, layout="packed" if masked else "padded", assume_symmetric=sym)
+    sp = (mp.pack_rows(s.cuda(), g) if masked else s.cuda().reshape(B * nmax, K)).detach().requires_grad_(True)
+    got = dp.link_pred_loss(sp, g, clamp=1.0, masked=masked, adj_hop=hop)
+    torch.testing.assert_close(got.detach().cpu().double(), ref.detach(), rtol=2e-4, atol=1e-6)
+    (got * 3.0).backward()
+    gs = mp.unpack_rows(sp.grad, g).cpu() if masked else sp.grad.reshape(B, nmax, K).cpu()
+    gr = sr.grad.clone()
+    if masked:
+        for b, n in enumerate(sizes):
+            gs[b, int(n):] = 0
+            gr[b, int(n):] = 0
+    err = (gs.double() - 3.0 * gr).abs().max().item()
+    assert err <= 2e-3 * (3.0 * gr).abs().max().item() + 1e-7, (err, gr.abs().max().item())
+
+
 def test_diffpool_linkpred_encoder_vs_oracle():
     """SoftPoolingGcnEncoder(linkpred=True, num_pooling=1): CE + link loss and all parameter gradients vs the oracle;
     num_pooling=2 reproduces the reference's failure (trap T7)"""

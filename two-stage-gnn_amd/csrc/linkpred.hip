@@ -32,11 +32,17 @@ __device__ __forceinline__ float lp_clamp(float p, float clamp, float& gate) {
 // is bound by LDS round trips, so reads are wide and batched (the first version, one b32 read per FMA, ran 5x slower).
 constexpr int LP_LD = LP_KMAX + 4;
 constexpr int LP_NY = 4;                 // column-tile chunks per row slab (grid.y): 4 blocks per CU hide each other's LDS / L2 round trips
-__global__ __launch_bounds__(256) void linkpred_pairs_kernel(const float* __restrict__ S, int64_t lds_, int K,
+// Y (nullable = S): the operand of the COLUMN index j, p_ij = <S_i, Y_j> — adj_hop > 1 (encoders.py:419-423) is
+// sum_p (S S^T)^p = (S M) S^T with a small per-graph M, i.e. two different row operands; grad_scale: 2 for the symmetric
+// one-operand form (row i receives entry (i, j) and its mirror), 1 when the caller runs one pass per operand.
+__global__ __launch_bounds__(256) void linkpred_pairs_kernel(const float* __restrict__ S, int64_t lds_, const float* __restrict__ Y,
+                                                             int64_t ldy, int K,
                                                              const int* __restrict__ slab_row_ptr, const int* __restrict__ slab_graph,
                                                              const int* __restrict__ graph_ptr, float clamp, float inv_entries,
+                                                             float grad_scale, int count_loss,
                                                              float* __restrict__ dSp, int64_t ldd, int64_t rows,
                                                              float* __restrict__ part) {
+  if (!Y) { Y = S; ldy = lds_; }
   __shared__ __attribute__((aligned(16))) float s_i[LP_TILE][LP_LD];
   __shared__ __attribute__((aligned(16))) float s_j[LP_TILE][LP_LD];
   __shared__ __attribute__((aligned(16))) float s_g[LP_TILE][LP_TILE + 4];
@@ -62,7 +68,7 @@ __global__ __launch_bounds__(256) void linkpred_pairs_kernel(const float* __rest
     __syncthreads();
     for (int t = tid; t < LP_TILE * K4; t += 256) {
       const int r = t / K4, k = t - r * K4;
-      s_j[r][k] = (j0 + r < g1 && k < K) ? S[(int64_t)(j0 + r) * lds_ + k] : 0.f;
+      s_j[r][k] = (j0 + r < g1 && k < K) ? Y[(int64_t)(j0 + r) * ldy + k] : 0.f;
     }
     __syncthreads();
     float p[4] = {0.f, 0.f, 0.f, 0.f};
@@ -104,7 +110,7 @@ __global__ __launch_bounds__(256) void linkpred_pairs_kernel(const float* __rest
     }
   }
   if (i0 + ti < i1) {
-    const float sc = 2.f * inv_entries;
+    const float sc = grad_scale * inv_entries;
 #pragma unroll
     for (int q = 0; q < LP_KMAX / 32; ++q) {
       const int k = 4 * kq + 32 * q;
@@ -118,17 +124,19 @@ __global__ __launch_bounds__(256) void linkpred_pairs_kernel(const float* __rest
   loss = wave_sum(loss);
   if ((tid & 63) == 0) s_red[tid >> 6] = loss;
   __syncthreads();
-  if (tid == 0) part[slab * LP_NY + blockIdx.y] = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) * inv_entries;
+  if (tid == 0) part[slab * LP_NY + blockIdx.y] = count_loss ? ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) * inv_entries : 0.f;
 }
 
 // edge corrections, one wave per row i: entries (i, j) of the CSR (and of its transpose when A is not symmetric):
 //   loss += a_ij (f1 - f0)(p_ij);  dS_i += sym_factor * a_ij (f1 - f0)'(p_ij) s_j
-__global__ __launch_bounds__(256) void linkpred_edges_kernel(const float* __restrict__ S, int64_t lds_, int K,
+__global__ __launch_bounds__(256) void linkpred_edges_kernel(const float* __restrict__ S, int64_t lds_, const float* __restrict__ Y,
+                                                             int64_t ldy, int K,
                                                              const int* __restrict__ rowptr, const int* __restrict__ col,
                                                              const float* __restrict__ val, int64_t rows, float clamp,
                                                              float inv_entries, float grad_factor, int count_loss,
                                                              const float* __restrict__ dSp /*nullable: LP_NY partials to start from*/,
                                                              float* __restrict__ dS, int64_t ldd, float* __restrict__ part) {
+  if (!Y) { Y = S; ldy = lds_; }
   const int lane = threadIdx.x & 63;
   const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   __shared__ float s_red[4];
@@ -150,8 +158,8 @@ __global__ __launch_bounds__(256) void linkpred_edges_kernel(const float* __rest
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int64_t j = __shfl(cj, min(q0 + u, cnt - 1), 64);
-          b0[u] = (lane < K && q0 + u < cnt) ? S[j * lds_ + lane] : 0.f;
-          b1[u] = (lane + 64 < K && q0 + u < cnt) ? S[j * lds_ + lane + 64] : 0.f;
+          b0[u] = (lane < K && q0 + u < cnt) ? Y[j * ldy + lane] : 0.f;
+          b1[u] = (lane + 64 < K && q0 + u < cnt) ? Y[j * ldy + lane + 64] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -219,18 +227,39 @@ int tsgnn_linkpred_loss_f32(const float* S, int64_t lds, int K, int64_t rows, co
   if (K > LP_KMAX) return TSGNN_EUNSUPPORTED;
   if ((rowptr_t == nullptr) != (col_t == nullptr)) return TSGNN_EINVAL;
   const unsigned eblk = (unsigned)ceil_div64(rows, 4);
-  linkpred_pairs_kernel<<<dim3((unsigned)nslab, LP_NY), 256, 0, stream>>>(S, lds, K, slab_row_ptr, slab_graph, graph_ptr, clamp,
-                                                                         inv_entries, ws, ldd, rows, part);
+  linkpred_pairs_kernel<<<dim3((unsigned)nslab, LP_NY), 256, 0, stream>>>(S, lds, nullptr, 0, K, slab_row_ptr, slab_graph, graph_ptr, clamp,
+                                                                         inv_entries, 2.f, 1, ws, ldd, rows, part);
   // symmetric adjacency: entry (i,j) and its mirror give row i the same term twice
-  linkpred_edges_kernel<<<eblk, 256, 0, stream>>>(S, lds, K, rowptr, col, val, rows, clamp, inv_entries, rowptr_t ? 1.f : 2.f, 1, ws, dS,
-                                                  ldd, part + nslab * LP_NY);
+  linkpred_edges_kernel<<<eblk, 256, 0, stream>>>(S, lds, nullptr, 0, K, rowptr, col, val, rows, clamp, inv_entries, rowptr_t ? 1.f : 2.f, 1, ws,
+                                                  dS, ldd, part + nslab * LP_NY);
   int nparts = nslab * LP_NY + (int)eblk;
   if (rowptr_t) {
-    linkpred_edges_kernel<<<eblk, 256, 0, stream>>>(S, lds, K, rowptr_t, col_t, val_t, rows, clamp, inv_entries, 1.f, 0, nullptr, dS,
-                                                    ldd, part + nparts);
+    linkpred_edges_kernel<<<eblk, 256, 0, stream>>>(S, lds, nullptr, 0, K, rowptr_t, col_t, val_t, rows, clamp, inv_entries, 1.f, 0, nullptr,
+                                                    dS, ldd, part + nparts);
     nparts += (int)eblk;
   }
   linkpred_sum_kernel<<<1, 256, 0, stream>>>(part, nparts, loss);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+/* two-operand form for adj_hop > 1 (encoders.py:419-423): p_ij = <X_i, Y_j> over the row pairs of every graph and the CSR
+ * entries (i, j).  Writes dX[i] = dL/dX_i = sum_j (dL/dp_ij) Y_j (the caller runs a second pass with the operands swapped and
+ * the transposed CSR for dL/dY) and, with count_loss, the loss value.  part: nslab * chunks + ceil(rows / 4) floats. */
+int tsgnn_linkpred_loss_xy_f32(const float* X, int64_t ldx, const float* Y, int64_t ldy, int K, int64_t rows, const int* slab_row_ptr,
+                               const int* slab_graph, int nslab, const int* graph_ptr, const int* rowptr, const int* col,
+                               const float* val, float clamp, float inv_entries, int count_loss, float* dX, int64_t ldd, float* ws,
+                               float* part, float* loss, tsgnn_stream_t stream) {
+  if (!X || !Y || !slab_row_ptr || !slab_graph || !graph_ptr || !rowptr || !dX || !ws || !part || (count_loss && !loss) || nslab <= 0 ||
+      rows <= 0 || K <= 0 || ldx < K || ldy < K || ldd < K)
+    return TSGNN_EINVAL;
+  if (K > LP_KMAX) return TSGNN_EUNSUPPORTED;
+  const unsigned eblk = (unsigned)ceil_div64(rows, 4);
+  linkpred_pairs_kernel<<<dim3((unsigned)nslab, LP_NY), 256, 0, stream>>>(X, ldx, Y, ldy, K, slab_row_ptr, slab_graph, graph_ptr, clamp,
+                                                                         inv_entries, 1.f, count_loss, ws, ldd, rows, part);
+  linkpred_edges_kernel<<<eblk, 256, 0, stream>>>(X, ldx, Y, ldy, K, rowptr, col, val, rows, clamp, inv_entries, 1.f, count_loss, ws, dX, ldd,
+                                                  part + nslab * LP_NY);
+  if (count_loss) linkpred_sum_kernel<<<1, 256, 0, stream>>>(part, nslab * LP_NY + (int)eblk, loss);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }

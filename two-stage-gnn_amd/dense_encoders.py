@@ -480,14 +480,12 @@ class SoftPoolingGcnEncoder(GcnEncoderGraph):
         loss = super().loss(pred, label)
         if self.linkpred:
             from . import diffpool as dp
-            if adj_hop != 1:
-                raise NotImplementedError("adj_hop > 1 (powers of S S^T) is never used by the reference (train.py:130)")
             if self.num_pooling != 1:
                 # trap T7: the reference multiplies the LAST level's assignment with the ORIGINAL adjacency (:418,428)
                 raise RuntimeError("link-prediction loss with num_pooling >= 2: the last assignment tensor [B, %d, .] does not "
                                    "match the input adjacency (the reference fails with a shape error here too)"
                                    % self.assign_tensor.size(-2))
             self.link_loss = dp.link_pred_loss(self.assign_tensor, self._link_graph, self.linkpred_clamp,
-                                               masked=self._link_masked)
+                                               masked=self._link_masked, adj_hop=adj_hop)
             return loss + self.link_loss
         return loss

@@ -227,10 +227,12 @@ def diffpool_contract_rows(S, Z, g):
 
 # ----------------------------------------------------------------------------- link-prediction side loss (f4)
 class _LinkPredLoss(torch.autograd.Function):
-    """encoders.py:416-440 (adj_hop = 1): value and d loss / d S from one launch set (csrc/linkpred.hip)."""
+    """encoders.py:416-440: value and d loss / d S from one launch set (csrc/linkpred.hip).  adj_hop > 1 (:419-423):
+    pred = sum_{p=1..hop} (S S^T)^p = (S M) S^T with M_b = sum_{p<hop} (S_b^T S_b)^p, a K x K matrix per graph — the pair / edge
+    kernels run on the two row operands P = S M and S (one pass per operand), the chain rule through M is K x K algebra."""
 
     @staticmethod
-    def forward(ctx, s, g, clamp, masked):
+    def forward(ctx, s, g, clamp, masked, adj_hop):
         import numpy as np
         s = s.contiguous()
         K = s.size(1)
@@ -245,7 +247,6 @@ class _LinkPredLoss(torch.autograd.Function):
         srp, slab_graph, nslab = cache
         sizes = g.sizes.astype(np.float64)
         entries = float((sizes * sizes).sum()) if masked else float(g.nmax) * g.nmax * g.B
-        ds = _f32(s.size(0), K, device=s.device, zero=(s.size(0) > rows))
         ny = int(nat.lib().tsgnn_linkpred_chunks())
         ws = _f32(ny * rows * K, device=s.device)
         part = _f32(ny * nslab + 2 * ((rows + 3) // 4), device=s.device)
@@ -254,18 +255,45 @@ class _LinkPredLoss(torch.autograd.Function):
             rp_t = col_t = val_t = None
         else:
             rp_t, col_t, val_t = g.transposed()
-        nat.call("linkpred_loss_f32", s, s.stride(0), K, rows, srp, slab_graph, nslab, g.graph_ptr, g.rowptr, g.col, g.val,
-                 rp_t, col_t, val_t, float(clamp), 1.0 / entries, ds, ds.stride(0), ws, part, loss)
+        pad = s.size(0) > rows
+        if adj_hop == 1:
+            ds = _f32(s.size(0), K, device=s.device, zero=pad)
+            nat.call("linkpred_loss_f32", s, s.stride(0), K, rows, srp, slab_graph, nslab, g.graph_ptr, g.rowptr, g.col, g.val,
+                     rp_t, col_t, val_t, float(clamp), 1.0 / entries, ds, ds.stride(0), ws, part, loss)
+        else:
+            B, R = g.B, s.size(0)
+            G = _ragged_tn(s, s, g)                                            # S_b^T S_b                      [B, K, K]
+            pw = [torch.eye(K, device=s.device).expand(B, K, K).contiguous()]
+            for _ in range(adj_hop - 1):
+                pw.append(torch.bmm(pw[-1], G))                                # G^p  (K x K: library plumbing, not the hot path)
+            M = torch.stack(pw).sum(0)
+            P = _ragged_nn(s, M, g, False, K, R)                               # P_b = S_b M_b, pred = P S^T    (:419-423)
+            dP, dQ = _f32(R, K, device=s.device, zero=pad), _f32(R, K, device=s.device, zero=pad)
+            nat.call("linkpred_loss_xy_f32", P, P.stride(0), s, s.stride(0), K, rows, srp, slab_graph, nslab, g.graph_ptr, g.rowptr,
+                     g.col, g.val, float(clamp), 1.0 / entries, 1, dP, dP.stride(0), ws, part, loss)
+            rt, ct, vt = (g.rowptr, g.col, g.val) if rp_t is None else (rp_t, col_t, val_t)
+            nat.call("linkpred_loss_xy_f32", s, s.stride(0), P, P.stride(0), K, rows, srp, slab_graph, nslab, g.graph_ptr, rt, ct, vt,
+                     float(clamp), 1.0 / entries, 0, dQ, dQ.stride(0), ws, part, None)
+            ds = dQ
+            _ragged_nn(dP, M.transpose(1, 2).contiguous(), g, False, K, R, out=ds)      # P = S M   : dS += dP M^T
+            dM = _ragged_tn(s, dP, g)                                                    #             dM  = S^T dP
+            dG = torch.zeros_like(G)
+            for p_ in range(1, adj_hop):                                                 # M = sum_p G^p : dG = sum_p sum_q (G^q)^T dM (G^(p-1-q))^T
+                for q in range(p_):
+                    dG += torch.bmm(torch.bmm(pw[q].transpose(1, 2), dM), pw[p_ - 1 - q].transpose(1, 2))
+            _ragged_nn(s, (dG + dG.transpose(1, 2)).contiguous(), g, False, K, R, out=ds)   # G = S^T S : dS += S (dG + dG^T)
         ctx.save_for_backward(ds)
         return loss.view(())
 
     @staticmethod
     def backward(ctx, dl):
         (ds,) = ctx.saved_tensors
-        return ds * dl, None, None, None
+        return ds * dl, None, None, None, None
 
 
-def link_pred_loss(s, g, clamp=1.0, masked=True):
+def link_pred_loss(s, g, clamp=1.0, masked=True, adj_hop=1):
     """DiffPool's link-prediction side loss on the packed assignment rows s[total_rows, K] of GraphBatch g
     (ghost rows carry zeros and are outside every graph: the reference's adj_mask)."""
-    return _LinkPredLoss.apply(s, g, float(clamp), bool(masked))
+    if int(adj_hop) < 1:
+        raise ValueError("adj_hop >= 1")
+    return _LinkPredLoss.apply(s, g, float(clamp), bool(masked), int(adj_hop))
