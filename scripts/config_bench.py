@@ -131,6 +131,25 @@ print("cfg4 full optimiser step (fwd + bwd + bucket + clip + Adam) from one hipG
       % (t, 128 / t * 1e6, float(gs4.loss)))
 torch.cuda.set_stream(_S)
 
+def optimiser_step_us(model, loss_fn, B, tag, iters=50):
+    """fwd + bwd + bucket + clip + Adam from one hipGraph (FlatTrainer / GraphedStep are model-agnostic)"""
+    tr = FlatTrainer(model, lr=5e-4, clip=2.0)
+    gs = GraphedStep(tr, loss_fn, warmup=3)
+    for _ in range(5):
+        gs.step()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record(gs.stream)
+    for _ in range(iters):
+        gs.step()
+    e1.record(gs.stream); e1.synchronize()
+    t = e0.elapsed_time(e1) / iters * 1e3
+    print("%s full optimiser step (fwd + bwd + bucket + clip + Adam) from one hipGraph: %.0f us/step -> %.0f graphs/s per GPU" % (tag, t, B / t * 1e6))
+    torch.cuda.set_stream(_S)
+
+
+optimiser_step_us(gat32, lambda: gat32.loss(gat32(x32, g32)[1], lab32), 32, "cfg3 b32")
+
 # config 5: DD DiffPool 64 -> 8, h=64, batch 16, Nmax 512
 hb5 = synthetic.host_batch(4, 16, "DD", 512)
 g5, x5, lab5 = synthetic.to_device(hb5, dev)
@@ -141,6 +160,7 @@ def step_dp():
 t = timeit(step_dp, iters=10, warm=3)
 tg = graph_us(step_dp)
 print("cfg5 DD DiffPool 512->64->8 h64 b16: %.0f us/step eager, %s us/step hipGraph -> %.0f graphs/s" % (t, "%.0f" % tg if tg else "n/a", 16 / (tg or t) * 1e6))
+optimiser_step_us(dpm, lambda: dpm.loss(dpm(x5, g5, hb5["sizes"], assign_x=x5)[1], lab5), 16, "cfg5")
 # the contraction alone, level 1 (S [rows,64], Z [rows,192]) + level 2 dense
 Sm = torch.softmax(torch.randn(g5.total_rows, 64, device=dev), -1); Sm[g5.n_rows:] = 0
 Z = torch.randn(g5.total_rows, 192, device=dev)

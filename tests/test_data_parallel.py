@@ -394,6 +394,51 @@ def test_graphed_step_replays_the_eager_step():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("family", ["gat", "diffpool"])
+def test_graphed_step_other_model_families(family):
+    """the flat-bucket trainer and the hipGraph step are model-agnostic: the fused GAT layers (packed heads, blocked dW) and the
+    DiffPool encoder (paired level-0 launches, one-launch pooled levels, fused contractions) replay from one hipGraph exactly
+    as they run eagerly, and the loss goes down"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from two_stage_gnn_amd import dense_encoders as E, gat_encoders as G, synthetic, message_passing as mp
+    from two_stage_gnn_amd.data_parallel import FlatTrainer, GraphedStep
+
+    class A:
+        bias = True
+    dev = torch.device("cuda")
+    out = []
+    for graphed in (False, True):
+        torch.manual_seed(7)
+        if family == "gat":
+            hb = synthetic.host_batch(seed=3, B=6, shape="DD", nmax=400)
+            x, adj = synthetic.to_dense(hb)
+            model = G.DGATEncoderGraph(89, 64, 64, 2, None, num_layers=2, num_heads=[4, 4], final_dim="number_classes",
+                                       per_graph_features=True).to(dev)
+            xr, g = model.packed_batch(x.to(dev), adj.to(dev), hb["sizes"])
+            label = torch.from_numpy(hb["label"]).to(dev)
+            loss_fn = lambda: model.loss(model(xr, g)[1], label)
+        else:
+            hb = synthetic.host_batch(seed=4, B=8, shape="DD", nmax=256)
+            g, x, label = synthetic.to_device(hb, dev)
+            model = E.SoftPoolingGcnEncoder(256, 89, 64, 64, 2, 3, 64, assign_ratio=0.125, num_pooling=2, bn=True, linkpred=False,
+                                            args=A(), assign_input_dim=89, final_dim="number_classes").to(dev)
+            loss_fn = lambda: model.loss(model(x, g, hb["sizes"], assign_x=x)[1], label)
+        tr = FlatTrainer(model, lr=5e-3, clip=2.0)
+        gs = GraphedStep(tr, loss_fn, warmup=2, use_graph=graphed)
+        losses = []
+        for _ in range(6):
+            gs.step()
+            torch.cuda.synchronize()                               # (the step runs on the GraphedStep's own stream)
+            losses.append(float(gs.loss.detach()))
+        mp.check_device_errors()
+        out.append((tr.flat_param.clone(), losses))
+    assert out[1][1][-1] < out[1][1][0]
+    torch.testing.assert_close(out[1][0], out[0][0], rtol=0, atol=0)
+    assert out[0][1] == out[1][1]
+
+
+@pytest.mark.gpu
 def test_deferred_loss_equals_ordinary_step():
     """FlatTrainer(defer_loss=True): the cross-entropy launches nothing, the head's backward kernel rebuilds its gradient and
     writes the loss value — same loss and same parameters after the step as the ordinary sequence (bitwise)"""
