@@ -416,13 +416,14 @@ int tsgnn_gat_fused_supported(int H, int Fh);
 /* y[i] = act( sum_j alpha_ij hp[j, :C] + sum_{edge-less j of i's graph} (iso_w / N) hp[j, :C] ), alpha = softmax over dim=1
  * (column-wise, :41) of the masked LeakyReLU scores; mean_heads: mean over heads before the ELU (:78-83), y is [rows, Fh].
  * (rowptr, col): A; (rp_t, col_t): A^T.  row_graph nullable (then graph = row / nmax).  iso_*: nullable together; iso_ptr[B + 1].
- * drop_p > 0: attention dropout (:42), Philox4x32-10 keyed on (seed; i, j, head).
+ * drop_p > 0: attention dropout (:42), Philox4x32-10 keyed on (seed + *drop_ctr; i, j, head); drop_ctr (nullable) is a DEVICE counter
+ * read when the kernel starts, so a step replayed from a hipGraph that advances it draws a new mask every replay.
  * stat[rows, H, 2] (out): (max, 1 / sum of exponentials) of every softmax column, written by a first small launch and read by
  * the attention kernel here and by the backward. */
 int tsgnn_gat_attn_fwd_f32(const float* hp, int64_t ldh, const int* rowptr, const int* col, const int* rp_t, const int* col_t,
                            int64_t rows, int H, int Fh, float slope, const int* row_graph, int nmax, const int* iso_idx,
                            const float* iso_w, const int* iso_ptr, float uscale, int mean_heads, int apply_elu, float drop_p,
-                           uint64_t seed, float* stat, float* y, int64_t ldy, tsgnn_stream_t stream);
+                           uint64_t seed, const unsigned long long* drop_ctr, float* stat, float* y, int64_t ldy, tsgnn_stream_t stream);
 /* backward, column-wise: dhp[:, :C] (features), dhp[:, C+H+h] (d s_col), zero pad columns; per-entry terms t1, t2 [nnz, H] (A^T
  * entry order) and S [rows, H] for tsgnn_gat_score_rowsum_f32, which writes dhp[:, C+h] (d s_row) and — from the partial sums
  * dupart[B, tsgnn_gat_bwd_parts(B), C] of dpre over each graph's rows — dh of the listed edge-less columns.  dy, y: the layer's
@@ -433,12 +434,13 @@ int tsgnn_gat_bwd_parts(int B);
 int tsgnn_gat_attn_bwd_f32(const float* hp, int64_t ldh, const float* y, int64_t ldy, const float* dy, int64_t lddy, const int* rp_t,
                            const int* col_t, int64_t rows, int H, int Fh, float slope, int mean_heads, int apply_elu,
                            const int* graph_ptr, int B, const int* iso_idx, const float* iso_w, const int* iso_ptr,
-                           const float* iso_row, int iso_row_ld, float uscale, float drop_p, uint64_t seed, const float* stat,
-                           float* dhp, int Ns, float* t1, float* t2, float* S, float* dupart, tsgnn_stream_t stream);
+                           const float* iso_row, int iso_row_ld, float uscale, float drop_p, uint64_t seed,
+                           const unsigned long long* drop_ctr, const float* stat, float* dhp, int Ns, float* t1, float* t2, float* S,
+                           float* dupart, tsgnn_stream_t stream);
 /* the dropout multipliers (0 or 1 / (1 - p)) of attention elements (i0 + i, j0 + j) of every head, out[ni, nj, H] — what the two
  * kernels above apply; lets a test hand the very same mask to the dense oracle */
-int tsgnn_gat_dropout_mult_f32(float drop_p, uint64_t seed, int64_t i0, int64_t ni, int64_t j0, int64_t nj, int H, float* out,
-                               tsgnn_stream_t stream);
+int tsgnn_gat_dropout_mult_f32(float drop_p, uint64_t seed, const unsigned long long* drop_ctr, int64_t i0, int64_t ni, int64_t j0,
+                               int64_t nj, int H, float* out, tsgnn_stream_t stream);
 int tsgnn_gat_score_rowsum_f32(const int* rowptr, const int* col, const int* eperm, const float* t1, const float* t2, const float* S,
                                int64_t rows, int H, float* dhp, int64_t ldh, int C, const float* dupart, int B, const int* iso_idx,
                                const float* iso_w, const int* iso_ptr, float uscale, tsgnn_stream_t stream);

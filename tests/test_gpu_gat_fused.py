@@ -107,14 +107,14 @@ def test_fused_path_is_the_one_that_runs():
     assert not any(n in names for n in ("edge_softmax_fwd_f32", "csr_sddmm_heads_f32", "node_scores2_f32"))
 
 
-def _mults(p, seed, B, N, H):
-    """[H][B, N, N] multipliers the kernels apply to the attention elements of a padded batch (rows b*N + i)"""
+def _mults(p, key, B, N, H):
+    """[H][B, N, N] multipliers the kernels apply to the attention elements of a padded batch (rows b*N + i); key = (seed,
+    device counter snapshot) of the layer call (gat_fused.last_dropout_key)"""
     from two_stage_gnn_amd import _native as nat
-    out = []
     blocks = []
     for b in range(B):
         t = torch.empty(N, N, H, device="cuda")
-        nat.call("gat_dropout_mult_f32", float(p), int(seed), b * N, N, b * N, N, H, t)
+        nat.call("gat_dropout_mult_f32", float(p), int(key[0]), key[1], b * N, N, b * N, N, H, t)
         blocks.append(t.cpu())
     full = torch.stack(blocks)                                   # [B, N, N, H]
     return [full[..., h].contiguous() for h in range(H)]
@@ -130,23 +130,18 @@ def test_attention_dropout_matches_oracle_with_the_same_mask(concat):
     adj[0, 3, :] = 0; adj[0, :, 3] = 0
     torch.manual_seed(5)
     m = G.DGATLayer(fin, Fo, dropout=p, n_heads=H, concat=concat).cuda().train()
-    seed = 123456789
-    old = gf.new_seed
-    gf.new_seed = lambda: seed
-    try:
-        xg = x.cuda().requires_grad_(True)
-        torch.manual_seed(11)                                     # F.dropout on x (:71) draws from torch's generator
-        y = m(xg, adj.cuda())
-        gy = torch.randn_like(y)
-        (y * gy).sum().backward()
-    finally:
-        gf.new_seed = old
+    xg = x.cuda().requires_grad_(True)
+    torch.manual_seed(11)                                         # F.dropout on x (:71) draws from torch's generator
+    y = m(xg, adj.cuda())
+    key = gf.last_dropout_key
+    gy = torch.randn_like(y)
+    (y * gy).sum().backward()
     # oracle: the same input dropout (replayed from the same generator state) and the same attention multipliers
     torch.manual_seed(11)
     xd_keep = torch.nn.functional.dropout(torch.ones_like(xg), p, training=True).cpu()
     p_ref = {"l." + k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
     xr = x.clone().requires_grad_(True)
-    mult = _mults(p, seed, B, N, H)
+    mult = _mults(p, key, B, N, H)
     yr = R.gat_layer(p_ref, "l", xr * xd_keep, adj, concat, 0.2, att_mult=mult)
     (yr * gy.cpu()).sum().backward()
     frac = sum(float((mm == 0).float().mean()) for mm in mult) / H
@@ -157,6 +152,31 @@ def test_attention_dropout_matches_oracle_with_the_same_mask(concat):
         ref = p_ref["l." + k].grad
         err = (prm.grad.cpu() - ref).abs().max().item()
         assert err <= 1e-3 * ref.abs().max().item() + 1e-6, (k, err)
+
+
+def test_attention_dropout_draws_a_new_mask_per_graph_replay():
+    """the dropout key lives on the device: a training step captured in a hipGraph advances it at every replay (a host seed
+    would be frozen into the capture)"""
+    from two_stage_gnn_amd import gat_encoders as G
+    B, N = 1, 40
+    x, adj, sizes = dense_batch(12, B, N, 12, sizes=[34], p_edge=0.15)
+    torch.manual_seed(8)
+    m = G.DGATLayer(12, 16, dropout=0.5, n_heads=2, concat=True).cuda().train()
+    m.dropout = 0.0                                               # (keep F.dropout on x out of it: only the attention masks vary)
+    xs, adjs = x.cuda(), adj.cuda()
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        for _ in range(2):
+            y = m(xs, adjs)
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=st):
+            y = m(xs, adjs)
+        outs = []
+        for _ in range(3):
+            gr.replay(); torch.cuda.synchronize()
+            outs.append(y.clone())
+    assert not torch.equal(outs[0], outs[1]) and not torch.equal(outs[1], outs[2])
 
 
 def test_attention_dropout_eval_and_batched():

@@ -41,7 +41,16 @@ struct Drop {
   unsigned thresh;     // an element is dropped when its 32 random bits are < thresh (= p * 2^32); 0: no dropout
   float scale;         // 1 / (1 - p)
   unsigned seed_lo, seed_hi;
-};
+  const unsigned long long* ctr;   // nullable: a DEVICE counter added to the key when the kernel starts (a step replayed from a
+};                                 // hipGraph advances it, so every replay draws a new mask; the backward reads the same value)
+__device__ __forceinline__ Drop drop_key(Drop d) {
+  if (d.thresh != 0u && d.ctr) {
+    const unsigned long long c = *d.ctr;
+    d.seed_lo += (unsigned)(c & 0xffffffffull);
+    d.seed_hi += (unsigned)(c >> 32);
+  }
+  return d;
+}
 // multiplier of attention element (i, j) of head h: 0 or 1 / (1 - p)
 __device__ __forceinline__ float drop_mult(const Drop& d, unsigned i, unsigned j, int h) {
   if (d.thresh == 0u) return 1.f;
@@ -115,6 +124,7 @@ __global__ __launch_bounds__(256, GAT_WAVES_PER_SIMD) void gat_attn_fwd_kernel(G
   const int co = live ? 4 * lane : 0;
   const float* __restrict__ hp = a.hp;
   const int64_t ldh = a.ldh;
+  if (DROP) a.drop = drop_key(a.drop);
   TR(0);
   const int e0 = a.rowptr[r], e1 = a.rowptr[r + 1];
   const int EB = min(8, 64 / H);              // entries per batch: lane p = (entry p / H, head p % H) computes one alpha
@@ -290,6 +300,7 @@ __device__ __forceinline__ void bwd_entry(const GatBwd& a, ColAcc& c, const floa
 template <int LPH, bool DROP>
 __global__ __launch_bounds__(256, GAT_BWD_WAVES_PER_SIMD) void gat_attn_bwd_kernel(GatBwd a) {
   __shared__ __attribute__((aligned(16))) float red[4][256];
+  if (DROP) a.drop = drop_key(a.drop);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int H = a.H, C = H * a.Fh, G = H * LPH;
   const bool live = lane < G;
@@ -438,6 +449,7 @@ __global__ void gat_dropout_mult_kernel(Drop d, int64_t i0, int64_t ni, int64_t 
   if (t >= ni * nj * H) return;
   const int h = (int)(t % H);
   const int64_t j = (t / H) % nj, i = t / H / nj;
+  d = drop_key(d);
   out[t] = drop_mult(d, (unsigned)(i0 + i), (unsigned)(j0 + j), h);
 }
 
@@ -543,8 +555,8 @@ inline bool fused_ok(int H, int Fh) {
          H * lph <= 64;
 }
 
-inline Drop make_drop(float p, uint64_t seed) {
-  Drop d{0u, 1.f, (unsigned)(seed & 0xffffffffu), (unsigned)(seed >> 32)};
+inline Drop make_drop(float p, uint64_t seed, const unsigned long long* ctr) {
+  Drop d{0u, 1.f, (unsigned)(seed & 0xffffffffu), (unsigned)(seed >> 32), ctr};
   if (p > 0.f) {
     const double t = (double)p * 4294967296.0;
     d.thresh = t >= 4294967295.0 ? 0xffffffffu : (unsigned)t;
@@ -590,7 +602,7 @@ int tsgnn_gat_fused_supported(int H, int Fh) { return fused_ok(H, Fh) ? 1 : 0; }
 int tsgnn_gat_attn_fwd_f32(const float* hp, int64_t ldh, const int* rowptr, const int* col, const int* rp_t, const int* col_t,
                            int64_t rows, int H, int Fh, float slope, const int* row_graph, int nmax, const int* iso_idx,
                            const float* iso_w, const int* iso_ptr, float uscale, int mean_heads, int apply_elu, float drop_p,
-                           uint64_t seed, float* stat, float* y, int64_t ldy, tsgnn_stream_t stream) {
+                           uint64_t seed, const unsigned long long* drop_ctr, float* stat, float* y, int64_t ldy, tsgnn_stream_t stream) {
   if (!hp || !rowptr || !col || !rp_t || !col_t || !y || !stat || (reinterpret_cast<uintptr_t>(stat) & 7) || rows < 0 || nmax <= 0 || drop_p < 0.f || drop_p >= 1.f) return TSGNN_EINVAL;
   if (!fused_ok(H, Fh)) return TSGNN_EUNSUPPORTED;
   const int C = H * Fh;
@@ -602,7 +614,7 @@ int tsgnn_gat_attn_fwd_f32(const float* hp, int64_t ldh, const int* rowptr, cons
   gat_col_stats_kernel<<<(unsigned)ceil_div64(rows * H * 8, 256), 256, 0, stream>>>(hp, ldh, rp_t, col_t, rows, H, C, slope,
                                                                                        reinterpret_cast<float2*>(stat));
   GatFwd a{hp, ldh, rowptr, col, reinterpret_cast<const float2*>(stat), rows, H, Fh, slope, row_graph, nmax, iso_idx, iso_w, iso_ptr, uscale, mean_heads,
-           apply_elu, make_drop(drop_p, seed), y, ldy};
+           apply_elu, make_drop(drop_p, seed, drop_ctr), y, ldy};
   const unsigned grid = (unsigned)ceil_div64(rows, 4);
   const bool drop = a.drop.thresh != 0u;
   TSGNN_KNAME("gat_attn_fwd_kernel<%d,%s>", Fh / 4, drop ? "true" : "false");
@@ -633,8 +645,9 @@ int tsgnn_gat_bwd_parts(int B) {
 int tsgnn_gat_attn_bwd_f32(const float* hp, int64_t ldh, const float* y, int64_t ldy, const float* dy, int64_t lddy, const int* rp_t,
                            const int* col_t, int64_t rows, int H, int Fh, float slope, int mean_heads, int apply_elu,
                            const int* graph_ptr, int B, const int* iso_idx, const float* iso_w, const int* iso_ptr,
-                           const float* iso_row, int iso_row_ld, float uscale, float drop_p, uint64_t seed, const float* stat,
-                           float* dhp, int Ns, float* t1, float* t2, float* S, float* dupart, tsgnn_stream_t stream) {
+                           const float* iso_row, int iso_row_ld, float uscale, float drop_p, uint64_t seed,
+                           const unsigned long long* drop_ctr, const float* stat, float* dhp, int Ns, float* t1, float* t2, float* S,
+                           float* dupart, tsgnn_stream_t stream) {
   if (!hp || !y || !dy || !rp_t || !col_t || !dhp || !stat || !t1 || !t2 || !S || rows < 0 || drop_p < 0.f || drop_p >= 1.f) return TSGNN_EINVAL;
   if (!fused_ok(H, Fh)) return TSGNN_EUNSUPPORTED;
   const int C = H * Fh, Co = mean_heads ? Fh : C;
@@ -648,7 +661,7 @@ int tsgnn_gat_attn_bwd_f32(const float* hp, int64_t ldh, const float* y, int64_t
   const int P = tsgnn_gat_bwd_parts(B);
   GatBwd a{hp, ldh, y, ldy, dy, lddy, rp_t, col_t, reinterpret_cast<const float2*>(stat), rows, H, Fh, slope, mean_heads, apply_elu, graph_ptr, B,
            lst ? iso_idx : nullptr, lst ? iso_w : nullptr, lst ? iso_ptr : nullptr, lst ? iso_row : nullptr, iso_row_ld, uscale,
-           make_drop(drop_p, seed), dhp, Ns, t1, t2, S, dupart, P, lst ? (unsigned)(B * P) : 0u};
+           make_drop(drop_p, seed, drop_ctr), dhp, Ns, t1, t2, S, dupart, P, lst ? (unsigned)(B * P) : 0u};
   const unsigned grid = (unsigned)ceil_div64(rows, 4) + a.ngraph_blocks;
   const bool drop = a.drop.thresh != 0u;
   TSGNN_KNAME("gat_attn_bwd_kernel<%d,%s>", Fh / 4, drop ? "true" : "false");
@@ -680,11 +693,11 @@ int tsgnn_gat_score_rowsum_f32(const int* rowptr, const int* col, const int* epe
   return TSGNN_OK;
 }
 
-int tsgnn_gat_dropout_mult_f32(float drop_p, uint64_t seed, int64_t i0, int64_t ni, int64_t j0, int64_t nj, int H, float* out,
-                               tsgnn_stream_t stream) {
+int tsgnn_gat_dropout_mult_f32(float drop_p, uint64_t seed, const unsigned long long* drop_ctr, int64_t i0, int64_t ni, int64_t j0,
+                               int64_t nj, int H, float* out, tsgnn_stream_t stream) {
   if (!out || ni < 0 || nj < 0 || H <= 0 || drop_p < 0.f || drop_p >= 1.f) return TSGNN_EINVAL;
   if (ni * nj == 0) return TSGNN_OK;
-  gat_dropout_mult_kernel<<<(unsigned)ceil_div64(ni * nj * H, 256), 256, 0, stream>>>(make_drop(drop_p, seed), i0, ni, j0, nj, H, out);
+  gat_dropout_mult_kernel<<<(unsigned)ceil_div64(ni * nj * H, 256), 256, 0, stream>>>(make_drop(drop_p, seed, drop_ctr), i0, ni, j0, nj, H, out);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }

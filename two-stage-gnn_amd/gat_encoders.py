@@ -181,8 +181,7 @@ def _gat_heads_forward(heads, x, adj, concat_heads, elu, wp=None):
             and _fused_layer_ok(heads, g, x0.size(0))):
         if wp is None:
             (wp,) = gf.pack_layers([heads])
-        y = gf.gat_layer(x0, wp, g, H, Fo, slope, mean_heads=not concat_heads, apply_elu=elu, drop_p=p if drop_on else 0.0,
-                         seed=gf.new_seed() if drop_on else 0)
+        y = gf.gat_layer(x0, wp, g, H, Fo, slope, mean_heads=not concat_heads, apply_elu=elu, drop_p=p if drop_on else 0.0)
         return y if ragged else y.reshape(B, N, -1)
     if drop_on:
         raise NotImplementedError("attention dropout > 0 needs the fused layer kernels (gat_fused.py): supported head shape, "

@@ -132,7 +132,7 @@ def wgrad_blocks(z, K_in, du):
 
 class _GatLayer(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, wp, g, H, Fo, slope, mean_heads, apply_elu, drop_p, seed):
+    def forward(ctx, x, wp, g, H, Fo, slope, mean_heads, apply_elu, drop_p, seed, ctr):
         """x [R, >= Fin] (16-byte rows), wp [Fin, Ns] -> y [R, H*Fo] ([R, Fo] with mean_heads)"""
         R, Fin, Ns, C = int(x.size(0)), int(wp.size(0)), int(wp.size(1)), H * Fo
         dev = x.device
@@ -146,8 +146,9 @@ class _GatLayer(torch.autograd.Function):
         i_idx, i_w, i_ptr = lst if lst is not None else (None, None, None)
         nat.call("gat_attn_fwd_f32", hp, hp.stride(0), g.rowptr, g.col, rp_t, col_t, R, H, Fo, float(slope), att._row_seg(g),
                  int(g.nmax), i_idx, i_w, i_ptr, 1.0 / max(int(g.nmax), 1), int(mean_heads), int(apply_elu), float(drop_p),
-                 int(seed), stat, y, y.stride(0))
+                 int(seed), ctr, stat, y, y.stride(0))
         ctx.cfg = (g, H, Fo, slope, mean_heads, apply_elu, drop_p, seed, Fin)
+        ctx.ctr = ctr
         ctx.save_for_backward(x, wp, hp, y, iso, stat)
         ctx.lst = lst
         return y
@@ -169,7 +170,7 @@ class _GatLayer(torch.autograd.Function):
         dupart = _f32(int(g.B) * int(nat.lib().tsgnn_gat_bwd_parts(int(g.B))) * C, device=dev) if lst is not None else None
         nat.call("gat_attn_bwd_f32", hp, hp.stride(0), y, y.stride(0), dy, dy.stride(0), rp_t, col_t, R, H, Fo, float(slope),
                  int(mean_heads), int(apply_elu), g.graph_ptr, int(g.B), i_idx, i_w, i_ptr, iso if lst is not None else None, H,
-                 us, float(drop_p), int(seed), stat, dhp, Ns, t1, t2, S, dupart)
+                 us, float(drop_p), int(seed), ctx.ctr, stat, dhp, Ns, t1, t2, S, dupart)
         fin = lst is not None and drop_p == 0.0                 # (with dropout the backward completes the listed columns itself)
         nat.call("gat_score_rowsum_f32", g.rowptr, g.col, att._inverse_entry_map(g, src_e_t), t1, t2, S, R, H, dhp, dhp.stride(0), C,
                  dupart if fin else None, int(g.B), i_idx if fin else None, i_w if fin else None, i_ptr if fin else None, us)
@@ -182,13 +183,32 @@ class _GatLayer(torch.autograd.Function):
             if x.size(1) > Fin:
                 dx[:, Fin:].zero_()
             nat.call("rowgemm_f32", dhp, dhp.stride(0), wp, wp.stride(0), 1, None, dx, dx.stride(0), None, R, Ns, Fin, 0, 0)
-        return dx, dwp, None, None, None, None, None, None, None, None
+        return dx, dwp, None, None, None, None, None, None, None, None, None
 
 
-def gat_layer(x, wp, g, H, Fo, slope, mean_heads, apply_elu, drop_p=0.0, seed=0):
-    return _GatLayer.apply(x, wp, g, int(H), int(Fo), float(slope), bool(mean_heads), bool(apply_elu), float(drop_p), int(seed))
+def gat_layer(x, wp, g, H, Fo, slope, mean_heads, apply_elu, drop_p=0.0):
+    """drop_p > 0: attention dropout with a fresh mask per call — the key is (process seed, device counter): the counter is
+    advanced and snapshotted ON THE DEVICE (two tiny launches), so a step captured in a hipGraph draws a new mask at every
+    replay and the backward of this call regenerates exactly the mask of its forward."""
+    seed, ctr = 0, None
+    if drop_p > 0.0:
+        seed, ctr = dropout_key(x.device)
+    return _GatLayer.apply(x, wp, g, int(H), int(Fo), float(slope), bool(mean_heads), bool(apply_elu), float(drop_p), int(seed), ctr)
 
 
-def new_seed():
-    """a fresh 63-bit seed from torch's CPU generator (follows torch.manual_seed; no device round trip)"""
-    return int(torch.empty((), dtype=torch.int64).random_().item())
+_drop_state = {}        # device -> (process seed, int64 device counter)
+last_dropout_key = None  # (seed, counter snapshot) of the most recent dropout layer call (tests hand it to the dense oracle)
+
+
+def dropout_key(dev):
+    """(seed, snapshot): the process seed (torch's CPU generator at first use: torch.manual_seed governs it) and a private
+    snapshot of the device counter after advancing it"""
+    global last_dropout_key
+    st = _drop_state.get(dev)
+    if st is None:
+        seed = int(torch.empty((), dtype=torch.int64).random_().item())
+        st = _drop_state[dev] = (seed, torch.zeros(1, dtype=torch.int64, device=dev))
+    st[1].add_(1)
+    snap = st[1].clone()
+    last_dropout_key = (st[0], snap)
+    return st[0], snap
