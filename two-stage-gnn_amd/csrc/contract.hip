@@ -188,6 +188,24 @@ __device__ __forceinline__ void ct_mfma(ct_f32x16& acc, const float* ap, int ald
     }
   };
   float a0[8], b0[8], a1[8], b1[8];
+  if ((depth & 31) == 0 && nvalid >= 32) {
+    // the common shapes (depth 64 / 192 / 256, full column tiles): a branch-free body of sixteen MFMAs whose reads carry no
+    // predicates — one basic block per iteration, so the scheduler keeps the reads of the next round in flight under the chain
+    auto load8 = [&](int s0, float (&av)[8], float (&bv)[8]) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { av[u] = arow[s0 + 2 * u]; bv[u] = bcol[(s0 + 2 * u) * bks]; }
+    };
+    load8(0, a0, b0);
+    for (int s0 = 0; s0 < depth; s0 += 32) {
+      load8(s0 + 16, a1, b1);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b0[u], acc, 0, 0, 0);
+      load8(s0 + 32 < depth ? s0 + 32 : 0, a0, b0);       // (last round: a harmless re-read)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b1[u], acc, 0, 0, 0);
+    }
+    return;
+  }
   fetch(0, a0, b0);
   for (int s0 = 0; s0 < depth; s0 += 32) {
     if (s0 + 16 < depth) fetch(s0 + 16, a1, b1);
