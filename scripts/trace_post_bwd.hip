@@ -2,6 +2,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -DTSGNN_TRACE scripts/trace_post_bwd.hip -o scripts/_build/trace_post_bwd
 #include "../two-stage-gnn_amd/csrc/sage_fused.hip"
 #include "trace_util.h"
+thread_local char tsgnn_kname_[160];
 #include <cstdio>
 #include <vector>
 #include <algorithm>

@@ -71,14 +71,22 @@ __global__ __launch_bounds__(BT) void slot_bn_fwd(SlotArgs s, const float* __res
   if (ghost && c == 0) atomicMin(&first_ghost, b);
   float4 x[NV];
   float s1 = 0.f, dummy = 0.f;
+  // all NV requests first, unconditionally and from clamped (always mapped) addresses, masked afterwards: a load inside its own
+  // `if` is waited for before the next one is issued (the ISA had four load -> s_waitcnt vmcnt(0) pairs here: four dependent
+  // round trips in a kernel that is one trip of useful memory time)
+  {
+    const float* vr = v + (row >= 0 ? row : 0) * ldv;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) { const int c4 = c + TPR * q; x[q] = ld4(vr + 4 * (c4 < F4 ? c4 : 0)); }
+  }
 #pragma unroll
   for (int q = 0; q < NV; ++q) {
     const int c4 = c + TPR * q;
-    x[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (row >= 0 && c4 < F4) {
-      x[q] = ld4(v + row * ldv + 4 * c4);
       if (relu) { x[q].x = fmaxf(x[q].x, 0.f); x[q].y = fmaxf(x[q].y, 0.f); x[q].z = fmaxf(x[q].z, 0.f); x[q].w = fmaxf(x[q].w, 0.f); }
       s1 += (x[q].x + x[q].y) + (x[q].z + x[q].w);
+    } else {
+      x[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
   const int have = s.slot_count[n];
@@ -178,18 +186,51 @@ __global__ __launch_bounds__(BT) void slot_post_bwd(SlotArgs s, const float* __r
   const bool fg = ghost && b == first_ghost;
   const bool any_ghost = first_ghost != 0x7fffffff;               // uniform
   const float mu = bn ? mean[n] : 0.f, rs = bn ? rstd[n] : 1.f;
-  float4 vv[NV], dy[NV];
+  float4 vv[NV], dy[NV], d2[NV];
   float a1 = 0.f, a2 = 0.f;
+  // every request of the row first (v, dxs, dxs2: up to 3 NV loads), unconditionally from clamped addresses, masked below: loads
+  // inside their own `if` were NV dependent round trips
+  {
+    const int64_t rv = row >= 0 ? row : 0, rd = (row >= 0 && !ghost) ? row : 0;
+    // (dxs / dxs2 are uniform over the grid: ONE branch on them, then straight-line request blocks — a null test per load puts a
+    // scalar branch and a full wait between the requests of consecutive q)
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (dxs && dxs2) {
+#pragma unroll
+      for (int q = 0; q < NV; ++q) {
+        const int c4 = c + TPR * q, cc = 4 * (c4 < F4 ? c4 : 0);
+        vv[q] = ld4(v + rv * ldv + cc); dy[q] = ld4(dxs + rd * lddxs + cc); d2[q] = ld4(dxs2 + rd * lddxs2 + cc);
+      }
+    } else if (dxs) {
+#pragma unroll
+      for (int q = 0; q < NV; ++q) {
+        const int c4 = c + TPR * q, cc = 4 * (c4 < F4 ? c4 : 0);
+        vv[q] = ld4(v + rv * ldv + cc); dy[q] = ld4(dxs + rd * lddxs + cc); d2[q] = z4;
+      }
+    } else if (dxs2) {
+#pragma unroll
+      for (int q = 0; q < NV; ++q) {
+        const int c4 = c + TPR * q, cc = 4 * (c4 < F4 ? c4 : 0);
+        vv[q] = ld4(v + rv * ldv + cc); dy[q] = z4; d2[q] = ld4(dxs2 + rd * lddxs2 + cc);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < NV; ++q) {
+        const int c4 = c + TPR * q, cc = 4 * (c4 < F4 ? c4 : 0);
+        vv[q] = ld4(v + rv * ldv + cc); dy[q] = z4; d2[q] = z4;
+      }
+    }
+  }
 #pragma unroll
   for (int q = 0; q < NV; ++q) {
     const int c4 = c + TPR * q;
-    vv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-    dy[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row >= 0 && c4 < F4) {
-      vv[q] = ld4(v + row * ldv + 4 * c4);
-      if (dxs && !ghost) dy[q] = ld4(dxs + row * lddxs + 4 * c4);   // nothing aggregates from a ghost row: its dxs is 0
+    if (!(row >= 0 && c4 < F4)) {
+      vv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      dy[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      if (!(dxs && !ghost)) dy[q] = make_float4(0.f, 0.f, 0.f, 0.f);   // nothing aggregates from a ghost row: its dxs is 0
       if (dxs2 && !ghost) {                               // gradient that reaches this layer's output directly (node-level outputs;
-        const float4 t = ld4(dxs2 + row * lddxs2 + 4 * c4);   // ghost rows are masked out of those)
+        const float4 t = d2[q];                               // ghost rows are masked out of those)
         dy[q].x += t.x; dy[q].y += t.y; dy[q].z += t.z; dy[q].w += t.w;
       }
       const int4 w = wq[q];
