@@ -163,7 +163,8 @@ __global__ __launch_bounds__(64 * HW) void packed_head_fwd_kernel(const unsigned
       else idx = (int64_t)(L - 1) * B * Fh + (int64_t)b * Fl + (k - PH);
     }
     pidx[u] = idx;
-    pk[u] = k < P ? packed[idx] : 0ull;
+    pk[u] = packed[idx];                               // unconditional (idx = 0 beyond P), masked below: a load inside a
+    if (k >= P) pk[u] = 0ull;                          // predicate is waited for before the next request is issued
   }
   // (2) this wave's rows of W1 (j = wid + HW * u), float4 column `lane` and `lane + 64` of each; W2 for the waves that own a class
   float4 w[NJ][2];
@@ -171,8 +172,15 @@ __global__ __launch_bounds__(64 * HW) void packed_head_fwd_kernel(const unsigned
   for (int u = 0; u < NJ; ++u) {
     const int j = wid + HW * u;
     const float* row = w1 + (int64_t)(j < E ? j : 0) * P;
-    w[u][0] = lane < P4 ? ld4(row + 4 * lane) : make_float4(0.f, 0.f, 0.f, 0.f);
-    w[u][1] = lane + 64 < P4 ? ld4(row + 4 * (lane + 64)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    // (every request unconditional from a clamped address, masked afterwards: with `cond ? ld4(..) : 0` the ISA had sixteen
+    // load -> s_waitcnt vmcnt(0) pairs here — sixteen dependent round trips in a kernel meant to be one)
+    w[u][0] = ld4(row + 4 * (lane < P4 ? lane : 0));
+    w[u][1] = ld4(row + 4 * (lane + 64 < P4 ? lane + 64 : 0));
+  }
+#pragma unroll
+  for (int u = 0; u < NJ; ++u) {
+    if (lane >= P4) w[u][0] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane + 64 >= P4) w[u][1] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   float bj[NJ];
 #pragma unroll
@@ -460,7 +468,9 @@ __global__ __launch_bounds__(64 * HW) void head2_bwd2_kernel(const float* __rest
 #pragma unroll
     for (int u = 0; u < RB_ROWS; ++u) {
       const int j = jg + G * u;
-      w[u] = (active && j < E) ? ld4(w1 + (int64_t)j * P + 4 * k4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      // (unconditional from a clamped address; rows / groups beyond the matrix are multiplied by ds = 0 below: a load inside a
+      // predicate is waited for before the next one is issued — sixteen dependent round trips here)
+      w[u] = ld4(w1 + (int64_t)((active && j < E) ? j : 0) * P + 4 * (active ? k4 : 0));
     }
     if (has_ce) {
       ce_rows(ce, B, C, dyl, lb, b == 0 ? -1 : b);
@@ -492,7 +502,7 @@ __global__ __launch_bounds__(64 * HW) void head2_bwd2_kernel(const float* __rest
 #pragma unroll
         for (int u = 0; u < RB_ROWS; ++u) {
           const int j = j0 + jg + G * u;
-          w[u] = (active && j < E) ? ld4(w1 + (int64_t)j * P + 4 * k4) : make_float4(0.f, 0.f, 0.f, 0.f);
+          w[u] = ld4(w1 + (int64_t)((active && j < E) ? j : 0) * P + 4 * (active ? k4 : 0));
         }
       }
 #pragma unroll
@@ -534,8 +544,8 @@ __global__ __launch_bounds__(64 * HW) void head2_bwd2_kernel(const float* __rest
 #pragma unroll
     for (int u = 0; u < WB_ROWS; ++u) {
       const int bb = bg + G * u;
-      x[u] = (active && bb < B) ? ld4(out + (int64_t)bb * ldo + 4 * k4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+      x[u] = ld4(out + (int64_t)((active && bb < B) ? bb : 0) * ldo + 4 * (active ? k4 : 0));      // (unconditional, see the row blocks;
+    }                                                                                                 //  used under `active && bb < B` only)
     if (has_ce) { ce_rows(ce, B, C, dyl, lb, -1); __syncthreads(); }
     for (int i = tid; i < 4 * B; i += NTH) {
       const int bb = i >> 2, jj = j0 + (i & 3);
@@ -553,7 +563,7 @@ __global__ __launch_bounds__(64 * HW) void head2_bwd2_kernel(const float* __rest
 #pragma unroll
         for (int u = 0; u < WB_ROWS; ++u) {
           const int bb = b0 + bg + G * u;
-          x[u] = (active && bb < B) ? ld4(out + (int64_t)bb * ldo + 4 * k4) : make_float4(0.f, 0.f, 0.f, 0.f);
+          x[u] = ld4(out + (int64_t)((active && bb < B) ? bb : 0) * ldo + 4 * (active ? k4 : 0));
         }
       }
 #pragma unroll
