@@ -53,9 +53,9 @@ int main(int argc, char** argv) {
   (void)hipMalloc(&d_du, (size_t)B * 8 * C * 4);
   hipStream_t s; (void)hipStreamCreate(&s);
   const int Co = mean ? Fh : C;
-  auto fwd = [&] { return tsgnn_gat_attn_fwd_f32(d_hp, Ns, d_rp, d_col, d_rp, d_col, R, H, Fh, 0.2f, d_rg, nmax, d_ii, d_iw, d_ip, 1.f / nmax, mean, 1, 0.f, 0, d_stat, d_y, Co, s); };
+  auto fwd = [&] { return tsgnn_gat_attn_fwd_f32(d_hp, Ns, d_rp, d_col, d_rp, d_col, R, H, Fh, 0.2f, d_rg, nmax, d_ii, d_iw, d_ip, 1.f / nmax, mean, 1, 0.f, 0, nullptr, d_stat, d_y, Co, s); };
   auto bw = [&] {
-    int rc = tsgnn_gat_attn_bwd_f32(d_hp, Ns, d_y, Co, d_dy, Co, d_rp, d_col, R, H, Fh, 0.2f, mean, 1, d_gp, B, d_ii, d_iw, d_ip, d_ir, H, 1.f / nmax, 0.f, 0,
+    int rc = tsgnn_gat_attn_bwd_f32(d_hp, Ns, d_y, Co, d_dy, Co, d_rp, d_col, R, H, Fh, 0.2f, mean, 1, d_gp, B, d_ii, d_iw, d_ip, d_ir, H, 1.f / nmax, 0.f, 0, nullptr,
                                     d_stat, d_dhp, Ns, d_t1, d_t2, d_S, d_du, s);
     return rc;
   };

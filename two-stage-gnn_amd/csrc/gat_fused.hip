@@ -147,13 +147,13 @@ __global__ __launch_bounds__(256, GAT_WAVES_PER_SIMD) void gat_attn_fwd_kernel(G
     const int j = a.col[has ? eb + pk : eb];
     TR_AFTER(j, 2);                                         // column ids arrived
     float4 v[8];
+    // the batch's feature rows, requested before the statistics chain.  All eight requests are unconditional (entries beyond the
+    // row's end repeat its first column; their alpha is 0): behind `if (k < cnt)` every request sat in its own block behind an
+    // s_waitcnt vmcnt(0) — eight DEPENDENT round trips per row
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {                           // the batch's feature rows: requested before the statistics chain
-      v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (k < cnt) {
-        const int jk = __shfl(j, k * H, 64);
-        v[k] = ldg4_(hp + (int64_t)jk * ldh + co);
-      }
+    for (int k = 0; k < 8; ++k) {
+      const int jk = __shfl(j, (k < cnt ? k : 0) * H, 64);
+      v[k] = ldg4_(hp + (int64_t)jk * ldh + co);
     }
     const float scol_j = hp[(int64_t)j * ldh + C + H + ph];
     const float2 st = a.stat[(int64_t)j * H + ph];           // (m, 1 / Z) of column j
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256, GAT_WAVES_PER_SIMD) void gat_attn_fwd_kernel(G
     TR_AFTER(__float_as_int(alpha), 3);                     // statistics and scalars arrived
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      if (k < cnt) {
+      if (k < cnt) {                                        // (arithmetic only: uniform, no memory operation inside)
         const float al = __shfl(alpha, k * H + h, 64);
         acc.x = fmaf(al, v[k].x, acc.x); acc.y = fmaf(al, v[k].y, acc.y);
         acc.z = fmaf(al, v[k].z, acc.z); acc.w = fmaf(al, v[k].w, acc.w);
@@ -247,17 +247,21 @@ struct GatBwd {
   unsigned ngraph_blocks;                     // B * P (0 without listed edge-less columns)
 };
 
-// dpre of row i for this lane's four features: dy * ELU'(y) (concat) or (dy * ELU'(y)) / H of the lane's slot (mean over heads)
+// dpre of row i for this lane's four features: dy * ELU'(y) (concat) or (dy * ELU'(y)) / H of the lane's slot (mean over heads).
+// Split in two so that a caller can issue the requests of SEVERAL rows before the arithmetic of the first one waits for them
+// (requests and arithmetic interleaved row by row were one dependent round trip per row).  Requests are unconditional — a lane
+// beyond the row's width reads column 0 and is masked at the end.
 template <int LPH>
-__device__ __forceinline__ float4 dpre_row(const GatBwd& a, int64_t i, int lane, int co, bool live) {
+__device__ __forceinline__ void dpre_load(const GatBwd& a, int64_t i, int lane, int co, float4& d, float4& yv) {
   const int c = a.mean_heads ? 4 * (lane % LPH) : co;
-  float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (!live) return d;
   d = ldg4_(a.dy + i * a.lddy + c);
+  yv = ldg4_(a.y + i * a.ldy + c);
+}
+__device__ __forceinline__ float4 dpre_finish(const GatBwd& a, float4 d, const float4& yv, bool live) {
   if (a.apply_elu) {
-    const float4 yv = ldg4_(a.y + i * a.ldy + c);
     d.x *= elu_grad_y(yv.x); d.y *= elu_grad_y(yv.y); d.z *= elu_grad_y(yv.z); d.w *= elu_grad_y(yv.w);
   }
+  if (!live) d = make_float4(0.f, 0.f, 0.f, 0.f);
   if (a.mean_heads) {
     if ((a.H & (a.H - 1)) == 0) {                            // 1 / H is exact: the product equals the quotient
       const float r = 1.f / (float)a.H;
@@ -268,6 +272,12 @@ __device__ __forceinline__ float4 dpre_row(const GatBwd& a, int64_t i, int lane,
     }
   }
   return d;
+}
+template <int LPH>
+__device__ __forceinline__ float4 dpre_row(const GatBwd& a, int64_t i, int lane, int co, bool live) {
+  float4 d, yv;
+  dpre_load<LPH>(a, i, lane, co, d, yv);
+  return dpre_finish(a, d, yv, live);
 }
 
 // per-column accumulators of the backward
@@ -336,11 +346,14 @@ __global__ __launch_bounds__(256, GAT_BWD_WAVES_PER_SIMD) void gat_attn_bwd_kern
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int64_t i = r0 + wid; i < r1; i += 16) {           // four rows of this wave in flight
       float4 d[4];
+      float4 yv[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int64_t ii = i + 4 * k;
-        d[k] = dpre_row<LPH>(a, ii < r1 ? ii : r0, lane, co, live && ii < r1);
+        dpre_load<LPH>(a, ii < r1 ? ii : r0, lane, co, d[k], yv[k]);
       }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) d[k] = dpre_finish(a, d[k], yv[k], live && i + 4 * k < r1);
 #pragma unroll
       for (int k = 0; k < 4; ++k) { s.x += d[k].x; s.y += d[k].y; s.z += d[k].z; s.w += d[k].w; }
     }
@@ -363,7 +376,8 @@ __global__ __launch_bounds__(256, GAT_BWD_WAVES_PER_SIMD) void gat_attn_bwd_kern
   const float* __restrict__ hp = a.hp;
   TR(0);
   const int t0 = a.rp_t[j], t1 = a.rp_t[j + 1];
-  const float4 hj = live ? ldg4_(hp + j * ldh + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 hj = ldg4_(hp + j * ldh + co);                       // (unconditional; lanes beyond the row's width are zeroed)
+  if (!live) hj = make_float4(0.f, 0.f, 0.f, 0.f);
   const float scol = hp[j * ldh + C + H + h];
   const float* srow = hp + C + h;
   const bool writer = live && (lane % LPH) == 0;
@@ -381,11 +395,14 @@ __global__ __launch_bounds__(256, GAT_BWD_WAVES_PER_SIMD) void gat_attn_bwd_kern
       float4 dp[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) i4[k] = tb < 8 ? (tb == 0 ? ii[k] : ii[4 + k]) : a.col_t[min(t0 + tb + k, t1 - 1)];
+      float4 yv[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < 4; ++k) {                            // twelve requests, then the arithmetic
         sr[k] = srow[(int64_t)i4[k] * ldh];
-        dp[k] = dpre_row<LPH>(a, i4[k], lane, co, live);
+        dpre_load<LPH>(a, i4[k], lane, co, dp[k], yv[k]);
       }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dp[k] = dpre_finish(a, dp[k], yv[k], live);
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         if (tb + k < deg) bwd_entry<LPH, DROP>(a, c, hj, dp[k], sr[k], scol, st.x, st.y, i4[k], j, t0 + tb + k, h, writer);
