@@ -189,6 +189,11 @@ int tsgnn_wgrad_blocks_plan(int64_t rows, int K_in, int N, int64_t ldz, int64_t 
                             int64_t* ws_floats);
 int tsgnn_wgrad_blocks_f32(const float* z, int64_t ldz, const float* du, int64_t lddu, int64_t rows, int K_in, int N, int nslab,
                            int64_t rows_per_slab, float* ws, float* dw, int64_t lddw, tsgnn_stream_t stream);
+/* The same product written in torch.nn.Linear's layout, dw_oi[N][K_in] (row stride lddw >= K_in), with db[N] = colsum(du)
+ * (nullable) from the same pass: the gradients of y = x W^T + b (DiffPool's assign_pred, encoders.py:369; Code/sag/network.py:
+ * 48-53) arrive as contiguous tensors of the parameters' own layout. */
+int tsgnn_wgrad_blocks_oi_f32(const float* z, int64_t ldz, const float* du, int64_t lddu, int64_t rows, int K_in, int N, int nslab,
+                              int64_t rows_per_slab, float* ws, float* dw_oi, int64_t lddw, float* db, tsgnn_stream_t stream);
 /* Ragged batched out[b][K,N] = s[rows_b,:K]^T . x[rows_b,:N] — DiffPool's S^T Z and S^T (A S) (encoders.py:374-375) over
  * the row ranges of the graphs: graph b owns slabs [seg_slab_ptr[b], seg_slab_ptr[b+1]); slab t covers rows
  * [slab_row_ptr[t], slab_row_ptr[t+1]).  ws >= nslab*(K+1)*N floats.  ceil(K/32)*ceil(N/32) <= 16. */

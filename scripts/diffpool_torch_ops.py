@@ -1,9 +1,9 @@
-"""which torch (non-library) kernels does one DiffPool step launch, and from which line of the package?  (wraps the torch entry
-points that launch copy / fill kernels and records the nearest caller inside two-stage-gnn_amd)"""
-import os, sys, collections, traceback
+#!/usr/bin/env python3
+"""which torch operators (not library launches) does one DiffPool step (BASELINE config 5) put on the device, and from where?"""
+import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from two_stage_gnn_amd import dense_encoders as E, synthetic
+from two_stage_gnn_amd import dense_encoders as E, synthetic, message_passing as mp
 dev = torch.device("cuda"); torch.manual_seed(0)
 class A: bias = True
 hb5 = synthetic.host_batch(4, 16, "DD", 512)
@@ -11,38 +11,21 @@ g5, x5, lab5 = synthetic.to_device(hb5, dev)
 dpm = E.SoftPoolingGcnEncoder(512, 89, 64, 64, 2, 3, 64, assign_ratio=0.125, num_pooling=2, bn=True, linkpred=False, args=A(),
                               assign_input_dim=89, final_dim="number_classes").to(dev)
 def step():
-    dpm.zero_grad(set_to_none=True); dpm.loss(dpm(x5, g5, hb5["sizes"], assign_x=x5)[1], lab5).backward()
+    dpm.zero_grad(set_to_none=True); dpm.loss(dpm(x5, g5, hb5["sizes"], assign_x=x5)[1], lab5).backward(gradient=mp.unit_seed(dev))
 for _ in range(3): step()
 torch.cuda.synchronize()
-cnt = collections.Counter()
-def where():
-    for f in reversed(traceback.extract_stack(limit=14)[:-2]):
-        if "two-stage-gnn_amd" in f.filename or "two_stage_gnn_amd" in f.filename:
-            return "%s:%d" % (os.path.basename(f.filename), f.lineno)
-    return "(autograd engine / torch)"
-def wrap(obj, name, cond=lambda *a, **k: True):
-    orig = getattr(obj, name)
-    def w(*a, **k):
-        if cond(*a, **k):
-            cnt[(name, where())] += 1
-        return orig(*a, **k)
-    setattr(obj, name, w)
-wrap(torch, "zeros"); wrap(torch, "cat"); wrap(torch, "zeros_like"); wrap(torch, "ones")
-wrap(torch.Tensor, "contiguous", lambda t, *a, **k: t.is_cuda and not t.is_contiguous())
-wrap(torch.Tensor, "zero_", lambda t, *a, **k: t.is_cuda); wrap(torch.Tensor, "copy_", lambda t, *a, **k: t.is_cuda)
-wrap(torch.Tensor, "clone", lambda t, *a, **k: t.is_cuda); wrap(torch.Tensor, "add_", lambda t, *a, **k: t.is_cuda)
-wrap(torch.Tensor, "fill_", lambda t, *a, **k: t.is_cuda); wrap(torch.Tensor, "float", lambda t, *a, **k: t.is_cuda and t.dtype != torch.float32)
-wrap(torch.Tensor, "reshape", lambda t, *a, **k: t.is_cuda and not t.is_contiguous())
-step()
-torch.cuda.synchronize()
-for k, v in cnt.most_common(50):
-    print(v, k)
-print("---- autograd / aten ops of one step (torch profiler, CPU side)")
 from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CPU]) as prof:
-    step()
-torch.cuda.synchronize()
-c2 = collections.Counter(ev.name for ev in prof.events())
-for k, v in c2.most_common(60):
-    if any(t in k for t in ("Backward", "aten::copy_", "aten::fill_", "aten::zero", "aten::add", "aten::cat", "aten::clone", "AccumulateGrad", "aten::contiguous", "aten::mul", "aten::sum", "aten::select", "aten::slice", "aten::index", "aten::empty_like", "aten::narrow")):
-        print(v, k)
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
+    step(); torch.cuda.synchronize()
+seen = set()
+def chain(e):
+    out = []
+    while e is not None and len(out) < 4:
+        out.append(e.name); e = e.cpu_parent
+    return " <- ".join(out)
+for e in prof.events():
+    if e.device_type != torch.autograd.DeviceType.CPU or not e.name.startswith("aten::") or not e.kernels:
+        continue
+    if any(c.kernels for c in e.cpu_children):
+        continue                                     # report the innermost operator only
+    print("%-60s %-44s %s" % (chain(e)[:60], str(e.input_shapes)[:44], ",".join(k.name[:40] for k in e.kernels)))

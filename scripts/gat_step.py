@@ -5,7 +5,7 @@ rows + one ghost representative per graph): fwd + bwd replayed from a hipGraph, 
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from two_stage_gnn_amd import gat_encoders as G, synthetic, _native as nat
+from two_stage_gnn_amd import gat_encoders as G, synthetic, _native as nat, message_passing as mp
 from torch.profiler import profile, ProfilerActivity
 dev = torch.device("cuda"); torch.manual_seed(0)
 S = torch.cuda.Stream(); torch.cuda.set_stream(S)
@@ -16,7 +16,7 @@ adj32d = adj32.to(dev)
 x32, g32 = gat32.packed_batch(x32.to(dev), adj32d, hb32["sizes"])
 lab32 = torch.from_numpy(hb32["label"]).to(dev)
 def step():
-    gat32.zero_grad(set_to_none=True); gat32.loss(gat32(x32, g32)[1], lab32).backward()
+    gat32.zero_grad(set_to_none=True); gat32.loss(gat32(x32, g32)[1], lab32).backward(gradient=mp.unit_seed(dev))
 for _ in range(3): step()
 torch.cuda.synchronize()
 eager = int(os.environ.get("GAT_EAGER", "0"))

@@ -581,6 +581,52 @@ def test_two_dense_stacks_in_one_launch(B, K, fin, hid, lasts, need_x):
         assert (f - c).abs().max().item() <= 2e-5 * scale
 
 
+@pytest.mark.parametrize("nstack", [1, 2])
+def test_dense_stacks_adjacency_pass_through(nstack):
+    """adj_pass: the node also hands the adjacency on to its other consumer; that consumer's gradient is summed into dA inside
+    the backward launch — same dA, dx and parameter gradients as autograd's own sum of the two consumers' gradients"""
+    from two_stage_gnn_amd import dense_encoders as E, dense_stack, message_passing as mp
+    B, K, fin, hid = 6, 32, 64, 32
+    torch.manual_seed(31)
+    stacks = [[E.GraphConv(fin, hid, normalize_embedding=True, bias=True), E.GraphConv(hid, hid, normalize_embedding=True, bias=True),
+               E.GraphConv(hid, 16, normalize_embedding=True, bias=True)] for _ in range(nstack)]
+    for convs in stacks:
+        for mod in convs:
+            mod.cuda()
+            torch.nn.init.xavier_uniform_(mod.weight.data)
+            torch.nn.init.normal_(mod.bias.data, std=0.1)
+    gen = torch.Generator().manual_seed(23)
+    x0 = torch.randn(B, K, fin, generator=gen).cuda()
+    a0 = torch.rand(B, K, K, generator=gen).cuda()
+    gys = [torch.randn(B, K, 2 * hid + 16, generator=gen).cuda() for _ in range(nstack)]
+    ga = torch.randn(B, K, K, generator=gen).cuda()
+    assert dense_stack.one_launch_ok(x0, a0, stacks)
+    res = []
+    for passing in (True, False):
+        x, a = x0.clone().requires_grad_(True), a0.clone().requires_grad_(True)
+        for convs in stacks:
+            for mod in convs:
+                mod.zero_grad(set_to_none=True)
+        out = dense_stack.dense_gcn_stacks(x, a, stacks, adj_pass=passing)
+        ys, a_other = (out[:-1], out[-1]) if passing else (out, a)
+        assert len(ys) == nstack
+        if passing:
+            assert a_other.data_ptr() == a.data_ptr()
+        (sum((y * gy).sum() for y, gy in zip(ys, gys)) + (a_other * a_other * ga).sum()).backward()
+        res.append([y.detach() for y in ys] + [x.grad, a.grad] + [p.grad.clone() for convs in stacks for mod in convs for p in mod.parameters()])
+    mp.check_device_errors()
+    for f, c in zip(res[0], res[1]):
+        scale = c.abs().max().item() + 1e-12
+        assert (f - c).abs().max().item() <= 2e-6 * scale
+    # the pass-through output left unused: dA is the stacks' own
+    x, a = x0.clone().requires_grad_(True), a0.clone().requires_grad_(True)
+    out = dense_stack.dense_gcn_stacks(x, a, stacks, adj_pass=True)
+    sum((y * gy).sum() for y, gy in zip(out[:-1], gys)).backward()
+    x2, a2 = x0.clone().requires_grad_(True), a0.clone().requires_grad_(True)
+    sum((y * gy).sum() for y, gy in zip(dense_stack.dense_gcn_stacks(x2, a2, stacks), gys)).backward()
+    assert torch.equal(a.grad, a2.grad) and torch.equal(x.grad, x2.grad)
+
+
 @pytest.mark.parametrize("masked", [True, False])
 @pytest.mark.parametrize("sym", [True, False])
 def test_link_pred_loss_vs_oracle(masked, sym):

@@ -50,6 +50,38 @@ def test_wgrad_blocks(R_, K, N):
     assert torch.equal(dw, gf.wgrad_blocks(z, K, du))
 
 
+@pytest.mark.parametrize("R_,K,N,bias", [(1024, 192, 64, True), (128, 136, 8, True), (5000, 64, 128, False), (77, 300, 260, True)])
+def test_wgrad_blocks_linear_layout(R_, K, N, bias):
+    """the same product written as torch.nn.Linear's [out, in] gradient with db = colsum(du) from the same pass
+    (message_passing._LinearOI.backward: a contiguous dW that AccumulateGrad keeps instead of copying a transposed view)"""
+    from two_stage_gnn_amd import message_passing as mp
+    torch.manual_seed(2)
+    x = torch.randn(R_, K, device="cuda")
+    dy = torch.randn(R_, N, device="cuda")
+    got = mp.linear_wgrad_oi(x, K, dy, bias)
+    assert got is not None
+    dw, db = got
+    assert tuple(dw.shape) == (N, K) and dw.is_contiguous() and (db is not None) == bias
+    ref = dy.double().t() @ x.double()
+    assert (dw.double() - ref).abs().max().item() <= 3e-5 * ref.abs().max().item() + 1e-6
+    if bias:
+        refb = dy.double().sum(0)
+        assert (db.double() - refb).abs().max().item() <= 3e-5 * refb.abs().max().item() + 1e-6
+    # through the autograd node: the parameter's .grad IS the tensor the kernel wrote (no copy), values as torch's Linear
+    w = torch.randn(N, K, device="cuda", requires_grad=True)
+    b = torch.randn(N, device="cuda", requires_grad=True) if bias else None
+    xr = x.clone().requires_grad_(True)
+    y = mp.linear_oi(xr, w, b)
+    (y * dy).sum().backward()
+    w2 = w.detach().clone().requires_grad_(True)
+    b2 = b.detach().clone().requires_grad_(True) if bias else None
+    x2 = x.clone().requires_grad_(True)
+    (torch.nn.functional.linear(x2.double(), w2.double(), b2.double() if bias else None) * dy.double()).sum().backward()
+    assert w.grad.is_contiguous()
+    for a_, r_ in ((w.grad, w2.grad), (xr.grad, x2.grad)) + (((b.grad, b2.grad),) if bias else ()):
+        assert (a_.double() - r_.double()).abs().max().item() <= 5e-5 * r_.abs().max().item() + 1e-6
+
+
 def _grads(m):
     return {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
 

@@ -178,10 +178,20 @@ def defer(fn):
         fn()
 
 
+def defer_zero(t):
+    """t.zero_() as a record of its own kind: two of them from paired records share one multi-tensor launch (sage_stack.run_paired)"""
+    if _defer is not None:
+        _defer.append(("_zero", (t,)))
+    else:
+        t.zero_()
+
+
 def run(q):
     for name, args in q:
         if name is None:
             args()
+        elif name == "_zero":
+            args[0].zero_()
         else:
             call(name, *args)
 

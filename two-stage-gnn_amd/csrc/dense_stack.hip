@@ -47,6 +47,8 @@ struct DsArgs {
   int64_t slab_floats; int finmax;
   float* dx; int64_t lddx; float* dadj;   // outputs (nullable)
   float* dadj_part;           // [nstack][B*K*K] when two stacks contribute
+  const float* dadj_add;      // nullable [B*K*K]: the gradient ANOTHER consumer of the same adjacency already produced (the next
+                              // level's contraction, through the node's adjacency pass-through), summed into dadj here
   unsigned* sync; float* err;   // sync: 32 words, zero before the first launch (barrier words + sign-off counter)
 };
 
@@ -518,7 +520,8 @@ __global__ __launch_bounds__(256) void dense_stack_bwd_kernel(DsArgs a) {
     if (rok) {
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        if (4 * cg + q < K) dst[row * K + 4 * cg + q] = dadj_acc[q];
+        if (4 * cg + q < K)
+          dst[row * K + 4 * cg + q] = dadj_acc[q] + ((a.nstack == 1 && a.dadj_add) ? a.dadj_add[row * K + 4 * cg + q] : 0.f);
     }
   }
   grid_barrier(a.sync, bar, nblocks, a.err);
@@ -560,7 +563,7 @@ __global__ __launch_bounds__(256) void dense_stack_bwd_kernel(DsArgs a) {
   }
   if (a.dadj && a.nstack == 2) {
     for (int64_t e = (int64_t)blockIdx.x * 256 + tid; e < (int64_t)R * K; e += (int64_t)nblocks * 256)
-      a.dadj[e] = a.dadj_part[e] + a.dadj_part[(int64_t)R * K + e];
+      a.dadj[e] = (a.dadj_part[e] + a.dadj_part[(int64_t)R * K + e]) + (a.dadj_add ? a.dadj_add[e] : 0.f);
   }
   grid_finish(a.sync, bar, nblocks);
 }
@@ -617,7 +620,7 @@ int tsgnn_dense_stack_supported(int B, int K, int nstack, int L, int fin0, int h
  *   [0] x  [1] ldx  [2] fin0  [3] adj  [4] B  [5] K  [6] nstack  [7] stats  [8] sync  [9] err
  *   [10] dagg  [11] dxn  [12] slabs  [13] slab_floats  [14] finmax  [15] dx  [16] lddx  [17] dadj  [18] dadj_part
  *   then per stack (2 x): out, ldo, dout, lddo, L, and per layer (4 x): w, ldw, bias, fin, n, off, agg, v, rinv, mean, rstd,
- *   dw, db, slab_off.
+ *   dw, db, slab_off; then [141] dadj_add (nullable).
  * Per hidden layer: u = (A x) W + b, v = u / max(|u|, 1e-12), y = BN_slot(ReLU(v)) (fresh statistics over batch and features,
  * eps 1e-5, biased variance); last layer: v only (encoders.py:140-167).  out[:, off_l : off_l + n_l] = the layer's output. */
 int tsgnn_dense_stack_fwd_f32(const int64_t* desc, tsgnn_stream_t stream);
@@ -642,6 +645,7 @@ static void ds_unpack(const int64_t* d, DsArgs& a) {
       o += 14;
     }
   }
+  a.dadj_add = P(o);
 }
 
 static void ds_attr() {

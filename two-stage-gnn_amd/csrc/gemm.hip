@@ -371,6 +371,7 @@ struct WgradBlocksReduce {
   const float* slabs; int nslab; int64_t set_stride;
   int K_in, N, NB, nsets;
   float* dw; int64_t lddw;
+  int oi; float* db;                                    // oi: dw is [N][K_in] (torch.nn.Linear's layout); db [N] nullable (oi form)
   int first_block[WB_MAXSETS + 1];
 };
 __global__ __launch_bounds__(256) void wgrad_blocks_reduce(WgradBlocksReduce r) {
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(256) void wgrad_blocks_reduce(WgradBlocksReduce r) 
   const float* slabs = r.slabs + (int64_t)set * r.set_stride;
   const int e_l = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int64_t e = ((int64_t)blockIdx.x - r.first_block[set]) * 64 + e_l;
-  const bool ok = e < (int64_t)kc * nc;
+  const bool ok = e < ((r.db && kb == 0) ? per_slab : (int64_t)kc * nc);   // (the slabs' last row is colsum(du) of the column block)
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   if (ok) {                                             // the arithmetic (and order) of tn_rows_reduce
     const int per = (r.nslab + 3) / 4;
@@ -402,7 +403,10 @@ __global__ __launch_bounds__(256) void wgrad_blocks_reduce(WgradBlocksReduce r) 
   __syncthreads();
   if (grp == 0 && ok) {
     const int k = (int)(e / nc), n = (int)(e % nc);
-    r.dw[(int64_t)(128 * kb + k) * r.lddw + 128 * nb + n] = (lds[0][e_l] + lds[1][e_l]) + (lds[2][e_l] + lds[3][e_l]);
+    const float v = (lds[0][e_l] + lds[1][e_l]) + (lds[2][e_l] + lds[3][e_l]);
+    if (k == kc) r.db[128 * nb + n] = v;
+    else if (r.oi) r.dw[(int64_t)(128 * nb + n) * r.lddw + 128 * kb + k] = v;
+    else r.dw[(int64_t)(128 * kb + k) * r.lddw + 128 * nb + n] = v;
   }
 }
 
@@ -699,9 +703,9 @@ int tsgnn_wgrad_blocks_plan(int64_t rows, int K_in, int N, int64_t ldz, int64_t 
   return TSGNN_OK;
 }
 
-int tsgnn_wgrad_blocks_f32(const float* z, int64_t ldz, const float* du, int64_t lddu, int64_t rows, int K_in, int N, int nslab,
-                           int64_t rows_per_slab, float* ws, float* dw, int64_t lddw, tsgnn_stream_t stream) {
-  if (!z || !du || !ws || !dw || rows < 0 || nslab <= 0 || rows_per_slab <= 0 || K_in <= 0 || N <= 0 || lddw < N) return TSGNN_EINVAL;
+static int wgrad_blocks_launch(const float* z, int64_t ldz, const float* du, int64_t lddu, int64_t rows, int K_in, int N, int nslab,
+                               int64_t rows_per_slab, float* ws, float* dw, int64_t lddw, int oi, float* db, tsgnn_stream_t stream) {
+  if (!z || !du || !ws || !dw || rows < 0 || nslab <= 0 || rows_per_slab <= 0 || K_in <= 0 || N <= 0 || lddw < (oi ? K_in : N)) return TSGNN_EINVAL;
   if (K_in > 512 || N > 512 || (ldz % 4) || (lddu % 4) || (N % 4) || ldz < ((K_in + 3) / 4) * 4 || lddu < N ||
       ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(du)) & 15))
     return TSGNN_EUNSUPPORTED;
@@ -716,17 +720,27 @@ int tsgnn_wgrad_blocks_f32(const float* z, int64_t ldz, const float* du, int64_t
   }
   TSGNN_KNAME("wgrad_blocks_kernel<2>");
   wgrad_blocks_kernel<2><<<dim3((unsigned)nslab, (unsigned)(2 * nsets)), 256, lds, stream>>>(w);
-  WgradBlocksReduce r{ws, nslab, w.set_stride, K_in, N, NB, nsets, dw, lddw, {0}};
+  WgradBlocksReduce r{ws, nslab, w.set_stride, K_in, N, NB, nsets, dw, lddw, oi, db, {0}};
   int blocks = 0;
   for (int t = 0; t < nsets; ++t) {
     r.first_block[t] = blocks;
     const int kc = K_in - 128 * (t / NB) < 128 ? K_in - 128 * (t / NB) : 128, nc = N - 128 * (t % NB) < 128 ? N - 128 * (t % NB) : 128;
-    blocks += (kc * nc + 63) / 64;
+    blocks += (((db && t / NB == 0) ? kc + 1 : kc) * nc + 63) / 64;
   }
   for (int t = nsets; t <= WB_MAXSETS; ++t) r.first_block[t] = blocks;
   wgrad_blocks_reduce<<<(unsigned)blocks, 256, 0, stream>>>(r);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
+}
+
+int tsgnn_wgrad_blocks_f32(const float* z, int64_t ldz, const float* du, int64_t lddu, int64_t rows, int K_in, int N, int nslab,
+                           int64_t rows_per_slab, float* ws, float* dw, int64_t lddw, tsgnn_stream_t stream) {
+  return wgrad_blocks_launch(z, ldz, du, lddu, rows, K_in, N, nslab, rows_per_slab, ws, dw, lddw, 0, nullptr, stream);
+}
+
+int tsgnn_wgrad_blocks_oi_f32(const float* z, int64_t ldz, const float* du, int64_t lddu, int64_t rows, int K_in, int N, int nslab,
+                              int64_t rows_per_slab, float* ws, float* dw_oi, int64_t lddw, float* db, tsgnn_stream_t stream) {
+  return wgrad_blocks_launch(z, ldz, du, lddu, rows, K_in, N, nslab, rows_per_slab, ws, dw_oi, lddw, 1, db, stream);
 }
 
 }  // extern "C"

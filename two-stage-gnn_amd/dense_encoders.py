@@ -457,7 +457,10 @@ class SoftPoolingGcnEncoder(GcnEncoderGraph):
                 asg_convs = ([self.assign_conv_first_modules[i + 1]] + list(self.assign_conv_block_modules[i + 1])
                              + [self.assign_conv_last_modules[i + 1]])
                 if dense_stack.ONE_LAUNCH and dense_stack.one_launch_ok(dense_x, dense_adj, [emb_convs, asg_convs]):
-                    emb_dense, a_next = dense_stack.dense_gcn_stacks(dense_x, dense_adj, [emb_convs, asg_convs])
+                    # (the next contraction reads the adjacency through this node's pass-through: one gradient sum, inside
+                    # the stacks' backward launch)
+                    emb_dense, a_next, dense_adj = dense_stack.dense_gcn_stacks(dense_x, dense_adj, [emb_convs, asg_convs],
+                                                                                adj_pass=True)
                     gd = GraphBatch.uniform(dense_x.size(0), dense_x.size(1), dense_x.device)
             if a_next is None:
                 emb_dense, gd = self.gcn_forward_dense(dense_x, dense_adj, self.conv_first_after_pool[i],

@@ -216,6 +216,7 @@ def _describe(x2, ldx, fin0, adj, B, K, stacks, stats, ws, bwd=None):
                     d += [0] * 14
         else:
             d += [0] * (5 + 14 * _MAXL)
+    d.append(P(bwd.get("dadj_add")) if bwd is not None else 0)
     return np.asarray(d, dtype=np.int64)
 
 
@@ -224,7 +225,10 @@ class _DenseGcnStacks(torch.autograd.Function):
     stack.  ONE launch forward, ONE backward (tsgnn_dense_stack_fwd_f32 / _bwd_f32)."""
 
     @staticmethod
-    def forward(ctx, x, adj, nstack, L, *params):
+    def forward(ctx, x, adj, nstack, L, adj_pass, *params):
+        """adj_pass: also return ``adj`` itself as a last differentiable output, for the OTHER consumer of the same adjacency
+        (the next level's contraction A'' = S^T A' S): its gradient then arrives here and is summed into this node's dA inside
+        the backward launch, instead of a separate element-wise add by autograd"""
         B, K, fin0 = x.shape
         R = B * K
         dev = x.device
@@ -255,11 +259,19 @@ class _DenseGcnStacks(torch.autograd.Function):
         nat.call("dense_stack_fwd_f32", desc.ctypes.data)                      # read from it on the host at launch)
         ctx.stacks, ctx.x2, ctx.adj, ctx.dims, ctx.stats, ctx.ws = stacks, x2, adj, (B, K, fin0, nstack, L), stats, ws
         ctx.params = params
+        ctx.adj_pass = bool(adj_pass)
+        if adj_pass:
+            return tuple(o.view(B, K, -1) for o in outs) + (adj.view_as(adj),)
         return tuple(o.view(B, K, -1) for o in outs)
 
     @staticmethod
     def backward(ctx, *douts):
         B, K, fin0, nstack, L = ctx.dims
+        dadj_add = None
+        if ctx.adj_pass:
+            dadj_add, douts = douts[-1], douts[:-1]
+            if dadj_add is not None:
+                dadj_add = dadj_add.contiguous()
         R = B * K
         stacks, x2, adj = ctx.stacks, ctx.x2, ctx.adj
         dev = x2.device
@@ -288,20 +300,21 @@ class _DenseGcnStacks(torch.autograd.Function):
                "slabs": _f32(tiles * B * nstack * slab, device=dev), "slab_floats": slab, "finmax": finmax,
                "dx": _f32(R, fin0, device=dev) if need_x else None, "lddx": fin0,
                "dadj": _f32(B, K, K, device=dev) if need_adj else None,
-               "dadj_part": _f32(2 * R * K, device=dev) if (need_adj and nstack == 2) else None}
+               "dadj_part": _f32(2 * R * K, device=dev) if (need_adj and nstack == 2) else None,
+               "dadj_add": dadj_add if need_adj else None}
         desc = _describe(x2, fin0, fin0, adj, B, K, stacks, ctx.stats, ctx.ws, bwd)
         nat.call("dense_stack_bwd_f32", desc.ctypes.data)
         dx = bwd["dx"].view(B, K, fin0) if need_x else None
         dadj = bwd["dadj"]
         del stacks, bwd, desc
-        return (dx, dadj, None, None, *grads)
+        return (dx, dadj, None, None, None, *grads)
 
 
-def dense_gcn_stacks(x, adj, stacks):
+def dense_gcn_stacks(x, adj, stacks, adj_pass=False):
     """the GCN stacks `stacks` (1 or 2 lists of GraphConv modules, same depth) on the pooled level (x[B,K,F], adj[B,K,K]):
     one concatenated output [B, K, sum(widths)] per stack, one launch forward and one backward for all of them"""
     params = []
     for convs in stacks:
         for c in convs:
             params += [c.weight, c.bias]
-    return _DenseGcnStacks.apply(x, adj, len(stacks), len(stacks[0]), *params)
+    return _DenseGcnStacks.apply(x, adj, len(stacks), len(stacks[0]), bool(adj_pass), *params)

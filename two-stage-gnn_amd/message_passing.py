@@ -153,6 +153,26 @@ def wgrad_reduce_multi(sets, norm_sink=None):
             norm_sink.stepped = norm_sink.stepped or step is not None
 
 
+def linear_wgrad_oi(z, K_in, du, want_db):
+    """(dW[N, K_in] — torch.nn.Linear's layout —, db[N] or None) = (du^T z[:, :K_in], colsum(du)): 128 x 128 output blocks in one
+    launch + one fixed-order reduction (K_in, N <= 512); None when the shape is not taken"""
+    R, N = int(du.size(0)), int(du.size(1))
+    nslab = np.zeros(1, dtype=np.int32)
+    rps = np.zeros(1, dtype=np.int64)
+    need = np.zeros(1, dtype=np.int64)
+    nat.call_nostream("wgrad_blocks_plan", R, int(K_in), N, int(z.stride(0)), int(du.stride(0)), nslab.ctypes.data, rps.ctypes.data,
+                      need.ctypes.data)
+    if int(nslab[0]) <= 0 or z.data_ptr() % 16 or du.data_ptr() % 16 or z.stride(0) < (int(K_in) + 3) // 4 * 4:
+        return None
+    ws = _f32(int(need[0]), device=du.device)
+    dw = _f32(N, int(K_in), device=du.device)
+    db = _f32(N, device=du.device) if want_db else None
+    if not nat.try_call("wgrad_blocks_oi_f32", z, z.stride(0), du, du.stride(0), R, int(K_in), N, int(nslab[0]), int(rps[0]), ws, dw,
+                        dw.stride(0), db):
+        return None
+    return dw, db
+
+
 def linear_wgrad(z, K_in, du, want_db, du_job=None):
     """(dW[K_in,N], db[N] or None) in one pass over the rows; falls back to split-K GEMM + column sums.
     du_job = (part, nb, F, dws, dbs): the partial rows tsgnn_sag_pool_graph_bwd_f32 left behind (called with dws = dbs = NULL);
@@ -327,8 +347,12 @@ class _LinearOI(torch.autograd.Function):
                 gemm(dy, dy.stride(0), 1, w, w.stride(0), 1, dx, dx.stride(0), 1, R, K, N)
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            dwt, db = linear_wgrad(x, K, dy, want_db)                                        # (dW)^T = X^T dY [in, out]
-            dw = dwt.t()
+            got = linear_wgrad_oi(x, K, dy, want_db)       # dW [out, in] contiguous: AccumulateGrad keeps it (a .t() view is copied)
+            if got is not None:
+                dw, db = got
+            else:
+                dwt, db = linear_wgrad(x, K, dy, want_db)                                    # (dW)^T = X^T dY [in, out]
+                dw = dwt.t()
         elif want_db:
             db = colsum(dy)
         return dx, dw, db
@@ -795,6 +819,9 @@ def _sink_or_new(param, shape, device):
 def unit_seed(device):
     """cached scalar 1.0 to seed ``loss.backward(gradient=unit_seed(dev))``: no fill launch, and the fused loss node
     recognises the object and skips the multiply by 1."""
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:       # the key the backward looks up is a tensor's device ("cuda:0")
+        device = torch.device("cuda", torch.cuda.current_device())
     t = _unit.get(device)
     if t is None:
         t = _unit[device] = torch.ones((), dtype=torch.float32, device=device)

@@ -186,7 +186,7 @@ class _SageStack(torch.autograd.Function):
         ctx.nodes = nodes
         if nodes:
             if nodes == 2 and g.n_ghost:
-                nat.defer(lambda: cat[g.n_rows:].zero_())    # embedding mask: ghost rows of the node output are zero
+                nat.defer_zero(cat[g.n_rows:])               # embedding mask: ghost rows of the node output are zero
             ctx.g, ctx.L, ctx.has_bias, ctx.dims = g, L, has_bias, (Fh, Fl)
             ctx.slots = (sn, sg)
             ctx.Ws, ctx.saved, ctx.arg = Ws, saved, None
@@ -426,6 +426,10 @@ def run_paired(qa, qb):
             if _multi([a[1], b[1]], []):
                 i += 1; j += 1
                 continue
+        if a[0] == b[0] == "_zero":
+            torch._foreach_zero_([a[1][0], b[1][0]])
+            i += 1; j += 1
+            continue
         if a[0] == b[0] and a[0] in _PAIRED and _PAIRED[a[0]](a[1], b[1]):
             i += 1; j += 1
             continue
