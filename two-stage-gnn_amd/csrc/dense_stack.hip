@@ -55,22 +55,40 @@ struct DsArgs {
 // Device-wide barrier number k of a launch: its own arrival word (words[k], zero before the launch), bounded spin.  Word k - 1 is
 // re-armed by workgroup 0 once barrier k has completed (every workgroup has left barrier k - 1 by then); the last barrier's word
 // by whichever workgroup signs off last (grid_finish).  Launches of different grid sizes can therefore share the words.
+//
+// LIGHT: for exchanges whose data travels in agent-scope ATOMIC stores / loads only (ds_put2 / ds_get2 below: the per-row
+// batch-norm partial sums, 8 bytes a row).  Those accesses are coherent across the XCDs by themselves (sc1), so the barrier needs
+// neither the L2 write-back of a release at agent scope nor the L2 invalidate of an acquire — which is what a device-wide barrier
+// costs here (the kernel's own dirty lines flushed, the weights re-fetched afterwards): the stores are complete when the
+// workgroup-scope fence of the __syncthreads() ahead of the arrival has passed (s_waitcnt vmcnt(0)), the arrival and the
+// spin are relaxed.  Nothing else written before a LIGHT barrier may be read by another workgroup after it.
+template <bool LIGHT = false>
 __device__ __forceinline__ void grid_barrier(unsigned* words, int& k, unsigned nblocks, float* err) {
   __syncthreads();
   if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(words + k, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (LIGHT) __hip_atomic_fetch_add(words + k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else __hip_atomic_fetch_add(words + k, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     bool ok = false;
     // spin on RELAXED loads, then ONE acquire fence: an acquire load invalidates the caches at every iteration of the spin
     for (int spin = 0; spin < (1 << 21); ++spin) {
       if (__hip_atomic_load(words + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= nblocks) { ok = true; break; }
       __builtin_amdgcn_s_sleep(2);
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (!LIGHT) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     if (!ok) __hip_atomic_store(err, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (k > 0 && blockIdx.x == 0) __hip_atomic_store(words + k - 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   ++k;
   __syncthreads();
+}
+// a pair of floats through agent-scope atomics (one 8-byte access): see grid_barrier<LIGHT>
+__device__ __forceinline__ void ds_put2(float* p, float x, float y) {
+  const unsigned long long bits = ((unsigned long long)__float_as_uint(y) << 32) | (unsigned long long)__float_as_uint(x);
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float2 ds_get2(const float* p) {
+  const unsigned long long bits = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return make_float2(__uint_as_float((unsigned)(bits & 0xffffffffull)), __uint_as_float((unsigned)(bits >> 32)));
 }
 // after a workgroup's last barrier: sign off; the last one re-arms the last barrier's word and the sign-off counter (no waiting)
 __device__ __forceinline__ void grid_finish(unsigned* words, int k, unsigned nblocks) {
@@ -195,11 +213,11 @@ __device__ __forceinline__ void slot_totals(const float* st, int B, int K, int n
   for (; bb + 8 <= B; bb += 8) {
     float2 v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float2*>(st + ((int64_t)(bb + u) * K + n) * 2);
+    for (int u = 0; u < 8; ++u) v[u] = ds_get2(st + ((int64_t)(bb + u) * K + n) * 2);
 #pragma unroll
     for (int u = 0; u < 8; ++u) { t1 += v[u].x; t2 += v[u].y; }
   }
-  for (; bb < B; ++bb) { const float2 v = *reinterpret_cast<const float2*>(st + ((int64_t)bb * K + n) * 2); t1 += v.x; t2 += v.y; }
+  for (; bb < B; ++bb) { const float2 v = ds_get2(st + ((int64_t)bb * K + n) * 2); t1 += v.x; t2 += v.y; }
 }
 
 constexpr int DS_LDA = 68;                // row stride of the A tile [TR][K <= 64] (+4: the 16 rows of an A request spread over the banks)
@@ -303,9 +321,11 @@ __global__ __launch_bounds__(256) void dense_stack_fwd_kernel(DsArgs a) {
     if (!last) {
       s1 = row16_sum(s1); s2 = row16_sum(s2);
       float* st = a.stats + ((int64_t)l * a.nstack * R + (int64_t)s * R) * 2;
-      if (rok && cg == 0) *reinterpret_cast<float2*>(st + row * 2) = make_float2(s1, s2);
+      if (rok && cg == 0) ds_put2(st + row * 2, s1, s2);
       if (l == 0) TR(5);
-      grid_barrier(a.sync, bar, nblocks, a.err);
+      // one tile per graph: only the partial sums cross workgroups here; else the sibling tiles' rows of v do too
+      if (tiles == 1) grid_barrier<true>(a.sync, bar, nblocks, a.err);
+      else grid_barrier(a.sync, bar, nblocks, a.err);
       if (l == 0) TR(6);
       // every workgroup finishes the statistics of all K slots
       if (tid < K) {
@@ -387,8 +407,8 @@ __global__ __launch_bounds__(256) void dense_stack_bwd_kernel(DsArgs a) {
         }
       p1 = row16_sum(p1); p2 = row16_sum(p2);
       float* st = a.stats + ((int64_t)l * a.nstack * R + (int64_t)s * R) * 2;
-      if (rok && cg == 0) *reinterpret_cast<float2*>(st + row * 2) = make_float2(p1, p2);
-      grid_barrier(a.sync, bar, nblocks, a.err);
+      if (rok && cg == 0) ds_put2(st + row * 2, p1, p2);
+      grid_barrier<true>(a.sync, bar, nblocks, a.err);     // (only the partial sums cross workgroups here)
       if (tid < K) {
         float t1, t2;
         slot_totals(st, B, K, tid, t1, t2);
@@ -493,7 +513,8 @@ __global__ __launch_bounds__(256) void dense_stack_bwd_kernel(DsArgs a) {
     }
     // ---- P5: dx[tile rows m, :] = sum_r A[r, m] dagg[r, :] over ALL rows r of the graph: the sibling tiles' dagg first
     if (l > 0 || a.dx) {
-      grid_barrier(a.sync, bar, nblocks, a.err);
+      if (tiles == 1) __syncthreads();                       // the graph is this tile: its dagg rows are the workgroup's own writes
+      else grid_barrier(a.sync, bar, nblocks, a.err);
       if (finP != fin) zero_lds(big, K * ldf);
       zero_lds(At, K * DS_TR);
       __syncthreads();
