@@ -89,7 +89,7 @@ int tsgnn_ingest_upload_f32(int32_t* dev, const int32_t* host, int64_t words, co
                             int F, float* x, int64_t ldx, tsgnn_stream_t stream);
 /* COMPACT staging (about a third of the expanded layout: the CSR, not the table) and the two launches that bring it in from
  * pinned host memory at the head of the step's own hipGraph — no copy engine, no second stream, no cross-stream events.
- * Layout: off[0..8] = header{n, nnz, ntail, largest}, graph_ptr[B+2], slot_count[nmax], label (int64[B]), rowptr[row_cap+1],
+ * Layout: off[0..8] = header{n, nnz, ntail, largest, sequence word, 3 spare}, graph_ptr[B+2], slot_count[nmax], label (int64[B]), rowptr[row_cap+1],
  * node_label[row_cap], tail_ptr[row_cap+1], col[edge_cap], tail_col[tail_cap]; off[9] = total words. */
 int tsgnn_ingest_compact_layout(int B, int nmax, int64_t row_cap, int64_t edge_cap, int64_t tail_cap, int64_t* off);
 /* HOST function: tsgnn_host_collate_tu's batch in the compact layout (TSGNN_EUNSUPPORTED also when edges exceed edge_cap) */
@@ -102,6 +102,13 @@ int tsgnn_host_collate_compact(const int64_t* ds_graph_ptr, const int64_t* ds_ro
 int tsgnn_ingest_pull_expand_f32(const int32_t* host, int32_t* mirror, int B, int nmax, int64_t row_cap, int64_t edge_cap, int ell_w,
                                  int64_t tail_cap, int32_t* row_graph, int32_t* row_slot, int32_t* ell, int32_t* tail_ptr, int F, float* x,
                                  int64_t ldx, tsgnn_stream_t stream);
+/* The same pair; the expand launch also echoes the batch's sequence word (header word 4 of the compact layout, written by whoever
+ * collated the batch) to host_ack[0] (PINNED HOST memory, system-scope store): once host_ack[0] == s, batch s has been pulled out
+ * of `host`, which may be refilled.  The hand-shake with the collate workers (tsgnn_collate_pool_submit_ack) without a HIP event
+ * per step (graph_sampler.py:102-114 / train.py:110-119: the per-step batch hand-over). */
+int tsgnn_ingest_pull_expand_ack_f32(const int32_t* host, int32_t* mirror, int B, int nmax, int64_t row_cap, int64_t edge_cap, int ell_w,
+                                     int64_t tail_cap, int32_t* row_graph, int32_t* row_slot, int32_t* ell, int32_t* tail_ptr, int F,
+                                     float* x, int64_t ldx, int64_t* host_ack, tsgnn_stream_t stream);
 /* Collate workers: native threads that run the host collate for the batches ahead of the step being enqueued.  submit: the
  * arguments of tsgnn_host_collate_tu (edge_cap = 0) or tsgnn_host_collate_compact (edge_cap > 0) (`ids`, `out` must stay valid
  * until waited for) + after_event (nullable hipEvent_t: the worker synchronises with it before writing `staging`); wait: blocks,
@@ -112,6 +119,12 @@ int tsgnn_collate_pool_submit(tsgnn_collate_pool* pool, const int64_t* ds_graph_
                               const int64_t* ds_node_label, const int64_t* ds_graph_label, const int64_t* ids, int B, int nmax,
                               int64_t row_cap, int64_t edge_cap, int ell_w, int64_t tail_cap, int32_t* staging, int64_t* out,
                               void* after_event, int64_t* ticket);
+/* submit (compact layout: edge_cap > 0) whose worker waits until host_ack[0] >= ack_target before it writes `staging` (gives up
+ * after 20 s: the job then reports a launch error) and stamps the collated batch with `seq` (header word 4) */
+int tsgnn_collate_pool_submit_ack(tsgnn_collate_pool* pool, const int64_t* ds_graph_ptr, const int64_t* ds_rowptr, const int64_t* ds_col,
+                                  const int64_t* ds_node_label, const int64_t* ds_graph_label, const int64_t* ids, int B, int nmax,
+                                  int64_t row_cap, int64_t edge_cap, int ell_w, int64_t tail_cap, int32_t* staging, int64_t* out,
+                                  const int64_t* host_ack, int64_t ack_target, int seq, int64_t* ticket);
 int tsgnn_collate_pool_wait(tsgnn_collate_pool* pool, int64_t ticket);
 int tsgnn_collate_pool_destroy(tsgnn_collate_pool* pool);
 

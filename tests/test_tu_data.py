@@ -330,3 +330,40 @@ def test_host_collate_compact_layout():
         args = dict(nmax=nmax, row_cap=cap, edge_cap=ecap, tail_cap=tcap); args.update(kw)
         with pytest.raises(RuntimeError, match="not supported"):
             ingest.host_collate_compact(ds, ids, B, args["nmax"], args["row_cap"], args["edge_cap"], st, 16, args["tail_cap"])
+
+
+@pytest.mark.gpu
+def test_ingest_acknowledges_pulled_batches():
+    """the hand-shake that replaced the per-step HIP event: whoever collates a batch stamps it with a sequence number, the
+    expand launch echoes the number of the batch it pulled into pinned host memory; inline collates and the worker pool wait for
+    the echo of the batch the staging buffer holds before they overwrite it"""
+    from two_stage_gnn_amd import ingest
+    dev = torch.device("cuda")
+    ds = ingest.synthetic_dataset(seed=3, n_graphs=12, shape="DD", nmax=400)
+    ids = np.array([1, 5, 7])
+    slot = ingest.CapacityBatch(3, 400, 1216, 8192, ds.num_node_labels, dev, ghost_slots=401)
+    assert slot.seq == 0 and int(slot.ack[0]) == 0
+    slot.collate(ds, ids)                                          # nothing staged before: no wait
+    assert slot.seq == 1
+    slot.pull(); slot.pull()                                       # the same staged batch twice: the same echo
+    torch.cuda.synchronize()
+    assert int(slot.ack[0]) == 1
+    rows1 = slot.rows
+    slot.collate(ds, ids[::-1].copy())                             # waits for the echo of batch 1 (already there)
+    assert slot.seq == 2 and int(slot.ack[0]) == 1
+    slot.pull()
+    torch.cuda.synchronize()
+    assert int(slot.ack[0]) == 2 and slot.rows == rows1
+    # through the native workers: the job waits for the echo of batch 2, then stamps batch 3
+    pool = ingest.CollatePool(1)
+    slot.collate_async(pool, ds, np.array([0, 2, 4]))
+    slot.collate_wait()
+    assert slot.seq == 3 and int(slot.host[slot._seq_word]) == 3
+    slot.pull()
+    torch.cuda.synchronize()
+    assert int(slot.ack[0]) == 3 and slot.rows == int(ds.sizes[[0, 2, 4]].sum())
+    # a batch that was never enqueued for pulling may be overwritten at once
+    slot.collate_async(pool, ds, ids)
+    slot.collate_wait()
+    assert slot.seq == 4 and int(slot.ack[0]) == 3
+    pool.close()

@@ -19,6 +19,7 @@
 #include <deque>
 #include <mutex>
 #include <thread>
+#include <chrono>
 #include <vector>
 
 namespace {
@@ -73,7 +74,7 @@ struct CLayout {
 inline CLayout make_clayout(int B, int nmax, int64_t row_cap, int64_t edge_cap, int64_t tail_cap) {
   CLayout L;
   int64_t o = 0;
-  L.header = o; o += 4;
+  L.header = o; o += 8;                                 // {n, nnz, ntail, largest, sequence word (written by the caller), 3 spare}
   L.graph_ptr = o; o += align4(B + 2);
   L.slot_count = o; o += align4(nmax);
   L.label = o; o += align4(2 * (int64_t)B);
@@ -105,6 +106,7 @@ struct ExpandArgs {
   const int32_t* mirror; CLayout L;
   int B, nmax, ell_w, F, ld4; int64_t row_cap;
   int32_t* row_graph; int32_t* row_slot; int32_t* ell; int32_t* tail_ptr; float* x; int64_t ldx;
+  int64_t* host_ack;                     // nullable (pinned host memory): receives the batch's sequence word once it is pulled
 };
 
 // 32 lanes per row, 8 rows per block.  Lane q of a row: q < ell_w/4 writes four entries of the row's neighbour table, q == ell_w/4
@@ -114,6 +116,11 @@ __global__ __launch_bounds__(256) void ingest_expand_kernel(ExpandArgs a) {
   const int64_t total_rows = a.row_cap + a.nmax;
   const int64_t r = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
   const int q = threadIdx.x & 31;
+  if (a.host_ack && blockIdx.x == 0 && threadIdx.x == 0) {
+    // the pull launch ahead of this one has finished reading the staging buffer: echo the batch's sequence word to the host,
+    // which may refill the buffer once it sees it (the collate workers wait on this word — no event between the step's launches)
+    __hip_atomic_store(a.host_ack, (int64_t)a.mirror[a.L.header + 4], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   if (r >= total_rows) return;
   const int64_t n = a.mirror[a.L.header];
   const int32_t ntail = a.mirror[a.L.header + 2];
@@ -157,11 +164,12 @@ __global__ __launch_bounds__(256) void ingest_expand_kernel(ExpandArgs a) {
   }
 }
 
+
 }  // namespace
 
 extern "C" {
 
-/* word offsets of the COMPACT staging layout: off[0..8] = header{n, nnz, ntail, largest}, graph_ptr[B+2], slot_count[nmax],
+/* word offsets of the COMPACT staging layout: off[0..8] = header{n, nnz, ntail, largest, sequence word, 3 spare}, graph_ptr[B+2], slot_count[nmax],
  * label (int64[B]), rowptr[row_cap+1], node_label[row_cap], tail_ptr[row_cap+1], col[edge_cap], tail_col[tail_cap]; off[9] = total */
 int tsgnn_ingest_compact_layout(int B, int nmax, int64_t row_cap, int64_t edge_cap, int64_t tail_cap, int64_t* off) {
   if (!off || B <= 0 || nmax <= 0 || row_cap <= 0 || edge_cap <= 0 || tail_cap < 0) return TSGNN_EINVAL;
@@ -237,9 +245,9 @@ int tsgnn_host_collate_compact(const int64_t* ds_graph_ptr, const int64_t* ds_ro
  * (+ graph_ptr, slot_count, label, node_label, tail_col: plain copies), then expand mirror -> row_graph, row_slot, ell
  * [(row_cap+nmax) x ell_w], tail_ptr[row_cap+nmax+1], one-hot x [(row_cap+nmax) x ldx] (F classes).  Sizes come from the batch's
  * own header, so one captured launch pair serves every batch of the slot. */
-int tsgnn_ingest_pull_expand_f32(const int32_t* host, int32_t* mirror, int B, int nmax, int64_t row_cap, int64_t edge_cap, int ell_w,
-                                 int64_t tail_cap, int32_t* row_graph, int32_t* row_slot, int32_t* ell, int32_t* tail_ptr, int F, float* x,
-                                 int64_t ldx, tsgnn_stream_t stream) {
+static int pull_expand_launch(const int32_t* host, int32_t* mirror, int B, int nmax, int64_t row_cap, int64_t edge_cap, int ell_w,
+                              int64_t tail_cap, int32_t* row_graph, int32_t* row_slot, int32_t* ell, int32_t* tail_ptr, int F, float* x,
+                              int64_t ldx, int64_t* host_ack, tsgnn_stream_t stream) {
   if (!host || !mirror || !row_graph || !row_slot || !ell || !tail_ptr || !x || B <= 0 || nmax <= 0 || row_cap <= 0 || edge_cap <= 0 ||
       tail_cap < 0 || F <= 0)
     return TSGNN_EINVAL;
@@ -254,10 +262,29 @@ int tsgnn_ingest_pull_expand_f32(const int32_t* host, int32_t* mirror, int B, in
   unsigned pgrid = (unsigned)ceil_div64(n4, 256 * 2);
   if (pgrid > 512) pgrid = 512;
   ingest_pull_kernel<<<pgrid, 256, 0, stream>>>(reinterpret_cast<const int4*>(host), reinterpret_cast<int4*>(mirror), n4);
-  ExpandArgs ea{mirror, L, B, nmax, ell_w, F, ld4, row_cap, row_graph, row_slot, ell, tail_ptr, x, ldx};
+  ExpandArgs ea{mirror, L, B, nmax, ell_w, F, ld4, row_cap, row_graph, row_slot, ell, tail_ptr, x, ldx, host_ack};
   ingest_expand_kernel<<<(unsigned)ceil_div64(row_cap + nmax, 8), 256, 0, stream>>>(ea);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
+}
+
+int tsgnn_ingest_pull_expand_f32(const int32_t* host, int32_t* mirror, int B, int nmax, int64_t row_cap, int64_t edge_cap, int ell_w,
+                                 int64_t tail_cap, int32_t* row_graph, int32_t* row_slot, int32_t* ell, int32_t* tail_ptr, int F, float* x,
+                                 int64_t ldx, tsgnn_stream_t stream) {
+  return pull_expand_launch(host, mirror, B, nmax, row_cap, edge_cap, ell_w, tail_cap, row_graph, row_slot, ell, tail_ptr, F, x, ldx,
+                            nullptr, stream);
+}
+
+/* the same pair; the expand launch also echoes the batch's sequence word (staging header word 4, written by whoever collated the
+ * batch) to host_ack[0] (pinned host memory, system-scope store): once host_ack[0] == s, batch s has been pulled out of `host`,
+ * which may then be refilled — the hand-shake with the collate workers (tsgnn_collate_pool_submit_ack) without a HIP event per
+ * step. */
+int tsgnn_ingest_pull_expand_ack_f32(const int32_t* host, int32_t* mirror, int B, int nmax, int64_t row_cap, int64_t edge_cap, int ell_w,
+                                     int64_t tail_cap, int32_t* row_graph, int32_t* row_slot, int32_t* ell, int32_t* tail_ptr, int F,
+                                     float* x, int64_t ldx, int64_t* host_ack, tsgnn_stream_t stream) {
+  if (!host_ack) return TSGNN_EINVAL;
+  return pull_expand_launch(host, mirror, B, nmax, row_cap, edge_cap, ell_w, tail_cap, row_graph, row_slot, ell, tail_ptr, F, x, ldx,
+                            host_ack, stream);
 }
 
 /* word offsets (4-byte words) of the segments of an ingest buffer: off[0..8] = graph_ptr[B+2], slot_count[nmax],
@@ -374,6 +401,8 @@ struct tsgnn_collate_pool {
     const int64_t *gp, *rp, *col, *nl, *gl, *ids;
     int B, nmax, ell_w; int64_t row_cap, tail_cap, edge_cap; int32_t* staging; int64_t* out; hipEvent_t after;
     int64_t ticket; int rc; bool done;
+    const int64_t* ack = nullptr; int64_t ack_target = 0; int32_t seq = 0;   // alternative to `after`: wait until *ack >= ack_target,
+                                                                             // stamp the collated batch with `seq`
   };
   std::mutex mu;
   std::condition_variable cv_work, cv_done;
@@ -395,11 +424,24 @@ static void collate_worker(tsgnn_collate_pool* p) {
       p->queue.pop_front();
     }
     if (j->after) (void)hipEventSynchronize(j->after);
-    const int rc = j->edge_cap > 0
+    bool acked = true;
+    if (j->ack) {                                          // (bounded: a device that never runs the step must not hang the worker)
+      const auto t0 = std::chrono::steady_clock::now();
+      unsigned spins = 0;
+      while (__atomic_load_n(j->ack, __ATOMIC_ACQUIRE) < j->ack_target) {
+        if ((++spins & 63u) == 0) {
+          std::this_thread::yield();
+          if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) { acked = false; break; }
+        }
+      }
+    }
+    const int rc = !acked ? TSGNN_ELAUNCH : j->edge_cap > 0
                        ? tsgnn_host_collate_compact(j->gp, j->rp, j->col, j->nl, j->gl, j->ids, j->B, j->nmax, j->row_cap, j->edge_cap,
                                                     j->ell_w, j->tail_cap, j->staging, j->out)
                        : tsgnn_host_collate_tu(j->gp, j->rp, j->col, j->nl, j->gl, j->ids, j->B, j->nmax, j->row_cap, j->ell_w,
                                                j->tail_cap, j->staging, j->out);
+    if (j->ack && rc == TSGNN_OK && j->edge_cap > 0)
+      j->staging[make_clayout(j->B, j->nmax, j->row_cap, j->edge_cap, j->tail_cap).header + 4] = j->seq;
     {
       std::lock_guard<std::mutex> lk(p->mu);
       j->rc = rc;
@@ -427,6 +469,30 @@ int tsgnn_collate_pool_submit(tsgnn_collate_pool* pool, const int64_t* ds_graph_
   if (!pool || !ticket) return TSGNN_EINVAL;
   auto* j = new tsgnn_collate_pool::Job{ds_graph_ptr, ds_rowptr, ds_col, ds_node_label, ds_graph_label, ids, B, nmax, ell_w, row_cap,
                                         tail_cap, edge_cap, staging, out, reinterpret_cast<hipEvent_t>(after_event), 0, 0, false};
+  {
+    std::lock_guard<std::mutex> lk(pool->mu);
+    j->ticket = pool->next_ticket++;
+    pool->queue.push_back(j);
+    pool->all.push_back(j);
+    *ticket = j->ticket;
+  }
+  pool->cv_work.notify_one();
+  return TSGNN_OK;
+}
+
+/* tsgnn_collate_pool_submit (compact layout only) whose worker waits for host_ack[0] >= ack_target (the word
+ * tsgnn_ingest_pull_expand_ack_f32 stores: the sequence word of the batch this buffer held before) instead of an event, and stamps
+ * the new batch with `seq` (header word 4); gives up after 20 s (the job then reports TSGNN_ELAUNCH) */
+int tsgnn_collate_pool_submit_ack(tsgnn_collate_pool* pool, const int64_t* ds_graph_ptr, const int64_t* ds_rowptr, const int64_t* ds_col,
+                                  const int64_t* ds_node_label, const int64_t* ds_graph_label, const int64_t* ids, int B, int nmax,
+                                  int64_t row_cap, int64_t edge_cap, int ell_w, int64_t tail_cap, int32_t* staging, int64_t* out,
+                                  const int64_t* host_ack, int64_t ack_target, int seq, int64_t* ticket) {
+  if (!pool || !ticket || !host_ack || edge_cap <= 0) return TSGNN_EINVAL;
+  auto* j = new tsgnn_collate_pool::Job{ds_graph_ptr, ds_rowptr, ds_col, ds_node_label, ds_graph_label, ids, B, nmax, ell_w, row_cap,
+                                        tail_cap, edge_cap, staging, out, nullptr, 0, 0, false};
+  j->ack = host_ack;
+  j->ack_target = ack_target;
+  j->seq = seq;
   {
     std::lock_guard<std::mutex> lk(pool->mu);
     j->ticket = pool->next_ticket++;

@@ -113,21 +113,38 @@ class CapacityBatch:
         ld = (fin + 3) // 4 * 4
         self.x = torch.zeros(R, ld, dtype=torch.float32, device=device)
         self.rows = self.edges = 0
-        if cuda:
-            self.consumed = torch.cuda.Event()      # the step that pulled this slot's staging buffer has finished
-            self._pending = False
+        # hand-shake with the device without an event per step: whoever collates a batch stamps it with a sequence number
+        # (header word 4); the expand launch echoes the number of the batch it has pulled into `ack` (pinned host memory); the
+        # staging buffer is refilled only once the last stamped batch was echoed
+        self._seq_word = off[0] + 4
+        self.seq = 0                                # sequence number of the batch in the staging buffer
+        self.ack = torch.zeros(1, dtype=torch.int64).pin_memory() if cuda else None
+        self._ack_np = self.ack.numpy() if cuda else None
+        self._replayed = True                       # the staged batch has been enqueued for pulling at least once
 
     # ------------------------------------------------------------------ host side
     def _check(self):
         if self.largest + 1 > self.g.ghost_slots_fixed:
             raise ValueError("a graph of %d nodes exceeds the slot's fixed ghost-slot bound %d" % (self.largest, self.g.ghost_slots_fixed))
 
+    def _wait_pulled(self):
+        """the batch in the staging buffer, if a pull of it was enqueued, has been pulled (bounded wait)"""
+        if self.ack is None or self.seq == 0 or not self._replayed:
+            return
+        import time
+        t0 = time.perf_counter()
+        while int(self._ack_np[0]) < self.seq:
+            if time.perf_counter() - t0 > 20.0:
+                raise RuntimeError("ingest: the device did not acknowledge batch %d of this slot within 20 s" % self.seq)
+
     def collate(self, ds, ids):
-        """write the mini-batch ``ids`` of ``ds`` into the staging buffer (after the step that last pulled from it finished)"""
-        if getattr(self, "_pending", False):
-            self.consumed.synchronize()
+        """write the mini-batch ``ids`` of ``ds`` into the staging buffer (after the pull of the batch it holds has finished)"""
+        self._wait_pulled()
         self.rows, self.edges, self.tail, self.largest = host_collate_compact(ds, ids, self.B, self.nmax, self.row_cap, self.edge_cap,
                                                                              self.host, ELL_W, self.tail_cap)
+        self.seq += 1
+        self.host[self._seq_word] = self.seq
+        self._replayed = False
         self._check()
 
     def collate_async(self, pool, ds, ids):
@@ -138,11 +155,14 @@ class CapacityBatch:
         self._out = np.zeros(4, dtype=np.int64)
         self._ticket = np.zeros(1, dtype=np.int64)
         nl = ds.node_label
-        after = self.consumed.cuda_event if getattr(self, "_pending", False) else None
-        nat.call_nostream("collate_pool_submit", pool.handle, ds.graph_ptr.ctypes.data, ds.rowptr.ctypes.data, ds.col.ctypes.data,
+        # the worker waits until the batch this buffer holds has been pulled (if a pull of it was ever enqueued)
+        target = self.seq if self._replayed else 0
+        self.seq += 1
+        self._replayed = False
+        nat.call_nostream("collate_pool_submit_ack", pool.handle, ds.graph_ptr.ctypes.data, ds.rowptr.ctypes.data, ds.col.ctypes.data,
                           nl.ctypes.data if nl is not None else None, ds.graph_label.ctypes.data, self._ids.ctypes.data, int(self.B),
                           int(self.nmax), int(self.row_cap), int(self.edge_cap), ELL_W, int(self.tail_cap), self.host.data_ptr(),
-                          self._out.ctypes.data, after, self._ticket.ctypes.data)
+                          self._out.ctypes.data, self.ack.data_ptr(), int(target), int(self.seq), self._ticket.ctypes.data)
         self._pool = pool
 
     def collate_wait(self):
@@ -155,12 +175,15 @@ class CapacityBatch:
         """enqueue (current stream; capturable) the pull of the staged batch and its expansion into the slot's arrays"""
         g = self.g
         ell, _, (tail_ptr, tail_col) = g._ell
-        nat.call("ingest_pull_expand_f32", self.host.data_ptr(), self.mirror, self.B, self.nmax, self.row_cap, self.edge_cap, ELL_W,
-                 self.tail_cap, g.row_graph, g.row_slot, ell, tail_ptr, self.fin, self.x, self.x.stride(0))
+        args = (self.host.data_ptr(), self.mirror, self.B, self.nmax, self.row_cap, self.edge_cap, ELL_W, self.tail_cap, g.row_graph,
+                g.row_slot, ell, tail_ptr, self.fin, self.x, self.x.stride(0), self.ack.data_ptr())
+        nat.call("ingest_pull_expand_ack_f32", *args)
+        if not torch.cuda.is_current_stream_capturing():
+            self._replayed = True
 
-    def mark_consumed(self, stream):
-        self.consumed.record(stream)
-        self._pending = True
+    def mark_consumed(self, stream=None):
+        """a replay of the captured step (whose first launches are this slot's pull) has been enqueued"""
+        self._replayed = True
 
 
 class CollatePool:
