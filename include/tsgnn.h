@@ -109,6 +109,18 @@ int tsgnn_ingest_pull_expand_f32(const int32_t* host, int32_t* mirror, int B, in
 int tsgnn_ingest_pull_expand_ack_f32(const int32_t* host, int32_t* mirror, int B, int nmax, int64_t row_cap, int64_t edge_cap, int ell_w,
                                      int64_t tail_cap, int32_t* row_graph, int32_t* row_slot, int32_t* ell, int32_t* tail_ptr, int F,
                                      float* x, int64_t ldx, int64_t* host_ack, tsgnn_stream_t stream);
+/* The two halves alone, and the pull as PASSENGERS of a launch of the previous step: tsgnn_ingest_arm_pull_rider arms the flat copy
+ * host -> mirror on the calling thread; the thread's next tsgnn_sage_layer_fwd_f32 / _ro_f32 launch carries it as extra workgroups
+ * (the pull of the NEXT mini-batch inside the CURRENT step: a launch of its own is ~10 us of PCIe latency per step);
+ * tsgnn_ingest_flush_pull_rider launches an armed rider that no launch took (no-op otherwise).  tsgnn_ingest_expand_ack_f32: the
+ * expansion of an already pulled batch (+ the sequence-word echo, host_ack nullable). */
+int tsgnn_ingest_pull_f32(const int32_t* host, int32_t* mirror, int B, int nmax, int64_t row_cap, int64_t edge_cap, int64_t tail_cap,
+                          tsgnn_stream_t stream);
+int tsgnn_ingest_expand_ack_f32(int32_t* mirror, int B, int nmax, int64_t row_cap, int64_t edge_cap, int ell_w, int64_t tail_cap,
+                                int32_t* row_graph, int32_t* row_slot, int32_t* ell, int32_t* tail_ptr, int F, float* x, int64_t ldx,
+                                int64_t* host_ack, tsgnn_stream_t stream);
+int tsgnn_ingest_arm_pull_rider(const int32_t* host, int32_t* mirror, int B, int nmax, int64_t row_cap, int64_t edge_cap, int64_t tail_cap);
+int tsgnn_ingest_flush_pull_rider(tsgnn_stream_t stream);
 /* Collate workers: native threads that run the host collate for the batches ahead of the step being enqueued.  submit: the
  * arguments of tsgnn_host_collate_tu (edge_cap = 0) or tsgnn_host_collate_compact (edge_cap > 0) (`ids`, `out` must stay valid
  * until waited for) + after_event (nullable hipEvent_t: the worker synchronises with it before writing `staging`); wait: blocks,

@@ -16,29 +16,10 @@ pipe = ingest.IngestPipeline(model, tr, ds, 32, 1000, dev, sched)
 pipe.run(sched[:20]); torch.cuda.synchronize()
 for workers in (3, 2, 1, 0):
     T = {}
-    def tick(name, t0):
-        t1 = time.perf_counter(); T[name] = T.get(name, 0.0) + (t1 - t0); return t1
-    depth = len(pipe.slots)
-    pool = pipe._get_pool(workers) if workers else None
     S = sched[20:]
     torch.cuda.synchronize()
     t_all = time.perf_counter()
-    if pool is not None:
-        for k in range(depth):
-            pipe.slots[k].collate_async(pool, ds, S[k])
-    for k, ids in enumerate(S):
-        s, gs = pipe.slots[k % depth], pipe.steps[k % depth]
-        t = time.perf_counter()
-        if pool is not None:
-            s.collate_wait()
-        else:
-            s.collate(ds, ids)
-        t = tick("collate/wait", t)
-        gs.step(); t = tick("replay", t)
-        s.mark_consumed(pipe.compute); t = tick("record", t)
-        if pool is not None and k + depth < len(S):
-            s.collate_async(pool, ds, S[k + depth])
-        t = tick("submit", t)
+    pipe.run(S, workers=workers, ticks=T)
     t_host = time.perf_counter() - t_all
     torch.cuda.synchronize()
     t_tot = time.perf_counter() - t_all
@@ -56,3 +37,4 @@ print("replay slot 0 only (pull + expand + step, same staged batch)  %.1f us" % 
 print("replay alternating slots                                      %.1f us" % timed(lambda k: pipe.steps[k % depth].step()))
 with torch.cuda.stream(pipe.compute):
     print("pull + expand alone                                           %.1f us" % timed(lambda k: pipe.slots[0].pull()))
+    print("expand alone                                                  %.1f us" % timed(lambda k: pipe.slots[0].expand()))

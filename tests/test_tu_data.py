@@ -367,3 +367,46 @@ def test_ingest_acknowledges_pulled_batches():
     slot.collate_wait()
     assert slot.seq == 4 and int(slot.ack[0]) == 3
     pool.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workers", [0, 2])
+def test_ingest_pipeline_riding_pull_equals_pull_at_the_head(workers):
+    """the pipeline whose steps pull the NEXT batch as passengers of their first hidden-layer product (csrc/ingest_rider.h) trains
+    exactly like the pipeline whose steps pull their own batch with their first launch: same parameters after the schedule, two
+    runs in a row (the first batch of a run is pulled by a launch of its own), and the rider really is taken by a layer launch"""
+    from two_stage_gnn_amd import dense_encoders as E, ingest, _native as nat
+    from two_stage_gnn_amd.data_parallel import FlatTrainer
+    dev = torch.device("cuda")
+    ds = ingest.synthetic_dataset(seed=21, n_graphs=40, shape="DD", nmax=600)
+    rng = np.random.default_rng(5)
+    sched = [rng.choice(len(ds), size=6, replace=False) for _ in range(11)]
+
+    class A:
+        bias = True
+    out = []
+    for ride in (True, False):
+        torch.manual_seed(4)
+        m = E.GcnEncoderGraph(ds.num_node_labels, 128, 128, 2, 3, bn=True, args=A(), final_dim="number_classes").to(dev)
+        tr = FlatTrainer(m, lr=1e-2, clip=2.0, defer_loss=True)
+        pipe = ingest.IngestPipeline(m, tr, ds, 6, 600, dev, sched, ride=ride)
+        assert pipe.ride == ride
+        if ride:                                                   # an eager step of position 0: who launches the copy?
+            nat.trace = []
+            try:
+                with torch.cuda.stream(pipe.compute):
+                    pipe.steps[0].loss_fn()
+                names = [t[0] for t in nat.trace]
+                flush = [t for t in nat.trace if t[0] == "ingest_flush_pull_rider"]
+            finally:
+                nat.trace = None
+            torch.cuda.synchronize()
+            assert names[0] == "ingest_expand_ack_f32" and not any(n in names for n in ("ingest_pull_f32", "ingest_pull_expand_ack_f32"))
+            assert names.count("sage_layer_fwd_f32") + names.count("sage_layer_fwd_ro_f32") == 2
+            assert len(flush) == 1 and not flush[0][2].startswith("ingest_")      # nothing was left for launches of their own
+        pipe.run(sched[:4], workers=workers)                       # (no synchronisation in between: the second run drains the
+        pipe.run(sched[4:], workers=workers)                       # last replay's passengers itself)
+        torch.cuda.synchronize()
+        out.append(tr.flat_param.clone())
+    assert torch.isfinite(out[0]).all()
+    assert torch.equal(out[0], out[1])

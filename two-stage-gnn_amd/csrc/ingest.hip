@@ -13,6 +13,7 @@
 // uploaded labels (tsgnn_onehot_rows_f32): 4 bytes per node cross PCIe instead of 4 * F.
 #include "common.h"
 #include "../../include/tsgnn.h"
+#include "ingest_rider.h"
 
 #include <condition_variable>
 #include <cstring>
@@ -21,6 +22,8 @@
 #include <thread>
 #include <chrono>
 #include <vector>
+
+thread_local PullRider tsgnn_pull_rider_ = {nullptr, nullptr, 0, 0};
 
 namespace {
 
@@ -71,6 +74,7 @@ __global__ __launch_bounds__(256) void onehot_rows_kernel(const int* __restrict_
 struct CLayout {
   int64_t header, graph_ptr, slot_count, label, rowptr, node_label, tail_ptr, col, tail_col, total;
 };
+
 inline CLayout make_clayout(int B, int nmax, int64_t row_cap, int64_t edge_cap, int64_t tail_cap) {
   CLayout L;
   int64_t o = 0;
@@ -102,6 +106,8 @@ __global__ __launch_bounds__(256) void ingest_pull_kernel(const int4* __restrict
   for (; i < n4; i += gsize) mirror[i] = host[i];
 }
 
+__global__ __launch_bounds__(256) void ingest_pull_rider_kernel(PullRider p) { pull_rider_body(p, blockIdx.x); }
+
 struct ExpandArgs {
   const int32_t* mirror; CLayout L;
   int B, nmax, ell_w, F, ld4; int64_t row_cap;
@@ -113,10 +119,11 @@ struct ExpandArgs {
 // the row maps and the tail pointer, the lanes after that (looping when a row has more than 32 - ell_w/4 - 1 float4) the one-hot
 // feature row.
 __global__ __launch_bounds__(256) void ingest_expand_kernel(ExpandArgs a) {
+  const unsigned vb = blockIdx.x;
   const int64_t total_rows = a.row_cap + a.nmax;
-  const int64_t r = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+  const int64_t r = (int64_t)vb * 8 + (threadIdx.x >> 5);
   const int q = threadIdx.x & 31;
-  if (a.host_ack && blockIdx.x == 0 && threadIdx.x == 0) {
+  if (a.host_ack && vb == 0 && threadIdx.x == 0) {
     // the pull launch ahead of this one has finished reading the staging buffer: echo the batch's sequence word to the host,
     // which may refill the buffer once it sees it (the collate workers wait on this word — no event between the step's launches)
     __hip_atomic_store(a.host_ack, (int64_t)a.mirror[a.L.header + 4], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -287,6 +294,69 @@ int tsgnn_ingest_pull_expand_ack_f32(const int32_t* host, int32_t* mirror, int B
                             host_ack, stream);
 }
 
+/* the expand launch alone (mirror -> row maps, neighbour table, tail pointers, one-hot rows; echoes the sequence word to host_ack,
+ * nullable): for a batch whose pull already happened — as passengers of the previous step (tsgnn_ingest_arm_pull_rider) or by
+ * tsgnn_ingest_pull_f32. */
+int tsgnn_ingest_expand_ack_f32(int32_t* mirror, int B, int nmax, int64_t row_cap, int64_t edge_cap, int ell_w, int64_t tail_cap,
+                                int32_t* row_graph, int32_t* row_slot, int32_t* ell, int32_t* tail_ptr, int F, float* x, int64_t ldx,
+                                int64_t* host_ack, tsgnn_stream_t stream) {
+  if (!mirror || !row_graph || !row_slot || !ell || !tail_ptr || !x || B <= 0 || nmax <= 0 || row_cap <= 0 || edge_cap <= 0 ||
+      tail_cap < 0 || F <= 0)
+    return TSGNN_EINVAL;
+  const int ld4 = (F + 3) / 4;
+  if ((ell_w != 4 && ell_w != 8 && ell_w != 16) || ldx < 4 * ld4 || (ldx % 4)) return TSGNN_EUNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(mirror) | reinterpret_cast<uintptr_t>(ell) | reinterpret_cast<uintptr_t>(x)) & 15) return TSGNN_EUNSUPPORTED;
+  const CLayout L = make_clayout(B, nmax, row_cap, edge_cap, tail_cap);
+  ExpandArgs ea{mirror, L, B, nmax, ell_w, F, ld4, row_cap, row_graph, row_slot, ell, tail_ptr, x, ldx, host_ack};
+  TSGNN_KNAME("ingest_expand_kernel");
+  ingest_expand_kernel<<<(unsigned)ceil_div64(row_cap + nmax, 8), 256, 0, stream>>>(ea);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+static int make_rider(const int32_t* host, int32_t* mirror, int B, int nmax, int64_t row_cap, int64_t edge_cap, int64_t tail_cap,
+                      PullRider* out) {
+  if (!host || !mirror || B <= 0 || nmax <= 0 || row_cap <= 0 || edge_cap <= 0 || tail_cap < 0) return TSGNN_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(host) | reinterpret_cast<uintptr_t>(mirror)) & 15) return TSGNN_EUNSUPPORTED;
+  const CLayout L = make_clayout(B, nmax, row_cap, edge_cap, tail_cap);
+  const int64_t n4 = L.total / 4;
+  unsigned blocks = (unsigned)ceil_div64(n4, 256 * 2);
+  if (blocks > 512) blocks = 512;
+  *out = PullRider{reinterpret_cast<const int4*>(host), reinterpret_cast<int4*>(mirror), (long long)n4, blocks};
+  return TSGNN_OK;
+}
+
+/* the pull launch alone (flat copy of the compact staging buffer `host`, pinned and device-readable, into `mirror`) */
+int tsgnn_ingest_pull_f32(const int32_t* host, int32_t* mirror, int B, int nmax, int64_t row_cap, int64_t edge_cap, int64_t tail_cap,
+                          tsgnn_stream_t stream) {
+  PullRider p;
+  const int rc = make_rider(host, mirror, B, nmax, row_cap, edge_cap, tail_cap, &p);
+  if (rc != TSGNN_OK) return rc;
+  TSGNN_KNAME("ingest_pull_rider_kernel");
+  ingest_pull_rider_kernel<<<p.blocks, 256, 0, stream>>>(p);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+/* Arm the same copy as PASSENGERS of this thread's next tsgnn_sage_layer_fwd_f32 / _ro_f32 launch (extra workgroups of that
+ * launch: csrc/ingest_rider.h) — the pull of the NEXT mini-batch inside the CURRENT step.  One rider at a time (arming again
+ * replaces it).  tsgnn_ingest_flush_pull_rider: launches an armed rider that no launch took, alone; no-op otherwise. */
+int tsgnn_ingest_arm_pull_rider(const int32_t* host, int32_t* mirror, int B, int nmax, int64_t row_cap, int64_t edge_cap, int64_t tail_cap) {
+  PullRider p;
+  const int rc = make_rider(host, mirror, B, nmax, row_cap, edge_cap, tail_cap, &p);
+  if (rc != TSGNN_OK) return rc;
+  tsgnn_pull_rider_ = p;
+  return TSGNN_OK;
+}
+int tsgnn_ingest_flush_pull_rider(tsgnn_stream_t stream) {
+  const PullRider p = take_pull_rider();
+  if (p.blocks == 0) return TSGNN_OK;
+  TSGNN_KNAME("ingest_pull_rider_kernel");
+  ingest_pull_rider_kernel<<<p.blocks, 256, 0, stream>>>(p);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
 /* word offsets (4-byte words) of the segments of an ingest buffer: off[0..8] = graph_ptr[B+2], slot_count[nmax],
  * row_graph[row_cap], row_slot[row_cap], ell[(row_cap+nmax)*ell_w], tail_ptr[row_cap+nmax+1], tail_col[tail_cap],
  * node_label[row_cap], label (int64[B]); off[9] = total words.  Every segment starts on a 16-byte boundary. */
@@ -429,8 +499,8 @@ static void collate_worker(tsgnn_collate_pool* p) {
       const auto t0 = std::chrono::steady_clock::now();
       unsigned spins = 0;
       while (__atomic_load_n(j->ack, __ATOMIC_ACQUIRE) < j->ack_target) {
-        if ((++spins & 63u) == 0) {
-          std::this_thread::yield();
+        if (++spins > 64u) {                               // not there yet: leave the core to the enqueueing thread for a while
+          std::this_thread::sleep_for(std::chrono::microseconds(20));
           if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) { acked = false; break; }
         }
       }

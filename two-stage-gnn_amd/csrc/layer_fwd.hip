@@ -9,6 +9,7 @@
 #include "../../include/tsgnn.h"
 #include "rowgemm_body.h"
 #include "readout_body.h"
+#include "ingest_rider.h"
 
 namespace {
 
@@ -16,13 +17,15 @@ namespace {
 // slot batch-norm follows, so the readout is taken on v itself)
 template <bool RO>
 __global__ __launch_bounds__(256) void sage_layer_fwd_kernel(RowGemmArgs ga, SlotArgs sa, unsigned n_gemm, unsigned ro_gx, int F4,
-                                                             unsigned long long* __restrict__ packed) {
+                                                             unsigned long long* __restrict__ packed, unsigned n_main, PullRider pr) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (blockIdx.x < n_gemm) {
     rowgemm_body<4, false, true, 1, RO>(ga, smem, blockIdx.x);
-  } else {
+  } else if (blockIdx.x < n_main) {
     const unsigned r = blockIdx.x - n_gemm;
     readout_partial_body<32>(sa, ga.a, ga.lda, F4, packed, r % ro_gx, r / ro_gx, reinterpret_cast<unsigned long long*>(smem));
+  } else {
+    pull_rider_body(pr, blockIdx.x - n_main);             // passengers: the next mini-batch's staging buffer -> its mirror (ingest_rider.h)
   }
 }
 
@@ -53,12 +56,14 @@ int tsgnn_sage_layer_fwd_ro_f32(const int* ell, int ell_w, const int* tail_ptr, 
   const unsigned ro_gx = (unsigned)((nslots + 63) / 64);
   size_t lds = rowgemm_lds_bytes<4, false, true>();
   if (lds < 8 * 128 * sizeof(unsigned long long)) lds = 8 * 128 * sizeof(unsigned long long);
+  const unsigned n_main = n_gemm + ro_gx * (unsigned)B;
+  const PullRider pr = take_pull_rider();                  // (blocks = 0 unless tsgnn_ingest_arm_pull_rider armed one on this thread)
   if (packed_out) {
     TSGNN_KNAME("sage_layer_fwd_kernel<true>");
-    sage_layer_fwd_kernel<true><<<n_gemm + ro_gx * (unsigned)B, 256, lds, stream>>>(ga, sa, n_gemm, ro_gx, K / 4, packed);
+    sage_layer_fwd_kernel<true><<<n_main + pr.blocks, 256, lds, stream>>>(ga, sa, n_gemm, ro_gx, K / 4, packed, n_main, pr);
   } else {
     TSGNN_KNAME("sage_layer_fwd_kernel<false>");
-    sage_layer_fwd_kernel<false><<<n_gemm + ro_gx * (unsigned)B, 256, lds, stream>>>(ga, sa, n_gemm, ro_gx, K / 4, packed);
+    sage_layer_fwd_kernel<false><<<n_main + pr.blocks, 256, lds, stream>>>(ga, sa, n_gemm, ro_gx, K / 4, packed, n_main, pr);
   }
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;

@@ -5,10 +5,13 @@ The reference builds ``adj[B, Nmax, Nmax]`` per item in python and ships it to t
   host    native worker threads (``CollatePool``) run ``tsgnn_host_collate_compact`` (C, csrc/ingest.hip) for the batches AHEAD:
           the mini-batch of a CSR-resident dataset (``tu_data.TUDataset``) as a compact CSR batch in a pinned staging buffer
           (graph pointers, slot counts, row pointers, columns, node labels, graph labels: ~0.3 MB for 32 DD graphs).
-  pull    the first two launches of the step's OWN hipGraph read the staging buffer over PCIe and expand it on the device: row
-          maps, the fixed-width neighbour table, the one-hot feature rows of the TU "node-label" mode (train.py:227-231).  No copy
-          engine, no second stream: on this stack the copy-engine -> shader hand-over and the cross-stream events cost more than
-          the transfer (measured, scripts/ingest_profile.py).
+  pull    kernels of the step's OWN hipGraph read the staging buffer over PCIe (a flat copy into a device mirror) and expand it on
+          the device: row maps, the fixed-width neighbour table, the one-hot feature rows of the TU "node-label" mode
+          (train.py:227-231).  The copy of the NEXT batch rides as extra workgroups of the current step's first hidden-layer
+          product (csrc/ingest_rider.h), so its PCIe round trip is off the step's critical path.  No copy engine, no second
+          stream, no event per step: on this stack the copy-engine -> shader hand-over and cross-stream events cost more than
+          the transfer (measured, scripts/ingest_profile.py); the host learns that a staging buffer may be refilled from a
+          sequence word the expand launch echoes into pinned memory.
   step    a capacity-padded batch (``CapacityBatch``): the row count every kernel is launched with is the slot's capacity, the
           rows beyond the batch's own are padding that belongs to a dummy graph, so ONE hipGraph per slot replays every batch.
   overlap three slots: while batch k replays from slot k % 3, the workers fill the other slots' staging buffers.
@@ -181,6 +184,27 @@ class CapacityBatch:
         if not torch.cuda.is_current_stream_capturing():
             self._replayed = True
 
+    def _expand_args(self):
+        g = self.g
+        ell, _, (tail_ptr, tail_col) = g._ell
+        return (self.mirror, self.B, self.nmax, self.row_cap, self.edge_cap, ELL_W, self.tail_cap, g.row_graph, g.row_slot, ell, tail_ptr,
+                self.fin, self.x, self.x.stride(0), self.ack.data_ptr())
+
+    def expand(self):
+        """the expansion alone, of a batch that is already in the mirror (pulled as passengers of the previous step, or by pull_only)"""
+        nat.call("ingest_expand_ack_f32", *self._expand_args())
+        if not torch.cuda.is_current_stream_capturing():
+            self._replayed = True
+
+    def pull_only(self):
+        """the flat copy staging buffer -> mirror as a launch of its own (current stream)"""
+        nat.call("ingest_pull_f32", self.host.data_ptr(), self.mirror, self.B, self.nmax, self.row_cap, self.edge_cap, self.tail_cap)
+
+    def arm_pull_rider(self):
+        """the same copy as passengers of this thread's next layer-product launch (csrc/ingest_rider.h)"""
+        nat.call_nostream("ingest_arm_pull_rider", self.host.data_ptr(), self.mirror, self.B, self.nmax, self.row_cap, self.edge_cap,
+                          self.tail_cap)
+
     def mark_consumed(self, stream=None):
         """a replay of the captured step (whose first launches are this slot's pull) has been enqueued"""
         self._replayed = True
@@ -209,10 +233,16 @@ class CollatePool:
 
 class IngestPipeline:
     """Training loop in which every step consumes a NEW mini-batch drawn from ``ds``: native workers collate the batches ahead
-    into the slots' pinned staging buffers, the enqueueing thread replays the slot's hipGraph, whose first two launches pull the
-    staged batch over PCIe and expand it (``CapacityBatch.pull``)."""
+    into the slots' pinned staging buffers, the enqueueing thread replays the slot's hipGraph.
 
-    def __init__(self, model, trainer, ds, batch, nmax, device, schedule, depth=3, make_loss=None):
+    ride (default; env TSGNN_INGEST_RIDE=0 turns it off): the graph of position p expands the batch that is already in p's mirror
+    and, as passengers of its first hidden layer's product launch, pulls the NEXT position's staging buffer over PCIe
+    (``CapacityBatch.arm_pull_rider``, csrc/ingest_rider.h) — the ~10 us PCIe round trip of the pull is hidden inside the previous
+    step.  The first batch of a run is pulled by a launch of its own.  Without it (or with a custom ``make_loss``) the first two
+    launches of the slot's graph pull and expand its own batch (``CapacityBatch.pull``)."""
+
+    def __init__(self, model, trainer, ds, batch, nmax, device, schedule, depth=3, make_loss=None, ride=None):
+        import os
         from .data_parallel import GraphedStep
         self.ds, self.B, self.schedule = ds, int(batch), schedule
         sizes = ds.sizes
@@ -225,8 +255,11 @@ class IngestPipeline:
         self.compute = torch.cuda.Stream()
         self.slots = [CapacityBatch(batch, nmax, self.row_cap, self.edge_cap, ds.num_node_labels, device, ghost_slots=ghost)
                       for _ in range(depth)]
+        if ride is None:
+            ride = os.environ.get("TSGNN_INGEST_RIDE", "1") != "0"
+        self.ride = bool(ride) and make_loss is None and depth >= 2
         self.steps = []
-        if make_loss is None:
+        if make_loss is None and not self.ride:
             def make_loss(s):
                 def loss():
                     s.pull()                                  # first launches of the step: bring the staged batch in
@@ -234,27 +267,72 @@ class IngestPipeline:
                 return loss
         for s in self.slots:
             s.collate(ds, schedule[0])
-            self.steps.append(GraphedStep(trainer, make_loss(s), warmup=2, stream=self.compute))
+        if self.ride:
+            with torch.cuda.stream(self.compute):
+                for s in self.slots:
+                    s.pull_only()                             # every mirror holds a batch before the first expansion
 
-    def run(self, schedule=None, workers=2):
+            def make_loss_ride(s, nxt):
+                def loss():
+                    s.expand()                                # this position's batch: pulled by the previous step's passengers
+                    nxt.arm_pull_rider()                      # the next position's staging buffer rides in the first layer product
+                    out = model.loss(model(s.x, s.g)[1], s.label)
+                    nat.call("ingest_flush_pull_rider")       # (a model without such a launch: the pull as a launch of its own)
+                    return out
+                return loss
+        for p, s in enumerate(self.slots):
+            fn = make_loss_ride(s, self.slots[(p + 1) % depth]) if self.ride else make_loss(s)
+            self.steps.append(GraphedStep(trainer, fn, warmup=2, stream=self.compute))
+
+    def run(self, schedule=None, workers=2, ticks=None):
         """enqueue one step per entry of the schedule; returns after the last step is enqueued (caller synchronises).
-        workers: native collate threads running ahead (0: collate inline on the enqueueing thread)."""
+        workers: native collate threads running ahead (0: collate inline on the enqueueing thread).
+        ticks: a dict that receives the host seconds spent waiting for collates / replaying / submitting (measurement)."""
+        import time
         sched = self.schedule if schedule is None else schedule
         depth = len(self.slots)
         pool = self._get_pool(workers) if workers else None
+        T = ticks if ticks is not None else {}
+
+        def tick(name, t0):
+            t1 = time.perf_counter()
+            T[name] = T.get(name, 0.0) + (t1 - t0)
+            return t1
+
+        def stage(k):                                         # batch k is in its slot's staging buffer when this returns
+            s = self.slots[k % depth]
+            if pool is not None:
+                s.collate_wait()
+            else:
+                s.collate(self.ds, sched[k])
+
+        if self.ride:
+            # the last replay of the previous run carried passengers for a batch that never came: they re-pull (and re-echo) whatever
+            # its staging buffer holds.  Let them finish before this run's batches go into the staging buffers, or an echo of
+            # theirs would be taken for the pull that feeds this run's step.
+            self.compute.synchronize()
         if pool is not None:
             for k in range(min(depth, len(sched))):
                 self.slots[k].collate_async(pool, self.ds, sched[k])
+        if self.ride and len(sched):
+            stage(0)
+            with torch.cuda.stream(self.compute):
+                self.slots[0].pull_only()                     # nobody rode for the first batch of the run
         for k, ids in enumerate(sched):
             s, gs = self.slots[k % depth], self.steps[k % depth]
-            if pool is not None:
-                s.collate_wait()                              # this batch is in the slot's staging buffer
+            t = time.perf_counter()
+            if self.ride:
+                if k + 1 < len(sched):
+                    stage(k + 1)                              # this step's passengers pull batch k + 1
             else:
-                s.collate(self.ds, ids)
-            gs.step()                                         # pull + expand + forward + backward + optimiser, one replay
+                stage(k)
+            t = tick("collate/wait", t)
+            gs.step()                                         # [pull +] expand + forward + backward + optimiser, one replay
+            t = tick("replay", t)
             s.mark_consumed(self.compute)
-            if pool is not None and k + depth < len(sched):   # the slot's next batch (the worker waits for `consumed` first)
+            if pool is not None and k + depth < len(sched):   # the slot's next batch (the worker waits for the echo first)
                 s.collate_async(pool, self.ds, sched[k + depth])
+            tick("submit", t)
         return len(sched)
 
     def _get_pool(self, workers):
