@@ -17,6 +17,7 @@
 // per SIMD nothing hides LDS latency, so what counts is instructions and LDS requests per flop (a first version on scalar FMAs
 // spent 14 us in one 16 x 192 x 64 tile product; scripts/trace_dense_stack.hip).
 #include "common.h"
+#include <utility>
 #include "../../include/tsgnn.h"
 
 namespace {
@@ -101,6 +102,20 @@ __device__ __forceinline__ void grid_finish(unsigned* words, int k, unsigned nbl
   }
 }
 
+// x / d for 0 <= x < 2^22, 0 < d <= 4096 without the ~35-instruction integer division sequence: a float reciprocal and one
+// correction step (exact).  The fills compute a (row, column) pair per 16-byte element; with `idx / c4n` they were bound by the
+// address arithmetic, not by memory (3-4 us a fill at one wave per SIMD: scripts/trace_dense_stack.hip).
+struct FastDiv {
+  float inv; int d;
+  __device__ __forceinline__ explicit FastDiv(int d_) : inv(1.0f / (float)d_), d(d_) {}
+  __device__ __forceinline__ int operator()(int x) const {
+    int q = (int)(((float)x + 0.5f) * inv);
+    const int r = x - q * d;
+    q += (r >= d) - (r < 0);
+    return q;
+  }
+};
+
 // rows x cols floats from global (row stride ldg) into LDS through `f(value, row, col)`; element (r, c) lands at
 // lds[r * lds_ld + c], or at lds[c * lds_ld + r] when TRANSPOSE.  Loads are issued eight 16-byte requests deep before anything is
 // stored (a plain `lds[i] = g[i]` loop is one dependent L2 round trip per iteration).  cols % 4 == 0, ldg % 4 == 0, g 16-byte aligned.
@@ -108,13 +123,14 @@ template <bool TRANSPOSE, typename F>
 __device__ __forceinline__ void fill_lds(float* lds, int lds_ld, const float* __restrict__ g, int64_t ldg, int rows, int cols, F f) {
   const int tid = threadIdx.x;
   const int c4n = cols >> 2, total = rows * c4n;
+  const FastDiv by_c4n(c4n);
   for (int base = tid; base < total; base += 8 * 256) {
     float4 v[8];
     int rr[8], cc[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int idx = base + u * 256;
-      rr[u] = idx / c4n; cc[u] = 4 * (idx - rr[u] * c4n);
+      rr[u] = by_c4n(idx); cc[u] = 4 * (idx - rr[u] * c4n);
       v[u] = idx < total ? *reinterpret_cast<const float4*>(g + (int64_t)rr[u] * ldg + cc[u]) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
@@ -132,6 +148,46 @@ __device__ __forceinline__ void fill_lds(float* lds, int lds_ld, const float* __
   }
 }
 struct Ident { __device__ __forceinline__ float operator()(float v, int, int) const { return v; } };
+
+// fill_lds in two halves: pf_load requests a matrix (rows x cols floats, <= NV * 1024) into registers, pf_store writes it to LDS
+// later.  A phase's operand that does not depend on the phases before it (the weights, forward data read by the backward) is
+// requested BEFORE them — its L2 round trip runs under their MFMA chains and barriers instead of after them; the LDS region it
+// lands in is free by the time it is stored.  Requests are unconditional from clamped addresses.
+template <int NV>
+struct Pf { float4 v[NV]; };
+// (index_sequence instead of a loop: every register of the set is named at compile time; a loop the compiler leaves rolled would
+// put the whole set into scratch)
+template <typename F, int... I>
+__device__ __forceinline__ void pf_each(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int NV>
+__device__ __forceinline__ void pf_load(Pf<NV>& p, const float* __restrict__ g, int64_t ldg, int rows, int cols) {
+  const int c4n = cols >> 2, total = rows * c4n;
+  const FastDiv by_c4n(c4n);
+  pf_each([&](auto u) {
+    const int idx = min(u.value * 256 + (int)threadIdx.x, total - 1);
+    const int rr = by_c4n(idx), cc = 4 * (idx - rr * c4n);
+    p.v[u.value] = *reinterpret_cast<const float4*>(g + (int64_t)rr * ldg + cc);
+  }, std::make_integer_sequence<int, NV>{});
+}
+template <int NV, bool TRANSPOSE>
+__device__ __forceinline__ void pf_store(float* lds, int lds_ld, const Pf<NV>& p, int rows, int cols) {
+  const int c4n = cols >> 2, total = rows * c4n;
+  const FastDiv by_c4n(c4n);
+  pf_each([&](auto u) {
+    const int idx = u.value * 256 + (int)threadIdx.x;
+    if (idx < total) {
+      const int rr = by_c4n(idx), cc = 4 * (idx - rr * c4n);
+      const float4 v = p.v[u.value];
+      if (TRANSPOSE) {
+        lds[(cc + 0) * lds_ld + rr] = v.x; lds[(cc + 1) * lds_ld + rr] = v.y;
+        lds[(cc + 2) * lds_ld + rr] = v.z; lds[(cc + 3) * lds_ld + rr] = v.w;
+      } else {
+        *reinterpret_cast<float4*>(lds + rr * lds_ld + cc) = v;
+      }
+    }
+  }, std::make_integer_sequence<int, NV>{});
+}
+constexpr int DS_PFW = 15;                // float4 per thread of a prefetched matrix of up to DS_BIG floats
 __device__ __forceinline__ void zero_lds(float* lds, int n) {
   for (int i = threadIdx.x; i < n; i += 256) lds[i] = 0.f;
 }
@@ -224,7 +280,7 @@ constexpr int DS_LDA = 68;                // row stride of the A tile [TR][K <= 
 constexpr int DS_PADB = 16;               // B-operand matrices have row stride (columns padded to 64) + 16
 
 // ------------------------------------------------------------------------------------------------------------ forward
-__global__ __launch_bounds__(256) void dense_stack_fwd_kernel(DsArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void dense_stack_fwd_kernel(DsArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* big = smem;                        // xin [K][finP + 16]  then  W [fin][nP + 16]
   float* At = big + DS_BIG;                 // [TR][DS_LDA]
@@ -243,9 +299,13 @@ __global__ __launch_bounds__(256) void dense_stack_fwd_kernel(DsArgs a) {
   const bool rok = r < nrows;
   int bar = 0;
   TR(0);
+  Pf<DS_PFW> wpf;                                            // the layer's weights, on their way while the phases before their product run
+  pf_load(wpf, S.layer[0].w, S.layer[0].ldw, S.layer[0].fin, S.layer[0].n);
   zero_lds(At, DS_TR * DS_LDA);
   __syncthreads();
   fill_lds<false>(At, DS_LDA, a.adj + ((int64_t)b * K + r0) * K, K, nrows, K, Ident());
+  float vprev[3][4];                                         // tiles == 1: this thread's entries of the layer below's v
+  zero_acc(vprev);
   for (int l = 0; l < S.L; ++l) {
     const DsLayer& Ly = S.layer[l];
     const int fin = Ly.fin, N = Ly.n, finP = pad64(fin), NP = pad64(N), Jf = finP >> 6, Jn = NP >> 6;
@@ -256,6 +316,23 @@ __global__ __launch_bounds__(256) void dense_stack_fwd_kernel(DsArgs a) {
     __syncthreads();
     if (l == 0) {
       fill_lds<false>(big, ldx, a.x + (int64_t)b * K * a.ldx, a.ldx, K, fin, Ident());
+    } else if (tiles == 1) {
+      // the graph is this tile: its rows of v are still in this thread's registers (no trip through memory)
+      const DsLayer& Lp = S.layer[l - 1];
+      float* outp = S.out + row * S.ldo + Lp.off;
+      if (rok) {
+        const float m = mu[r0 + r], q_ = rs[r0 + r];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const int c = 4 * cg + 64 * j;
+          if (j < Jf && c < fin) {
+            const float4 y = make_float4((fmaxf(vprev[j][0], 0.f) - m) * q_, (fmaxf(vprev[j][1], 0.f) - m) * q_,
+                                         (fmaxf(vprev[j][2], 0.f) - m) * q_, (fmaxf(vprev[j][3], 0.f) - m) * q_);
+            *reinterpret_cast<float4*>(big + (r0 + r) * ldx + c) = y;
+            *reinterpret_cast<float4*>(outp + c) = y;
+          }
+        }
+      }
     } else {
       const DsLayer& Lp = S.layer[l - 1];
       float* outp = S.out + (int64_t)b * K * S.ldo + Lp.off;
@@ -281,10 +358,11 @@ __global__ __launch_bounds__(256) void dense_stack_fwd_kernel(DsArgs a) {
       }
     }
     if (l == 0) TR(2);
-    // (3) W -> LDS, u = agg . W + bias, row L2 normalise
+    // (3) W (requested a layer ago) -> LDS, u = agg . W + bias, row L2 normalise
     if (NP != N) zero_lds(big, fin * ldw);
     __syncthreads();
-    fill_lds<false>(big, ldw, Ly.w, Ly.ldw, fin, N, Ident());
+    pf_store<DS_PFW, false>(big, ldw, wpf, fin, N);
+    if (!last) pf_load(wpf, S.layer[l + 1].w, S.layer[l + 1].ldw, S.layer[l + 1].fin, S.layer[l + 1].n);   // under this product and the barrier
     __syncthreads();
     if (l == 0) TR(3);
     tile_mfma(ut, NP, aggt, lda, 1, big, ldw, fin, NP >> 4);
@@ -306,8 +384,9 @@ __global__ __launch_bounds__(256) void dense_stack_fwd_kernel(DsArgs a) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const int c = 4 * cg + 64 * j;
+      const float4 v = make_float4(u[j][0] * ri, u[j][1] * ri, u[j][2] * ri, u[j][3] * ri);
+      vprev[j][0] = v.x; vprev[j][1] = v.y; vprev[j][2] = v.z; vprev[j][3] = v.w;
       if (j < Jn && c < N) {
-        const float4 v = make_float4(u[j][0] * ri, u[j][1] * ri, u[j][2] * ri, u[j][3] * ri);
         if (rok) {
           if (last) *reinterpret_cast<float4*>(S.out + row * S.ldo + Ly.off + c) = v;
           else *reinterpret_cast<float4*>(Ly.v + row * N + c) = v;
@@ -349,7 +428,7 @@ __global__ __launch_bounds__(256) void dense_stack_fwd_kernel(DsArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------ backward
-__global__ __launch_bounds__(256) void dense_stack_bwd_kernel(DsArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void dense_stack_bwd_kernel(DsArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* big = smem;                        // W^T [n][finP + 16] / xin^T [fin][80] / dagg of the graph [K][finP + 16]
   float* At = big + DS_BIG;                 // [K][TR] columns of A
@@ -575,8 +654,9 @@ __global__ __launch_bounds__(256) void dense_stack_bwd_kernel(DsArgs a) {
   // ---- the stacks' input gradients add up (two stacks: both read the same x and adjacency)
   if (a.dx) {
     const int f0 = a.fin0;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + tid; e < (int64_t)R * f0; e += (int64_t)nblocks * 256) {
-      const int64_t rr = e / f0; const int c = (int)(e - rr * f0);
+    const FastDiv by_f0(f0);                               // (R * f0 < 2^22: ds_check)
+    for (int e = (int)blockIdx.x * 256 + tid; e < R * f0; e += (int)nblocks * 256) {
+      const int64_t rr = by_f0(e); const int c = (int)(e - rr * f0);
       float v = a.dxn[rr * a.finmax + c];
       if (a.nstack == 2) v += a.dxn[(int64_t)R * a.finmax + rr * a.finmax + c];
       a.dx[rr * a.lddx + c] = v;
