@@ -3,6 +3,7 @@
 // (add -DTSGNN_TRACE_WPB=8 for the gather variant: its row panels are 512-thread blocks, waves 4-7 = the second K group)
 #include "../two-stage-gnn_amd/csrc/rowgemm.hip"
 #include "trace_util.h"
+thread_local char tsgnn_kname_[160] = "";
 #include <cstdio>
 #include <vector>
 #include <algorithm>
