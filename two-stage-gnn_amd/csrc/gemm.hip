@@ -364,8 +364,14 @@ __global__ __launch_bounds__(256) void wgrad_blocks_kernel(WgradBlocks w) {
   g.K_in = min(128, w.g.K_in - 128 * kb);
   g.N = min(128, w.g.N - 128 * nb);
   g.slabs = w.g.slabs + (int64_t)set * w.set_stride;
-  if (g.N <= 32) tn_rows_body<4, 1, NY>(g, tn_smem, blockIdx.x, by, gridDim.x);     // a narrow last column block (the 2H score columns)
-  else tn_rows_body<4, 4, NY>(g, tn_smem, blockIdx.x, by, gridDim.x);
+  // (row tiles of 32: a 92-row block — the GAT input projection — runs three of them, not four)
+  if (g.N <= 32) {                                                                   // a narrow last column block (the 2H score columns)
+    if (g.K_in <= 96) tn_rows_body<3, 1, NY>(g, tn_smem, blockIdx.x, by, gridDim.x);
+    else tn_rows_body<4, 1, NY>(g, tn_smem, blockIdx.x, by, gridDim.x);
+  } else {
+    if (g.K_in <= 96) tn_rows_body<3, 4, NY>(g, tn_smem, blockIdx.x, by, gridDim.x);
+    else tn_rows_body<4, 4, NY>(g, tn_smem, blockIdx.x, by, gridDim.x);
+  }
 }
 struct WgradBlocksReduce {
   const float* slabs; int nslab; int64_t set_stride;
