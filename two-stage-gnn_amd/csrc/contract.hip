@@ -42,6 +42,52 @@ __device__ __forceinline__ void ct_load(float* dst, int ld, const float* __restr
   }
 }
 
+// All operands of a kernel in ONE round trip: the operands are taken as one sequence of 16-byte elements, every thread requests
+// up to sixteen of them before anything is stored (ct_load per operand: one dependent round trip each — three forward, six
+// backward — with a 4-byte request and an integer division per float).  cols % 4 == 0, sources 16-byte aligned (ct_vec_ok).
+struct CtOp { const float* src; float* dst; int ld, cols, n4; };
+template <int NOPS>
+__device__ __forceinline__ void ct_load_many(const CtOp (&op)[NOPS]) {
+  int start[NOPS + 1];
+  float inv[NOPS];
+  start[0] = 0;
+#pragma unroll
+  for (int i = 0; i < NOPS; ++i) { start[i + 1] = start[i] + op[i].n4; inv[i] = 1.0f / (float)op[i].cols; }
+  const int total = start[NOPS];
+  for (int base = threadIdx.x; base < total; base += 16 * CT_THREADS) {
+    float4 v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int e = min(base + u * CT_THREADS, total - 1);
+      const float* src = op[0].src;
+      int l = e;
+#pragma unroll
+      for (int i = 1; i < NOPS; ++i)
+        if (e >= start[i]) { src = op[i].src; l = e - start[i]; }
+      v[u] = reinterpret_cast<const float4*>(src)[l];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int e = base + u * CT_THREADS;
+      if (e < total) {
+        float* dst = op[0].dst;
+        int l = e, ld = op[0].ld, cols = op[0].cols;
+        float iv = inv[0];
+#pragma unroll
+        for (int i = 1; i < NOPS; ++i)
+          if (e >= start[i]) { dst = op[i].dst; l = e - start[i]; ld = op[i].ld; cols = op[i].cols; iv = inv[i]; }
+        const int x = 4 * l;
+        int r = (int)(((float)x + 0.5f) * iv);              // x / cols by reciprocal + one correction (exact for x < 2^22)
+        int c = x - r * cols;
+        if (c < 0) { --r; c += cols; } else if (c >= cols) { ++r; c -= cols; }
+        float* d = dst + r * ld + c;                        // (rows are padded by one float: four 4-byte stores)
+        d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+      }
+    }
+  }
+}
+__device__ __forceinline__ bool ct_vec_ok(const void* p, int cols) { return (cols & 3) == 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 __global__ __launch_bounds__(CT_THREADS) void contract_dense_fwd_kernel(const float* __restrict__ s, const float* __restrict__ z,
                                                                         const float* __restrict__ adj, int N, int K, int F,
                                                                         float* __restrict__ xo, float* __restrict__ ao,
@@ -53,9 +99,17 @@ __global__ __launch_bounds__(CT_THREADS) void contract_dense_fwd_kernel(const fl
   float* A = Z + N * d.ldZ;
   float* T = A + N * d.ldA;
   const int b = blockIdx.x;
-  ct_load(S, d.ldS, s + (int64_t)b * N * K, N, K);
-  ct_load(Z, d.ldZ, z + (int64_t)b * N * F, N, F);
-  ct_load(A, d.ldA, adj + (int64_t)b * N * N, N, N);
+  const float* sb = s + (int64_t)b * N * K;
+  const float* zb = z + (int64_t)b * N * F;
+  const float* ab = adj + (int64_t)b * N * N;
+  if (ct_vec_ok(sb, K) && ct_vec_ok(zb, F) && ct_vec_ok(ab, N)) {
+    const CtOp ops[3] = {{sb, S, d.ldS, K, N * K / 4}, {zb, Z, d.ldZ, F, N * F / 4}, {ab, A, d.ldA, N, N * N / 4}};
+    ct_load_many<3>(ops);
+  } else {
+    ct_load(S, d.ldS, sb, N, K);
+    ct_load(Z, d.ldZ, zb, N, F);
+    ct_load(A, d.ldA, ab, N, N);
+  }
   __syncthreads();
   // X' = S^T Z   [K, F]
   for (int i = threadIdx.x; i < K * F; i += CT_THREADS) {
@@ -97,13 +151,29 @@ __global__ __launch_bounds__(CT_THREADS) void contract_dense_bwd_kernel(const fl
   float* DA = DX + K * d.ldZ;          // [K][K+1]
   float* DT = DA + K * d.ldS;          // [K][N+1]
   const int b = blockIdx.x;
-  ct_load(S, d.ldS, s + (int64_t)b * N * K, N, K);
-  ct_load(DX, d.ldZ, dxo + (int64_t)b * K * F, K, F);
-  ct_load(DA, d.ldS, dao + (int64_t)b * K * K, K, K);
-  if (ds) {
-    ct_load(Z, d.ldZ, z + (int64_t)b * N * F, N, F);
-    ct_load(A, d.ldA, adj + (int64_t)b * N * N, N, N);
-    ct_load(T, d.ldT, t + (int64_t)b * K * N, K, N);
+  const float* sb = s + (int64_t)b * N * K;
+  const float* dxb = dxo + (int64_t)b * K * F;
+  const float* dab = dao + (int64_t)b * K * K;
+  const float* zb = ds ? z + (int64_t)b * N * F : nullptr;
+  const float* ab = ds ? adj + (int64_t)b * N * N : nullptr;
+  const float* tb = ds ? t + (int64_t)b * K * N : nullptr;
+  const bool vec = ct_vec_ok(sb, K) && ct_vec_ok(dxb, F) && ct_vec_ok(dab, K) && ct_vec_ok(zb, F) && ct_vec_ok(ab, N) && ct_vec_ok(tb, N);
+  if (vec && ds) {
+    const CtOp ops[6] = {{sb, S, d.ldS, K, N * K / 4}, {dxb, DX, d.ldZ, F, K * F / 4}, {dab, DA, d.ldS, K, K * K / 4},
+                         {zb, Z, d.ldZ, F, N * F / 4}, {ab, A, d.ldA, N, N * N / 4}, {tb, T, d.ldT, N, K * N / 4}};
+    ct_load_many<6>(ops);
+  } else if (vec) {
+    const CtOp ops[3] = {{sb, S, d.ldS, K, N * K / 4}, {dxb, DX, d.ldZ, F, K * F / 4}, {dab, DA, d.ldS, K, K * K / 4}};
+    ct_load_many<3>(ops);
+  } else {
+    ct_load(S, d.ldS, sb, N, K);
+    ct_load(DX, d.ldZ, dxb, K, F);
+    ct_load(DA, d.ldS, dab, K, K);
+    if (ds) {
+      ct_load(Z, d.ldZ, zb, N, F);
+      ct_load(A, d.ldA, ab, N, N);
+      ct_load(T, d.ldT, tb, K, N);
+    }
   }
   __syncthreads();
   // dT = dA' S^T   [K, N]
