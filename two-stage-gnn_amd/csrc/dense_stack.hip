@@ -263,6 +263,8 @@ __device__ __forceinline__ void read_tile(float (&acc)[3][4], const float* tile,
   }
 }
 // per-slot totals of the per-row partial sums of all graphs (same order in every workgroup: the same bits)
+// (fetching the B x K entries with all 256 threads into LDS first and summing from there was slower: 5.4 k cycles against 3.7 k
+// for the 64 threads that walk their slot's graphs — the relaxed atomic loads are L2 hits of ~230 cycles each)
 __device__ __forceinline__ void slot_totals(const float* st, int B, int K, int n, float& t1, float& t2) {
   t1 = 0.f; t2 = 0.f;
   int bb = 0;
@@ -365,18 +367,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     if (!last) pf_load(wpf, S.layer[l + 1].w, S.layer[l + 1].ldw, S.layer[l + 1].fin, S.layer[l + 1].n);   // under this product and the barrier
     __syncthreads();
     if (l == 0) TR(3);
+    // the bias, requested before the product from clamped addresses (per-element `bias ? bias[c] : 0` loads were waited for one
+    // by one); no bias: the same requests go to the weights and are discarded
+    float4 bias4[3];
+    {
+      const float* bsrc = Ly.bias ? Ly.bias : Ly.w;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int c = 4 * cg + 64 * j;
+        bias4[j] = *reinterpret_cast<const float4*>(bsrc + ((j < Jn && c < N) ? c : 0));
+        if (!Ly.bias) bias4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
     tile_mfma(ut, NP, aggt, lda, 1, big, ldw, fin, NP >> 4);
     __syncthreads();
     float u[3][4];
     read_tile(u, ut, NP, r, cg, Jn);
     float ss = 0.f;
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
+    for (int j = 0; j < 3; ++j) {
+      const float bq[4] = {bias4[j].x, bias4[j].y, bias4[j].z, bias4[j].w};
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int c = 4 * cg + 64 * j + q;
-        if (j < Jn && c < N) { u[j][q] += Ly.bias ? Ly.bias[c] : 0.f; ss = fmaf(u[j][q], u[j][q], ss); } else u[j][q] = 0.f;
+        if (j < Jn && c < N) { u[j][q] += bq[q]; ss = fmaf(u[j][q], u[j][q], ss); } else u[j][q] = 0.f;
       }
+    }
     if (l == 0) TR(4);
     ss = row16_sum(ss);                                    // the 16 lanes of a row are one DPP row
     const float ri = fminf(__builtin_amdgcn_rsqf(ss), 1.0f / DS_NORM_EPS);
@@ -458,24 +474,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const bool last = l == S.L - 1;
     // ---- P1: dy = dout block (+ the gradient from the layer above), then back through BN / ReLU / L2 normalise -> du
     float dy[3][4], vv[3][4];
+    {
+      // every operand of the phase requested at once from clamped addresses, masked afterwards (loads inside `if (rok && ...)`
+      // were waited for one by one: nine dependent L2 round trips per layer)
+      const float* vsrc = last ? S.out + row * S.ldo + Ly.off : Ly.v + row * N;
+      const float* esrc = last ? vsrc : dxnS + row * a.finmax;
+      float4 d4[3], e4[3], v4[3];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int c = 4 * cg + 64 * j;
-      float4 d = make_float4(0.f, 0.f, 0.f, 0.f), v = d;
-      if (rok && j < Jn && c < N) {
-        d = *reinterpret_cast<const float4*>(S.dout + row * S.lddo + Ly.off + c);
-        if (!last) {
-          const float4 e = *reinterpret_cast<const float4*>(dxnS + row * a.finmax + c);
-          d.x += e.x; d.y += e.y; d.z += e.z; d.w += e.w;
-        }
-        v = last ? *reinterpret_cast<const float4*>(S.out + row * S.ldo + Ly.off + c) : *reinterpret_cast<const float4*>(Ly.v + row * N + c);
+      for (int j = 0; j < 3; ++j) {
+        const int c = 4 * cg + 64 * j;
+        const int cc = (j < Jn && c < N) ? c : 0;
+        d4[j] = *reinterpret_cast<const float4*>(S.dout + row * S.lddo + Ly.off + cc);
+        e4[j] = *reinterpret_cast<const float4*>(esrc + cc);
+        v4[j] = *reinterpret_cast<const float4*>(vsrc + cc);
       }
-      dy[j][0] = d.x; dy[j][1] = d.y; dy[j][2] = d.z; dy[j][3] = d.w;
-      vv[j][0] = v.x; vv[j][1] = v.y; vv[j][2] = v.z; vv[j][3] = v.w;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int c = 4 * cg + 64 * j;
+        const bool ok = rok && j < Jn && c < N;
+        float4 d = d4[j];
+        if (!last) { d.x += e4[j].x; d.y += e4[j].y; d.z += e4[j].z; d.w += e4[j].w; }
+        dy[j][0] = ok ? d.x : 0.f; dy[j][1] = ok ? d.y : 0.f; dy[j][2] = ok ? d.z : 0.f; dy[j][3] = ok ? d.w : 0.f;
+        vv[j][0] = ok ? v4[j].x : 0.f; vv[j][1] = ok ? v4[j].y : 0.f; vv[j][2] = ok ? v4[j].z : 0.f; vv[j][3] = ok ? v4[j].w : 0.f;
+      }
     }
     float dv[3][4];
     if (!last) {
-      const float mean = rok ? Ly.mean[r0 + r] : 0.f, rstd = rok ? Ly.rstd[r0 + r] : 1.f;
+      const int rs_ = r0 + min(r, nrows - 1);                // (clamped: unconditional requests)
+      const float mean_l = Ly.mean[rs_], rstd_l = Ly.rstd[rs_];
+      const float mean = rok ? mean_l : 0.f, rstd = rok ? rstd_l : 1.f;
       float p1 = 0.f, p2 = 0.f;
 #pragma unroll
       for (int j = 0; j < 3; ++j)
@@ -517,7 +544,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
       for (int q = 0; q < 4; ++q) dot = fmaf(vv[j][q], dv[j][q], dot);
     dot = row16_sum(dot);
-    const float ri = rok ? Ly.rinv[row] : 0.f;
+    const float ri_l = Ly.rinv[row];                       // (row is clamped)
+    const float ri = rok ? ri_l : 0.f;
     if (ri >= 0.999e12f) dot = 0.f;                        // clamped norm: F.normalize passes no norm gradient
     __syncthreads();                                       // (the layer above's readers of dut / aggt / big are done)
 #pragma unroll
