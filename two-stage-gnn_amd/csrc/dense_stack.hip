@@ -23,6 +23,16 @@
 namespace {
 
 constexpr int DS_TR = 16;                 // rows per tile
+#ifndef TSGNN_DS_THREADS
+#define TSGNN_DS_THREADS 512
+#endif
+// Threads of a workgroup.  The first 256 ("main": thread (r, cg) = row r of the tile, columns 4 cg + 64 j + q) run the epilogues
+// and own the register tiles; with 512, waves 4-7 are HELPERS that take part in what parallelises freely — the fills, the zeroing,
+// the tile products (column groups dealt over eight waves), the dW tiles, the final sums — so that two waves per SIMD interleave
+// where one wave per SIMD was bound by instruction issue and LDS round trips (scripts/trace_dense_stack.hip).
+constexpr int DS_NT = TSGNN_DS_THREADS;
+constexpr int DS_NW = DS_NT / 64;
+static_assert(DS_NT == 256 || DS_NT == 512, "main threads are the first 256");
 constexpr int DS_MAXL = 4;
 constexpr int DS_BIG = 15360;             // floats of the big LDS region: [K][finP + 16], [fin][nP + 16], [n][finP + 16], [fin][80] (P: padded to 64)
 constexpr float DS_NORM_EPS = 1e-12f;
@@ -124,18 +134,18 @@ __device__ __forceinline__ void fill_lds(float* lds, int lds_ld, const float* __
   const int tid = threadIdx.x;
   const int c4n = cols >> 2, total = rows * c4n;
   const FastDiv by_c4n(c4n);
-  for (int base = tid; base < total; base += 8 * 256) {
+  for (int base = tid; base < total; base += 8 * DS_NT) {
     float4 v[8];
     int rr[8], cc[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int idx = base + u * 256;
+      const int idx = base + u * DS_NT;
       rr[u] = by_c4n(idx); cc[u] = 4 * (idx - rr[u] * c4n);
       v[u] = idx < total ? *reinterpret_cast<const float4*>(g + (int64_t)rr[u] * ldg + cc[u]) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      if (base + u * 256 < total) {
+      if (base + u * DS_NT < total) {
         const float o0 = f(v[u].x, rr[u], cc[u]), o1 = f(v[u].y, rr[u], cc[u] + 1), o2 = f(v[u].z, rr[u], cc[u] + 2), o3 = f(v[u].w, rr[u], cc[u] + 3);
         if (TRANSPOSE) {
           lds[(cc[u] + 0) * lds_ld + rr[u]] = o0; lds[(cc[u] + 1) * lds_ld + rr[u]] = o1;
@@ -164,7 +174,7 @@ __device__ __forceinline__ void pf_load(Pf<NV>& p, const float* __restrict__ g, 
   const int c4n = cols >> 2, total = rows * c4n;
   const FastDiv by_c4n(c4n);
   pf_each([&](auto u) {
-    const int idx = min(u.value * 256 + (int)threadIdx.x, total - 1);
+    const int idx = min(u.value * DS_NT + (int)threadIdx.x, total - 1);
     const int rr = by_c4n(idx), cc = 4 * (idx - rr * c4n);
     p.v[u.value] = *reinterpret_cast<const float4*>(g + (int64_t)rr * ldg + cc);
   }, std::make_integer_sequence<int, NV>{});
@@ -174,7 +184,7 @@ __device__ __forceinline__ void pf_store(float* lds, int lds_ld, const Pf<NV>& p
   const int c4n = cols >> 2, total = rows * c4n;
   const FastDiv by_c4n(c4n);
   pf_each([&](auto u) {
-    const int idx = u.value * 256 + (int)threadIdx.x;
+    const int idx = u.value * DS_NT + (int)threadIdx.x;
     if (idx < total) {
       const int rr = by_c4n(idx), cc = 4 * (idx - rr * c4n);
       const float4 v = p.v[u.value];
@@ -187,9 +197,9 @@ __device__ __forceinline__ void pf_store(float* lds, int lds_ld, const Pf<NV>& p
     }
   }, std::make_integer_sequence<int, NV>{});
 }
-constexpr int DS_PFW = 15;                // float4 per thread of a prefetched matrix of up to DS_BIG floats
+constexpr int DS_PFW = (15360 / 4 + DS_NT - 1) / DS_NT;   // float4 per thread of a prefetched matrix of up to DS_BIG floats
 __device__ __forceinline__ void zero_lds(float* lds, int n) {
-  for (int i = threadIdx.x; i < n; i += 256) lds[i] = 0.f;
+  for (int i = threadIdx.x; i < n; i += DS_NT) lds[i] = 0.f;
 }
 __device__ __forceinline__ int pad64(int n) { return (n + 63) & ~63; }
 
@@ -200,12 +210,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // Wave w takes the 16-column groups w, w + 4, ...; lane l supplies A(l % 16, k0 + l / 16) and Bm(k0 + l / 16, 16 g + l % 16) per
 // step of four k and holds C(4 (l / 16) + v, 16 g + l % 16) in accumulator register v.  Sixteen steps' operands are requested
 // before their MFMA chain issues.  depth % 4 == 0; ldb % 32 == 16 keeps the four k-rows of a B request on disjoint bank halves.
-// All 256 threads must call it (barrier-free inside; the caller synchronises before and after).
+// All threads of the workgroup must call it (barrier-free inside; the caller synchronises before and after).
 __device__ __forceinline__ void tile_mfma(float* c, int ldc, const float* a, int ars, int acs, const float* bm, int ldb, int depth, int ng) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int i = lane & 15, kq = lane >> 4;
   const int steps = depth >> 2;
-  for (int g = w; g < ng; g += 4) {
+  for (int g = w; g < ng; g += DS_NW) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if ((steps & 15) == 0) {
       // whole rounds of sixteen steps (depth 64, 192: every product of the DD levels with 64 nodes): reads without predicates in
@@ -282,7 +292,7 @@ constexpr int DS_LDA = 68;                // row stride of the A tile [TR][K <= 
 constexpr int DS_PADB = 16;               // B-operand matrices have row stride (columns padded to 64) + 16
 
 // ------------------------------------------------------------------------------------------------------------ forward
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void dense_stack_fwd_kernel(DsArgs a) {
+__global__ __launch_bounds__(DS_NT) __attribute__((amdgpu_waves_per_eu(DS_NW / 4, DS_NW / 4))) void dense_stack_fwd_kernel(DsArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* big = smem;                        // xin [K][finP + 16]  then  W [fin][nP + 16]
   float* At = big + DS_BIG;                 // [TR][DS_LDA]
@@ -290,7 +300,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   float* ut = aggt + DS_TR * 196;           // [TR][nP]
   float* mu = ut + DS_TR * 148;             // [K]
   float* rs = mu + 64;                      // [K]
-  const int tid = threadIdx.x, r = tid >> 4, cg = tid & 15;
+  const int tid = threadIdx.x, r = (tid & 255) >> 4, cg = tid & 15;
+  const bool main_t = tid < 256;                             // (helper waves shadow a main thread's addresses and store nothing)
   const int K = a.K, B = a.B, R = B * K;
   const int tiles = (K + DS_TR - 1) / DS_TR;
   const unsigned nblocks = gridDim.x;
@@ -298,7 +309,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const DsStack& S = a.st[s];
   const int r0 = t * DS_TR, nrows = min(DS_TR, K - r0);
   const int64_t row = (int64_t)b * K + r0 + min(r, nrows - 1);     // (threads of missing rows shadow the tile's last row: no stores)
-  const bool rok = r < nrows;
+  const bool rok = main_t && r < nrows;
   int bar = 0;
   TR(0);
   Pf<DS_PFW> wpf;                                            // the layer's weights, on their way while the phases before their product run
@@ -444,7 +455,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 }
 
 // ------------------------------------------------------------------------------------------------------------ backward
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void dense_stack_bwd_kernel(DsArgs a) {
+__global__ __launch_bounds__(DS_NT) __attribute__((amdgpu_waves_per_eu(DS_NW / 4, DS_NW / 4))) void dense_stack_bwd_kernel(DsArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* big = smem;                        // W^T [n][finP + 16] / xin^T [fin][80] / dagg of the graph [K][finP + 16]
   float* At = big + DS_BIG;                 // [K][TR] columns of A
@@ -452,7 +463,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   float* dut = aggt + DS_TR * 196;          // [TR][nP + 20]  du tile ; later the dA tile [TR][64]
   float* m1s = dut + DS_TR * 148;           // [K]
   float* m2s = m1s + 64;                    // [K]
-  const int tid = threadIdx.x, r = tid >> 4, cg = tid & 15;
+  const int tid = threadIdx.x, r = (tid & 255) >> 4, cg = tid & 15;
+  const bool main_t = tid < 256;                             // (helper waves shadow a main thread's addresses and store nothing)
   const int lane = tid & 63, wv = tid >> 6;
   const int K = a.K, B = a.B, R = B * K;
   const int tiles = (K + DS_TR - 1) / DS_TR;
@@ -460,7 +472,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int t = blockIdx.x % tiles, b = (blockIdx.x / tiles) % B, s = blockIdx.x / (tiles * B);
   const DsStack& S = a.st[s];
   const int r0 = t * DS_TR, nrows = min(DS_TR, K - r0);
-  const bool rok = r < nrows;
+  const bool rok = main_t && r < nrows;
   const int64_t row = (int64_t)b * K + r0 + min(r, nrows - 1);
   float* slab = a.slabs + (int64_t)blockIdx.x * a.slab_floats;
   float* daggS = a.dagg + (int64_t)s * R * a.finmax;
@@ -550,7 +562,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     __syncthreads();                                       // (the layer above's readers of dut / aggt / big are done)
 #pragma unroll
     for (int j = 0; j < 3; ++j)
-      if (j < Jn)
+      if (main_t && j < Jn)
         *reinterpret_cast<float4*>(dut + r * ldu + 4 * cg + 64 * j) =
             rok ? make_float4(ri * (dv[j][0] - vv[j][0] * dot), ri * (dv[j][1] - vv[j][1] * dot), ri * (dv[j][2] - vv[j][2] * dot),
                               ri * (dv[j][3] - vv[j][3] * dot))
@@ -565,7 +577,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       float* sl = slab + Ly.slab_off;
       const int i = lane & 15, kq = lane >> 4;
       const int nkb = (fin + 15) >> 4, ncg = (N + 15) >> 4;
-      for (int tl = wv; tl < nkb * ncg; tl += 4) {
+      for (int tl = wv; tl < nkb * ncg; tl += DS_NW) {
         const int kb = tl / ncg, g = tl - kb * ncg;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         float af[4], bf[4];
@@ -583,7 +595,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           if (k < fin && c < N) sl[(int64_t)k * N + c] = acc[v];
         }
       }
-      for (int c = tid; c < N; c += 256) {
+      for (int c = tid; c < N; c += DS_NT) {
         float sacc = 0.f;
 #pragma unroll
         for (int rr = 0; rr < DS_TR; ++rr) sacc += dut[rr * ldu + c];
@@ -627,7 +639,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       __syncthreads();
       fill_lds<false>(big, ldf, daggS + (int64_t)b * K * a.finmax, a.finmax, K, fin, Ident());
       if ((nrows & 3) == 0) fill_lds<false>(At, DS_TR, a.adj + (int64_t)b * K * K + r0, K, K, nrows, Ident());   // At[rr][mm] = A[rr][r0 + mm]
-      else for (int i = tid; i < K * nrows; i += 256) { const int rr = i / nrows, mm = i - rr * nrows; At[rr * DS_TR + mm] = a.adj[((int64_t)b * K + rr) * K + r0 + mm]; }
+      else for (int i = tid; i < K * nrows; i += DS_NT) { const int rr = i / nrows, mm = i - rr * nrows; At[rr * DS_TR + mm] = a.adj[((int64_t)b * K + rr) * K + r0 + mm]; }
       __syncthreads();
       tile_mfma(aggt, lda, At, 1, DS_TR, big, ldf, K, finP >> 4);
       __syncthreads();
@@ -661,7 +673,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int l = 0; l < T.L; ++l) {
         const DsLayer& Ly = T.layer[l];
         const int64_t ne = (int64_t)(Ly.fin + 1) * Ly.n;
-        for (int64_t e = (int64_t)blockIdx.x * 256 + tid; e < ne; e += (int64_t)nblocks * 256) {
+        for (int64_t e = (int64_t)blockIdx.x * DS_NT + tid; e < ne; e += (int64_t)nblocks * DS_NT) {
           const float* p = a.slabs + (int64_t)ss * per_stack * a.slab_floats + Ly.slab_off + e;
           float sacc = 0.f;
           int w = 0;
@@ -683,7 +695,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   if (a.dx) {
     const int f0 = a.fin0;
     const FastDiv by_f0(f0);                               // (R * f0 < 2^22: ds_check)
-    for (int e = (int)blockIdx.x * 256 + tid; e < R * f0; e += (int)nblocks * 256) {
+    for (int e = (int)blockIdx.x * DS_NT + tid; e < R * f0; e += (int)nblocks * DS_NT) {
       const int64_t rr = by_f0(e); const int c = (int)(e - rr * f0);
       float v = a.dxn[rr * a.finmax + c];
       if (a.nstack == 2) v += a.dxn[(int64_t)R * a.finmax + rr * a.finmax + c];
@@ -691,7 +703,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
   }
   if (a.dadj && a.nstack == 2) {
-    for (int64_t e = (int64_t)blockIdx.x * 256 + tid; e < (int64_t)R * K; e += (int64_t)nblocks * 256)
+    for (int64_t e = (int64_t)blockIdx.x * DS_NT + tid; e < (int64_t)R * K; e += (int64_t)nblocks * DS_NT)
       a.dadj[e] = (a.dadj_part[e] + a.dadj_part[(int64_t)R * K + e]) + (a.dadj_add ? a.dadj_add[e] : 0.f);
   }
   grid_finish(a.sync, bar, nblocks);
@@ -795,7 +807,7 @@ int tsgnn_dense_stack_fwd_f32(const int64_t* desc, tsgnn_stream_t stream) {
   ds_attr();
   const int tiles = (a.K + DS_TR - 1) / DS_TR;
   TSGNN_KNAME("dense_stack_fwd_kernel");
-  dense_stack_fwd_kernel<<<(unsigned)(tiles * a.B * a.nstack), 256, ds_lds_bytes(), stream>>>(a);
+  dense_stack_fwd_kernel<<<(unsigned)(tiles * a.B * a.nstack), DS_NT, ds_lds_bytes(), stream>>>(a);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }
@@ -812,7 +824,7 @@ int tsgnn_dense_stack_bwd_f32(const int64_t* desc, tsgnn_stream_t stream) {
   ds_attr();
   const int tiles = (a.K + DS_TR - 1) / DS_TR;
   TSGNN_KNAME("dense_stack_bwd_kernel");
-  dense_stack_bwd_kernel<<<(unsigned)(tiles * a.B * a.nstack), 256, ds_lds_bytes(), stream>>>(a);
+  dense_stack_bwd_kernel<<<(unsigned)(tiles * a.B * a.nstack), DS_NT, ds_lds_bytes(), stream>>>(a);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }
