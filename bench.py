@@ -396,8 +396,9 @@ def ingest_run(a, model, trainer, dev, steps, rank, value):
             "pcie_bytes_per_batch_mean": float(4 * (4 + a.batch + 2 + a.nmax + 2 * a.batch + 3 * np.mean(rows) + 2
                                                     + np.mean([int((ds.rowptr[ds.graph_ptr[ids + 1]] - ds.rowptr[ds.graph_ptr[ids]]).sum()) for ids in sched]))),
             "note": "every step draws %d new graphs from a 512-graph %s-shaped dataset; node-label (one-hot) features expanded on the "
-                    "device; one hipGraph per slot (expand + step, the NEXT batch's PCIe pull riding in the step's first hidden-layer "
-                    "launch) replays every batch (capacity-padded rows); 2 native collate threads" % (a.batch, a.shape)}
+                    "device; one hipGraph per slot (the step, with the NEXT batch's PCIe pull and expansion riding in its first "
+                    "hidden-layer and head launches) replays every batch (capacity-padded rows); 2 native collate threads"
+                    % (a.batch, a.shape)}
 
 
 def main():

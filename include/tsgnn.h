@@ -120,6 +120,12 @@ int tsgnn_ingest_expand_ack_f32(int32_t* mirror, int B, int nmax, int64_t row_ca
                                 int32_t* row_graph, int32_t* row_slot, int32_t* ell, int32_t* tail_ptr, int F, float* x, int64_t ldx,
                                 int64_t* host_ack, tsgnn_stream_t stream);
 int tsgnn_ingest_arm_pull_rider(const int32_t* host, int32_t* mirror, int B, int nmax, int64_t row_cap, int64_t edge_cap, int64_t tail_cap);
+/* the EXPANSION of that batch (arguments of tsgnn_ingest_expand_ack_f32) as passengers of the thread's next
+ * tsgnn_packed_head_fwd_f32 launch (a few latency-bound workgroups: most of the chip is idle under it), later in the same step than
+ * the launch that carries the pull.  tsgnn_ingest_flush_pull_rider launches whichever of the two riders no launch took. */
+int tsgnn_ingest_arm_expand_rider(int32_t* mirror, int B, int nmax, int64_t row_cap, int64_t edge_cap, int ell_w, int64_t tail_cap,
+                                  int32_t* row_graph, int32_t* row_slot, int32_t* ell, int32_t* tail_ptr, int F, float* x, int64_t ldx,
+                                  int64_t* host_ack);
 int tsgnn_ingest_flush_pull_rider(tsgnn_stream_t stream);
 /* Collate workers: native threads that run the host collate for the batches ahead of the step being enqueued.  submit: the
  * arguments of tsgnn_host_collate_tu (edge_cap = 0) or tsgnn_host_collate_compact (edge_cap > 0) (`ids`, `out` must stay valid

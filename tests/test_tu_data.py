@@ -385,13 +385,13 @@ def test_ingest_pipeline_riding_pull_equals_pull_at_the_head(workers):
     class A:
         bias = True
     out = []
-    for ride in (True, False):
+    for ride in (2, 1, 0):                                         # 2: pull and expansion ride; 1: the pull only; 0: neither
         torch.manual_seed(4)
         m = E.GcnEncoderGraph(ds.num_node_labels, 128, 128, 2, 3, bn=True, args=A(), final_dim="number_classes").to(dev)
         tr = FlatTrainer(m, lr=1e-2, clip=2.0, defer_loss=True)
         pipe = ingest.IngestPipeline(m, tr, ds, 6, 600, dev, sched, ride=ride)
-        assert pipe.ride == ride
-        if ride:                                                   # an eager step of position 0: who launches the copy?
+        assert pipe.ride == bool(ride) and pipe.ride_expand == (ride == 2)
+        if ride:                                                   # an eager step of position 0: who launches what?
             nat.trace = []
             try:
                 with torch.cuda.stream(pipe.compute):
@@ -401,12 +401,13 @@ def test_ingest_pipeline_riding_pull_equals_pull_at_the_head(workers):
             finally:
                 nat.trace = None
             torch.cuda.synchronize()
-            assert names[0] == "ingest_expand_ack_f32" and not any(n in names for n in ("ingest_pull_f32", "ingest_pull_expand_ack_f32"))
-            assert names.count("sage_layer_fwd_f32") + names.count("sage_layer_fwd_ro_f32") == 2
+            assert not any(n in names for n in ("ingest_pull_f32", "ingest_pull_expand_ack_f32"))
+            assert ("ingest_expand_ack_f32" in names) == (ride == 1) and (ride == 2 or names[0] == "ingest_expand_ack_f32")
+            assert names.count("sage_layer_fwd_f32") + names.count("sage_layer_fwd_ro_f32") == 2 and "packed_head_fwd_f32" in names
             assert len(flush) == 1 and not flush[0][2].startswith("ingest_")      # nothing was left for launches of their own
         pipe.run(sched[:4], workers=workers)                       # (no synchronisation in between: the second run drains the
         pipe.run(sched[4:], workers=workers)                       # last replay's passengers itself)
         torch.cuda.synchronize()
         out.append(tr.flat_param.clone())
     assert torch.isfinite(out[0]).all()
-    assert torch.equal(out[0], out[1])
+    assert torch.equal(out[0], out[2]) and torch.equal(out[1], out[2])

@@ -5,6 +5,7 @@
 #include "common.h"
 #include "../../include/tsgnn.h"
 #include "readout_body.h"
+#include "ingest_rider.h"
 
 namespace {
 
@@ -145,8 +146,12 @@ __global__ __launch_bounds__(64 * HW) void packed_head_fwd_kernel(const unsigned
                                                               int Fl, float* __restrict__ out, int64_t ldo, int* __restrict__ arg,
                                                               const float* __restrict__ w1, const float* __restrict__ b1,
                                                               const float* __restrict__ w2, const float* __restrict__ b2, int P, int E,
-                                                              int C, float* __restrict__ vec, float* __restrict__ y) {
+                                                              int C, float* __restrict__ vec, float* __restrict__ y, ExpandRider rider) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if ((int)blockIdx.x >= B) {                        // passengers: the next mini-batch's expansion on the CUs this launch leaves idle
+    expand_rider_body(rider, blockIdx.x - (unsigned)B, 64 * HW);
+    return;
+  }
   float* xs = smem;                                  // [P]
   float* vs = smem + ((P + 3) & ~3);                 // [E]
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -677,8 +682,10 @@ int tsgnn_packed_head_fwd_f32(const unsigned long long* packed, int B, int L, in
   const int P = (L - 1) * Fh + Fl;
   if ((P % 4) || P > 2048 || E > 8 * HW || ldo < P || (reinterpret_cast<uintptr_t>(w1) & 15)) return TSGNN_EUNSUPPORTED;
   const size_t lds = sizeof(float) * (size_t)(((P + 3) & ~3) + ((E + 3) & ~3));
+  const ExpandRider rider = take_expand_rider();       // (no workgroups unless tsgnn_ingest_arm_expand_rider armed one on this thread)
   TSGNN_KNAME("packed_head_fwd_kernel<8>");
-  packed_head_fwd_kernel<8><<<B, 64 * HW, lds, stream>>>(packed, B, L, Fh, Fl, out, ldo, arg, w1, b1, w2, b2, P, E, C, vec, y);
+  packed_head_fwd_kernel<8><<<(unsigned)B + rider.blocks, 64 * HW, lds, stream>>>(packed, B, L, Fh, Fl, out, ldo, arg, w1, b1, w2, b2, P, E, C,
+                                                                               vec, y, rider);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }

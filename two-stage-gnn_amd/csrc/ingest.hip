@@ -24,6 +24,7 @@
 #include <vector>
 
 thread_local PullRider tsgnn_pull_rider_ = {nullptr, nullptr, 0, 0};
+thread_local ExpandRider tsgnn_expand_rider_ = {};
 
 namespace {
 
@@ -71,10 +72,6 @@ __global__ __launch_bounds__(256) void onehot_rows_kernel(const int* __restrict_
 // columns are used straight out of the mirror —; `ingest_expand` builds row maps, the fixed-width neighbour table and the one-hot
 // feature rows from it.  No copy engine,
 // no second stream, no cross-stream events: the copy-engine -> shader hand-over alone cost more than the whole transfer.
-struct CLayout {
-  int64_t header, graph_ptr, slot_count, label, rowptr, node_label, tail_ptr, col, tail_col, total;
-};
-
 inline CLayout make_clayout(int B, int nmax, int64_t row_cap, int64_t edge_cap, int64_t tail_cap) {
   CLayout L;
   int64_t o = 0;
@@ -108,69 +105,10 @@ __global__ __launch_bounds__(256) void ingest_pull_kernel(const int4* __restrict
 
 __global__ __launch_bounds__(256) void ingest_pull_rider_kernel(PullRider p) { pull_rider_body(p, blockIdx.x); }
 
-struct ExpandArgs {
-  const int32_t* mirror; CLayout L;
-  int B, nmax, ell_w, F, ld4; int64_t row_cap;
-  int32_t* row_graph; int32_t* row_slot; int32_t* ell; int32_t* tail_ptr; float* x; int64_t ldx;
-  int64_t* host_ack;                     // nullable (pinned host memory): receives the batch's sequence word once it is pulled
-};
-
-// 32 lanes per row, 8 rows per block.  Lane q of a row: q < ell_w/4 writes four entries of the row's neighbour table, q == ell_w/4
-// the row maps and the tail pointer, the lanes after that (looping when a row has more than 32 - ell_w/4 - 1 float4) the one-hot
-// feature row.
 __global__ __launch_bounds__(256) void ingest_expand_kernel(ExpandArgs a) {
-  const unsigned vb = blockIdx.x;
-  const int64_t total_rows = a.row_cap + a.nmax;
-  const int64_t r = (int64_t)vb * 8 + (threadIdx.x >> 5);
-  const int q = threadIdx.x & 31;
-  if (a.host_ack && vb == 0 && threadIdx.x == 0) {
-    // the pull launch ahead of this one has finished reading the staging buffer: echo the batch's sequence word to the host,
-    // which may refill the buffer once it sees it (the collate workers wait on this word — no event between the step's launches)
-    __hip_atomic_store(a.host_ack, (int64_t)a.mirror[a.L.header + 4], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-  if (r >= total_rows) return;
-  const int64_t n = a.mirror[a.L.header];
-  const int32_t ntail = a.mirror[a.L.header + 2];
-  const int EQ = a.ell_w / 4;
-  const int l = (r < n) ? a.mirror[a.L.node_label + r] : -1;
-  if (q < EQ) {
-    int4 v = make_int4(-1, -1, -1, -1);
-    if (r < n) {
-      const int32_t* rowptr = a.mirror + a.L.rowptr;
-      const int e0 = rowptr[r], d = rowptr[r + 1] - e0;
-      const int32_t* col = a.mirror + a.L.col + e0;
-      const int k = 4 * q;
-      if (k < d) v.x = col[k];
-      if (k + 1 < d) v.y = col[k + 1];
-      if (k + 2 < d) v.z = col[k + 2];
-      if (k + 3 < d) v.w = col[k + 3];
-    }
-    *reinterpret_cast<int4*>(a.ell + r * a.ell_w + 4 * q) = v;
-  } else if (q == EQ) {
-    if (r < a.row_cap) {
-      int g = a.B, slot = 0;
-      if (r < n) {                                          // binary search: the graph whose row range holds r
-        const int32_t* gp = a.mirror + a.L.graph_ptr;
-        int lo = 0, hi = a.B;                               // gp[lo] <= r < gp[hi]
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (gp[mid] <= r) lo = mid; else hi = mid; }
-        g = lo; slot = (int)(r - gp[lo]);
-      }
-      a.row_graph[r] = g;
-      a.row_slot[r] = slot;
-    }
-    a.tail_ptr[r] = r < n ? a.mirror[a.L.tail_ptr + r] : ntail;
-    if (r == total_rows - 1) a.tail_ptr[total_rows] = ntail;
-  } else {
-    const bool ok = l >= 0 && l < a.F;                      // (no dynamic register indexing: that would go through scratch)
-    for (int c4 = q - EQ - 1; c4 < a.ld4; c4 += 32 - EQ - 1) {
-      const int c = 4 * c4;
-      const float4 v = make_float4((ok && l == c) ? 1.f : 0.f, (ok && l == c + 1) ? 1.f : 0.f, (ok && l == c + 2) ? 1.f : 0.f,
-                                   (ok && l == c + 3) ? 1.f : 0.f);
-      *reinterpret_cast<float4*>(a.x + r * a.ldx + c) = v;
-    }
-  }
+  expand_row_lane(a, (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5), threadIdx.x & 31);
 }
-
+__global__ __launch_bounds__(256) void ingest_expand_rider_kernel(ExpandRider e) { expand_rider_body(e, blockIdx.x, 256); }
 
 }  // namespace
 
@@ -348,12 +286,40 @@ int tsgnn_ingest_arm_pull_rider(const int32_t* host, int32_t* mirror, int B, int
   tsgnn_pull_rider_ = p;
   return TSGNN_OK;
 }
+/* ... and the EXPANSION of that batch (arguments of tsgnn_ingest_expand_ack_f32) as passengers of this thread's next
+ * tsgnn_packed_head_fwd_f32 launch — a launch of a few workgroups that leaves most of the chip idle, later in the same step than the
+ * launch that carries the pull. */
+int tsgnn_ingest_arm_expand_rider(int32_t* mirror, int B, int nmax, int64_t row_cap, int64_t edge_cap, int ell_w, int64_t tail_cap,
+                                  int32_t* row_graph, int32_t* row_slot, int32_t* ell, int32_t* tail_ptr, int F, float* x, int64_t ldx,
+                                  int64_t* host_ack) {
+  if (!mirror || !row_graph || !row_slot || !ell || !tail_ptr || !x || B <= 0 || nmax <= 0 || row_cap <= 0 || edge_cap <= 0 ||
+      tail_cap < 0 || F <= 0)
+    return TSGNN_EINVAL;
+  const int ld4 = (F + 3) / 4;
+  if ((ell_w != 4 && ell_w != 8 && ell_w != 16) || ldx < 4 * ld4 || (ldx % 4)) return TSGNN_EUNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(mirror) | reinterpret_cast<uintptr_t>(ell) | reinterpret_cast<uintptr_t>(x)) & 15) return TSGNN_EUNSUPPORTED;
+  const CLayout L = make_clayout(B, nmax, row_cap, edge_cap, tail_cap);
+  ExpandRider e;
+  e.ex = ExpandArgs{mirror, L, B, nmax, ell_w, F, ld4, row_cap, row_graph, row_slot, ell, tail_ptr, x, ldx, host_ack};
+  e.rows = row_cap + nmax;
+  const long long want = (e.rows + 15) / 16;                 // one 512-thread workgroup per 16 rows, at most 448 of them (looping)
+  e.blocks = (unsigned)(want < 448 ? want : 448);
+  tsgnn_expand_rider_ = e;
+  return TSGNN_OK;
+}
+/* launches the armed riders that no launch took, each as a launch of its own (pull, then expansion); no-op otherwise */
 int tsgnn_ingest_flush_pull_rider(tsgnn_stream_t stream) {
   const PullRider p = take_pull_rider();
-  if (p.blocks == 0) return TSGNN_OK;
-  TSGNN_KNAME("ingest_pull_rider_kernel");
-  ingest_pull_rider_kernel<<<p.blocks, 256, 0, stream>>>(p);
-  TSGNN_CHECK_LAUNCH();
+  if (p.blocks) {
+    TSGNN_KNAME("ingest_pull_rider_kernel");
+    ingest_pull_rider_kernel<<<p.blocks, 256, 0, stream>>>(p);
+  }
+  const ExpandRider e = take_expand_rider();
+  if (e.blocks) {
+    TSGNN_KNAME("ingest_expand_rider_kernel");
+    ingest_expand_rider_kernel<<<e.blocks, 256, 0, stream>>>(e);
+  }
+  if (p.blocks || e.blocks) TSGNN_CHECK_LAUNCH();          // (nothing armed: no runtime call at all)
   return TSGNN_OK;
 }
 

@@ -3,8 +3,10 @@
 // is 10 us of every step; as passengers of a 12 us row-panel launch (which leaves a second workgroup slot free on every CU) the
 // copy is over before the launch is.  tsgnn_ingest_arm_pull_rider arms it (thread-local), the next tsgnn_sage_layer_fwd*_f32 call of
 // the thread takes it along; tsgnn_ingest_flush_pull_rider launches it alone if nothing did.
-// (The expansion of the pulled batch was tried as passengers of the following layer launch as well: the step took as long as
-// with the expansion as its first launch — 0.1825 vs 0.1819 ms — so it stayed a launch.)
+// The EXPANSION of the pulled batch (mirror -> row maps, neighbour table, tail pointers, one-hot feature rows, + the echo of its
+// sequence word) rides later in the same step, in tsgnn_packed_head_fwd_f32's launch: a few workgroups of latency-bound work that
+// leave most of the chip idle.  (As passengers of the next layer-product launch it lengthened that launch by what a launch of its
+// own cost: 0.1825 vs 0.1819 ms.)  tsgnn_ingest_arm_expand_rider arms it.
 #pragma once
 #include "common.h"
 
@@ -29,4 +31,83 @@ __device__ __forceinline__ void pull_rider_body(const PullRider& p, unsigned b) 
     for (int u = 0; u < 4; ++u) p.mirror[i + u * gsize] = v[u];
   }
   for (; i < p.n4; i += gsize) p.mirror[i] = p.host[i];
+}
+
+// ---- the expansion
+struct CLayout {
+  int64_t header, graph_ptr, slot_count, label, rowptr, node_label, tail_ptr, col, tail_col, total;
+};
+
+struct ExpandArgs {
+  const int32_t* mirror; CLayout L;
+  int B, nmax, ell_w, F, ld4; int64_t row_cap;
+  int32_t* row_graph; int32_t* row_slot; int32_t* ell; int32_t* tail_ptr; float* x; int64_t ldx;
+  int64_t* host_ack;                     // nullable (pinned host memory): receives the batch's sequence word once it is pulled
+};
+
+// 32 lanes per row, 8 rows per block.  Lane q of a row: q < ell_w/4 writes four entries of the row's neighbour table, q == ell_w/4
+// the row maps and the tail pointer, the lanes after that (looping when a row has more than 32 - ell_w/4 - 1 float4) the one-hot
+// feature row.
+__device__ __forceinline__ void expand_row_lane(const ExpandArgs& a, int64_t r, int q) {
+  const int64_t total_rows = a.row_cap + a.nmax;
+  if (a.host_ack && r == 0 && q == 0) {
+    // the pull launch ahead of this one has finished reading the staging buffer: echo the batch's sequence word to the host,
+    // which may refill the buffer once it sees it (the collate workers wait on this word — no event between the step's launches)
+    __hip_atomic_store(a.host_ack, (int64_t)a.mirror[a.L.header + 4], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (r >= total_rows) return;
+  const int64_t n = a.mirror[a.L.header];
+  const int32_t ntail = a.mirror[a.L.header + 2];
+  const int EQ = a.ell_w / 4;
+  const int l = (r < n) ? a.mirror[a.L.node_label + r] : -1;
+  if (q < EQ) {
+    int4 v = make_int4(-1, -1, -1, -1);
+    if (r < n) {
+      const int32_t* rowptr = a.mirror + a.L.rowptr;
+      const int e0 = rowptr[r], d = rowptr[r + 1] - e0;
+      const int32_t* col = a.mirror + a.L.col + e0;
+      const int k = 4 * q;
+      if (k < d) v.x = col[k];
+      if (k + 1 < d) v.y = col[k + 1];
+      if (k + 2 < d) v.z = col[k + 2];
+      if (k + 3 < d) v.w = col[k + 3];
+    }
+    *reinterpret_cast<int4*>(a.ell + r * a.ell_w + 4 * q) = v;
+  } else if (q == EQ) {
+    if (r < a.row_cap) {
+      int g = a.B, slot = 0;
+      if (r < n) {                                          // binary search: the graph whose row range holds r
+        const int32_t* gp = a.mirror + a.L.graph_ptr;
+        int lo = 0, hi = a.B;                               // gp[lo] <= r < gp[hi]
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (gp[mid] <= r) lo = mid; else hi = mid; }
+        g = lo; slot = (int)(r - gp[lo]);
+      }
+      a.row_graph[r] = g;
+      a.row_slot[r] = slot;
+    }
+    a.tail_ptr[r] = r < n ? a.mirror[a.L.tail_ptr + r] : ntail;
+    if (r == total_rows - 1) a.tail_ptr[total_rows] = ntail;
+  } else {
+    const bool ok = l >= 0 && l < a.F;                      // (no dynamic register indexing: that would go through scratch)
+    for (int c4 = q - EQ - 1; c4 < a.ld4; c4 += 32 - EQ - 1) {
+      const int c = 4 * c4;
+      const float4 v = make_float4((ok && l == c) ? 1.f : 0.f, (ok && l == c + 1) ? 1.f : 0.f, (ok && l == c + 2) ? 1.f : 0.f,
+                                   (ok && l == c + 3) ? 1.f : 0.f);
+      *reinterpret_cast<float4*>(a.x + r * a.ldx + c) = v;
+    }
+  }
+}
+
+struct ExpandRider { ExpandArgs ex; long long rows; unsigned blocks; };   // armed while blocks > 0
+extern thread_local ExpandRider tsgnn_expand_rider_;
+static inline ExpandRider take_expand_rider() {
+  ExpandRider r = tsgnn_expand_rider_;
+  tsgnn_expand_rider_.blocks = 0;
+  return r;
+}
+// workgroup b of e.blocks, `nthreads` threads (a multiple of 32): 32 lanes a row, looping over the rows
+__device__ __forceinline__ void expand_rider_body(const ExpandRider& e, unsigned b, int nthreads) {
+  const int rpb = nthreads >> 5;
+  for (long long r0 = (long long)b * rpb; r0 < e.rows; r0 += (long long)e.blocks * rpb)
+    expand_row_lane(e.ex, r0 + (threadIdx.x >> 5), threadIdx.x & 31);
 }

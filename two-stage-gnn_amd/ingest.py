@@ -205,6 +205,10 @@ class CapacityBatch:
         nat.call_nostream("ingest_arm_pull_rider", self.host.data_ptr(), self.mirror, self.B, self.nmax, self.row_cap, self.edge_cap,
                           self.tail_cap)
 
+    def arm_expand_rider(self):
+        """the expansion (and the echo) as passengers of this thread's next packed-head launch (csrc/ingest_rider.h)"""
+        nat.call_nostream("ingest_arm_expand_rider", *self._expand_args())
+
     def mark_consumed(self, stream=None):
         """a replay of the captured step (whose first launches are this slot's pull) has been enqueued"""
         self._replayed = True
@@ -235,10 +239,12 @@ class IngestPipeline:
     """Training loop in which every step consumes a NEW mini-batch drawn from ``ds``: native workers collate the batches ahead
     into the slots' pinned staging buffers, the enqueueing thread replays the slot's hipGraph.
 
-    ride (default; env TSGNN_INGEST_RIDE=0 turns it off): the graph of position p expands the batch that is already in p's mirror
-    and, as passengers of its first hidden layer's product launch, pulls the NEXT position's staging buffer over PCIe
-    (``CapacityBatch.arm_pull_rider``, csrc/ingest_rider.h) — the ~10 us PCIe round trip of the pull is hidden inside the previous
-    step.  The first batch of a run is pulled by a launch of its own.  Without it (or with a custom ``make_loss``) the first two
+    ride (default 2; env TSGNN_INGEST_RIDE=0 turns it off): the graph of position p steps on the batch that is already expanded
+    in p's arrays and brings the NEXT position's batch in as passengers of its own launches (csrc/ingest_rider.h): the flat copy of
+    that staging buffer over PCIe rides in the first hidden layer's product launch (``CapacityBatch.arm_pull_rider``: the ~10 us
+    round trip is hidden inside the step), its expansion in the head's forward launch (``arm_expand_rider``: a few workgroups
+    that leave most of the chip idle).  ride = 1: only the pull rides, the expansion is the step's first launch.  The first batch
+    of a run comes in by launches of its own.  Without it (or with a custom ``make_loss``) the first two
     launches of the slot's graph pull and expand its own batch (``CapacityBatch.pull``)."""
 
     def __init__(self, model, trainer, ds, batch, nmax, device, schedule, depth=3, make_loss=None, ride=None):
@@ -256,8 +262,10 @@ class IngestPipeline:
         self.slots = [CapacityBatch(batch, nmax, self.row_cap, self.edge_cap, ds.num_node_labels, device, ghost_slots=ghost)
                       for _ in range(depth)]
         if ride is None:
-            ride = os.environ.get("TSGNN_INGEST_RIDE", "1") != "0"
+            ride = int(os.environ.get("TSGNN_INGEST_RIDE", "2"))
         self.ride = bool(ride) and make_loss is None and depth >= 2
+        # 2 (default): the next batch's EXPANSION rides too (in the head's forward launch); 1: it is the step's first launch
+        self.ride_expand = self.ride and int(ride) >= 2
         self.steps = []
         if make_loss is None and not self.ride:
             def make_loss(s):
@@ -270,12 +278,15 @@ class IngestPipeline:
         if self.ride:
             with torch.cuda.stream(self.compute):
                 for s in self.slots:
-                    s.pull_only()                             # every mirror holds a batch before the first expansion
+                    s.pull_only(); s.expand()                 # every position's arrays hold a batch before the first step
 
             def make_loss_ride(s, nxt):
                 def loss():
-                    s.expand()                                # this position's batch: pulled by the previous step's passengers
-                    nxt.arm_pull_rider()                      # the next position's staging buffer rides in the first layer product
+                    if not self.ride_expand:
+                        s.expand()                            # this position's batch: pulled by the previous step's passengers
+                    nxt.arm_pull_rider()                      # the next position's staging buffer rides in the first layer product,
+                    if self.ride_expand:
+                        nxt.arm_expand_rider()                # its expansion in the head's forward launch
                     out = model.loss(model(s.x, s.g)[1], s.label)
                     nat.call("ingest_flush_pull_rider")       # (a model without such a launch: the pull as a launch of its own)
                     return out
@@ -318,6 +329,8 @@ class IngestPipeline:
             stage(0)
             with torch.cuda.stream(self.compute):
                 self.slots[0].pull_only()                     # nobody rode for the first batch of the run
+                if self.ride_expand:
+                    self.slots[0].expand()
         for k, ids in enumerate(sched):
             s, gs = self.slots[k % depth], self.steps[k % depth]
             t = time.perf_counter()
@@ -329,7 +342,7 @@ class IngestPipeline:
             t = tick("collate/wait", t)
             gs.step()                                         # [pull +] expand + forward + backward + optimiser, one replay
             t = tick("replay", t)
-            s.mark_consumed(self.compute)
+            (self.slots[(k + 1) % depth] if self.ride_expand else s).mark_consumed(self.compute)   # whose echo this replay emits
             if pool is not None and k + depth < len(sched):   # the slot's next batch (the worker waits for the echo first)
                 s.collate_async(pool, self.ds, sched[k + depth])
             tick("submit", t)
