@@ -92,6 +92,31 @@ __device__ __forceinline__ void grid_barrier(unsigned* words, int& k, unsigned n
   ++k;
   __syncthreads();
 }
+// The same barrier in two halves — arrive, (work that does not depend on the others), wait — so that a phase's operands which are
+// forward data (not produced by this launch) are staged into LDS while the arrivals travel.
+template <bool LIGHT = false>
+__device__ __forceinline__ void grid_arrive(unsigned* words, int k) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (LIGHT) __hip_atomic_fetch_add(words + k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else __hip_atomic_fetch_add(words + k, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+template <bool LIGHT = false>
+__device__ __forceinline__ void grid_wait(unsigned* words, int& k, unsigned nblocks, float* err) {
+  if (threadIdx.x == 0) {
+    bool ok = false;
+    for (int spin = 0; spin < (1 << 21); ++spin) {
+      if (__hip_atomic_load(words + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= nblocks) { ok = true; break; }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    if (!LIGHT) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (!ok) __hip_atomic_store(err, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (k > 0 && blockIdx.x == 0) __hip_atomic_store(words + k - 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  ++k;
+  __syncthreads();
+}
 // a pair of floats through agent-scope atomics (one 8-byte access): see grid_barrier<LIGHT>
 __device__ __forceinline__ void ds_put2(float* p, float x, float y) {
   const unsigned long long bits = ((unsigned long long)__float_as_uint(y) << 32) | (unsigned long long)__float_as_uint(x);
@@ -526,7 +551,22 @@ __global__ __launch_bounds__(DS_NT) __attribute__((amdgpu_waves_per_eu(DS_NW / 4
       p1 = row16_sum(p1); p2 = row16_sum(p2);
       float* st = a.stats + ((int64_t)l * a.nstack * R + (int64_t)s * R) * 2;
       if (rok && cg == 0) ds_put2(st + row * 2, p1, p2);
-      grid_barrier<true>(a.sync, bar, nblocks, a.err);     // (only the partial sums cross workgroups here)
+      grid_arrive<true>(a.sync, bar);                      // (only the partial sums cross workgroups here)
+    } else {
+      __syncthreads();                                     // (the layer above's readers of aggt / big are done)
+    }
+    // under the barrier's wait: the forward data this layer's products read — the agg tile (P2) and W^T (P3) — go to LDS now
+    zero_lds(aggt, DS_TR * lda);
+    if (finP != fin) zero_lds(big, N * ldf);
+    __syncthreads();
+    fill_lds<false>(aggt, lda, Ly.agg + ((int64_t)b * K + r0) * fin, fin, nrows, fin, Ident());
+    fill_lds<true>(big, ldf, Ly.w, Ly.ldw, fin, N, Ident());
+    if (!last) {
+      const int rs_ = r0 + min(r, nrows - 1);
+      const float mean_l = Ly.mean[rs_], rstd_l = Ly.rstd[rs_];
+      const float mean = rok ? mean_l : 0.f, rstd = rok ? rstd_l : 1.f;
+      float* st = a.stats + ((int64_t)l * a.nstack * R + (int64_t)s * R) * 2;
+      grid_wait<true>(a.sync, bar, nblocks, a.err);
       if (tid < K) {
         float t1, t2;
         slot_totals(st, B, K, tid, t1, t2);
@@ -559,17 +599,13 @@ __global__ __launch_bounds__(DS_NT) __attribute__((amdgpu_waves_per_eu(DS_NW / 4
     const float ri_l = Ly.rinv[row];                       // (row is clamped)
     const float ri = rok ? ri_l : 0.f;
     if (ri >= 0.999e12f) dot = 0.f;                        // clamped norm: F.normalize passes no norm gradient
-    __syncthreads();                                       // (the layer above's readers of dut / aggt / big are done)
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
+    for (int j = 0; j < 3; ++j)                            // (dut's readers of the layer above are behind the barriers since)
       if (main_t && j < Jn)
         *reinterpret_cast<float4*>(dut + r * ldu + 4 * cg + 64 * j) =
             rok ? make_float4(ri * (dv[j][0] - vv[j][0] * dot), ri * (dv[j][1] - vv[j][1] * dot), ri * (dv[j][2] - vv[j][2] * dot),
                               ri * (dv[j][3] - vv[j][3] * dot))
                 : make_float4(0.f, 0.f, 0.f, 0.f);
-    zero_lds(aggt, DS_TR * lda);
-    __syncthreads();
-    fill_lds<false>(aggt, lda, Ly.agg + ((int64_t)b * K + r0) * fin, fin, nrows, fin, Ident());
     __syncthreads();
     // ---- P2: this tile's share of dW = agg^T du (MFMA: M = fin, N = n, depth = the tile's 16 rows) and db = colsum(du) -> the
     //          workgroup's slab (the slabs are summed in a fixed order at the end)
@@ -602,11 +638,8 @@ __global__ __launch_bounds__(DS_NT) __attribute__((amdgpu_waves_per_eu(DS_NW / 4
         sl[fin * N + c] = sacc;
       }
     }
-    // ---- P3: dagg tile = du . W^T   (W^T [n][finP + 16] in LDS: the product has the forward's shape)
-    if (finP != fin) zero_lds(big, N * ldf);
-    __syncthreads();                                       // (P2's readers of aggt are done too)
-    fill_lds<true>(big, ldf, Ly.w, Ly.ldw, fin, N, Ident());
-    __syncthreads();
+    // ---- P3: dagg tile = du . W^T   (W^T [n][finP + 16] went to LDS under the barrier: the product has the forward's shape)
+    __syncthreads();                                       // (P2's readers of aggt are done)
     tile_mfma(aggt, lda, dut, ldu, 1, big, ldf, N, finP >> 4);
     __syncthreads();
     float dg[3][4];
