@@ -325,6 +325,7 @@ __global__ __launch_bounds__(DS_NT) __attribute__((amdgpu_waves_per_eu(DS_NW / 4
   float* ut = aggt + DS_TR * 196;           // [TR][nP]
   float* mu = ut + DS_TR * 148;             // [K]
   float* rs = mu + 64;                      // [K]
+  float* big2 = rs + 64;                    // W [fin][nP + 16]: its own region, so that the next layer's weights land under the barrier
   const int tid = threadIdx.x, r = (tid & 255) >> 4, cg = tid & 15;
   const bool main_t = tid < 256;                             // (helper waves shadow a main thread's addresses and store nothing)
   const int K = a.K, B = a.B, R = B * K;
@@ -340,8 +341,14 @@ __global__ __launch_bounds__(DS_NT) __attribute__((amdgpu_waves_per_eu(DS_NW / 4
   Pf<DS_PFW> wpf;                                            // the layer's weights, on their way while the phases before their product run
   pf_load(wpf, S.layer[0].w, S.layer[0].ldw, S.layer[0].fin, S.layer[0].n);
   zero_lds(At, DS_TR * DS_LDA);
+  {
+    const DsLayer& L0 = S.layer[0];
+    if (pad64(L0.n) != L0.n) zero_lds(big2, L0.fin * (pad64(L0.n) + DS_PADB));
+  }
   __syncthreads();
   fill_lds<false>(At, DS_LDA, a.adj + ((int64_t)b * K + r0) * K, K, nrows, K, Ident());
+  pf_store<DS_PFW, false>(big2, pad64(S.layer[0].n) + DS_PADB, wpf, S.layer[0].fin, S.layer[0].n);
+  if (S.L > 1) pf_load(wpf, S.layer[1].w, S.layer[1].ldw, S.layer[1].fin, S.layer[1].n);       // (stored under layer 0's barrier)
   float vprev[3][4];                                         // tiles == 1: this thread's entries of the layer below's v
   zero_acc(vprev);
   for (int l = 0; l < S.L; ++l) {
@@ -396,12 +403,7 @@ __global__ __launch_bounds__(DS_NT) __attribute__((amdgpu_waves_per_eu(DS_NW / 4
       }
     }
     if (l == 0) TR(2);
-    // (3) W (requested a layer ago) -> LDS, u = agg . W + bias, row L2 normalise
-    if (NP != N) zero_lds(big, fin * ldw);
-    __syncthreads();
-    pf_store<DS_PFW, false>(big, ldw, wpf, fin, N);
-    if (!last) pf_load(wpf, S.layer[l + 1].w, S.layer[l + 1].ldw, S.layer[l + 1].fin, S.layer[l + 1].n);   // under this product and the barrier
-    __syncthreads();
+    // (3) u = agg . W + bias (W went to big2 under the previous barrier / at the start), row L2 normalise
     if (l == 0) TR(3);
     // the bias, requested before the product from clamped addresses (per-element `bias ? bias[c] : 0` loads were waited for one
     // by one); no bias: the same requests go to the weights and are discarded
@@ -415,7 +417,7 @@ __global__ __launch_bounds__(DS_NT) __attribute__((amdgpu_waves_per_eu(DS_NW / 4
         if (!Ly.bias) bias4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
-    tile_mfma(ut, NP, aggt, lda, 1, big, ldw, fin, NP >> 4);
+    tile_mfma(ut, NP, aggt, lda, 1, big2, ldw, fin, NP >> 4);
     __syncthreads();
     float u[3][4];
     read_tile(u, ut, NP, r, cg, Jn);
@@ -454,9 +456,19 @@ __global__ __launch_bounds__(DS_NT) __attribute__((amdgpu_waves_per_eu(DS_NW / 4
       float* st = a.stats + ((int64_t)l * a.nstack * R + (int64_t)s * R) * 2;
       if (rok && cg == 0) ds_put2(st + row * 2, s1, s2);
       if (l == 0) TR(5);
-      // one tile per graph: only the partial sums cross workgroups here; else the sibling tiles' rows of v do too
-      if (tiles == 1) grid_barrier<true>(a.sync, bar, nblocks, a.err);
-      else grid_barrier(a.sync, bar, nblocks, a.err);
+      // one tile per graph: only the partial sums cross workgroups here; else the sibling tiles' rows of v do too.  While the
+      // arrivals travel, the next layer's weights (in registers since a layer ago) go to big2 and the ones after are requested
+      if (tiles == 1) grid_arrive<true>(a.sync, bar);
+      else grid_arrive(a.sync, bar);
+      {
+        const DsLayer& Ln = S.layer[l + 1];
+        const int ldn = pad64(Ln.n) + DS_PADB;
+        if (pad64(Ln.n) != Ln.n) { zero_lds(big2, Ln.fin * ldn); __syncthreads(); }
+        pf_store<DS_PFW, false>(big2, ldn, wpf, Ln.fin, Ln.n);
+        if (l + 2 < S.L) pf_load(wpf, S.layer[l + 2].w, S.layer[l + 2].ldw, S.layer[l + 2].fin, S.layer[l + 2].n);
+      }
+      if (tiles == 1) grid_wait<true>(a.sync, bar, nblocks, a.err);
+      else grid_wait(a.sync, bar, nblocks, a.err);
       if (l == 0) TR(6);
       // every workgroup finishes the statistics of all K slots
       if (tid < K) {
@@ -488,6 +500,7 @@ __global__ __launch_bounds__(DS_NT) __attribute__((amdgpu_waves_per_eu(DS_NW / 4
   float* dut = aggt + DS_TR * 196;          // [TR][nP + 20]  du tile ; later the dA tile [TR][64]
   float* m1s = dut + DS_TR * 148;           // [K]
   float* m2s = m1s + 64;                    // [K]
+  float* big2 = m2s + 64;                   // xin^T [fin][80]: a second big region, so that it is staged while W^T is still in use
   const int tid = threadIdx.x, r = (tid & 255) >> 4, cg = tid & 15;
   const bool main_t = tid < 256;                             // (helper waves shadow a main thread's addresses and store nothing)
   const int lane = tid & 63, wv = tid >> 6;
@@ -504,6 +517,11 @@ __global__ __launch_bounds__(DS_NT) __attribute__((amdgpu_waves_per_eu(DS_NW / 4
   float* dxnS = a.dxn + (int64_t)s * R * a.finmax;
   float dadj_acc[4] = {0.f, 0.f, 0.f, 0.f};               // this thread's entries (r, 4 cg + q) of the graph's dA tile
   int bar = 0;
+  // the adjacency columns of this tile (P5's A operand) are the same for every layer: staged once
+  zero_lds(At, K * DS_TR);
+  __syncthreads();
+  if ((nrows & 3) == 0) fill_lds<false>(At, DS_TR, a.adj + (int64_t)b * K * K + r0, K, K, nrows, Ident());   // At[rr][mm] = A[rr][r0 + mm]
+  else for (int i = tid; i < K * nrows; i += DS_NT) { const int rr = i / nrows, mm = i - rr * nrows; At[rr * DS_TR + mm] = a.adj[((int64_t)b * K + rr) * K + r0 + mm]; }
   for (int l = S.L - 1; l >= 0; --l) {
     const DsLayer& Ly = S.layer[l];
     const int fin = Ly.fin, N = Ly.n, finP = pad64(fin), NP = pad64(N), Jf = finP >> 6, Jn = NP >> 6;
@@ -555,12 +573,18 @@ __global__ __launch_bounds__(DS_NT) __attribute__((amdgpu_waves_per_eu(DS_NW / 4
     } else {
       __syncthreads();                                     // (the layer above's readers of aggt / big are done)
     }
-    // under the barrier's wait: the forward data this layer's products read — the agg tile (P2) and W^T (P3) — go to LDS now
+    // under the barrier's wait: the forward data this layer's products read — the agg tile (P2), W^T (P3), xin^T (P4) — go to
+    // LDS now
     zero_lds(aggt, DS_TR * lda);
     if (finP != fin) zero_lds(big, N * ldf);
+    if (a.dadj && K != 64) zero_lds(big2, fin * 80);
     __syncthreads();
     fill_lds<false>(aggt, lda, Ly.agg + ((int64_t)b * K + r0) * fin, fin, nrows, fin, Ident());
     fill_lds<true>(big, ldf, Ly.w, Ly.ldw, fin, N, Ident());
+    if (a.dadj) {
+      if (l == 0) fill_lds<true>(big2, 80, a.x + (int64_t)b * K * a.ldx, a.ldx, K, fin, Ident());
+      else fill_lds<true>(big2, 80, S.out + (int64_t)b * K * S.ldo + S.layer[l - 1].off, S.ldo, K, fin, Ident());
+    }
     if (!last) {
       const int rs_ = r0 + min(r, nrows - 1);
       const float mean_l = Ly.mean[rs_], rstd_l = Ly.rstd[rs_];
@@ -652,13 +676,8 @@ __global__ __launch_bounds__(DS_NT) __attribute__((amdgpu_waves_per_eu(DS_NW / 4
       }
     }
     // ---- P4: dA[tile rows, m] += dagg[r, :] . xin[m, :]   (xin^T [fin][80] in LDS; the dA tile lands in the du tile's place)
-    if (a.dadj) {
-      if (K != 64) zero_lds(big, fin * 80);
-      __syncthreads();
-      if (l == 0) fill_lds<true>(big, 80, a.x + (int64_t)b * K * a.ldx, a.ldx, K, fin, Ident());
-      else fill_lds<true>(big, 80, S.out + (int64_t)b * K * S.ldo + S.layer[l - 1].off, S.ldo, K, fin, Ident());
-      __syncthreads();
-      tile_mfma(dut, 64, aggt, lda, 1, big, 80, fin, 4);
+    if (a.dadj) {                                          // (xin^T went to big2 under the barrier)
+      tile_mfma(dut, 64, aggt, lda, 1, big2, 80, fin, 4);
       __syncthreads();
       const float4 v = *reinterpret_cast<const float4*>(dut + r * 64 + 4 * cg);
       dadj_acc[0] += v.x; dadj_acc[1] += v.y; dadj_acc[2] += v.z; dadj_acc[3] += v.w;
@@ -668,11 +687,8 @@ __global__ __launch_bounds__(DS_NT) __attribute__((amdgpu_waves_per_eu(DS_NW / 4
       if (tiles == 1) __syncthreads();                       // the graph is this tile: its dagg rows are the workgroup's own writes
       else grid_barrier(a.sync, bar, nblocks, a.err);
       if (finP != fin) zero_lds(big, K * ldf);
-      zero_lds(At, K * DS_TR);
       __syncthreads();
       fill_lds<false>(big, ldf, daggS + (int64_t)b * K * a.finmax, a.finmax, K, fin, Ident());
-      if ((nrows & 3) == 0) fill_lds<false>(At, DS_TR, a.adj + (int64_t)b * K * K + r0, K, K, nrows, Ident());   // At[rr][mm] = A[rr][r0 + mm]
-      else for (int i = tid; i < K * nrows; i += DS_NT) { const int rr = i / nrows, mm = i - rr * nrows; At[rr * DS_TR + mm] = a.adj[((int64_t)b * K + rr) * K + r0 + mm]; }
       __syncthreads();
       tile_mfma(aggt, lda, At, 1, DS_TR, big, ldf, K, finP >> 4);
       __syncthreads();
@@ -742,7 +758,7 @@ __global__ __launch_bounds__(DS_NT) __attribute__((amdgpu_waves_per_eu(DS_NW / 4
   grid_finish(a.sync, bar, nblocks);
 }
 
-constexpr size_t ds_lds_bytes() { return sizeof(float) * (DS_BIG + DS_TR * 68 + DS_TR * 196 + DS_TR * 148 + 128); }
+constexpr size_t ds_lds_bytes() { return sizeof(float) * (2 * DS_BIG + DS_TR * 68 + DS_TR * 196 + DS_TR * 148 + 128); }   // 150 KB: one workgroup per CU
 
 int ds_check(const DsArgs& a) {
   if (!a.x || !a.adj || !a.stats || !a.sync || !a.err || a.B <= 0 || a.K <= 0 || a.nstack < 1 || a.nstack > 2) return TSGNN_EINVAL;
