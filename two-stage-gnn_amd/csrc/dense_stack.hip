@@ -714,30 +714,46 @@ __global__ __launch_bounds__(DS_NT) __attribute__((amdgpu_waves_per_eu(DS_NW / 4
     }
   }
   grid_barrier(a.sync, bar, nblocks, a.err);
-  // ---- weight / bias gradients: every element is the sum of the stack's workgroups' slabs, in workgroup order
+  // ---- weight / bias gradients: every element is the sum of the stack's workgroups' slabs, in workgroup order.  The elements of
+  // ALL layers of both stacks are one index space (a slab holds its layers back to back), so every thread of the grid has its
+  // element at once; layer after layer, each loop kept a fifth of the threads busy with eight dependent rounds of loads.
   {
     const int per_stack = tiles * B;
-    for (int ss = 0; ss < a.nstack; ++ss) {
-      const DsStack& T = a.st[ss];
-      for (int l = 0; l < T.L; ++l) {
-        const DsLayer& Ly = T.layer[l];
-        const int64_t ne = (int64_t)(Ly.fin + 1) * Ly.n;
-        for (int64_t e = (int64_t)blockIdx.x * DS_NT + tid; e < ne; e += (int64_t)nblocks * DS_NT) {
-          const float* p = a.slabs + (int64_t)ss * per_stack * a.slab_floats + Ly.slab_off + e;
-          float sacc = 0.f;
-          int w = 0;
-          for (; w + 8 <= per_stack; w += 8) {               // eight slabs in flight, added in workgroup order
-            float v[8];
+    int used[2] = {0, 0};
 #pragma unroll
-            for (int u_ = 0; u_ < 8; ++u_) v[u_] = p[(int64_t)(w + u_) * a.slab_floats];
+    for (int ss = 0; ss < 2; ++ss)
+      if (ss < a.nstack)
 #pragma unroll
-            for (int u_ = 0; u_ < 8; ++u_) sacc += v[u_];
-          }
-          for (; w < per_stack; ++w) sacc += p[(int64_t)w * a.slab_floats];
-          if (e < (int64_t)Ly.fin * Ly.n) { if (Ly.dw) Ly.dw[e] = sacc; }
-          else if (Ly.db) Ly.db[e - (int64_t)Ly.fin * Ly.n] = sacc;
-        }
+        for (int l = 0; l < DS_MAXL; ++l)
+          if (l < a.st[ss].L) used[ss] = (int)a.st[ss].layer[l].slab_off + (a.st[ss].layer[l].fin + 1) * a.st[ss].layer[l].n;
+    const int total = used[0] + used[1];
+    for (int g = (int)blockIdx.x * DS_NT + tid; g < total; g += (int)nblocks * DS_NT) {
+      const int ss = g >= used[0] ? 1 : 0;
+      const int e = g - (ss ? used[0] : 0);                 // offset inside the slab
+      const float* p = a.slabs + (int64_t)ss * per_stack * a.slab_floats + e;
+      float sacc = 0.f;
+      int w = 0;
+      for (; w + 16 <= per_stack; w += 16) {               // sixteen slabs in flight, added in workgroup order
+        float v[16];
+#pragma unroll
+        for (int u_ = 0; u_ < 16; ++u_) v[u_] = p[(int64_t)(w + u_) * a.slab_floats];
+#pragma unroll
+        for (int u_ = 0; u_ < 16; ++u_) sacc += v[u_];
       }
+      for (; w < per_stack; ++w) sacc += p[(int64_t)w * a.slab_floats];
+      // which layer's dw / db entry this is (compile-time walk over the descriptions: no dynamic indexing of the arguments)
+      float* dst = nullptr;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int l = 0; l < DS_MAXL; ++l) {
+          if (s2 < a.nstack && l < a.st[s2].L && s2 == ss) {
+            const DsLayer& Ly = a.st[s2].layer[l];
+            const int o = e - (int)Ly.slab_off, nw = Ly.fin * Ly.n;
+            if (o >= 0 && o < nw + Ly.n) dst = o < nw ? (Ly.dw ? Ly.dw + o : nullptr) : (Ly.db ? Ly.db + (o - nw) : nullptr);
+          }
+        }
+      if (dst) *dst = sacc;
     }
   }
   // ---- the stacks' input gradients add up (two stacks: both read the same x and adjacency)
