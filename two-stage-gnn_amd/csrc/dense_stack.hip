@@ -20,6 +20,15 @@
 #include <utility>
 #include "../../include/tsgnn.h"
 
+// developer timeline stamps (scripts/trace_dense_stack.hip): forward by default, backward with -DTSGNN_TRACE_BWD
+#ifdef TSGNN_TRACE_BWD
+#define TRF(x) do { } while (0)
+#define TRB(x) TR(x)
+#else
+#define TRF(x) TR(x)
+#define TRB(x) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int DS_TR = 16;                 // rows per tile
@@ -337,7 +346,7 @@ __global__ __launch_bounds__(DS_NT) __attribute__((amdgpu_waves_per_eu(DS_NW / 4
   const int64_t row = (int64_t)b * K + r0 + min(r, nrows - 1);     // (threads of missing rows shadow the tile's last row: no stores)
   const bool rok = main_t && r < nrows;
   int bar = 0;
-  TR(0);
+  TRF(0);
   Pf<DS_PFW> wpf;                                            // the layer's weights, on their way while the phases before their product run
   pf_load(wpf, S.layer[0].w, S.layer[0].ldw, S.layer[0].fin, S.layer[0].n);
   zero_lds(At, DS_TR * DS_LDA);
@@ -389,7 +398,7 @@ __global__ __launch_bounds__(DS_NT) __attribute__((amdgpu_waves_per_eu(DS_NW / 4
       });
     }
     __syncthreads();
-    if (l == 0) TR(1);
+    if (l == 0) TRF(1);
     // (2) agg tile = A[tile rows, :] . xin   (rows beyond the tile are zero rows of At)
     tile_mfma(aggt, lda, At, DS_LDA, 1, big, ldx, K, finP >> 4);
     __syncthreads();
@@ -402,9 +411,9 @@ __global__ __launch_bounds__(DS_NT) __attribute__((amdgpu_waves_per_eu(DS_NW / 4
         if (j < Jf && c < fin) *reinterpret_cast<float4*>(Ly.agg + row * fin + c) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
       }
     }
-    if (l == 0) TR(2);
+    if (l == 0) TRF(2);
     // (3) u = agg . W + bias (W went to big2 under the previous barrier / at the start), row L2 normalise
-    if (l == 0) TR(3);
+    if (l == 0) TRF(3);
     // the bias, requested before the product from clamped addresses (per-element `bias ? bias[c] : 0` loads were waited for one
     // by one); no bias: the same requests go to the weights and are discarded
     float4 bias4[3];
@@ -431,7 +440,7 @@ __global__ __launch_bounds__(DS_NT) __attribute__((amdgpu_waves_per_eu(DS_NW / 4
         if (j < Jn && c < N) { u[j][q] += bq[q]; ss = fmaf(u[j][q], u[j][q], ss); } else u[j][q] = 0.f;
       }
     }
-    if (l == 0) TR(4);
+    if (l == 0) TRF(4);
     ss = row16_sum(ss);                                    // the 16 lanes of a row are one DPP row
     const float ri = fminf(__builtin_amdgcn_rsqf(ss), 1.0f / DS_NORM_EPS);
     float s1 = 0.f, s2 = 0.f;
@@ -455,7 +464,7 @@ __global__ __launch_bounds__(DS_NT) __attribute__((amdgpu_waves_per_eu(DS_NW / 4
       s1 = row16_sum(s1); s2 = row16_sum(s2);
       float* st = a.stats + ((int64_t)l * a.nstack * R + (int64_t)s * R) * 2;
       if (rok && cg == 0) ds_put2(st + row * 2, s1, s2);
-      if (l == 0) TR(5);
+      if (l == 0) TRF(5);
       // one tile per graph: only the partial sums cross workgroups here; else the sibling tiles' rows of v do too.  While the
       // arrivals travel, the next layer's weights (in registers since a layer ago) go to big2 and the ones after are requested
       if (tiles == 1) grid_arrive<true>(a.sync, bar);
@@ -469,7 +478,7 @@ __global__ __launch_bounds__(DS_NT) __attribute__((amdgpu_waves_per_eu(DS_NW / 4
       }
       if (tiles == 1) grid_wait<true>(a.sync, bar, nblocks, a.err);
       else grid_wait(a.sync, bar, nblocks, a.err);
-      if (l == 0) TR(6);
+      if (l == 0) TRF(6);
       // every workgroup finishes the statistics of all K slots
       if (tid < K) {
         float t1, t2;
@@ -482,12 +491,14 @@ __global__ __launch_bounds__(DS_NT) __attribute__((amdgpu_waves_per_eu(DS_NW / 4
         if (b == 0 && t == 0) { Ly.mean[tid] = m; Ly.rstd[tid] = rstd; }
       }
       __syncthreads();
-      if (l == 0) TR(7);
-      if (l == 1) TR(8);
+      if (l == 0) TRF(7);
+      if (l == 1) TRF(8);
     }
   }
-  TR(9);
+  TRF(9);
+#ifndef TSGNN_TRACE_BWD
   TR_END();
+#endif
   grid_finish(a.sync, bar, nblocks);
 }
 
@@ -522,9 +533,12 @@ __global__ __launch_bounds__(DS_NT) __attribute__((amdgpu_waves_per_eu(DS_NW / 4
   __syncthreads();
   if ((nrows & 3) == 0) fill_lds<false>(At, DS_TR, a.adj + (int64_t)b * K * K + r0, K, K, nrows, Ident());   // At[rr][mm] = A[rr][r0 + mm]
   else for (int i = tid; i < K * nrows; i += DS_NT) { const int rr = i / nrows, mm = i - rr * nrows; At[rr * DS_TR + mm] = a.adj[((int64_t)b * K + rr) * K + r0 + mm]; }
+  TRB(0);
   for (int l = S.L - 1; l >= 0; --l) {
+    const bool trl = l == S.L - 2;                           // the stamped layer: one with a batch-norm barrier
     const DsLayer& Ly = S.layer[l];
     const int fin = Ly.fin, N = Ly.n, finP = pad64(fin), NP = pad64(N), Jf = finP >> 6, Jn = NP >> 6;
+    if (trl) TRB(1);
     const int ldu = NP + 20, ldf = finP + DS_PADB, lda = finP + 4;    // ldu: the du tile is a B operand (P2) and an A operand (P3)
     const bool last = l == S.L - 1;
     // ---- P1: dy = dout block (+ the gradient from the layer above), then back through BN / ReLU / L2 normalise -> du
@@ -569,6 +583,7 @@ __global__ __launch_bounds__(DS_NT) __attribute__((amdgpu_waves_per_eu(DS_NW / 4
       p1 = row16_sum(p1); p2 = row16_sum(p2);
       float* st = a.stats + ((int64_t)l * a.nstack * R + (int64_t)s * R) * 2;
       if (rok && cg == 0) ds_put2(st + row * 2, p1, p2);
+      if (trl) TRB(2);
       grid_arrive<true>(a.sync, bar);                      // (only the partial sums cross workgroups here)
     } else {
       __syncthreads();                                     // (the layer above's readers of aggt / big are done)
@@ -590,7 +605,9 @@ __global__ __launch_bounds__(DS_NT) __attribute__((amdgpu_waves_per_eu(DS_NW / 4
       const float mean_l = Ly.mean[rs_], rstd_l = Ly.rstd[rs_];
       const float mean = rok ? mean_l : 0.f, rstd = rok ? rstd_l : 1.f;
       float* st = a.stats + ((int64_t)l * a.nstack * R + (int64_t)s * R) * 2;
+      if (trl) TRB(3);
       grid_wait<true>(a.sync, bar, nblocks, a.err);
+      if (trl) TRB(4);
       if (tid < K) {
         float t1, t2;
         slot_totals(st, B, K, tid, t1, t2);
@@ -631,6 +648,7 @@ __global__ __launch_bounds__(DS_NT) __attribute__((amdgpu_waves_per_eu(DS_NW / 4
                               ri * (dv[j][3] - vv[j][3] * dot))
                 : make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
+    if (trl) TRB(5);
     // ---- P2: this tile's share of dW = agg^T du (MFMA: M = fin, N = n, depth = the tile's 16 rows) and db = colsum(du) -> the
     //          workgroup's slab (the slabs are summed in a fixed order at the end)
     {
@@ -662,6 +680,7 @@ __global__ __launch_bounds__(DS_NT) __attribute__((amdgpu_waves_per_eu(DS_NW / 4
         sl[fin * N + c] = sacc;
       }
     }
+    if (trl) TRB(6);
     // ---- P3: dagg tile = du . W^T   (W^T [n][finP + 16] went to LDS under the barrier: the product has the forward's shape)
     __syncthreads();                                       // (P2's readers of aggt are done)
     tile_mfma(aggt, lda, dut, ldu, 1, big, ldf, N, finP >> 4);
@@ -675,6 +694,7 @@ __global__ __launch_bounds__(DS_NT) __attribute__((amdgpu_waves_per_eu(DS_NW / 4
         if (j < Jf && k < fin) *reinterpret_cast<float4*>(daggS + row * a.finmax + k) = make_float4(dg[j][0], dg[j][1], dg[j][2], dg[j][3]);
       }
     }
+    if (trl) TRB(7);
     // ---- P4: dA[tile rows, m] += dagg[r, :] . xin[m, :]   (xin^T [fin][80] in LDS; the dA tile lands in the du tile's place)
     if (a.dadj) {                                          // (xin^T went to big2 under the barrier)
       tile_mfma(dut, 64, aggt, lda, 1, big2, 80, fin, 4);
@@ -682,10 +702,12 @@ __global__ __launch_bounds__(DS_NT) __attribute__((amdgpu_waves_per_eu(DS_NW / 4
       const float4 v = *reinterpret_cast<const float4*>(dut + r * 64 + 4 * cg);
       dadj_acc[0] += v.x; dadj_acc[1] += v.y; dadj_acc[2] += v.z; dadj_acc[3] += v.w;
     }
+    if (trl) TRB(8);
     // ---- P5: dx[tile rows m, :] = sum_r A[r, m] dagg[r, :] over ALL rows r of the graph: the sibling tiles' dagg first
     if (l > 0 || a.dx) {
       if (tiles == 1) __syncthreads();                       // the graph is this tile: its dagg rows are the workgroup's own writes
       else grid_barrier(a.sync, bar, nblocks, a.err);
+      if (trl) TRB(9);
       if (finP != fin) zero_lds(big, K * ldf);
       __syncthreads();
       fill_lds<false>(big, ldf, daggS + (int64_t)b * K * a.finmax, a.finmax, K, fin, Ident());
@@ -703,6 +725,7 @@ __global__ __launch_bounds__(DS_NT) __attribute__((amdgpu_waves_per_eu(DS_NW / 4
       }
     }
   }
+  TRB(10);
   // ---- dA tile of this stack
   if (a.dadj) {
     float* dst = a.nstack == 1 ? a.dadj : a.dadj_part + (int64_t)s * R * K;
@@ -714,6 +737,7 @@ __global__ __launch_bounds__(DS_NT) __attribute__((amdgpu_waves_per_eu(DS_NW / 4
     }
   }
   grid_barrier(a.sync, bar, nblocks, a.err);
+  TRB(11);
   // ---- weight / bias gradients: every element is the sum of the stack's workgroups' slabs, in workgroup order.  The elements of
   // ALL layers of both stacks are one index space (a slab holds its layers back to back), so every thread of the grid has its
   // element at once; layer after layer, each loop kept a fifth of the threads busy with eight dependent rounds of loads.
@@ -756,6 +780,7 @@ __global__ __launch_bounds__(DS_NT) __attribute__((amdgpu_waves_per_eu(DS_NW / 4
       if (dst) *dst = sacc;
     }
   }
+  TRB(12);
   // ---- the stacks' input gradients add up (two stacks: both read the same x and adjacency)
   if (a.dx) {
     const int f0 = a.fin0;
@@ -771,6 +796,10 @@ __global__ __launch_bounds__(DS_NT) __attribute__((amdgpu_waves_per_eu(DS_NW / 4
     for (int64_t e = (int64_t)blockIdx.x * DS_NT + tid; e < (int64_t)R * K; e += (int64_t)nblocks * DS_NT)
       a.dadj[e] = (a.dadj_part[e] + a.dadj_part[(int64_t)R * K + e]) + (a.dadj_add ? a.dadj_add[e] : 0.f);
   }
+  TRB(13);
+#ifdef TSGNN_TRACE_BWD
+  TR_END();
+#endif
   grid_finish(a.sync, bar, nblocks);
 }
 
