@@ -18,7 +18,7 @@ int main() {
   std::vector<int64_t> d(19 + 2 * (5 + 4 * 14) + 1, 0);
   auto P = [](void* p) { return (int64_t)(uintptr_t)p; };
   d[0] = P(x); d[1] = fin0; d[2] = fin0; d[3] = P(adj); d[4] = B; d[5] = K; d[6] = nstack;
-  d[7] = P(dmalloc(4 * nstack * R * 2)); d[8] = P(dmalloc(64)); d[9] = P(dmalloc(4));
+  d[7] = P(dmalloc(4 * nstack * R * 2)); d[8] = P(dmalloc(32 + 256)); d[9] = P(dmalloc(4));
   int o = 19;
   for (int s = 0; s < 2; ++s) {
     const int widths[3] = {H, H, s == 0 ? 64 : 8};

@@ -69,7 +69,7 @@ struct DsArgs {
   float* dadj_part;           // [nstack][B*K*K] when two stacks contribute
   const float* dadj_add;      // nullable [B*K*K]: the gradient ANOTHER consumer of the same adjacency already produced (the next
                               // level's contraction, through the node's adjacency pass-through), summed into dadj here
-  unsigned* sync; float* err;   // sync: 32 words, zero before the first launch (barrier words + sign-off counter)
+  unsigned* sync; float* err;   // sync: 32 + 256 words, zero before the first launch (barrier words, sign-off counter, per-graph words)
 };
 
 // Device-wide barrier number k of a launch: its own arrival word (words[k], zero before the launch), bounded spin.  Word k - 1 is
@@ -124,6 +124,23 @@ __device__ __forceinline__ void grid_wait(unsigned* words, int& k, unsigned nblo
     if (k > 0 && blockIdx.x == 0) __hip_atomic_store(words + k - 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   ++k;
+  __syncthreads();
+}
+// Barrier among the `n` workgroups that own the tiles of ONE graph (the exchange of dagg rows before dx = A^T dagg concerns nobody
+// else): its own arrival word (sync[32 + stack * B + graph]), counted up through the launch — the j-th use waits for n * j —
+// and zeroed by the graph's first tile after the launch's last device-wide barrier.  Four arrivals instead of the whole grid's.
+__device__ __forceinline__ void group_barrier(unsigned* word, unsigned target, float* err) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(word, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    bool ok = false;
+    for (int spin = 0; spin < (1 << 21); ++spin) {
+      if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = true; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (!ok) __hip_atomic_store(err, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   __syncthreads();
 }
 // a pair of floats through agent-scope atomics (one 8-byte access): see grid_barrier<LIGHT>
@@ -527,7 +544,7 @@ __global__ __launch_bounds__(DS_NT) __attribute__((amdgpu_waves_per_eu(DS_NW / 4
   float* daggS = a.dagg + (int64_t)s * R * a.finmax;
   float* dxnS = a.dxn + (int64_t)s * R * a.finmax;
   float dadj_acc[4] = {0.f, 0.f, 0.f, 0.f};               // this thread's entries (r, 4 cg + q) of the graph's dA tile
-  int bar = 0;
+  int bar = 0, p5_uses = 0;
   // the adjacency columns of this tile (P5's A operand) are the same for every layer: staged once
   zero_lds(At, K * DS_TR);
   __syncthreads();
@@ -706,7 +723,7 @@ __global__ __launch_bounds__(DS_NT) __attribute__((amdgpu_waves_per_eu(DS_NW / 4
     // ---- P5: dx[tile rows m, :] = sum_r A[r, m] dagg[r, :] over ALL rows r of the graph: the sibling tiles' dagg first
     if (l > 0 || a.dx) {
       if (tiles == 1) __syncthreads();                       // the graph is this tile: its dagg rows are the workgroup's own writes
-      else grid_barrier(a.sync, bar, nblocks, a.err);
+      else group_barrier(a.sync + 32 + s * B + b, (unsigned)tiles * (unsigned)(++p5_uses), a.err);
       if (trl) TRB(9);
       if (finP != fin) zero_lds(big, K * ldf);
       __syncthreads();
@@ -737,6 +754,7 @@ __global__ __launch_bounds__(DS_NT) __attribute__((amdgpu_waves_per_eu(DS_NW / 4
     }
   }
   grid_barrier(a.sync, bar, nblocks, a.err);
+  if (tid == 0 && t == 0 && tiles > 1) __hip_atomic_store(a.sync + 32 + s * B + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
   TRB(11);
   // ---- weight / bias gradients: every element is the sum of the stack's workgroups' slabs, in workgroup order.  The elements of
   // ALL layers of both stacks are one index space (a slab holds its layers back to back), so every thread of the grid has its

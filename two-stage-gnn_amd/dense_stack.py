@@ -170,7 +170,7 @@ def _workspace(dev):
     """(barrier words, error flag) of the device-wide barriers: zeroed once, re-armed by the kernels themselves"""
     w = _ws.get(dev)
     if w is None:
-        w = _ws[dev] = (torch.zeros(32, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.float32, device=dev))
+        w = _ws[dev] = (torch.zeros(32 + 256, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.float32, device=dev))
         mp.DEVICE_ERRORS.append((w[1], "a device-wide barrier of the pooled-level stack kernels (dense_stack.hip) timed out: "
                                        "its workgroups were not all resident; results of that launch are invalid", w[0]))
     return w
