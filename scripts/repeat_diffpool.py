@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""is the DiffPool step (BASELINE config 5) bitwise repeatable?  N eager steps on the same batch and parameters: distinct (loss,
+gradient) results, and where two of them differ."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from two_stage_gnn_amd import dense_encoders as E, synthetic, message_passing as mp
+dev = torch.device("cuda"); torch.manual_seed(0)
+class A: bias = True
+hb5 = synthetic.host_batch(4, 16, "DD", 512)
+g5, x5, lab5 = synthetic.to_device(hb5, dev)
+dpm = E.SoftPoolingGcnEncoder(512, 89, 64, 64, 2, 3, 64, assign_ratio=0.125, num_pooling=2, bn=True, linkpred=False, args=A(),
+                              assign_input_dim=89, final_dim="number_classes").to(dev)
+names = [k for k, p in dpm.named_parameters()]
+res = []
+for it in range(int(os.environ.get("N", "60"))):
+    dpm.zero_grad(set_to_none=True)
+    loss = dpm.loss(dpm(x5, g5, hb5["sizes"], assign_x=x5)[1], lab5)
+    loss.backward(gradient=mp.unit_seed(dev))
+    res.append((loss.detach().clone(), {k: p.grad.clone() for k, p in dpm.named_parameters() if p.grad is not None}))
+torch.cuda.synchronize(); mp.check_device_errors()
+keys = []
+for l, g in res:
+    keys.append((float(l),) + tuple(float(g[k].double().sum()) for k in sorted(g)))
+distinct = sorted(set(keys))
+print("steps", len(res), "distinct results", len(distinct), "losses", sorted(set(k[0] for k in keys))[:5])
+l0, g0 = res[0]
+for i in (1, 2, len(res) - 1):
+    li, gi = res[i]
+    diff = [(k, float((gi[k] - g0[k]).abs().max()), float(g0[k].abs().max())) for k in sorted(g0) if not torch.equal(gi[k], g0[k])]
+    print("step", i, "vs 0: loss equal", bool(torch.equal(li, l0)), "; differing tensors", len(diff), diff[:6])

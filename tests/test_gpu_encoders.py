@@ -376,6 +376,40 @@ def test_diffpool_level0_stack_pairs_equal_separate_stacks(monkeypatch):
         assert err <= 2e-4 * g0[k].abs().max().item() + 1e-8, (k, err)
 
 
+def test_diffpool_first_step_on_a_batch_equals_the_second():
+    """a CSR-native batch builds its neighbour table lazily; built inside one stack's launch record it shifted the two records of
+    the paired first-level stacks against each other, so the FIRST step on a batch ran every launch singly (another product
+    kernel: slightly different numbers than every later step).  Same launches and bitwise the same loss / gradients now"""
+    from two_stage_gnn_amd import dense_encoders as E, synthetic, message_passing as mp, _native as nat
+
+    class A:
+        bias = True
+    torch.manual_seed(0)
+    hb = synthetic.host_batch(4, 6, "DD", 256)
+    g, x, lab = synthetic.to_device(hb, torch.device("cuda"))
+    m = E.SoftPoolingGcnEncoder(256, 89, 64, 64, 2, 3, 64, assign_ratio=0.125, num_pooling=1, bn=True, linkpred=False, args=A(),
+                                assign_input_dim=89, final_dim="number_classes").cuda()
+    res = []
+    for it in range(3):
+        m.zero_grad(set_to_none=True)
+        nat.trace = []
+        try:
+            loss = m.loss(m(x, g, hb["sizes"], assign_x=x)[1], lab)
+            loss.backward(gradient=mp.unit_seed(loss.device))
+            names = [t[0] for t in nat.trace]
+        finally:
+            nat.trace = None
+        res.append((loss.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}, names))
+    mp.check_device_errors()
+    assert res[0][2].count("sage_multi_f32") >= 2 and "csr_to_ell" in res[0][2] and "csr_to_ell" not in res[1][2]
+    assert res[0][2].count("sage_multi_f32") == res[1][2].count("sage_multi_f32") == res[2][2].count("sage_multi_f32")
+    assert res[0][2].count("gather_rowgemm_f32") == res[1][2].count("gather_rowgemm_f32")     # (nothing ran singly the first time)
+    for later in res[1:]:
+        assert torch.equal(later[0], res[0][0])
+        for k, v in res[0][1].items():
+            assert torch.equal(later[1][k], v), k
+
+
 def test_gat_column_softmax_mass_at_baseline_size():
     """attention aggregation on the full DD-shaped 32-graph batch (packed rows + one ghost representative per graph, 4 heads x
     64): every COLUMN j of the (column-)softmax of encoders_GAT.py:41-45 hands out exactly one unit of mass — to its neighbours

@@ -528,6 +528,13 @@ def sage_stack_nodes_pair(xa, xb, g, convs_a, convs_b, mask_ghost):
         params.append(c.weight)
         params.append(c.bias if has_bias else c.weight.new_zeros(1))
     nodes = 2 if (mask_ghost and g.n_ghost) else 1
+    # lazily built structures of the batch are built NOW: a build launch recorded inside one stack's launch record shifts it
+    # against the other's, and the first step on a batch would run every launch singly (a different — split-K — product
+    # kernel, so also slightly different numbers than every later step)
+    if mp.ell_ok(xa) and g.val is None:
+        g.ell()
+        if not g.symmetric:
+            g.transposed()
     return _SageStackPair.apply(xa, xb, g, has_bias, nodes, nodes, 2 * len(convs_a), *params)
 
 
