@@ -6,6 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from two_stage_gnn_amd import dense_encoders as E, synthetic, message_passing as mp
 dev = torch.device("cuda"); torch.manual_seed(0)
 class A: bias = True
+S = torch.cuda.Stream(); torch.cuda.set_stream(S)         # (everything on the stream the capture below uses)
 hb5 = synthetic.host_batch(4, 16, "DD", 512)
 g5, x5, lab5 = synthetic.to_device(hb5, dev)
 dpm = E.SoftPoolingGcnEncoder(512, 89, 64, 64, 2, 3, 64, assign_ratio=0.125, num_pooling=2, bn=True, linkpred=False, args=A(),
@@ -28,3 +29,27 @@ for i in (1, 2, len(res) - 1):
     li, gi = res[i]
     diff = [(k, float((gi[k] - g0[k]).abs().max()), float(g0[k].abs().max())) for k in sorted(g0) if not torch.equal(gi[k], g0[k])]
     print("step", i, "vs 0: loss equal", bool(torch.equal(li, l0)), "; differing tensors", len(diff), diff[:6])
+
+# ---- the same under hipGraph replay (kernels back to back: the barriers of the pooled-level stacks at full speed)
+del res
+def step():
+    dpm.zero_grad(set_to_none=True)
+    l = dpm.loss(dpm(x5, g5, hb5["sizes"], assign_x=x5)[1], lab5)
+    l.backward(gradient=mp.unit_seed(dev))
+    return l
+for _ in range(3): step()
+torch.cuda.synchronize()
+gr = torch.cuda.CUDAGraph()
+with torch.cuda.graph(gr, stream=S):
+    lg = step()
+grads = [p.grad for p in dpm.parameters() if p.grad is not None]
+NR = int(os.environ.get("REPLAYS", "1000"))
+seen = set()
+for it in range(NR):
+    gr.replay()
+    if it % 10 == 9 or it < 5:                       # (read back every tenth replay: the rest run back to back)
+        torch.cuda.synchronize()
+        seen.add((float(lg),) + tuple(float(t.double().sum()) for t in grads))
+torch.cuda.synchronize(); mp.check_device_errors()
+print("hipGraph replays", NR, ": distinct (loss, gradient sums) among the sampled replays:", len(seen), "; equal to the eager result:",
+      (float(lg),) + tuple(float(g0[k].double().sum()) for k in [n for n, p in dpm.named_parameters() if p.grad is not None]) in seen)
