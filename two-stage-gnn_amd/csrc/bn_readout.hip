@@ -252,9 +252,9 @@ __global__ __launch_bounds__(256) void readout_max_direct(SlotArgs s, const floa
       int64_t rr[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int n = n0 + u;
-        rr[u] = n < sz ? (int64_t)g0 + n : s.n_real + n;
-        val[u] = n < nslots ? x[rr[u] * ld + f] : 0.f;
+        const int n = min(n0 + u, nslots - 1);                 // clamped: the eight requests are unconditional (a load inside its
+        rr[u] = n < sz ? (int64_t)g0 + n : s.n_real + n;       // own `n < nslots ?` was waited for before the next was issued)
+        val[u] = x[rr[u] * ld + f];
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
