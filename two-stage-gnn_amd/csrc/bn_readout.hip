@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void readout_max_partial(SlotArgs s, const flo
   }
 }
 // nmax <= 64 (the pooled DiffPool levels: 64- and 8-node graphs): one chunk per graph, so neither the zeroed packed buffer,
-// nor atomics, nor the decode launch are needed — block b scans graph b's slots, thread per feature, eight slots in flight
+// nor atomics, nor the decode launch are needed — block b scans graph b's slots, thread per feature, sixteen slots in flight
 __global__ __launch_bounds__(256) void readout_max_direct(SlotArgs s, const float* __restrict__ x, int64_t ld, int F, int relu,
                                                           float* __restrict__ out, int64_t ldo, int* __restrict__ arg) {
   const int b = blockIdx.x;
@@ -247,17 +247,17 @@ __global__ __launch_bounds__(256) void readout_max_direct(SlotArgs s, const floa
   const int nslots = s.n_ghost ? s.nmax : sz;
   for (int f = threadIdx.x; f < F; f += 256) {
     unsigned long long best = 0ull;
-    for (int n0 = 0; n0 < nslots; n0 += 8) {
-      float val[8];
-      int64_t rr[8];
+    for (int n0 = 0; n0 < nslots; n0 += 16) {
+      float val[16];
+      int64_t rr[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < 16; ++u) {
         const int n = min(n0 + u, nslots - 1);                 // clamped: the eight requests are unconditional (a load inside its
         rr[u] = n < sz ? (int64_t)g0 + n : s.n_real + n;       // own `n < nslots ?` was waited for before the next was issued)
         val[u] = x[rr[u] * ld + f];
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < 16; ++u) {
         if (n0 + u < nslots) {
           const unsigned long long p = ((unsigned long long)f32_ordered(act(val[u], relu)) << 32) |
                                        (unsigned long long)(0xFFFFFFFFu - (unsigned)rr[u]);
