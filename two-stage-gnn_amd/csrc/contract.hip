@@ -16,15 +16,29 @@ constexpr int CT_THREADS = 512;
 
 struct CtDims {
   int N, K, F;              // nodes, clusters, features
-  int ldS, ldZ, ldA, ldT;   // padded LDS row lengths: K+1, F+1, N+1, N+1
+  int ldS, ldZ, ldA, ldT;   // padded LDS row lengths: K+1, F+1, N+1, N+1 (operands whose ROWS the lanes walk: odd strides)
+  int ldDX, ldDT;           // backward: dX' [K][F], dT [K][N] are read as 16-byte fragments along a row: unpadded, 16-byte aligned
 };
-__host__ __device__ inline CtDims ct_dims(int N, int K, int F) { return CtDims{N, K, F, K + 1, F + 1, N + 1, N + 1}; }
-// floats of LDS: S, Z, A, T (+ backward: dX', dA', dT)
+__host__ __device__ inline int ct_up4(int n) { return (n + 3) & ~3; }
+__host__ __device__ inline CtDims ct_dims(int N, int K, int F) { return CtDims{N, K, F, K + 1, F + 1, N + 1, N + 1, ct_up4(F), ct_up4(N)}; }
+// floats of LDS: S, Z, A, T (+ backward: dX', dA', dT); every region starts on a 16-byte boundary
 inline size_t ct_lds_floats(int N, int K, int F, bool bwd) {
-  size_t n = (size_t)N * (K + 1) + (size_t)N * (F + 1) + (size_t)N * (N + 1) + (size_t)K * (N + 1);
-  if (bwd) n += (size_t)K * (F + 1) + (size_t)K * (K + 1) + (size_t)K * (N + 1);
+  size_t n = (size_t)ct_up4(N * (K + 1)) + (size_t)ct_up4(N * (F + 1)) + (size_t)ct_up4(N * (N + 1)) + (size_t)ct_up4(K * (N + 1));
+  if (bwd) n += (size_t)K * ct_up4(F) + (size_t)ct_up4(K * (K + 1)) + (size_t)K * ct_up4(N);
   return n;
 }
+// x / d by a float reciprocal and one correction step (exact for x < 2^22, d <= 4096): the element loops below computed a
+// (row, column) pair per output with a ~35-instruction integer division
+struct CtDiv {
+  float inv; int d;
+  __device__ __forceinline__ explicit CtDiv(int d_) : inv(1.0f / (float)d_), d(d_) {}
+  __device__ __forceinline__ int operator()(int x) const {
+    int q = (int)(((float)x + 0.5f) * inv);
+    const int r = x - q * d;
+    q += (r >= d) - (r < 0);
+    return q;
+  }
+};
 
 // rows x cols contiguous floats -> LDS rows of stride ld.  Eight requests in flight per thread before the first LDS store (a
 // load-then-store loop is one dependent L2 round trip per iteration: 24 trips for a 64 x 192 operand).
@@ -95,9 +109,9 @@ __global__ __launch_bounds__(CT_THREADS) void contract_dense_fwd_kernel(const fl
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const CtDims d = ct_dims(N, K, F);
   float* S = sm;
-  float* Z = S + N * d.ldS;
-  float* A = Z + N * d.ldZ;
-  float* T = A + N * d.ldA;
+  float* Z = S + ct_up4(N * d.ldS);
+  float* A = Z + ct_up4(N * d.ldZ);
+  float* T = A + ct_up4(N * d.ldA);
   const int b = blockIdx.x;
   const float* sb = s + (int64_t)b * N * K;
   const float* zb = z + (int64_t)b * N * F;
@@ -112,15 +126,16 @@ __global__ __launch_bounds__(CT_THREADS) void contract_dense_fwd_kernel(const fl
   }
   __syncthreads();
   // X' = S^T Z   [K, F]
+  const CtDiv byF(F), byN(N), byK(K);
   for (int i = threadIdx.x; i < K * F; i += CT_THREADS) {
-    const int k = i / F, f = i - k * F;
+    const int k = byF(i), f = i - k * F;
     float acc = 0.f;
     for (int n = 0; n < N; ++n) acc = fmaf(S[n * d.ldS + k], Z[n * d.ldZ + f], acc);
     xo[(int64_t)b * K * F + i] = acc;
   }
   // T = S^T A   [K, N]
   for (int i = threadIdx.x; i < K * N; i += CT_THREADS) {
-    const int k = i / N, m = i - k * N;
+    const int k = byN(i), m = i - k * N;
     float acc = 0.f;
     for (int n = 0; n < N; ++n) acc = fmaf(S[n * d.ldS + k], A[n * d.ldA + m], acc);
     T[k * d.ldT + m] = acc;
@@ -129,7 +144,7 @@ __global__ __launch_bounds__(CT_THREADS) void contract_dense_fwd_kernel(const fl
   __syncthreads();
   // A' = T S    [K, K]
   for (int i = threadIdx.x; i < K * K; i += CT_THREADS) {
-    const int k = i / K, l = i - k * K;
+    const int k = byK(i), l = i - k * K;
     float acc = 0.f;
     for (int m = 0; m < N; ++m) acc = fmaf(T[k * d.ldT + m], S[m * d.ldS + l], acc);
     ao[(int64_t)b * K * K + i] = acc;
@@ -144,12 +159,12 @@ __global__ __launch_bounds__(CT_THREADS) void contract_dense_bwd_kernel(const fl
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const CtDims d = ct_dims(N, K, F);
   float* S = sm;
-  float* Z = S + N * d.ldS;
-  float* A = Z + N * d.ldZ;
-  float* T = A + N * d.ldA;
-  float* DX = T + K * d.ldT;           // [K][F+1]
-  float* DA = DX + K * d.ldZ;          // [K][K+1]
-  float* DT = DA + K * d.ldS;          // [K][N+1]
+  float* Z = S + ct_up4(N * d.ldS);
+  float* A = Z + ct_up4(N * d.ldZ);
+  float* T = A + ct_up4(N * d.ldA);
+  float* DX = T + ct_up4(K * d.ldT);   // [K][up4(F)]
+  float* DA = DX + K * d.ldDX;         // [K][K+1]
+  float* DT = DA + ct_up4(K * d.ldS);  // [K][up4(N)]
   const int b = blockIdx.x;
   const float* sb = s + (int64_t)b * N * K;
   const float* dxb = dxo + (int64_t)b * K * F;
@@ -159,15 +174,15 @@ __global__ __launch_bounds__(CT_THREADS) void contract_dense_bwd_kernel(const fl
   const float* tb = ds ? t + (int64_t)b * K * N : nullptr;
   const bool vec = ct_vec_ok(sb, K) && ct_vec_ok(dxb, F) && ct_vec_ok(dab, K) && ct_vec_ok(zb, F) && ct_vec_ok(ab, N) && ct_vec_ok(tb, N);
   if (vec && ds) {
-    const CtOp ops[6] = {{sb, S, d.ldS, K, N * K / 4}, {dxb, DX, d.ldZ, F, K * F / 4}, {dab, DA, d.ldS, K, K * K / 4},
+    const CtOp ops[6] = {{sb, S, d.ldS, K, N * K / 4}, {dxb, DX, d.ldDX, F, K * F / 4}, {dab, DA, d.ldS, K, K * K / 4},
                          {zb, Z, d.ldZ, F, N * F / 4}, {ab, A, d.ldA, N, N * N / 4}, {tb, T, d.ldT, N, K * N / 4}};
     ct_load_many<6>(ops);
   } else if (vec) {
-    const CtOp ops[3] = {{sb, S, d.ldS, K, N * K / 4}, {dxb, DX, d.ldZ, F, K * F / 4}, {dab, DA, d.ldS, K, K * K / 4}};
+    const CtOp ops[3] = {{sb, S, d.ldS, K, N * K / 4}, {dxb, DX, d.ldDX, F, K * F / 4}, {dab, DA, d.ldS, K, K * K / 4}};
     ct_load_many<3>(ops);
   } else {
     ct_load(S, d.ldS, sb, N, K);
-    ct_load(DX, d.ldZ, dxb, K, F);
+    ct_load(DX, d.ldDX, dxb, K, F);
     ct_load(DA, d.ldS, dab, K, K);
     if (ds) {
       ct_load(Z, d.ldZ, zb, N, F);
@@ -176,19 +191,35 @@ __global__ __launch_bounds__(CT_THREADS) void contract_dense_bwd_kernel(const fl
     }
   }
   __syncthreads();
+  const CtDiv byN(N);
+  const bool v4 = (F & 3) == 0 && (N & 3) == 0;            // outputs as 16-byte fragments (dX' and dT rows are 16-byte aligned in LDS)
   // dT = dA' S^T   [K, N]
   for (int i = threadIdx.x; i < K * N; i += CT_THREADS) {
-    const int k = i / N, m = i - k * N;
+    const int k = byN(i), m = i - k * N;
     float acc = 0.f;
     for (int l = 0; l < K; ++l) acc = fmaf(DA[k * d.ldS + l], S[m * d.ldS + l], acc);
-    DT[k * d.ldT + m] = acc;
+    DT[k * d.ldDT + m] = acc;
   }
   // dZ = S dX'     [N, F]
-  if (dz) {
+  if (dz && v4) {
+    const int F4 = F >> 2;
+    const CtDiv byF4(F4);
+    for (int i = threadIdx.x; i < N * F4; i += CT_THREADS) {
+      const int n = byF4(i), f4 = i - n * F4;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int k = 0; k < K; ++k) {
+        const float sv = S[n * d.ldS + k];
+        const float4 x4 = *reinterpret_cast<const float4*>(DX + k * d.ldDX + 4 * f4);
+        acc.x = fmaf(sv, x4.x, acc.x); acc.y = fmaf(sv, x4.y, acc.y); acc.z = fmaf(sv, x4.z, acc.z); acc.w = fmaf(sv, x4.w, acc.w);
+      }
+      *reinterpret_cast<float4*>(dz + (int64_t)b * N * F + 4 * (int64_t)i) = acc;
+    }
+  } else if (dz) {
+    const CtDiv byF(F);
     for (int i = threadIdx.x; i < N * F; i += CT_THREADS) {
-      const int n = i / F, f = i - n * F;
+      const int n = byF(i), f = i - n * F;
       float acc = 0.f;
-      for (int k = 0; k < K; ++k) acc = fmaf(S[n * d.ldS + k], DX[k * d.ldZ + f], acc);
+      for (int k = 0; k < K; ++k) acc = fmaf(S[n * d.ldS + k], DX[k * d.ldDX + f], acc);
       dz[(int64_t)b * N * F + i] = acc;
     }
   }
@@ -196,20 +227,33 @@ __global__ __launch_bounds__(CT_THREADS) void contract_dense_bwd_kernel(const fl
   // dS = Z dX'^T + T^T dA' + A dT^T   [N, K]   (the three terms in this order)
   if (ds) {
     for (int i = threadIdx.x; i < N * K; i += CT_THREADS) {
-      const int k = i / N, n = i - k * N;                  // n fastest: lanes walk rows of Z / A (padded: conflict-free)
+      const int k = byN(i), n = i - k * N;                 // n fastest: lanes walk rows of Z / A (padded: conflict-free)
       float acc = 0.f;
-      for (int f = 0; f < F; ++f) acc = fmaf(Z[n * d.ldZ + f], DX[k * d.ldZ + f], acc);
+      for (int f = 0; f < F; ++f) acc = fmaf(Z[n * d.ldZ + f], DX[k * d.ldDX + f], acc);
       for (int l = 0; l < K; ++l) acc = fmaf(T[l * d.ldT + n], DA[l * d.ldS + k], acc);
-      for (int m = 0; m < N; ++m) acc = fmaf(A[n * d.ldA + m], DT[k * d.ldT + m], acc);
+      for (int m = 0; m < N; ++m) acc = fmaf(A[n * d.ldA + m], DT[k * d.ldDT + m], acc);
       ds[(int64_t)b * N * K + (int64_t)n * K + k] = acc;
     }
   }
   // dA = S dT      [N, N]
-  if (dadj) {
+  if (dadj && v4) {
+    const int N4 = N >> 2;
+    const CtDiv byN4(N4);
+    for (int i = threadIdx.x; i < N * N4; i += CT_THREADS) {
+      const int n = byN4(i), m4 = i - n * N4;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int k = 0; k < K; ++k) {
+        const float sv = S[n * d.ldS + k];
+        const float4 t4 = *reinterpret_cast<const float4*>(DT + k * d.ldDT + 4 * m4);
+        acc.x = fmaf(sv, t4.x, acc.x); acc.y = fmaf(sv, t4.y, acc.y); acc.z = fmaf(sv, t4.z, acc.z); acc.w = fmaf(sv, t4.w, acc.w);
+      }
+      *reinterpret_cast<float4*>(dadj + (int64_t)b * N * N + 4 * (int64_t)i) = acc;
+    }
+  } else if (dadj) {
     for (int i = threadIdx.x; i < N * N; i += CT_THREADS) {
-      const int n = i / N, m = i - n * N;
+      const int n = byN(i), m = i - n * N;
       float acc = 0.f;
-      for (int k = 0; k < K; ++k) acc = fmaf(S[n * d.ldS + k], DT[k * d.ldT + m], acc);
+      for (int k = 0; k < K; ++k) acc = fmaf(S[n * d.ldS + k], DT[k * d.ldDT + m], acc);
       dadj[(int64_t)b * N * N + i] = acc;
     }
   }
