@@ -348,16 +348,19 @@ int tsgnn_softmax_ce_f32(const float* logits, int64_t ld, const int64_t* label, 
  * only (after an all-reduce the local shares no longer describe the gradient). */
 int tsgnn_adam_from_partials_f32(float* param, const float* grad, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                                  float eps, float weight_decay, float max_norm, float* state, const float* parts, int nparts,
-                                 tsgnn_stream_t stream);
+                                 const float* poison, tsgnn_stream_t stream);
 /* clip_grad_norm(max_norm) + Adam.step() of the reference loop (train.py:128-129) on one flat fp32
  * parameter / gradient buffer (the buffer RCCL all-reduces): grad is first scaled by grad_scale
- * (1/world_size).  state: 4 floats {step, grad_norm, applied scale, reserved (always 0)} (zeroed before the first
- * step); ws >= 258 floats, 8-byte aligned, zeroed once (word 256 is the sign-off counter of the one-launch variant used
+ * (1/world_size).  state: 4 floats {step, grad_norm, applied scale, skipped} (zeroed before the first step).
+ * poison (nullable, both optimiser entry points): one device float, the device's error word — a kernel with a bounded
+ * device-wide barrier that could not complete it (tsgnn_dense_stack_*_f32) stores a non-zero value there.  The optimiser reads
+ * it first and, if set, leaves parameters, moments and the step counter untouched and sets state[3] = 1: an invalid gradient is
+ * never applied, and the host raises at its next synchronisation; ws >= 258 floats, 8-byte aligned, zeroed once (word 256 is the sign-off counter of the one-launch variant used
  * for n <= 131,072: every block sums the norm of the whole gradient itself, so there is NO device-wide barrier, no
  * co-residency assumption and no partial update; larger n: norm partials, norm, update = three launches). */
 int tsgnn_clip_adam_step_f32(float* param, const float* grad, float* m, float* v, int64_t n, float lr, float beta1,
                              float beta2, float eps, float weight_decay, float max_norm, float grad_scale, float* state,
-                             float* ws, tsgnn_stream_t stream);
+                             float* ws, const float* poison, tsgnn_stream_t stream);
 
 /* ---------------------------------------------------------------- pooled-level GCN stacks in one launch (dense_stack.hip) */
 
@@ -369,11 +372,19 @@ int tsgnn_dense_stack_supported(int B, int K, int nstack, int L, int fin0, int h
  * v = u / max(|u|, 1e-12), y = BN_slot(ReLU(v)) (apply_bn, :134-138: fresh statistics over batch and features, eps 1e-5, biased
  * variance); last layer: v only; out[:, off_l : off_l + n_l] = the layer's output.  The workgroups (16 rows of one graph each,
  * all resident) meet at a device-wide barrier per hidden layer (per-slot statistics) forward, twice per layer backward; a
- * barrier that is not completed within its bound raises err[0] (checked by the host at its next synchronisation).
+ * barrier that is not completed within its bound raises err[0]: the optimiser entry points skip their update while it is set
+ * (`poison`) and the host raises at its next synchronisation (message_passing.check_device_errors).
  * `desc`: host array of 8-byte words (pointers / integers), layout in csrc/dense_stack.hip::ds_unpack, built by
  * two_stage_gnn_amd/dense_stack.py::_describe. */
 int tsgnn_dense_stack_fwd_f32(const int64_t* desc, tsgnn_stream_t stream);
 int tsgnn_dense_stack_bwd_f32(const int64_t* desc, tsgnn_stream_t stream);
+/* Workgroups of the dense-stack kernels the CURRENT device keeps resident at once (compute units x the runtime's occupancy for
+ * them): the grid limit tsgnn_dense_stack_supported applies.  0 without a usable device. */
+int tsgnn_dense_stack_max_resident(void);
+/* Test hook for the failure path of the bounded device-wide barriers: one workgroup waits for `expect` arrivals on the barrier
+ * words `sync` (>= 32 words, zero).  expect = 1 passes; expect = 2 can never complete: the spin gives up at its bound (~1 s) and
+ * stores 1.0 to *err, as a dense-stack launch does whose workgroups were not all resident. */
+int tsgnn_dense_stack_barrier_selftest(unsigned* sync, float* err, int expect, tsgnn_stream_t stream);
 
 /* ---------------------------------------------------------------- edge-softmax attention (attention.hip) */
 

@@ -11,7 +11,7 @@ with torch.cuda.stream(s):
     gr = torch.cuda.CUDAGraph()
     gr.enable_debug_mode()
     with torch.cuda.graph(gr, stream=s):
-        nat.call("clip_adam_step_f32", p, g, m, v, 1000, 1e-2, 0.9, 0.999, 1e-8, 0.0, 0.7, 0.5, state, ws)
+        nat.call("clip_adam_step_f32", p, g, m, v, 1000, 1e-2, 0.9, 0.999, 1e-8, 0.0, 0.7, 0.5, state, ws, None)
         y = x * 2
     os.makedirs("gpurun_out", exist_ok=True)
     gr.debug_dump("gpurun_out/graph_dump.dot")

@@ -568,7 +568,7 @@ def test_selfnorm_optimiser_sizes_and_replay():
             gbuf.copy_(grads[0])
             torch.cuda.synchronize()
             with torch.cuda.graph(graph, stream=s):
-                nat.call("clip_adam_step_f32", p, gbuf, m, v, n, 1e-2, 0.9, 0.999, 1e-8, 0.0, 0.7, 0.5, state, ws)
+                nat.call("clip_adam_step_f32", p, gbuf, m, v, n, 1e-2, 0.9, 0.999, 1e-8, 0.0, 0.7, 0.5, state, ws, None)
             for gi in grads:
                 gbuf.copy_(gi)
                 graph.replay()
@@ -626,4 +626,59 @@ def test_failed_collective_capture_falls_back_to_two_graphs():
         assert "fell back" in note and "two graphs" in note, note
         assert n_graph == n_eager == 3.0
         np.testing.assert_array_equal(p_graph, p_eager)            # the fall-back step == the eager step, state untouched by the attempt
+    np.testing.assert_array_equal(res[0][1][0][0], res[1][1][0][0])    # replicas identical
+
+
+def _disagree_worker(rank, port, q):
+    """rank 0's capture fails for real (a gloo collective inside a capture); rank 1's capture SUCCEEDS (its all_reduce is left
+    out of the capture, so nothing un-capturable is recorded).  The ranks then disagree about the one-graph step: both must fall
+    back to two graphs, with matched collectives all the way (the failing rank used to skip the verification replay
+    its peer ran — a bucket-sized SUM against a 1-element MIN)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TSGNN_ONE_GRAPH_ANY_BACKEND="1", TSGNN_GRAPH_ALLREDUCE="auto")
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    torch.cuda.set_device(0)
+    from two_stage_gnn_amd import dense_encoders as E, synthetic
+    from two_stage_gnn_amd.data_parallel import FlatTrainer, GraphedStep
+
+    class A:
+        bias = True
+    hb = synthetic.host_batch(seed=rank, B=6, shape="DD", nmax=400)
+    g, x, label = synthetic.to_device(hb, torch.device("cuda"))
+    finals = []
+    for use_graph in (True, False):
+        torch.manual_seed(1)
+        m = E.GcnEncoderGraph(89, 128, 128, 2, 3, bn=True, args=A(), final_dim="number_classes").cuda()
+        tr = FlatTrainer(m, lr=1e-3, clip=2.0)
+        if rank == 1 and use_graph:
+            real = tr.all_reduce
+            tr.all_reduce = lambda: None if torch.cuda.is_current_stream_capturing() else real()
+        gs = GraphedStep(tr, lambda: m.loss(m(x, g)[1], label), warmup=2, use_graph=use_graph)
+        for _ in range(3):
+            gs.step()
+        gs.synchronize()
+        finals.append((tr.flat_param.detach().cpu().numpy(), float(tr.state[0]), gs.describe()))
+    q.put((rank, finals))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_ranks_that_disagree_about_the_capture_fall_back_together():
+    ctx = mp_.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 977) % 2000
+    procs = [ctx.Process(target=_disagree_worker, args=(r, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    notes = [r[1][0][2] for r in res]
+    assert "this rank" in notes[0] and "another rank" in notes[1], notes
+    for rank, ((p_graph, n_graph, note), (p_eager, n_eager, _)) in res:
+        assert "fell back" in note and "two graphs" in note, note
+        assert n_graph == n_eager == 3.0
+        np.testing.assert_array_equal(p_graph, p_eager)
     np.testing.assert_array_equal(res[0][1][0][0], res[1][1][0][0])    # replicas identical

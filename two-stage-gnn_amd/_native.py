@@ -60,38 +60,65 @@ def source_hash():
     return h.hexdigest()
 
 
+_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+
+
+def _object_hash(src, headers):
+    """what one object file depends on: its source, every header it may include, the compile flags"""
+    import hashlib
+    h = hashlib.sha256(" ".join(_FLAGS).encode())
+    for d in [src] + headers:
+        h.update(os.path.basename(d).encode())
+        h.update(open(d, "rb").read())
+    return h.hexdigest()
+
+
 def build(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 -> two-stage-gnn_amd/libtsgnn_hip.so (in-tree, travels with gpurun).  The library is reused
-    only if the hash of the sources it was built from (stored beside it) equals the hash of the sources in the tree: a stale
-    binary is rebuilt whatever its time stamp says."""
+    """hipcc --offload-arch=gfx950 -> two-stage-gnn_amd/libtsgnn_hip.so (in-tree, travels with gpurun).  Nothing is trusted by
+    time stamp: the library is reused only if the hash of the sources it was built from (stored beside it) equals the hash of
+    the sources in the tree, and each object only if ITS hash file does (a tree restored with older mtimes than build/*.o used to
+    re-link stale objects and certify them).  One builder at a time (file lock: the ranks of a torchrun launch may all find the
+    library stale), and the link goes to a temporary name that is renamed into place, so a process that is loading the library
+    never sees a half-written file."""
+    import fcntl
     srcs = sources()
-    deps = srcs + [HEADER] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    cur = source_hash()
-    if not force and os.path.exists(LIB_PATH) and os.path.exists(HASH_PATH) and open(HASH_PATH).read().strip() == cur:
-        return LIB_PATH
-    objs = []
-    procs = []
-    os.makedirs(os.path.join(_PKG_DIR, "build"), exist_ok=True)
-    for s in srcs:
-        o = os.path.join(_PKG_DIR, "build", os.path.basename(s)[:-4] + ".o")
-        objs.append(o)
-        if (not force and os.path.exists(o)
-                and os.path.getmtime(o) >= max(os.path.getmtime(d) for d in [s, HEADER] + [x for x in deps if x.endswith(".h")])):
-            continue
-        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", s, "-o", o]
-        if verbose:
-            print(" ".join(cmd))
-        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-    for s, p in procs:
-        log = p.communicate()[0].decode()
-        if p.returncode != 0:
-            raise RuntimeError("hipcc failed on %s:\n%s" % (s, log))
-    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
-    if r.returncode != 0:
-        raise RuntimeError("link failed:\n" + r.stdout.decode())
-    with open(HASH_PATH, "w") as f:
-        f.write(cur + "\n")
+    headers = sorted([HEADER] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")])
+    bdir = os.path.join(_PKG_DIR, "build")
+    os.makedirs(bdir, exist_ok=True)
+    with open(os.path.join(bdir, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        cur = source_hash()                                  # (after the lock: another process may just have built it)
+        if not force and os.path.exists(LIB_PATH) and os.path.exists(HASH_PATH) and open(HASH_PATH).read().strip() == cur:
+            return LIB_PATH
+        objs = []
+        procs = []
+        for s in srcs:
+            o = os.path.join(bdir, os.path.basename(s)[:-4] + ".o")
+            objs.append(o)
+            oh = _object_hash(s, headers)
+            if not force and os.path.exists(o) and os.path.exists(o + ".hash") and open(o + ".hash").read().strip() == oh:
+                continue
+            if os.path.exists(o + ".hash"):
+                os.remove(o + ".hash")
+            cmd = ["hipcc"] + _FLAGS + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((s, o, oh, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        for s, o, oh, p in procs:
+            log = p.communicate()[0].decode()
+            if p.returncode != 0:
+                raise RuntimeError("hipcc failed on %s:\n%s" % (s, log))
+            with open(o + ".hash", "w") as f:
+                f.write(oh + "\n")
+        tmp = "%s.tmp.%d" % (LIB_PATH, os.getpid())
+        cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n" + r.stdout.decode())
+        os.replace(tmp, LIB_PATH)
+        with open(HASH_PATH + ".tmp", "w") as f:
+            f.write(cur + "\n")
+        os.replace(HASH_PATH + ".tmp", HASH_PATH)
     global _lib
     _lib = None
     return LIB_PATH

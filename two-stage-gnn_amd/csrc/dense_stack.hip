@@ -79,11 +79,19 @@ struct DsArgs {
 // LIGHT: for exchanges whose data travels in agent-scope ATOMIC stores / loads only (ds_put2 / ds_get2 below: the per-row
 // batch-norm partial sums, 8 bytes a row).  Those accesses are coherent across the XCDs by themselves (sc1), so the barrier needs
 // neither the L2 write-back of a release at agent scope nor the L2 invalidate of an acquire — which is what a device-wide barrier
-// costs here (the kernel's own dirty lines flushed, the weights re-fetched afterwards): the stores are complete when the
-// workgroup-scope fence of the __syncthreads() ahead of the arrival has passed (s_waitcnt vmcnt(0)), the arrival and the
-// spin are relaxed.  Nothing else written before a LIGHT barrier may be read by another workgroup after it.
+// costs here (the kernel's own dirty lines flushed, the weights re-fetched afterwards).  What it DOES need is that every thread's
+// own ds_put2 stores have been acknowledged before the workgroup's arrival is issued: the stores and the arrival go to different
+// L2 channels, which are not ordered against each other, and on gfx950 __syncthreads() does NOT wait for outstanding global
+// stores (the ISA showed global_store -> s_barrier -> global_atomic_add with no vmcnt wait: ADVICE r2).  drain_stores() is that
+// wait — `s_waitcnt vmcnt(0)` by every thread ahead of the s_barrier, no cache maintenance.  The arrival and the spin are relaxed.
+// Nothing else written before a LIGHT barrier may be read by another workgroup after it.
+// The full barriers drain too: their agent-scope release (buffer_wbl2 sc1 + s_waitcnt vmcnt(0)) is executed by thread 0 ALONE and
+// waits for thread 0's wave's stores only; the write-back covers the other waves' data once it has reached the L2, which is what
+// their own vmcnt(0) ahead of the s_barrier guarantees (hip's grid.sync() has every thread fence for the same reason).
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 template <bool LIGHT = false>
 __device__ __forceinline__ void grid_barrier(unsigned* words, int& k, unsigned nblocks, float* err) {
+  drain_stores();
   __syncthreads();
   if (threadIdx.x == 0) {
     if (LIGHT) __hip_atomic_fetch_add(words + k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -105,6 +113,7 @@ __device__ __forceinline__ void grid_barrier(unsigned* words, int& k, unsigned n
 // forward data (not produced by this launch) are staged into LDS while the arrivals travel.
 template <bool LIGHT = false>
 __device__ __forceinline__ void grid_arrive(unsigned* words, int k) {
+  drain_stores();
   __syncthreads();
   if (threadIdx.x == 0) {
     if (LIGHT) __hip_atomic_fetch_add(words + k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -130,6 +139,7 @@ __device__ __forceinline__ void grid_wait(unsigned* words, int& k, unsigned nblo
 // else): its own arrival word (sync[32 + stack * B + graph]), counted up through the launch — the j-th use waits for n * j —
 // and zeroed by the graph's first tile after the launch's last device-wide barrier.  Four arrivals instead of the whole grid's.
 __device__ __forceinline__ void group_barrier(unsigned* word, unsigned target, float* err) {
+  drain_stores();
   __syncthreads();
   if (threadIdx.x == 0) {
     __hip_atomic_fetch_add(word, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -823,6 +833,38 @@ __global__ __launch_bounds__(DS_NT) __attribute__((amdgpu_waves_per_eu(DS_NW / 4
 
 constexpr size_t ds_lds_bytes() { return sizeof(float) * (2 * DS_BIG + DS_TR * 68 + DS_TR * 196 + DS_TR * 148 + 128); }   // 150 KB: one workgroup per CU
 
+// Test hook (tsgnn_dense_stack_barrier_selftest): ONE workgroup waits at a device-wide barrier for `expect` arrivals.  expect = 1
+// completes; expect = 2 can never complete — the bounded spin gives up and raises the error word, exactly what a launch whose
+// workgroups are not co-resident does.
+__global__ __launch_bounds__(64) void ds_barrier_selftest_kernel(unsigned* sync, float* err, unsigned expect) {
+  int bar = 0;
+  grid_barrier(sync, bar, expect, err);
+  grid_finish(sync, bar, 1u);
+}
+
+// How many workgroups of these kernels the CURRENT device keeps resident at once — what the spin barriers rest on.  From the
+// device itself (compute units x the occupancy the runtime reports for each kernel at DS_NT threads and ds_lds_bytes() of LDS),
+// not a literal: a partition or a part with fewer compute units gets the limit that is true for it.  Also raises the kernels'
+// dynamic-LDS limit, once per DEVICE (the attribute is per device; a process-wide flag left the second device of a process
+// without it).  0 when no device is usable: the callers then report "unsupported" and the layer-by-layer path runs.
+int ds_max_resident() {
+  constexpr int MAXDEV = 64;
+  static int cache[MAXDEV];                   // 0 = not queried yet, -1 = unusable, > 0 = the limit
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) { (void)hipGetLastError(); return 0; }
+  if (cache[dev] != 0) return cache[dev] > 0 ? cache[dev] : 0;
+  int cus = 0, occ_f = 0, occ_b = 0;
+  bool ok = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess;
+  ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(dense_stack_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ds_lds_bytes()) == hipSuccess;
+  ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(dense_stack_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ds_lds_bytes()) == hipSuccess;
+  ok = ok && hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_f, dense_stack_fwd_kernel, DS_NT, ds_lds_bytes()) == hipSuccess;
+  ok = ok && hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_b, dense_stack_bwd_kernel, DS_NT, ds_lds_bytes()) == hipSuccess;
+  if (!ok) (void)hipGetLastError();
+  const int occ = occ_f < occ_b ? occ_f : occ_b;
+  cache[dev] = (ok && cus > 0 && occ > 0) ? cus * occ : -1;
+  return cache[dev] > 0 ? cache[dev] : 0;
+}
+
 int ds_check(const DsArgs& a) {
   if (!a.x || !a.adj || !a.stats || !a.sync || !a.err || a.B <= 0 || a.K <= 0 || a.nstack < 1 || a.nstack > 2) return TSGNN_EINVAL;
   if (a.K > 64 || (a.K % 4) || (a.ldx % 4) || (reinterpret_cast<uintptr_t>(a.x) & 15) || (reinterpret_cast<uintptr_t>(a.adj) & 15)) return TSGNN_EUNSUPPORTED;
@@ -843,7 +885,7 @@ int ds_check(const DsArgs& a) {
   }
   if (a.nstack == 2 && a.st[0].L != a.st[1].L) return TSGNN_EUNSUPPORTED;      // the workgroups of both stacks meet at the same barriers
   const int tiles = (a.K + DS_TR - 1) / DS_TR;
-  if ((int64_t)tiles * a.B * a.nstack > 256) return TSGNN_EUNSUPPORTED;       // all workgroups must be resident
+  if ((int64_t)tiles * a.B * a.nstack > ds_max_resident()) return TSGNN_EUNSUPPORTED;       // all workgroups must be resident
   return TSGNN_OK;
 }
 
@@ -855,7 +897,7 @@ extern "C" {
 int tsgnn_dense_stack_supported(int B, int K, int nstack, int L, int fin0, int hidden, int last0, int last1) {
   if (B <= 0 || K <= 0 || K > 64 || (K % 4) || nstack < 1 || nstack > 2 || L < 1 || L > DS_MAXL) return 0;
   const int tiles = (K + DS_TR - 1) / DS_TR;
-  if ((int64_t)tiles * B * nstack > 256) return 0;
+  if ((int64_t)tiles * B * nstack > ds_max_resident()) return 0;
   const int widths[4] = {fin0, hidden, last0, last1};
   for (int i = 0; i < 4; ++i)
     if (widths[i] <= 0 || (widths[i] % 4)) return 0;
@@ -901,22 +943,12 @@ static void ds_unpack(const int64_t* d, DsArgs& a) {
   a.dadj_add = P(o);
 }
 
-static void ds_attr() {
-  static bool done = false;
-  if (!done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_stack_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ds_lds_bytes());
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_stack_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ds_lds_bytes());
-    done = true;
-  }
-}
-
 int tsgnn_dense_stack_fwd_f32(const int64_t* desc, tsgnn_stream_t stream) {
   if (!desc) return TSGNN_EINVAL;
   DsArgs a;
   ds_unpack(desc, a);
   const int rc = ds_check(a);
   if (rc != TSGNN_OK) return rc;
-  ds_attr();
   const int tiles = (a.K + DS_TR - 1) / DS_TR;
   TSGNN_KNAME("dense_stack_fwd_kernel");
   dense_stack_fwd_kernel<<<(unsigned)(tiles * a.B * a.nstack), DS_NT, ds_lds_bytes(), stream>>>(a);
@@ -933,12 +965,25 @@ int tsgnn_dense_stack_bwd_f32(const int64_t* desc, tsgnn_stream_t stream) {
   if (!a.dagg || !a.dxn || !a.slabs || a.slab_floats <= 0 || a.finmax <= 0 || (a.dadj && a.nstack == 2 && !a.dadj_part)) return TSGNN_EINVAL;
   for (int s = 0; s < a.nstack; ++s)
     if (!a.st[s].dout) return TSGNN_EINVAL;
-  ds_attr();
   const int tiles = (a.K + DS_TR - 1) / DS_TR;
   TSGNN_KNAME("dense_stack_bwd_kernel");
   dense_stack_bwd_kernel<<<(unsigned)(tiles * a.B * a.nstack), DS_NT, ds_lds_bytes(), stream>>>(a);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }
+
+/* Test hook for the failure path of the bounded device-wide barriers: one workgroup waits for `expect` arrivals on the barrier
+ * words `sync` (>= 32 words, zero).  expect = 1 passes; expect = 2 times out after the barrier's bound (~1 s) and stores 1.0 to
+ * *err — what a dense-stack launch whose workgroups were not all resident does.  tests/test_gpu_encoders.py uses it to prove
+ * that the optimiser then skips its update and the host raises. */
+int tsgnn_dense_stack_barrier_selftest(unsigned* sync, float* err, int expect, tsgnn_stream_t stream) {
+  if (!sync || !err || expect < 1) return TSGNN_EINVAL;
+  ds_barrier_selftest_kernel<<<1, 64, 0, stream>>>(sync, err, (unsigned)expect);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+/* workgroups of the dense-stack kernels the current device keeps resident (compute units x occupancy); 0 without a device */
+int tsgnn_dense_stack_max_resident(void) { return ds_max_resident(); }
 
 }  // extern "C"

@@ -10,6 +10,14 @@ namespace {
 
 constexpr int NPART = 256;
 
+// `poison` (nullable): the device's error word (message_passing.device_error_word).  A kernel with a bounded device-wide barrier
+// that could not complete it (dense_stack.hip) stores a non-zero value there: the gradients of that step are invalid.  Every
+// optimiser kernel reads the word first and, if it is set, leaves parameters, moments and the step counter untouched and marks
+// state[3] = 1 — the host raises at its next synchronisation (check_device_errors), and nothing wrong was applied meanwhile.
+__device__ __forceinline__ bool poisoned(const float* __restrict__ poison) {
+  return poison != nullptr && __hip_atomic_load(poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.f;
+}
+
 __global__ __launch_bounds__(256) void sqnorm_partial(const float* __restrict__ g, int64_t n, float* __restrict__ part) {
   __shared__ float lds[4];
   float s = 0.f;
@@ -21,8 +29,9 @@ __global__ __launch_bounds__(256) void sqnorm_partial(const float* __restrict__ 
 }
 // state[0] = step count (float), state[1] = total grad norm of the last step, state[2] = clip coefficient
 __global__ __launch_bounds__(256) void sqnorm_final(const float* __restrict__ part, int nparts, float grad_scale, float max_norm,
-                                                    float* __restrict__ state) {
+                                                    float* __restrict__ state, const float* __restrict__ poison) {
   __shared__ float lds[4];
+  if (poisoned(poison)) { if (threadIdx.x == 0) state[3] = 1.f; return; }
   float s = threadIdx.x < nparts ? part[threadIdx.x] : 0.f;
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = s;
@@ -37,9 +46,10 @@ __global__ __launch_bounds__(256) void sqnorm_final(const float* __restrict__ pa
   }
 }
 __global__ void adam_update(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            int64_t n, float lr, float b1, float b2, float eps, float wd, const float* __restrict__ state) {
+                            int64_t n, float lr, float b1, float b2, float eps, float wd, const float* __restrict__ state,
+                            const float* __restrict__ poison) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  if (i >= n || poisoned(poison)) return;
   const float step = state[0], scale = state[2];
   const float bc1 = 1.f - powf(b1, step), bc2 = 1.f - powf(b2, step);
   float gi = g[i] * scale;
@@ -63,9 +73,16 @@ constexpr int64_t SELFNORM_MAX_N = 131072;
 __global__ __launch_bounds__(256) void clip_adam_selfnorm(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                           float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
                                                           float wd, float max_norm, float grad_scale, float* __restrict__ state,
-                                                          unsigned* __restrict__ done) {
+                                                          unsigned* __restrict__ done, const float* __restrict__ poison) {
   __shared__ float lds[4];
   const int tid = threadIdx.x;
+  if (poisoned(poison)) {                               // sign off all the same: `done` must be re-armed for the next launch
+    if (tid == 0) {
+      const unsigned prev = __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      if (prev == gridDim.x - 1) { __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); state[3] = 1.f; }
+    }
+    return;
+  }
   const int64_t base = ((int64_t)blockIdx.x * 256 + tid) * CV;
   float gv[CV], pv[CV], mv[CV], vv[CV];                // the update's operands travel while the norm is summed
 #pragma unroll
@@ -130,9 +147,13 @@ __global__ __launch_bounds__(256) void clip_adam_selfnorm(float* __restrict__ p,
 __global__ __launch_bounds__(256) void adam_from_partials(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                           float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
                                                           float wd, float max_norm, float* __restrict__ state,
-                                                          const float* __restrict__ parts, int nparts) {
+                                                          const float* __restrict__ parts, int nparts, const float* __restrict__ poison) {
   __shared__ float lds[4];
   const int tid = threadIdx.x;
+  if (poisoned(poison)) {                               // (the producers advanced the counter for this step: take that back)
+    if (blockIdx.x == 0 && tid == 0) { state[0] -= 1.f; state[3] = 1.f; }
+    return;
+  }
   const int64_t base = ((int64_t)blockIdx.x * 256 + tid) * CV;
   float gv[CV], pv[CV], mv[CV], vv[CV];
 #pragma unroll
@@ -209,29 +230,29 @@ int tsgnn_softmax_ce_f32(const float* logits, int64_t ld, const int64_t* label, 
  * tsgnn_wgrad_reduce_multi_f32(step_state).  One launch, no device-wide barrier. */
 int tsgnn_adam_from_partials_f32(float* param, const float* grad, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                                  float eps, float weight_decay, float max_norm, float* state, const float* parts, int nparts,
-                                 tsgnn_stream_t stream) {
+                                 const float* poison, tsgnn_stream_t stream) {
   if (!param || !grad || !m || !v || !state || !parts || n <= 0 || nparts <= 0) return TSGNN_EINVAL;
   TSGNN_KNAME("adam_from_partials");
   adam_from_partials<<<(unsigned)ceil_div64(n, 256 * CV), 256, 0, stream>>>(param, grad, m, v, n, lr, beta1, beta2, eps, weight_decay,
-                                                                           max_norm, state, parts, nparts);
+                                                                           max_norm, state, parts, nparts, poison);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }
 
 /* One optimiser step on flat buffers: g *= grad_scale (1/world after the all-reduce), clip to max_norm
  * (<=0: off), Adam.  ws >= 258 floats, 8-byte aligned, zeroed once before the first step (word 256 is the sign-off counter
- * of the one-launch variant, which re-arms it itself); state = 4 floats {step, grad_norm, applied scale, reserved = 0},
- * zero before step 1.  n <= 131,072: ONE launch, no device-wide barrier (every block sums the whole norm); larger: three. */
+ * of the one-launch variant, which re-arms it itself); state = 4 floats {step, grad_norm, applied scale, skipped (1 after a
+ * launch that found *poison != 0 and left everything untouched)}, zero before step 1.  n <= 131,072: ONE launch, no device-wide barrier (every block sums the whole norm); larger: three. */
 int tsgnn_clip_adam_step_f32(float* param, const float* grad, float* m, float* v, int64_t n, float lr, float beta1,
                              float beta2, float eps, float weight_decay, float max_norm, float grad_scale, float* state,
-                             float* ws, tsgnn_stream_t stream) {
+                             float* ws, const float* poison, tsgnn_stream_t stream) {
   if (!param || !grad || !m || !v || !state || !ws || n <= 0) return TSGNN_EINVAL;
   if (reinterpret_cast<uintptr_t>(ws) & 7) return TSGNN_EINVAL;
   if (n <= SELFNORM_MAX_N) {
     const int nbc = (int)ceil_div64(n, 256 * CV);
     TSGNN_KNAME("clip_adam_selfnorm");
     clip_adam_selfnorm<<<nbc, 256, 0, stream>>>(param, grad, m, v, n, lr, beta1, beta2, eps, weight_decay, max_norm, grad_scale, state,
-                                                reinterpret_cast<unsigned*>(ws + 256));
+                                                reinterpret_cast<unsigned*>(ws + 256), poison);
     TSGNN_CHECK_LAUNCH();
     return TSGNN_OK;
   }
@@ -239,8 +260,8 @@ int tsgnn_clip_adam_step_f32(float* param, const float* grad, float* m, float* v
   if (nb > NPART) nb = NPART;
   TSGNN_KNAME("sqnorm_partial + sqnorm_final + adam_update");
   sqnorm_partial<<<nb, 256, 0, stream>>>(grad, n, ws);
-  sqnorm_final<<<1, 256, 0, stream>>>(ws, nb, grad_scale, max_norm, state);
-  adam_update<<<(unsigned)ceil_div64(n, 256), 256, 0, stream>>>(param, grad, m, v, n, lr, beta1, beta2, eps, weight_decay, state);
+  sqnorm_final<<<1, 256, 0, stream>>>(ws, nb, grad_scale, max_norm, state, poison);
+  adam_update<<<(unsigned)ceil_div64(n, 256), 256, 0, stream>>>(param, grad, m, v, n, lr, beta1, beta2, eps, weight_decay, state, poison);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }

@@ -57,7 +57,9 @@ class FlatTrainer:
         self.on_gpu = dev.type == "cuda"
         self.exp_avg = torch.zeros_like(self.flat_param)
         self.exp_avg_sq = torch.zeros_like(self.flat_param)
-        self.state = torch.zeros(4, dtype=torch.float32, device=dev)      # step, grad norm, applied scale, reserved
+        self.state = torch.zeros(4, dtype=torch.float32, device=dev)      # step, grad norm, applied scale, 1 = an update was skipped
+        # the device's error word: the optimiser kernels skip their update while a kernel's bounded barrier has reported a time-out
+        self.poison = mp.device_error_word(dev) if dev.type == "cuda" else None
         self.ws = torch.zeros(264, dtype=torch.float32, device=dev)       # norm partials + the optimiser kernel's sign-off counter
         self._zeros = [torch.zeros_like(p).reshape(-1) for p in self.params]     # stand-ins for parameters without a gradient
         self._pad_zeros = [torch.zeros(k, dtype=torch.float32, device=dev) if k else None for k in self._pads]
@@ -205,13 +207,25 @@ class FlatTrainer:
         if getattr(self, "_norm_ready", False):
             nat.call("adam_from_partials_f32", self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.numel,
                      float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd), float(self.clip),
-                     self.state, self.sink.norm_parts, int(self.sink.norm_used))
+                     self.state, self.sink.norm_parts, int(self.sink.norm_used), self.poison)
             return
         if self.sink is not None and self.sink.stepped:
             self.state[0] -= 1.0                        # the gradient reduction advanced the counter for the barrier-free path
         nat.call("clip_adam_step_f32", self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.numel,
                  float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd),
-                 float(self.clip), float(scale), self.state, self.ws)
+                 float(self.clip), float(scale), self.state, self.ws, self.poison)
+
+    def check(self):
+        """synchronise and raise if a kernel of a step since the last check reported invalid results (a bounded device-wide
+        barrier that timed out).  The optimiser has skipped every update since then (state[3] = 1), so parameters and moments
+        are those of the last good step."""
+        torch.cuda.synchronize()
+        try:
+            mp.check_device_errors()
+        finally:
+            if self.on_gpu and float(self.state[3]) != 0.0:
+                self.state[3] = 0.0
+                torch.cuda.synchronize()
 
     def step(self, loss_fn):
         """loss_fn() -> scalar loss.  fwd + bwd + all-reduce + clip + Adam."""
@@ -271,33 +285,16 @@ class GraphedStep:
             if want == "auto" and self.multi and dist.is_initialized() and dist.get_backend(trainer.group) != "nccl" \
                     and os.environ.get("TSGNN_ONE_GRAPH_ANY_BACKEND") != "1":
                 want = "0"                  # gloo moves the data through the host: its collectives cannot be captured
-            broken = False
             if self.multi and want != "0":
-                ok, broken = self._try_one_graph(mode, verify=(want != "1"))
+                ok = self._try_one_graph(mode, verify=(want != "1"))
                 if not ok:
                     self._fb = None
-                    self.mode_note = " (one-graph step failed its %s: fell back)" % ("capture" if broken else "check")
+                    if want == "1":
+                        raise RuntimeError("TSGNN_GRAPH_ALLREDUCE=1: the all-reduce could not be captured into the step's hipGraph "
+                                           "on every rank; use TSGNN_GRAPH_ALLREDUCE=auto (checked, falls back) or 0 (two graphs)")
                 self.one_graph = ok
-            if self._fb is None and not broken:
-                self._capture_two(mode)
-        if broken and want == "1":
-            raise RuntimeError("TSGNN_GRAPH_ALLREDUCE=1: the all-reduce could not be captured into the step's hipGraph; "
-                               "use TSGNN_GRAPH_ALLREDUCE=auto (checked, falls back) or 0 (two graphs)")
-        if broken:
-            # A capture that was invalidated half-way leaves its stream unusable on this stack (every later call on it reports
-            # hipErrorStreamCaptureInvalidated): carry on with a fresh stream.
-            self.stream = torch.cuda.Stream()
-            with torch.cuda.stream(self.stream):
-                for _ in range(4):                                   # the runtime's sticky "last error" is reported once more
-                    try:
-                        torch.cuda.synchronize()
-                        break
-                    except Exception:                                # noqa: BLE001
-                        pass
-                for t, s_ in zip(self._bufs(), self._snap):
-                    t.copy_(s_)
-                torch.cuda.synchronize()
-                self._agree(False)
+        if self._fb is None:
+            with torch.cuda.stream(self.stream):                 # (self.stream is a fresh one if a capture was invalidated)
                 self._capture_two(mode)
         self._snap = None
 
@@ -309,10 +306,11 @@ class GraphedStep:
         """every rank takes the same decision about the one-graph step (eager MIN all-reduce of the local verdicts)"""
         tr = self.trainer
         if dist.is_initialized():
-            flag = torch.tensor([1.0 if ok else 0.0], device=tr.flat_param.device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=tr.group)
-            ok = bool(flag.item() > 0.5)
-            torch.cuda.synchronize()
+            with torch.cuda.stream(self.stream):                 # (the caller's current stream may be one a capture poisoned)
+                flag = torch.tensor([1.0 if ok else 0.0], device=tr.flat_param.device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=tr.group)
+                ok = bool(flag.item() > 0.5)
+                torch.cuda.synchronize()
         return ok
 
     def _capture_two(self, mode):
@@ -328,15 +326,42 @@ class GraphedStep:
             with torch.cuda.graph(self._opt, stream=self.stream, **mode):
                 trainer.apply()
 
+    def _abandon_stream(self):
+        """A capture that was invalidated half-way leaves its stream unusable on this stack (every later call on it reports
+        hipErrorStreamCaptureInvalidated), and a side stream that was forked into it is in the same state: carry on with fresh
+        ones, swallow the runtime's sticky "last error", put the trainer's state back."""
+        tr = self.trainer
+        self.stream = torch.cuda.Stream()
+        if tr._side is not None:
+            tr._side = torch.cuda.Stream()
+        tr._early_issued = False
+        with torch.cuda.stream(self.stream):
+            for _ in range(4):                                   # the sticky error is reported once more
+                try:
+                    torch.cuda.synchronize()
+                    break
+                except Exception:                                # noqa: BLE001
+                    pass
+            for t, s_ in zip(self._bufs(), self._snap):
+                t.copy_(s_)
+            torch.cuda.synchronize()
+
     def _try_one_graph(self, mode, verify):
         """capture forward + backward + bucket + all-reduce + optimiser as ONE graph; verify=True: replay it once from a
-        snapshot and compare with the eager sequence from the same snapshot, agree across ranks.  Leaves the trainer's state as
-        it found it.  -> (installed in self._fb, capture raised: the stream must be abandoned)"""
+        snapshot and compare with the eager sequence from the same snapshot.  Leaves the trainer's state as it found it.
+        -> installed in self._fb.
+
+        Every rank issues the SAME sequence of collectives whatever happened locally (a rank whose capture raised
+        used to skip the verification replay — a captured SUM all-reduce of the bucket on its peers — and go straight to the
+        1-element MIN, i.e. collectives mismatched in order and size):
+          capture attempt (no communication: the collective is recorded, not run) -> [a failed rank recovers its stream] ->
+          MIN all-reduce "did every rank capture?" -> only if all did: replay + eager step (both all-reduce the bucket) ->
+          MIN all-reduce "did every rank's check pass?"."""
         tr = self.trainer
         bufs = self._bufs()
         self._snap = snap = [t.clone() for t in bufs]
-        ok = True
         graph = torch.cuda.CUDAGraph()
+        captured = True
         try:
             tr._allow_early = True
             with torch.cuda.graph(graph, stream=self.stream, **mode):
@@ -345,25 +370,35 @@ class GraphedStep:
                 tr.apply()
         except Exception as e:                                  # noqa: BLE001 - any capture failure selects the two-graph step
             print("GraphedStep: one-graph capture failed (%s: %s)" % (type(e).__name__, str(e).splitlines()[0]), flush=True)
-            return False, True
-        if verify:
-            graph.replay()
-            torch.cuda.synchronize()
-            got = tr.flat_param.clone()
+            captured = False
+            graph = None
+            self._abandon_stream()
+        all_captured = self._agree(captured)
+        if not all_captured:
+            self.mode_note = " (one-graph step failed its capture on %s: fell back)" % ("this rank" if not captured else "another rank")
+            return False
+        ok = True
+        with torch.cuda.stream(self.stream):
+            if verify:
+                graph.replay()
+                torch.cuda.synchronize()
+                got = tr.flat_param.clone()
+                for t, s_ in zip(bufs, snap):
+                    t.copy_(s_)
+                self._fwd_bwd(); tr.all_reduce(); tr.apply()
+                torch.cuda.synchronize()
+                scale = float(tr.flat_param.abs().max()) + 1e-30
+                ok = bool(torch.isfinite(got).all()) and float((got - tr.flat_param).abs().max()) <= 1e-5 * scale
             for t, s_ in zip(bufs, snap):
                 t.copy_(s_)
-            self._fwd_bwd(); tr.all_reduce(); tr.apply()
             torch.cuda.synchronize()
-            scale = float(tr.flat_param.abs().max()) + 1e-30
-            ok = bool(torch.isfinite(got).all()) and float((got - tr.flat_param).abs().max()) <= 1e-5 * scale
-        for t, s_ in zip(bufs, snap):
-            t.copy_(s_)
-        torch.cuda.synchronize()
         if verify:
             ok = self._agree(ok)
+            if not ok:
+                self.mode_note = " (one-graph step failed its check: fell back)"
         if ok:
             self._fb = graph
-        return ok, False
+        return ok
 
     def describe(self):
         if not self.use_graph:
@@ -382,8 +417,20 @@ class GraphedStep:
         tr.backward(self.loss)
         tr.gather_grads()
 
+    def synchronize(self):
+        """wait for the enqueued steps and raise if one of them reported invalid results (FlatTrainer.check): call it wherever
+        the loop synchronises anyway — reading the loss, logging, the end of an epoch"""
+        self.stream.synchronize()
+        self.trainer.check()
+
+    def loss_value(self):
+        """the last step's loss as a float (synchronises; checked)"""
+        self.synchronize()
+        return float(self.loss)
+
     def step(self):
-        """enqueue one step on self.stream (returns immediately; self.loss is the device scalar of the last step)"""
+        """enqueue one step on self.stream (returns immediately; self.loss is the device scalar of the last step; read it through
+        loss_value(), which also checks the device's error word)"""
         with torch.cuda.stream(self.stream):
             if not self.use_graph:
                 self._fwd_bwd(); self.trainer.all_reduce(); self.trainer.apply()

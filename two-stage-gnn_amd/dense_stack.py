@@ -167,12 +167,15 @@ _ws = {}
 
 
 def _workspace(dev):
-    """(barrier words, error flag) of the device-wide barriers: zeroed once, re-armed by the kernels themselves"""
-    w = _ws.get(dev)
+    """(barrier words, error word) of the device-wide barriers.  The words are zeroed once and re-armed by the kernels
+    themselves; they are keyed by (device, stream) — launches on different streams may overlap and must not count each other's
+    arrivals — while the error word is the device's one (message_passing.device_error_word)."""
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    w = _ws.get(key)
     if w is None:
-        w = _ws[dev] = (torch.zeros(32 + 256, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.float32, device=dev))
-        mp.DEVICE_ERRORS.append((w[1], "a device-wide barrier of the pooled-level stack kernels (dense_stack.hip) timed out: "
-                                       "its workgroups were not all resident; results of that launch are invalid", w[0]))
+        words = torch.zeros(32 + 256, dtype=torch.int32, device=dev)
+        mp.register_barrier_words(dev, words)
+        w = _ws[key] = (words, mp.device_error_word(dev))
     return w
 
 

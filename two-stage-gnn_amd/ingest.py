@@ -22,6 +22,7 @@ import numpy as np
 import torch
 
 from . import _native as nat
+from . import message_passing as mp
 from .graph import GraphBatch
 from .tu_data import TUDataset
 
@@ -322,6 +323,7 @@ class IngestPipeline:
             # its staging buffer holds.  Let them finish before this run's batches go into the staging buffers, or an echo of
             # theirs would be taken for the pull that feeds this run's step.
             self.compute.synchronize()
+            mp.check_device_errors()                          # the host has synchronised anyway: did a step of the last run fail?
         if pool is not None:
             for k in range(min(depth, len(sched))):
                 self.slots[k].collate_async(pool, self.ds, sched[k])

@@ -790,17 +790,47 @@ class GradSink:
 
 
 DEVICE_ERRORS = []                  # (flag tensor, message, state to clear): raised by kernels with a bounded device-wide barrier
+_err_words = {}
 
 
-def check_device_errors():
-    """Synchronises and raises if a kernel reported a failure it could not return through its status (a bounded device-wide
-    barrier that was not completed: the launch's results are invalid).  Called where the host synchronises anyway (end of a
-    GraphedStep's warm-up, test fixtures); call it after any synchronisation point of a long run."""
+def _dev_key(device):
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    return device
+
+
+def device_error_word(device):
+    """THE error word of a device: one float, zero while all is well.  Kernels with a bounded device-wide barrier store a non-zero
+    value when a barrier was not completed (their results are invalid); the optimiser kernels read it as `poison` and skip their
+    update while it is set (csrc/optim.hip), and check_device_errors() raises and clears it."""
+    device = _dev_key(device)
+    w = _err_words.get(device)
+    if w is None:
+        flag = torch.zeros(1, dtype=torch.float32, device=device)
+        w = _err_words[device] = (flag, [])
+        DEVICE_ERRORS.append((flag, "a bounded device-wide barrier timed out on %s (a kernel's workgroups were not all resident): the "
+                                    "results of that launch are invalid; the optimiser skipped every update since" % (device,), w[1]))
+    return w[0]
+
+
+def register_barrier_words(device, words):
+    """barrier words that must be zeroed when the device's error word fires (a failed launch leaves arrival counts behind)"""
+    device_error_word(device)
+    _err_words[_dev_key(device)][1].append(words)
+
+
+def check_device_errors(synchronize=True):
+    """Raises if a kernel reported a failure it could not return through its status (a bounded device-wide barrier that was not
+    completed: the launch's results are invalid).  Reads one float per device that ever armed such a kernel, so it belongs where
+    the host synchronises anyway: GraphedStep.synchronize() / loss_value(), IngestPipeline.run(), bench.py after its timed
+    region, test fixtures.  Clears the flag and the barrier words of the failed launch (start clean) before raising."""
     for flag, msg, state in DEVICE_ERRORS:
         if float(flag.item()) != 0.0:
             flag.zero_()
-            if state is not None:
-                state.zero_()               # the barrier words of the failed launch: start clean
+            for t in (state if isinstance(state, list) else [state]):
+                if t is not None:
+                    t.zero_()               # the barrier words of the failed launch
             raise RuntimeError(msg)
 
 
