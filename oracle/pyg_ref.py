@@ -19,19 +19,20 @@ import torch.nn.functional as F
 
 
 # ----------------------------------------------------------------------------- GCNConv (a11)
-def gcn_norm(edge_index, num_nodes, edge_weight=None, improved=False):
-    """add_remaining_self_loops(fill 1, or 2 when improved) ; deg over targets ; D^-1/2 (A+I) D^-1/2."""
+def gcn_norm(edge_index, num_nodes, edge_weight=None, improved=False, dtype=torch.float32):
+    """add_remaining_self_loops(fill 1, or 2 when improved) ; deg over targets ; D^-1/2 (A+I) D^-1/2.
+    dtype: the arithmetic type (float64 for the arbitration runs of tests/test_gpu_fullsize.py)."""
     row, col = edge_index[0], edge_index[1]
     if edge_weight is None:
-        edge_weight = torch.ones(row.numel())
+        edge_weight = torch.ones(row.numel(), dtype=dtype)
     mask = row != col
-    loop_w = torch.full((num_nodes,), 2.0 if improved else 1.0)
+    loop_w = torch.full((num_nodes,), 2.0 if improved else 1.0, dtype=edge_weight.dtype)
     loop_w[row[~mask]] = edge_weight[~mask]                 # existing self loops keep their weight
     loop = torch.arange(num_nodes)
     row = torch.cat([row[mask], loop])
     col = torch.cat([col[mask], loop])
     w = torch.cat([edge_weight[mask], loop_w])
-    deg = torch.zeros(num_nodes).index_add_(0, col, w)
+    deg = torch.zeros(num_nodes, dtype=w.dtype).index_add_(0, col, w)
     dis = deg.pow(-0.5)
     dis[dis == float("inf")] = 0
     return row, col, dis[row] * w * dis[col]
@@ -40,9 +41,9 @@ def gcn_norm(edge_index, num_nodes, edge_weight=None, improved=False):
 def gcn_conv(x, edge_index, weight, bias=None, edge_weight=None, improved=False):
     """out = A_hat (x W) + b ; message flows source (edge_index[0]) -> target (edge_index[1])."""
     n = x.size(0)
-    row, col, w = gcn_norm(edge_index, n, edge_weight, improved)
+    row, col, w = gcn_norm(edge_index, n, edge_weight, improved, dtype=x.dtype)
     xw = x @ weight
-    out = torch.zeros(n, weight.size(1)).index_add_(0, col, xw[row] * w.unsqueeze(1))
+    out = torch.zeros(n, weight.size(1), dtype=x.dtype).index_add_(0, col, xw[row] * w.unsqueeze(1))
     return out + bias if bias is not None else out
 
 

@@ -582,10 +582,12 @@ def test_selfnorm_optimiser_sizes_and_replay():
 
 
 def _fallback_worker(rank, port, q):
-    """gloo collectives cannot be captured: with TSGNN_ONE_GRAPH_ANY_BACKEND=1 the auto mode tries anyway, the capture is
-    invalidated, and GraphedStep must carry on (fresh stream, two graphs) with the trainer's state intact"""
+    """a one-graph capture that raises on every rank (TSGNN_ONE_GRAPH_ANY_BACKEND=1 makes the auto mode try on a gloo group,
+    TSGNN_TEST_BREAK_CAPTURE=all puts an operation no capture admits into it): the capture is invalidated, and GraphedStep must
+    carry on (fresh stream, two graphs) with the trainer's state intact"""
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TSGNN_ONE_GRAPH_ANY_BACKEND="1", TSGNN_GRAPH_ALLREDUCE="auto")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TSGNN_ONE_GRAPH_ANY_BACKEND="1", TSGNN_GRAPH_ALLREDUCE="auto",
+                      TSGNN_TEST_BREAK_CAPTURE="all")
     dist.init_process_group("gloo", rank=rank, world_size=2)
     torch.cuda.set_device(0)
     from two_stage_gnn_amd import dense_encoders as E, synthetic
@@ -618,7 +620,7 @@ def test_failed_collective_capture_falls_back_to_two_graphs():
     procs = [ctx.Process(target=_fallback_worker, args=(r, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=180) for _ in range(2)], key=lambda t: t[0])
+    res = sorted([q.get(timeout=90) for _ in range(2)], key=lambda t: t[0])
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -630,12 +632,13 @@ def test_failed_collective_capture_falls_back_to_two_graphs():
 
 
 def _disagree_worker(rank, port, q):
-    """rank 0's capture fails for real (a gloo collective inside a capture); rank 1's capture SUCCEEDS (its all_reduce is left
-    out of the capture, so nothing un-capturable is recorded).  The ranks then disagree about the one-graph step: both must fall
+    """rank 0's capture raises (TSGNN_TEST_BREAK_CAPTURE=0: an operation no capture admits); rank 1's capture SUCCEEDS (its gloo
+    all_reduce is left out of the capture, so nothing un-capturable is recorded).  The ranks then disagree about the one-graph step: both must fall
     back to two graphs, with matched collectives all the way (the failing rank used to skip the verification replay
     its peer ran — a bucket-sized SUM against a 1-element MIN)."""
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TSGNN_ONE_GRAPH_ANY_BACKEND="1", TSGNN_GRAPH_ALLREDUCE="auto")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TSGNN_ONE_GRAPH_ANY_BACKEND="1", TSGNN_GRAPH_ALLREDUCE="auto",
+                      TSGNN_TEST_BREAK_CAPTURE="0")
     dist.init_process_group("gloo", rank=rank, world_size=2)
     torch.cuda.set_device(0)
     from two_stage_gnn_amd import dense_encoders as E, synthetic
@@ -671,7 +674,7 @@ def test_ranks_that_disagree_about_the_capture_fall_back_together():
     procs = [ctx.Process(target=_disagree_worker, args=(r, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=180) for _ in range(2)], key=lambda t: t[0])
+    res = sorted([q.get(timeout=90) for _ in range(2)], key=lambda t: t[0])
     for p in procs:
         p.join(60)
         assert p.exitcode == 0

@@ -48,7 +48,7 @@ class _OracleLoop:
         return float(loss), logits.detach().double(), float(norm)
 
 
-def _run(model, loss_fn, forward32, forward64, lr, clip=2.0, steps=3, defer_loss=False, logit_scale=1.0, handful=8, tag=""):
+def _run(model, loss_fn, forward32, forward64, lr, clip=2.0, steps=3, defer_loss=False, logit_scale=1.0, handful=8, tag="", pre_step=None):
     """loss_fn(stash) builds the step the bench times (stash['logits'] = the head's output); forwardNN(p) -> (loss, logits) on
     the oracle with parameter dict p."""
     from two_stage_gnn_amd import message_passing as mp
@@ -63,6 +63,8 @@ def _run(model, loss_fn, forward32, forward64, lr, clip=2.0, steps=3, defer_loss
     names = [k for k, _ in model.named_parameters()]
     report = []
     for i in range(1, steps + 1):
+        if pre_step is not None:
+            pre_step(i, p64)                                        # (per-step inputs that depend on the oracle's parameters)
         gs.step()
         loss_hip = gs.loss_value()                                  # synchronises and checks the device's error word
         logits_hip = stash["logits"].detach().cpu().double()
@@ -193,7 +195,8 @@ def test_gat_timed_step_vs_oracle():
 
 
 # ------------------------------------------------------------------------------------------------ SAGPool (config 4)
-def _imdb_batch(dev, x_mode):
+def _imdb_batch(x_seed=None):
+    """the batch scripts/config_bench.py times for config 4; x_seed None: its constant features, else 1 + 0.25 N(0,1)"""
     from two_stage_gnn_amd import synthetic
     hb = synthetic.host_batch(3, 128, "IMDB-BINARY", 136)
     sizes = hb["sizes"]
@@ -202,28 +205,46 @@ def _imdb_batch(dev, x_mode):
     dst = np.repeat(np.arange(n), np.diff(rp))
     ei = torch.from_numpy(np.stack([col.astype(np.int64), dst.astype(np.int64)]))
     batch = torch.repeat_interleave(torch.arange(128), torch.from_numpy(sizes))
-    if x_mode == "ones":
+    if x_seed is None:
         x = torch.ones(n, 1)                                   # IMDB-B has no node features: what the bench feeds
     else:
-        x = 1.0 + 0.25 * torch.randn(n, 1, generator=torch.Generator().manual_seed(5))     # tie-free scores
+        x = 1.0 + 0.25 * torch.randn(n, 1, generator=torch.Generator().manual_seed(x_seed))
     return hb, x, ei, batch, torch.from_numpy(hb["label"])
 
 
-def _cut_margins(p, x, ei, batch, ratio):
-    """fp64 oracle, level by level: for every graph the smallest relative gap, over the three levels, between the last kept and
-    the first dropped score (a graph whose cut falls between two (nearly) tied scores has no defined top-k: SURVEY H5)"""
+def _ambiguous_graphs(p, x, ei, batch, ratio, tol=1e-4):
+    """fp64 oracle, level by level: the graphs whose top-k has no defined answer.  A graph is ambiguous at a level when
+    scores within `tol` of the last kept score (relative to the graph's largest score; 1e-4 ~ ten times what fp32 rounding moves a
+    pooled level's score, a 128-term dot product with cancellation) lie on BOTH sides of the cut — unless the tied nodes are true twins (equal
+    feature rows and equal closed neighbourhoods, e.g. the nodes of a complete graph after a GCN layer): keeping one twin or the
+    other is an automorphism of the graph, every readout and every parameter gradient is the same."""
     B = int(batch.max()) + 1
-    margin = torch.full((B,), float("inf"), dtype=torch.float64)
+    bad = torch.zeros(B, dtype=torch.bool)
     for i in (1, 2, 3):
         x = torch.relu(P.gcn_conv(x, ei, p["conv%d.weight" % i], p["conv%d.bias" % i]))
         score = P.gcn_conv(x, ei, p["pool%d.score_layer.weight" % i], p["pool%d.score_layer.bias" % i]).squeeze(-1)
+        n = x.size(0)
+        A = torch.eye(n, dtype=torch.bool)                            # closed neighbourhoods
+        A[ei[1], ei[0]] = True
         for b in range(B):
-            s = torch.sort(score[batch == b], descending=True)[0]
+            idx = (batch == b).nonzero().view(-1)
+            s = score[idx]
             k = int(np.ceil(np.float32(ratio) * np.float32(s.numel())))
-            if k < s.numel():
-                margin[b] = min(margin[b], float((s[k - 1] - s[k]).abs() / (s.abs().max() + 1e-30)))
+            if k >= s.numel():
+                continue
+            order = torch.argsort(s, descending=True)
+            rank = torch.empty_like(order)
+            rank[order] = torch.arange(order.numel())
+            near = (s - s[order[k - 1]]).abs() <= tol * (float(s.abs().max()) + 1e-30)
+            if not (int(rank[near].min()) < k <= int(rank[near].max())):
+                continue                                               # the tie group does not reach across the cut
+            tied = idx[near]
+            xs = x[tied]
+            twins = (float((xs - xs[0]).abs().max()) <= 1e-9 * (float(xs.abs().max()) + 1e-30)) and bool((A[tied] == A[tied[0]]).all())
+            if not twins:
+                bad[b] = True
         x, ei, batch, _ = P.sag_pool(x, ei, batch, ratio, p["pool%d.score_layer.weight" % i], p["pool%d.score_layer.bias" % i])
-    return margin
+    return bad
 
 
 @pytest.mark.parametrize("x_mode", ["tie_free", "ones"])
@@ -231,23 +252,24 @@ def test_sagpool_timed_step_vs_oracle(x_mode):
     """IMDB-B SAGPool(0.5) h = 128, batch 128 (scripts/config_bench.py cfg4; Code/sag/network.py:30-53 with PyG's per-graph
     `batch`).  The oracle behind it (oracle/pyg_ref.py) is PARITY UNPINNED — torch_geometric is absent from the reference tree
     and from this image.  Dropout (network.py:50) is off: another implementation cannot reproduce torch's random stream.
-      tie_free  node features 1 + 0.25 N(0,1): every top-k cut is well separated; three optimiser steps, everything compared.
-      ones      the bench's own input (constant features): structurally equivalent nodes tie, and a cut between two tied scores
-                has no defined answer — the forward is compared on the graphs whose cuts are separated in the fp64
-                oracle (they must be the large majority), per graph (graphs do not interact in this model)."""
+    The workload is small DENSE graphs (20 nodes, 97 edges: many are complete): nodes tie in score, and a top-k cut between two
+    tied nodes that are not twins has no defined answer (_ambiguous_graphs) — with 128 graphs x 3 levels about one graph
+    per step is in that state by chance.  Graphs do not interact in this model (no batch statistics), so such a graph is taken out
+    of the comparison individually:
+      tie_free  node features 1 + 0.25 N(0,1).  Three optimiser steps of the WHOLE batch; before each step the graphs that are
+                ambiguous for the fp64 oracle's current parameters get weight 0 in the loss (a device vector updated in place
+                between replays; the same weights in the oracle), so they contribute nothing to the loss or to any gradient on
+                either side; at least 96 of the 128 graphs must count in every step.  Everything compared.
+      ones      the bench's own input (constant features): the forward is compared on the graphs whose top-k is defined in the
+                fp64 oracle (they must be the large majority), per graph."""
     from two_stage_gnn_amd import sag_layers as S
     dev = torch.device("cuda")
-    hb, x, ei, batch, lab = _imdb_batch(dev, x_mode)
-
-    class D:
-        pass
-    d = D(); d.x, d.edge_index, d.batch = x.to(dev), ei.to(dev), batch.to(dev)
-    label = lab.to(dev)
     torch.manual_seed(0)
     net = S.Net(1, 128, 2, 0.5, 0.0, use_batch=True).to(dev).train()
     assert net._fused_ok()
+    lr = 5e-4
 
-    def fwd(dtype):
+    def fwd(x, ei, batch, lab, dtype):
         xx = x.to(dtype)
 
         def f(p):
@@ -255,23 +277,54 @@ def test_sagpool_timed_step_vs_oracle(x_mode):
             return torch.nn.functional.nll_loss(y, lab), y
         return f
 
+    class D:
+        pass
+    d = D()
     if x_mode == "ones":
+        hb, x, ei, batch, lab = _imdb_batch(None)
+        d.x, d.edge_index, d.batch = x.to(dev), ei.to(dev), batch.to(dev)
         p64 = _clone_params(net, torch.float64)
         with torch.no_grad():
-            margin = _cut_margins(p64, x.double(), ei, batch, 0.5)
+            safe = ~_ambiguous_graphs(p64, x.double(), ei, batch, 0.5)
             ref = P.sag_net(p64, x.double(), ei, 0.5, batch)
             out = net(d).detach().cpu().double()
-        safe = margin > 1e-4
-        print("IMDB-B b128, constant features: %d of 128 graphs have every top-k cut separated by > 1e-4" % int(safe.sum()))
+        print("IMDB-B b128, constant features: %d of 128 graphs have a defined top-k at every level" % int(safe.sum()))
         assert int(safe.sum()) >= 96
         torch.testing.assert_close(out[safe], ref[safe], rtol=1e-4, atol=1e-4)
         return
 
-    def loss_fn(stash):
-        stash["logits"] = net(d)
-        return torch.nn.functional.nll_loss(stash["logits"], label)
+    hb, x, ei, batch, lab = _imdb_batch(5)
+    d.x, d.edge_index, d.batch = x.to(dev), ei.to(dev), batch.to(dev)
+    label = lab.to(dev)
+    w_cpu = torch.ones(128, dtype=torch.float64)
+    w_dev = torch.ones(128, dtype=torch.float32, device=dev)
+    counted = []
 
-    _run(net, loss_fn, fwd(torch.float32), fwd(torch.float64), lr=5e-4, tag="SAGPool IMDB-B b128 (tie-free features)")
+    def weighted(dtype):
+        xx = x.to(dtype)
+
+        def f(p):
+            y = P.sag_net(p, xx, ei, 0.5, batch)
+            w = w_cpu.to(dtype)
+            return -(y.gather(1, lab.view(-1, 1)).squeeze(1) * w).sum() / w.sum(), y * w.view(-1, 1)
+        return f
+
+    def loss_fn(stash):
+        y = net(d)
+        stash["logits"] = y * w_dev.view(-1, 1)                    # (masked graphs are not compared)
+        return -(y.gather(1, label.view(-1, 1)).squeeze(1) * w_dev).sum() / w_dev.sum()
+
+    def mask(i, p64):
+        with torch.no_grad():
+            bad = _ambiguous_graphs({k: v.detach() for k, v in p64.items()}, x.double(), ei, batch, 0.5)
+        w_cpu.copy_((~bad).double())
+        w_dev.copy_((~bad).float().to(dev))
+        torch.cuda.synchronize()
+        counted.append(int((~bad).sum()))
+        assert counted[-1] >= 96, counted
+
+    _run(net, loss_fn, weighted(torch.float32), weighted(torch.float64), lr=lr, tag="SAGPool IMDB-B b128 (tie-free features)", pre_step=mask)
+    print("graphs counted per step:", counted)
 
 
 # ------------------------------------------------------------------------------------------------ failure path of the barriers

@@ -286,13 +286,18 @@ class GraphedStep:
                     and os.environ.get("TSGNN_ONE_GRAPH_ANY_BACKEND") != "1":
                 want = "0"                  # gloo moves the data through the host: its collectives cannot be captured
             if self.multi and want != "0":
-                ok = self._try_one_graph(mode, verify=(want != "1"))
-                if not ok:
-                    self._fb = None
-                    if want == "1":
-                        raise RuntimeError("TSGNN_GRAPH_ALLREDUCE=1: the all-reduce could not be captured into the step's hipGraph "
-                                           "on every rank; use TSGNN_GRAPH_ALLREDUCE=auto (checked, falls back) or 0 (two graphs)")
-                self.one_graph = ok
+                self._snap = [t.clone() for t in self._bufs()]
+                graph = self._capture_one(mode)                  # None: the capture raised
+        # (the rest runs outside the block above: its stream may be one a failed capture has just poisoned)
+        if self.multi and want != "0":
+            ok = self._try_one_graph(graph, verify=(want != "1"))
+            graph = None
+            if not ok:
+                self._fb = None
+                if want == "1":
+                    raise RuntimeError("TSGNN_GRAPH_ALLREDUCE=1: the all-reduce could not be captured into the step's hipGraph "
+                                       "on every rank; use TSGNN_GRAPH_ALLREDUCE=auto (checked, falls back) or 0 (two graphs)")
+            self.one_graph = ok
         if self._fb is None:
             with torch.cuda.stream(self.stream):                 # (self.stream is a fresh one if a capture was invalidated)
                 self._capture_two(mode)
@@ -346,8 +351,25 @@ class GraphedStep:
                 t.copy_(s_)
             torch.cuda.synchronize()
 
-    def _try_one_graph(self, mode, verify):
-        """capture forward + backward + bucket + all-reduce + optimiser as ONE graph; verify=True: replay it once from a
+    def _capture_one(self, mode):
+        tr = self.trainer
+        graph = torch.cuda.CUDAGraph()
+        try:
+            tr._allow_early = True
+            with torch.cuda.graph(graph, stream=self.stream, **mode):
+                self._fwd_bwd()
+                if os.environ.get("TSGNN_TEST_BREAK_CAPTURE") in ("all", str(dist.get_rank() if dist.is_initialized() else 0)):
+                    torch.cuda.current_stream().synchronize()   # test hook: an operation a capture does not admit — the
+                tr.all_reduce()                                 # capture is invalidated and raises (rehearsal of the fall-back)
+                tr.apply()
+        except Exception as e:                                  # noqa: BLE001 - any capture failure selects the two-graph step
+            print("GraphedStep: one-graph capture failed (%s: %s)" % (type(e).__name__, str(e).splitlines()[0]), flush=True)
+            return None
+        return graph
+
+    def _try_one_graph(self, graph, verify):
+        """`graph`: forward + backward + bucket + all-reduce + optimiser captured as ONE graph (_capture_one; None if the capture
+        raised on this rank); verify=True: replay it once from a
         snapshot and compare with the eager sequence from the same snapshot.  Leaves the trainer's state as it found it.
         -> installed in self._fb.
 
@@ -358,20 +380,9 @@ class GraphedStep:
           MIN all-reduce "did every rank capture?" -> only if all did: replay + eager step (both all-reduce the bucket) ->
           MIN all-reduce "did every rank's check pass?"."""
         tr = self.trainer
-        bufs = self._bufs()
-        self._snap = snap = [t.clone() for t in bufs]
-        graph = torch.cuda.CUDAGraph()
-        captured = True
-        try:
-            tr._allow_early = True
-            with torch.cuda.graph(graph, stream=self.stream, **mode):
-                self._fwd_bwd()
-                tr.all_reduce()
-                tr.apply()
-        except Exception as e:                                  # noqa: BLE001 - any capture failure selects the two-graph step
-            print("GraphedStep: one-graph capture failed (%s: %s)" % (type(e).__name__, str(e).splitlines()[0]), flush=True)
-            captured = False
-            graph = None
+        bufs, snap = self._bufs(), self._snap
+        captured = graph is not None
+        if not captured:
             self._abandon_stream()
         all_captured = self._agree(captured)
         if not all_captured:

@@ -147,7 +147,10 @@ def wgrad_reduce_multi(sets, norm_sink=None):
             else:
                 args += [None, 0, 0, 0, None, None]
         parts = norm_sink.norm_slots(nblk) if norm_sink is not None else None
-        step = norm_sink.step_state if (norm_sink is not None and parts is not None and i == 0) else None
+        # the step counter is advanced ONCE per optimiser step, by the first such launch (a model with several fused nodes —
+        # DiffPool's paired stacks and pooled levels — reduces weight gradients more than once per backward; every call used to
+        # advance it, and Adam's bias correction ran a step ahead: found by tests/test_gpu_fullsize.py)
+        step = norm_sink.step_state if (norm_sink is not None and parts is not None and i == 0 and not norm_sink.stepped) else None
         nat.call("wgrad_reduce_multi_f32", *args, parts, step)
         if norm_sink is not None and parts is not None:
             norm_sink.stepped = norm_sink.stepped or step is not None
