@@ -36,7 +36,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md:36
 MFMA_F32_PEAK_TF = 157.3       # dense fp32 MFMA, /opt/skills/guides/MI355X_MICROARCH.md:42
-PROFILE_DIR = os.path.join("profiles", "r02")
+PROFILE_DIR = os.path.join("profiles", "r03")
 
 
 def parse():
@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--no-sweep", action="store_true", help="skip the aggregation-kernel batch-size sweep")
     ap.add_argument("--no-kernels", action="store_true", help="skip the per-kernel table of the step (rocprof runs of the bare step)")
     ap.add_argument("--sweep-sizes", default="32,256,2048,16384")
+    ap.add_argument("--no-seeds", action="store_true", help="skip `value_over_seeds` (the same step on the batches of seeds 0-7)")
+    ap.add_argument("--seeds", default="0,1,2,3,4,5,6,7")
     ap.add_argument("--ingest", action="store_true", help="also time the step fed with a NEW host batch every step (collate + "
                                                           "upload on a copy stream, double-buffered): `ingest` in the JSON line")
     return ap.parse_args()
@@ -322,6 +324,40 @@ def cpu_baseline(hb, hidden, layers, steps, state):
                                          "padded rows otherwise as the reference (%.1f ms/step)" % (steps_s, dts * 1e3)}}
 
 
+# ----------------------------------------------------------------------------------------------- the step over seeds
+def over_seeds(a, model, trainer, dev, seeds, steps):
+    """The timed step on the batches of several seeds (at N ranks, rank r draws seed r: the slowest of them paces every
+    all-reduce), each replayed from its own hipGraph on the same model / trainer.  The headline batch (seed 0: 8,151 rows =
+    255 row panels, one per compute unit) is a favourable case; the mean and the worst of seeds 0-7 say what a DD batch costs."""
+    import torch
+    from two_stage_gnn_amd import synthetic
+    from two_stage_gnn_amd.data_parallel import GraphedStep
+    out = []
+    snap = [t.clone() for t in (trainer.flat_param, trainer.exp_avg, trainer.exp_avg_sq, trainer.state)]
+    for seed in seeds:
+        hb = synthetic.host_batch(seed=seed, B=a.batch, shape=a.shape, nmax=a.nmax)
+        g, x, label = synthetic.to_device(hb, dev)
+        gs = GraphedStep(trainer, lambda: model.loss(model(x, g)[1], label), warmup=3)
+        for _ in range(10):
+            gs.step()
+        gs.stream.synchronize()
+        best = None
+        for _ in range(3):
+            ms = hip_event_ms(gs.step, steps, gs.stream)
+            best = ms if best is None else min(best, ms)
+        out.append({"seed": seed, "rows": int(g.n_rows), "row_panels": (int(g.n_rows) + 31) // 32, "edges_directed": int(g.nnz),
+                    "ms_per_step": best})
+        del gs, g, x, label
+    for t, s_ in zip((trainer.flat_param, trainer.exp_avg, trainer.exp_avg_sq, trainer.state), snap):
+        t.copy_(s_)
+    torch.cuda.synchronize()
+    ms = [r["ms_per_step"] for r in out]
+    mean = sum(ms) / len(ms)
+    return {"per_seed": out, "mean_ms_per_step": mean, "worst_ms_per_step": max(ms), "best_ms_per_step": min(ms),
+            "worst_over_best": max(ms) / min(ms), "value_mean": a.batch / (mean * 1e-3), "value_worst": a.batch / (max(ms) * 1e-3),
+            "unit": "graphs/s", "note": "HIP events around %d replays per seed, best of 3; one GPU; the same model and optimiser state" % steps}
+
+
 # ----------------------------------------------------------------------------------------------- ingest on the clock
 def ingest_run(a, model, trainer, dev, steps, rank, value):
     """graphs/s when every step consumes a NEW mini-batch (f1, train.py:110-119 / graph_sampler.py:102-114): random batches of a
@@ -472,9 +508,17 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        per_rank = None
         if multi:
+            mine = torch.tensor([elapsed, float(g.n_rows), float(g.nnz)], device=dev, dtype=torch.float64)
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            per_rank = [{"rank": r, "seed": r, "rows": int(v[1].item()), "edges_directed": int(v[2].item()),
+                         "ms_per_step": float(v[0].item()) / a.steps * 1e3} for r, v in enumerate(allr)]
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    from two_stage_gnn_amd import message_passing as mp_
+    mp_.check_device_errors()                     # the host has synchronised: did any step report invalid results?
 
     out = None
     if rank == 0:
@@ -491,6 +535,8 @@ def main():
                        "launch": ("hipGraph replay (%s)" % gstep.describe()) if use_graph else "eager",
                        "rows": int(g.n_rows), "edges_directed": int(g.nnz)},
         }
+        if per_rank is not None:
+            out["per_rank"] = per_rank            # every rank's own batch and its own clock around the same K steps
         roofline = {}
         traffic, traffic_src = load_traffic()
         with torch.cuda.stream(stream):
@@ -565,6 +611,14 @@ def main():
                 roofline["sweep_note"] = ("stand-alone aggregation, F=%d, DD-shaped graphs; batches above 256 graphs repeat 256 generated "
                                           "graphs (every copy owns its rows)" % a.hidden)
         out["roofline"] = roofline
+        if not a.no_seeds and world == 1 and use_graph:
+            vs = over_seeds(a, model, trainer, dev, [int(v) for v in a.seeds.split(",") if v != ""], max(50, min(a.steps, 200)))
+            out["value_over_seeds"] = vs
+            # what an N-rank step is paced by: rank r draws seed r, every rank waits for the slowest at the all-reduce
+            roofline["straggler"] = {"ms_per_step": vs["worst_ms_per_step"], "seed": max(vs["per_seed"], key=lambda r: r["ms_per_step"])["seed"],
+                                     "rows": max(vs["per_seed"], key=lambda r: r["ms_per_step"])["rows"],
+                                     "vs_headline_batch": vs["worst_ms_per_step"] / ms_step,
+                                     "note": "max over seeds 0-7 of the one-GPU step = the pace of an 8-rank step before the all-reduce"}
     if a.ingest and world == 1:
         out["ingest"] = ingest_run(a, model, trainer, dev, max(a.steps, 100), rank, out["value"])
     if rank == 0:
