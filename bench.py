@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--sweep-sizes", default="32,256,2048,16384")
     ap.add_argument("--no-seeds", action="store_true", help="skip `value_over_seeds` (the same step on the batches of seeds 0-7)")
     ap.add_argument("--seeds", default="0,1,2,3,4,5,6,7")
+    ap.add_argument("--seed-base", type=int, default=0, help="rank r draws the batch of seed seed-base + r (default 0: the contract's batches)")
     ap.add_argument("--ingest", action="store_true", help="also time the step fed with a NEW host batch every step (collate + "
                                                           "upload on a copy stream, double-buffered): `ingest` in the JSON line")
     return ap.parse_args()
@@ -482,7 +483,7 @@ def main():
     fin = synthetic.SHAPES[a.shape][2]
     model = E.GcnEncoderGraph(fin, a.hidden, a.hidden, 2, a.layers, bn=True, args=Args(), final_dim="number_classes").to(dev)
     init_state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    hb = synthetic.host_batch(seed=rank, B=a.batch, shape=a.shape, nmax=a.nmax)      # per-rank batch (weak scaling)
+    hb = synthetic.host_batch(seed=a.seed_base + rank, B=a.batch, shape=a.shape, nmax=a.nmax)      # per-rank batch (weak scaling)
     g, x, label = synthetic.to_device(hb, dev)
     trainer = FlatTrainer(model, lr=1e-3, clip=2.0, defer_loss=True)     # the loss value is written by the head's backward kernel
     trainer.always_reduce = multi

@@ -35,6 +35,10 @@ inline int device_cu_count() {
   return n;
 }
 
+inline unsigned ks2_max_blocks() {                       // TSGNN_KS2_MAX_BLOCKS: up to how many row panels the two-group kernel is used
+  static const unsigned n = [] { const char* e = getenv("TSGNN_KS2_MAX_BLOCKS"); return e ? (unsigned)atoi(e) : (unsigned)device_cu_count(); }();
+  return n;
+}
 inline bool rowgemm_ks2_enabled() {                      // TSGNN_ROWGEMM_KS2=0 selects the one-group kernel (A/B measurements)
   static const bool on = [] { const char* e = getenv("TSGNN_ROWGEMM_KS2"); return !(e && e[0] == '0'); }();
   return on;
@@ -163,7 +167,7 @@ void launch_rowgemm(const RowGemmArgs& g, hipStream_t s) {
     // two wave groups per panel only while every panel has a CU to itself: with more panels than CUs the one-group kernel's
     // second co-resident block hides the same waits and keeps the MFMA pipe busier (measured: 308 panels 15.3 vs 13.6 us,
     // 17,324 panels 528 vs 474 us; <= 256 panels 9.5 vs 11.1 us)
-    if (g.K > KC && nblk <= (unsigned)device_cu_count() && rowgemm_ks2_enabled()) {
+    if (g.K > KC && nblk <= ks2_max_blocks() && rowgemm_ks2_enabled()) {
       constexpr size_t lds2 = rowgemm_lds_bytes<NT, TRANS_B, true, 2>();
       static bool attr = false;
       if (!attr && lds2 > 64 * 1024) {
