@@ -437,12 +437,159 @@ __device__ __forceinline__ void ce_rows(const CeArgs& ce, int B, int C, float* d
   }
 }
 
+// ---- third role of the backward launch (tsgnn_head2_bwd_du_f32): dU of the stack's LAST GraphConv layer.  That layer has no
+// batch-norm, so its dU is a row-wise function of the readout gradient (readout_l2_bwd_rows in sage_fused.hip):
+//   du[r] = rinv_r (g_r - v_r <v_r, g_r>),   g_r[f] = dout[b, off + f] if r is the max-readout winner of (graph b, column f), else 0.
+// It used to be a launch of its own between this one and the layer's weight-gradient / input-gradient launch.  Here block
+// (b, c) owns rows [64c, 64c + 64) of graph b and does not wait for row block b: it rebuilds the 128-wide segment of dout[b, :]
+// itself from the same operands in the same order (same bits), with every request — its rows of v, rinv, the winners, its W1
+// rows — issued before anything is waited for.  Ghost rows: all ghost rows of this layer are identical, so graph b can only
+// have won with its first one (row n_real + size_b); its contribution is written to du[n_real + b] — the rows behind the real
+// ones feed the bias gradient only (they aggregate nothing), where only their SUM matters, so B contribution rows stand for
+// the ghost rows (the caller passes bias_only_rows = B to the weight-gradient launch).  b == B: the padding rows of a
+// capacity-padded batch ([graph_ptr[B], n_real)) are zero-filled.
+struct DuArgs {
+  const int* graph_ptr; int64_t n_real; int n_ghost_rows; int chunks;
+  const float* v; int64_t ldv; const float* rinv; const int* arg; int off; int F;
+  float* du; int64_t lddu;
+};
+
+__device__ __forceinline__ void head2_du_role(const DuArgs& a, float* smem, const float* dy /* LDS or global [B, C] */, int d,
+                                              const float* __restrict__ dvec, const float* __restrict__ w1, const float* __restrict__ w2,
+                                              int B, int P, int E, int C, bool dy_ready_needs_sync) {
+  const int tid = threadIdx.x, NTH = 64 * HW;
+  const int b = d / a.chunks, c = d - b * a.chunks;
+  const int F4 = a.F >> 2, lig = tid & 31, rg = tid >> 5;       // 32 lanes per row (F <= 128), 32 rows per pass
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (b >= B) {                                                  // padding rows of a capacity-padded batch: zeros
+    const int64_t lo = a.graph_ptr[B];
+    for (int64_t r = lo + (int64_t)c * 32 + rg; r < a.n_real; r += (int64_t)a.chunks * 32)
+      if (lig < F4) *reinterpret_cast<float4*>(a.du + r * a.lddu + 4 * lig) = z4;
+    return;
+  }
+  const int g0 = a.graph_ptr[b], sz = a.graph_ptr[b + 1] - g0;
+  const int lo = 64 * c, hi = min(sz, lo + 64);
+  const bool ghost_job = c == 0;                                 // chunk 0 also writes the graph's ghost contribution row
+  if (lo >= hi && !ghost_job) return;
+  const int P4 = P >> 2;
+  const int G = min(16, NTH / P4);                               // the row block's grouping of the W1 rows: same sums, same order
+  float* ds = smem;                                              // [E]
+  float* part = smem + ((E + 3) & ~3);                           // [G][F]
+  float* dseg = part + G * a.F;                                  // [F]
+  // ---- requests
+  const int jg = tid >> 5;                                       // W1 row group (groups >= G idle)
+  const bool wact = jg < G && lig < F4;
+  float4 w[RB_ROWS];
+#pragma unroll
+  for (int u = 0; u < RB_ROWS; ++u) {
+    const int j = jg + G * u;
+    w[u] = ld4(w1 + (int64_t)((wact && j < E) ? j : 0) * P + a.off + 4 * (wact ? lig : 0));
+  }
+  float w2r[4];
+  float dv0 = 0.f;
+  if (tid < E) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w2r[q] = q < C ? w2[(int64_t)q * E + tid] : 0.f;
+    if (dvec) dv0 = dvec[(int64_t)b * E + tid];
+  }
+  float4 vv[2];
+  float ri[2];
+  int64_t rows[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int n = lo + rg + 32 * u;
+    rows[u] = n < hi ? (int64_t)g0 + n : -1;
+    const int64_t rr = rows[u] >= 0 ? rows[u] : 0;
+    vv[u] = ld4(a.v + rr * a.ldv + 4 * (lig < F4 ? lig : 0));
+    ri[u] = a.rinv[rr];
+  }
+  const bool has_ghost = ghost_job && sz < a.n_ghost_rows;      // (a graph that fills every slot has no padded row)
+  const int64_t grow = a.n_real + (has_ghost ? sz : 0);
+  float4 gv = z4;
+  float gri = 0.f;
+  if (ghost_job && rg == 0) { gv = ld4(a.v + grow * a.ldv + 4 * (lig < F4 ? lig : 0)); gri = a.rinv[grow]; }
+  const int4 win = *reinterpret_cast<const int4*>(a.arg + (int64_t)b * a.F + 4 * (lig < F4 ? lig : 0));
+  if (dy_ready_needs_sync) __syncthreads();
+  // ---- dvt row of graph b, then the segment of dout[b, :]   (expressions and order of the row blocks)
+  for (int j = tid; j < E; j += NTH) {
+    float acc = j == tid ? dv0 : (dvec ? dvec[(int64_t)b * E + j] : 0.f);
+    for (int q = 0; q < C; ++q) acc = fmaf(dy[(int64_t)b * C + q], (j == tid && q < 4) ? w2r[q] : w2[(int64_t)q * E + j], acc);
+    ds[j] = acc;
+  }
+  __syncthreads();
+  float4 acc = z4;
+  for (int j0 = 0; j0 < E; j0 += G * RB_ROWS) {
+    if (j0 > 0) {
+#pragma unroll
+      for (int u = 0; u < RB_ROWS; ++u) {
+        const int j = j0 + jg + G * u;
+        w[u] = ld4(w1 + (int64_t)((wact && j < E) ? j : 0) * P + a.off + 4 * (wact ? lig : 0));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < RB_ROWS; ++u) {
+      const int j = j0 + jg + G * u;
+      const float dd = (wact && j < E) ? ds[j] : 0.f;
+      acc.x = fmaf(dd, w[u].x, acc.x); acc.y = fmaf(dd, w[u].y, acc.y); acc.z = fmaf(dd, w[u].z, acc.z); acc.w = fmaf(dd, w[u].w, acc.w);
+    }
+  }
+  if (wact) *reinterpret_cast<float4*>(part + jg * a.F + 4 * lig) = acc;
+  __syncthreads();
+  for (int k = tid; k < a.F; k += NTH) {
+    float t = 0.f;
+    for (int q = 0; q < G; ++q) t += part[q * a.F + k];
+    dseg[k] = t;
+  }
+  __syncthreads();
+  const float4 gd = lig < F4 ? *reinterpret_cast<const float4*>(dseg + 4 * lig) : z4;
+  // ---- rows
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int r32 = (int)rows[u];
+    float4 dyv = z4;
+    if (rows[u] >= 0 && lig < F4) {
+      if (win.x == r32) dyv.x = gd.x;
+      if (win.y == r32) dyv.y = gd.y;
+      if (win.z == r32) dyv.z = gd.z;
+      if (win.w == r32) dyv.w = gd.w;
+    } else {
+      vv[u] = z4;
+    }
+    float dot = (vv[u].x * dyv.x + vv[u].y * dyv.y) + (vv[u].z * dyv.z + vv[u].w * dyv.w);
+    dot = group_sum<32>(dot);
+    if (rows[u] >= 0 && lig < F4) {
+      if (ri[u] >= 0.999e12f) dot = 0.f;
+      *reinterpret_cast<float4*>(a.du + rows[u] * a.lddu + 4 * lig) =
+          make_float4(ri[u] * (dyv.x - vv[u].x * dot), ri[u] * (dyv.y - vv[u].y * dot), ri[u] * (dyv.z - vv[u].z * dot),
+                      ri[u] * (dyv.w - vv[u].w * dot));
+    }
+  }
+  if (ghost_job && rg == 0) {                                    // (one whole half-wave: the cross-lane sum below is complete)
+    const int r32 = (int)grow;
+    float4 dyv = z4;
+    if (has_ghost && lig < F4) {
+      if (win.x == r32) dyv.x = gd.x;
+      if (win.y == r32) dyv.y = gd.y;
+      if (win.z == r32) dyv.z = gd.z;
+      if (win.w == r32) dyv.w = gd.w;
+    } else {
+      gv = z4;
+    }
+    float dot = (gv.x * dyv.x + gv.y * dyv.y) + (gv.z * dyv.z + gv.w * dyv.w);
+    dot = group_sum<32>(dot);
+    if (gri >= 0.999e12f) dot = 0.f;
+    if (lig < F4)
+      *reinterpret_cast<float4*>(a.du + (a.n_real + b) * a.lddu + 4 * lig) =
+          make_float4(gri * (dyv.x - gv.x * dot), gri * (dyv.y - gv.y * dot), gri * (dyv.z - gv.z * dot), gri * (dyv.w - gv.w * dot));
+  }
+}
+
 __global__ __launch_bounds__(64 * HW) void head2_bwd2_kernel(const float* __restrict__ out, int64_t ldo, const float* __restrict__ vec,
                                                          const float* __restrict__ dy_in, const float* __restrict__ dvec,
                                                          const float* __restrict__ w1, const float* __restrict__ w2, int B, int P, int E,
                                                          int C, float* __restrict__ dout, int64_t lddo, float* __restrict__ dw1,
                                                          float* __restrict__ db1, float* __restrict__ dw2, float* __restrict__ db2,
-                                                         float* __restrict__ normparts, CeArgs ce) {
+                                                         float* __restrict__ normparts, CeArgs ce, DuArgs dua) {
   extern __shared__ __attribute__((aligned(16))) float smem_all[];
   const int tid = threadIdx.x, NTH = 64 * HW;
   const int P4 = P >> 2, PP = P;                         // P % 4 == 0 on this path
@@ -452,6 +599,14 @@ __global__ __launch_bounds__(64 * HW) void head2_bwd2_kernel(const float* __rest
   float* smem = lb + (has_ce ? ((B + 3) & ~3) : 0);      // role-specific region, 16-byte aligned
   const float* dy = has_ce ? dyl : dy_in;
   const int nj = (E + 3) / 4;
+  if ((int)blockIdx.x >= B + nj + 1) {
+    // ------------------------------------------------------------------------------------------------ last layer's dU rows
+    const int d = (int)blockIdx.x - (B + nj + 1);
+    const int gb = d / dua.chunks;
+    if (has_ce && gb < B) ce_rows(ce, B, C, dyl, lb, gb);          // (thread 0 rebuilds row gb; synchronised inside the role)
+    head2_du_role(dua, smem, dy, d, dvec, w1, w2, B, P, E, C, has_ce);
+    return;
+  }
 
   if ((int)blockIdx.x < B) {
     // ------------------------------------------------------------------------------------------------ row block
@@ -693,7 +848,7 @@ int tsgnn_packed_head_fwd_f32(const unsigned long long* packed, int B, int L, in
 static int head2_bwd_launch(const float* out, int64_t ldo, const float* vec, const float* dy, const float* dvec, const float* w1,
                             const float* w2, int B, int P, int E, int C, float* dout, int64_t lddo, float* dw1, float* db1,
                             float* dw2, float* db2, float* normparts, const float* ce_y, const int64_t* ce_label, float* ce_loss,
-                            tsgnn_stream_t stream) {
+                            tsgnn_stream_t stream, const DuArgs* du = nullptr) {
   if (!out || !vec || (!dy && !ce_label) || !w1 || !w2 || !dout || !dw1 || !dw2 || B <= 0 || P <= 0 || E <= 0 || C <= 0) return TSGNN_EINVAL;
   if (ce_label && (!ce_y || !ce_loss)) return TSGNN_EINVAL;
   if ((P % 4) || P > 2048 || E > 4096 || B > 1024 || (reinterpret_cast<uintptr_t>(w1) & 15)) return TSGNN_EUNSUPPORTED;
@@ -707,6 +862,16 @@ static int head2_bwd_launch(const float* out, int64_t ldo, const float* vec, con
     if (wrole > role) role = wrole;
     if (role < HW) role = HW;
     size_t lds2 = sizeof(float) * role;
+    DuArgs dua{};
+    unsigned du_blocks = 0;
+    if (du) {
+      dua = *du;
+      const int G = 64 * HW / P4 < 16 ? 64 * HW / P4 : 16;
+      const size_t drole = (size_t)((E + 3) & ~3) + (size_t)(G + 1) * dua.F;
+      if (drole > role) role = drole;
+      du_blocks = (unsigned)(B + 1) * (unsigned)dua.chunks;
+    }
+    lds2 = sizeof(float) * role;
     if (ce_label) lds2 += sizeof(float) * (size_t)(((B * C + 3) & ~3) + ((B + 3) & ~3));
     if (lds2 <= 160 * 1024 - 1024) {
       static size_t attr_set = 0;
@@ -714,13 +879,15 @@ static int head2_bwd_launch(const float* out, int64_t ldo, const float* vec, con
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(head2_bwd2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
         attr_set = lds2;
       }
-      TSGNN_KNAME("head2_bwd2_kernel");
-      head2_bwd2_kernel<<<B + (E + 3) / 4 + 1, 64 * HW, lds2, stream>>>(out, ldo, vec, dy, dvec, w1, w2, B, P, E, C, dout, lddo, dw1, db1, dw2, db2,
-                                                                    normparts, CeArgs{ce_y, ce_label, ce_loss});
+      TSGNN_KNAME(du ? "head2_bwd2_kernel (+ last layer's dU rows)" : "head2_bwd2_kernel");
+      head2_bwd2_kernel<<<B + (E + 3) / 4 + 1 + du_blocks, 64 * HW, lds2, stream>>>(out, ldo, vec, dy, dvec, w1, w2, B, P, E, C, dout, lddo,
+                                                                                dw1, db1, dw2, db2, normparts,
+                                                                                CeArgs{ce_y, ce_label, ce_loss}, dua);
       TSGNN_CHECK_LAUNCH();
       return TSGNN_OK;
     }
   }
+  if (du) return TSGNN_EUNSUPPORTED;                   // the dU role rides in the second-generation kernel only
   size_t lds = sizeof(float) * (size_t)(((E + 3) & ~3) + HW * ((P + 3) & ~3));
   if (lds < sizeof(float) * (4 * (size_t)B + HW)) lds = sizeof(float) * (4 * (size_t)B + HW);
   if (ce_label) lds += sizeof(float) * (size_t)(((B * C + 3) & ~3) + ((B + 3) & ~3));
@@ -746,6 +913,29 @@ int tsgnn_head2_bwd_ce_f32(const float* out, int64_t ldo, const float* vec, cons
   if (!y || !label || !loss) return TSGNN_EINVAL;
   return head2_bwd_launch(out, ldo, vec, nullptr, dvec, w1, w2, B, P, E, C, dout, lddo, dw1, db1, dw2, db2, normparts, y, label, loss,
                           stream);
+}
+
+/* tsgnn_head2_bwd_ce_f32 / tsgnn_head2_bwd_f32 (y == NULL: dy given) whose launch ALSO produces dU of the stack's last GraphConv
+ * layer (no batch-norm: dU is a row-wise function of the readout gradient — what tsgnn_readout_l2_bwd_f32 computes in a launch of
+ * its own): extra workgroups (graph b, 64-row chunk) rebuild the F-wide segment [seg_off, seg_off + F) of dout[b, :] themselves.
+ * v / rinv: the layer's output rows and 1/norm; arg [B, F]: its max-readout winners; du rows [0, n_real) are written, and
+ * du[n_real + b] = graph b's ghost-row contribution (all ghost rows of this layer are identical; only the SUM of the rows behind the
+ * real ones is ever used — the bias gradient — so pass bias_only_rows = B downstream).  n_ghost_rows: ghost rows that exist
+ * (a graph with size >= n_ghost_rows has none); chunks = ceil(largest graph / 64).  TSGNN_EUNSUPPORTED: shapes the
+ * second-generation backward kernel does not take (nothing launched: fall back to the two launches). */
+int tsgnn_head2_bwd_du_f32(const float* out, int64_t ldo, const float* vec, const float* y, const int64_t* label, float* loss,
+                           const float* dy, const float* dvec, const float* w1, const float* w2, int B, int P, int E, int C, float* dout,
+                           int64_t lddo, float* dw1, float* db1, float* dw2, float* db2, float* normparts, const int* graph_ptr,
+                           int64_t n_real, int n_ghost_rows, int chunks, const float* v, int64_t ldv, const float* rinv, const int* arg,
+                           int seg_off, int F, float* du, int64_t lddu, tsgnn_stream_t stream) {
+  if (!graph_ptr || !v || !rinv || !arg || !du || n_real < 0 || n_ghost_rows < 0 || chunks <= 0 || F <= 0 || seg_off < 0) return TSGNN_EINVAL;
+  if ((y == nullptr) == (dy == nullptr)) return TSGNN_EINVAL;
+  if (y && (!label || !loss)) return TSGNN_EINVAL;
+  if ((F % 4) || F > 128 || (seg_off % 4) || seg_off + F > P || (ldv % 4) || (lddu % 4) || ldv < F || lddu < F || chunks > 4096 ||
+      ((reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(du) | reinterpret_cast<uintptr_t>(arg)) & 15))
+    return TSGNN_EUNSUPPORTED;
+  const DuArgs a{graph_ptr, n_real, n_ghost_rows, chunks, v, ldv, rinv, arg, seg_off, F, du, lddu};
+  return head2_bwd_launch(out, ldo, vec, dy, dvec, w1, w2, B, P, E, C, dout, lddo, dw1, db1, dw2, db2, normparts, y, label, loss, stream, &a);
 }
 
 }  // extern "C"

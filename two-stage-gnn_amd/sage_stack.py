@@ -55,6 +55,7 @@ GATHER_MAX_ROWS = int(os.environ.get("TSGNN_GATHER_MAX_ROWS", 65536))   # above:
 GATHER_FUSED = os.environ.get("TSGNN_GATHER_FUSED", "1") != "0"     # aggregate inside the `.W` product when the neighbour table has no CSR tail
 EPILOGUE_READOUT = os.environ.get("TSGNN_EPILOGUE_READOUT", "1") != "0"   # the last layer's max readout in its product's epilogue
 LAST_LAYER_ROWS = os.environ.get("TSGNN_LAST_LAYER_ROWS", "1") != "0"     # the last layer's dU from a row-parallel kernel
+HEAD_DU = os.environ.get("TSGNN_HEAD_DU", "1") != "0"                     # ... computed by extra workgroups of the head's backward launch
 
 
 SLABS_BESIDE = os.environ.get("TSGNN_SLABS_BESIDE", "1") != "0"
@@ -251,6 +252,7 @@ class _SageStack(torch.autograd.Function):
         Fh, Fl = ctx.dims
         R, B = g.total_rows, g.B
         head_grads = ()
+        du_last = None                                # the last layer's dU when the head's backward launch produced it
         if ctx.head is None:
             dout = gouts[0].contiguous()
             dev = dout.device
@@ -271,7 +273,21 @@ class _SageStack(torch.autograd.Function):
             db1, s3 = mp._sink_or_new(pb1, (E,), dev) if pb1 is not None else (None, False)
             db2, s4 = mp._sink_or_new(pb2, (C,), dev) if pb2 is not None else (None, False)
             parts = mp.head_norm_slots((s1, s2, s3, s4), (pb1 is not None, pb2 is not None), (pw1, pb1, pw2, pb2), E)
-            if ce is not None:
+            sn_, sg_ = ctx.slots
+            v_l, rinv_l, lean_l = ctx.saved[L - 1][1], ctx.saved[L - 1][2], ctx.saved[L - 1][5]
+            if (HEAD_DU and LAST_LAYER_ROWS and not ctx.nodes and L > 1 and lean_l and Fl % 4 == 0 and Fl <= 128 and g.n_ghost == g.nmax
+                    and sn_ == sg_ and g.n_ghost >= B and ctx.needs_input_grad[5 + 2 * (L - 1)] and v_l.stride(0) % 4 == 0):
+                # the last layer's dU (a row-wise function of the readout gradient: it has no batch-norm) rides in this launch
+                du_l = torch.empty(R, Fl, dtype=torch.float32, device=dev)
+                argl = ctx.arg[(L - 1) * B * Fh:(L - 1) * B * Fh + B * Fl]
+                if nat.try_call("head2_bwd_du_f32", out, out.stride(0), vec, ce[0] if ce is not None else None,
+                                ce[1] if ce is not None else None, ce[2] if ce is not None else None, None if ce is not None else dy, dvec,
+                                w1c, w2c, B, P, E, C, dout, dout.stride(0), dw1, db1, dw2, db2, parts, g.graph_ptr, g.n_rows, sg_,
+                                (sn_ + 63) // 64, v_l, v_l.stride(0), rinv_l, argl, (L - 1) * Fh, Fl, du_l, du_l.stride(0)):
+                    du_last = du_l
+            if du_last is not None:
+                pass
+            elif ce is not None:
                 nat.call("head2_bwd_ce_f32", out, out.stride(0), vec, ce[0], ce[1], ce[2], dvec, w1c, w2c, B, P, E, C, dout,
                          dout.stride(0), dw1, db1, dw2, db2, parts)
             else:
@@ -292,7 +308,8 @@ class _SageStack(torch.autograd.Function):
             W = ctx.Ws[l]
             K, N = W.size(0), W.size(1)
             last = l == L - 1
-            du = torch.empty(R, N, dtype=torch.float32, device=dev)
+            du = du_last if (last and du_last is not None) else torch.empty(R, N, dtype=torch.float32, device=dev)
+            bo = sg                                   # rows behind the real ones that feed the bias gradient only
             if ctx.nodes:
                 dsl = argl = None
                 dnode = dout[:, l * Fh:l * Fh + N]           # gradient of this layer's block of the node output
@@ -300,7 +317,9 @@ class _SageStack(torch.autograd.Function):
                 dsl = dout[:, l * Fh:l * Fh + N]
                 argl = ctx.arg[l * B * Fh:l * B * Fh + B * N]
                 dnode = None
-            if (LAST_LAYER_ROWS and last and not ctx.nodes and dxs is None and N % 4 == 0 and N <= 128 and g.n_ghost == g.nmax
+            if last and du_last is not None:
+                bo = B                                # B ghost CONTRIBUTION rows stand for the sg ghost rows (tsgnn_head2_bwd_du_f32)
+            elif (LAST_LAYER_ROWS and last and not ctx.nodes and dxs is None and N % 4 == 0 and N <= 128 and g.n_ghost == g.nmax
                     and sn == sg and dout.stride(0) % 4 == 0 and dsl.data_ptr() % 16 == 0 and g.row_graph is not None):
                 # the last layer has no batch-norm: its dU is a row-wise function of the readout gradient (no slot structure)
                 nat.call("readout_l2_bwd_f32", g.graph_ptr, g.row_graph, B, g.n_rows, sg, v, v.stride(0), dsl, dout.stride(0), argl, N, rinv,
@@ -325,7 +344,7 @@ class _SageStack(torch.autograd.Function):
                     ws = torch.empty(need, dtype=torch.float32, device=dev)
                     dxs = torch.empty(R, K, dtype=torch.float32, device=dev)
                     nat.call("sage_layer_bwd_f32", ell, ell_w, tp, tc, du, du.stride(0), W, W.stride(0), dxs, dxs.stride(0), z, z.stride(0),
-                             g.n_rows, nslab, rps, sg, ws)
+                             g.n_rows, nslab, rps, bo, ws)
                     dw, sw = mp._sink_or_new(ctx.params[2 * l], (K, N), dev)
                     db, sb = mp._sink_or_new(ctx.params[2 * l + 1], (N,), dev) if want_b else (None, False)
                     pending.append((ws, nslab, K, N, dw, db))
@@ -338,7 +357,7 @@ class _SageStack(torch.autograd.Function):
             if want_w:
                 if not lean and sg < g.n_ghost:
                     du[g.n_rows + sg:].zero_()          # rows no slot kernel wrote
-                sl = mp.linear_wgrad_slabs(z, K, du[:g.n_rows + sg] if lean else du, bias_only_rows=sg if lean else 0)
+                sl = mp.linear_wgrad_slabs(z, K, du[:g.n_rows + bo] if lean else du, bias_only_rows=bo if lean else 0)
                 if sl is not None:                      # slabs now, ONE reduction for all layers at the end
                     dw, sw = mp._sink_or_new(ctx.params[2 * l], (K, N), dev)     # straight into the flat bucket if one is installed
                     db, sb = mp._sink_or_new(ctx.params[2 * l + 1], (N,), dev) if want_b else (None, False)
