@@ -477,13 +477,21 @@ __device__ __forceinline__ void head2_du_role(const DuArgs& a, float* smem, cons
   float* part = smem + ((E + 3) & ~3);                           // [G][F]
   float* dseg = part + G * a.F;                                  // [F]
   // ---- requests
+  // (W1 rows in batches of DU_ROWS = 8: sixteen rows in flight plus the row operands below spilled 46 registers of this 1,024-thread
+  // kernel into scratch — 17.5 us for the launch instead of 6.2; the FIRST batch is requested up front, the second after its products,
+  // accumulated in the row block's order u = 0..15)
+  constexpr int DU_ROWS = 8;
+  static_assert(RB_ROWS % DU_ROWS == 0, "the row block's batches are walked in pieces");
   const int jg = tid >> 5;                                       // W1 row group (groups >= G idle)
   const bool wact = jg < G && lig < F4;
-  float4 w[RB_ROWS];
+  // (addresses as a uniform base + a 32-bit lane offset: one register per request instead of a 64-bit pair — this kernel runs at
+  // 128 registers per lane, and the pairs were what spilled)
+  const unsigned wcol = (unsigned)a.off + 4u * (unsigned)(wact ? lig : 0);
+  float4 w[DU_ROWS];
 #pragma unroll
-  for (int u = 0; u < RB_ROWS; ++u) {
+  for (int u = 0; u < DU_ROWS; ++u) {
     const int j = jg + G * u;
-    w[u] = ld4(w1 + (int64_t)((wact && j < E) ? j : 0) * P + a.off + 4 * (wact ? lig : 0));
+    w[u] = ld4(w1 + (size_t)((unsigned)((wact && j < E) ? j : 0) * (unsigned)P + wcol));
   }
   float w2r[4];
   float dv0 = 0.f;
@@ -492,23 +500,24 @@ __device__ __forceinline__ void head2_du_role(const DuArgs& a, float* smem, cons
     for (int q = 0; q < 4; ++q) w2r[q] = q < C ? w2[(int64_t)q * E + tid] : 0.f;
     if (dvec) dv0 = dvec[(int64_t)b * E + tid];
   }
+  const unsigned ldv = (unsigned)a.ldv, lddu = (unsigned)a.lddu, col = 4u * (unsigned)(lig < F4 ? lig : 0);
   float4 vv[2];
   float ri[2];
-  int64_t rows[2];
+  int rows[2];                                                   // (rows < 2^31 / ld: checked by the entry point)
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int n = lo + rg + 32 * u;
-    rows[u] = n < hi ? (int64_t)g0 + n : -1;
-    const int64_t rr = rows[u] >= 0 ? rows[u] : 0;
-    vv[u] = ld4(a.v + rr * a.ldv + 4 * (lig < F4 ? lig : 0));
+    rows[u] = n < hi ? g0 + n : -1;
+    const unsigned rr = rows[u] >= 0 ? (unsigned)rows[u] : 0u;
+    vv[u] = ld4(a.v + (size_t)(rr * ldv + col));
     ri[u] = a.rinv[rr];
   }
   const bool has_ghost = ghost_job && sz < a.n_ghost_rows;      // (a graph that fills every slot has no padded row)
-  const int64_t grow = a.n_real + (has_ghost ? sz : 0);
+  const int grow = (int)a.n_real + (has_ghost ? sz : 0);
   float4 gv = z4;
   float gri = 0.f;
-  if (ghost_job && rg == 0) { gv = ld4(a.v + grow * a.ldv + 4 * (lig < F4 ? lig : 0)); gri = a.rinv[grow]; }
-  const int4 win = *reinterpret_cast<const int4*>(a.arg + (int64_t)b * a.F + 4 * (lig < F4 ? lig : 0));
+  if (ghost_job && rg == 0 && a.n_ghost_rows > 0) { gv = ld4(a.v + (size_t)((unsigned)grow * ldv + col)); gri = a.rinv[grow]; }
+  const int4 win = *reinterpret_cast<const int4*>(a.arg + (size_t)((unsigned)b * (unsigned)a.F + col));
   if (dy_ready_needs_sync) __syncthreads();
   // ---- dvt row of graph b, then the segment of dout[b, :]   (expressions and order of the row blocks)
   for (int j = tid; j < E; j += NTH) {
@@ -517,21 +526,25 @@ __device__ __forceinline__ void head2_du_role(const DuArgs& a, float* smem, cons
     ds[j] = acc;
   }
   __syncthreads();
+  // (E <= G * RB_ROWS, checked by the entry point: the row block's loop over batches of G * RB_ROWS rows has ONE iteration, and
+  // no loop here keeps the address arithmetic of the requests out of long live ranges)
   float4 acc = z4;
-  for (int j0 = 0; j0 < E; j0 += G * RB_ROWS) {
-    if (j0 > 0) {
 #pragma unroll
-      for (int u = 0; u < RB_ROWS; ++u) {
-        const int j = j0 + jg + G * u;
-        w[u] = ld4(w1 + (int64_t)((wact && j < E) ? j : 0) * P + a.off + 4 * (wact ? lig : 0));
+  for (int u0 = 0; u0 < RB_ROWS; u0 += DU_ROWS) {
+    if (u0 > 0) {
+#pragma unroll
+      for (int u = 0; u < DU_ROWS; ++u) {
+        const int j = jg + G * (u0 + u);
+        w[u] = ld4(w1 + (size_t)((unsigned)((wact && j < E) ? j : 0) * (unsigned)P + wcol));
       }
     }
 #pragma unroll
-    for (int u = 0; u < RB_ROWS; ++u) {
-      const int j = j0 + jg + G * u;
+    for (int u = 0; u < DU_ROWS; ++u) {
+      const int j = jg + G * (u0 + u);
       const float dd = (wact && j < E) ? ds[j] : 0.f;
       acc.x = fmaf(dd, w[u].x, acc.x); acc.y = fmaf(dd, w[u].y, acc.y); acc.z = fmaf(dd, w[u].z, acc.z); acc.w = fmaf(dd, w[u].w, acc.w);
     }
+    __builtin_amdgcn_sched_barrier(0);                           // (the second batch's requests stay behind the first batch's products)
   }
   if (wact) *reinterpret_cast<float4*>(part + jg * a.F + 4 * lig) = acc;
   __syncthreads();
@@ -545,7 +558,7 @@ __device__ __forceinline__ void head2_du_role(const DuArgs& a, float* smem, cons
   // ---- rows
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
-    const int r32 = (int)rows[u];
+    const int r32 = rows[u];
     float4 dyv = z4;
     if (rows[u] >= 0 && lig < F4) {
       if (win.x == r32) dyv.x = gd.x;
@@ -559,13 +572,13 @@ __device__ __forceinline__ void head2_du_role(const DuArgs& a, float* smem, cons
     dot = group_sum<32>(dot);
     if (rows[u] >= 0 && lig < F4) {
       if (ri[u] >= 0.999e12f) dot = 0.f;
-      *reinterpret_cast<float4*>(a.du + rows[u] * a.lddu + 4 * lig) =
+      *reinterpret_cast<float4*>(a.du + (size_t)((unsigned)rows[u] * lddu + col)) =
           make_float4(ri[u] * (dyv.x - vv[u].x * dot), ri[u] * (dyv.y - vv[u].y * dot), ri[u] * (dyv.z - vv[u].z * dot),
                       ri[u] * (dyv.w - vv[u].w * dot));
     }
   }
   if (ghost_job && rg == 0) {                                    // (one whole half-wave: the cross-lane sum below is complete)
-    const int r32 = (int)grow;
+    const int r32 = grow;
     float4 dyv = z4;
     if (has_ghost && lig < F4) {
       if (win.x == r32) dyv.x = gd.x;
@@ -579,7 +592,7 @@ __device__ __forceinline__ void head2_du_role(const DuArgs& a, float* smem, cons
     dot = group_sum<32>(dot);
     if (gri >= 0.999e12f) dot = 0.f;
     if (lig < F4)
-      *reinterpret_cast<float4*>(a.du + (a.n_real + b) * a.lddu + 4 * lig) =
+      *reinterpret_cast<float4*>(a.du + (size_t)((unsigned)((int)a.n_real + b) * lddu + col)) =
           make_float4(gri * (dyv.x - gv.x * dot), gri * (dyv.y - gv.y * dot), gri * (dyv.z - gv.z * dot), gri * (dyv.w - gv.w * dot));
   }
 }
@@ -934,6 +947,11 @@ int tsgnn_head2_bwd_du_f32(const float* out, int64_t ldo, const float* vec, cons
   if ((F % 4) || F > 128 || (seg_off % 4) || seg_off + F > P || (ldv % 4) || (lddu % 4) || ldv < F || lddu < F || chunks > 4096 ||
       ((reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(du) | reinterpret_cast<uintptr_t>(arg)) & 15))
     return TSGNN_EUNSUPPORTED;
+  if ((n_real + 1024 + B) * (ldv > lddu ? ldv : lddu) >= (int64_t)1 << 30 || (int64_t)E * P >= (int64_t)1 << 30) return TSGNN_EUNSUPPORTED;   // 32-bit offsets
+  {
+    const int P4 = P / 4, G = P4 > 0 ? (64 * HW / P4 < 16 ? 64 * HW / P4 : 16) : 0;
+    if ((P % 4) || G < 1 || E > G * RB_ROWS || G * 32 > 64 * HW) return TSGNN_EUNSUPPORTED;     // one batch of W1 rows per row group (head2_du_role)
+  }
   const DuArgs a{graph_ptr, n_real, n_ghost_rows, chunks, v, ldv, rinv, arg, seg_off, F, du, lddu};
   return head2_bwd_launch(out, ldo, vec, dy, dvec, w1, w2, B, P, E, C, dout, lddo, dw1, db1, dw2, db2, normparts, y, label, loss, stream, &a);
 }
