@@ -268,6 +268,29 @@ int tsgnn_rowgemm_f32(const float* a, int64_t lda, const float* b, int64_t ldb, 
 int tsgnn_gather_rowgemm_f32(const int* ell, int ell_w, const int* tail_ptr, const int* tail_col, const float* x, int64_t ldx, const float* b, int64_t ldb, int trans_b,
                              const float* bias, float* c, int64_t ldc, float* rinv, float* zout, int64_t ldz, int64_t rows, int K,
                              int N, int normalize, int64_t fill_rows, tsgnn_stream_t stream);
+/* tsgnn_gather_rowgemm_f32 (trans_b = 0, normalize = 1, 96 < N <= 128, no CSR tail) for a layer that is followed by the slot
+ * batch-norm (apply_bn, encoders.py:134-138) WITHOUT a launch for it: the epilogue adds every real row's
+ * (sum_f relu(v), sum_f relu(v)^2) to sums[2 * row_slot[r]] as 64-bit fixed-point integers (2^-40 units: integer addition is
+ * associative, so the totals do not depend on the order the panels finish in — bitwise reproducible) and the filler block leaves
+ * the ghost row's two numbers in ghost[0..1].  sums [2 * nslots], 16-byte aligned, zero before the launch; row_slot[r] < 0: row r
+ * belongs to no graph (padding of a capacity-padded batch).  Consumer: tsgnn_sage_layer_fwd_bn_f32. */
+int tsgnn_gather_rowgemm_st_f32(const int* ell, int ell_w, const float* x, int64_t ldx, const float* b, int64_t ldb, const float* bias,
+                                float* c, int64_t ldc, float* rinv, float* zout, int64_t ldz, int64_t rows, int K, int N,
+                                int64_t fill_rows, const int* row_slot, unsigned long long* sums, float* ghost, tsgnn_stream_t stream);
+/* tsgnn_sage_layer_fwd[_ro]_f32 for a layer whose INPUT's slot batch-norm has no launch of its own: x = the previous layer's
+ * normalised pre-activations v, sums_in / ghost_in = what its statistics epilogue left, slot_count[n] = graphs with more than n
+ * nodes.  Every row-panel block turns the sums into (mean, rstd) per slot — exact from the integers, ghost copies by their
+ * multiplicity B - slot_count[n], biased variance, eps 1e-5 — and gathers y_j = (relu(v_j) - mean[slot_j]) * rstd[slot_j]; the
+ * readout partial does the same for the rows it scans, and its blocks of graph 0 write mean_out / rstd_out [nslots] for the
+ * backward (tsgnn_slot_post_bwd_f32).  ell: entry = slot << 20 | row (no CSR tail), nslots <= 1024, rows < 2^20, n_ghost = nslots.
+ * row_slot != NULL: this layer is followed by a batch-norm as well, its statistics go to sums_out / ghost_out (zero before);
+ * packed_out != NULL: last layer, readout epilogue as in tsgnn_sage_layer_fwd_ro_f32 (not both). */
+int tsgnn_sage_layer_fwd_bn_f32(const int* ell, int ell_w, const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias,
+                                float* v, int64_t ldv, float* rinv, float* zout, int64_t ldz, int64_t rows, int K, int64_t fill_rows,
+                                const int* graph_ptr, const int* slot_count, int B, int nslots, int n_ghost, unsigned long long* packed,
+                                unsigned long long* packed_out, const int* row_graph, const unsigned long long* sums_in,
+                                const float* ghost_in, float* mean_out, float* rstd_out, const int* row_slot,
+                                unsigned long long* sums_out, float* ghost_out, tsgnn_stream_t stream);
 /* Forward of a hidden 128 -> 128 GraphConv layer in ONE launch together with the max-readout partial of its INPUT x (the
  * previous layer's output; both only read x): tsgnn_gather_rowgemm_f32(normalize = 1, fill_rows) + tsgnn_readout_partial_f32
  * over x into packed[B*128] (layout and ghost-row rule as there; n_real = rows). */
@@ -725,6 +748,12 @@ int tsgnn_readout_head_fwd_f32(const unsigned long long* packed, int B, int L, i
 int tsgnn_packed_head_fwd_f32(const unsigned long long* packed, int B, int L, int Fh, int Fl, float* out, int64_t ldo, int* arg,
                               const float* w1, const float* b1, const float* w2, const float* b2, int E, int C, float* vec, float* y,
                               tsgnn_stream_t stream);
+/* tsgnn_packed_head_fwd_f32 that also does the step's housekeeping: every decoded entry of packed is zeroed (ready for the next
+ * step's atomicMax) and clear[0 .. clear_n) 64-bit words are zeroed (the integer sums of the fused slot batch-norms: all
+ * consumed by the launches before this one). */
+int tsgnn_packed_head_fwd_z_f32(unsigned long long* packed, int B, int L, int Fh, int Fl, float* out, int64_t ldo, int* arg,
+                                const float* w1, const float* b1, const float* w2, const float* b2, int E, int C, float* vec, float* y,
+                                unsigned long long* clear, int64_t clear_n, tsgnn_stream_t stream);
 /* backward in one launch: dvt = dvec (nullable) + W2^T dy (internal) ; dout = W1^T dvt ; dW1 = dvt^T out ; db1 ; dW2 = dy^T vec ; db2.
  * normparts (nullable, ceil(E/4) + 1 floats): per weight block, the sum of squares of the gradient entries it wrote. */
 int tsgnn_head2_bwd_f32(const float* out, int64_t ldo, const float* vec, const float* dy, const float* dvec, const float* w1,

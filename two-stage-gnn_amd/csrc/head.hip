@@ -146,12 +146,17 @@ __global__ __launch_bounds__(64 * HW) void packed_head_fwd_kernel(const unsigned
                                                               int Fl, float* __restrict__ out, int64_t ldo, int* __restrict__ arg,
                                                               const float* __restrict__ w1, const float* __restrict__ b1,
                                                               const float* __restrict__ w2, const float* __restrict__ b2, int P, int E,
-                                                              int C, float* __restrict__ vec, float* __restrict__ y, ExpandRider rider) {
+                                                              int C, float* __restrict__ vec, float* __restrict__ y, ExpandRider rider,
+                                                              unsigned long long* __restrict__ clear, int64_t clear_n, int clear_packed) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if ((int)blockIdx.x >= B) {                        // passengers: the next mini-batch's expansion on the CUs this launch leaves idle
     expand_rider_body(rider, blockIdx.x - (unsigned)B, 64 * HW);
     return;
   }
+  // housekeeping for the NEXT step (tsgnn_packed_head_fwd_z_f32): the integer sums of the fused slot batch-norms were consumed by
+  // the launches before this one; zeroing them here (and this graph's packed maxima after they are decoded, below) takes the
+  // clearing launch out of the step
+  for (int64_t i2 = (int64_t)blockIdx.x * (64 * HW) + threadIdx.x; i2 < clear_n; i2 += (int64_t)B * (64 * HW)) clear[i2] = 0ull;
   float* xs = smem;                                  // [P]
   float* vs = smem + ((P + 3) & ~3);                 // [E]
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -204,6 +209,7 @@ __global__ __launch_bounds__(64 * HW) void packed_head_fwd_kernel(const unsigned
       xs[k] = val;
       out[(int64_t)b * ldo + k] = val;
       arg[pidx[u]] = p ? (int)(0xFFFFFFFFu - (unsigned)(p & 0xFFFFFFFFull)) : -1;
+      if (clear_packed) const_cast<unsigned long long*>(packed)[pidx[u]] = 0ull;
     }
   }
   __syncthreads();
@@ -853,7 +859,27 @@ int tsgnn_packed_head_fwd_f32(const unsigned long long* packed, int B, int L, in
   const ExpandRider rider = take_expand_rider();       // (no workgroups unless tsgnn_ingest_arm_expand_rider armed one on this thread)
   TSGNN_KNAME("packed_head_fwd_kernel<8>");
   packed_head_fwd_kernel<8><<<(unsigned)B + rider.blocks, 64 * HW, lds, stream>>>(packed, B, L, Fh, Fl, out, ldo, arg, w1, b1, w2, b2, P, E, C,
-                                                                               vec, y, rider);
+                                                                               vec, y, rider, nullptr, 0, 0);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+/* tsgnn_packed_head_fwd_f32 that also does the step's housekeeping: every decoded entry of packed is zeroed (ready for the next
+ * step's atomicMax) and clear[0 .. clear_n) 64-bit words are zeroed (the integer sums of the fused slot batch-norms,
+ * tsgnn_gather_rowgemm_st_f32 / tsgnn_sage_layer_fwd_bn_f32: all consumed by the launches before this one). */
+int tsgnn_packed_head_fwd_z_f32(unsigned long long* packed, int B, int L, int Fh, int Fl, float* out, int64_t ldo, int* arg,
+                                const float* w1, const float* b1, const float* w2, const float* b2, int E, int C, float* vec, float* y,
+                                unsigned long long* clear, int64_t clear_n, tsgnn_stream_t stream) {
+  if (!packed || !out || !arg || !w1 || !w2 || !vec || !y || B <= 0 || L <= 0 || Fh <= 0 || Fl <= 0 || E <= 0 || C <= 0 || clear_n < 0 ||
+      (clear_n > 0 && !clear))
+    return TSGNN_EINVAL;
+  const int P = (L - 1) * Fh + Fl;
+  if ((P % 4) || P > 2048 || E > 8 * HW || ldo < P || (reinterpret_cast<uintptr_t>(w1) & 15)) return TSGNN_EUNSUPPORTED;
+  const size_t lds = sizeof(float) * (size_t)(((P + 3) & ~3) + ((E + 3) & ~3));
+  const ExpandRider rider = take_expand_rider();
+  TSGNN_KNAME("packed_head_fwd_kernel<8> (+ housekeeping)");
+  packed_head_fwd_kernel<8><<<(unsigned)B + rider.blocks, 64 * HW, lds, stream>>>(packed, B, L, Fh, Fl, out, ldo, arg, w1, b1, w2, b2, P, E, C,
+                                                                               vec, y, rider, clear, clear_n, 1);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }

@@ -29,9 +29,80 @@ __global__ __launch_bounds__(256) void sage_layer_fwd_kernel(RowGemmArgs ga, Slo
   }
 }
 
+// The same launch for a layer whose INPUT's slot batch-norm was not materialised (rowgemm_body.h BNIN / STATS, readout_body.h):
+// x = the previous layer's v; the gather and the readout partial form y = BN(relu(v)) on the fly from the previous layer's integer
+// sums.  ST: this layer is followed by a batch-norm too (statistics epilogue); RO: it is the last one (readout epilogue).
+template <bool RO, bool ST>
+__global__ __launch_bounds__(256, 2) void sage_layer_fwd_bn_kernel(RowGemmArgs ga, SlotArgs sa, BnReadArgs bn, unsigned n_gemm, unsigned ro_gx,
+                                                                int F4, unsigned long long* __restrict__ packed, unsigned n_main,
+                                                                PullRider pr) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (blockIdx.x < n_gemm) {
+    rowgemm_body<4, false, true, 1, RO, true, ST>(ga, smem, blockIdx.x);
+  } else if (blockIdx.x < n_main) {
+    const unsigned r = blockIdx.x - n_gemm;
+    readout_partial_bn_body<32>(sa, bn, ga.a, ga.lda, F4, packed, r % ro_gx, r / ro_gx, reinterpret_cast<unsigned long long*>(smem));
+  } else {
+    pull_rider_body(pr, blockIdx.x - n_main);
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+/* tsgnn_sage_layer_fwd[_ro]_f32 for a layer whose input's slot batch-norm (apply_bn, encoders.py:134-138) has NO launch of its own:
+ * x = the previous layer's normalised pre-activations v, sums_in / ghost_in = what its statistics epilogue left
+ * (tsgnn_gather_rowgemm_st_f32 or this entry point with row_slot != NULL), slot_count[n] = graphs with more than n nodes.  Every
+ * row-panel block turns the sums into (mean, rstd) per slot and gathers y_j = (relu(v_j) - mean[slot_j]) * rstd[slot_j]; the
+ * readout partial does the same for the rows it scans, and the blocks of graph 0 write mean_out / rstd_out [nslots] for the
+ * backward.  ell: entry = slot << 20 | row (GraphBatch.ell_slots(); no CSR tail), nslots <= 1024, rows < 2^20.
+ * row_slot != NULL: this layer is followed by a batch-norm as well: its statistics go to sums_out / ghost_out (zero before).
+ * packed_out != NULL: last layer, readout epilogue (as tsgnn_sage_layer_fwd_ro_f32). */
+int tsgnn_sage_layer_fwd_bn_f32(const int* ell, int ell_w, const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias,
+                                float* v, int64_t ldv, float* rinv, float* zout, int64_t ldz, int64_t rows, int K, int64_t fill_rows,
+                                const int* graph_ptr, const int* slot_count, int B, int nslots, int n_ghost, unsigned long long* packed,
+                                unsigned long long* packed_out, const int* row_graph, const unsigned long long* sums_in,
+                                const float* ghost_in, float* mean_out, float* rstd_out, const int* row_slot,
+                                unsigned long long* sums_out, float* ghost_out, tsgnn_stream_t stream) {
+  if (!ell || !x || !w || !v || !rinv || !graph_ptr || !slot_count || !packed || !sums_in || !ghost_in || !mean_out || !rstd_out ||
+      rows <= 0 || fill_rows < 0 || K <= 0 || B <= 0 || nslots <= 0 || (n_ghost != 0 && n_ghost != nslots) || (packed_out && !row_graph) ||
+      (row_slot && (!sums_out || !ghost_out)))
+    return TSGNN_EINVAL;
+  if (ell_w != 4 && ell_w != 8 && ell_w != 16) return TSGNN_EUNSUPPORTED;
+  const uintptr_t al = reinterpret_cast<uintptr_t>(ell) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w) |
+                       reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(zout) | reinterpret_cast<uintptr_t>(bias) |
+                       reinterpret_cast<uintptr_t>(sums_in) | reinterpret_cast<uintptr_t>(sums_out);
+  if ((al & 15) || K != 128 || (ldx % 4) || (ldw % 4) || (ldv % 4) || (zout && (ldz % 4 || ldz < K)) || ldx < K || ldw < 128 || ldv < 128 ||
+      nslots > BN_TAB || rows >= (1 << 20) || n_ghost == 0 || (packed_out && row_slot))
+    return TSGNN_EUNSUPPORTED;
+  if (packed_out && fill_rows <= 0) return TSGNN_EUNSUPPORTED;
+  RowGemmArgs ga{x, ldx, w, ldw, bias, v, ldv, rinv, rows, K, 128, 1, fill_rows, ell, ell_w, zout, ldz, nullptr, nullptr,
+                 packed_out, graph_ptr, row_graph, B, nslots, n_ghost};
+  ga.st_row_slot = row_slot; ga.st_sums = sums_out; ga.st_ghost = ghost_out;
+  ga.bn_sums = sums_in; ga.bn_ghost = ghost_in; ga.bn_slot_count = slot_count; ga.bn_B = B; ga.bn_nslots = nslots; ga.bn_F = K;
+  SlotArgs sa{graph_ptr, slot_count, B, nslots, rows, n_ghost};
+  BnReadArgs bn{sums_in, ghost_in, K, mean_out, rstd_out};
+  const unsigned n_gemm = (unsigned)ceil_div64(rows, 32) + (fill_rows > 0 ? 1u : 0u);
+  const unsigned ro_gx = (unsigned)((nslots + 63) / 64);
+  size_t lds = rowgemm_lds_bytes<4, false, true, 1, true>();
+  const size_t lro = 8 * 128 * sizeof(unsigned long long) + 64 * sizeof(float2);
+  if (lds < lro) lds = lro;
+  const unsigned n_main = n_gemm + ro_gx * (unsigned)B;
+  const PullRider pr = take_pull_rider();
+  if (packed_out) {
+    TSGNN_KNAME("sage_layer_fwd_bn_kernel<ro>");
+    sage_layer_fwd_bn_kernel<true, false><<<n_main + pr.blocks, 256, lds, stream>>>(ga, sa, bn, n_gemm, ro_gx, K / 4, packed, n_main, pr);
+  } else if (row_slot) {
+    TSGNN_KNAME("sage_layer_fwd_bn_kernel<stats>");
+    sage_layer_fwd_bn_kernel<false, true><<<n_main + pr.blocks, 256, lds, stream>>>(ga, sa, bn, n_gemm, ro_gx, K / 4, packed, n_main, pr);
+  } else {
+    TSGNN_KNAME("sage_layer_fwd_bn_kernel<>");
+    sage_layer_fwd_bn_kernel<false, false><<<n_main + pr.blocks, 256, lds, stream>>>(ga, sa, bn, n_gemm, ro_gx, K / 4, packed, n_main, pr);
+  }
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
 
 /* packed_out (nullable) [B*128], zeroed by the caller: receives the packed max readout of the layer's own OUTPUT v (real rows
  * from the product's epilogue, each graph's first ghost row from the filler block); row_graph[rows] = graph of each row. */

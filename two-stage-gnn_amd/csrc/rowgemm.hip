@@ -57,6 +57,17 @@ __global__ __launch_bounds__(512) void rowgemm_gather_ks2_kernel(RowGemmArgs g) 
   rowgemm_body<NT, TRANS_B, true, 2>(g, smem, blockIdx.x);
 }
 
+// the same two kernels with the statistics epilogue (rowgemm_body.h, STATS): the layer in front of a slot batch-norm that has no
+// launch of its own (tsgnn_gather_rowgemm_st_f32)
+__global__ __launch_bounds__(256) void rowgemm_gather_st_kernel(RowGemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  rowgemm_body<4, false, true, 1, false, false, true>(g, smem, blockIdx.x);
+}
+__global__ __launch_bounds__(512) void rowgemm_gather_ks2_st_kernel(RowGemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  rowgemm_body<4, false, true, 2, false, false, true>(g, smem, blockIdx.x);
+}
+
 // column-split variant for products WITHOUT the row epilogue (no normalise: rows need not be whole): grid.y column blocks of
 // 32 * NT.  A 1,000-row x 256-column product (GAT projection, DiffPool's dagg = du W^T) is 32 panels on a 256-CU chip whose
 // waves each run two 32 x 32 tiles over the whole K: split in two, twice the CUs work and each wave's MFMA chain is half as long
@@ -241,6 +252,42 @@ int tsgnn_rowgemm_f32(const float* a, int64_t lda, const float* b, int64_t ldb, 
       if (N > 256) return TSGNN_EUNSUPPORTED;
       dispatch_rowgemm<false, false>(g, stream);
     }
+  }
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+/* tsgnn_gather_rowgemm_f32 (trans_b = 0, normalize = 1, 96 < N <= 128) for a layer that is followed by the slot batch-norm
+ * (apply_bn, encoders.py:134-138) WITHOUT a launch for it: the epilogue adds every real row's (sum_f relu(v), sum_f relu(v)^2) to
+ * sums[2 * row_slot[r]] as 64-bit fixed-point integers (2^-40 units; order-independent, so bitwise reproducible) and the filler
+ * block leaves the ghost row's two numbers in ghost[0..1].  sums: zero before the launch.  row_slot[r] < 0: row r belongs to no
+ * graph (padding of a capacity-padded batch).  The consumer is tsgnn_sage_layer_fwd_bn_f32. */
+int tsgnn_gather_rowgemm_st_f32(const int* ell, int ell_w, const float* x, int64_t ldx, const float* b, int64_t ldb, const float* bias,
+                                float* c, int64_t ldc, float* rinv, float* zout, int64_t ldz, int64_t rows, int K, int N,
+                                int64_t fill_rows, const int* row_slot, unsigned long long* sums, float* ghost, tsgnn_stream_t stream) {
+  if (!ell || !x || !b || !c || !row_slot || !sums || !ghost || rows <= 0 || fill_rows < 0 || K <= 0 || N <= 0 || ldx < K || ldc < N)
+    return TSGNN_EINVAL;
+  if (ell_w != 4 && ell_w != 8 && ell_w != 16) return TSGNN_EUNSUPPORTED;
+  if (!tsgnn_rowgemm_supported(x, ldx, b, ldb, c, ldc, K, N, 0) || N > 128 || N <= 96 || K > 128 || (reinterpret_cast<uintptr_t>(ell) & 15) ||
+      (reinterpret_cast<uintptr_t>(sums) & 15))
+    return TSGNN_EUNSUPPORTED;
+  if (zout && ((ldz % 4) || ldz < K || (reinterpret_cast<uintptr_t>(zout) & 15))) return TSGNN_EUNSUPPORTED;
+  if ((N % 4) || (ldc % 4) || (reinterpret_cast<uintptr_t>(c) & 15) || (bias && (reinterpret_cast<uintptr_t>(bias) & 15))) return TSGNN_EUNSUPPORTED;
+  RowGemmArgs g{x, ldx, b, ldb, bias, c, ldc, rinv, rows, K, N, 1, fill_rows, ell, ell_w, zout, ldz, nullptr, nullptr};
+  g.st_row_slot = row_slot; g.st_sums = sums; g.st_ghost = ghost;
+  const unsigned nblk = (unsigned)(ceil_div64(rows, 32) + (fill_rows > 0 ? 1 : 0));
+  if (K > KC && nblk <= ks2_max_blocks() && rowgemm_ks2_enabled()) {
+    constexpr size_t lds2 = rowgemm_lds_bytes<4, false, true, 2>();
+    static bool attr = false;
+    if (!attr && lds2 > 64 * 1024) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rowgemm_gather_ks2_st_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+      attr = true;
+    }
+    TSGNN_KNAME("rowgemm_gather_ks2_st_kernel");
+    rowgemm_gather_ks2_st_kernel<<<nblk, 512, lds2, stream>>>(g);
+  } else {
+    TSGNN_KNAME("rowgemm_gather_st_kernel");
+    rowgemm_gather_st_kernel<<<nblk, 256, rowgemm_lds_bytes<4, false, true>(), stream>>>(g);
   }
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;

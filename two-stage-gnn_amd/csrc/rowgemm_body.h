@@ -33,7 +33,30 @@ struct RowGemmArgs {
   unsigned long long* ro_packed;              // nullable
   const int* ro_graph_ptr; const int* ro_row_graph;
   int ro_B, ro_nslots, ro_nghost;
+  // Slot batch-norm WITHOUT a launch of its own (apply_bn, encoders.py:134-138, between two GraphConv layers):
+  // STATS (epilogue): every output row adds  sum_f relu(v), sum_f relu(v)^2  to st_sums[2 * slot] as 64-bit FIXED-POINT integers
+  //   (2^-40 units: integer addition is associative, so the totals do not depend on the order the panels finish in — bitwise
+  //   reproducible, unlike float atomics); the filler block leaves the same two numbers of the ghost row in st_ghost[0..1].
+  // BNIN (gather prologue): the gathered operand rows are the PREVIOUS layer's normalised pre-activations v; every block turns
+  //   the previous layer's sums into (mean, rstd) per slot (LDS table, exact from the integer sums, ghost copies by multiplicity
+  //   B - slot_count[n]) and gathers  y_j = (relu(v_j) - mean[slot_j]) * rstd[slot_j]  on the fly.  The neighbour table then
+  //   carries the slot beside the row:  entry = slot << 20 | row  (GraphBatch.ell_slots()).
+  const int* st_row_slot; unsigned long long* st_sums; float* st_ghost;
+  const unsigned long long* bn_sums; const float* bn_ghost; const int* bn_slot_count; int bn_B, bn_nslots, bn_F;
 };
+
+constexpr int BN_TAB = 1024;                  // slots the LDS table of (mean, rstd) holds
+constexpr float BN_FWD_EPS = 1e-5f;
+constexpr double BN_FIX = 1099511627776.0;    // 2^40
+
+// (mean, rstd) of slot n from the integer sums of its real rows + the ghost row's two numbers times its multiplicity
+__device__ __forceinline__ float2 bn_slot_stats(unsigned long long s1, unsigned long long s2, int have, float g1, float g2, int B, int F) {
+  const double mult = (double)(B - have), cnt = (double)B * (double)F;
+  const double m = ((double)(long long)s1 * (1.0 / BN_FIX) + mult * (double)g1) / cnt;
+  const double e2 = ((double)(long long)s2 * (1.0 / BN_FIX) + mult * (double)g2) / cnt;
+  const double var = fmax(e2 - m * m, 0.0);
+  return make_float2((float)m, (float)(1.0 / sqrt(var + (double)BN_FWD_EPS)));
+}
 
 __device__ __forceinline__ unsigned long long rg_pack_max(float val, unsigned r) {      // = pack_max of readout_body.h
   return ((unsigned long long)f32_ordered(val) << 32) | (unsigned long long)(0xFFFFFFFFu - r);
@@ -51,10 +74,12 @@ constexpr int LDA_F = 128;            // row stride of the gathered full-K A pan
 // epilogue), so a CU idles through every memory wait; with two wave groups the gather prologue is shared by twice the
 // lanes (half the rows per lane), each group runs half of the K chunks on its own LDS stages while the other group's
 // waits are covered, and group 1 hands its accumulators to group 0 through LDS before the (unchanged) epilogue.
-template <int NT, bool TRANS_B, bool GATHER, int KS = 1, bool READOUT = false>
+template <int NT, bool TRANS_B, bool GATHER, int KS = 1, bool READOUT = false, bool BNIN = false, bool STATS = false>
 __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem_all, unsigned bid) {
   static_assert(KS == 1 || (KS == 2 && GATHER && NT <= 4), "the split-K variant is built for the gather kernel, widths <= 128");
   static_assert(!READOUT || (NT <= 4 && KS == 1), "the readout epilogue is built for one column tile per wave");
+  static_assert(!BNIN || (GATHER && KS == 1), "batch-norm on the fly lives in the gather prologue of the one-group kernel");
+  static_assert(!STATS || NT <= 4, "the statistics epilogue is built for one column tile per wave");
   constexpr int NP = 32 * NT;
   constexpr int TPW = (NT + 3) / 4;
   constexpr int BV = NT;                               // float4 of B per thread per chunk (KC * NP / 1024)
@@ -96,6 +121,14 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem_a
     float sc = 1.f;
     if (g.normalize) sc = fminf(__builtin_amdgcn_rsqf((fred[0] + fred[1]) + (fred[2] + fred[3])), 1.0f / NORM_EPS);
     const float4 out = make_float4(bv.x * sc, bv.y * sc, bv.z * sc, bv.w * sc);
+    if constexpr (STATS) {
+      if (g.st_ghost && wid == 0) {                      // the ghost row's two numbers (all of row 0's float4 live in wave 0: N4 <= 32)
+        const float a = fmaxf(out.x, 0.f), b = fmaxf(out.y, 0.f), c = fmaxf(out.z, 0.f), d = fmaxf(out.w, 0.f);
+        float g1 = rsub == 0 ? (a + b) + (c + d) : 0.f, g2 = rsub == 0 ? (a * a + b * b) + (c * c + d * d) : 0.f;
+        g1 = wave_sum(g1); g2 = wave_sum(g2);
+        if (lane == 0) { g.st_ghost[0] = g1; g.st_ghost[1] = g2; }
+      }
+    }
     if (rsub < rpp) {
       for (int64_t r = rsub; r < g.fill_rows; r += rpp) {
         *reinterpret_cast<float4*>(g.c + (g.rows + r) * g.ldc + 4 * c4) = out;
@@ -277,6 +310,25 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem_a
       }
     }
   }
+  // BNIN: the previous layer's integer sums (16 bytes a slot) and slot counts, requested right behind the neighbour ids
+  constexpr int BN_PT = BN_TAB / 256;                  // slots per thread
+  float2* bn_tab = reinterpret_cast<float2*>(Apanel + 32 * LDA_F);
+  ulonglong2 bn_s[BNIN ? BN_PT : 1];
+  int bn_have[BNIN ? BN_PT : 1];
+  float bn_g1 = 0.f, bn_g2 = 0.f;
+  if constexpr (BNIN) {
+#pragma unroll
+    for (int q = 0; q < BN_PT; ++q) {
+      const int n = min(tid_all + 256 * q, g.bn_nslots - 1);
+      bn_s[q] = *reinterpret_cast<const ulonglong2*>(g.bn_sums + 2 * n);
+      bn_have[q] = g.bn_slot_count[n];
+    }
+    bn_g1 = g.bn_ghost[0]; bn_g2 = g.bn_ghost[1];
+  }
+  int st_slot = -1;                                    // STATS: the slot of row m0 + lane (wave 0, lanes < 32), used last
+  if constexpr (STATS) {
+    if (g.st_sums && wid == 0 && grp == 0 && lane < 32 && (m0 + lane) < g.rows) st_slot = g.st_row_slot[m0 + lane];
+  }
 #pragma unroll
   for (int c = 0; c < NS; ++c)
     if (c == 0 || c * KC < Kc) fetch(st[c], c * KC);
@@ -287,14 +339,38 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem_a
     const int c4 = tid_all & 31, rsub = tid_all >> 5;
     const bool colok = 4 * c4 < g.K;                   // a float4 that straddles K is taken whole: B's rows >= K are zero in
                                                        // LDS and the row padding of x is finite (zero) by the layout rule
+    if constexpr (BNIN) {
+      // (mean, rstd) of every slot BEFORE the rows are requested: the sums arrived with the ids, and their registers are dead by
+      // the time the 32 row requests per lane go out (with both live the kernel needed > 256 registers: one block per CU, and the
+      // readout blocks of the same launch could no longer ride beside the row panels)
+#pragma unroll
+      for (int q = 0; q < BN_PT; ++q) {
+        const int n = tid_all + 256 * q;
+        if (n < g.bn_nslots) bn_tab[n] = bn_slot_stats(bn_s[q].x, bn_s[q].y, bn_have[q], bn_g1, bn_g2, g.bn_B, g.bn_F);
+      }
+    }
     float4 nbv[NPASS][GN];
 #pragma unroll
     for (int p = 0; p < NPASS; ++p)
 #pragma unroll
       for (int k = 0; k < GN; ++k) {
         nbv[p][k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (colok && ids[p][k] >= 0) nbv[p][k] = ldg4(g.a + (int64_t)ids[p][k] * g.lda + 4 * c4);
+        if (colok && ids[p][k] >= 0) nbv[p][k] = ldg4(g.a + (int64_t)(BNIN ? (ids[p][k] & 0xFFFFF) : ids[p][k]) * g.lda + 4 * c4);
       }
+    if constexpr (BNIN) {
+      __syncthreads();                                 // the table of (mean, rstd) is complete
+#pragma unroll
+      for (int p = 0; p < NPASS; ++p)
+#pragma unroll
+        for (int k = 0; k < GN; ++k) {
+          if (ids[p][k] >= 0) {
+            const float2 ms = bn_tab[ids[p][k] >> 20];
+            float4& t = nbv[p][k];
+            t.x = (fmaxf(t.x, 0.f) - ms.x) * ms.y; t.y = (fmaxf(t.y, 0.f) - ms.x) * ms.y;
+            t.z = (fmaxf(t.z, 0.f) - ms.x) * ms.y; t.w = (fmaxf(t.w, 0.f) - ms.x) * ms.y;
+          }
+        }
+    }
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
       const int64_t row = m0 + 8 * KS * p + rsub;
@@ -305,7 +381,12 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem_a
         for (int k = GN; k < g.ell_w; ++k) {
           const int j = g.ell[row * g.ell_w + k];
           if (j < 0) break;
-          const float4 t = ldg4(g.a + (int64_t)j * g.lda + 4 * c4);
+          float4 t = ldg4(g.a + (int64_t)(BNIN ? (j & 0xFFFFF) : j) * g.lda + 4 * c4);
+          if constexpr (BNIN) {
+            const float2 ms = bn_tab[j >> 20];
+            t.x = (fmaxf(t.x, 0.f) - ms.x) * ms.y; t.y = (fmaxf(t.y, 0.f) - ms.x) * ms.y;
+            t.z = (fmaxf(t.z, 0.f) - ms.x) * ms.y; t.w = (fmaxf(t.w, 0.f) - ms.x) * ms.y;
+          }
           va.x += t.x; va.y += t.y; va.z += t.z; va.w += t.w;
         }
       }
@@ -436,6 +517,35 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem_a
       }
     }
   }
+  if constexpr (STATS) {
+    if (g.st_sums) {
+      // per row: sum_f relu(v), sum_f relu(v)^2 over the N columns (same reduction as the norm above: transposing DPP sums inside
+      // the wave, the four column tiles through LDS in wave order), then ONE pair of 64-bit integer atomics per row
+      float* red1 = scratch;                           // [32 rows][4 waves]
+      float* red2 = scratch + 128;
+      float q1[16], q2[16];
+      const bool okc = wid < NT && (wid * 32 + i) < g.N;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float rl = okc ? fmaxf(acc[0][r] * scale[r], 0.f) : 0.f;
+        q1[r] = rl; q2[r] = rl * rl;
+      }
+      float t1 = row16_sum_transpose(q1), t2 = row16_sum_transpose(q2);
+      t1 += __shfl_xor(t1, 16, 64); t2 += __shfl_xor(t2, 16, 64);
+      __syncthreads();                                 // (the normalisation's readers of `scratch` are done)
+      if ((lane & 16) == 0) {
+        const int r = lane & 15, row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        red1[row * 4 + wid] = t1; red2[row * 4 + wid] = t2;
+      }
+      __syncthreads();
+      if (wid == 0 && lane < 32 && st_slot >= 0) {
+        const float4 a = *reinterpret_cast<const float4*>(red1 + lane * 4), b = *reinterpret_cast<const float4*>(red2 + lane * 4);
+        const float s1 = (a.x + a.y) + (a.z + a.w), s2 = (b.x + b.y) + (b.z + b.w);
+        atomicAdd(g.st_sums + 2 * st_slot, (unsigned long long)__double2ll_rn((double)s1 * BN_FIX));
+        atomicAdd(g.st_sums + 2 * st_slot + 1, (unsigned long long)__double2ll_rn((double)s2 * BN_FIX));
+      }
+    }
+  }
   const bool full = panel_full;                        // uniform: no per-element predicates on the common path
 #pragma unroll
   for (int t = 0; t < TPW; ++t) {
@@ -486,12 +596,12 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem_a
 }
 
 
-template <int NT, bool TRANS_B, bool GATHER, int KS = 1>
+template <int NT, bool TRANS_B, bool GATHER, int KS = 1, bool BNIN = false>
 constexpr size_t rowgemm_lds_bytes() {
   constexpr int NP = 32 * NT;
   constexpr int STAGE2 = 2 * ((GATHER ? 0 : 32 * LDA_S) + (TRANS_B ? NP * LDA_S : KC * NP));
   constexpr int GRP = (KS == 2 && STAGE2 < 4096 + 256) ? 4096 + 256 : STAGE2;
-  return sizeof(float) * (KS * GRP + (KS == 2 ? 0 : 128 + 4 * 32) + (GATHER ? 32 * LDA_F : 0));
+  return sizeof(float) * (KS * GRP + (KS == 2 ? 0 : 128 + 4 * 32) + (GATHER ? 32 * LDA_F : 0) + (BNIN ? 2 * BN_TAB : 0));
 }
 
 }  // namespace

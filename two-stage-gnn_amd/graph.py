@@ -242,6 +242,40 @@ class GraphBatch:
             self._ell = (ell, W, tail)
         return self._ell
 
+    def ell_slots(self):
+        """the neighbour table with the neighbour's SLOT beside its row: entry = slot << 20 | row (empty entries stay -1), or None
+        (CSR tail, >= 2^20 rows, > 1024 slots).  Operand of the layers whose input's slot batch-norm is formed on the fly
+        (tsgnn_sage_layer_fwd_bn_f32).  Built once per batch structure, outside the step."""
+        if getattr(self, "_ell_slots", None) is None:
+            e = self.ell()
+            if e is None or e[2] is not None or self.total_rows >= (1 << 20) or self.nmax > 1024 or self.row_slot is None:
+                self._ell_slots = False
+            else:
+                ell, W, _ = e
+                ids = ell[: self.total_rows * W].to(torch.int64)
+                ok = (ids >= 0) & (ids < self.n_rows)                  # (nothing aggregates from a ghost row)
+                slot = self.row_slot.to(torch.int64)[ids.clamp(0, max(self.n_rows - 1, 0))]
+                packed = torch.where(ok, (slot << 20) | ids, torch.full_like(ids, -1)).to(torch.int32)
+                out = _i32(max(self.total_rows * W, 1), self.device)
+                out[: packed.numel()] = packed
+                self._ell_slots = out
+        return self._ell_slots if self._ell_slots is not False else None
+
+    def bn_workspace(self, B, L, Fh, Fl, nslots):
+        """persistent device buffers of the fused slot batch-norms of a stack on this batch (sage_stack.py): the integer sums
+        [L-1][2 * nslots] and the ghost rows' numbers [L-1][2] — zero between steps, the step's own head launch clears them —, and
+        the packed max-readout buffer (zero between steps as well).  `dirty`: a forward that did not reach its head left them
+        in an undefined state; the next forward clears them explicitly."""
+        key = (B, L, Fh, Fl, nslots)
+        ws = getattr(self, "_bn_ws", None)
+        if ws is None or ws["key"] != key:
+            words = (L - 1) * 2 * nslots
+            ws = {"key": key, "sums": torch.zeros(max(words, 2), dtype=torch.int64, device=self.device),
+                  "ghost": torch.zeros(max(2 * (L - 1), 2), dtype=torch.float32, device=self.device),
+                  "packed": torch.zeros(B * ((L - 1) * Fh + Fl) + Fl, dtype=torch.int64, device=self.device), "dirty": False}
+            self._bn_ws = ws
+        return ws
+
     # ------------------------------------------------------------------ transpose (for dX = A^T dY)
     def _ensure_transpose(self):
         if self._t is None:

@@ -55,6 +55,8 @@ GATHER_MAX_ROWS = int(os.environ.get("TSGNN_GATHER_MAX_ROWS", 65536))   # above:
 GATHER_FUSED = os.environ.get("TSGNN_GATHER_FUSED", "1") != "0"     # aggregate inside the `.W` product when the neighbour table has no CSR tail
 EPILOGUE_READOUT = os.environ.get("TSGNN_EPILOGUE_READOUT", "1") != "0"   # the last layer's max readout in its product's epilogue
 LAST_LAYER_ROWS = os.environ.get("TSGNN_LAST_LAYER_ROWS", "1") != "0"     # the last layer's dU from a row-parallel kernel
+FUSED_BN = os.environ.get("TSGNN_FUSED_BN", "1") != "0"                   # slot batch-norm without launches of its own (statistics in the
+                                                                          # producing product's epilogue, normalisation in the consumers)
 HEAD_DU = os.environ.get("TSGNN_HEAD_DU", "1") != "0"                     # ... computed by extra workgroups of the head's backward launch
 
 
@@ -136,7 +138,52 @@ class _SageStack(torch.autograd.Function):
         pending_ro = None
         keep = []
         last_ro_done = False
-        for l in range(L):
+        bnf = None
+        if (FUSED_BN and head is not None and not nodes and L >= 2 and g.n_ghost == g.nmax and sn == sg and sn <= 1024
+                and Fh == 128 and Fl == 128 and Ws[0].size(0) <= 128 and x.size(1) % 4 == 0 and MERGED_FWD and EPILOGUE_READOUT
+                and _gather_ok(g, x) and all(Ws[l].size(0) == 128 and Ws[l].stride(0) % 4 == 0 for l in range(1, L))
+                and all(Ws[l].data_ptr() % 16 == 0 and (bs[l] is None or bs[l].data_ptr() % 16 == 0) for l in range(L))
+                and mp.rowgemm_ok(x, x.stride(0), Ws[0], Ws[0].stride(0), Ws[0].size(0), Fh, False)
+                and head[0].size(0) <= 128 and (L - 1) * Fh + Fl <= 2048 and g.row_graph is not None):
+            ell_s = g.ell_slots()
+            if ell_s is not None:
+                bnf = g.bn_workspace(B, L, Fh, Fl, sn)
+                if bnf["dirty"]:
+                    bnf["sums"].zero_(); bnf["ghost"].zero_(); bnf["packed"].zero_()
+                bnf["dirty"] = True
+                packed = bnf["packed"]
+        if bnf is not None:
+            # ---- slot batch-norm without launches of its own (L launches for the conv stack instead of 2L - 1)
+            ell, ell_w, _ = g.ell()
+            sums, ghost = bnf["sums"], bnf["ghost"]
+            for l in range(L):
+                K, N = Ws[l].size(0), Ws[l].size(1)
+                v = torch.empty(R, N, dtype=torch.float32, device=dev)
+                rinv = torch.empty(R, dtype=torch.float32, device=dev)
+                z = torch.empty(R, x.size(1) if l == 0 else Fh, dtype=torch.float32, device=dev)
+                s_out = sums[l * 2 * sn:(l + 1) * 2 * sn] if l < L - 1 else None
+                g_out = ghost[2 * l:2 * l + 2] if l < L - 1 else None
+                if l == 0:
+                    nat.call("gather_rowgemm_st_f32", ell, ell_w, x, x.stride(0), Ws[0], Ws[0].stride(0), bs[0], v, v.stride(0), rinv, z,
+                             z.stride(0), g.n_rows, K, N, gs, g.row_slot, s_out, g_out)
+                    mean = rstd = None
+                else:
+                    pm, pr_ = saved[l - 1][3], saved[l - 1][4]
+                    last = l == L - 1
+                    nat.call("sage_layer_fwd_bn_f32", ell_s, ell_w, saved[l - 1][1], saved[l - 1][1].stride(0), Ws[l], Ws[l].stride(0), bs[l],
+                             v, v.stride(0), rinv, z, z.stride(0), g.n_rows, K, gs, g.graph_ptr, g.slot_count, B, sn, sg,
+                             packed[(l - 1) * B * Fh:(l - 1) * B * Fh + B * Fh],
+                             packed[l * B * Fh:l * B * Fh + (B + 1) * N] if last else None, g.row_graph,
+                             sums[(l - 1) * 2 * sn:l * 2 * sn], ghost[2 * (l - 1):2 * l], pm, pr_,
+                             None if last else g.row_slot, s_out, g_out)
+                if l < L - 1:
+                    mean = torch.empty(g.nmax, dtype=torch.float32, device=dev)     # written by the NEXT launch's readout blocks
+                    rstd = torch.empty(g.nmax, dtype=torch.float32, device=dev)
+                else:
+                    mean = rstd = None
+                saved.append((z, v, rinv, mean, rstd, True))
+            last_ro_done = True
+        for l in (range(L) if bnf is None else ()):
             K, N = Ws[l].size(0), Ws[l].size(1)
             if nodes and l == L - 1:
                 v = cat[:, (L - 1) * Fh:]                    # the last layer's output IS its block of the concatenation
@@ -236,7 +283,12 @@ class _SageStack(torch.autograd.Function):
         vec = torch.empty(B, E, dtype=torch.float32, device=dev)
         y = torch.empty(B, C, dtype=torch.float32, device=dev)
         v_last = saved[-1][1]
-        if last_ro_done and E <= 128 and out.size(1) <= 2048:
+        if bnf is not None:
+            # decode + both Linear layers + the step's housekeeping (packed and the integer sums zeroed for the next step)
+            nat.call("packed_head_fwd_z_f32", packed, B, L, Fh, Fl, out, out.stride(0), arg, w1c, b1, w2c, b2, E, C, vec, y,
+                     bnf["sums"], (L - 1) * 2 * sn)
+            bnf["dirty"] = False
+        elif last_ro_done and E <= 128 and out.size(1) <= 2048:
             # every layer's maxima are in `packed`: decode + both Linear layers, one memory round trip per block
             nat.call("packed_head_fwd_f32", packed, B, L, Fh, Fl, out, out.stride(0), arg, w1c, b1, w2c, b2, E, C, vec, y)
         else:
