@@ -142,3 +142,16 @@ __device__ __forceinline__ unsigned f32_ordered(float f) {
 __device__ __forceinline__ float ordered_f32(unsigned u) {
   return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
 }
+
+// (mean, rstd) of a batch-norm slot from the 64-bit fixed-point sums (2^-40 units) of its real rows + the ghost row's two numbers
+// times its multiplicity (rowgemm_body.h STATS / BNIN, readout_body.h).  The combination runs in double (the sums are exact, so
+// E[x^2] - mean^2 loses nothing); no double division or square root: one reciprocal of the count per call site, a float rsqrt at
+// the end (four slots per thread with double div + sqrt were 2 us of a row panel's prologue).
+__device__ __forceinline__ float2 bn_stats_from_sums(unsigned long long s1, unsigned long long s2, int have, float g1, float g2, int B,
+                                                     double inv_cnt, float eps) {
+  const double mult = (double)(B - have), fix = 1.0 / 1099511627776.0;
+  const double m = fma((double)(long long)s1, fix, mult * (double)g1) * inv_cnt;
+  const double e2 = fma((double)(long long)s2, fix, mult * (double)g2) * inv_cnt;
+  const float var = fmaxf((float)(e2 - m * m), 0.f);
+  return make_float2((float)m, 1.0f / sqrtf(var + eps));
+}

@@ -57,13 +57,6 @@ struct BnReadArgs {
   const unsigned long long* sums; const float* ghost; int F;      // F = feature width the statistics run over
   float* mean; float* rstd;
 };
-__device__ __forceinline__ float2 bn_read_stats(unsigned long long s1, unsigned long long s2, int have, float g1, float g2, int B, int F) {
-  const double mult = (double)(B - have), cnt = (double)B * (double)F;
-  const double m = ((double)(long long)s1 * (1.0 / 1099511627776.0) + mult * (double)g1) / cnt;
-  const double e2 = ((double)(long long)s2 * (1.0 / 1099511627776.0) + mult * (double)g2) / cnt;
-  const double var = fmax(e2 - m * m, 0.0);
-  return make_float2((float)m, (float)(1.0 / sqrt(var + 1e-5)));
-}
 template <int G>
 __device__ __forceinline__ void readout_partial_bn_body(const SlotArgs& s, const BnReadArgs& bn, const float* __restrict__ x, int64_t ld,
                                                         int F4, unsigned long long* __restrict__ packed, unsigned bx, unsigned by,
@@ -79,7 +72,7 @@ __device__ __forceinline__ void readout_partial_bn_body(const SlotArgs& s, const
   if (threadIdx.x < 64) {
     const int n = min(n_lo + (int)threadIdx.x, s.nmax - 1);
     const ulonglong2 sm = *reinterpret_cast<const ulonglong2*>(bn.sums + 2 * n);
-    const float2 ms = bn_read_stats(sm.x, sm.y, s.slot_count[n], bn.ghost[0], bn.ghost[1], s.B, bn.F);
+    const float2 ms = bn_stats_from_sums(sm.x, sm.y, s.slot_count[n], bn.ghost[0], bn.ghost[1], s.B, 1.0 / ((double)s.B * (double)bn.F), 1e-5f);
     tab[threadIdx.x] = ms;
     if (b == 0 && n_lo + (int)threadIdx.x < s.nmax) { bn.mean[n] = ms.x; bn.rstd[n] = ms.y; }
   }

@@ -49,15 +49,6 @@ constexpr int BN_TAB = 1024;                  // slots the LDS table of (mean, r
 constexpr float BN_FWD_EPS = 1e-5f;
 constexpr double BN_FIX = 1099511627776.0;    // 2^40
 
-// (mean, rstd) of slot n from the integer sums of its real rows + the ghost row's two numbers times its multiplicity
-__device__ __forceinline__ float2 bn_slot_stats(unsigned long long s1, unsigned long long s2, int have, float g1, float g2, int B, int F) {
-  const double mult = (double)(B - have), cnt = (double)B * (double)F;
-  const double m = ((double)(long long)s1 * (1.0 / BN_FIX) + mult * (double)g1) / cnt;
-  const double e2 = ((double)(long long)s2 * (1.0 / BN_FIX) + mult * (double)g2) / cnt;
-  const double var = fmax(e2 - m * m, 0.0);
-  return make_float2((float)m, (float)(1.0 / sqrt(var + (double)BN_FWD_EPS)));
-}
-
 __device__ __forceinline__ unsigned long long rg_pack_max(float val, unsigned r) {      // = pack_max of readout_body.h
   return ((unsigned long long)f32_ordered(val) << 32) | (unsigned long long)(0xFFFFFFFFu - r);
 }
@@ -343,10 +334,14 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem_a
       // (mean, rstd) of every slot BEFORE the rows are requested: the sums arrived with the ids, and their registers are dead by
       // the time the 32 row requests per lane go out (with both live the kernel needed > 256 registers: one block per CU, and the
       // readout blocks of the same launch could no longer ride beside the row panels)
+      const double inv_cnt = 1.0 / ((double)g.bn_B * (double)g.bn_F);
 #pragma unroll
       for (int q = 0; q < BN_PT; ++q) {
         const int n = tid_all + 256 * q;
-        if (n < g.bn_nslots) bn_tab[n] = bn_slot_stats(bn_s[q].x, bn_s[q].y, bn_have[q], bn_g1, bn_g2, g.bn_B, g.bn_F);
+        if (n < g.bn_nslots) {
+          const float2 ms = bn_stats_from_sums(bn_s[q].x, bn_s[q].y, bn_have[q], bn_g1, bn_g2, g.bn_B, inv_cnt, BN_FWD_EPS);
+          bn_tab[n] = make_float2(ms.y, ms.x * ms.y);        // (rstd, mean * rstd):  y = relu(v) * rstd - mean * rstd
+        }
       }
     }
     float4 nbv[NPASS][GN];
@@ -358,16 +353,18 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem_a
         if (colok && ids[p][k] >= 0) nbv[p][k] = ldg4(g.a + (int64_t)(BNIN ? (ids[p][k] & 0xFFFFF) : ids[p][k]) * g.lda + 4 * c4);
       }
     if constexpr (BNIN) {
-      __syncthreads();                                 // the table of (mean, rstd) is complete
+      __syncthreads();                                 // the table of (rstd, mean * rstd) is complete
+      // y = (relu(v) - mean) rstd = fma(relu(v), rstd, -mean rstd): one max + one fma per element
+      // (summing relu(v) rstd first and subtracting sum_j mean_j rstd_j once per row measured SLOWER: 14.0 -> 17.1 us)
 #pragma unroll
       for (int p = 0; p < NPASS; ++p)
 #pragma unroll
         for (int k = 0; k < GN; ++k) {
           if (ids[p][k] >= 0) {
-            const float2 ms = bn_tab[ids[p][k] >> 20];
+            const float2 rm = bn_tab[ids[p][k] >> 20];
             float4& t = nbv[p][k];
-            t.x = (fmaxf(t.x, 0.f) - ms.x) * ms.y; t.y = (fmaxf(t.y, 0.f) - ms.x) * ms.y;
-            t.z = (fmaxf(t.z, 0.f) - ms.x) * ms.y; t.w = (fmaxf(t.w, 0.f) - ms.x) * ms.y;
+            t.x = fmaf(fmaxf(t.x, 0.f), rm.x, -rm.y); t.y = fmaf(fmaxf(t.y, 0.f), rm.x, -rm.y);
+            t.z = fmaf(fmaxf(t.z, 0.f), rm.x, -rm.y); t.w = fmaf(fmaxf(t.w, 0.f), rm.x, -rm.y);
           }
         }
     }
@@ -383,9 +380,9 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem_a
           if (j < 0) break;
           float4 t = ldg4(g.a + (int64_t)(BNIN ? (j & 0xFFFFF) : j) * g.lda + 4 * c4);
           if constexpr (BNIN) {
-            const float2 ms = bn_tab[j >> 20];
-            t.x = (fmaxf(t.x, 0.f) - ms.x) * ms.y; t.y = (fmaxf(t.y, 0.f) - ms.x) * ms.y;
-            t.z = (fmaxf(t.z, 0.f) - ms.x) * ms.y; t.w = (fmaxf(t.w, 0.f) - ms.x) * ms.y;
+            const float2 rm = bn_tab[j >> 20];
+            t.x = fmaf(fmaxf(t.x, 0.f), rm.x, -rm.y); t.y = fmaf(fmaxf(t.y, 0.f), rm.x, -rm.y);
+            t.z = fmaf(fmaxf(t.z, 0.f), rm.x, -rm.y); t.w = fmaf(fmaxf(t.w, 0.f), rm.x, -rm.y);
           }
           va.x += t.x; va.y += t.y; va.z += t.z; va.w += t.w;
         }
@@ -473,6 +470,7 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem_a
   for (int r = 0; r < 16; ++r) scale[r] = 1.f;
   if (g.bias || g.normalize) {
     float ss[16];
+    float q1[STATS ? 16 : 1], q2[STATS ? 16 : 1];      // STATS: sum_f relu(u), sum_f relu(u)^2 of the un-normalised row
 #pragma unroll
     for (int r = 0; r < 16; ++r) ss[r] = 0.f;
 #pragma unroll
@@ -486,20 +484,31 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem_a
         const float v = okc ? acc[t][r] + bv : 0.f;
         acc[t][r] = v;
         ss[r] = fmaf(v, v, ss[r]);
+        if constexpr (STATS) { const float rl = fmaxf(v, 0.f); q1[r] = rl; q2[r] = rl * rl; }
       }
     }
     if (g.normalize) {
       // row sums of squares: transposing DPP reduction inside each 16-lane row (lane l ends with row r = l & 15 of its
       // half), the two rows of a half through one bpermute, the four waves (column tiles) through LDS; then each wave
       // turns the 32 totals into 1/max(|u|, eps) with one v_rsq per lane and hands them out through LDS.
+      // STATS: the batch-norm statistics of the NORMALISED row ride in the same two barriers — relu(u * s) = s * relu(u) for the
+      // positive row scale s, so  sum_f relu(v) = s * sum_f relu(u)  and  sum_f relu(v)^2 = s^2 * sum_f relu(u)^2 : the two extra
+      // row sums travel through the (idle) first LDS stage, and ONE pair of 64-bit integer atomics per row follows.
       float* red = scratch;                            // [32 rows][4 waves]
       float* inv = red + 128 + wid * 32;               // per wave [32 rows]
+      float* redq = smem_all;                          // [2][32 rows][4 waves]: the K loop's stages are idle (K > 2 KC: synchronised)
       float tot = row16_sum_transpose(ss);
       tot += __shfl_xor(tot, 16, 64);
+      float t1 = 0.f, t2 = 0.f;
+      if constexpr (STATS) {
+        t1 = row16_sum_transpose(q1); t2 = row16_sum_transpose(q2);
+        t1 += __shfl_xor(t1, 16, 64); t2 += __shfl_xor(t2, 16, 64);
+      }
       TR(11);
       if ((lane & 16) == 0) {
-        const int r = lane & 15;
-        red[((r & 3) + 8 * (r >> 2) + 4 * h) * 4 + wid] = tot;
+        const int r = lane & 15, row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        red[row * 4 + wid] = tot;
+        if constexpr (STATS) { redq[row * 4 + wid] = t1; redq[128 + row * 4 + wid] = t2; }
       }
       __syncthreads();
       TR(12);
@@ -508,41 +517,20 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem_a
         const float rs = fminf(__builtin_amdgcn_rsqf((p.x + p.y) + (p.z + p.w)), 1.0f / NORM_EPS);
         inv[lane] = rs;
         if (g.rinv && wid == 0 && (m0 + lane) < g.rows) g.rinv[m0 + lane] = rs;
+        if constexpr (STATS) {
+          if (g.st_sums && wid == 0 && st_slot >= 0) {
+            const float4 a = *reinterpret_cast<const float4*>(redq + lane * 4), b = *reinterpret_cast<const float4*>(redq + 128 + lane * 4);
+            const float s1 = ((a.x + a.y) + (a.z + a.w)) * rs, s2 = ((b.x + b.y) + (b.z + b.w)) * (rs * rs);
+            atomicAdd(g.st_sums + 2 * st_slot, (unsigned long long)__double2ll_rn((double)s1 * BN_FIX));
+            atomicAdd(g.st_sums + 2 * st_slot + 1, (unsigned long long)__double2ll_rn((double)s2 * BN_FIX));
+          }
+        }
       }
       __syncthreads();
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float4 v = *reinterpret_cast<const float4*>(inv + 8 * q + 4 * h);
         scale[4 * q] = v.x; scale[4 * q + 1] = v.y; scale[4 * q + 2] = v.z; scale[4 * q + 3] = v.w;
-      }
-    }
-  }
-  if constexpr (STATS) {
-    if (g.st_sums) {
-      // per row: sum_f relu(v), sum_f relu(v)^2 over the N columns (same reduction as the norm above: transposing DPP sums inside
-      // the wave, the four column tiles through LDS in wave order), then ONE pair of 64-bit integer atomics per row
-      float* red1 = scratch;                           // [32 rows][4 waves]
-      float* red2 = scratch + 128;
-      float q1[16], q2[16];
-      const bool okc = wid < NT && (wid * 32 + i) < g.N;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float rl = okc ? fmaxf(acc[0][r] * scale[r], 0.f) : 0.f;
-        q1[r] = rl; q2[r] = rl * rl;
-      }
-      float t1 = row16_sum_transpose(q1), t2 = row16_sum_transpose(q2);
-      t1 += __shfl_xor(t1, 16, 64); t2 += __shfl_xor(t2, 16, 64);
-      __syncthreads();                                 // (the normalisation's readers of `scratch` are done)
-      if ((lane & 16) == 0) {
-        const int r = lane & 15, row = (r & 3) + 8 * (r >> 2) + 4 * h;
-        red1[row * 4 + wid] = t1; red2[row * 4 + wid] = t2;
-      }
-      __syncthreads();
-      if (wid == 0 && lane < 32 && st_slot >= 0) {
-        const float4 a = *reinterpret_cast<const float4*>(red1 + lane * 4), b = *reinterpret_cast<const float4*>(red2 + lane * 4);
-        const float s1 = (a.x + a.y) + (a.z + a.w), s2 = (b.x + b.y) + (b.z + b.w);
-        atomicAdd(g.st_sums + 2 * st_slot, (unsigned long long)__double2ll_rn((double)s1 * BN_FIX));
-        atomicAdd(g.st_sums + 2 * st_slot + 1, (unsigned long long)__double2ll_rn((double)s2 * BN_FIX));
       }
     }
   }
