@@ -268,13 +268,13 @@ int tsgnn_rowgemm_f32(const float* a, int64_t lda, const float* b, int64_t ldb, 
 int tsgnn_gather_rowgemm_f32(const int* ell, int ell_w, const int* tail_ptr, const int* tail_col, const float* x, int64_t ldx, const float* b, int64_t ldb, int trans_b,
                              const float* bias, float* c, int64_t ldc, float* rinv, float* zout, int64_t ldz, int64_t rows, int K,
                              int N, int normalize, int64_t fill_rows, tsgnn_stream_t stream);
-/* tsgnn_gather_rowgemm_f32 (trans_b = 0, normalize = 1, 96 < N <= 128, no CSR tail) for a layer that is followed by the slot
- * batch-norm (apply_bn, encoders.py:134-138) WITHOUT a launch for it: the epilogue adds every real row's
+/* tsgnn_gather_rowgemm_f32 (trans_b = 0, normalize = 1, 96 < N <= 128, 64 < K <= 128) for a layer that is followed by the slot
+ * batch-norm (apply_bn, encoders.py:134-138) WITHOUT a launch for it (tail_ptr / tail_col as there): the epilogue adds every real row's
  * (sum_f relu(v), sum_f relu(v)^2) to sums[2 * row_slot[r]] as 64-bit fixed-point integers (2^-40 units: integer addition is
  * associative, so the totals do not depend on the order the panels finish in — bitwise reproducible) and the filler block leaves
  * the ghost row's two numbers in ghost[0..1].  sums [2 * nslots], 16-byte aligned, zero before the launch; row_slot[r] < 0: row r
  * belongs to no graph (padding of a capacity-padded batch).  Consumer: tsgnn_sage_layer_fwd_bn_f32. */
-int tsgnn_gather_rowgemm_st_f32(const int* ell, int ell_w, const float* x, int64_t ldx, const float* b, int64_t ldb, const float* bias,
+int tsgnn_gather_rowgemm_st_f32(const int* ell, int ell_w, const int* tail_ptr, const int* tail_col, const float* x, int64_t ldx, const float* b, int64_t ldb, const float* bias,
                                 float* c, int64_t ldc, float* rinv, float* zout, int64_t ldz, int64_t rows, int K, int N,
                                 int64_t fill_rows, const int* row_slot, unsigned long long* sums, float* ghost, tsgnn_stream_t stream);
 /* tsgnn_sage_layer_fwd[_ro]_f32 for a layer whose INPUT's slot batch-norm has no launch of its own: x = the previous layer's
@@ -282,10 +282,10 @@ int tsgnn_gather_rowgemm_st_f32(const int* ell, int ell_w, const float* x, int64
  * nodes.  Every row-panel block turns the sums into (mean, rstd) per slot — exact from the integers, ghost copies by their
  * multiplicity B - slot_count[n], biased variance, eps 1e-5 — and gathers y_j = (relu(v_j) - mean[slot_j]) * rstd[slot_j]; the
  * readout partial does the same for the rows it scans, and its blocks of graph 0 write mean_out / rstd_out [nslots] for the
- * backward (tsgnn_slot_post_bwd_f32).  ell: entry = slot << 20 | row (no CSR tail), nslots <= 1024, rows < 2^20, n_ghost = nslots.
+ * backward (tsgnn_slot_post_bwd_f32).  ell / tail_col: entry = slot << 20 | row, nslots <= 1024, rows < 2^20, n_ghost = nslots.
  * row_slot != NULL: this layer is followed by a batch-norm as well, its statistics go to sums_out / ghost_out (zero before);
  * packed_out != NULL: last layer, readout epilogue as in tsgnn_sage_layer_fwd_ro_f32 (not both). */
-int tsgnn_sage_layer_fwd_bn_f32(const int* ell, int ell_w, const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias,
+int tsgnn_sage_layer_fwd_bn_f32(const int* ell, int ell_w, const int* tail_ptr, const int* tail_col, const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias,
                                 float* v, int64_t ldv, float* rinv, float* zout, int64_t ldz, int64_t rows, int K, int64_t fill_rows,
                                 const int* graph_ptr, const int* slot_count, int B, int nslots, int n_ghost, unsigned long long* packed,
                                 unsigned long long* packed_out, const int* row_graph, const unsigned long long* sums_in,

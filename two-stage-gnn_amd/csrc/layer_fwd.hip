@@ -59,7 +59,7 @@ extern "C" {
  * backward.  ell: entry = slot << 20 | row (GraphBatch.ell_slots(); no CSR tail), nslots <= 1024, rows < 2^20.
  * row_slot != NULL: this layer is followed by a batch-norm as well: its statistics go to sums_out / ghost_out (zero before).
  * packed_out != NULL: last layer, readout epilogue (as tsgnn_sage_layer_fwd_ro_f32). */
-int tsgnn_sage_layer_fwd_bn_f32(const int* ell, int ell_w, const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias,
+int tsgnn_sage_layer_fwd_bn_f32(const int* ell, int ell_w, const int* tail_ptr, const int* tail_col, const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias,
                                 float* v, int64_t ldv, float* rinv, float* zout, int64_t ldz, int64_t rows, int K, int64_t fill_rows,
                                 const int* graph_ptr, const int* slot_count, int B, int nslots, int n_ghost, unsigned long long* packed,
                                 unsigned long long* packed_out, const int* row_graph, const unsigned long long* sums_in,
@@ -77,7 +77,8 @@ int tsgnn_sage_layer_fwd_bn_f32(const int* ell, int ell_w, const float* x, int64
       nslots > BN_TAB || rows >= (1 << 20) || n_ghost == 0 || (packed_out && row_slot))
     return TSGNN_EUNSUPPORTED;
   if (packed_out && fill_rows <= 0) return TSGNN_EUNSUPPORTED;
-  RowGemmArgs ga{x, ldx, w, ldw, bias, v, ldv, rinv, rows, K, 128, 1, fill_rows, ell, ell_w, zout, ldz, nullptr, nullptr,
+  if ((tail_ptr == nullptr) != (tail_col == nullptr)) return TSGNN_EINVAL;
+  RowGemmArgs ga{x, ldx, w, ldw, bias, v, ldv, rinv, rows, K, 128, 1, fill_rows, ell, ell_w, zout, ldz, tail_ptr, tail_col,
                  packed_out, graph_ptr, row_graph, B, nslots, n_ghost};
   ga.st_row_slot = row_slot; ga.st_sums = sums_out; ga.st_ghost = ghost_out;
   ga.bn_sums = sums_in; ga.bn_ghost = ghost_in; ga.bn_slot_count = slot_count; ga.bn_B = B; ga.bn_nslots = nslots; ga.bn_F = K;

@@ -262,7 +262,7 @@ int tsgnn_rowgemm_f32(const float* a, int64_t lda, const float* b, int64_t ldb, 
  * sums[2 * row_slot[r]] as 64-bit fixed-point integers (2^-40 units; order-independent, so bitwise reproducible) and the filler
  * block leaves the ghost row's two numbers in ghost[0..1].  sums: zero before the launch.  row_slot[r] < 0: row r belongs to no
  * graph (padding of a capacity-padded batch).  The consumer is tsgnn_sage_layer_fwd_bn_f32. */
-int tsgnn_gather_rowgemm_st_f32(const int* ell, int ell_w, const float* x, int64_t ldx, const float* b, int64_t ldb, const float* bias,
+int tsgnn_gather_rowgemm_st_f32(const int* ell, int ell_w, const int* tail_ptr, const int* tail_col, const float* x, int64_t ldx, const float* b, int64_t ldb, const float* bias,
                                 float* c, int64_t ldc, float* rinv, float* zout, int64_t ldz, int64_t rows, int K, int N,
                                 int64_t fill_rows, const int* row_slot, unsigned long long* sums, float* ghost, tsgnn_stream_t stream) {
   if (!ell || !x || !b || !c || !row_slot || !sums || !ghost || rows <= 0 || fill_rows < 0 || K <= 0 || N <= 0 || ldx < K || ldc < N)
@@ -273,7 +273,8 @@ int tsgnn_gather_rowgemm_st_f32(const int* ell, int ell_w, const float* x, int64
     return TSGNN_EUNSUPPORTED;
   if (zout && ((ldz % 4) || ldz < K || (reinterpret_cast<uintptr_t>(zout) & 15))) return TSGNN_EUNSUPPORTED;
   if ((N % 4) || (ldc % 4) || (reinterpret_cast<uintptr_t>(c) & 15) || (bias && (reinterpret_cast<uintptr_t>(bias) & 15))) return TSGNN_EUNSUPPORTED;
-  RowGemmArgs g{x, ldx, b, ldb, bias, c, ldc, rinv, rows, K, N, 1, fill_rows, ell, ell_w, zout, ldz, nullptr, nullptr};
+  if ((tail_ptr == nullptr) != (tail_col == nullptr)) return TSGNN_EINVAL;
+  RowGemmArgs g{x, ldx, b, ldb, bias, c, ldc, rinv, rows, K, N, 1, fill_rows, ell, ell_w, zout, ldz, tail_ptr, tail_col};
   g.st_row_slot = row_slot; g.st_sums = sums; g.st_ghost = ghost;
   const unsigned nblk = (unsigned)(ceil_div64(rows, 32) + (fill_rows > 0 ? 1 : 0));
   if (K > KC && nblk <= ks2_max_blocks() && rowgemm_ks2_enabled()) {

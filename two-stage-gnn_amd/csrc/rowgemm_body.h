@@ -389,7 +389,13 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem_a
       }
       if (colok && g.tail_ptr && row < g.rows && ids[p][GN - 1] >= 0) {   // lists longer than the table continue in the CSR tail
         for (int e = g.tail_ptr[row]; e < g.tail_ptr[row + 1]; ++e) {
-          const float4 t = ldg4(g.a + (int64_t)g.tail_col[e] * g.lda + 4 * c4);
+          const int j = g.tail_col[e];                     // BNIN: slot << 20 | row, like the table's entries
+          float4 t = ldg4(g.a + (int64_t)(BNIN ? (j & 0xFFFFF) : j) * g.lda + 4 * c4);
+          if constexpr (BNIN) {
+            const float2 rm = bn_tab[j >> 20];
+            t.x = fmaf(fmaxf(t.x, 0.f), rm.x, -rm.y); t.y = fmaf(fmaxf(t.y, 0.f), rm.x, -rm.y);
+            t.z = fmaf(fmaxf(t.z, 0.f), rm.x, -rm.y); t.w = fmaf(fmaxf(t.w, 0.f), rm.x, -rm.y);
+          }
           va.x += t.x; va.y += t.y; va.z += t.z; va.w += t.w;
         }
       }

@@ -243,22 +243,27 @@ class GraphBatch:
         return self._ell
 
     def ell_slots(self):
-        """the neighbour table with the neighbour's SLOT beside its row: entry = slot << 20 | row (empty entries stay -1), or None
-        (CSR tail, >= 2^20 rows, > 1024 slots).  Operand of the layers whose input's slot batch-norm is formed on the fly
-        (tsgnn_sage_layer_fwd_bn_f32).  Built once per batch structure, outside the step."""
+        """(table, tail_col) of the neighbour table with the neighbour's SLOT beside its row: entry = slot << 20 | row (empty
+        entries stay -1), or None (>= 2^20 rows, > 1024 slots).  Operand of the layers whose input's slot batch-norm is formed on
+        the fly (tsgnn_sage_layer_fwd_bn_f32).  Built once per batch structure, outside the step."""
         if getattr(self, "_ell_slots", None) is None:
             e = self.ell()
-            if e is None or e[2] is not None or self.total_rows >= (1 << 20) or self.nmax > 1024 or self.row_slot is None:
+            if e is None or self.total_rows >= (1 << 20) or self.nmax > 1024 or self.row_slot is None:
                 self._ell_slots = False
             else:
-                ell, W, _ = e
-                ids = ell[: self.total_rows * W].to(torch.int64)
-                ok = (ids >= 0) & (ids < self.n_rows)                  # (nothing aggregates from a ghost row)
-                slot = self.row_slot.to(torch.int64)[ids.clamp(0, max(self.n_rows - 1, 0))]
-                packed = torch.where(ok, (slot << 20) | ids, torch.full_like(ids, -1)).to(torch.int32)
-                out = _i32(max(self.total_rows * W, 1), self.device)
-                out[: packed.numel()] = packed
-                self._ell_slots = out
+                ell, W, tail = e
+                slot_of = self.row_slot.to(torch.int64)
+
+                def pack(ids32, n):
+                    ids = ids32[:n].to(torch.int64)
+                    ok = (ids >= 0) & (ids < self.n_rows)              # (nothing aggregates from a ghost row)
+                    packed = torch.where(ok, (slot_of[ids.clamp(0, max(self.n_rows - 1, 0))] << 20) | ids, torch.full_like(ids, -1))
+                    out = _i32(max(ids32.numel(), 1), self.device)
+                    out[:n] = packed.to(torch.int32)
+                    return out
+                table = pack(ell, self.total_rows * W)
+                tcol = pack(tail[1], int(tail[0][-1].item())) if tail is not None else None
+                self._ell_slots = (table, tcol)
         return self._ell_slots if self._ell_slots is not False else None
 
     def bn_workspace(self, B, L, Fh, Fl, nslots):

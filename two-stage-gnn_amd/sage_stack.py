@@ -154,7 +154,9 @@ class _SageStack(torch.autograd.Function):
                 packed = bnf["packed"]
         if bnf is not None:
             # ---- slot batch-norm without launches of its own (L launches for the conv stack instead of 2L - 1)
-            ell, ell_w, _ = g.ell()
+            ell, ell_w, tail = g.ell()
+            tp, tc = tail if tail is not None else (None, None)
+            ell_s, tc_s = ell_s
             sums, ghost = bnf["sums"], bnf["ghost"]
             for l in range(L):
                 K, N = Ws[l].size(0), Ws[l].size(1)
@@ -164,13 +166,13 @@ class _SageStack(torch.autograd.Function):
                 s_out = sums[l * 2 * sn:(l + 1) * 2 * sn] if l < L - 1 else None
                 g_out = ghost[2 * l:2 * l + 2] if l < L - 1 else None
                 if l == 0:
-                    nat.call("gather_rowgemm_st_f32", ell, ell_w, x, x.stride(0), Ws[0], Ws[0].stride(0), bs[0], v, v.stride(0), rinv, z,
+                    nat.call("gather_rowgemm_st_f32", ell, ell_w, tp, tc, x, x.stride(0), Ws[0], Ws[0].stride(0), bs[0], v, v.stride(0), rinv, z,
                              z.stride(0), g.n_rows, K, N, gs, g.row_slot, s_out, g_out)
                     mean = rstd = None
                 else:
                     pm, pr_ = saved[l - 1][3], saved[l - 1][4]
                     last = l == L - 1
-                    nat.call("sage_layer_fwd_bn_f32", ell_s, ell_w, saved[l - 1][1], saved[l - 1][1].stride(0), Ws[l], Ws[l].stride(0), bs[l],
+                    nat.call("sage_layer_fwd_bn_f32", ell_s, ell_w, tp, tc_s, saved[l - 1][1], saved[l - 1][1].stride(0), Ws[l], Ws[l].stride(0), bs[l],
                              v, v.stride(0), rinv, z, z.stride(0), g.n_rows, K, gs, g.graph_ptr, g.slot_count, B, sn, sg,
                              packed[(l - 1) * B * Fh:(l - 1) * B * Fh + B * Fh],
                              packed[l * B * Fh:l * B * Fh + (B + 1) * N] if last else None, g.row_graph,
