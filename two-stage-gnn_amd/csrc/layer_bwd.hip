@@ -16,11 +16,16 @@ namespace {
 
 // PANELS_FIRST: the row panels take the low block indices (dispatched first), the slab blocks follow
 template <bool PANELS_FIRST>
-__global__ __launch_bounds__(256) void sage_layer_bwd_kernel(RowGemmArgs ga, TnArgs gt, unsigned n_tn, unsigned nslab, unsigned n_pan) {
+__global__ __launch_bounds__(256) void sage_layer_bwd_kernel(RowGemmArgs ga, TnArgs gt, unsigned n_tn, unsigned nslab, unsigned n_pan, int slab_delay) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (PANELS_FIRST) {
     if (blockIdx.x < n_pan) rowgemm_body<4, true, true>(ga, smem, blockIdx.x);
-    else { const unsigned b = blockIdx.x - n_pan; tn_rows_body<4, 4, 2>(gt, smem, b % nslab, b / nslab, nslab); }
+    else {
+      // the slab blocks finish well before the row panels (whose gather prologue is two dependent round trips): let the panels'
+      // requests go first instead of competing with the slabs' 64 KB per block for the same first microseconds
+      for (int i = 0; i < slab_delay; ++i) __builtin_amdgcn_s_sleep(16);
+      const unsigned b = blockIdx.x - n_pan; tn_rows_body<4, 4, 2>(gt, smem, b % nslab, b / nslab, nslab);
+    }
   } else {
     if (blockIdx.x < n_tn) tn_rows_body<4, 4, 2>(gt, smem, blockIdx.x % nslab, blockIdx.x / nslab, nslab);
     else rowgemm_body<4, true, true>(ga, smem, blockIdx.x - n_tn);
@@ -47,9 +52,10 @@ int tsgnn_sage_layer_bwd_f32(const int* ell, int ell_w, const int* tail_ptr, con
   const unsigned n_tn = 2u * (unsigned)nslab, n_pan = (unsigned)ceil_div64(rows, 32);
   constexpr size_t la = rowgemm_lds_bytes<4, true, true>(), lt = tn_rows_lds_bytes<4, 4>();
   static const int panels_first = [] { const char* e = getenv("TSGNN_BWD_PANELS_FIRST"); return e ? atoi(e) : 1; }();
+  static const int slab_delay = [] { const char* e = getenv("TSGNN_SLAB_DELAY"); return e ? atoi(e) : 0; }();
   TSGNN_KNAME("sage_layer_bwd_kernel");
-  if (panels_first) sage_layer_bwd_kernel<true><<<n_tn + n_pan, 256, la > lt ? la : lt, stream>>>(ga, gt, n_tn, (unsigned)nslab, n_pan);
-  else sage_layer_bwd_kernel<false><<<n_tn + n_pan, 256, la > lt ? la : lt, stream>>>(ga, gt, n_tn, (unsigned)nslab, n_pan);
+  if (panels_first) sage_layer_bwd_kernel<true><<<n_tn + n_pan, 256, la > lt ? la : lt, stream>>>(ga, gt, n_tn, (unsigned)nslab, n_pan, slab_delay);
+  else sage_layer_bwd_kernel<false><<<n_tn + n_pan, 256, la > lt ? la : lt, stream>>>(ga, gt, n_tn, (unsigned)nslab, n_pan, slab_delay);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }

@@ -161,8 +161,16 @@ __global__ __launch_bounds__(256) void adam_from_partials(float* __restrict__ p,
     const bool ok = (base + c) < n;
     gv[c] = ok ? g[base + c] : 0.f; pv[c] = ok ? p[base + c] : 0.f; mv[c] = ok ? m[base + c] : 0.f; vv[c] = ok ? v[base + c] : 0.f;
   }
+  // (the shares, ~3 per thread: requested together — a `t += parts[k]` loop was one dependent L2 round trip per iteration —
+  // and added in the loop's order: the same bits)
   float t = 0.f;
-  for (int k = tid; k < nparts; k += 256) t += parts[k];
+  for (int k0 = tid; k0 < nparts; k0 += 4 * 256) {
+    float q[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) q[u] = parts[min(k0 + 256 * u, nparts - 1)];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (k0 + 256 * u < nparts) t += q[u];
+  }
   t = wave_sum(t);
   if ((tid & 63) == 0) lds[tid >> 6] = t;
   __syncthreads();

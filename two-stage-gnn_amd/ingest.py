@@ -111,6 +111,9 @@ class CapacityBatch:
         g.symmetric = True
         g.sizes = None
         g.ghost_slots_fixed = self.nmax if ghost_slots is None else int(ghost_slots)
+        # the neighbour table of this batch is rewritten on the device every step: a slot-annotated copy built once on the host side
+        # (GraphBatch.ell_slots, operand of the fused slot batch-norm path) would go stale, so that path is off for these batches
+        g._ell_slots = False
         self.g = g
         self.node_label = m[off[5]:off[5] + row_cap]
         self.label = m[off[3]:off[3] + 2 * B].view(torch.int64)
