@@ -98,16 +98,20 @@ int tsgnn_host_collate_compact(const int64_t* ds_graph_ptr, const int64_t* ds_ro
                                int ell_w, int64_t tail_cap, int32_t* staging, int64_t* out);
 /* pull (flat copy of the whole staging buffer into its device mirror: graph_ptr, slot_count, label, node_label, tail_col are used
  * straight out of the mirror at the layout's offsets) and expand (mirror -> row maps, neighbour table, tail pointers, one-hot
- * feature rows); the expansion reads the sizes from the batch's header, so the captured pair serves every batch. */
+ * feature rows); the expansion reads the sizes from the batch's header, so the captured pair serves every batch.
+ * ell_slots [(row_cap+nmax)*ell_w] / tail_slots [tail_cap] (nullable, here and in the entry points below): the neighbour table and
+ * the CSR tail once more with the neighbour's SLOT beside its row (entry = slot << 20 | row; a neighbour lives in the row's own
+ * graph, so its slot is its row minus the graph's first row) — the operand of tsgnn_sage_layer_fwd_bn_f32.  row_slot of a
+ * padding row (>= n) is -1. */
 int tsgnn_ingest_pull_expand_f32(const int32_t* host, int32_t* mirror, int B, int nmax, int64_t row_cap, int64_t edge_cap, int ell_w,
-                                 int64_t tail_cap, int32_t* row_graph, int32_t* row_slot, int32_t* ell, int32_t* tail_ptr, int F, float* x,
+                                 int64_t tail_cap, int32_t* row_graph, int32_t* row_slot, int32_t* ell, int32_t* tail_ptr, int32_t* ell_slots, int32_t* tail_slots, int F, float* x,
                                  int64_t ldx, tsgnn_stream_t stream);
 /* The same pair; the expand launch also echoes the batch's sequence word (header word 4 of the compact layout, written by whoever
  * collated the batch) to host_ack[0] (PINNED HOST memory, system-scope store): once host_ack[0] == s, batch s has been pulled out
  * of `host`, which may be refilled.  The hand-shake with the collate workers (tsgnn_collate_pool_submit_ack) without a HIP event
  * per step (graph_sampler.py:102-114 / train.py:110-119: the per-step batch hand-over). */
 int tsgnn_ingest_pull_expand_ack_f32(const int32_t* host, int32_t* mirror, int B, int nmax, int64_t row_cap, int64_t edge_cap, int ell_w,
-                                     int64_t tail_cap, int32_t* row_graph, int32_t* row_slot, int32_t* ell, int32_t* tail_ptr, int F,
+                                     int64_t tail_cap, int32_t* row_graph, int32_t* row_slot, int32_t* ell, int32_t* tail_ptr, int32_t* ell_slots, int32_t* tail_slots, int F,
                                      float* x, int64_t ldx, int64_t* host_ack, tsgnn_stream_t stream);
 /* The two halves alone, and the pull as PASSENGERS of a launch of the previous step: tsgnn_ingest_arm_pull_rider arms the flat copy
  * host -> mirror on the calling thread; the thread's next tsgnn_sage_layer_fwd_f32 / _ro_f32 launch carries it as extra workgroups
@@ -117,14 +121,14 @@ int tsgnn_ingest_pull_expand_ack_f32(const int32_t* host, int32_t* mirror, int B
 int tsgnn_ingest_pull_f32(const int32_t* host, int32_t* mirror, int B, int nmax, int64_t row_cap, int64_t edge_cap, int64_t tail_cap,
                           tsgnn_stream_t stream);
 int tsgnn_ingest_expand_ack_f32(int32_t* mirror, int B, int nmax, int64_t row_cap, int64_t edge_cap, int ell_w, int64_t tail_cap,
-                                int32_t* row_graph, int32_t* row_slot, int32_t* ell, int32_t* tail_ptr, int F, float* x, int64_t ldx,
+                                int32_t* row_graph, int32_t* row_slot, int32_t* ell, int32_t* tail_ptr, int32_t* ell_slots, int32_t* tail_slots, int F, float* x, int64_t ldx,
                                 int64_t* host_ack, tsgnn_stream_t stream);
 int tsgnn_ingest_arm_pull_rider(const int32_t* host, int32_t* mirror, int B, int nmax, int64_t row_cap, int64_t edge_cap, int64_t tail_cap);
 /* the EXPANSION of that batch (arguments of tsgnn_ingest_expand_ack_f32) as passengers of the thread's next
  * tsgnn_packed_head_fwd_f32 launch (a few latency-bound workgroups: most of the chip is idle under it), later in the same step than
  * the launch that carries the pull.  tsgnn_ingest_flush_pull_rider launches whichever of the two riders no launch took. */
 int tsgnn_ingest_arm_expand_rider(int32_t* mirror, int B, int nmax, int64_t row_cap, int64_t edge_cap, int ell_w, int64_t tail_cap,
-                                  int32_t* row_graph, int32_t* row_slot, int32_t* ell, int32_t* tail_ptr, int F, float* x, int64_t ldx,
+                                  int32_t* row_graph, int32_t* row_slot, int32_t* ell, int32_t* tail_ptr, int32_t* ell_slots, int32_t* tail_slots, int F, float* x, int64_t ldx,
                                   int64_t* host_ack);
 int tsgnn_ingest_flush_pull_rider(tsgnn_stream_t stream);
 /* Collate workers: native threads that run the host collate for the batches ahead of the step being enqueued.  submit: the

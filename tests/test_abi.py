@@ -65,10 +65,10 @@ def test_new_entry_points_validate_on_the_host():
     assert L.tsgnn_wgrad_blocks_plan(100, 600, 264, 600, 264, ns.ctypes.data, rps.ctypes.data, need.ctypes.data) == 0 and ns[0] == 0
     # late round 2: Linear-layout weight gradients, the ingest hand-shake and the riding pull
     assert L.tsgnn_wgrad_blocks_oi_f32(None, 8, None, 8, 16, 8, 8, 1, 32, None, None, 8, None, None) == -1
-    assert L.tsgnn_ingest_pull_expand_ack_f32(None, None, 4, 64, 256, 1024, 16, 64, None, None, None, None, 8, None, 8, None, None) == -1
+    assert L.tsgnn_ingest_pull_expand_ack_f32(None, None, 4, 64, 256, 1024, 16, 64, None, None, None, None, None, None, 8, None, 8, None, None) == -1
     assert L.tsgnn_ingest_pull_f32(None, None, 4, 64, 256, 1024, 64, None) == -1
     assert L.tsgnn_ingest_arm_pull_rider(None, None, 4, 64, 256, 1024, 64) == -1       # nothing armed by a rejected call:
-    assert L.tsgnn_ingest_arm_expand_rider(None, 4, 64, 256, 1024, 16, 64, None, None, None, None, 8, None, 8, None) == -1
+    assert L.tsgnn_ingest_arm_expand_rider(None, 4, 64, 256, 1024, 16, 64, None, None, None, None, None, None, 8, None, 8, None) == -1
     assert L.tsgnn_ingest_flush_pull_rider(None) == 0                                   # ... so this launches nothing
     assert L.tsgnn_collate_pool_submit_ack(None, None, None, None, None, None, None, 4, 64, 256, 1024, 16, 64, None, None, None, 0, 1,
                                            None) == -1

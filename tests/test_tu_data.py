@@ -254,6 +254,11 @@ def test_capacity_padded_step_equals_exact_batch():
     assert torch.equal(slot.g.slot_count[:nmax], g.slot_count)
     assert torch.equal(slot.g.row_graph[:n], g.row_graph[:n]) and torch.equal(slot.g.row_slot[:n], g.row_slot[:n])
     assert bool((slot.g.row_graph[n:] == B).all()) and int(slot.g._ell[2][0].abs().sum()) == 0
+    # the slot-annotated copy of the table (operand of the fused slot batch-norm path) = what the exact batch builds on the host side
+    es_ref = g.ell_slots()[0].view(-1, W)
+    es_slot = slot.g.ell_slots()[0].view(-1, 16)
+    torch.testing.assert_close(es_slot[:n, :W], es_ref[:n], rtol=0, atol=0)
+    assert bool((es_slot[:n, W:] == -1).all()) and bool((es_slot[n:] == -1).all()) and bool((slot.g.row_slot[n:] == -1).all())
 
     class A:
         bias = True

@@ -191,7 +191,7 @@ int tsgnn_host_collate_compact(const int64_t* ds_graph_ptr, const int64_t* ds_ro
  * [(row_cap+nmax) x ell_w], tail_ptr[row_cap+nmax+1], one-hot x [(row_cap+nmax) x ldx] (F classes).  Sizes come from the batch's
  * own header, so one captured launch pair serves every batch of the slot. */
 static int pull_expand_launch(const int32_t* host, int32_t* mirror, int B, int nmax, int64_t row_cap, int64_t edge_cap, int ell_w,
-                              int64_t tail_cap, int32_t* row_graph, int32_t* row_slot, int32_t* ell, int32_t* tail_ptr, int F, float* x,
+                              int64_t tail_cap, int32_t* row_graph, int32_t* row_slot, int32_t* ell, int32_t* tail_ptr, int32_t* ell_slots, int32_t* tail_slots, int F, float* x,
                               int64_t ldx, int64_t* host_ack, tsgnn_stream_t stream) {
   if (!host || !mirror || !row_graph || !row_slot || !ell || !tail_ptr || !x || B <= 0 || nmax <= 0 || row_cap <= 0 || edge_cap <= 0 ||
       tail_cap < 0 || F <= 0)
@@ -207,16 +207,16 @@ static int pull_expand_launch(const int32_t* host, int32_t* mirror, int B, int n
   unsigned pgrid = (unsigned)ceil_div64(n4, 256 * 2);
   if (pgrid > 512) pgrid = 512;
   ingest_pull_kernel<<<pgrid, 256, 0, stream>>>(reinterpret_cast<const int4*>(host), reinterpret_cast<int4*>(mirror), n4);
-  ExpandArgs ea{mirror, L, B, nmax, ell_w, F, ld4, row_cap, row_graph, row_slot, ell, tail_ptr, x, ldx, host_ack};
+  ExpandArgs ea{mirror, L, B, nmax, ell_w, F, ld4, row_cap, row_graph, row_slot, ell, tail_ptr, x, ldx, host_ack, ell_slots, tail_slots};
   ingest_expand_kernel<<<(unsigned)ceil_div64(row_cap + nmax, 8), 256, 0, stream>>>(ea);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }
 
 int tsgnn_ingest_pull_expand_f32(const int32_t* host, int32_t* mirror, int B, int nmax, int64_t row_cap, int64_t edge_cap, int ell_w,
-                                 int64_t tail_cap, int32_t* row_graph, int32_t* row_slot, int32_t* ell, int32_t* tail_ptr, int F, float* x,
+                                 int64_t tail_cap, int32_t* row_graph, int32_t* row_slot, int32_t* ell, int32_t* tail_ptr, int32_t* ell_slots, int32_t* tail_slots, int F, float* x,
                                  int64_t ldx, tsgnn_stream_t stream) {
-  return pull_expand_launch(host, mirror, B, nmax, row_cap, edge_cap, ell_w, tail_cap, row_graph, row_slot, ell, tail_ptr, F, x, ldx,
+  return pull_expand_launch(host, mirror, B, nmax, row_cap, edge_cap, ell_w, tail_cap, row_graph, row_slot, ell, tail_ptr, ell_slots, tail_slots, F, x, ldx,
                             nullptr, stream);
 }
 
@@ -225,10 +225,10 @@ int tsgnn_ingest_pull_expand_f32(const int32_t* host, int32_t* mirror, int B, in
  * which may then be refilled — the hand-shake with the collate workers (tsgnn_collate_pool_submit_ack) without a HIP event per
  * step. */
 int tsgnn_ingest_pull_expand_ack_f32(const int32_t* host, int32_t* mirror, int B, int nmax, int64_t row_cap, int64_t edge_cap, int ell_w,
-                                     int64_t tail_cap, int32_t* row_graph, int32_t* row_slot, int32_t* ell, int32_t* tail_ptr, int F,
+                                     int64_t tail_cap, int32_t* row_graph, int32_t* row_slot, int32_t* ell, int32_t* tail_ptr, int32_t* ell_slots, int32_t* tail_slots, int F,
                                      float* x, int64_t ldx, int64_t* host_ack, tsgnn_stream_t stream) {
   if (!host_ack) return TSGNN_EINVAL;
-  return pull_expand_launch(host, mirror, B, nmax, row_cap, edge_cap, ell_w, tail_cap, row_graph, row_slot, ell, tail_ptr, F, x, ldx,
+  return pull_expand_launch(host, mirror, B, nmax, row_cap, edge_cap, ell_w, tail_cap, row_graph, row_slot, ell, tail_ptr, ell_slots, tail_slots, F, x, ldx,
                             host_ack, stream);
 }
 
@@ -236,7 +236,7 @@ int tsgnn_ingest_pull_expand_ack_f32(const int32_t* host, int32_t* mirror, int B
  * nullable): for a batch whose pull already happened — as passengers of the previous step (tsgnn_ingest_arm_pull_rider) or by
  * tsgnn_ingest_pull_f32. */
 int tsgnn_ingest_expand_ack_f32(int32_t* mirror, int B, int nmax, int64_t row_cap, int64_t edge_cap, int ell_w, int64_t tail_cap,
-                                int32_t* row_graph, int32_t* row_slot, int32_t* ell, int32_t* tail_ptr, int F, float* x, int64_t ldx,
+                                int32_t* row_graph, int32_t* row_slot, int32_t* ell, int32_t* tail_ptr, int32_t* ell_slots, int32_t* tail_slots, int F, float* x, int64_t ldx,
                                 int64_t* host_ack, tsgnn_stream_t stream) {
   if (!mirror || !row_graph || !row_slot || !ell || !tail_ptr || !x || B <= 0 || nmax <= 0 || row_cap <= 0 || edge_cap <= 0 ||
       tail_cap < 0 || F <= 0)
@@ -245,7 +245,7 @@ int tsgnn_ingest_expand_ack_f32(int32_t* mirror, int B, int nmax, int64_t row_ca
   if ((ell_w != 4 && ell_w != 8 && ell_w != 16) || ldx < 4 * ld4 || (ldx % 4)) return TSGNN_EUNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(mirror) | reinterpret_cast<uintptr_t>(ell) | reinterpret_cast<uintptr_t>(x)) & 15) return TSGNN_EUNSUPPORTED;
   const CLayout L = make_clayout(B, nmax, row_cap, edge_cap, tail_cap);
-  ExpandArgs ea{mirror, L, B, nmax, ell_w, F, ld4, row_cap, row_graph, row_slot, ell, tail_ptr, x, ldx, host_ack};
+  ExpandArgs ea{mirror, L, B, nmax, ell_w, F, ld4, row_cap, row_graph, row_slot, ell, tail_ptr, x, ldx, host_ack, ell_slots, tail_slots};
   TSGNN_KNAME("ingest_expand_kernel");
   ingest_expand_kernel<<<(unsigned)ceil_div64(row_cap + nmax, 8), 256, 0, stream>>>(ea);
   TSGNN_CHECK_LAUNCH();
@@ -290,7 +290,7 @@ int tsgnn_ingest_arm_pull_rider(const int32_t* host, int32_t* mirror, int B, int
  * tsgnn_packed_head_fwd_f32 launch — a launch of a few workgroups that leaves most of the chip idle, later in the same step than the
  * launch that carries the pull. */
 int tsgnn_ingest_arm_expand_rider(int32_t* mirror, int B, int nmax, int64_t row_cap, int64_t edge_cap, int ell_w, int64_t tail_cap,
-                                  int32_t* row_graph, int32_t* row_slot, int32_t* ell, int32_t* tail_ptr, int F, float* x, int64_t ldx,
+                                  int32_t* row_graph, int32_t* row_slot, int32_t* ell, int32_t* tail_ptr, int32_t* ell_slots, int32_t* tail_slots, int F, float* x, int64_t ldx,
                                   int64_t* host_ack) {
   if (!mirror || !row_graph || !row_slot || !ell || !tail_ptr || !x || B <= 0 || nmax <= 0 || row_cap <= 0 || edge_cap <= 0 ||
       tail_cap < 0 || F <= 0)
@@ -300,7 +300,7 @@ int tsgnn_ingest_arm_expand_rider(int32_t* mirror, int B, int nmax, int64_t row_
   if ((reinterpret_cast<uintptr_t>(mirror) | reinterpret_cast<uintptr_t>(ell) | reinterpret_cast<uintptr_t>(x)) & 15) return TSGNN_EUNSUPPORTED;
   const CLayout L = make_clayout(B, nmax, row_cap, edge_cap, tail_cap);
   ExpandRider e;
-  e.ex = ExpandArgs{mirror, L, B, nmax, ell_w, F, ld4, row_cap, row_graph, row_slot, ell, tail_ptr, x, ldx, host_ack};
+  e.ex = ExpandArgs{mirror, L, B, nmax, ell_w, F, ld4, row_cap, row_graph, row_slot, ell, tail_ptr, x, ldx, host_ack, ell_slots, tail_slots};
   e.rows = row_cap + nmax;
   const long long want = (e.rows + 15) / 16;                 // one 512-thread workgroup per 16 rows, at most 448 of them (looping)
   e.blocks = (unsigned)(want < 448 ? want : 448);

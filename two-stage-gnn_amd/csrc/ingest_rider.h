@@ -43,7 +43,17 @@ struct ExpandArgs {
   int B, nmax, ell_w, F, ld4; int64_t row_cap;
   int32_t* row_graph; int32_t* row_slot; int32_t* ell; int32_t* tail_ptr; float* x; int64_t ldx;
   int64_t* host_ack;                     // nullable (pinned host memory): receives the batch's sequence word once it is pulled
+  // nullable: the neighbour table / the CSR tail once more with the neighbour's SLOT beside its row (entry = slot << 20 | row), the
+  // operand of the layers that form their input's slot batch-norm on the fly (tsgnn_sage_layer_fwd_bn_f32).  A neighbour lives in
+  // the row's own graph, so its slot is its row minus the graph's first row.
+  int32_t* ell_slots; int32_t* tail_slots;
 };
+__device__ __forceinline__ int expand_graph_of(const ExpandArgs& a, int64_t r) {      // the graph whose row range holds r (r < n)
+  const int32_t* gp = a.mirror + a.L.graph_ptr;
+  int lo = 0, hi = a.B;                                  // gp[lo] <= r < gp[hi]
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (gp[mid] <= r) lo = mid; else hi = mid; }
+  return lo;
+}
 
 // 32 lanes per row, 8 rows per block.  Lane q of a row: q < ell_w/4 writes four entries of the row's neighbour table, q == ell_w/4
 // the row maps and the tail pointer, the lanes after that (looping when a row has more than 32 - ell_w/4 - 1 float4) the one-hot
@@ -73,20 +83,38 @@ __device__ __forceinline__ void expand_row_lane(const ExpandArgs& a, int64_t r, 
       if (k + 3 < d) v.w = col[k + 3];
     }
     *reinterpret_cast<int4*>(a.ell + r * a.ell_w + 4 * q) = v;
+    if (a.ell_slots) {
+      int4 w = make_int4(-1, -1, -1, -1);
+      if (r < n) {
+        const int g0 = a.mirror[a.L.graph_ptr + expand_graph_of(a, r)];
+        if (v.x >= 0) w.x = ((v.x - g0) << 20) | v.x;
+        if (v.y >= 0) w.y = ((v.y - g0) << 20) | v.y;
+        if (v.z >= 0) w.z = ((v.z - g0) << 20) | v.z;
+        if (v.w >= 0) w.w = ((v.w - g0) << 20) | v.w;
+      }
+      *reinterpret_cast<int4*>(a.ell_slots + r * a.ell_w + 4 * q) = w;
+    }
   } else if (q == EQ) {
+    int g0 = 0;
     if (r < a.row_cap) {
-      int g = a.B, slot = 0;
-      if (r < n) {                                          // binary search: the graph whose row range holds r
-        const int32_t* gp = a.mirror + a.L.graph_ptr;
-        int lo = 0, hi = a.B;                               // gp[lo] <= r < gp[hi]
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (gp[mid] <= r) lo = mid; else hi = mid; }
-        g = lo; slot = (int)(r - gp[lo]);
+      int g = a.B, slot = -1;                               // (padding rows of the capacity: no graph, no slot)
+      if (r < n) {
+        g = expand_graph_of(a, r);
+        g0 = a.mirror[a.L.graph_ptr + g];
+        slot = (int)(r - g0);
       }
       a.row_graph[r] = g;
       a.row_slot[r] = slot;
     }
     a.tail_ptr[r] = r < n ? a.mirror[a.L.tail_ptr + r] : ntail;
     if (r == total_rows - 1) a.tail_ptr[total_rows] = ntail;
+    if (a.tail_slots && r < n) {                            // this row's share of the CSR tail (rows with more than ell_w neighbours: few)
+      const int e1 = (r + 1 < n) ? a.mirror[a.L.tail_ptr + r + 1] : ntail;
+      for (int e = a.mirror[a.L.tail_ptr + r]; e < e1; ++e) {
+        const int j = a.mirror[a.L.tail_col + e];
+        a.tail_slots[e] = ((j - g0) << 20) | j;
+      }
+    }
   } else {
     const bool ok = l >= 0 && l < a.F;                      // (no dynamic register indexing: that would go through scratch)
     for (int c4 = q - EQ - 1; c4 < a.ld4; c4 += 32 - EQ - 1) {

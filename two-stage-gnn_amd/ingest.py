@@ -111,9 +111,11 @@ class CapacityBatch:
         g.symmetric = True
         g.sizes = None
         g.ghost_slots_fixed = self.nmax if ghost_slots is None else int(ghost_slots)
-        # the neighbour table of this batch is rewritten on the device every step: a slot-annotated copy built once on the host side
-        # (GraphBatch.ell_slots, operand of the fused slot batch-norm path) would go stale, so that path is off for these batches
-        g._ell_slots = False
+        # the neighbour table of this batch is rewritten on the device every step, and so is its slot-annotated copy (the operand
+        # of the fused slot batch-norm path, GraphBatch.ell_slots): the expansion writes both
+        self.ell_slots = torch.full((R * ELL_W,), -1, dtype=torch.int32, device=device)
+        self.tail_slots = i32(max(tail_cap, 1))
+        g._ell_slots = (self.ell_slots, self.tail_slots) if (R < (1 << 20) and self.nmax <= 1024) else False
         self.g = g
         self.node_label = m[off[5]:off[5] + row_cap]
         self.label = m[off[3]:off[3] + 2 * B].view(torch.int64)
@@ -183,7 +185,7 @@ class CapacityBatch:
         g = self.g
         ell, _, (tail_ptr, tail_col) = g._ell
         args = (self.host.data_ptr(), self.mirror, self.B, self.nmax, self.row_cap, self.edge_cap, ELL_W, self.tail_cap, g.row_graph,
-                g.row_slot, ell, tail_ptr, self.fin, self.x, self.x.stride(0), self.ack.data_ptr())
+                g.row_slot, ell, tail_ptr, self.ell_slots, self.tail_slots, self.fin, self.x, self.x.stride(0), self.ack.data_ptr())
         nat.call("ingest_pull_expand_ack_f32", *args)
         if not torch.cuda.is_current_stream_capturing():
             self._replayed = True
@@ -192,7 +194,7 @@ class CapacityBatch:
         g = self.g
         ell, _, (tail_ptr, tail_col) = g._ell
         return (self.mirror, self.B, self.nmax, self.row_cap, self.edge_cap, ELL_W, self.tail_cap, g.row_graph, g.row_slot, ell, tail_ptr,
-                self.fin, self.x, self.x.stride(0), self.ack.data_ptr())
+                self.ell_slots, self.tail_slots, self.fin, self.x, self.x.stride(0), self.ack.data_ptr())
 
     def expand(self):
         """the expansion alone, of a batch that is already in the mirror (pulled as passengers of the previous step, or by pull_only)"""

@@ -61,6 +61,7 @@ HEAD_DU = os.environ.get("TSGNN_HEAD_DU", "1") != "0"                     # ... 
 
 
 SLABS_BESIDE = os.environ.get("TSGNN_SLABS_BESIDE", "1") != "0"
+NSLAB_MAX = int(os.environ.get("TSGNN_NSLAB_MAX", "0"))
 _ncu = {}
 
 
@@ -71,6 +72,10 @@ def _slabs_beside_panels(nslab, rps, need, rows, K, N, dev):
     13.7 -> 18.2 us).  Fewer, longer slabs keep the launch at two blocks per CU."""
     if not SLABS_BESIDE or nslab <= 0:
         return nslab, rps, need
+    if NSLAB_MAX and nslab > NSLAB_MAX:                         # (experiment knob: fewer, longer slabs)
+        rps = (-(-rows // NSLAB_MAX) + 7) // 8 * 8
+        nslab = -(-rows // rps)
+        need = nslab * (K + 1) * N
     ncu = _ncu.get(dev)
     if ncu is None:
         ncu = _ncu[dev] = torch.cuda.get_device_properties(dev).multi_processor_count
