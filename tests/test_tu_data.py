@@ -415,7 +415,9 @@ def test_ingest_pipeline_riding_pull_equals_pull_at_the_head(workers):
             torch.cuda.synchronize()
             assert not any(n in names for n in ("ingest_pull_f32", "ingest_pull_expand_ack_f32"))
             assert ("ingest_expand_ack_f32" in names) == (ride == 1) and (ride == 2 or names[0] == "ingest_expand_ack_f32")
-            assert names.count("sage_layer_fwd_f32") + names.count("sage_layer_fwd_ro_f32") == 2 and "packed_head_fwd_f32" in names
+            # (the carriers: the hidden layers' product launches and the head's forward — with or without the fused slot batch-norm)
+            assert (names.count("sage_layer_fwd_f32") + names.count("sage_layer_fwd_ro_f32") + names.count("sage_layer_fwd_bn_f32") == 2
+                    and ("packed_head_fwd_f32" in names or "packed_head_fwd_z_f32" in names))
             assert len(flush) == 1 and not flush[0][2].startswith("ingest_")      # nothing was left for launches of their own
         pipe.run(sched[:4], workers=workers)                       # (no synchronisation in between: the second run drains the
         pipe.run(sched[4:], workers=workers)                       # last replay's passengers itself)
