@@ -447,13 +447,15 @@ __device__ __forceinline__ void ce_rows(const CeArgs& ce, int B, int C, float* d
 // batch-norm, so its dU is a row-wise function of the readout gradient (readout_l2_bwd_rows in sage_fused.hip):
 //   du[r] = rinv_r (g_r - v_r <v_r, g_r>),   g_r[f] = dout[b, off + f] if r is the max-readout winner of (graph b, column f), else 0.
 // It used to be a launch of its own between this one and the layer's weight-gradient / input-gradient launch.  Here block
-// (b, c) owns rows [64c, 64c + 64) of graph b and does not wait for row block b: it rebuilds the 128-wide segment of dout[b, :]
+// (b, c) owns rows [128c, 128c + 128) of graph b and does not wait for row block b: it rebuilds the 128-wide segment of dout[b, :]
 // itself from the same operands in the same order (same bits), with every request — its rows of v, rinv, the winners, its W1
 // rows — issued before anything is waited for.  Ghost rows: all ghost rows of this layer are identical, so graph b can only
 // have won with its first one (row n_real + size_b); its contribution is written to du[n_real + b] — the rows behind the real
 // ones feed the bias gradient only (they aggregate nothing), where only their SUM matters, so B contribution rows stand for
 // the ghost rows (the caller passes bias_only_rows = B to the weight-gradient launch).  b == B: the padding rows of a
 // capacity-padded batch ([graph_ptr[B], n_real)) are zero-filled.
+constexpr int DU_CHUNK = 128;     // rows of a graph per dU block (every block rebuilds its graph's dout segment: fewer, larger blocks —
+                                  // with 64 the DD batches whose largest graph has > 448 nodes overflowed one block per compute unit)
 struct DuArgs {
   const int* graph_ptr; int64_t n_real; int n_ghost_rows; int chunks;
   const float* v; int64_t ldv; const float* rinv; const int* arg; int off; int F;
@@ -474,7 +476,7 @@ __device__ __forceinline__ void head2_du_role(const DuArgs& a, float* smem, cons
     return;
   }
   const int g0 = a.graph_ptr[b], sz = a.graph_ptr[b + 1] - g0;
-  const int lo = 64 * c, hi = min(sz, lo + 64);
+  const int lo = DU_CHUNK * c, hi = min(sz, lo + DU_CHUNK);
   const bool ghost_job = c == 0;                                 // chunk 0 also writes the graph's ghost contribution row
   if (lo >= hi && !ghost_job) return;
   const int P4 = P >> 2;
@@ -506,24 +508,6 @@ __device__ __forceinline__ void head2_du_role(const DuArgs& a, float* smem, cons
     for (int q = 0; q < 4; ++q) w2r[q] = q < C ? w2[(int64_t)q * E + tid] : 0.f;
     if (dvec) dv0 = dvec[(int64_t)b * E + tid];
   }
-  const unsigned ldv = (unsigned)a.ldv, lddu = (unsigned)a.lddu, col = 4u * (unsigned)(lig < F4 ? lig : 0);
-  float4 vv[2];
-  float ri[2];
-  int rows[2];                                                   // (rows < 2^31 / ld: checked by the entry point)
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int n = lo + rg + 32 * u;
-    rows[u] = n < hi ? g0 + n : -1;
-    const unsigned rr = rows[u] >= 0 ? (unsigned)rows[u] : 0u;
-    vv[u] = ld4(a.v + (size_t)(rr * ldv + col));
-    ri[u] = a.rinv[rr];
-  }
-  const bool has_ghost = ghost_job && sz < a.n_ghost_rows;      // (a graph that fills every slot has no padded row)
-  const int grow = (int)a.n_real + (has_ghost ? sz : 0);
-  float4 gv = z4;
-  float gri = 0.f;
-  if (ghost_job && rg == 0 && a.n_ghost_rows > 0) { gv = ld4(a.v + (size_t)((unsigned)grow * ldv + col)); gri = a.rinv[grow]; }
-  const int4 win = *reinterpret_cast<const int4*>(a.arg + (size_t)((unsigned)b * (unsigned)a.F + col));
   if (dy_ready_needs_sync) __syncthreads();
   // ---- dvt row of graph b, then the segment of dout[b, :]   (expressions and order of the row blocks)
   for (int j = tid; j < E; j += NTH) {
@@ -552,6 +536,26 @@ __device__ __forceinline__ void head2_du_role(const DuArgs& a, float* smem, cons
     }
     __builtin_amdgcn_sched_barrier(0);                           // (the second batch's requests stay behind the first batch's products)
   }
+  // the rows' own operands are requested HERE: the W1 registers are dead, and the requests travel under the two barriers and the
+  // group sums below (requested up front next to the W1 rows they pushed the kernel over its 128 registers per lane)
+  const unsigned ldv = (unsigned)a.ldv, lddu = (unsigned)a.lddu, col = 4u * (unsigned)(lig < F4 ? lig : 0);
+  float4 vv[DU_CHUNK / 32];
+  float ri[DU_CHUNK / 32];
+  int rows[DU_CHUNK / 32];                                       // (rows < 2^31 / ld: checked by the entry point)
+#pragma unroll
+  for (int u = 0; u < DU_CHUNK / 32; ++u) {
+    const int n = lo + rg + 32 * u;
+    rows[u] = n < hi ? g0 + n : -1;
+    const unsigned rr = rows[u] >= 0 ? (unsigned)rows[u] : 0u;
+    vv[u] = ld4(a.v + (size_t)(rr * ldv + col));
+    ri[u] = a.rinv[rr];
+  }
+  const bool has_ghost = ghost_job && sz < a.n_ghost_rows;      // (a graph that fills every slot has no padded row)
+  const int grow = (int)a.n_real + (has_ghost ? sz : 0);
+  float4 gv = z4;
+  float gri = 0.f;
+  if (ghost_job && rg == 0 && a.n_ghost_rows > 0) { gv = ld4(a.v + (size_t)((unsigned)grow * ldv + col)); gri = a.rinv[grow]; }
+  const int4 win = *reinterpret_cast<const int4*>(a.arg + (size_t)((unsigned)b * (unsigned)a.F + col));
   if (wact) *reinterpret_cast<float4*>(part + jg * a.F + 4 * lig) = acc;
   __syncthreads();
   for (int k = tid; k < a.F; k += NTH) {
@@ -563,7 +567,7 @@ __device__ __forceinline__ void head2_du_role(const DuArgs& a, float* smem, cons
   const float4 gd = lig < F4 ? *reinterpret_cast<const float4*>(dseg + 4 * lig) : z4;
   // ---- rows
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
+  for (int u = 0; u < DU_CHUNK / 32; ++u) {
     const int r32 = rows[u];
     float4 dyv = z4;
     if (rows[u] >= 0 && lig < F4) {
@@ -956,11 +960,11 @@ int tsgnn_head2_bwd_ce_f32(const float* out, int64_t ldo, const float* vec, cons
 
 /* tsgnn_head2_bwd_ce_f32 / tsgnn_head2_bwd_f32 (y == NULL: dy given) whose launch ALSO produces dU of the stack's last GraphConv
  * layer (no batch-norm: dU is a row-wise function of the readout gradient — what tsgnn_readout_l2_bwd_f32 computes in a launch of
- * its own): extra workgroups (graph b, 64-row chunk) rebuild the F-wide segment [seg_off, seg_off + F) of dout[b, :] themselves.
+ * its own): extra workgroups (graph b, 128-row chunk) rebuild the F-wide segment [seg_off, seg_off + F) of dout[b, :] themselves.
  * v / rinv: the layer's output rows and 1/norm; arg [B, F]: its max-readout winners; du rows [0, n_real) are written, and
  * du[n_real + b] = graph b's ghost-row contribution (all ghost rows of this layer are identical; only the SUM of the rows behind the
  * real ones is ever used — the bias gradient — so pass bias_only_rows = B downstream).  n_ghost_rows: ghost rows that exist
- * (a graph with size >= n_ghost_rows has none); chunks = ceil(largest graph / 64).  TSGNN_EUNSUPPORTED: shapes the
+ * (a graph with size >= n_ghost_rows has none); chunks = ceil(largest graph / 128).  TSGNN_EUNSUPPORTED: shapes the
  * second-generation backward kernel does not take (nothing launched: fall back to the two launches). */
 int tsgnn_head2_bwd_du_f32(const float* out, int64_t ldo, const float* vec, const float* y, const int64_t* label, float* loss,
                            const float* dy, const float* dvec, const float* w1, const float* w2, int B, int P, int E, int C, float* dout,

@@ -34,14 +34,14 @@ __global__ __launch_bounds__(256) void sage_layer_fwd_kernel(RowGemmArgs ga, Slo
 // sums.  ST: this layer is followed by a batch-norm too (statistics epilogue); RO: it is the last one (readout epilogue).
 template <bool RO, bool ST>
 __global__ __launch_bounds__(256, 2) void sage_layer_fwd_bn_kernel(RowGemmArgs ga, SlotArgs sa, BnReadArgs bn, unsigned n_gemm, unsigned ro_gx,
-                                                                int F4, unsigned long long* __restrict__ packed, unsigned n_main,
+                                                                int ro_ch, int F4, unsigned long long* __restrict__ packed, unsigned n_main,
                                                                 PullRider pr) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (blockIdx.x < n_gemm) {
     rowgemm_body<4, false, true, 1, RO, true, ST>(ga, smem, blockIdx.x);
   } else if (blockIdx.x < n_main) {
     const unsigned r = blockIdx.x - n_gemm;
-    readout_partial_bn_body<32>(sa, bn, ga.a, ga.lda, F4, packed, r % ro_gx, r / ro_gx, reinterpret_cast<unsigned long long*>(smem));
+    readout_partial_bn_body<32>(sa, bn, ga.a, ga.lda, F4, packed, r % ro_gx, r / ro_gx, ro_ch, reinterpret_cast<unsigned long long*>(smem));
   } else {
     pull_rider_body(pr, blockIdx.x - n_main);
   }
@@ -85,21 +85,30 @@ int tsgnn_sage_layer_fwd_bn_f32(const int* ell, int ell_w, const int* tail_ptr, 
   SlotArgs sa{graph_ptr, slot_count, B, nslots, rows, n_ghost};
   BnReadArgs bn{sums_in, ghost_in, K, mean_out, rstd_out};
   const unsigned n_gemm = (unsigned)ceil_div64(rows, 32) + (fill_rows > 0 ? 1u : 0u);
-  const unsigned ro_gx = (unsigned)((nslots + 63) / 64);
+  // slots per readout block: 64 while [panels + readout blocks] fit two blocks per compute unit (what the registers allow), else 128
+  // or 256 — DD seed 2: 266 panels + 256 readout blocks = 523 > 512 ran a third round for eleven blocks (13.9 -> 17.8 us)
+  static int ncu = 0;
+  if (ncu == 0) {
+    int dev = 0, v = 0;
+    ncu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+  }
+  int ro_ch = 64;
+  while (ro_ch < 256 && n_gemm + (unsigned)((nslots + ro_ch - 1) / ro_ch) * (unsigned)B > 2u * (unsigned)ncu) ro_ch *= 2;
+  const unsigned ro_gx = (unsigned)((nslots + ro_ch - 1) / ro_ch);
   size_t lds = rowgemm_lds_bytes<4, false, true, 1, true>();
-  const size_t lro = 8 * 128 * sizeof(unsigned long long) + 64 * sizeof(float2);
+  const size_t lro = 8 * 128 * sizeof(unsigned long long) + 256 * sizeof(float2);
   if (lds < lro) lds = lro;
   const unsigned n_main = n_gemm + ro_gx * (unsigned)B;
   const PullRider pr = take_pull_rider();
   if (packed_out) {
     TSGNN_KNAME("sage_layer_fwd_bn_kernel<ro>");
-    sage_layer_fwd_bn_kernel<true, false><<<n_main + pr.blocks, 256, lds, stream>>>(ga, sa, bn, n_gemm, ro_gx, K / 4, packed, n_main, pr);
+    sage_layer_fwd_bn_kernel<true, false><<<n_main + pr.blocks, 256, lds, stream>>>(ga, sa, bn, n_gemm, ro_gx, ro_ch, K / 4, packed, n_main, pr);
   } else if (row_slot) {
     TSGNN_KNAME("sage_layer_fwd_bn_kernel<stats>");
-    sage_layer_fwd_bn_kernel<false, true><<<n_main + pr.blocks, 256, lds, stream>>>(ga, sa, bn, n_gemm, ro_gx, K / 4, packed, n_main, pr);
+    sage_layer_fwd_bn_kernel<false, true><<<n_main + pr.blocks, 256, lds, stream>>>(ga, sa, bn, n_gemm, ro_gx, ro_ch, K / 4, packed, n_main, pr);
   } else {
     TSGNN_KNAME("sage_layer_fwd_bn_kernel<>");
-    sage_layer_fwd_bn_kernel<false, false><<<n_main + pr.blocks, 256, lds, stream>>>(ga, sa, bn, n_gemm, ro_gx, K / 4, packed, n_main, pr);
+    sage_layer_fwd_bn_kernel<false, false><<<n_main + pr.blocks, 256, lds, stream>>>(ga, sa, bn, n_gemm, ro_gx, ro_ch, K / 4, packed, n_main, pr);
   }
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;

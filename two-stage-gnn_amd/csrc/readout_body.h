@@ -59,8 +59,10 @@ struct BnReadArgs {
 };
 template <int G>
 __device__ __forceinline__ void readout_partial_bn_body(const SlotArgs& s, const BnReadArgs& bn, const float* __restrict__ x, int64_t ld,
-                                                        int F4, unsigned long long* __restrict__ packed, unsigned bx, unsigned by,
-                                                        unsigned long long* best_mem /* [256/G][4*G] + 64 float2 behind it */) {
+                                                        int F4, unsigned long long* __restrict__ packed, unsigned bx, unsigned by, int ch,
+                                                        unsigned long long* best_mem /* [256/G][4*G] + 256 float2 behind it */) {
+  // ch = slots per block (64, 128 or 256): the caller picks the smallest one that keeps [row panels + these blocks] within two
+  // blocks per compute unit (registers allow two): a launch a little over that limit runs a third round for a handful of blocks
   constexpr int RL = 256 / G;
   unsigned long long (*best)[4 * G] = reinterpret_cast<unsigned long long (*)[4 * G]>(best_mem);
   float2* tab = reinterpret_cast<float2*>(best_mem + RL * 4 * G);
@@ -68,8 +70,8 @@ __device__ __forceinline__ void readout_partial_bn_body(const SlotArgs& s, const
   const int c4 = threadIdx.x % G, rl = threadIdx.x / G;
   const int g0 = s.graph_ptr[b], sz = s.graph_ptr[b + 1] - g0;
   const int nslots = s.n_ghost ? s.nmax : sz;
-  const int n_lo = (int)bx * 64, n_hi = min(nslots, n_lo + 64);
-  if (threadIdx.x < 64) {
+  const int n_lo = (int)bx * ch, n_hi = min(nslots, n_lo + ch);
+  if ((int)threadIdx.x < ch) {
     const int n = min(n_lo + (int)threadIdx.x, s.nmax - 1);
     const ulonglong2 sm = *reinterpret_cast<const ulonglong2*>(bn.sums + 2 * n);
     const float2 ms = bn_stats_from_sums(sm.x, sm.y, s.slot_count[n], bn.ghost[0], bn.ghost[1], s.B, 1.0 / ((double)s.B * (double)bn.F), 1e-5f);
