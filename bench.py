@@ -574,10 +574,10 @@ def main():
                 table = summarise_kernels(rows, int(g.nnz))
                 top = max(table, key=lambda r: r["us_per_step"])
                 for r_ in table:                                # PMC traffic (recorded measurement) next to the algorithmic bytes
-                    t_ = traffic.get(r_["kernel"].replace(" ", ""))
+                    t_ = traffic.get(r_["kernel"].split(" (")[0].replace(" ", ""))
                     if isinstance(t_, dict):
                         r_["traffic"] = t_.get("traffic_bytes_per_launch")
-                tr = traffic.get(top["kernel"].replace(" ", ""), {})
+                tr = traffic.get(top["kernel"].split(" (")[0].replace(" ", ""), {})
                 tr = tr if isinstance(tr, dict) else {}
                 roofline = {"bound": top["bound"], "kernel": "%s (%s: %s)" % (top["kernel"], top["entry"], top["what"]),
                             "achieved": top["tflops"] if top["bound"] == "mfma" else top["gbs"],

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Parse gpurun_out/pmc_step_{f,w} (scripts/pmc_step.sh) -> profiles/r02/step_traffic.json: HBM bytes per launch of each kernel of
+"""Parse gpurun_out/pmc_step_{f,w} (scripts/pmc_step.sh) -> profiles/r03/step_traffic.json: HBM bytes per launch of each kernel of
 the timed step.  gfx950 corrections (MI355X_MICROARCH.md §HBM): FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE reports exactly half
 of the bytes of wide (16 B / lane) coalesced reads -> doubled; WRITE_SIZE is exact for 16-B-per-lane stores."""
 import collections, csv, glob, json, os, re
@@ -25,6 +25,6 @@ for k in F:
     fetch, write = F[k], W.get(k, 0.0)
     out[short(k)] = {"FETCH_SIZE_KiB_raw": fetch, "WRITE_SIZE_KiB_raw": write, "hbm_read_bytes": 2 * fetch * 1024,
                      "hbm_write_bytes": write * 1024, "traffic_bytes_per_launch": 2 * fetch * 1024 + write * 1024}
-os.makedirs("profiles/r02", exist_ok=True)
-json.dump(out, open("profiles/r02/step_traffic.json", "w"), indent=1, sort_keys=True)
+os.makedirs("profiles/r03", exist_ok=True)
+json.dump(out, open("profiles/r03/step_traffic.json", "w"), indent=1, sort_keys=True)
 print(json.dumps(out, indent=1, sort_keys=True))

@@ -881,7 +881,7 @@ int tsgnn_packed_head_fwd_z_f32(unsigned long long* packed, int B, int L, int Fh
   if ((P % 4) || P > 2048 || E > 8 * HW || ldo < P || (reinterpret_cast<uintptr_t>(w1) & 15)) return TSGNN_EUNSUPPORTED;
   const size_t lds = sizeof(float) * (size_t)(((P + 3) & ~3) + ((E + 3) & ~3));
   const ExpandRider rider = take_expand_rider();
-  TSGNN_KNAME("packed_head_fwd_kernel<8> (+ housekeeping)");
+  TSGNN_KNAME("packed_head_fwd_kernel<8>");
   packed_head_fwd_kernel<8><<<(unsigned)B + rider.blocks, 64 * HW, lds, stream>>>(packed, B, L, Fh, Fl, out, ldo, arg, w1, b1, w2, b2, P, E, C,
                                                                                vec, y, rider, clear, clear_n, 1);
   TSGNN_CHECK_LAUNCH();
@@ -922,7 +922,7 @@ static int head2_bwd_launch(const float* out, int64_t ldo, const float* vec, con
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(head2_bwd2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
         attr_set = lds2;
       }
-      TSGNN_KNAME(du ? "head2_bwd2_kernel (+ last layer's dU rows)" : "head2_bwd2_kernel");
+      TSGNN_KNAME("head2_bwd2_kernel");
       head2_bwd2_kernel<<<B + (E + 3) / 4 + 1 + du_blocks, 64 * HW, lds2, stream>>>(out, ldo, vec, dy, dvec, w1, w2, B, P, E, C, dout, lddo,
                                                                                 dw1, db1, dw2, db2, normparts,
                                                                                 CeArgs{ce_y, ce_label, ce_loss}, dua);

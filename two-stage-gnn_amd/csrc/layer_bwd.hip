@@ -53,7 +53,7 @@ int tsgnn_sage_layer_bwd_f32(const int* ell, int ell_w, const int* tail_ptr, con
   constexpr size_t la = rowgemm_lds_bytes<4, true, true>(), lt = tn_rows_lds_bytes<4, 4>();
   static const int panels_first = [] { const char* e = getenv("TSGNN_BWD_PANELS_FIRST"); return e ? atoi(e) : 1; }();
   static const int slab_delay = [] { const char* e = getenv("TSGNN_SLAB_DELAY"); return e ? atoi(e) : 0; }();
-  TSGNN_KNAME("sage_layer_bwd_kernel");
+  TSGNN_KNAME(panels_first ? "sage_layer_bwd_kernel<true>" : "sage_layer_bwd_kernel<false>");
   if (panels_first) sage_layer_bwd_kernel<true><<<n_tn + n_pan, 256, la > lt ? la : lt, stream>>>(ga, gt, n_tn, (unsigned)nslab, n_pan, slab_delay);
   else sage_layer_bwd_kernel<false><<<n_tn + n_pan, 256, la > lt ? la : lt, stream>>>(ga, gt, n_tn, (unsigned)nslab, n_pan, slab_delay);
   TSGNN_CHECK_LAUNCH();

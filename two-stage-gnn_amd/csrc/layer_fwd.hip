@@ -101,13 +101,13 @@ int tsgnn_sage_layer_fwd_bn_f32(const int* ell, int ell_w, const int* tail_ptr, 
   const unsigned n_main = n_gemm + ro_gx * (unsigned)B;
   const PullRider pr = take_pull_rider();
   if (packed_out) {
-    TSGNN_KNAME("sage_layer_fwd_bn_kernel<ro>");
+    TSGNN_KNAME("sage_layer_fwd_bn_kernel<true,false>");
     sage_layer_fwd_bn_kernel<true, false><<<n_main + pr.blocks, 256, lds, stream>>>(ga, sa, bn, n_gemm, ro_gx, ro_ch, K / 4, packed, n_main, pr);
   } else if (row_slot) {
-    TSGNN_KNAME("sage_layer_fwd_bn_kernel<stats>");
+    TSGNN_KNAME("sage_layer_fwd_bn_kernel<false,true>");
     sage_layer_fwd_bn_kernel<false, true><<<n_main + pr.blocks, 256, lds, stream>>>(ga, sa, bn, n_gemm, ro_gx, ro_ch, K / 4, packed, n_main, pr);
   } else {
-    TSGNN_KNAME("sage_layer_fwd_bn_kernel<>");
+    TSGNN_KNAME("sage_layer_fwd_bn_kernel<false,false>");
     sage_layer_fwd_bn_kernel<false, false><<<n_main + pr.blocks, 256, lds, stream>>>(ga, sa, bn, n_gemm, ro_gx, ro_ch, K / 4, packed, n_main, pr);
   }
   TSGNN_CHECK_LAUNCH();
