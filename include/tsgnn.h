@@ -770,17 +770,17 @@ int tsgnn_head2_bwd_ce_f32(const float* out, int64_t ldo, const float* vec, cons
                            float* dw1, float* db1, float* dw2, float* db2, float* normparts, tsgnn_stream_t stream);
 
 /* The same launch ALSO producing dU of the stack's LAST GraphConv layer (it has no batch-norm: dU is a row-wise function of the
- * readout gradient, what tsgnn_readout_l2_bwd_f32 computes in a launch of its own): extra workgroups (graph b, 128-row chunk)
+ * readout gradient, what tsgnn_readout_l2_bwd_f32 computes in a launch of its own): extra workgroups (graph b, chunk of 64 or 128 rows)
  * rebuild the F-wide segment [seg_off, seg_off + F) of dout[b, :] themselves (same operands, same order, same bits) and do not
  * wait for anybody.  y != NULL: cross-entropy folded in (label, loss) — else dy is given.  v / rinv: the layer's output rows and
  * 1 / norm; arg [B, F]: its max-readout winners; du rows [0, n_real) are written, and du[n_real + b] = graph b's ghost-row
  * contribution (all ghost rows of this layer are identical, and only the SUM of the rows behind the real ones is ever used —
- * the bias gradient — so pass bias_only_rows = B downstream).  n_ghost_rows: ghost rows that exist; chunks = ceil(largest
- * graph / 128).  TSGNN_EUNSUPPORTED (nothing launched): fall back to tsgnn_head2_bwd*_f32 + tsgnn_readout_l2_bwd_f32. */
+ * the bias gradient — so pass bias_only_rows = B downstream).  n_ghost_rows: ghost rows that exist; max_nodes = a bound on
+ * the largest graph.  TSGNN_EUNSUPPORTED (nothing launched): fall back to tsgnn_head2_bwd*_f32 + tsgnn_readout_l2_bwd_f32. */
 int tsgnn_head2_bwd_du_f32(const float* out, int64_t ldo, const float* vec, const float* y, const int64_t* label, float* loss,
                            const float* dy, const float* dvec, const float* w1, const float* w2, int B, int P, int E, int C, float* dout,
                            int64_t lddo, float* dw1, float* db1, float* dw2, float* db2, float* normparts, const int* graph_ptr,
-                           int64_t n_real, int n_ghost_rows, int chunks, const float* v, int64_t ldv, const float* rinv, const int* arg,
+                           int64_t n_real, int n_ghost_rows, int max_nodes, const float* v, int64_t ldv, const float* rinv, const int* arg,
                            int seg_off, int F, float* du, int64_t lddu, tsgnn_stream_t stream);
 
 /* ---- DiffPool contraction of a pooled level (dense per-graph operands small enough for LDS), one workgroup per graph

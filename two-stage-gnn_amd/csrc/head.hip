@@ -454,14 +454,16 @@ __device__ __forceinline__ void ce_rows(const CeArgs& ce, int B, int C, float* d
 // ones feed the bias gradient only (they aggregate nothing), where only their SUM matters, so B contribution rows stand for
 // the ghost rows (the caller passes bias_only_rows = B to the weight-gradient launch).  b == B: the padding rows of a
 // capacity-padded batch ([graph_ptr[B], n_real)) are zero-filled.
-constexpr int DU_CHUNK = 128;     // rows of a graph per dU block (every block rebuilds its graph's dout segment: fewer, larger blocks —
-                                  // with 64 the DD batches whose largest graph has > 448 nodes overflowed one block per compute unit)
+// DU_CHUNK (64 or 128): rows of a graph per dU block.  Every block rebuilds its graph's dout segment, so fewer, larger blocks do less
+// redundant work — but 128 rows per block is four rows per lane group and a slower block; the entry point takes 64 while the launch
+// stays near one block per compute unit and 128 above (DD batches whose largest graph has > 448 nodes).
 struct DuArgs {
   const int* graph_ptr; int64_t n_real; int n_ghost_rows; int chunks;
   const float* v; int64_t ldv; const float* rinv; const int* arg; int off; int F;
   float* du; int64_t lddu;
 };
 
+template <int DU_CHUNK>
 __device__ __forceinline__ void head2_du_role(const DuArgs& a, float* smem, const float* dy /* LDS or global [B, C] */, int d,
                                               const float* __restrict__ dvec, const float* __restrict__ w1, const float* __restrict__ w2,
                                               int B, int P, int E, int C, bool dy_ready_needs_sync) {
@@ -607,6 +609,7 @@ __device__ __forceinline__ void head2_du_role(const DuArgs& a, float* smem, cons
   }
 }
 
+template <int DU_CHUNK>
 __global__ __launch_bounds__(64 * HW) void head2_bwd2_kernel(const float* __restrict__ out, int64_t ldo, const float* __restrict__ vec,
                                                          const float* __restrict__ dy_in, const float* __restrict__ dvec,
                                                          const float* __restrict__ w1, const float* __restrict__ w2, int B, int P, int E,
@@ -627,7 +630,7 @@ __global__ __launch_bounds__(64 * HW) void head2_bwd2_kernel(const float* __rest
     const int d = (int)blockIdx.x - (B + nj + 1);
     const int gb = d / dua.chunks;
     if (has_ce && gb < B) ce_rows(ce, B, C, dyl, lb, gb);          // (thread 0 rebuilds row gb; synchronised inside the role)
-    head2_du_role(dua, smem, dy, d, dvec, w1, w2, B, P, E, C, has_ce);
+    head2_du_role<DU_CHUNK>(dua, smem, dy, d, dvec, w1, w2, B, P, E, C, has_ce);
     return;
   }
 
@@ -907,8 +910,17 @@ static int head2_bwd_launch(const float* out, int64_t ldo, const float* vec, con
     size_t lds2 = sizeof(float) * role;
     DuArgs dua{};
     unsigned du_blocks = 0;
+    int du_chunk = 64;
     if (du) {
-      dua = *du;
+      dua = *du;                                         // (du->chunks carries the largest graph's bound: see the entry point)
+      static int ncu = 0;
+      if (ncu == 0) {
+        int dev = 0, v = 0;
+        ncu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+      }
+      const int nodes = dua.chunks;                      // bound on the largest graph
+      if ((B + 1) * ((nodes + 63) / 64) + B + (E + 3) / 4 + 1 > ncu + ncu / 5) du_chunk = 128;
+      dua.chunks = (nodes + du_chunk - 1) / du_chunk;
       const int G = 64 * HW / P4 < 16 ? 64 * HW / P4 : 16;
       const size_t drole = (size_t)((E + 3) & ~3) + (size_t)(G + 1) * dua.F;
       if (drole > role) role = drole;
@@ -919,13 +931,19 @@ static int head2_bwd_launch(const float* out, int64_t ldo, const float* vec, con
     if (lds2 <= 160 * 1024 - 1024) {
       static size_t attr_set = 0;
       if (lds2 > 64 * 1024 && lds2 > attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(head2_bwd2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(head2_bwd2_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(head2_bwd2_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
         attr_set = lds2;
       }
-      TSGNN_KNAME("head2_bwd2_kernel");
-      head2_bwd2_kernel<<<B + (E + 3) / 4 + 1 + du_blocks, 64 * HW, lds2, stream>>>(out, ldo, vec, dy, dvec, w1, w2, B, P, E, C, dout, lddo,
-                                                                                dw1, db1, dw2, db2, normparts,
-                                                                                CeArgs{ce_y, ce_label, ce_loss}, dua);
+      TSGNN_KNAME(du_chunk == 128 ? "head2_bwd2_kernel<128>" : "head2_bwd2_kernel<64>");
+      if (du_chunk == 128)
+        head2_bwd2_kernel<128><<<B + (E + 3) / 4 + 1 + du_blocks, 64 * HW, lds2, stream>>>(out, ldo, vec, dy, dvec, w1, w2, B, P, E, C, dout, lddo,
+                                                                                        dw1, db1, dw2, db2, normparts,
+                                                                                        CeArgs{ce_y, ce_label, ce_loss}, dua);
+      else
+        head2_bwd2_kernel<64><<<B + (E + 3) / 4 + 1 + du_blocks, 64 * HW, lds2, stream>>>(out, ldo, vec, dy, dvec, w1, w2, B, P, E, C, dout, lddo,
+                                                                                       dw1, db1, dw2, db2, normparts,
+                                                                                       CeArgs{ce_y, ce_label, ce_loss}, dua);
       TSGNN_CHECK_LAUNCH();
       return TSGNN_OK;
     }
@@ -964,17 +982,18 @@ int tsgnn_head2_bwd_ce_f32(const float* out, int64_t ldo, const float* vec, cons
  * v / rinv: the layer's output rows and 1/norm; arg [B, F]: its max-readout winners; du rows [0, n_real) are written, and
  * du[n_real + b] = graph b's ghost-row contribution (all ghost rows of this layer are identical; only the SUM of the rows behind the
  * real ones is ever used — the bias gradient — so pass bias_only_rows = B downstream).  n_ghost_rows: ghost rows that exist
- * (a graph with size >= n_ghost_rows has none); chunks = ceil(largest graph / 128).  TSGNN_EUNSUPPORTED: shapes the
+ * (a graph with size >= n_ghost_rows has none); max_nodes = a bound on the largest graph.  TSGNN_EUNSUPPORTED: shapes the
  * second-generation backward kernel does not take (nothing launched: fall back to the two launches). */
 int tsgnn_head2_bwd_du_f32(const float* out, int64_t ldo, const float* vec, const float* y, const int64_t* label, float* loss,
                            const float* dy, const float* dvec, const float* w1, const float* w2, int B, int P, int E, int C, float* dout,
                            int64_t lddo, float* dw1, float* db1, float* dw2, float* db2, float* normparts, const int* graph_ptr,
-                           int64_t n_real, int n_ghost_rows, int chunks, const float* v, int64_t ldv, const float* rinv, const int* arg,
+                           int64_t n_real, int n_ghost_rows, int max_nodes, const float* v, int64_t ldv, const float* rinv, const int* arg,
                            int seg_off, int F, float* du, int64_t lddu, tsgnn_stream_t stream) {
+  const int chunks = max_nodes;
   if (!graph_ptr || !v || !rinv || !arg || !du || n_real < 0 || n_ghost_rows < 0 || chunks <= 0 || F <= 0 || seg_off < 0) return TSGNN_EINVAL;
   if ((y == nullptr) == (dy == nullptr)) return TSGNN_EINVAL;
   if (y && (!label || !loss)) return TSGNN_EINVAL;
-  if ((F % 4) || F > 128 || (seg_off % 4) || seg_off + F > P || (ldv % 4) || (lddu % 4) || ldv < F || lddu < F || chunks > 4096 ||
+  if ((F % 4) || F > 128 || (seg_off % 4) || seg_off + F > P || (ldv % 4) || (lddu % 4) || ldv < F || lddu < F || chunks > (1 << 20) ||
       ((reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(du) | reinterpret_cast<uintptr_t>(arg)) & 15))
     return TSGNN_EUNSUPPORTED;
   if ((n_real + 1024 + B) * (ldv > lddu ? ldv : lddu) >= (int64_t)1 << 30 || (int64_t)E * P >= (int64_t)1 << 30) return TSGNN_EUNSUPPORTED;   // 32-bit offsets

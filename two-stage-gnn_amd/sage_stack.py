@@ -342,7 +342,7 @@ class _SageStack(torch.autograd.Function):
                 if nat.try_call("head2_bwd_du_f32", out, out.stride(0), vec, ce[0] if ce is not None else None,
                                 ce[1] if ce is not None else None, ce[2] if ce is not None else None, None if ce is not None else dy, dvec,
                                 w1c, w2c, B, P, E, C, dout, dout.stride(0), dw1, db1, dw2, db2, parts, g.graph_ptr, g.n_rows, sg_,
-                                (sn_ + 127) // 128, v_l, v_l.stride(0), rinv_l, argl, (L - 1) * Fh, Fl, du_l, du_l.stride(0)):
+                                sn_, v_l, v_l.stride(0), rinv_l, argl, (L - 1) * Fh, Fl, du_l, du_l.stride(0)):
                     du_last = du_l
             if du_last is not None:
                 pass
