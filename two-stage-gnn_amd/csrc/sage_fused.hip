@@ -172,7 +172,8 @@ __global__ __launch_bounds__(BT) void slot_post_bwd(SlotArgs s, const float* __r
       gq[q] = ld4(dout + (int64_t)b * ldo + 4 * c4);
     }
   }
-  __syncthreads();
+  // the candidate row (one trip to graph_ptr), then EVERY request of the row at once — before the two barriers of the first-ghost
+  // protocol, which used to sit between the two trips
   int64_t row = -1;
   bool ghost = false;
   if (b < s.B) {
@@ -181,17 +182,15 @@ __global__ __launch_bounds__(BT) void slot_post_bwd(SlotArgs s, const float* __r
     else if (s.n_ghost) { row = s.n_real + n; ghost = true; }
   }
   TR(1);
-  if (ghost && c == 0) atomicMin(&first_ghost, b);
-  __syncthreads();
-  const bool fg = ghost && b == first_ghost;
-  const bool any_ghost = first_ghost != 0x7fffffff;               // uniform
   const float mu = bn ? mean[n] : 0.f, rs = bn ? rstd[n] : 1.f;
   float4 vv[NV], dy[NV], d2[NV];
   float a1 = 0.f, a2 = 0.f;
   // every request of the row first (v, dxs, dxs2: up to 3 NV loads), unconditionally from clamped addresses, masked below: loads
   // inside their own `if` were NV dependent round trips
-  {
+  float ri_pre;                                                   // 1 / norm of the row: requested with the row (a load at its use, behind
+  {                                                               // the block reductions, was one more dependent round trip at the end)
     const int64_t rv = row >= 0 ? row : 0, rd = (row >= 0 && !ghost) ? row : 0;
+    ri_pre = rinv[rv];
     // (dxs / dxs2 are uniform over the grid: ONE branch on them, then straight-line request blocks — a null test per load puts a
     // scalar branch and a full wait between the requests of consecutive q)
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -221,6 +220,11 @@ __global__ __launch_bounds__(BT) void slot_post_bwd(SlotArgs s, const float* __r
       }
     }
   }
+  __syncthreads();                                                // first_ghost is initialised
+  if (ghost && c == 0) atomicMin(&first_ghost, b);
+  __syncthreads();
+  const bool fg = ghost && b == first_ghost;
+  const bool any_ghost = first_ghost != 0x7fffffff;               // uniform
 #pragma unroll
   for (int q = 0; q < NV; ++q) {
     const int c4 = c + TPR * q;
@@ -327,7 +331,7 @@ __global__ __launch_bounds__(BT) void slot_post_bwd(SlotArgs s, const float* __r
   for (int q = 0; q < NV; ++q) dot += (vv[q].x * dv[q].x + vv[q].y * dv[q].y) + (vv[q].z * dv[q].z + vv[q].w * dv[q].w);
   dot = group_sum<TPR>(dot);
   if (writer) {
-    const float ri = rinv[row];
+    const float ri = ri_pre;
     if (ri >= 0.999e12f) dot = 0.f;
 #pragma unroll
     for (int q = 0; q < NV; ++q) {
