@@ -491,11 +491,24 @@ def test_diffpool_encoder_golden(tag):
     np.testing.assert_allclose(a.detach().cpu().numpy(), g["out_a"], rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(b.detach().cpu().numpy(), g["out_b"], rtol=1e-4, atol=1e-5)
     ((a * torch.tensor(g["ga"]).cuda()).sum() + (b * torch.tensor(g["gb"]).cuda()).sum()).backward()
-    for k, p in m.named_parameters():
-        ref = g["g." + k]
-        got = p.grad.cpu().numpy() if p.grad is not None else np.zeros_like(ref)
-        err = np.abs(got - ref).max()
-        assert err <= 5e-3 * np.abs(ref).max() + 2e-5, (k, err, np.abs(ref).max())
+    # gradients: arbitrated by an fp64 run of the oracle on the fixture's inputs.  The reference's own fp32
+    # gradients (the fixture) play the part of the fp32 CPU run: per tensor the HIP result must be as close to the exact gradient
+    # as the reference's fp32 is (x10), with the 2e-3 floor of assert_grads_arbitrated for tensors fp32 itself cannot resolve
+    # (pooled-level biases in front of normalise + BN sum thousands of cancelling terms; arg-max winners flip on a last bit), and
+    # only a handful of entries may be further than 1e-4 of the tensor's scale from fp64.
+    p64 = {k[2:]: torch.tensor(v).double().requires_grad_(True) for k, v in g.items() if k.startswith("p.")}
+    a64, b64 = R.diffpool_encoder(p64, torch.tensor(g["x"]).double(), torch.tensor(g["adj"]).double(), bnn, npool,
+                                  assign_x=torch.tensor(g["x"]).double(), final_dim=str(g["final_dim"]))
+    ((a64 * torch.tensor(g["ga"]).double()).sum() + (b64 * torch.tensor(g["gb"]).double()).sum()).backward()
+
+    class _G:                                              # (what assert_grads_arbitrated reads: `.grad`)
+        def __init__(self, t):
+            self.grad = t
+    p32 = {k: _G(torch.tensor(g["g." + k])) for k, _ in m.named_parameters() if "g." + k in g}
+    for k, v in p64.items():
+        if v.grad is None:
+            v.grad = torch.zeros_like(v)
+    assert_grads_arbitrated([(k, p) for k, p in m.named_parameters() if k in p32], p32, p64)
 
 
 def test_diffpool_dd_config_vs_oracle():
