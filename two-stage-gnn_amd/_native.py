@@ -140,7 +140,9 @@ def lib():
         raise RuntimeError(
             "libtsgnn_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "from the repo root. There is no CPU fallback for the product path." % LIB_PATH)
-    L = ctypes.CDLL(LIB_PATH)
+    # TSGNN_LIB_PATH: load ANOTHER build of the same sources (an A/B variant compiled with a different -D flag); still a HIP
+    # library with the same ABI: not a fallback
+    L = ctypes.CDLL(os.environ.get("TSGNN_LIB_PATH") or LIB_PATH)
     _decls = parse_header()
     for name, (ret, params) in _decls.items():
         try:

@@ -45,6 +45,30 @@ extern thread_local char tsgnn_kname_[160];
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// store of a value that THIS kernel will not read again (results handed to a later launch): -DTSGNN_NT_STORES=1 marks them
+// non-temporal.  Measured (round 3, A/B of two builds through TSGNN_LIB_PATH): the producers' own burst times drop (row panels
+// 10.0 -> 9.4 / 14.5 -> 13.8 / 13.1 -> 12.1 us: less to write back at the kernel boundary) and the replayed STEP does not move at all
+// (0.1295 ms both ways): what a producer saves its consumer pays on the read.  Off.
+#ifndef TSGNN_NT_STORES
+#define TSGNN_NT_STORES 0
+#endif
+typedef float tsgnn_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_out(float* p, float v) {
+#if TSGNN_NT_STORES
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+__device__ __forceinline__ void st_out(float4* p, float4 v) {
+#if TSGNN_NT_STORES
+  tsgnn_f32x4 t = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(t, reinterpret_cast<tsgnn_f32x4*>(p));
+#else
+  *p = v;
+#endif
+}
+
 // ---- cross-lane reductions on DPP (no LDS-crossbar round trips): quad_perm xor1 / xor2, row_half_mirror,
 // row_mirror give every lane its 16-lane row total; rows are combined through v_readlane (SGPR broadcast).
 // All 64 lanes of the wave must be active.

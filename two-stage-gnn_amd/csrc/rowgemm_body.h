@@ -403,7 +403,7 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem_a
         const int pr = 8 * KS * p + rsub;
         *reinterpret_cast<float4*>(Apanel + pr * LDA_F + 4 * (c4 ^ (pr & 7))) = va;
       }
-      if (g.zout && colok && row < g.rows) *reinterpret_cast<float4*>(g.zout + row * g.ldz + 4 * c4) = va;
+      if (g.zout && colok && row < g.rows) st_out(reinterpret_cast<float4*>(g.zout + row * g.ldz + 4 * c4), va);
     }
   }
   float bias_v[TPW];                                   // fetched now, used in the epilogue
@@ -549,7 +549,7 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem_a
       float* cp = g.c + (m0 + 4 * h) * g.ldc + cn;
       if (full) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) cp[(int64_t)((r & 3) + 8 * (r >> 2)) * g.ldc] = acc[t][r] * scale[r];
+        for (int r = 0; r < 16; ++r) st_out(cp + (int64_t)((r & 3) + 8 * (r >> 2)) * g.ldc, acc[t][r] * scale[r]);
       } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {

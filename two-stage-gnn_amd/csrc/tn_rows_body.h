@@ -212,7 +212,7 @@ __device__ __forceinline__ void tn_rows_body(const TnArgs& g, float* tn_smem, un
       float* sp = slab + (int64_t)(tm_[t] * 32 + 4 * h) * g.N + cn;
       if (full) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sp[((r & 3) + 8 * (r >> 2)) * g.N] = acc[t][r];
+        for (int r = 0; r < 16; ++r) st_out(sp + ((r & 3) + 8 * (r >> 2)) * g.N, acc[t][r]);
       } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
