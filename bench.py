@@ -181,6 +181,10 @@ def account(entry, a, nnz):
         nread = 1 + (a[8] is not None) + (a[10] is not None)
         by = f4 * (n + sg) * F * (nread + 1) + f4 * (n + sg) + (8 * int(a[2]) * F if a[12] is not None else 0)
         return 0.0, by, "backward of readout scatter + slot BN + ReLU + L2 normalise -> dU, F=%d" % F
+    if entry == "slot_post_wgrad_f32":
+        n, sg, F, K, nblk = int(a[4]), int(a[5]), int(a[13]), int(a[21]), int(a[23])
+        by = f4 * (n + sg) * F * 2 + f4 * n * K + f4 * (n + sg) + 8 * int(a[2]) * F + f4 * nblk * (K + 1) * F
+        return 2.0 * n * K * F, by, "layer 0: backward of readout scatter + slot BN + ReLU + normalise AND the dW/db slabs (dU stays in LDS), K=%d N=%d" % (K, F)
     if entry == "readout_head_fwd_f32":
         B, L, Fh, Fl, n, sg, E, C = int(a[1]), int(a[2]), int(a[3]), int(a[4]), int(a[8]), int(a[10]), int(a[18]), int(a[19])
         P = (L - 1) * Fh + Fl

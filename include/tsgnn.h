@@ -719,6 +719,15 @@ int tsgnn_slot_post_bwd_f32(const int* graph_ptr, const int* slot_count, int B, 
                             const float* v, int64_t ldv, const float* dxs, int64_t lddxs, const float* dxs2, int64_t lddxs2,
                             const float* dout, int64_t ldo, const int* arg, int F, int relu, int bn, const float* mean,
                             const float* rstd, const float* rinv, float* du, int64_t lddu, tsgnn_stream_t stream);
+/* Layer 0 of a stack — the layer whose dU has no consumer but its own weight / bias gradient (the input features need no gradient):
+ * tsgnn_slot_post_bwd_f32 (no dxs2) AND the slabs of tsgnn_linear_wgrad_f32 in ONE launch; the rows of dU never go to memory.
+ * z [rows, K_in] (16-byte rows): the layer's aggregated input kept by the forward.  ws: nblocks slabs of (K_in + 1) * 128 floats
+ * (nblocks <= nmax persistent workgroups walk the slots; sum them with tsgnn_wgrad_reduce_multi_f32, nslab = nblocks).
+ * B <= 32, F = 128, K_in <= 128, n_ghost = nmax. */
+int tsgnn_slot_post_wgrad_f32(const int* graph_ptr, const int* slot_count, int B, int nmax, int64_t n_real, int n_ghost,
+                              const float* v, int64_t ldv, const float* dxs, int64_t lddxs, const float* dout, int64_t ldo,
+                              const int* arg, int F, int relu, int bn, const float* mean, const float* rstd, const float* rinv,
+                              const float* z, int64_t ldz, int K_in, float* ws, int nblocks, tsgnn_stream_t stream);
 /* The same for the LAST layer of a stack (relu = bn = 0, nothing above it): du from the max-readout gradient alone, one lane
  * group per row instead of one workgroup per slot.  row_graph[n_real]: graph of every real row (>= B: padding row of a
  * capacity-padded batch, du = 0); rows [0, n_real + n_ghost_rows) of du are written; a ghost row n_real + n collects the

@@ -871,10 +871,10 @@ def _stack_run(B, nmax, sizes, fin, hid, p_edge, flags, seed=5):
     return a.detach().cpu(), b.detach().cpu(), grads, (m, x, adj, sizes)
 
 
-ALL_ON = dict(GATHER_FUSED=True, MERGED_FWD=True, MERGED_BWD=True, FUSED_TAIL=True, HEAD_DU=True, FUSED_BN=True)
+ALL_ON = dict(GATHER_FUSED=True, MERGED_FWD=True, MERGED_BWD=True, FUSED_TAIL=True, HEAD_DU=True, FUSED_BN=True, SLOT_WGRAD=True)
 
 
-@pytest.mark.parametrize("off", ["GATHER_FUSED", "MERGED_FWD", "MERGED_BWD", "FUSED_TAIL", "HEAD_DU", "FUSED_BN"])
+@pytest.mark.parametrize("off", ["GATHER_FUSED", "MERGED_FWD", "MERGED_BWD", "FUSED_TAIL", "HEAD_DU", "FUSED_BN", "SLOT_WGRAD"])
 def test_stack_fusion_variants_agree(off):
     """every launch fusion of the GraphSage stack (aggregation inside the product, product + readout partial, slabs + dX,
     readout tail + head, the last layer's dU inside the head's backward launch) gives the results of the launch sequence it replaces"""

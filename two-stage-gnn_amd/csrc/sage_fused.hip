@@ -130,27 +130,26 @@ __global__ __launch_bounds__(BT) void slot_bn_fwd(SlotArgs s, const float* __res
 //           + (arg[b,f] == row ? dout[b,f] : 0)                       [max-readout winner of graph b]
 // BN:   dv = rstd (dy - m1 - xhat m2) ; ReLU mask ; ghost copies summed in graph order ;
 // L2:   du = rinv (dv - v <v,dv>)   (rinv = 1e12 marks the clamped norm: du = rinv dv)
-template <int TPR, int NV, int BT>
-__global__ __launch_bounds__(BT) void slot_post_bwd(SlotArgs s, const float* __restrict__ v, int64_t ldv,
-                                                     const float* __restrict__ dxs, int64_t lddxs,
-                                                     const float* __restrict__ dxs2, int64_t lddxs2,
-                                                     const float* __restrict__ dout, int64_t ldo, const int* __restrict__ arg,
-                                                     int F4, int relu, int bn, const float* __restrict__ mean,
-                                                     const float* __restrict__ rstd, const float* __restrict__ rinv,
-                                                     float* __restrict__ du, int64_t lddu, SlotBwdAlt alt) {
-  if (blockIdx.y) { v = alt.v; dxs = alt.dxs; dxs2 = alt.dxs2; mean = alt.mean; rstd = alt.rstd; rinv = alt.rinv; du = alt.du; }
+// slot n of the launch.  TO_LDS: the rows of dU do not go to memory but into the tile u_lds[B <= BT / TPR][F] (zeroed by the caller;
+// candidate b's row at u_lds + b * F — ghost copies other than the first stay zero, the first carries their sum), for a caller that
+// consumes them at once (slot_post_wgrad_kernel: layer 0's weight gradient, whose dU nobody else reads).
+template <int TPR, int NV, int BT, bool TO_LDS>
+__device__ __forceinline__ void slot_post_body(const SlotArgs& s, const int n, float* smem, const float* __restrict__ v, int64_t ldv,
+                                               const float* __restrict__ dxs, int64_t lddxs, const float* __restrict__ dxs2,
+                                               int64_t lddxs2, const float* __restrict__ dout, int64_t ldo, const int* __restrict__ arg,
+                                               int F4, int relu, int bn, const float* __restrict__ mean,
+                                               const float* __restrict__ rstd, const float* __restrict__ rinv,
+                                               float* __restrict__ du, int64_t lddu, float* u_lds) {
   constexpr int NW = BT / 64;
-  // all LDS in ONE dynamic array (16-byte aligned base for the float4 ghost accumulators, Guideline 17)
-  extern __shared__ __attribute__((aligned(16))) float smem[];
   const int F = 4 * F4;
   float* gacc = smem;                                                // [NW waves][F] ghost-copy sums (only with ghost rows)
   float* red = smem + (s.n_ghost ? NW * F : 0);                      // 2 * NW floats
   int& first_ghost = *reinterpret_cast<int*>(red + 2 * NW);
-  const int n = blockIdx.x, tid = threadIdx.x;
+  const int tid = threadIdx.x;
   const int b = tid / TPR, c = tid % TPR;
   TR(0);
   if (tid == 0) first_ghost = 0x7fffffff;
-  {
+  if constexpr (!TO_LDS) {
     // capacity-padded batches (ingest.hip): rows [graph_ptr[B], n_real) belong to no graph; nothing below writes their du,
     // and the weight / bias gradients sum du over all n_real rows: they are zeroed here (no-op for exact batches)
     const int64_t pad_lo = s.graph_ptr[s.B], npad = s.n_real - pad_lo;
@@ -333,23 +332,136 @@ __global__ __launch_bounds__(BT) void slot_post_bwd(SlotArgs s, const float* __r
   if (writer) {
     const float ri = ri_pre;
     if (ri >= 0.999e12f) dot = 0.f;
+    float* dst = TO_LDS ? u_lds + b * F : du + row * lddu;
 #pragma unroll
     for (int q = 0; q < NV; ++q) {
       const int c4 = c + TPR * q;
       if (c4 < F4)
-        st4(du + row * lddu + 4 * c4, make_float4(ri * (dv[q].x - vv[q].x * dot), ri * (dv[q].y - vv[q].y * dot),
-                                                   ri * (dv[q].z - vv[q].z * dot), ri * (dv[q].w - vv[q].w * dot)));
+        st4(dst + 4 * c4, make_float4(ri * (dv[q].x - vv[q].x * dot), ri * (dv[q].y - vv[q].y * dot),
+                                      ri * (dv[q].z - vv[q].z * dot), ri * (dv[q].w - vv[q].w * dot)));
     }
   }
-  if (s.n_ghost && s.slot_count[n] == s.B && b == 0) {           // unused ghost row: zero gradient
-    const int64_t gr = s.n_real + n;
+  if constexpr (!TO_LDS) {
+    if (s.n_ghost && s.slot_count[n] == s.B && b == 0) {         // unused ghost row: zero gradient
+      const int64_t gr = s.n_real + n;
 #pragma unroll
-    for (int q = 0; q < NV; ++q) {
-      const int c4 = c + TPR * q;
-      if (c4 < F4) st4(du + gr * lddu + 4 * c4, make_float4(0.f, 0.f, 0.f, 0.f));
+      for (int q = 0; q < NV; ++q) {
+        const int c4 = c + TPR * q;
+        if (c4 < F4) st4(du + gr * lddu + 4 * c4, make_float4(0.f, 0.f, 0.f, 0.f));
+      }
     }
   }
   TR(6);
+}
+
+template <int TPR, int NV, int BT>
+__global__ __launch_bounds__(BT) void slot_post_bwd(SlotArgs s, const float* __restrict__ v, int64_t ldv,
+                                                     const float* __restrict__ dxs, int64_t lddxs,
+                                                     const float* __restrict__ dxs2, int64_t lddxs2,
+                                                     const float* __restrict__ dout, int64_t ldo, const int* __restrict__ arg,
+                                                     int F4, int relu, int bn, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const float* __restrict__ rinv,
+                                                     float* __restrict__ du, int64_t lddu, SlotBwdAlt alt) {
+  if (blockIdx.y) { v = alt.v; dxs = alt.dxs; dxs2 = alt.dxs2; mean = alt.mean; rstd = alt.rstd; rinv = alt.rinv; du = alt.du; }
+  // all LDS in ONE dynamic array (16-byte aligned base for the float4 ghost accumulators, Guideline 17)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  slot_post_body<TPR, NV, BT, false>(s, (int)blockIdx.x, smem, v, ldv, dxs, lddxs, dxs2, lddxs2, dout, ldo, arg, F4, relu, bn, mean, rstd, rinv, du,
+                                     lddu, nullptr);
+  TR_END();
+}
+
+// ---------------------------------------------------------------------------------------------- layer 0: dU and its only consumer
+// The FIRST layer's dU has one consumer — its weight / bias gradient (the input features need no gradient) — so the rows never
+// go to memory: a persistent workgroup walks slots n = blockIdx.x, + gridDim.x, ...; slot_post_body leaves the slot's <= 32 rows of dU
+// in an LDS tile, the rows of z (= A x0, kept by the forward) of the same candidates are staged beside it, and the chunk of 32 rows
+// goes through the slab body's MFMA step (tn_rows_body.h: A[m][k] = Z[row k][m], B[k][j] = dU[row k][j], wave w owns column tile w)
+// into accumulators that live across the slots.  One slab per workgroup at the end, summed by tsgnn_wgrad_reduce_multi_f32 like any
+// other.  Replaces slot_post_bwd + gemm_tn_rows_kernel of layer 0 (two launches, 4.2 MB of dU written and read back).  B <= 32, F = 128.
+typedef float sp_f32x16 __attribute__((ext_vector_type(16)));
+constexpr int SPW_AUX = 528;                             // gacc [4][128] + red [8] + first_ghost, rounded to 16 bytes
+template <int MT>
+__global__ __launch_bounds__(256) void slot_post_wgrad_kernel(SlotArgs s, const float* __restrict__ v, int64_t ldv,
+                                                              const float* __restrict__ dxs, int64_t lddxs,
+                                                              const float* __restrict__ dout, int64_t ldo, const int* __restrict__ arg,
+                                                              int relu, int bn, const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd, const float* __restrict__ rinv,
+                                                              const float* __restrict__ z, int64_t ldz, int K_in,
+                                                              float* __restrict__ slabs) {
+  constexpr int F = 128, F4 = 32, TPR = 8, KP = 32 * MT, KQ = (KP / 4 + TPR - 1) / TPR;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* aux = smem;
+  float* Us = smem + SPW_AUX;                            // [2 stages][32][F]
+  float* Zs = Us + 2 * 32 * F;                           // [2 stages][32][KP]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, i = lane & 31, h = lane >> 5;
+  const int b = tid / TPR, c = tid % TPR;
+  sp_f32x16 acc[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float dbacc = 0.f;
+  int it = 0;
+  for (int n = blockIdx.x; n < s.nmax; n += gridDim.x, ++it) {
+    float* U = Us + (it & 1) * 32 * F;
+    float* Z = Zs + (it & 1) * 32 * KP;
+    // the z rows of the slot's REAL candidates (a ghost row aggregates nothing: z = 0), requested first
+    int64_t zrow = -1;
+    if (b < s.B) {
+      const int g0 = s.graph_ptr[b], sz = s.graph_ptr[b + 1] - g0;
+      if (n < sz) zrow = (int64_t)g0 + n;
+    }
+    float4 zq[KQ];
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+      const int c4 = c + TPR * q;
+      zq[q] = ld4(z + (zrow >= 0 ? zrow : 0) * ldz + 4 * ((4 * c4 < K_in) ? c4 : 0));
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) st4(U + 4 * (tid + 256 * q), make_float4(0.f, 0.f, 0.f, 0.f));     // rows nobody writes stay zero
+    slot_post_body<TPR, 4, 256, true>(s, n, aux, v, ldv, dxs, lddxs, nullptr, 0, dout, ldo, arg, F4, relu, bn, mean, rstd, rinv, nullptr, 0, U);
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+      const int c4 = c + TPR * q;
+      if (c4 < KP / 4) {
+        float4 t = (zrow >= 0 && 4 * c4 < K_in) ? zq[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int nv = K_in - 4 * c4;                    // (K_in % 4 may be non-zero: the row padding of z contributes nothing)
+        if (nv < 4) t.w = 0.f;
+        if (nv < 3) t.z = 0.f;
+        if (nv < 2) t.y = 0.f;
+        st4(Z + b * KP + 4 * c4, t);
+      }
+    }
+    __syncthreads();
+    // the chunk's MFMA step: 32 rows = 16 k-steps
+    float bfr[16];
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) bfr[s2] = U[(2 * s2 + h) * F + wid * 32 + i];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      float afr[16];
+#pragma unroll
+      for (int s2 = 0; s2 < 16; ++s2) afr[s2] = Z[(2 * s2 + h) * KP + t * 32 + i];
+#pragma unroll
+      for (int s2 = 0; s2 < 16; ++s2) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[s2], bfr[s2], acc[t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) dbacc += bfr[s2];
+    // (no barrier here: the next slot writes the OTHER stage, and its slot_post_body synchronises before anybody gets back to this one)
+  }
+  float* slab = slabs + (int64_t)blockIdx.x * (K_in + 1) * F;
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const int cn = wid * 32 + i;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int cm = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (cm < K_in) slab[(int64_t)cm * F + cn] = acc[t][r];
+    }
+  }
+  {
+    const float vsum = dbacc + __shfl_xor(dbacc, 32, 64);      // rows of parity h = 0 and h = 1
+    if (lane < 32) slab[(int64_t)K_in * F + wid * 32 + i] = vsum;
+  }
   TR_END();
 }
 
@@ -506,6 +618,34 @@ int tsgnn_slot_post_bwd_f32(const int* graph_ptr, const int* slot_count, int B, 
   const int nw = B <= 32 ? 4 : (B <= 64 ? 8 : 16);
   const size_t lds = sizeof(float) * ((n_ghost ? (size_t)nw * F : 0) + 2 * nw + 4);
   TSGNN_SLOT_DISPATCH(slot_post_bwd, nmax, lds, (s, v, ldv, dxs, lddxs, dxs2, lddxs2, dout, ldo, arg, F / 4, relu, bn, mean, rstd, rinv, du, lddu, SlotBwdAlt{}));
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+/* Layer 0 of a stack: tsgnn_slot_post_bwd_f32 (relu = bn = 1, no dxs2) AND the weight / bias gradient slabs of tsgnn_linear_wgrad_f32 in
+ * ONE launch, for the layer whose dU has no other consumer (its input needs no gradient): the rows of dU stay in LDS.  z [rows, K_in]:
+ * the layer's aggregated input kept by the forward.  ws: nblocks slabs of (K_in + 1) * 128 floats (nblocks <= nslots workgroups walk the
+ * slots; sum them with tsgnn_wgrad_reduce_multi_f32, nslab = nblocks).  B <= 32, F = 128, K_in <= 128, n_ghost = nmax. */
+int tsgnn_slot_post_wgrad_f32(const int* graph_ptr, const int* slot_count, int B, int nmax, int64_t n_real, int n_ghost,
+                              const float* v, int64_t ldv, const float* dxs, int64_t lddxs, const float* dout, int64_t ldo,
+                              const int* arg, int F, int relu, int bn, const float* mean, const float* rstd, const float* rinv,
+                              const float* z, int64_t ldz, int K_in, float* ws, int nblocks, tsgnn_stream_t stream) {
+  if (!graph_ptr || !slot_count || !v || ((dout == nullptr) != (arg == nullptr)) || !rinv || !z || !ws || nmax <= 0 || nblocks <= 0 ||
+      (bn && (!mean || !rstd)) || ldv < F || (ldv % 4) || (arg && (ldo % 4)) || (dxs && (lddxs % 4)) || K_in <= 0 || ldz < K_in)
+    return TSGNN_EINVAL;
+  if (B > 32 || F != 128 || K_in > 128 || (ldz % 4) || n_ghost != nmax || nblocks > nmax ||
+      ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(ws)) & 15))
+    return TSGNN_EUNSUPPORTED;
+  SlotArgs s{graph_ptr, slot_count, B, nmax, n_real, n_ghost};
+  const int mt = (K_in + 31) / 32;
+  const size_t lds = sizeof(float) * (size_t)(SPW_AUX + 2 * 32 * 128 + 2 * 32 * 32 * mt);
+#define TSGNN_SPW(M_) do { \
+    static bool attr_##M_ = false; \
+    if (!attr_##M_ && lds > 64 * 1024) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(slot_post_wgrad_kernel<M_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_##M_ = true; } \
+    slot_post_wgrad_kernel<M_><<<(unsigned)nblocks, 256, lds, stream>>>(s, v, ldv, dxs, lddxs, dout, ldo, arg, relu, bn, mean, rstd, rinv, z, ldz, K_in, ws); } while (0)
+  TSGNN_KNAME("slot_post_wgrad_kernel<%d>", mt);
+  switch (mt) { case 1: TSGNN_SPW(1); break; case 2: TSGNN_SPW(2); break; case 3: TSGNN_SPW(3); break; default: TSGNN_SPW(4); break; }
+#undef TSGNN_SPW
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }

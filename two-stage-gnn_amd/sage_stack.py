@@ -57,12 +57,20 @@ EPILOGUE_READOUT = os.environ.get("TSGNN_EPILOGUE_READOUT", "1") != "0"   # the 
 LAST_LAYER_ROWS = os.environ.get("TSGNN_LAST_LAYER_ROWS", "1") != "0"     # the last layer's dU from a row-parallel kernel
 FUSED_BN = os.environ.get("TSGNN_FUSED_BN", "1") != "0"                   # slot batch-norm without launches of its own (statistics in the
                                                                           # producing product's epilogue, normalisation in the consumers)
+SLOT_WGRAD = os.environ.get("TSGNN_SLOT_WGRAD", "1") != "0"               # layer 0: dU and its weight gradient in one launch
 HEAD_DU = os.environ.get("TSGNN_HEAD_DU", "1") != "0"                     # ... computed by extra workgroups of the head's backward launch
 
 
 SLABS_BESIDE = os.environ.get("TSGNN_SLABS_BESIDE", "1") != "0"
 NSLAB_MAX = int(os.environ.get("TSGNN_NSLAB_MAX", "0"))
 _ncu = {}
+
+
+def _cu_count(dev):
+    n = _ncu.get(dev)
+    if n is None:
+        n = _ncu[dev] = torch.cuda.get_device_properties(dev).multi_processor_count
+    return n
 
 
 def _slabs_beside_panels(nslab, rps, need, rows, K, N, dev):
@@ -383,6 +391,21 @@ class _SageStack(torch.autograd.Function):
                 # the last layer has no batch-norm: its dU is a row-wise function of the readout gradient (no slot structure)
                 nat.call("readout_l2_bwd_f32", g.graph_ptr, g.row_graph, B, g.n_rows, sg, v, v.stride(0), dsl, dout.stride(0), argl, N, rinv,
                          du, du.stride(0))
+            elif (SLOT_WGRAD and l == 0 and L > 1 and not ctx.nodes and not ctx.needs_input_grad[0] and lean and B <= 32 and N == 128
+                  and K <= 128 and sn == sg and g.n_ghost == g.nmax and ctx.needs_input_grad[5] and z.stride(0) % 4 == 0
+                  and z.data_ptr() % 16 == 0 and v.data_ptr() % 16 == 0 and (not ctx.has_bias or ctx.needs_input_grad[6])):
+                # layer 0's dU has ONE consumer, its own weight / bias gradient: both in one launch, the rows of dU stay in LDS
+                nblk = min(sn, _cu_count(dev))
+                ws0 = torch.empty(nblk * (K + 1) * N, dtype=torch.float32, device=dev)
+                nat.call("slot_post_wgrad_f32", g.graph_ptr, g.slot_count, B, sn, g.n_rows, sg, v, v.stride(0), dxs,
+                         dxs.stride(0) if dxs is not None else 0, dsl, dout.stride(0) if dsl is not None else 0, argl, N, 1, 1, mean, rstd,
+                         rinv, z, z.stride(0), K, ws0, nblk)
+                dw, sw = mp._sink_or_new(ctx.params[0], (K, N), dev)
+                db, sb = mp._sink_or_new(ctx.params[1], (N,), dev) if ctx.has_bias else (None, False)
+                pending.append((ws0, nblk, K, N, dw, db))
+                pend_sunk.append(sw and (sb or not ctx.has_bias)); pend_layers.append(0)
+                grads[0], grads[1] = (None if sw else dw), (None if sb else db)
+                continue
             else:
                 nat.call("slot_post_bwd_f32", g.graph_ptr, g.slot_count, B, sn, g.n_rows, sg, v, v.stride(0), dxs,
                          dxs.stride(0) if dxs is not None else 0, dnode, dnode.stride(0) if dnode is not None else 0, dsl,
