@@ -57,7 +57,11 @@ EPILOGUE_READOUT = os.environ.get("TSGNN_EPILOGUE_READOUT", "1") != "0"   # the 
 LAST_LAYER_ROWS = os.environ.get("TSGNN_LAST_LAYER_ROWS", "1") != "0"     # the last layer's dU from a row-parallel kernel
 FUSED_BN = os.environ.get("TSGNN_FUSED_BN", "1") != "0"                   # slot batch-norm without launches of its own (statistics in the
                                                                           # producing product's epilogue, normalisation in the consumers)
-SLOT_WGRAD = os.environ.get("TSGNN_SLOT_WGRAD", "1") != "0"               # layer 0: dU and its weight gradient in one launch
+# layer 0: dU and its weight-gradient slabs in ONE launch, dU kept in LDS (tsgnn_slot_post_wgrad_f32).  Correct (tests run it) and one
+# launch less, but measured SLOWER than the two launches it replaces (DD b32: 12.7 us at one slot per workgroup + 10.7 us for the
+# reduction of 399 slabs, 15.3 + 5.1 at two slots, against 6.7 + 7.8 + 4.2): a slot is a full latency chain, and the slabs are per
+# workgroup.  Off by default.
+SLOT_WGRAD = os.environ.get("TSGNN_SLOT_WGRAD", "0") != "0"
 HEAD_DU = os.environ.get("TSGNN_HEAD_DU", "1") != "0"                     # ... computed by extra workgroups of the head's backward launch
 
 
@@ -395,7 +399,8 @@ class _SageStack(torch.autograd.Function):
                   and K <= 128 and sn == sg and g.n_ghost == g.nmax and ctx.needs_input_grad[5] and z.stride(0) % 4 == 0
                   and z.data_ptr() % 16 == 0 and v.data_ptr() % 16 == 0 and (not ctx.has_bias or ctx.needs_input_grad[6])):
                 # layer 0's dU has ONE consumer, its own weight / bias gradient: both in one launch, the rows of dU stay in LDS
-                nblk = min(sn, _cu_count(dev))
+                per = int(os.environ.get("TSGNN_SLOT_WGRAD_PER", "2"))      # slots per workgroup (each slot is a full latency chain)
+                nblk = max(1, -(-sn // per))
                 ws0 = torch.empty(nblk * (K + 1) * N, dtype=torch.float32, device=dev)
                 nat.call("slot_post_wgrad_f32", g.graph_ptr, g.slot_count, B, sn, g.n_rows, sg, v, v.stride(0), dxs,
                          dxs.stride(0) if dxs is not None else 0, dsl, dout.stride(0) if dsl is not None else 0, argl, N, 1, 1, mean, rstd,
