@@ -131,6 +131,9 @@ int tsgnn_ingest_arm_expand_rider(int32_t* mirror, int B, int nmax, int64_t row_
                                   int32_t* row_graph, int32_t* row_slot, int32_t* ell, int32_t* tail_ptr, int32_t* ell_slots, int32_t* tail_slots, int F, float* x, int64_t ldx,
                                   int64_t* host_ack);
 int tsgnn_ingest_flush_pull_rider(tsgnn_stream_t stream);
+/* drops the riders this thread armed WITHOUT launching them: a forward that raised between arming and its carrier launches must not
+ * leave passengers behind for an unrelated later launch (ingest.IngestPipeline calls it on its error path) */
+int tsgnn_ingest_disarm_riders(void);
 /* Collate workers: native threads that run the host collate for the batches ahead of the step being enqueued.  submit: the
  * arguments of tsgnn_host_collate_tu (edge_cap = 0) or tsgnn_host_collate_compact (edge_cap > 0) (`ids`, `out` must stay valid
  * until waited for) + after_event (nullable hipEvent_t: the worker synchronises with it before writing `staging`); wait: blocks,

@@ -323,6 +323,14 @@ int tsgnn_ingest_flush_pull_rider(tsgnn_stream_t stream) {
   return TSGNN_OK;
 }
 
+/* drops the riders this thread armed without launching them (a forward that raised between arming and its carrier launches must not
+ * leave passengers behind for an unrelated later launch) */
+int tsgnn_ingest_disarm_riders(void) {
+  (void)take_pull_rider();
+  (void)take_expand_rider();
+  return TSGNN_OK;
+}
+
 /* word offsets (4-byte words) of the segments of an ingest buffer: off[0..8] = graph_ptr[B+2], slot_count[nmax],
  * row_graph[row_cap], row_slot[row_cap], ell[(row_cap+nmax)*ell_w], tail_ptr[row_cap+nmax+1], tail_col[tail_cap],
  * node_label[row_cap], label (int64[B]); off[9] = total words.  Every segment starts on a 16-byte boundary. */

@@ -293,8 +293,12 @@ class IngestPipeline:
                     nxt.arm_pull_rider()                      # the next position's staging buffer rides in the first layer product,
                     if self.ride_expand:
                         nxt.arm_expand_rider()                # its expansion in the head's forward launch
-                    out = model.loss(model(s.x, s.g)[1], s.label)
-                    nat.call("ingest_flush_pull_rider")       # (a model without such a launch: the pull as a launch of its own)
+                    try:
+                        out = model.loss(model(s.x, s.g)[1], s.label)
+                    except BaseException:
+                        nat.call_nostream("ingest_disarm_riders")     # nobody carried them: they must not ride an unrelated launch later
+                        raise
+                    nat.call("ingest_flush_pull_rider")       # (a model without such a launch: the riders as launches of their own)
                     return out
                 return loss
         for p, s in enumerate(self.slots):
