@@ -291,13 +291,19 @@ int tsgnn_gather_rowgemm_st_f32(const int* ell, int ell_w, const int* tail_ptr, 
  * readout partial does the same for the rows it scans, and its blocks of graph 0 write mean_out / rstd_out [nslots] for the
  * backward (tsgnn_slot_post_bwd_f32).  ell / tail_col: entry = slot << 20 | row, nslots <= 1024, rows < 2^20, n_ghost = nslots.
  * row_slot != NULL: this layer is followed by a batch-norm as well, its statistics go to sums_out / ghost_out (zero before);
- * packed_out != NULL: last layer, readout epilogue as in tsgnn_sage_layer_fwd_ro_f32 (not both). */
+ * packed_out != NULL: last layer, readout epilogue as in tsgnn_sage_layer_fwd_ro_f32 (not both).  ro_map (nullable): see
+ * tsgnn_sage_layer_fwd_bn_plan; ignored unless ro_map_ch equals the chunk size the launch uses. */
 int tsgnn_sage_layer_fwd_bn_f32(const int* ell, int ell_w, const int* tail_ptr, const int* tail_col, const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias,
                                 float* v, int64_t ldv, float* rinv, float* zout, int64_t ldz, int64_t rows, int K, int64_t fill_rows,
                                 const int* graph_ptr, const int* slot_count, int B, int nslots, int n_ghost, unsigned long long* packed,
                                 unsigned long long* packed_out, const int* row_graph, const unsigned long long* sums_in,
                                 const float* ghost_in, float* mean_out, float* rstd_out, const int* row_slot,
-                                unsigned long long* sums_out, float* ghost_out, tsgnn_stream_t stream);
+                                unsigned long long* sums_out, float* ghost_out, const int* ro_map, int ro_map_ch, tsgnn_stream_t stream);
+/* HOST function: slots per readout block (64 / 128 / 256) and row-panel blocks (filler included) of that launch — what a caller needs to
+ * build ro_map: a permutation of the B * ceil(nslots / ro_ch) readout work items (graph * chunks + chunk) that puts the blocks scanning
+ * a graph on the XCD whose row panels gather it (workgroups b, b + 8, ... share an XCD; the k-th readout block is workgroup n_gemm + k).
+ * Speed only: any permutation gives the same results. */
+int tsgnn_sage_layer_fwd_bn_plan(int64_t rows, int64_t fill_rows, int B, int nslots, int* ro_ch, int* n_gemm);
 /* Forward of a hidden 128 -> 128 GraphConv layer in ONE launch together with the max-readout partial of its INPUT x (the
  * previous layer's output; both only read x): tsgnn_gather_rowgemm_f32(normalize = 1, fill_rows) + tsgnn_readout_partial_f32
  * over x into packed[B*128] (layout and ghost-row rule as there; n_real = rows). */

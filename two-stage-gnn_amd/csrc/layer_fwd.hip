@@ -35,12 +35,16 @@ __global__ __launch_bounds__(256) void sage_layer_fwd_kernel(RowGemmArgs ga, Slo
 template <bool RO, bool ST>
 __global__ __launch_bounds__(256, 2) void sage_layer_fwd_bn_kernel(RowGemmArgs ga, SlotArgs sa, BnReadArgs bn, unsigned n_gemm, unsigned ro_gx,
                                                                 int ro_ch, int F4, unsigned long long* __restrict__ packed, unsigned n_main,
-                                                                PullRider pr) {
+                                                                PullRider pr, const int* __restrict__ ro_map) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (blockIdx.x < n_gemm) {
     rowgemm_body<4, false, true, 1, RO, true, ST>(ga, smem, blockIdx.x);
   } else if (blockIdx.x < n_main) {
-    const unsigned r = blockIdx.x - n_gemm;
+    // ro_map (nullable): which (graph, chunk) this block scans — chosen on the host so that the block sits on the XCD whose row
+    // panels gather that graph's rows (blocks b, b + 8, ... share an XCD): the rows are in that L2 already instead of being
+    // fetched into another one a second time
+    unsigned r = blockIdx.x - n_gemm;
+    if (ro_map) r = (unsigned)ro_map[r];
     readout_partial_bn_body<32>(sa, bn, ga.a, ga.lda, F4, packed, r % ro_gx, r / ro_gx, ro_ch, reinterpret_cast<unsigned long long*>(smem));
   } else {
     pull_rider_body(pr, blockIdx.x - n_main);
@@ -51,6 +55,18 @@ __global__ __launch_bounds__(256, 2) void sage_layer_fwd_bn_kernel(RowGemmArgs g
 
 extern "C" {
 
+/* slots per readout block and row-panel blocks (filler included) of a tsgnn_sage_layer_fwd_bn_f32 launch: what a caller needs to build ro_map */
+int tsgnn_sage_layer_fwd_bn_plan(int64_t rows, int64_t fill_rows, int B, int nslots, int* ro_ch, int* n_gemm) {
+  if (!ro_ch || !n_gemm || rows <= 0 || B <= 0 || nslots <= 0) return TSGNN_EINVAL;
+  int dev = 0, v = 0;
+  const int ncu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+  const unsigned ng = (unsigned)ceil_div64(rows, 32) + (fill_rows > 0 ? 1u : 0u);
+  int ch = 64;
+  while (ch < 256 && ng + (unsigned)((nslots + ch - 1) / ch) * (unsigned)B > 2u * (unsigned)ncu) ch *= 2;
+  *ro_ch = ch; *n_gemm = (int)ng;
+  return TSGNN_OK;
+}
+
 /* tsgnn_sage_layer_fwd[_ro]_f32 for a layer whose input's slot batch-norm (apply_bn, encoders.py:134-138) has NO launch of its own:
  * x = the previous layer's normalised pre-activations v, sums_in / ghost_in = what its statistics epilogue left
  * (tsgnn_gather_rowgemm_st_f32 or this entry point with row_slot != NULL), slot_count[n] = graphs with more than n nodes.  Every
@@ -58,13 +74,15 @@ extern "C" {
  * readout partial does the same for the rows it scans, and the blocks of graph 0 write mean_out / rstd_out [nslots] for the
  * backward.  ell: entry = slot << 20 | row (GraphBatch.ell_slots(); no CSR tail), nslots <= 1024, rows < 2^20.
  * row_slot != NULL: this layer is followed by a batch-norm as well: its statistics go to sums_out / ghost_out (zero before).
- * packed_out != NULL: last layer, readout epilogue (as tsgnn_sage_layer_fwd_ro_f32). */
+ * packed_out != NULL: last layer, readout epilogue (as tsgnn_sage_layer_fwd_ro_f32).
+ * ro_map (nullable, B * ceil(nslots / ro_map_ch) ints, a permutation): readout block r scans work item ro_map[r] = graph * chunks + chunk;
+ * tsgnn_sage_layer_fwd_bn_plan tells the chunk size the launch will use. */
 int tsgnn_sage_layer_fwd_bn_f32(const int* ell, int ell_w, const int* tail_ptr, const int* tail_col, const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias,
                                 float* v, int64_t ldv, float* rinv, float* zout, int64_t ldz, int64_t rows, int K, int64_t fill_rows,
                                 const int* graph_ptr, const int* slot_count, int B, int nslots, int n_ghost, unsigned long long* packed,
                                 unsigned long long* packed_out, const int* row_graph, const unsigned long long* sums_in,
                                 const float* ghost_in, float* mean_out, float* rstd_out, const int* row_slot,
-                                unsigned long long* sums_out, float* ghost_out, tsgnn_stream_t stream) {
+                                unsigned long long* sums_out, float* ghost_out, const int* ro_map, int ro_map_ch, tsgnn_stream_t stream) {
   if (!ell || !x || !w || !v || !rinv || !graph_ptr || !slot_count || !packed || !sums_in || !ghost_in || !mean_out || !rstd_out ||
       rows <= 0 || fill_rows < 0 || K <= 0 || B <= 0 || nslots <= 0 || (n_ghost != 0 && n_ghost != nslots) || (packed_out && !row_graph) ||
       (row_slot && (!sums_out || !ghost_out)))
@@ -95,6 +113,7 @@ int tsgnn_sage_layer_fwd_bn_f32(const int* ell, int ell_w, const int* tail_ptr, 
   int ro_ch = 64;
   while (ro_ch < 256 && n_gemm + (unsigned)((nslots + ro_ch - 1) / ro_ch) * (unsigned)B > 2u * (unsigned)ncu) ro_ch *= 2;
   const unsigned ro_gx = (unsigned)((nslots + ro_ch - 1) / ro_ch);
+  if (ro_map && ro_map_ch != ro_ch) ro_map = nullptr;      // (the map was built for another chunk size: plain order)
   size_t lds = rowgemm_lds_bytes<4, false, true, 1, true>();
   const size_t lro = 8 * 128 * sizeof(unsigned long long) + 256 * sizeof(float2);
   if (lds < lro) lds = lro;
@@ -102,13 +121,13 @@ int tsgnn_sage_layer_fwd_bn_f32(const int* ell, int ell_w, const int* tail_ptr, 
   const PullRider pr = take_pull_rider();
   if (packed_out) {
     TSGNN_KNAME("sage_layer_fwd_bn_kernel<true,false>");
-    sage_layer_fwd_bn_kernel<true, false><<<n_main + pr.blocks, 256, lds, stream>>>(ga, sa, bn, n_gemm, ro_gx, ro_ch, K / 4, packed, n_main, pr);
+    sage_layer_fwd_bn_kernel<true, false><<<n_main + pr.blocks, 256, lds, stream>>>(ga, sa, bn, n_gemm, ro_gx, ro_ch, K / 4, packed, n_main, pr, ro_map);
   } else if (row_slot) {
     TSGNN_KNAME("sage_layer_fwd_bn_kernel<false,true>");
-    sage_layer_fwd_bn_kernel<false, true><<<n_main + pr.blocks, 256, lds, stream>>>(ga, sa, bn, n_gemm, ro_gx, ro_ch, K / 4, packed, n_main, pr);
+    sage_layer_fwd_bn_kernel<false, true><<<n_main + pr.blocks, 256, lds, stream>>>(ga, sa, bn, n_gemm, ro_gx, ro_ch, K / 4, packed, n_main, pr, ro_map);
   } else {
     TSGNN_KNAME("sage_layer_fwd_bn_kernel<false,false>");
-    sage_layer_fwd_bn_kernel<false, false><<<n_main + pr.blocks, 256, lds, stream>>>(ga, sa, bn, n_gemm, ro_gx, ro_ch, K / 4, packed, n_main, pr);
+    sage_layer_fwd_bn_kernel<false, false><<<n_main + pr.blocks, 256, lds, stream>>>(ga, sa, bn, n_gemm, ro_gx, ro_ch, K / 4, packed, n_main, pr, ro_map);
   }
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;

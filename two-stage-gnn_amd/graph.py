@@ -266,6 +266,49 @@ class GraphBatch:
                 self._ell_slots = (table, tcol)
         return self._ell_slots if self._ell_slots is not False else None
 
+    def readout_map(self, nslots, fill_rows):
+        """(ro_map int32[B * chunks], chunk size) for tsgnn_sage_layer_fwd_bn_f32, or (None, 0): readout block k of that launch is
+        workgroup n_gemm + k and therefore sits on XCD (n_gemm + k) % 8; the row panels of XCD x are a contiguous range of the batch's
+        rows (xcd_remap, csrc/common.h), i.e. whole graphs — so the blocks that scan graph b are given slots on the XCD whose L2 already
+        holds b's rows.  Host side, once per batch structure; batches whose structure lives on the device only (ingest slots) get the
+        plain order."""
+        if self.sizes is None:
+            return None, 0
+        key = (int(nslots), int(fill_rows))
+        cache = self.__dict__.setdefault("_ro_maps", {})
+        if key not in cache:
+            ch = np.zeros(1, dtype=np.int32)
+            ng = np.zeros(1, dtype=np.int32)
+            nat.call_nostream("sage_layer_fwd_bn_plan", int(self.n_rows), int(fill_rows), int(self.B), int(nslots), ch.ctypes.data, ng.ctypes.data)
+            ch, ng = int(ch[0]), int(ng[0])
+            chunks = -(-int(nslots) // ch)
+            npan = -(-self.n_rows // 32)
+            q, r = divmod(npan, 8)
+            start = np.zeros(9, dtype=np.int64)
+            for x in range(8):
+                start[x + 1] = start[x] + (q + 1 if x < r else q)
+            gp = np.concatenate([[0], np.cumsum(np.asarray(self.sizes, dtype=np.int64))])
+            mid_panel = ((gp[:-1] + gp[1:]) // 2) // 32
+            xcd_of_graph = np.clip(np.searchsorted(start, mid_panel, side="right") - 1, 0, 7)
+            want = [[] for _ in range(8)]                       # work items per XCD
+            for b in range(self.B):
+                for c in range(chunks):
+                    want[int(xcd_of_graph[b])].append(b * chunks + c)
+            items = self.B * chunks
+            slots = [[k for k in range(items) if (ng + k) % 8 == x] for x in range(8)]
+            ro = np.full(items, -1, dtype=np.int32)
+            left = []
+            for x in range(8):
+                n = min(len(want[x]), len(slots[x]))
+                ro[slots[x][:n]] = want[x][:n]
+                left += want[x][n:]
+                slots[x] = slots[x][n:]
+            free = [k for x in range(8) for k in slots[x]]
+            ro[free] = left
+            assert (np.sort(ro) == np.arange(items)).all()
+            cache[key] = (torch.from_numpy(ro).to(self.device), ch)
+        return cache[key]
+
     def bn_workspace(self, B, L, Fh, Fl, nslots):
         """persistent device buffers of the fused slot batch-norms of a stack on this batch (sage_stack.py): the integer sums
         [L-1][2 * nslots] and the ghost rows' numbers [L-1][2] — zero between steps, the step's own head launch clears them —, and

@@ -55,6 +55,7 @@ GATHER_MAX_ROWS = int(os.environ.get("TSGNN_GATHER_MAX_ROWS", 65536))   # above:
 GATHER_FUSED = os.environ.get("TSGNN_GATHER_FUSED", "1") != "0"     # aggregate inside the `.W` product when the neighbour table has no CSR tail
 EPILOGUE_READOUT = os.environ.get("TSGNN_EPILOGUE_READOUT", "1") != "0"   # the last layer's max readout in its product's epilogue
 LAST_LAYER_ROWS = os.environ.get("TSGNN_LAST_LAYER_ROWS", "1") != "0"     # the last layer's dU from a row-parallel kernel
+RO_MAP = os.environ.get("TSGNN_RO_MAP", "1") != "0"                       # readout blocks placed on the XCD that holds their graph's rows
 FUSED_BN = os.environ.get("TSGNN_FUSED_BN", "1") != "0"                   # slot batch-norm without launches of its own (statistics in the
                                                                           # producing product's epilogue, normalisation in the consumers)
 # layer 0: dU and its weight-gradient slabs in ONE launch, dU kept in LDS (tsgnn_slot_post_wgrad_f32).  Correct (tests run it) and one
@@ -175,6 +176,7 @@ class _SageStack(torch.autograd.Function):
             tp, tc = tail if tail is not None else (None, None)
             ell_s, tc_s = ell_s
             sums, ghost = bnf["sums"], bnf["ghost"]
+            ro_map, ro_ch = g.readout_map(sn, gs) if RO_MAP else (None, 0)
             for l in range(L):
                 K, N = Ws[l].size(0), Ws[l].size(1)
                 v = torch.empty(R, N, dtype=torch.float32, device=dev)
@@ -194,7 +196,7 @@ class _SageStack(torch.autograd.Function):
                              packed[(l - 1) * B * Fh:(l - 1) * B * Fh + B * Fh],
                              packed[l * B * Fh:l * B * Fh + (B + 1) * N] if last else None, g.row_graph,
                              sums[(l - 1) * 2 * sn:l * 2 * sn], ghost[2 * (l - 1):2 * l], pm, pr_,
-                             None if last else g.row_slot, s_out, g_out)
+                             None if last else g.row_slot, s_out, g_out, ro_map, ro_ch)
                 if l < L - 1:
                     mean = torch.empty(g.nmax, dtype=torch.float32, device=dev)     # written by the NEXT launch's readout blocks
                     rstd = torch.empty(g.nmax, dtype=torch.float32, device=dev)
