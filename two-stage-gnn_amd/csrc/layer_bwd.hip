@@ -24,7 +24,12 @@ __global__ __launch_bounds__(256) void sage_layer_bwd_kernel(RowGemmArgs ga, TnA
       // the slab blocks finish well before the row panels (whose gather prologue is two dependent round trips): let the panels'
       // requests go first instead of competing with the slabs' 64 KB per block for the same first microseconds
       for (int i = 0; i < slab_delay; ++i) __builtin_amdgcn_s_sleep(16);
-      const unsigned b = blockIdx.x - n_pan; tn_rows_body<4, 4, 2>(gt, smem, b % nslab, b / nslab, nslab);
+      // XCD-aware slab order: workgroups b, b + 8, ... share an XCD, and the row panels of XCD x gather a contiguous eighth of the
+      // rows (xcd_remap) — a slab block is given the slab whose rows (dU, read by both roles) that XCD's L2 holds already
+      const unsigned b = blockIdx.x - n_pan, by = b / nslab, sp = b % nslab;
+      unsigned sl = sp;
+      if ((nslab & 7u) == 0) sl = ((blockIdx.x & 7u) * (nslab >> 3)) + (sp >> 3);
+      tn_rows_body<4, 4, 2>(gt, smem, sl, by, nslab);
     }
   } else {
     if (blockIdx.x < n_tn) tn_rows_body<4, 4, 2>(gt, smem, blockIdx.x % nslab, blockIdx.x / nslab, nslab);
