@@ -361,3 +361,31 @@ def test_barrier_timeout_poisons_the_optimiser_and_raises():
     assert float(err) == 0.0 and int(words.abs().sum()) == 0 and float(tr.state[3]) == 0.0      # cleared, barrier words re-armed
     one(); tr.check()                                                    # and the next step is applied again
     assert not torch.equal(tr.flat_param, before) and float(tr.state[0]) == 2.0
+
+
+# ------------------------------------------------------------------------------------------------ bitwise repeatability
+@pytest.mark.parametrize("seed", [0, 6])
+def test_timed_step_is_bitwise_repeatable(seed):
+    """The benched step run five times from the same state gives the same bits (loss, every gradient, every parameter): the slot
+    batch-norm statistics are accumulated with 64-bit INTEGER atomics (order-independent), the max readout with packed atomicMax,
+    the weight gradients as slabs summed in fixed order — no float atomics anywhere on the path."""
+    from two_stage_gnn_amd import dense_encoders as E, synthetic
+    from two_stage_gnn_amd.data_parallel import FlatTrainer, GraphedStep
+    dev = torch.device("cuda")
+    hb = synthetic.host_batch(seed=seed, B=32, shape="DD", nmax=1000)
+    g, x, label = synthetic.to_device(hb, dev)
+    torch.manual_seed(1234)
+    model = E.GcnEncoderGraph(89, 128, 128, 2, 3, bn=True, args=_A(), final_dim="number_classes").to(dev)
+    tr = FlatTrainer(model, lr=1e-3, clip=2.0, defer_loss=True)
+    gs = GraphedStep(tr, lambda: model.loss(model(x, g)[1], label), warmup=3)
+    snap = [t.clone() for t in (tr.flat_param, tr.exp_avg, tr.exp_avg_sq, tr.state)]
+    runs = []
+    for _ in range(5):
+        for t, s_ in zip((tr.flat_param, tr.exp_avg, tr.exp_avg_sq, tr.state), snap):
+            t.copy_(s_)
+        gs.step(); gs.step()                                        # two steps: the second starts from accumulators the first one cleared
+        loss = gs.loss_value()
+        runs.append((loss, tr.flat_grad.clone(), tr.flat_param.clone()))
+    for loss, grad, param in runs[1:]:
+        assert loss == runs[0][0]
+        assert torch.equal(grad, runs[0][1]) and torch.equal(param, runs[0][2])
