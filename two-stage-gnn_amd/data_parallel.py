@@ -437,7 +437,7 @@ class GraphedStep:
     def loss_value(self):
         """the last step's loss as a float (synchronises; checked)"""
         self.synchronize()
-        return float(self.loss)
+        return float(self.loss.detach())
 
     def step(self):
         """enqueue one step on self.stream (returns immediately; self.loss is the device scalar of the last step; read it through
