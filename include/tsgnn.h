@@ -275,7 +275,7 @@ int tsgnn_rowgemm_f32(const float* a, int64_t lda, const float* b, int64_t ldb, 
 int tsgnn_gather_rowgemm_f32(const int* ell, int ell_w, const int* tail_ptr, const int* tail_col, const float* x, int64_t ldx, const float* b, int64_t ldb, int trans_b,
                              const float* bias, float* c, int64_t ldc, float* rinv, float* zout, int64_t ldz, int64_t rows, int K,
                              int N, int normalize, int64_t fill_rows, tsgnn_stream_t stream);
-/* tsgnn_gather_rowgemm_f32 (trans_b = 0, normalize = 1, 96 < N <= 128, 64 < K <= 128) for a layer that is followed by the slot
+/* tsgnn_gather_rowgemm_f32 (trans_b = 0, normalize = 1, 96 < N <= 128, K <= 128) for a layer that is followed by the slot
  * batch-norm (apply_bn, encoders.py:134-138) WITHOUT a launch for it (tail_ptr / tail_col as there): the epilogue adds every real row's
  * (sum_f relu(v), sum_f relu(v)^2) to sums[2 * row_slot[r]] as 64-bit fixed-point integers (2^-40 units: integer addition is
  * associative, so the totals do not depend on the order the panels finish in — bitwise reproducible) and the filler block leaves

@@ -268,7 +268,7 @@ int tsgnn_gather_rowgemm_st_f32(const int* ell, int ell_w, const int* tail_ptr, 
   if (!ell || !x || !b || !c || !row_slot || !sums || !ghost || rows <= 0 || fill_rows < 0 || K <= 0 || N <= 0 || ldx < K || ldc < N)
     return TSGNN_EINVAL;
   if (ell_w != 4 && ell_w != 8 && ell_w != 16) return TSGNN_EUNSUPPORTED;
-  if (!tsgnn_rowgemm_supported(x, ldx, b, ldb, c, ldc, K, N, 0) || N > 128 || N <= 96 || K > 128 || K <= 2 * KC || (reinterpret_cast<uintptr_t>(ell) & 15) ||
+  if (!tsgnn_rowgemm_supported(x, ldx, b, ldb, c, ldc, K, N, 0) || N > 128 || N <= 96 || K > 128 || (reinterpret_cast<uintptr_t>(ell) & 15) ||
       (reinterpret_cast<uintptr_t>(sums) & 15))
     return TSGNN_EUNSUPPORTED;
   if (zout && ((ldz % 4) || ldz < K || (reinterpret_cast<uintptr_t>(zout) & 15))) return TSGNN_EUNSUPPORTED;

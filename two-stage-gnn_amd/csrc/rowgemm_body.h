@@ -502,7 +502,8 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem_a
       // row sums travel through the (idle) first LDS stage, and ONE pair of 64-bit integer atomics per row follows.
       float* red = scratch;                            // [32 rows][4 waves]
       float* inv = red + 128 + wid * 32;               // per wave [32 rows]
-      float* redq = smem_all;                          // [2][32 rows][4 waves]: the K loop's stages are idle (K > 2 KC: synchronised)
+      float* redq = smem_all;                          // [2][32 rows][4 waves]: the K loop's stages are idle once every wave has left it
+      if constexpr (STATS) { if (Kc <= 2 * KC) __syncthreads(); }      // (the loop only synchronises beyond two chunks)
       float tot = row16_sum_transpose(ss);
       tot += __shfl_xor(tot, 16, 64);
       float t1 = 0.f, t2 = 0.f;

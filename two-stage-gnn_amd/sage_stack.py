@@ -158,7 +158,7 @@ class _SageStack(torch.autograd.Function):
         last_ro_done = False
         bnf = None
         if (FUSED_BN and head is not None and not nodes and L >= 2 and g.n_ghost == g.nmax and sn == sg and sn <= 1024
-                and Fh == 128 and Fl == 128 and 64 < Ws[0].size(0) <= 128 and x.size(1) % 4 == 0 and MERGED_FWD and EPILOGUE_READOUT
+                and Fh == 128 and Fl == 128 and Ws[0].size(0) <= 128 and x.size(1) % 4 == 0 and MERGED_FWD and EPILOGUE_READOUT
                 and _gather_ok(g, x) and all(Ws[l].size(0) == 128 and Ws[l].stride(0) % 4 == 0 for l in range(1, L))
                 and all(Ws[l].data_ptr() % 16 == 0 and (bs[l] is None or bs[l].data_ptr() % 16 == 0) for l in range(L))
                 and mp.rowgemm_ok(x, x.stride(0), Ws[0], Ws[0].stride(0), Ws[0].size(0), Fh, False)
