@@ -237,6 +237,13 @@ int tsgnn_wgrad_blocks_oi_f32(const float* z, int64_t ldz, const float* du, int6
  * [slab_row_ptr[t], slab_row_ptr[t+1]).  ws >= nslab*(K+1)*N floats.  ceil(K/32)*ceil(N/32) <= 16. */
 int tsgnn_ragged_tn_f32(const float* s_mat, int64_t lds_, const float* x, int64_t ldx, int K, int N, const int* slab_row_ptr,
                         int nslab, const int* seg_slab_ptr, int nseg, float* ws, float* out, tsgnn_stream_t stream);
+/* The same products for SHORT segments and K <= 128, without slabs and for two X operands at once (DiffPool's first contraction:
+ * S^T Z and S^T (A S), encoders.py:374-375): out0[b] = S[rows_b]^T X0[rows_b] ([B, K, N0]) and, when x1 is given,
+ * out1[b] = S[rows_b]^T X1[rows_b] ([B, K, N1]) in ONE launch — workgroup (32 x 32 output tile, segment) walks the whole segment, its eight
+ * waves split the rows and add their accumulators in wave order (csrc/ragged.hip).  rows_b = [graph_ptr[b], graph_ptr[b+1]). */
+int tsgnn_ragged_tn_direct_supported(int K, int64_t max_rows);
+int tsgnn_ragged_tn_direct_f32(const float* s_mat, int64_t lds_, int K, const int* graph_ptr, int B, const float* x0, int64_t ldx0,
+                               int N0, float* out0, const float* x1, int64_t ldx1, int N1, float* out1, tsgnn_stream_t stream);
 /* Weight + bias gradient of a layer with a narrow input (K_in <= 4, e.g. the one-column constant feature of IMDB-B,
  * network.py:34 with num_features = 1): dwb[(K_in + 1), N], rows 0..K_in-1 = z[:, :K_in]^T du, row K_in = column sums of du,
  * from one pass over du.  ws: *ws_floats of tsgnn_wgrad_narrow_plan(rows, K_in, N, &ws_floats). */
@@ -352,7 +359,10 @@ int tsgnn_row_ln_bwd_f32(const float* v, int64_t ldv, const float* dy, int64_t l
                          const float* rstd, float* dv, int64_t lddv, tsgnn_stream_t stream);
 
 /* out[b,f] = max over the nmax node slots of graph b (ghost rows included, trap T5), arg = winning row.
- * Replaces torch.max(x, dim=1) (encoders.py:183,190,197,353,383). packed_ws: B*F uint64 scratch. */
+ * Replaces torch.max(x, dim=1) (encoders.py:183,190,197,353,383).  ONE launch.  packed_ws: tsgnn_readout_max_ws_words(B, nmax, F)
+ * uint64 words (B * F packed maxima, then the graphs' arrival counters), ALL zero on entry and all zero again on return: a workspace
+ * zeroed once serves every later call issued on the same stream. */
+int tsgnn_readout_max_ws_words(int B, int nmax, int F);   /* <= 0: the shape is out of range */
 int tsgnn_readout_max_fwd_f32(const int* graph_ptr, const int* slot_count, int B, int nmax, int64_t n_real, int n_ghost,
                               const float* x, int64_t ldx, int F, int relu, unsigned long long* packed_ws, float* out,
                               int64_t ldo, int* arg, tsgnn_stream_t stream);
@@ -844,6 +854,10 @@ int tsgnn_wgrad_reduce_sets_f32(const int64_t* desc, tsgnn_stream_t stream);
 int tsgnn_sage_multi_tn_words(void);
 int tsgnn_sage_multi_g_words(void);
 int tsgnn_sage_multi_f32(const int64_t* desc, tsgnn_stream_t stream);
+/* the same launch; zero0[0..n0) / zero1[0..n1) (nullable) are cleared by the filler block of product 0 / 1 AFTER it has written its
+ * fill rows: the embedding mask of a stack that returns node features (ghost rows of the concatenation := 0, encoders.py:150-151,
+ * 355-356) without a launch of its own.  Needs fill_rows > 0, n % 4 == 0, 16-byte aligned regions; TSGNN_EUNSUPPORTED otherwise. */
+int tsgnn_sage_multi_zero_f32(const int64_t* desc, float* zero0, int64_t n0, float* zero1, int64_t n1, tsgnn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -54,8 +54,8 @@ def main():
     res["bn_slots fwd (stats+apply)"] = burst_us(lambda: nat.call("bn_slots_fwd_f32", g.graph_ptr, g.slot_count, g.row_slot, g.B, g.nmax, g.n_rows, g.n_ghost, X, H, H, 1, 1, mean, rstd, Y, H))
     m1 = torch.empty(g.nmax, device="cuda"); m2 = torch.empty(g.nmax, device="cuda")
     res["bn_slots bwd (stats+apply)"] = burst_us(lambda: nat.call("bn_slots_bwd_f32", g.graph_ptr, g.slot_count, g.row_slot, g.B, g.nmax, g.n_rows, g.n_ghost, X, H, Y, H, H, 1, 1, mean, rstd, m1, m2, dz, H))
-    out = torch.empty(g.B, H, device="cuda"); arg = torch.empty(g.B, H, dtype=torch.int32, device="cuda"); ws = torch.empty(g.B * H, dtype=torch.int64, device="cuda")
-    res["readout fwd (memset+partial+decode)"] = burst_us(lambda: nat.call("readout_max_fwd_f32", g.graph_ptr, g.slot_count, g.B, g.nmax, g.n_rows, g.n_ghost, X, H, H, 0, ws, out, H, arg))
+    out = torch.empty(g.B, H, device="cuda"); arg = torch.empty(g.B, H, dtype=torch.int32, device="cuda"); ws = mp._readout_ws(g, H, torch.device("cuda"))
+    res["readout fwd (one launch)"] = burst_us(lambda: nat.call("readout_max_fwd_f32", g.graph_ptr, g.slot_count, g.B, g.nmax, g.n_rows, g.n_ghost, X, H, H, 0, ws, out, H, arg))
     res["l2norm_bwd"] = burst_us(lambda: nat.call("l2norm_bwd_f32", X, H, Y, H, rinv, dz, H, R, H))
     res["torch.mm 9151x128x128 (rocBLAS ref)"] = burst_us(lambda: torch.mm(X, W, out=Y))
     res["torch.mm X^T.Y (rocBLAS ref)"] = burst_us(lambda: torch.mm(X.t(), Y))

@@ -950,3 +950,113 @@ def test_epilogue_readout_equals_row_scan(B, nmax, nbar, monkeypatch):
     torch.testing.assert_close(res[0][1], res[1][1], rtol=0, atol=0)
     for ga, gb in zip(res[0][2], res[1][2]):
         torch.testing.assert_close(ga, gb, rtol=0, atol=0)
+
+
+# ------------------------------------------------------------------------------------------------ DiffPool glue (round 3)
+@pytest.mark.parametrize("K,N0,N1,ld_pad", [(64, 192, 64, 0), (64, 192, 0, 0), (24, 50, 24, 4), (33, 7, 33, 1)])
+def test_ragged_tn_direct_vs_fp64(K, N0, N1, ld_pad):
+    """out[b] = S[rows_b]^T X[rows_b] for two operands in one launch (csrc/ragged.hip; encoders.py:374-375) against fp64 per graph:
+    empty, one-row, odd and > 512-row graphs, partial tiles, padded leading dimensions"""
+    from two_stage_gnn_amd import _native as nat
+    sizes = [0, 1, 7, 64, 129, 513, 2, 300, 0, 1025]
+    gp = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32, device="cuda")
+    R = int(sum(sizes))
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    S = torch.randn(R + 3, K + ld_pad, generator=gen, device="cuda")[:, :K]
+    X0 = torch.randn(R + 3, N0 + ld_pad, generator=gen, device="cuda")[:, :N0]
+    X1 = torch.randn(R + 3, N1 + ld_pad, generator=gen, device="cuda")[:, :N1] if N1 else None
+    B = len(sizes)
+    assert nat.lib().tsgnn_ragged_tn_direct_supported(K, max(sizes))
+    o0 = torch.full((B, K, N0), float("nan"), device="cuda")
+    o1 = torch.full((B, K, N1), float("nan"), device="cuda") if N1 else None
+    nat.call("ragged_tn_direct_f32", S, S.stride(0), K, gp, B, X0, X0.stride(0), N0, o0, X1, X1.stride(0) if N1 else 0, N1, o1)
+    o0b = torch.empty_like(o0)
+    nat.call("ragged_tn_direct_f32", S, S.stride(0), K, gp, B, X0, X0.stride(0), N0, o0b, None, 0, 0, None)
+    assert torch.equal(o0, o0b)                                 # alone or beside the second operand: the same bits
+    off = 0
+    for b, n in enumerate(sizes):
+        s64 = S[off:off + n].double()
+        for o, X in ((o0, X0), (o1, X1)):
+            if X is None:
+                continue
+            ref = s64.t() @ X[off:off + n].double()
+            err = (o[b].double() - ref).abs().max().item()
+            assert err <= 2e-6 * max(1.0, n ** 0.5) * max(1.0, ref.abs().max().item()), (b, n, err)
+        off += n
+
+
+@pytest.mark.parametrize("nmax,F", [(65, 4), (200, 192), (1000, 256), (512, 70)])
+def test_readout_max_one_launch_repeated_calls(nmax, F):
+    """the max readout over more than 64 slots is ONE launch whose last-arriving workgroup per graph decodes (bn_readout.hip); its
+    ticket counters must be back at zero after every call: repeated calls on one workspace, against torch.max over the padded rows"""
+    from two_stage_gnn_amd import message_passing as mp, _native as nat
+    from two_stage_gnn_amd.graph import GraphBatch
+    B = 9
+    x, adj, sizes = dense_batch(17, B, nmax, 3, sizes=[min(n, nmax) for n in (nmax, 1, 64, 65, nmax // 2, 7, nmax - 1, 130, 2)], p_edge=0.02)
+    g = GraphBatch.from_dense(adj.cuda(), sizes)
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    names = []
+    for it in range(3):
+        feat = torch.randn(g.total_rows, F, generator=gen, device="cuda") - 0.5 * it
+        nat.trace = []
+        try:
+            out, arg = mp.readout_max(feat, g, return_arg=True)
+            names = [t[2] for t in nat.trace]
+        finally:
+            nat.trace = None
+        ref = torch.stack([feat[g.graph_ptr[b]:g.graph_ptr[b + 1]].max(0).values for b in range(B)])
+        if g.n_ghost:                                                     # padded slots take part (trap T5): the ghost rows' values
+            ghost = feat[g.n_rows:g.n_rows + g.n_ghost]
+            for b in range(B):
+                if sizes[b] < nmax:
+                    ref[b] = torch.maximum(ref[b], ghost[int(sizes[b]):].max(0).values)
+        assert torch.equal(out, ref), it
+        assert torch.equal(feat[arg.long(), torch.arange(F, device="cuda").expand(B, F)], out), it
+    assert len(names) == 1, names
+    ws = list(g._readout_ws.values())[0]
+    words = ws.numel() - (B + 1) // 2
+    assert int(ws[words:].abs().sum()) == 0                               # the counters are back at zero
+
+
+def test_diffpool_glue_variants_agree(monkeypatch):
+    """round-3 launch removals of the DiffPool step — the levels' readouts written into one buffer (no torch.cat), the embedding
+    mask's clearing inside the last paired product launch, both first-contraction products as one launch — against the
+    launch-by-launch forms: outputs, loss, every parameter gradient; and the launches really are gone"""
+    from two_stage_gnn_amd import dense_encoders as E, sage_stack, diffpool as dp, synthetic, message_passing as mp, _native as nat
+
+    class A:
+        bias = True
+    torch.manual_seed(3)
+    hb = synthetic.host_batch(5, 8, "DD", 512)          # 512 * 0.125 = 64 assignment columns: both stacks' last layers share a launch
+    g, x, lab = synthetic.to_device(hb, torch.device("cuda"))
+    m = E.SoftPoolingGcnEncoder(512, 89, 64, 64, 2, 3, 64, assign_ratio=0.125, num_pooling=2, bn=True, linkpred=False, args=A(),
+                                assign_input_dim=89, final_dim="number_classes").cuda()
+    res = []
+    for on in (False, True, False):                     # (the first pass also builds the batch's lazily built structures)
+        monkeypatch.setattr(E, "READOUT_COLUMNS", on)
+        monkeypatch.setattr(sage_stack, "ZERO_RIDER", on)
+        monkeypatch.setattr(dp, "RAGGED_DIRECT", on)
+        m.zero_grad(set_to_none=True)
+        nat.trace = []
+        try:
+            a, b = m(x, g, hb["sizes"], assign_x=x)
+            loss = m.loss(b, lab)
+            loss.backward()
+            names = [t[0] for t in nat.trace]
+        finally:
+            nat.trace = None
+        res.append((a.detach().clone(), b.detach().clone(), loss.detach().clone(),
+                    {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}, names))
+    mp.check_device_errors()
+    (a1, b1, l1, g1, n1), (a0, b0, l0, g0, n0) = res[1:]
+    assert "sage_multi_zero_f32" in n1 and "sage_multi_zero_f32" not in n0
+    assert "ragged_tn_direct_f32" in n1 and n1.count("ragged_tn_f32") == 0 and n0.count("ragged_tn_f32") == 2
+    assert len(n1) <= len(n0) - 1
+    torch.testing.assert_close(a1, a0, rtol=2e-5, atol=2e-6)
+    torch.testing.assert_close(b1, b0, rtol=2e-5, atol=2e-6)
+    assert set(g1) == set(g0)
+    gmax = max(v.abs().max().item() for v in g0.values())
+    for k in g0:
+        # (another summation order in the contraction; the biases in front of a batch-norm have gradients that are rounding noise)
+        err = (g1[k] - g0[k]).abs().max().item()
+        assert err <= 1e-3 * g0[k].abs().max().item() + 5e-4 * gmax, (k, err, gmax)

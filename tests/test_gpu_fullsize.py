@@ -45,7 +45,7 @@ class _OracleLoop:
         loss.backward()
         norm = torch.nn.utils.clip_grad_norm_([v for v in self.p.values() if v.grad is not None], self.clip)
         self.opt.step()
-        return float(loss), logits.detach().double(), float(norm)
+        return float(loss.detach()), logits.detach().double(), float(norm)
 
 
 def _run(model, loss_fn, forward32, forward64, lr, clip=2.0, steps=3, defer_loss=False, logit_scale=1.0, handful=8, tag="", pre_step=None):

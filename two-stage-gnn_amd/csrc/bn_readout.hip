@@ -193,11 +193,19 @@ __global__ __launch_bounds__(256) void row_ln_bwd(const float* __restrict__ v, i
 }
 
 // ---------------------------------------------------------------- max readout over node slots
-// grid (chunks of 64 slots, B); block = 4 waves x 16 slots, lanes over features
-__global__ __launch_bounds__(256) void readout_max_partial(SlotArgs s, const float* __restrict__ x, int64_t ld, int F,
-                                                           int relu, unsigned long long* __restrict__ packed) {
+// grid (chunks of 64 slots, B); block = 4 waves x 16 slots, lanes over features.  ONE launch: every block folds the packed
+// (value, row) maxima of its chunk into packed[b, :] with device-scope atomicMax (performed at the memory side: coherent across
+// the XCDs' L2s without any cache write-back — an agent-scope fence here cost 10 us: it writes back whatever the previous launches
+// left dirty in the L2), waits for the atomics' RETURN values, and takes a ticket of its graph; the block that draws the last ticket
+// reads the graph's maxima back with atomic loads, decodes them into (out, arg) and leaves packed[b, :] and the ticket counter at
+// zero for the next call.  max is order-free, so the result does not depend on which block comes last.
+__global__ __launch_bounds__(256) void readout_max_chunks(SlotArgs s, const float* __restrict__ x, int64_t ld, int F, int relu,
+                                                          unsigned long long* part, unsigned* count, float* __restrict__ out,
+                                                          int64_t ldo, int* __restrict__ arg) {
   extern __shared__ unsigned long long best_lds[];          // [4][FP]
+  __shared__ unsigned ticket;
   const int b = blockIdx.y;
+  const int nch = gridDim.x;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int g0 = s.graph_ptr[b];
   const int sz = s.graph_ptr[b + 1] - g0;
@@ -230,11 +238,24 @@ __global__ __launch_bounds__(256) void readout_max_partial(SlotArgs s, const flo
     best_lds[wid * FP + fb + lane] = best;
   }
   __syncthreads();
+  unsigned long long* mine = part + (int64_t)b * F;
+  unsigned long long seen = 0ull;
   for (int f = threadIdx.x; f < F; f += 256) {
     unsigned long long m = best_lds[f];
 #pragma unroll
     for (int w = 1; w < 4; ++w) { const unsigned long long o = best_lds[w * FP + f]; m = o > m ? o : m; }
-    if (m) atomicMax(&packed[(int64_t)b * F + f], m);
+    if (m) seen |= atomicMax(&mine[f], m);                  // the RETURNING form: once the value is here the atomic has been performed
+  }
+  asm volatile("" ::"v"((unsigned)(seen >> 32)), "v"((unsigned)seen));   // every return value is in its register before the barrier
+  __syncthreads();
+  if (threadIdx.x == 0) ticket = atomicAdd(&count[b], 1u);
+  __syncthreads();
+  if (ticket != (unsigned)(nch - 1)) return;
+  if (threadIdx.x == 0) atomicExch(&count[b], 0u);          // nobody else touches it any more in this launch
+  for (int f = threadIdx.x; f < F; f += 256) {
+    const unsigned long long m = __hip_atomic_exchange(&mine[f], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    out[(int64_t)b * ldo + f] = m ? ordered_f32((unsigned)(m >> 32)) : 0.f;
+    arg[(int64_t)b * F + f] = m ? (int)(0xFFFFFFFFu - (unsigned)(m & 0xFFFFFFFFull)) : -1;
   }
 }
 // nmax <= 64 (the pooled DiffPool levels: 64- and 8-node graphs): one chunk per graph, so neither the zeroed packed buffer,
@@ -268,15 +289,6 @@ __global__ __launch_bounds__(256) void readout_max_direct(SlotArgs s, const floa
     out[(int64_t)b * ldo + f] = best ? ordered_f32((unsigned)(best >> 32)) : 0.f;
     arg[(int64_t)b * F + f] = best ? (int)(0xFFFFFFFFu - (unsigned)(best & 0xFFFFFFFFull)) : -1;
   }
-}
-__global__ void readout_max_decode(const unsigned long long* __restrict__ packed, int B, int F, float* __restrict__ out,
-                                   int64_t ldo, int* __restrict__ arg) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (int64_t)B * F) return;
-  const int b = (int)(i / F), f = (int)(i % F);
-  const unsigned long long p = packed[i];
-  out[(int64_t)b * ldo + f] = p ? ordered_f32((unsigned)(p >> 32)) : 0.f;
-  arg[i] = p ? (int)(0xFFFFFFFFu - (unsigned)(p & 0xFFFFFFFFull)) : -1;
 }
 // dx[arg[b,f], f] += dout[b,f]   (ghost rows can be chosen by several graphs -> atomic)
 __global__ void readout_max_bwd(const float* __restrict__ dout, int64_t ldo, const int* __restrict__ arg, int B, int F,
@@ -404,6 +416,13 @@ int tsgnn_row_ln_bwd_f32(const float* v, int64_t ldv, const float* dy, int64_t l
   return TSGNN_OK;
 }
 
+int tsgnn_readout_max_ws_words(int B, int nmax, int F) {
+  if (B <= 0 || nmax <= 0 || F <= 0) return 0;
+  if (nmax <= 64) return 1;
+  const int64_t w = (int64_t)B * F + (B + 1) / 2;
+  return w < (int64_t)1 << 30 ? (int)w : -1;
+}
+
 int tsgnn_readout_max_fwd_f32(const int* graph_ptr, const int* slot_count, int B, int nmax, int64_t n_real, int n_ghost,
                               const float* x, int64_t ldx, int F, int relu, unsigned long long* packed_ws, float* out,
                               int64_t ldo, int* arg, tsgnn_stream_t stream) {
@@ -416,11 +435,11 @@ int tsgnn_readout_max_fwd_f32(const int* graph_ptr, const int* slot_count, int B
     TSGNN_CHECK_LAUNCH();
     return TSGNN_OK;
   }
-  (void)hipMemsetAsync(packed_ws, 0, sizeof(unsigned long long) * (size_t)B * F, stream);
   const int FP = (F + 63) & ~63;
-  dim3 grid((unsigned)((nmax + 63) / 64), (unsigned)B);
-  readout_max_partial<<<grid, 256, sizeof(unsigned long long) * 4 * FP, stream>>>(s, x, ldx, F, relu, packed_ws);
-  readout_max_decode<<<(unsigned)ceil_div64((int64_t)B * F, 256), 256, 0, stream>>>(packed_ws, B, F, out, ldo, arg);
+  const int nch = (nmax + 63) / 64;
+  dim3 grid((unsigned)nch, (unsigned)B);
+  unsigned* count = reinterpret_cast<unsigned*>(packed_ws + (size_t)B * F);
+  readout_max_chunks<<<grid, 256, sizeof(unsigned long long) * 4 * FP, stream>>>(s, x, ldx, F, relu, packed_ws, count, out, ldo, arg);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }

@@ -19,6 +19,8 @@ struct MultiArgs {
   unsigned ntn, ng;           // problems of each kind (0..2)
   unsigned tn_blocks, nslab;  // blocks per weight-gradient problem (= slabs, NY = 1)
   unsigned g_blocks;          // blocks per product problem (row panels + filler)
+  float4* zero[2];            // nullable: cleared by the filler block of product 0 / 1 AFTER its own rows (the embedding mask of
+  int64_t zero_n4[2];         // a stack that returns node features: the ghost rows of the whole concatenation, the fill rows included)
 };
 
 template <int MT, int GMODE>   // MT: 32-row tiles of K_in of the weight-gradient problems (0: none); GMODE 0: no product, 1: W, 2: W^T
@@ -36,7 +38,14 @@ __global__ __launch_bounds__(256) void sage_multi_kernel(MultiArgs m) {
   }
   if constexpr (GMODE > 0) {
     const bool second = b >= m.g_blocks;
-    rowgemm_body<2, GMODE == 2, true>(second ? m.g1 : m.g0, smem, second ? b - m.g_blocks : b);
+    const unsigned bl = second ? b - m.g_blocks : b;
+    rowgemm_body<2, GMODE == 2, true>(second ? m.g1 : m.g0, smem, bl);
+    float4* z = m.zero[second];
+    if (z && bl == m.g_blocks - 1) {                     // the filler block: all of its threads are back here
+      __syncthreads();                                   // its fill rows are stored before they are cleared
+      const int64_t n4 = m.zero_n4[second];
+      for (int64_t i = threadIdx.x; i < n4; i += 256) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
 }
 
@@ -78,8 +87,13 @@ int tsgnn_sage_multi_g_words(void) { return 20; }
  *    ng  x (ell, ell_w, tail_ptr, tail_col, x, ldx, b, ldb, trans_b, bias, c, ldc, rinv, zout, ldz, rows, K, N, normalize, fill_rows)]
  * N = 64 wide (33..64), K, K_in <= 128, the problems of one kind share every shape; TSGNN_EUNSUPPORTED otherwise (launch them
  * one by one then). */
-int tsgnn_sage_multi_f32(const int64_t* desc, tsgnn_stream_t stream) {
-  if (!desc) return TSGNN_EINVAL;
+int tsgnn_sage_multi_zero_f32(const int64_t* desc, float* zero0, int64_t n0, float* zero1, int64_t n1, tsgnn_stream_t stream);
+int tsgnn_sage_multi_f32(const int64_t* desc, tsgnn_stream_t stream) { return tsgnn_sage_multi_zero_f32(desc, nullptr, 0, nullptr, 0, stream); }
+
+/* The same launch; additionally zero0[0..n0) / zero1[0..n1) are cleared by the filler block of product 0 / 1 after it has written
+ * its fill rows (the regions may contain them).  Needs fill_rows > 0, n % 4 == 0 and 16-byte aligned regions. */
+int tsgnn_sage_multi_zero_f32(const int64_t* desc, float* zero0, int64_t n0, float* zero1, int64_t n1, tsgnn_stream_t stream) {
+  if (!desc || n0 < 0 || n1 < 0 || (!zero0 && n0) || (!zero1 && n1)) return TSGNN_EINVAL;
   const int ntn = (int)desc[0], ng = (int)desc[1];
   if (ntn < 0 || ntn > 2 || ng < 0 || ng > 2 || ntn + ng == 0) return TSGNN_EINVAL;
   MultiArgs m{};
@@ -124,6 +138,12 @@ int tsgnn_sage_multi_f32(const int64_t* desc, tsgnn_stream_t stream) {
   m.nslab = (unsigned)nslab;
   m.tn_blocks = (unsigned)nslab;
   m.g_blocks = ng ? (unsigned)(ceil_div64(m.g0.rows, 32) + (m.g0.fill_rows > 0 ? 1 : 0)) : 0u;
+  if (zero0 || zero1) {
+    if (!ng || m.g0.fill_rows <= 0 || (zero1 && ng < 2)) return TSGNN_EUNSUPPORTED;
+    if ((n0 % 4) || (n1 % 4) || ((reinterpret_cast<uintptr_t>(zero0) | reinterpret_cast<uintptr_t>(zero1)) & 15)) return TSGNN_EUNSUPPORTED;
+    m.zero[0] = reinterpret_cast<float4*>(zero0); m.zero_n4[0] = n0 / 4;
+    m.zero[1] = reinterpret_cast<float4*>(zero1); m.zero_n4[1] = n1 / 4;
+  }
   const int mt = ntn ? (m.t0.K_in + 31) / 32 : 0;
   const int gm = ng ? (trans ? 2 : 1) : 0;
   switch (mt * 10 + gm) {

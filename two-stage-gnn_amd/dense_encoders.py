@@ -10,6 +10,7 @@ Accepted inputs of ``forward(x, adj, batch_num_nodes)``:
   * the reference's tensors ``x[B,Nmax,F]``, ``adj[B,Nmax,Nmax]`` (dense -> CSR conversion on the GPU), or
   * a prebuilt ``GraphBatch`` as ``adj`` with ``x`` either padded ``[B,Nmax,F]`` or already in rows.
 """
+import os
 import weakref
 
 import numpy as np
@@ -46,6 +47,7 @@ FUSED_HEAD = True              # the two chained nn.Linear after the readout as 
 FUSED_DENSE_POST = True       # pooled DiffPool levels: transform + normalise + ReLU + slot BN as one node
 FUSED_DENSE_STACK = True    # pooled DiffPool levels: the whole GCN stack as one autograd node (dense_stack.py)
 READOUT_PASS = True            # DiffPool: readout backward and the contraction's gradient of the same embeddings in one pass
+READOUT_COLUMNS = os.environ.get("TSGNN_READOUT_COLUMNS", "1") != "0"   # DiffPool: the levels' readouts written into one buffer (no cat)
 FUSED_STACK = True             # GcnEncoderGraph: run the conv stack as one fused autograd node when it qualifies
 DENSE_ADJ_MAX_NODES = 128      # at or below this many nodes per graph a dense batched MFMA product is used
 
@@ -418,13 +420,15 @@ class SoftPoolingGcnEncoder(GcnEncoderGraph):
                 masked)
         else:
             emb = self.gcn_forward_rows(x, g, self.conv_first, self.conv_block, self.conv_last, mask_ghost=masked)
+        # the levels' readouts land in their column blocks of ONE buffer (no torch.cat launch; mp.ReadoutColumns)
+        cols = mp.ReadoutColumns(g.B, emb.size(1) * (self.num_pooling + 1), emb.device) if (self.concat and READOUT_COLUMNS) else None
         if self.num_pooling > 0 and READOUT_PASS:
             # the embeddings feed the readout AND the contraction: one backward pass sums both gradients (mp._ReadoutMax);
             # masked: the ghost rows of `emb` are constants (zeros), their gradient is discarded by the stack's backward
-            ro, emb = mp.readout_max_pass(emb, g, ghost_unused=bool(masked and g.n_ghost))
+            ro, emb = mp.readout_max_pass(emb, g, ghost_unused=bool(masked and g.n_ghost), into=cols and cols.take(emb.size(1)))
             out_all = [ro]
         else:
-            out_all = [mp.readout_max(emb, g)]
+            out_all = [mp.readout_max(emb, g, into=cols and cols.take(emb.size(1)))]
         dense_x = dense_adj = None
         a_next = None
         for i in range(self.num_pooling):
@@ -467,12 +471,15 @@ class SoftPoolingGcnEncoder(GcnEncoderGraph):
                                                        self.conv_block_after_pool[i], self.conv_last_after_pool[i])
             Bq, Kq, Cq = emb_dense.shape
             if i + 1 < self.num_pooling and READOUT_PASS:
-                ro, e2 = mp.readout_max_pass(emb_dense.reshape(Bq * Kq, Cq), gd)
+                ro, e2 = mp.readout_max_pass(emb_dense.reshape(Bq * Kq, Cq), gd, into=cols and cols.take(Cq))
                 emb_dense = e2.reshape(Bq, Kq, Cq)
                 out_all.append(ro)
             else:
-                out_all.append(mp.readout_max(emb_dense.reshape(Bq * Kq, Cq), gd))
-        output = torch.cat(out_all, dim=1) if self.concat else out_all[-1]
+                out_all.append(mp.readout_max(emb_dense.reshape(Bq * Kq, Cq), gd, into=cols and cols.take(Cq)))
+        if not self.concat:
+            output = out_all[-1]
+        else:
+            output = cols.join(out_all) if cols is not None else torch.cat(out_all, dim=1)
         return self._heads(output)
 
     linkpred_clamp = 1.0        # the reference clamps pred_adj with an UNINITIALISED tensor (encoders.py:424); see DESIGN.md

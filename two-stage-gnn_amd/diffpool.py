@@ -14,6 +14,7 @@ from . import _native as nat
 from . import message_passing as mp
 
 
+RAGGED_DIRECT = os.environ.get("TSGNN_RAGGED_DIRECT", "1") != "0"       # first contraction: S^T Z and S^T (A S) as one launch (ragged.hip)
 FUSED_CONTRACT = os.environ.get("TSGNN_FUSED_CONTRACT", "1") != "0"     # pooled-level contraction: one launch each way (contract.hip)
 
 
@@ -190,8 +191,16 @@ class _ContractRows(torch.autograd.Function):
     def forward(ctx, S, Z, g):
         S, Z = S.contiguous(), Z.contiguous()
         AS = mp.spmm_raw(g.rowptr, g.col, g.val, S, g.total_rows)
-        xo = _ragged_tn(S, Z, g)
-        ao = _ragged_tn(S, AS, g)
+        K, F = S.size(1), Z.size(1)
+        xo = ao = None
+        if RAGGED_DIRECT and g.n_rows > 0 and nat.lib().tsgnn_ragged_tn_direct_supported(int(K), int(g.sizes.max())):
+            # both products in one launch, a workgroup per (column tile, graph): no slabs, no reduction launches (ragged.hip)
+            xo, ao = _f32(g.B, K, F, device=S.device), _f32(g.B, K, K, device=S.device)
+            if not nat.try_call("ragged_tn_direct_f32", S, S.stride(0), K, g.graph_ptr, g.B, Z, Z.stride(0), F, xo, AS, AS.stride(0), K, ao):
+                xo = ao = None
+        if xo is None:
+            xo = _ragged_tn(S, Z, g)
+            ao = _ragged_tn(S, AS, g)
         ctx.g = g
         ctx.save_for_backward(S, Z, AS)
         return xo, ao

@@ -595,6 +595,19 @@ def bn_slots(v, g, relu=True, bn=True, per_graph=False):
 
 
 # ----------------------------------------------------------------------------- max readout over node slots
+def _readout_ws(g, F, dev):
+    """workspace of tsgnn_readout_max_fwd_f32: zeroed ONCE per (batch, width, stream) — the launch leaves its counters at zero"""
+    cache = g.__dict__.setdefault("_readout_ws", {})
+    key = (int(F), torch.cuda.current_stream(dev).cuda_stream)
+    ws = cache.get(key)
+    if ws is None:
+        words = int(nat.lib().tsgnn_readout_max_ws_words(int(g.B), int(g.nmax), int(F)))
+        if words <= 0:
+            raise ValueError("max readout: batch of %d graphs x %d slots x %d features is out of range" % (g.B, g.nmax, F))
+        ws = cache[key] = torch.zeros(words, dtype=torch.int64, device=dev)
+    return ws
+
+
 class _ReadoutMax(torch.autograd.Function):
     """out[b] = max over ALL nmax node slots of graph b (ghost rows included) — encoders.py:183 (trap T5).
     passthrough: also returns x itself as a second differentiable output for the OTHER consumer of the same tensor (DiffPool's
@@ -603,14 +616,13 @@ class _ReadoutMax(torch.autograd.Function):
     ghost_unused: the caller discards the gradient of the ghost rows (masked embeddings) — the dense pass may be used with them."""
 
     @staticmethod
-    def forward(ctx, x, g, passthrough, ghost_unused):
+    def forward(ctx, x, g, passthrough, ghost_unused, into=None):
         x = _check(x, g.total_rows)
         F = x.size(1)
-        out = _f32(g.B, F, device=x.device)
+        out = into.t if into is not None else _f32(g.B, F, device=x.device)
         arg = torch.empty(g.B, F, dtype=torch.int32, device=x.device)
-        ws = torch.empty(g.B * F, dtype=torch.int64, device=x.device)
         nat.call("readout_max_fwd_f32", g.graph_ptr, g.slot_count, g.B, g.nmax, g.n_rows, g.n_ghost, x, x.stride(0),
-                 F, 0, ws, out, out.stride(0), arg)
+                 F, 0, _readout_ws(g, F, x.device), out, out.stride(0), arg)
         ctx.g = g
         ctx.rows = x.size(0)
         ctx.ghost_unused = bool(ghost_unused)
@@ -626,7 +638,7 @@ class _ReadoutMax(torch.autograd.Function):
         (arg,) = ctx.saved_tensors
         g = ctx.g
         if dout is None:
-            return dpass, None, None, None
+            return dpass, None, None, None, None
         if dout.stride(1) != 1 or dout.stride(0) < dout.size(1):
             dout = dout.contiguous()                     # (a column slice of the concatenated readouts' gradient is read in place)
         F = dout.size(1)
@@ -638,23 +650,74 @@ class _ReadoutMax(torch.autograd.Function):
             dx = _f32(ctx.rows, F, device=dout.device)              # one dense pass writes every element
             nat.call("readout_max_bwd_rows_f32", dout, dout.stride(0), arg, g.row_graph, F, g.n_rows, ctx.rows, dpass,
                      dpass.stride(0) if dpass is not None else 0, dx, dx.stride(0))
-            return dx, None, None, None
+            return dx, None, None, None, None
         dx = _f32(ctx.rows, F, device=dout.device, zero=True)
         nat.call("readout_max_bwd_f32", dout, dout.stride(0), arg, g.B, F, None, 0, 0, g.n_rows, dx, dx.stride(0))
         if dpass is not None:
             dx = dx + dpass
-        return dx, None, None, None
+        return dx, None, None, None, None
 
 
-def readout_max(x, g, return_arg=False):
-    out, arg = _ReadoutMax.apply(x, g, False, False)
+def readout_max(x, g, return_arg=False, into=None):
+    out, arg = _ReadoutMax.apply(x, g, False, False, into)
     return (out, arg) if return_arg else out
 
 
-def readout_max_pass(x, g, ghost_unused=False):
+def readout_max_pass(x, g, ghost_unused=False, into=None):
     """(max readout of x, x): the second output is x for its other consumer; see _ReadoutMax"""
-    out, _arg, xp = _ReadoutMax.apply(x, g, True, bool(ghost_unused))
+    out, _arg, xp = _ReadoutMax.apply(x, g, True, bool(ghost_unused), into)
     return out, xp
+
+
+class _Into:
+    """a column block of a ReadoutColumns buffer (handed to the readout as a plain object: not an autograd input)"""
+    __slots__ = ("t",)
+
+    def __init__(self, t):
+        self.t = t
+
+
+class _JoinColumns(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cols, *parts):
+        ctx.widths = [p.size(1) for p in parts]
+        return cols.buf
+
+    @staticmethod
+    def backward(ctx, d):
+        out, c0 = [None], 0
+        for w in ctx.widths:
+            out.append(d[:, c0:c0 + w])              # read in place by the part's backward
+            c0 += w
+        return tuple(out)
+
+
+class ReadoutColumns:
+    """torch.cat(readouts, dim=1) (encoders.py:203,388-391) without the copy launch: ONE [B, total] buffer, every readout writes its
+    column block (`take`), `join` hands the buffer on as the concatenation; backwards, a part's gradient is a column slice of the
+    buffer's.  The blocks alias the buffer's storage without being autograd views of it (nothing here is modified in place by
+    autograd's bookkeeping: each block is written by exactly one launch)."""
+
+    def __init__(self, B, total, device):
+        self.buf = _f32(int(B), int(total), device=device)
+        self.c0, self.parts = 0, 0
+
+    def take(self, F):
+        """the next F columns (None: they do not fit, or are not 16-byte aligned — the caller then concatenates)"""
+        F = int(F)
+        if self.c0 < 0 or self.c0 + F > self.buf.size(1) or F % 4 or self.c0 % 4:
+            self.c0 = -1
+            return None
+        t = torch.empty(0, dtype=torch.float32, device=self.buf.device)
+        t.set_(self.buf.untyped_storage(), self.buf.storage_offset() + self.c0, (self.buf.size(0), F), (self.buf.stride(0), 1))
+        self.c0 += F
+        self.parts += 1
+        return _Into(t)
+
+    def join(self, parts):
+        if self.c0 == self.buf.size(1) and self.parts == len(parts):
+            return _JoinColumns.apply(self, *parts)
+        return torch.cat(parts, dim=1)
 
 
 # ----------------------------------------------------------------------------- padded <-> packed rows

@@ -521,11 +521,13 @@ def sage_stack_nodes(x, g, convs, mask_ghost):
 
 # ----------------------------------------------------------------------------- two stacks on one graph, launches shared
 PAIR_LAUNCHES = os.environ.get("TSGNN_STACK_PAIRS", "1") != "0"
+ZERO_RIDER = os.environ.get("TSGNN_ZERO_RIDER", "1") != "0"        # the embedding mask's clearing inside the last paired product launch
 
 
-def _multi(tn, gs):
+def _multi(tn, gs, zero=None):
     """one launch for the recorded argument tuples of <= 2 tsgnn_linear_wgrad_f32 (slab form) and <= 2 tsgnn_gather_rowgemm_f32
-    calls; False when the entry point does not take the combination (csrc/multi.hip)"""
+    calls; False when the entry point does not take the combination (csrc/multi.hip).  zero: two contiguous tensors that the
+    products' filler blocks clear after their own rows (the deferred `_zero` records that follow the products)."""
     import numpy as np
     words = [len(tn), len(gs)]
     for a in tn:
@@ -533,7 +535,16 @@ def _multi(tn, gs):
     for a in gs:
         words += [(nat._arg(v) or 0) if not isinstance(v, bool) else int(v) for v in a[:20]]
     d = np.asarray(words, dtype=np.int64)
+    if zero is not None:
+        za, zb = zero
+        if not (za.is_contiguous() and zb.is_contiguous()):
+            return False
+        return nat.try_call("sage_multi_zero_f32", d.ctypes.data, za, za.numel(), zb, zb.numel())
     return nat.try_call("sage_multi_f32", d.ctypes.data)
+
+
+def _zero_after(q, i):
+    return q[i + 1][1][0] if i + 1 < len(q) and q[i + 1][0] == "_zero" else None
 
 
 def _slab_form(rec):
@@ -547,9 +558,14 @@ def run_paired(qa, qb):
     i = j = 0
     while i < len(qa) and j < len(qb):
         a, b = qa[i], qb[j]
-        if a[0] == b[0] == "gather_rowgemm_f32" and _multi([], [a[1], b[1]]):
-            i += 1; j += 1
-            continue
+        if a[0] == b[0] == "gather_rowgemm_f32":
+            za, zb = _zero_after(qa, i), _zero_after(qb, j)
+            if ZERO_RIDER and za is not None and zb is not None and _multi([], [a[1], b[1]], zero=(za, zb)):
+                i += 2; j += 2                      # the ghost rows' clearing rode in the products' filler blocks
+                continue
+            if _multi([], [a[1], b[1]]):
+                i += 1; j += 1
+                continue
         if _slab_form(a) and _slab_form(b):
             na = qa[i + 1] if i + 1 < len(qa) else (None,)
             nb = qb[j + 1] if j + 1 < len(qb) else (None,)
