@@ -244,6 +244,13 @@ int tsgnn_ragged_tn_f32(const float* s_mat, int64_t lds_, const float* x, int64_
 int tsgnn_ragged_tn_direct_supported(int K, int64_t max_rows);
 int tsgnn_ragged_tn_direct_f32(const float* s_mat, int64_t lds_, int K, const int* graph_ptr, int B, const float* x0, int64_t ldx0,
                                int N0, float* out0, const float* x1, int64_t ldx1, int N1, float* out1, tsgnn_stream_t stream);
+/* the same + the max readout of x0 over each segment's node slots (encoders.py:353; trap T5) from the values the product's
+ * workgroups hold anyway: ro_out [B, N0] (leading dimension ro_ldo), ro_arg [B, N0] = winning row.  ghost_zero != 0: a segment
+ * shorter than nmax also has ZERO rows behind the real ones (row n_real + slot: the masked embeddings of a packed batch); the first
+ * of them takes part, exactly as in tsgnn_readout_max_fwd_f32.  ghost_zero = 0: the segment's rows are all of its slots. */
+int tsgnn_ragged_tn_direct_ro_f32(const float* s_mat, int64_t lds_, int K, const int* graph_ptr, int B, const float* x0, int64_t ldx0,
+                                  int N0, float* out0, const float* x1, int64_t ldx1, int N1, float* out1, float* ro_out,
+                                  int64_t ro_ldo, int* ro_arg, int nmax, int64_t n_real, int ghost_zero, tsgnn_stream_t stream);
 /* Weight + bias gradient of a layer with a narrow input (K_in <= 4, e.g. the one-column constant feature of IMDB-B,
  * network.py:34 with num_features = 1): dwb[(K_in + 1), N], rows 0..K_in-1 = z[:, :K_in]^T du, row K_in = column sums of du,
  * from one pass over du.  ws: *ws_floats of tsgnn_wgrad_narrow_plan(rows, K_in, N, &ws_floats). */
@@ -818,9 +825,19 @@ int tsgnn_contract_dense_supported(int N, int K, int F);
  * s [B,N,K], z [B,N,F], adj [B,N,N], all contiguous. */
 int tsgnn_contract_dense_fwd_f32(const float* s, const float* z, const float* adj, int B, int N, int K, int F, float* xo, float* ao,
                                  float* t, tsgnn_stream_t stream);
+/* the same + the max readout of z over each graph's N rows (encoders.py:383) out of the staged operand: ro_out [B, F] (leading
+ * dimension ro_ldo), ro_arg [B, F] = winning row b * N + n (what tsgnn_readout_max_fwd_f32 returns for the uniform batch (B, N)) */
+int tsgnn_contract_dense_fwd_ro_f32(const float* s, const float* z, const float* adj, int B, int N, int K, int F, float* xo, float* ao,
+                                    float* t, float* ro_out, int64_t ro_ldo, int* ro_arg, tsgnn_stream_t stream);
 /* ds [B,N,K], dz [B,N,F], dadj [B,N,N] (each nullable) from dxo [B,K,F], dao [B,K,K] */
 int tsgnn_contract_dense_bwd_f32(const float* s, const float* z, const float* adj, const float* t, const float* dxo, const float* dao,
                                  int B, int N, int K, int F, float* ds, float* dz, float* dadj, tsgnn_stream_t stream);
+/* the same; dz additionally takes the gradient of the max readout of z over each graph's N rows — ro_dout [B, F] (leading dimension
+ * ro_ldo), ro_arg [B, F] = winning row b * N + n or -1 — i.e. the pass tsgnn_readout_max_bwd_rows_f32 would make over dz afterwards
+ * (the embeddings feed the readout AND the next contraction, encoders.py:383,374) */
+int tsgnn_contract_dense_bwd_ro_f32(const float* s, const float* z, const float* adj, const float* t, const float* dxo, const float* dao,
+                                    int B, int N, int K, int F, float* ds, float* dz, float* dadj, const float* ro_dout, int64_t ro_ldo,
+                                    const int* ro_arg, tsgnn_stream_t stream);
 
 /* backward of the ROW-layout (level 1) contraction X'[b] = S_b^T Z_b, A'[b] = S_b^T (A S)_b (diffpool.py::_ContractRows) in one
  * launch: dZ = S dX', dS = Z dX'^T + (AS) dA'^T, d(AS) = S dA' for the rows of every slab (slab_row_ptr[nslab + 1]: at most 32
@@ -830,6 +847,13 @@ int tsgnn_contract_rows_bwd_f32(const float* S, int64_t ldS, const float* Z, int
                                 const float* dxo, const float* dao, const int* slab_row_ptr, const int* slab_graph, int nslab, int K,
                                 int F, float* dZ, int64_t lddZ, float* dS, int64_t lddS, float* dAS, int64_t lddAS,
                                 int64_t zero_from, int64_t zero_to, tsgnn_stream_t stream);
+/* the same; dZ additionally takes the gradient of the max readout of Z (ro_dout [B, F], ro_ldo, ro_arg [B, F] = winning row or -1);
+ * winners outside the slabs' rows (ghost rows) are dropped */
+int tsgnn_contract_rows_bwd_ro_f32(const float* S, int64_t ldS, const float* Z, int64_t ldZ, const float* AS, int64_t ldAS,
+                                   const float* dxo, const float* dao, const int* slab_row_ptr, const int* slab_graph, int nslab, int K,
+                                   int F, float* dZ, int64_t lddZ, float* dS, int64_t lddS, float* dAS, int64_t lddAS,
+                                   int64_t zero_from, int64_t zero_to, const float* ro_dout, int64_t ro_ldo, const int* ro_arg,
+                                   tsgnn_stream_t stream);
 
 /* paired forms for two stacks that share batch and shapes (grid.y = 2; sage_stack._SageStackPair): tsgnn_slot_bn_fwd_f32 without
  * the readout-buffer clear, tsgnn_slot_post_bwd_f32 without a readout gradient, and the slab reduction of up to 8 sets described

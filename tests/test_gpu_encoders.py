@@ -973,6 +973,29 @@ def test_ragged_tn_direct_vs_fp64(K, N0, N1, ld_pad):
     o0b = torch.empty_like(o0)
     nat.call("ragged_tn_direct_f32", S, S.stride(0), K, gp, B, X0, X0.stride(0), N0, o0b, None, 0, 0, None)
     assert torch.equal(o0, o0b)                                 # alone or beside the second operand: the same bits
+    # ... and with the max readout of X0 riding along (padded slots: none / zero rows behind the real ones)
+    nmax = max(sizes)
+    for ghost in (0, 1):
+        o0c = torch.empty_like(o0)
+        ro = torch.full((B, N0 + 4), float("nan"), device="cuda")
+        arg = torch.full((B, N0), -7, dtype=torch.int32, device="cuda")
+        nat.call("ragged_tn_direct_ro_f32", S, S.stride(0), K, gp, B, X0, X0.stride(0), N0, o0c, None, 0, 0, None, ro, ro.stride(0), arg,
+                 nmax, R, ghost)
+        assert torch.equal(o0c, o0)
+        off = 0
+        for b, n in enumerate(sizes):
+            if n:
+                ref, idx = X0[off:off + n].max(0)
+                refarg = idx.int() + off
+            else:
+                ref, refarg = torch.zeros(N0, device="cuda"), torch.full((N0,), -1, dtype=torch.int32, device="cuda")
+            if ghost and n < nmax:
+                lose = ref < 0 if n else torch.ones(N0, dtype=torch.bool, device="cuda")
+                ref = torch.where(lose, torch.zeros_like(ref), ref)
+                refarg = torch.where(lose, torch.full_like(refarg, R + n), refarg)
+            assert torch.equal(ro[b, :N0], ref), (ghost, b, n)
+            assert torch.equal(arg[b], refarg), (ghost, b, n)
+            off += n
     off = 0
     for b, n in enumerate(sizes):
         s64 = S[off:off + n].double()
@@ -1019,8 +1042,9 @@ def test_readout_max_one_launch_repeated_calls(nmax, F):
 
 
 def test_diffpool_glue_variants_agree(monkeypatch):
-    """round-3 launch removals of the DiffPool step — the levels' readouts written into one buffer (no torch.cat), the embedding
-    mask's clearing inside the last paired product launch, both first-contraction products as one launch — against the
+    """round-3 launch removals of the DiffPool step — the levels' readouts written into one buffer (no torch.cat), their gradients
+    added inside the contractions' backward launches, the embedding mask's clearing inside the last paired product launch, both
+    first-contraction products as one launch — against the
     launch-by-launch forms: outputs, loss, every parameter gradient; and the launches really are gone"""
     from two_stage_gnn_amd import dense_encoders as E, sage_stack, diffpool as dp, synthetic, message_passing as mp, _native as nat
 
@@ -1034,6 +1058,7 @@ def test_diffpool_glue_variants_agree(monkeypatch):
     res = []
     for on in (False, True, False):                     # (the first pass also builds the batch's lazily built structures)
         monkeypatch.setattr(E, "READOUT_COLUMNS", on)
+        monkeypatch.setattr(E, "READOUT_IN_CONTRACT", on)
         monkeypatch.setattr(sage_stack, "ZERO_RIDER", on)
         monkeypatch.setattr(dp, "RAGGED_DIRECT", on)
         m.zero_grad(set_to_none=True)
@@ -1050,7 +1075,10 @@ def test_diffpool_glue_variants_agree(monkeypatch):
     mp.check_device_errors()
     (a1, b1, l1, g1, n1), (a0, b0, l0, g0, n0) = res[1:]
     assert "sage_multi_zero_f32" in n1 and "sage_multi_zero_f32" not in n0
-    assert "ragged_tn_direct_f32" in n1 and n1.count("ragged_tn_f32") == 0 and n0.count("ragged_tn_f32") == 2
+    assert "contract_rows_bwd_ro_f32" in n1 and "contract_dense_bwd_ro_f32" in n1 and n1.count("readout_max_bwd_rows_f32") == 1
+    assert n0.count("readout_max_bwd_rows_f32") == 3
+    assert "ragged_tn_direct_ro_f32" in n1 and n1.count("ragged_tn_f32") == 0 and n0.count("ragged_tn_f32") == 2
+    assert n1.count("readout_max_fwd_f32") == 1 and n0.count("readout_max_fwd_f32") == 3
     assert len(n1) <= len(n0) - 1
     torch.testing.assert_close(a1, a0, rtol=2e-5, atol=2e-6)
     torch.testing.assert_close(b1, b0, rtol=2e-5, atol=2e-6)

@@ -105,7 +105,8 @@ __device__ __forceinline__ bool ct_vec_ok(const void* p, int cols) { return (col
 __global__ __launch_bounds__(CT_THREADS) void contract_dense_fwd_kernel(const float* __restrict__ s, const float* __restrict__ z,
                                                                         const float* __restrict__ adj, int N, int K, int F,
                                                                         float* __restrict__ xo, float* __restrict__ ao,
-                                                                        float* __restrict__ t_out) {
+                                                                        float* __restrict__ t_out, float* __restrict__ ro_out,
+                                                                        int64_t ro_ldo, int* __restrict__ ro_arg) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const CtDims d = ct_dims(N, K, F);
   float* S = sm;
@@ -125,6 +126,20 @@ __global__ __launch_bounds__(CT_THREADS) void contract_dense_fwd_kernel(const fl
     ct_load(A, d.ldA, ab, N, N);
   }
   __syncthreads();
+  if (ro_out) {
+    // max readout of z over the graph's N rows (encoders.py:383), rows b * N + n: the same packed (value, row) order as
+    // readout_max_direct (bn_readout.hip) — ties go to the smallest row
+    for (int f = threadIdx.x; f < F; f += CT_THREADS) {
+      unsigned long long best = 0ull;
+      for (int n = 0; n < N; ++n) {
+        const unsigned long long p = ((unsigned long long)f32_ordered(Z[n * d.ldZ + f]) << 32) |
+                                     (unsigned long long)(0xFFFFFFFFu - (unsigned)(b * N + n));
+        best = p > best ? p : best;
+      }
+      ro_out[(int64_t)b * ro_ldo + f] = best ? ordered_f32((unsigned)(best >> 32)) : 0.f;
+      ro_arg[(int64_t)b * F + f] = best ? (int)(0xFFFFFFFFu - (unsigned)(best & 0xFFFFFFFFull)) : -1;
+    }
+  }
   // X' = S^T Z   [K, F]
   const CtDiv byF(F), byN(N), byK(K);
   for (int i = threadIdx.x; i < K * F; i += CT_THREADS) {
@@ -155,7 +170,9 @@ __global__ __launch_bounds__(CT_THREADS) void contract_dense_bwd_kernel(const fl
                                                                         const float* __restrict__ adj, const float* __restrict__ t,
                                                                         const float* __restrict__ dxo, const float* __restrict__ dao,
                                                                         int N, int K, int F, float* __restrict__ ds,
-                                                                        float* __restrict__ dz, float* __restrict__ dadj) {
+                                                                        float* __restrict__ dz, float* __restrict__ dadj,
+                                                                        const float* __restrict__ ro_dout, int64_t ro_ldo,
+                                                                        const int* __restrict__ ro_arg) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const CtDims d = ct_dims(N, K, F);
   float* S = sm;
@@ -207,6 +224,12 @@ __global__ __launch_bounds__(CT_THREADS) void contract_dense_bwd_kernel(const fl
     for (int i = threadIdx.x; i < N * F4; i += CT_THREADS) {
       const int n = byF4(i), f4 = i - n * F4;
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ro_arg) {                                      // + the max readout's gradient where row b * N + n won its column
+        const int4 ra = *reinterpret_cast<const int4*>(ro_arg + (int64_t)b * F + 4 * f4);
+        const float4 rd = *reinterpret_cast<const float4*>(ro_dout + (int64_t)b * ro_ldo + 4 * f4);
+        const int row = b * N + n;
+        acc = make_float4(ra.x == row ? rd.x : 0.f, ra.y == row ? rd.y : 0.f, ra.z == row ? rd.z : 0.f, ra.w == row ? rd.w : 0.f);
+      }
       for (int k = 0; k < K; ++k) {
         const float sv = S[n * d.ldS + k];
         const float4 x4 = *reinterpret_cast<const float4*>(DX + k * d.ldDX + 4 * f4);
@@ -218,7 +241,7 @@ __global__ __launch_bounds__(CT_THREADS) void contract_dense_bwd_kernel(const fl
     const CtDiv byF(F);
     for (int i = threadIdx.x; i < N * F; i += CT_THREADS) {
       const int n = byF(i), f = i - n * F;
-      float acc = 0.f;
+      float acc = (ro_arg && ro_arg[(int64_t)b * F + f] == b * N + n) ? ro_dout[(int64_t)b * ro_ldo + f] : 0.f;
       for (int k = 0; k < K; ++k) acc = fmaf(S[n * d.ldS + k], DX[k * d.ldDX + f], acc);
       dz[(int64_t)b * N * F + i] = acc;
     }
@@ -280,6 +303,7 @@ struct CtRows {
   int K, F;
   float* dZ; int64_t lddZ; float* dS; int64_t lddS; float* dAS; int64_t lddAS;
   int64_t zero_from, zero_to;                    // rows [zero_from, zero_to) of the three outputs are cleared
+  const float* ro_dout; int64_t ro_ldo; const int* ro_arg;   // nullable: dZ += the max readout's gradient (dout [B, F], arg = winning row)
   signed char job[4][CR_MAXJOBS];                // per wave: job codes, -1 ends.  0..7: dZ tile t; 8..9: d(AS) tile; 10..11: dS tile
 };
 
@@ -407,8 +431,15 @@ __global__ __launch_bounds__(256) void contract_rows_bwd_kernel(CtRows a) {
     float* out;
     int64_t ldo;
     int t, ncols;
+    int ra = -1;
+    float rd = 0.f;
     if (code < 8) {                                      // dZ tile: S . dX'
       t = code; ncols = F; out = a.dZ; ldo = a.lddZ;
+      if (a.ro_arg) {                                    // (requested before the product, used at the store)
+        const int cc = min(32 * t + i, F - 1);
+        ra = a.ro_arg[(int64_t)b * F + cc];
+        rd = a.ro_dout[(int64_t)b * a.ro_ldo + cc];
+      }
       ct_mfma(acc, Sp, lda, DX + 32 * t, ldx, 1, K, F - 32 * t);
     } else if (code < 10) {                              // d(AS) tile: S . dA'
       t = code - 8; ncols = K; out = a.dAS; ldo = a.lddAS;
@@ -424,7 +455,7 @@ __global__ __launch_bounds__(256) void contract_rows_bwd_kernel(CtRows a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m < nr) out[(int64_t)(r0 + m) * ldo + c] = acc[r];
+        if (m < nr) out[(int64_t)(r0 + m) * ldo + c] = acc[r] + ((r0 + m) == ra ? rd : 0.f);
       }
     }
     TR(4 + 2 * min(q, 3));
@@ -464,7 +495,15 @@ int tsgnn_contract_dense_supported(int N, int K, int F) {
  * s [B,N,K], z [B,N,F], adj [B,N,N] contiguous (encoders.py:374-375) */
 int tsgnn_contract_dense_fwd_f32(const float* s, const float* z, const float* adj, int B, int N, int K, int F, float* xo, float* ao,
                                  float* t, tsgnn_stream_t stream) {
+  return tsgnn_contract_dense_fwd_ro_f32(s, z, adj, B, N, K, F, xo, ao, t, nullptr, 0, nullptr, stream);
+}
+
+/* the same + the max readout of z over each graph's N rows (encoders.py:383) out of the staged operand: ro_out [B, F] (leading
+ * dimension ro_ldo), ro_arg [B, F] = winning row b * N + n — what tsgnn_readout_max_fwd_f32 returns for the uniform batch (B, N) */
+int tsgnn_contract_dense_fwd_ro_f32(const float* s, const float* z, const float* adj, int B, int N, int K, int F, float* xo, float* ao,
+                                    float* t, float* ro_out, int64_t ro_ldo, int* ro_arg, tsgnn_stream_t stream) {
   if (!s || !z || !adj || !xo || !ao || !t || B < 0) return TSGNN_EINVAL;
+  if ((ro_out == nullptr) != (ro_arg == nullptr) || (ro_out && ro_ldo < F)) return TSGNN_EINVAL;
   if (!tsgnn_contract_dense_supported(N, K, F)) return TSGNN_EUNSUPPORTED;
   if (B == 0) return TSGNN_OK;
   const size_t lds = ct_lds_floats(N, K, F, false) * sizeof(float);
@@ -473,7 +512,7 @@ int tsgnn_contract_dense_fwd_f32(const float* s, const float* z, const float* ad
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(contract_dense_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CT_LDS_MAX);
     attr = CT_LDS_MAX;
   }
-  contract_dense_fwd_kernel<<<(unsigned)B, CT_THREADS, lds, stream>>>(s, z, adj, N, K, F, xo, ao, t);
+  contract_dense_fwd_kernel<<<(unsigned)B, CT_THREADS, lds, stream>>>(s, z, adj, N, K, F, xo, ao, t, ro_out, ro_ldo, ro_arg);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }
@@ -481,8 +520,19 @@ int tsgnn_contract_dense_fwd_f32(const float* s, const float* z, const float* ad
 /* gradients of the pair above: ds [B,N,K], dz [B,N,F], dadj [B,N,N] (each nullable) from dxo [B,K,F], dao [B,K,K] */
 int tsgnn_contract_dense_bwd_f32(const float* s, const float* z, const float* adj, const float* t, const float* dxo, const float* dao,
                                  int B, int N, int K, int F, float* ds, float* dz, float* dadj, tsgnn_stream_t stream) {
+  return tsgnn_contract_dense_bwd_ro_f32(s, z, adj, t, dxo, dao, B, N, K, F, ds, dz, dadj, nullptr, 0, nullptr, stream);
+}
+
+/* the same; dz additionally takes the gradient of the max readout of z over each graph's N rows (ro_dout [B, F] with leading
+ * dimension ro_ldo, ro_arg [B, F] = winning row b * N + n or -1): the pass tsgnn_readout_max_bwd_rows_f32 would make over dz */
+int tsgnn_contract_dense_bwd_ro_f32(const float* s, const float* z, const float* adj, const float* t, const float* dxo, const float* dao,
+                                    int B, int N, int K, int F, float* ds, float* dz, float* dadj, const float* ro_dout, int64_t ro_ldo,
+                                    const int* ro_arg, tsgnn_stream_t stream) {
   if (!s || !dxo || !dao || B < 0 || (ds && (!z || !adj || !t))) return TSGNN_EINVAL;
+  if ((ro_dout == nullptr) != (ro_arg == nullptr) || (ro_arg && (!dz || ro_ldo < F))) return TSGNN_EINVAL;
   if (!tsgnn_contract_dense_supported(N, K, F)) return TSGNN_EUNSUPPORTED;
+  if (ro_arg && (F % 4 == 0) && ((ro_ldo % 4) || ((reinterpret_cast<uintptr_t>(ro_dout) | reinterpret_cast<uintptr_t>(ro_arg)) & 15)))
+    return TSGNN_EUNSUPPORTED;
   if (B == 0 || (!ds && !dz && !dadj)) return TSGNN_OK;
   const size_t lds = ct_lds_floats(N, K, F, true) * sizeof(float);
   static size_t attr = 0;
@@ -490,7 +540,7 @@ int tsgnn_contract_dense_bwd_f32(const float* s, const float* z, const float* ad
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(contract_dense_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CT_LDS_MAX);
     attr = CT_LDS_MAX;
   }
-  contract_dense_bwd_kernel<<<(unsigned)B, CT_THREADS, lds, stream>>>(s, z, adj, t, dxo, dao, N, K, F, ds, dz, dadj);
+  contract_dense_bwd_kernel<<<(unsigned)B, CT_THREADS, lds, stream>>>(s, z, adj, t, dxo, dao, N, K, F, ds, dz, dadj, ro_dout, ro_ldo, ro_arg);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }
@@ -507,8 +557,20 @@ int tsgnn_contract_rows_bwd_f32(const float* S, int64_t ldS, const float* Z, int
                                 const float* dxo, const float* dao, const int* slab_row_ptr, const int* slab_graph, int nslab, int K,
                                 int F, float* dZ, int64_t lddZ, float* dS, int64_t lddS, float* dAS, int64_t lddAS,
                                 int64_t zero_from, int64_t zero_to, tsgnn_stream_t stream) {
+  return tsgnn_contract_rows_bwd_ro_f32(S, ldS, Z, ldZ, AS, ldAS, dxo, dao, slab_row_ptr, slab_graph, nslab, K, F, dZ, lddZ, dS, lddS, dAS,
+                                        lddAS, zero_from, zero_to, nullptr, 0, nullptr, stream);
+}
+
+/* the same; dZ additionally takes the gradient of the max readout of Z over each graph's rows (ro_dout [B, F] with leading dimension
+ * ro_ldo, ro_arg [B, F] = winning row or -1; winners outside the slabs' rows — ghost rows — are dropped, as the caller discards them) */
+int tsgnn_contract_rows_bwd_ro_f32(const float* S, int64_t ldS, const float* Z, int64_t ldZ, const float* AS, int64_t ldAS,
+                                   const float* dxo, const float* dao, const int* slab_row_ptr, const int* slab_graph, int nslab, int K,
+                                   int F, float* dZ, int64_t lddZ, float* dS, int64_t lddS, float* dAS, int64_t lddAS,
+                                   int64_t zero_from, int64_t zero_to, const float* ro_dout, int64_t ro_ldo, const int* ro_arg,
+                                   tsgnn_stream_t stream) {
   if (!S || !Z || !AS || !dxo || !dao || !slab_row_ptr || !slab_graph || !dZ || !dS || !dAS || nslab < 0 || zero_to < zero_from)
     return TSGNN_EINVAL;
+  if ((ro_dout == nullptr) != (ro_arg == nullptr) || (ro_arg && ro_ldo < F)) return TSGNN_EINVAL;
   if (!tsgnn_contract_rows_bwd_supported(K, F) || (ldS % 4) || (ldZ % 4) || (ldAS % 4) || (lddZ % 4) || (lddAS % 4) || ldS < K ||
       ldZ < F || ldAS < K || lddZ < F || lddS < K || lddAS < K ||
       ((reinterpret_cast<uintptr_t>(S) | reinterpret_cast<uintptr_t>(Z) | reinterpret_cast<uintptr_t>(AS) | reinterpret_cast<uintptr_t>(dxo) |
@@ -523,7 +585,8 @@ int tsgnn_contract_rows_bwd_f32(const float* S, int64_t ldS, const float* Z, int
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(contract_rows_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CT_LDS_MAX);
     attr = true;
   }
-  CtRows a{S, ldS, Z, ldZ, AS, ldAS, dxo, dao, slab_row_ptr, slab_graph, nslab, K, F, dZ, lddZ, dS, lddS, dAS, lddAS, zero_from, zero_to, {}};
+  CtRows a{S, ldS, Z, ldZ, AS, ldAS, dxo, dao, slab_row_ptr, slab_graph, nslab, K, F, dZ, lddZ, dS, lddS, dAS, lddAS, zero_from, zero_to,
+           ro_dout, ro_ldo, ro_arg, {}};
   ct_rows_jobs(K, F, a.job);
   contract_rows_bwd_kernel<<<(unsigned)nslab + zblocks, 256, lds, stream>>>(a);
   TSGNN_CHECK_LAUNCH();

@@ -18,6 +18,9 @@ struct RaggedTn {
   const int* graph_ptr;
   const float* x[2]; int64_t ldx[2]; int N[2]; float* out[2];
   int nt0;                                    // column tiles of operand 0 (blocks x >= nt0 work on operand 1)
+  // nullable: the max readout of operand 0 over each graph's node slots (encoders.py:353) from the values the tm = 0 workgroups
+  // hold anyway.  ro_ghost: the graph's padded slots (sizes < nmax) are ZERO rows n_real + slot that take part (trap T5).
+  float* ro_out; int64_t ro_ldo; int* ro_arg; int ro_nmax; int64_t ro_n_real; int ro_ghost;
 };
 
 constexpr int RT_WAVES = 8;
@@ -26,6 +29,7 @@ constexpr int RT_STEPS = 16;                  // row pairs per batch: 2 * 16 req
 // grid (mt * (nt0 + nt1), B): one 32 x 32 tile of one product of one graph per workgroup (DD b16, K = 64, N = 192 + 64: 256 workgroups)
 __global__ __launch_bounds__(64 * RT_WAVES) void ragged_tn_direct_kernel(RaggedTn a, int mt) {
   __shared__ __attribute__((aligned(16))) float part[RT_WAVES * 1024];       // [RT_WAVES][16][64]
+  __shared__ unsigned long long ro_best[RT_WAVES][32];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int i = lane & 31, h = lane >> 5;
   const int b = blockIdx.y;
@@ -48,6 +52,8 @@ __global__ __launch_bounds__(64 * RT_WAVES) void ragged_tn_direct_kernel(RaggedT
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const int last = max(r0, r1 - 1);                                   // clamp target (an empty graph runs no batch)
+  const bool ro = a.ro_out && op == 0 && tm == 0;                     // uniform over the workgroup
+  unsigned long long best = 0ull;                                     // packed (ordered value, ~row): ties go to the smallest row
   for (int p = p0; p < p1; p += RT_STEPS) {
     float av[RT_STEPS], bv[RT_STEPS];
 #pragma unroll
@@ -58,9 +64,19 @@ __global__ __launch_bounds__(64 * RT_WAVES) void ragged_tn_direct_kernel(RaggedT
     }
 #pragma unroll
     for (int u = 0; u < RT_STEPS; ++u) {
-      const bool ok = s_ok && (p + u) < p1 && r0 + 2 * (p + u) + h < r1;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ok ? av[u] : 0.f, bv[u], acc, 0, 0, 0);
+      const int row = r0 + 2 * (p + u) + h;
+      const bool row_ok = (p + u) < p1 && row < r1;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32((row_ok && s_ok) ? av[u] : 0.f, bv[u], acc, 0, 0, 0);
+      if (ro && row_ok) {
+        const unsigned long long q = ((unsigned long long)f32_ordered(bv[u]) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)row);
+        best = q > best ? q : best;
+      }
     }
+  }
+  if (ro) {
+    const unsigned long long o = __shfl_xor(best, 32, 64);            // the other row parity of the same column
+    best = o > best ? o : best;
+    if (h == 0) ro_best[wid][i] = best;
   }
   // the waves' accumulators meet in LDS: element (r, lane) of wave w at (w * 16 + r) * 64 + lane
 #pragma unroll
@@ -76,6 +92,19 @@ __global__ __launch_bounds__(64 * RT_WAVES) void ragged_tn_direct_kernel(RaggedT
     const int c = tn * 32 + (l & 31);
     if (cm < a.K && c < N) out[(int64_t)cm * N + c] = v;
   }
+  if (ro && tid < 32 && cn < N) {
+    unsigned long long m = ro_best[0][tid];
+#pragma unroll
+    for (int w = 1; w < RT_WAVES; ++w) { const unsigned long long o = ro_best[w][tid]; m = o > m ? o : m; }
+    const int sz = r1 - r0;
+    if (a.ro_ghost && sz < a.ro_nmax) {                               // the first padded slot's (zero) row
+      const unsigned long long gq = ((unsigned long long)f32_ordered(0.f) << 32) |
+                                    (unsigned long long)(0xFFFFFFFFu - (unsigned)(a.ro_n_real + sz));
+      m = gq > m ? gq : m;
+    }
+    a.ro_out[(int64_t)b * a.ro_ldo + cn] = m ? ordered_f32((unsigned)(m >> 32)) : 0.f;
+    a.ro_arg[(int64_t)b * N + cn] = m ? (int)(0xFFFFFFFFu - (unsigned)(m & 0xFFFFFFFFull)) : -1;
+  }
 }
 
 }  // namespace
@@ -89,6 +118,18 @@ int tsgnn_ragged_tn_direct_supported(int K, int64_t max_rows) { return K > 0 && 
  * segment (tsgnn_ragged_tn_f32 cuts long segments into slabs instead). */
 int tsgnn_ragged_tn_direct_f32(const float* s_mat, int64_t lds_, int K, const int* graph_ptr, int B, const float* x0, int64_t ldx0,
                                int N0, float* out0, const float* x1, int64_t ldx1, int N1, float* out1, tsgnn_stream_t stream) {
+  return tsgnn_ragged_tn_direct_ro_f32(s_mat, lds_, K, graph_ptr, B, x0, ldx0, N0, out0, x1, ldx1, N1, out1, nullptr, 0, nullptr, 0, 0, 0,
+                                       stream);
+}
+
+/* the same + the max readout of x0 over each segment's node slots (encoders.py:353; trap T5): ro_out [B, N0] (leading dimension
+ * ro_ldo), ro_arg [B, N0] = winning row, from the values the product's workgroups hold anyway.  ghost_zero != 0: a segment shorter
+ * than nmax also has ZERO rows behind the real ones (row n_real + slot for its padded slots — the masked embeddings of a packed
+ * batch): the first of them takes part, as in tsgnn_readout_max_fwd_f32; ghost_zero = 0: the segment's rows are all its slots. */
+int tsgnn_ragged_tn_direct_ro_f32(const float* s_mat, int64_t lds_, int K, const int* graph_ptr, int B, const float* x0, int64_t ldx0,
+                                  int N0, float* out0, const float* x1, int64_t ldx1, int N1, float* out1, float* ro_out,
+                                  int64_t ro_ldo, int* ro_arg, int nmax, int64_t n_real, int ghost_zero, tsgnn_stream_t stream) {
+  if ((ro_out == nullptr) != (ro_arg == nullptr) || (ro_out && (ro_ldo < N0 || nmax <= 0 || n_real < 0))) return TSGNN_EINVAL;
   if (!s_mat || !graph_ptr || !x0 || !out0 || K <= 0 || B <= 0 || N0 <= 0 || lds_ < K || ldx0 < N0) return TSGNN_EINVAL;
   if (x1 && (!out1 || N1 <= 0 || ldx1 < N1)) return TSGNN_EINVAL;
   if (K > 128 || B > 65535) return TSGNN_EUNSUPPORTED;
@@ -97,6 +138,7 @@ int tsgnn_ragged_tn_direct_f32(const float* s_mat, int64_t lds_, int K, const in
   a.x[0] = x0; a.ldx[0] = ldx0; a.N[0] = N0; a.out[0] = out0;
   a.x[1] = x1 ? x1 : x0; a.ldx[1] = x1 ? ldx1 : ldx0; a.N[1] = x1 ? N1 : N0; a.out[1] = x1 ? out1 : out0;
   a.nt0 = (N0 + 31) / 32;
+  a.ro_out = ro_out; a.ro_ldo = ro_ldo; a.ro_arg = ro_arg; a.ro_nmax = nmax; a.ro_n_real = n_real; a.ro_ghost = ghost_zero;
   const int nt = a.nt0 + (x1 ? (N1 + 31) / 32 : 0);
   const int mt = (K + 31) / 32;
   TSGNN_KNAME("ragged_tn_direct_kernel");

@@ -47,6 +47,7 @@ FUSED_HEAD = True              # the two chained nn.Linear after the readout as 
 FUSED_DENSE_POST = True       # pooled DiffPool levels: transform + normalise + ReLU + slot BN as one node
 FUSED_DENSE_STACK = True    # pooled DiffPool levels: the whole GCN stack as one autograd node (dense_stack.py)
 READOUT_PASS = True            # DiffPool: readout backward and the contraction's gradient of the same embeddings in one pass
+READOUT_IN_CONTRACT = os.environ.get("TSGNN_READOUT_IN_CONTRACT", "1") != "0"   # ... and inside the contraction's node (no backward pass of its own)
 READOUT_COLUMNS = os.environ.get("TSGNN_READOUT_COLUMNS", "1") != "0"   # DiffPool: the levels' readouts written into one buffer (no cat)
 FUSED_STACK = True             # GcnEncoderGraph: run the conv stack as one fused autograd node when it qualifies
 DENSE_ADJ_MAX_NODES = 128      # at or below this many nodes per graph a dense batched MFMA product is used
@@ -422,9 +423,15 @@ class SoftPoolingGcnEncoder(GcnEncoderGraph):
             emb = self.gcn_forward_rows(x, g, self.conv_first, self.conv_block, self.conv_last, mask_ghost=masked)
         # the levels' readouts land in their column blocks of ONE buffer (no torch.cat launch; mp.ReadoutColumns)
         cols = mp.ReadoutColumns(g.B, emb.size(1) * (self.num_pooling + 1), emb.device) if (self.concat and READOUT_COLUMNS) else None
-        if self.num_pooling > 0 and READOUT_PASS:
-            # the embeddings feed the readout AND the contraction: one backward pass sums both gradients (mp._ReadoutMax);
+        ro_next = None              # (READOUT_IN_CONTRACT) the readout of this level's embeddings, made by the contraction that reads them
+        if self.num_pooling > 0 and READOUT_PASS and READOUT_IN_CONTRACT:
+            # the embeddings feed the readout AND the contraction: the readout is a third output of the contraction's node and its
+            # gradient is added inside the launch that produces the embeddings' gradient (diffpool._ContractRows / _ContractDense);
             # masked: the ghost rows of `emb` are constants (zeros), their gradient is discarded by the stack's backward
+            ro_next = (bool(masked and g.n_ghost), cols and cols.take(emb.size(1)), bool(masked and g.n_ghost))
+            out_all = []
+        elif self.num_pooling > 0 and READOUT_PASS:
+            # ... or a node of its own that passes the embeddings through: one backward pass sums both gradients (mp._ReadoutMax)
             ro, emb = mp.readout_max_pass(emb, g, ghost_unused=bool(masked and g.n_ghost), into=cols and cols.take(emb.size(1)))
             out_all = [ro]
         else:
@@ -441,7 +448,12 @@ class SoftPoolingGcnEncoder(GcnEncoderGraph):
                                    g.n_rows if (masked and g.n_ghost) else None)              # :371 (ghost rows -> 0)
                 self.assign_tensor = s
                 self._link_graph, self._link_masked = g, masked
-                dense_x, dense_adj = dp.diffpool_contract_rows(s, emb, g)                     # :374-375
+                if ro_next is not None:
+                    dense_x, dense_adj, ro = dp.diffpool_contract_rows(s, emb, g, readout=ro_next)     # :374-375 (+ :353)
+                    out_all.append(ro)
+                    ro_next = None
+                else:
+                    dense_x, dense_adj = dp.diffpool_contract_rows(s, emb, g)                 # :374-375
             else:
                 if a_next is not None:
                     a = a_next                  # came out of the launch that ran this level's embedding stack
@@ -451,7 +463,12 @@ class SoftPoolingGcnEncoder(GcnEncoderGraph):
                 Bq, Kq, Cq = a.shape
                 s = dp.row_softmax(mp.linear_oi(a.reshape(Bq * Kq, Cq), lin.weight, lin.bias)).reshape(Bq, Kq, -1)
                 self.assign_tensor = s
-                dense_x, dense_adj = dp.diffpool_contract_dense(s, emb_dense, dense_adj)
+                if ro_next is not None:
+                    dense_x, dense_adj, ro = dp.diffpool_contract_dense(s, emb_dense, dense_adj, readout=ro_next)
+                    out_all.append(ro)
+                    ro_next = None
+                else:
+                    dense_x, dense_adj = dp.diffpool_contract_dense(s, emb_dense, dense_adj)
             a_next = None
             emb_convs = [self.conv_first_after_pool[i]] + list(self.conv_block_after_pool[i]) + [self.conv_last_after_pool[i]]
             if i + 1 < self.num_pooling and FUSED_DENSE_STACK and self.bn and not self.per_graph_bn:
@@ -470,7 +487,9 @@ class SoftPoolingGcnEncoder(GcnEncoderGraph):
                 emb_dense, gd = self.gcn_forward_dense(dense_x, dense_adj, self.conv_first_after_pool[i],
                                                        self.conv_block_after_pool[i], self.conv_last_after_pool[i])
             Bq, Kq, Cq = emb_dense.shape
-            if i + 1 < self.num_pooling and READOUT_PASS:
+            if i + 1 < self.num_pooling and READOUT_PASS and READOUT_IN_CONTRACT:
+                ro_next = (gd, cols and cols.take(Cq))         # made by the next level's contraction
+            elif i + 1 < self.num_pooling and READOUT_PASS:
                 ro, e2 = mp.readout_max_pass(emb_dense.reshape(Bq * Kq, Cq), gd, into=cols and cols.take(Cq))
                 emb_dense = e2.reshape(Bq, Kq, Cq)
                 out_all.append(ro)

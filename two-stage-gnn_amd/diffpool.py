@@ -92,34 +92,57 @@ class _ContractDense(torch.autograd.Function):
     batched products themselves (composed from bmm nodes autograd adds them with two element-wise launches)."""
 
     @staticmethod
-    def forward(ctx, s, z, adj):
+    def forward(ctx, s, z, adj, ro=None):
         s, z, adj = s.contiguous(), z.contiguous(), adj.contiguous()
         B, N, K, F = s.size(0), s.size(1), s.size(2), z.size(2)
         ctx.fused = bool(FUSED_CONTRACT and s.is_cuda and nat.lib().tsgnn_contract_dense_supported(int(N), int(K), int(F)))
+        ctx.ro = None
+        out = arg = None
+        if ro is not None:                                     # the max readout of z is part of this node (see diffpool_contract_dense)
+            gd, into = ro
+            ctx.ro = gd
+            ctx.set_materialize_grads(False)
+            if ctx.fused:                                      # ... and of its launch: the staged operand is scanned in LDS
+                out = into.t if into is not None else _f32(B, F, device=s.device)
+                arg = torch.empty(B, F, dtype=torch.int32, device=s.device)
+            else:
+                out, arg = mp.readout_fwd_raw(z.reshape(B * N, F), gd, into)
         if ctx.fused:                                          # one workgroup per graph, operands in LDS: one launch each way
             xo, ao, t = _f32(B, K, F, device=s.device), _f32(B, K, K, device=s.device), _f32(B, K, N, device=s.device)
-            nat.call("contract_dense_fwd_f32", s, z, adj, B, N, K, F, xo, ao, t)
-            ctx.save_for_backward(s, z, adj, t)
-            return xo, ao
-        xo = _bmm_raw(s, z, True, False)
-        t = _bmm_raw(s, adj, True, False)                      # S^T A
-        ao = _bmm_raw(t, s, False, False)
+            nat.call("contract_dense_fwd_ro_f32", s, z, adj, B, N, K, F, xo, ao, t, out, out.stride(0) if out is not None else 0, arg)
+        else:
+            xo = _bmm_raw(s, z, True, False)
+            t = _bmm_raw(s, adj, True, False)                  # S^T A
+            ao = _bmm_raw(t, s, False, False)
+        if ro is not None:
+            ctx.save_for_backward(s, z, adj, t, arg)
+            return xo, ao, out
         ctx.save_for_backward(s, z, adj, t)
         return xo, ao
 
     @staticmethod
-    def backward(ctx, dxo, dao):
-        s, z, adj, t = ctx.saved_tensors
+    def backward(ctx, dxo, dao, dro=None):
+        s, z, adj, t = ctx.saved_tensors[:4]
+        arg = ctx.saved_tensors[4] if ctx.ro is not None else None
+        B, N, K, F = s.size(0), s.size(1), s.size(2), z.size(2)
+        if ctx.ro is not None and (dxo is None or dao is None):   # (materialisation is off for the readout's sake)
+            dxo = dxo if dxo is not None else torch.zeros(B, K, F, device=s.device)
+            dao = dao if dao is not None else torch.zeros(B, K, K, device=s.device)
         dxo, dao = dxo.contiguous(), dao.contiguous()
-        ns, nz, na = ctx.needs_input_grad
+        ns, nz, na = ctx.needs_input_grad[:3]
         ds = dz = dadj = None
         if ctx.fused:
-            B, N, K, F = s.size(0), s.size(1), s.size(2), z.size(2)
             ds = torch.empty_like(s) if ns else None
             dz = torch.empty_like(z) if nz else None
             dadj = torch.empty_like(adj) if na else None
+            if dro is not None and nz:
+                dro = mp.readout_dout_in_place(dro)
+                if nat.try_call("contract_dense_bwd_ro_f32", s, z, adj, t, dxo, dao, B, N, K, F, ds, dz, dadj, dro, dro.stride(0), arg):
+                    return ds, dz, dadj, None                  # the readout's gradient rode in the dz pass
             nat.call("contract_dense_bwd_f32", s, z, adj, t, dxo, dao, B, N, K, F, ds, dz, dadj)
-            return ds, dz, dadj
+            if dro is not None and nz:
+                dz = mp.readout_bwd_raw(dro, arg, ctx.ro, B * N, False, dpass=dz.reshape(B * N, F)).reshape(B, N, F)
+            return ds, dz, dadj, None
         if nz:
             dz = _bmm_raw(s, dxo, False, False)                # X' = S^T Z : dZ = S dX'
         if ns or na:
@@ -130,12 +153,16 @@ class _ContractDense(torch.autograd.Function):
             _bmm_raw(adj, dt, False, True, out=ds)             # T = S^T A : dS += A dT^T
         if na:
             dadj = _bmm_raw(s, dt, False, False)               #             dA  = S dT
-        return ds, dz, dadj
+        if dro is not None and nz:
+            dz = mp.readout_bwd_raw(dro, arg, ctx.ro, B * N, False, dpass=dz.reshape(B * N, F)).reshape(B, N, F)
+        return ds, dz, dadj, None
 
 
-def diffpool_contract_dense(s, z, adj):
-    """encoders.py:374-375 on dense [B,N,*] tensors: (S^T Z, S^T A S)."""
-    return _ContractDense.apply(s, z, adj)
+def diffpool_contract_dense(s, z, adj, readout=None):
+    """encoders.py:374-375 on dense [B,N,*] tensors: (S^T Z, S^T A S).  readout = (uniform GraphBatch of z's rows, column block or
+    None): the max readout of z over each graph's nodes (:383) becomes a third output of the SAME node, so that its gradient is
+    added inside the launch that produces dz (no pass of its own over the rows)."""
+    return _ContractDense.apply(s, z, adj, readout)
 
 
 # ----------------------------------------------------------------------------- ragged (row-layout) contraction
@@ -188,50 +215,92 @@ class _ContractRows(torch.autograd.Function):
     """X'[b] = S_b^T Z_b ;  A'[b] = S_b^T (A S)_b   over the real rows of every graph."""
 
     @staticmethod
-    def forward(ctx, S, Z, g):
+    def forward(ctx, S, Z, g, ro=None):
         S, Z = S.contiguous(), Z.contiguous()
-        AS = mp.spmm_raw(g.rowptr, g.col, g.val, S, g.total_rows)
+        ctx.ro = None
+        out = arg = None
         K, F = S.size(1), Z.size(1)
+        direct = bool(RAGGED_DIRECT and g.n_rows > 0 and nat.lib().tsgnn_ragged_tn_direct_supported(int(K), int(g.sizes.max())))
+        ro_in_launch = False
+        if ro is not None:                                     # the max readout of Z is part of this node (see diffpool_contract_rows)
+            ghost_unused, into, ghost_zero = ro
+            ctx.ro = (bool(ghost_unused),)
+            ctx.set_materialize_grads(False)
+            # ... and of the products' launch when the padded slots' rows are known (none, or zeros)
+            ro_in_launch = direct and (g.n_ghost == 0 or bool(ghost_zero))
+            if not ro_in_launch:
+                out, arg = mp.readout_fwd_raw(Z, g, into)
+        AS = mp.spmm_raw(g.rowptr, g.col, g.val, S, g.total_rows)
         xo = ao = None
-        if RAGGED_DIRECT and g.n_rows > 0 and nat.lib().tsgnn_ragged_tn_direct_supported(int(K), int(g.sizes.max())):
-            # both products in one launch, a workgroup per (column tile, graph): no slabs, no reduction launches (ragged.hip)
+        if direct:
+            # both products in one launch, a workgroup per (32 x 32 output tile, graph): no slabs, no reduction launches (ragged.hip)
             xo, ao = _f32(g.B, K, F, device=S.device), _f32(g.B, K, K, device=S.device)
-            if not nat.try_call("ragged_tn_direct_f32", S, S.stride(0), K, g.graph_ptr, g.B, Z, Z.stride(0), F, xo, AS, AS.stride(0), K, ao):
+            if ro_in_launch:
+                out = into.t if into is not None else _f32(g.B, F, device=S.device)
+                arg = torch.empty(g.B, F, dtype=torch.int32, device=S.device)
+            if not nat.try_call("ragged_tn_direct_ro_f32", S, S.stride(0), K, g.graph_ptr, g.B, Z, Z.stride(0), F, xo, AS, AS.stride(0), K, ao,
+                                out if ro_in_launch else None, out.stride(0) if ro_in_launch else 0, arg if ro_in_launch else None,
+                                g.nmax, g.n_rows, 1 if g.n_ghost else 0):
                 xo = ao = None
+                if ro_in_launch:
+                    out, arg = mp.readout_fwd_raw(Z, g, into)
         if xo is None:
             xo = _ragged_tn(S, Z, g)
             ao = _ragged_tn(S, AS, g)
         ctx.g = g
+        if ro is not None:
+            ctx.save_for_backward(S, Z, AS, arg)
+            return xo, ao, out
         ctx.save_for_backward(S, Z, AS)
         return xo, ao
 
     @staticmethod
-    def backward(ctx, dxo, dao):
-        S, Z, AS = ctx.saved_tensors
+    def backward(ctx, dxo, dao, dro=None):
+        S, Z, AS = ctx.saved_tensors[:3]
+        arg = ctx.saved_tensors[3] if ctx.ro is not None else None
         g = ctx.g
-        dxo, dao = dxo.contiguous(), dao.contiguous()
         R, K, F = S.size(0), S.size(1), Z.size(1)
+        if ctx.ro is not None and (dxo is None or dao is None):   # (materialisation is off for the readout's sake)
+            dxo = dxo if dxo is not None else torch.zeros(g.B, K, F, device=S.device)
+            dao = dao if dao is not None else torch.zeros(g.B, K, K, device=S.device)
+        dxo, dao = dxo.contiguous(), dao.contiguous()
+        # the readout's gradient: inside the fused launch when the caller discards the ghost rows' share (or there are none)
+        ro_fold = dro is not None and (g.n_ghost == 0 or ctx.ro[0])
         if (FUSED_CONTRACT and S.is_cuda and nat.lib().tsgnn_contract_rows_bwd_supported(int(K), int(F)) and Z.stride(0) % 4 == 0
                 and S.stride(0) % 4 == 0 and all(t.data_ptr() % 16 == 0 for t in (S, Z, AS, dxo, dao))):
             # the three row-ragged products (+ their zero fills) as one launch: one workgroup per 32-row slab of one graph
             srp, slab_graph, nslab = _slabs32(g)
             dZ, dS, dAS = _f32(R, F, device=S.device), _f32(R, K, device=S.device), _f32(R, K, device=S.device)
-            nat.call("contract_rows_bwd_f32", S, S.stride(0), Z, Z.stride(0), AS, AS.stride(0), dxo, dao, srp, slab_graph, nslab, K, F,
-                     dZ, dZ.stride(0), dS, dS.stride(0), dAS, dAS.stride(0), g.n_rows, R)
+            folded = False
+            if ro_fold:
+                dro_ = mp.readout_dout_in_place(dro)
+                folded = bool(dro_.stride(0) % 4 == 0 and dro_.data_ptr() % 16 == 0 and nat.try_call(
+                    "contract_rows_bwd_ro_f32", S, S.stride(0), Z, Z.stride(0), AS, AS.stride(0), dxo, dao, srp, slab_graph, nslab, K, F,
+                    dZ, dZ.stride(0), dS, dS.stride(0), dAS, dAS.stride(0), g.n_rows, R, dro_, dro_.stride(0), arg))
+            if not folded:
+                nat.call("contract_rows_bwd_f32", S, S.stride(0), Z, Z.stride(0), AS, AS.stride(0), dxo, dao, srp, slab_graph, nslab, K, F,
+                         dZ, dZ.stride(0), dS, dS.stride(0), dAS, dAS.stride(0), g.n_rows, R)
+                if dro is not None:
+                    dZ = mp.readout_bwd_raw(dro, arg, g, R, ctx.ro[0], dpass=dZ)
             rp, col, val = g.transposed()
             mp.spmm_raw(rp, col, val, dAS, g.total_rows, out=dS, accumulate=True)     # AS = A S  : dS += A^T d(AS)
-            return dS, dZ, None
+            return dS, dZ, None, None
         dZ = _ragged_nn(S, dxo, g, False, F, R)                     # dZ_b = S_b dX'_b
         dS = _ragged_nn(Z, dxo, g, True, K, R)                      # S^T Z     : dS_b  = Z_b dX'_b^T
         _ragged_nn(AS, dao, g, True, K, R, out=dS)                  # S^T (AS)  : dS_b += (AS)_b dA'_b^T   (accumulated in place)
         dAS = _ragged_nn(S, dao, g, False, K, R)                    #             d(AS)_b = S_b dA'_b
         rp, col, val = g.transposed()
         mp.spmm_raw(rp, col, val, dAS, g.total_rows, out=dS, accumulate=True)     # AS = A S  : dS += A^T d(AS)
-        return dS, dZ, None
+        if dro is not None:
+            dZ = mp.readout_bwd_raw(dro, arg, g, R, ctx.ro[0], dpass=dZ)
+        return dS, dZ, None, None
 
 
-def diffpool_contract_rows(S, Z, g):
-    return _ContractRows.apply(S, Z, g)
+def diffpool_contract_rows(S, Z, g, readout=None):
+    """readout = (ghost_unused, column block or None, ghost_zero): the max readout of Z (encoders.py:353) as a third output of the
+    same node — made by the products' launch when the padded slots' rows are known to be zeros (ghost_zero: masked embeddings) or
+    absent, and its gradient is added inside the launch that produces dZ (ghost_unused: the caller discards the ghost rows' share)"""
+    return _ContractRows.apply(S, Z, g, readout)
 
 
 # ----------------------------------------------------------------------------- link-prediction side loss (f4)

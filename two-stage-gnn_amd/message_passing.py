@@ -608,6 +608,44 @@ def _readout_ws(g, F, dev):
     return ws
 
 
+def readout_fwd_raw(x, g, into=None):
+    """(out [B, F], arg [B, F]) of the max readout, no autograd; ``into``: the column block of a ReadoutColumns buffer to write"""
+    x = _check(x, g.total_rows)
+    F = x.size(1)
+    out = into.t if into is not None else _f32(g.B, F, device=x.device)
+    arg = torch.empty(g.B, F, dtype=torch.int32, device=x.device)
+    nat.call("readout_max_fwd_f32", g.graph_ptr, g.slot_count, g.B, g.nmax, g.n_rows, g.n_ghost, x, x.stride(0),
+             F, 0, _readout_ws(g, F, x.device), out, out.stride(0), arg)
+    return out, arg
+
+
+def readout_dout_in_place(dout):
+    """the readout's gradient as the kernels read it: a column slice of the concatenated readouts' gradient stays where it is"""
+    if dout.stride(1) != 1 or dout.stride(0) < dout.size(1):
+        dout = dout.contiguous()
+    return dout
+
+
+def readout_bwd_raw(dout, arg, g, rows, ghost_unused, dpass=None):
+    """gradient of the rows [rows, F] from the readout's (dout, arg), summed with ``dpass`` (a second gradient of the same rows)"""
+    dout = readout_dout_in_place(dout)
+    F = dout.size(1)
+    dense_ok = (F % 4 == 0 and dout.stride(0) % 4 == 0 and dout.data_ptr() % 16 == 0 and g.row_graph is not None
+                and (g.n_ghost == 0 or ghost_unused) and rows >= g.n_rows)
+    if dpass is not None and dense_ok:
+        dpass = dpass if (dpass.stride(1) == 1 and dpass.stride(0) % 4 == 0 and dpass.data_ptr() % 16 == 0) else dpass.contiguous()
+    if dense_ok:
+        dx = _f32(rows, F, device=dout.device)              # one dense pass writes every element
+        nat.call("readout_max_bwd_rows_f32", dout, dout.stride(0), arg, g.row_graph, F, g.n_rows, rows, dpass,
+                 dpass.stride(0) if dpass is not None else 0, dx, dx.stride(0))
+        return dx
+    dx = _f32(rows, F, device=dout.device, zero=True)
+    nat.call("readout_max_bwd_f32", dout, dout.stride(0), arg, g.B, F, None, 0, 0, g.n_rows, dx, dx.stride(0))
+    if dpass is not None:
+        dx = dx + dpass
+    return dx
+
+
 class _ReadoutMax(torch.autograd.Function):
     """out[b] = max over ALL nmax node slots of graph b (ghost rows included) — encoders.py:183 (trap T5).
     passthrough: also returns x itself as a second differentiable output for the OTHER consumer of the same tensor (DiffPool's
@@ -617,12 +655,7 @@ class _ReadoutMax(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, g, passthrough, ghost_unused, into=None):
-        x = _check(x, g.total_rows)
-        F = x.size(1)
-        out = into.t if into is not None else _f32(g.B, F, device=x.device)
-        arg = torch.empty(g.B, F, dtype=torch.int32, device=x.device)
-        nat.call("readout_max_fwd_f32", g.graph_ptr, g.slot_count, g.B, g.nmax, g.n_rows, g.n_ghost, x, x.stride(0),
-                 F, 0, _readout_ws(g, F, x.device), out, out.stride(0), arg)
+        out, arg = readout_fwd_raw(x, g, into)
         ctx.g = g
         ctx.rows = x.size(0)
         ctx.ghost_unused = bool(ghost_unused)
@@ -636,26 +669,9 @@ class _ReadoutMax(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout, _darg, dpass=None):
         (arg,) = ctx.saved_tensors
-        g = ctx.g
         if dout is None:
             return dpass, None, None, None, None
-        if dout.stride(1) != 1 or dout.stride(0) < dout.size(1):
-            dout = dout.contiguous()                     # (a column slice of the concatenated readouts' gradient is read in place)
-        F = dout.size(1)
-        dense_ok = (F % 4 == 0 and dout.stride(0) % 4 == 0 and dout.data_ptr() % 16 == 0 and g.row_graph is not None
-                    and (g.n_ghost == 0 or ctx.ghost_unused) and ctx.rows >= g.n_rows)
-        if dpass is not None and dense_ok:
-            dpass = dpass if (dpass.stride(1) == 1 and dpass.stride(0) % 4 == 0 and dpass.data_ptr() % 16 == 0) else dpass.contiguous()
-        if dense_ok:
-            dx = _f32(ctx.rows, F, device=dout.device)              # one dense pass writes every element
-            nat.call("readout_max_bwd_rows_f32", dout, dout.stride(0), arg, g.row_graph, F, g.n_rows, ctx.rows, dpass,
-                     dpass.stride(0) if dpass is not None else 0, dx, dx.stride(0))
-            return dx, None, None, None, None
-        dx = _f32(ctx.rows, F, device=dout.device, zero=True)
-        nat.call("readout_max_bwd_f32", dout, dout.stride(0), arg, g.B, F, None, 0, 0, g.n_rows, dx, dx.stride(0))
-        if dpass is not None:
-            dx = dx + dpass
-        return dx, None, None, None, None
+        return readout_bwd_raw(dout, arg, ctx.g, ctx.rows, ctx.ghost_unused, dpass), None, None, None, None
 
 
 def readout_max(x, g, return_arg=False, into=None):
