@@ -1059,6 +1059,7 @@ def test_diffpool_glue_variants_agree(monkeypatch):
     for on in (False, True, False):                     # (the first pass also builds the batch's lazily built structures)
         monkeypatch.setattr(E, "READOUT_COLUMNS", on)
         monkeypatch.setattr(E, "READOUT_IN_CONTRACT", on)
+        monkeypatch.setattr(mp, "HEAD_TAIL", on)
         monkeypatch.setattr(sage_stack, "ZERO_RIDER", on)
         monkeypatch.setattr(dp, "RAGGED_DIRECT", on)
         m.zero_grad(set_to_none=True)
@@ -1075,10 +1076,10 @@ def test_diffpool_glue_variants_agree(monkeypatch):
     mp.check_device_errors()
     (a1, b1, l1, g1, n1), (a0, b0, l0, g0, n0) = res[1:]
     assert "sage_multi_zero_f32" in n1 and "sage_multi_zero_f32" not in n0
-    assert "contract_rows_bwd_ro_f32" in n1 and "contract_dense_bwd_ro_f32" in n1 and n1.count("readout_max_bwd_rows_f32") == 1
-    assert n0.count("readout_max_bwd_rows_f32") == 3
+    assert "contract_rows_bwd_ro_f32" in n1 and "contract_dense_bwd_ro_f32" in n1 and n1.count("readout_max_bwd_rows_f32") == 0
+    assert "head2_fwd_ro_f32" in n1 and "head2_bwd_ro_f32" in n1 and n0.count("readout_max_bwd_rows_f32") == 3
     assert "ragged_tn_direct_ro_f32" in n1 and n1.count("ragged_tn_f32") == 0 and n0.count("ragged_tn_f32") == 2
-    assert n1.count("readout_max_fwd_f32") == 1 and n0.count("readout_max_fwd_f32") == 3
+    assert n1.count("readout_max_fwd_f32") == 0 and n0.count("readout_max_fwd_f32") == 3
     assert len(n1) <= len(n0) - 1
     torch.testing.assert_close(a1, a0, rtol=2e-5, atol=2e-6)
     torch.testing.assert_close(b1, b0, rtol=2e-5, atol=2e-6)

@@ -53,15 +53,46 @@ __device__ __forceinline__ void head2_fwd_tail(const float* xs, float* vs, int b
   }
 }
 
-__global__ __launch_bounds__(64 * HW) void head2_fwd_kernel(const float* __restrict__ out, int64_t ldo, const float* __restrict__ w1,
+// the max readout of a LAST uniform level (N <= 64 rows per graph: rows b * N + n of z) that fills columns [c0, c0 + F) of the
+// head's input inside the head's own launches (DiffPool's last pooled level, encoders.py:383,388-391)
+struct RoTail {
+  const float* z; int64_t ldz; int N, c0, F;
+  int* arg;                         // [B, F] winning rows (forward: written; backward: read)
+  float* dz; int64_t lddz;          // backward: gradient of z's rows, every element written
+};
+
+__global__ __launch_bounds__(64 * HW) void head2_fwd_kernel(float* __restrict__ out, int64_t ldo, const float* __restrict__ w1,
                                                         const float* __restrict__ b1, const float* __restrict__ w2,
                                                         const float* __restrict__ b2, int P, int E, int C,
-                                                        float* __restrict__ vec, float* __restrict__ y) {
+                                                        float* __restrict__ vec, float* __restrict__ y, RoTail rt) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* xs = smem;                 // [P]
   float* vs = smem + ((P + 3) & ~3);  // [E]
   const int b = blockIdx.x, tid = threadIdx.x;
-  for (int k = tid; k < P; k += 64 * HW) xs[k] = out[(int64_t)b * ldo + k];
+  const int c0 = rt.z ? rt.c0 : P;
+  for (int k = tid; k < P; k += 64 * HW) {
+    if (k < c0) { xs[k] = out[(int64_t)b * ldo + k]; continue; }
+    // column f of the tail: the same packed (value, row) order as readout_max_direct (bn_readout.hip), rows in batches of 16
+    const int f = k - c0;
+    unsigned long long best = 0ull;
+    for (int n0 = 0; n0 < rt.N; n0 += 16) {
+      float val[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) val[u] = rt.z[((int64_t)b * rt.N + min(n0 + u, rt.N - 1)) * rt.ldz + f];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        if (n0 + u < rt.N) {
+          const unsigned long long q = ((unsigned long long)f32_ordered(val[u]) << 32) |
+                                       (unsigned long long)(0xFFFFFFFFu - (unsigned)(b * rt.N + n0 + u));
+          best = q > best ? q : best;
+        }
+      }
+    }
+    const float v = best ? ordered_f32((unsigned)(best >> 32)) : 0.f;
+    xs[k] = v;
+    out[(int64_t)b * ldo + k] = v;
+    rt.arg[(int64_t)b * rt.F + f] = best ? (int)(0xFFFFFFFFu - (unsigned)(best & 0xFFFFFFFFull)) : -1;
+  }
   __syncthreads();
   head2_fwd_tail(xs, vs, b, w1, b1, w2, b2, P, E, C, vec, y);
 }
@@ -615,7 +646,7 @@ __global__ __launch_bounds__(64 * HW) void head2_bwd2_kernel(const float* __rest
                                                          const float* __restrict__ w1, const float* __restrict__ w2, int B, int P, int E,
                                                          int C, float* __restrict__ dout, int64_t lddo, float* __restrict__ dw1,
                                                          float* __restrict__ db1, float* __restrict__ dw2, float* __restrict__ db2,
-                                                         float* __restrict__ normparts, CeArgs ce, DuArgs dua) {
+                                                         float* __restrict__ normparts, CeArgs ce, DuArgs dua, RoTail rt) {
   extern __shared__ __attribute__((aligned(16))) float smem_all[];
   const int tid = threadIdx.x, NTH = 64 * HW;
   const int P4 = P >> 2, PP = P;                         // P % 4 == 0 on this path
@@ -704,6 +735,11 @@ __global__ __launch_bounds__(64 * HW) void head2_bwd2_kernel(const float* __rest
       float a = 0.f;
       for (int q = 0; q < G; ++q) a += part[q * PP + k];
       dout[(int64_t)b * lddo + k] = a;
+      if (rt.dz && k >= rt.c0 && k < rt.c0 + rt.F) {     // the tail readout's backward: graph b's rows of dz, every element
+        const int f = k - rt.c0;
+        const int win = rt.arg[(int64_t)b * rt.F + f];
+        for (int n = 0; n < rt.N; ++n) rt.dz[((int64_t)b * rt.N + n) * rt.lddz + f] = (b * rt.N + n) == win ? a : 0.f;
+      }
     }
     return;
   }
@@ -832,7 +868,24 @@ int tsgnn_head2_fwd_f32(const float* out, int64_t ldo, const float* w1, const fl
   if ((P % 4) || P > 4096 || E > 4096 || (reinterpret_cast<uintptr_t>(w1) & 15)) return TSGNN_EUNSUPPORTED;
   const size_t lds = sizeof(float) * (size_t)(((P + 3) & ~3) + E);
   TSGNN_KNAME("head2_fwd_kernel");
-  head2_fwd_kernel<<<B, 64 * HW, lds, stream>>>(out, ldo, w1, b1, w2, b2, P, E, C, vec, y);
+  head2_fwd_kernel<<<B, 64 * HW, lds, stream>>>(const_cast<float*>(out), ldo, w1, b1, w2, b2, P, E, C, vec, y, RoTail{});
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+/* tsgnn_head2_fwd_f32 whose launch first FILLS columns [c0, c0 + F) of its input with the max readout of a uniform level —
+ * out[b, c0 + f] = max_n z[b * N + n, f], arg[b, f] = the winning row (what tsgnn_readout_max_fwd_f32 returns for the uniform batch
+ * (B, N), N <= 64) — DiffPool's last pooled level (encoders.py:383,388-391) without a readout launch */
+int tsgnn_head2_fwd_ro_f32(float* out, int64_t ldo, const float* w1, const float* b1, const float* w2, const float* b2, int B, int P,
+                           int E, int C, float* vec, float* y, const float* z, int64_t ldz, int N, int c0, int F, int* arg,
+                           tsgnn_stream_t stream) {
+  if (!out || !w1 || !w2 || !vec || !y || !z || !arg || B <= 0 || P <= 0 || E <= 0 || C <= 0 || ldo < P || N <= 0 || F <= 0 || c0 < 0 ||
+      c0 + F != P || ldz < F)
+    return TSGNN_EINVAL;
+  if ((P % 4) || P > 4096 || E > 4096 || N > 64 || (reinterpret_cast<uintptr_t>(w1) & 15)) return TSGNN_EUNSUPPORTED;
+  const size_t lds = sizeof(float) * (size_t)(((P + 3) & ~3) + E);
+  TSGNN_KNAME("head2_fwd_kernel(ro)");
+  head2_fwd_kernel<<<B, 64 * HW, lds, stream>>>(out, ldo, w1, b1, w2, b2, P, E, C, vec, y, RoTail{z, ldz, N, c0, F, arg, nullptr, 0});
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }
@@ -894,7 +947,7 @@ int tsgnn_packed_head_fwd_z_f32(unsigned long long* packed, int B, int L, int Fh
 static int head2_bwd_launch(const float* out, int64_t ldo, const float* vec, const float* dy, const float* dvec, const float* w1,
                             const float* w2, int B, int P, int E, int C, float* dout, int64_t lddo, float* dw1, float* db1,
                             float* dw2, float* db2, float* normparts, const float* ce_y, const int64_t* ce_label, float* ce_loss,
-                            tsgnn_stream_t stream, const DuArgs* du = nullptr) {
+                            tsgnn_stream_t stream, const DuArgs* du = nullptr, const RoTail* rtail = nullptr) {
   if (!out || !vec || (!dy && !ce_label) || !w1 || !w2 || !dout || !dw1 || !dw2 || B <= 0 || P <= 0 || E <= 0 || C <= 0) return TSGNN_EINVAL;
   if (ce_label && (!ce_y || !ce_loss)) return TSGNN_EINVAL;
   if ((P % 4) || P > 2048 || E > 4096 || B > 1024 || (reinterpret_cast<uintptr_t>(w1) & 15)) return TSGNN_EUNSUPPORTED;
@@ -909,6 +962,7 @@ static int head2_bwd_launch(const float* out, int64_t ldo, const float* vec, con
     if (role < HW) role = HW;
     size_t lds2 = sizeof(float) * role;
     DuArgs dua{};
+    const RoTail rt = rtail ? *rtail : RoTail{};
     unsigned du_blocks = 0;
     int du_chunk = 64;
     if (du) {
@@ -939,16 +993,16 @@ static int head2_bwd_launch(const float* out, int64_t ldo, const float* vec, con
       if (du_chunk == 128)
         head2_bwd2_kernel<128><<<B + (E + 3) / 4 + 1 + du_blocks, 64 * HW, lds2, stream>>>(out, ldo, vec, dy, dvec, w1, w2, B, P, E, C, dout, lddo,
                                                                                         dw1, db1, dw2, db2, normparts,
-                                                                                        CeArgs{ce_y, ce_label, ce_loss}, dua);
+                                                                                        CeArgs{ce_y, ce_label, ce_loss}, dua, rt);
       else
         head2_bwd2_kernel<64><<<B + (E + 3) / 4 + 1 + du_blocks, 64 * HW, lds2, stream>>>(out, ldo, vec, dy, dvec, w1, w2, B, P, E, C, dout, lddo,
                                                                                        dw1, db1, dw2, db2, normparts,
-                                                                                       CeArgs{ce_y, ce_label, ce_loss}, dua);
+                                                                                       CeArgs{ce_y, ce_label, ce_loss}, dua, rt);
       TSGNN_CHECK_LAUNCH();
       return TSGNN_OK;
     }
   }
-  if (du) return TSGNN_EUNSUPPORTED;                   // the dU role rides in the second-generation kernel only
+  if (du || rtail) return TSGNN_EUNSUPPORTED;          // the dU role / the tail readout ride in the second-generation kernel only
   size_t lds = sizeof(float) * (size_t)(((E + 3) & ~3) + HW * ((P + 3) & ~3));
   if (lds < sizeof(float) * (4 * (size_t)B + HW)) lds = sizeof(float) * (4 * (size_t)B + HW);
   if (ce_label) lds += sizeof(float) * (size_t)(((B * C + 3) & ~3) + ((B + 3) & ~3));
@@ -964,6 +1018,19 @@ int tsgnn_head2_bwd_f32(const float* out, int64_t ldo, const float* vec, const f
                         float* dw2, float* db2, float* normparts, tsgnn_stream_t stream) {
   return head2_bwd_launch(out, ldo, vec, dy, dvec, w1, w2, B, P, E, C, dout, lddo, dw1, db1, dw2, db2, normparts, nullptr, nullptr,
                           nullptr, stream);
+}
+
+/* tsgnn_head2_bwd_f32 for a head whose input columns [c0, c0 + F) were filled by tsgnn_head2_fwd_ro_f32: the row block of graph b
+ * also writes the gradient of that level's rows, dz[b * N + n, f] = (arg[b, f] == b * N + n) ? dout[b, c0 + f] : 0, every element
+ * (the pass tsgnn_readout_max_bwd_rows_f32 would make).  TSGNN_EUNSUPPORTED: shapes the second-generation kernel does not take. */
+int tsgnn_head2_bwd_ro_f32(const float* out, int64_t ldo, const float* vec, const float* dy, const float* dvec, const float* w1,
+                           const float* w2, int B, int P, int E, int C, float* dout, int64_t lddo, float* dw1, float* db1,
+                           float* dw2, float* db2, float* normparts, const int* arg, int c0, int F, int N, float* dz, int64_t lddz,
+                           tsgnn_stream_t stream) {
+  if (!arg || !dz || N <= 0 || F <= 0 || c0 < 0 || c0 + F > P || lddz < F) return TSGNN_EINVAL;
+  const RoTail rt{nullptr, 0, N, c0, F, const_cast<int*>(arg), dz, lddz};
+  return head2_bwd_launch(out, ldo, vec, dy, dvec, w1, w2, B, P, E, C, dout, lddo, dw1, db1, dw2, db2, normparts, nullptr, nullptr,
+                          nullptr, stream, nullptr, &rt);
 }
 
 /* the same with the loss folded in: dy = d mean-softmax-cross-entropy(y, label) / dy is rebuilt inside the kernel and the loss

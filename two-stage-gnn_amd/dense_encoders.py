@@ -261,6 +261,14 @@ class GcnEncoderGraph(nn.Module):
         out_all.append(mp.readout_max(x, g))
         return torch.cat(out_all, dim=1) if self.concat else out_all[-1]
 
+    def _head_linears(self):
+        """the two chained nn.Linear after the readout (None for the 2stg setting, whose first output IS the readout)"""
+        if self.final_dim == "pretrain":
+            return self.map_model, self.map2_model
+        if self.final_dim != "output_dim":
+            return self.pre_pred_model, self.pred_model
+        return None
+
     def _heads(self, output):
         if self.final_dim == "pretrain":          # 2stg+
             if FUSED_HEAD and mp.head2_ok(output, self.map_model, self.map2_model):
@@ -494,6 +502,12 @@ class SoftPoolingGcnEncoder(GcnEncoderGraph):
                 emb_dense = e2.reshape(Bq, Kq, Cq)
                 out_all.append(ro)
             else:
+                lins = self._head_linears()
+                if (i + 1 == self.num_pooling and self.concat and lins is not None and FUSED_HEAD and gd.n_ghost == 0
+                        and mp.head2_tail_ok(cols, emb_dense, Kq, *lins)):
+                    # the LAST level's readout fills its column block inside the head's own launches (mp._Head2Tail)
+                    a, b = mp.head2_tail(cols, out_all, emb_dense.reshape(Bq * Kq, Cq), Kq, *lins)
+                    return (b, a) if self.final_dim == "pretrain" else (a, b)
                 out_all.append(mp.readout_max(emb_dense.reshape(Bq * Kq, Cq), gd, into=cols and cols.take(Cq)))
         if not self.concat:
             output = out_all[-1]

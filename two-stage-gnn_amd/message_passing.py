@@ -5,6 +5,8 @@ Each torch.autograd.Function here is a thin host wrapper around C-ABI kernels of
 The reference relies on autograd through dense bmm's (encoders.py:30-42); here every backward is a
 hand-written kernel as SURVEY §8(a) requires.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -941,6 +943,7 @@ def unit_seed(device):
 
 
 # ----------------------------------------------------------------------------- loss
+HEAD_TAIL = os.environ.get("TSGNN_HEAD_TAIL", "1") != "0"     # DiffPool: the last level's max readout inside the head's launches
 CE_DEFER = False        # set by FlatTrainer(defer_loss=True) between zero_grad() and the backward: see _SoftmaxCE
 _deferred_ce = None     # (placeholder gradient, logits, label, loss) handed from _SoftmaxCE.backward to the head node's backward
 
@@ -1040,6 +1043,74 @@ class _Head2(torch.autograd.Function):
         parts = head_norm_slots((s1, s2, s3, s4), ctx.has_b, (pw1, pb1, pw2, pb2), E)
         nat.call("head2_bwd_f32", out, out.stride(0), vec, dy, dvec, w1, w2, B, P, E, C, dout, dout.stride(0), dw1, db1, dw2, db2, parts)
         return dout, None if s1 else dw1, None if s3 else db1, None if s2 else dw2, None if s4 else db2
+
+
+class _Head2Tail(torch.autograd.Function):
+    """_Head2 whose launches also make the max readout of the LAST uniform level: forward(cols, z, N, w1, b1, w2, b2, *parts) — `cols`
+    is the ReadoutColumns buffer whose leading column blocks `parts` were written by their readouts; the launch fills the remaining
+    F = z.size(1) columns with max_n z[b * N + n, :] and runs the head; the backward's launch writes dz (tsgnn_head2_*_ro_f32)."""
+
+    @staticmethod
+    def forward(ctx, cols, z, N, w1, b1, w2, b2, *parts):
+        out = cols.buf
+        w1c, w2c = w1.contiguous(), w2.contiguous()
+        z = _check(z)
+        B, P = out.shape
+        F = z.size(1)
+        E, C = w1c.size(0), w2c.size(0)
+        widths = [p_.size(1) for p_ in parts]
+        c0 = sum(widths)
+        if c0 + F != P or z.size(0) != B * N:
+            raise ValueError("head tail: %d + %d columns for a %d-wide input, %d rows for %d graphs x %d" % (c0, F, P, z.size(0), B, N))
+        vec, y = _f32(B, E, device=out.device), _f32(B, C, device=out.device)
+        arg = torch.empty(B, F, dtype=torch.int32, device=out.device)
+        nat.call("head2_fwd_ro_f32", out, out.stride(0), w1c, b1, w2c, b2, B, P, E, C, vec, y, z, z.stride(0), int(N), c0, F, arg)
+        ctx.save_for_backward(out, w1c, w2c, vec, arg)
+        ctx.has_b = (b1 is not None, b2 is not None)
+        ctx.params = (w1, b1, w2, b2)
+        ctx.geom = (int(N), c0, F, widths)
+        ctx.set_materialize_grads(False)
+        return vec, y
+
+    @staticmethod
+    def backward(ctx, dvec, dy):
+        out, w1, w2, vec, arg = ctx.saved_tensors
+        N, c0, F, widths = ctx.geom
+        B, P = out.shape
+        E, C = w1.size(0), w2.size(0)
+        dev = out.device
+        if dy is None and dvec is None:
+            return (None,) * (7 + len(widths))
+        dy = dy.contiguous() if dy is not None else torch.zeros(B, C, device=dev)
+        dvec = dvec.contiguous() if dvec is not None else None
+        dout = _f32(B, P, device=dev)
+        dz = _f32(B * N, F, device=dev)
+        pw1, pb1, pw2, pb2 = ctx.params
+        dw1, s1 = _sink_or_new(pw1, (E, P), dev)
+        dw2, s2 = _sink_or_new(pw2, (C, E), dev)
+        db1, s3 = _sink_or_new(pb1, (E,), dev) if ctx.has_b[0] else (None, False)
+        db2, s4 = _sink_or_new(pb2, (C,), dev) if ctx.has_b[1] else (None, False)
+        parts = head_norm_slots((s1, s2, s3, s4), ctx.has_b, (pw1, pb1, pw2, pb2), E)
+        if not nat.try_call("head2_bwd_ro_f32", out, out.stride(0), vec, dy, dvec, w1, w2, B, P, E, C, dout, dout.stride(0), dw1, db1, dw2,
+                            db2, parts, arg, c0, F, N, dz, dz.stride(0)):
+            nat.call("head2_bwd_f32", out, out.stride(0), vec, dy, dvec, w1, w2, B, P, E, C, dout, dout.stride(0), dw1, db1, dw2, db2, parts)
+            nat.call("readout_max_bwd_f32", dout[:, c0:], dout.stride(0), arg, B, F, None, 0, 0, B * N, dz.zero_(), dz.stride(0))
+        grads, o = [], 0
+        for w in widths:
+            grads.append(dout[:, o:o + w])                # read in place by the part's backward
+            o += w
+        return (None, dz, None, None if s1 else dw1, None if s3 else db1, None if s2 else dw2, None if s4 else db2) + tuple(grads)
+
+
+def head2_tail_ok(cols, z, N, lin1, lin2):
+    """the last level's readout may ride in the head's launches (tsgnn_head2_fwd_ro_f32 / _bwd_ro_f32)"""
+    return (HEAD_TAIL and cols is not None and cols.c0 >= 0 and cols.c0 + z.size(-1) == cols.buf.size(1) and int(N) <= 64
+            and z.size(-1) % 4 == 0 and head2_ok(cols.buf, lin1, lin2) and cols.buf.size(1) // 4 <= 512)
+
+
+def head2_tail(cols, parts, z, N, lin1, lin2):
+    """(lin1(out), lin2(lin1(out))) with out = [parts | max readout of the uniform level z (N rows per graph)]"""
+    return _Head2Tail.apply(cols, z, int(N), lin1.weight, lin1.bias, lin2.weight, lin2.bias, *parts)
 
 
 def head_norm_slots(sunk, has_b, params, E):
