@@ -837,18 +837,21 @@ int tsgnn_contract_dense_supported(int N, int K, int F);
 int tsgnn_contract_dense_fwd_f32(const float* s, const float* z, const float* adj, int B, int N, int K, int F, float* xo, float* ao,
                                  float* t, tsgnn_stream_t stream);
 /* the same + the max readout of z over each graph's N rows (encoders.py:383) out of the staged operand: ro_out [B, F] (leading
- * dimension ro_ldo), ro_arg [B, F] = winning row b * N + n (what tsgnn_readout_max_fwd_f32 returns for the uniform batch (B, N)) */
+ * dimension ro_ldo), ro_arg [B, F] = winning row b * N + n (what tsgnn_readout_max_fwd_f32 returns for the uniform batch (B, N)); ro_out
+ * nullable.  s_out (nullable) given: `s` holds the assignment LOGITS, S = softmax over the K clusters of every row (nn.Softmax(dim=-1),
+ * encoders.py:369) is formed on the staged operand, used for the products and written to s_out [B, N, K] */
 int tsgnn_contract_dense_fwd_ro_f32(const float* s, const float* z, const float* adj, int B, int N, int K, int F, float* xo, float* ao,
-                                    float* t, float* ro_out, int64_t ro_ldo, int* ro_arg, tsgnn_stream_t stream);
+                                    float* t, float* ro_out, int64_t ro_ldo, int* ro_arg, float* s_out, tsgnn_stream_t stream);
 /* ds [B,N,K], dz [B,N,F], dadj [B,N,N] (each nullable) from dxo [B,K,F], dao [B,K,K] */
 int tsgnn_contract_dense_bwd_f32(const float* s, const float* z, const float* adj, const float* t, const float* dxo, const float* dao,
                                  int B, int N, int K, int F, float* ds, float* dz, float* dadj, tsgnn_stream_t stream);
 /* the same; dz additionally takes the gradient of the max readout of z over each graph's N rows — ro_dout [B, F] (leading dimension
  * ro_ldo), ro_arg [B, F] = winning row b * N + n or -1 — i.e. the pass tsgnn_readout_max_bwd_rows_f32 would make over dz afterwards
- * (the embeddings feed the readout AND the next contraction, encoders.py:383,374) */
+ * (the embeddings feed the readout AND the next contraction, encoders.py:383,374); ro_dout nullable.  softmax != 0: `s` is the softmax the
+ * forward formed from the logits (s_out), and ds is returned as the gradient of the LOGITS, s * (dS - rowsum(s * dS)) */
 int tsgnn_contract_dense_bwd_ro_f32(const float* s, const float* z, const float* adj, const float* t, const float* dxo, const float* dao,
                                     int B, int N, int K, int F, float* ds, float* dz, float* dadj, const float* ro_dout, int64_t ro_ldo,
-                                    const int* ro_arg, tsgnn_stream_t stream);
+                                    const int* ro_arg, int softmax, tsgnn_stream_t stream);
 
 /* backward of the ROW-layout (level 1) contraction X'[b] = S_b^T Z_b, A'[b] = S_b^T (A S)_b (diffpool.py::_ContractRows) in one
  * launch: dZ = S dX', dS = Z dX'^T + (AS) dA'^T, d(AS) = S dA' for the rows of every slab (slab_row_ptr[nslab + 1]: at most 32

@@ -1060,6 +1060,7 @@ def test_diffpool_glue_variants_agree(monkeypatch):
         monkeypatch.setattr(E, "READOUT_COLUMNS", on)
         monkeypatch.setattr(E, "READOUT_IN_CONTRACT", on)
         monkeypatch.setattr(mp, "HEAD_TAIL", on)
+        monkeypatch.setattr(E, "SOFTMAX_IN_CONTRACT", on)
         monkeypatch.setattr(sage_stack, "ZERO_RIDER", on)
         monkeypatch.setattr(dp, "RAGGED_DIRECT", on)
         m.zero_grad(set_to_none=True)
@@ -1080,6 +1081,8 @@ def test_diffpool_glue_variants_agree(monkeypatch):
     assert "head2_fwd_ro_f32" in n1 and "head2_bwd_ro_f32" in n1 and n0.count("readout_max_bwd_rows_f32") == 3
     assert "ragged_tn_direct_ro_f32" in n1 and n1.count("ragged_tn_f32") == 0 and n0.count("ragged_tn_f32") == 2
     assert n1.count("readout_max_fwd_f32") == 0 and n0.count("readout_max_fwd_f32") == 3
+    assert n1.count("row_softmax_masked_fwd_f32") == 1 and n0.count("row_softmax_masked_fwd_f32") == 2
+    assert n1.count("row_softmax_masked_bwd_f32") == 1 and n0.count("row_softmax_masked_bwd_f32") == 2
     assert len(n1) <= len(n0) - 1
     torch.testing.assert_close(a1, a0, rtol=2e-5, atol=2e-6)
     torch.testing.assert_close(b1, b0, rtol=2e-5, atol=2e-6)

@@ -24,7 +24,7 @@ __host__ __device__ inline CtDims ct_dims(int N, int K, int F) { return CtDims{N
 // floats of LDS: S, Z, A, T (+ backward: dX', dA', dT); every region starts on a 16-byte boundary
 inline size_t ct_lds_floats(int N, int K, int F, bool bwd) {
   size_t n = (size_t)ct_up4(N * (K + 1)) + (size_t)ct_up4(N * (F + 1)) + (size_t)ct_up4(N * (N + 1)) + (size_t)ct_up4(K * (N + 1));
-  if (bwd) n += (size_t)K * ct_up4(F) + (size_t)ct_up4(K * (K + 1)) + (size_t)K * ct_up4(N);
+  if (bwd) n += (size_t)K * ct_up4(F) + (size_t)ct_up4(K * (K + 1)) + (size_t)K * ct_up4(N) + (size_t)ct_up4(N * K);   // (+ dS rows: softmax)
   return n;
 }
 // x / d by a float reciprocal and one correction step (exact for x < 2^22, d <= 4096): the element loops below computed a
@@ -106,7 +106,8 @@ __global__ __launch_bounds__(CT_THREADS) void contract_dense_fwd_kernel(const fl
                                                                         const float* __restrict__ adj, int N, int K, int F,
                                                                         float* __restrict__ xo, float* __restrict__ ao,
                                                                         float* __restrict__ t_out, float* __restrict__ ro_out,
-                                                                        int64_t ro_ldo, int* __restrict__ ro_arg) {
+                                                                        int64_t ro_ldo, int* __restrict__ ro_arg,
+                                                                        float* __restrict__ s_out) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const CtDims d = ct_dims(N, K, F);
   float* S = sm;
@@ -126,6 +127,22 @@ __global__ __launch_bounds__(CT_THREADS) void contract_dense_fwd_kernel(const fl
     ct_load(A, d.ldA, ab, N, N);
   }
   __syncthreads();
+  if (s_out) {
+    // `s` holds the assignment LOGITS: S = softmax over the K clusters of every row (nn.Softmax(dim=-1), encoders.py:369), kept
+    // for the backward and the caller (a launch of its own otherwise: 16 x 64 rows of 8 numbers)
+    for (int n = threadIdx.x; n < N; n += CT_THREADS) {
+      float m = -INFINITY;
+      for (int k = 0; k < K; ++k) m = fmaxf(m, S[n * d.ldS + k]);
+      float den = 0.f;
+      for (int k = 0; k < K; ++k) den += expf(S[n * d.ldS + k] - m);
+      for (int k = 0; k < K; ++k) {
+        const float v = expf(S[n * d.ldS + k] - m) / den;
+        S[n * d.ldS + k] = v;
+        s_out[(int64_t)b * N * K + (int64_t)n * K + k] = v;
+      }
+    }
+    __syncthreads();
+  }
   if (ro_out) {
     // max readout of z over the graph's N rows (encoders.py:383), rows b * N + n: the same packed (value, row) order as
     // readout_max_direct (bn_readout.hip) — ties go to the smallest row
@@ -172,7 +189,7 @@ __global__ __launch_bounds__(CT_THREADS) void contract_dense_bwd_kernel(const fl
                                                                         int N, int K, int F, float* __restrict__ ds,
                                                                         float* __restrict__ dz, float* __restrict__ dadj,
                                                                         const float* __restrict__ ro_dout, int64_t ro_ldo,
-                                                                        const int* __restrict__ ro_arg) {
+                                                                        const int* __restrict__ ro_arg, int softmax) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const CtDims d = ct_dims(N, K, F);
   float* S = sm;
@@ -182,6 +199,7 @@ __global__ __launch_bounds__(CT_THREADS) void contract_dense_bwd_kernel(const fl
   float* DX = T + ct_up4(K * d.ldT);   // [K][up4(F)]
   float* DA = DX + K * d.ldDX;         // [K][K+1]
   float* DT = DA + ct_up4(K * d.ldS);  // [K][up4(N)]
+  float* DSL = DT + K * d.ldDT;        // [N][K]  (softmax: the rows of dS meet here)
   const int b = blockIdx.x;
   const float* sb = s + (int64_t)b * N * K;
   const float* dxb = dxo + (int64_t)b * K * F;
@@ -255,7 +273,19 @@ __global__ __launch_bounds__(CT_THREADS) void contract_dense_bwd_kernel(const fl
       for (int f = 0; f < F; ++f) acc = fmaf(Z[n * d.ldZ + f], DX[k * d.ldDX + f], acc);
       for (int l = 0; l < K; ++l) acc = fmaf(T[l * d.ldT + n], DA[l * d.ldS + k], acc);
       for (int m = 0; m < N; ++m) acc = fmaf(A[n * d.ldA + m], DT[k * d.ldDT + m], acc);
-      ds[(int64_t)b * N * K + (int64_t)n * K + k] = acc;
+      if (softmax) DSL[n * K + k] = acc;
+      else ds[(int64_t)b * N * K + (int64_t)n * K + k] = acc;
+    }
+    if (softmax) {
+      // S = softmax(logits): d logits[n, k] = S[n, k] * (dS[n, k] - sum_l S[n, l] dS[n, l])   (row_softmax_bwd, pooling.hip)
+      __syncthreads();
+      const CtDiv byK(K);
+      for (int i = threadIdx.x; i < N * K; i += CT_THREADS) {
+        const int n = byK(i), k = i - n * K;
+        float dot = 0.f;
+        for (int l = 0; l < K; ++l) dot = fmaf(S[n * d.ldS + l], DSL[n * K + l], dot);
+        ds[(int64_t)b * N * K + i] = S[n * d.ldS + k] * (DSL[i] - dot);
+      }
     }
   }
   // dA = S dT      [N, N]
@@ -495,13 +525,13 @@ int tsgnn_contract_dense_supported(int N, int K, int F) {
  * s [B,N,K], z [B,N,F], adj [B,N,N] contiguous (encoders.py:374-375) */
 int tsgnn_contract_dense_fwd_f32(const float* s, const float* z, const float* adj, int B, int N, int K, int F, float* xo, float* ao,
                                  float* t, tsgnn_stream_t stream) {
-  return tsgnn_contract_dense_fwd_ro_f32(s, z, adj, B, N, K, F, xo, ao, t, nullptr, 0, nullptr, stream);
+  return tsgnn_contract_dense_fwd_ro_f32(s, z, adj, B, N, K, F, xo, ao, t, nullptr, 0, nullptr, nullptr, stream);
 }
 
 /* the same + the max readout of z over each graph's N rows (encoders.py:383) out of the staged operand: ro_out [B, F] (leading
  * dimension ro_ldo), ro_arg [B, F] = winning row b * N + n — what tsgnn_readout_max_fwd_f32 returns for the uniform batch (B, N) */
 int tsgnn_contract_dense_fwd_ro_f32(const float* s, const float* z, const float* adj, int B, int N, int K, int F, float* xo, float* ao,
-                                    float* t, float* ro_out, int64_t ro_ldo, int* ro_arg, tsgnn_stream_t stream) {
+                                    float* t, float* ro_out, int64_t ro_ldo, int* ro_arg, float* s_out, tsgnn_stream_t stream) {
   if (!s || !z || !adj || !xo || !ao || !t || B < 0) return TSGNN_EINVAL;
   if ((ro_out == nullptr) != (ro_arg == nullptr) || (ro_out && ro_ldo < F)) return TSGNN_EINVAL;
   if (!tsgnn_contract_dense_supported(N, K, F)) return TSGNN_EUNSUPPORTED;
@@ -512,7 +542,7 @@ int tsgnn_contract_dense_fwd_ro_f32(const float* s, const float* z, const float*
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(contract_dense_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CT_LDS_MAX);
     attr = CT_LDS_MAX;
   }
-  contract_dense_fwd_kernel<<<(unsigned)B, CT_THREADS, lds, stream>>>(s, z, adj, N, K, F, xo, ao, t, ro_out, ro_ldo, ro_arg);
+  contract_dense_fwd_kernel<<<(unsigned)B, CT_THREADS, lds, stream>>>(s, z, adj, N, K, F, xo, ao, t, ro_out, ro_ldo, ro_arg, s_out);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }
@@ -520,14 +550,14 @@ int tsgnn_contract_dense_fwd_ro_f32(const float* s, const float* z, const float*
 /* gradients of the pair above: ds [B,N,K], dz [B,N,F], dadj [B,N,N] (each nullable) from dxo [B,K,F], dao [B,K,K] */
 int tsgnn_contract_dense_bwd_f32(const float* s, const float* z, const float* adj, const float* t, const float* dxo, const float* dao,
                                  int B, int N, int K, int F, float* ds, float* dz, float* dadj, tsgnn_stream_t stream) {
-  return tsgnn_contract_dense_bwd_ro_f32(s, z, adj, t, dxo, dao, B, N, K, F, ds, dz, dadj, nullptr, 0, nullptr, stream);
+  return tsgnn_contract_dense_bwd_ro_f32(s, z, adj, t, dxo, dao, B, N, K, F, ds, dz, dadj, nullptr, 0, nullptr, 0, stream);
 }
 
 /* the same; dz additionally takes the gradient of the max readout of z over each graph's N rows (ro_dout [B, F] with leading
  * dimension ro_ldo, ro_arg [B, F] = winning row b * N + n or -1): the pass tsgnn_readout_max_bwd_rows_f32 would make over dz */
 int tsgnn_contract_dense_bwd_ro_f32(const float* s, const float* z, const float* adj, const float* t, const float* dxo, const float* dao,
                                     int B, int N, int K, int F, float* ds, float* dz, float* dadj, const float* ro_dout, int64_t ro_ldo,
-                                    const int* ro_arg, tsgnn_stream_t stream) {
+                                    const int* ro_arg, int softmax, tsgnn_stream_t stream) {
   if (!s || !dxo || !dao || B < 0 || (ds && (!z || !adj || !t))) return TSGNN_EINVAL;
   if ((ro_dout == nullptr) != (ro_arg == nullptr) || (ro_arg && (!dz || ro_ldo < F))) return TSGNN_EINVAL;
   if (!tsgnn_contract_dense_supported(N, K, F)) return TSGNN_EUNSUPPORTED;
@@ -540,7 +570,7 @@ int tsgnn_contract_dense_bwd_ro_f32(const float* s, const float* z, const float*
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(contract_dense_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CT_LDS_MAX);
     attr = CT_LDS_MAX;
   }
-  contract_dense_bwd_kernel<<<(unsigned)B, CT_THREADS, lds, stream>>>(s, z, adj, t, dxo, dao, N, K, F, ds, dz, dadj, ro_dout, ro_ldo, ro_arg);
+  contract_dense_bwd_kernel<<<(unsigned)B, CT_THREADS, lds, stream>>>(s, z, adj, t, dxo, dao, N, K, F, ds, dz, dadj, ro_dout, ro_ldo, ro_arg, softmax);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }

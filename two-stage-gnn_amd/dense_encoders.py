@@ -48,6 +48,7 @@ FUSED_DENSE_POST = True       # pooled DiffPool levels: transform + normalise + 
 FUSED_DENSE_STACK = True    # pooled DiffPool levels: the whole GCN stack as one autograd node (dense_stack.py)
 READOUT_PASS = True            # DiffPool: readout backward and the contraction's gradient of the same embeddings in one pass
 READOUT_IN_CONTRACT = os.environ.get("TSGNN_READOUT_IN_CONTRACT", "1") != "0"   # ... and inside the contraction's node (no backward pass of its own)
+SOFTMAX_IN_CONTRACT = os.environ.get("TSGNN_SOFTMAX_IN_CONTRACT", "1") != "0"   # pooled levels: the assignment softmax inside the contraction's launches
 READOUT_COLUMNS = os.environ.get("TSGNN_READOUT_COLUMNS", "1") != "0"   # DiffPool: the levels' readouts written into one buffer (no cat)
 FUSED_STACK = True             # GcnEncoderGraph: run the conv stack as one fused autograd node when it qualifies
 DENSE_ADJ_MAX_NODES = 128      # at or below this many nodes per graph a dense batched MFMA product is used
@@ -469,14 +470,19 @@ class SoftPoolingGcnEncoder(GcnEncoderGraph):
                     a, _ = self.gcn_forward_dense(dense_x, dense_adj, self.assign_conv_first_modules[i],
                                                   self.assign_conv_block_modules[i], self.assign_conv_last_modules[i])
                 Bq, Kq, Cq = a.shape
-                s = dp.row_softmax(mp.linear_oi(a.reshape(Bq * Kq, Cq), lin.weight, lin.bias)).reshape(Bq, Kq, -1)
-                self.assign_tensor = s
-                if ro_next is not None:
-                    dense_x, dense_adj, ro = dp.diffpool_contract_dense(s, emb_dense, dense_adj, readout=ro_next)
-                    out_all.append(ro)
-                    ro_next = None
+                logits = mp.linear_oi(a.reshape(Bq * Kq, Cq), lin.weight, lin.bias)
+                if SOFTMAX_IN_CONTRACT:
+                    # nn.Softmax(dim=-1) (:369) on the operand the contraction stages anyway, its backward in the backward launch
+                    res = dp.diffpool_contract_dense(logits.reshape(Bq, Kq, -1), emb_dense, dense_adj, readout=ro_next, softmax=True)
+                    s = res[-1]
                 else:
-                    dense_x, dense_adj = dp.diffpool_contract_dense(s, emb_dense, dense_adj)
+                    s = dp.row_softmax(logits).reshape(Bq, Kq, -1)
+                    res = dp.diffpool_contract_dense(s, emb_dense, dense_adj, readout=ro_next)
+                self.assign_tensor = s
+                dense_x, dense_adj = res[0], res[1]
+                if ro_next is not None:
+                    out_all.append(res[2])
+                    ro_next = None
             a_next = None
             emb_convs = [self.conv_first_after_pool[i]] + list(self.conv_block_after_pool[i]) + [self.conv_last_after_pool[i]]
             if i + 1 < self.num_pooling and FUSED_DENSE_STACK and self.bn and not self.per_graph_bn:

@@ -89,14 +89,18 @@ def bmm(a, b, trans_a=False, trans_b=False):
 
 class _ContractDense(torch.autograd.Function):
     """(S^T Z, S^T A S) of a pooled level as one node: the three gradient contributions to S are accumulated by the
-    batched products themselves (composed from bmm nodes autograd adds them with two element-wise launches)."""
+    batched products themselves (composed from bmm nodes autograd adds them with two element-wise launches).
+    forward(s, z, adj, ro, softmax) -> xo, ao[, readout of z][, S]:
+      ro = (uniform GraphBatch of z's rows, column block or None): the max readout of z (encoders.py:383) is a further output;
+      softmax: `s` holds the assignment LOGITS, S = softmax(s, dim=-1) (:369) is formed inside the launch and returned too
+      (not differentiable: the node's gradient goes to the logits)."""
 
     @staticmethod
-    def forward(ctx, s, z, adj, ro=None):
+    def forward(ctx, s, z, adj, ro=None, softmax=False):
         s, z, adj = s.contiguous(), z.contiguous(), adj.contiguous()
         B, N, K, F = s.size(0), s.size(1), s.size(2), z.size(2)
         ctx.fused = bool(FUSED_CONTRACT and s.is_cuda and nat.lib().tsgnn_contract_dense_supported(int(N), int(K), int(F)))
-        ctx.ro = None
+        ctx.ro, ctx.softmax = None, bool(softmax)
         out = arg = None
         if ro is not None:                                     # the max readout of z is part of this node (see diffpool_contract_dense)
             gd, into = ro
@@ -107,23 +111,36 @@ class _ContractDense(torch.autograd.Function):
                 arg = torch.empty(B, F, dtype=torch.int32, device=s.device)
             else:
                 out, arg = mp.readout_fwd_raw(z.reshape(B * N, F), gd, into)
+        sm = None
+        if softmax:
+            sm = torch.empty_like(s)
+            if not ctx.fused:
+                nat.call("row_softmax_masked_fwd_f32", s, K, B * N, K, sm, K, B * N)
         if ctx.fused:                                          # one workgroup per graph, operands in LDS: one launch each way
             xo, ao, t = _f32(B, K, F, device=s.device), _f32(B, K, K, device=s.device), _f32(B, K, N, device=s.device)
-            nat.call("contract_dense_fwd_ro_f32", s, z, adj, B, N, K, F, xo, ao, t, out, out.stride(0) if out is not None else 0, arg)
-        else:
+            nat.call("contract_dense_fwd_ro_f32", s, z, adj, B, N, K, F, xo, ao, t, out, out.stride(0) if out is not None else 0, arg, sm)
+        if softmax:
+            s = sm                                             # what the products used, and what the backward needs
+        if not ctx.fused:
             xo = _bmm_raw(s, z, True, False)
             t = _bmm_raw(s, adj, True, False)                  # S^T A
             ao = _bmm_raw(t, s, False, False)
+        outs = [xo, ao]
         if ro is not None:
             ctx.save_for_backward(s, z, adj, t, arg)
-            return xo, ao, out
-        ctx.save_for_backward(s, z, adj, t)
-        return xo, ao
+            outs.append(out)
+        else:
+            ctx.save_for_backward(s, z, adj, t)
+        if softmax:
+            ctx.mark_non_differentiable(sm)
+            outs.append(sm)
+        return tuple(outs)
 
     @staticmethod
-    def backward(ctx, dxo, dao, dro=None):
+    def backward(ctx, dxo, dao, *rest):
         s, z, adj, t = ctx.saved_tensors[:4]
         arg = ctx.saved_tensors[4] if ctx.ro is not None else None
+        dro = rest[0] if ctx.ro is not None else None
         B, N, K, F = s.size(0), s.size(1), s.size(2), z.size(2)
         if ctx.ro is not None and (dxo is None or dao is None):   # (materialisation is off for the readout's sake)
             dxo = dxo if dxo is not None else torch.zeros(B, K, F, device=s.device)
@@ -135,14 +152,16 @@ class _ContractDense(torch.autograd.Function):
             ds = torch.empty_like(s) if ns else None
             dz = torch.empty_like(z) if nz else None
             dadj = torch.empty_like(adj) if na else None
-            if dro is not None and nz:
+            fold = dro is not None and nz
+            if fold:
                 dro = mp.readout_dout_in_place(dro)
-                if nat.try_call("contract_dense_bwd_ro_f32", s, z, adj, t, dxo, dao, B, N, K, F, ds, dz, dadj, dro, dro.stride(0), arg):
-                    return ds, dz, dadj, None                  # the readout's gradient rode in the dz pass
-            nat.call("contract_dense_bwd_f32", s, z, adj, t, dxo, dao, B, N, K, F, ds, dz, dadj)
-            if dro is not None and nz:
-                dz = mp.readout_bwd_raw(dro, arg, ctx.ro, B * N, False, dpass=dz.reshape(B * N, F)).reshape(B, N, F)
-            return ds, dz, dadj, None
+            if not nat.try_call("contract_dense_bwd_ro_f32", s, z, adj, t, dxo, dao, B, N, K, F, ds, dz, dadj, dro if fold else None,
+                                dro.stride(0) if fold else 0, arg if fold else None, 1 if ctx.softmax else 0):
+                # (the readout's gradient could not ride in the dz pass: alignment of a gradient slice)
+                nat.call("contract_dense_bwd_ro_f32", s, z, adj, t, dxo, dao, B, N, K, F, ds, dz, dadj, None, 0, None, 1 if ctx.softmax else 0)
+                if fold:
+                    dz = mp.readout_bwd_raw(dro, arg, ctx.ro, B * N, False, dpass=dz.reshape(B * N, F)).reshape(B, N, F)
+            return ds, dz, dadj, None, None
         if nz:
             dz = _bmm_raw(s, dxo, False, False)                # X' = S^T Z : dZ = S dX'
         if ns or na:
@@ -151,18 +170,23 @@ class _ContractDense(torch.autograd.Function):
             ds = _bmm_raw(z, dxo, False, True)                 #             dS  = Z dX'^T
             _bmm_raw(t, dao, True, False, out=ds)              #             dS += T^T dA'
             _bmm_raw(adj, dt, False, True, out=ds)             # T = S^T A : dS += A dT^T
+            if ctx.softmax:
+                dl = torch.empty_like(ds)
+                nat.call("row_softmax_masked_bwd_f32", s, K, ds, K, B * N, K, dl, K, B * N)
+                ds = dl
         if na:
             dadj = _bmm_raw(s, dt, False, False)               #             dA  = S dT
         if dro is not None and nz:
             dz = mp.readout_bwd_raw(dro, arg, ctx.ro, B * N, False, dpass=dz.reshape(B * N, F)).reshape(B, N, F)
-        return ds, dz, dadj, None
+        return ds, dz, dadj, None, None
 
 
-def diffpool_contract_dense(s, z, adj, readout=None):
+def diffpool_contract_dense(s, z, adj, readout=None, softmax=False):
     """encoders.py:374-375 on dense [B,N,*] tensors: (S^T Z, S^T A S).  readout = (uniform GraphBatch of z's rows, column block or
     None): the max readout of z over each graph's nodes (:383) becomes a third output of the SAME node, so that its gradient is
-    added inside the launch that produces dz (no pass of its own over the rows)."""
-    return _ContractDense.apply(s, z, adj, readout)
+    added inside the launch that produces dz (no pass of its own over the rows).  softmax: `s` holds the assignment logits; the
+    softmax of :369 is formed inside the launch (and its backward inside the backward launch) and S is returned as the last output."""
+    return _ContractDense.apply(s, z, adj, readout, bool(softmax))
 
 
 # ----------------------------------------------------------------------------- ragged (row-layout) contraction
