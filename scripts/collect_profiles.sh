@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collects the round's measurements on the GPU box (run through gpurun); outputs under gpurun_out/r03/, copied to profiles/r03/ afterwards.
-#   bash scripts/collect_profiles.sh [bench|rocprof|pmc|ingest|configs|diffpool_pmc ...]
+#   bash scripts/collect_profiles.sh [bench|rocprof|pmc|ingest|configs|diffpool_pmc|diffpool_stats|diffpool_replay|gat_stats|gat_replay ...]
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/r03; mkdir -p $O
 for what in "$@"; do
@@ -16,6 +16,12 @@ for what in "$@"; do
     diffpool_pmc) bash scripts/pmc_diffpool.sh > $O/diffpool_mfma_pmc.txt 2>&1 ;;
     diffpool_stats) rm -rf $O/rocprof_dp
              rocprofv3 --kernel-trace --stats --output-format csv -d $O/rocprof_dp -- python3 scripts/prof_diffpool.py > /dev/null 2>&1 && cp $O/rocprof_dp/*/*kernel_stats.csv $O/diffpool_kernel_stats.csv ;;
+    diffpool_replay) rm -rf $O/rocprof_dpr
+             rocprofv3 --kernel-trace --output-format csv -d $O/rocprof_dpr -- python3 scripts/diffpool_step.py > /dev/null 2>&1 &&
+             python3 scripts/replay_trace.py $(ls $O/rocprof_dpr/*/*kernel_trace.csv | head -1) tn_rows_reduce_multi > $O/diffpool_replay_timeline.txt; rm -rf $O/rocprof_dpr ;;
+    gat_replay) rm -rf $O/rocprof_gr
+             rocprofv3 --kernel-trace --output-format csv -d $O/rocprof_gr -- python3 scripts/gat_step.py > /dev/null 2>&1 &&
+             python3 scripts/replay_trace.py $(ls $O/rocprof_gr/*/*kernel_trace.csv | head -1) gat_unpack_kernel > $O/gat_replay_timeline.txt; rm -rf $O/rocprof_gr ;;
     gat_stats) rm -rf $O/rocprof_gat
              GAT_EAGER=20 rocprofv3 --kernel-trace --stats --output-format csv -d $O/rocprof_gat -- python3 scripts/gat_step.py > /dev/null 2>&1 && cp $O/rocprof_gat/*/*kernel_stats.csv $O/gat_b32_kernel_stats.csv ;;
   esac

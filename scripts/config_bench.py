@@ -187,7 +187,7 @@ print("f4 link-pred loss + gradient, DD b16 K=64 (%.2f M row pairs, no [B,N,N] t
 nb = hb5["sizes"].astype(np.float64)
 dense_flops = 16 * (2 * 512 * 512 * 64 + 2 * 64 * 512 * 64 + 2 * 64 * 512 * 192)          # reference's padded bmm's, level 1
 sparse_flops = 2 * g5.nnz * 64 + float((2 * 64 * nb * 64 + 2 * 64 * nb * 192).sum())    # what is executed: SpMM + ragged GEMMs
-print("cfg5 level-1 contraction X'=S^T Z, A'=S^T A S (3 launches): %.1f us ; executed %.1f MFLOP -> %.1f TF (%.1f%% of 157.3 TF fp32 MFMA); "
+print("cfg5 level-1 contraction X'=S^T Z, A'=S^T A S (2 launches: SpMM + both ragged products): %.1f us ; executed %.1f MFLOP -> %.1f TF (%.1f%% of 157.3 TF fp32 MFMA); "
       "reference-equivalent dense work %.1f MFLOP -> %.1f TF-equivalent (%.0f%%)"
       % (us, sparse_flops / 1e6, sparse_flops / us / 1e6, sparse_flops / us / 1e6 / 157.3 * 100, dense_flops / 1e6,
          dense_flops / us / 1e6, dense_flops / us / 1e6 / 157.3 * 100))
