@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--hidden", type=int, default=128)
     ap.add_argument("--layers", type=int, default=3)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--steps-per-graph", type=int, default=4,
+                    help="N = 1: consecutive optimiser steps captured into one hipGraph launch (GraphedStep.run); 1 = one step per launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=0, help="0 = auto-size the sample to ~15 s")
     ap.add_argument("--no-sweep", action="store_true", help="skip the aggregation-kernel batch-size sweep")
@@ -370,13 +372,12 @@ def over_seeds(a, model, trainer, dev, seeds, steps):
     for seed in seeds:
         hb = synthetic.host_batch(seed=seed, B=a.batch, shape=a.shape, nmax=a.nmax)
         g, x, label = synthetic.to_device(hb, dev)
-        gs = GraphedStep(trainer, lambda: model.loss(model(x, g)[1], label), warmup=3)
-        for _ in range(10):
-            gs.step()
+        gs = GraphedStep(trainer, lambda: model.loss(model(x, g)[1], label), warmup=3, steps_per_replay=max(1, a.steps_per_graph))
+        gs.run(12)
         gs.stream.synchronize()
         best = None
         for _ in range(3):
-            ms = hip_event_ms(gs.step, steps, gs.stream)
+            ms = hip_event_ms(lambda: gs.run(steps), 1, gs.stream) / steps
             best = ms if best is None else min(best, ms)
         out.append({"seed": seed, "rows": int(g.n_rows), "row_panels": (int(g.n_rows) + 31) // 32, "edges_directed": int(g.nnz),
                     "ms_per_step": best})
@@ -522,19 +523,17 @@ def main():
 
     use_graph = not a.no_graph
     # N = 1: one hipGraph for the whole step; N > 1: hipGraphs around the RCCL all-reduce (data_parallel.GraphedStep)
-    gstep = GraphedStep(trainer, lambda: model.loss(model(x, g)[1], label), warmup=3, use_graph=use_graph)
+    gstep = GraphedStep(trainer, lambda: model.loss(model(x, g)[1], label), warmup=3, use_graph=use_graph,
+                        steps_per_replay=1 if multi else max(1, a.steps_per_graph))
     stream = gstep.stream
-    step = gstep.step
     with torch.cuda.stream(stream):
-        for _ in range(a.warmup):
-            step()
+        gstep.run(a.warmup)
         torch.cuda.synchronize()
         if multi:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(a.steps):
-            step()
+        gstep.run(a.steps)                       # exactly a.steps optimiser steps (graph launches of steps_per_replay steps + the rest)
         torch.cuda.synchronize()
         if multi:
             dist.barrier()

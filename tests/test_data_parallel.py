@@ -467,6 +467,40 @@ def test_deferred_loss_equals_ordinary_step():
 
 
 @pytest.mark.gpu
+def test_run_of_multi_step_graphs_equals_single_steps_bitwise():
+    """GraphedStep(steps_per_replay=k).run(n): graph launches of k consecutive optimiser steps + single steps for the rest are the
+    same n steps as n calls of step() — parameters, Adam moments, step counter and the last loss, bit for bit; and constructing
+    the multi-step graph leaves the trainer's state as it found it"""
+    sys.path.insert(0, ROOT)
+    from two_stage_gnn_amd import dense_encoders as E, synthetic
+    from two_stage_gnn_amd.data_parallel import FlatTrainer, GraphedStep
+
+    class A:
+        bias = True
+    dev = torch.device("cuda")
+    hb = synthetic.host_batch(seed=2, B=12, shape="DD", nmax=400)
+    g, x, label = synthetic.to_device(hb, dev)
+    outs = []
+    for k in (1, 3):
+        torch.manual_seed(3)
+        m = E.GcnEncoderGraph(89, 128, 128, 2, 3, bn=True, args=A(), final_dim="number_classes").to(dev)
+        tr = FlatTrainer(m, lr=1e-2, clip=2.0, defer_loss=True)
+        before = tr.flat_param.clone()
+        gs = GraphedStep(tr, lambda: m.loss(m(x, g)[1], label), warmup=2, steps_per_replay=k)
+        assert torch.equal(tr.flat_param, before) and float(tr.state[0]) == 0.0
+        assert ("3 consecutive steps" in gs.describe()) == (k == 3)
+        gs.run(7)                                            # k = 3: two graph launches of three steps + one single step
+        l7 = gs.loss_value()
+        gs.run(6)                                            # ... and a run that ends on a multi-step graph
+        l13 = gs.loss_value()
+        outs.append((l7, l13, tr.flat_param.clone(), tr.exp_avg.clone(), tr.exp_avg_sq.clone(), float(tr.state[0])))
+    assert outs[0][5] == outs[1][5] == 13.0
+    assert outs[0][0] == outs[1][0] and outs[0][1] == outs[1][1] and outs[0][0] != outs[0][1]
+    for a_, b_ in zip(outs[0][2:5], outs[1][2:5]):
+        assert torch.equal(a_, b_)
+
+
+@pytest.mark.gpu
 def test_deferred_nll_equals_ordinary_sagpool_step():
     """SAGPool Net under FlatTrainer(defer_loss=True) with mp.nll_loss: the head's backward forms the nll gradient and writes
     the loss — same losses and parameters as torch's nll_loss through autograd (dropout off: identical random state)"""

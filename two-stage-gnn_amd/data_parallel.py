@@ -250,12 +250,13 @@ class GraphedStep:
     use ``capture_error_mode="thread_local"`` because the RCCL watchdog thread touches the HIP runtime concurrently.
     ``use_graph=False`` runs the same sequence eagerly (debugging)."""
 
-    def __init__(self, trainer, loss_fn, warmup=3, use_graph=True, stream=None):
+    def __init__(self, trainer, loss_fn, warmup=3, use_graph=True, stream=None, steps_per_replay=1):
         self.trainer, self.loss_fn, self.use_graph = trainer, loss_fn, use_graph
         self.multi = trainer.world > 1 or trainer.always_reduce
         self.stream = stream if stream is not None else torch.cuda.Stream()
         self.loss = None
         self._fb = self._opt = None
+        self._fbk, self.steps_per_replay = None, 1
         self.one_graph = False
         with torch.cuda.stream(self.stream):
             # allocator / lazy-init warm-up on the capture stream.  The warm-up steps are real optimiser steps on whatever the
@@ -302,6 +303,23 @@ class GraphedStep:
             with torch.cuda.stream(self.stream):                 # (self.stream is a fresh one if a capture was invalidated)
                 self._capture_two(mode)
         self._snap = None
+        self._loss1 = self._lossk = self.loss                    # the loss scalar the single-step graph(s) write
+        if int(steps_per_replay) > 1 and not self.multi:
+            # run(): k CONSECUTIVE optimiser steps on the same resident buffers as ONE graph launch — between two graph launches the
+            # device idles for the launch's own latency (8.7 us behind a 0.131 ms step: scripts/replay_trace.py), once per replay
+            # whatever the graph holds.  N = 1 only: at N > 1 a step is paced by its all-reduce, and run() replays step by step.
+            self.steps_per_replay = int(steps_per_replay)
+            with torch.cuda.stream(self.stream):
+                snap = [t.clone() for t in (trainer.flat_param, trainer.exp_avg, trainer.exp_avg_sq, trainer.state)]
+                self._fbk = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._fbk, stream=self.stream):
+                    for _ in range(self.steps_per_replay):
+                        self._fwd_bwd()
+                        trainer.apply()
+                for t, s_ in zip((trainer.flat_param, trainer.exp_avg, trainer.exp_avg_sq, trainer.state), snap):
+                    t.copy_(s_)                                  # (capturing runs nothing, but keep the contract explicit)
+                torch.cuda.synchronize()
+            self._lossk, self.loss = self.loss, self._loss1      # (the k-step graph's LAST step writes its own scalar)
 
     def _bufs(self):
         tr = self.trainer
@@ -415,7 +433,8 @@ class GraphedStep:
         if not self.use_graph:
             return "eager"
         if not self.multi:
-            return "one graph: forward + backward + bucket + optimiser"
+            k = ("; run(): %d consecutive steps per graph launch" % self.steps_per_replay) if self._fbk is not None else ""
+            return "one graph: forward + backward + bucket + optimiser" + k
         bk = ", early bucket [%d, %d) all-reduced on a side branch" % self.trainer._early if self.trainer._early else ""
         if self.one_graph:
             return "one graph incl. the captured all-reduce" + bk
@@ -439,6 +458,20 @@ class GraphedStep:
         self.synchronize()
         return float(self.loss.detach())
 
+    def run(self, n):
+        """enqueue n consecutive steps on self.stream: graphs of `steps_per_replay` steps while they fit, single steps for the rest
+        (the same n optimiser steps as n calls of step(), bit for bit — tests/test_data_parallel.py)"""
+        n = int(n)
+        if self._fbk is not None:
+            with torch.cuda.stream(self.stream):
+                while n >= self.steps_per_replay:
+                    self._fbk.replay()
+                    n -= self.steps_per_replay
+                    self.loss = self._lossk
+        for _ in range(n):
+            self.step()
+        return self.loss
+
     def step(self):
         """enqueue one step on self.stream (returns immediately; self.loss is the device scalar of the last step; read it through
         loss_value(), which also checks the device's error word)"""
@@ -447,6 +480,8 @@ class GraphedStep:
                 self._fwd_bwd(); self.trainer.all_reduce(); self.trainer.apply()
             elif not self.multi or self.one_graph:
                 self._fb.replay()
+                self.loss = self._loss1
             else:
                 self._fb.replay(); self.trainer.all_reduce(); self._opt.replay()
+                self.loss = self._loss1
         return self.loss
