@@ -564,6 +564,16 @@ int tsgnn_mlp3_supported(int B, int D0, int D1, int D2, int C);
 int tsgnn_mlp3_fwd_f32(const float* x, int64_t ldx, const float* w1, const float* b1, const float* keep, float keep_scale, const float* w2,
                        const float* b2, const float* w3, const float* b3, int B, int D0, int D1, int D2, int C, float* a1, float* a2,
                        float* logp, tsgnn_stream_t stream);
+/* tsgnn_mlp3_fwd_f32 with the dropout mask (F.dropout after the first ReLU, network.py:49: probability p of dropping, survivors
+ * scaled by 1 / (1 - p)) made INSIDE the launch: Philox4x32-10 keyed on (seed + the device counter state[0]; graph, hidden unit).
+ * state: two uint64 words, zeroed once: [0] counts the launches — the launch advances it itself, so a step replayed from a hipGraph
+ * draws a new mask at every replay and no host generator is involved —, [1] is its ticket word (zero between launches).
+ * used[0] receives the counter value this launch keyed its mask with; tsgnn_mlp3_dropout_mask_f32 regenerates that mask. */
+int tsgnn_mlp3_fwd_drop_f32(const float* x, int64_t ldx, const float* w1, const float* b1, float p, uint64_t seed,
+                            unsigned long long* state, unsigned long long* used, const float* w2, const float* b2, const float* w3,
+                            const float* b3, int B, int D0, int D1, int D2, int C, float* a1, float* a2, float* logp,
+                            tsgnn_stream_t stream);
+int tsgnn_mlp3_dropout_mask_f32(float p, uint64_t seed, uint64_t counter, int B, int D1, float* out, tsgnn_stream_t stream);
 /* its backward in one launch ([dW1 tiles | dW2 tiles | dW3 | dX rows] blocks, each recomputing dlogits -> dz2 in LDS);
  * dlogp[B, C] = gradient w.r.t. logp; dx nullable. */
 int tsgnn_mlp3_bwd_f32(const float* x, int64_t ldx, const float* w1, const float* w2, const float* w3, const float* a1,

@@ -108,7 +108,9 @@ t = timeit(step_sag_c, iters=10, warm=3)
 print("cfg4 IMDB-B SAGPool(0.5) h128 b128, drop-ins composed level by level: %.0f us/step eager (host syncs for k / E'), %.0f graphs/s" % (t, 128 / t * 1e6))
 net = S.Net(1, 128, 2, 0.5, 0.5, use_batch=True).to(dev).train()
 def step_sag():
-    net.zero_grad(set_to_none=True); torch.nn.functional.nll_loss(net(d), lab4).backward()
+    net.zero_grad(set_to_none=True)
+    with mp.deferred_loss():                     # the library's nll_loss inside the head's backward (scripts/sagpool_step.py)
+        mp.nll_loss(net(d), lab4).backward(gradient=mp.unit_seed(dev))
 t = timeit(step_sag, iters=20, warm=3)
 tg = graph_us(step_sag)
 print("cfg4 IMDB-B SAGPool(0.5) h128 b128, sync-free fused levels: %.0f us/step eager, %s us/step hipGraph -> %.0f graphs/s" % (t, "%.0f" % tg if tg else "n/a", 128 / (tg or t) * 1e6))
@@ -116,8 +118,8 @@ print("cfg4 IMDB-B SAGPool(0.5) h128 b128, sync-free fused levels: %.0f us/step 
 # the same step as a data-parallel optimiser step (gradient bucket + clip + Adam; the RCCL all-reduce of the bucket sits between
 # the two hipGraphs at N > 1): FlatTrainer / GraphedStep are model-agnostic
 from two_stage_gnn_amd.data_parallel import FlatTrainer, GraphedStep
-tr4 = FlatTrainer(net, lr=5e-4, clip=2.0)
-gs4 = GraphedStep(tr4, lambda: torch.nn.functional.nll_loss(net(d), lab4), warmup=3)
+tr4 = FlatTrainer(net, lr=5e-4, clip=2.0, defer_loss=True)
+gs4 = GraphedStep(tr4, lambda: mp.nll_loss(net(d), lab4), warmup=3)
 for _ in range(5):
     gs4.step()
 torch.cuda.synchronize()
@@ -128,7 +130,7 @@ for _ in range(50):
 e1.record(gs4.stream); e1.synchronize()
 t = e0.elapsed_time(e1) / 50 * 1e3
 print("cfg4 full optimiser step (fwd + bwd + bucket + clip + Adam) from one hipGraph: %.0f us/step -> %.0f graphs/s per GPU, loss %.4f"
-      % (t, 128 / t * 1e6, float(gs4.loss)))
+      % (t, 128 / t * 1e6, gs4.loss_value()))
 torch.cuda.set_stream(_S)
 
 def optimiser_step_us(model, loss_fn, B, tag, iters=50):

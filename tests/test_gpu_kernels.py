@@ -450,6 +450,55 @@ def test_mlp3_head_matches_torch(B, D0, D1, D2, C, p):
         torch.testing.assert_close(a.bias.grad.cpu(), b.bias.grad, rtol=1e-4, atol=1e-5)
 
 
+def test_mlp3_head_dropout_inside_the_launch():
+    """mp.mlp3_log_softmax in training mode: the dropout mask is made inside the forward launch (Philox, device counter advanced by
+    the launch).  With the regenerated mask handed to torch's own ops outputs and gradients agree like the no-dropout case; the
+    keep rate is 1 - p; consecutive launches — and consecutive REPLAYS of a captured step — draw different masks"""
+    from two_stage_gnn_amd import message_passing as mp
+    B, D0, D1, D2, C, p = 128, 256, 128, 64, 2, 0.5
+    torch.manual_seed(5)
+    lins = [torch.nn.Linear(D0, D1).cuda(), torch.nn.Linear(D1, D2).cuda(), torch.nn.Linear(D2, C).cuda()]
+    x = torch.randn(B, D0, device="cuda")
+    xg = x.clone().requires_grad_(True)
+    out = mp.mlp3_log_softmax(xg, *lins, p=p, training=True)
+    pk, seed, used = mp.last_mlp3_dropout
+    keep = mp.mlp3_dropout_mask(pk, seed, used, B, D1)
+    assert set(keep.unique().tolist()) <= {0.0, 1.0} and abs(float(keep.mean()) - (1 - p)) < 0.03
+    gy = torch.randn(B, C, device="cuda")
+    (out * gy).sum().backward()
+    xr = x.clone().requires_grad_(True)
+    ws = [(l.weight.detach().clone().requires_grad_(True), l.bias.detach().clone().requires_grad_(True)) for l in lins]
+    h = torch.relu(xr @ ws[0][0].t() + ws[0][1]) * keep / (1 - p)
+    ref = torch.log_softmax(torch.relu(h @ ws[1][0].t() + ws[1][1]) @ ws[2][0].t() + ws[2][1], dim=-1)
+    (ref * gy).sum().backward()
+    torch.testing.assert_close(out.detach(), ref.detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(xg.grad, xr.grad, rtol=1e-4, atol=1e-5)
+    for l, (w, b) in zip(lins, ws):
+        torch.testing.assert_close(l.weight.grad, w.grad, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(l.bias.grad, b.grad, rtol=1e-4, atol=1e-5)
+    # a second launch: the counter has advanced by exactly one, the mask is another one
+    mp.mlp3_log_softmax(x, *lins, p=p, training=True)
+    _, _, used2 = mp.last_mlp3_dropout
+    assert int(used2) == int(used) + 1
+    assert not torch.equal(mp.mlp3_dropout_mask(pk, seed, used2, B, D1), keep)
+    # replays of one captured forward: a new mask each time (the counter lives on the device)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        g = torch.cuda.CUDAGraph()
+        with torch.no_grad():
+            mp.mlp3_log_softmax(x, *lins, p=p, training=True)
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, stream=st):
+                y = mp.mlp3_log_softmax(x, *lins, p=p, training=True)
+        _, _, used3 = mp.last_mlp3_dropout
+        seen = []
+        for _ in range(3):
+            g.replay(); torch.cuda.synchronize()
+            seen.append((int(used3), y.clone()))
+    assert [s_[0] for s_ in seen] == [seen[0][0], seen[0][0] + 1, seen[0][0] + 2]
+    assert not torch.equal(seen[0][1], seen[1][1]) and not torch.equal(seen[1][1], seen[2][1])
+
+
 @pytest.mark.parametrize("K,ld,N,trans_b,normalize,fill", [(128, 128, 128, False, 1, 37), (89, 92, 128, False, 1, 0), (128, 128, 64, False, 0, 0),
                                                             (128, 128, 128, True, 0, 0), (64, 64, 128, True, 0, 0), (40, 40, 96, False, 1, 5)])
 def test_rowgemm_large_batch_kernel_equals_row_panel_kernel(T, K, ld, N, trans_b, normalize, fill):

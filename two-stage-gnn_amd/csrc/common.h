@@ -150,6 +150,18 @@ __device__ __forceinline__ float group_max(float v) {
   return v;
 }
 
+// ---------------------------------------------------------------- Philox4x32-10 (Salmon et al., SC'11), counter-based
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+    const unsigned hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+    c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+    k.x += 0x9E3779B9u; k.y += 0xBB67AE85u;
+  }
+  return c;
+}
+
 // XCD-aware block remap: blocks b and b+8 share an XCD (round-robin dispatch, speed only).
 // Gives every XCD one contiguous range of logical blocks so that neighbouring rows (which share
 // gathered feature rows of the same graph) meet in one L2.  Bijective for any nblk.

@@ -26,17 +26,6 @@ __device__ __forceinline__ float lrelu_(float t, float slope) { return t > 0.f ?
 __device__ __forceinline__ float4 ldg4_(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float elu_grad_y(float y) { return y > 0.f ? 1.f : y + 1.f; }      // d/dx elu(x) = exp(x) = elu(x) + 1 for x <= 0
 
-// ---------------------------------------------------------------- Philox4x32-10 (Salmon et al., SC'11), counter-based
-__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const unsigned hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
-    const unsigned hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
-    c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
-    k.x += 0x9E3779B9u; k.y += 0xBB67AE85u;
-  }
-  return c;
-}
 struct Drop {
   unsigned thresh;     // an element is dropped when its 32 random bits are < thresh (= p * 2^32); 0: no dropout
   float scale;         // 1 / (1 - p)

@@ -52,24 +52,46 @@ __device__ __forceinline__ void dense_row(const float* xs, int P, const float* _
   }
 }
 
+// Dropout mask made inside the launch (tsgnn_mlp3_fwd_drop_f32): element (b, j) of the hidden layer is kept when its 32 Philox bits
+// are >= thresh (= p * 2^32), keyed on (seed + the DEVICE counter state[0]; b, j).  The counter advances once per launch — every
+// block reads it first and draws a ticket (state[1]) when it is done; the block with the last ticket increments it — so a training
+// step replayed from a hipGraph draws a new mask at every replay without a host-side generator (torch's graph-safe generator costs
+// a bernoulli launch plus two fill launches per replay).  used[0] = the counter value of this launch (tests regenerate the mask).
+struct Mlp3Drop {
+  unsigned thresh; unsigned seed_lo, seed_hi;
+  unsigned long long* state;             // [0] launches so far, [1] tickets of the running launch (zero between launches)
+  unsigned long long* used;
+};
+__device__ __forceinline__ float mlp3_keep(unsigned thresh, unsigned klo, unsigned khi, unsigned b, unsigned j) {
+  const uint4 r = philox4x32_10(make_uint4(b, j >> 2, 0u, 0x4D4C5033u), make_uint2(klo, khi));
+  const unsigned v = (j & 3) == 0 ? r.x : (j & 3) == 1 ? r.y : (j & 3) == 2 ? r.z : r.w;
+  return v < thresh ? 0.f : 1.f;
+}
+
 __global__ __launch_bounds__(64 * MH_WAVES) void mlp3_fwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ w1,
                                                                  const float* __restrict__ b1, const float* __restrict__ keep,
                                                                  float keep_scale, const float* __restrict__ w2, const float* __restrict__ b2,
                                                                  const float* __restrict__ w3, const float* __restrict__ b3, int D0,
                                                                  int D1, int D2, int C, float* __restrict__ a1, float* __restrict__ a2,
-                                                                 float* __restrict__ logp) {
+                                                                 float* __restrict__ logp, Mlp3Drop drop) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* xs = smem;                              // [D0]
   float* v1 = xs + D0;                           // [D1]
   float* v2 = v1 + ((D1 + 3) & ~3);              // [D2]
   float* lg = v2 + ((D2 + 3) & ~3);              // [C]
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  unsigned long long ctr = 0ull;
+  if (drop.state) ctr = __hip_atomic_load(drop.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (read before anything else)
   for (int k = tid; k < D0; k += 64 * MH_WAVES) xs[k] = x[(int64_t)b * ldx + k];
   __syncthreads();
   dense_row<true>(xs, D0, w1, b1, D1, v1);
   __syncthreads();
+  const unsigned klo = drop.seed_lo + (unsigned)(ctr & 0xffffffffull), khi = drop.seed_hi + (unsigned)(ctr >> 32);
   for (int j = tid; j < D1; j += 64 * MH_WAVES) {
-    const float v = v1[j] * (keep ? keep[(int64_t)b * D1 + j] * keep_scale : 1.f);   // dropout after the ReLU (network.py:48-49)
+    float m = 1.f;                                                                    // dropout after the ReLU (network.py:48-49)
+    if (drop.state) m = mlp3_keep(drop.thresh, klo, khi, (unsigned)b, (unsigned)j) * keep_scale;
+    else if (keep) m = keep[(int64_t)b * D1 + j] * keep_scale;
+    const float v = v1[j] * m;
     v1[j] = v;
     a1[(int64_t)b * D1 + j] = v;
   }
@@ -91,6 +113,23 @@ __global__ __launch_bounds__(64 * MH_WAVES) void mlp3_fwd_kernel(const float* __
     for (int c = 0; c < C; ++c) s += expf(lg[c] - m);
     logp[(int64_t)b * C + tid] = lg[tid] - m - logf(s);
   }
+  if (drop.state && tid == 0) {
+    if (b == 0) drop.used[0] = ctr;
+    // every block has read the counter before it draws its ticket: the last one advances it for the next launch
+    asm volatile("" ::"v"((unsigned)ctr));
+    const unsigned long long t = atomicAdd(drop.state + 1, 1ull);
+    if (t == (unsigned long long)gridDim.x - 1ull) {
+      atomicExch(drop.state + 1, 0ull);
+      atomicAdd(drop.state, 1ull);
+    }
+  }
+}
+
+// the mask of a launch, regenerated (tests; [B, D1] of 0 / 1)
+__global__ void mlp3_mask_kernel(unsigned thresh, unsigned klo, unsigned khi, int B, int D1, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)B * D1) return;
+  out[i] = mlp3_keep(thresh, klo, khi, (unsigned)(i / D1), (unsigned)(i % D1));
 }
 
 struct Mlp3Bwd {
@@ -476,7 +515,44 @@ int tsgnn_mlp3_fwd_f32(const float* x, int64_t ldx, const float* w1, const float
   const size_t lds = sizeof(float) * ((size_t)D0 + ((D1 + 3) & ~3) + ((D2 + 3) & ~3) + C);
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp3_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  mlp3_fwd_kernel<<<(unsigned)B, 64 * MH_WAVES, lds, stream>>>(x, ldx, w1, b1, keep, keep_scale, w2, b2, w3, b3, D0, D1, D2, C, a1, a2, logp);
+  mlp3_fwd_kernel<<<(unsigned)B, 64 * MH_WAVES, lds, stream>>>(x, ldx, w1, b1, keep, keep_scale, w2, b2, w3, b3, D0, D1, D2, C, a1, a2, logp,
+                                                                Mlp3Drop{});
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+static unsigned mlp3_thresh(float p) {
+  const double t = (double)p * 4294967296.0;
+  return t >= 4294967295.0 ? 0xFFFFFFFFu : (unsigned)t;
+}
+
+/* tsgnn_mlp3_fwd_f32 with the dropout mask (probability p of dropping, survivors scaled by 1 / (1 - p)) made INSIDE the launch:
+ * Philox4x32-10 keyed on (seed + the device counter state[0]; graph, hidden unit).  state: two uint64 words, zero-initialised once:
+ * [0] counts the launches (advanced by the launch itself: a step replayed from a hipGraph draws a new mask every replay), [1] is
+ * its ticket word (zero between launches).  used[0] (nullable) receives the counter value this launch keyed its mask with. */
+int tsgnn_mlp3_fwd_drop_f32(const float* x, int64_t ldx, const float* w1, const float* b1, float p, uint64_t seed,
+                            unsigned long long* state, unsigned long long* used, const float* w2, const float* b2, const float* w3,
+                            const float* b3, int B, int D0, int D1, int D2, int C, float* a1, float* a2, float* logp,
+                            tsgnn_stream_t stream) {
+  if (!x || !w1 || !w2 || !w3 || !a1 || !a2 || !logp || !state || !used || ldx < D0 || !(p >= 0.f) || !(p < 1.f)) return TSGNN_EINVAL;
+  if (!tsgnn_mlp3_supported(B, D0, D1, D2, C) || (reinterpret_cast<uintptr_t>(w1) & 15) || (reinterpret_cast<uintptr_t>(w2) & 15))
+    return TSGNN_EUNSUPPORTED;
+  const size_t lds = sizeof(float) * ((size_t)D0 + ((D1 + 3) & ~3) + ((D2 + 3) & ~3) + C);
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp3_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const Mlp3Drop d{mlp3_thresh(p), (unsigned)(seed & 0xffffffffull), (unsigned)(seed >> 32), state, used};
+  mlp3_fwd_kernel<<<(unsigned)B, 64 * MH_WAVES, lds, stream>>>(x, ldx, w1, b1, nullptr, 1.0f / (1.0f - p), w2, b2, w3, b3, D0, D1, D2, C, a1, a2,
+                                                                logp, d);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+/* the 0 / 1 keep mask [B, D1] that tsgnn_mlp3_fwd_drop_f32 used in the launch whose counter value was `counter` (tests, oracles) */
+int tsgnn_mlp3_dropout_mask_f32(float p, uint64_t seed, uint64_t counter, int B, int D1, float* out, tsgnn_stream_t stream) {
+  if (!out || B <= 0 || D1 <= 0 || !(p >= 0.f) || !(p < 1.f)) return TSGNN_EINVAL;
+  const unsigned klo = (unsigned)(seed & 0xffffffffull) + (unsigned)(counter & 0xffffffffull);
+  const unsigned khi = (unsigned)(seed >> 32) + (unsigned)(counter >> 32);
+  mlp3_mask_kernel<<<(unsigned)ceil_div64((int64_t)B * D1, 256), 256, 0, stream>>>(mlp3_thresh(p), klo, khi, B, D1, out);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }

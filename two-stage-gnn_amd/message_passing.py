@@ -374,12 +374,18 @@ class _Mlp3LogSoftmax(torch.autograd.Function):
     """log_softmax(lin3(relu(lin2(dropout(relu(lin1(x))))))) — Code/sag/network.py:48-53 — forward and backward in one launch each"""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, w3, b3, keep, keep_scale):
+    def forward(ctx, x, w1, b1, w2, b2, w3, b3, keep, keep_scale, drop=None):
         x = _check(x)
         w1, w2, w3 = w1.contiguous(), w2.contiguous(), w3.contiguous()
         B, D0, D1, D2, C = x.size(0), w1.size(1), w1.size(0), w2.size(0), w3.size(0)
         a1, a2, logp = _f32(B, D1, device=x.device), _f32(B, D2, device=x.device), _f32(B, C, device=x.device)
-        nat.call("mlp3_fwd_f32", x, x.stride(0), w1, b1, keep, float(keep_scale), w2, b2, w3, b3, B, D0, D1, D2, C, a1, a2, logp)
+        if drop is not None:                              # (p, seed, device state, used): the mask is made inside the launch
+            p_, seed, state, used = drop
+            nat.call("mlp3_fwd_drop_f32", x, x.stride(0), w1, b1, float(p_), int(seed), state, used, w2, b2, w3, b3, B, D0, D1, D2, C,
+                     a1, a2, logp)
+            keep_scale, keep = 1.0 / (1.0 - float(p_)), True
+        else:
+            nat.call("mlp3_fwd_f32", x, x.stride(0), w1, b1, keep, float(keep_scale), w2, b2, w3, b3, B, D0, D1, D2, C, a1, a2, logp)
         ctx.save_for_backward(x, w1, w2, w3, a1, a2, logp)
         ctx.keep_scale = float(keep_scale) if keep is not None else 1.0
         ctx.has_b = (b1 is not None, b2 is not None, b3 is not None)
@@ -409,7 +415,7 @@ class _Mlp3LogSoftmax(torch.autograd.Function):
             nat.call("mlp3_bwd_f32", x, x.stride(0), w1, w2, w3, a1, a2, logp, dlogp, ctx.keep_scale, B, D0, D1, D2, C,
                      dw1, db1, dw2, db2, dw3, db3, dx, D0)
         hb = ctx.has_b
-        return dx, dw1, db1 if hb[0] else None, dw2, db2 if hb[1] else None, dw3, db3 if hb[2] else None, None, None
+        return dx, dw1, db1 if hb[0] else None, dw2, db2 if hb[1] else None, dw3, db3 if hb[2] else None, None, None, None
 
 
 _deferred_nll = None
@@ -441,6 +447,24 @@ class _NllLoss(torch.autograd.Function):
         return d * g, None
 
 
+class deferred_loss:
+    """`with mp.deferred_loss(): loss = model.loss(...) / mp.nll_loss(...); loss.backward(gradient=mp.unit_seed(dev))` — what
+    FlatTrainer(defer_loss=True) arranges for its own steps, for a hand-written loop: inside the block a cross-entropy / nll on the
+    fused head's output launches nothing and the head's backward forms its gradient and writes the loss value (valid after the
+    backward).  The backward MUST be seeded with unit_seed (d loss = 1): any other upstream gradient falls back to the late,
+    launch-by-launch formulas."""
+
+    def __enter__(self):
+        global CE_DEFER
+        self.prev, CE_DEFER = CE_DEFER, True
+        return self
+
+    def __exit__(self, *exc):
+        global CE_DEFER
+        CE_DEFER = self.prev
+        return False
+
+
 def take_deferred_nll(dlogp):
     global _deferred_nll
     d = _deferred_nll
@@ -464,13 +488,37 @@ def mlp3_ok(x, lin1, lin2, lin3):
                                                    int(lin2.out_features), int(lin3.out_features)))
 
 
+MLP3_DROP_IN_KERNEL = os.environ.get("TSGNN_MLP3_DROP_IN_KERNEL", "1") != "0"
+_mlp3_drop = {}             # device -> (process seed, uint64[2] device state of tsgnn_mlp3_fwd_drop_f32)
+last_mlp3_dropout = None    # (p, seed, used) of the most recent in-kernel dropout launch: tests regenerate its mask from it
+
+
+def mlp3_dropout_mask(p, seed, used, B, D1):
+    """the 0 / 1 keep mask [B, D1] of the launch that left `used` (tsgnn_mlp3_dropout_mask_f32)"""
+    out = _f32(B, D1, device=used.device)
+    nat.call("mlp3_dropout_mask_f32", float(p), int(seed), int(used.item()), int(B), int(D1), out)
+    return out
+
+
 def mlp3_log_softmax(x, lin1, lin2, lin3, p=0.0, training=False):
-    """the SAGPool head on three nn.Linear modules; the dropout mask comes from torch's generator (one bernoulli launch)"""
-    keep, scale = None, 1.0
-    if training and p > 0.0:
+    """the SAGPool head on three nn.Linear modules.  Dropout (network.py:49): the mask is made INSIDE the forward launch (Philox keyed
+    on a process seed — drawn from torch's CPU generator at first use, so torch.manual_seed governs it — and a device counter that
+    the launch advances itself: a hipGraph replay draws a new mask every time).  TSGNN_MLP3_DROP_IN_KERNEL=0: the mask comes from
+    torch's generator instead (one bernoulli launch, and two fill launches per hipGraph replay for its graph-safe state)."""
+    global last_mlp3_dropout
+    keep, scale, drop = None, 1.0, None
+    if training and p > 0.0 and MLP3_DROP_IN_KERNEL:
+        st = _mlp3_drop.get(x.device)
+        if st is None:
+            seed = int(torch.empty((), dtype=torch.int64).random_().item())
+            st = _mlp3_drop[x.device] = (seed, torch.zeros(2, dtype=torch.int64, device=x.device))
+        used = torch.empty(1, dtype=torch.int64, device=x.device)
+        drop = (float(p), st[0], st[1], used)
+        last_mlp3_dropout = (float(p), st[0], used)
+    elif training and p > 0.0:
         keep = torch.empty(x.size(0), lin1.out_features, dtype=torch.float32, device=x.device).bernoulli_(1.0 - p)
         scale = 1.0 / (1.0 - p)
-    logp = _Mlp3LogSoftmax.apply(x, lin1.weight, lin1.bias, lin2.weight, lin2.bias, lin3.weight, lin3.bias, keep, scale)
+    logp = _Mlp3LogSoftmax.apply(x, lin1.weight, lin1.bias, lin2.weight, lin2.bias, lin3.weight, lin3.bias, keep, scale, drop)
     logp._tsgnn_defer_nll = True          # mp.nll_loss on this output may be folded into the head's backward
     return logp
 
