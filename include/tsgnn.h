@@ -811,14 +811,15 @@ int tsgnn_head2_bwd_f32(const float* out, int64_t ldo, const float* vec, const f
 /* The head whose launches also make the max readout of a LAST uniform level (N <= 64 rows per graph, rows b * N + n of z; DiffPool's
  * last pooled level, encoders.py:383,388-391).  Forward: columns [c0, c0 + F) of `out` (c0 + F == P) are FILLED with
  * max_n z[b * N + n, f] first, arg[b, f] = the winning row.  Backward: the row block of graph b also writes
- * dz[b * N + n, f] = (arg[b, f] == b * N + n) ? dout[b, c0 + f] : 0 for every row of the graph. */
+ * dz[b * N + n, f] = (arg[b, f] == b * N + n) ? dout[b, c0 + f] : 0 for every row of the graph; dy NULL: the cross-entropy is folded
+ * in as in tsgnn_head2_bwd_ce_f32 (ce_y = the logits, ce_label, ce_loss; all NULL otherwise). */
 int tsgnn_head2_fwd_ro_f32(float* out, int64_t ldo, const float* w1, const float* b1, const float* w2, const float* b2, int B, int P,
                            int E, int C, float* vec, float* y, const float* z, int64_t ldz, int N, int c0, int F, int* arg,
                            tsgnn_stream_t stream);
 int tsgnn_head2_bwd_ro_f32(const float* out, int64_t ldo, const float* vec, const float* dy, const float* dvec, const float* w1,
                            const float* w2, int B, int P, int E, int C, float* dout, int64_t lddo, float* dw1, float* db1,
                            float* dw2, float* db2, float* normparts, const int* arg, int c0, int F, int N, float* dz, int64_t lddz,
-                           tsgnn_stream_t stream);
+                           const float* ce_y, const int64_t* ce_label, float* ce_loss, tsgnn_stream_t stream);
 /* the same with F.cross_entropy (encoders.py:221-224) folded in: the gradient of mean softmax cross-entropy of the logits
  * y[B, C] w.r.t. them is rebuilt inside the kernel (B * C values per block in LDS) and the loss value is written to loss[0] */
 int tsgnn_head2_bwd_ce_f32(const float* out, int64_t ldo, const float* vec, const float* y, const int64_t* label, float* loss,

@@ -60,7 +60,9 @@ hb = synthetic.host_batch(1, 64, "PROTEINS", 620)
 g, x, label = synthetic.to_device(hb, dev)
 m = E.GcnEncoderGraph(3, 128, 128, 2, 3, bn=True, args=A(), final_dim="number_classes").to(dev)
 def step_sage():
-    m.zero_grad(set_to_none=True); m.loss(m(x, g)[1], label).backward(gradient=mp.unit_seed(dev))
+    m.zero_grad(set_to_none=True)
+    with mp.deferred_loss():          # the cross-entropy inside the head's backward, as FlatTrainer(defer_loss=True) runs it
+        m.loss(m(x, g)[1], label).backward(gradient=mp.unit_seed(dev))
 t = timeit(step_sage)
 tg = graph_us(step_sage)
 print("cfg2 PROTEINS SAGE-3L h128 b64 (Nmax 620): %.0f us/step eager, %s us/step hipGraph -> %.0f graphs/s" % (t, "%.0f" % tg if tg else "n/a", 64 / (tg or t) * 1e6))
@@ -73,7 +75,9 @@ x1, adj1 = x1.to(dev), adj1.to(dev)
 gpad = GraphBatch.from_dense(adj1, layout="padded"); gpad.transpose_map()
 lab1 = torch.tensor([1], device=dev)
 def step_gat():
-    gat.zero_grad(set_to_none=True); gat.loss(gat(x1, adj1, hb1["sizes"])[1], lab1).backward(gradient=mp.unit_seed(dev))
+    gat.zero_grad(set_to_none=True)
+    with mp.deferred_loss():          # the cross-entropy inside the head's backward, as FlatTrainer(defer_loss=True) runs it
+        gat.loss(gat(x1, adj1, hb1["sizes"])[1], lab1).backward(gradient=mp.unit_seed(dev))
 t = timeit(step_gat)
 tg = graph_us(step_gat)
 print("cfg3 DD GAT-2L 4 heads h64, one graph per step (Nmax 1000): %.0f us/step eager, %s us/step hipGraph -> %.0f graphs/s" % (t, "%.0f" % tg if tg else "n/a", 1 / (tg or t) * 1e6))
@@ -86,7 +90,9 @@ adj32d = adj32.to(dev)
 x32, g32 = gat32.packed_batch(x32.to(dev), adj32d, hb32["sizes"])        # n_b rows + one ghost representative per graph
 lab32 = torch.from_numpy(hb32["label"]).to(dev)
 def step_gat32():
-    gat32.zero_grad(set_to_none=True); gat32.loss(gat32(x32, g32)[1], lab32).backward(gradient=mp.unit_seed(dev))
+    gat32.zero_grad(set_to_none=True)
+    with mp.deferred_loss():          # the cross-entropy inside the head's backward, as FlatTrainer(defer_loss=True) runs it
+        gat32.loss(gat32(x32, g32)[1], lab32).backward(gradient=mp.unit_seed(dev))
 t = timeit(step_gat32)
 tg = graph_us(step_gat32)
 print("cfg3 DD GAT-2L 4 heads h64, batch 32 in one block-diagonal step (per-graph features, packed rows + 1 ghost row per graph, Nmax 1000): %.0f us/step eager, %s us/step hipGraph -> %.0f graphs/s" % (t, "%.0f" % tg if tg else "n/a", 32 / (tg or t) * 1e6))
@@ -135,7 +141,7 @@ torch.cuda.set_stream(_S)
 
 def optimiser_step_us(model, loss_fn, B, tag, iters=50):
     """fwd + bwd + bucket + clip + Adam from one hipGraph (FlatTrainer / GraphedStep are model-agnostic)"""
-    tr = FlatTrainer(model, lr=5e-4, clip=2.0)
+    tr = FlatTrainer(model, lr=5e-4, clip=2.0, defer_loss=True)
     gs = GraphedStep(tr, loss_fn, warmup=3)
     for _ in range(5):
         gs.step()
@@ -158,7 +164,9 @@ g5, x5, lab5 = synthetic.to_device(hb5, dev)
 dpm = E.SoftPoolingGcnEncoder(512, 89, 64, 64, 2, 3, 64, assign_ratio=0.125, num_pooling=2, bn=True, linkpred=False, args=A(),
                               assign_input_dim=89, final_dim="number_classes").to(dev)
 def step_dp():
-    dpm.zero_grad(set_to_none=True); dpm.loss(dpm(x5, g5, hb5["sizes"], assign_x=x5)[1], lab5).backward(gradient=mp.unit_seed(dev))
+    dpm.zero_grad(set_to_none=True)
+    with mp.deferred_loss():          # the cross-entropy inside the head's backward, as FlatTrainer(defer_loss=True) runs it
+        dpm.loss(dpm(x5, g5, hb5["sizes"], assign_x=x5)[1], lab5).backward(gradient=mp.unit_seed(dev))
 t = timeit(step_dp, iters=10, warm=3)
 tg = graph_us(step_dp)
 print("cfg5 DD DiffPool 512->64->8 h64 b16: %.0f us/step eager, %s us/step hipGraph -> %.0f graphs/s" % (t, "%.0f" % tg if tg else "n/a", 16 / (tg or t) * 1e6))

@@ -16,7 +16,9 @@ adj32d = adj32.to(dev)
 x32, g32 = gat32.packed_batch(x32.to(dev), adj32d, hb32["sizes"])
 lab32 = torch.from_numpy(hb32["label"]).to(dev)
 def step():
-    gat32.zero_grad(set_to_none=True); gat32.loss(gat32(x32, g32)[1], lab32).backward(gradient=mp.unit_seed(dev))
+    gat32.zero_grad(set_to_none=True)
+    with mp.deferred_loss():          # the cross-entropy inside the head's backward, as FlatTrainer(defer_loss=True) runs it
+        gat32.loss(gat32(x32, g32)[1], lab32).backward(gradient=mp.unit_seed(dev))
 for _ in range(3): step()
 torch.cuda.synchronize()
 eager = int(os.environ.get("GAT_EAGER", "0"))

@@ -159,7 +159,7 @@ def test_diffpool_timed_step_vs_oracle():
         stash["logits"] = model(x, g, sizes, assign_x=x)[1]
         return model.loss(stash["logits"], label)
 
-    _run(model, loss_fn, fwd(torch.float32), fwd(torch.float64), lr=5e-4, tag="DiffPool DD b16 Nmax 512")
+    _run(model, loss_fn, fwd(torch.float32), fwd(torch.float64), lr=5e-4, defer_loss=True, tag="DiffPool DD b16 Nmax 512")
 
 
 # ------------------------------------------------------------------------------------------------ GAT (config 3)
@@ -191,7 +191,7 @@ def test_gat_timed_step_vs_oracle():
         stash["logits"] = model(x, g)[1]
         return model.loss(stash["logits"], label)
 
-    _run(model, loss_fn, fwd(torch.float32), fwd(torch.float64), lr=5e-4, tag="GAT DD b32 Nmax 1000")
+    _run(model, loss_fn, fwd(torch.float32), fwd(torch.float64), lr=5e-4, defer_loss=True, tag="GAT DD b32 Nmax 1000")
 
 
 # ------------------------------------------------------------------------------------------------ SAGPool (config 4)

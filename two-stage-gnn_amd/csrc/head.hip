@@ -1022,15 +1022,17 @@ int tsgnn_head2_bwd_f32(const float* out, int64_t ldo, const float* vec, const f
 
 /* tsgnn_head2_bwd_f32 for a head whose input columns [c0, c0 + F) were filled by tsgnn_head2_fwd_ro_f32: the row block of graph b
  * also writes the gradient of that level's rows, dz[b * N + n, f] = (arg[b, f] == b * N + n) ? dout[b, c0 + f] : 0, every element
- * (the pass tsgnn_readout_max_bwd_rows_f32 would make).  TSGNN_EUNSUPPORTED: shapes the second-generation kernel does not take. */
+ * (the pass tsgnn_readout_max_bwd_rows_f32 would make).  dy NULL: the loss is folded in as in tsgnn_head2_bwd_ce_f32 (ce_y = the
+ * logits, ce_label, ce_loss).  TSGNN_EUNSUPPORTED: shapes the second-generation kernel does not take. */
 int tsgnn_head2_bwd_ro_f32(const float* out, int64_t ldo, const float* vec, const float* dy, const float* dvec, const float* w1,
                            const float* w2, int B, int P, int E, int C, float* dout, int64_t lddo, float* dw1, float* db1,
                            float* dw2, float* db2, float* normparts, const int* arg, int c0, int F, int N, float* dz, int64_t lddz,
-                           tsgnn_stream_t stream) {
+                           const float* ce_y, const int64_t* ce_label, float* ce_loss, tsgnn_stream_t stream) {
   if (!arg || !dz || N <= 0 || F <= 0 || c0 < 0 || c0 + F > P || lddz < F) return TSGNN_EINVAL;
+  if ((dy == nullptr) == (ce_label == nullptr)) return TSGNN_EINVAL;         // dy given, or the loss folded in (ce_y, ce_label, ce_loss)
   const RoTail rt{nullptr, 0, N, c0, F, const_cast<int*>(arg), dz, lddz};
-  return head2_bwd_launch(out, ldo, vec, dy, dvec, w1, w2, B, P, E, C, dout, lddo, dw1, db1, dw2, db2, normparts, nullptr, nullptr,
-                          nullptr, stream, nullptr, &rt);
+  return head2_bwd_launch(out, ldo, vec, dy, dvec, w1, w2, B, P, E, C, dout, lddo, dw1, db1, dw2, db2, normparts, ce_y, ce_label,
+                          ce_loss, stream, nullptr, &rt);
 }
 
 /* the same with the loss folded in: dy = d mean-softmax-cross-entropy(y, label) / dy is rebuilt inside the kernel and the loss

@@ -313,7 +313,9 @@ class DGATEncoderGraph(nn.Module):
             eye = _eye_cache.get((C, x.device))
             if eye is None:
                 eye = _eye_cache[(C, x.device)] = torch.eye(C, dtype=torch.float32, device=x.device)
-            return x, mp._Head2.apply(x, lin1.weight, lin1.bias, eye, None)[1]
+            y = mp._Head2.apply(x, lin1.weight, lin1.bias, eye, None)[1]
+            y._tsgnn_defer_ce = True          # (under FlatTrainer(defer_loss=True) / mp.deferred_loss(): mp._SoftmaxCE)
+            return x, y
         return x, self.map2_model(lin1(x))
 
     def loss(self, pred, label, type="softmax"):

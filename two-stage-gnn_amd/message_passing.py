@@ -1080,7 +1080,9 @@ class _Head2(torch.autograd.Function):
         dev = out.device
         if dy is None and dvec is None:
             return None, None, None, None, None
-        dy = dy.contiguous() if dy is not None else torch.zeros(B, C, device=dev)
+        ce = take_deferred_ce(dy) if dy is not None else None      # deferred cross-entropy: this backward rebuilds dy
+        if ce is None:
+            dy = dy.contiguous() if dy is not None else torch.zeros(B, C, device=dev)
         dvec = dvec.contiguous() if dvec is not None else None
         dout = _f32(B, P, device=dev)
         pw1, pb1, pw2, pb2 = ctx.params
@@ -1089,7 +1091,11 @@ class _Head2(torch.autograd.Function):
         db1, s3 = _sink_or_new(pb1, (E,), dev) if ctx.has_b[0] else (None, False)
         db2, s4 = _sink_or_new(pb2, (C,), dev) if ctx.has_b[1] else (None, False)
         parts = head_norm_slots((s1, s2, s3, s4), ctx.has_b, (pw1, pb1, pw2, pb2), E)
-        nat.call("head2_bwd_f32", out, out.stride(0), vec, dy, dvec, w1, w2, B, P, E, C, dout, dout.stride(0), dw1, db1, dw2, db2, parts)
+        if ce is not None:
+            nat.call("head2_bwd_ce_f32", out, out.stride(0), vec, ce[0], ce[1], ce[2], dvec, w1, w2, B, P, E, C, dout, dout.stride(0),
+                     dw1, db1, dw2, db2, parts)
+        else:
+            nat.call("head2_bwd_f32", out, out.stride(0), vec, dy, dvec, w1, w2, B, P, E, C, dout, dout.stride(0), dw1, db1, dw2, db2, parts)
         return dout, None if s1 else dw1, None if s3 else db1, None if s2 else dw2, None if s4 else db2
 
 
@@ -1129,7 +1135,9 @@ class _Head2Tail(torch.autograd.Function):
         dev = out.device
         if dy is None and dvec is None:
             return (None,) * (7 + len(widths))
-        dy = dy.contiguous() if dy is not None else torch.zeros(B, C, device=dev)
+        ce = take_deferred_ce(dy) if dy is not None else None      # deferred cross-entropy: this backward rebuilds dy
+        if ce is None:
+            dy = dy.contiguous() if dy is not None else torch.zeros(B, C, device=dev)
         dvec = dvec.contiguous() if dvec is not None else None
         dout = _f32(B, P, device=dev)
         dz = _f32(B * N, F, device=dev)
@@ -1139,9 +1147,15 @@ class _Head2Tail(torch.autograd.Function):
         db1, s3 = _sink_or_new(pb1, (E,), dev) if ctx.has_b[0] else (None, False)
         db2, s4 = _sink_or_new(pb2, (C,), dev) if ctx.has_b[1] else (None, False)
         parts = head_norm_slots((s1, s2, s3, s4), ctx.has_b, (pw1, pb1, pw2, pb2), E)
-        if not nat.try_call("head2_bwd_ro_f32", out, out.stride(0), vec, dy, dvec, w1, w2, B, P, E, C, dout, dout.stride(0), dw1, db1, dw2,
-                            db2, parts, arg, c0, F, N, dz, dz.stride(0)):
-            nat.call("head2_bwd_f32", out, out.stride(0), vec, dy, dvec, w1, w2, B, P, E, C, dout, dout.stride(0), dw1, db1, dw2, db2, parts)
+        cy, cl, closs = ce if ce is not None else (None, None, None)
+        if not nat.try_call("head2_bwd_ro_f32", out, out.stride(0), vec, None if ce is not None else dy, dvec, w1, w2, B, P, E, C, dout,
+                            dout.stride(0), dw1, db1, dw2, db2, parts, arg, c0, F, N, dz, dz.stride(0), cy, cl, closs):
+            if ce is not None:
+                nat.call("head2_bwd_ce_f32", out, out.stride(0), vec, cy, cl, closs, dvec, w1, w2, B, P, E, C, dout, dout.stride(0),
+                         dw1, db1, dw2, db2, parts)
+            else:
+                nat.call("head2_bwd_f32", out, out.stride(0), vec, dy, dvec, w1, w2, B, P, E, C, dout, dout.stride(0), dw1, db1, dw2, db2,
+                         parts)
             nat.call("readout_max_bwd_f32", dout[:, c0:], dout.stride(0), arg, B, F, None, 0, 0, B * N, dz.zero_(), dz.stride(0))
         grads, o = [], 0
         for w in widths:
@@ -1158,7 +1172,9 @@ def head2_tail_ok(cols, z, N, lin1, lin2):
 
 def head2_tail(cols, parts, z, N, lin1, lin2):
     """(lin1(out), lin2(lin1(out))) with out = [parts | max readout of the uniform level z (N rows per graph)]"""
-    return _Head2Tail.apply(cols, z, int(N), lin1.weight, lin1.bias, lin2.weight, lin2.bias, *parts)
+    vec, y = _Head2Tail.apply(cols, z, int(N), lin1.weight, lin1.bias, lin2.weight, lin2.bias, *parts)
+    y._tsgnn_defer_ce = True              # a cross-entropy on these logits may be folded into this node's backward (mp._SoftmaxCE)
+    return vec, y
 
 
 def head_norm_slots(sunk, has_b, params, E):
@@ -1182,4 +1198,6 @@ def head2_ok(out, lin1, lin2):
 
 def head2(out, lin1, lin2):
     """lin2(lin1(out)) returning (lin1 output, lin2 output)."""
-    return _Head2.apply(out, lin1.weight, lin1.bias, lin2.weight, lin2.bias)
+    vec, y = _Head2.apply(out, lin1.weight, lin1.bias, lin2.weight, lin2.bias)
+    y._tsgnn_defer_ce = True              # a cross-entropy on these logits may be folded into this node's backward (mp._SoftmaxCE)
+    return vec, y
