@@ -537,6 +537,17 @@ int tsgnn_gat_attn_bwd_f32(const float* hp, int64_t ldh, const float* y, int64_t
                            const float* iso_row, int iso_row_ld, float uscale, float drop_p, uint64_t seed,
                            const unsigned long long* drop_ctr, const float* stat, float* dhp, int Ns, float* t1, float* t2, float* S,
                            float* dupart, tsgnn_stream_t stream);
+/* the same for a layer whose output feeds ONLY the max readout over each graph's rows (the last layer, encoders_GAT.py:189): dy NULL,
+ * and instead the readout's gradient ro_dout [B, Co] (leading dimension ro_ldo), its winners ro_arg [B, Co] (rows) and row_graph
+ * [rows]: dy[i, c] = (ro_arg[b, c] == i) ? ro_dout[b, c] : 0 with b = row_graph[i] is formed on the fly — neither the [rows, Co]
+ * gradient tensor nor the pass that would write it (tsgnn_readout_max_bwd_rows_f32) exists.  Co = the layer's output width. */
+int tsgnn_gat_attn_bwd_ro_f32(const float* hp, int64_t ldh, const float* y, int64_t ldy, const float* dy, int64_t lddy, const int* rp_t,
+                              const int* col_t, int64_t rows, int H, int Fh, float slope, int mean_heads, int apply_elu,
+                              const int* graph_ptr, int B, const int* iso_idx, const float* iso_w, const int* iso_ptr,
+                              const float* iso_row, int iso_row_ld, float uscale, float drop_p, uint64_t seed,
+                              const unsigned long long* drop_ctr, const float* stat, float* dhp, int Ns, float* t1, float* t2, float* S,
+                              float* dupart, const float* ro_dout, int64_t ro_ldo, const int* ro_arg, const int* row_graph,
+                              tsgnn_stream_t stream);
 /* the dropout multipliers (0 or 1 / (1 - p)) of attention elements (i0 + i, j0 + j) of every head, out[ni, nj, H] — what the two
  * kernels above apply; lets a test hand the very same mask to the dense oracle */
 int tsgnn_gat_dropout_mult_f32(float drop_p, uint64_t seed, const unsigned long long* drop_ctr, int64_t i0, int64_t ni, int64_t j0,

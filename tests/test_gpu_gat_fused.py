@@ -134,7 +134,8 @@ def test_fused_path_is_the_one_that_runs():
     finally:
         nat.trace = None
     assert names.count("gat_pack_f32") == 1 and names.count("gat_unpack_f32") == 1
-    assert names.count("gat_attn_fwd_f32") == 2 and names.count("gat_attn_bwd_f32") == 2
+    assert names.count("gat_attn_fwd_f32") == 2 and names.count("gat_attn_bwd_ro_f32") == 2
+    assert names.count("readout_max_fwd_f32") == 1 and names.count("readout_max_bwd_rows_f32") == 0    # (the last layer's node made the readout)
     assert names.count("wgrad_blocks_f32") == 2
     assert not any(n in names for n in ("edge_softmax_fwd_f32", "csr_sddmm_heads_f32", "node_scores2_f32"))
 

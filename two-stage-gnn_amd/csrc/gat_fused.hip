@@ -234,16 +234,36 @@ struct GatBwd {
   float* S;                                   // [rows, H]: sum_i alpha_ij dalpha_ij of column j
   float* dupart; int P;                       // [B, P, C]: partial sums of dpre over the P row ranges of every graph
   unsigned ngraph_blocks;                     // B * P (0 without listed edge-less columns)
+  // nullable: the layer's output feeds ONLY the max readout over each graph's rows (the LAST layer, encoders_GAT.py:189): dy is not
+  // a tensor then but dy[i, c] = (ro_arg[b, c] == i) ? ro_dout[b, c] : 0 with b = row_graph[i] — formed on the fly, so the pass that
+  // would scatter the readout's gradient into a [rows, C] tensor and the gathers of its rows here both disappear
+  const float* ro_dout; int64_t ro_ldo; const int* ro_arg; const int* row_graph;
 };
+// the readout's (winning row, gradient) of graph b for this lane's four output columns
+struct RoPair { int4 win; float4 g; };
+template <int LPH>
+__device__ __forceinline__ RoPair ro_pair(const GatBwd& a, int b, int lane, int co) {
+  const int c = a.mean_heads ? 4 * (lane % LPH) : co;
+  const int Co = a.mean_heads ? a.Fh : a.H * a.Fh;
+  RoPair r;
+  r.win = *reinterpret_cast<const int4*>(a.ro_arg + (int64_t)b * Co + c);
+  r.g = ldg4_(a.ro_dout + (int64_t)b * a.ro_ldo + c);
+  return r;
+}
 
 // dpre of row i for this lane's four features: dy * ELU'(y) (concat) or (dy * ELU'(y)) / H of the lane's slot (mean over heads).
 // Split in two so that a caller can issue the requests of SEVERAL rows before the arithmetic of the first one waits for them
 // (requests and arithmetic interleaved row by row were one dependent round trip per row).  Requests are unconditional — a lane
 // beyond the row's width reads column 0 and is masked at the end.
 template <int LPH>
-__device__ __forceinline__ void dpre_load(const GatBwd& a, int64_t i, int lane, int co, float4& d, float4& yv) {
+__device__ __forceinline__ void dpre_load(const GatBwd& a, int64_t i, int lane, int co, float4& d, float4& yv, const RoPair& ro) {
   const int c = a.mean_heads ? 4 * (lane % LPH) : co;
-  d = ldg4_(a.dy + i * a.lddy + c);
+  if (a.ro_arg) {                                            // (uniform) the readout's gradient: no request at all
+    const int ii = (int)i;
+    d = make_float4(ro.win.x == ii ? ro.g.x : 0.f, ro.win.y == ii ? ro.g.y : 0.f, ro.win.z == ii ? ro.g.z : 0.f, ro.win.w == ii ? ro.g.w : 0.f);
+  } else {
+    d = ldg4_(a.dy + i * a.lddy + c);
+  }
   yv = ldg4_(a.y + i * a.ldy + c);
 }
 __device__ __forceinline__ float4 dpre_finish(const GatBwd& a, float4 d, const float4& yv, bool live) {
@@ -263,9 +283,9 @@ __device__ __forceinline__ float4 dpre_finish(const GatBwd& a, float4 d, const f
   return d;
 }
 template <int LPH>
-__device__ __forceinline__ float4 dpre_row(const GatBwd& a, int64_t i, int lane, int co, bool live) {
+__device__ __forceinline__ float4 dpre_row(const GatBwd& a, int64_t i, int lane, int co, bool live, const RoPair& ro) {
   float4 d, yv;
-  dpre_load<LPH>(a, i, lane, co, d, yv);
+  dpre_load<LPH>(a, i, lane, co, d, yv, ro);
   return dpre_finish(a, d, yv, live);
 }
 
@@ -314,6 +334,8 @@ __global__ __launch_bounds__(256, GAT_BWD_WAVES_PER_SIMD) void gat_attn_bwd_kern
     const int64_t g0 = a.graph_ptr[b], g1 = a.graph_ptr[b + 1];
     const int q0 = a.iso_ptr[b], q1 = a.iso_ptr[b + 1];
     if (q0 == q1) return;
+    RoPair ro{};
+    if (a.ro_arg) ro = ro_pair<LPH>(a, b, lane, co);
     if (DROP) {
       // with dropout every (i, j) element has its own mask: column by column (the reference's dense attention^T . dpre)
       if (part != 0) return;
@@ -323,7 +345,7 @@ __global__ __launch_bounds__(256, GAT_BWD_WAVES_PER_SIMD) void gat_attn_bwd_kern
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int64_t i = g0; i < g1; ++i) {
           const float mlt = drop_mult(a.drop, (unsigned)i, (unsigned)jj, h);
-          const float4 d = dpre_row<LPH>(a, i, lane, co, live);
+          const float4 d = dpre_row<LPH>(a, i, lane, co, live, ro);
           s.x = fmaf(mlt, d.x, s.x); s.y = fmaf(mlt, d.y, s.y); s.z = fmaf(mlt, d.z, s.z); s.w = fmaf(mlt, d.w, s.w);
         }
         if (live) *reinterpret_cast<float4*>(a.dhp + (int64_t)jj * ldh + co) = make_float4(w * s.x, w * s.y, w * s.z, w * s.w);
@@ -339,7 +361,7 @@ __global__ __launch_bounds__(256, GAT_BWD_WAVES_PER_SIMD) void gat_attn_bwd_kern
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int64_t ii = i + 4 * k;
-        dpre_load<LPH>(a, ii < r1 ? ii : r0, lane, co, d[k], yv[k]);
+        dpre_load<LPH>(a, ii < r1 ? ii : r0, lane, co, d[k], yv[k], ro);
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) d[k] = dpre_finish(a, d[k], yv[k], live && i + 4 * k < r1);
@@ -365,6 +387,8 @@ __global__ __launch_bounds__(256, GAT_BWD_WAVES_PER_SIMD) void gat_attn_bwd_kern
   const float* __restrict__ hp = a.hp;
   TR(0);
   const int t0 = a.rp_t[j], t1 = a.rp_t[j + 1];
+  RoPair ro{};
+  if (a.ro_arg) ro = ro_pair<LPH>(a, a.row_graph[j], lane, co);      // column j's entries are rows of j's own graph
   float4 hj = ldg4_(hp + j * ldh + co);                       // (unconditional; lanes beyond the row's width are zeroed)
   if (!live) hj = make_float4(0.f, 0.f, 0.f, 0.f);
   const float scol = hp[j * ldh + C + H + h];
@@ -388,7 +412,7 @@ __global__ __launch_bounds__(256, GAT_BWD_WAVES_PER_SIMD) void gat_attn_bwd_kern
 #pragma unroll
       for (int k = 0; k < 4; ++k) {                            // twelve requests, then the arithmetic
         sr[k] = srow[(int64_t)i4[k] * ldh];
-        dpre_load<LPH>(a, i4[k], lane, co, dp[k], yv[k]);
+        dpre_load<LPH>(a, i4[k], lane, co, dp[k], yv[k], ro);
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) dp[k] = dpre_finish(a, dp[k], yv[k], live);
@@ -654,9 +678,32 @@ int tsgnn_gat_attn_bwd_f32(const float* hp, int64_t ldh, const float* y, int64_t
                            const float* iso_row, int iso_row_ld, float uscale, float drop_p, uint64_t seed,
                            const unsigned long long* drop_ctr, const float* stat, float* dhp, int Ns, float* t1, float* t2, float* S,
                            float* dupart, tsgnn_stream_t stream) {
-  if (!hp || !y || !dy || !rp_t || !col_t || !dhp || !stat || !t1 || !t2 || !S || rows < 0 || drop_p < 0.f || drop_p >= 1.f) return TSGNN_EINVAL;
+  if (!dy) return TSGNN_EINVAL;
+  return tsgnn_gat_attn_bwd_ro_f32(hp, ldh, y, ldy, dy, lddy, rp_t, col_t, rows, H, Fh, slope, mean_heads, apply_elu, graph_ptr, B, iso_idx,
+                                   iso_w, iso_ptr, iso_row, iso_row_ld, uscale, drop_p, seed, drop_ctr, stat, dhp, Ns, t1, t2, S, dupart,
+                                   nullptr, 0, nullptr, nullptr, stream);
+}
+
+/* the same for a layer whose output feeds ONLY the max readout over each graph's rows (the last layer, encoders_GAT.py:189): dy NULL,
+ * and instead the readout's gradient ro_dout [B, Co] (leading dimension ro_ldo), its winners ro_arg [B, Co] and row_graph [rows]:
+ * dy[i, c] = (ro_arg[b, c] == i) ? ro_dout[b, c] : 0 with b = row_graph[i] is formed on the fly (Co = the layer's output width). */
+int tsgnn_gat_attn_bwd_ro_f32(const float* hp, int64_t ldh, const float* y, int64_t ldy, const float* dy, int64_t lddy, const int* rp_t,
+                              const int* col_t, int64_t rows, int H, int Fh, float slope, int mean_heads, int apply_elu,
+                              const int* graph_ptr, int B, const int* iso_idx, const float* iso_w, const int* iso_ptr,
+                              const float* iso_row, int iso_row_ld, float uscale, float drop_p, uint64_t seed,
+                              const unsigned long long* drop_ctr, const float* stat, float* dhp, int Ns, float* t1, float* t2, float* S,
+                              float* dupart, const float* ro_dout, int64_t ro_ldo, const int* ro_arg, const int* row_graph,
+                              tsgnn_stream_t stream) {
+  if (!hp || !y || !rp_t || !col_t || !dhp || !stat || !t1 || !t2 || !S || rows < 0 || drop_p < 0.f || drop_p >= 1.f) return TSGNN_EINVAL;
+  if ((dy == nullptr) == (ro_arg == nullptr)) return TSGNN_EINVAL;            // exactly one source of the output's gradient
+  if (ro_arg && (!ro_dout || !row_graph)) return TSGNN_EINVAL;
   if (!fused_ok(H, Fh)) return TSGNN_EUNSUPPORTED;
   const int C = H * Fh, Co = mean_heads ? Fh : C;
+  if (ro_arg) {
+    if (ro_ldo < Co) return TSGNN_EINVAL;
+    if ((ro_ldo % 4) || (Co % 4) || ((reinterpret_cast<uintptr_t>(ro_dout) | reinterpret_cast<uintptr_t>(ro_arg)) & 15)) return TSGNN_EUNSUPPORTED;
+    dy = y; lddy = ldy;                                                        // (never read; keeps the checks below meaningful)
+  }
   if (Ns < C + 2 * H || ldh < Ns || Ns - C - 2 * H > 64 || (ldh % 4) || (ldy % 4) || (lddy % 4) || ldy < Co || lddy < Co ||
       ((reinterpret_cast<uintptr_t>(hp) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dhp) |
         reinterpret_cast<uintptr_t>(dupart)) & 15))
@@ -667,7 +714,8 @@ int tsgnn_gat_attn_bwd_f32(const float* hp, int64_t ldh, const float* y, int64_t
   const int P = tsgnn_gat_bwd_parts(B);
   GatBwd a{hp, ldh, y, ldy, dy, lddy, rp_t, col_t, reinterpret_cast<const float2*>(stat), rows, H, Fh, slope, mean_heads, apply_elu, graph_ptr, B,
            lst ? iso_idx : nullptr, lst ? iso_w : nullptr, lst ? iso_ptr : nullptr, lst ? iso_row : nullptr, iso_row_ld, uscale,
-           make_drop(drop_p, seed, drop_ctr), dhp, Ns, t1, t2, S, dupart, P, lst ? (unsigned)(B * P) : 0u};
+           make_drop(drop_p, seed, drop_ctr), dhp, Ns, t1, t2, S, dupart, P, lst ? (unsigned)(B * P) : 0u,
+           ro_arg ? ro_dout : nullptr, ro_ldo, ro_arg, row_graph};
   const unsigned grid = (unsigned)ceil_div64(rows, 4) + a.ngraph_blocks;
   const bool drop = a.drop.thresh != 0u;
   TSGNN_KNAME("gat_attn_bwd_kernel<%d,%s>", Fh / 4, drop ? "true" : "false");

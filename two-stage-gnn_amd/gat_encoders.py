@@ -157,9 +157,11 @@ def _fused_layer_ok(heads, g, rows):
     return gf.batch_ok(g, rows, len(heads), drop_on)
 
 
-def _gat_heads_forward(heads, x, adj, concat_heads, elu, wp=None):
+def _gat_heads_forward(heads, x, adj, concat_heads, elu, wp=None, readout=False):
     """all heads of a layer in one pass: h = x0 [W_0|W_1|...], one edge-softmax / aggregation launch set.
-    wp: this layer's packed operand when the caller packed several layers in one launch (gat_fused.pack_layers)."""
+    wp: this layer's packed operand when the caller packed several layers in one launch (gat_fused.pack_layers).
+    readout: the caller only wants the max readout of the output over each graph's rows (the last layer, :189); returned as
+    (tensor, True) when the fused layer made it inside its own node, (node output, False) otherwise."""
     g = _padded_batch(adj)
     B, N = g.B, g.nmax
     H = len(heads)
@@ -181,8 +183,12 @@ def _gat_heads_forward(heads, x, adj, concat_heads, elu, wp=None):
             and _fused_layer_ok(heads, g, x0.size(0))):
         if wp is None:
             (wp,) = gf.pack_layers([heads])
+        if readout and gf.readout_ok(g, x0.size(0)):
+            return gf.gat_layer(x0, wp, g, H, Fo, slope, mean_heads=not concat_heads, apply_elu=elu, drop_p=p if drop_on else 0.0,
+                                readout=True), True
         y = gf.gat_layer(x0, wp, g, H, Fo, slope, mean_heads=not concat_heads, apply_elu=elu, drop_p=p if drop_on else 0.0)
-        return y if ragged else y.reshape(B, N, -1)
+        y = y if ragged else y.reshape(B, N, -1)
+        return (y, False) if readout else y
     if drop_on:
         raise NotImplementedError("attention dropout > 0 needs the fused layer kernels (gat_fused.py): supported head shape, "
                                   "per-graph features (or B = 1), un-packed rows")
@@ -196,7 +202,8 @@ def _gat_heads_forward(heads, x, adj, concat_heads, elu, wp=None):
         h = h.unsqueeze(0).expand(B, N, H * Fo).reshape(B * N, H * Fo)       # T4: graph 0's features everywhere
     pre = att.attention_aggregate(h, a_row, a_col, g, H, slope, by_column=True, uniform_isolated=True)
     out = att.elu_heads(pre, H, mean_heads=not concat_heads, apply_elu=elu)
-    return out if ragged else out.reshape(B, N, -1)
+    out = out if ragged else out.reshape(B, N, -1)
+    return (out, False) if readout else out
 
 
 class DGATLayer(nn.Module):
@@ -210,11 +217,11 @@ class DGATLayer(nn.Module):
         for i, attention in enumerate(self.attentions):
             self.add_module("attention_{}".format(i), attention)
 
-    def forward(self, x, adj, wp=None):
+    def forward(self, x, adj, wp=None, readout=False):
         if self.dropout > 0 and self.training:
             x = F.dropout(x, self.dropout, training=True)
         # concat: per-head ELU then concatenation (:75); otherwise mean over heads then ELU (:78-83)
-        return _gat_heads_forward(self.attentions, x, adj, concat_heads=self.concat, elu=True, wp=wp)
+        return _gat_heads_forward(self.attentions, x, adj, concat_heads=self.concat, elu=True, wp=wp, readout=readout)
 
 
 class DGATEncoderGraph(nn.Module):
@@ -261,16 +268,22 @@ class DGATEncoderGraph(nn.Module):
     def build_pred_layers(self, pred_input_dim, label_dim, num_aggs=1):
         return nn.Linear(pred_input_dim * num_aggs, label_dim)
 
-    def gcn_forward(self, x, adj, conv_first, conv_block, conv_last):
+    def gcn_forward(self, x, adj, conv_first, conv_block, conv_last, readout=False):
+        """readout: returns (tensor, made) — the max readout of the last layer's output when its fused node made it (made = True),
+        the node output otherwise"""
         g = _padded_batch(adj)
         layers = [conv_first] + (list(conv_block) if conv_block is not None else []) + [conv_last]
         wps = [None] * len(layers)
         rows = x.size(0) if x.dim() == 2 else (x.size(0) * x.size(1) if _own_features(conv_first.attentions, g) else x.size(1))
         if len(layers) <= 4 and all(isinstance(l, DGATLayer) and _fused_layer_ok(l.attentions, g, rows) for l in layers):
             wps = gf.pack_layers([l.attentions for l in layers])        # the parameters of every layer: one launch each way
-        for layer, wp in zip(layers, wps):
-            x = layer(x, g, wp=wp) if isinstance(layer, DGATLayer) else layer(x, g)
-        return x
+        made = False
+        for k, (layer, wp) in enumerate(zip(layers, wps)):
+            if readout and k == len(layers) - 1 and isinstance(layer, DGATLayer):
+                x, made = layer(x, g, wp=wp, readout=True)
+            else:
+                x = layer(x, g, wp=wp) if isinstance(layer, DGATLayer) else layer(x, g)
+        return (x, made) if readout else x
 
     def packed_batch(self, x, adj, batch_num_nodes):
         """(rows, GraphBatch) of the packed block-diagonal batch (per_graph_features mode): dense adj [B,Nmax,Nmax] -> CSR
@@ -298,10 +311,11 @@ class DGATEncoderGraph(nn.Module):
                 and not drop_on:                          # (attention dropout makes a graph's padded rows differ: no packing)
             x, adj = self.packed_batch(x, adj, batch_num_nodes)
         g = _padded_batch(adj)
-        x = self.gcn_forward(x, g, self.conv_first, self.conv_block, self.conv_last)       # [B,N,E] ([rows,E] packed)
-        if x.dim() == 3:
-            x = x.reshape(g.B * g.nmax, x.size(2))
-        x = mp.readout_max(x, g)                                                            # max over ALL padded rows (:189)
+        x, made = self.gcn_forward(x, g, self.conv_first, self.conv_block, self.conv_last, readout=True)   # [B,N,E] ([rows,E] packed)
+        if not made:                                           # (else: the last layer's node made the readout itself)
+            if x.dim() == 3:
+                x = x.reshape(g.B * g.nmax, x.size(2))
+            x = mp.readout_max(x, g)                                                        # max over ALL padded rows (:189)
         lin1 = self.pred_model if self.final_dim != "output_dim" else self.map_model
         if mp.head2_ok(x, lin1, self.map2_model):
             return x, mp.head2(x, lin1, self.map2_model)[1]                                # both nn.Linear: one launch each way

@@ -132,8 +132,10 @@ def wgrad_blocks(z, K_in, du):
 
 class _GatLayer(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, wp, g, H, Fo, slope, mean_heads, apply_elu, drop_p, seed, ctr):
-        """x [R, >= Fin] (16-byte rows), wp [Fin, Ns] -> y [R, H*Fo] ([R, Fo] with mean_heads)"""
+    def forward(ctx, x, wp, g, H, Fo, slope, mean_heads, apply_elu, drop_p, seed, ctr, readout=False):
+        """x [R, >= Fin] (16-byte rows), wp [Fin, Ns] -> y [R, H*Fo] ([R, Fo] with mean_heads); readout: returns the max readout of y
+        over each graph's rows [B, .] instead (the LAST layer, encoders_GAT.py:189) — its gradient then reaches the backward kernel
+        as (dout, winners) and dy is never a tensor"""
         R, Fin, Ns, C = int(x.size(0)), int(wp.size(0)), int(wp.size(1)), H * Fo
         dev = x.device
         hp = _f32(R, Ns, device=dev)
@@ -149,18 +151,30 @@ class _GatLayer(torch.autograd.Function):
                  int(seed), ctr, stat, y, y.stride(0))
         ctx.cfg = (g, H, Fo, slope, mean_heads, apply_elu, drop_p, seed, Fin)
         ctx.ctr = ctr
-        ctx.save_for_backward(x, wp, hp, y, iso, stat)
         ctx.lst = lst
+        ctx.readout = bool(readout)
+        if readout:
+            out, arg = mp.readout_fwd_raw(y, g)
+            ctx.save_for_backward(x, wp, hp, y, iso, stat, arg)
+            return out
+        ctx.save_for_backward(x, wp, hp, y, iso, stat)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, wp, hp, y, iso, stat = ctx.saved_tensors
+        x, wp, hp, y, iso, stat = ctx.saved_tensors[:6]
         g, H, Fo, slope, mean_heads, apply_elu, drop_p, seed, Fin = ctx.cfg
         lst = ctx.lst
         R, Ns, C = int(x.size(0)), int(wp.size(1)), H * Fo
         dev = x.device
-        dy = dy.contiguous()
+        ro = None
+        if ctx.readout:                                          # dy = the readout's gradient: handed on as (dout, winners)
+            dro = mp.readout_dout_in_place(dy)
+            if dro.stride(0) % 4 or dro.data_ptr() % 16:
+                dro = dro.contiguous()
+            ro, dy = (dro, ctx.saved_tensors[6]), None
+        else:
+            dy = dy.contiguous()
         rp_t, col_t, src_e_t = g.transpose_map()
         nnz = max(int(g.nnz), 1)
         dhp = _f32(R, Ns, device=dev)
@@ -168,9 +182,10 @@ class _GatLayer(torch.autograd.Function):
         i_idx, i_w, i_ptr = lst if lst is not None else (None, None, None)
         us = 1.0 / max(int(g.nmax), 1)
         dupart = _f32(int(g.B) * int(nat.lib().tsgnn_gat_bwd_parts(int(g.B))) * C, device=dev) if lst is not None else None
-        nat.call("gat_attn_bwd_f32", hp, hp.stride(0), y, y.stride(0), dy, dy.stride(0), rp_t, col_t, R, H, Fo, float(slope),
-                 int(mean_heads), int(apply_elu), g.graph_ptr, int(g.B), i_idx, i_w, i_ptr, iso if lst is not None else None, H,
-                 us, float(drop_p), int(seed), ctx.ctr, stat, dhp, Ns, t1, t2, S, dupart)
+        nat.call("gat_attn_bwd_ro_f32", hp, hp.stride(0), y, y.stride(0), dy, dy.stride(0) if dy is not None else 0, rp_t, col_t, R, H, Fo,
+                 float(slope), int(mean_heads), int(apply_elu), g.graph_ptr, int(g.B), i_idx, i_w, i_ptr, iso if lst is not None else None,
+                 H, us, float(drop_p), int(seed), ctx.ctr, stat, dhp, Ns, t1, t2, S, dupart,
+                 ro[0] if ro else None, ro[0].stride(0) if ro else 0, ro[1] if ro else None, g.row_graph if ro else None)
         fin = lst is not None and drop_p == 0.0                 # (with dropout the backward completes the listed columns itself)
         nat.call("gat_score_rowsum_f32", g.rowptr, g.col, att._inverse_entry_map(g, src_e_t), t1, t2, S, R, H, dhp, dhp.stride(0), C,
                  dupart if fin else None, int(g.B), i_idx if fin else None, i_w if fin else None, i_ptr if fin else None, us)
@@ -183,18 +198,26 @@ class _GatLayer(torch.autograd.Function):
             if x.size(1) > Fin:
                 dx[:, Fin:].zero_()
             nat.call("rowgemm_f32", dhp, dhp.stride(0), wp, wp.stride(0), 1, None, dx, dx.stride(0), None, R, Ns, Fin, 0, 0)
-        return dx, dwp, None, None, None, None, None, None, None, None, None
+        return dx, dwp, None, None, None, None, None, None, None, None, None, None
 
 
-def gat_layer(x, wp, g, H, Fo, slope, mean_heads, apply_elu, drop_p=0.0):
+def readout_ok(g, rows):
+    """the last layer's max readout may ride in the layer's node (every row is a slot of its graph: no separate ghost rows)"""
+    return READOUT_IN_LAYER and g.row_graph is not None and g.n_ghost == 0 and int(g.total_rows) == int(rows)
+
+
+def gat_layer(x, wp, g, H, Fo, slope, mean_heads, apply_elu, drop_p=0.0, readout=False):
     """drop_p > 0: attention dropout with a fresh mask per call — the key is (process seed, device counter): the counter is
     advanced and snapshotted ON THE DEVICE (two tiny launches), so a step captured in a hipGraph draws a new mask at every
     replay and the backward of this call regenerates exactly the mask of its forward."""
     seed, ctr = 0, None
     if drop_p > 0.0:
         seed, ctr = dropout_key(x.device)
-    return _GatLayer.apply(x, wp, g, int(H), int(Fo), float(slope), bool(mean_heads), bool(apply_elu), float(drop_p), int(seed), ctr)
+    return _GatLayer.apply(x, wp, g, int(H), int(Fo), float(slope), bool(mean_heads), bool(apply_elu), float(drop_p), int(seed), ctr,
+                           bool(readout))
 
+
+READOUT_IN_LAYER = os.environ.get("TSGNN_GAT_READOUT_IN_LAYER", "1") != "0"   # the last layer's max readout inside its autograd node
 
 _drop_state = {}        # device -> (process seed, int64 device counter)
 last_dropout_key = None  # (seed, counter snapshot) of the most recent dropout layer call (tests hand it to the dense oracle)
