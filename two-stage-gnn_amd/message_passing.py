@@ -507,7 +507,10 @@ def mlp3_log_softmax(x, lin1, lin2, lin3, p=0.0, training=False):
     torch's generator instead (one bernoulli launch, and two fill launches per hipGraph replay for its graph-safe state)."""
     global last_mlp3_dropout
     keep, scale, drop = None, 1.0, None
-    if training and p > 0.0 and MLP3_DROP_IN_KERNEL:
+    in_kernel = MLP3_DROP_IN_KERNEL
+    if in_kernel and _mlp3_drop.get(x.device) is None and x.is_cuda and torch.cuda.is_current_stream_capturing():
+        in_kernel = False       # (the device counter cannot be created inside a capture — its zero fill would replay; torch's mask here)
+    if training and p > 0.0 and in_kernel:
         st = _mlp3_drop.get(x.device)
         if st is None:
             seed = int(torch.empty((), dtype=torch.int64).random_().item())
