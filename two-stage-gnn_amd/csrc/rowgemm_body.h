@@ -374,20 +374,33 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem_a
       float4 va = nbv[p][0];
 #pragma unroll
       for (int k = 1; k < GN; ++k) { va.x += nbv[p][k].x; va.y += nbv[p][k].y; va.z += nbv[p][k].z; va.w += nbv[p][k].w; }
+      bool table_full = g.ell_w <= GN && ids[p][GN - 1] >= 0;  // only a row whose table is full can continue in the CSR tail
       if (colok && g.ell_w > GN && ids[p][GN - 1] >= 0) {      // the table fills from the left: maybe more than GN neighbours
-        for (int k = GN; k < g.ell_w; ++k) {
-          const int j = g.ell[row * g.ell_w + k];
-          if (j < 0) break;
-          float4 t = ldg4(g.a + (int64_t)(BNIN ? (j & 0xFFFFF) : j) * g.lda + 4 * c4);
-          if constexpr (BNIN) {
-            const float2 rm = bn_tab[j >> 20];
-            t.x = fmaf(fmaxf(t.x, 0.f), rm.x, -rm.y); t.y = fmaf(fmaxf(t.y, 0.f), rm.x, -rm.y);
-            t.z = fmaf(fmaxf(t.z, 0.f), rm.x, -rm.y); t.w = fmaf(fmaxf(t.w, 0.f), rm.x, -rm.y);
+        // the second half of the row's table entries in ONE 32-byte request (same cache line as the first half), then ALL of their
+        // rows in one round trip from clamped addresses, added in table order (the same sum, bit for bit, as a loop that fetched
+        // entry k, then its row, then entry k + 1 ...: two dependent trips per extra neighbour)
+        static_assert(GN == 8, "the second half of a 16-wide table");
+        const int4 e0 = *reinterpret_cast<const int4*>(g.ell + row * g.ell_w + 8), e1 = *reinterpret_cast<const int4*>(g.ell + row * g.ell_w + 12);
+        const int js[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+        table_full = js[7] >= 0;
+        float4 t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = ldg4(g.a + (int64_t)(js[k] >= 0 ? (BNIN ? (js[k] & 0xFFFFF) : js[k]) : 0) * g.lda + 4 * c4);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          if (js[k] >= 0) {                                  // (entries fill from the left: the first negative one ends the list)
+            if constexpr (BNIN) {
+              const float2 rm = bn_tab[js[k] >> 20];
+              t[k].x = fmaf(fmaxf(t[k].x, 0.f), rm.x, -rm.y); t[k].y = fmaf(fmaxf(t[k].y, 0.f), rm.x, -rm.y);
+              t[k].z = fmaf(fmaxf(t[k].z, 0.f), rm.x, -rm.y); t[k].w = fmaf(fmaxf(t[k].w, 0.f), rm.x, -rm.y);
+            }
+            va.x += t[k].x; va.y += t[k].y; va.z += t[k].z; va.w += t[k].w;
           }
-          va.x += t.x; va.y += t.y; va.z += t.z; va.w += t.w;
         }
       }
-      if (colok && g.tail_ptr && row < g.rows && ids[p][GN - 1] >= 0) {   // lists longer than the table continue in the CSR tail
+      if (colok && g.tail_ptr && row < g.rows && table_full) {   // lists longer than the table continue in the CSR tail (a handful
+                                                                 // of rows per batch: asking every row with >= GN neighbours for its
+                                                                 // tail range was a dependent round trip for 7 % of the rows)
         for (int e = g.tail_ptr[row]; e < g.tail_ptr[row + 1]; ++e) {
           const int j = g.tail_col[e];                     // BNIN: slot << 20 | row, like the table's entries
           float4 t = ldg4(g.a + (int64_t)(BNIN ? (j & 0xFFFFF) : j) * g.lda + 4 * c4);
