@@ -148,7 +148,7 @@ def account(entry, a, nnz):
         P = (L - 1) * Fh + Fl
         return 2.0 * B * (P * E + E * C), 16 * B * P + f4 * (E * P + C * E) + 2 * f4 * B * P + 8 * int(a[17]), \
             "decode of all layers' packed maxima + Linear(%d,%d) + Linear(%d,%d) + zeroing of the step's accumulators" % (P, E, E, C)
-    if entry == "head2_bwd_du_f32":
+    if entry in ("head2_bwd_du_f32", "head2_bwd_du_map_f32"):
         B, P, E, C, n, F = int(a[10]), int(a[11]), int(a[12]), int(a[13]), int(a[22]), int(a[30])
         return 4.0 * B * (P * E + E * C), 2 * f4 * (E * P + C * E) + 2 * f4 * B * P + 2 * f4 * n * F + f4 * n + 8 * B * F, \
             "CE loss + head backward (dW1, db1, dW2, db2, d readout) || last layer's dU rows from the readout gradient"

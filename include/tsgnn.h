@@ -850,6 +850,16 @@ int tsgnn_head2_bwd_du_f32(const float* out, int64_t ldo, const float* vec, cons
                            int64_t lddo, float* dw1, float* db1, float* dw2, float* db2, float* normparts, const int* graph_ptr,
                            int64_t n_real, int n_ghost_rows, int max_nodes, const float* v, int64_t ldv, const float* rinv, const int* arg,
                            int seg_off, int F, float* du, int64_t lddu, tsgnn_stream_t stream);
+/* the same with the dU workgroups LISTED by the host: du_map[n_map] = graph << 8 | chunk for every chunk of du_chunk (64 or 128) rows
+ * that holds rows — chunk 0 of EVERY graph (it also writes the graph's ghost contribution row); graph == B with chunks 0 .. k-1 for a
+ * capacity-padded batch's padding rows (zero-filled by k workgroups) —, so that an exact batch launches no workgroup that only
+ * returns and the launch's duration does not depend on where the batch's large graphs sit.  du_map NULL: the dense grid above. */
+int tsgnn_head2_bwd_du_map_f32(const float* out, int64_t ldo, const float* vec, const float* y, const int64_t* label, float* loss,
+                               const float* dy, const float* dvec, const float* w1, const float* w2, int B, int P, int E, int C,
+                               float* dout, int64_t lddo, float* dw1, float* db1, float* dw2, float* db2, float* normparts,
+                               const int* graph_ptr, int64_t n_real, int n_ghost_rows, int max_nodes, const float* v, int64_t ldv,
+                               const float* rinv, const int* arg, int seg_off, int F, float* du, int64_t lddu, const int* du_map,
+                               int n_map, int du_chunk, tsgnn_stream_t stream);
 
 /* ---- DiffPool contraction of a pooled level (dense per-graph operands small enough for LDS), one workgroup per graph
  * (csrc/contract.hip).  Replaces the three bmm's of encoders.py:374-375 and their six backward products. */

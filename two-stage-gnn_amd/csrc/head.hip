@@ -492,14 +492,20 @@ struct DuArgs {
   const int* graph_ptr; int64_t n_real; int n_ghost_rows; int chunks;
   const float* v; int64_t ldv; const float* rinv; const int* arg; int off; int F;
   float* du; int64_t lddu;
+  // nullable: the (graph, chunk) of dU block d as graph << 8 | chunk — the host lists the NON-EMPTY chunks of an exact batch
+  // (tsgnn_head2_bwd_du_map_f32), so that no workgroup is launched only to return; without it block d is (d / chunks, d % chunks)
+  // of the dense (B + 1) x chunks grid, and which blocks come in a second round depends on where the batch's large graphs sit
+  // (8.5 us for one DD batch, 11.1 for another)
+  const int* map;
 };
+__device__ __forceinline__ int du_graph(const DuArgs& a, int d) { return a.map ? (a.map[d] >> 8) : d / a.chunks; }
 
 template <int DU_CHUNK>
 __device__ __forceinline__ void head2_du_role(const DuArgs& a, float* smem, const float* dy /* LDS or global [B, C] */, int d,
                                               const float* __restrict__ dvec, const float* __restrict__ w1, const float* __restrict__ w2,
                                               int B, int P, int E, int C, bool dy_ready_needs_sync) {
   const int tid = threadIdx.x, NTH = 64 * HW;
-  const int b = d / a.chunks, c = d - b * a.chunks;
+  const int b = du_graph(a, d), c = a.map ? (a.map[d] & 255) : d - b * a.chunks;
   const int F4 = a.F >> 2, lig = tid & 31, rg = tid >> 5;       // 32 lanes per row (F <= 128), 32 rows per pass
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (b >= B) {                                                  // padding rows of a capacity-padded batch: zeros
@@ -659,7 +665,7 @@ __global__ __launch_bounds__(64 * HW) void head2_bwd2_kernel(const float* __rest
   if ((int)blockIdx.x >= B + nj + 1) {
     // ------------------------------------------------------------------------------------------------ last layer's dU rows
     const int d = (int)blockIdx.x - (B + nj + 1);
-    const int gb = d / dua.chunks;
+    const int gb = du_graph(dua, d);
     if (has_ce && gb < B) ce_rows(ce, B, C, dyl, lb, gb);          // (thread 0 rebuilds row gb; synchronised inside the role)
     head2_du_role<DU_CHUNK>(dua, smem, dy, d, dvec, w1, w2, B, P, E, C, has_ce);
     return;
@@ -947,7 +953,8 @@ int tsgnn_packed_head_fwd_z_f32(unsigned long long* packed, int B, int L, int Fh
 static int head2_bwd_launch(const float* out, int64_t ldo, const float* vec, const float* dy, const float* dvec, const float* w1,
                             const float* w2, int B, int P, int E, int C, float* dout, int64_t lddo, float* dw1, float* db1,
                             float* dw2, float* db2, float* normparts, const float* ce_y, const int64_t* ce_label, float* ce_loss,
-                            tsgnn_stream_t stream, const DuArgs* du = nullptr, const RoTail* rtail = nullptr) {
+                            tsgnn_stream_t stream, const DuArgs* du = nullptr, const RoTail* rtail = nullptr, int du_map_n = 0,
+                            int du_map_chunk = 64) {
   if (!out || !vec || (!dy && !ce_label) || !w1 || !w2 || !dout || !dw1 || !dw2 || B <= 0 || P <= 0 || E <= 0 || C <= 0) return TSGNN_EINVAL;
   if (ce_label && (!ce_y || !ce_loss)) return TSGNN_EINVAL;
   if ((P % 4) || P > 2048 || E > 4096 || B > 1024 || (reinterpret_cast<uintptr_t>(w1) & 15)) return TSGNN_EUNSUPPORTED;
@@ -973,12 +980,13 @@ static int head2_bwd_launch(const float* out, int64_t ldo, const float* vec, con
         ncu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
       }
       const int nodes = dua.chunks;                      // bound on the largest graph
-      if ((B + 1) * ((nodes + 63) / 64) + B + (E + 3) / 4 + 1 > ncu + ncu / 5) du_chunk = 128;
+      if (dua.map) du_chunk = du_map_chunk;              // (the host listed the non-empty chunks of this size)
+      else if ((B + 1) * ((nodes + 63) / 64) + B + (E + 3) / 4 + 1 > ncu + ncu / 5) du_chunk = 128;
       dua.chunks = (nodes + du_chunk - 1) / du_chunk;
       const int G = 64 * HW / P4 < 16 ? 64 * HW / P4 : 16;
       const size_t drole = (size_t)((E + 3) & ~3) + (size_t)(G + 1) * dua.F;
       if (drole > role) role = drole;
-      du_blocks = (unsigned)(B + 1) * (unsigned)dua.chunks;
+      du_blocks = dua.map ? (unsigned)du_map_n : (unsigned)(B + 1) * (unsigned)dua.chunks;
     }
     lds2 = sizeof(float) * role;
     if (ce_label) lds2 += sizeof(float) * (size_t)(((B * C + 3) & ~3) + ((B + 3) & ~3));
@@ -1058,6 +1066,21 @@ int tsgnn_head2_bwd_du_f32(const float* out, int64_t ldo, const float* vec, cons
                            int64_t lddo, float* dw1, float* db1, float* dw2, float* db2, float* normparts, const int* graph_ptr,
                            int64_t n_real, int n_ghost_rows, int max_nodes, const float* v, int64_t ldv, const float* rinv, const int* arg,
                            int seg_off, int F, float* du, int64_t lddu, tsgnn_stream_t stream) {
+  return tsgnn_head2_bwd_du_map_f32(out, ldo, vec, y, label, loss, dy, dvec, w1, w2, B, P, E, C, dout, lddo, dw1, db1, dw2, db2, normparts,
+                                    graph_ptr, n_real, n_ghost_rows, max_nodes, v, ldv, rinv, arg, seg_off, F, du, lddu, nullptr, 0, 64, stream);
+}
+
+/* the same with the dU workgroups LISTED by the host: du_map[n_map] = graph << 8 | chunk for every chunk of du_chunk (64 or 128) rows
+ * that holds rows (chunk 0 of EVERY graph: it also writes the graph's ghost contribution row; graph == B, chunks 0 .. k-1: the
+ * padding rows of a capacity-padded batch, zero-filled by k workgroups) — an exact batch launches no workgroup that only returns.
+ * du_map NULL: the dense (B + 1) x chunks grid of tsgnn_head2_bwd_du_f32. */
+int tsgnn_head2_bwd_du_map_f32(const float* out, int64_t ldo, const float* vec, const float* y, const int64_t* label, float* loss,
+                               const float* dy, const float* dvec, const float* w1, const float* w2, int B, int P, int E, int C,
+                               float* dout, int64_t lddo, float* dw1, float* db1, float* dw2, float* db2, float* normparts,
+                               const int* graph_ptr, int64_t n_real, int n_ghost_rows, int max_nodes, const float* v, int64_t ldv,
+                               const float* rinv, const int* arg, int seg_off, int F, float* du, int64_t lddu, const int* du_map,
+                               int n_map, int du_chunk, tsgnn_stream_t stream) {
+  if (du_map && (n_map <= 0 || (du_chunk != 64 && du_chunk != 128) || max_nodes > 255 * du_chunk || B > (1 << 22))) return TSGNN_EINVAL;
   const int chunks = max_nodes;
   if (!graph_ptr || !v || !rinv || !arg || !du || n_real < 0 || n_ghost_rows < 0 || chunks <= 0 || F <= 0 || seg_off < 0) return TSGNN_EINVAL;
   if ((y == nullptr) == (dy == nullptr)) return TSGNN_EINVAL;
@@ -1070,8 +1093,9 @@ int tsgnn_head2_bwd_du_f32(const float* out, int64_t ldo, const float* vec, cons
     const int P4 = P / 4, G = P4 > 0 ? (64 * HW / P4 < 16 ? 64 * HW / P4 : 16) : 0;
     if ((P % 4) || G < 1 || E > G * RB_ROWS || G * 32 > 64 * HW) return TSGNN_EUNSUPPORTED;     // one batch of W1 rows per row group (head2_du_role)
   }
-  const DuArgs a{graph_ptr, n_real, n_ghost_rows, chunks, v, ldv, rinv, arg, seg_off, F, du, lddu};
-  return head2_bwd_launch(out, ldo, vec, dy, dvec, w1, w2, B, P, E, C, dout, lddo, dw1, db1, dw2, db2, normparts, y, label, loss, stream, &a);
+  const DuArgs a{graph_ptr, n_real, n_ghost_rows, chunks, v, ldv, rinv, arg, seg_off, F, du, lddu, du_map};
+  return head2_bwd_launch(out, ldo, vec, dy, dvec, w1, w2, B, P, E, C, dout, lddo, dw1, db1, dw2, db2, normparts, y, label, loss, stream, &a,
+                          nullptr, n_map, du_chunk);
 }
 
 }  // extern "C"

@@ -266,6 +266,28 @@ class GraphBatch:
                 self._ell_slots = (table, tcol)
         return self._ell_slots if self._ell_slots is not False else None
 
+    def du_map(self, other_blocks):
+        """(du_map int32[n], n, chunk rows) for tsgnn_head2_bwd_du_map_f32, or (None, 0, 64): the non-empty (graph, chunk) pairs of the
+        last layer's dU role — chunk 0 of every graph, then one entry per further 64 (128) rows —, 64-row chunks while the launch
+        (other_blocks = the head's own workgroups) stays within one workgroup per compute unit, else 128.  Host side, once per batch
+        structure; batches whose sizes live on the device only (ingest slots) use the dense grid."""
+        if self.sizes is None or getattr(self, "ghost_slots_fixed", None) is not None:
+            return None, 0, 64
+        cache = self.__dict__.setdefault("_du_maps", {})
+        key = int(other_blocks)
+        if key not in cache:
+            sizes = np.asarray(self.sizes, dtype=np.int64)
+            ncu = torch.cuda.get_device_properties(self.device).multi_processor_count
+            chunk = 64
+            if key + int(np.maximum(1, -(-sizes // 64)).sum()) > ncu:
+                chunk = 128
+            if int(sizes.max()) > 255 * chunk or self.B >= (1 << 22):
+                cache[key] = (None, 0, 64)
+            else:
+                ent = [(b << 8) | c for b in range(self.B) for c in range(max(1, -(-int(sizes[b]) // chunk)))]
+                cache[key] = (torch.from_numpy(np.asarray(ent, dtype=np.int32)).to(self.device), len(ent), chunk)
+        return cache[key]
+
     def readout_map(self, nslots, fill_rows):
         """(ro_map int32[B * chunks], chunk size) for tsgnn_sage_layer_fwd_bn_f32, or (None, 0): readout block k of that launch is
         workgroup n_gemm + k and therefore sits on XCD (n_gemm + k) % 8; the row panels of XCD x are a contiguous range of the batch's

@@ -66,6 +66,7 @@ SLOT_WGRAD = os.environ.get("TSGNN_SLOT_WGRAD", "0") != "0"
 HEAD_DU = os.environ.get("TSGNN_HEAD_DU", "1") != "0"                     # ... computed by extra workgroups of the head's backward launch
 
 
+DU_MAP = os.environ.get("TSGNN_DU_MAP", "1") != "0"             # exact batches: the head backward's dU workgroups listed by the host
 SLABS_BESIDE = os.environ.get("TSGNN_SLABS_BESIDE", "1") != "0"
 NSLAB_MAX = int(os.environ.get("TSGNN_NSLAB_MAX", "0"))
 _ncu = {}
@@ -353,10 +354,12 @@ class _SageStack(torch.autograd.Function):
                 # the last layer's dU (a row-wise function of the readout gradient: it has no batch-norm) rides in this launch
                 du_l = torch.empty(R, Fl, dtype=torch.float32, device=dev)
                 argl = ctx.arg[(L - 1) * B * Fh:(L - 1) * B * Fh + B * Fl]
-                if nat.try_call("head2_bwd_du_f32", out, out.stride(0), vec, ce[0] if ce is not None else None,
+                # (the non-empty (graph, chunk) pairs listed by the host for an exact batch: no workgroup that only returns)
+                dmap, ndmap, dchunk = g.du_map(B + (E + 3) // 4 + 1) if DU_MAP else (None, 0, 64)
+                if nat.try_call("head2_bwd_du_map_f32", out, out.stride(0), vec, ce[0] if ce is not None else None,
                                 ce[1] if ce is not None else None, ce[2] if ce is not None else None, None if ce is not None else dy, dvec,
                                 w1c, w2c, B, P, E, C, dout, dout.stride(0), dw1, db1, dw2, db2, parts, g.graph_ptr, g.n_rows, sg_,
-                                sn_, v_l, v_l.stride(0), rinv_l, argl, (L - 1) * Fh, Fl, du_l, du_l.stride(0)):
+                                sn_, v_l, v_l.stride(0), rinv_l, argl, (L - 1) * Fh, Fl, du_l, du_l.stride(0), dmap, ndmap, dchunk):
                     du_last = du_l
             if du_last is not None:
                 pass
