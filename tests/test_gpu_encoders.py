@@ -872,13 +872,14 @@ def _stack_run(B, nmax, sizes, fin, hid, p_edge, flags, seed=5):
     return a.detach().cpu(), b.detach().cpu(), grads, (m, x, adj, sizes)
 
 
-ALL_ON = dict(GATHER_FUSED=True, MERGED_FWD=True, MERGED_BWD=True, FUSED_TAIL=True, HEAD_DU=True, FUSED_BN=True, SLOT_WGRAD=True)
+ALL_ON = dict(GATHER_FUSED=True, MERGED_FWD=True, MERGED_BWD=True, FUSED_TAIL=True, HEAD_DU=True, FUSED_BN=True, SLOT_WGRAD=True, DU_MAP=True)
 
 
-@pytest.mark.parametrize("off", ["GATHER_FUSED", "MERGED_FWD", "MERGED_BWD", "FUSED_TAIL", "HEAD_DU", "FUSED_BN", "SLOT_WGRAD"])
+@pytest.mark.parametrize("off", ["GATHER_FUSED", "MERGED_FWD", "MERGED_BWD", "FUSED_TAIL", "HEAD_DU", "FUSED_BN", "SLOT_WGRAD", "DU_MAP"])
 def test_stack_fusion_variants_agree(off):
     """every launch fusion of the GraphSage stack (aggregation inside the product, product + readout partial, slabs + dX,
-    readout tail + head, the last layer's dU inside the head's backward launch) gives the results of the launch sequence it replaces"""
+    readout tail + head, the last layer's dU inside the head's backward launch — on the dense (graph, chunk) grid or on the
+    host's list of non-empty chunks —) gives the results of the launch sequence it replaces"""
     sizes = dd_like_sizes(3, 6, nbar=70, nmax=150).tolist()
     ref = _stack_run(6, 150, sizes, 89, 128, 0.06, ALL_ON)
     alt = _stack_run(6, 150, sizes, 89, 128, 0.06, dict(ALL_ON, **{off: False}))
