@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void ingest_pull_kernel(const int4* __restrict
 __global__ __launch_bounds__(256) void ingest_pull_rider_kernel(PullRider p) { pull_rider_body(p, blockIdx.x); }
 
 __global__ __launch_bounds__(256) void ingest_expand_kernel(ExpandArgs a) {
-  expand_row_lane(a, (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5), threadIdx.x & 31);
+  expand_row_lane(a, (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5), threadIdx.x & 31, a.mirror + a.L.graph_ptr);
 }
 __global__ __launch_bounds__(256) void ingest_expand_rider_kernel(ExpandRider e) { expand_rider_body(e, blockIdx.x, 256); }
 

@@ -48,8 +48,9 @@ struct ExpandArgs {
   // the row's own graph, so its slot is its row minus the graph's first row.
   int32_t* ell_slots; int32_t* tail_slots;
 };
-__device__ __forceinline__ int expand_graph_of(const ExpandArgs& a, int64_t r) {      // the graph whose row range holds r (r < n)
-  const int32_t* gp = a.mirror + a.L.graph_ptr;
+// gp: the batch's graph pointers — the mirror's copy, or the workgroup's copy of it in LDS (expand_rider_body): the search is five
+// DEPENDENT reads for 32 graphs, and out of global memory they were the longest chain of a row's expansion
+__device__ __forceinline__ int expand_graph_of(const ExpandArgs& a, int64_t r, const int32_t* gp) {      // the graph whose row range holds r (r < n)
   int lo = 0, hi = a.B;                                  // gp[lo] <= r < gp[hi]
   while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (gp[mid] <= r) lo = mid; else hi = mid; }
   return lo;
@@ -58,7 +59,7 @@ __device__ __forceinline__ int expand_graph_of(const ExpandArgs& a, int64_t r) {
 // 32 lanes per row, 8 rows per block.  Lane q of a row: q < ell_w/4 writes four entries of the row's neighbour table, q == ell_w/4
 // the row maps and the tail pointer, the lanes after that (looping when a row has more than 32 - ell_w/4 - 1 float4) the one-hot
 // feature row.
-__device__ __forceinline__ void expand_row_lane(const ExpandArgs& a, int64_t r, int q) {
+__device__ __forceinline__ void expand_row_lane(const ExpandArgs& a, int64_t r, int q, const int32_t* gp) {
   const int64_t total_rows = a.row_cap + a.nmax;
   if (a.host_ack && r == 0 && q == 0) {
     // the pull launch ahead of this one has finished reading the staging buffer: echo the batch's sequence word to the host,
@@ -86,7 +87,7 @@ __device__ __forceinline__ void expand_row_lane(const ExpandArgs& a, int64_t r, 
     if (a.ell_slots) {
       int4 w = make_int4(-1, -1, -1, -1);
       if (r < n) {
-        const int g0 = a.mirror[a.L.graph_ptr + expand_graph_of(a, r)];
+        const int g0 = gp[expand_graph_of(a, r, gp)];
         if (v.x >= 0) w.x = ((v.x - g0) << 20) | v.x;
         if (v.y >= 0) w.y = ((v.y - g0) << 20) | v.y;
         if (v.z >= 0) w.z = ((v.z - g0) << 20) | v.z;
@@ -99,8 +100,8 @@ __device__ __forceinline__ void expand_row_lane(const ExpandArgs& a, int64_t r, 
     if (r < a.row_cap) {
       int g = a.B, slot = -1;                               // (padding rows of the capacity: no graph, no slot)
       if (r < n) {
-        g = expand_graph_of(a, r);
-        g0 = a.mirror[a.L.graph_ptr + g];
+        g = expand_graph_of(a, r, gp);
+        g0 = gp[g];
         slot = (int)(r - g0);
       }
       a.row_graph[r] = g;
@@ -134,8 +135,16 @@ static inline ExpandRider take_expand_rider() {
   return r;
 }
 // workgroup b of e.blocks, `nthreads` threads (a multiple of 32): 32 lanes a row, looping over the rows
+constexpr int EXPAND_GP_LDS = 256;          // graph pointers a workgroup keeps in LDS (larger batches search the mirror)
 __device__ __forceinline__ void expand_rider_body(const ExpandRider& e, unsigned b, int nthreads) {
+  __shared__ int32_t gp_s[EXPAND_GP_LDS + 1];
+  const int32_t* gp = e.ex.mirror + e.ex.L.graph_ptr;
+  if (e.ex.B <= EXPAND_GP_LDS) {             // (uniform; every thread of a rider workgroup is here)
+    for (int i = threadIdx.x; i <= e.ex.B; i += nthreads) gp_s[i] = gp[i];
+    __syncthreads();
+    gp = gp_s;
+  }
   const int rpb = nthreads >> 5;
   for (long long r0 = (long long)b * rpb; r0 < e.rows; r0 += (long long)e.blocks * rpb)
-    expand_row_lane(e.ex, r0 + (threadIdx.x >> 5), threadIdx.x & 31);
+    expand_row_lane(e.ex, r0 + (threadIdx.x >> 5), threadIdx.x & 31, gp);
 }
