@@ -853,7 +853,9 @@ int tsgnn_head2_bwd_du_f32(const float* out, int64_t ldo, const float* vec, cons
 /* the same with the dU workgroups LISTED by the host: du_map[n_map] = graph << 8 | chunk for every chunk of du_chunk (64 or 128) rows
  * that holds rows — chunk 0 of EVERY graph (it also writes the graph's ghost contribution row); graph == B with chunks 0 .. k-1 for a
  * capacity-padded batch's padding rows (zero-filled by k workgroups) —, so that an exact batch launches no workgroup that only
- * returns and the launch's duration does not depend on where the batch's large graphs sit.  du_map NULL: the dense grid above. */
+ * returns and the launch's duration does not depend on where the batch's large graphs sit.  du_map NULL: the dense grid above
+ * (n_map = 0), or — n_map < 0, B <= 64 — the same compact order resolved INSIDE the kernel from graph_ptr (a 64-lane prefix sum of
+ * the graphs' chunk counts): for batches whose sizes live on the device (capacity-padded ingest batches). */
 int tsgnn_head2_bwd_du_map_f32(const float* out, int64_t ldo, const float* vec, const float* y, const int64_t* label, float* loss,
                                const float* dy, const float* dvec, const float* w1, const float* w2, int B, int P, int E, int C,
                                float* dout, int64_t lddo, float* dw1, float* db1, float* dw2, float* db2, float* normparts,

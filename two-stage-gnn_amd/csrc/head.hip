@@ -497,20 +497,42 @@ struct DuArgs {
   // of the dense (B + 1) x chunks grid, and which blocks come in a second round depends on where the batch's large graphs sit
   // (8.5 us for one DD batch, 11.1 for another)
   const int* map;
+  // compact != 0 (B <= 64, no map): block d is the d-th NON-EMPTY (graph, chunk) pair, resolved by every wave itself from the graph
+  // pointers (a 64-lane prefix sum of the graphs' chunk counts: no host list — the sizes of a capacity-padded ingest batch live on
+  // the device); the blocks behind the last pair (compact = their number) zero-fill the padding rows
+  int compact;
 };
-__device__ __forceinline__ int du_graph(const DuArgs& a, int d) { return a.map ? (a.map[d] >> 8) : d / a.chunks; }
+// (graph, chunk) of dU block d; pad_k >= 0: not a pair but the pad_k-th of pad_n zero-fill blocks
+template <int DU_CHUNK>
+__device__ __forceinline__ void du_resolve(const DuArgs& a, int d, int B, int& b, int& c, int& pad_k, int& pad_n) {
+  pad_k = -1; pad_n = a.chunks;
+  if (a.map) { b = a.map[d] >> 8; c = a.map[d] & 255; }
+  else if (a.compact) {
+    const int lane = threadIdx.x & 63;
+    const int g0 = a.graph_ptr[min(lane, B)], g1 = a.graph_ptr[min(lane + 1, B)];
+    const int nch = lane < B ? max(1, (g1 - g0 + DU_CHUNK - 1) / DU_CHUNK) : 0;
+    int pre = nch;                                               // inclusive prefix over the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(pre, o, 64); if (lane >= o) pre += t; }
+    const int total = __shfl(pre, 63, 64);
+    if (d >= total) { b = B; c = 0; pad_k = d - total; pad_n = (int)gridDim.x - a.compact - total; return; }
+    const unsigned long long m = __ballot(pre > d);              // the first lane whose prefix exceeds d owns block d
+    b = __ffsll((long long)m) - 1;
+    c = d - (__shfl(pre, b, 64) - __shfl(nch, b, 64));
+  } else { b = d / a.chunks; c = d - b * a.chunks; }
+  if (b >= B) { pad_k = c; b = B; }
+}
 
 template <int DU_CHUNK>
-__device__ __forceinline__ void head2_du_role(const DuArgs& a, float* smem, const float* dy /* LDS or global [B, C] */, int d,
-                                              const float* __restrict__ dvec, const float* __restrict__ w1, const float* __restrict__ w2,
-                                              int B, int P, int E, int C, bool dy_ready_needs_sync) {
+__device__ __forceinline__ void head2_du_role(const DuArgs& a, float* smem, const float* dy /* LDS or global [B, C] */, int b, int c,
+                                              int pad_k, int pad_n, const float* __restrict__ dvec, const float* __restrict__ w1,
+                                              const float* __restrict__ w2, int B, int P, int E, int C, bool dy_ready_needs_sync) {
   const int tid = threadIdx.x, NTH = 64 * HW;
-  const int b = du_graph(a, d), c = a.map ? (a.map[d] & 255) : d - b * a.chunks;
   const int F4 = a.F >> 2, lig = tid & 31, rg = tid >> 5;       // 32 lanes per row (F <= 128), 32 rows per pass
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (b >= B) {                                                  // padding rows of a capacity-padded batch: zeros
+  if (pad_k >= 0) {                                              // padding rows of a capacity-padded batch: zeros
     const int64_t lo = a.graph_ptr[B];
-    for (int64_t r = lo + (int64_t)c * 32 + rg; r < a.n_real; r += (int64_t)a.chunks * 32)
+    for (int64_t r = lo + (int64_t)pad_k * 32 + rg; r < a.n_real; r += (int64_t)max(pad_n, 1) * 32)
       if (lig < F4) *reinterpret_cast<float4*>(a.du + r * a.lddu + 4 * lig) = z4;
     return;
   }
@@ -665,9 +687,10 @@ __global__ __launch_bounds__(64 * HW) void head2_bwd2_kernel(const float* __rest
   if ((int)blockIdx.x >= B + nj + 1) {
     // ------------------------------------------------------------------------------------------------ last layer's dU rows
     const int d = (int)blockIdx.x - (B + nj + 1);
-    const int gb = du_graph(dua, d);
-    if (has_ce && gb < B) ce_rows(ce, B, C, dyl, lb, gb);          // (thread 0 rebuilds row gb; synchronised inside the role)
-    head2_du_role<DU_CHUNK>(dua, smem, dy, d, dvec, w1, w2, B, P, E, C, has_ce);
+    int gb, gc, pad_k, pad_n;
+    du_resolve<DU_CHUNK>(dua, d, B, gb, gc, pad_k, pad_n);
+    if (has_ce && pad_k < 0) ce_rows(ce, B, C, dyl, lb, gb);       // (thread 0 rebuilds row gb; synchronised inside the role)
+    head2_du_role<DU_CHUNK>(dua, smem, dy, gb, gc, pad_k, pad_n, dvec, w1, w2, B, P, E, C, has_ce);
     return;
   }
 
@@ -954,7 +977,7 @@ static int head2_bwd_launch(const float* out, int64_t ldo, const float* vec, con
                             const float* w2, int B, int P, int E, int C, float* dout, int64_t lddo, float* dw1, float* db1,
                             float* dw2, float* db2, float* normparts, const float* ce_y, const int64_t* ce_label, float* ce_loss,
                             tsgnn_stream_t stream, const DuArgs* du = nullptr, const RoTail* rtail = nullptr, int du_map_n = 0,
-                            int du_map_chunk = 64) {
+                            int du_map_chunk = 64, int du_compact = 0) {
   if (!out || !vec || (!dy && !ce_label) || !w1 || !w2 || !dout || !dw1 || !dw2 || B <= 0 || P <= 0 || E <= 0 || C <= 0) return TSGNN_EINVAL;
   if (ce_label && (!ce_y || !ce_loss)) return TSGNN_EINVAL;
   if ((P % 4) || P > 2048 || E > 4096 || B > 1024 || (reinterpret_cast<uintptr_t>(w1) & 15)) return TSGNN_EUNSUPPORTED;
@@ -980,13 +1003,23 @@ static int head2_bwd_launch(const float* out, int64_t ldo, const float* vec, con
         ncu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
       }
       const int nodes = dua.chunks;                      // bound on the largest graph
+      const int other = B + (E + 3) / 4 + 1;
+      unsigned compact_blocks = 0;
       if (dua.map) du_chunk = du_map_chunk;              // (the host listed the non-empty chunks of this size)
-      else if ((B + 1) * ((nodes + 63) / 64) + B + (E + 3) / 4 + 1 > ncu + ncu / 5) du_chunk = 128;
+      else if (du_compact && B <= 64) {
+        // the pairs resolved in the kernel: at most ceil(rows / chunk) + B of them, + a few blocks for the padding rows
+        constexpr unsigned PADB = 4;
+        unsigned n64 = (unsigned)((dua.n_real + 63) / 64) + (unsigned)B;
+        if (other + (int)(n64 + PADB) > ncu) { du_chunk = 128; n64 = (unsigned)((dua.n_real + 127) / 128) + (unsigned)B; }
+        compact_blocks = n64 + PADB;
+        dua.compact = other;                             // (the role subtracts the launch's other blocks from gridDim.x)
+      }
+      else if ((B + 1) * ((nodes + 63) / 64) + other > ncu + ncu / 5) du_chunk = 128;
       dua.chunks = (nodes + du_chunk - 1) / du_chunk;
       const int G = 64 * HW / P4 < 16 ? 64 * HW / P4 : 16;
       const size_t drole = (size_t)((E + 3) & ~3) + (size_t)(G + 1) * dua.F;
       if (drole > role) role = drole;
-      du_blocks = dua.map ? (unsigned)du_map_n : (unsigned)(B + 1) * (unsigned)dua.chunks;
+      du_blocks = dua.map ? (unsigned)du_map_n : (compact_blocks ? compact_blocks : (unsigned)(B + 1) * (unsigned)dua.chunks);
     }
     lds2 = sizeof(float) * role;
     if (ce_label) lds2 += sizeof(float) * (size_t)(((B * C + 3) & ~3) + ((B + 3) & ~3));
@@ -1081,6 +1114,7 @@ int tsgnn_head2_bwd_du_map_f32(const float* out, int64_t ldo, const float* vec, 
                                const float* rinv, const int* arg, int seg_off, int F, float* du, int64_t lddu, const int* du_map,
                                int n_map, int du_chunk, tsgnn_stream_t stream) {
   if (du_map && (n_map <= 0 || (du_chunk != 64 && du_chunk != 128) || max_nodes > 255 * du_chunk || B > (1 << 22))) return TSGNN_EINVAL;
+  const int compact = (!du_map && n_map < 0) ? 1 : 0;           // n_map < 0 without a list: the pairs are resolved inside the kernel
   const int chunks = max_nodes;
   if (!graph_ptr || !v || !rinv || !arg || !du || n_real < 0 || n_ghost_rows < 0 || chunks <= 0 || F <= 0 || seg_off < 0) return TSGNN_EINVAL;
   if ((y == nullptr) == (dy == nullptr)) return TSGNN_EINVAL;
@@ -1093,9 +1127,9 @@ int tsgnn_head2_bwd_du_map_f32(const float* out, int64_t ldo, const float* vec, 
     const int P4 = P / 4, G = P4 > 0 ? (64 * HW / P4 < 16 ? 64 * HW / P4 : 16) : 0;
     if ((P % 4) || G < 1 || E > G * RB_ROWS || G * 32 > 64 * HW) return TSGNN_EUNSUPPORTED;     // one batch of W1 rows per row group (head2_du_role)
   }
-  const DuArgs a{graph_ptr, n_real, n_ghost_rows, chunks, v, ldv, rinv, arg, seg_off, F, du, lddu, du_map};
+  const DuArgs a{graph_ptr, n_real, n_ghost_rows, chunks, v, ldv, rinv, arg, seg_off, F, du, lddu, du_map, 0};
   return head2_bwd_launch(out, ldo, vec, dy, dvec, w1, w2, B, P, E, C, dout, lddo, dw1, db1, dw2, db2, normparts, y, label, loss, stream, &a,
-                          nullptr, n_map, du_chunk);
+                          nullptr, n_map, du_chunk, compact);
 }
 
 }  // extern "C"

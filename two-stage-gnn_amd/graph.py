@@ -272,7 +272,8 @@ class GraphBatch:
         (other_blocks = the head's own workgroups) stays within one workgroup per compute unit, else 128.  Host side, once per batch
         structure; batches whose sizes live on the device only (ingest slots) use the dense grid."""
         if self.sizes is None or getattr(self, "ghost_slots_fixed", None) is not None:
-            return None, 0, 64
+            # sizes on the device only (a capacity-padded ingest slot): n = -1 asks the kernel to resolve the same compact order itself
+            return None, (-1 if self.B <= 64 else 0), 64
         cache = self.__dict__.setdefault("_du_maps", {})
         key = int(other_blocks)
         if key not in cache:
