@@ -186,6 +186,12 @@ int tsgnn_ell_spmm_f32(const int* ell, int W, const float* x, int64_t ldx, float
 int tsgnn_gcn_norm_f32(const int* rowptr, const int* col, const float* val, int64_t n_rows, float self_fill,
                        float* dinv, float* val_out, float* self_w, tsgnn_stream_t stream);
 
+/* Gradient of the weighted aggregation y[i] = self_w[i] x[i] + sum_e val[e] x[col[e]] with respect to its weights (PyG
+ * GCNConv(edge_weight=) with weights that require grad, torch_geometric gcn_norm; the reference passes none, Code/sag/layers.py:18):
+ * dval[e] = dy[i] . x[col[e]], dself[i] = dy[i] . x[i] (dself nullable).  feat <= 1024. */
+int tsgnn_sddmm_rows_f32(const int* rowptr, const int* col, const float* dy, int64_t lddy, const float* x, int64_t ldx,
+                         int64_t n_rows, int feat, float* dval, float* dself, tsgnn_stream_t stream);
+
 /* ---------------------------------------------------------------- dense transform (gemm.hip, linear.hip) */
 
 /* C[z] (+)= alpha * op(A[z]) . op(B[z]); element (m,k) of op(A) at A + m*sam + k*sak (transposes are

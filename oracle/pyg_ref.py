@@ -164,6 +164,17 @@ def sag_pooling(x, edge_index, batch, ratio, w_l, b_l, w_r):
     return x, filter_adj(edge_index, perm, score.numel()), batch[perm], perm, score[perm]
 
 
+def topk_pooling(x, edge_index, batch, ratio, weight):
+    """PyG TopKPooling (imported, never called, Code/sag/network.py:3): score = tanh(x . p / ||p||), top-k on the score,
+    x[perm] * score[perm]; weight [1, F]."""
+    if batch is None:
+        batch = edge_index.new_zeros(x.size(0))
+    score = torch.tanh((x * weight).sum(dim=-1) / weight.norm(p=2, dim=-1))
+    perm = topk(score, ratio, batch)
+    x = x[perm] * score[perm].view(-1, 1)
+    return x, filter_adj(edge_index, perm, score.numel()), batch[perm], perm, score[perm]
+
+
 def dense_diff_pool(x, adj, s, mask=None, eps=1e-15):
     s = torch.softmax(s, dim=-1)
     if mask is not None:

@@ -89,6 +89,68 @@ def test_gcn_conv_edge_weight_and_improved(improved, weighted, self_loops):
         torch.testing.assert_close(a.cpu(), c, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("improved,self_loops,sym", [(False, False, False), (True, True, False), (False, False, True)])
+def test_gcn_conv_edge_weight_gradient(improved, self_loops, sym):
+    """gradient with respect to edge_weight (PyG's gcn_norm is differentiable in the weights; never exercised by the reference,
+    Code/sag/layers.py:18): through the normalisation's degrees and the aggregation's sampled product, against the oracle"""
+    from two_stage_gnn_amd import pyg
+    n, fin, fout = 150, 10, 20
+    ei = rand_graph(21, n, 500, sym)
+    if self_loops:
+        loops = torch.arange(0, n, 5)
+        ei = torch.cat([ei, torch.stack([loops, loops])], dim=1)
+    ew = 0.25 + torch.rand(ei.size(1), generator=torch.Generator().manual_seed(22))
+    x = tie_free(23, n, fin)
+    m = pyg.GCNConv(fin, fout, improved=improved).cuda()
+    w, b = m.weight.detach().cpu().requires_grad_(True), m.bias.detach().cpu().requires_grad_(True)
+    xr, ewr = x.clone().requires_grad_(True), ew.clone().requires_grad_(True)
+    ref = P.gcn_conv(xr, ei, w, b, edge_weight=ewr, improved=improved)
+    xg, ewg = x.cuda().requires_grad_(True), ew.cuda().requires_grad_(True)
+    out = m(xg, ei.cuda(), ewg)
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-5)
+    gy = tie_free(24, n, fout)
+    gr = grads((ref * gy).sum(), [xr, w, b, ewr])
+    gg = grads((out * gy.cuda()).sum(), [xg, m.weight, m.bias, ewg])
+    assert gr[3].abs().max() > 1e-2
+    for a, c in zip(gg, gr):
+        torch.testing.assert_close(a.cpu(), c, rtol=1e-4, atol=1e-4)
+
+
+def test_topk_pooling():
+    """PyG TopKPooling (imported beside GraphConv, Code/sag/network.py:3, never called): selection, gated features, filtered
+    edges and the gradients of x and the projection vector against the oracle"""
+    from two_stage_gnn_amd import pyg
+    sizes = [23, 1, 40, 9, 31]
+    n, f = sum(sizes), 12
+    batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
+    ei = rand_graph(31, n, 400, True, batch_sizes=sizes)
+    x = tie_free(32, n, f)
+    m = pyg.TopKPooling(f, ratio=0.5).cuda()
+    w = m.weight.detach().cpu().requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    rx, rei, rb, rperm, rscore = P.topk_pooling(xr, ei, batch, 0.5, w)
+    xg = x.cuda().requires_grad_(True)
+    ox, oei, _, ob, operm, oscore = m(xg, ei.cuda(), None, batch.cuda())
+    assert torch.equal(operm.cpu(), rperm) and torch.equal(ob.cpu(), rb) and torch.equal(oei.cpu(), rei)
+    torch.testing.assert_close(ox.detach().cpu(), rx.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(oscore.detach().cpu(), rscore.detach(), rtol=1e-5, atol=1e-6)
+    gy = tie_free(33, rx.size(0), f)
+    gs = tie_free(34, rx.size(0))
+    gr = grads((rx * gy).sum() + (rscore * gs).sum(), [xr, w])
+    gg = grads((ox * gy.cuda()).sum() + (oscore * gs.cuda()).sum(), [xg, m.weight])
+    for a, c in zip(gg, gr):
+        torch.testing.assert_close(a.cpu(), c, rtol=1e-4, atol=1e-5)
+    # one graph, no batch vector, multiplier
+    m2 = pyg.TopKPooling(f, ratio=0.3, multiplier=2.0).cuda()
+    with torch.no_grad():
+        m2.weight.copy_(m.weight)
+    e1 = rand_graph(35, 40, 120, True)
+    r1 = P.topk_pooling(x[:40], e1, None, 0.3, w.detach())
+    o1 = m2(x[:40].cuda(), e1.cuda())
+    assert torch.equal(o1[4].cpu(), r1[3])
+    torch.testing.assert_close(o1[0].cpu(), 2.0 * r1[0], rtol=1e-5, atol=1e-6)
+
+
 def test_topk_min_score():
     """PyG topk's threshold mode (never used by the reference): nodes above min(min_score, graph max - 1e-7), node order"""
     from two_stage_gnn_amd import pyg

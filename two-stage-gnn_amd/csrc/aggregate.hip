@@ -327,6 +327,34 @@ __global__ void gcn_norm_kernel(const int* __restrict__ rowptr, const int* __res
   self_w[i] = di * di * self_w[i];
 }
 
+
+// gradient of the weighted aggregation with respect to its weights: dval[e] = dy[i] . x[col[e]] for the entries e of row i,
+// dself[i] = dy[i] . x[i]; one wave per row, the row of dy held in registers (feat <= 1024)
+__global__ __launch_bounds__(256) void sddmm_rows_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                        const float* __restrict__ dy, int64_t lddy, const float* __restrict__ x,
+                                                        int64_t ldx, int64_t n, int feat, float* __restrict__ dval,
+                                                        float* __restrict__ dself) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  float g[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) g[u] = lane + 64 * u < feat ? dy[i * lddy + lane + 64 * u] : 0.f;
+  const int e0 = rowptr[i], e1 = rowptr[i + 1];
+  for (int e = e0 - (dself ? 1 : 0); e < e1; ++e) {
+    const int64_t c = e < e0 ? i : (int64_t)col[e];
+    float acc = 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      if (lane + 64 * u < feat) acc = fmaf(g[u], x[c * ldx + lane + 64 * u], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      if (e < e0) dself[i] = acc;
+      else dval[e] = acc;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -428,6 +456,17 @@ int tsgnn_gcn_norm_f32(const int* rowptr, const int* col, const float* val, int6
   const unsigned nblk = (unsigned)ceil_div64(n_rows, 256);
   gcn_deg_kernel<<<nblk, 256, 0, stream>>>(rowptr, col, val, n_rows, self_fill, dinv, self_w);
   gcn_norm_kernel<<<nblk, 256, 0, stream>>>(rowptr, col, val, dinv, n_rows, self_fill, val_out, self_w);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+int tsgnn_sddmm_rows_f32(const int* rowptr, const int* col, const float* dy, int64_t lddy, const float* x, int64_t ldx,
+                         int64_t n_rows, int feat, float* dval, float* dself, hipStream_t stream) {
+  if (n_rows < 0 || feat <= 0 || !rowptr || !col || !dy || !x || !dval || lddy < feat || ldx < feat) return TSGNN_EINVAL;
+  if (feat > 1024) return TSGNN_EUNSUPPORTED;
+  if (n_rows == 0) return TSGNN_OK;
+  TSGNN_KNAME("sddmm_rows_kernel");
+  sddmm_rows_kernel<<<(unsigned)ceil_div64(n_rows, 4), 256, 0, stream>>>(rowptr, col, dy, lddy, x, ldx, n_rows, feat, dval, dself);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }

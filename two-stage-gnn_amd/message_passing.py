@@ -62,6 +62,8 @@ class _Aggregate(torch.autograd.Function):
     def forward(ctx, x, g, add_self, val, self_w):
         x = _check(x, g.total_rows)
         ctx.g, ctx.add_self, ctx.val, ctx.self_w = g, add_self, val, self_w
+        # weights that require grad (PyG GCNConv(edge_weight=) with learnt weights): their gradient is a sampled product of dy and x
+        ctx.x = x if ctx.needs_input_grad[3] or ctx.needs_input_grad[4] else None
         ctx.fast = val is None and self_w is None and g.val is None and ell_ok(x) and g.total_rows <= ELL_MAX_ROWS
         if ctx.fast:
             return spmm_ell(g, x, 1.0 if add_self else 0.0)
@@ -73,10 +75,22 @@ class _Aggregate(torch.autograd.Function):
         dy = _check(dy)
         if ctx.fast and g.symmetric and ell_ok(dy):
             return spmm_ell(g, dy, 1.0 if ctx.add_self else 0.0), None, None, None, None
-        rowptr_t, col_t, val_t = g.transposed(ctx.val)
-        dx = spmm_raw(rowptr_t, col_t, val_t, dy, g.total_rows, self_w=ctx.self_w,
+        val = ctx.val.detach() if ctx.val is not None else None
+        self_w = ctx.self_w.detach() if ctx.self_w is not None else None
+        rowptr_t, col_t, val_t = g.transposed(val)
+        dx = spmm_raw(rowptr_t, col_t, val_t, dy, g.total_rows, self_w=self_w,
                       self_scalar=1.0 if ctx.add_self else 0.0)
-        return dx, None, None, None, None
+        dval = dself = None
+        if ctx.x is not None:
+            if dy.size(1) > 1024:
+                raise NotImplementedError("weight gradients of the aggregation for more than 1024 features")
+            dval = _f32(max(g.nnz, 1), device=dy.device)
+            dself = _f32(g.total_rows, device=dy.device)
+            nat.call("sddmm_rows_f32", g.rowptr, g.col, dy, dy.stride(0), ctx.x, ctx.x.stride(0), g.total_rows, int(dy.size(1)),
+                     dval, dself)
+            dval = dval[: ctx.val.numel()] if ctx.needs_input_grad[3] else None
+            dself = dself if ctx.needs_input_grad[4] else None
+        return dx, None, None, dval, dself
 
 
 def aggregate(x, g, add_self=False, val="graph", self_w=None):

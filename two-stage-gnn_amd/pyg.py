@@ -4,7 +4,7 @@
     ``global_mean_pool`` (Code/sag/network.py:2-4, layers.py:1-2) — signatures, parameter names
     (``weight[in,out]``, ``bias``; PyG 1.6.x layout) and return conventions preserved;
 (B) the operators BASELINE.json's north_star names: ``SAGEConv``, ``GATConv``, ``SAGPooling``,
-    ``dense_diff_pool`` (plus PyG's ``GraphConv``, SAGPooling's default scorer).
+    ``dense_diff_pool`` (plus PyG's ``GraphConv``, SAGPooling's default scorer, and ``TopKPooling``, which network.py:3 imports).
 Inputs are PyG's: ``x[N,F]`` fp32, ``edge_index[2,E]`` int64 (row 0 = source, row 1 = target), ``batch[N]``.
 The COO list is converted to CSR (grouped by target) on the GPU once per distinct edge_index tensor.
 """
@@ -152,17 +152,38 @@ class _GcnPropagate(torch.autograd.Function):
         return dx, None
 
 
+def _gcn_propagate_learnt(x, g, edge_weight, fill):
+    """A^ x with edge weights that require grad (PyG gcn_norm is differentiable in them; no reference call site passes weights,
+    layers.py:18).  The normalisation is a handful of per-entry device operations under autograd; the aggregation and the sampled
+    product dval[e] = dy[i] . x[col[e]] of its backward are the native kernels (tsgnn_csr_spmm_f32, tsgnn_sddmm_rows_f32)."""
+    R, nnz = g.total_rows, g.nnz
+    w = edge_weight.float().view(-1)
+    eid = getattr(g, "eid", None)
+    w = w[eid[:nnz].long()] if eid is not None else w[:nnz]            # CSR entry order
+    rows = torch.repeat_interleave(torch.arange(R, device=x.device), (g.rowptr[1:] - g.rowptr[:-1]).long())
+    cols = g.col[:nnz].long()
+    no_self = torch.ones(R, device=x.device)
+    no_self[rows[rows == cols]] = 0.0                                  # add_remaining_self_loops keeps an existing self loop
+    deg = torch.zeros(R, device=x.device).index_add(0, rows, w) + fill * no_self
+    dinv = torch.where(deg > 0, deg.clamp(min=1e-38).rsqrt(), torch.zeros_like(deg))
+    val = dinv[rows] * w * dinv[cols]
+    self_w = dinv * dinv * (fill * no_self)
+    if val.numel() == 0:
+        val = None
+    return mp.aggregate(x, g, False, val=val, self_w=self_w)
+
+
 def gcn_propagate(x, g, edge_weight=None, improved=False):
     """A^ x.  Unit weights, fill 1 (every reference call site, network.py:34, layers.py:18): the per-row-coefficient kernels.
     ``edge_weight`` (per edge of the edge list the graph was built from, or per CSR entry for a GraphBatch without ``eid``) and
     ``improved`` (self loops of weight 2) take PyG's general gcn_norm: per-entry normalised weights (tsgnn_gcn_norm_f32) and the
-    weighted aggregation; the weights are data, not parameters (no gradient flows to them)."""
+    weighted aggregation; weights that require grad take _gcn_propagate_learnt."""
     if edge_weight is None and not improved and g.val is None:
         return _GcnPropagate.apply(x, g)
     val = g.val
     if edge_weight is not None:
         if edge_weight.requires_grad:
-            raise NotImplementedError("gradients with respect to edge_weight")
+            return _gcn_propagate_learnt(x, g, edge_weight, 2.0 if improved else 1.0)
         w = edge_weight.detach().contiguous().float().view(-1)
         eid = getattr(g, "eid", None)
         val = w[eid[: g.nnz].long()] if eid is not None else w          # CSR entry order
@@ -441,6 +462,54 @@ class SAGPooling(nn.Module):
             score = self.nonlinearity(raw)
             xo = x[perm] * score[perm].view(-1, 1)
             score_perm = score[perm]
+        if self.multiplier != 1:
+            xo = self.multiplier * xo
+        ei, edge_attr = filter_adj(edge_index, edge_attr, perm, num_nodes=raw.numel())
+        return xo, ei, edge_attr, batch[perm], perm, score_perm
+
+
+class TopKPooling(nn.Module):
+    """PyG TopKPooling (imported beside GraphConv and never called, Code/sag/network.py:3): score = tanh(x . p / ||p||), the
+    ceil(ratio n) best nodes of every graph, x[perm] * score[perm].  Same kernels as SAGPooling with a projection as the scorer."""
+
+    def __init__(self, in_channels, ratio=0.5, min_score=None, multiplier=1, nonlinearity=torch.tanh):
+        super().__init__()
+        self.in_channels, self.ratio, self.min_score = in_channels, ratio, min_score
+        self.multiplier, self.nonlinearity = multiplier, nonlinearity
+        self.weight = nn.Parameter(torch.empty(1, in_channels, device=_default_device()))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        bound = 1.0 / math.sqrt(self.in_channels)                      # PyG's uniform(size, tensor)
+        with torch.no_grad():
+            self.weight.uniform_(-bound, bound)
+
+    def forward(self, x, edge_index, edge_attr=None, batch=None, attn=None):
+        if batch is None:
+            batch = edge_index.new_zeros(x.size(0))
+        attn = x if attn is None else attn
+        attn = attn.unsqueeze(-1) if attn.dim() == 1 else attn
+        if self.min_score is not None:
+            # PyG's threshold mode: per-graph softmax of the raw projection, nodes above min_score
+            raw = linear(attn, self.weight.t()).view(-1)
+            B = int(batch.max().item()) + 1
+            mx = torch.full((B,), float("-inf"), device=raw.device).scatter_reduce(0, batch, raw.detach(), "amax")
+            e = torch.exp(raw - mx[batch])
+            score = e / torch.zeros(B, device=raw.device).index_add(0, batch, e)[batch]
+            perm = topk(score, self.ratio, batch, self.min_score)
+            xo = x[perm] * score[perm].view(-1, 1)
+            score_perm = score[perm]
+        else:
+            raw = linear(attn, (self.weight / self.weight.norm(p=2, dim=-1)).t()).view(-1)
+            if self.nonlinearity is torch.tanh:
+                perm = topk(raw, self.ratio, batch)                    # tanh is monotone: same selection as PyG
+                xo = gather_gate(x, raw, perm, use_tanh=True)
+                score_perm = torch.tanh(raw[perm])
+            else:
+                score = self.nonlinearity(raw)
+                perm = topk(score, self.ratio, batch)
+                xo = x[perm] * score[perm].view(-1, 1)
+                score_perm = score[perm]
         if self.multiplier != 1:
             xo = self.multiplier * xo
         ei, edge_attr = filter_adj(edge_index, edge_attr, perm, num_nodes=raw.numel())
