@@ -282,10 +282,13 @@ def test_linear_wgrad_narrow_input(T, rows, K, N, ldz):
 
 
 @pytest.mark.parametrize("rows,K,N,trans_b,bias", [(1000, 92, 256, False, True), (1000, 256, 256, True, False), (1024, 64, 192, True, False),
-                                                    (37, 128, 132, False, True), (4096, 128, 256, False, False)])
+                                                    (37, 128, 132, False, True), (4096, 128, 256, False, False),
+                                                    (8518, 256, 264, False, False), (8518, 264, 256, True, False), (100, 20, 264, False, True),
+                                                    (70, 36, 140, True, True), (1000, 89, 264, False, True), (33, 4, 160, True, False)])
 def test_rowgemm_column_split(T, rows, K, N, trans_b, bias):
-    """products without the row epilogue and more than 128 output columns on few row panels run as column blocks of 128
-    (grid.y): same result as the torch product, ragged last block and partial row panel included"""
+    """products without the row epilogue and more than 128 output columns run as column blocks of 128 (grid.y): same result as the
+    torch product — ragged last column block (the 2H score columns of a GAT projection at its real size), partial row panel, K below
+    and across a 32-wide chunk, padded K"""
     from two_stage_gnn_amd import _native as nat
     gen = torch.Generator(device="cuda").manual_seed(rows + N)
     ldk = (K + 3) // 4 * 4
