@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--no-seeds", action="store_true", help="skip `value_over_seeds` (the same step on the batches of seeds 0-7)")
     ap.add_argument("--seeds", default="0,1,2,3,4,5,6,7")
     ap.add_argument("--seed-base", type=int, default=0, help="rank r draws the batch of seed seed-base + r (default 0: the contract's batches)")
+    ap.add_argument("--triplet", action="store_true", help="also time the 2stg triplet step (f3: one triplet per optimiser step)")
     ap.add_argument("--ingest", action="store_true", help="also time the step fed with a NEW host batch every step (collate + "
                                                           "upload on a copy stream, double-buffered): `ingest` in the JSON line")
     return ap.parse_args()
@@ -471,6 +472,120 @@ def ingest_run(a, model, trainer, dev, steps, rank, value):
                     % (a.batch, a.shape)}
 
 
+def triplet_run(a, dev, with_cpu):
+    """f3 — the 2stg / 2stg+ training step (tripletnet.py:16-45, train_triplet.py:247-287): ONE triplet (anchor, positive, negative)
+    per optimiser step, MarginRankingLoss on the pairwise distances of the three embeddings, clip 2.0 + Adam.  The reference runs the
+    encoder three times at B = 1 on dense [1, Nmax, Nmax] adjacencies; here the three graphs are one block-diagonal batch with the
+    per-graph batch-norm statistics a B = 1 forward has (two_stage_gnn_amd/triplet.py).  Three figures: the drop-in module fed from
+    host dicts every step as the reference's loop feeds it (upload and dense->CSR inside the step), the same step on a resident
+    packed triplet replayed from a hipGraph, and the CPU oracle's three B = 1 forwards."""
+    import numpy as np
+    import torch
+    from two_stage_gnn_amd import dense_encoders as E, synthetic
+    from two_stage_gnn_amd.triplet import tripletnet
+    from two_stage_gnn_amd.data_parallel import FlatTrainer, GraphedStep
+    hb = synthetic.host_batch(11, 3, a.shape, a.nmax)
+    x, adj = synthetic.to_dense(hb)                                   # the reference's inputs: dense, padded to Nmax, on the host
+
+    class Args:
+        bias = True
+
+    class G_:
+        def __init__(self, b):
+            self.graph = {"adj": adj[b].numpy(), "feats": x[b].numpy(), "num_nodes": int(hb["sizes"][b]), "assign_feats": x[b].numpy()}
+
+    torch.manual_seed(5)
+    model = E.GcnEncoderGraph(hb["fin"], a.hidden, a.hidden, 2, a.layers, bn=True, args=Args(), final_dim="output_dim").to(dev)
+    state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    net = tripletnet(model)
+    trip = [G_(b) for b in range(3)]
+    crit = torch.nn.MarginRankingLoss(margin=1.0)
+    target = torch.full((1,), -1.0, device=dev)
+    params = [q for q in model.parameters() if q.requires_grad]
+    opt = torch.optim.Adam(params, lr=1e-3)
+
+    def drop_in():
+        opt.zero_grad(set_to_none=True)
+        dp, dn = net(*trip)[:2]
+        crit(dp, dn, target).backward()
+        torch.nn.utils.clip_grad_norm_(params, 2.0)
+        opt.step()
+
+    for _ in range(5):
+        drop_in()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n_e = 30
+    for _ in range(n_e):
+        drop_in()
+    torch.cuda.synchronize()
+    eager_ms = (time.perf_counter() - t0) / n_e * 1e3
+    # resident: the packed triplet in HBM, fwd + loss + bwd + clip + Adam from one hipGraph
+    g3, x3, _ = synthetic.to_device(hb, dev)
+    trainer = FlatTrainer(model, lr=1e-3, clip=2.0)
+
+    def loss_fn():
+        model.per_graph_bn = True
+        try:
+            embed = model(x3, g3)[1]
+        finally:
+            model.per_graph_bn = False
+        dp = torch.nn.functional.pairwise_distance(embed[0:1], embed[1:2], 2)
+        dn = torch.nn.functional.pairwise_distance(embed[0:1], embed[2:3], 2)
+        return crit(dp, dn, target)
+
+    gs = GraphedStep(trainer, loss_fn, warmup=3)
+    for _ in range(10):
+        gs.step()
+    torch.cuda.synchronize()
+    n_g = 200
+    t0 = time.perf_counter()
+    for _ in range(n_g):
+        gs.step()
+    torch.cuda.synchronize()
+    graph_ms = (time.perf_counter() - t0) / n_g * 1e3
+    out = {"unit": "triplets/s",
+           "config": "%s-shaped triplet (%s nodes, Nmax %d), GcnEncoderGraph %d layers h=%d final_dim='output_dim', margin 1, clip 2.0 + Adam"
+                     % (a.shape, "/".join(str(int(v)) for v in hb["sizes"]), a.nmax, a.layers, a.hidden),
+           "drop_in_from_host_dicts": {"value": 1e3 / eager_ms, "ms_per_step": eager_ms, "steps": n_e,
+                                       "note": "tripletnet(model)(a, p, n) on `.graph` dicts as the reference's loop passes them: three "
+                                               "dense [Nmax, Nmax] adjacencies uploaded and turned into CSR inside every step, eager launches, "
+                                               "torch clip + Adam"},
+           "resident_hipgraph": {"value": 1e3 / graph_ms, "ms_per_step": graph_ms, "steps": n_g,
+                                 "note": "the packed triplet resident in HBM, forward + loss + backward + clip + Adam replayed from one "
+                                         "hipGraph (per-graph batch-norm: the per-op kernels, not the fused stack)"},
+           "cpu_baseline": None}
+    if with_cpu:
+        from oracle import dense_ref as R
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        cores = min(cores, int(os.environ.get("TSGNN_CPU_THREADS", 16)))
+        torch.set_num_threads(cores)
+        pr = {k: v.clone().requires_grad_(True) for k, v in state.items()}
+        opt_c = torch.optim.Adam(list(pr.values()), lr=1e-3)
+        tgt = torch.tensor([-1.0])
+
+        def cpu_step():
+            opt_c.zero_grad()
+            e = [R.gcn_encoder(pr, x[b:b + 1], adj[b:b + 1], bn=True, final_dim="output_dim")[1] for b in range(3)]
+            dp = torch.nn.functional.pairwise_distance(e[0], e[1], 2)
+            dn = torch.nn.functional.pairwise_distance(e[0], e[2], 2)
+            crit(dp, dn, tgt).backward()
+            torch.nn.utils.clip_grad_norm_(list(pr.values()), 2.0)
+            opt_c.step()
+
+        cpu_step()
+        t0 = time.perf_counter(); cpu_step(); t1 = time.perf_counter()
+        n_c = int(max(3, min(200, 6.0 / max(t1 - t0, 1e-3))))
+        t0 = time.perf_counter()
+        for _ in range(n_c):
+            cpu_step()
+        dt = (time.perf_counter() - t0) / n_c
+        out["cpu_baseline"] = {"value": 1.0 / dt, "unit": "triplets/s", "cores": cores, "kind": "port",
+                               "sample": "%d steps of the same triplet: three B = 1 dense forwards of the oracle at Nmax=%d, margin loss, "
+                                         "backward, clip, Adam (%.1f ms/step)" % (n_c, a.nmax, dt * 1e3)}
+    return out
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -671,6 +786,8 @@ def main():
                                      "note": "max over seeds 0-7 of the one-GPU step = the pace of an 8-rank step before the all-reduce"}
     if a.ingest and world == 1:
         out["ingest"] = ingest_run(a, model, trainer, dev, max(a.steps, 100), rank, out["value"])
+    if a.triplet and world == 1:
+        out["triplet"] = triplet_run(a, dev, not a.no_cpu_baseline)
     if rank == 0:
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(hb, a.hidden, a.layers, a.cpu_steps, init_state)
