@@ -548,9 +548,9 @@ def triplet_run(a, dev, with_cpu):
            "config": "%s-shaped triplet (%s nodes, Nmax %d), GcnEncoderGraph %d layers h=%d final_dim='output_dim', margin 1, clip 2.0 + Adam"
                      % (a.shape, "/".join(str(int(v)) for v in hb["sizes"]), a.nmax, a.layers, a.hidden),
            "drop_in_from_host_dicts": {"value": 1e3 / eager_ms, "ms_per_step": eager_ms, "steps": n_e,
-                                       "note": "tripletnet(model)(a, p, n) on `.graph` dicts as the reference's loop passes them: three "
-                                               "dense [Nmax, Nmax] adjacencies uploaded and turned into CSR inside every step, eager launches, "
-                                               "torch clip + Adam"},
+                                       "note": "tripletnet(model)(a, p, n) on `.graph` dicts as the reference's loop passes them (a graph "
+                                               "object's CSR rows and features go to the device at its first use and stay resident), eager "
+                                               "launches, torch clip + Adam"},
            "resident_hipgraph": {"value": 1e3 / graph_ms, "ms_per_step": graph_ms, "steps": n_g,
                                  "note": "the packed triplet resident in HBM, forward + loss + backward + clip + Adam replayed from one "
                                          "hipGraph (per-graph batch-norm: the per-op kernels, not the fused stack)"},
