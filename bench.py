@@ -525,13 +525,7 @@ def triplet_run(a, dev, with_cpu):
     trainer = FlatTrainer(model, lr=1e-3, clip=2.0)
 
     def loss_fn():
-        model.per_graph_bn = True
-        try:
-            embed = model(x3, g3)[1]
-        finally:
-            model.per_graph_bn = False
-        dp = torch.nn.functional.pairwise_distance(embed[0:1], embed[1:2], 2)
-        dn = torch.nn.functional.pairwise_distance(embed[0:1], embed[2:3], 2)
+        dp, dn = net._embed(x3, g3, hb["sizes"], x3)[:2]               # what tripletnet.forward runs once the batch is assembled
         return crit(dp, dn, target)
 
     gs = GraphedStep(trainer, loss_fn, warmup=3)

@@ -937,6 +937,18 @@ int tsgnn_sage_multi_f32(const int64_t* desc, tsgnn_stream_t stream);
  * 355-356) without a launch of its own.  Needs fill_rows > 0, n % 4 == 0, 16-byte aligned regions; TSGNN_EUNSUPPORTED otherwise. */
 int tsgnn_sage_multi_zero_f32(const int64_t* desc, float* zero0, int64_t n0, float* zero1, int64_t n1, tsgnn_stream_t stream);
 
+/* ---- tail of the 2stg triplet step (csrc/triplet.hip; Code/sage+gat+diffpool/tripletnet.py:35-45): the three graphs' embeddings
+ * embed[b] = W r[b] + bias (encoders.py:217 `map_model`, nn.Linear's [E, D] layout; r[3, D] = the concatenated readouts of anchor,
+ * positive, negative) and dist = (||e_a - e_p + eps||_2, ||e_a - e_n + eps||_2) (F.pairwise_distance) in one launch; the backward
+ * from the gradients of the two distances (d_dp[1], d_dn[1]) and of the three embeddings (d_ea, d_ep, d_en [E]; every one
+ * nullable = zero) to d_r[3, D], dW[E, D], db[E] (nullable) in one launch.
+ * D % 4 == 0, E <= 512, 16-byte aligned r / W rows. */
+int tsgnn_triplet_embed_fwd_f32(const float* r, int64_t ldr, const float* w, int64_t ldw, const float* b, int D, int E, float eps,
+                                float* embed, float* dist, tsgnn_stream_t stream);
+int tsgnn_triplet_embed_bwd_f32(const float* r, int64_t ldr, const float* w, int64_t ldw, int D, int E, float eps, const float* embed,
+                                const float* dist, const float* d_dp, const float* d_dn, const float* d_ea, const float* d_ep,
+                                const float* d_en, float* d_r, int64_t lddr, float* dw, int64_t lddw, float* db, tsgnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -791,6 +791,37 @@ def test_diffpool_linkpred_encoder_vs_oracle():
 
 
 # ----------------------------------------------------------------------------- triplet step (tripletnet.py)
+@pytest.mark.parametrize("D,E,bias", [(384, 128, True), (20, 7, True), (48, 16, False)])
+def test_triplet_tail_kernels(D, E, bias):
+    """embeddings + both pairwise distances in one launch and their backward in one launch (csrc/triplet.hip) against torch's
+    Linear + F.pairwise_distance, with gradient reaching the embeddings directly as well (the norm regularisers of
+    train_triplet.py:262-263) and with one of the two distances unused"""
+    from two_stage_gnn_amd import triplet as T3
+    gen = torch.Generator().manual_seed(D + E)
+    r = torch.randn(3, D, generator=gen)
+    lin = torch.nn.Linear(D, E, bias=bias)
+    for used in ("both", "dp_only"):
+        rr = r.clone().requires_grad_(True)
+        e = lin(rr)
+        dp = torch.nn.functional.pairwise_distance(e[0:1], e[1:2], 2)
+        dn = torch.nn.functional.pairwise_distance(e[0:1], e[2:3], 2)
+        loss = torch.nn.MarginRankingLoss(margin=5.0)(dp, dn, torch.tensor([-1.0])) + 0.1 * (e[0:1].norm(2) + e[2:3].norm(1)) if used == "both" \
+            else (dp * 1.5).sum()
+        g_ref = torch.autograd.grad(loss, [rr, lin.weight] + ([lin.bias] if bias else []))
+        rg = r.cuda().requires_grad_(True)
+        w = lin.weight.detach().cuda().requires_grad_(True)
+        b = lin.bias.detach().cuda().requires_grad_(True) if bias else None
+        dpg, dng, ea, ep, en = T3._TripletTail.apply(rg, w, b)
+        torch.testing.assert_close(torch.cat([ea, ep, en]).detach().cpu(), e.detach(), rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(dpg.detach().cpu(), dp.detach(), rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(dng.detach().cpu(), dn.detach(), rtol=1e-5, atol=1e-5)
+        lg = torch.nn.MarginRankingLoss(margin=5.0)(dpg, dng, torch.tensor([-1.0]).cuda()) + 0.1 * (ea.norm(2) + en.norm(1)) if used == "both" \
+            else (dpg * 1.5).sum()
+        g = torch.autograd.grad(lg, [rg, w] + ([b] if bias else []))
+        for a, c in zip(g, g_ref):
+            torch.testing.assert_close(a.cpu(), c, rtol=1e-4, atol=1e-5)
+
+
 class _G:                       # stand-in for the networkx graphs cross_val.split_train_val prepares (cross_val.py:158-184)
     def __init__(self, adj, feats, n):
         self.graph = {"adj": adj, "feats": feats, "num_nodes": n, "assign_feats": feats}

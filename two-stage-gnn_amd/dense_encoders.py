@@ -253,17 +253,23 @@ class GcnEncoderGraph(nn.Module):
                 bool(mp.nat.lib().tsgnn_slot_fused_supported(g.B, convs[0].output_dim)) and \
                 bool(mp.nat.lib().tsgnn_slot_fused_supported(g.B, convs[-1].output_dim)):
             return sage_stack.sage_stack_readouts(x, g, convs)
+        # the layers' readouts land in their column blocks of ONE buffer (no torch.cat launch, no slice copies backwards)
+        cols = mp.ReadoutColumns(g.B, self.pred_input_dim, x.device) if (self.concat and READOUT_COLUMNS) else None
         x = self._post(self.conv_first.forward_rows(x, g), g)
-        out_all = [mp.readout_max(x, g)]
+        out_all = [mp.readout_max(x, g, into=cols and cols.take(x.size(1)))]
         for conv in self.conv_block:
             x = self._post(conv.forward_rows(x, g), g)
-            out_all.append(mp.readout_max(x, g))
+            out_all.append(mp.readout_max(x, g, into=cols and cols.take(x.size(1))))
         x = self.conv_last.forward_rows(x, g)
-        out_all.append(mp.readout_max(x, g))
-        return torch.cat(out_all, dim=1) if self.concat else out_all[-1]
+        out_all.append(mp.readout_max(x, g, into=cols and cols.take(x.size(1))))
+        if not self.concat:
+            return out_all[-1]
+        return cols.join(out_all) if cols is not None else torch.cat(out_all, dim=1)
 
     def _head_linears(self):
         """the two chained nn.Linear after the readout (None for the 2stg setting, whose first output IS the readout)"""
+        if getattr(self, "_defer_map", False):
+            return None
         if self.final_dim == "pretrain":
             return self.map_model, self.map2_model
         if self.final_dim != "output_dim":
@@ -272,6 +278,8 @@ class GcnEncoderGraph(nn.Module):
 
     def _heads(self, output):
         if self.final_dim == "pretrain":          # 2stg+
+            if getattr(self, "_defer_map", False):
+                return None, output                 # (tripletnet reads the embedding only; it applies map_model to `output` itself)
             if FUSED_HEAD and mp.head2_ok(output, self.map_model, self.map2_model):
                 out, ypred = mp.head2(output, self.map_model, self.map2_model)
                 return ypred, out
@@ -282,6 +290,8 @@ class GcnEncoderGraph(nn.Module):
                 return mp.head2(output, self.pre_pred_model, self.pred_model)
             vec = self.pre_pred_model(output)
             return vec, self.pred_model(vec)
+        if getattr(self, "_defer_map", False):    # triplet.tripletnet applies map_model itself (embeddings + distances, one launch)
+            return output, None
         return output, self.map_model(output)     # 2stg
 
     def _stack_fusable(self, x, g):

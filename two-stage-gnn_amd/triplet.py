@@ -13,6 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _native as nat
 from .graph import GraphBatch
 
 
@@ -107,11 +108,74 @@ def _assemble(parts, dev, cache):
     return g, x, xa, sizes
 
 
+# ----------------------------------------------------------------------------- embeddings + distances: one launch each way
+FUSED_TAIL = os.environ.get("TSGNN_TRIPLET_TAIL", "1") != "0"
+_EPS = 1e-6                      # F.pairwise_distance's default
+
+
+class _TripletTail(torch.autograd.Function):
+    """(readouts r[3, D], map_model's weight [E, D], bias) -> (dist_p[1], dist_n[1], embed_a[1, E], embed_p, embed_n): the Linear on
+    the three readout rows and both pairwise distances (tripletnet.py:35-45) as tsgnn_triplet_embed_fwd_f32 / _bwd_f32.  The five
+    outputs are separate tensors, so no slice (and no zero-filled slice gradient) is launched around them."""
+
+    @staticmethod
+    def forward(ctx, r, w, b):
+        r, w = r.contiguous(), w.contiguous()
+        D, E = int(w.size(1)), int(w.size(0))
+        embed = torch.empty(3, E, dtype=torch.float32, device=r.device)
+        dist = torch.empty(2, dtype=torch.float32, device=r.device)
+        nat.call("triplet_embed_fwd_f32", r, r.stride(0), w, w.stride(0), b, D, E, _EPS, embed, dist)
+        ctx.save_for_backward(r, w, embed, dist)
+        ctx.has_bias = b is not None
+        outs = (dist[0:1], dist[1:2], embed[0:1], embed[1:2], embed[2:3])
+        return outs
+
+    @staticmethod
+    def backward(ctx, g_dp, g_dn, g_a, g_p, g_n):
+        r, w, embed, dist = ctx.saved_tensors
+        D, E = int(w.size(1)), int(w.size(0))
+        dev = r.device
+        c = lambda t: t.contiguous() if t is not None else None
+        d_r = torch.empty(3, D, dtype=torch.float32, device=dev)
+        dw = torch.empty(E, D, dtype=torch.float32, device=dev)
+        db = torch.empty(E, dtype=torch.float32, device=dev) if ctx.has_bias else None
+        nat.call("triplet_embed_bwd_f32", r, r.stride(0), w, w.stride(0), D, E, _EPS, embed, dist, c(g_dp), c(g_dn), c(g_a), c(g_p), c(g_n), d_r,
+                 d_r.stride(0), dw, dw.stride(0), db)
+        return d_r, dw, db
+
+
+def tail_ok(model, r):
+    lin = getattr(model, "map_model", None)
+    return (FUSED_TAIL and isinstance(lin, nn.Linear) and r is not None and r.is_cuda and r.dim() == 2 and r.size(0) == 3
+            and r.dtype == torch.float32 and lin.in_features == r.size(1) and lin.in_features % 4 == 0 and lin.out_features <= 512
+            and lin.weight.dtype == torch.float32)
+
+
 class tripletnet(nn.Module):
     def __init__(self, model):
         super().__init__()
         self.model = model
         self._resident = {}
+
+    def _embed(self, x, g_or_adj, sizes, assign_x):
+        """model forward with the per-graph batch-norm statistics of a B = 1 call -> (dist_p, dist_n, embed_a, embed_p, embed_n)"""
+        m = self.model
+        prev = getattr(m, "per_graph_bn", False)
+        fuse = FUSED_TAIL and getattr(m, "final_dim", None) in ("output_dim", "pretrain") and isinstance(getattr(m, "map_model", None), nn.Linear)
+        m.per_graph_bn = True
+        m._defer_map = fuse
+        try:
+            out, embed = m(x, g_or_adj, sizes, assign_x=assign_x)
+        finally:
+            m.per_graph_bn = prev
+            m._defer_map = False
+        if fuse:
+            r = out if m.final_dim == "output_dim" else embed      # the concatenated readouts (encoders.py:201-205)
+            if tail_ok(m, r):
+                return _TripletTail.apply(r, m.map_model.weight, m.map_model.bias)
+            embed = m.map_model(r)
+        embed_a, embed_p, embed_n = embed[0:1], embed[1:2], embed[2:3]
+        return (F.pairwise_distance(embed_a, embed_p, 2), F.pairwise_distance(embed_a, embed_n, 2), embed_a, embed_p, embed_n)
 
     @staticmethod
     def _stack(graphs, key, device):
@@ -124,25 +188,9 @@ class tripletnet(nn.Module):
         trip = (a, p, n)
         if RESIDENT and dev.type == "cuda":
             g, x, xa, sizes = _assemble([_resident(t, dev, self._resident) for t in trip], dev, self._resident)
-            prev = getattr(self.model, "per_graph_bn", False)
-            self.model.per_graph_bn = True
-            try:
-                out, embed = self.model(x, g, sizes, assign_x=x if xa is None else xa)
-            finally:
-                self.model.per_graph_bn = prev
-            embed_a, embed_p, embed_n = embed[0:1], embed[1:2], embed[2:3]
-            return (F.pairwise_distance(embed_a, embed_p, 2), F.pairwise_distance(embed_a, embed_n, 2), embed_a, embed_p, embed_n)
+            return self._embed(x, g, sizes, x if xa is None else xa)
         adj = self._stack(trip, "adj", dev)
         h0 = self._stack(trip, "feats", dev)
         assign = self._stack(trip, "assign_feats", dev)
         sizes = np.array([int(g.graph["num_nodes"]) for g in trip])
-        prev = getattr(self.model, "per_graph_bn", False)
-        self.model.per_graph_bn = True
-        try:
-            out, embed = self.model(h0, adj, sizes, assign_x=assign if assign.shape == h0.shape and not torch.equal(assign, h0) else h0)
-        finally:
-            self.model.per_graph_bn = prev
-        embed_a, embed_p, embed_n = embed[0:1], embed[1:2], embed[2:3]
-        dist_p = F.pairwise_distance(embed_a, embed_p, 2)
-        dist_n = F.pairwise_distance(embed_a, embed_n, 2)
-        return dist_p, dist_n, embed_a, embed_p, embed_n
+        return self._embed(h0, adj, sizes, assign if assign.shape == h0.shape and not torch.equal(assign, h0) else h0)
