@@ -371,6 +371,15 @@ int tsgnn_row_ln_fwd_f32(const float* v, int64_t ldv, int64_t rows, int F, int r
 int tsgnn_row_ln_bwd_f32(const float* v, int64_t ldv, const float* dy, int64_t lddy, int64_t rows, int F, int relu, const float* mean,
                          const float* rstd, float* dv, int64_t lddv, tsgnn_stream_t stream);
 
+/* Backward of [max readout ; tsgnn_row_ln_fwd_f32 ; L2 normalise] of a hidden GraphConv layer in one pass (the row-local counterpart
+ * of tsgnn_slot_post_bwd_f32 for per-graph statistics): rows [0, n_real) are real rows (graph row_graph[r]), rows [n_real, rows) ghost
+ * rows (row n_real + s = the padded slot s of every graph; it can be the readout winner of any graph).  dy = dxs (real rows; nullable)
+ * + the readout gradient dout[b, f] where arg[b * F + f] == r (both nullable together); ln = 0 / relu = 0 skip those stages;
+ * du = rinv (dv - v <v, dv>).  F <= 256. */
+int tsgnn_row_post_bwd_f32(const int* row_graph, int B, int64_t n_real, int64_t rows, const float* v, int64_t ldv, const float* dxs,
+                           int64_t lddxs, const float* dout, int64_t ldo, const int* arg, int F, int relu, int ln, const float* mean,
+                           const float* rstd, const float* rinv, float* du, int64_t lddu, tsgnn_stream_t stream);
+
 /* out[b,f] = max over the nmax node slots of graph b (ghost rows included, trap T5), arg = winning row.
  * Replaces torch.max(x, dim=1) (encoders.py:183,190,197,353,383).  ONE launch.  packed_ws: tsgnn_readout_max_ws_words(B, nmax, F)
  * uint64 words (B * F packed maxima, then the graphs' arrival counters), ALL zero on entry and all zero again on return: a workspace

@@ -791,6 +791,65 @@ def test_diffpool_linkpred_encoder_vs_oracle():
 
 
 # ----------------------------------------------------------------------------- triplet step (tripletnet.py)
+@pytest.mark.parametrize("hidden,nmax,sizes", [(128, 40, [40, 17, 29]), (128, 64, [33, 64, 5]), (64, 48, [20, 31, 9])])
+def test_triplet_fused_stack_with_per_graph_statistics(hidden, nmax, sizes):
+    """the triplet step on the fused conv stack (sage_stack.per_graph_stats: the slot batch-norm launches replaced by their
+    row-local counterparts, tsgnn_row_ln_fwd_f32 / tsgnn_row_post_bwd_f32) against the oracle's three B = 1 forwards — embeddings,
+    distances and every parameter gradient — and against the per-op path (TSGNN_PER_GRAPH_STACK=0); graphs that fill all Nmax
+    slots, padded winners of the max readout (ghost rows) included"""
+    from two_stage_gnn_amd import dense_encoders as E, _native as nat
+    from two_stage_gnn_amd.triplet import tripletnet
+    fin = 12
+    x, adj, sz = dense_batch(57 + hidden, 3, nmax, fin, sizes=sizes, p_edge=0.15)
+
+    class A:
+        bias = True
+    torch.manual_seed(6)
+    m = E.GcnEncoderGraph(fin, hidden, hidden, 2, 3, bn=True, args=A(), final_dim="output_dim")
+    with torch.no_grad():
+        for k, p in m.named_parameters():
+            if "conv" in k and k.endswith("bias"):
+                p.copy_(torch.randn_like(p) * 0.3)           # padded rows then carry values that can win the max readout
+    m = m.cuda()
+    p_ref = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    embeds = [R.gcn_encoder(p_ref, x[b:b + 1], adj[b:b + 1], bn=True, final_dim="output_dim")[1] for b in range(3)]
+    dp_ref = torch.nn.functional.pairwise_distance(embeds[0], embeds[1], 2)
+    dn_ref = torch.nn.functional.pairwise_distance(embeds[0], embeds[2], 2)
+    (torch.nn.MarginRankingLoss(margin=10.0)(dp_ref, dn_ref, torch.tensor([-1.0])) + 0.05 * embeds[1].norm(2)).backward()
+    net = tripletnet(m)
+    gs = [_G(adj[b].numpy(), x[b].numpy(), int(sz[b])) for b in range(3)]
+
+    def run():
+        m.zero_grad(set_to_none=True)
+        nat.trace = []
+        dp, dn, ea, ep, en = net(*gs)
+        (torch.nn.MarginRankingLoss(margin=10.0)(dp, dn, torch.tensor([-1.0]).cuda()) + 0.05 * ep.norm(2)).backward()
+        names = [t[0] for t in nat.trace]
+        nat.trace = None
+        return dp.detach(), dn.detach(), ea.detach(), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}, names
+
+    dp, dn, ea, grads, names = run()
+    assert "row_post_bwd_f32" in names and "row_ln_fwd_f32" in names and "ell_spmm_f32" not in names, names
+    torch.testing.assert_close(dp.cpu(), dp_ref.detach(), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(dn.cpu(), dn_ref.detach(), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(ea.cpu(), embeds[0].detach(), rtol=1e-4, atol=1e-4)
+    for k, gr in grads.items():
+        ref = p_ref[k].grad
+        if ref is None:
+            continue
+        err = (gr.cpu() - ref).abs().max().item()
+        assert err <= 2e-3 * ref.abs().max().item() + 1e-6, (k, err, ref.abs().max().item())
+    E.PER_GRAPH_STACK = False
+    try:
+        dp2, dn2, ea2, grads2, names2 = run()
+    finally:
+        E.PER_GRAPH_STACK = True
+    assert "row_post_bwd_f32" not in names2
+    torch.testing.assert_close(dp2, dp, rtol=1e-5, atol=1e-5)
+    for k in grads:
+        torch.testing.assert_close(grads2[k], grads[k], rtol=1e-3, atol=1e-5 + 1e-4 * float(grads[k].abs().max()))
+
+
 @pytest.mark.parametrize("D,E,bias", [(384, 128, True), (20, 7, True), (48, 16, False)])
 def test_triplet_tail_kernels(D, E, bias):
     """embeddings + both pairwise distances in one launch and their backward in one launch (csrc/triplet.hip) against torch's

@@ -192,6 +192,62 @@ __global__ __launch_bounds__(256) void row_ln_bwd(const float* __restrict__ v, i
   }
 }
 
+// Backward of [max readout ; per-row layer norm ; ReLU ; L2 normalise] of a hidden GraphConv layer in ONE pass when the batch-norm
+// statistics are per graph (B = 1 semantics, row_ln_fwd): the row-local counterpart of slot_post_bwd (sage_fused.hip).
+//   dy(r, f) = dxs[r, f]                                   (real rows: what the next layer's input gradient brought; a ghost row has no edges)
+//            + sum_b (arg[b, f] == r ? dout[b, f] : 0)     (max-readout winners: a real row can only win in its own graph, a ghost row —
+//                                                            the first padded slot of every graph of its size — in any)
+//   LN:  dv = rstd (dy - mean(dy) - xhat mean(dy xhat)) ; ReLU mask ;  L2:  du = rinv (dv - v <v, dv>)   (rinv >= 1e12: clamped norm)
+// One wave per row, F <= 256 (four values per lane in registers).
+__global__ __launch_bounds__(256) void row_post_bwd(const int* __restrict__ row_graph, int B, int64_t n_real, int64_t rows,
+                                                    const float* __restrict__ v, int64_t ldv, const float* __restrict__ dxs, int64_t lddxs,
+                                                    const float* __restrict__ dout, int64_t ldo, const int* __restrict__ arg, int F,
+                                                    int relu, int ln, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                    const float* __restrict__ rinv, float* __restrict__ du, int64_t lddu) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const bool ghost = r >= n_real;
+  const int b0 = ghost ? 0 : row_graph[r], b1 = ghost ? B : b0 + 1;
+  const float mu = ln ? mean[r] : 0.f, rs = ln ? rstd[r] : 1.f;
+  const float ri = rinv[r];
+  float x[4], dy[4];
+  float a = 0.f, c = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int f = lane + 64 * q;
+    x[q] = 0.f; dy[q] = 0.f;
+    if (f < F) {
+      x[q] = v[r * ldv + f];
+      float d = (dxs && !ghost) ? dxs[r * lddxs + f] : 0.f;
+      if (arg)
+        for (int b = b0; b < b1; ++b)
+          if ((int64_t)arg[(int64_t)b * F + f] == r) d += dout[(int64_t)b * ldo + f];
+      dy[q] = d;
+      a += d;
+      c = fmaf(d, (act(x[q], relu) - mu) * rs, c);
+    }
+  }
+  float dot = 0.f;
+  if (ln) {
+    const float m1 = wave_sum(a) / (float)F, m2 = wave_sum(c) / (float)F;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dy[q] = rs * (dy[q] - m1 - (act(x[q], relu) - mu) * rs * m2);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (relu && !(x[q] > 0.f)) dy[q] = 0.f;
+    if (lane + 64 * q >= F) dy[q] = 0.f;
+    dot = fmaf(x[q], dy[q], dot);
+  }
+  dot = ri >= 0.999e12f ? 0.f : wave_sum(dot);            // |u| < eps: F.normalize's clamp_min passes no norm gradient
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int f = lane + 64 * q;
+    if (f < F) du[r * lddu + f] = ri * (dy[q] - x[q] * dot);
+  }
+}
+
 // ---------------------------------------------------------------- max readout over node slots
 // grid (chunks of 64 slots, B); block = 4 waves x 16 slots, lanes over features.  ONE launch: every block folds the packed
 // (value, row) maxima of its chunk into packed[b, :] with device-scope atomicMax (performed at the memory side: coherent across
@@ -412,6 +468,21 @@ int tsgnn_row_ln_bwd_f32(const float* v, int64_t ldv, const float* dy, int64_t l
   if (!v || !dy || !mean || !rstd || !dv || rows < 0 || F <= 0 || ldv < F || lddy < F || lddv < F) return TSGNN_EINVAL;
   if (rows == 0) return TSGNN_OK;
   row_ln_bwd<<<(unsigned)ceil_div64(rows, 4), 256, 0, stream>>>(v, ldv, dy, lddy, rows, F, relu, mean, rstd, dv, lddv);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+int tsgnn_row_post_bwd_f32(const int* row_graph, int B, int64_t n_real, int64_t rows, const float* v, int64_t ldv, const float* dxs,
+                           int64_t lddxs, const float* dout, int64_t ldo, const int* arg, int F, int relu, int ln, const float* mean,
+                           const float* rstd, const float* rinv, float* du, int64_t lddu, tsgnn_stream_t stream) {
+  if (!v || !rinv || !du || B <= 0 || n_real < 0 || rows < n_real || F <= 0 || ldv < F || lddu < F || (dxs && lddxs < F) ||
+      (n_real > 0 && !row_graph) || ((arg == nullptr) != (dout == nullptr)) || (arg && ldo < F) || (ln && (!mean || !rstd)))
+    return TSGNN_EINVAL;
+  if (F > 256) return TSGNN_EUNSUPPORTED;
+  if (rows == 0) return TSGNN_OK;
+  TSGNN_KNAME("row_post_bwd");
+  row_post_bwd<<<(unsigned)ceil_div64(rows, 4), 256, 0, stream>>>(row_graph, B, n_real, rows, v, ldv, dxs, lddxs, dout, ldo, arg, F, relu, ln,
+                                                                 mean, rstd, rinv, du, lddu);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }

@@ -3,9 +3,9 @@
 // launch forward and ONE launch backward.  With torch ops this tail was ~25 launches of a 80-launch step (three 1-row GEMMs of
 // hipBLASLt, slices and their zero-filled gradients, sub / add / norm and their backward).
 //
-// Forward: one workgroup of 16 waves; a wave takes output columns e = wave, wave + 16, ...: lanes stride over the D inputs with
-// 16-byte loads of W's row e (nn.Linear's [out, in] layout) and of the three readout rows, three wave sums per column; the distances
-// from the finished embeddings in LDS.  196 KB of W through one CU is ~3 us; the step is launch-bound, not byte-bound.
+// Forward: one workgroup of 16 waves; a wave takes eight output columns at a time: lanes stride over the D inputs with
+// 16-byte loads of W's rows (nn.Linear's [out, in] layout, eight rows requested together) and of the three readout rows, three wave
+// sums per column; the distances from the finished embeddings in LDS.
 // Backward: grid over slices of 32 input columns (no dependency between workgroups): every workgroup re-derives the embeddings'
 // gradient de[3, E] (distance terms + the gradient that reaches the embeddings directly, e.g. the norm regularisers of
 // train_triplet.py:262-263) and produces its columns of d_r = de W and of dW = de^T r; workgroup 0 also writes db.
@@ -16,6 +16,9 @@ namespace {
 
 constexpr int TE_MAXE = 512;
 
+// TE_EPW output columns per wave and pass: their W rows are requested together (one round trip for eight rows instead of one per row:
+// the first version walked its rows one after the other and spent 12 us on 16 dependent trips)
+constexpr int TE_EPW = 8;
 __global__ __launch_bounds__(1024) void triplet_embed_fwd_kernel(const float* __restrict__ r, int64_t ldr, const float* __restrict__ w,
                                                                  int64_t ldw, const float* __restrict__ b, int D, int E, float eps,
                                                                  float* __restrict__ embed, float* __restrict__ dist) {
@@ -23,22 +26,33 @@ __global__ __launch_bounds__(1024) void triplet_embed_fwd_kernel(const float* __
   __shared__ float red[2][16];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int D4 = D >> 2;
-  for (int e = wid; e < E; e += 16) {
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    const float4* wp = reinterpret_cast<const float4*>(w + (int64_t)e * ldw);
+  for (int e0 = wid * TE_EPW; e0 < E; e0 += 16 * TE_EPW) {
+    float s0[TE_EPW], s1[TE_EPW], s2[TE_EPW];
+#pragma unroll
+    for (int j = 0; j < TE_EPW; ++j) { s0[j] = 0.f; s1[j] = 0.f; s2[j] = 0.f; }
     for (int c = lane; c < D4; c += 64) {
-      const float4 wv = wp[c];
+      float4 wv[TE_EPW];
+#pragma unroll
+      for (int j = 0; j < TE_EPW; ++j)                                  // rows past E: a mapped row, result dropped
+        wv[j] = reinterpret_cast<const float4*>(w + (int64_t)min(e0 + j, E - 1) * ldw)[c];
       const float4 a = reinterpret_cast<const float4*>(r)[c];
       const float4 p = reinterpret_cast<const float4*>(r + ldr)[c];
       const float4 n = reinterpret_cast<const float4*>(r + 2 * ldr)[c];
-      s0 = fmaf(wv.x, a.x, fmaf(wv.y, a.y, fmaf(wv.z, a.z, fmaf(wv.w, a.w, s0))));
-      s1 = fmaf(wv.x, p.x, fmaf(wv.y, p.y, fmaf(wv.z, p.z, fmaf(wv.w, p.w, s1))));
-      s2 = fmaf(wv.x, n.x, fmaf(wv.y, n.y, fmaf(wv.z, n.z, fmaf(wv.w, n.w, s2))));
+#pragma unroll
+      for (int j = 0; j < TE_EPW; ++j) {
+        s0[j] = fmaf(wv[j].x, a.x, fmaf(wv[j].y, a.y, fmaf(wv[j].z, a.z, fmaf(wv[j].w, a.w, s0[j]))));
+        s1[j] = fmaf(wv[j].x, p.x, fmaf(wv[j].y, p.y, fmaf(wv[j].z, p.z, fmaf(wv[j].w, p.w, s1[j]))));
+        s2[j] = fmaf(wv[j].x, n.x, fmaf(wv[j].y, n.y, fmaf(wv[j].z, n.z, fmaf(wv[j].w, n.w, s2[j]))));
+      }
     }
-    s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
-    if (lane == 0) {
-      const float bias = b ? b[e] : 0.f;
-      es[0][e] = s0 + bias; es[1][e] = s1 + bias; es[2][e] = s2 + bias;
+#pragma unroll
+    for (int j = 0; j < TE_EPW; ++j) {
+      const float t0 = wave_sum(s0[j]), t1 = wave_sum(s1[j]), t2 = wave_sum(s2[j]);
+      const int e = e0 + j;
+      if (lane == 0 && e < E) {
+        const float bias = b ? b[e] : 0.f;
+        es[0][e] = t0 + bias; es[1][e] = t1 + bias; es[2][e] = t2 + bias;
+      }
     }
   }
   __syncthreads();
@@ -85,12 +99,19 @@ __global__ __launch_bounds__(256) void triplet_embed_bwd_kernel(const float* __r
   const bool ok = d < D;
   const float ra = ok ? r[d] : 0.f, rp = ok ? r[ldr + d] : 0.f, rn = ok ? r[2 * ldr + d] : 0.f;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-  for (int e = k; e < E; e += 8) {
-    const float g0 = de[0][e], g1 = de[1][e], g2 = de[2][e];
-    if (ok) {
-      const float wv = w[(int64_t)e * ldw + d];
-      s0 = fmaf(g0, wv, s0); s1 = fmaf(g1, wv, s1); s2 = fmaf(g2, wv, s2);
-      dw[(int64_t)e * lddw + d] = fmaf(g0, ra, fmaf(g1, rp, g2 * rn));
+  const int dc = ok ? d : 0;
+  for (int e0 = k; e0 < E; e0 += 64) {                               // eight rows of W per pass, requested together
+    float wv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wv[j] = w[(int64_t)min(e0 + 8 * j, E - 1) * ldw + dc];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int e = e0 + 8 * j;
+      if (ok && e < E) {
+        const float g0 = de[0][e], g1 = de[1][e], g2 = de[2][e];
+        s0 = fmaf(g0, wv[j], s0); s1 = fmaf(g1, wv[j], s1); s2 = fmaf(g2, wv[j], s2);
+        dw[(int64_t)e * lddw + d] = fmaf(g0, ra, fmaf(g1, rp, g2 * rn));
+      }
     }
   }
   part[0][k][j] = s0; part[1][k][j] = s1; part[2][k][j] = s2;

@@ -51,6 +51,7 @@ READOUT_IN_CONTRACT = os.environ.get("TSGNN_READOUT_IN_CONTRACT", "1") != "0"   
 SOFTMAX_IN_CONTRACT = os.environ.get("TSGNN_SOFTMAX_IN_CONTRACT", "1") != "0"   # pooled levels: the assignment softmax inside the contraction's launches
 READOUT_COLUMNS = os.environ.get("TSGNN_READOUT_COLUMNS", "1") != "0"   # DiffPool: the levels' readouts written into one buffer (no cat)
 FUSED_STACK = True             # GcnEncoderGraph: run the conv stack as one fused autograd node when it qualifies
+PER_GRAPH_STACK = os.environ.get("TSGNN_PER_GRAPH_STACK", "1") != "0"   # ... also with per-graph statistics (the triplet step)
 DENSE_ADJ_MAX_NODES = 128      # at or below this many nodes per graph a dense batched MFMA product is used
 
 
@@ -249,10 +250,14 @@ class GcnEncoderGraph(nn.Module):
         """encoders.py:177-205 up to the concatenated max readout."""
         from . import sage_stack
         convs = [self.conv_first] + list(self.conv_block) + [self.conv_last]
-        if self.concat and FUSED_STACK and not self.per_graph_bn and sage_stack.eligible(g, convs, self.bn, x) and \
+        if self.concat and FUSED_STACK and sage_stack.eligible(g, convs, self.bn, x) and \
                 bool(mp.nat.lib().tsgnn_slot_fused_supported(g.B, convs[0].output_dim)) and \
-                bool(mp.nat.lib().tsgnn_slot_fused_supported(g.B, convs[-1].output_dim)):
-            return sage_stack.sage_stack_readouts(x, g, convs)
+                bool(mp.nat.lib().tsgnn_slot_fused_supported(g.B, convs[-1].output_dim)) and \
+                (not self.per_graph_bn or (PER_GRAPH_STACK and g.row_graph is not None and g.n_ghost == g.nmax
+                                           and convs[0].output_dim <= 256)):
+            # (per-graph statistics, the triplet step: the same node with the row-local batch-norm launches, sage_stack.per_graph_stats)
+            with sage_stack.per_graph_stats(self.per_graph_bn):
+                return sage_stack.sage_stack_readouts(x, g, convs)
         # the layers' readouts land in their column blocks of ONE buffer (no torch.cat launch, no slice copies backwards)
         cols = mp.ReadoutColumns(g.B, self.pred_input_dim, x.device) if (self.concat and READOUT_COLUMNS) else None
         x = self._post(self.conv_first.forward_rows(x, g), g)

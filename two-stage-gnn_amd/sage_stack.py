@@ -115,6 +115,29 @@ def _flush_readout(g, B, sn, sg, pending):
         nat.call("readout_partial_f32", g.graph_ptr, B, sn, g.n_rows, sg, y, y.stride(0), y.size(1), pk)
 
 
+# Per-graph statistics (B = 1 semantics: the 2stg triplet step runs anchor / positive / negative as one batch in which every graph
+# keeps the batch-norm statistics it would have alone, tripletnet.py:36-38): the slot batch-norm degenerates to a per-row layer norm,
+# so the two slot launches of a hidden layer are replaced by their row-local counterparts (tsgnn_row_ln_fwd_f32 forward,
+# tsgnn_row_post_bwd_f32 backward) and everything else of the stack — aggregation inside the products, the readout partials riding
+# in the next layer's launch, merged weight-gradient / input-gradient launches, one reduction for all layers — stays.  Selected by
+# the caller around the node's forward (`with per_graph_stats(True):`); the statistics without launches of their own (FUSED_BN)
+# are per slot across graphs and are not used in this mode.
+_PER_GRAPH = [False]
+
+
+class per_graph_stats:
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.prev = _PER_GRAPH[0]
+        _PER_GRAPH[0] = self.on
+
+    def __exit__(self, *exc):
+        _PER_GRAPH[0] = self.prev
+        return False
+
+
 class _SageStack(torch.autograd.Function):
     """forward(x0, g, has_bias, n_head, nodes, *conv params[, w1, b1, w2, b2]).  n_head = 0: returns the concatenated readout
     [B, P].  n_head = 4: the two chained nn.Linear after the readout (encoders.py:207-217) are part of the node: the last
@@ -158,7 +181,10 @@ class _SageStack(torch.autograd.Function):
         keep = []
         last_ro_done = False
         bnf = None
-        if (FUSED_BN and head is not None and not nodes and L >= 2 and g.n_ghost == g.nmax and sn == sg and sn <= 1024
+        per_graph = ctx.per_graph = bool(_PER_GRAPH[0])
+        if per_graph and (nodes or head is not None):
+            raise NotImplementedError("per-graph statistics: the readout form of the stack only")
+        if (FUSED_BN and not per_graph and head is not None and not nodes and L >= 2 and g.n_ghost == g.nmax and sn == sg and sn <= 1024
                 and Fh == 128 and Fl == 128 and Ws[0].size(0) <= 128 and x.size(1) % 4 == 0 and MERGED_FWD and EPILOGUE_READOUT
                 and _gather_ok(g, x) and all(Ws[l].size(0) == 128 and Ws[l].stride(0) % 4 == 0 for l in range(1, L))
                 and all(Ws[l].data_ptr() % 16 == 0 and (bs[l] is None or bs[l].data_ptr() % 16 == 0) for l in range(L))
@@ -261,7 +287,17 @@ class _SageStack(torch.autograd.Function):
                         lean = False
                     nat.call("linear_l2norm_f32", z, z.stride(0), Ws[l], Ws[l].stride(0), bs[l], v, v.stride(0), rinv, R, K, N, 1)
             pk = packed[off:off + B * N] if not nodes else None
-            if l < L - 1:
+            if l < L - 1 and per_graph:
+                mean = torch.empty(R, dtype=torch.float32, device=dev)      # per ROW
+                rstd = torch.empty(R, dtype=torch.float32, device=dev)
+                y = torch.empty_like(v)
+                if l == 0:
+                    packed[:total].zero_()                    # (what the first slot_bn_fwd launch does on its way)
+                nat.call("row_ln_fwd_f32", v, v.stride(0), g.n_rows + sg, N, 1, mean, rstd, y, y.stride(0))
+                pending_ro = (y, pk)
+                keep.append(y)
+                x = y
+            elif l < L - 1:
                 mean = torch.empty(g.nmax, dtype=torch.float32, device=dev)
                 rstd = torch.empty(g.nmax, dtype=torch.float32, device=dev)
                 y = torch.empty_like(v) if not nodes else cat[:, l * Fh:(l + 1) * Fh]
@@ -416,6 +452,11 @@ class _SageStack(torch.autograd.Function):
                 pend_sunk.append(sw and (sb or not ctx.has_bias)); pend_layers.append(0)
                 grads[0], grads[1] = (None if sw else dw), (None if sb else db)
                 continue
+            elif ctx.per_graph:
+                # per-graph statistics: readout winners + row layer norm + ReLU + normalise backward, row by row
+                nat.call("row_post_bwd_f32", g.row_graph, B, g.n_rows, g.n_rows + sg, v, v.stride(0), dxs,
+                         dxs.stride(0) if dxs is not None else 0, dsl, dout.stride(0), argl, N, 0 if last else 1, 0 if last else 1, mean,
+                         rstd, rinv, du, du.stride(0))
             else:
                 nat.call("slot_post_bwd_f32", g.graph_ptr, g.slot_count, B, sn, g.n_rows, sg, v, v.stride(0), dxs,
                          dxs.stride(0) if dxs is not None else 0, dnode, dnode.stride(0) if dnode is not None else 0, dsl,

@@ -127,6 +127,7 @@ class _TripletTail(torch.autograd.Function):
         nat.call("triplet_embed_fwd_f32", r, r.stride(0), w, w.stride(0), b, D, E, _EPS, embed, dist)
         ctx.save_for_backward(r, w, embed, dist)
         ctx.has_bias = b is not None
+        ctx.set_materialize_grads(False)                  # an unused output's gradient arrives as None, not as a zero-filled tensor
         outs = (dist[0:1], dist[1:2], embed[0:1], embed[1:2], embed[2:3])
         return outs
 
