@@ -958,6 +958,13 @@ int tsgnn_triplet_embed_bwd_f32(const float* r, int64_t ldr, const float* w, int
                                 const float* dist, const float* d_dp, const float* d_dn, const float* d_ea, const float* d_ep,
                                 const float* d_en, float* d_r, int64_t lddr, float* dw, int64_t lddw, float* db, tsgnn_stream_t stream);
 
+/* torch.nn.MarginRankingLoss(margin) of the triplet loop (Code/sage+gat+diffpool/train_triplet.py:235,277) in one launch:
+ * loss[0] = mean (mean != 0) or sum over i of max(0, -target[i] (x1[i] - x2[i]) + margin); coef[n] = the gradient coefficients the
+ * backward scales: dx1 = g[0] coef, dx2 = -g[0] coef (either nullable). */
+int tsgnn_margin_rank_fwd_f32(const float* x1, const float* x2, const float* target, int64_t n, float margin, int mean, float* loss,
+                              float* coef, tsgnn_stream_t stream);
+int tsgnn_margin_rank_bwd_f32(const float* g, const float* coef, int64_t n, float* dx1, float* dx2, tsgnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -881,6 +881,25 @@ def test_triplet_tail_kernels(D, E, bias):
             torch.testing.assert_close(a.cpu(), c, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("n,margin,reduction", [(1, 1.0, "mean"), (7, 0.3, "mean"), (300, 0.0, "sum")])
+def test_margin_ranking_loss_drop_in(n, margin, reduction):
+    """triplet.MarginRankingLoss == torch.nn.MarginRankingLoss (train_triplet.py:235,277): value and both input gradients, mixed
+    targets, hinge on and off"""
+    from two_stage_gnn_amd.triplet import MarginRankingLoss
+    gen = torch.Generator().manual_seed(n)
+    x1, x2 = torch.randn(n, generator=gen), torch.randn(n, generator=gen)
+    t = torch.where(torch.rand(n, generator=gen) < 0.5, -torch.ones(n), torch.ones(n)) if n > 1 else torch.tensor([-1.0])
+    a, b = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+    ref = torch.nn.MarginRankingLoss(margin=margin, reduction=reduction)(a, b, t)
+    (ref * 1.7).backward()
+    ag, bg = x1.cuda().requires_grad_(True), x2.cuda().requires_grad_(True)
+    out = MarginRankingLoss(margin=margin, reduction=reduction)(ag, bg, t.cuda())
+    (out * 1.7).backward()
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(ag.grad.cpu(), a.grad, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(bg.grad.cpu(), b.grad, rtol=1e-6, atol=1e-7)
+
+
 class _G:                       # stand-in for the networkx graphs cross_val.split_train_val prepares (cross_val.py:158-184)
     def __init__(self, adj, feats, n):
         self.graph = {"adj": adj, "feats": feats, "num_nodes": n, "assign_feats": feats}

@@ -127,9 +127,55 @@ __global__ __launch_bounds__(256) void triplet_embed_bwd_kernel(const float* __r
     for (int e = tid; e < E; e += 256) db[e] = (de[0][e] + de[1][e]) + de[2][e];
 }
 
+// torch.nn.MarginRankingLoss (train_triplet.py:235,277) on n pairs of distances: loss = reduce(max(0, -t (x1 - x2) + margin)), and
+// the per-element coefficient of its gradient (dx1 = g coef, dx2 = -g coef) kept for the backward.  One workgroup: n is the number
+// of triplets of a step (1 in the reference's loop); torch's composite runs ~9 element-wise launches forward and ~8 backward.
+__global__ __launch_bounds__(256) void margin_rank_fwd_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
+                                                              const float* __restrict__ t, int64_t n, float margin, int mean,
+                                                              float* __restrict__ loss, float* __restrict__ coef) {
+  __shared__ float red[4];
+  const float scale = mean ? 1.0f / (float)n : 1.0f;
+  float s = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += 256) {
+    const float v = fmaf(-t[i], x1[i] - x2[i], margin);
+    const bool on = v > 0.f;
+    s += on ? v : 0.f;
+    coef[i] = on ? -t[i] * scale : 0.f;
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) loss[0] = ((red[0] + red[1]) + (red[2] + red[3])) * scale;
+}
+__global__ __launch_bounds__(256) void margin_rank_bwd_kernel(const float* __restrict__ g, const float* __restrict__ coef, int64_t n,
+                                                              float* __restrict__ dx1, float* __restrict__ dx2) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float v = g[0] * coef[i];
+  if (dx1) dx1[i] = v;
+  if (dx2) dx2[i] = -v;
+}
+
 }  // namespace
 
 extern "C" {
+
+int tsgnn_margin_rank_fwd_f32(const float* x1, const float* x2, const float* target, int64_t n, float margin, int mean, float* loss,
+                              float* coef, hipStream_t stream) {
+  if (!x1 || !x2 || !target || !loss || !coef || n <= 0) return TSGNN_EINVAL;
+  TSGNN_KNAME("margin_rank_fwd_kernel");
+  margin_rank_fwd_kernel<<<1, 256, 0, stream>>>(x1, x2, target, n, margin, mean, loss, coef);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+int tsgnn_margin_rank_bwd_f32(const float* g, const float* coef, int64_t n, float* dx1, float* dx2, hipStream_t stream) {
+  if (!g || !coef || n <= 0) return TSGNN_EINVAL;
+  TSGNN_KNAME("margin_rank_bwd_kernel");
+  margin_rank_bwd_kernel<<<(unsigned)ceil_div64(n, 256), 256, 0, stream>>>(g, coef, n, dx1, dx2);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
 
 int tsgnn_triplet_embed_fwd_f32(const float* r, int64_t ldr, const float* w, int64_t ldw, const float* b, int D, int E, float eps,
                                 float* embed, float* dist, hipStream_t stream) {

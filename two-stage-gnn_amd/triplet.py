@@ -145,6 +145,45 @@ class _TripletTail(torch.autograd.Function):
         return d_r, dw, db
 
 
+class _MarginRank(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x1, x2, target, margin, mean):
+        x1, x2, target = x1.contiguous().view(-1), x2.contiguous().view(-1), target.contiguous().view(-1).float()
+        n = int(x1.numel())
+        loss = torch.empty(1, dtype=torch.float32, device=x1.device)
+        coef = torch.empty(n, dtype=torch.float32, device=x1.device)
+        nat.call("margin_rank_fwd_f32", x1, x2, target, n, float(margin), int(mean), loss, coef)
+        ctx.save_for_backward(coef)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        coef, = ctx.saved_tensors
+        n = int(coef.numel())
+        dx1 = torch.empty(n, dtype=torch.float32, device=coef.device) if ctx.needs_input_grad[0] else None
+        dx2 = torch.empty(n, dtype=torch.float32, device=coef.device) if ctx.needs_input_grad[1] else None
+        nat.call("margin_rank_bwd_f32", g.contiguous().view(-1), coef, n, dx1, dx2)
+        return dx1, dx2, None, None, None
+
+
+class MarginRankingLoss(nn.Module):
+    """torch.nn.MarginRankingLoss (train_triplet.py:235: `criterion = torch.nn.MarginRankingLoss(margin=args.alpha)`) as one launch
+    forward and one backward; same constructor and call.  Inputs that are not float32 CUDA vectors of one shape, or reduction
+    'none', go to torch's implementation."""
+
+    def __init__(self, margin=0.0, size_average=None, reduce=None, reduction="mean"):
+        super().__init__()
+        self.margin, self.reduction = float(margin), reduction
+        self._torch = nn.MarginRankingLoss(margin=margin, size_average=size_average, reduce=reduce, reduction=reduction)
+        self.reduction = self._torch.reduction
+
+    def forward(self, input1, input2, target):
+        if (self.reduction in ("mean", "sum") and input1.is_cuda and input1.dtype == torch.float32 and input2.dtype == torch.float32
+                and input1.shape == input2.shape == target.shape and input1.numel() > 0):
+            return _MarginRank.apply(input1, input2, target, self.margin, self.reduction == "mean")
+        return self._torch(input1, input2, target)
+
+
 def tail_ok(model, r):
     lin = getattr(model, "map_model", None)
     return (FUSED_TAIL and isinstance(lin, nn.Linear) and r is not None and r.is_cuda and r.dim() == 2 and r.size(0) == 3
