@@ -881,6 +881,29 @@ def test_triplet_tail_kernels(D, E, bias):
             torch.testing.assert_close(a.cpu(), c, rtol=1e-4, atol=1e-5)
 
 
+def test_triplet_with_the_gat_encoder_keeps_the_dense_inputs():
+    """tripletnet on a DGATEncoderGraph (tripletnet.py is encoder-agnostic): the GAT encoder packs its batch itself, so the module hands
+    it the dense tensors as the reference does; distances equal those of three separate B = 1 calls of the same module"""
+    from two_stage_gnn_amd import gat_encoders as G
+    from two_stage_gnn_amd.triplet import tripletnet
+    nmax, fin = 20, 8
+    x, adj, sizes = dense_batch(71, 3, nmax, fin, sizes=[20, 9, 14], p_edge=0.25)
+    torch.manual_seed(3)
+    m = G.DGATEncoderGraph(fin, 8, 8, 2, None, num_layers=2, num_heads=[2, 2], final_dim="output_dim", per_graph_features=True).cuda()
+    net = tripletnet(m)
+    gs = [_G(adj[b].numpy(), x[b].numpy(), int(sizes[b])) for b in range(3)]
+    dp, dn, ea, ep, en = net(*gs)
+    assert len(net._resident) == 0                                   # the resident CSR pieces are for the GraphSage / DiffPool family
+    e = [m(x[b:b + 1].cuda(), adj[b:b + 1].cuda(), sizes[b:b + 1])[1] for b in range(3)]
+    torch.testing.assert_close(ea, e[0], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(dp, torch.nn.functional.pairwise_distance(e[0], e[1], 2), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(dn, torch.nn.functional.pairwise_distance(e[0], e[2], 2), rtol=1e-4, atol=1e-5)
+    (dp - dn).sum().backward()
+    got = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    assert any("attention" in k or "conv" in k for k in got) and any(k.startswith("map_model") for k in got)
+    assert all(torch.isfinite(gr).all() for gr in got.values())      # (pred_model is not on this output's path: no gradient)
+
+
 @pytest.mark.parametrize("n,margin,reduction", [(1, 1.0, "mean"), (7, 0.3, "mean"), (300, 0.0, "sum")])
 def test_margin_ranking_loss_drop_in(n, margin, reduction):
     """triplet.MarginRankingLoss == torch.nn.MarginRankingLoss (train_triplet.py:235,277): value and both input gradients, mixed

@@ -191,6 +191,13 @@ def tail_ok(model, r):
             and lin.weight.dtype == torch.float32)
 
 
+def _rows_models():
+    """encoders whose forward takes (packed rows, GraphBatch with ghost-slot rows): the GraphSage / DiffPool family.  Others (the GAT
+    encoder packs its batch itself, with one ghost representative per graph) keep the dense inputs."""
+    from .dense_encoders import GcnEncoderGraph
+    return (GcnEncoderGraph,)
+
+
 class tripletnet(nn.Module):
     def __init__(self, model):
         super().__init__()
@@ -201,7 +208,8 @@ class tripletnet(nn.Module):
         """model forward with the per-graph batch-norm statistics of a B = 1 call -> (dist_p, dist_n, embed_a, embed_p, embed_n)"""
         m = self.model
         prev = getattr(m, "per_graph_bn", False)
-        fuse = FUSED_TAIL and getattr(m, "final_dim", None) in ("output_dim", "pretrain") and isinstance(getattr(m, "map_model", None), nn.Linear)
+        fuse = (FUSED_TAIL and isinstance(m, _rows_models()) and getattr(m, "final_dim", None) in ("output_dim", "pretrain")
+                and isinstance(getattr(m, "map_model", None), nn.Linear))       # (encoders whose _heads honours _defer_map)
         m.per_graph_bn = True
         m._defer_map = fuse
         try:
@@ -226,7 +234,7 @@ class tripletnet(nn.Module):
         prepares them (cross_val.py:158-184)."""
         dev = next(self.model.parameters()).device
         trip = (a, p, n)
-        if RESIDENT and dev.type == "cuda":
+        if RESIDENT and dev.type == "cuda" and isinstance(self.model, _rows_models()):
             g, x, xa, sizes = _assemble([_resident(t, dev, self._resident) for t in trip], dev, self._resident)
             return self._embed(x, g, sizes, x if xa is None else xa)
         adj = self._stack(trip, "adj", dev)
