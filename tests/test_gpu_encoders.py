@@ -791,8 +791,9 @@ def test_diffpool_linkpred_encoder_vs_oracle():
 
 
 # ----------------------------------------------------------------------------- triplet step (tripletnet.py)
-@pytest.mark.parametrize("hidden,nmax,sizes", [(128, 40, [40, 17, 29]), (128, 64, [33, 64, 5]), (64, 48, [20, 31, 9])])
-def test_triplet_fused_stack_with_per_graph_statistics(hidden, nmax, sizes):
+@pytest.mark.parametrize("hidden,nmax,sizes,final", [(128, 40, [40, 17, 29], "output_dim"), (128, 64, [33, 64, 5], "pretrain"),
+                                                     (64, 48, [20, 31, 9], "output_dim")])
+def test_triplet_fused_stack_with_per_graph_statistics(hidden, nmax, sizes, final):
     """the triplet step on the fused conv stack (sage_stack.per_graph_stats: the slot batch-norm launches replaced by their
     row-local counterparts, tsgnn_row_ln_fwd_f32 / tsgnn_row_post_bwd_f32) against the oracle's three B = 1 forwards — embeddings,
     distances and every parameter gradient — and against the per-op path (TSGNN_PER_GRAPH_STACK=0); graphs that fill all Nmax
@@ -805,14 +806,14 @@ def test_triplet_fused_stack_with_per_graph_statistics(hidden, nmax, sizes):
     class A:
         bias = True
     torch.manual_seed(6)
-    m = E.GcnEncoderGraph(fin, hidden, hidden, 2, 3, bn=True, args=A(), final_dim="output_dim")
+    m = E.GcnEncoderGraph(fin, hidden, hidden, 2, 3, bn=True, args=A(), final_dim=final)      # "pretrain" = 2stg+ (embedding second too)
     with torch.no_grad():
         for k, p in m.named_parameters():
             if "conv" in k and k.endswith("bias"):
                 p.copy_(torch.randn_like(p) * 0.3)           # padded rows then carry values that can win the max readout
     m = m.cuda()
     p_ref = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
-    embeds = [R.gcn_encoder(p_ref, x[b:b + 1], adj[b:b + 1], bn=True, final_dim="output_dim")[1] for b in range(3)]
+    embeds = [R.gcn_encoder(p_ref, x[b:b + 1], adj[b:b + 1], bn=True, final_dim=final)[1] for b in range(3)]
     dp_ref = torch.nn.functional.pairwise_distance(embeds[0], embeds[1], 2)
     dn_ref = torch.nn.functional.pairwise_distance(embeds[0], embeds[2], 2)
     (torch.nn.MarginRankingLoss(margin=10.0)(dp_ref, dn_ref, torch.tensor([-1.0])) + 0.05 * embeds[1].norm(2)).backward()
