@@ -946,6 +946,14 @@ int tsgnn_sage_multi_f32(const int64_t* desc, tsgnn_stream_t stream);
  * 355-356) without a launch of its own.  Needs fill_rows > 0, n % 4 == 0, 16-byte aligned regions; TSGNN_EUNSUPPORTED otherwise. */
 int tsgnn_sage_multi_zero_f32(const int64_t* desc, float* zero0, int64_t n0, float* zero1, int64_t n1, tsgnn_stream_t stream);
 
+/* ---- backward of a GAT layer's packed projection hp = x W' (csrc/gat_products.hip; encoders_GAT.py:29-36): the slab partials of
+ * dW'[K_in, N] = x[:, :K_in]^T du into ws (plan: tsgnn_wgrad_blocks_plan(rows, K_in, N, ldx, lddu); reduce:
+ * tsgnn_wgrad_blocks_reduce_f32) and dx[rows, K_in] = du[rows, N] . wp[K_in, N]^T in ONE launch — the same blocks as
+ * tsgnn_wgrad_blocks_f32's slab launch + tsgnn_rowgemm_f32(trans_b = 1), same bits.  128 < K_in <= 512, N <= 512, N % 4 == 0. */
+int tsgnn_gat_bwd_products_f32(const float* x, int64_t ldx, const float* du, int64_t lddu, int64_t rows, int K_in, int N, const float* wp,
+                               int64_t ldwp, float* dx, int64_t lddx, int nslab, int64_t rows_per_slab, float* ws, tsgnn_stream_t stream);
+int tsgnn_wgrad_blocks_reduce_f32(const float* ws, int nslab, int K_in, int N, float* dw, int64_t lddw, tsgnn_stream_t stream);
+
 /* ---- tail of the 2stg triplet step (csrc/triplet.hip; Code/sage+gat+diffpool/tripletnet.py:35-45): the three graphs' embeddings
  * embed[b] = W r[b] + bias (encoders.py:217 `map_model`, nn.Linear's [E, D] layout; r[3, D] = the concatenated readouts of anchor,
  * positive, negative) and dist = (||e_a - e_p + eps||_2, ||e_a - e_n + eps||_2) (F.pairwise_distance) in one launch; the backward

@@ -50,6 +50,24 @@ def test_wgrad_blocks(R_, K, N):
     assert torch.equal(dw, gf.wgrad_blocks(z, K, du))
 
 
+@pytest.mark.parametrize("R_,K,N", [(8518, 256, 264), (1000, 192, 132), (37, 256, 264)])
+def test_bwd_products_merged_equals_separate(R_, K, N):
+    """the weight-gradient slabs and the input-gradient product of a layer's packed projection in one launch
+    (tsgnn_gat_bwd_products_f32) == the two launches they replace, bit for bit, and the torch products"""
+    from two_stage_gnn_amd import gat_fused as gf, _native as nat
+    gen = torch.Generator(device="cuda").manual_seed(R_ + K)
+    x = torch.randn(R_, K, generator=gen, device="cuda")
+    du = torch.randn(R_, N, generator=gen, device="cuda")
+    wp = torch.randn(K, N, generator=gen, device="cuda") * 0.1
+    dw, dx = gf.bwd_products(x, K, du, wp)
+    dw_s = gf.wgrad_blocks(x, K, du)
+    dx_s = torch.empty(R_, K, device="cuda")
+    nat.call("rowgemm_f32", du, du.stride(0), wp, wp.stride(0), 1, None, dx_s, dx_s.stride(0), None, R_, N, K, 0, 0)
+    assert torch.equal(dw, dw_s) and torch.equal(dx, dx_s)
+    torch.testing.assert_close(dw.double(), x.double().t() @ du.double(), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(dx.double(), du.double() @ wp.double().t(), rtol=1e-4, atol=1e-4)
+
+
 @pytest.mark.parametrize("R_,K,N,bias", [(1024, 192, 64, True), (128, 136, 8, True), (5000, 64, 128, False), (77, 300, 260, True)])
 def test_wgrad_blocks_linear_layout(R_, K, N, bias):
     """the same product written as torch.nn.Linear's [out, in] gradient with db = colsum(du) from the same pass
@@ -136,7 +154,10 @@ def test_fused_path_is_the_one_that_runs():
     assert names.count("gat_pack_f32") == 1 and names.count("gat_unpack_f32") == 1
     assert names.count("gat_attn_fwd_f32") == 2 and names.count("gat_attn_bwd_ro_f32") == 2
     assert names.count("readout_max_fwd_f32") == 1 and names.count("readout_max_bwd_rows_f32") == 0    # (the last layer's node made the readout)
-    assert names.count("wgrad_blocks_f32") == 2
+    # layer 2 (256 -> 264): weight-gradient slabs beside the input-gradient product in one launch + the slabs' reduction; layer 1
+    # (92 -> 264; the input features need no gradient): the blocked weight gradient alone
+    assert names.count("gat_bwd_products_f32") == 1 and names.count("wgrad_blocks_reduce_f32") == 1
+    assert names.count("wgrad_blocks_f32") == 1
     assert not any(n in names for n in ("edge_softmax_fwd_f32", "csr_sddmm_heads_f32", "node_scores2_f32"))
 
 

@@ -19,6 +19,7 @@
 #include "../../include/tsgnn.h"
 
 #include "tn_rows_body.h"
+#include "wgrad_blocks_body.h"
 #include "du_reduce_body.h"
 
 namespace {
@@ -346,32 +347,10 @@ __global__ __launch_bounds__(256) void tn_rows_reduce_multi(ReduceMulti m) {
 // ---- blocked weight gradient: dW[K_in, N] for K_in, N up to 512 as 128 x 128 output blocks ("sets"), all of them and all of
 // their row slabs in ONE launch of the slab body (tn_rows_body.h), then ONE fixed-order reduction.  The GAT projections have
 // 92 x 264 and 256 x 264 outputs; one set at a time was a launch per set.
-constexpr int WB_MAXSETS = 16;
-constexpr int64_t WB_SET_FLOATS = 129 * 128;            // per slab: [kc + 1][nc] <= 129 x 128
-struct WgradBlocks {
-  TnArgs g;                                             // z, du, rows, rows_per_slab; K_in / N hold the TOTAL widths
-  int NB, nsets;                                        // column blocks; sets = row blocks x column blocks
-  int64_t set_stride;                                   // floats between the slab arrays of two sets
-};
 template <int NY>
 __global__ __launch_bounds__(256) void wgrad_blocks_kernel(WgradBlocks w) {
   extern __shared__ __attribute__((aligned(16))) float tn_smem[];
-  const int set = (int)blockIdx.y / NY, by = (int)blockIdx.y % NY;
-  const int kb = set / w.NB, nb = set % w.NB;
-  TnArgs g = w.g;
-  g.z += 128 * kb;
-  g.du += 128 * nb;
-  g.K_in = min(128, w.g.K_in - 128 * kb);
-  g.N = min(128, w.g.N - 128 * nb);
-  g.slabs = w.g.slabs + (int64_t)set * w.set_stride;
-  // (row tiles of 32: a 92-row block — the GAT input projection — runs three of them, not four)
-  if (g.N <= 32) {                                                                   // a narrow last column block (the 2H score columns)
-    if (g.K_in <= 96) tn_rows_body<3, 1, NY>(g, tn_smem, blockIdx.x, by, gridDim.x);
-    else tn_rows_body<4, 1, NY>(g, tn_smem, blockIdx.x, by, gridDim.x);
-  } else {
-    if (g.K_in <= 96) tn_rows_body<3, 4, NY>(g, tn_smem, blockIdx.x, by, gridDim.x);
-    else tn_rows_body<4, 4, NY>(g, tn_smem, blockIdx.x, by, gridDim.x);
-  }
+  wgrad_blocks_role<NY>(w, tn_smem, blockIdx.x, blockIdx.y, gridDim.x);
 }
 struct WgradBlocksReduce {
   const float* slabs; int nslab; int64_t set_stride;
@@ -709,6 +688,8 @@ int tsgnn_wgrad_blocks_plan(int64_t rows, int K_in, int N, int64_t ldz, int64_t 
   return TSGNN_OK;
 }
 
+static int wgrad_blocks_reduce_launch(const float* ws, int nslab, int K_in, int N, float* dw, int64_t lddw, int oi, float* db,
+                                      tsgnn_stream_t stream);
 static int wgrad_blocks_launch(const float* z, int64_t ldz, const float* du, int64_t lddu, int64_t rows, int K_in, int N, int nslab,
                                int64_t rows_per_slab, float* ws, float* dw, int64_t lddw, int oi, float* db, tsgnn_stream_t stream) {
   if (!z || !du || !ws || !dw || rows < 0 || nslab <= 0 || rows_per_slab <= 0 || K_in <= 0 || N <= 0 || lddw < (oi ? K_in : N)) return TSGNN_EINVAL;
@@ -726,7 +707,13 @@ static int wgrad_blocks_launch(const float* z, int64_t ldz, const float* du, int
   }
   TSGNN_KNAME("wgrad_blocks_kernel<2>");
   wgrad_blocks_kernel<2><<<dim3((unsigned)nslab, (unsigned)(2 * nsets)), 256, lds, stream>>>(w);
-  WgradBlocksReduce r{ws, nslab, w.set_stride, K_in, N, NB, nsets, dw, lddw, oi, db, {0}};
+  return wgrad_blocks_reduce_launch(ws, nslab, K_in, N, dw, lddw, oi, db, stream);
+}
+
+static int wgrad_blocks_reduce_launch(const float* ws, int nslab, int K_in, int N, float* dw, int64_t lddw, int oi, float* db,
+                                      tsgnn_stream_t stream) {
+  const int KB = (K_in + 127) / 128, NB = (N + 127) / 128, nsets = KB * NB;
+  WgradBlocksReduce r{ws, nslab, (int64_t)nslab * WB_SET_FLOATS, K_in, N, NB, nsets, dw, lddw, oi, db, {0}};
   int blocks = 0;
   for (int t = 0; t < nsets; ++t) {
     r.first_block[t] = blocks;
@@ -737,6 +724,13 @@ static int wgrad_blocks_launch(const float* z, int64_t ldz, const float* du, int
   wgrad_blocks_reduce<<<(unsigned)blocks, 256, 0, stream>>>(r);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
+}
+
+/* the fixed-order reduction of slabs a blocked weight-gradient launch left in ws (tsgnn_gat_bwd_products_f32) */
+int tsgnn_wgrad_blocks_reduce_f32(const float* ws, int nslab, int K_in, int N, float* dw, int64_t lddw, tsgnn_stream_t stream) {
+  if (!ws || !dw || nslab <= 0 || K_in <= 0 || N <= 0 || K_in > 512 || N > 512 || lddw < N) return TSGNN_EINVAL;
+  if (((K_in + 127) / 128) * ((N + 127) / 128) > WB_MAXSETS) return TSGNN_EINVAL;
+  return wgrad_blocks_reduce_launch(ws, nslab, K_in, N, dw, lddw, 0, nullptr, stream);
 }
 
 int tsgnn_wgrad_blocks_f32(const float* z, int64_t ldz, const float* du, int64_t lddu, int64_t rows, int K_in, int N, int nslab,

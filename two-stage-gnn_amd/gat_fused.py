@@ -130,6 +130,33 @@ def wgrad_blocks(z, K_in, du):
     return dw
 
 
+MERGED_BWD_PRODUCTS = os.environ.get("TSGNN_GAT_MERGED_BWD", "1") != "0"   # a layer's weight-gradient slabs beside its input-gradient product
+
+
+def bwd_products(x, K_in, du, wp):
+    """(dW'[K_in, N], dx[R, x.size(1)]) of hp = x W' from du = dhp: the slab launch of wgrad_blocks and the product du W'^T as ONE
+    launch (tsgnn_gat_bwd_products_f32) + the slabs' reduction; None when the shape is not taken (K_in <= 128, ...)"""
+    R, N = int(du.size(0)), int(du.size(1))
+    if not (128 < K_in <= 512 and N <= 512 and N % 4 == 0 and x.size(1) == K_in and x.stride(0) % 4 == 0 and du.stride(0) % 4 == 0
+            and wp.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and du.data_ptr() % 16 == 0 and wp.data_ptr() % 16 == 0 and R > 0):
+        return None
+    nslab = np.zeros(1, dtype=np.int32)
+    rps = np.zeros(1, dtype=np.int64)
+    need = np.zeros(1, dtype=np.int64)
+    nat.call_nostream("wgrad_blocks_plan", R, int(K_in), N, int(x.stride(0)), int(du.stride(0)), nslab.ctypes.data, rps.ctypes.data,
+                      need.ctypes.data)
+    if int(nslab[0]) <= 0:
+        return None
+    ws = _f32(int(need[0]), device=du.device)
+    dw = _f32(int(K_in), N, device=du.device)
+    dx = _f32(R, int(K_in), device=du.device)
+    if not nat.try_call("gat_bwd_products_f32", x, x.stride(0), du, du.stride(0), R, int(K_in), N, wp, wp.stride(0), dx, dx.stride(0),
+                        int(nslab[0]), int(rps[0]), ws):
+        return None
+    nat.call("wgrad_blocks_reduce_f32", ws, int(nslab[0]), int(K_in), N, dw, dw.stride(0))
+    return dw, dx
+
+
 class _GatLayer(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, wp, g, H, Fo, slope, mean_heads, apply_elu, drop_p, seed, ctr, readout=False):
@@ -189,6 +216,10 @@ class _GatLayer(torch.autograd.Function):
         fin = lst is not None and drop_p == 0.0                 # (with dropout the backward completes the listed columns itself)
         nat.call("gat_score_rowsum_f32", g.rowptr, g.col, att._inverse_entry_map(g, src_e_t), t1, t2, S, R, H, dhp, dhp.stride(0), C,
                  dupart if fin else None, int(g.B), i_idx if fin else None, i_w if fin else None, i_ptr if fin else None, us)
+        if ctx.needs_input_grad[0] and MERGED_BWD_PRODUCTS:
+            both = bwd_products(x, Fin, dhp, wp)                 # dW' slabs and dx = dhp W'^T side by side in one launch
+            if both is not None:
+                return both[1], both[0], None, None, None, None, None, None, None, None, None, None
         dwp = wgrad_blocks(x, Fin, dhp)
         if dwp is None:
             dwp = mp.gemm_tn_splitk(x, Fin, dhp)
