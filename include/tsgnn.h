@@ -953,6 +953,12 @@ int tsgnn_sage_multi_zero_f32(const int64_t* desc, float* zero0, int64_t n0, flo
 int tsgnn_gat_bwd_products_f32(const float* x, int64_t ldx, const float* du, int64_t lddu, int64_t rows, int K_in, int N, const float* wp,
                                int64_t ldwp, float* dx, int64_t lddx, int nslab, int64_t rows_per_slab, float* ws, tsgnn_stream_t stream);
 int tsgnn_wgrad_blocks_reduce_f32(const float* ws, int nslab, int K_in, int N, float* dw, int64_t lddw, tsgnn_stream_t stream);
+/* two such reductions in one launch (both layers of a GAT encoder's backward); the slab-only form of the blocked weight gradient:
+ * tsgnn_wgrad_blocks_slabs_f32 = tsgnn_wgrad_blocks_f32 without its reduction. */
+int tsgnn_wgrad_blocks_reduce2_f32(const float* ws0, int nslab0, int K0, int N0, float* dw0, int64_t lddw0, const float* ws1, int nslab1,
+                                   int K1, int N1, float* dw1, int64_t lddw1, tsgnn_stream_t stream);
+int tsgnn_wgrad_blocks_slabs_f32(const float* z, int64_t ldz, const float* du, int64_t lddu, int64_t rows, int K_in, int N, int nslab,
+                                 int64_t rows_per_slab, float* ws, tsgnn_stream_t stream);
 
 /* ---- tail of the 2stg triplet step (csrc/triplet.hip; Code/sage+gat+diffpool/tripletnet.py:35-45): the three graphs' embeddings
  * embed[b] = W r[b] + bias (encoders.py:217 `map_model`, nn.Linear's [E, D] layout; r[3, D] = the concatenated readouts of anchor,

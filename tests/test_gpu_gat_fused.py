@@ -155,9 +155,11 @@ def test_fused_path_is_the_one_that_runs():
     assert names.count("gat_attn_fwd_f32") == 2 and names.count("gat_attn_bwd_ro_f32") == 2
     assert names.count("readout_max_fwd_f32") == 1 and names.count("readout_max_bwd_rows_f32") == 0    # (the last layer's node made the readout)
     # layer 2 (256 -> 264): weight-gradient slabs beside the input-gradient product in one launch + the slabs' reduction; layer 1
-    # (92 -> 264; the input features need no gradient): the blocked weight gradient alone
-    assert names.count("gat_bwd_products_f32") == 1 and names.count("wgrad_blocks_reduce_f32") == 1
-    assert names.count("wgrad_blocks_f32") == 1
+    # (92 -> 264)
+    # (the input features need no gradient): the blocked weight gradient's slabs alone; ONE reduction launch for both layers, issued
+    # by the parameter unpack
+    assert names.count("gat_bwd_products_f32") == 1 and names.count("wgrad_blocks_slabs_f32") == 1
+    assert names.count("wgrad_blocks_reduce2_f32") == 1 and names.index("wgrad_blocks_reduce2_f32") == names.index("gat_unpack_f32") - 1
     assert not any(n in names for n in ("edge_softmax_fwd_f32", "csr_sddmm_heads_f32", "node_scores2_f32"))
 
 

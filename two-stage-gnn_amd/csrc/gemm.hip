@@ -359,17 +359,17 @@ struct WgradBlocksReduce {
   int oi; float* db;                                    // oi: dw is [N][K_in] (torch.nn.Linear's layout); db [N] nullable (oi form)
   int first_block[WB_MAXSETS + 1];
 };
-__global__ __launch_bounds__(256) void wgrad_blocks_reduce(WgradBlocksReduce r) {
+__device__ __forceinline__ void wgrad_blocks_reduce_body(const WgradBlocksReduce& r, const int bx) {
   __shared__ float lds[4][64];
   int set = 0;
 #pragma unroll
-  for (int t = 1; t < WB_MAXSETS; ++t) if (t < r.nsets && (int)blockIdx.x >= r.first_block[t]) set = t;
+  for (int t = 1; t < WB_MAXSETS; ++t) if (t < r.nsets && bx >= r.first_block[t]) set = t;
   const int kb = set / r.NB, nb = set % r.NB;
   const int kc = min(128, r.K_in - 128 * kb), nc = min(128, r.N - 128 * nb);
   const int64_t per_slab = (int64_t)(kc + 1) * nc;
   const float* slabs = r.slabs + (int64_t)set * r.set_stride;
   const int e_l = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int64_t e = ((int64_t)blockIdx.x - r.first_block[set]) * 64 + e_l;
+  const int64_t e = ((int64_t)bx - r.first_block[set]) * 64 + e_l;
   const bool ok = e < ((r.db && kb == 0) ? per_slab : (int64_t)kc * nc);   // (the slabs' last row is colsum(du) of the column block)
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   if (ok) {                                             // the arithmetic (and order) of tn_rows_reduce
@@ -393,6 +393,12 @@ __global__ __launch_bounds__(256) void wgrad_blocks_reduce(WgradBlocksReduce r) 
     else if (r.oi) r.dw[(int64_t)(128 * nb + n) * r.lddw + 128 * kb + k] = v;
     else r.dw[(int64_t)(128 * kb + k) * r.lddw + 128 * nb + n] = v;
   }
+}
+__global__ __launch_bounds__(256) void wgrad_blocks_reduce(WgradBlocksReduce r) { wgrad_blocks_reduce_body(r, (int)blockIdx.x); }
+// the reductions of TWO blocked weight gradients (the two layers of a GAT encoder) in one launch: blocks [0, n0) work on r0
+__global__ __launch_bounds__(256) void wgrad_blocks_reduce2(WgradBlocksReduce r0, WgradBlocksReduce r1, int n0) {
+  if ((int)blockIdx.x < n0) wgrad_blocks_reduce_body(r0, (int)blockIdx.x);
+  else wgrad_blocks_reduce_body(r1, (int)blockIdx.x - n0);
 }
 
 }  // namespace
@@ -692,7 +698,7 @@ static int wgrad_blocks_reduce_launch(const float* ws, int nslab, int K_in, int 
                                       tsgnn_stream_t stream);
 static int wgrad_blocks_launch(const float* z, int64_t ldz, const float* du, int64_t lddu, int64_t rows, int K_in, int N, int nslab,
                                int64_t rows_per_slab, float* ws, float* dw, int64_t lddw, int oi, float* db, tsgnn_stream_t stream) {
-  if (!z || !du || !ws || !dw || rows < 0 || nslab <= 0 || rows_per_slab <= 0 || K_in <= 0 || N <= 0 || lddw < (oi ? K_in : N)) return TSGNN_EINVAL;
+  if (!z || !du || !ws || rows < 0 || nslab <= 0 || rows_per_slab <= 0 || K_in <= 0 || N <= 0 || (dw && lddw < (oi ? K_in : N))) return TSGNN_EINVAL;
   if (K_in > 512 || N > 512 || (ldz % 4) || (lddu % 4) || (N % 4) || ldz < ((K_in + 3) / 4) * 4 || lddu < N ||
       ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(du)) & 15))
     return TSGNN_EUNSUPPORTED;
@@ -707,11 +713,15 @@ static int wgrad_blocks_launch(const float* z, int64_t ldz, const float* du, int
   }
   TSGNN_KNAME("wgrad_blocks_kernel<2>");
   wgrad_blocks_kernel<2><<<dim3((unsigned)nslab, (unsigned)(2 * nsets)), 256, lds, stream>>>(w);
+  if (!dw) {                                              // slabs only: the caller reduces them later (tsgnn_wgrad_blocks_reduce[2]_f32)
+    TSGNN_CHECK_LAUNCH();
+    return TSGNN_OK;
+  }
   return wgrad_blocks_reduce_launch(ws, nslab, K_in, N, dw, lddw, oi, db, stream);
 }
 
-static int wgrad_blocks_reduce_launch(const float* ws, int nslab, int K_in, int N, float* dw, int64_t lddw, int oi, float* db,
-                                      tsgnn_stream_t stream) {
+static WgradBlocksReduce wgrad_blocks_reduce_args(const float* ws, int nslab, int K_in, int N, float* dw, int64_t lddw, int oi, float* db,
+                                                  int* nblocks) {
   const int KB = (K_in + 127) / 128, NB = (N + 127) / 128, nsets = KB * NB;
   WgradBlocksReduce r{ws, nslab, (int64_t)nslab * WB_SET_FLOATS, K_in, N, NB, nsets, dw, lddw, oi, db, {0}};
   int blocks = 0;
@@ -721,6 +731,13 @@ static int wgrad_blocks_reduce_launch(const float* ws, int nslab, int K_in, int 
     blocks += (((db && t / NB == 0) ? kc + 1 : kc) * nc + 63) / 64;
   }
   for (int t = nsets; t <= WB_MAXSETS; ++t) r.first_block[t] = blocks;
+  *nblocks = blocks;
+  return r;
+}
+static int wgrad_blocks_reduce_launch(const float* ws, int nslab, int K_in, int N, float* dw, int64_t lddw, int oi, float* db,
+                                      tsgnn_stream_t stream) {
+  int blocks = 0;
+  const WgradBlocksReduce r = wgrad_blocks_reduce_args(ws, nslab, K_in, N, dw, lddw, oi, db, &blocks);
   wgrad_blocks_reduce<<<(unsigned)blocks, 256, 0, stream>>>(r);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
@@ -731,6 +748,27 @@ int tsgnn_wgrad_blocks_reduce_f32(const float* ws, int nslab, int K_in, int N, f
   if (!ws || !dw || nslab <= 0 || K_in <= 0 || N <= 0 || K_in > 512 || N > 512 || lddw < N) return TSGNN_EINVAL;
   if (((K_in + 127) / 128) * ((N + 127) / 128) > WB_MAXSETS) return TSGNN_EINVAL;
   return wgrad_blocks_reduce_launch(ws, nslab, K_in, N, dw, lddw, 0, nullptr, stream);
+}
+
+/* two such reductions in one launch (the two layers of a GAT encoder's backward) */
+int tsgnn_wgrad_blocks_reduce2_f32(const float* ws0, int nslab0, int K0, int N0, float* dw0, int64_t lddw0, const float* ws1, int nslab1,
+                                   int K1, int N1, float* dw1, int64_t lddw1, tsgnn_stream_t stream) {
+  if (!ws0 || !dw0 || !ws1 || !dw1 || nslab0 <= 0 || nslab1 <= 0 || K0 <= 0 || N0 <= 0 || K1 <= 0 || N1 <= 0 || K0 > 512 || N0 > 512 ||
+      K1 > 512 || N1 > 512 || lddw0 < N0 || lddw1 < N1)
+    return TSGNN_EINVAL;
+  if (((K0 + 127) / 128) * ((N0 + 127) / 128) > WB_MAXSETS || ((K1 + 127) / 128) * ((N1 + 127) / 128) > WB_MAXSETS) return TSGNN_EINVAL;
+  int n0 = 0, n1 = 0;
+  const WgradBlocksReduce r0 = wgrad_blocks_reduce_args(ws0, nslab0, K0, N0, dw0, lddw0, 0, nullptr, &n0);
+  const WgradBlocksReduce r1 = wgrad_blocks_reduce_args(ws1, nslab1, K1, N1, dw1, lddw1, 0, nullptr, &n1);
+  TSGNN_KNAME("wgrad_blocks_reduce2");
+  wgrad_blocks_reduce2<<<(unsigned)(n0 + n1), 256, 0, stream>>>(r0, r1, n0);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+int tsgnn_wgrad_blocks_slabs_f32(const float* z, int64_t ldz, const float* du, int64_t lddu, int64_t rows, int K_in, int N, int nslab,
+                                 int64_t rows_per_slab, float* ws, tsgnn_stream_t stream) {
+  return wgrad_blocks_launch(z, ldz, du, lddu, rows, K_in, N, nslab, rows_per_slab, ws, nullptr, 0, 0, nullptr, stream);
 }
 
 int tsgnn_wgrad_blocks_f32(const float* z, int64_t ldz, const float* du, int64_t lddu, int64_t rows, int K_in, int N, int nslab,

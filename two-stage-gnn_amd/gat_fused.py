@@ -90,6 +90,7 @@ class _PackLayers(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *dwps):
+        flush_reductions()                                       # the layers' dW' still sit in their slabs: ONE reduction launch for two
         layers = ctx.layers
         dev = layers[0][4][0].device
         ptrs, res = [], []
@@ -111,11 +112,38 @@ def pack_layers(layers_heads):
     params = []
     for heads in layers_heads:
         params += [hd.w for hd in heads] + [hd.a for hd in heads]
-    return _PackLayers.apply(tuple(len(h) for h in layers_heads), *params)
+    outs = _PackLayers.apply(tuple(len(h) for h in layers_heads), *params)
+    for o in outs:
+        o._tsgnn_packed = True          # its gradient goes to _PackLayers.backward, which reduces the pending slabs first
+    return outs
 
 
-def wgrad_blocks(z, K_in, du):
-    """dW[K_in, N] = z[:, :K_in]^T du (N = du.size(1) <= 512) in two launches; None if the shape is not taken"""
+# A layer's dW' is read only when the parameters are unpacked at the end of the backward pass: the layers leave their slabs pending
+# and _PackLayers.backward reduces them two products per launch (a GAT encoder has two layers: one reduction launch instead of two).
+DEFER_REDUCE = os.environ.get("TSGNN_GAT_DEFER_REDUCE", "1") != "0"
+_pending_reduce = []        # (ws, nslab, K_in, N, dw)
+
+
+def flush_reductions():
+    while _pending_reduce:
+        a = _pending_reduce.pop(0)
+        if _pending_reduce:
+            b = _pending_reduce.pop(0)
+            nat.call("wgrad_blocks_reduce2_f32", a[0], a[1], a[2], a[3], a[4], a[4].stride(0), b[0], b[1], b[2], b[3], b[4], b[4].stride(0))
+        else:
+            nat.call("wgrad_blocks_reduce_f32", a[0], a[1], a[2], a[3], a[4], a[4].stride(0))
+
+
+def _reduce(ws, nslab, K_in, N, dw, defer):
+    if defer and DEFER_REDUCE:
+        _pending_reduce.append((ws, nslab, K_in, N, dw))
+    else:
+        nat.call("wgrad_blocks_reduce_f32", ws, nslab, K_in, N, dw, dw.stride(0))
+
+
+def wgrad_blocks(z, K_in, du, defer=False):
+    """dW[K_in, N] = z[:, :K_in]^T du (N = du.size(1) <= 512) in two launches; None if the shape is not taken.  defer: only the slab
+    launch now, the reduction with the next flush_reductions() (the returned tensor is filled then)"""
     R, N = int(du.size(0)), int(du.size(1))
     nslab = np.zeros(1, dtype=np.int32)
     rps = np.zeros(1, dtype=np.int64)
@@ -126,6 +154,10 @@ def wgrad_blocks(z, K_in, du):
         return None
     ws = _f32(int(need[0]), device=du.device)
     dw = _f32(int(K_in), N, device=du.device)
+    if defer and DEFER_REDUCE:
+        nat.call("wgrad_blocks_slabs_f32", z, z.stride(0), du, du.stride(0), R, int(K_in), N, int(nslab[0]), int(rps[0]), ws)
+        _reduce(ws, int(nslab[0]), int(K_in), N, dw, True)
+        return dw
     nat.call("wgrad_blocks_f32", z, z.stride(0), du, du.stride(0), R, int(K_in), N, int(nslab[0]), int(rps[0]), ws, dw, dw.stride(0))
     return dw
 
@@ -133,7 +165,7 @@ def wgrad_blocks(z, K_in, du):
 MERGED_BWD_PRODUCTS = os.environ.get("TSGNN_GAT_MERGED_BWD", "1") != "0"   # a layer's weight-gradient slabs beside its input-gradient product
 
 
-def bwd_products(x, K_in, du, wp):
+def bwd_products(x, K_in, du, wp, defer=False):
     """(dW'[K_in, N], dx[R, x.size(1)]) of hp = x W' from du = dhp: the slab launch of wgrad_blocks and the product du W'^T as ONE
     launch (tsgnn_gat_bwd_products_f32) + the slabs' reduction; None when the shape is not taken (K_in <= 128, ...)"""
     R, N = int(du.size(0)), int(du.size(1))
@@ -153,7 +185,7 @@ def bwd_products(x, K_in, du, wp):
     if not nat.try_call("gat_bwd_products_f32", x, x.stride(0), du, du.stride(0), R, int(K_in), N, wp, wp.stride(0), dx, dx.stride(0),
                         int(nslab[0]), int(rps[0]), ws):
         return None
-    nat.call("wgrad_blocks_reduce_f32", ws, int(nslab[0]), int(K_in), N, dw, dw.stride(0))
+    _reduce(ws, int(nslab[0]), int(K_in), N, dw, defer)
     return dw, dx
 
 
@@ -177,6 +209,7 @@ class _GatLayer(torch.autograd.Function):
                  int(g.nmax), i_idx, i_w, i_ptr, 1.0 / max(int(g.nmax), 1), int(mean_heads), int(apply_elu), float(drop_p),
                  int(seed), ctr, stat, y, y.stride(0))
         ctx.cfg = (g, H, Fo, slope, mean_heads, apply_elu, drop_p, seed, Fin)
+        ctx.packed = bool(getattr(wp, "_tsgnn_packed", False))   # wp came from pack_layers: its gradient's consumer reduces pending slabs
         ctx.ctr = ctr
         ctx.lst = lst
         ctx.readout = bool(readout)
@@ -217,10 +250,10 @@ class _GatLayer(torch.autograd.Function):
         nat.call("gat_score_rowsum_f32", g.rowptr, g.col, att._inverse_entry_map(g, src_e_t), t1, t2, S, R, H, dhp, dhp.stride(0), C,
                  dupart if fin else None, int(g.B), i_idx if fin else None, i_w if fin else None, i_ptr if fin else None, us)
         if ctx.needs_input_grad[0] and MERGED_BWD_PRODUCTS:
-            both = bwd_products(x, Fin, dhp, wp)                 # dW' slabs and dx = dhp W'^T side by side in one launch
+            both = bwd_products(x, Fin, dhp, wp, defer=ctx.packed)    # dW' slabs and dx = dhp W'^T side by side in one launch
             if both is not None:
                 return both[1], both[0], None, None, None, None, None, None, None, None, None, None
-        dwp = wgrad_blocks(x, Fin, dhp)
+        dwp = wgrad_blocks(x, Fin, dhp, defer=ctx.packed)
         if dwp is None:
             dwp = mp.gemm_tn_splitk(x, Fin, dhp)
         dx = None
