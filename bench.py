@@ -52,11 +52,11 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--steps-per-graph", type=int, default=4,
                     help="N = 1: consecutive optimiser steps captured into one hipGraph launch (GraphedStep.run); 1 = one step per launch")
-    ap.add_argument("--settle-ms", type=float, default=15.0,
-                    help="untimed replays of the captured step for this long right after capture, BEFORE the --warmup steps: the first "
-                         "~80 replays of a freshly captured step run 3-4 %% slower than every later one (0.131 -> 0.127 ms over ~10 ms, "
-                         "scripts/_build measurements in DESIGN.md §5; a matmul burst of the same length does not remove it), so a 20-step "
-                         "timed region right after capture measures the settling, not the step.  0 disables; reported as `settle`")
+    ap.add_argument("--settle-steps", type=int, default=128,
+                    help="untimed replays of the captured step right after capture, BEFORE the --warmup steps (the same count on every "
+                         "rank): the first ~80 replays of a freshly captured step run 3-4 %% slower than every later one (0.131 -> "
+                         "0.127 ms over ~10 ms; a matmul burst of the same length does not remove it, DESIGN.md §5), so a 20-step timed "
+                         "region right after capture measures the settling, not the step.  0 disables; reported as `config.settle`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=0, help="0 = auto-size the sample to ~15 s")
     ap.add_argument("--no-sweep", action="store_true", help="skip the aggregation-kernel batch-size sweep")
@@ -657,12 +657,10 @@ def main():
     stream = gstep.stream
     settle_steps = 0
     with torch.cuda.stream(stream):
-        if use_graph and a.settle_ms > 0:        # part of the set-up (capture + settle), not of the W warm-up steps below
-            ts = time.perf_counter()
-            while (time.perf_counter() - ts) * 1e3 < a.settle_ms:
-                gstep.run(16)
-                settle_steps += 16
-                torch.cuda.synchronize()
+        if use_graph and a.settle_steps > 0:     # part of the set-up (capture + settle), not of the W warm-up steps below
+            settle_steps = int(a.settle_steps)   # (a fixed count: every rank issues the same collectives)
+            gstep.run(settle_steps)
+            torch.cuda.synchronize()
         gstep.run(a.warmup)
         torch.cuda.synchronize()
         if multi:
@@ -701,9 +699,9 @@ def main():
                                    "clip 2.0 + Adam" % (a.shape, *synthetic.SHAPES[a.shape], a.batch, a.layers, a.hidden, a.nmax),
                        "global_batch": world * a.batch, "parallelism": "dp%d" % world,
                        "launch": ("hipGraph replay (%s)" % gstep.describe()) if use_graph else "eager",
-                       "settle": {"ms": a.settle_ms if use_graph else 0.0, "untimed_steps": settle_steps,
+                       "settle": {"untimed_steps": settle_steps,
                                   "note": "set-up, before the warm-up steps: replays of the freshly captured step until its time has "
-                                          "settled (the first ~80 replays after capture run 3-4 % slower; --settle-ms 0 disables)"},
+                                          "settled (the first ~80 replays after capture run 3-4 % slower; --settle-steps 0 disables)"},
                        "rows": int(g.n_rows), "edges_directed": int(g.nnz)},
         }
         if per_rank is not None:
