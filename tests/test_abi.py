@@ -72,6 +72,17 @@ def test_new_entry_points_validate_on_the_host():
     assert L.tsgnn_ingest_flush_pull_rider(None) == 0                                   # ... so this launches nothing
     assert L.tsgnn_collate_pool_submit_ack(None, None, None, None, None, None, None, 4, 64, 256, 1024, 16, 64, None, None, None, 0, 1,
                                            None) == -1
+    # late round 3: entry points whose argument checks run before anything is launched (no GPU here)
+    assert L.tsgnn_sddmm_rows_f32(None, None, None, 8, None, 8, 16, 8, None, None, None) == -1
+    assert L.tsgnn_triplet_embed_fwd_f32(None, 8, None, 8, None, 8, 4, 1e-6, None, None, None) == -1
+    assert L.tsgnn_triplet_embed_bwd_f32(None, 8, None, 8, 8, 4, 1e-6, None, None, None, None, None, None, None, None, 8, None, 8, None, None) == -1
+    assert L.tsgnn_margin_rank_fwd_f32(None, None, None, 1, 1.0, 1, None, None, None) == -1
+    assert L.tsgnn_margin_rank_bwd_f32(None, None, 1, None, None, None) == -1
+    assert L.tsgnn_row_post_bwd_f32(None, 3, 10, 12, None, 8, None, 8, None, 8, None, 8, 1, 1, None, None, None, None, 8, None) == -1
+    assert L.tsgnn_gat_bwd_products_f32(None, 256, None, 264, 100, 256, 264, None, 264, None, 256, 4, 32, None, None) == -1
+    assert L.tsgnn_wgrad_blocks_reduce_f32(None, 4, 256, 264, None, 264, None) == -1
+    assert L.tsgnn_wgrad_blocks_reduce2_f32(None, 4, 256, 264, None, 264, None, 4, 92, 264, None, 264, None) == -1
+    assert L.tsgnn_wgrad_blocks_slabs_f32(None, 256, None, 264, 100, 256, 264, 4, 32, None, None) == -1
     off = np.zeros(10, dtype=np.int64)
     assert L.tsgnn_ingest_compact_layout(4, 64, 256, 1024, 64, off.ctypes.data) == 0
     assert off[1] - off[0] == 8 and all(int(o) % 4 == 0 for o in off)                   # header: 4 sizes + sequence word + 3 spare
