@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collects the round's measurements on the GPU box (run through gpurun); outputs under gpurun_out/r03/, copied to profiles/r03/ afterwards.
-#   bash scripts/collect_profiles.sh [bench|rocprof|pmc|ingest|configs|diffpool_pmc|diffpool_stats|diffpool_replay|gat_stats|gat_replay|bench_replay|sagpool_replay ...]
+#   bash scripts/collect_profiles.sh [bench|rocprof|pmc|ingest|configs|diffpool_pmc|diffpool_stats|diffpool_replay|gat_stats|gat_replay|bench_replay|sagpool_replay|triplet_replay ...]
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/r03; mkdir -p $O
 for what in "$@"; do
@@ -29,6 +29,11 @@ for what in "$@"; do
              rocprofv3 --kernel-trace --output-format csv -d $O/rocprof_sr -- python3 scripts/sagpool_step.py > /dev/null 2>&1 &&
              python3 scripts/replay_trace.py $(ls $O/rocprof_sr/*/*kernel_trace.csv | head -1) splitk_reduce_kernel > $O/sagpool_replay_timeline.txt; rm -rf $O/rocprof_sr
              python3 scripts/sagpool_step.py >> $O/sagpool_replay_timeline.txt 2>/dev/null ;;
+    triplet_replay) rm -rf $O/rocprof_tr
+             rocprofv3 --kernel-trace --output-format csv -d $O/rocprof_tr -- python3 scripts/triplet_step.py > /dev/null 2>&1 &&
+             python3 scripts/replay_trace.py $(ls $O/rocprof_tr/*/*kernel_trace.csv | head -1) adam_update > $O/triplet_replay_timeline.txt; rm -rf $O/rocprof_tr
+             python3 scripts/triplet_step.py >> $O/triplet_replay_timeline.txt 2>/dev/null
+             TRIPLET_CRITERION=torch python3 scripts/triplet_step.py >> $O/triplet_replay_timeline.txt 2>/dev/null ;;
     gat_stats) rm -rf $O/rocprof_gat
              GAT_EAGER=20 rocprofv3 --kernel-trace --stats --output-format csv -d $O/rocprof_gat -- python3 scripts/gat_step.py > /dev/null 2>&1 && cp $O/rocprof_gat/*/*kernel_stats.csv $O/gat_b32_kernel_stats.csv ;;
   esac

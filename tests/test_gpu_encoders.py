@@ -851,6 +851,51 @@ def test_triplet_fused_stack_with_per_graph_statistics(hidden, nmax, sizes, fina
         torch.testing.assert_close(grads2[k], grads[k], rtol=1e-3, atol=1e-5 + 1e-4 * float(grads[k].abs().max()))
 
 
+def test_triplet_step_under_flat_trainer_equals_torch_adam():
+    """the triplet step as bench.py --triplet replays it (FlatTrainer: every fused backward node writes its gradients straight into the
+    flat bucket — the triplet tail's dW / db included —, clip 2.0 + Adam in the library's kernels, one hipGraph) against the same
+    model stepped by autograd + clip_grad_norm_ + torch.optim.Adam: parameters after three steps"""
+    import copy
+    from two_stage_gnn_amd import dense_encoders as E
+    from two_stage_gnn_amd.triplet import tripletnet, MarginRankingLoss
+    from two_stage_gnn_amd.data_parallel import FlatTrainer, GraphedStep
+    from two_stage_gnn_amd.graph import GraphBatch
+    nmax, fin, hidden = 48, 12, 128
+    x, adj, sz = dense_batch(91, 3, nmax, fin, sizes=[48, 21, 30], p_edge=0.15)
+
+    class A:
+        bias = True
+    torch.manual_seed(8)
+    m1 = E.GcnEncoderGraph(fin, hidden, hidden, 2, 3, bn=True, args=A(), final_dim="output_dim").cuda()
+    m2 = copy.deepcopy(m1)
+    g = GraphBatch.from_dense(adj.cuda(), sizes=sz, layout="packed", assume_symmetric=True)
+    g.val = None                                                   # unit weights (what tripletnet's resident pieces carry)
+    from two_stage_gnn_amd import message_passing as mp
+    xr = mp.pack_rows(x.cuda(), g, 12)
+    tgt = torch.tensor([-1.0]).cuda()
+    # (a) autograd + torch's optimiser
+    net2, crit2 = tripletnet(m2), torch.nn.MarginRankingLoss(margin=10.0)
+    params2 = [p for p in m2.parameters()]
+    opt = torch.optim.Adam(params2, lr=1e-3)
+    for _ in range(3):
+        opt.zero_grad(set_to_none=True)
+        dp, dn = net2._embed(xr, g, sz, xr)[:2]
+        crit2(dp, dn, tgt).backward()
+        torch.nn.utils.clip_grad_norm_([p for p in params2 if p.grad is not None], 2.0)
+        opt.step()
+    # (b) the flat trainer, one hipGraph per step
+    net1, crit1 = tripletnet(m1), MarginRankingLoss(margin=10.0)
+    tr = FlatTrainer(m1, lr=1e-3, clip=2.0)
+    gs = GraphedStep(tr, lambda: crit1(*net1._embed(xr, g, sz, xr)[:2], tgt), warmup=3)      # (warm-up steps are rolled back)
+    for _ in range(3):
+        gs.step()
+    gs.loss_value()
+    for (k, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        if p2.grad is None:
+            continue
+        torch.testing.assert_close(p1.detach(), p2.detach(), rtol=2e-4, atol=2e-6, msg=lambda s_, k=k: k + ": " + s_)
+
+
 @pytest.mark.parametrize("D,E,bias", [(384, 128, True), (20, 7, True), (48, 16, False)])
 def test_triplet_tail_kernels(D, E, bias):
     """embeddings + both pairwise distances in one launch and their backward in one launch (csrc/triplet.hip) against torch's

@@ -14,6 +14,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _native as nat
+from . import message_passing as mp
 from .graph import GraphBatch
 
 
@@ -120,6 +121,7 @@ class _TripletTail(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, r, w, b):
+        w0 = w
         r, w = r.contiguous(), w.contiguous()
         D, E = int(w.size(1)), int(w.size(0))
         embed = torch.empty(3, E, dtype=torch.float32, device=r.device)
@@ -127,6 +129,7 @@ class _TripletTail(torch.autograd.Function):
         nat.call("triplet_embed_fwd_f32", r, r.stride(0), w, w.stride(0), b, D, E, _EPS, embed, dist)
         ctx.save_for_backward(r, w, embed, dist)
         ctx.has_bias = b is not None
+        ctx.params = (w0, b)                              # (the Parameter objects: their slices of a trainer's flat gradient bucket)
         ctx.set_materialize_grads(False)                  # an unused output's gradient arrives as None, not as a zero-filled tensor
         outs = (dist[0:1], dist[1:2], embed[0:1], embed[1:2], embed[2:3])
         return outs
@@ -138,11 +141,12 @@ class _TripletTail(torch.autograd.Function):
         dev = r.device
         c = lambda t: t.contiguous() if t is not None else None
         d_r = torch.empty(3, D, dtype=torch.float32, device=dev)
-        dw = torch.empty(E, D, dtype=torch.float32, device=dev)
-        db = torch.empty(E, dtype=torch.float32, device=dev) if ctx.has_bias else None
+        # straight into the trainer's flat gradient bucket when one is installed (FlatTrainer): no AccumulateGrad copy, no zeroing
+        dw, sw = mp._sink_or_new(ctx.params[0], (E, D), dev)
+        db, sb = mp._sink_or_new(ctx.params[1], (E,), dev) if ctx.has_bias else (None, False)
         nat.call("triplet_embed_bwd_f32", r, r.stride(0), w, w.stride(0), D, E, _EPS, embed, dist, c(g_dp), c(g_dn), c(g_a), c(g_p), c(g_n), d_r,
                  d_r.stride(0), dw, dw.stride(0), db)
-        return d_r, dw, db
+        return d_r, (None if sw else dw), (None if sb else db)
 
 
 class _MarginRank(torch.autograd.Function):
