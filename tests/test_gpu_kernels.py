@@ -540,3 +540,48 @@ def test_rowgemm_large_batch_kernel_equals_row_panel_kernel(T, K, ld, N, trans_b
     if normalize:
         ref = torch.nn.functional.normalize(ref, p=2, dim=1)
     torch.testing.assert_close(out[0][0][:R], ref, rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("F,ln,relu,with_dxs", [(128, 1, 1, True), (64, 1, 1, False), (200, 1, 1, True), (128, 0, 0, True)])
+def test_row_post_bwd_against_autograd(T, F, ln, relu, with_dxs):
+    """tsgnn_row_post_bwd_f32 (readout winners + per-row layer norm + ReLU + L2 normalise backward in one pass; the triplet step's
+    row-local counterpart of slot_post_bwd) against torch autograd through the same chain: real rows take the next layer's gradient
+    and the readout gradient of their own graph, ghost rows (no edges) only the readout gradients — of EVERY graph that picked them"""
+    from two_stage_gnn_amd import _native as nat
+    gen = torch.Generator().manual_seed(F + ln)
+    sizes, n_ghost, B = [7, 12, 5], 6, 3
+    n_real, R = sum(sizes), sum(sizes) + 6
+    row_graph = torch.repeat_interleave(torch.arange(B), torch.tensor(sizes)).int()
+    u = torch.randn(R, F, generator=gen, dtype=torch.float64, requires_grad=True)
+    nrm = u.norm(dim=1, keepdim=True).clamp_min(1e-12)
+    v = u / nrm
+    y = torch.relu(v) if relu else v
+    if ln:
+        mu = y.mean(1, keepdim=True)
+        y = (y - mu) / torch.sqrt(((y - mu) ** 2).mean(1, keepdim=True) + 1e-5)
+    # readout winners: random rows of the own graph, or a ghost row (shared by several graphs)
+    arg = torch.empty(B, F, dtype=torch.int32)
+    off = 0
+    for b, n in enumerate(sizes):
+        own = torch.randint(off, off + n, (F,), generator=gen)
+        gh = n_real + torch.randint(0, n_ghost, (F,), generator=gen)
+        arg[b] = torch.where(torch.rand(F, generator=gen) < 0.3, gh, own).int()
+        off += n
+    dout = torch.randn(B, F, generator=gen, dtype=torch.float64)
+    dxs = torch.randn(R, F, generator=gen, dtype=torch.float64)
+    dy = torch.zeros(R, F, dtype=torch.float64)
+    if with_dxs:
+        dy[:n_real] += dxs[:n_real]
+    for b in range(B):
+        dy[arg[b].long(), torch.arange(F)] += dout[b]
+    (y * dy).sum().backward()
+    vg = v.detach().float().cuda()
+    yr = torch.relu(vg) if relu else vg
+    mean = yr.mean(1).contiguous() if ln else None
+    rstd = (1.0 / torch.sqrt(((yr - yr.mean(1, keepdim=True)) ** 2).mean(1) + 1e-5)).contiguous() if ln else None
+    rinv = (1.0 / nrm.detach().float().view(-1)).cuda()
+    du = torch.full((R, F), float("nan"), device="cuda")
+    dx_g = dxs.float().cuda() if with_dxs else None
+    nat.call("row_post_bwd_f32", row_graph.cuda(), B, n_real, R, vg, vg.stride(0), dx_g, dx_g.stride(0) if with_dxs else 0,
+             dout.float().cuda(), F, arg.cuda(), F, relu, ln, mean, rstd, rinv, du, du.stride(0))
+    torch.testing.assert_close(du.cpu().double(), u.grad, rtol=2e-4, atol=2e-5)
