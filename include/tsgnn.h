@@ -953,6 +953,12 @@ int tsgnn_sage_multi_zero_f32(const int64_t* desc, float* zero0, int64_t n0, flo
 int tsgnn_gat_bwd_products_f32(const float* x, int64_t ldx, const float* du, int64_t lddu, int64_t rows, int K_in, int N, const float* wp,
                                int64_t ldwp, float* dx, int64_t lddx, int nslab, int64_t rows_per_slab, float* ws, tsgnn_stream_t stream);
 int tsgnn_wgrad_blocks_reduce_f32(const float* ws, int nslab, int K_in, int N, float* dw, int64_t lddw, tsgnn_stream_t stream);
+/* the same pairing for a torch.nn.Linear y = x W^T + b with W [N = out, K_in = in] (DiffPool's assignment predictor, encoders.py:362-372):
+ * the slab partials of (dW^T, db) from x and dy into ws and dx[rows, K_in] = dy[rows, N] . W in one launch; the reduction into
+ * nn.Linear's layout dw_oi[N][K_in] + db[N] (nullable).  K_in, N <= 512, both multiples of 4. */
+int tsgnn_linear_bwd_products_f32(const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t rows, int K_in, int N, const float* w,
+                                  int64_t ldw, float* dx, int64_t lddx, int nslab, int64_t rows_per_slab, float* ws, tsgnn_stream_t stream);
+int tsgnn_wgrad_blocks_reduce_oi_f32(const float* ws, int nslab, int K_in, int N, float* dw_oi, int64_t lddw, float* db, tsgnn_stream_t stream);
 /* two such reductions in one launch (both layers of a GAT encoder's backward); the slab-only form of the blocked weight gradient:
  * tsgnn_wgrad_blocks_slabs_f32 = tsgnn_wgrad_blocks_f32 without its reduction. */
 int tsgnn_wgrad_blocks_reduce2_f32(const float* ws0, int nslab0, int K0, int N0, float* dw0, int64_t lddw0, const float* ws1, int nslab1,

@@ -585,3 +585,41 @@ def test_row_post_bwd_against_autograd(T, F, ln, relu, with_dxs):
     nat.call("row_post_bwd_f32", row_graph.cuda(), B, n_real, R, vg, vg.stride(0), dx_g, dx_g.stride(0) if with_dxs else 0,
              dout.float().cuda(), F, arg.cuda(), F, relu, ln, mean, rstd, rinv, du, du.stride(0))
     torch.testing.assert_close(du.cpu().double(), u.grad, rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("R_,K,N,bias", [(8183, 192, 64, True), (1024, 192, 64, True), (500, 64, 128, False), (300, 260, 200, True)])
+def test_linear_backward_products_merged_equals_separate(T, R_, K, N, bias):
+    """torch.nn.Linear's backward with the weight-gradient slabs beside the input-gradient product in one launch
+    (tsgnn_linear_bwd_products_f32 + tsgnn_wgrad_blocks_reduce_oi_f32; DiffPool's assignment predictor) == the separate launches,
+    bit for bit, and torch"""
+    mp, _ = T
+    from two_stage_gnn_amd import _native as nat
+    gen = torch.Generator(device="cuda").manual_seed(R_ + K + N)
+    x = torch.randn(R_, K, generator=gen, device="cuda")
+    dy = torch.randn(R_, N, generator=gen, device="cuda")
+    w = torch.randn(N, K, generator=gen, device="cuda") * 0.1
+    got = mp.linear_bwd_products(x, K, dy, w, bias)
+    assert got is not None
+    dw, db, dx = got
+    dw_s, db_s = mp.linear_wgrad_oi(x, K, dy, bias)
+    dx_s = torch.empty(R_, K, device="cuda")
+    nat.call("rowgemm_f32", dy, dy.stride(0), w, w.stride(0), 0, None, dx_s, dx_s.stride(0), None, R_, N, K, 0, 0)
+    assert torch.equal(dw, dw_s) and (not bias or torch.equal(db, db_s))
+    torch.testing.assert_close(dx, dx_s, rtol=1e-5, atol=1e-5)            # (large row counts take the B-stationary kernel separately)
+    torch.testing.assert_close(dw.double(), dy.double().t() @ x.double(), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(dx.double(), dy.double() @ w.double(), rtol=1e-4, atol=1e-4)
+    if bias:
+        torch.testing.assert_close(db.double(), dy.double().sum(0), rtol=1e-4, atol=1e-3)
+    # through the autograd node, switch on and off
+    outs = []
+    for on in (True, False):
+        mp.LINEAR_MERGED_BWD = on
+        try:
+            xg, wg = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+            bg = torch.zeros(N, device="cuda", requires_grad=True) if bias else None
+            (mp.linear_oi(xg, wg, bg) * dy).sum().backward()
+            outs.append((xg.grad, wg.grad, bg.grad if bias else None))
+        finally:
+            mp.LINEAR_MERGED_BWD = True
+    torch.testing.assert_close(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-5)
+    assert torch.equal(outs[0][1], outs[1][1])

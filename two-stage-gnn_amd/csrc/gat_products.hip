@@ -16,6 +16,9 @@
 
 namespace {
 
+// TRANS_B: the input-gradient product's B operand is given as W[N_out][K] (the GAT layer: dx = dhp W'^T with W' [K_in, N]) or as
+// B[K][N_out] (a torch.nn.Linear: dx = dy W with W [out, in])
+template <bool TRANS_B>
 __global__ __launch_bounds__(256) void gat_bwd_products_kernel(RowGemmArgs g, WgradBlocks w, unsigned npan, unsigned n_dx, unsigned nslab) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (blockIdx.x < n_dx) {
@@ -24,8 +27,8 @@ __global__ __launch_bounds__(256) void gat_bwd_products_kernel(RowGemmArgs g, Wg
     const int n0 = (int)y * 128;
     g.N = min(128, g.N - n0);
     g.c += n0;
-    g.b += (int64_t)n0 * g.ldb;                            // B given transposed: W'[N][K] row-major, rows = output columns
-    rowgemm_body<4, true, false>(g, smem, x);
+    g.b += TRANS_B ? (int64_t)n0 * g.ldb : (int64_t)n0;   // (transposed: rows of W'[N][K] = output columns)
+    rowgemm_body<4, TRANS_B, false>(g, smem, x);
   } else {
     const unsigned b = blockIdx.x - n_dx;
     wgrad_blocks_role<2>(w, smem, b % nslab, b / nslab, nslab);
@@ -59,11 +62,43 @@ int tsgnn_gat_bwd_products_f32(const float* x, int64_t ldx, const float* du, int
   constexpr size_t lds = la > lt ? la : lt;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gat_bwd_products_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gat_bwd_products_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
-  TSGNN_KNAME("gat_bwd_products_kernel");
-  gat_bwd_products_kernel<<<n_dx + n_w, 256, lds, stream>>>(g, w, npan, n_dx, (unsigned)nslab);
+  TSGNN_KNAME("gat_bwd_products_kernel<true>");
+  gat_bwd_products_kernel<true><<<n_dx + n_w, 256, lds, stream>>>(g, w, npan, n_dx, (unsigned)nslab);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+/* The same pairing for a torch.nn.Linear y = x W^T + b with W [N = out, K_in = in] (message_passing._LinearOI: DiffPool's assignment
+ * predictor, encoders.py:362-372): the slab partials of (dW^T, db) from x and dy into ws (reduce with tsgnn_wgrad_blocks_reduce_oi_f32)
+ * and dx[rows, K_in] = dy[rows, N] . W in one launch.  K_in, N <= 512, K_in % 4 == 0, N % 4 == 0. */
+int tsgnn_linear_bwd_products_f32(const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t rows, int K_in, int N, const float* w,
+                                  int64_t ldw, float* dx, int64_t lddx, int nslab, int64_t rows_per_slab, float* ws, tsgnn_stream_t stream) {
+  if (!x || !dy || !w || !dx || !ws || rows <= 0 || K_in <= 0 || N <= 0 || nslab <= 0 || rows_per_slab <= 0 || ldx < K_in || lddy < N ||
+      ldw < K_in || lddx < K_in || (int64_t)nslab * rows_per_slab < rows)
+    return TSGNN_EINVAL;
+  const uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(w) |
+                       reinterpret_cast<uintptr_t>(dx);
+  if ((al & 15) || (ldx % 4) || (lddy % 4) || (ldw % 4) || (lddx % 4) || (N % 4) || (K_in % 4) || K_in > 512 || N > 512)
+    return TSGNN_EUNSUPPORTED;
+  const int KB = (K_in + 127) / 128, NB = (N + 127) / 128, nsets = KB * NB;
+  if (nsets > WB_MAXSETS) return TSGNN_EUNSUPPORTED;
+  // dx = dy . W : A = dy [rows, N], B = W[K = N][N_out = K_in] row-major, no epilogue
+  RowGemmArgs g{dy, lddy, w, ldw, nullptr, dx, lddx, nullptr, rows, N, K_in, 0, 0, nullptr, 0, nullptr, 0};
+  WgradBlocks wb{TnArgs{x, ldx, dy, lddy, rows, rows_per_slab, K_in, N, ws, nullptr, 0}, NB, nsets, (int64_t)nslab * WB_SET_FLOATS};
+  const unsigned npan = (unsigned)ceil_div64(rows, 32), ny = (unsigned)KB;
+  const unsigned n_dx = npan * ny, n_w = (unsigned)nslab * 2u * (unsigned)nsets;
+  constexpr size_t la = rowgemm_lds_bytes<4, false, false>(), lt = 2 * TN_CH * 32 * (4 + 4) * sizeof(float);
+  constexpr size_t lds = la > lt ? la : lt;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gat_bwd_products_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  TSGNN_KNAME("gat_bwd_products_kernel<false>");
+  gat_bwd_products_kernel<false><<<n_dx + n_w, 256, lds, stream>>>(g, wb, npan, n_dx, (unsigned)nslab);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }

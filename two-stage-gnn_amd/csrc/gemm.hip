@@ -750,6 +750,13 @@ int tsgnn_wgrad_blocks_reduce_f32(const float* ws, int nslab, int K_in, int N, f
   return wgrad_blocks_reduce_launch(ws, nslab, K_in, N, dw, lddw, 0, nullptr, stream);
 }
 
+/* the same into torch.nn.Linear's layout: dw_oi[N][K_in], db[N] (nullable) — after tsgnn_linear_bwd_products_f32 */
+int tsgnn_wgrad_blocks_reduce_oi_f32(const float* ws, int nslab, int K_in, int N, float* dw_oi, int64_t lddw, float* db, tsgnn_stream_t stream) {
+  if (!ws || !dw_oi || nslab <= 0 || K_in <= 0 || N <= 0 || K_in > 512 || N > 512 || lddw < K_in) return TSGNN_EINVAL;
+  if (((K_in + 127) / 128) * ((N + 127) / 128) > WB_MAXSETS) return TSGNN_EINVAL;
+  return wgrad_blocks_reduce_launch(ws, nslab, K_in, N, dw_oi, lddw, 1, db, stream);
+}
+
 /* two such reductions in one launch (the two layers of a GAT encoder's backward) */
 int tsgnn_wgrad_blocks_reduce2_f32(const float* ws0, int nslab0, int K0, int N0, float* dw0, int64_t lddw0, const float* ws1, int nslab1,
                                    int K1, int N1, float* dw1, int64_t lddw1, tsgnn_stream_t stream) {

@@ -358,6 +358,11 @@ class _LinearOI(torch.autograd.Function):
         dy = _check(dy)
         R, N, K = dy.size(0), w.size(0), w.size(1)
         dx = dw = db = None
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and LINEAR_MERGED_BWD:
+            got = linear_bwd_products(x, K, dy, w, want_db)      # (dW, db) slabs and dx = dy W side by side in one launch
+            if got is not None:
+                return got[2], got[0], got[1]
         if ctx.needs_input_grad[0]:
             dx = _f32(R, K, device=dy.device)
             if rowgemm_ok(dy, dy.stride(0), w, w.stride(0), N, K, False):                   # dX = dY W
@@ -375,6 +380,35 @@ class _LinearOI(torch.autograd.Function):
         elif want_db:
             db = colsum(dy)
         return dx, dw, db
+
+
+LINEAR_MERGED_BWD = os.environ.get("TSGNN_LINEAR_MERGED_BWD", "1") != "0"   # nn.Linear backward: weight-gradient slabs beside dx = dy W
+
+
+def linear_bwd_products(x, K_in, dy, w, want_db):
+    """(dW[N, K_in], db[N] or None, dx[R, K_in]) of y = x W^T + b in two launches: the blocked weight-gradient slabs beside the
+    input-gradient product (tsgnn_linear_bwd_products_f32) and the slabs' reduction; None when the shape is not taken"""
+    R, N = int(dy.size(0)), int(dy.size(1))
+    if not (R >= 256 and K_in <= 512 and N <= 512 and K_in % 4 == 0 and N % 4 == 0 and x.size(1) == K_in and x.stride(0) % 4 == 0
+            and dy.stride(0) % 4 == 0 and w.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0
+            and w.data_ptr() % 16 == 0):
+        return None
+    nslab = np.zeros(1, dtype=np.int32)
+    rps = np.zeros(1, dtype=np.int64)
+    need = np.zeros(1, dtype=np.int64)
+    nat.call_nostream("wgrad_blocks_plan", R, int(K_in), N, int(x.stride(0)), int(dy.stride(0)), nslab.ctypes.data, rps.ctypes.data,
+                      need.ctypes.data)
+    if int(nslab[0]) <= 0:
+        return None
+    ws = _f32(int(need[0]), device=dy.device)
+    dx = _f32(R, int(K_in), device=dy.device)
+    if not nat.try_call("linear_bwd_products_f32", x, x.stride(0), dy, dy.stride(0), R, int(K_in), N, w, w.stride(0), dx, dx.stride(0),
+                        int(nslab[0]), int(rps[0]), ws):
+        return None
+    dw = _f32(N, int(K_in), device=dy.device)
+    db = _f32(N, device=dy.device) if want_db else None
+    nat.call("wgrad_blocks_reduce_oi_f32", ws, int(nslab[0]), int(K_in), N, dw, dw.stride(0), db)
+    return dw, db, dx
 
 
 def linear_oi(x, weight, bias=None):
