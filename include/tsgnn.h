@@ -953,6 +953,10 @@ int tsgnn_sage_multi_zero_f32(const int64_t* desc, float* zero0, int64_t n0, flo
 int tsgnn_gat_bwd_products_f32(const float* x, int64_t ldx, const float* du, int64_t lddu, int64_t rows, int K_in, int N, const float* wp,
                                int64_t ldwp, float* dx, int64_t lddx, int nslab, int64_t rows_per_slab, float* ws, tsgnn_stream_t stream);
 int tsgnn_wgrad_blocks_reduce_f32(const float* ws, int nslab, int K_in, int N, float* dw, int64_t lddw, tsgnn_stream_t stream);
+/* K_in, N <= 128 (one 128 x 128 set: the slab layout of tsgnn_linear_wgrad_f32): the reduction of tsgnn_linear_wgrad_du_f32 alone
+ * (part nullable) — the SAGPool conv layers (Code/sag/network.py:19-23) run their slabs beside dagg = du W^T in tsgnn_gat_bwd_products_f32 */
+int tsgnn_linear_wgrad_du_reduce_f32(const float* ws, int nslab, int K_in, int N, float* dw, float* db, float* part, int nb, int F_du,
+                                     float* dws, float* dbs, tsgnn_stream_t stream);
 /* the same pairing for a torch.nn.Linear y = x W^T + b with W [N = out, K_in = in] (DiffPool's assignment predictor, encoders.py:362-372):
  * the slab partials of (dW^T, db) from x and dy into ws and dx[rows, K_in] = dy[rows, N] . W in one launch; the reduction into
  * nn.Linear's layout dw_oi[N][K_in] + db[N] (nullable).  K_in, N <= 512, both multiples of 4. */

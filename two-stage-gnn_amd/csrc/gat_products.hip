@@ -41,7 +41,8 @@ extern "C" {
 
 /* dw_slabs (ws) <- the slab partials of dW'[K_in, N] = x[:, :K_in]^T du  (reduce with tsgnn_wgrad_blocks_reduce_f32; plan with
  * tsgnn_wgrad_blocks_plan(rows, K_in, N, ldx, lddu)) and dx[rows, K_in] = du[rows, N] . wp[K_in, N]^T, one launch.
- * 128 < K_in <= 512, N <= 512, N % 4 == 0, 16-byte aligned rows everywhere. */
+ * K_in, N <= 512, both multiples of 4, 16-byte aligned rows everywhere.  (K_in = N = 128: the slabs have tsgnn_linear_wgrad_f32's
+ * layout [nslab][K_in + 1][N] — the SAGPool conv layers reduce them with tsgnn_linear_wgrad_du_reduce_f32.) */
 int tsgnn_gat_bwd_products_f32(const float* x, int64_t ldx, const float* du, int64_t lddu, int64_t rows, int K_in, int N, const float* wp,
                                int64_t ldwp, float* dx, int64_t lddx, int nslab, int64_t rows_per_slab, float* ws, tsgnn_stream_t stream) {
   if (!x || !du || !wp || !dx || !ws || rows <= 0 || K_in <= 0 || N <= 0 || nslab <= 0 || rows_per_slab <= 0 || ldx < K_in || lddu < N ||
@@ -49,7 +50,7 @@ int tsgnn_gat_bwd_products_f32(const float* x, int64_t ldx, const float* du, int
     return TSGNN_EINVAL;
   const uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(du) | reinterpret_cast<uintptr_t>(wp) |
                        reinterpret_cast<uintptr_t>(dx);
-  if ((al & 15) || (ldx % 4) || (lddu % 4) || (ldwp % 4) || (lddx % 4) || (N % 4) || K_in <= 128 || K_in > 512 || N > 512)
+  if ((al & 15) || (ldx % 4) || (lddu % 4) || (ldwp % 4) || (lddx % 4) || (N % 4) || (K_in % 4) || K_in > 512 || N > 512)
     return TSGNN_EUNSUPPORTED;
   const int KB = (K_in + 127) / 128, NB = (N + 127) / 128, nsets = KB * NB;
   if (nsets > WB_MAXSETS) return TSGNN_EUNSUPPORTED;

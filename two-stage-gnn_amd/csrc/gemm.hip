@@ -563,6 +563,24 @@ int tsgnn_linear_wgrad_du_f32(const float* z, int64_t ldz, const float* du, int6
 }
 
 
+/* only the reduction of tsgnn_linear_wgrad_du_f32 (part nullable: tsgnn_linear_wgrad_f32's), for slabs [nslab][K_in + 1][N] another
+ * launch produced (tsgnn_gat_bwd_products_f32: the slab blocks beside the input-gradient product) */
+int tsgnn_linear_wgrad_du_reduce_f32(const float* ws, int nslab, int K_in, int N, float* dw, float* db, float* part, int nb, int F_du,
+                                     float* dws, float* dbs, tsgnn_stream_t stream) {
+  if (!ws || !dw || nslab <= 0 || K_in <= 0 || N <= 0 || K_in > 128 || N > 128) return TSGNN_EINVAL;
+  if (part && (!dws || !dbs || nb <= 0 || nb > 256 || F_du <= 0 || (F_du % 4) || (reinterpret_cast<uintptr_t>(part) & 15) ||
+               (reinterpret_cast<uintptr_t>(dws) & 15)))
+    return TSGNN_EINVAL;
+  const int64_t per_slab = (int64_t)(K_in + 1) * N;
+  if (part)
+    tn_rows_reduce_du<<<(unsigned)ceil_div64(per_slab, 64) + 1, 256, 0, stream>>>(ws, nslab, per_slab, (int64_t)K_in * N, dw, db, part, nb,
+                                                                                   F_du, dws, dbs);
+  else
+    tn_rows_reduce<<<(unsigned)ceil_div64(per_slab, 64), 256, 0, stream>>>(ws, nslab, per_slab, (int64_t)K_in * N, dw, db, nullptr);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
 /* Ragged batched  out[b][K,N] = S[rows_b, :K]^T . X[rows_b, :N]  (DiffPool's S^T Z and S^T (A S), encoders.py:374-375):
  * every graph is cut into row slabs (slab_row_ptr[nslab+1], graph b owns slabs [seg_slab_ptr[b], seg_slab_ptr[b+1])),
  * each slab is one workgroup of MFMA work, slabs are summed per graph in fixed order.  ceil(K/32)*ceil(N/32) <= 16. */

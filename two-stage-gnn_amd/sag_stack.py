@@ -22,6 +22,8 @@ A step is therefore capturable in a hipGraph.  Per level (csrc/sagpool.hip):
             backward -> du ; reduction of dw_s / db_s partials ; dW, db in one pass ; dagg = du W^T ; level 0: dx = A^ dagg
 ReLU is applied by the consumers of ``y`` (it is stored pre-activation), so no activation tensor is written.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -134,6 +136,34 @@ def _al16(t):
 
 def supported(hidden):
     return bool(nat.lib().tsgnn_sag_supported(int(hidden)))
+
+
+MERGED_BWD = os.environ.get("TSGNN_SAG_MERGED_BWD", "1") != "0"   # a conv layer's weight-gradient slabs beside dagg = du W^T (one launch)
+
+
+def _wgrad_beside_dagg(agg, du, W, du_job):
+    """(dW[K, N], db[N], dagg[R, K]) of a 128 -> 128 conv layer: the slab blocks of mp.linear_wgrad and the product du W^T as roles of
+    one launch (tsgnn_gat_bwd_products_f32: both only read du), then linear_wgrad's own reduction with the score layer's partial rows
+    riding along; None when the shape is not taken"""
+    R, N, K = int(du.size(0)), int(du.size(1)), int(agg.size(1))
+    part, nb, F_du, dws, dbs = du_job
+    if not (K == 128 and N == 128 and nb <= 256 and R >= 64 and agg.stride(0) % 4 == 0 and du.stride(0) % 4 == 0 and W.stride(0) % 4 == 0
+            and agg.data_ptr() % 16 == 0 and du.data_ptr() % 16 == 0 and W.data_ptr() % 16 == 0 and W.size(0) == K and W.size(1) == N):
+        return None
+    nslab = np.zeros(1, dtype=np.int32)
+    rps = np.zeros(1, dtype=np.int64)
+    need = np.zeros(1, dtype=np.int64)
+    nat.call_nostream("linear_wgrad_plan", R, K, N, int(agg.stride(0)), int(du.stride(0)), nslab.ctypes.data, rps.ctypes.data, need.ctypes.data)
+    if int(nslab[0]) <= 0 or int(nslab[0]) >= 512:
+        return None
+    ws = _f32(int(need[0]), device=du.device)
+    dagg = _f32(R, K, device=du.device)
+    if not nat.try_call("gat_bwd_products_f32", agg, agg.stride(0), du, du.stride(0), R, K, N, W, W.stride(0), dagg, dagg.stride(0),
+                        int(nslab[0]), int(rps[0]), ws):
+        return None
+    dW, db = _f32(K, N, device=du.device), _f32(N, device=du.device)
+    nat.call("linear_wgrad_du_reduce_f32", ws, int(nslab[0]), K, N, dW, db, part, int(nb), int(F_du), dws, dbs)
+    return dW, db, dagg
 
 
 class _SagStack(torch.autograd.Function):
@@ -266,10 +296,18 @@ class _SagStack(torch.autograd.Function):
                 # dt = A^T dscore: the score layer's propagate transposed
                 nat.call("sag_du_f32", rowptr_t, rowend, col_t, dinv, self_w, dscore, y, y.stride(0), wsv, dyb, dyb.stride(0), N, H, part,
                          dws, dbs)
-            dW, db = mp.linear_wgrad(agg, agg.size(1), dyb, True, du_job=du_job)
+            need_dagg = l > 0 or ctx.x_needs_grad
+            dagg = None
+            if need_dagg and MERGED_BWD and du_job is not None:
+                both = _wgrad_beside_dagg(agg, dyb, W, du_job)      # (dW, db) slabs and dagg = du W^T: ONE launch + the reduction
+                if both is not None:
+                    dW, db, dagg = both
+            if dagg is None:
+                dW, db = mp.linear_wgrad(agg, agg.size(1), dyb, True, du_job=du_job)
             grads[4 * l: 4 * l + 4] = [dW, db, dws.view(-1, 1), dbs]
-            if l > 0 or ctx.x_needs_grad:
-                dagg = _linear_t(dyb, W)
+            if need_dagg:
+                if dagg is None:
+                    dagg = _linear_t(dyb, W)
                 nxt = None
                 if l > 0 and ctx.saved_levels[l - 1][-1]:
                     # level l - 1 ran the fused per-graph forward (symmetric, filter in-kernel): its backward kernel takes
