@@ -989,6 +989,49 @@ int tsgnn_margin_rank_fwd_f32(const float* x1, const float* x2, const float* tar
                               float* coef, tsgnn_stream_t stream);
 int tsgnn_margin_rank_bwd_f32(const float* g, const float* coef, int64_t n, float* dx1, float* dx2, tsgnn_stream_t stream);
 
+/* ---------------------------------------------------------------- torch_geometric-named fused layers (csrc/sageconv.hip)
+ * BASELINE.json's north_star names PyG's SAGEConv / GATConv / SAGPooling / dense_diff_pool; the reference itself never calls them
+ * (no call site; PARITY UNPINNED — the oracle is oracle/pyg_ref.py's restatement of PyG's documented formulas).
+ *
+ * tsgnn_sage_conv_f32: ONE launch for
+ *     out[i, :] = act( [ dst_scale[i] * sum_{j in N(i)} xg[j, :K]  ||  xs[i, :K] ] . [ W_l ; W_r ] + bias )
+ *   forward of SAGEConv (lin_l(mean_j x_j) + lin_r(x_i)): xg = xs = x, dst_scale = 1 / max(deg, 1), the weights packed
+ *     from lin_l.weight / lin_r.weight (nn.Linear's [N = out, K = in] layout: kn = 0), bias = lin_l.bias;
+ *   its input gradient for a symmetric edge list, dx = A_mean^T (du W_l) + du W_r: xg = du scaled row-wise by 1 / max(deg, 1)
+ *     (tsgnn_sage_relu_readout_bwd_f32 writes it beside du), xs = du, dst_scale = NULL, the same weight tensors packed as
+ *     [K = out][N = in] (kn = 1);
+ *   PyG GraphConv (sum aggregation): dst_scale NULL, xg = xs.
+ * wl_pk / wr_pk: FRAGMENT-MAJOR copies of the two weight matrices (16,384 floats each, tsgnn_sage_conv_pack_f32): the matrix cores'
+ * B operand is read with full-width, fully coalesced loads and never staged in LDS.
+ * ell / tail: the fixed-width neighbour table of tsgnn_csr_to_ell (+ CSR tail).  K, N <= 128; xg / xs / zout rows 16-byte aligned with
+ * at least ceil4(K) floats.  zout (nullable): the scaled aggregate [rows, K] (operand of the weight gradient).  relu_out: ReLU in the
+ * epilogue; normalize: F.normalize(out, dim = -1) (rinv nullable: 1 / max(|row|, 1e-12)).  ro_packed / ro_sums [B, N] (nullable pair,
+ * zero before the launch): per-graph column maxima of the output rows as packed (ordered value, ~row) atomicMax and column sums as
+ * 64-bit fixed-point integers (2^-32 units; order-independent) — global_max_pool / global_mean_pool (network.py:36) without a pass
+ * of their own; decode with tsgnn_sage_readout_decode_f32. */
+int tsgnn_sage_conv_supported(int K, int N);
+/* desc (HOST memory): [nsets <= 16, nsets x (w, ldw, K, N, kn, out)] — out[16384] = fragment-major copy of the K x N matrix w
+ * (kn = 0: w[n * ldw + k], nn.Linear's [out, in]; kn = 1: w[k * ldw + n]), zero beyond K / N; one launch for all layers of a step */
+int tsgnn_sage_conv_pack_f32(const int64_t* desc, tsgnn_stream_t stream);
+int tsgnn_sage_conv_f32(const int* ell, int ell_w, const int* tail_ptr, const int* tail_col, const float* xg, int64_t ldxg, const float* xs,
+                        int64_t ldxs, const float* dst_scale, const float* wl_pk, const float* wr_pk,
+                        const float* bias, float* out, int64_t ldo, float* zout, int64_t ldz, float* rinv,
+                        int64_t rows, int K, int N, int relu_out, int normalize, unsigned long long* ro_packed,
+                        unsigned long long* ro_sums, const int* ro_row_graph, const int* ro_graph_ptr, tsgnn_stream_t stream);
+/* du[r, c] = ( dxs[r, c] (nullable) + [arg[b, c] == r] dread[b, c] + dread[b, F + c] / n_b ) * [h[r, c] > 0] (relu != 0), b = row_graph[r]:
+ * backward of h = relu(u) feeding the next layer, the max readout (arg = winning rows) and the mean readout (dread [B, 2F], nullable);
+ * dus (nullable) = du scaled row-wise by row_scale[r] (1 / deg: the rows the input-gradient launch gathers) */
+int tsgnn_sage_relu_readout_bwd_f32(const float* h, int64_t ldh, const float* dxs, int64_t lddxs, const float* dread, int64_t lddr,
+                                    const int* arg, const int* row_graph, const int* graph_ptr, int64_t rows, int F, int relu, float* du,
+                                    int64_t lddu, const float* row_scale, float* dus, int64_t lddus, tsgnn_stream_t stream);
+/* read[b, :F] = sum_l max_l[b, :], read[b, F:2F] = sum_l sum_l[b, :] / n_b (network.py:36-46), arg[l, b, f] = the row that holds layer l's
+ * maximum; packed / sums [L, B, F] as left by tsgnn_sage_conv_f32's epilogue, zero again afterwards */
+int tsgnn_sage_readout_decode_f32(unsigned long long* packed, unsigned long long* sums, const int* graph_ptr, int B, int L, int F, float* read,
+                                  int64_t ldr, int* arg, tsgnn_stream_t stream);
+/* desc (HOST memory): [nsets <= 8, nsets x (ws, nslab, K, N, dw_oi, lddw, db)]: slab sets of tsgnn_linear_wgrad_f32 (dw == NULL form) summed
+ * in slab order into nn.Linear's layout dw_oi[n * lddw + k] (+ db[n], nullable): all layers' lin_l / lin_r gradients in one launch */
+int tsgnn_sage_wgrad_reduce_oi_f32(const int64_t* desc, tsgnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -120,16 +120,30 @@ def sage_conv(x, edge_index, w_l, b_l, w_r):
     """SAGEConv: lin_l(mean_{j in N(i)} x_j) + lin_r(x_i)."""
     n = x.size(0)
     row, col = edge_index[0], edge_index[1]
-    s = torch.zeros(n, x.size(1)).index_add_(0, col, x[row])
-    deg = torch.zeros(n).index_add_(0, col, torch.ones(row.numel())).clamp(min=1)
+    s = torch.zeros(n, x.size(1), dtype=x.dtype).index_add_(0, col, x[row])
+    deg = torch.zeros(n, dtype=x.dtype).index_add_(0, col, torch.ones(row.numel(), dtype=x.dtype)).clamp(min=1)
     out = F.linear(s / deg.unsqueeze(1), w_l, b_l)
     return out + F.linear(x, w_r)
+
+
+def sage_net(p, x, edge_index, batch, num_layers):
+    """two_stage_gnn_amd.pyg.SageNet: Code/sag/network.py:30-53's shape (conv + ReLU, [gmp || gap] per layer summed, three Linear,
+    log_softmax; eval mode) with SAGEConv layers and no pooling — BASELINE configs 1-2 as worded."""
+    B = int(batch.max()) + 1
+    out = None
+    for l in range(num_layers):
+        x = F.relu(sage_conv(x, edge_index, p["convs.%d.lin_l.weight" % l], p["convs.%d.lin_l.bias" % l], p["convs.%d.lin_r.weight" % l]))
+        r = torch.cat([global_max_pool(x, batch, B), global_mean_pool(x, batch, B)], dim=1)
+        out = r if out is None else out + r
+    x = F.relu(F.linear(out, p["lin1.weight"], p["lin1.bias"]))
+    x = F.relu(F.linear(x, p["lin2.weight"], p["lin2.bias"]))
+    return F.log_softmax(F.linear(x, p["lin3.weight"], p["lin3.bias"]), dim=-1)
 
 
 def graph_conv(x, edge_index, w_l, b_l, w_r):
     """PyG GraphConv (SAGPooling's default scorer): lin_l(sum_j x_j) + lin_r(x_i)."""
     n = x.size(0)
-    s = torch.zeros(n, x.size(1)).index_add_(0, edge_index[1], x[edge_index[0]])
+    s = torch.zeros(n, x.size(1), dtype=x.dtype).index_add_(0, edge_index[1], x[edge_index[0]])
     return F.linear(s, w_l, b_l) + F.linear(x, w_r)
 
 

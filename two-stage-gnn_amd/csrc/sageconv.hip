@@ -1,0 +1,249 @@
+// The torch_geometric-named SAGEConv layer as fused launches (BASELINE.json north_star: "SAGEConv ... drop-ins"; SURVEY §8 a15 —
+// no call site in the reference, PARITY UNPINNED: the arithmetic is PyG's documented  lin_l(mean_{j in N(i)} x_j) + lin_r(x_i)).
+//
+//   tsgnn_sage_conv_f32                one launch per layer and direction (sageconv_body.h): gather + scale + both products + bias
+//                                      [+ ReLU] [+ L2 normalise] [+ per-graph max / sum readouts of the output in the epilogue]
+//   tsgnn_sage_relu_readout_bwd_f32    du = (dxs + readout gradients) * [h > 0]: the row-wise pass between two layers' backward
+//   tsgnn_sage_readout_decode_f32      packed maxima / fixed-point sums of all layers -> sum_l [gmp || gap] and the arg-max rows
+//   tsgnn_sage_wgrad_reduce_oi_f32     slab partials of all layers -> nn.Linear-layout gradients (lin_l.weight, lin_l.bias, lin_r.weight)
+#include "common.h"
+#include "../../include/tsgnn.h"
+#include "sageconv_body.h"
+
+namespace {
+
+__global__ __launch_bounds__(512) void sage_conv_kernel(SageConvArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  sageconv_body(g, smem, blockIdx.x);
+}
+
+// du[r, c] = ( dxs[r, c] + [arg[b, c] == r] dread[b, c] + dread[b, F + c] / n_b ) * [h[r, c] > 0]      b = row_graph[r]
+// (backward of h = relu(u) feeding the next layer, the max readout and the mean readout, Code/sag/network.py:34-46 shape)
+__global__ __launch_bounds__(256) void sage_relu_readout_bwd_kernel(const float* __restrict__ h, int64_t ldh, const float* __restrict__ dxs,
+                                                                    int64_t lddxs, const float* __restrict__ dread, int64_t lddr,
+                                                                    const int* __restrict__ arg, const int* __restrict__ row_graph,
+                                                                    const int* __restrict__ graph_ptr, int64_t rows, int F, int relu,
+                                                                    float* __restrict__ du, int64_t lddu, const float* __restrict__ row_scale,
+                                                                    float* __restrict__ dus, int64_t lddus) {
+  const int F4 = F >> 2;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= rows * F4) return;
+  const int64_t r = idx / F4;
+  const int c = 4 * (int)(idx % F4);
+  const int b = row_graph[r];
+  const float4 hv = *reinterpret_cast<const float4*>(h + r * ldh + c);
+  float4 d = dxs ? *reinterpret_cast<const float4*>(dxs + r * lddxs + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  if (dread) {
+    const float inv_n = 1.0f / (float)max(graph_ptr[b + 1] - graph_ptr[b], 1);
+    const float4 dm = *reinterpret_cast<const float4*>(dread + (int64_t)b * lddr + c);
+    const float4 ds = *reinterpret_cast<const float4*>(dread + (int64_t)b * lddr + F + c);
+    const int4 a = *reinterpret_cast<const int4*>(arg + (int64_t)b * F + c);
+    const int ri = (int)r;
+    d.x += (a.x == ri ? dm.x : 0.f) + ds.x * inv_n;
+    d.y += (a.y == ri ? dm.y : 0.f) + ds.y * inv_n;
+    d.z += (a.z == ri ? dm.z : 0.f) + ds.z * inv_n;
+    d.w += (a.w == ri ? dm.w : 0.f) + ds.w * inv_n;
+  }
+  if (relu) {
+    d.x = hv.x > 0.f ? d.x : 0.f; d.y = hv.y > 0.f ? d.y : 0.f; d.z = hv.z > 0.f ? d.z : 0.f; d.w = hv.w > 0.f ? d.w : 0.f;
+  }
+  st_out(reinterpret_cast<float4*>(du + r * lddu + c), d);
+  if (dus) {                                              // the same rows scaled by 1 / deg: what the next launch GATHERS
+    const float sc = row_scale[r];
+    st_out(reinterpret_cast<float4*>(dus + r * lddus + c), make_float4(d.x * sc, d.y * sc, d.z * sc, d.w * sc));
+  }
+}
+
+// read[b, f] = sum_l max_l[b, f] ; read[b, F + f] = sum_l sum_l[b, f] / n_b ; arg[l, b, f] = the row that holds layer l's max;
+// the packed maxima and the integer sums are left ZERO for the next step (this launch is their only reader)
+__global__ __launch_bounds__(128) void sage_readout_decode_kernel(unsigned long long* __restrict__ packed, unsigned long long* __restrict__ sums,
+                                                                  const int* __restrict__ graph_ptr, int B, int L, int F,
+                                                                  float* __restrict__ read, int64_t ldr, int* __restrict__ arg) {
+  const int b = blockIdx.x;
+  const float inv_n = 1.0f / (float)max(graph_ptr[b + 1] - graph_ptr[b], 1);
+  for (int f = threadIdx.x; f < F; f += 128) {
+    float m = 0.f, s = 0.f;
+    for (int l = 0; l < L; ++l) {
+      const int64_t o = ((int64_t)l * B + b) * F + f;
+      const unsigned long long pk = packed[o];
+      const long long q = (long long)sums[o];
+      packed[o] = 0ull; sums[o] = 0ull;
+      m += pk ? ordered_f32((unsigned)(pk >> 32)) : 0.f;                 // (pk == 0: a graph without rows)
+      s += (float)((double)q * (1.0 / SC_RO_FIX)) * inv_n;
+      arg[o] = (int)(0xFFFFFFFFu - (unsigned)(pk & 0xFFFFFFFFull));
+    }
+    read[(int64_t)b * ldr + f] = m;
+    read[(int64_t)b * ldr + F + f] = s;
+  }
+}
+
+// ---- fragment-major copies of the weights (the B operand of sageconv_body.h)
+struct PackSet {
+  const float* w; int64_t ldw; int K, N; int kn;        // kn = 0: w[n * ldw + k] (nn.Linear's [out, in]); 1: w[k * ldw + n]
+  float4* out;                                          // [4 waves][16 steps][64 lanes]
+};
+struct PackArgs { PackSet s[16]; int nsets; };
+
+// out[(wv * 16 + u) * 64 + lane] = W[k = 8u + 4h + 0..3][n = 32 wv + i]  (lane = 32 h + i), zero beyond K / N
+__global__ __launch_bounds__(256) void sage_conv_pack_kernel(PackArgs a) {
+  const PackSet& s = a.s[blockIdx.y];
+  const int e = (int)blockIdx.x * 256 + (int)threadIdx.x;         // 0 .. 4095
+  const int lane = e & 63, u = (e >> 6) & 15, wv = e >> 10;
+  const int i = lane & 31, h = lane >> 5;
+  const int n = 32 * wv + i, k0 = 8 * u + 4 * h;
+  float v[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int k = k0 + c;
+    const bool ok = n < s.N && k < s.K;
+    v[c] = ok ? (s.kn ? s.w[(int64_t)k * s.ldw + n] : s.w[(int64_t)n * s.ldw + k]) : 0.f;
+  }
+  s.out[e] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+struct OiSet {
+  const float* ws; int nslab, K, N;     // slabs [nslab][K + 1][N] (row K = bias partial)
+  float* dw; int64_t lddw;              // dw[n * lddw + k]  (nn.Linear's [out, in])
+  float* db;                            // nullable [N]
+  int first_block;
+};
+struct OiArgs { OiSet s[8]; int nsets; };
+
+// block -> 64 consecutive entries (k, n) of one set's [K + 1][N] slab image, n fastest: coalesced slab reads, fixed slab order
+__global__ __launch_bounds__(64) void sage_wgrad_reduce_oi_kernel(OiArgs a) {
+  int si = 0;
+#pragma unroll
+  for (int t = 1; t < 8; ++t)
+    if (t < a.nsets && (int)blockIdx.x >= a.s[t].first_block) si = t;
+  const OiSet& s = a.s[si];
+  const int e = ((int)blockIdx.x - s.first_block) * 64 + (int)threadIdx.x;
+  const int tot = (s.K + 1) * s.N;
+  if (e >= tot) return;
+  const int64_t stride = (int64_t)tot;
+  float acc = 0.f;
+  int sl = 0;
+  for (; sl + 8 <= s.nslab; sl += 8) {                  // eight slab loads in flight
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = s.ws[(int64_t)(sl + q) * stride + e];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc += v[q];
+  }
+  for (; sl < s.nslab; ++sl) acc += s.ws[(int64_t)sl * stride + e];
+  const int k = e / s.N, n = e % s.N;
+  if (k < s.K) s.dw[(int64_t)n * s.lddw + k] = acc;
+  else if (s.db) s.db[n] = acc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tsgnn_sage_conv_supported(int K, int N) { return (K >= 1 && K <= 128 && N >= 1 && N <= 128) ? 1 : 0; }
+
+/* desc (HOST memory): [nsets <= 16, nsets x (w, ldw, K, N, kn, out)]: fragment-major copies (16,384 floats each) of weight matrices */
+int tsgnn_sage_conv_pack_f32(const int64_t* desc, tsgnn_stream_t stream) {
+  if (!desc) return TSGNN_EINVAL;
+  const int nsets = (int)desc[0];
+  if (nsets <= 0 || nsets > 16) return TSGNN_EINVAL;
+  PackArgs a{};
+  a.nsets = nsets;
+  const int64_t* d = desc + 1;
+  for (int t = 0; t < nsets; ++t, d += 6) {
+    PackSet& s = a.s[t];
+    s.w = reinterpret_cast<const float*>(d[0]); s.ldw = d[1]; s.K = (int)d[2]; s.N = (int)d[3]; s.kn = (int)d[4];
+    s.out = reinterpret_cast<float4*>(d[5]);
+    if (!s.w || !s.out || !tsgnn_sage_conv_supported(s.K, s.N) || s.ldw < (s.kn ? s.N : s.K)) return TSGNN_EINVAL;
+    if (reinterpret_cast<uintptr_t>(s.out) & 15) return TSGNN_EUNSUPPORTED;
+  }
+  TSGNN_KNAME("sage_conv_pack_kernel");
+  sage_conv_pack_kernel<<<dim3(16, (unsigned)nsets), 256, 0, stream>>>(a);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+int tsgnn_sage_conv_f32(const int* ell, int ell_w, const int* tail_ptr, const int* tail_col, const float* xg, int64_t ldxg, const float* xs,
+                        int64_t ldxs, const float* dst_scale, const float* wl_pk, const float* wr_pk,
+                        const float* bias, float* out, int64_t ldo, float* zout, int64_t ldz, float* rinv,
+                        int64_t rows, int K, int N, int relu_out, int normalize, unsigned long long* ro_packed,
+                        unsigned long long* ro_sums, const int* ro_row_graph, const int* ro_graph_ptr, tsgnn_stream_t stream) {
+  if (!ell || !xg || !xs || !wl_pk || !wr_pk || !out || rows < 0 || K <= 0 || N <= 0) return TSGNN_EINVAL;
+  if ((tail_ptr == nullptr) != (tail_col == nullptr)) return TSGNN_EINVAL;
+  if ((ro_packed == nullptr) != (ro_sums == nullptr) || (ro_packed && (!ro_row_graph || !ro_graph_ptr))) return TSGNN_EINVAL;
+  if (ell_w != 4 && ell_w != 8 && ell_w != 16) return TSGNN_EUNSUPPORTED;
+  if (!tsgnn_sage_conv_supported(K, N)) return TSGNN_EUNSUPPORTED;
+  const int K4 = (K + 3) / 4 * 4;
+  if ((ldxg % 4) || (ldxs % 4) || ldxg < K4 || ldxs < K4 || ldo < N || (zout && ((ldz % 4) || ldz < K4))) return TSGNN_EUNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(ell) | reinterpret_cast<uintptr_t>(xg) | reinterpret_cast<uintptr_t>(xs) | reinterpret_cast<uintptr_t>(zout) |
+       reinterpret_cast<uintptr_t>(wl_pk) | reinterpret_cast<uintptr_t>(wr_pk)) & 15)
+    return TSGNN_EUNSUPPORTED;
+  if (rows == 0) return TSGNN_OK;
+  if (rows >= (int64_t)1 << 31) return TSGNN_EUNSUPPORTED;
+  SageConvArgs g{xg, ldxg, xs, ldxs, ell, ell_w, tail_ptr, tail_col, dst_scale, reinterpret_cast<const float4*>(wl_pk),
+                 reinterpret_cast<const float4*>(wr_pk), bias, out, ldo, zout, ldz, rinv, rows, K, N, relu_out, normalize, ro_packed, ro_sums,
+                 ro_row_graph, ro_graph_ptr};
+  constexpr size_t lds = sageconv_lds_bytes();
+  static bool attr = false;
+  if (!attr && lds > 48 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sage_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  TSGNN_KNAME("sage_conv_kernel");
+  sage_conv_kernel<<<(unsigned)ceil_div64(rows, 32), 512, lds, stream>>>(g);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+int tsgnn_sage_relu_readout_bwd_f32(const float* h, int64_t ldh, const float* dxs, int64_t lddxs, const float* dread, int64_t lddr,
+                                    const int* arg, const int* row_graph, const int* graph_ptr, int64_t rows, int F, int relu, float* du,
+                                    int64_t lddu, const float* row_scale, float* dus, int64_t lddus, tsgnn_stream_t stream) {
+  if (!h || !du || rows < 0 || F <= 0 || (dread && (!arg || !row_graph || !graph_ptr)) || (dus && (!row_scale || (lddus % 4))))
+    return TSGNN_EINVAL;
+  if ((F % 4) || (ldh % 4) || (lddu % 4) || (dxs && (lddxs % 4)) || (dread && (lddr % 4)) ||
+      ((reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(du) | reinterpret_cast<uintptr_t>(dxs) | reinterpret_cast<uintptr_t>(dread) |
+        reinterpret_cast<uintptr_t>(arg)) & 15))
+    return TSGNN_EUNSUPPORTED;
+  if (!row_graph) return TSGNN_EINVAL;
+  if (rows == 0) return TSGNN_OK;
+  const int64_t n = rows * (F / 4);
+  TSGNN_KNAME("sage_relu_readout_bwd_kernel");
+  sage_relu_readout_bwd_kernel<<<(unsigned)ceil_div64(n, 256), 256, 0, stream>>>(h, ldh, dxs, lddxs, dread, lddr, arg, row_graph, graph_ptr, rows, F,
+                                                                              relu, du, lddu, row_scale, dus, lddus);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+int tsgnn_sage_readout_decode_f32(unsigned long long* packed, unsigned long long* sums, const int* graph_ptr, int B, int L, int F, float* read,
+                                  int64_t ldr, int* arg, tsgnn_stream_t stream) {
+  if (!packed || !sums || !graph_ptr || !read || !arg || B <= 0 || L <= 0 || F <= 0 || ldr < 2 * F) return TSGNN_EINVAL;
+  TSGNN_KNAME("sage_readout_decode_kernel");
+  sage_readout_decode_kernel<<<(unsigned)B, 128, 0, stream>>>(packed, sums, graph_ptr, B, L, F, read, ldr, arg);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+/* desc (HOST memory): [nsets, nsets x (ws, nslab, K, N, dw_oi, lddw, db)] — slab sets in the layout of tsgnn_linear_wgrad_f32
+ * (dw == NULL form), summed in slab order and written transposed: dw_oi[n * lddw + k]; db nullable. */
+int tsgnn_sage_wgrad_reduce_oi_f32(const int64_t* desc, tsgnn_stream_t stream) {
+  if (!desc) return TSGNN_EINVAL;
+  const int nsets = (int)desc[0];
+  if (nsets <= 0 || nsets > 8) return TSGNN_EINVAL;
+  OiArgs a{};
+  a.nsets = nsets;
+  int blocks = 0;
+  const int64_t* d = desc + 1;
+  for (int t = 0; t < nsets; ++t, d += 7) {
+    OiSet& s = a.s[t];
+    s.ws = reinterpret_cast<const float*>(d[0]); s.nslab = (int)d[1]; s.K = (int)d[2]; s.N = (int)d[3];
+    s.dw = reinterpret_cast<float*>(d[4]); s.lddw = d[5]; s.db = reinterpret_cast<float*>(d[6]);
+    if (!s.ws || !s.dw || s.nslab <= 0 || s.K <= 0 || s.N <= 0 || s.lddw < s.K) return TSGNN_EINVAL;
+    s.first_block = blocks;
+    blocks += ((s.K + 1) * s.N + 63) / 64;
+  }
+  TSGNN_KNAME("sage_wgrad_reduce_oi_kernel");
+  sage_wgrad_reduce_oi_kernel<<<(unsigned)blocks, 64, 0, stream>>>(a);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+}  // extern "C"

@@ -33,20 +33,26 @@ _graph_cache = {}
 _gat_graph_cache = {}
 
 
-def graph_of(edge_index, num_nodes, check_symmetry=False):
+def graph_of(edge_index, num_nodes, check_symmetry=False, sizes=None):
     """CSR (rows = targets) of a PyG edge list, cached per edge_index tensor.  ``check_symmetry``: also find out (once per
     edge list, at ingest) whether every edge has its reverse — all TU datasets do —, in which case backward passes reuse
-    the CSR instead of building its transpose."""
+    the CSR instead of building its transpose.  ``sizes`` (np.int64[B], from PyG's ``batch``): the graphs of the mini-batch, for the
+    operators that need per-graph structure (readouts, pooling)."""
     if not edge_index.is_cuda:
         raise RuntimeError("two_stage_gnn_amd operators run on the GPU only (no CPU fallback)")
-    key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, int(num_nodes))
+    skey = None if sizes is None else np.asarray(sizes, dtype=np.int64).tobytes()
+    key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, int(num_nodes), skey)
     hit = _graph_cache.get(key)
     if hit is not None and hit[0]() is edge_index:
         g = hit[1]
         if check_symmetry and not getattr(g, "_sym_checked", False):
             _check_symmetry(g, edge_index, num_nodes)
         return g
-    g = GraphBatch.from_edge_index(edge_index, num_nodes, ghosts=False)
+    if sizes is None:
+        g = GraphBatch.from_edge_index(edge_index, num_nodes, ghosts=False)
+    else:
+        sizes = np.asarray(sizes, dtype=np.int64)
+        g = GraphBatch.from_edge_index(edge_index, num_nodes, sizes=sizes, nmax=int(max(1, sizes.max())), ghosts=False)
     if check_symmetry:
         _check_symmetry(g, edge_index, num_nodes)
     if len(_graph_cache) > 16:
@@ -349,37 +355,54 @@ def _mean_aggregate(x, g):
 
 
 class SAGEConv(nn.Module):
-    """PyG SAGEConv (mean aggregator): lin_l(mean_j x_j) + lin_r(x_i).  No call site in the reference."""
+    """PyG SAGEConv (mean aggregator): lin_l(mean_j x_j) + lin_r(x_i) [, L2-normalised].  No call site in the reference (north_star
+    names it; SURVEY 8 a15).  ONE launch forward (pyg_sage.py / csrc/sageconv.hip: gather + 1/deg + both products + bias + normalise);
+    backward: weight-gradient slabs, one reduction into nn.Linear's layout, the input gradient through the same fused kernel."""
 
-    def __init__(self, in_channels, out_channels, normalize=False, bias=True, **kwargs):
+    aggr = "mean"
+
+    def __init__(self, in_channels, out_channels, normalize=False, root_weight=True, bias=True, **kwargs):
         super().__init__()
-        self.normalize = normalize
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.normalize, self.root_weight = normalize, root_weight
         dev = _default_device()
         self.lin_l = nn.Linear(in_channels, out_channels, bias=bias).to(dev)
-        self.lin_r = nn.Linear(in_channels, out_channels, bias=False).to(dev)
+        if root_weight:
+            self.lin_r = nn.Linear(in_channels, out_channels, bias=False).to(dev)
+
+    def _graph(self, x, edge_index):
+        return edge_index if isinstance(edge_index, GraphBatch) else graph_of(edge_index, x.size(0), check_symmetry=True)
 
     def forward(self, x, edge_index):
-        g = edge_index if isinstance(edge_index, GraphBatch) else graph_of(edge_index, x.size(0))
-        agg = _mean_aggregate(x, g)
-        out = linear(agg, self.lin_l.weight.t(), self.lin_l.bias) + linear(x, self.lin_r.weight.t())
+        from . import pyg_sage as ps
+        g = self._graph(x, edge_index)
+        if self.root_weight and g.val is None and self.out_channels % 4 == 0 and ps.conv_ok(self.in_channels, self.out_channels):
+            return ps.sage_conv(x, g, self.lin_l.weight, self.lin_l.bias, self.lin_r.weight, mean=self.aggr == "mean",
+                                normalize=self.normalize)
+        agg = mp.aggregate(x, g, val=None)
+        if self.aggr == "mean":
+            agg = agg * _inv_degree(g)
+        out = mp.linear_oi(agg, self.lin_l.weight, self.lin_l.bias)
+        if self.root_weight:
+            out = out + mp.linear_oi(x, self.lin_r.weight)
         if self.normalize:
-            out = mp.linear_l2norm(out, torch.eye(out.size(1), device=out.device), None, normalize=True)
+            out = torch.nn.functional.normalize(out, p=2.0, dim=-1)
         return out
 
 
-class GraphConv(nn.Module):
-    """PyG GraphConv: lin_l(sum_j x_j) + lin_r(x_i) — SAGPooling's default scorer."""
+class GraphConv(SAGEConv):
+    """PyG GraphConv: lin_l(sum_j x_j) + lin_r(x_i) — SAGPooling's default scorer.  The same fused launch without the 1/deg scale."""
+
+    aggr = "add"
 
     def __init__(self, in_channels, out_channels, aggr="add", bias=True, **kwargs):
-        super().__init__()
-        dev = _default_device()
-        self.lin_l = nn.Linear(in_channels, out_channels, bias=bias).to(dev)
-        self.lin_r = nn.Linear(in_channels, out_channels, bias=False).to(dev)
+        super().__init__(in_channels, out_channels, normalize=False, root_weight=True, bias=bias)
+        self.aggr = aggr
 
     def forward(self, x, edge_index, edge_weight=None):
-        g = edge_index if isinstance(edge_index, GraphBatch) else graph_of(edge_index, x.size(0))
-        agg = mp.aggregate(x, g)
-        return linear(agg, self.lin_l.weight.t(), self.lin_l.bias) + linear(x, self.lin_r.weight.t())
+        if edge_weight is not None:
+            raise NotImplementedError("GraphConv(edge_weight=) has no call site (Code/sag passes none)")
+        return super().forward(x, edge_index)
 
 
 class GATConv(nn.Module):
@@ -532,3 +555,52 @@ def dense_diff_pool(x, adj, s, mask=None, eps=1e-15):
     link = torch.norm(adj - sst, p=2) / adj.numel()
     ent = (-s * torch.log(s + eps)).sum(dim=-1).mean()
     return out, out_adj, link, ent
+
+
+# ----------------------------------------------------------------------------- graph classifiers on the PyG-named layers
+class SageNet(nn.Module):
+    """BASELINE configs 1-2 as worded ("MUTAG SAGEConv 2-layer h=64", "PROTEINS SAGEConv 3-layer h=128"): the shape of the reference's one
+    PyG network (Code/sag/network.py:9-53 — conv + ReLU per layer, [gmp || gap] of every layer summed, lin1 / lin2 / lin3, log_softmax)
+    with SAGEConv layers and no pooling.  ``fused=True``: the conv stack is ONE autograd node (pyg_sage._SageStack: one launch per
+    layer forward, readouts in the layers' epilogues) and the head one launch each way; ``fused=False`` composes the drop-in modules."""
+
+    def __init__(self, num_features, nhid, num_classes, num_layers=3, dropout_ratio=0.0, fused=True):
+        super().__init__()
+        self.num_features, self.nhid, self.num_classes, self.num_layers = num_features, nhid, num_classes, num_layers
+        self.dropout_ratio, self.fused = dropout_ratio, fused
+        self.convs = nn.ModuleList([SAGEConv(num_features if l == 0 else nhid, nhid) for l in range(num_layers)])
+        dev = _default_device()
+        self.lin1 = nn.Linear(nhid * 2, nhid).to(dev)
+        self.lin2 = nn.Linear(nhid, nhid // 2).to(dev)
+        self.lin3 = nn.Linear(nhid // 2, num_classes).to(dev)
+
+    def graph(self, data):
+        x = data.x
+        if isinstance(data.edge_index, GraphBatch):
+            return data.edge_index
+        batch = getattr(data, "batch", None)
+        return graph_of(data.edge_index, x.size(0), check_symmetry=True, sizes=segment_sizes(batch, x.size(0)))
+
+    def head(self, x):
+        if mp.mlp3_ok(x, self.lin1, self.lin2, self.lin3):
+            return mp.mlp3_log_softmax(x, self.lin1, self.lin2, self.lin3, self.dropout_ratio, self.training)
+        x = relu(mp.linear_oi(x, self.lin1.weight, self.lin1.bias))
+        x = torch.nn.functional.dropout(x, p=self.dropout_ratio, training=self.training)
+        x = relu(mp.linear_oi(x, self.lin2.weight, self.lin2.bias))
+        return torch.nn.functional.log_softmax(mp.linear_oi(x, self.lin3.weight, self.lin3.bias), dim=-1)
+
+    def forward(self, data):
+        from . import pyg_sage as ps
+        g = self.graph(data)
+        x = data.x
+        if self.fused and ps.stack_ok(g, list(self.convs), x):
+            return self.head(ps.sage_stack(x, g, list(self.convs)))
+        batch = getattr(data, "batch", None)
+        if batch is None:
+            batch = torch.zeros(x.size(0), dtype=torch.int64, device=x.device)
+        out = None
+        for conv in self.convs:
+            x = relu(conv(x, g))
+            r = torch.cat([global_max_pool(x, batch), global_mean_pool(x, batch)], dim=1)
+            out = r if out is None else out + r
+        return self.head(out)

@@ -131,3 +131,20 @@ def aggregation_bytes(n_rows, nnz, feat, weighted=False):
     """Algorithmic HBM bytes of one aggregation pass:
     4NF (read X) + 4NF (write Y) + 4E (col) + 4(N+1) (rowptr) [+4E weights]."""
     return 8 * n_rows * feat + 4 * nnz + 4 * (n_rows + 1) + (4 * nnz if weighted else 0)
+
+
+def to_pyg(hb, device, pad_features=True):
+    """host batch -> what a torch_geometric DataLoader hands a model: (x [N, F], edge_index int64 [2, E] (row 0 = source, row 1 = target),
+    batch int64 [N], label int64 [B]) on `device`.  pad_features: feature rows padded with zero columns to 16 bytes (what a CSR-native
+    collate emits, like to_device() for the dense path); False: exactly [N, fin]."""
+    sizes = hb["sizes"]
+    n = int(sizes.sum())
+    rp, col = hb["rowptr"][: n + 1], hb["col"]
+    dst = np.repeat(np.arange(n, dtype=np.int64), np.diff(rp))
+    ei = torch.from_numpy(np.stack([col[: int(rp[-1])].astype(np.int64), dst]))
+    batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.from_numpy(np.asarray(sizes, dtype=np.int64)))
+    fin = hb["fin"]
+    ld = (fin + 3) // 4 * 4 if pad_features else fin
+    x = torch.zeros(n, ld, dtype=torch.float32)
+    x[:, :fin] = torch.from_numpy(hb["x"])
+    return x.to(device), ei.to(device), batch.to(device), torch.from_numpy(hb["label"]).to(device)
