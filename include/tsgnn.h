@@ -619,6 +619,15 @@ int tsgnn_mlp3_bwd2_nll_f32(const float* x, int64_t ldx, const float* w1, const 
                             int D1, int D2, int C, float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3, float* dx,
                             int64_t lddx, float* ws, tsgnn_stream_t stream);
 
+/* the same two launches that also leave |grad|^2 shares: normparts[tsgnn_mlp3_bwd2_norm_blocks(D1, D2)], entry k = the sum of squares
+ * of the gradient entries block k of the weights launch wrote (label != NULL: the nll form, dlogp ignored) — the head's part of the
+ * norm for tsgnn_adam_from_partials_f32 when its six gradients go straight into the optimiser's flat bucket */
+int tsgnn_mlp3_bwd2_norm_blocks(int D1, int D2);
+int tsgnn_mlp3_bwd2_np_f32(const float* x, int64_t ldx, const float* w1, const float* w2, const float* w3, const float* a1,
+                           const float* a2, const float* logp, const float* dlogp, const int64_t* label, float* loss, float keep_scale, int B,
+                           int D0, int D1, int D2, int C, float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3, float* dx,
+                           int64_t lddx, float* ws, float* normparts, tsgnn_stream_t stream);
+
 /* ---------------------------------------------------------------- DiffPool link-prediction side loss (linkpred.hip) */
 
 /* encoders.py:416-440 for adj_hop = 1, value and gradient in one pass, no [B,N,N] tensor:
@@ -1029,8 +1038,11 @@ int tsgnn_sage_relu_readout_bwd_f32(const float* h, int64_t ldh, const float* dx
 int tsgnn_sage_readout_decode_f32(unsigned long long* packed, unsigned long long* sums, const int* graph_ptr, int B, int L, int F, float* read,
                                   int64_t ldr, int* arg, tsgnn_stream_t stream);
 /* desc (HOST memory): [nsets <= 8, nsets x (ws, nslab, K, N, dw_oi, lddw, db)]: slab sets of tsgnn_linear_wgrad_f32 (dw == NULL form) summed
- * in slab order into nn.Linear's layout dw_oi[n * lddw + k] (+ db[n], nullable): all layers' lin_l / lin_r gradients in one launch */
-int tsgnn_sage_wgrad_reduce_oi_f32(const int64_t* desc, tsgnn_stream_t stream);
+ * in slab order into nn.Linear's layout dw_oi[n * lddw + k] (+ db[n], nullable): all layers' lin_l / lin_r gradients in one launch.
+ * normparts (nullable; tsgnn_sage_wgrad_reduce_oi_blocks(desc) entries): block k's sum of squares of what it wrote; step_state
+ * (nullable): step_state[0] += 1 — both as tsgnn_wgrad_reduce_multi_f32, for tsgnn_adam_from_partials_f32 */
+int tsgnn_sage_wgrad_reduce_oi_blocks(const int64_t* desc);
+int tsgnn_sage_wgrad_reduce_oi_f32(const int64_t* desc, float* normparts, float* step_state, tsgnn_stream_t stream);
 
 #ifdef __cplusplus
 }

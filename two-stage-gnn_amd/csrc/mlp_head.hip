@@ -357,9 +357,21 @@ __global__ __launch_bounds__(MR_T) void mlp3_bwd_rows_kernel(Mlp3Bwd p, float* _
 constexpr int MW_TILE = 4;                   // weight rows per block
 __global__ __launch_bounds__(256) void mlp3_bwd_weights_kernel(Mlp3Bwd p, const float* __restrict__ dlgg, const float* __restrict__ dz2g,
                                                               const float* __restrict__ dz1g, int nW1, int nW2,
-                                                              const int64_t* __restrict__ nll_label, float* __restrict__ nll_loss) {
+                                                              const int64_t* __restrict__ nll_label, float* __restrict__ nll_loss,
+                                                              float* __restrict__ normparts) {
   extern __shared__ __attribute__((aligned(16))) float smem[];      // [B][MW_TILE] operand tile
+  __shared__ float nred[4];
   const int tid = threadIdx.x, bid = blockIdx.x;
+  float sq = 0.f;                                                    // this thread's share of the squares of what the block writes
+  // normparts (nullable): block k leaves the sum of squares of the gradient entries it wrote (dW tile rows + their bias entries; the
+  // last block: dW3 + db3) — the shares tsgnn_adam_from_partials_f32 adds up instead of a norm pass over the gradient
+  auto leave_share = [&]() {
+    if (!normparts) return;
+    sq = wave_sum(sq);
+    if ((tid & 63) == 0) nred[tid >> 6] = sq;
+    __syncthreads();
+    if (tid == 0) normparts[bid] = (nred[0] + nred[1]) + (nred[2] + nred[3]);
+  };
   const int B = p.B, D0 = p.D0, D1 = p.D1, D2 = p.D2, C = p.C;
   if (bid < nW1 + nW2) {
     const bool first = bid < nW1;
@@ -403,7 +415,7 @@ __global__ __launch_bounds__(256) void mlp3_bwd_weights_kernel(Mlp3Bwd p, const 
         const int u = idx / min(256, Dc - 4 * cb), c = 4 * cb + idx % min(256, Dc - 4 * cb);
         const float v = (part[(0 * MW_TILE + u) * Dc + c] + part[(1 * MW_TILE + u) * Dc + c]) +
                         (part[(2 * MW_TILE + u) * Dc + c] + part[(3 * MW_TILE + u) * Dc + c]);
-        if (r0 + u < Dr) dw[(int64_t)(r0 + u) * Dc + c] = v;
+        if (r0 + u < Dr) { dw[(int64_t)(r0 + u) * Dc + c] = v; sq = fmaf(v, v, sq); }
       }
       __syncthreads();
     }
@@ -411,7 +423,9 @@ __global__ __launch_bounds__(256) void mlp3_bwd_weights_kernel(Mlp3Bwd p, const 
       float s = 0.f;
       for (int b = 0; b < B; ++b) s += smem[b * MW_TILE + tid];
       (first ? p.db1 : p.db2)[r0 + tid] = s;
+      sq = fmaf(s, s, sq);
     }
+    leave_share();
     return;
   }
   // dW3[c, k] = sum_b dlogits[b, c] a2[b, k]: the row loop is spread over the block (one thread per output walked all B rows
@@ -445,6 +459,7 @@ __global__ __launch_bounds__(256) void mlp3_bwd_weights_kernel(Mlp3Bwd p, const 
       float sum = 0.f;
       for (int q = 0; q < nbl; ++q) sum += part[(size_t)q * C * D2 + idx];
       p.dw3[idx] = sum;
+      sq = fmaf(sum, sum, sq);
     }
   } else {
     for (int idx = tid; idx < C * D2; idx += 256) {
@@ -453,6 +468,7 @@ __global__ __launch_bounds__(256) void mlp3_bwd_weights_kernel(Mlp3Bwd p, const 
 #pragma unroll 16
       for (int b = 0; b < B; ++b) sum = fmaf(dlgg[(int64_t)b * C + c], p.a2[(int64_t)b * D2 + k], sum);
       p.dw3[idx] = sum;
+      sq = fmaf(sum, sum, sq);
     }
   }
   // db3: 16 row lanes per class through LDS (one thread per class walking all rows from global memory was a chain of B loads)
@@ -470,8 +486,10 @@ __global__ __launch_bounds__(256) void mlp3_bwd_weights_kernel(Mlp3Bwd p, const 
 #pragma unroll
       for (int q = 0; q < 16; ++q) t += pr[q * C + tid];
       p.db3[tid] = t;
+      sq = fmaf(t, t, sq);
     }
   }
+  leave_share();
   if (nll_label != nullptr) {                                          // loss = -mean_b logp[b, label_b], 256 row lanes then in order
     __syncthreads();
     float s = 0.f;
@@ -581,7 +599,7 @@ int tsgnn_mlp3_bwd_f32(const float* x, int64_t ldx, const float* w1, const float
 static int mlp3_bwd2_launch(const float* x, int64_t ldx, const float* w1, const float* w2, const float* w3, const float* a1,
                             const float* a2, const float* logp, const float* dlogp, float keep_scale, int B, int D0, int D1, int D2, int C,
                             float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3, float* dx, int64_t lddx, float* ws,
-                            const int64_t* nll_label, float* nll_loss, tsgnn_stream_t stream) {
+                            const int64_t* nll_label, float* nll_loss, float* normparts, tsgnn_stream_t stream) {
   if (!x || !w1 || !w2 || !w3 || !a1 || !a2 || !logp || (!dlogp && !nll_label) || !dw1 || !db1 || !dw2 || !db2 || !dw3 || !db3 || !ws ||
       ldx < D0 || (dx && lddx < D0) || (nll_label && !nll_loss))
     return TSGNN_EINVAL;
@@ -597,7 +615,7 @@ static int mlp3_bwd2_launch(const float* x, int64_t ldx, const float* w1, const 
   if (lds_w < sizeof(float) * 1024 * (size_t)C) lds_w = sizeof(float) * 1024 * (size_t)C;       // dW3 block: [256 / (D2/4)][C][D2] partials
   if (lds_w > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp3_bwd_weights_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w);
-  mlp3_bwd_weights_kernel<<<(unsigned)(nW1 + nW2 + 1), 256, lds_w, stream>>>(p, dlgg, dz2g, dz1g, nW1, nW2, nll_label, nll_loss);
+  mlp3_bwd_weights_kernel<<<(unsigned)(nW1 + nW2 + 1), 256, lds_w, stream>>>(p, dlgg, dz2g, dz1g, nW1, nW2, nll_label, nll_loss, normparts);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }
@@ -607,7 +625,7 @@ int tsgnn_mlp3_bwd2_f32(const float* x, int64_t ldx, const float* w1, const floa
                         float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3, float* dx, int64_t lddx, float* ws,
                         tsgnn_stream_t stream) {
   return mlp3_bwd2_launch(x, ldx, w1, w2, w3, a1, a2, logp, dlogp, keep_scale, B, D0, D1, D2, C, dw1, db1, dw2, db2, dw3, db3, dx, lddx,
-                          ws, nullptr, nullptr, stream);
+                          ws, nullptr, nullptr, nullptr, stream);
 }
 
 /* the same with F.nll_loss(logp, label) (mean) folded in: its gradient is formed inside the rows kernel and the loss value is
@@ -618,7 +636,22 @@ int tsgnn_mlp3_bwd2_nll_f32(const float* x, int64_t ldx, const float* w1, const 
                             int64_t lddx, float* ws, tsgnn_stream_t stream) {
   if (!label || !loss) return TSGNN_EINVAL;
   return mlp3_bwd2_launch(x, ldx, w1, w2, w3, a1, a2, logp, nullptr, keep_scale, B, D0, D1, D2, C, dw1, db1, dw2, db2, dw3, db3, dx, lddx,
-                          ws, label, loss, stream);
+                          ws, label, loss, nullptr, stream);
+}
+
+/* blocks of the weights launch of tsgnn_mlp3_bwd2*_f32 = entries of normparts */
+int tsgnn_mlp3_bwd2_norm_blocks(int D1, int D2) { return (D1 + MW_TILE - 1) / MW_TILE + (D2 + MW_TILE - 1) / MW_TILE + 1; }
+
+/* tsgnn_mlp3_bwd2_f32 / _nll_f32 (label != NULL: the nll form, dlogp ignored) that also leaves, per block of its weights launch, the
+ * sum of squares of the gradient entries that block wrote (normparts[tsgnn_mlp3_bwd2_norm_blocks(D1, D2)]): the head's shares of
+ * |grad|^2 for tsgnn_adam_from_partials_f32 when all six gradients are written straight into the optimiser's flat bucket */
+int tsgnn_mlp3_bwd2_np_f32(const float* x, int64_t ldx, const float* w1, const float* w2, const float* w3, const float* a1,
+                           const float* a2, const float* logp, const float* dlogp, const int64_t* label, float* loss, float keep_scale, int B,
+                           int D0, int D1, int D2, int C, float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3, float* dx,
+                           int64_t lddx, float* ws, float* normparts, tsgnn_stream_t stream) {
+  if (!normparts || (label && !loss)) return TSGNN_EINVAL;
+  return mlp3_bwd2_launch(x, ldx, w1, w2, w3, a1, a2, logp, label ? nullptr : dlogp, keep_scale, B, D0, D1, D2, C, dw1, db1, dw2, db2, dw3, db3,
+                          dx, lddx, ws, label, loss, normparts, stream);
 }
 
 }  // extern "C"

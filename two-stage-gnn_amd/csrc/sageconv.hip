@@ -107,7 +107,7 @@ struct OiSet {
   float* db;                            // nullable [N]
   int first_block;
 };
-struct OiArgs { OiSet s[8]; int nsets; };
+struct OiArgs { OiSet s[8]; int nsets; float* normparts; float* step_state; };
 
 // block -> 64 consecutive entries (k, n) of one set's [K + 1][N] slab image, n fastest: coalesced slab reads, fixed slab order
 __global__ __launch_bounds__(64) void sage_wgrad_reduce_oi_kernel(OiArgs a) {
@@ -118,21 +118,28 @@ __global__ __launch_bounds__(64) void sage_wgrad_reduce_oi_kernel(OiArgs a) {
   const OiSet& s = a.s[si];
   const int e = ((int)blockIdx.x - s.first_block) * 64 + (int)threadIdx.x;
   const int tot = (s.K + 1) * s.N;
-  if (e >= tot) return;
-  const int64_t stride = (int64_t)tot;
-  float acc = 0.f;
-  int sl = 0;
-  for (; sl + 8 <= s.nslab; sl += 8) {                  // eight slab loads in flight
-    float v[8];
+  float sq = 0.f;
+  if (e < tot) {
+    const int64_t stride = (int64_t)tot;
+    float acc = 0.f;
+    int sl = 0;
+    for (; sl + 8 <= s.nslab; sl += 8) {                // eight slab loads in flight
+      float v[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) v[q] = s.ws[(int64_t)(sl + q) * stride + e];
+      for (int q = 0; q < 8; ++q) v[q] = s.ws[(int64_t)(sl + q) * stride + e];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) acc += v[q];
+      for (int q = 0; q < 8; ++q) acc += v[q];
+    }
+    for (; sl < s.nslab; ++sl) acc += s.ws[(int64_t)sl * stride + e];
+    const int k = e / s.N, n = e % s.N;
+    if (k < s.K) { s.dw[(int64_t)n * s.lddw + k] = acc; sq = acc * acc; }
+    else if (s.db) { s.db[n] = acc; sq = acc * acc; }
   }
-  for (; sl < s.nslab; ++sl) acc += s.ws[(int64_t)sl * stride + e];
-  const int k = e / s.N, n = e % s.N;
-  if (k < s.K) s.dw[(int64_t)n * s.lddw + k] = acc;
-  else if (s.db) s.db[n] = acc;
+  if (a.normparts) {                                    // this block's share of |grad|^2 (summed in fixed order by the optimiser)
+    sq = wave_sum(sq);
+    if (threadIdx.x == 0) a.normparts[blockIdx.x] = sq;
+  }
+  if (a.step_state && blockIdx.x == 0 && threadIdx.x == 0) a.step_state[0] += 1.f;   // optimiser step counter, ahead of the update kernel
 }
 
 }  // namespace
@@ -224,12 +231,19 @@ int tsgnn_sage_readout_decode_f32(unsigned long long* packed, unsigned long long
 
 /* desc (HOST memory): [nsets, nsets x (ws, nslab, K, N, dw_oi, lddw, db)] — slab sets in the layout of tsgnn_linear_wgrad_f32
  * (dw == NULL form), summed in slab order and written transposed: dw_oi[n * lddw + k]; db nullable. */
-int tsgnn_sage_wgrad_reduce_oi_f32(const int64_t* desc, tsgnn_stream_t stream) {
+int tsgnn_sage_wgrad_reduce_oi_blocks(const int64_t* desc) {
+  if (!desc || desc[0] <= 0 || desc[0] > 8) return -1;
+  int blocks = 0;
+  for (int t = 0; t < (int)desc[0]; ++t) blocks += (((int)desc[1 + 7 * t + 2] + 1) * (int)desc[1 + 7 * t + 3] + 63) / 64;
+  return blocks;
+}
+
+int tsgnn_sage_wgrad_reduce_oi_f32(const int64_t* desc, float* normparts, float* step_state, tsgnn_stream_t stream) {
   if (!desc) return TSGNN_EINVAL;
   const int nsets = (int)desc[0];
   if (nsets <= 0 || nsets > 8) return TSGNN_EINVAL;
   OiArgs a{};
-  a.nsets = nsets;
+  a.nsets = nsets; a.normparts = normparts; a.step_state = step_state;
   int blocks = 0;
   const int64_t* d = desc + 1;
   for (int t = 0; t < nsets; ++t, d += 7) {

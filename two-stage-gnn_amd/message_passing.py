@@ -424,6 +424,7 @@ class _Mlp3LogSoftmax(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, w3, b3, keep, keep_scale, drop=None):
         x = _check(x)
+        _w_in = (w1, w2, w3)                              # the parameters as given (the gradient sink is keyed by their storage)
         w1, w2, w3 = w1.contiguous(), w2.contiguous(), w3.contiguous()
         B, D0, D1, D2, C = x.size(0), w1.size(1), w1.size(0), w2.size(0), w3.size(0)
         a1, a2, logp = _f32(B, D1, device=x.device), _f32(B, D2, device=x.device), _f32(B, C, device=x.device)
@@ -437,6 +438,7 @@ class _Mlp3LogSoftmax(torch.autograd.Function):
         ctx.save_for_backward(x, w1, w2, w3, a1, a2, logp)
         ctx.keep_scale = float(keep_scale) if keep is not None else 1.0
         ctx.has_b = (b1 is not None, b2 is not None, b3 is not None)
+        ctx.params = (_w_in[0], b1, _w_in[1], b2, _w_in[2], b3)
         return logp
 
     @staticmethod
@@ -444,14 +446,32 @@ class _Mlp3LogSoftmax(torch.autograd.Function):
         x, w1, w2, w3, a1, a2, logp = ctx.saved_tensors
         dev = x.device
         B, D0, D1, D2, C = x.size(0), w1.size(1), w1.size(0), w2.size(0), w3.size(0)
-        dw1, db1 = _f32(D1, D0, device=dev), _f32(D1, device=dev)
-        dw2, db2 = _f32(D2, D1, device=dev), _f32(D2, device=dev)
-        dw3, db3 = _f32(C, D2, device=dev), _f32(C, device=dev)
+        # gradients straight into the trainer's flat bucket when one is installed (no AccumulateGrad copies, no concatenation)
+        pw1, pb1, pw2, pb2, pw3, pb3 = ctx.params
+        hb = ctx.has_b
+        dw1, s1 = _sink_or_new(pw1, (D1, D0), dev)
+        dw2, s2 = _sink_or_new(pw2, (D2, D1), dev)
+        dw3, s3 = _sink_or_new(pw3, (C, D2), dev)
+        db1, t1 = _sink_or_new(pb1, (D1,), dev) if hb[0] else (_f32(D1, device=dev), False)
+        db2, t2 = _sink_or_new(pb2, (D2,), dev) if hb[1] else (_f32(D2, device=dev), False)
+        db3, t3 = _sink_or_new(pb3, (C,), dev) if hb[2] else (_f32(C, device=dev), False)
         dx = _f32(B, D0, device=dev) if ctx.needs_input_grad[0] else None
         nll = take_deferred_nll(dlogp)                    # deferred F.nll_loss: this backward forms its gradient and the loss
         if nll is None:
             dlogp = dlogp.contiguous()
-        if nll is not None:
+        parts = None
+        if GRAD_SINK is not None and s1 and s2 and s3 and all(hb) and t1 and t2 and t3 and MLP3_TWO_LAUNCH_BWD:
+            # ... and their shares of |grad|^2 for the barrier-free optimiser
+            parts = GRAD_SINK.norm_slots(int(nat.lib().tsgnn_mlp3_bwd2_norm_blocks(int(D1), int(D2))))
+            if parts is not None:
+                for p_ in ctx.params:
+                    GRAD_SINK.normed.add(p_.data_ptr())
+        if parts is not None:
+            ws = _f32(B * (C + D2 + D1), device=dev)
+            nat.call("mlp3_bwd2_np_f32", x, x.stride(0), w1, w2, w3, a1, a2, logp, None if nll is not None else dlogp,
+                     nll[0] if nll is not None else None, nll[1] if nll is not None else None, ctx.keep_scale, B, D0, D1, D2, C,
+                     dw1, db1, dw2, db2, dw3, db3, dx, D0, ws, parts)
+        elif nll is not None:
             ws = _f32(B * (C + D2 + D1), device=dev)
             nat.call("mlp3_bwd2_nll_f32", x, x.stride(0), w1, w2, w3, a1, a2, logp, nll[0], nll[1], ctx.keep_scale, B, D0, D1, D2, C,
                      dw1, db1, dw2, db2, dw3, db3, dx, D0, ws)
@@ -462,8 +482,8 @@ class _Mlp3LogSoftmax(torch.autograd.Function):
         else:
             nat.call("mlp3_bwd_f32", x, x.stride(0), w1, w2, w3, a1, a2, logp, dlogp, ctx.keep_scale, B, D0, D1, D2, C,
                      dw1, db1, dw2, db2, dw3, db3, dx, D0)
-        hb = ctx.has_b
-        return dx, dw1, db1 if hb[0] else None, dw2, db2 if hb[1] else None, dw3, db3 if hb[2] else None, None, None, None
+        return (dx, None if s1 else dw1, (None if t1 else db1) if hb[0] else None, None if s2 else dw2,
+                (None if t2 else db2) if hb[1] else None, None if s3 else dw3, (None if t3 else db3) if hb[2] else None, None, None, None)
 
 
 _deferred_nll = None

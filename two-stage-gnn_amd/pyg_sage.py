@@ -126,15 +126,26 @@ def wgrad_slabs(z, x, K, du):
     return a, b
 
 
-def reduce_oi(sets):
-    """sets: list of (ws, nslab, K, N, dw_oi [N, K], db or None): ONE launch for up to 8 sets (tsgnn_sage_wgrad_reduce_oi_f32)"""
+def reduce_oi(sets, norm_sink=None):
+    """sets: list of (ws, nslab, K, N, dw_oi [N, K], db or None): ONE launch for up to 8 sets (tsgnn_sage_wgrad_reduce_oi_f32).
+    norm_sink: a GradSink whose optimiser wants the |grad|^2 shares of these gradients (and its step counter advanced) from this
+    launch; returns True when the shares were left."""
+    normed = norm_sink is not None
     for i in range(0, len(sets), 8):
         chunk = sets[i:i + 8]
         words = [len(chunk)]
         for ws, nslab, K, N, dw, db in chunk:
             words += [ws.data_ptr(), int(nslab), int(K), int(N), dw.data_ptr(), int(dw.stride(0)), db.data_ptr() if db is not None else 0]
         d = np.asarray(words, dtype=np.int64)
-        nat.call("sage_wgrad_reduce_oi_f32", d.ctypes.data)
+        parts = step = None
+        if norm_sink is not None:
+            parts = norm_sink.norm_slots(int(nat.lib().tsgnn_sage_wgrad_reduce_oi_blocks(d.ctypes.data)))
+            step = norm_sink.step_state if (parts is not None and not norm_sink.stepped) else None
+        normed = normed and parts is not None
+        nat.call("sage_wgrad_reduce_oi_f32", d.ctypes.data, parts, step)
+        if step is not None:
+            norm_sink.stepped = True
+    return normed
 
 
 class _SageConv(torch.autograd.Function):
@@ -240,6 +251,7 @@ class _SageStack(torch.autograd.Function):
         hs, zs = ctx.hs, ctx.zs
         grads = [None] * (3 * L)
         sets = []
+        sunk = []
         dxs = None
         dx0 = None
         for l in range(L - 1, -1, -1):
@@ -260,11 +272,18 @@ class _SageStack(torch.autograd.Function):
             sets.append((sl[0][0], sl[0][1], K, H, dwl, dbl))
             sets.append((sl[1][0], sl[1][1], K, H, dwr, None))
             grads[3 * l], grads[3 * l + 1], grads[3 * l + 2] = (None if s1 else dwl), (None if s2 else dbl), (None if s3 else dwr)
+            sunk.append(s1 and s3 and (s2 or not ctx.has_bias))
             if l > 0:
                 dxs = conv_dx(g, du, dus, ctx.pk_bwd[l][0], ctx.pk_bwd[l][1], K, H, K)
             elif ctx.needs_input_grad[0]:
                 dx0 = conv_dx(g, du, dus, ctx.pk_bwd[0][0], ctx.pk_bwd[0][1], K, H, hs[0].size(1))
-        reduce_oi(sets)
+        sink = mp.GRAD_SINK
+        all_sunk = sink is not None and all(sunk)
+        if reduce_oi(sets, norm_sink=sink if all_sunk else None):
+            for l in range(L):
+                sink.normed.add(ctx.params[3 * l].data_ptr()); sink.normed.add(ctx.params[3 * l + 2].data_ptr())
+                if ctx.has_bias:
+                    sink.normed.add(ctx.params[3 * l + 1].data_ptr())
         return (dx0, None, None, None) + tuple(grads)
 
 
