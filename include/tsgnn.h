@@ -1022,11 +1022,20 @@ int tsgnn_sage_conv_supported(int K, int N);
 /* desc (HOST memory): [nsets <= 16, nsets x (w, ldw, K, N, kn, out)] — out[16384] = fragment-major copy of the K x N matrix w
  * (kn = 0: w[n * ldw + k], nn.Linear's [out, in]; kn = 1: w[k * ldw + n]), zero beyond K / N; one launch for all layers of a step */
 int tsgnn_sage_conv_pack_f32(const int64_t* desc, tsgnn_stream_t stream);
+/* post_h (nullable; input-gradient launches): the epilogue finishes the dU of the layer BELOW without a launch of its own — with v = the product, out = ( v + [post_arg[b, c] == r] post_dread[b, c] + post_dread[b, N + c] / n_b ) *
+ * [post_h[r, c] > 0] and out2 (nullable) = out * post_row_scale[r] (see tsgnn_sage_relu_readout_bwd_f32; needs ro_row_graph /
+ * ro_graph_ptr, excludes bias-free options relu_out / normalize / ro_packed). */
 int tsgnn_sage_conv_f32(const int* ell, int ell_w, const int* tail_ptr, const int* tail_col, const float* xg, int64_t ldxg, const float* xs,
                         int64_t ldxs, const float* dst_scale, const float* wl_pk, const float* wr_pk,
                         const float* bias, float* out, int64_t ldo, float* zout, int64_t ldz, float* rinv,
                         int64_t rows, int K, int N, int relu_out, int normalize, unsigned long long* ro_packed,
-                        unsigned long long* ro_sums, const int* ro_row_graph, const int* ro_graph_ptr, tsgnn_stream_t stream);
+                        unsigned long long* ro_sums, const int* ro_row_graph, const int* ro_graph_ptr, const float* post_h, int64_t post_ldh,
+                        const float* post_dread, int64_t post_lddr, const int* post_arg, const float* post_row_scale, float* out2,
+                        int64_t ldo2, tsgnn_stream_t stream);
+/* slab partials of (z[:, :K]^T du, colsum du) into ws_l and of x[:, :K]^T du into ws_r ([nslab][K + 1][N] each, the layout of
+ * tsgnn_linear_wgrad_f32's dw == NULL form; plan with tsgnn_linear_wgrad_plan): both weights of a SAGEConv layer in ONE launch */
+int tsgnn_sage_wgrad_pair_f32(const float* z, int64_t ldz, const float* x, int64_t ldx, const float* du, int64_t lddu, int64_t rows, int K,
+                              int N, int nslab, int64_t rows_per_slab, float* ws_l, float* ws_r, tsgnn_stream_t stream);
 /* du[r, c] = ( dxs[r, c] (nullable) + [arg[b, c] == r] dread[b, c] + dread[b, F + c] / n_b ) * [h[r, c] > 0] (relu != 0), b = row_graph[r]:
  * backward of h = relu(u) feeding the next layer, the max readout (arg = winning rows) and the mean readout (dread [B, 2F], nullable);
  * dus (nullable) = du scaled row-wise by row_scale[r] (1 / deg: the rows the input-gradient launch gathers) */

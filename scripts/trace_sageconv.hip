@@ -42,9 +42,9 @@ int main(int argc, char** argv) {
   for (int kn = 0; kn < 2; ++kn) {
     auto run = [&]() {
       if (!kn) tsgnn_sage_conv_f32(ell, 16, nullptr, nullptr, a, 128, a, 128, invd, pk, pk + 16384, bias, c, N, z, 128, nullptr, R, K, N, 1, 0,
-                                   nullptr, nullptr, nullptr, nullptr, s);
+                                   nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, 0, s);
       else tsgnn_sage_conv_f32(ell, 16, nullptr, nullptr, a, 128, a, 128, nullptr, pk + 2 * 16384, pk + 3 * 16384, nullptr, c, N, nullptr, 0, nullptr, R, N, K, 0, 0,
-                               nullptr, nullptr, nullptr, nullptr, s);
+                               nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, 0, s);
     };
     for (int it = 0; it < 20; ++it) run();
     hipStreamSynchronize(s);

@@ -9,12 +9,21 @@
 #include "common.h"
 #include "../../include/tsgnn.h"
 #include "sageconv_body.h"
+#include "tn_rows_body.h"
 
 namespace {
 
 __global__ __launch_bounds__(512) void sage_conv_kernel(SageConvArgs g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   sageconv_body(g, smem, blockIdx.x);
+}
+
+// the weight-gradient slabs of BOTH weights of a layer in one launch: blockIdx.z = 0: (z^T du, colsum du) -> lin_l, 1: x^T du -> lin_r
+// (the unchanged slab body of gemm.hip; a CU hosts one block of each role)
+template <int MT, int NTt, int NY>
+__global__ __launch_bounds__(256) void sage_wgrad_pair_kernel(TnArgs a, TnArgs b) {
+  extern __shared__ __attribute__((aligned(16))) float tn_smem[];
+  tn_rows_body<MT, NTt, NY>(blockIdx.z ? b : a, tn_smem, blockIdx.x, blockIdx.y, gridDim.x);
 }
 
 // du[r, c] = ( dxs[r, c] + [arg[b, c] == r] dread[b, c] + dread[b, F + c] / n_b ) * [h[r, c] > 0]      b = row_graph[r]
@@ -109,37 +118,47 @@ struct OiSet {
 };
 struct OiArgs { OiSet s[8]; int nsets; float* normparts; float* step_state; };
 
-// block -> 64 consecutive entries (k, n) of one set's [K + 1][N] slab image, n fastest: coalesced slab reads, fixed slab order
-__global__ __launch_bounds__(64) void sage_wgrad_reduce_oi_kernel(OiArgs a) {
+// block -> 64 consecutive entries (k, n) of one set's [K + 1][N] slab image, n fastest: coalesced slab reads; four wave groups
+// split the slabs (fixed ranges), their partial sums meet in LDS and are added in group order: the same bits every run
+__global__ __launch_bounds__(256) void sage_wgrad_reduce_oi_kernel(OiArgs a) {
+  __shared__ float lds[4][64];
   int si = 0;
 #pragma unroll
   for (int t = 1; t < 8; ++t)
     if (t < a.nsets && (int)blockIdx.x >= a.s[t].first_block) si = t;
   const OiSet& s = a.s[si];
-  const int e = ((int)blockIdx.x - s.first_block) * 64 + (int)threadIdx.x;
+  const int e_l = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int e = ((int)blockIdx.x - s.first_block) * 64 + e_l;
   const int tot = (s.K + 1) * s.N;
-  float sq = 0.f;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   if (e < tot) {
     const int64_t stride = (int64_t)tot;
-    float acc = 0.f;
-    int sl = 0;
-    for (; sl + 8 <= s.nslab; sl += 8) {                // eight slab loads in flight
-      float v[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] = s.ws[(int64_t)(sl + q) * stride + e];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) acc += v[q];
+    const int per = (s.nslab + 3) / 4;
+    const int s0 = grp * per, s1 = min(s.nslab, s0 + per);
+    int sl = s0;
+    for (; sl + 4 <= s1; sl += 4) {
+      a0 += s.ws[(int64_t)sl * stride + e];
+      a1 += s.ws[(int64_t)(sl + 1) * stride + e];
+      a2 += s.ws[(int64_t)(sl + 2) * stride + e];
+      a3 += s.ws[(int64_t)(sl + 3) * stride + e];
     }
-    for (; sl < s.nslab; ++sl) acc += s.ws[(int64_t)sl * stride + e];
+    for (; sl < s1; ++sl) a0 += s.ws[(int64_t)sl * stride + e];
+  }
+  lds[grp][e_l] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (grp != 0) return;
+  float sq = 0.f;
+  if (e < tot) {
+    const float v = (lds[0][e_l] + lds[1][e_l]) + (lds[2][e_l] + lds[3][e_l]);
     const int k = e / s.N, n = e % s.N;
-    if (k < s.K) { s.dw[(int64_t)n * s.lddw + k] = acc; sq = acc * acc; }
-    else if (s.db) { s.db[n] = acc; sq = acc * acc; }
+    if (k < s.K) { s.dw[(int64_t)n * s.lddw + k] = v; sq = v * v; }
+    else if (s.db) { s.db[n] = v; sq = v * v; }
   }
   if (a.normparts) {                                    // this block's share of |grad|^2 (summed in fixed order by the optimiser)
     sq = wave_sum(sq);
-    if (threadIdx.x == 0) a.normparts[blockIdx.x] = sq;
+    if (e_l == 0) a.normparts[blockIdx.x] = sq;
   }
-  if (a.step_state && blockIdx.x == 0 && threadIdx.x == 0) a.step_state[0] += 1.f;   // optimiser step counter, ahead of the update kernel
+  if (a.step_state && blockIdx.x == 0 && e_l == 0) a.step_state[0] += 1.f;   // optimiser step counter, ahead of the update kernel
 }
 
 }  // namespace
@@ -173,10 +192,16 @@ int tsgnn_sage_conv_f32(const int* ell, int ell_w, const int* tail_ptr, const in
                         int64_t ldxs, const float* dst_scale, const float* wl_pk, const float* wr_pk,
                         const float* bias, float* out, int64_t ldo, float* zout, int64_t ldz, float* rinv,
                         int64_t rows, int K, int N, int relu_out, int normalize, unsigned long long* ro_packed,
-                        unsigned long long* ro_sums, const int* ro_row_graph, const int* ro_graph_ptr, tsgnn_stream_t stream) {
+                        unsigned long long* ro_sums, const int* ro_row_graph, const int* ro_graph_ptr, const float* post_h, int64_t post_ldh,
+                        const float* post_dread, int64_t post_lddr, const int* post_arg, const float* post_row_scale, float* out2,
+                        int64_t ldo2, tsgnn_stream_t stream) {
   if (!ell || !xg || !xs || !wl_pk || !wr_pk || !out || rows < 0 || K <= 0 || N <= 0) return TSGNN_EINVAL;
   if ((tail_ptr == nullptr) != (tail_col == nullptr)) return TSGNN_EINVAL;
   if ((ro_packed == nullptr) != (ro_sums == nullptr) || (ro_packed && (!ro_row_graph || !ro_graph_ptr))) return TSGNN_EINVAL;
+  if (post_h && (!post_dread || !post_arg || !ro_row_graph || !ro_graph_ptr || post_ldh < N || post_lddr < 2 * N || ro_packed || relu_out ||
+                 normalize || (out2 && (!post_row_scale || ldo2 < N))))
+    return TSGNN_EINVAL;
+  if (!post_h && out2) return TSGNN_EINVAL;
   if (ell_w != 4 && ell_w != 8 && ell_w != 16) return TSGNN_EUNSUPPORTED;
   if (!tsgnn_sage_conv_supported(K, N)) return TSGNN_EUNSUPPORTED;
   const int K4 = (K + 3) / 4 * 4;
@@ -188,7 +213,7 @@ int tsgnn_sage_conv_f32(const int* ell, int ell_w, const int* tail_ptr, const in
   if (rows >= (int64_t)1 << 31) return TSGNN_EUNSUPPORTED;
   SageConvArgs g{xg, ldxg, xs, ldxs, ell, ell_w, tail_ptr, tail_col, dst_scale, reinterpret_cast<const float4*>(wl_pk),
                  reinterpret_cast<const float4*>(wr_pk), bias, out, ldo, zout, ldz, rinv, rows, K, N, relu_out, normalize, ro_packed, ro_sums,
-                 ro_row_graph, ro_graph_ptr};
+                 ro_row_graph, ro_graph_ptr, post_h, post_ldh, post_dread, post_lddr, post_arg, post_row_scale, out2, ldo2};
   constexpr size_t lds = sageconv_lds_bytes();
   static bool attr = false;
   if (!attr && lds > 48 * 1024) {
@@ -197,6 +222,41 @@ int tsgnn_sage_conv_f32(const int* ell, int ell_w, const int* tail_ptr, const in
   }
   TSGNN_KNAME("sage_conv_kernel");
   sage_conv_kernel<<<(unsigned)ceil_div64(rows, 32), 512, lds, stream>>>(g);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+/* slab partials of (z[:, :K]^T du, colsum du) into ws_l and of x[:, :K]^T du into ws_r ([nslab][K + 1][N] each, the layout of
+ * tsgnn_linear_wgrad_f32's dw == NULL form; plan with tsgnn_linear_wgrad_plan) in ONE launch */
+int tsgnn_sage_wgrad_pair_f32(const float* z, int64_t ldz, const float* x, int64_t ldx, const float* du, int64_t lddu, int64_t rows, int K,
+                              int N, int nslab, int64_t rows_per_slab, float* ws_l, float* ws_r, tsgnn_stream_t stream) {
+  if (!z || !x || !du || !ws_l || !ws_r || rows < 0 || nslab <= 0 || rows_per_slab <= 0 || K <= 0 || N <= 0) return TSGNN_EINVAL;
+  if (K > 128 || N > 128 || (ldz % 4) || (ldx % 4) || (lddu % 4) || (N % 4) ||
+      ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(du)) & 15))
+    return TSGNN_EUNSUPPORTED;
+  TnArgs a{z, ldz, du, lddu, rows, rows_per_slab, K, N, ws_l, nullptr, 0};
+  TnArgs b{x, ldx, du, lddu, rows, rows_per_slab, K, N, ws_r, nullptr, 0};
+  const int mt = (K + 31) / 32, nt = (N + 31) / 32;
+  const unsigned ny = (mt * nt >= 8 && nslab < 512) ? 2u : 1u;
+  const dim3 grid((unsigned)nslab, ny, 2);
+  TSGNN_KNAME("sage_wgrad_pair_kernel<%d,%d,%u>", mt, nt, ny);
+#define TSGNN_TN(M_, N_) do { \
+    constexpr size_t lds_ = tn_rows_lds_bytes<M_, N_>(); \
+    static bool attr_ = false; \
+    if (ny == 2) { \
+      if (!attr_ && lds_ > 48 * 1024) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sage_wgrad_pair_kernel<M_, N_, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_); attr_ = true; } \
+      sage_wgrad_pair_kernel<M_, N_, 2><<<grid, 256, lds_, stream>>>(a, b); \
+    } else { \
+      if (!attr_ && lds_ > 48 * 1024) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sage_wgrad_pair_kernel<M_, N_, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_); attr_ = true; } \
+      sage_wgrad_pair_kernel<M_, N_, 1><<<grid, 256, lds_, stream>>>(a, b); \
+    } } while (0)
+  switch (mt * 10 + nt) {
+    case 11: TSGNN_TN(1, 1); break; case 12: TSGNN_TN(1, 2); break; case 13: TSGNN_TN(1, 3); break; case 14: TSGNN_TN(1, 4); break;
+    case 21: TSGNN_TN(2, 1); break; case 22: TSGNN_TN(2, 2); break; case 23: TSGNN_TN(2, 3); break; case 24: TSGNN_TN(2, 4); break;
+    case 31: TSGNN_TN(3, 1); break; case 32: TSGNN_TN(3, 2); break; case 33: TSGNN_TN(3, 3); break; case 34: TSGNN_TN(3, 4); break;
+    case 41: TSGNN_TN(4, 1); break; case 42: TSGNN_TN(4, 2); break; case 43: TSGNN_TN(4, 3); break; default: TSGNN_TN(4, 4); break;
+  }
+#undef TSGNN_TN
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }
@@ -255,7 +315,7 @@ int tsgnn_sage_wgrad_reduce_oi_f32(const int64_t* desc, float* normparts, float*
     blocks += ((s.K + 1) * s.N + 63) / 64;
   }
   TSGNN_KNAME("sage_wgrad_reduce_oi_kernel");
-  sage_wgrad_reduce_oi_kernel<<<(unsigned)blocks, 64, 0, stream>>>(a);
+  sage_wgrad_reduce_oi_kernel<<<(unsigned)blocks, 256, 0, stream>>>(a);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }

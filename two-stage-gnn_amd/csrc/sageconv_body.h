@@ -47,6 +47,13 @@ struct SageConvArgs {
   // ro_packed[B, N], and the column sums as 64-bit fixed-point integers (2^-32 units) into ro_sums[B, N]
   unsigned long long* ro_packed; unsigned long long* ro_sums;
   const int* ro_row_graph; const int* ro_graph_ptr;
+  // post epilogue (nullable; the input-gradient launch of layer l + 1 finishing layer l's dU): with v = the product's value,
+  //   out[r, c] = ( v + [post_arg[b, c] == r] post_dread[b, c] + post_dread[b, N + c] / n_b ) * [post_h[r, c] > 0]     b = graph of row r
+  //   out2[r, c] = out[r, c] * post_row_scale[r]                      (nullable: the rows the NEXT input-gradient launch gathers)
+  // i.e. tsgnn_sage_relu_readout_bwd_f32 without a launch of its own.  Uses ro_row_graph / ro_graph_ptr.
+  const float* post_h; int64_t post_ldh;
+  const float* post_dread; int64_t post_lddr; const int* post_arg;
+  const float* post_row_scale; float* out2; int64_t ldo2;
 };
 
 constexpr int SC_LDP = 256;           // floats per panel row: [agg 128 | self 128]
@@ -234,7 +241,7 @@ __device__ __forceinline__ void sageconv_body(const SageConvArgs& g, float* smem
   load_ids();
   const float bias_v = (g.bias && (32 * wid + i) < N) ? g.bias[32 * wid + i] : 0.f;
   int ro_gf = 0, ro_gl = -1;
-  if (g.ro_packed) {
+  if (g.ro_packed || g.post_h) {
     ro_gf = g.ro_row_graph[m0];
     ro_gl = g.ro_row_graph[min(m0 + 31, g.rows - 1)];
   }
@@ -250,14 +257,34 @@ __device__ __forceinline__ void sageconv_body(const SageConvArgs& g, float* smem
   TR_AFTER(__float_as_int(bw4[15].w), 8);
   __syncthreads();                                        // #2: the aggregated half and group 1's partial sums are complete
   TR(3);
+  const int cn = 32 * wid + i;
+  const bool okc = cn < N;
+  float hpost[16], rsc[16];                               // post epilogue operands, requested before the chain (its registers: the
+  constexpr int PG = 3;                                   // neighbour rows' that are dead by now); the first PG graphs of the panel
+  float pdm[PG], pds[PG]; int pa[PG], plo[PG], phi[PG];
+  if (g.post_h) {
+#pragma unroll
+    for (int q = 0; q < PG; ++q) {
+      const int b = min(ro_gf + q, ro_gl);                // (clamped: always a valid graph)
+      plo[q] = g.ro_graph_ptr[b]; phi[q] = g.ro_graph_ptr[b + 1];
+      pdm[q] = okc ? g.post_dread[(int64_t)b * g.post_lddr + cn] : 0.f;
+      pds[q] = okc ? g.post_dread[(int64_t)b * g.post_lddr + N + cn] : 0.f;
+      pa[q] = okc ? g.post_arg[(int64_t)b * N + cn] : -1;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t gm = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const bool ok = gm < g.rows && okc;
+      hpost[r] = ok ? g.post_h[gm * g.post_ldh + cn] : 0.f;
+      rsc[r] = (g.out2 && gm < g.rows) ? g.post_row_scale[gm] : 0.f;
+    }
+  }
   if (wave_on) kloop(0, 0, 16);
   TR(4);
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] += xch[(wid * 16 + r) * 64 + lane];
 
   // ---- epilogue in registers: lane (i, h) of wave wid holds C[(r & 3) + 8 (r >> 2) + 4 h][32 wid + i] in acc[r] ---------
-  const int cn = 32 * wid + i;
-  const bool okc = cn < N;
   float scale[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -265,6 +292,45 @@ __device__ __forceinline__ void sageconv_body(const SageConvArgs& g, float* smem
     if (g.relu_out) v = fmaxf(v, 0.f);
     acc[r] = v;
     scale[r] = 1.f;
+  }
+  if (g.post_h) {
+    // the readout gradients of the rows' graphs (a panel touches one to a few graphs), then the ReLU mask of the layer's output
+    const int64_t last = min(m0 + 31, g.rows - 1);
+#pragma unroll
+    for (int q = 0; q < PG; ++q) {                        // the panel's first PG graphs: their operands arrived during the chain
+      if (ro_gf + q <= ro_gl) {
+        const int64_t lo = max(m0, (int64_t)plo[q]), hi = min(last + 1, (int64_t)phi[q]);
+        const float ds = pds[q] * (1.0f / (float)max(phi[q] - plo[q], 1));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t gm = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (gm >= lo && gm < hi) acc[r] += ((int64_t)pa[q] == gm ? pdm[q] : 0.f) + ds;
+        }
+      }
+    }
+    for (int b = ro_gf + PG; b <= ro_gl; ++b) {           // panels of many small graphs: the rest, one trip per graph
+      const int64_t glo = g.ro_graph_ptr[b], ghi = g.ro_graph_ptr[b + 1];
+      const int64_t lo = max(m0, glo), hi = min(last + 1, ghi);
+      const float inv_n = 1.0f / (float)max((int)(ghi - glo), 1);
+      const float dm = okc ? g.post_dread[(int64_t)b * g.post_lddr + cn] : 0.f;
+      const float ds = okc ? g.post_dread[(int64_t)b * g.post_lddr + N + cn] * inv_n : 0.f;
+      const int a = okc ? g.post_arg[(int64_t)b * N + cn] : -1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t gm = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (gm >= lo && gm < hi) acc[r] += ((int64_t)a == gm ? dm : 0.f) + ds;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = hpost[r] > 0.f ? acc[r] : 0.f;
+    if (g.out2 && wave_on) {
+      float* cp2 = g.out2 + (m0 + 4 * h) * g.ldo2 + cn;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t gm = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (gm < g.rows && okc) cp2[(int64_t)((r & 3) + 8 * (r >> 2)) * g.ldo2] = acc[r] * rsc[r];
+      }
+    }
   }
   if (g.normalize) {                                      // F.normalize(out, p = 2, dim = -1) (SAGEConv(normalize=True))
     float ss[16];

@@ -101,24 +101,53 @@ def conv_fwd(g, x, wl_pk, wr_pk, bl, K, N, mean, relu_out=False, normalize=False
     nat.call("sage_conv_f32", ell, W, tp, tc, x, x.stride(0), x, x.stride(0), inv_degree(g) if mean else None,
              wl_pk, wr_pk, bl, out, out.stride(0), z, z.stride(0) if z is not None else 0, rinv, R, K, N,
              int(relu_out), int(normalize), ro[0] if ro else None, ro[1] if ro else None, g.row_graph if ro else None,
-             g.graph_ptr if ro else None)
+             g.graph_ptr if ro else None, None, 0, None, 0, None, None, None, 0)
     return out, z, rinv
 
 
-def conv_dx(g, du, dus, wl_pk, wr_pk, K, N, K_out):
+def conv_dx(g, du, dus, wl_pk, wr_pk, K, N, K_out, post=None):
     """dx [R, K_out] = A_mean^T (du W_l) + du W_r through the same fused kernel: the gathered rows are dus = du / deg (rows scaled by
     their OWN degree; dus = du for sum aggregation), the self rows du; wl_pk / wr_pk: the kn = 1 packs; K = the layer's input width,
-    N = its output width"""
+    N = its output width.  post = (h, dread, arg, want_scaled): the epilogue finishes the dU of the layer below — returns
+    (du_below, dus_below or None) instead of dx (tsgnn_sage_conv_f32's post epilogue)."""
     R = g.total_rows
     ell, W, tp, tc = ell_of(g, transposed=True)
     dx = _f32(R, K_out, device=du.device, zero=K_out > K)
+    if post is None:
+        nat.call("sage_conv_f32", ell, W, tp, tc, dus, dus.stride(0), du, du.stride(0), None,
+                 wl_pk, wr_pk, None, dx, dx.stride(0), None, 0, None, R, N, K, 0, 0, None, None, None, None, None, 0, None, 0, None, None, None, 0)
+        return dx
+    h, dread, arg, want_scaled = post
+    dx2 = _f32(R, K_out, device=du.device) if want_scaled else None
     nat.call("sage_conv_f32", ell, W, tp, tc, dus, dus.stride(0), du, du.stride(0), None,
-             wl_pk, wr_pk, None, dx, dx.stride(0), None, 0, None, R, N, K, 0, 0, None, None, None, None)
-    return dx
+             wl_pk, wr_pk, None, dx, dx.stride(0), None, 0, None, R, N, K, 0, 0, None, None, g.row_graph, g.graph_ptr,
+             h, h.stride(0), dread, dread.stride(0), arg, inv_degree(g) if want_scaled else None, dx2, K_out if want_scaled else 0)
+    return dx, dx2
+
+
+SLAB_MERGE = int(os.environ.get("TSGNN_SAGE_SLAB_MERGE", "2"))
+WGRAD_PAIR = os.environ.get("TSGNN_SAGE_WGRAD_PAIR", "1") != "0"     # both weights' slabs in one launch
+POST_EPILOGUE = os.environ.get("TSGNN_SAGE_POST_EPILOGUE", "1") != "0"   # the dU of the layer below in the input-gradient launch's epilogue
 
 
 def wgrad_slabs(z, x, K, du):
-    """slab partials of (dW_l^T, db) = (z^T du, colsum du) and dW_r^T = x^T du: two launches of the row-slab kernel, or None"""
+    """slab partials ((ws_l, nslab), (ws_r, nslab)) of (dW_l^T, db) = (z^T du, colsum du) and dW_r^T = x^T du — one launch
+    (tsgnn_sage_wgrad_pair_f32), or two launches of the row-slab kernel; None when the shape is not taken"""
+    R, N = int(du.size(0)), int(du.size(1))
+    if WGRAD_PAIR and z.stride(0) % 4 == 0 and x.stride(0) % 4 == 0 and z.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 \
+            and du.data_ptr() % 16 == 0:
+        nslab, rps, need = mp.wgrad_plan(R, K, N, z.stride(0), du.stride(0))
+        if nslab >= 2 * SLAB_MERGE and SLAB_MERGE > 1:
+            # the plan sizes ONE role to the chip; two roles share the launch, so each gets slabs of SLAB_MERGE times the rows: fewer
+            # partials to write and to sum (DD b32: 50 MB of slabs across the three layers at 128 slabs per weight)
+            rps = rps * SLAB_MERGE
+            nslab = -(-R // rps)
+            need = nslab * (K + 1) * N
+        if nslab > 0:
+            ws = _f32(2 * need, device=du.device)
+            if nat.try_call("sage_wgrad_pair_f32", z, z.stride(0), x, x.stride(0), du, du.stride(0), R, int(K), N, nslab, rps, ws[:need],
+                            ws[need:]):
+                return (ws[:need], nslab), (ws[need:], nslab)
     a = mp.linear_wgrad_slabs(z, K, du)
     b = mp.linear_wgrad_slabs(x, K, du)
     if a is None or b is None:
@@ -254,15 +283,18 @@ class _SageStack(torch.autograd.Function):
         sunk = []
         dxs = None
         dx0 = None
+        du = dus = None
         for l in range(L - 1, -1, -1):
             wl, wr = ctx.wls[l], ctx.wrs[l]
             K = int(wl.size(1))
-            du = _f32(R, H, device=dev)
             need_dx = l > 0 or ctx.needs_input_grad[0]
-            dus = _f32(R, H, device=dev) if need_dx else None
-            nat.call("sage_relu_readout_bwd_f32", hs[l + 1], hs[l + 1].stride(0), dxs, dxs.stride(0) if dxs is not None else 0, dread,
-                     dread.stride(0), ctx.arg[l * B * H:(l + 1) * B * H], g.row_graph, g.graph_ptr, R, H, 1, du, du.stride(0),
-                     inv_degree(g) if need_dx else None, dus, H if need_dx else 0)
+            if du is None:
+                # (the last layer, or every layer with TSGNN_SAGE_POST_EPILOGUE=0): the row-wise pass as a launch of its own
+                du = _f32(R, H, device=dev)
+                dus = _f32(R, H, device=dev) if need_dx else None
+                nat.call("sage_relu_readout_bwd_f32", hs[l + 1], hs[l + 1].stride(0), dxs, dxs.stride(0) if dxs is not None else 0, dread,
+                         dread.stride(0), ctx.arg[l * B * H:(l + 1) * B * H], g.row_graph, g.graph_ptr, R, H, 1, du, du.stride(0),
+                         inv_degree(g) if need_dx else None, dus, H if need_dx else 0)
             sl = wgrad_slabs(zs[l], hs[l], K, du)
             if sl is None:
                 raise RuntimeError("SAGEConv stack: weight-gradient shape %d x %d is not taken by the slab kernel" % (K, H))
@@ -274,7 +306,16 @@ class _SageStack(torch.autograd.Function):
             grads[3 * l], grads[3 * l + 1], grads[3 * l + 2] = (None if s1 else dwl), (None if s2 else dbl), (None if s3 else dwr)
             sunk.append(s1 and s3 and (s2 or not ctx.has_bias))
             if l > 0:
-                dxs = conv_dx(g, du, dus, ctx.pk_bwd[l][0], ctx.pk_bwd[l][1], K, H, K)
+                if POST_EPILOGUE:
+                    # the input gradient of this layer IS (up to the readout terms and the ReLU mask) the dU of the layer below: its
+                    # launch's epilogue finishes it — no row-wise launch between the layers
+                    below_dx = l - 1 > 0 or ctx.needs_input_grad[0]
+                    du, dus = conv_dx(g, du, dus, ctx.pk_bwd[l][0], ctx.pk_bwd[l][1], K, H, K,
+                                      post=(hs[l], dread, ctx.arg[(l - 1) * B * H:l * B * H], below_dx))
+                    dxs = None
+                else:
+                    dxs = conv_dx(g, du, dus, ctx.pk_bwd[l][0], ctx.pk_bwd[l][1], K, H, K)
+                    du = dus = None
             elif ctx.needs_input_grad[0]:
                 dx0 = conv_dx(g, du, dus, ctx.pk_bwd[0][0], ctx.pk_bwd[0][1], K, H, hs[0].size(1))
         sink = mp.GRAD_SINK
