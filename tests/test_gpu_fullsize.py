@@ -375,6 +375,34 @@ def test_pyg_sage_timed_step_vs_oracle(shape, B, layers, hid, seed):
          tag="PyG SAGEConv %s b%d %dL h%d seed %d (%d rows)" % (shape, B, layers, hid, seed, int(d.x.size(0))))
 
 
+def test_pyg_gat_timed_step_vs_oracle():
+    """BASELINE config 3 as worded — "DD GATConv 2-layer 4-head h=64 batch=32" — pyg.GatNet at the size scripts/pyg_bench.py times:
+    three replayed optimiser steps against oracle/pyg_ref.gat_net + clip_grad_norm_ + Adam (fp32, fp64).  PARITY UNPINNED."""
+    from two_stage_gnn_amd import pyg, synthetic
+    dev = torch.device("cuda")
+    hb = synthetic.host_batch(seed=2, B=32, shape="DD", nmax=1000)
+    d = _Data()
+    d.x, d.edge_index, d.batch, label = synthetic.to_pyg(hb, dev, pad_features=False)
+    torch.manual_seed(0)
+    net = pyg.GatNet(89, 64, 2, heads=4, num_layers=2).to(dev).train()
+    x_cpu = torch.from_numpy(hb["x"])
+    ei, batch, lab = d.edge_index.cpu(), d.batch.cpu(), torch.from_numpy(hb["label"])
+
+    def fwd(dtype):
+        xx = x_cpu.to(dtype)
+
+        def f(p):
+            y = P.gat_net(p, xx, ei, batch, 2, 4)
+            return torch.nn.functional.nll_loss(y, lab), y
+        return f
+
+    def loss_fn(stash):
+        stash["logits"] = net(d)
+        return torch.nn.functional.nll_loss(stash["logits"], label)
+
+    _run(net, loss_fn, fwd(torch.float32), fwd(torch.float64), lr=5e-4, max_frac=0.05, tag="PyG GATConv DD b32 2L 4 heads h64")
+
+
 # ------------------------------------------------------------------------------------------------ failure path of the barriers
 def test_barrier_timeout_poisons_the_optimiser_and_raises():
     """A bounded device-wide barrier that cannot complete (dense_stack.hip; forced with the library's self-test hook: one workgroup

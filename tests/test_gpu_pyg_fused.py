@@ -142,3 +142,45 @@ def test_sage_net_fused_vs_oracle_and_composed(fin, hid, L, sizes):
     # a second forward on the same batch starts from clean readout accumulators
     net.fused = True
     torch.testing.assert_close(net(d), y, rtol=0, atol=0)
+
+
+# ------------------------------------------------------------------------------------------------ GATConv / GatNet
+def _edge_order_mult(g, mult):
+    """the dropout multiplier [nnz, H] of a GATConv forward (CSR entry order) in the order of the self-looped edge list"""
+    out = torch.empty_like(mult)
+    out[g.eid[: g.nnz].long()] = mult[: g.nnz]
+    return out.cpu()
+
+
+@pytest.mark.parametrize("dropout", [0.0, 0.4])
+def test_gat_net_vs_oracle(dropout):
+    """pyg.GatNet (per-target edge softmax, self loops, heads concatenated then averaged, attention dropout with the SAME mask handed
+    to the oracle) on a small batch: log-probabilities and every parameter gradient, fp64-arbitrated"""
+    from two_stage_gnn_amd import pyg
+    sizes = (40, 90, 23, 64)
+    x, ei, batch = _batch(41, sizes, 2.5, 12)
+    lab = torch.arange(len(sizes)) % 2
+    torch.manual_seed(11)
+    net = pyg.GatNet(12, 16, 2, heads=4, num_layers=2, dropout=dropout).cuda().train()
+    with torch.no_grad():
+        for c in net.convs:
+            c.bias.copy_(0.1 * torch.randn_like(c.bias))
+    d = _D(); d.x, d.edge_index, d.batch = x.cuda(), ei.cuda(), batch.cuda()
+    names = [k for k, _ in net.named_parameters()]
+    params = [p for _, p in net.named_parameters()]
+    y = net(d)
+    g = net.graph(d)
+    mults = [_edge_order_mult(g, c.last_drop_mult) for c in net.convs] if dropout > 0 else None
+
+    def oracle(dtype):
+        p = {k: v.detach().cpu().to(dtype).requires_grad_(True) for k, v in net.state_dict().items()}
+        mm = None if mults is None else [m.to(dtype) for m in mults]
+        yy = P.gat_net(p, x.to(dtype), ei, batch, 2, 4, mm)
+        return yy, grads(torch.nn.functional.nll_loss(yy, lab), [p[k] for k in names])
+
+    y32, g32 = oracle(torch.float32)
+    y64, g64 = oracle(torch.float64)
+    assert_arbitrated(y, y32, y64, "log-probabilities")
+    gg = grads(torch.nn.functional.nll_loss(y, lab.cuda()), params)
+    for k, a, b, c in zip(names, gg, g32, g64):
+        assert_arbitrated(a, b, c, k)

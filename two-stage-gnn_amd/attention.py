@@ -106,9 +106,14 @@ def _isolated_columns(g, rp_t, R, H):
 
 class _AttentionAggregate(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, h, a_row, a_col, g, H, slope, by_column, uniform_isolated):
+    def forward(ctx, h, a_row, a_col, g, H, slope, by_column, uniform_isolated, drop_mult=None):
         """h [R, H*Fh]; a_row / a_col [H, Fh]: vectors dotted with the ROW node i / COLUMN node j of entry (i,j).
-        returns pre-activation out[i] = sum_j alpha_ij h_j (+ uniform term)."""
+        returns pre-activation out[i] = sum_j alpha_ij h_j (+ uniform term).  drop_mult [nnz, H] (per-target mode only): the
+        attention dropout of PyG GATConv as a multiplier per CSR entry and head (0 or 1 / (1 - p)), applied to the normalised
+        coefficients before the aggregation."""
+        if drop_mult is not None and (by_column or uniform_isolated):
+            raise NotImplementedError("the per-entry dropout multiplier belongs to the per-target softmax (GATConv); the column-softmax "
+                                      "layers draw their mask inside the fused kernels (gat_fused.py)")
         h = h.contiguous()
         a_row = a_row.contiguous()
         a_col = a_col.contiguous()
@@ -130,6 +135,9 @@ class _AttentionAggregate(torch.autograd.Function):
             alpha_g = None
             alpha = _f32(nnz, H, device=dev)
             nat.call("edge_softmax_fwd_f32", g.rowptr, g.col, R, H, s_row, s_col, 0, float(slope), alpha)
+            if drop_mult is not None:
+                ctx.alpha_soft = alpha                         # the softmax backward needs the un-dropped coefficients
+                alpha = alpha * drop_mult
         out = _f32(R, C, device=dev)
         iso = None
         if uniform_isolated:
@@ -151,6 +159,7 @@ class _AttentionAggregate(torch.autograd.Function):
         else:
             nat.call("csr_spmm_heads_f32", g.rowptr, g.col, alpha, H, Fh, h, h.stride(0), 0, out, out.stride(0), R)
         ctx.g, ctx.H, ctx.Fh, ctx.slope, ctx.by_column = g, H, Fh, slope, by_column
+        ctx.drop_mult = drop_mult
         ctx.save_for_backward(h, a_row, a_col, s_row, s_col, alpha, alpha_g, iso)
         return out
 
@@ -179,7 +188,11 @@ class _AttentionAggregate(torch.autograd.Function):
             dalpha = _f32(nnz, H, device=dev)
             nat.call("csr_sddmm_heads_f32", g.rowptr, g.col, H, Fh, dout, dout.stride(0), h, h.stride(0), 0, dalpha, R)
             dt = _f32(nnz, H, device=dev)
-            nat.call("edge_softmax_bwd_f32", g.rowptr, g.col, R, H, s_row, s_col, 0, float(slope), alpha, dalpha, dt, ds_row)
+            alpha_s = alpha
+            if ctx.drop_mult is not None:                      # out = sum_j (alpha_ij m_ij) h_j: d alpha = m * d(alpha m)
+                dalpha = dalpha * ctx.drop_mult
+                alpha_s = ctx.alpha_soft
+            nat.call("edge_softmax_bwd_f32", g.rowptr, g.col, R, H, s_row, s_col, 0, float(slope), alpha_s, dalpha, dt, ds_row)
             dt_t = _f32(nnz, H, device=dev)
             nat.call("edge_permute_f32", dt, src_e_t, g.nnz, H, 0, dt_t)
             nat.call("csr_row_sum_f32", rp_t, dt_t, R, H, ds_col)
@@ -195,11 +208,11 @@ class _AttentionAggregate(torch.autograd.Function):
                  iso, N, _row_seg(g), 1.0 / N, None)
         da_row, da_col = segment_wsum2(h, ds_row, ds_col, H, Fh)
         da_row, da_col = da_row.view(H, Fh), da_col.view(H, Fh)
-        return dh, da_row, da_col, None, None, None, None, None
+        return dh, da_row, da_col, None, None, None, None, None, None
 
 
-def attention_aggregate(h, a_row, a_col, g, heads, slope=0.2, by_column=True, uniform_isolated=True):
-    return _AttentionAggregate.apply(h, a_row, a_col, g, int(heads), float(slope), bool(by_column), bool(uniform_isolated))
+def attention_aggregate(h, a_row, a_col, g, heads, slope=0.2, by_column=True, uniform_isolated=True, drop_mult=None):
+    return _AttentionAggregate.apply(h, a_row, a_col, g, int(heads), float(slope), bool(by_column), bool(uniform_isolated), drop_mult)
 
 
 class _EluHeads(torch.autograd.Function):

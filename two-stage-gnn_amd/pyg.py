@@ -303,10 +303,21 @@ def global_mean_pool(x, batch, size=None):
     return _SegmentMean.apply(x, gp, B, int(sizes.max()) if len(sizes) else 0)
 
 
-def global_max_pool(x, batch, size=None):
-    sizes, gp, B = _pool_struct(x, batch, size)
+def _pool_graph(x, batch):
+    """structure-only GraphBatch of PyG's ``batch`` vector, cached on the tensor object (a step replayed from a hipGraph must not
+    upload anything)"""
+    hit = getattr(batch, "_tsgnn_pool_g", None) if batch is not None else None
+    if hit is not None and hit[0] == batch._version:
+        return hit[1]
+    sizes = segment_sizes(batch, x.size(0))
     g = GraphBatch.structure_only(sizes, int(max(1, sizes.max())), x.device, ghosts=False)
-    return mp.readout_max(x, g)
+    if batch is not None:
+        batch._tsgnn_pool_g = (batch._version, g)
+    return g
+
+
+def global_max_pool(x, batch, size=None):
+    return mp.readout_max(x, _pool_graph(x, batch))
 
 
 # ----------------------------------------------------------------------------- gated gather of the kept nodes
@@ -406,13 +417,15 @@ class GraphConv(SAGEConv):
 
 
 class GATConv(nn.Module):
-    """PyG GATConv: per-TARGET edge softmax (standard GAT), self loops added, heads concatenated/averaged."""
+    """PyG GATConv: per-TARGET edge softmax (standard GAT), self loops added, heads concatenated / averaged, attention dropout.
+    No call site in the reference (north_star names it; SURVEY 8 a15 — PARITY UNPINNED).  Parameters as PyG 1.6: lin_l (shared
+    projection, no bias), att_l / att_r [1, H, C] (dotted with the SOURCE / TARGET node), bias."""
 
     def __init__(self, in_channels, out_channels, heads=1, concat=True, negative_slope=0.2, dropout=0.0, bias=True, **kwargs):
         super().__init__()
+        self.in_channels = in_channels
         self.heads, self.out_channels, self.concat, self.negative_slope = heads, out_channels, concat, negative_slope
-        if dropout:
-            raise NotImplementedError("attention dropout is not on the benchmarked path")
+        self.dropout = float(dropout)
         dev = _default_device()
         self.lin_l = nn.Linear(in_channels, heads * out_channels, bias=False).to(dev)
         self.att_l = nn.Parameter(torch.empty(1, heads, out_channels, device=dev))
@@ -421,20 +434,27 @@ class GATConv(nn.Module):
         nn.init.xavier_uniform_(self.lin_l.weight)
         nn.init.xavier_uniform_(self.att_l)
         nn.init.xavier_uniform_(self.att_r)
+        self.last_drop_mult = None          # [nnz, H] multiplier of the most recent training forward, in g.eid order (tests)
 
     @staticmethod
-    def _loop_graph(edge_index, n):
+    def _loop_graph(edge_index, n, sizes=None):
         """remove_self_loops + add_self_loops, as a CSR cached per edge_index tensor (the boolean compaction and the COO
         ingest each cost a host round trip: once per edge list, not per forward)"""
-        key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, int(n))
+        skey = None if sizes is None else np.asarray(sizes, dtype=np.int64).tobytes()
+        key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, int(n), skey)
         hit = _gat_graph_cache.get(key)
         if hit is not None and hit[0]() is edge_index:
             return hit[1]
         keep = edge_index[0] != edge_index[1]
         loop = torch.arange(n, device=edge_index.device)
         ei = torch.cat([edge_index[:, keep], torch.stack([loop, loop])], dim=1)
-        g = GraphBatch.from_edge_index(ei, n, ghosts=False)
+        if sizes is None:
+            g = GraphBatch.from_edge_index(ei, n, ghosts=False)
+        else:
+            sizes = np.asarray(sizes, dtype=np.int64)
+            g = GraphBatch.from_edge_index(ei, n, sizes=sizes, nmax=int(max(1, sizes.max())), ghosts=False)
         g.transpose_map()
+        g.loop_edge_index = ei                                # (kept alive: tests rebuild the oracle's edge order from it)
         if len(_gat_graph_cache) > 16:
             _gat_graph_cache.clear()
         _gat_graph_cache[key] = (weakref.ref(edge_index), g)
@@ -442,11 +462,17 @@ class GATConv(nn.Module):
 
     def forward(self, x, edge_index):
         n = x.size(0)
-        g = self._loop_graph(edge_index, n)
-        h = linear(x, self.lin_l.weight.t())
+        g = edge_index if isinstance(edge_index, GraphBatch) else self._loop_graph(edge_index, n)
+        h = mp.linear_oi(x, self.lin_l.weight)
+        mult = None
+        if self.training and self.dropout > 0.0:
+            # F.dropout(alpha, p) on the normalised coefficients (one per edge of the self-looped list and head)
+            keep = torch.empty(max(g.nnz, 1), self.heads, dtype=torch.float32, device=x.device).bernoulli_(1.0 - self.dropout)
+            mult = keep * (1.0 / (1.0 - self.dropout))
+            self.last_drop_mult = mult
         # entry (i = target row, j = source col): score = att_r.h_i + att_l.h_j, softmax over the row
         pre = att.attention_aggregate(h, self.att_r.view(self.heads, -1), self.att_l.view(self.heads, -1), g, self.heads,
-                                      self.negative_slope, by_column=False, uniform_isolated=False)
+                                      self.negative_slope, by_column=False, uniform_isolated=False, drop_mult=mult)
         out = pre if self.concat else att.elu_heads(pre, self.heads, mean_heads=True, apply_elu=False)
         return bias_add(out, self.bias)
 
@@ -604,3 +630,34 @@ class SageNet(nn.Module):
             r = torch.cat([global_max_pool(x, batch), global_mean_pool(x, batch)], dim=1)
             out = r if out is None else out + r
         return self.head(out)
+
+
+class GatNet(nn.Module):
+    """BASELINE config 3 as worded ("DD GATConv 2-layer 4-head h=64 batch=32"): GATConv(F -> heads x nhid, concat) + ELU, ...,
+    GATConv(heads x nhid -> nhid, mean over heads), global_max_pool, Linear, log_softmax — the layer shapes of the reference's
+    DGATEncoderGraph (encoders_GAT.py:175-198: concat layers, a mean layer, max over nodes, Linear) on PyG's per-target GATConv."""
+
+    def __init__(self, num_features, nhid, num_classes, heads=4, num_layers=2, dropout=0.0):
+        super().__init__()
+        self.heads, self.nhid = heads, nhid
+        convs = []
+        for l in range(num_layers):
+            last = l == num_layers - 1
+            convs.append(GATConv(num_features if l == 0 else heads * nhid, nhid, heads=heads, concat=not last, dropout=dropout))
+        self.convs = nn.ModuleList(convs)
+        self.lin = nn.Linear(nhid, num_classes).to(_default_device())
+
+    def graph(self, data):
+        if isinstance(data.edge_index, GraphBatch):
+            return data.edge_index
+        return GATConv._loop_graph(data.edge_index, data.x.size(0), sizes=segment_sizes(getattr(data, "batch", None), data.x.size(0)))
+
+    def forward(self, data):
+        g = self.graph(data)
+        x = data.x
+        for l, conv in enumerate(self.convs):
+            x = conv(x, g)
+            if l < len(self.convs) - 1:
+                x = att.elu_heads(x, 1, mean_heads=False, apply_elu=True)
+        r = mp.readout_max(x, g) if g.row_graph is not None and g.n_ghost == 0 else global_max_pool(x, getattr(data, "batch", None))
+        return torch.nn.functional.log_softmax(mp.linear_oi(r, self.lin.weight, self.lin.bias), dim=-1)
