@@ -58,5 +58,28 @@ def main():
               % (shape, B, L, hid, seed, int(hb["sizes"].sum()), ta, B / ta * 1e6, tb, B / tb * 1e6, tb / ta), flush=True)
 
 
+def gat():
+    """config 3 as worded: DD GATConv 2 layers x 4 heads x 64, batch 32 — beside the reference-surface DGATEncoderGraph step"""
+    from two_stage_gnn_amd import gat_encoders as G
+    dev = torch.device("cuda")
+    hb = synthetic.host_batch(2, 32, "DD", 1000)
+    xd, adj = synthetic.to_dense(hb)
+    torch.manual_seed(0)
+    ga = G.DGATEncoderGraph(89, 64, 64, 2, None, num_layers=2, num_heads=[4, 4], final_dim="number_classes", per_graph_features=True).to(dev)
+    x32, g32 = ga.packed_batch(xd.to(dev), adj.to(dev), hb["sizes"])
+    lab = torch.from_numpy(hb["label"]).to(dev)
+    ta, _, _ = step_us(ga, lambda: ga.loss(ga(x32, g32)[1], lab), iters=100)
+    d = D()
+    d.x, d.edge_index, d.batch, lab2 = synthetic.to_pyg(hb, dev, pad_features=False)
+    torch.manual_seed(0)
+    gb = pyg.GatNet(89, 64, 2, heads=4, num_layers=2).to(dev).train()
+    tb, _, _ = step_us(gb, lambda: torch.nn.functional.nll_loss(gb(d), lab2), iters=100)
+    print("DD GAT  b32  2L 4 heads h64 (%5d rows): surface A DGATEncoderGraph %.1f us/step (%.0f graphs/s) | surface B GatNet[GATConv] %.1f us/step (%.0f graphs/s) | B / A = %.2f"
+          % (int(hb["sizes"].sum()), ta, 32 / ta * 1e6, tb, 32 / tb * 1e6, tb / ta), flush=True)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "GAT":
+        gat()
+        sys.exit(0)
     main()
