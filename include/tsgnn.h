@@ -1053,6 +1053,30 @@ int tsgnn_sage_readout_decode_f32(unsigned long long* packed, unsigned long long
 int tsgnn_sage_wgrad_reduce_oi_blocks(const int64_t* desc);
 int tsgnn_sage_wgrad_reduce_oi_f32(const int64_t* desc, float* normparts, float* step_state, tsgnn_stream_t stream);
 
+/* ---------------------------------------------------------------- torch_geometric GATConv as fused launches (csrc/gatconv.hip)
+ * Per-TARGET edge softmax (standard GAT; the reference's own DGATHead normalises per column: tsgnn_gat_attn_*).  No call site in the
+ * reference (PARITY UNPINNED).  hp = x W' [rows, >= C + 2H] with W' = [W^T | W_h^T att_r_h | W_h^T att_l_h | pad] (C = H * Co):
+ * features, then the node's scalar as TARGET (hp[:, C + h]) and as SOURCE (hp[:, C + H + h]).  (rowptr, col): CSR grouped by target, self
+ * loops included.  H in {1, 2, 4, 8}, Co in {4, 8, 16, 32, 64}, C <= 256. */
+int tsgnn_gatconv_supported(int H, int Co);
+/* y[i] = act( sum_j alpha_ij hp[j, :C] [mean over heads] + bias ), alpha_ij = softmax over the sources j of row i of
+ * LeakyReLU(hp[i, C + h] + hp[j, C + H + h]); stat[rows, H, 2] (out): (max, 1 / sum of exponentials) of every row, by a first small launch */
+int tsgnn_gatconv_fwd_f32(const float* hp, int64_t ldh, const int* rowptr, const int* col, int64_t rows, int H, int Co, float slope,
+                          int mean_heads, int apply_elu, const float* bias, float* stat, float* y, int64_t ldy, tsgnn_stream_t stream);
+/* backward, target side (one wave per row): dpre[rows, C] = dy * ELU'(y) [/ H per head] (out: the transposed pass gathers it; its column
+ * sums are the bias gradient), dhp[:, C + h] = d s_dst, the zero pad of dhp, per-entry alpha / t1 / t2 [nnz, H] in A's entry order and
+ * S [rows, H].  The source side is two existing launches over A^T: dhp[:, :C] = tsgnn_csr_spmm_heads_epi_f32(alpha through the entry
+ * map, x = dpre) and dhp[:, C + H + h] = tsgnn_gat_score_rowsum_f32(t1, t2, S; column offset C + H). */
+int tsgnn_gatconv_bwd_rows_f32(const float* hp, int64_t ldh, const float* y, int64_t ldy, const float* dy, int64_t lddy, const int* rowptr,
+                               const int* col, int64_t rows, int H, int Co, float slope, int mean_heads, int apply_elu, const float* stat,
+                               float* dpre, int64_t lddp, float* dhp, int Ns, float* alpha, float* t1, float* t2, float* S,
+                               tsgnn_stream_t stream);
+/* lin_l.weight [H * Co, Fin] (nn.Linear layout) + att_r / att_l [H * Co] -> W' [Fin, Ns] for up to 4 layers in ONE launch, and dW' -> their
+ * gradients in one launch.  desc (HOST memory): [L, L x (H, Fin, Co, Ns, w, ldw, att_r, att_l, wp (W' out / dW' in), gw, gar, gal)] */
+int tsgnn_gatconv_pack_desc_words(void);
+int tsgnn_gatconv_pack_f32(const int64_t* desc, tsgnn_stream_t stream);
+int tsgnn_gatconv_unpack_f32(const int64_t* desc, tsgnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,7 +10,7 @@ source text is written anywhere.
 
 The GPU box has no /root/reference: tests read only the committed fixtures.
 
-Usage:  python oracle/gen_golden.py [encoders] [tu]     (rewrites tests/golden/*.npz; default: both sections)
+Usage:  python oracle/gen_golden.py [encoders] [tu] [linkpred]     (rewrites tests/golden/*.npz; default: all sections)
 """
 import os
 import sys
@@ -176,6 +176,81 @@ def gen_diffpool(enc, gen):
          adj_out=ao.detach(), gx=gx, ga=ga, gs=s.grad, gz=z.grad, gadj=adj.grad)
 
 
+class _TorchProxy:
+    """stands in for the `torch` module attribute of the reference's encoders module WHILE its loss runs: every attribute is the real
+    torch's, except that `Tensor(...)` — the reference clamps the predicted adjacency with `torch.Tensor(1)`, an UNINITIALISED
+    one-element tensor (encoders.py:424) — calls the real constructor, RECORDS the value it returned, and passes it on.  Harness
+    process only (same category as the `.cuda()` neutralisation): the reference's arithmetic runs unchanged."""
+
+    def __init__(self, real):
+        object.__setattr__(self, "_real", real)
+        object.__setattr__(self, "captured", [])
+
+    def __getattr__(self, name):
+        return getattr(object.__getattribute__(self, "_real"), name)
+
+    def Tensor(self, *a, **k):
+        t = object.__getattribute__(self, "_real").Tensor(*a, **k)
+        object.__getattribute__(self, "captured").append(t.detach().clone())
+        return t
+
+
+def gen_diffpool_linkpred(enc, gen):
+    """SoftPoolingGcnEncoder(linkpred=True).loss (encoders.py:409-441) at num_pooling = 1, masked and unmasked: inputs, parameters,
+    the clamp value the reference's uninitialised `torch.Tensor(1)` held IN THIS RUN (captured, not chosen), loss, link loss and all
+    gradients.  Whatever the allocation holds is recorded: 0 (every entry clipped: the link loss is a constant and its gradient
+    vanishes) and a value above 1 (nothing clipped: rows of S are softmax outputs, so (S S^T)_ij <= 1) both occur.  Draws whose
+    captured value is not finite are retried."""
+    class A:
+        bias = True
+    real_torch = enc.torch
+    # want_open: keep drawing (the heap is stirred with freed tensors of random contents between attempts) until the allocation
+    # holds a value > 0.05, so that at least one fixture exercises the loss where the clamp does NOT flatten everything; the value is
+    # still whatever the reference's own `torch.Tensor(1)` returned
+    for tag, B, nmax, sizes, masked, want_open in [("masked", 3, 16, [16, 6, 11], True, False), ("nomask", 2, 16, [16, 9], False, False),
+                                                   ("masked2", 2, 16, [12, 16], True, True), ("nomask2", 3, 16, [7, 16, 10], False, True)]:
+        fin, hid, emb, lab, L = 5, 6, 7, 2, 3
+        x, adj, sz = make_batch(gen, B, nmax, fin, sizes=sizes)
+        m = enc.SoftPoolingGcnEncoder(nmax, fin, hid, emb, lab, L, hid, assign_ratio=0.25, num_pooling=1, bn=True, linkpred=True,
+                                      args=A(), assign_input_dim=fin, final_dim="number_classes")
+        randomise_(m, gen, 0.4)
+        label = torch.randint(0, lab, (B,), generator=gen)
+        bnn = sz if masked else None
+        for attempt in range(2000 if want_open else 20):
+            if want_open and attempt:
+                junk = [real_torch.rand(int(n)) * 2 for n in np.random.randint(1, 40, size=8)]
+                del junk
+            m.zero_grad()
+            _, ypred = m(x, adj, bnn, assign_x=x)
+            proxy = _TorchProxy(real_torch)
+            enc.torch = proxy
+            # torch >= 2.x no longer takes a uint8 tensor as a mask in `t[mask] = v` (encoders.py:436 `self.link_loss[1 - adj_mask.byte()] = 0.0`;
+            # torch 1.x, which the reference targets, did): for the duration of the call a uint8 index is read as the boolean mask it was
+            orig_setitem = real_torch.Tensor.__setitem__
+
+            def setitem(self, idx, val):
+                if isinstance(idx, real_torch.Tensor) and idx.dtype == real_torch.uint8:
+                    idx = idx.bool()
+                return orig_setitem(self, idx, val)
+            real_torch.Tensor.__setitem__ = setitem
+            try:
+                loss = m.loss(ypred, label, adj, bnn)
+            finally:
+                enc.torch = real_torch
+                real_torch.Tensor.__setitem__ = orig_setitem
+            assert len(proxy.captured) == 1 and proxy.captured[0].numel() == 1
+            clamp = float(proxy.captured[0])
+            if np.isfinite(clamp) and np.isfinite(float(loss)) and (not want_open or 0.05 < clamp < 1e6):
+                break
+        else:
+            raise RuntimeError("no usable clamp value in %d draws" % (attempt + 1))
+        loss.backward()
+        print("linkpred %s: captured clamp %.6g, loss %.6f, link loss %.6f" % (tag, clamp, float(loss), float(m.link_loss)))
+        save("diffpool_linkpred_" + tag, x=x, adj=adj, sizes=sz, masked=int(masked), label=label.numpy(), clamp=np.float32(clamp),
+             loss=loss.detach(), link_loss=m.link_loss.detach(), ypred=ypred.detach(), assign=m.assign_tensor.detach(),
+             cfg=np.array([nmax, fin, hid, emb, lab, L, 1]), ratio=0.25, **sd_np(m), **grads_np(m))
+
+
 def gen_gat(gat, gen):
     # single head: B=1 (the only batch size at which the reference is meaningful, T4) and B=2
     for tag, B, concat, sizes in [("b1_concat", 1, True, [10]), ("b1_raw", 1, False, [12]),
@@ -308,7 +383,10 @@ def gen_tu():
 
 
 def main(argv):
-    want = set(argv) or {"encoders", "tu"}
+    want = set(argv) or {"encoders", "tu", "linkpred"}
+    if "linkpred" in want:                      # (its own generator: adding fixtures must not move the seeded streams of the others)
+        enc, _ = _import_reference()
+        gen_diffpool_linkpred(enc, torch.Generator().manual_seed(20261005))
     if "encoders" in want:
         enc, gat = _import_reference()
         gen = torch.Generator().manual_seed(20261003)

@@ -719,3 +719,28 @@ def test_ranks_that_disagree_about_the_capture_fall_back_together():
         assert n_graph == n_eager == 3.0
         np.testing.assert_array_equal(p_graph, p_eager)
     np.testing.assert_array_equal(res[0][1][0][0], res[1][1][0][0])    # replicas identical
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_end_to_end_gloo():
+    """`python bench.py --gpus 2` exactly as the driver's launcher runs it (self-spawned ranks through torch.distributed.run, per-rank
+    seeds, the barrier + max-over-ranks clock, `per_rank` in the JSON line, check_device_errors) — on ONE GPU with the gloo backend
+    (TSGNN_DIST_BACKEND=gloo: both ranks share the card), so that the first real multi-GPU run cannot fail on plumbing (VERDICT r3 #8)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TSGNN_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--no-cpu-baseline",
+                        "--no-sweep", "--no-kernels", "--no-seeds", "--no-pyg", "--settle-steps", "4"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                         # exactly ONE JSON line on stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "weak" and d["config"]["global_batch"] == 64
+    assert d["value"] > 0 and abs(d["value"] - 2 * 32 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    pr = d["per_rank"]
+    assert [p["rank"] for p in pr] == [0, 1] and pr[0]["rows"] != pr[1]["rows"]          # rank r drew the batch of seed r
+    assert all(p["ms_per_step"] > 0 for p in pr)
+    assert d["steps_per_graph_launch"] == 1 and d["settle_untimed_steps"] == 4

@@ -512,6 +512,45 @@ def test_diffpool_encoder_golden(tag):
     assert_grads_arbitrated([(k, p) for k, p in m.named_parameters() if k in p32], p32, p64)
 
 
+@pytest.mark.parametrize("tag", ["masked", "nomask", "masked2", "nomask2"])
+def test_diffpool_linkpred_golden(tag):
+    """f4 against the REFERENCE's own run (tests/golden/diffpool_linkpred_*.npz, oracle/gen_golden.py linkpred): the loss with the
+    link-prediction term of encoders.py:409-441, `model.linkpred_clamp` set to the value the reference's uninitialised clamp tensor
+    held when the fixture was made; loss, link loss and every parameter gradient (fp64-arbitrated like the encoder fixtures)"""
+    from two_stage_gnn_amd import dense_encoders as E
+    g = load_golden("diffpool_linkpred_" + tag)
+    nmax, fin, hid, emb, lab, L, npool = (int(v) for v in g["cfg"])
+
+    class A:
+        bias = True
+    m = E.SoftPoolingGcnEncoder(nmax, fin, hid, emb, lab, L, hid, assign_ratio=float(g["ratio"]), num_pooling=npool,
+                                bn=True, linkpred=True, args=A(), assign_input_dim=fin, final_dim="number_classes")
+    load_state(m, g)
+    m.linkpred_clamp = float(g["clamp"])
+    x, adj = torch.tensor(g["x"]).cuda(), torch.tensor(g["adj"]).cuda()
+    bnn = g["sizes"] if int(g["masked"]) else None
+    _, ypred = m(x, adj, bnn, assign_x=x)
+    np.testing.assert_allclose(ypred.detach().cpu().numpy(), g["ypred"], rtol=1e-4, atol=1e-5)
+    loss = m.loss(ypred, torch.tensor(g["label"]).cuda(), adj, bnn)
+    np.testing.assert_allclose(float(m.link_loss), float(g["link_loss"]), rtol=1e-4)
+    np.testing.assert_allclose(float(loss), float(g["loss"]), rtol=1e-4)
+    loss.backward()
+    p64 = {k[2:]: torch.tensor(v).double().requires_grad_(True) for k, v in g.items() if k.startswith("p.")}
+    _, y64, s64 = R.diffpool_encoder(p64, torch.tensor(g["x"]).double(), torch.tensor(g["adj"]).double(), bnn, npool,
+                                     assign_x=torch.tensor(g["x"]).double(), final_dim="number_classes", return_assign=True)
+    (torch.nn.functional.cross_entropy(y64, torch.tensor(g["label"])) +
+     R.diffpool_link_loss(s64, torch.tensor(g["adj"]).double(), bnn, clamp=float(g["clamp"]))).backward()
+
+    class _G:
+        def __init__(self, t):
+            self.grad = t
+    p32 = {k: _G(torch.tensor(g["g." + k])) for k, _ in m.named_parameters() if "g." + k in g}
+    for k, v in p64.items():
+        if v.grad is None:
+            v.grad = torch.zeros_like(v)
+    assert_grads_arbitrated([(k, p) for k, p in m.named_parameters() if k in p32], p32, p64)
+
+
 def test_diffpool_dd_config_vs_oracle():
     """BASELINE config 5 shape (scaled down 4x in batch): Nmax=512 -> 64 -> 8, h=64, 3 layers, masked."""
     from two_stage_gnn_amd import dense_encoders as E

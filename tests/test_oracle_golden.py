@@ -75,6 +75,28 @@ def test_diffpool_encoder(tag):
             np.testing.assert_allclose(got.numpy(), g["g." + k], err_msg=k, rtol=2e-3, atol=2e-4)
 
 
+@pytest.mark.parametrize("tag", ["masked", "nomask", "masked2", "nomask2"])
+def test_diffpool_linkpred_loss(tag):
+    """f4 pinned by the reference's own arithmetic: SoftPoolingGcnEncoder(linkpred=True).loss (encoders.py:409-441) run by
+    oracle/gen_golden.py with the value its uninitialised `torch.Tensor(1)` clamp held CAPTURED into the fixture (0: everything clipped,
+    0.698: part of the entries clipped, 98.4: nothing clipped): loss, link loss and every parameter gradient of the restatement"""
+    g = load_golden("diffpool_linkpred_" + tag)
+    p = params_of(g, requires_grad=True)
+    bnn = g["sizes"] if int(g["masked"]) else None
+    _, ypred, s = R.diffpool_encoder(p, T(g["x"]), T(g["adj"]), bnn, 1, assign_x=T(g["x"]), final_dim="number_classes", return_assign=True)
+    np.testing.assert_allclose(ypred.detach().numpy(), g["ypred"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(s.detach().numpy(), g["assign"], rtol=1e-4, atol=1e-5)
+    link = R.diffpool_link_loss(s, T(g["adj"]), bnn, clamp=float(g["clamp"]))
+    loss = torch.nn.functional.cross_entropy(ypred, torch.tensor(g["label"])) + link
+    np.testing.assert_allclose(float(link), float(g["link_loss"]), rtol=1e-5)
+    np.testing.assert_allclose(float(loss), float(g["loss"]), rtol=1e-5)
+    loss.backward()
+    for k, t in p.items():
+        if "g." + k in g:
+            got = t.grad if t.grad is not None else torch.zeros_like(t)
+            np.testing.assert_allclose(got.numpy(), g["g." + k], err_msg=k, rtol=2e-3, atol=2e-4)
+
+
 def test_diffpool_contract():
     g = load_golden("diffpool_contract")
     s, z, adj = (T(g[k]).requires_grad_(True) for k in ("s", "z", "adj"))

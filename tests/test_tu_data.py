@@ -425,3 +425,18 @@ def test_ingest_pipeline_riding_pull_equals_pull_at_the_head(workers):
         out.append(tr.flat_param.clone())
     assert torch.isfinite(out[0]).all()
     assert torch.equal(out[0], out[2]) and torch.equal(out[1], out[2])
+
+
+def test_malformed_integer_file_raises(tmp_path):
+    """a token that is not an integer (float-formatted label, stray word) must raise like the reference's int() (load_data.py:24-60),
+    not silently truncate the file"""
+    from two_stage_gnn_amd import tu_data
+    f = tmp_path / "X_graph_indicator.txt"
+    f.write_text("1\n1\n2.0\n2\n")
+    with pytest.raises(ValueError):
+        tu_data._read_ints(str(f))
+    f.write_text("1\n1\nabc\n2\n")
+    with pytest.raises(ValueError):
+        tu_data._read_ints(str(f))
+    f.write_text("1, 2\n3,4\n")
+    assert tu_data._read_ints(str(f)).tolist() == [1, 2, 3, 4]

@@ -86,11 +86,15 @@ class _PackLayers(torch.autograd.Function):
         d = _desc(layers, [(o, None, None) for o in outs])
         nat.call("gat_pack_f32", d.ctypes.data)
         ctx.layers = layers
+        # the slab sets the layers' backward leaves for this node's backward to reduce: a container of THIS forward (not a module
+        # global: two models, streams or threads must not see each other's entries, and a backward that never reaches this node
+        # leaves nothing behind — the container dies with the graph)
+        ctx.pending = []
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *dwps):
-        flush_reductions()                                       # the layers' dW' still sit in their slabs: ONE reduction launch for two
+        flush_reductions(ctx.pending)                            # the layers' dW' still sit in their slabs: ONE reduction launch for two
         layers = ctx.layers
         dev = layers[0][4][0].device
         ptrs, res = [], []
@@ -113,35 +117,40 @@ def pack_layers(layers_heads):
     for heads in layers_heads:
         params += [hd.w for hd in heads] + [hd.a for hd in heads]
     outs = _PackLayers.apply(tuple(len(h) for h in layers_heads), *params)
+    pending = outs[0].grad_fn.pending if (outs and outs[0].grad_fn is not None and hasattr(outs[0].grad_fn, "pending")) else None
     for o in outs:
-        o._tsgnn_packed = True          # its gradient goes to _PackLayers.backward, which reduces the pending slabs first
+        # its gradient goes to _PackLayers.backward, which reduces the pending slabs first; `uses` counts the layer calls that
+        # consume this W' (deferring is only sound with exactly one: autograd would otherwise SUM two not-yet-reduced gradients)
+        o._tsgnn_pending = pending
+        o._tsgnn_uses = [0]
     return outs
 
 
 # A layer's dW' is read only when the parameters are unpacked at the end of the backward pass: the layers leave their slabs pending
 # and _PackLayers.backward reduces them two products per launch (a GAT encoder has two layers: one reduction launch instead of two).
 DEFER_REDUCE = os.environ.get("TSGNN_GAT_DEFER_REDUCE", "1") != "0"
-_pending_reduce = []        # (ws, nslab, K_in, N, dw)
 
 
-def flush_reductions():
-    while _pending_reduce:
-        a = _pending_reduce.pop(0)
-        if _pending_reduce:
-            b = _pending_reduce.pop(0)
+def flush_reductions(pending):
+    """reduce the slab sets (ws, nslab, K_in, N, dw) the layers of one forward left pending, two per launch"""
+    while pending:
+        a = pending.pop(0)
+        if pending:
+            b = pending.pop(0)
             nat.call("wgrad_blocks_reduce2_f32", a[0], a[1], a[2], a[3], a[4], a[4].stride(0), b[0], b[1], b[2], b[3], b[4], b[4].stride(0))
         else:
             nat.call("wgrad_blocks_reduce_f32", a[0], a[1], a[2], a[3], a[4], a[4].stride(0))
 
 
 def _reduce(ws, nslab, K_in, N, dw, defer):
-    if defer and DEFER_REDUCE:
-        _pending_reduce.append((ws, nslab, K_in, N, dw))
+    """defer: the pending list of the pack node that will consume dw (None / False: reduce now)"""
+    if defer is not None and defer is not False and DEFER_REDUCE:
+        defer.append((ws, nslab, K_in, N, dw))
     else:
         nat.call("wgrad_blocks_reduce_f32", ws, nslab, K_in, N, dw, dw.stride(0))
 
 
-def wgrad_blocks(z, K_in, du, defer=False):
+def wgrad_blocks(z, K_in, du, defer=None):
     """dW[K_in, N] = z[:, :K_in]^T du (N = du.size(1) <= 512) in two launches; None if the shape is not taken.  defer: only the slab
     launch now, the reduction with the next flush_reductions() (the returned tensor is filled then)"""
     R, N = int(du.size(0)), int(du.size(1))
@@ -154,9 +163,9 @@ def wgrad_blocks(z, K_in, du, defer=False):
         return None
     ws = _f32(int(need[0]), device=du.device)
     dw = _f32(int(K_in), N, device=du.device)
-    if defer and DEFER_REDUCE:
+    if defer is not None and defer is not False and DEFER_REDUCE:
         nat.call("wgrad_blocks_slabs_f32", z, z.stride(0), du, du.stride(0), R, int(K_in), N, int(nslab[0]), int(rps[0]), ws)
-        _reduce(ws, int(nslab[0]), int(K_in), N, dw, True)
+        _reduce(ws, int(nslab[0]), int(K_in), N, dw, defer)
         return dw
     nat.call("wgrad_blocks_f32", z, z.stride(0), du, du.stride(0), R, int(K_in), N, int(nslab[0]), int(rps[0]), ws, dw, dw.stride(0))
     return dw
@@ -165,7 +174,7 @@ def wgrad_blocks(z, K_in, du, defer=False):
 MERGED_BWD_PRODUCTS = os.environ.get("TSGNN_GAT_MERGED_BWD", "1") != "0"   # a layer's weight-gradient slabs beside its input-gradient product
 
 
-def bwd_products(x, K_in, du, wp, defer=False):
+def bwd_products(x, K_in, du, wp, defer=None):
     """(dW'[K_in, N], dx[R, x.size(1)]) of hp = x W' from du = dhp: the slab launch of wgrad_blocks and the product du W'^T as ONE
     launch (tsgnn_gat_bwd_products_f32) + the slabs' reduction; None when the shape is not taken (K_in <= 128, ...)"""
     R, N = int(du.size(0)), int(du.size(1))
@@ -209,7 +218,12 @@ class _GatLayer(torch.autograd.Function):
                  int(g.nmax), i_idx, i_w, i_ptr, 1.0 / max(int(g.nmax), 1), int(mean_heads), int(apply_elu), float(drop_p),
                  int(seed), ctr, stat, y, y.stride(0))
         ctx.cfg = (g, H, Fo, slope, mean_heads, apply_elu, drop_p, seed, Fin)
-        ctx.packed = bool(getattr(wp, "_tsgnn_packed", False))   # wp came from pack_layers: its gradient's consumer reduces pending slabs
+        # wp came from pack_layers: its gradient's consumer (the pack node's backward) reduces pending slabs — sound only while this
+        # call is the ONLY consumer of wp (a second one, a hook or retain_grad would make autograd sum un-reduced gradients)
+        ctx.pending = getattr(wp, "_tsgnn_pending", None)
+        ctx.uses = getattr(wp, "_tsgnn_uses", None)
+        if ctx.uses is not None:
+            ctx.uses[0] += 1
         ctx.ctr = ctr
         ctx.lst = lst
         ctx.readout = bool(readout)
@@ -249,13 +263,18 @@ class _GatLayer(torch.autograd.Function):
         fin = lst is not None and drop_p == 0.0                 # (with dropout the backward completes the listed columns itself)
         nat.call("gat_score_rowsum_f32", g.rowptr, g.col, att._inverse_entry_map(g, src_e_t), t1, t2, S, R, H, dhp, dhp.stride(0), C,
                  dupart if fin else None, int(g.B), i_idx if fin else None, i_w if fin else None, i_ptr if fin else None, us)
-        if ctx.needs_input_grad[0] and MERGED_BWD_PRODUCTS:
-            both = bwd_products(x, Fin, dhp, wp, defer=ctx.packed)    # dW' slabs and dx = dhp W'^T side by side in one launch
+        want_w = ctx.needs_input_grad[1]
+        # defer the slab reduction to the pack node only when that node will run (W' needs a gradient) and this is W''s one consumer
+        defer = ctx.pending if (want_w and ctx.pending is not None and ctx.uses is not None and ctx.uses[0] == 1 and not wp.retains_grad) else None
+        if ctx.needs_input_grad[0] and want_w and MERGED_BWD_PRODUCTS:
+            both = bwd_products(x, Fin, dhp, wp, defer=defer)    # dW' slabs and dx = dhp W'^T side by side in one launch
             if both is not None:
                 return both[1], both[0], None, None, None, None, None, None, None, None, None, None
-        dwp = wgrad_blocks(x, Fin, dhp, defer=ctx.packed)
-        if dwp is None:
-            dwp = mp.gemm_tn_splitk(x, Fin, dhp)
+        dwp = None
+        if want_w:
+            dwp = wgrad_blocks(x, Fin, dhp, defer=defer)
+            if dwp is None:
+                dwp = mp.gemm_tn_splitk(x, Fin, dhp)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = _f32(R, int(x.size(1)), device=dev)

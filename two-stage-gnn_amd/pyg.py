@@ -460,9 +460,19 @@ class GATConv(nn.Module):
         _gat_graph_cache[key] = (weakref.ref(edge_index), g)
         return g
 
-    def forward(self, x, edge_index):
+    def forward(self, x, edge_index, wp=None, apply_elu=False):
+        """wp: this layer's packed projection from pyg_gat.pack_layers (a model packs all of its layers in one launch); apply_elu:
+        ELU folded into the fused launch (a model's activation between layers)"""
+        from . import pyg_gat as pgat
+        from . import pyg_sage as ps
         n = x.size(0)
         g = edge_index if isinstance(edge_index, GraphBatch) else self._loop_graph(edge_index, n)
+        if pgat.conv_ok(self, x):
+            if wp is None:
+                wp = pgat.pack_layers([self])[0]
+            bias = self.bias if (self.bias is None or self.bias.data_ptr() % 16 == 0) else self.bias.clone()
+            return pgat.gat_conv(ps._rows16(x), wp, bias, g, self.heads, self.out_channels, self.negative_slope,
+                                 mean_heads=not self.concat, apply_elu=apply_elu)
         h = mp.linear_oi(x, self.lin_l.weight)
         mult = None
         if self.training and self.dropout > 0.0:
@@ -474,7 +484,8 @@ class GATConv(nn.Module):
         pre = att.attention_aggregate(h, self.att_r.view(self.heads, -1), self.att_l.view(self.heads, -1), g, self.heads,
                                       self.negative_slope, by_column=False, uniform_isolated=False, drop_mult=mult)
         out = pre if self.concat else att.elu_heads(pre, self.heads, mean_heads=True, apply_elu=False)
-        return bias_add(out, self.bias)
+        out = bias_add(out, self.bias)
+        return att.elu_heads(out, 1, mean_heads=False, apply_elu=True) if apply_elu else out
 
 
 class SAGPooling(nn.Module):
@@ -653,11 +664,11 @@ class GatNet(nn.Module):
         return GATConv._loop_graph(data.edge_index, data.x.size(0), sizes=segment_sizes(getattr(data, "batch", None), data.x.size(0)))
 
     def forward(self, data):
+        from . import pyg_gat as pgat
         g = self.graph(data)
         x = data.x
+        wps = pgat.pack_layers(list(self.convs)) if all(pgat.conv_ok(c, x) for c in self.convs) else [None] * len(self.convs)
         for l, conv in enumerate(self.convs):
-            x = conv(x, g)
-            if l < len(self.convs) - 1:
-                x = att.elu_heads(x, 1, mean_heads=False, apply_elu=True)
+            x = conv(x, g, wp=wps[l], apply_elu=l < len(self.convs) - 1)
         r = mp.readout_max(x, g) if g.row_graph is not None and g.n_ghost == 0 else global_max_pool(x, getattr(data, "batch", None))
         return torch.nn.functional.log_softmax(mp.linear_oi(r, self.lin.weight, self.lin.bias), dim=-1)

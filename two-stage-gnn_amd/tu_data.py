@@ -29,7 +29,19 @@ def _read_ints(path):
         text = f.read().replace(",", " ")
     if not text.strip():
         return np.zeros(0, dtype=np.int64)
-    return np.fromstring(text, dtype=np.int64, sep=" ")
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                   # numpy's text mode only WARNS when it stops at a token it cannot parse
+        try:
+            out = np.fromstring(text, dtype=np.int64, sep=" ")
+        except (DeprecationWarning, ValueError) as e:
+            raise ValueError("%s: not a list of integers (%s)" % (path, e))
+    # ... and returns the prefix it did parse: a float-formatted or malformed file must fail loudly, as the reference's int() does
+    # (load_data.py:24-60), not yield fewer nodes / edges / labels
+    n_tok = len(text.split())
+    if out.size != n_tok:
+        raise ValueError("%s: %d of %d tokens are integers" % (path, out.size, n_tok))
+    return out
 
 
 class TUDataset:
