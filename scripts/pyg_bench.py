@@ -70,10 +70,10 @@ def gat():
     lab = torch.from_numpy(hb["label"]).to(dev)
     ta, _, _ = step_us(ga, lambda: ga.loss(ga(x32, g32)[1], lab), iters=100)
     d = D()
-    d.x, d.edge_index, d.batch, lab2 = synthetic.to_pyg(hb, dev, pad_features=False)
+    d.x, d.edge_index, d.batch, lab2 = synthetic.to_pyg(hb, dev)
     torch.manual_seed(0)
     gb = pyg.GatNet(89, 64, 2, heads=4, num_layers=2).to(dev).train()
-    tb, _, _ = step_us(gb, lambda: torch.nn.functional.nll_loss(gb(d), lab2), iters=100)
+    tb, _, _ = step_us(gb, lambda: gb.loss(d, lab2), iters=100)
     print("DD GAT  b32  2L 4 heads h64 (%5d rows): surface A DGATEncoderGraph %.1f us/step (%.0f graphs/s) | surface B GatNet[GATConv] %.1f us/step (%.0f graphs/s) | B / A = %.2f"
           % (int(hb["sizes"].sum()), ta, 32 / ta * 1e6, tb, 32 / tb * 1e6, tb / ta), flush=True)
 

@@ -378,11 +378,11 @@ def test_pyg_sage_timed_step_vs_oracle(shape, B, layers, hid, seed):
 def test_pyg_gat_timed_step_vs_oracle():
     """BASELINE config 3 as worded — "DD GATConv 2-layer 4-head h=64 batch=32" — pyg.GatNet at the size scripts/pyg_bench.py times:
     three replayed optimiser steps against oracle/pyg_ref.gat_net + clip_grad_norm_ + Adam (fp32, fp64).  PARITY UNPINNED."""
-    from two_stage_gnn_amd import pyg, synthetic
+    from two_stage_gnn_amd import message_passing as mp, pyg, synthetic
     dev = torch.device("cuda")
     hb = synthetic.host_batch(seed=2, B=32, shape="DD", nmax=1000)
     d = _Data()
-    d.x, d.edge_index, d.batch, label = synthetic.to_pyg(hb, dev, pad_features=False)
+    d.x, d.edge_index, d.batch, label = synthetic.to_pyg(hb, dev)
     torch.manual_seed(0)
     net = pyg.GatNet(89, 64, 2, heads=4, num_layers=2).to(dev).train()
     x_cpu = torch.from_numpy(hb["x"])
@@ -397,17 +397,24 @@ def test_pyg_gat_timed_step_vs_oracle():
         return f
 
     def loss_fn(stash):
-        stash["logits"] = net(d)
-        return torch.nn.functional.nll_loss(stash["logits"], label)
+        logits = net.logits(d)
+        stash["logits"] = torch.log_softmax(logits.detach(), dim=-1)           # (what net(d) returns; compared with the oracle's)
+        return mp.cross_entropy(logits, label)
 
-    _run(net, loss_fn, fwd(torch.float32), fwd(torch.float64), lr=5e-4, max_frac=0.05, tag="PyG GATConv DD b32 2L 4 heads h64")
+    _run(net, loss_fn, fwd(torch.float32), fwd(torch.float64), lr=5e-4, max_frac=0.05, defer_loss=True,
+         tag="PyG GATConv DD b32 2L 4 heads h64")
 
 
 # ------------------------------------------------------------------------------------------------ long trajectories
-def _trajectory(model, loss_fn, forward32, forward64, lr, steps=200, every=20, clip=2.0, tag=""):
+TRAJ_STEPS = int(__import__("os").environ.get("TSGNN_TRAJ_STEPS", "100"))
+
+
+def _trajectory(model, loss_fn, forward32, forward64, lr, steps=None, every=20, clip=2.0, tag=""):
     """`steps` replayed optimiser steps against the oracle loop in fp32 and fp64; the loss is compared every `every` steps within
     max(10 |cpu32 - fp64|, 1e-3): a defect that shows once per N steps (a step counter that runs ahead, an accumulator that is not
-    re-armed, a workspace left dirty) moves a trajectory long before it moves three steps (VERDICT r3 #9)."""
+    re-armed, a workspace left dirty) moves a trajectory long before it moves three steps.  100 steps by default (the
+    two CPU oracle loops cost ~1.4 s per step); TSGNN_TRAJ_STEPS=200 is the run recorded in profiles/r04/trajectories.txt."""
+    steps = TRAJ_STEPS if steps is None else steps
     from two_stage_gnn_amd import message_passing as mp
     from two_stage_gnn_amd.data_parallel import FlatTrainer, GraphedStep
     p32, p64 = _clone_params(model, torch.float32), _clone_params(model, torch.float64)

@@ -253,29 +253,35 @@ __global__ __launch_bounds__(256) void gatconv_pack_kernel(GcPack p) {
   if (tid < L.Ns - C - 2 * L.H) L.wp[(int64_t)k * L.Ns + C + 2 * L.H + tid] = 0.f;
 }
 
-// gradients: thread c of block k' ... gw[c, k] = dW'[k, c] + dW'[k, C + h] att_r[c] + dW'[k, C + H + h] att_l[c]  (blocks [blk0, blk0 + Fin));
-// the layer's last block: gar[c] = sum_k W[c, k] dW'[k, C + h], gal[c] = sum_k W[c, k] dW'[k, C + H + h]   (h = c / Co)
+// gradients.  Blocks [blk0, blk0 + Fin): gw[c, k] = dW'[k, c] + dW'[k, C + h] att_r[c] + dW'[k, C + H + h] att_l[c]  (thread c, h = c / Co);
+// blocks [blk0 + Fin, blk0 + Fin + ceil(C / 4)): gar[c] = sum_k W[c, k] dW'[k, C + h], gal[c] = sum_k W[c, k] dW'[k, C + H + h] — one wave
+// per c, lanes stride over k (W's row is contiguous in k), lane sums added by DPP
 __global__ __launch_bounds__(256) void gatconv_unpack_kernel(GcPack p) {
   int li = 0;
 #pragma unroll
   for (int t = 1; t < GC_LMAX; ++t) if (t < p.L && (int)blockIdx.x >= p.l[t].blk0) li = t;
   const GcLayer& L = p.l[li];
-  const int b = (int)blockIdx.x - L.blk0, c = threadIdx.x;
+  const int b = (int)blockIdx.x - L.blk0;
   const int C = L.H * L.Co;
-  if (c >= C) return;
-  const int h = c / L.Co;
   if (b < L.Fin) {
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    const int h = c / L.Co;
     const float* d = L.wp + (int64_t)b * L.Ns;
     L.gw[(int64_t)c * L.ldw + b] = d[c] + d[C + h] * L.att_r[c] + d[C + L.H + h] * L.att_l[c];
     return;
   }
+  const int c = 4 * (b - L.Fin) + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= C) return;
+  const int h = c / L.Co;
   float sr = 0.f, sl = 0.f;
-  for (int k = 0; k < L.Fin; ++k) {
+  for (int k = lane; k < L.Fin; k += 64) {
     const float w = L.w[(int64_t)c * L.ldw + k];
     sr = fmaf(w, L.wp[(int64_t)k * L.Ns + C + h], sr);
     sl = fmaf(w, L.wp[(int64_t)k * L.Ns + C + L.H + h], sl);
   }
-  L.gar[c] = sr; L.gal[c] = sl;
+  sr = wave_sum(sr); sl = wave_sum(sl);
+  if (lane == 0) { L.gar[c] = sr; L.gal[c] = sl; }
 }
 
 int fill_pack(const int64_t* desc, GcPack& p, bool unpack) {
@@ -294,7 +300,7 @@ int fill_pack(const int64_t* desc, GcPack& p, bool unpack) {
     if (!l.w || !l.att_r || !l.att_l || !l.wp || l.Fin <= 0 || l.ldw < l.Fin || (unpack && (!l.gw || !l.gar || !l.gal))) return TSGNN_EINVAL;
     if (!gatconv_ok(l.H, l.Co) || l.Ns < l.H * l.Co + 2 * l.H || l.Ns - l.H * l.Co - 2 * l.H > 256) return TSGNN_EUNSUPPORTED;
     l.blk0 = blk;
-    blk += l.Fin + (unpack ? 1 : 0);
+    blk += l.Fin + (unpack ? (l.H * l.Co + 3) / 4 : 0);
   }
   return blk;
 }

@@ -31,6 +31,7 @@ def _f32(*shape, device, zero=False):
 
 _graph_cache = {}
 _gat_graph_cache = {}
+_eye_cache = {}
 
 
 def graph_of(edge_index, num_nodes, check_symmetry=False, sizes=None):
@@ -663,7 +664,7 @@ class GatNet(nn.Module):
             return data.edge_index
         return GATConv._loop_graph(data.edge_index, data.x.size(0), sizes=segment_sizes(getattr(data, "batch", None), data.x.size(0)))
 
-    def forward(self, data):
+    def features(self, data):
         from . import pyg_gat as pgat
         g = self.graph(data)
         x = data.x
@@ -671,4 +672,27 @@ class GatNet(nn.Module):
         for l, conv in enumerate(self.convs):
             x = conv(x, g, wp=wps[l], apply_elu=l < len(self.convs) - 1)
         r = mp.readout_max(x, g) if g.row_graph is not None and g.n_ghost == 0 else global_max_pool(x, getattr(data, "batch", None))
-        return torch.nn.functional.log_softmax(mp.linear_oi(r, self.lin.weight, self.lin.bias), dim=-1)
+        return r
+
+    def logits(self, data):
+        """lin(readout): the head as ONE launch each way (the two-Linear head kernels with W2 = I: 1 * v + 0 * u is exact), so that a
+        cross-entropy on it can be folded into the head's backward (mp.cross_entropy under FlatTrainer(defer_loss=True))"""
+        r = self.features(data)
+        C = self.lin.out_features
+        if mp.HEAD_TAIL is not None and r.is_cuda and r.size(1) % 4 == 0 and r.size(1) <= 2048 and r.size(0) <= 1024 \
+                and self.lin.weight.data_ptr() % 16 == 0:
+            eye = _eye_cache.get((C, r.device))
+            if eye is None:
+                eye = _eye_cache[(C, r.device)] = torch.eye(C, dtype=torch.float32, device=r.device)
+            y = mp._Head2.apply(r, self.lin.weight, self.lin.bias, eye, None)[1]
+            y._tsgnn_defer_ce = True
+            return y
+        return mp.linear_oi(r, self.lin.weight, self.lin.bias)
+
+    def forward(self, data):
+        return torch.nn.functional.log_softmax(self.logits(data), dim=-1)
+
+    def loss(self, data, label):
+        """nll_loss(log_softmax(lin(readout))) = cross_entropy(lin(readout)): the fused softmax + CE kernel (folded into the head's
+        backward under FlatTrainer(defer_loss=True))"""
+        return mp.cross_entropy(self.logits(data), label)

@@ -142,9 +142,14 @@ class _GatConv(torch.autograd.Function):
         nat.call("gat_score_rowsum_f32", rp_t, col_t, src_e_t, t1, t2, S, R, H, dhp, dhp.stride(0), C + H, None, int(g.B), None, None, None, 1.0)
         db = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = mp.colsum(dpre)                                  # [C]
-            if mean_heads:                                        # bias [Co] is added after the mean: dpre carries dy / H per head
-                db = db.view(H, Co).sum(0)
+            # bias is added after the aggregation (and after the mean over heads): its gradient is the column sum of the gradient of
+            # the pre-activation — dpre [R, C] for concatenated heads; with the mean, of d(out) = dy * ELU'(y) [R, Co] (= sum_h dpre_h)
+            if not mean_heads:
+                db = mp.colsum(dpre)
+            elif not apply_elu:
+                db = mp.colsum(dy)
+            else:
+                db = mp.colsum(dpre).view(H, Co).sum(0)
         want_w = ctx.needs_input_grad[1]
         defer = ctx.pending if (want_w and ctx.pending is not None and ctx.uses is not None and ctx.uses[0] == 1 and not wp.retains_grad) else None
         if ctx.needs_input_grad[0] and want_w and gf.MERGED_BWD_PRODUCTS:
