@@ -194,6 +194,24 @@ def sag_pooling(x, edge_index, batch, ratio, w_l, b_l, w_r):
     return x, filter_adj(edge_index, perm, score.numel()), batch[perm], perm, score[perm]
 
 
+def sage_pool_net(p, x, edge_index, batch, ratio, return_perms=False):
+    """two_stage_gnn_amd.pyg.SagePoolNet: Code/sag/network.py:30-53's shape with SAGEConv layers and PyG SAGPooling (GraphConv scorer)
+    — BASELINE config 4 as worded; eval mode"""
+    B = int(batch.max()) + 1
+    out, perms = None, []
+    for l in range(3):
+        x = F.relu(sage_conv(x, edge_index, p["convs.%d.lin_l.weight" % l], p["convs.%d.lin_l.bias" % l], p["convs.%d.lin_r.weight" % l]))
+        x, edge_index, batch, perm, _ = sag_pooling(x, edge_index, batch, ratio, p["pools.%d.gnn.lin_l.weight" % l],
+                                                    p["pools.%d.gnn.lin_l.bias" % l], p["pools.%d.gnn.lin_r.weight" % l])
+        perms.append(perm)
+        r = torch.cat([global_max_pool(x, batch, B), global_mean_pool(x, batch, B)], dim=1)
+        out = r if out is None else out + r
+    h = F.relu(F.linear(out, p["lin1.weight"], p["lin1.bias"]))
+    h = F.relu(F.linear(h, p["lin2.weight"], p["lin2.bias"]))
+    y = F.log_softmax(F.linear(h, p["lin3.weight"], p["lin3.bias"]), dim=-1)
+    return (y, perms) if return_perms else y
+
+
 def topk_pooling(x, edge_index, batch, ratio, weight):
     """PyG TopKPooling (imported, never called, Code/sag/network.py:3): score = tanh(x . p / ||p||), top-k on the score,
     x[perm] * score[perm]; weight [1, F]."""

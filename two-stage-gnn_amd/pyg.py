@@ -696,3 +696,43 @@ class GatNet(nn.Module):
         """nll_loss(log_softmax(lin(readout))) = cross_entropy(lin(readout)): the fused softmax + CE kernel (folded into the head's
         backward under FlatTrainer(defer_loss=True))"""
         return mp.cross_entropy(self.logits(data), label)
+
+
+class SagePoolNet(nn.Module):
+    """BASELINE config 4 as worded ("IMDB-BINARY SAGPool (ratio 0.5) + SAGEConv h=128 batch=128"): Code/sag/network.py:9-53 with its
+    GCNConv layers replaced by SAGEConv and its pooling by PyG's SAGPooling (GraphConv scorer) — conv + ReLU, pool, [gmp || gap] per
+    level, summed; lin1-3; log_softmax.  The conv layers are the fused SAGEConv launches; the pooling levels are composed from the
+    drop-in operators (top-k / filter_adj size their outputs from the data: three host round trips per level, like PyG).  The
+    sync-free single-node form exists for the reference's own SAGPool + GCNConv network (sag_layers.Net, sag_stack.py); carrying the
+    mean aggregation and the GraphConv scorer through those per-graph kernels is listed as open in DESIGN.md."""
+
+    def __init__(self, num_features, nhid, num_classes, pooling_ratio=0.5, dropout_ratio=0.0):
+        super().__init__()
+        self.nhid, self.pooling_ratio, self.dropout_ratio = nhid, pooling_ratio, dropout_ratio
+        self.convs = nn.ModuleList([SAGEConv(num_features if l == 0 else nhid, nhid) for l in range(3)])
+        self.pools = nn.ModuleList([SAGPooling(nhid, ratio=pooling_ratio) for _ in range(3)])
+        dev = _default_device()
+        self.lin1 = nn.Linear(nhid * 2, nhid).to(dev)
+        self.lin2 = nn.Linear(nhid, nhid // 2).to(dev)
+        self.lin3 = nn.Linear(nhid // 2, num_classes).to(dev)
+        self.last_perms = None
+
+    def forward(self, data):
+        x, edge_index = data.x, data.edge_index
+        batch = getattr(data, "batch", None)
+        if batch is None:
+            batch = torch.zeros(x.size(0), dtype=torch.int64, device=x.device)
+        out, perms = None, []
+        for conv, pool in zip(self.convs, self.pools):
+            x = relu(conv(x, edge_index))
+            x, edge_index, _, batch, perm, _ = pool(x, edge_index, None, batch)
+            perms.append(perm)
+            r = torch.cat([global_max_pool(x, batch), global_mean_pool(x, batch)], dim=1)
+            out = r if out is None else out + r
+        self.last_perms = perms
+        if mp.mlp3_ok(out, self.lin1, self.lin2, self.lin3):
+            return mp.mlp3_log_softmax(out, self.lin1, self.lin2, self.lin3, self.dropout_ratio, self.training)
+        h = relu(mp.linear_oi(out, self.lin1.weight, self.lin1.bias))
+        h = torch.nn.functional.dropout(h, p=self.dropout_ratio, training=self.training)
+        h = relu(mp.linear_oi(h, self.lin2.weight, self.lin2.bias))
+        return torch.nn.functional.log_softmax(mp.linear_oi(h, self.lin3.weight, self.lin3.bias), dim=-1)
