@@ -78,8 +78,52 @@ def gat():
           % (int(hb["sizes"].sum()), ta, 32 / ta * 1e6, tb, 32 / tb * 1e6, tb / ta), flush=True)
 
 
+def sagpool():
+    """config 4 as worded: IMDB-B SAGPooling(0.5) + SAGEConv h = 128, batch 128 — composed per level (host round trips for the data-
+    dependent sizes, like PyG) beside the reference-surface network (sag_layers.Net: SAGPool + GCNConv as one sync-free node)"""
+    import numpy as np
+    from two_stage_gnn_amd import sag_layers as S
+    dev = torch.device("cuda")
+    hb = synthetic.host_batch(3, 128, "IMDB-BINARY", 136)
+    sizes = hb["sizes"]; n = int(sizes.sum())
+    rp, col = hb["rowptr"][: n + 1], hb["col"]
+    dst = np.repeat(np.arange(n), np.diff(rp))
+    d = D()
+    d.edge_index = torch.from_numpy(np.stack([col.astype(np.int64), dst.astype(np.int64)])).to(dev)
+    d.x = torch.ones(n, 1, device=dev)
+    d.batch = torch.repeat_interleave(torch.arange(128), torch.from_numpy(sizes)).to(dev)
+    lab = torch.from_numpy(hb["label"]).to(dev)
+    torch.manual_seed(0)
+    na = S.Net(1, 128, 2, 0.5, 0.0, use_batch=True).to(dev).train()
+    ta, _, _ = step_us(na, lambda: mp.nll_loss(na(d), lab), iters=100)
+    torch.manual_seed(0)
+    nb = pyg.SagePoolNet(1, 128, 2, 0.5).to(dev).train()
+    opt = torch.optim.Adam(nb.parameters(), lr=1e-3)
+
+    def eager():
+        opt.zero_grad(set_to_none=True)
+        torch.nn.functional.nll_loss(nb(d), lab).backward()
+        torch.nn.utils.clip_grad_norm_(nb.parameters(), 2.0)
+        opt.step()
+    for _ in range(5):
+        eager()
+    torch.cuda.synchronize()
+    import time
+    t0 = time.perf_counter()
+    for _ in range(20):
+        eager()
+    torch.cuda.synchronize()
+    tb = (time.perf_counter() - t0) / 20 * 1e6
+    print("IMDB-B   b128 h128 ratio .5 (%5d rows): surface A Net[SAGPool + GCNConv] %.1f us/step (%.0f graphs/s, one hipGraph) | surface B "
+          "SagePoolNet[SAGPooling + SAGEConv] %.0f us/step EAGER (%.0f graphs/s; three host round trips per level for k / E' / batch) | B / A = %.1f"
+          % (n, ta, 128 / ta * 1e6, tb, 128 / tb * 1e6, tb / ta), flush=True)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "GAT":
         gat()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "SAGPOOL":
+        sagpool()
         sys.exit(0)
     main()

@@ -24,6 +24,11 @@ d.x, d.edge_index, d.batch, lab = synthetic.to_pyg(hb, dev)
 torch.manual_seed(1234)
 net = pyg.SageNet(synthetic.SHAPES[shape][2], hid, 2, num_layers=L).to(dev).train()
 tr = FlatTrainer(net, lr=1e-3, clip=2.0, defer_loss=True)
+if os.environ.get("PYG_EAGER") == "1":                    # eager steps (PMC counters are attributed per dispatch outside a hipGraph)
+    for _ in range(reps):
+        tr.step(lambda: mp.nll_loss(net(d), lab))
+    torch.cuda.synchronize()
+    sys.exit(0)
 gs = GraphedStep(tr, lambda: mp.nll_loss(net(d), lab), warmup=3)
 for _ in range(20):
     gs.step()
