@@ -744,3 +744,59 @@ def test_bench_two_ranks_end_to_end_gloo():
     assert [p["rank"] for p in pr] == [0, 1] and pr[0]["rows"] != pr[1]["rows"]          # rank r drew the batch of seed r
     assert all(p["ms_per_step"] > 0 for p in pr)
     assert d["steps_per_graph_launch"] == 1 and d["settle_untimed_steps"] == 4
+
+
+def _poison_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from two_stage_gnn_amd import message_passing as mp
+    from two_stage_gnn_amd.data_parallel import FlatTrainer
+    dev = torch.device("cuda")
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(32, 4).to(dev)
+    tr = FlatTrainer(lin, lr=1e-2, clip=2.0)
+    x = torch.randn(8, 32, device=dev, generator=torch.Generator(device=dev).manual_seed(rank))
+
+    def one():
+        return tr.step(lambda: lin(x).square().mean())
+    one(); tr.check()
+    before = tr.flat_param.clone()
+    if rank == 1:
+        mp.device_error_word(dev).fill_(1.0)                 # what a kernel whose bounded barrier timed out leaves behind
+    one()
+    torch.cuda.synchronize()
+    unchanged = bool(torch.equal(tr.flat_param, before))
+    skipped = float(tr.state[3])
+    msg = ""
+    try:
+        tr.check()
+    except RuntimeError as e:
+        msg = str(e)
+    one(); tr.check()                                        # cleared: the next step is applied again, on every rank
+    q.put((rank, unchanged, skipped, msg, tr.flat_param.detach().cpu().numpy(), float(tr.state[0])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_error_word_of_one_rank_stops_every_rank():
+    """the device error word used to be rank-local — the rank whose kernel failed skipped its optimiser update while the other
+    ranks applied theirs with the already all-reduced gradients.  It now rides in the gradient all-reduce: a failure on rank 1 makes BOTH
+    ranks skip, both raise at their next check, and the replicas stay bit-identical."""
+    ctx = mp_.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 311) % 2000
+    procs = [ctx.Process(target=_poison_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for r in res:
+        assert r[1] and r[2] == 1.0, r[:4]                   # neither rank applied the poisoned step
+    assert "another rank" in res[0][3] and "timed out" in res[1][3], (res[0][3], res[1][3])
+    np.testing.assert_array_equal(res[0][4], res[1][4])      # replicas identical after the recovery step
+    assert res[0][5] == res[1][5] == 2.0

@@ -474,10 +474,9 @@ def _trajectory(model, loss_fn, forward32, forward64, lr, steps=None, every=20, 
             lh = gs.loss_value()                                     # (synchronises, checks the device's error word)
             assert float(trainer.state[0]) == float(i) and float(trainer.state[3]) == 0.0
             rows.append((i, lh, l32, l64))
+            print("%s step %3d: loss hip %.6f cpu32 %.6f fp64 %.6f" % (tag, i, lh, l32, l64), flush=True)
             assert abs(lh - l64) <= max(10 * abs(l32 - l64), 1e-3), (tag, i, lh, l32, l64)
     mp.check_device_errors()
-    for r in rows:
-        print("%s step %3d: loss hip %.6f cpu32 %.6f fp64 %.6f" % ((tag,) + r))
     assert rows[-1][3] < rows[0][3]                                   # (and the model did learn something on its one batch)
 
 

@@ -49,7 +49,12 @@ class FlatTrainer:
             off += p.numel()
         self.numel = off
         self.flat_param = torch.zeros(self.numel, dtype=torch.float32, device=dev)
-        self.flat_grad = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        # the gradient bucket with one spare slot behind it: at N > 1 every rank puts ITS device error word there before the collective,
+        # so the SUM all-reduce hands every rank the same verdict and all of them skip (and later raise) together — a rank-local word
+        # let the healthy ranks apply an update the failed rank skipped
+        self._grad_store = torch.zeros(self.numel + 4, dtype=torch.float32, device=dev)
+        self.flat_grad = self._grad_store[:self.numel]
+        self._err_slot = self._grad_store[self.numel:self.numel + 1]
         for p, (o, n) in zip(self.params, self.views):
             self.flat_param[o:o + n].copy_(p.data.reshape(-1))
             p.data = self.flat_param[o:o + n].view_as(p.data)
@@ -188,16 +193,23 @@ class FlatTrainer:
         return self.flat_grad
 
     def all_reduce(self):
-        """SUM over ranks on the flat bucket; the 1/world factor is applied inside the optimiser kernel."""
+        """SUM over ranks on the flat bucket (+ the error-word slot behind it); the 1/world factor is applied inside the optimiser
+        kernel."""
         if self.world > 1 or self.always_reduce:
+            if self.poison is not None:
+                self._err_slot.copy_(self.poison)                           # this rank's error word rides in the collective
             if self._early_issued:
                 a, b = self._early
-                for s_, e_ in ((0, a), (b, self.numel)):
+                for s_, e_ in ((0, a), (b, self.numel + 4)):
                     if e_ > s_:
-                        dist.all_reduce(self.flat_grad[s_:e_], op=dist.ReduceOp.SUM, group=self.group)
+                        dist.all_reduce(self._grad_store[s_:e_], op=dist.ReduceOp.SUM, group=self.group)
                 torch.cuda.current_stream().wait_stream(self._side)        # join: the optimiser needs both buckets
                 return
-            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(self._grad_store, op=dist.ReduceOp.SUM, group=self.group)
+
+    def _poison_word(self):
+        """what the optimiser kernels read as `poison`: the device's error word, or — after an all-reduce — the sum of every rank's"""
+        return self._err_slot if ((self.world > 1 or self.always_reduce) and self.poison is not None) else self.poison
 
     def apply(self):
         scale = 1.0 / self.world
@@ -207,24 +219,30 @@ class FlatTrainer:
         if getattr(self, "_norm_ready", False):
             nat.call("adam_from_partials_f32", self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.numel,
                      float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd), float(self.clip),
-                     self.state, self.sink.norm_parts, int(self.sink.norm_used), self.poison)
+                     self.state, self.sink.norm_parts, int(self.sink.norm_used), self._poison_word())
             return
         if self.sink is not None and self.sink.stepped:
             self.state[0] -= 1.0                        # the gradient reduction advanced the counter for the barrier-free path
         nat.call("clip_adam_step_f32", self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.numel,
                  float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd),
-                 float(self.clip), float(scale), self.state, self.ws, self.poison)
+                 float(self.clip), float(scale), self.state, self.ws, self._poison_word())
 
     def check(self):
         """synchronise and raise if a kernel of a step since the last check reported invalid results (a bounded device-wide
         barrier that timed out).  The optimiser has skipped every update since then (state[3] = 1), so parameters and moments
         are those of the last good step."""
         torch.cuda.synchronize()
+        skipped = self.on_gpu and float(self.state[3]) != 0.0
         try:
             mp.check_device_errors()
+            if skipped and (self.world > 1 or self.always_reduce):
+                # this rank's own kernels are fine, but the optimiser skipped: ANOTHER rank's error word arrived with the gradients
+                raise RuntimeError("a bounded device-wide barrier timed out on another rank: every rank skipped the optimiser update "
+                                   "since (the replicas still hold identical parameters)")
         finally:
-            if self.on_gpu and float(self.state[3]) != 0.0:
+            if skipped:
                 self.state[3] = 0.0
+                self._err_slot.zero_()
                 torch.cuda.synchronize()
 
     def step(self, loss_fn):
@@ -462,6 +480,7 @@ class GraphedStep:
         """enqueue n consecutive steps on self.stream: graphs of `steps_per_replay` steps while they fit, single steps for the rest
         (the same n optimiser steps as n calls of step(), bit for bit — tests/test_data_parallel.py)"""
         n = int(n)
+        self._since_check = getattr(self, "_since_check", 0) + n
         if self._fbk is not None:
             with torch.cuda.stream(self.stream):
                 while n >= self.steps_per_replay:
@@ -470,7 +489,14 @@ class GraphedStep:
                     self.loss = self._lossk
         for _ in range(n):
             self.step()
+        if self._since_check >= self.CHECK_EVERY:
+            # a loop that only ever calls run() / step() would never raise: look at the error word at a coarse interval (one
+            # synchronisation per CHECK_EVERY enqueued steps)
+            self._since_check = 0
+            self.synchronize()
         return self.loss
+
+    CHECK_EVERY = 4096
 
     def step(self):
         """enqueue one step on self.stream (returns immediately; self.loss is the device scalar of the last step; read it through
