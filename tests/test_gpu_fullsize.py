@@ -566,6 +566,13 @@ def test_barrier_timeout_poisons_the_optimiser_and_raises():
     assert float(err) == 0.0 and int(words.abs().sum()) == 0 and float(tr.state[3]) == 0.0      # cleared, barrier words re-armed
     one(); tr.check()                                                    # and the next step is applied again
     assert not torch.equal(tr.flat_param, before) and float(tr.state[0]) == 2.0
+    # self-clearing workspaces (a completed launch leaves them zero, an aborted one may not) are re-zeroed by the same path
+    ws = mp.register_clear_on_error(torch.ones(16, dtype=torch.int64, device=dev))
+    nat.call("dense_stack_barrier_selftest", words, err, 2)
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="barrier timed out"):
+        tr.check()
+    assert int(ws.abs().sum()) == 0
 
 
 # ------------------------------------------------------------------------------------------------ bitwise repeatability

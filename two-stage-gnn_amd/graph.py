@@ -341,9 +341,11 @@ class GraphBatch:
         ws = getattr(self, "_bn_ws", None)
         if ws is None or ws["key"] != key:
             words = (L - 1) * 2 * nslots
-            ws = {"key": key, "sums": torch.zeros(max(words, 2), dtype=torch.int64, device=self.device),
-                  "ghost": torch.zeros(max(2 * (L - 1), 2), dtype=torch.float32, device=self.device),
-                  "packed": torch.zeros(B * ((L - 1) * Fh + Fl) + Fl, dtype=torch.int64, device=self.device), "dirty": False}
+            from . import message_passing as mp        # (zeroed again if a launch is reported aborted: mp.register_clear_on_error)
+            ws = {"key": key, "sums": mp.register_clear_on_error(torch.zeros(max(words, 2), dtype=torch.int64, device=self.device)),
+                  "ghost": mp.register_clear_on_error(torch.zeros(max(2 * (L - 1), 2), dtype=torch.float32, device=self.device)),
+                  "packed": mp.register_clear_on_error(torch.zeros(B * ((L - 1) * Fh + Fl) + Fl, dtype=torch.int64, device=self.device)),
+                  "dirty": False}
             self._bn_ws = ws
         return ws
 

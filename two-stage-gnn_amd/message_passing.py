@@ -725,7 +725,7 @@ def _readout_ws(g, F, dev):
         words = int(nat.lib().tsgnn_readout_max_ws_words(int(g.B), int(g.nmax), int(F)))
         if words <= 0:
             raise ValueError("max readout: batch of %d graphs x %d slots x %d features is out of range" % (g.B, g.nmax, F))
-        ws = cache[key] = torch.zeros(words, dtype=torch.int64, device=dev)
+        ws = cache[key] = register_clear_on_error(torch.zeros(words, dtype=torch.int64, device=dev))
     return ws
 
 
@@ -1023,6 +1023,23 @@ def register_barrier_words(device, words):
     _err_words[_dev_key(device)][1].append(words)
 
 
+_clear_on_error = {}                # device -> [weakref to a tensor that a COMPLETED launch leaves zero and an aborted one may not]
+
+
+def register_clear_on_error(t):
+    """Workspaces that launches re-arm themselves (the packed max-readout buffers and ticket counters of tsgnn_readout_max_fwd_f32, the
+    integer batch-norm sums / packed maxima of the fused stacks, the readout accumulators of the SAGEConv stack): a launch that does not
+    complete — the case the device error word reports — may leave stale values behind, and every later launch on that batch would be
+    silently wrong.  Registered here (weakly: the workspace lives and dies with its batch), they are zeroed when check_device_errors()
+    finds the error word set."""
+    import weakref
+    lst = _clear_on_error.setdefault(_dev_key(t.device), [])
+    lst.append(weakref.ref(t))
+    if len(lst) > 4096:                                     # prune dead entries now and then
+        lst[:] = [r for r in lst if r() is not None]
+    return t
+
+
 def check_device_errors(synchronize=True):
     """Raises if a kernel reported a failure it could not return through its status (a bounded device-wide barrier that was not
     completed: the launch's results are invalid).  Reads one float per device that ever armed such a kernel, so it belongs where
@@ -1034,6 +1051,10 @@ def check_device_errors(synchronize=True):
             for t in (state if isinstance(state, list) else [state]):
                 if t is not None:
                     t.zero_()               # the barrier words of the failed launch
+            for ref in _clear_on_error.get(_dev_key(flag.device), []):
+                t = ref()
+                if t is not None:
+                    t.zero_()               # self-clearing workspaces an aborted launch may have left dirty
             raise RuntimeError(msg)
 
 

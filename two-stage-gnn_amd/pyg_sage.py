@@ -229,8 +229,8 @@ def _ro_workspace(g, L, B, H):
     key = (L, B, H)
     ws = getattr(g, "_sage_ro_ws", None)
     if ws is None or ws["key"] != key:
-        ws = g._sage_ro_ws = {"key": key, "packed": torch.zeros(L * B * H, dtype=torch.int64, device=g.device),
-                              "sums": torch.zeros(L * B * H, dtype=torch.int64, device=g.device), "dirty": False}
+        ws = g._sage_ro_ws = {"key": key, "packed": mp.register_clear_on_error(torch.zeros(L * B * H, dtype=torch.int64, device=g.device)),
+                              "sums": mp.register_clear_on_error(torch.zeros(L * B * H, dtype=torch.int64, device=g.device)), "dirty": False}
     return ws
 
 
