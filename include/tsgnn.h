@@ -696,6 +696,14 @@ int tsgnn_gcn_propagate_affine_f32(const int* rowptr, const int* rowend, const i
                                    const float* x, int64_t ldx, float* agg, int64_t ldagg, int64_t n_rows, int feat, const float* w,
                                    int64_t ldw, const float* bias, float* y, int64_t ldy, int n_out, tsgnn_stream_t stream);
 /* 1 when the fused level kernels below accept feature width F (F % 4 == 0, F <= 256) */
+/* the propagate launches with SEPARATE row / column coefficients (round 4): y[i] = row_scale[i] * sum_{j in row i} col_scale[j] x[j] +
+ * self_w[i] x[i] — the mean aggregation of PyG SAGEConv on a (filtered) level's CSR: row_scale = 1 / deg, col_scale = 1, self_w = 0; its
+ * transpose on a symmetric edge list: row_scale = 1, col_scale = 1 / deg.  rowend nullable as in tsgnn_gcn_propagate_re_f32. */
+int tsgnn_propagate_scaled_f32(const int* rowptr, const int* rowend, const int* col, const float* row_scale, const float* col_scale,
+                               const float* self_w, const float* x, int64_t ldx, float* y, int64_t ldy, int64_t n_rows, int feat,
+                               tsgnn_stream_t stream);
+/* out[i] = 1 / max(cnt[i], 1) */
+int tsgnn_inv_count_f32(const int* cnt, int64_t n, float* out, tsgnn_stream_t stream);
 int tsgnn_sag_supported(int F);
 /* kept rows (layers.py:21): xp[p,:] = relu?(y[perm[p],:]) * tanh(score[perm[p]]); cnt[p] = kept neighbours of perm[p].
  * y = xp = NULL: count only (the transposed adjacency of a non-symmetric graph). */

@@ -99,12 +99,16 @@ def sag_pool(x, edge_index, batch, ratio, score_w, score_b):
     return x, filter_adj(edge_index, perm, score.size(0)), batch[perm], perm
 
 
-def sag_net(p, x, edge_index, ratio, batch=None):
+def sag_net(p, x, edge_index, ratio, batch=None, conv="gcn"):
     """Code/sag/network.py:30-53 (eval mode: dropout off).  batch=None reproduces the reference, which
-    discards data.batch (:32, trap T6)."""
+    discards data.batch (:32, trap T6).  conv = "sage": the network's GCNConv layers replaced by PyG SAGEConv (BASELINE config 4 as
+    worded: "SAGPool + SAGEConv"); the SAGPool layers are the reference's (layers.py:14-25)."""
     outs = []
     for i in (1, 2, 3):
-        x = F.relu(gcn_conv(x, edge_index, p["conv%d.weight" % i], p["conv%d.bias" % i]))
+        if conv == "sage":
+            x = F.relu(sage_conv(x, edge_index, p["conv%d.lin_l.weight" % i], p["conv%d.lin_l.bias" % i], p["conv%d.lin_r.weight" % i]))
+        else:
+            x = F.relu(gcn_conv(x, edge_index, p["conv%d.weight" % i], p["conv%d.bias" % i]))
         x, edge_index, batch, _ = sag_pool(x, edge_index, batch, ratio, p["pool%d.score_layer.weight" % i],
                                            p["pool%d.score_layer.bias" % i])
         B = int(batch.max()) + 1

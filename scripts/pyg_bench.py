@@ -97,6 +97,12 @@ def sagpool():
     na = S.Net(1, 128, 2, 0.5, 0.0, use_batch=True).to(dev).train()
     ta, _, _ = step_us(na, lambda: mp.nll_loss(na(d), lab), iters=100)
     torch.manual_seed(0)
+    nc = S.Net(1, 128, 2, 0.5, 0.0, use_batch=True, conv="sage").to(dev).train()
+    tc, _, _ = step_us(nc, lambda: mp.nll_loss(nc(d), lab), iters=100)
+    print("IMDB-B   b128 h128 ratio .5 (%5d rows): surface A Net[SAGPool + GCNConv] %.1f us/step (%.0f graphs/s) | config 4 as worded, "
+          "Net[SAGPool + SAGEConv] as one sync-free node %.1f us/step (%.0f graphs/s) | B / A = %.2f"
+          % (n, ta, 128 / ta * 1e6, tc, 128 / tc * 1e6, tc / ta), flush=True)
+    torch.manual_seed(0)
     nb = pyg.SagePoolNet(1, 128, 2, 0.5).to(dev).train()
     opt = torch.optim.Adam(nb.parameters(), lr=1e-3)
 

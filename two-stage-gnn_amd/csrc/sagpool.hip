@@ -63,7 +63,12 @@ struct PropArgs {
   // narrow inputs only (feat <= 8, wave-per-row kernel): the GCNConv transform that follows the aggregation in the same launch,
   // lin_y[row, :lin_n] = agg[row, :feat] . lin_w[feat, lin_n] + lin_b  (network.py:34 at num_features = 1: an outer product)
   const float* lin_w; int64_t ldlw; const float* lin_b; float* lin_y; int64_t ldly; int lin_n;
+  // nullable (round 4): separate coefficients for the gathered rows — out_i = dinv[i] * sum_j col_scale[j] x_j + self_w[i] x_i.  NULL: the
+  // symmetric GCN normalisation (col_scale = dinv).  Mean aggregation (PyG SAGEConv): dinv = 1 / deg, col_scale = 1, self_w = 0; its
+  // transpose for a symmetric edge list: dinv = 1, col_scale = 1 / deg.
+  const float* col_scale;
 };
+__device__ __forceinline__ const float* prop_cs(const PropArgs& a) { return a.col_scale ? a.col_scale : a.dinv; }
 
 template <int G>
 __global__ __launch_bounds__(256) void gcn_propagate_vec4(PropArgs a, unsigned nblk) {
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(256) void gcn_propagate_vec4(PropArgs a, unsigned n
   for (int eb = e0; eb < e1; eb += G) {
     const int me = eb + lig;
     const int cj = (me < e1) ? a.col[me] : 0;
-    const float dj = (me < e1) ? a.dinv[cj] : 0.f;
+    const float dj = (me < e1) ? prop_cs(a)[cj] : 0.f;
     const int cnt = min(G, e1 - eb);
     int k = 0;
     for (; k + 4 <= cnt; k += 4) {
@@ -141,7 +146,7 @@ __global__ __launch_bounds__(256) void gcn_propagate_vec4_rb(PropArgs a, unsigne
   for (int base = eb[0]; base < eb[RB]; base += G) {
     const int me = base + lig;
     const int cj = (me < eb[RB]) ? a.col[me] : 0;
-    const float dj = (me < eb[RB]) ? a.dinv[cj] : 0.f;
+    const float dj = (me < eb[RB]) ? prop_cs(a)[cj] : 0.f;
     const int cnt = min(G, eb[RB] - base);
     for (int k = 0; k < cnt; k += 8) {
       float4 v[8];
@@ -207,7 +212,7 @@ __global__ __launch_bounds__(256) void gcn_propagate_generic(PropArgs a) {
           const int j = a.col[e];
           float v = a.x[(int64_t)j * a.ldx + f];
           if (a.relu_in) v = fmaxf(v, 0.f);
-          acc = fmaf(a.dinv[j], v, acc);
+          acc = fmaf(prop_cs(a)[j], v, acc);
         }
         acc = wave_sum(acc);
         float xs = a.x[row * a.ldx + f];
@@ -239,7 +244,7 @@ __global__ __launch_bounds__(256) void gcn_propagate_generic(PropArgs a) {
     for (int eb = e0; eb < e1; eb += 64) {
       const int me = eb + lane;
       const int cj = (me < e1) ? a.col[me] : 0;
-      const float dj = (me < e1) ? a.dinv[cj] : 0.f;
+      const float dj = (me < e1) ? prop_cs(a)[cj] : 0.f;
       const int cnt = min(64, e1 - eb);
       for (int k = 0; k < cnt; ++k) {
         const int j = __shfl(cj, k, 64);
@@ -275,7 +280,7 @@ __global__ __launch_bounds__(256) void gcn_propagate_narrow(PropArgs a) {
 #pragma unroll 4
   for (int e = e0; e < e1; ++e) {
     const int j = a.col[e];
-    const float dj = a.dinv[j];
+    const float dj = prop_cs(a)[j];
     const float* xr = a.x + (int64_t)j * a.ldx;
 #pragma unroll
     for (int f = 0; f < PROP_NARROW_MAX; ++f) {
@@ -1137,6 +1142,47 @@ int tsgnn_gcn_propagate_re_f32(const int* rowptr, const int* rowend, const int* 
   } else {
     gcn_propagate_generic<<<(unsigned)ceil_div64(n_rows, 4), 256, 0, stream>>>(a);
   }
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+/* the same launches with SEPARATE row / column coefficients: y[i] = row_scale[i] * sum_{j in row i} col_scale[j] x[j] + self_w[i] x[i]
+ * (mean aggregation of PyG SAGEConv: row_scale = 1 / deg, col_scale = 1, self_w = 0; its transpose on a symmetric edge list: row_scale = 1,
+ * col_scale = 1 / deg) */
+int tsgnn_propagate_scaled_f32(const int* rowptr, const int* rowend, const int* col, const float* row_scale, const float* col_scale,
+                               const float* self_w, const float* x, int64_t ldx, float* y, int64_t ldy, int64_t n_rows, int feat,
+                               tsgnn_stream_t stream) {
+  if (n_rows < 0 || feat <= 0 || !rowptr || !row_scale || !col_scale || !self_w || !x || !y || ldx < feat || ldy < feat) return TSGNN_EINVAL;
+  if (n_rows == 0) return TSGNN_OK;
+  PropArgs a{rowptr, rowend, col, row_scale, self_w, x, ldx, nullptr, nullptr, nullptr, y, ldy, nullptr, n_rows, feat, 0};
+  a.col_scale = col_scale;
+  const bool vec_ok = feat % 4 == 0 && feat <= 256 && ldx % 4 == 0 && aligned16(x) && ldy % 4 == 0 && aligned16(y);
+  if (vec_ok) {
+    switch (group_of(feat)) {
+      case 8: launch_prop<8>(a, stream); break;
+      case 16: launch_prop<16>(a, stream); break;
+      case 32: launch_prop<32>(a, stream); break;
+      default: launch_prop<64>(a, stream); break;
+    }
+  } else {
+    gcn_propagate_generic<<<(unsigned)ceil_div64(n_rows, 4), 256, 0, stream>>>(a);
+  }
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+namespace {
+__global__ void inv_count_kernel(const int* __restrict__ cnt, int64_t n, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = 1.0f / (float)max(cnt[i], 1);
+}
+}  // namespace
+
+/* out[i] = 1 / max(cnt[i], 1): the mean aggregation's row coefficients from a level's kept-neighbour counts */
+int tsgnn_inv_count_f32(const int* cnt, int64_t n, float* out, tsgnn_stream_t stream) {
+  if (!cnt || !out || n < 0) return TSGNN_EINVAL;
+  if (n == 0) return TSGNN_OK;
+  inv_count_kernel<<<(unsigned)ceil_div64(n, 256), 256, 0, stream>>>(cnt, n, out);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }

@@ -41,16 +41,20 @@ class Net(nn.Module):
     (hipGraph-capturable); ``fused=False`` composes the PyG-named drop-ins level by level as the reference does (three
     host round trips per level for the data-dependent tensor sizes)."""
 
-    def __init__(self, num_features, nhid, num_classes, pooling_ratio, dropout_ratio, use_batch=False, fused=True):
+    def __init__(self, num_features, nhid, num_classes, pooling_ratio, dropout_ratio, use_batch=False, fused=True, conv="gcn"):
+        """conv = "gcn": the reference's network (network.py:19-23).  conv = "sage": the same network with its conv layers replaced by PyG
+        SAGEConv — BASELINE config 4 as worded ("SAGPool (ratio 0.5) + SAGEConv"); the pooling layers stay the reference's SAGPool."""
         super().__init__()
         self.num_features, self.nhid, self.num_classes = num_features, nhid, num_classes
         self.pooling_ratio, self.dropout_ratio, self.use_batch = pooling_ratio, dropout_ratio, use_batch
         self.fused = fused
-        self.conv1 = GCNConv(self.num_features, self.nhid)
+        self.conv_kind = conv
+        Conv = GCNConv if conv == "gcn" else pyg.SAGEConv
+        self.conv1 = Conv(self.num_features, self.nhid)
         self.pool1 = SAGPool(self.nhid, ratio=self.pooling_ratio)
-        self.conv2 = GCNConv(self.nhid, self.nhid)
+        self.conv2 = Conv(self.nhid, self.nhid)
         self.pool2 = SAGPool(self.nhid, ratio=self.pooling_ratio)
-        self.conv3 = GCNConv(self.nhid, self.nhid)
+        self.conv3 = Conv(self.nhid, self.nhid)
         self.pool3 = SAGPool(self.nhid, ratio=self.pooling_ratio)
         dev = pyg._default_device()
         self.lin1 = nn.Linear(self.nhid * 2, self.nhid).to(dev)
@@ -60,9 +64,12 @@ class Net(nn.Module):
     def _fused_ok(self):
         from . import sag_stack
         pools = (self.pool1, self.pool2, self.pool3)
-        return (self.fused and sag_stack.supported(self.nhid) and all(p.non_linearity is torch.tanh for p in pools)
-                and all(isinstance(p.score_layer, GCNConv) and p.score_layer.bias is not None for p in pools)
-                and all(c.bias is not None for c in (self.conv1, self.conv2, self.conv3)))
+        convs = (self.conv1, self.conv2, self.conv3)
+        ok = (self.fused and sag_stack.supported(self.nhid) and all(p.non_linearity is torch.tanh for p in pools)
+              and all(isinstance(p.score_layer, GCNConv) and p.score_layer.bias is not None for p in pools))
+        if self.conv_kind == "gcn":
+            return ok and all(c.bias is not None for c in convs)
+        return ok and all(c.lin_l.bias is not None and c.root_weight and not c.normalize for c in convs) and self.nhid % 4 == 0
 
     def _forward_fused(self, data):
         from . import sag_stack
@@ -72,13 +79,20 @@ class Net(nn.Module):
         sizes = pyg.segment_sizes(batch, x.size(0))
         plan = sag_stack.SagPlan.get(sizes, self.pooling_ratio, x.device, depth=3)
         params = []
+        if self.conv_kind != "gcn":
+            if g.symmetric and plan.levels[0].max_seg <= int(mp.nat.lib().tsgnn_sag_pool_graph_max_nodes()):
+                from . import sag_stack_sage
+                for conv, pool in ((self.conv1, self.pool1), (self.conv2, self.pool2), (self.conv3, self.pool3)):
+                    params += [conv.lin_l.weight, conv.lin_l.bias, conv.lin_r.weight, pool.score_layer.weight, pool.score_layer.bias]
+                return sag_stack_sage.sag_sage_stack(x, g, plan, params)
+            return None
         for conv, pool in ((self.conv1, self.pool1), (self.conv2, self.pool2), (self.conv3, self.pool3)):
             params += [conv.weight, conv.bias, pool.score_layer.weight, pool.score_layer.bias]
         return sag_stack.sag_stack(x, g, plan, params)
 
     def forward(self, data):
-        if self._fused_ok():
-            x = self._forward_fused(data)                                # network.py:33-46 in one node
+        x = self._forward_fused(data) if self._fused_ok() else None      # network.py:33-46 in one node
+        if x is not None:
             if mp.mlp3_ok(x, self.lin1, self.lin2, self.lin3):
                 return mp.mlp3_log_softmax(x, self.lin1, self.lin2, self.lin3, self.dropout_ratio, self.training)   # :48-53
             x = pyg.relu(mp.linear_oi(x, self.lin1.weight, self.lin1.bias))
