@@ -696,14 +696,12 @@ int tsgnn_gcn_propagate_affine_f32(const int* rowptr, const int* rowend, const i
                                    const float* x, int64_t ldx, float* agg, int64_t ldagg, int64_t n_rows, int feat, const float* w,
                                    int64_t ldw, const float* bias, float* y, int64_t ldy, int n_out, tsgnn_stream_t stream);
 /* 1 when the fused level kernels below accept feature width F (F % 4 == 0, F <= 256) */
-/* the propagate launches with SEPARATE row / column coefficients (round 4): y[i] = row_scale[i] * sum_{j in row i} col_scale[j] x[j] +
- * self_w[i] x[i] — the mean aggregation of PyG SAGEConv on a (filtered) level's CSR: row_scale = 1 / deg, col_scale = 1, self_w = 0; its
- * transpose on a symmetric edge list: row_scale = 1, col_scale = 1 / deg.  rowend nullable as in tsgnn_gcn_propagate_re_f32. */
-int tsgnn_propagate_scaled_f32(const int* rowptr, const int* rowend, const int* col, const float* row_scale, const float* col_scale,
-                               const float* self_w, const float* x, int64_t ldx, float* y, int64_t ldy, int64_t n_rows, int feat,
-                               tsgnn_stream_t stream);
-/* out[i] = 1 / max(cnt[i], 1) */
-int tsgnn_inv_count_f32(const int* cnt, int64_t n, float* out, tsgnn_stream_t stream);
+/* mean aggregation with the coefficients taken from the row lengths (rowend nullable as tsgnn_gcn_propagate_re_f32):
+ *   transpose = 0:  y[i] = (1 / max(len_i, 1)) sum_{j in row i} x[j] (+ xself[i])     PyG SAGEConv's aggregation
+ *   transpose = 1:  y[i] = sum_{j in row i} x[j] / max(len_j, 1)     (+ xself[i])     its adjoint on a symmetric edge list
+ * xself nullable ([n_rows, >= feat]): added with weight 1 — the input gradient of lin_l(mean_j x_j) + lin_r(x_i) in one launch */
+int tsgnn_propagate_mean_f32(const int* rowptr, const int* rowend, const int* col, int transpose, const float* x, int64_t ldx,
+                             const float* xself, int64_t ldxs, float* y, int64_t ldy, int64_t n_rows, int feat, tsgnn_stream_t stream);
 int tsgnn_sag_supported(int F);
 /* kept rows (layers.py:21): xp[p,:] = relu?(y[perm[p],:]) * tanh(score[perm[p]]); cnt[p] = kept neighbours of perm[p].
  * y = xp = NULL: count only (the transposed adjacency of a non-symmetric graph). */
@@ -1054,12 +1052,19 @@ int tsgnn_sage_relu_readout_bwd_f32(const float* h, int64_t ldh, const float* dx
  * maximum; packed / sums [L, B, F] as left by tsgnn_sage_conv_f32's epilogue, zero again afterwards */
 int tsgnn_sage_readout_decode_f32(unsigned long long* packed, unsigned long long* sums, const int* graph_ptr, int B, int L, int F, float* read,
                                   int64_t ldr, int* arg, tsgnn_stream_t stream);
-/* desc (HOST memory): [nsets <= 8, nsets x (ws, nslab, K, N, dw_oi, lddw, db)]: slab sets of tsgnn_linear_wgrad_f32 (dw == NULL form) summed
- * in slab order into nn.Linear's layout dw_oi[n * lddw + k] (+ db[n], nullable): all layers' lin_l / lin_r gradients in one launch.
+/* desc (HOST memory): [nsets <= 12, nsets x (ws, nslab, K, N, dw_oi, lddw, db, n_db, tail, kn)]: slab sets of tsgnn_linear_wgrad_f32
+ * (dw == NULL form) summed in slab order into nn.Linear's layout dw_oi[n * lddw + k] (kn = 1: GCNConv's [in, out], dw[k * lddw + n])
+ * (+ db[n < n_db], nullable; n_db = N for a weight set): all layers' weight gradients in one launch.  K = 0: a set of partial ROWS [nslab][N] only, column sums to db[0 .. n_db)
+ * and column n_db to tail[0] (nullable) — the SAGPool score layer's partial rows [nb][F + 4] of tsgnn_sag_pool_graph_bwd_f32
+ * (Code/sag/layers.py:18 weight / bias gradients), i.e. tsgnn_sag_du_reduce_f32 riding in this launch.
  * normparts (nullable; tsgnn_sage_wgrad_reduce_oi_blocks(desc) entries): block k's sum of squares of what it wrote; step_state
  * (nullable): step_state[0] += 1 — both as tsgnn_wgrad_reduce_multi_f32, for tsgnn_adam_from_partials_f32 */
 int tsgnn_sage_wgrad_reduce_oi_blocks(const int64_t* desc);
 int tsgnn_sage_wgrad_reduce_oi_f32(const int64_t* desc, float* normparts, float* step_state, tsgnn_stream_t stream);
+/* desc (HOST memory): [njobs <= 16, njobs x (src, lds, rows, cols, dst, ldd, dst_cols)]: dst[r, 0 .. dst_cols) = src[r, 0 .. cols) then
+ * zeros — the [W_l | W_r] images of every level of a SAGEConv stack placed and zero-padded in ONE launch (host glue of the reference's
+ * network with PyG SAGEConv layers; no reference line) */
+int tsgnn_copy2d_multi_f32(const int64_t* desc, tsgnn_stream_t stream);
 
 /* ---------------------------------------------------------------- torch_geometric GATConv as fused launches (csrc/gatconv.hip)
  * Per-TARGET edge softmax (standard GAT; the reference's own DGATHead normalises per column: tsgnn_gat_attn_*).  No call site in the

@@ -46,6 +46,10 @@ for what in "$@"; do
              rocprofv3 --kernel-trace --output-format csv -d $O/rocprof_pr -- python3 scripts/pyg_gat_step.py > $O/pyg_gat.log 2>&1 &&
              python3 scripts/replay_trace.py $(ls $O/rocprof_pr/*/*kernel_trace.csv | head -1) adam > $O/pyg_gat_replay_timeline.txt
              grep "us/step" $O/pyg_gat.log >> $O/pyg_gat_replay_timeline.txt; rm -rf $O/rocprof_pr $O/pyg_gat.log ;;
+    sagpool_sage) for c in gcn sage; do rm -rf $O/rocprof_sp
+             rocprofv3 --kernel-trace --output-format csv -d $O/rocprof_sp -- python3 scripts/sagpool_sage_step.py $c 50 > $O/sp_$c.log 2>&1 &&
+             python3 scripts/replay_trace.py $(ls $O/rocprof_sp/*/*kernel_trace.csv | head -1) adam > $O/sagpool_${c}conv_replay_timeline.txt
+             grep "us/step" $O/sp_$c.log >> $O/sagpool_${c}conv_replay_timeline.txt; rm -f $O/sp_$c.log; done; rm -rf $O/rocprof_sp ;;
     pyg_stats) rm -rf $O/rocprof_ps
              rocprofv3 --kernel-trace --stats --output-format csv -d $O/rocprof_ps -- python3 scripts/pyg_step.py DD 0 400 > /dev/null 2>&1 &&
              cp $O/rocprof_ps/*/*kernel_stats.csv $O/pyg_sage_dd_b32_kernel_stats.csv; rm -rf $O/rocprof_ps ;;

@@ -184,3 +184,118 @@ def test_gat_net_vs_oracle(dropout):
     gg = grads(torch.nn.functional.nll_loss(y, lab.cuda()), params)
     for k, a, b, c in zip(names, gg, g32, g64):
         assert_arbitrated(a, b, c, k)
+
+
+# ------------------------------------------------------------------------------------------------ the SAGPool + SAGEConv stack's helpers
+@pytest.mark.parametrize("feat,ld", [(1, 8), (3, 4), (128, 256), (64, 64), (20, 24)])
+@pytest.mark.parametrize("with_rowend", [False, True])
+def test_propagate_mean_both_forms(feat, ld, with_rowend):
+    """tsgnn_propagate_mean_f32: y = D^-1 A x (+ xself) and its adjoint A D^-1 x (+ xself) on a symmetric list, coefficients from the row
+    lengths; rowend form = rows with slack after them (what the per-graph pooling kernel leaves); isolated rows divide by max(len, 1)"""
+    from two_stage_gnn_amd import _native as nat
+    n = 700
+    ei = _hub_graph(5, n, 1800)
+    A = torch.zeros(n, n, dtype=torch.float64)
+    A[ei[1], ei[0]] = 1.0
+    deg = A.sum(1)
+    order = torch.argsort(ei[1] * n + ei[0])
+    dst, src = ei[1][order], ei[0][order]
+    counts = torch.bincount(dst, minlength=n)
+    if with_rowend:                                                   # three slack entries after every row
+        rowptr = torch.cumsum(counts + 3, 0) - (counts + 3)
+        rowend = rowptr + counts
+        col = torch.full((int((counts + 3).sum()),), -7, dtype=torch.int64)
+        pos = rowptr[dst] + (torch.arange(dst.numel()) - (torch.cumsum(counts, 0) - counts)[dst])
+        col[pos] = src
+        rp, re = rowptr.int().cuda(), rowend.int().cuda()
+    else:
+        rowptr = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(counts, 0)])
+        col = src
+        rp, re = rowptr.int().cuda(), None
+    col = col.int().cuda()
+    x = torch.zeros(n, ld)
+    x[:, :feat] = tie_free(6, n, feat)
+    xs = torch.zeros(n, ld)
+    xs[:, :feat] = tie_free(7, n, feat)
+    xd, xsd = x.cuda(), xs.cuda()
+    inv = 1.0 / deg.clamp(min=1.0)
+    for transpose, with_self in ((0, False), (1, True), (0, True), (1, False)):
+        y = torch.full((n, ld), 3.0, device="cuda")
+        nat.call("propagate_mean_f32", rp, re, col, transpose, xd, ld, xsd if with_self else None, ld if with_self else 0, y, ld, n, feat)
+        torch.cuda.synchronize()
+        xx = x[:, :feat].double()
+        ref = (inv.view(-1, 1) * (A @ xx)) if transpose == 0 else (A @ (inv.view(-1, 1) * xx))
+        if with_self:
+            ref = ref + xs[:, :feat].double()
+        torch.testing.assert_close(y[:, :feat].cpu().double(), ref, rtol=1e-5, atol=1e-5)
+        if ld > feat and feat % 4:
+            assert float((y[:, feat:].cpu() - 3.0).abs().max()) == 0.0          # columns beyond feat are left alone
+
+
+def test_copy2d_multi_and_score_rows_in_the_reduction():
+    """tsgnn_copy2d_multi_f32 (zero-padded placement of several matrices in one launch) and the K = 0 sets of
+    tsgnn_sage_wgrad_reduce_oi_f32 (column sums of the score layer's partial rows beside the weight slabs, with |grad|^2 shares)"""
+    from two_stage_gnn_amd import _native as nat, pyg_sage as ps
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(3)
+    srcs = [torch.randn(128, 1, generator=g), torch.randn(128, 128, generator=g), torch.randn(64, 7, generator=g)]
+    outs, words = [], [len(srcs)]
+    dsrc = [s.to(dev) for s in srcs]
+    for s in dsrc:
+        Kp = (s.size(1) + 3) // 4 * 4
+        o = torch.full((s.size(0), 2 * Kp), 9.0, device=dev)
+        words += [s.data_ptr(), s.stride(0), s.size(0), s.size(1), o.data_ptr() + 4 * Kp, o.stride(0), Kp]
+        outs.append(o)
+    nat.call("copy2d_multi_f32", np.asarray(words, dtype=np.int64).ctypes.data)
+    torch.cuda.synchronize()
+    for s, o in zip(srcs, outs):
+        Kp = o.size(1) // 2
+        assert float((o[:, :Kp].cpu() - 9.0).abs().max()) == 0.0
+        assert torch.equal(o[:, Kp:Kp + s.size(1)].cpu(), s)
+        assert int(o[:, Kp + s.size(1):].count_nonzero()) == 0
+    # a weight set and a score-row set in one reduction
+    nslab, K, N, nb, F = 5, 6, 8, 37, 128
+    ws = torch.randn(nslab, K + 1, N, generator=g)
+    part = torch.randn(nb, F + 4, generator=g)
+    dw, db = torch.zeros(N, K, device=dev), torch.zeros(N, device=dev)
+    dws, dbs = torch.zeros(F + 3, device=dev), torch.zeros(2, device=dev)
+    wsd, partd = ws.to(dev), part.to(dev)
+    sets = [(wsd, nslab, K, N, dw, db), (partd, nb, 0, F + 4, None, dws, F, dbs)]
+    ps.reduce_oi(sets)
+    torch.cuda.synchronize()
+    tot = ws.double().sum(0)
+    torch.testing.assert_close(dw.cpu().double(), tot[:K].t(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(db.cpu().double(), tot[K], rtol=1e-5, atol=1e-5)
+    col = part.double().sum(0)
+    torch.testing.assert_close(dws[:F].cpu().double(), col[:F], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(dbs[:1].cpu().double(), col[F:F + 1], rtol=1e-5, atol=1e-5)
+    assert float(dws[F:].abs().max()) == 0.0 and float(dbs[1]) == 0.0                 # nothing written past the two outputs
+
+
+def test_sagpool_sage_net_fused_vs_composed_small():
+    """sag_layers.Net(conv="sage") as one node against the same modules composed op by op (its own SAGPool / pyg.SAGEConv classes) and
+    against oracle/pyg_ref.sag_net(conv="sage"), on a small batch with a 7-column input (K % 4 != 0: padded halves of the concatenation)"""
+    from two_stage_gnn_amd import sag_layers as S
+    sizes = (18, 30, 9, 41, 17, 26)
+    x, ei, batch = _batch(51, sizes, 2.2, 7)
+    lab = torch.arange(len(sizes)) % 2
+    torch.manual_seed(5)
+    net = S.Net(7, 64, 2, 0.5, 0.0, use_batch=True, conv="sage").cuda().train()
+    d = _D(); d.x, d.edge_index, d.batch = x.cuda(), ei.cuda(), batch.cuda()
+    assert net._fused_ok()
+    names = [k for k, _ in net.named_parameters()]
+    params = [p for _, p in net.named_parameters()]
+    y = net(d)
+    gg = grads(torch.nn.functional.nll_loss(y, lab.cuda()), params)
+    p64 = {k: v.detach().cpu().double().requires_grad_(True) for k, v in net.state_dict().items()}
+    y64 = P.sag_net(p64, x.double(), ei, 0.5, batch, conv="sage")
+    g64 = grads(torch.nn.functional.nll_loss(y64, lab), [p64[k] for k in names])
+    torch.testing.assert_close(y.detach().cpu().double(), y64.detach(), rtol=1e-4, atol=1e-5)
+    for k, a, c in zip(names, gg, g64):
+        torch.testing.assert_close(a.cpu().double(), c, rtol=2e-4, atol=1e-5, msg=k)
+    net.fused = False
+    y2 = net(d)
+    g2 = grads(torch.nn.functional.nll_loss(y2, lab.cuda()), params)
+    torch.testing.assert_close(y2, y, rtol=1e-5, atol=1e-5)
+    for k, a, b in zip(names, gg, g2):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5, msg=k)

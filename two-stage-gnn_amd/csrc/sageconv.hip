@@ -6,6 +6,7 @@
 //   tsgnn_sage_relu_readout_bwd_f32    du = (dxs + readout gradients) * [h > 0]: the row-wise pass between two layers' backward
 //   tsgnn_sage_readout_decode_f32      packed maxima / fixed-point sums of all layers -> sum_l [gmp || gap] and the arg-max rows
 //   tsgnn_sage_wgrad_reduce_oi_f32     slab partials of all layers -> nn.Linear-layout gradients (lin_l.weight, lin_l.bias, lin_r.weight)
+#include <algorithm>
 #include "common.h"
 #include "../../include/tsgnn.h"
 #include "sageconv_body.h"
@@ -111,12 +112,17 @@ __global__ __launch_bounds__(256) void sage_conv_pack_kernel(PackArgs a) {
 }
 
 struct OiSet {
-  const float* ws; int nslab, K, N;     // slabs [nslab][K + 1][N] (row K = bias partial)
-  float* dw; int64_t lddw;              // dw[n * lddw + k]  (nn.Linear's [out, in])
-  float* db;                            // nullable [N]
+  const float* ws; int nslab, K, N;     // slabs [nslab][K + 1][N] (row K = bias partial); K = 0: rows of partial column sums only
+  float* dw; int64_t lddw;              // dw[n * lddw + k]  (nn.Linear's [out, in]; kn = 1: dw[k * lddw + n], GCNConv's [in, out]); unused when K = 0
+  int kn;
+  float* db;                            // nullable [n_db]
+  int n_db;                             // columns of the bias row that go to db (N for a weight set)
+  float* tail;                          // nullable: column n_db of the bias row goes to tail[0] (the SAGPool score layer's
+                                        // partial rows [nb][F + 4]: dw_s in columns 0 .. F-1, db_s in column F)
   int first_block;
 };
-struct OiArgs { OiSet s[8]; int nsets; float* normparts; float* step_state; };
+constexpr int OI_MAX_SETS = 12;
+struct OiArgs { OiSet s[OI_MAX_SETS]; int nsets; float* normparts; float* step_state; };
 
 // block -> 64 consecutive entries (k, n) of one set's [K + 1][N] slab image, n fastest: coalesced slab reads; four wave groups
 // split the slabs (fixed ranges), their partial sums meet in LDS and are added in group order: the same bits every run
@@ -124,7 +130,7 @@ __global__ __launch_bounds__(256) void sage_wgrad_reduce_oi_kernel(OiArgs a) {
   __shared__ float lds[4][64];
   int si = 0;
 #pragma unroll
-  for (int t = 1; t < 8; ++t)
+  for (int t = 1; t < OI_MAX_SETS; ++t)
     if (t < a.nsets && (int)blockIdx.x >= a.s[t].first_block) si = t;
   const OiSet& s = a.s[si];
   const int e_l = threadIdx.x & 63, grp = threadIdx.x >> 6;
@@ -151,8 +157,9 @@ __global__ __launch_bounds__(256) void sage_wgrad_reduce_oi_kernel(OiArgs a) {
   if (e < tot) {
     const float v = (lds[0][e_l] + lds[1][e_l]) + (lds[2][e_l] + lds[3][e_l]);
     const int k = e / s.N, n = e % s.N;
-    if (k < s.K) { s.dw[(int64_t)n * s.lddw + k] = v; sq = v * v; }
-    else if (s.db) { s.db[n] = v; sq = v * v; }
+    if (k < s.K) { s.dw[s.kn ? (int64_t)k * s.lddw + n : (int64_t)n * s.lddw + k] = v; sq = v * v; }
+    else if (s.db && n < s.n_db) { s.db[n] = v; sq = v * v; }
+    else if (s.tail && n == s.n_db) { s.tail[0] = v; sq = v * v; }
   }
   if (a.normparts) {                                    // this block's share of |grad|^2 (summed in fixed order by the optimiser)
     sq = wave_sum(sq);
@@ -289,33 +296,77 @@ int tsgnn_sage_readout_decode_f32(unsigned long long* packed, unsigned long long
   return TSGNN_OK;
 }
 
-/* desc (HOST memory): [nsets, nsets x (ws, nslab, K, N, dw_oi, lddw, db)] — slab sets in the layout of tsgnn_linear_wgrad_f32
- * (dw == NULL form), summed in slab order and written transposed: dw_oi[n * lddw + k]; db nullable. */
+/* desc (HOST memory): [nsets <= 12, nsets x (ws, nslab, K, N, dw_oi, lddw, db, n_db, tail, kn)] — slab sets in the layout of
+ * tsgnn_linear_wgrad_f32 (dw == NULL form), summed in slab order and written transposed: dw_oi[n * lddw + k] (kn = 1: as they lie,
+ * dw[k * lddw + n]); db nullable, takes the first n_db columns of the bias row (n_db = N for a weight set).  K = 0: a set of partial ROWS [nslab][N] only (dw_oi unused) whose
+ * column sums go to db[0 .. n_db) and, column n_db, to tail[0] when tail != NULL (the SAGPool score layer's per-graph partial rows
+ * [nb][F + 4] left by tsgnn_sag_pool_graph_bwd_f32: the work of tsgnn_sag_du_reduce_f32 riding in this launch). */
 int tsgnn_sage_wgrad_reduce_oi_blocks(const int64_t* desc) {
-  if (!desc || desc[0] <= 0 || desc[0] > 8) return -1;
+  if (!desc || desc[0] <= 0 || desc[0] > OI_MAX_SETS) return -1;
   int blocks = 0;
-  for (int t = 0; t < (int)desc[0]; ++t) blocks += (((int)desc[1 + 7 * t + 2] + 1) * (int)desc[1 + 7 * t + 3] + 63) / 64;
+  for (int t = 0; t < (int)desc[0]; ++t) blocks += (((int)desc[1 + 10 * t + 2] + 1) * (int)desc[1 + 10 * t + 3] + 63) / 64;
   return blocks;
 }
 
 int tsgnn_sage_wgrad_reduce_oi_f32(const int64_t* desc, float* normparts, float* step_state, tsgnn_stream_t stream) {
   if (!desc) return TSGNN_EINVAL;
   const int nsets = (int)desc[0];
-  if (nsets <= 0 || nsets > 8) return TSGNN_EINVAL;
+  if (nsets <= 0 || nsets > OI_MAX_SETS) return TSGNN_EINVAL;
   OiArgs a{};
   a.nsets = nsets; a.normparts = normparts; a.step_state = step_state;
   int blocks = 0;
   const int64_t* d = desc + 1;
-  for (int t = 0; t < nsets; ++t, d += 7) {
+  for (int t = 0; t < nsets; ++t, d += 10) {
     OiSet& s = a.s[t];
     s.ws = reinterpret_cast<const float*>(d[0]); s.nslab = (int)d[1]; s.K = (int)d[2]; s.N = (int)d[3];
-    s.dw = reinterpret_cast<float*>(d[4]); s.lddw = d[5]; s.db = reinterpret_cast<float*>(d[6]);
-    if (!s.ws || !s.dw || s.nslab <= 0 || s.K <= 0 || s.N <= 0 || s.lddw < s.K) return TSGNN_EINVAL;
+    s.dw = reinterpret_cast<float*>(d[4]); s.lddw = d[5]; s.db = reinterpret_cast<float*>(d[6]); s.n_db = (int)d[7];
+    s.tail = reinterpret_cast<float*>(d[8]); s.kn = d[9] ? 1 : 0;
+    if (!s.ws || s.nslab <= 0 || s.K < 0 || s.N <= 0 || s.n_db < 0 || s.n_db > s.N) return TSGNN_EINVAL;
+    if (s.K > 0 && (!s.dw || s.lddw < (s.kn ? s.N : s.K))) return TSGNN_EINVAL;
+    if (s.tail && s.n_db >= s.N) return TSGNN_EINVAL;
     s.first_block = blocks;
     blocks += ((s.K + 1) * s.N + 63) / 64;
   }
   TSGNN_KNAME("sage_wgrad_reduce_oi_kernel");
   sage_wgrad_reduce_oi_kernel<<<(unsigned)blocks, 256, 0, stream>>>(a);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+namespace {
+struct CopyJob { const float* src; int64_t lds; int rows, cols; float* dst; int64_t ldd; int dst_cols; };
+struct CopyArgs { CopyJob j[16]; int njobs; };
+__global__ __launch_bounds__(256) void copy2d_multi_kernel(CopyArgs a) {
+  const CopyJob& j = a.j[blockIdx.y];
+  const int64_t tot = (int64_t)j.rows * j.dst_cols;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < tot; e += (int64_t)gridDim.x * 256) {
+    const int r = (int)(e / j.dst_cols), c = (int)(e % j.dst_cols);
+    j.dst[(int64_t)r * j.ldd + c] = c < j.cols ? j.src[(int64_t)r * j.lds + c] : 0.f;
+  }
+}
+}  // namespace
+
+/* desc (HOST memory): [njobs <= 16, njobs x (src, lds, rows, cols, dst, ldd, dst_cols)]: dst[r, 0 .. dst_cols) = src[r, 0 .. cols) then
+ * zeros — several small matrices placed (and zero-padded) in ONE launch: the [W_l | W_r] images of every level of a SAGEConv stack
+ * (sag_stack_sage.py), which torch builds with two pads and a concatenation per level. */
+int tsgnn_copy2d_multi_f32(const int64_t* desc, tsgnn_stream_t stream) {
+  if (!desc) return TSGNN_EINVAL;
+  const int njobs = (int)desc[0];
+  if (njobs <= 0 || njobs > 16) return TSGNN_EINVAL;
+  CopyArgs a{};
+  a.njobs = njobs;
+  int64_t most = 0;
+  const int64_t* d = desc + 1;
+  for (int t = 0; t < njobs; ++t, d += 7) {
+    CopyJob& j = a.j[t];
+    j.src = reinterpret_cast<const float*>(d[0]); j.lds = d[1]; j.rows = (int)d[2]; j.cols = (int)d[3];
+    j.dst = reinterpret_cast<float*>(d[4]); j.ldd = d[5]; j.dst_cols = (int)d[6];
+    if (!j.src || !j.dst || j.rows <= 0 || j.cols <= 0 || j.dst_cols < j.cols || j.lds < j.cols || j.ldd < j.dst_cols) return TSGNN_EINVAL;
+    most = std::max<int64_t>(most, (int64_t)j.rows * j.dst_cols);
+  }
+  const unsigned gx = (unsigned)std::min<int64_t>((most + 255) / 256, 64);
+  TSGNN_KNAME("copy2d_multi_kernel");
+  copy2d_multi_kernel<<<dim3(gx, (unsigned)njobs), 256, 0, stream>>>(a);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }

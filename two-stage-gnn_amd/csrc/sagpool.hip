@@ -63,12 +63,22 @@ struct PropArgs {
   // narrow inputs only (feat <= 8, wave-per-row kernel): the GCNConv transform that follows the aggregation in the same launch,
   // lin_y[row, :lin_n] = agg[row, :feat] . lin_w[feat, lin_n] + lin_b  (network.py:34 at num_features = 1: an outer product)
   const float* lin_w; int64_t ldlw; const float* lin_b; float* lin_y; int64_t ldly; int lin_n;
-  // nullable (round 4): separate coefficients for the gathered rows — out_i = dinv[i] * sum_j col_scale[j] x_j + self_w[i] x_i.  NULL: the
-  // symmetric GCN normalisation (col_scale = dinv).  Mean aggregation (PyG SAGEConv): dinv = 1 / deg, col_scale = 1, self_w = 0; its
-  // transpose for a symmetric edge list: dinv = 1, col_scale = 1 / deg.
-  const float* col_scale;
+  // mean aggregation with the coefficients taken from the row lengths (no coefficient arrays; vec4 / generic kernels only):
+  //   1: out_i = (1 / max(len_i, 1)) sum_j x_j            2 (its transpose on a symmetric list): out_i = sum_j x_j / max(len_j, 1)
+  // and, with either, the self term read from a SECOND buffer with weight 1: out_i += xself[i]  (NULL: no self term)
+  int scale_mode;
+  const float* xself; int64_t ldxs;
 };
-__device__ __forceinline__ const float* prop_cs(const PropArgs& a) { return a.col_scale ? a.col_scale : a.dinv; }
+__device__ __forceinline__ float prop_col(const PropArgs& a, int j) {
+  if (a.scale_mode == 0) return a.dinv[j];
+  if (a.scale_mode == 1) return 1.f;
+  const int len = (a.rowend ? a.rowend[j] : a.rowptr[j + 1]) - a.rowptr[j];
+  return 1.0f / (float)max(len, 1);
+}
+__device__ __forceinline__ float prop_row(const PropArgs& a, int64_t row, int e0, int e1) {
+  if (a.scale_mode == 0) return a.dinv[row];
+  return a.scale_mode == 1 ? 1.0f / (float)max(e1 - e0, 1) : 1.f;
+}
 
 template <int G>
 __global__ __launch_bounds__(256) void gcn_propagate_vec4(PropArgs a, unsigned nblk) {
@@ -85,7 +95,7 @@ __global__ __launch_bounds__(256) void gcn_propagate_vec4(PropArgs a, unsigned n
   for (int eb = e0; eb < e1; eb += G) {
     const int me = eb + lig;
     const int cj = (me < e1) ? a.col[me] : 0;
-    const float dj = (me < e1) ? prop_cs(a)[cj] : 0.f;
+    const float dj = (me < e1) ? prop_col(a, cj) : 0.f;
     const int cnt = min(G, e1 - eb);
     int k = 0;
     for (; k + 4 <= cnt; k += 4) {
@@ -105,9 +115,17 @@ __global__ __launch_bounds__(256) void gcn_propagate_vec4(PropArgs a, unsigned n
       fma4(acc, __shfl(dj, k, G), v);
     }
   }
-  const float di = a.dinv[row], sw = a.self_w[row];
-  float4 xs = ld4(a.x + row * a.ldx + co);
-  if (a.relu_in) xs = relu4(xs);
+  const float di = prop_row(a, row, e0, e1);
+  float sw;
+  float4 xs;
+  if (a.scale_mode == 0) {
+    sw = a.self_w[row];
+    xs = ld4(a.x + row * a.ldx + co);
+    if (a.relu_in) xs = relu4(xs);
+  } else {
+    sw = a.xself ? 1.f : 0.f;
+    xs = a.xself ? ld4(a.xself + row * a.ldxs + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   float4 o = make_float4(fmaf(di, acc.x, sw * xs.x), fmaf(di, acc.y, sw * xs.y), fmaf(di, acc.z, sw * xs.z), fmaf(di, acc.w, sw * xs.w));
   if (a.bias != nullptr) {
     const float4 b = ld4(a.bias + co);
@@ -146,7 +164,7 @@ __global__ __launch_bounds__(256) void gcn_propagate_vec4_rb(PropArgs a, unsigne
   for (int base = eb[0]; base < eb[RB]; base += G) {
     const int me = base + lig;
     const int cj = (me < eb[RB]) ? a.col[me] : 0;
-    const float dj = (me < eb[RB]) ? prop_cs(a)[cj] : 0.f;
+    const float dj = (me < eb[RB]) ? prop_col(a, cj) : 0.f;
     const int cnt = min(G, eb[RB] - base);
     for (int k = 0; k < cnt; k += 8) {
       float4 v[8];
@@ -197,7 +215,11 @@ __global__ __launch_bounds__(256) void gcn_propagate_generic(PropArgs a) {
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= a.n_rows) return;
   const int e0 = a.rowptr[row], e1 = a.rowend ? a.rowend[row] : a.rowptr[row + 1];
-  const float di = a.dinv[row], sw = a.self_w[row];
+  const float di = prop_row(a, row, e0, e1);
+  const float sw = a.scale_mode == 0 ? a.self_w[row] : (a.xself ? 1.f : 0.f);
+  const float* xself = a.scale_mode == 0 ? a.x : (a.xself ? a.xself : a.x);      // self rows (weight 0 without xself in the mean modes)
+  const int64_t ldxs = (a.scale_mode != 0 && a.xself) ? a.ldxs : a.ldx;
+  const bool self_relu = a.relu_in && a.scale_mode == 0;
   float dot = 0.f;
   if (a.feat <= 8) {
     // narrow inputs (the one-column degree / constant feature): lanes over the ENTRIES — with lanes over features one lane
@@ -212,11 +234,11 @@ __global__ __launch_bounds__(256) void gcn_propagate_generic(PropArgs a) {
           const int j = a.col[e];
           float v = a.x[(int64_t)j * a.ldx + f];
           if (a.relu_in) v = fmaxf(v, 0.f);
-          acc = fmaf(prop_cs(a)[j], v, acc);
+          acc = fmaf(prop_col(a, j), v, acc);
         }
         acc = wave_sum(acc);
-        float xs = a.x[row * a.ldx + f];
-        if (a.relu_in) xs = fmaxf(xs, 0.f);
+        float xs = xself[row * ldxs + f];
+        if (self_relu) xs = fmaxf(xs, 0.f);
         float o = fmaf(di, acc, sw * xs);
         if (a.bias != nullptr) o += a.bias[f];
         if (a.y != nullptr && lane == 0) a.y[row * a.ldy + f] = o;
@@ -244,7 +266,7 @@ __global__ __launch_bounds__(256) void gcn_propagate_generic(PropArgs a) {
     for (int eb = e0; eb < e1; eb += 64) {
       const int me = eb + lane;
       const int cj = (me < e1) ? a.col[me] : 0;
-      const float dj = (me < e1) ? prop_cs(a)[cj] : 0.f;
+      const float dj = (me < e1) ? prop_col(a, cj) : 0.f;
       const int cnt = min(64, e1 - eb);
       for (int k = 0; k < cnt; ++k) {
         const int j = __shfl(cj, k, 64);
@@ -253,8 +275,8 @@ __global__ __launch_bounds__(256) void gcn_propagate_generic(PropArgs a) {
         acc = fmaf(__shfl(dj, k, 64), v, acc);
       }
     }
-    float xs = a.x[row * a.ldx + fo];
-    if (a.relu_in) xs = fmaxf(xs, 0.f);
+    float xs = xself[row * ldxs + fo];
+    if (self_relu) xs = fmaxf(xs, 0.f);
     float o = fmaf(di, acc, sw * xs);
     if (a.bias != nullptr) o += a.bias[fo];
     if (a.y != nullptr && live) a.y[row * a.ldy + f] = o;
@@ -280,7 +302,7 @@ __global__ __launch_bounds__(256) void gcn_propagate_narrow(PropArgs a) {
 #pragma unroll 4
   for (int e = e0; e < e1; ++e) {
     const int j = a.col[e];
-    const float dj = prop_cs(a)[j];
+    const float dj = prop_col(a, j);
     const float* xr = a.x + (int64_t)j * a.ldx;
 #pragma unroll
     for (int f = 0; f < PROP_NARROW_MAX; ++f) {
@@ -1146,17 +1168,20 @@ int tsgnn_gcn_propagate_re_f32(const int* rowptr, const int* rowend, const int* 
   return TSGNN_OK;
 }
 
-/* the same launches with SEPARATE row / column coefficients: y[i] = row_scale[i] * sum_{j in row i} col_scale[j] x[j] + self_w[i] x[i]
- * (mean aggregation of PyG SAGEConv: row_scale = 1 / deg, col_scale = 1, self_w = 0; its transpose on a symmetric edge list: row_scale = 1,
- * col_scale = 1 / deg) */
-int tsgnn_propagate_scaled_f32(const int* rowptr, const int* rowend, const int* col, const float* row_scale, const float* col_scale,
-                               const float* self_w, const float* x, int64_t ldx, float* y, int64_t ldy, int64_t n_rows, int feat,
-                               tsgnn_stream_t stream) {
-  if (n_rows < 0 || feat <= 0 || !rowptr || !row_scale || !col_scale || !self_w || !x || !y || ldx < feat || ldy < feat) return TSGNN_EINVAL;
+/* mean aggregation with the coefficients taken from the row lengths (no coefficient arrays):
+ *   transpose = 0:  y[i] = (1 / max(len_i, 1)) sum_{j in row i} x[j]  (+ xself[i])      PyG SAGEConv's aggregation
+ *   transpose = 1:  y[i] = sum_{j in row i} x[j] / max(len_j, 1)      (+ xself[i])      its adjoint on a symmetric edge list
+ * xself (nullable, [n_rows, >= feat], leading dimension ldxs) is added with weight 1: the input gradient of lin_l(mean) + lin_r(x)
+ * is ONE launch, the gathered half and the self half of d[agg || x] read from their own columns. */
+int tsgnn_propagate_mean_f32(const int* rowptr, const int* rowend, const int* col, int transpose, const float* x, int64_t ldx,
+                             const float* xself, int64_t ldxs, float* y, int64_t ldy, int64_t n_rows, int feat, tsgnn_stream_t stream) {
+  if (n_rows < 0 || feat <= 0 || !rowptr || !col || !x || !y || ldx < feat || ldy < feat || (xself && ldxs < feat)) return TSGNN_EINVAL;
   if (n_rows == 0) return TSGNN_OK;
-  PropArgs a{rowptr, rowend, col, row_scale, self_w, x, ldx, nullptr, nullptr, nullptr, y, ldy, nullptr, n_rows, feat, 0};
-  a.col_scale = col_scale;
-  const bool vec_ok = feat % 4 == 0 && feat <= 256 && ldx % 4 == 0 && aligned16(x) && ldy % 4 == 0 && aligned16(y);
+  PropArgs a{rowptr, rowend, col, nullptr, nullptr, x, ldx, nullptr, nullptr, nullptr, y, ldy, nullptr, n_rows, feat, 0};
+  a.scale_mode = transpose ? 2 : 1;
+  a.xself = xself; a.ldxs = ldxs;
+  const bool vec_ok = feat % 4 == 0 && feat <= 256 && ldx % 4 == 0 && aligned16(x) && ldy % 4 == 0 && aligned16(y) &&
+                      (!xself || (ldxs % 4 == 0 && aligned16(xself)));
   if (vec_ok) {
     switch (group_of(feat)) {
       case 8: launch_prop<8>(a, stream); break;
@@ -1167,22 +1192,6 @@ int tsgnn_propagate_scaled_f32(const int* rowptr, const int* rowend, const int* 
   } else {
     gcn_propagate_generic<<<(unsigned)ceil_div64(n_rows, 4), 256, 0, stream>>>(a);
   }
-  TSGNN_CHECK_LAUNCH();
-  return TSGNN_OK;
-}
-
-namespace {
-__global__ void inv_count_kernel(const int* __restrict__ cnt, int64_t n, float* __restrict__ out) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = 1.0f / (float)max(cnt[i], 1);
-}
-}  // namespace
-
-/* out[i] = 1 / max(cnt[i], 1): the mean aggregation's row coefficients from a level's kept-neighbour counts */
-int tsgnn_inv_count_f32(const int* cnt, int64_t n, float* out, tsgnn_stream_t stream) {
-  if (!cnt || !out || n < 0) return TSGNN_EINVAL;
-  if (n == 0) return TSGNN_OK;
-  inv_count_kernel<<<(unsigned)ceil_div64(n, 256), 256, 0, stream>>>(cnt, n, out);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }

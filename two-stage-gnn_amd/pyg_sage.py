@@ -156,15 +156,21 @@ def wgrad_slabs(z, x, K, du):
 
 
 def reduce_oi(sets, norm_sink=None):
-    """sets: list of (ws, nslab, K, N, dw_oi [N, K], db or None): ONE launch for up to 8 sets (tsgnn_sage_wgrad_reduce_oi_f32).
+    """sets: list of (ws, nslab, K, N, dw_oi [N, K], db or None) — or (part, nb, 0, F + 4, None, dw_s, F, db_s): the SAGPool score layer's
+    partial rows, column sums to dw_s[0:F] and db_s[0]; a ninth entry kn = 1 writes dw as [K, N] (GCNConv's layout) —: ONE launch for up to 12 sets (tsgnn_sage_wgrad_reduce_oi_f32).
     norm_sink: a GradSink whose optimiser wants the |grad|^2 shares of these gradients (and its step counter advanced) from this
     launch; returns True when the shares were left."""
     normed = norm_sink is not None
-    for i in range(0, len(sets), 8):
-        chunk = sets[i:i + 8]
+    for i in range(0, len(sets), 12):
+        chunk = sets[i:i + 12]
         words = [len(chunk)]
-        for ws, nslab, K, N, dw, db in chunk:
-            words += [ws.data_ptr(), int(nslab), int(K), int(N), dw.data_ptr(), int(dw.stride(0)), db.data_ptr() if db is not None else 0]
+        for st in chunk:
+            ws, nslab, K, N, dw, db = st[:6]
+            n_db, tail = (st[6], st[7]) if len(st) > 6 else (N, None)
+            kn = int(st[8]) if len(st) > 8 else 0
+            words += [ws.data_ptr(), int(nslab), int(K), int(N), dw.data_ptr() if dw is not None else 0,
+                      int(dw.stride(0)) if dw is not None else 0, db.data_ptr() if db is not None else 0, int(n_db),
+                      tail.data_ptr() if tail is not None else 0, kn]
         d = np.asarray(words, dtype=np.int64)
         parts = step = None
         if norm_sink is not None:

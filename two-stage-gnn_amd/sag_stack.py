@@ -138,32 +138,27 @@ def supported(hidden):
     return bool(nat.lib().tsgnn_sag_supported(int(hidden)))
 
 
+DEFERRED_REDUCE = os.environ.get("TSGNN_SAG_DEFERRED_REDUCE", "1") != "0"   # one closing reduction for every level's slabs + score rows
 MERGED_BWD = os.environ.get("TSGNN_SAG_MERGED_BWD", "1") != "0"   # a conv layer's weight-gradient slabs beside dagg = du W^T (one launch)
 
 
-def _wgrad_beside_dagg(agg, du, W, du_job):
-    """(dW[K, N], db[N], dagg[R, K]) of a 128 -> 128 conv layer: the slab blocks of mp.linear_wgrad and the product du W^T as roles of
-    one launch (tsgnn_gat_bwd_products_f32: both only read du), then linear_wgrad's own reduction with the score layer's partial rows
-    riding along; None when the shape is not taken"""
+def _wgrad_beside_dagg(agg, du, W, nb):
+    """(ws, nslab, dagg[R, K]) of a 128 -> 128 conv layer: the slab blocks of the weight gradient and the product du W^T as roles of one
+    launch (tsgnn_gat_bwd_products_f32: both only read du); the slabs are summed by the backward's ONE closing reduction.  None when the
+    shape is not taken"""
     R, N, K = int(du.size(0)), int(du.size(1)), int(agg.size(1))
-    part, nb, F_du, dws, dbs = du_job
     if not (K == 128 and N == 128 and nb <= 256 and R >= 64 and agg.stride(0) % 4 == 0 and du.stride(0) % 4 == 0 and W.stride(0) % 4 == 0
             and agg.data_ptr() % 16 == 0 and du.data_ptr() % 16 == 0 and W.data_ptr() % 16 == 0 and W.size(0) == K and W.size(1) == N):
         return None
-    nslab = np.zeros(1, dtype=np.int32)
-    rps = np.zeros(1, dtype=np.int64)
-    need = np.zeros(1, dtype=np.int64)
-    nat.call_nostream("linear_wgrad_plan", R, K, N, int(agg.stride(0)), int(du.stride(0)), nslab.ctypes.data, rps.ctypes.data, need.ctypes.data)
-    if int(nslab[0]) <= 0 or int(nslab[0]) >= 512:
+    nslab, rps, need = mp.wgrad_plan(R, K, N, agg.stride(0), du.stride(0))
+    if nslab <= 0 or nslab >= 512:
         return None
-    ws = _f32(int(need[0]), device=du.device)
+    ws = _f32(need, device=du.device)
     dagg = _f32(R, K, device=du.device)
     if not nat.try_call("gat_bwd_products_f32", agg, agg.stride(0), du, du.stride(0), R, K, N, W, W.stride(0), dagg, dagg.stride(0),
-                        int(nslab[0]), int(rps[0]), ws):
+                        nslab, rps, ws):
         return None
-    dW, db = _f32(K, N, device=du.device), _f32(N, device=du.device)
-    nat.call("linear_wgrad_du_reduce_f32", ws, int(nslab[0]), K, N, dW, db, part, int(nb), int(F_du), dws, dbs)
-    return dW, db, dagg
+    return ws, nslab, dagg
 
 
 class _SagStack(torch.autograd.Function):
@@ -202,7 +197,8 @@ class _SagStack(torch.autograd.Function):
             elif xin.size(1) <= 8 and N < NARROW_FUSED_MAX_ROWS:
                 # narrow input (one constant column on the IMDB sets): aggregation and transform in one launch (a launch-count
                 # saving: 162 vs 168 us at 128 graphs; from 32,768 rows on the thread-per-row propagate + MFMA product are faster)
-                agg, y = _f32(N, xin.size(1), device=dev), _f32(N, H, device=dev)
+                # (agg rows padded to 4 floats: the weight-gradient slab kernel reads them as aligned rows)
+                agg, y = _f32(N, (xin.size(1) + 3) // 4 * 4, device=dev)[:, :xin.size(1)], _f32(N, H, device=dev)
                 nat.call("gcn_propagate_affine_f32", rowptr, rowend, col, dinv, self_w, xin, xin.stride(0), agg, agg.stride(0), N,
                          xin.size(1), W, W.stride(0), b, y, y.stride(0), H)
             else:
@@ -256,6 +252,7 @@ class _SagStack(torch.autograd.Function):
             xin = xp
         ctx.plan, ctx.saved_levels, ctx.H, ctx.sym = plan, saved, H, sym
         ctx.x_needs_grad = x.requires_grad
+        ctx.params = params
         return read
 
     @staticmethod
@@ -270,24 +267,27 @@ class _SagStack(torch.autograd.Function):
         dxp = None
         dx = None
         nxt = None          # (dagg, rowptr, rowend, col, dinv, self_w) of level l + 1 when this level's kernel forms dxp itself
+        sets, set_params, sunk = [], [], []
         for l in range(depth - 1, -1, -1):
             L, Ln = plan.levels[l], plan.levels[l + 1]
             N = L.N
             xin, agg, y, score, new_id, arg, rowptr, col, rowptr_t, col_t, dinv, self_w, W, wsv, rowend, _ = ctx.saved_levels[l]
             dyb = _f32(N, H, device=dev)
-            dws, dbs = _f32(H, device=dev), _f32(1, device=dev)
+            pW, pb, pws, pbs = ctx.params[4 * l: 4 * l + 4]
             du_job = None
             if sym and L.max_seg <= pool_graph_max and PER_GRAPH_POOL:
-                # pooled-row gradients -> score-layer backward -> du: one workgroup per graph, then the partial-sum reduction
+                # pooled-row gradients -> score-layer backward -> du: one workgroup per graph; the partial rows of (dw_s, db_s) it leaves are
+                # summed by the closing reduction
                 part = _f32(L.B * (H + 4), device=dev)
                 nat.call("sag_pool_graph_bwd_f32", y, y.stride(0), score, new_id, L.gp, Ln.gp, arg, dxp,
                          dxp.stride(0) if dxp is not None else 0, dread, dread.stride(0), rowptr, rowend, col, dinv, self_w, wsv,
-                         L.B, L.max_seg, H, dyb, dyb.stride(0), part, None, None,      # partial rows: summed with the dW slabs below
+                         L.B, L.max_seg, H, dyb, dyb.stride(0), part, None, None,
                          *((nxt[0], nxt[0].stride(0)) + nxt[1:] if nxt is not None else (None, 0, None, None, None, None, None)))
-                du_job = (part, L.B, H, dws, dbs)
+                du_job = (part, L.B, H)
             else:
                 if nxt is not None:
                     raise RuntimeError("the in-kernel gradient propagate belongs to the per-graph backward")
+                dws, dbs = _f32(H, device=dev), _f32(1, device=dev)
                 dscore = _f32(N, device=dev)
                 nat.call("sag_pool_bwd_f32", y, y.stride(0), score, new_id, Ln.row_graph, Ln.gp, arg, dxp,
                          dxp.stride(0) if dxp is not None else 0, dread, dread.stride(0), N, H, 1, dyb, dyb.stride(0), dscore)
@@ -298,13 +298,33 @@ class _SagStack(torch.autograd.Function):
                          dws, dbs)
             need_dagg = l > 0 or ctx.x_needs_grad
             dagg = None
-            if need_dagg and MERGED_BWD and du_job is not None:
-                both = _wgrad_beside_dagg(agg, dyb, W, du_job)      # (dW, db) slabs and dagg = du W^T: ONE launch + the reduction
-                if both is not None:
-                    dW, db, dagg = both
-            if dagg is None:
-                dW, db = mp.linear_wgrad(agg, agg.size(1), dyb, True, du_job=du_job)
-            grads[4 * l: 4 * l + 4] = [dW, db, dws.view(-1, 1), dbs]
+            Kin = int(agg.size(1))
+            slabs = None
+            if du_job is not None and DEFERRED_REDUCE:
+                if need_dagg and MERGED_BWD:
+                    both = _wgrad_beside_dagg(agg, dyb, W, L.B)     # weight-gradient slabs and dagg = du W^T: ONE launch
+                    if both is not None:
+                        slabs, dagg = both[:2], both[2]
+                if slabs is None:
+                    slabs = mp.linear_wgrad_slabs(agg, Kin, dyb)
+            if slabs is not None:
+                # every level's slabs and score-layer partial rows wait for ONE reduction at the end of the backward, written straight into
+                # the flat gradient bucket (with |grad|^2 shares) when a FlatTrainer is listening
+                dW, s1 = mp._sink_or_new(pW, (Kin, H), dev)
+                db, s2 = mp._sink_or_new(pb, (H,), dev)
+                dws, s3 = mp._sink_or_new(pws, tuple(pws.shape), dev)
+                dbs, s4 = mp._sink_or_new(pbs, (1,), dev)
+                sets.append((slabs[0], slabs[1], Kin, H, dW, db, H, None, 1))
+                sets.append((part, L.B, 0, H + 4, None, dws, H, dbs))
+                set_params += [pW, pb, pws, pbs]
+                sunk.append(s1 and s2 and s3 and s4)
+                grads[4 * l: 4 * l + 4] = [None if s1 else dW, None if s2 else db, None if s3 else dws, None if s4 else dbs]
+            else:
+                if du_job is not None:
+                    dws, dbs = _f32(H, device=dev), _f32(1, device=dev)
+                    du_job = du_job + (dws, dbs)
+                dW, db = mp.linear_wgrad(agg, Kin, dyb, True, du_job=du_job)
+                grads[4 * l: 4 * l + 4] = [dW, db, dws.view(-1, 1), dbs]
             if need_dagg:
                 if dagg is None:
                     dagg = _linear_t(dyb, W)
@@ -319,6 +339,12 @@ class _SagStack(torch.autograd.Function):
                     dxp = dxin
                 else:
                     dx = dxin
+        if sets:
+            from .pyg_sage import reduce_oi
+            sink = mp.GRAD_SINK
+            if reduce_oi(sets, norm_sink=sink if (sink is not None and all(sunk)) else None):
+                for p in set_params:
+                    sink.normed.add(p.data_ptr())
         return (dx, None, None, *grads)
 
 

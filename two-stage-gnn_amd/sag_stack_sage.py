@@ -4,19 +4,22 @@ conv -> SAGPool -> readout levels of Code/sag/network.py:33-44 with the network'
 tanh gate, filter_adj), i.e. the per-graph kernels of sag_stack.py unchanged.
 
 What changes against sag_stack._SagStack is the conv of a level:
-    agg  = mean aggregation over the level's (filtered) CSR        tsgnn_propagate_scaled_f32 (row scale 1 / deg, unit columns, no self term)
+    agg  = mean aggregation over the level's (filtered) CSR        tsgnn_propagate_mean_f32 (1 / deg from the row lengths: no coefficient arrays)
     y    = [agg || x] . [W_l | W_r]^T + b                           ONE row-panel product on the concatenation (K = 2 * ceil4(F_in)): the
                                                                     aggregation writes the left half of the buffer, the previous level's gated
                                                                     gather wrote the right half in place (its output stride is a parameter)
-and, backward, dW = [agg || x]^T dy (one slab pass for both weights), d[agg || x] = dy . [W_l | W_r], dx = A_mean^T dagg + dself.
-The mean's coefficients of a pooled level come from the kept-neighbour counts the per-graph kernel leaves (tsgnn_inv_count_f32); the levels'
-GCN coefficients (for the SCORE layer) come from the filter as before.  Symmetric edge lists (every TU dataset); other inputs take the
+and, backward, the slabs of dW_l = agg^T dy and dW_r = x^T dy in one launch (tsgnn_sage_wgrad_pair_f32), d[agg || x] = dy . [W_l | W_r],
+dx = A_mean^T dagg + dself in one launch (tsgnn_propagate_mean_f32, transpose form, self half added from its own columns); ONE reduction
+at the end of the backward sums every level's slabs into nn.Linear's layout AND the score layers' per-graph partial rows, straight into
+the flat gradient bucket with |grad|^2 shares when a FlatTrainer is listening.  The [W_l | W_r] images of all levels: one launch
+(tsgnn_copy2d_multi_f32).  Launches per step: 1 + 3 x 3 forward, 3 + 4 + 4 + 1 backward (the GCN network of sag_stack.py: 6 and 10).  Symmetric edge lists (every TU dataset); other inputs take the
 composed operators (pyg.SagePoolNet).  PARITY UNPINNED for the SAGEConv half; the SAGPool half follows layers.py:14-25."""
 import numpy as np
 import torch
 
 from . import _native as nat
 from . import message_passing as mp
+from . import pyg_sage as ps
 from . import sag_stack as ss
 
 _f32 = mp._f32
@@ -27,28 +30,23 @@ def _ceil4(k):
     return (int(k) + 3) // 4 * 4
 
 
-def _prop_scaled(rowptr, rowend, col, row_scale, col_scale, self_w, x, ldx, y, ldy, n, feat):
-    nat.call("propagate_scaled_f32", rowptr, rowend, col, row_scale, col_scale, self_w, x, int(ldx), y, int(ldy), int(n), int(feat))
+def _prop_mean(rowptr, rowend, col, transpose, x, ldx, xself, ldxs, y, ldy, n, feat):
+    nat.call("propagate_mean_f32", rowptr, rowend, col, int(transpose), x, int(ldx), xself, int(ldxs), y, int(ldy), int(n), int(feat))
 
 
-def _wcat(wl, wr, K, Kp):
-    """[W_l | W_r] in nn.Linear's [out, in] layout with both halves padded to Kp columns: [H, 2 Kp]"""
-    if K == Kp:
-        return torch.cat([wl, wr], dim=1)
-    pad = (0, Kp - K)
-    return torch.cat([torch.nn.functional.pad(wl, pad), torch.nn.functional.pad(wr, pad)], dim=1)
-
-
-class _Consts:
-    """ones / zeros vectors of every level's row count (coefficient arrays of the scaled propagate), cached on the plan"""
-
-    @staticmethod
-    def get(plan, device):
-        c = getattr(plan, "_sage_consts", None)
-        if c is None:
-            n = max(L.N for L in plan.levels)
-            c = plan._sage_consts = (torch.ones(n, dtype=torch.float32, device=device), torch.zeros(n, dtype=torch.float32, device=device))
-        return c
+def _wcats(pairs, device):
+    """[W_l | W_r] of every level in nn.Linear's [out, in] layout, both halves padded to Kp = ceil4(K) columns: [H, 2 Kp] each, ONE launch"""
+    outs, words = [], [2 * len(pairs)]
+    for wl, wr in pairs:
+        H, K = int(wl.size(0)), int(wl.size(1))
+        Kp = _ceil4(K)
+        o = _f32(H, 2 * Kp, device=device)
+        for t, w in enumerate((wl, wr)):
+            words += [w.data_ptr(), int(w.stride(0)), H, K, o.data_ptr() + 4 * t * Kp, int(o.stride(0)), Kp]
+        outs.append(o)
+    d = np.asarray(words, dtype=np.int64)
+    nat.call("copy2d_multi_f32", d.ctypes.data)
+    return outs
 
 
 class _SagSageStack(torch.autograd.Function):
@@ -66,11 +64,8 @@ class _SagSageStack(torch.autograd.Function):
         dev = x.device
         H = int(params[0].size(0))
         B = plan.levels[0].B
-        ones, zeros = _Consts.get(plan, dev)
         rowptr, col, rowend = g.rowptr, g.col, None
         dinv, self_w = ss.gcn_coef(g)                           # GCN coefficients: the SCORE layer of the pool (layers.py:18)
-        from .pyg_sage import inv_degree
-        inv_deg = inv_degree(g)                                 # mean coefficients: the conv
         nnz_bound = max(int(col.numel()), 1)
         read = _f32(B, 2 * H, device=dev)
         pool_graph_max = int(nat.lib().tsgnn_sag_pool_graph_max_nodes())
@@ -86,17 +81,18 @@ class _SagSageStack(torch.autograd.Function):
             cat[:, Kp0:Kp0 + K0].copy_(x)
             plan._sage_cat0 = hit = (key, cat)
         cat = hit[1]
+        wcats = _wcats([(params[5 * l].contiguous(), params[5 * l + 2].contiguous()) for l in range(depth)], dev)
         saved = []
         K, Kp = K0, Kp0
         for l in range(depth):
             L, Ln = plan.levels[l], plan.levels[l + 1]
             N, Kn = L.N, Ln.N
             wl, bl, wr, ws, bs = params[5 * l: 5 * l + 5]
-            wcat = _wcat(wl, wr, K, Kp)
+            wcat = wcats[l]
             wsv = ss._al16(ws.contiguous().view(-1))
             bl = ss._al16(bl.contiguous())
             # agg -> the left half of the concatenation, then ONE product for both weights
-            _prop_scaled(rowptr, rowend, col, inv_deg, ones, zeros, cat[:, Kp:], cat.stride(0), cat, cat.stride(0), N, K)
+            _prop_mean(rowptr, rowend, col, 0, cat[:, Kp:], cat.stride(0), None, 0, cat, cat.stride(0), N, K)
             y = _f32(N, H, device=dev)
             nat.call("rowgemm_f32", cat, cat.stride(0), wcat, wcat.stride(0), 1, bl, y, y.stride(0), None, N, 2 * Kp, H, 0, 0)
             # the level's tail (score, top-k, gated gather, readout, filter): one workgroup per graph; the kept rows land in the right half of
@@ -116,14 +112,13 @@ class _SagSageStack(torch.autograd.Function):
             nat.call("sag_pool_graph_f32", y, y.stride(0), rowptr, rowend, col, dinv, self_w, wsv, bs, L.gp, Ln.gp, B, L.max_seg, H,
                      score, perm, new_id, xp, xp.stride(0), cnt, read, read.stride(0), arg, int(l > 0),
                      rp_n, re_n, col_n, dinv_n, self_w_n, None, 0)
-            saved.append((cat, y, score, new_id, arg, rowptr, col, rowend, dinv, self_w, inv_deg, wcat, wsv, K, Kp))
+            saved.append((cat, y, score, new_id, arg, rowptr, col, rowend, dinv, self_w, wcat, wsv, K, Kp))
             if not last:
-                inv_n = _f32(Kn, device=dev)
-                nat.call("inv_count_f32", cnt, Kn, inv_n)
-                rowptr, col, rowend, dinv, self_w, inv_deg = rp_n, col_n, re_n, dinv_n, self_w_n, inv_n
+                rowptr, col, rowend, dinv, self_w = rp_n, col_n, re_n, dinv_n, self_w_n
             cat, K, Kp = cat_n, H, H
         ctx.plan, ctx.saved_levels, ctx.H = plan, saved, H
         ctx.x_needs_grad = x.requires_grad
+        ctx.params = params
         return read
 
     @staticmethod
@@ -132,34 +127,49 @@ class _SagSageStack(torch.autograd.Function):
         depth = plan.depth
         dread = dread.contiguous()
         dev = dread.device
-        ones, zeros = _Consts.get(plan, dev)
         grads = [None] * (5 * depth)
+        sets, sunk = [], []
         dxp = None
         dx = None
         for l in range(depth - 1, -1, -1):
             L, Ln = plan.levels[l], plan.levels[l + 1]
             N = L.N
-            cat, y, score, new_id, arg, rowptr, col, rowend, dinv, self_w, inv_deg, wcat, wsv, K, Kp = ctx.saved_levels[l]
+            cat, y, score, new_id, arg, rowptr, col, rowend, dinv, self_w, wcat, wsv, K, Kp = ctx.saved_levels[l]
+            wl, bl, wr, ws, bs = ctx.params[5 * l: 5 * l + 5]
             dyb = _f32(N, H, device=dev)
-            dws, dbs = _f32(H, device=dev), _f32(1, device=dev)
             part = _f32(L.B * (H + 4), device=dev)
             nat.call("sag_pool_graph_bwd_f32", y, y.stride(0), score, new_id, L.gp, Ln.gp, arg, dxp,
                      dxp.stride(0) if dxp is not None else 0, dread, dread.stride(0), rowptr, rowend, col, dinv, self_w, wsv,
                      L.B, L.max_seg, H, dyb, dyb.stride(0), part, None, None, None, 0, None, None, None, None, None)
-            # both weights' gradient in one pass over the concatenation: dWcat [2 Kp, H] = [agg || x]^T dy ; db ; the score layer's partials
-            dwc, db = mp.linear_wgrad(cat, 2 * Kp, dyb, True, du_job=(part, L.B, H, dws, dbs))
-            grads[5 * l: 5 * l + 5] = [dwc[:K].t(), db, dwc[Kp:Kp + K].t(), dws.view(-1, 1), dbs]
+            # the slabs of dW_l = agg^T dy (+ db) and dW_r = x^T dy: one launch; their sum waits for the end of the backward
+            sl = ps.wgrad_slabs(cat, cat[:, Kp:], K, dyb)
+            if sl is None:
+                raise RuntimeError("SAGPool + SAGEConv stack: weight-gradient shape %d x %d is not taken by the slab kernel" % (K, H))
+            dwl, s1 = mp._sink_or_new(wl, (H, K), dev)
+            dbl, s2 = mp._sink_or_new(bl, (H,), dev)
+            dwr, s3 = mp._sink_or_new(wr, (H, K), dev)
+            dws, s4 = mp._sink_or_new(ws, tuple(ws.shape), dev)
+            dbs, s5 = mp._sink_or_new(bs, (1,), dev)
+            sets.append((sl[0][0], sl[0][1], K, H, dwl, dbl))
+            sets.append((sl[1][0], sl[1][1], K, H, dwr, None))
+            sets.append((part, L.B, 0, H + 4, None, dws, H, dbs))
+            grads[5 * l: 5 * l + 5] = [None if s1 else dwl, None if s2 else dbl, None if s3 else dwr, None if s4 else dws, None if s5 else dbs]
+            sunk.append(s1 and s2 and s3 and s4 and s5)
             if l > 0 or ctx.x_needs_grad:
                 dcat = _f32(N, 2 * Kp, device=dev)
                 nat.call("rowgemm_f32", dyb, dyb.stride(0), wcat, wcat.stride(0), 0, None, dcat, dcat.stride(0), None, N, H, 2 * Kp, 0, 0)
                 # dx = A_mean^T dagg + dself   (symmetric edge list: rows of A^T = rows of A; the 1 / deg moves to the gathered rows)
                 dxin = _f32(N, Kp, device=dev)
-                _prop_scaled(rowptr, rowend, col, ones, inv_deg, zeros, dcat, dcat.stride(0), dxin, dxin.stride(0), N, K)
-                dxin = dxin[:, :K] + dcat[:, Kp:Kp + K]
+                _prop_mean(rowptr, rowend, col, 1, dcat, dcat.stride(0), dcat[:, Kp:], dcat.stride(0), dxin, dxin.stride(0), N, K)
                 if l > 0:
                     dxp = dxin
                 else:
-                    dx = dxin
+                    dx = dxin[:, :K]
+        sink = mp.GRAD_SINK
+        all_sunk = sink is not None and all(sunk)
+        if ps.reduce_oi(sets, norm_sink=sink if all_sunk else None):
+            for p in ctx.params:
+                sink.normed.add(p.data_ptr())
         return (dx, None, None, *grads)
 
 
