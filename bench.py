@@ -741,6 +741,27 @@ def main():
                          "ms_per_step": float(v[0].item()) / a.steps * 1e3} for r, v in enumerate(allr)]
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        allreduce = None
+        if multi:
+            # the gradient all-reduce BY ITSELF (the bucket of the timed step, same communicator and stream), 50 back to back, slowest
+            # rank: with TSGNN_AR_BUCKETS = 1 (default) the collective sits between the backward and the optimiser of every step, so
+            # this is also what the step exposes of it; every rank issues the same count (collective-safe)
+            keep = trainer._grad_store.clone()    # (55 sums of the same bucket: put the step's own gradients back afterwards)
+            for _ in range(5):
+                trainer.all_reduce()
+            torch.cuda.synchronize()
+            dist.barrier()
+            ar_ms = torch.tensor([hip_event_ms(trainer.all_reduce, 50, stream)], device=dev, dtype=torch.float64)
+            dist.all_reduce(ar_ms, op=dist.ReduceOp.MAX)
+            allreduce = {"us_alone": float(ar_ms.item()) * 1e3, "bytes": int(trainer._grad_store.numel()) * 4,
+                         "buckets": int(trainer.buckets), "inside_the_hipgraph": bool(getattr(gstep, "one_graph", False)),
+                         "backend": backend,
+                         "note": "50 consecutive all-reduces of the flat gradient bucket (+ the 16-byte error-word slot) on the step's stream, "
+                                 "max over ranks; one per optimiser step, between backward and optimiser (exposed unless TSGNN_AR_BUCKETS=2 "
+                                 "starts the head's share early)"}
+            trainer._grad_store.copy_(keep)
+            trainer._err_slot.zero_()
+            torch.cuda.synchronize()
     from two_stage_gnn_amd import message_passing as mp_
     mp_.check_device_errors()                     # the host has synchronised: did any step report invalid results?
 
@@ -773,6 +794,8 @@ def main():
             out["ms_per_step_one_step_per_graph"] = ms_step
         if per_rank is not None:
             out["per_rank"] = per_rank            # every rank's own batch and its own clock around the same K steps
+        if allreduce is not None:
+            out["allreduce"] = allreduce
         roofline = {}
         traffic, traffic_src = load_traffic()
         with torch.cuda.stream(stream):

@@ -744,6 +744,8 @@ def test_bench_two_ranks_end_to_end_gloo():
     assert [p["rank"] for p in pr] == [0, 1] and pr[0]["rows"] != pr[1]["rows"]          # rank r drew the batch of seed r
     assert all(p["ms_per_step"] > 0 for p in pr)
     assert d["steps_per_graph_launch"] == 1 and d["settle_untimed_steps"] == 4
+    ar = d["allreduce"]                                         # the collective by itself, for the scaling analysis of a real N > 1 run
+    assert ar["us_alone"] > 0 and ar["bytes"] > 4 * 50000 and ar["backend"] == "gloo" and ar["buckets"] == 1
 
 
 def _poison_worker(rank, world, port, q):
