@@ -124,6 +124,11 @@ int tsgnn_ingest_expand_ack_f32(int32_t* mirror, int B, int nmax, int64_t row_ca
                                 int32_t* row_graph, int32_t* row_slot, int32_t* ell, int32_t* tail_ptr, int32_t* ell_slots, int32_t* tail_slots, int F, float* x, int64_t ldx,
                                 int64_t* host_ack, tsgnn_stream_t stream);
 int tsgnn_ingest_arm_pull_rider(const int32_t* host, int32_t* mirror, int B, int nmax, int64_t row_cap, int64_t edge_cap, int64_t tail_cap);
+/* the same copy dealt over `parts` (1..4) carrier launches of the thread in equal shares, after `skip` carriers that go without — carriers: tsgnn_gather_rowgemm_st_f32 (its
+ * two-group kernel) and tsgnn_sage_layer_fwd[_bn]_f32; the passengers are the FIRST workgroups of the carrier (a multiple of 8 of them).
+ * A DD batch's staging buffer is ~15 us of PCIe, longer than any launch of the step (graph_sampler.py:102-114 / train.py:110-119) */
+int tsgnn_ingest_arm_pull_rider_parts(const int32_t* host, int32_t* mirror, int B, int nmax, int64_t row_cap, int64_t edge_cap, int64_t tail_cap,
+                                      int parts, int skip);
 /* the EXPANSION of that batch (arguments of tsgnn_ingest_expand_ack_f32) as passengers of the thread's next
  * tsgnn_packed_head_fwd_f32 launch (a few latency-bound workgroups: most of the chip is idle under it), later in the same step than
  * the launch that carries the pull.  tsgnn_ingest_flush_pull_rider launches whichever of the two riders no launch took. */

@@ -427,6 +427,38 @@ def test_ingest_pipeline_riding_pull_equals_pull_at_the_head(workers):
     assert torch.equal(out[0], out[2]) and torch.equal(out[1], out[2])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("parts,skip", [(1, 0), (2, 0), (3, 0), (4, 0), (1, 2), (2, 2)])
+def test_ingest_pull_rider_placements_train_alike(parts, skip, monkeypatch):
+    """the next batch's PCIe pull dealt over `parts` carrier launches after `skip` carriers that go without (csrc/ingest_rider.h,
+    tsgnn_ingest_arm_pull_rider_parts; the default of a 3-layer model is parts 2 / skip 1): whatever the placement — including shares
+    that no carrier is left for and that the closing flush launches alone — the pipeline trains exactly like the one whose steps pull
+    their own batch with their first launch"""
+    from two_stage_gnn_amd import dense_encoders as E, ingest
+    from two_stage_gnn_amd.data_parallel import FlatTrainer
+    dev = torch.device("cuda")
+    ds = ingest.synthetic_dataset(seed=22, n_graphs=30, shape="DD", nmax=600)
+    rng = np.random.default_rng(6)
+    sched = [rng.choice(len(ds), size=6, replace=False) for _ in range(7)]
+
+    class A:
+        bias = True
+    out = []
+    for ride in (2, 0):
+        monkeypatch.setenv("TSGNN_INGEST_PULL_PARTS", str(parts))
+        monkeypatch.setenv("TSGNN_INGEST_PULL_SKIP", str(skip))
+        torch.manual_seed(4)
+        m = E.GcnEncoderGraph(ds.num_node_labels, 128, 128, 2, 3, bn=True, args=A(), final_dim="number_classes").to(dev)
+        tr = FlatTrainer(m, lr=1e-2, clip=2.0, defer_loss=True)
+        pipe = ingest.IngestPipeline(m, tr, ds, 6, 600, dev, sched, ride=ride)
+        if ride:
+            assert (pipe.pull_parts, pipe.pull_skip) == (parts, skip)
+        pipe.run(sched, workers=2)
+        torch.cuda.synchronize()
+        out.append(tr.flat_param.clone())
+    assert torch.isfinite(out[0]).all() and torch.equal(out[0], out[1])
+
+
 def test_malformed_integer_file_raises(tmp_path):
     """a token that is not an integer (float-formatted label, stray word) must raise like the reference's int() (load_data.py:24-60),
     not silently truncate the file"""

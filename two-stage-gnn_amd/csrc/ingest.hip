@@ -23,7 +23,7 @@
 #include <chrono>
 #include <vector>
 
-thread_local PullRider tsgnn_pull_rider_ = {nullptr, nullptr, 0, 0};
+thread_local PullRider tsgnn_pull_rider_ = {nullptr, nullptr, 0, 0, 0, 0, 0};
 thread_local ExpandRider tsgnn_expand_rider_ = {};
 
 namespace {
@@ -260,7 +260,7 @@ static int make_rider(const int32_t* host, int32_t* mirror, int B, int nmax, int
   const int64_t n4 = L.total / 4;
   unsigned blocks = (unsigned)ceil_div64(n4, 256 * 2);
   if (blocks > 512) blocks = 512;
-  *out = PullRider{reinterpret_cast<const int4*>(host), reinterpret_cast<int4*>(mirror), (long long)n4, blocks};
+  *out = PullRider{reinterpret_cast<const int4*>(host), reinterpret_cast<int4*>(mirror), (long long)n4, blocks, 0, 1, 0};
   return TSGNN_OK;
 }
 
@@ -280,9 +280,18 @@ int tsgnn_ingest_pull_f32(const int32_t* host, int32_t* mirror, int B, int nmax,
  * launch: csrc/ingest_rider.h) — the pull of the NEXT mini-batch inside the CURRENT step.  One rider at a time (arming again
  * replaces it).  tsgnn_ingest_flush_pull_rider: launches an armed rider that no launch took, alone; no-op otherwise. */
 int tsgnn_ingest_arm_pull_rider(const int32_t* host, int32_t* mirror, int B, int nmax, int64_t row_cap, int64_t edge_cap, int64_t tail_cap) {
+  return tsgnn_ingest_arm_pull_rider_parts(host, mirror, B, nmax, row_cap, edge_cap, tail_cap, 1, 0);
+}
+/* the same, dealt over `parts` carrier launches of the thread (tsgnn_gather_rowgemm_st_f32 — the first layer's product — and
+ * tsgnn_sage_layer_fwd[_bn][_ro]_f32) in equal shares, after letting `skip` carriers pass without passengers */
+int tsgnn_ingest_arm_pull_rider_parts(const int32_t* host, int32_t* mirror, int B, int nmax, int64_t row_cap, int64_t edge_cap,
+                                      int64_t tail_cap, int parts, int skip) {
+  if (parts < 1 || parts > 4 || skip < 0 || skip > 8) return TSGNN_EINVAL;
   PullRider p;
   const int rc = make_rider(host, mirror, B, nmax, row_cap, edge_cap, tail_cap, &p);
   if (rc != TSGNN_OK) return rc;
+  p.parts_left = parts;
+  p.skip = skip;
   tsgnn_pull_rider_ = p;
   return TSGNN_OK;
 }
@@ -309,12 +318,16 @@ int tsgnn_ingest_arm_expand_rider(int32_t* mirror, int B, int nmax, int64_t row_
 }
 /* launches the armed riders that no launch took, each as a launch of its own (pull, then expansion); no-op otherwise */
 int tsgnn_ingest_flush_pull_rider(tsgnn_stream_t stream) {
-  const PullRider p = take_pull_rider();
+  PullRider p = tsgnn_pull_rider_;                          // whatever is left of the armed copy, in one launch
+  disarm_pull_rider();
   if (p.blocks) {
+    p.parts_left = 1;
+    unsigned blocks = (unsigned)ceil_div64(p.n4 - p.lo, 256 * 2);
+    p.blocks = blocks > 512 ? 512u : (blocks < 1 ? 1u : blocks);
     TSGNN_KNAME("ingest_pull_rider_kernel");
     ingest_pull_rider_kernel<<<p.blocks, 256, 0, stream>>>(p);
   }
-  const ExpandRider e = take_expand_rider();
+  const ExpandRider e = take_expand_rider_for_flush();
   if (e.blocks) {
     TSGNN_KNAME("ingest_expand_rider_kernel");
     ingest_expand_rider_kernel<<<e.blocks, 256, 0, stream>>>(e);
@@ -326,8 +339,8 @@ int tsgnn_ingest_flush_pull_rider(tsgnn_stream_t stream) {
 /* drops the riders this thread armed without launching them (a forward that raised between arming and its carrier launches must not
  * leave passengers behind for an unrelated later launch) */
 int tsgnn_ingest_disarm_riders(void) {
-  (void)take_pull_rider();
-  (void)take_expand_rider();
+  disarm_pull_rider();
+  (void)take_expand_rider_for_flush();
   return TSGNN_OK;
 }
 

@@ -10,20 +10,39 @@
 #pragma once
 #include "common.h"
 
-struct PullRider { const int4* host; int4* mirror; long long n4; unsigned blocks; };
+// lo / n4: the range of 16-byte words this launch copies; parts_left > 1: the armed copy is dealt over several carrier launches (the
+// staging buffer of a DD batch is ~340 KB = ~15 us of PCIe, longer than any one launch of the step: carried whole by a 14.5 us launch it
+// ended 4.4 us after it; half in the first layer's product and half in the second ends inside both)
+struct PullRider { const int4* host; int4* mirror; long long n4; unsigned blocks; long long lo; int parts_left; int skip; };   // skip: carrier launches to let pass first
 extern thread_local PullRider tsgnn_pull_rider_;          // armed while blocks > 0
 
-static inline PullRider take_pull_rider() {
-  PullRider r = tsgnn_pull_rider_;
-  tsgnn_pull_rider_.blocks = 0;
+// the next part of the armed copy, sized for carrier workgroups of `threads` threads; the rider stays armed until its last part is taken.
+// blocks is a multiple of 8: as the FIRST workgroups of the carrier launch they leave the XCD (index mod 8) of every block behind unchanged.
+static inline PullRider take_pull_rider(int threads = 256) {
+  PullRider& a = tsgnn_pull_rider_;
+  PullRider r = a;
+  if (a.blocks == 0) return r;
+  if (a.skip > 0) { --a.skip; r.blocks = 0; return r; }   // this carrier goes without passengers
+  const int parts = a.parts_left > 1 ? a.parts_left : 1;
+  const long long left = a.n4 - a.lo;
+  const long long take = parts > 1 ? ((left / parts + 3) & ~3ll) : left;
+  r.n4 = a.lo + (take < left ? take : left);
+  long long blocks = (r.n4 - r.lo + 2ll * threads - 1) / (2ll * threads);
+  if (blocks > 512) blocks = 512;
+  if (blocks < 1) blocks = 1;
+  r.blocks = (unsigned)((blocks + 7) & ~7ll);
+  a.lo = r.n4;
+  a.parts_left = parts - 1;
+  if (a.parts_left <= 0 || a.lo >= a.n4) a.blocks = 0;
   return r;
 }
+static inline void disarm_pull_rider() { tsgnn_pull_rider_.blocks = 0; }
 
 // workgroup b of p.blocks: no dependence on the batch's header, so every thread's 16-byte loads are in flight at once
 __device__ __forceinline__ void pull_rider_body(const PullRider& p, unsigned b) {
-  const long long gtid = (long long)b * 256 + threadIdx.x, gsize = (long long)p.blocks * 256;
+  const long long gtid = (long long)b * blockDim.x + threadIdx.x, gsize = (long long)p.blocks * blockDim.x;
   int4 v[4];
-  long long i = gtid;
+  long long i = p.lo + gtid;
   for (; i + 3 * gsize < p.n4; i += 4 * gsize) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) v[u] = p.host[i + u * gsize];
@@ -130,6 +149,14 @@ __device__ __forceinline__ void expand_row_lane(const ExpandArgs& a, int64_t r, 
 struct ExpandRider { ExpandArgs ex; long long rows; unsigned blocks; };   // armed while blocks > 0
 extern thread_local ExpandRider tsgnn_expand_rider_;
 static inline ExpandRider take_expand_rider() {
+  ExpandRider r = tsgnn_expand_rider_;
+  // the expansion reads what the pull wrote: while a share of the pull still waits for a carrier (a placement with more shares than the
+  // model has carriers in front of the head) the expansion does not ride either — tsgnn_ingest_flush_pull_rider launches both, in order
+  if (tsgnn_pull_rider_.blocks != 0) { r.blocks = 0; return r; }
+  tsgnn_expand_rider_.blocks = 0;
+  return r;
+}
+static inline ExpandRider take_expand_rider_for_flush() {
   ExpandRider r = tsgnn_expand_rider_;
   tsgnn_expand_rider_.blocks = 0;
   return r;

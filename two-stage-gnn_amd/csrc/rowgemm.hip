@@ -19,6 +19,7 @@
 
 #include <cstdlib>
 #include "rowgemm_body.h"
+#include "ingest_rider.h"
 #include "rowgemm_big_body.h"
 
 namespace {
@@ -59,13 +60,16 @@ __global__ __launch_bounds__(512) void rowgemm_gather_ks2_kernel(RowGemmArgs g) 
 
 // the same two kernels with the statistics epilogue (rowgemm_body.h, STATS): the layer in front of a slot batch-norm that has no
 // launch of its own (tsgnn_gather_rowgemm_st_f32)
-__global__ __launch_bounds__(256) void rowgemm_gather_st_kernel(RowGemmArgs g) {
+__global__ __launch_bounds__(256) void rowgemm_gather_st_kernel(RowGemmArgs g, PullRider pr) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  rowgemm_body<4, false, true, 1, false, false, true>(g, smem, blockIdx.x);
+  if (blockIdx.x < pr.blocks) { pull_rider_body(pr, blockIdx.x); return; }      // passengers, as below
+  rowgemm_body<4, false, true, 1, false, false, true>(g, smem, blockIdx.x - pr.blocks);
 }
-__global__ __launch_bounds__(512) void rowgemm_gather_ks2_st_kernel(RowGemmArgs g) {
+// pr: passengers (csrc/ingest_rider.h) — a share of the NEXT mini-batch's staging buffer -> its mirror as the launch's first workgroups
+__global__ __launch_bounds__(512) void rowgemm_gather_ks2_st_kernel(RowGemmArgs g, PullRider pr) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  rowgemm_body<4, false, true, 2, false, false, true>(g, smem, blockIdx.x);
+  if (blockIdx.x < pr.blocks) { pull_rider_body(pr, blockIdx.x); return; }
+  rowgemm_body<4, false, true, 2, false, false, true>(g, smem, blockIdx.x - pr.blocks);
 }
 
 // column-split variant for products WITHOUT the row epilogue (no normalise: rows need not be whole): grid.y column blocks of
@@ -284,11 +288,13 @@ int tsgnn_gather_rowgemm_st_f32(const int* ell, int ell_w, const int* tail_ptr, 
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rowgemm_gather_ks2_st_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
       attr = true;
     }
+    const PullRider pr = take_pull_rider(512);             // (blocks = 0 unless tsgnn_ingest_arm_pull_rider[_parts] armed one on this thread)
     TSGNN_KNAME("rowgemm_gather_ks2_st_kernel");
-    rowgemm_gather_ks2_st_kernel<<<nblk, 512, lds2, stream>>>(g);
+    rowgemm_gather_ks2_st_kernel<<<nblk + pr.blocks, 512, lds2, stream>>>(g, pr);
   } else {
+    const PullRider pr = take_pull_rider(256);
     TSGNN_KNAME("rowgemm_gather_st_kernel");
-    rowgemm_gather_st_kernel<<<nblk, 256, rowgemm_lds_bytes<4, false, true>(), stream>>>(g);
+    rowgemm_gather_st_kernel<<<nblk + pr.blocks, 256, rowgemm_lds_bytes<4, false, true>(), stream>>>(g, pr);
   }
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;

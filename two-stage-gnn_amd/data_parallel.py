@@ -256,6 +256,36 @@ class FlatTrainer:
         return loss
 
 
+class _capture:
+    """torch.cuda.graph(...) with the cyclic garbage collector held off for the duration of the capture: a collection that happens to run
+    between two captured launches finalises whatever unreachable device objects it finds (graphs, events, pinned buffers of a discarded
+    trainer or pipeline) — runtime calls a capturing stream does not admit, which abort the process from inside a destructor (seen
+    when several pipelines were built one after the other in one process).  The garbage is collected right before the capture instead."""
+
+    def __init__(self, graph, **kw):
+        self._ctx = torch.cuda.graph(graph, **kw)
+
+    def __enter__(self):
+        import gc
+        self._was = gc.isenabled()
+        gc.collect()
+        gc.disable()
+        try:
+            return self._ctx.__enter__()
+        except BaseException:
+            if self._was:
+                gc.enable()
+            raise
+
+    def __exit__(self, *exc):
+        import gc
+        try:
+            return self._ctx.__exit__(*exc)
+        finally:
+            if self._was:
+                gc.enable()
+
+
 class GraphedStep:
     """One optimiser step on FIXED device buffers, replayed from hipGraphs (the b = 32 step is launch-bound: 15 launches).
 
@@ -330,7 +360,7 @@ class GraphedStep:
             with torch.cuda.stream(self.stream):
                 snap = [t.clone() for t in (trainer.flat_param, trainer.exp_avg, trainer.exp_avg_sq, trainer.state)]
                 self._fbk = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self._fbk, stream=self.stream):
+                with _capture(self._fbk, stream=self.stream):
                     for _ in range(self.steps_per_replay):
                         self._fwd_bwd()
                         trainer.apply()
@@ -358,13 +388,13 @@ class GraphedStep:
         trainer = self.trainer
         trainer._allow_early = not self.multi                # a fork inside the first of two graphs could not be joined
         self._fb = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._fb, stream=self.stream, **mode):
+        with _capture(self._fb, stream=self.stream, **mode):
             self._fwd_bwd()
             if not self.multi:
                 trainer.apply()
         if self.multi:
             self._opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._opt, stream=self.stream, **mode):
+            with _capture(self._opt, stream=self.stream, **mode):
                 trainer.apply()
 
     def _abandon_stream(self):
@@ -392,7 +422,7 @@ class GraphedStep:
         graph = torch.cuda.CUDAGraph()
         try:
             tr._allow_early = True
-            with torch.cuda.graph(graph, stream=self.stream, **mode):
+            with _capture(graph, stream=self.stream, **mode):
                 self._fwd_bwd()
                 if os.environ.get("TSGNN_TEST_BREAK_CAPTURE") in ("all", str(dist.get_rank() if dist.is_initialized() else 0)):
                     torch.cuda.current_stream().synchronize()   # test hook: an operation a capture does not admit — the

@@ -206,10 +206,11 @@ class CapacityBatch:
         """the flat copy staging buffer -> mirror as a launch of its own (current stream)"""
         nat.call("ingest_pull_f32", self.host.data_ptr(), self.mirror, self.B, self.nmax, self.row_cap, self.edge_cap, self.tail_cap)
 
-    def arm_pull_rider(self):
-        """the same copy as passengers of this thread's next layer-product launch (csrc/ingest_rider.h)"""
-        nat.call_nostream("ingest_arm_pull_rider", self.host.data_ptr(), self.mirror, self.B, self.nmax, self.row_cap, self.edge_cap,
-                          self.tail_cap)
+    def arm_pull_rider(self, parts=1, skip=0):
+        """the same copy as passengers of this thread's layer-product launches (csrc/ingest_rider.h): an equal share in each of ``parts``
+        carrier launches, after ``skip`` carriers that go without"""
+        nat.call_nostream("ingest_arm_pull_rider_parts", self.host.data_ptr(), self.mirror, self.B, self.nmax, self.row_cap, self.edge_cap,
+                          self.tail_cap, int(parts), int(skip))
 
     def arm_expand_rider(self):
         """the expansion (and the echo) as passengers of this thread's next packed-head launch (csrc/ingest_rider.h)"""
@@ -272,6 +273,15 @@ class IngestPipeline:
         self.ride = bool(ride) and make_loss is None and depth >= 2
         # 2 (default): the next batch's EXPANSION rides too (in the head's forward launch); 1: it is the step's first launch
         self.ride_expand = self.ride and int(ride) >= 2
+        # Where the pull rides.  A read of pinned host memory by the GPU is ~10 us of latency + ~25 GB/s here: the ~340 KB staging buffer
+        # of a DD batch takes longer than any one launch of the step, and a rider that outlives its carrier lengthens the step.  The
+        # carriers are the conv layers' forward products, the later ones the longer: the copy is dealt over the LAST TWO of them in equal
+        # shares (3 layers: the first carrier goes without, half in each of the other two).  Measured at 255 panels (scripts/dev/
+        # ingest_rider_sweep.sh; the slot's step alone, ms): whole copy in layer 1's launch 0.1407, in layer 2's 0.1391, in layer 3's 0.1399,
+        # halves in 1 + 2 0.1403, halves in 2 + 3 0.1368.  TSGNN_INGEST_PULL_PARTS / _SKIP override.
+        L = int(getattr(model, "num_layers", 0) or 0)
+        self.pull_parts = int(os.environ.get("TSGNN_INGEST_PULL_PARTS", "2" if L >= 3 else "1"))
+        self.pull_skip = int(os.environ.get("TSGNN_INGEST_PULL_SKIP", str(max(0, L - 2)) if L >= 2 else "0"))
         self.steps = []
         if make_loss is None and not self.ride:
             def make_loss(s):
@@ -290,7 +300,7 @@ class IngestPipeline:
                 def loss():
                     if not self.ride_expand:
                         s.expand()                            # this position's batch: pulled by the previous step's passengers
-                    nxt.arm_pull_rider()                      # the next position's staging buffer rides in the first layer product,
+                    nxt.arm_pull_rider(self.pull_parts, self.pull_skip)   # the next position's staging buffer rides in the layer products,
                     if self.ride_expand:
                         nxt.arm_expand_rider()                # its expansion in the head's forward launch
                     try:
