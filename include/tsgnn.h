@@ -783,6 +783,14 @@ int tsgnn_row_softmax_masked_fwd_f32(const float* x, int64_t ldx, int64_t rows, 
                                      tsgnn_stream_t stream);
 int tsgnn_row_softmax_masked_bwd_f32(const float* y, int64_t ldy, const float* dy, int64_t lddy, int64_t rows, int C, float* dx,
                                      int64_t lddx, int64_t zero_from, tsgnn_stream_t stream);
+/* PyG dense_diff_pool's assignment (north_star operator; no call site in the reference): y = softmax(x, -1) * mask (mask:
+ * one float per row, nullable) and hpart[ceil(rows / 4)] = partial sums (fixed order) of the rows' entropy terms -sum_k y log(y + eps);
+ * the backward adds g_ent[0] * g_scale * d(sum of the entropy terms)/dy to the gradient arriving at y (ds, nullable; g_ent: device scalar,
+ * nullable) and goes through the mask and the softmax. */
+int tsgnn_row_softmax_ent_fwd_f32(const float* x, int64_t ldx, int64_t rows, int C, const float* mask, float eps, float* y, int64_t ldy,
+                                  float* hpart, tsgnn_stream_t stream);
+int tsgnn_row_softmax_ent_bwd_f32(const float* y, int64_t ldy, const float* ds, int64_t ldds, const float* mask, const float* g_ent,
+                                  float g_scale, float eps, int64_t rows, int C, float* dx, int64_t lddx, tsgnn_stream_t stream);
 
 /* ---------------------------------------------------------------- fused slot kernels of the GraphSage stack (sage_fused.hip) */
 

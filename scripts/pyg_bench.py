@@ -125,7 +125,63 @@ def sagpool():
           % (n, ta, 128 / ta * 1e6, tb, 128 / tb * 1e6, tb / ta), flush=True)
 
 
+def diffpool():
+    """pyg.dense_diff_pool (operator forward + backward, eager and replayed from a hipGraph) at BASELINE config 5's first pooling level,
+    beside the same operator with the link loss written as PyG writes it (the [B, N, N] product s s^T, a subtraction, a norm)"""
+    import numpy as np
+    from two_stage_gnn_amd.diffpool import bmm, diffpool_contract_dense, row_softmax
+    dev = torch.device("cuda")
+    B, N, K, Fd = 16, 512, 64, 64
+    hb = synthetic.host_batch(seed=2, B=B, shape="DD", nmax=N)
+    _, adj = synthetic.to_dense(hb)
+    adj = adj.to(dev)
+    mask = (torch.arange(N)[None, :] < torch.from_numpy(np.asarray(hb["sizes"]))[:, None]).to(dev)
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(B, N, Fd, generator=g).to(dev).requires_grad_(True)
+    s = torch.randn(B, N, K, generator=g).to(dev).requires_grad_(True)
+
+    def fused():
+        o = pyg.dense_diff_pool(x, adj, s, mask)
+        return (o[0].sum() + o[1].sum()) * 1e-3 + o[2] + o[3]
+
+    def as_written():
+        ss = row_softmax(s.reshape(B * N, K)).reshape(B, N, K)
+        m = mask.view(B, N, 1).to(x.dtype)
+        xx, ss = x * m, ss * m
+        out, out_adj = diffpool_contract_dense(ss, xx, adj)
+        link = torch.norm(adj - bmm(ss, ss, trans_b=True), p=2) / adj.numel()
+        ent = (-ss * torch.log(ss + 1e-15)).sum(dim=-1).mean()
+        return (out.sum() + out_adj.sum()) * 1e-3 + link + ent
+
+    St = torch.cuda.Stream()
+    for name, fn in (("closed-form link loss, softmax + mask + entropy in one launch each way", fused),
+                     ("as PyG writes it (s s^T [B, N, N], subtraction, norm; element-wise entropy) on the same kernels", as_written)):
+        with torch.cuda.stream(St):
+            def step():
+                x.grad = s.grad = None
+                fn().backward()
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=St):
+                step()
+            for _ in range(5):
+                gr.replay()
+            torch.cuda.synchronize()
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(St)
+            for _ in range(100):
+                gr.replay()
+            e1.record(St); e1.synchronize()
+        print("dense_diff_pool b16 N512 -> K64 h64, forward + backward from one hipGraph: %6.1f us  (%s)" % (e0.elapsed_time(e1) / 100 * 1e3, name),
+              flush=True)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "DIFFPOOL":
+        diffpool()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "GAT":
         gat()
         sys.exit(0)

@@ -484,6 +484,47 @@ def test_sagpool_sage_timed_step_vs_oracle():
     print("graphs counted per step:", counted)
 
 
+def test_pyg_dense_diff_pool_config5_size_vs_oracle():
+    """pyg.dense_diff_pool at BASELINE config 5's first pooling level (16 graphs, Nmax 512 -> 64 clusters, h = 64; DD-shaped adjacency,
+    ragged sizes through the mask) against oracle/pyg_ref.dense_diff_pool in fp32 and fp64: the four outputs, and the gradients of EACH
+    of them alone with respect to x and the assignment logits (the link loss here is the closed form ||A||^2 - 2 tr(S^T A S) + ||S^T S||^2
+    — no [B, N, N] product — and the entropy term comes out of the softmax launch: their gradients are the new code).  PARITY UNPINNED."""
+    from two_stage_gnn_amd import pyg, synthetic
+    B, N, K, Fd = 16, 512, 64, 64
+    hb = synthetic.host_batch(seed=2, B=B, shape="DD", nmax=N)
+    _, adj = synthetic.to_dense(hb)
+    sizes = torch.from_numpy(np.asarray(hb["sizes"]))
+    mask = torch.arange(N)[None, :] < sizes[:, None]
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(B, N, Fd, generator=g)
+    s = torch.randn(B, N, K, generator=g)
+    wo = [torch.randn(B, K, Fd, generator=g), torch.randn(B, K, K, generator=g)]
+
+    def oracle(dtype):
+        xr, sr = x.to(dtype).requires_grad_(True), s.to(dtype).requires_grad_(True)
+        o = P.dense_diff_pool(xr, adj.to(dtype), sr, mask)
+        losses = [(o[0] * wo[0].to(dtype)).sum(), (o[1] * wo[1].to(dtype)).sum(), o[2], o[3]]
+        return o, [torch.autograd.grad(l, [xr, sr], retain_graph=True, allow_unused=True) for l in losses]
+
+    o32, g32 = oracle(torch.float32)
+    o64, g64 = oracle(torch.float64)
+    xg, sg = x.cuda().requires_grad_(True), s.cuda().requires_grad_(True)
+    o = pyg.dense_diff_pool(xg, adj.cuda(), sg, mask.cuda())
+    from test_gpu_pyg_fused import assert_arbitrated
+    for name, a, b, c in zip(("out", "out_adj", "link", "ent"), o, o32, o64):
+        assert_arbitrated(a, b, c, name)
+    print("link loss hip %.9g cpu32 %.9g fp64 %.9g | entropy hip %.9g cpu32 %.9g fp64 %.9g"
+          % (float(o[2]), float(o32[2]), float(o64[2]), float(o[3]), float(o32[3]), float(o64[3])))
+    losses = [(o[0] * wo[0].cuda()).sum(), (o[1] * wo[1].cuda()).sum(), o[2], o[3]]
+    for li, (name, l) in enumerate(zip(("out", "out_adj", "link", "ent"), losses)):
+        got = torch.autograd.grad(l, [xg, sg], retain_graph=True, allow_unused=True)
+        for vn, a, b, c in zip(("dx", "dlogits"), got, g32[li], g64[li]):
+            if c is None:
+                assert a is None or float(a.abs().max()) == 0.0, (name, vn)
+                continue
+            assert_arbitrated(a, b, c, "%s of %s" % (vn, name), handful=16)
+
+
 def test_pyg_sagpool_sage_config4_vs_oracle():
     """BASELINE config 4 as worded — "IMDB-BINARY SAGPool (ratio 0.5) + SAGEConv h=128 batch=128" — pyg.SagePoolNet (fused SAGEConv
     launches + PyG SAGPooling with its GraphConv scorer) at full size against oracle/pyg_ref.sage_pool_net in fp64: log-probabilities

@@ -151,9 +151,88 @@ __global__ __launch_bounds__(256) void row_softmax_bwd(const float* __restrict__
   for (int c = lane; c < C; c += 64) dx[r * lddx + c] = y[r * ldy + c] * (dy[r * lddy + c] - dot);
 }
 
+// PyG dense_diff_pool's assignment: s = softmax(logits) * m (row mask, nullable) AND the row's entropy term h = -sum_k s_k log(s_k + eps)
+// in the same pass; hpart[block] = the block's four rows' sum (fixed order), summed by the host-side caller's one small reduction
+__global__ __launch_bounds__(256) void row_softmax_ent_fwd(const float* __restrict__ x, int64_t ldx, int64_t rows, int C,
+                                                           const float* __restrict__ mask, float eps, float* __restrict__ y, int64_t ldy,
+                                                           float* __restrict__ hpart) {
+  __shared__ float hs[4];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int64_t r = (int64_t)blockIdx.x * 4 + wid;
+  float h = 0.f;
+  if (r < rows) {
+    const float mk = mask ? mask[r] : 1.f;
+    float m = -INFINITY;
+    for (int c = lane; c < C; c += 64) m = fmaxf(m, x[r * ldx + c]);
+    m = wave_max(m);
+    float d = 0.f;
+    for (int c = lane; c < C; c += 64) d += expf(x[r * ldx + c] - m);
+    d = wave_sum(d);
+    for (int c = lane; c < C; c += 64) {
+      const float sv = expf(x[r * ldx + c] - m) / d * mk;
+      y[r * ldy + c] = sv;
+      h -= sv * logf(sv + eps);
+    }
+    h = wave_sum(h);
+  }
+  if (lane == 0) hs[wid] = h;
+  __syncthreads();
+  if (threadIdx.x == 0) hpart[blockIdx.x] = (hs[0] + hs[1]) + (hs[2] + hs[3]);
+}
+// dlogits of the same: the gradient arriving at s (ds, nullable) plus g_ent[0] * d h / d s = -g (log(s + eps) + s / (s + eps)), through the
+// mask and the softmax.  y = the MASKED s the forward wrote; the softmax itself is y / m on unmasked rows (masked rows: zero gradient).
+__global__ __launch_bounds__(256) void row_softmax_ent_bwd(const float* __restrict__ y, int64_t ldy, const float* __restrict__ ds, int64_t ldds,
+                                                           const float* __restrict__ mask, const float* __restrict__ g_ent, float g_scale,
+                                                           float eps, int64_t rows, int C, float* __restrict__ dx, int64_t lddx) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float mk = mask ? mask[r] : 1.f;
+  if (mk == 0.f) {
+    for (int c = lane; c < C; c += 64) dx[r * lddx + c] = 0.f;
+    return;
+  }
+  const float g = g_ent ? g_ent[0] * g_scale : 0.f;
+  const float inv = 1.f / mk;
+  float dot = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float sv = y[r * ldy + c];
+    const float dv = (ds ? ds[r * ldds + c] : 0.f) - g * (logf(sv + eps) + sv / (sv + eps));
+    dot = fmaf(sv * inv, dv * mk, dot);              // softmax value . gradient arriving at the softmax
+  }
+  dot = wave_sum(dot);
+  for (int c = lane; c < C; c += 64) {
+    const float sv = y[r * ldy + c];
+    const float dv = (ds ? ds[r * ldds + c] : 0.f) - g * (logf(sv + eps) + sv / (sv + eps));
+    dx[r * lddx + c] = sv * inv * (dv * mk - dot);
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+/* PyG dense_diff_pool (north_star operator; no call site in the reference): s = softmax(x, -1) * mask (mask nullable,
+ * one float per row) and hpart[ceil(rows / 4)] = partial sums of the rows' entropy terms -sum_k s log(s + eps) (their total / rows is
+ * the operator's entropy loss) — one pass. */
+int tsgnn_row_softmax_ent_fwd_f32(const float* x, int64_t ldx, int64_t rows, int C, const float* mask, float eps, float* y, int64_t ldy,
+                                  float* hpart, tsgnn_stream_t stream) {
+  if (!x || !y || !hpart || rows < 0 || C <= 0 || ldx < C || ldy < C) return TSGNN_EINVAL;
+  if (rows == 0) return TSGNN_OK;
+  row_softmax_ent_fwd<<<(unsigned)ceil_div64(rows, 4), 256, 0, stream>>>(x, ldx, rows, C, mask, eps, y, ldy, hpart);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+/* its backward: dx = d logits from ds (gradient arriving at the masked s, nullable) and the entropy term's own gradient
+ * g_ent[0] * g_scale * d(sum of the rows' entropy terms) / ds (g_ent: DEVICE scalar, nullable).  y = the forward's output. */
+int tsgnn_row_softmax_ent_bwd_f32(const float* y, int64_t ldy, const float* ds, int64_t ldds, const float* mask, const float* g_ent,
+                                  float g_scale, float eps, int64_t rows, int C, float* dx, int64_t lddx, tsgnn_stream_t stream) {
+  if (!y || !dx || rows < 0 || C <= 0 || ldy < C || lddx < C || (ds && ldds < C)) return TSGNN_EINVAL;
+  if (rows == 0) return TSGNN_OK;
+  row_softmax_ent_bwd<<<(unsigned)ceil_div64(rows, 4), 256, 0, stream>>>(y, ldy, ds, ldds, mask, g_ent, g_scale, eps, rows, C, dx, lddx);
+  TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
 
 int tsgnn_topk_max_segment(void) { return TOPK_MAX_SEG; }
 

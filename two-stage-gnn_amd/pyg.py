@@ -577,21 +577,55 @@ class TopKPooling(nn.Module):
         return xo, ei, edge_attr, batch[perm], perm, score_perm
 
 
+class _SoftmaxEntropy(torch.autograd.Function):
+    """(s, h) = (softmax(logits, -1) * mask, sum over the rows of -sum_k s log(s + eps)): dense_diff_pool's assignment and the numerator of
+    its entropy loss in one launch each way (tsgnn_row_softmax_ent_{fwd,bwd}_f32)"""
+
+    @staticmethod
+    def forward(ctx, logits, mask, eps):
+        x = logits.contiguous()
+        rows, K = x.shape
+        y = torch.empty_like(x)
+        hpart = torch.empty((rows + 3) // 4, dtype=torch.float32, device=x.device)
+        nat.call("row_softmax_ent_fwd_f32", x, x.stride(0), rows, K, mask, float(eps), y, y.stride(0), hpart)
+        ctx.save_for_backward(y, mask)
+        ctx.eps = float(eps)
+        return y, hpart.sum()
+
+    @staticmethod
+    def backward(ctx, ds, gh):
+        y, mask = ctx.saved_tensors
+        ds = ds.contiguous() if ds is not None else None
+        gh = gh.contiguous().view(1) if gh is not None else None
+        dx = torch.empty_like(y)
+        nat.call("row_softmax_ent_bwd_f32", y, y.stride(0), ds, ds.stride(0) if ds is not None else 0, mask, gh, 1.0, ctx.eps,
+                 y.size(0), y.size(1), dx, dx.stride(0))
+        return dx, None, None
+
+
 def dense_diff_pool(x, adj, s, mask=None, eps=1e-15):
-    """PyG dense_diff_pool: (s^T x, s^T adj s, link loss, entropy loss); contractions on fp32 MFMA."""
-    from .diffpool import bmm, diffpool_contract_dense, row_softmax
+    """PyG dense_diff_pool: (s^T x, s^T adj s, link loss, entropy loss) with s = softmax(s, -1) [* mask].
+
+    The contractions run on fp32 MFMA (diffpool.diffpool_contract_dense).  The link loss ||adj - s s^T||_F / numel never forms the
+    [B, N, N] product s s^T (config 5: 16 x 512 x 512 x 64 x 2 = 0.54 GFLOP and three 16 MB tensors for one scalar):
+        ||adj - s s^T||^2 = ||adj||^2 - 2 tr(s^T adj s) + ||s^T s||^2        (<adj, s s^T> = tr(s^T adj s);  ||s s^T||_F = ||s^T s||_F)
+    with tr(s^T adj s) read off the pooled adjacency that is computed anyway and G = s^T s a [B, K, K] product; its gradient reaches s
+    (and adj) through those two products' own backward.  Softmax, mask and the entropy term are one launch each way."""
+    from .diffpool import bmm, diffpool_contract_dense
     x = x.unsqueeze(0) if x.dim() == 2 else x
     adj = adj.unsqueeze(0) if adj.dim() == 2 else adj
     s = s.unsqueeze(0) if s.dim() == 2 else s
     B, N, K = s.shape
-    s = row_softmax(s.reshape(B * N, K)).reshape(B, N, K)
+    m = mask.reshape(B * N).to(torch.float32).contiguous() if mask is not None else None
+    s, h = _SoftmaxEntropy.apply(s.reshape(B * N, K), m, eps)
+    s = s.reshape(B, N, K)
     if mask is not None:
-        m = mask.view(B, N, 1).to(x.dtype)
-        x, s = x * m, s * m
+        x = x * mask.view(B, N, 1).to(x.dtype)
     out, out_adj = diffpool_contract_dense(s, x, adj)
-    sst = bmm(s, s, trans_b=True)
-    link = torch.norm(adj - sst, p=2) / adj.numel()
-    ent = (-s * torch.log(s + eps)).sum(dim=-1).mean()
+    G = bmm(s, s, trans_a=True)                                                   # s^T s  [B, K, K]
+    d2 = (adj * adj).sum() - 2.0 * torch.diagonal(out_adj, dim1=1, dim2=2).sum() + (G * G).sum()
+    link = torch.sqrt(torch.clamp(d2, min=0.0)) / adj.numel()
+    ent = h / (B * N)
     return out, out_adj, link, ent
 
 
