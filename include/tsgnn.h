@@ -125,7 +125,7 @@ int tsgnn_ingest_expand_ack_f32(int32_t* mirror, int B, int nmax, int64_t row_ca
                                 int64_t* host_ack, tsgnn_stream_t stream);
 int tsgnn_ingest_arm_pull_rider(const int32_t* host, int32_t* mirror, int B, int nmax, int64_t row_cap, int64_t edge_cap, int64_t tail_cap);
 /* the same copy dealt over `parts` (1..4) carrier launches of the thread in equal shares, after `skip` carriers that go without — carriers: tsgnn_gather_rowgemm_st_f32 (its
- * two-group kernel) and tsgnn_sage_layer_fwd[_bn]_f32; the passengers are the FIRST workgroups of the carrier (a multiple of 8 of them).
+ * kernels) and tsgnn_sage_layer_fwd[_bn]_f32; the passengers are extra workgroups at the END of the carrier's grid.
  * A DD batch's staging buffer is ~15 us of PCIe, longer than any launch of the step (graph_sampler.py:102-114 / train.py:110-119) */
 int tsgnn_ingest_arm_pull_rider_parts(const int32_t* host, int32_t* mirror, int B, int nmax, int64_t row_cap, int64_t edge_cap, int64_t tail_cap,
                                       int parts, int skip);

@@ -17,7 +17,6 @@ struct PullRider { const int4* host; int4* mirror; long long n4; unsigned blocks
 extern thread_local PullRider tsgnn_pull_rider_;          // armed while blocks > 0
 
 // the next part of the armed copy, sized for carrier workgroups of `threads` threads; the rider stays armed until its last part is taken.
-// blocks is a multiple of 8: as the FIRST workgroups of the carrier launch they leave the XCD (index mod 8) of every block behind unchanged.
 static inline PullRider take_pull_rider(int threads = 256) {
   PullRider& a = tsgnn_pull_rider_;
   PullRider r = a;
@@ -30,7 +29,7 @@ static inline PullRider take_pull_rider(int threads = 256) {
   long long blocks = (r.n4 - r.lo + 2ll * threads - 1) / (2ll * threads);
   if (blocks > 512) blocks = 512;
   if (blocks < 1) blocks = 1;
-  r.blocks = (unsigned)((blocks + 7) & ~7ll);
+  r.blocks = (unsigned)blocks;
   a.lo = r.n4;
   a.parts_left = parts - 1;
   if (a.parts_left <= 0 || a.lo >= a.n4) a.blocks = 0;

@@ -19,17 +19,15 @@ template <bool RO>
 __global__ __launch_bounds__(256) void sage_layer_fwd_kernel(RowGemmArgs ga, SlotArgs sa, unsigned n_gemm, unsigned ro_gx, int F4,
                                                              unsigned long long* __restrict__ packed, unsigned n_main, PullRider pr) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  // passengers FIRST (the lowest workgroup indices are dispatched first): the next mini-batch's staging buffer -> its mirror
-  // (ingest_rider.h) is one PCIe round trip of ~8 us that must start with the launch to end inside it — as the last indices the
-  // riders waited for a free slot behind 512 panel / readout blocks and the launch ended 4.4 us late.  pr.blocks is a multiple of 8,
-  // so the blocks behind keep their XCD (workgroup index mod 8), which the panel order and the readout map are built on.
-  if (blockIdx.x < pr.blocks) { pull_rider_body(pr, blockIdx.x); return; }
-  const unsigned bx = blockIdx.x - pr.blocks;
-  if (bx < n_gemm) {
-    rowgemm_body<4, false, true, 1, RO>(ga, smem, bx);
-  } else {
-    const unsigned r = bx - n_gemm;
+  if (blockIdx.x < n_gemm) {
+    rowgemm_body<4, false, true, 1, RO>(ga, smem, blockIdx.x);
+  } else if (blockIdx.x < n_main) {
+    const unsigned r = blockIdx.x - n_gemm;
     readout_partial_body<32>(sa, ga.a, ga.lda, F4, packed, r % ro_gx, r / ro_gx, reinterpret_cast<unsigned long long*>(smem));
+  } else {
+    // passengers: a share of the next mini-batch's staging buffer -> its mirror (ingest_rider.h).  (As the FIRST workgroups of the launch
+    // they changed nothing for the ingest step and cost the resident step 0.4 us per launch — measured both ways.)
+    pull_rider_body(pr, blockIdx.x - n_main);
   }
 }
 
@@ -41,17 +39,17 @@ __global__ __launch_bounds__(256, 2) void sage_layer_fwd_bn_kernel(RowGemmArgs g
                                                                 int ro_ch, int F4, unsigned long long* __restrict__ packed, unsigned n_main,
                                                                 PullRider pr, const int* __restrict__ ro_map) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  if (blockIdx.x < pr.blocks) { pull_rider_body(pr, blockIdx.x); return; }      // passengers first (see sage_layer_fwd_kernel)
-  const unsigned bx = blockIdx.x - pr.blocks;
-  if (bx < n_gemm) {
-    rowgemm_body<4, false, true, 1, RO, true, ST>(ga, smem, bx);
-  } else {
+  if (blockIdx.x < n_gemm) {
+    rowgemm_body<4, false, true, 1, RO, true, ST>(ga, smem, blockIdx.x);
+  } else if (blockIdx.x < n_main) {
     // ro_map (nullable): which (graph, chunk) this block scans — chosen on the host so that the block sits on the XCD whose row
     // panels gather that graph's rows (blocks b, b + 8, ... share an XCD): the rows are in that L2 already instead of being
     // fetched into another one a second time
-    unsigned r = bx - n_gemm;
+    unsigned r = blockIdx.x - n_gemm;
     if (ro_map) r = (unsigned)ro_map[r];
     readout_partial_bn_body<32>(sa, bn, ga.a, ga.lda, F4, packed, r % ro_gx, r / ro_gx, ro_ch, reinterpret_cast<unsigned long long*>(smem));
+  } else {
+    pull_rider_body(pr, blockIdx.x - n_main);
   }
 }
 
