@@ -25,7 +25,7 @@ for what in "$@"; do
              rocprofv3 --kernel-trace --output-format csv -d $O/rocprof_gr -- python3 scripts/gat_step.py > /dev/null 2>&1 &&
              python3 scripts/replay_trace.py $(ls $O/rocprof_gr/*/*kernel_trace.csv | head -1) gat_unpack_kernel > $O/gat_replay_timeline.txt; rm -rf $O/rocprof_gr ;;
     bench_replay) rm -rf $O/rocprof_br
-             rocprofv3 --kernel-trace --output-format csv -d $O/rocprof_br -- python3 bench.py --no-cpu-baseline --no-seeds --no-sweep --no-kernels --steps-per-graph 1 > /dev/null 2>&1 &&
+             rocprofv3 --kernel-trace --output-format csv -d $O/rocprof_br -- python3 bench.py --no-cpu-baseline --no-seeds --no-sweep --no-kernels --no-pyg --steps-per-graph 1 > /dev/null 2>&1 &&
              python3 scripts/replay_trace.py $(ls $O/rocprof_br/*/*kernel_trace.csv | head -1) adam_from_partials > $O/bench_replay_timeline.txt; rm -rf $O/rocprof_br ;;
     sagpool_replay) rm -rf $O/rocprof_sr
              rocprofv3 --kernel-trace --output-format csv -d $O/rocprof_sr -- python3 scripts/sagpool_step.py > /dev/null 2>&1 &&

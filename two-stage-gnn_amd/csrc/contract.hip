@@ -12,7 +12,10 @@
 
 namespace {
 
-constexpr int CT_THREADS = 512;
+#ifndef TSGNN_CT_THREADS
+#define TSGNN_CT_THREADS 512
+#endif
+constexpr int CT_THREADS = TSGNN_CT_THREADS;
 
 struct CtDims {
   int N, K, F;              // nodes, clusters, features

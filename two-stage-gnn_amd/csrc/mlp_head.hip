@@ -355,6 +355,10 @@ __global__ __launch_bounds__(MR_T) void mlp3_bwd_rows_kernel(Mlp3Bwd p, float* _
 }
 
 constexpr int MW_TILE = 4;                   // weight rows per block
+#ifndef TSGNN_MW_UNROLL
+#define TSGNN_MW_UNROLL 8
+#endif
+#define MW_UNROLL TSGNN_MW_UNROLL
 __global__ __launch_bounds__(256) void mlp3_bwd_weights_kernel(Mlp3Bwd p, const float* __restrict__ dlgg, const float* __restrict__ dz2g,
                                                               const float* __restrict__ dz1g, int nW1, int nW2,
                                                               const int64_t* __restrict__ nll_label, float* __restrict__ nll_loss,
@@ -397,8 +401,8 @@ __global__ __launch_bounds__(256) void mlp3_bwd_weights_kernel(Mlp3Bwd p, const 
 #pragma unroll
       for (int u = 0; u < MW_TILE; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (cc < Dc4) {
-#pragma unroll 8
-        for (int b = bl; b < B; b += 4) {                               // B / 4 independent 16-byte loads, eight in flight
+#pragma unroll MW_UNROLL
+        for (int b = bl; b < B; b += 4) {                               // B / 4 independent 16-byte loads, MW_UNROLL in flight
           const float4 v = ld4(act + (int64_t)b * lda + 4 * cc);
 #pragma unroll
           for (int u = 0; u < MW_TILE; ++u) {
