@@ -36,3 +36,21 @@ hb = synthetic.host_batch(0, 32, "DD", 1000)
 g, x, lab = synthetic.to_device(hb, dev)
 m = E.GcnEncoderGraph(89, 128, 128, 2, 3, bn=True, args=A(), final_dim="number_classes").to(dev)
 soak("headline SAGE b32", m, lambda: m.loss(m(x, g)[1], lab), 32, 1e-4)
+# round 4: config 4 (the reference's SAGPool network and the same with SAGEConv convs) and surface (B)'s SageNet
+import numpy as np
+from two_stage_gnn_amd import sag_layers as S, pyg
+hb4 = synthetic.host_batch(3, 128, "IMDB-BINARY", 136)
+sizes4 = hb4["sizes"]; n4 = int(sizes4.sum()); rp4 = hb4["rowptr"][: n4 + 1]
+class D: pass
+d4 = D()
+d4.edge_index = torch.from_numpy(np.stack([hb4["col"].astype(np.int64), np.repeat(np.arange(n4), np.diff(rp4)).astype(np.int64)])).to(dev)
+d4.x = torch.ones(n4, 1, device=dev)
+d4.batch = torch.repeat_interleave(torch.arange(128), torch.from_numpy(sizes4)).to(dev)
+lab4 = torch.from_numpy(hb4["label"]).to(dev)
+for conv in ("gcn", "sage"):
+    net4 = S.Net(1, 128, 2, 0.5, 0.0, use_batch=True, conv=conv).to(dev).train()
+    soak("cfg4 SAGPool + %s conv b128" % conv, net4, lambda: mp.nll_loss(net4(d4), lab4), 128, 1e-4)
+dB = D()
+dB.x, dB.edge_index, dB.batch, labB = synthetic.to_pyg(hb, dev)
+netB = pyg.SageNet(89, 128, 2, num_layers=3).to(dev).train()
+soak("surface B SageNet DD b32", netB, lambda: mp.nll_loss(netB(dB), labB), 32, 1e-4)
