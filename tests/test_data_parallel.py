@@ -201,13 +201,31 @@ def _rccl_one_rank_worker(port, q):
 
 @pytest.mark.gpu
 def test_one_graph_allreduce_step_equals_two_graph_step():
+    """one rank over RCCL: the step as two hipGraphs around an eager all-reduce == one hipGraph with the collective captured == the checked
+    ("auto") one-graph step == the same with the head's bucket on a side branch == eager with that overlap — bitwise.
+
+    The worker is started a second time if the FIRST one dies without a result: torch's ProcessGroupNCCL watchdog thread polls the events of
+    collectives it still holds, and a poll that lands inside a stream capture aborts the process (hipErrorCapturedEvent, seen once in some tens
+    of runs before GraphedStep began to wait out a watchdog pass ahead of its captures; the race is in the process group, not in the step)."""
     ctx = mp_.get_context("spawn")
-    q = ctx.Queue()
-    p = ctx.Process(target=_rccl_one_rank_worker, args=(29500 + (os.getpid() + 977) % 2000, q))
-    p.start()
-    out = q.get(timeout=240)
-    p.join(60)
-    assert p.exitcode == 0
+    out = None
+    for attempt in range(2):
+        q = ctx.Queue()
+        p = ctx.Process(target=_rccl_one_rank_worker, args=(29500 + (os.getpid() + 977 + 13 * attempt) % 2000, q))
+        p.start()
+        try:
+            out = q.get(timeout=240)
+        except Exception:                                       # noqa: BLE001 - queue.Empty: the worker died (or hung) without a result
+            out = None
+        p.join(60)
+        if p.is_alive():
+            p.kill()
+            p.join(10)
+        if out is not None:
+            assert p.exitcode == 0
+            break
+        print("worker attempt %d ended without a result (exit code %s)" % (attempt, p.exitcode))
+    assert out is not None
     for o in out:                                             # two graphs == one graph == checked one graph == 2 buckets == eager
         assert o[1] == 3.0
         np.testing.assert_array_equal(out[0][0], o[0])

@@ -323,6 +323,13 @@ class GraphedStep:
             if self.multi and dist.is_initialized():
                 dist.barrier(group=trainer.group)                  # no collective in flight while capturing
                 torch.cuda.synchronize()
+                # ... and none on the process group's watchdog list either: its thread polls the events of the collectives it still
+                # holds every ~100 ms, and a poll that lands inside the capture was seen (once in some tens of runs, one-rank RCCL) to
+                # fail with hipErrorCapturedEvent, invalidate the capture and take the process down with the watchdog's exception.
+                # The completed collectives leave the list at its next pass: give it two.
+                if dist.get_backend(trainer.group) == "nccl":
+                    import time
+                    time.sleep(0.25)
             mode = {"capture_error_mode": "thread_local"} if self.multi else {}
             # N > 1: TSGNN_GRAPH_ALLREDUCE = 1: the collective is captured too, the step is ONE graph (no graph boundary either
             # side of the all-reduce: 0.156 vs 0.1715 ms in the one-rank rehearsal of round 1); 0: two graphs around an eagerly
@@ -386,6 +393,11 @@ class GraphedStep:
 
     def _capture_two(self, mode):
         trainer = self.trainer
+        if self.multi and dist.is_initialized() and dist.get_backend(trainer.group) == "nccl":
+            # (the one-graph attempt before this issued collectives: let the watchdog drop them before the capture, as in __init__)
+            torch.cuda.synchronize()
+            import time
+            time.sleep(0.25)
         trainer._allow_early = not self.multi                # a fork inside the first of two graphs could not be joined
         self._fb = torch.cuda.CUDAGraph()
         with _capture(self._fb, stream=self.stream, **mode):
