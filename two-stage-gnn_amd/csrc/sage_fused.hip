@@ -558,12 +558,19 @@ int tsgnn_slot_fused_supported(int B, int F) {
 }
 
 // (TPR threads per graph row, NV float4 per thread, block threads): F/4 = TPR * NV lanes-worth of columns per row
+// 64-wide rows of up to 16 graphs: 16 threads per row (one float4 each) fill the 256-thread workgroup that 8 threads x two float4 left half
+// empty (DiffPool b16: five slot launches per step, 430-433 -> 428 us; TSGNN_SLOT_WIDE16=0: the table's entry)
+static inline bool slot_wide16() {
+  static const bool on = [] { const char* e = getenv("TSGNN_SLOT_WIDE16"); return e ? atoi(e) != 0 : true; }();
+  return on;
+}
 #define TSGNN_SLOT_DISPATCH(KERNEL, GRID, LDS, ...)                                                                     \
   do {                                                                                                                   \
     const int F4_ = F / 4;                                                                                               \
     TSGNN_KNAME("%s<8,%d,%d>", #KERNEL, F4_ <= 8 ? 1 : (F4_ <= 16 ? 2 : 4), B <= 32 ? 256 : (B <= 64 ? 512 : 1024));     \
     if (B <= 32) {                                                                                                       \
       if (F4_ <= 8) KERNEL<8, 1, 256><<<GRID, 256, LDS, stream>>> __VA_ARGS__;                                            \
+      else if (F4_ <= 16 && B <= 16 && slot_wide16()) KERNEL<16, 1, 256><<<GRID, 256, LDS, stream>>> __VA_ARGS__;         \
       else if (F4_ <= 16) KERNEL<8, 2, 256><<<GRID, 256, LDS, stream>>> __VA_ARGS__;                                      \
       else KERNEL<8, 4, 256><<<GRID, 256, LDS, stream>>> __VA_ARGS__;                                                     \
     } else if (B <= 64) {                                                                                                \
