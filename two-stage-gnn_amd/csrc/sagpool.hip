@@ -452,7 +452,10 @@ inline bool pg_small_block(int max_seg, int B) {
   }
   return max_seg <= PG_SMALL_NODES && B > 2 * ncu;
 }
-constexpr int PG_RGROUPS = 8;            // lane groups that run the gather / readout phase
+#ifndef TSGNN_PG_RGROUPS
+#define TSGNN_PG_RGROUPS 8
+#endif
+constexpr int PG_RGROUPS = TSGNN_PG_RGROUPS;            // lane groups that run the gather / readout phase
 constexpr int PG_RANK_MAX = 1024;        // up to this many (padded) nodes the top-k order comes from a rank count instead of a bitonic sort
 
 struct PoolGraphArgs {
