@@ -289,6 +289,11 @@ int tsgnn_rowgemm_supported(const float* a, int64_t lda, const float* b, int64_t
 int tsgnn_rowgemm_f32(const float* a, int64_t lda, const float* b, int64_t ldb, int trans_b, const float* bias, float* c,
                       int64_t ldc, float* rinv, int64_t rows, int K, int N, int normalize, int64_t fill_rows,
                       tsgnn_stream_t stream);
+/* workgroups the row panels of a `rows`-row fused layer launch take on the current device: ceil(rows / 32) 32-row panels, or — when that
+ * is a few more than the device has compute units — one full panel per unit and the remaining rows as 16-row units (a unit with two
+ * full panels decided the launch: 1.3-1.4 x).  For callers that size a co-resident role of the same launch (encoders.py:33-40 backward:
+ * the weight-gradient slab blocks beside the input-gradient panels). */
+int tsgnn_panel_blocks(int64_t rows);
 /* Aggregation fused into the product (GraphConv.forward lines encoders.py:33-40 in one launch; and its input gradient
  * dX = (A dU) W^T for a symmetric A): the A operand of tsgnn_rowgemm_f32 is replaced by
  *   z[r,:] = sum_k x[ell[r*ell_w + k], :K]      (ell = fixed-width neighbour table of tsgnn_csr_to_ell, entries < 0 skipped,

@@ -54,7 +54,12 @@ int tsgnn_sage_layer_bwd_f32(const int* ell, int ell_w, const int* tail_ptr, con
   if ((tail_ptr == nullptr) != (tail_col == nullptr)) return TSGNN_EINVAL;
   RowGemmArgs ga{du, lddu, w, ldw, nullptr, dxs, lddxs, nullptr, rows, 128, 128, 0, 0, ell, ell_w, nullptr, 0, tail_ptr, tail_col};
   TnArgs gt{z, ldz, du, lddu, rows, rows_per_slab, 128, 128, ws, nullptr, bias_only_rows};
-  const unsigned n_tn = 2u * (unsigned)nslab, n_pan = (unsigned)ceil_div64(rows, 32);
+  static int ncu = 0;
+  if (ncu == 0) {
+    int dev = 0, v = 0;
+    ncu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+  }
+  const unsigned n_tn = 2u * (unsigned)nslab, n_pan = panel_split(rows, ncu, &ga.n_full, &ga.unit);   // (a few more panels than CUs: 16-row units)
   constexpr size_t la = rowgemm_lds_bytes<4, true, true>(), lt = tn_rows_lds_bytes<4, 4>();
   static const int panels_first = [] { const char* e = getenv("TSGNN_BWD_PANELS_FIRST"); return e ? atoi(e) : 1; }();
   // the slab blocks wait `delay` x ~0.43 us before their first request: with at most one row panel per CU the panels' two dependent gather
@@ -62,11 +67,6 @@ int tsgnn_sage_layer_bwd_f32(const int* ell, int ell_w, const int* tail_ptr, con
   // one box; 1 and 4+: nothing); batches of more panels than CUs: no difference either way (seeds 1-7 within 0.1 us), so only the
   // one-panel-per-CU launches delay.  TSGNN_SLAB_DELAY overrides.
   static const int slab_delay_env = [] { const char* e = getenv("TSGNN_SLAB_DELAY"); return e ? atoi(e) : -1; }();
-  static int ncu = 0;
-  if (ncu == 0) {
-    int dev = 0, v = 0;
-    ncu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
-  }
   const int slab_delay = slab_delay_env >= 0 ? slab_delay_env : ((int64_t)n_pan <= (int64_t)ncu ? 2 : 0);
   TSGNN_KNAME(panels_first ? "sage_layer_bwd_kernel<true>" : "sage_layer_bwd_kernel<false>");
   if (panels_first) sage_layer_bwd_kernel<true><<<n_tn + n_pan, 256, la > lt ? la : lt, stream>>>(ga, gt, n_tn, (unsigned)nslab, n_pan, slab_delay);

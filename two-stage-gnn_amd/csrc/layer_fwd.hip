@@ -62,7 +62,8 @@ int tsgnn_sage_layer_fwd_bn_plan(int64_t rows, int64_t fill_rows, int B, int nsl
   if (!ro_ch || !n_gemm || rows <= 0 || B <= 0 || nslots <= 0) return TSGNN_EINVAL;
   int dev = 0, v = 0;
   const int ncu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
-  const unsigned ng = (unsigned)ceil_div64(rows, 32) + (fill_rows > 0 ? 1u : 0u);
+  int n_full_ = 0, unit_ = 16;
+  const unsigned ng = panel_split(rows, ncu, &n_full_, &unit_) + (fill_rows > 0 ? 1u : 0u);
   int ch = 64;
   while (ch < 256 && ng + (unsigned)((nslots + ch - 1) / ch) * (unsigned)B > 2u * (unsigned)ncu) ch *= 2;
   *ro_ch = ch; *n_gemm = (int)ng;
@@ -104,7 +105,6 @@ int tsgnn_sage_layer_fwd_bn_f32(const int* ell, int ell_w, const int* tail_ptr, 
   ga.bn_sums = sums_in; ga.bn_ghost = ghost_in; ga.bn_slot_count = slot_count; ga.bn_B = B; ga.bn_nslots = nslots; ga.bn_F = K;
   SlotArgs sa{graph_ptr, slot_count, B, nslots, rows, n_ghost};
   BnReadArgs bn{sums_in, ghost_in, K, mean_out, rstd_out};
-  const unsigned n_gemm = (unsigned)ceil_div64(rows, 32) + (fill_rows > 0 ? 1u : 0u);
   // slots per readout block: 64 while [panels + readout blocks] fit two blocks per compute unit (what the registers allow), else 128
   // or 256 — DD seed 2: 266 panels + 256 readout blocks = 523 > 512 ran a third round for eleven blocks (13.9 -> 17.8 us)
   static int ncu = 0;
@@ -112,6 +112,7 @@ int tsgnn_sage_layer_fwd_bn_f32(const int* ell, int ell_w, const int* tail_ptr, 
     int dev = 0, v = 0;
     ncu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
   }
+  const unsigned n_gemm = panel_split(rows, ncu, &ga.n_full, &ga.unit) + (fill_rows > 0 ? 1u : 0u);   // (a few more panels than CUs: 16-row units)
   int ro_ch = 64;
   while (ro_ch < 256 && n_gemm + (unsigned)((nslots + ro_ch - 1) / ro_ch) * (unsigned)B > 2u * (unsigned)ncu) ro_ch *= 2;
   const unsigned ro_gx = (unsigned)((nslots + ro_ch - 1) / ro_ch);

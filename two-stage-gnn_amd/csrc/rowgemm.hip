@@ -280,8 +280,17 @@ int tsgnn_gather_rowgemm_st_f32(const int* ell, int ell_w, const int* tail_ptr, 
   if ((tail_ptr == nullptr) != (tail_col == nullptr)) return TSGNN_EINVAL;
   RowGemmArgs g{x, ldx, b, ldb, bias, c, ldc, rinv, rows, K, N, 1, fill_rows, ell, ell_w, zout, ldz, tail_ptr, tail_col};
   g.st_row_slot = row_slot; g.st_sums = sums; g.st_ghost = ghost;
-  const unsigned nblk = (unsigned)(ceil_div64(rows, 32) + (fill_rows > 0 ? 1 : 0));
-  if (K > KC && nblk <= ks2_max_blocks() && rowgemm_ks2_enabled()) {
+  unsigned nblk = (unsigned)(ceil_div64(rows, 32) + (fill_rows > 0 ? 1 : 0));
+  const bool ks2 = K > KC && nblk <= ks2_max_blocks() && rowgemm_ks2_enabled();
+  if (!ks2) {                                            // (the one-group kernel: a few more panels than CUs go as 16-row units)
+    static int ncu = 0;
+    if (ncu == 0) {
+      int dev = 0, v = 0;
+      ncu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+    }
+    nblk = panel_split(rows, ncu, &g.n_full, &g.unit) + (fill_rows > 0 ? 1u : 0u);
+  }
+  if (ks2) {
     constexpr size_t lds2 = rowgemm_lds_bytes<4, false, true, 2>();
     static bool attr = false;
     if (!attr && lds2 > 64 * 1024) {
@@ -298,6 +307,20 @@ int tsgnn_gather_rowgemm_st_f32(const int* ell, int ell_w, const int* tail_ptr, 
   }
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
+}
+
+/* workgroups the row panels of a `rows`-row launch take on the current device (rowgemm_body.h panel_split: 32-row panels, or — a few more
+ * panels than compute units — one full panel per unit and the rest of the rows in 16-row units); callers that size a co-resident role
+ * (the merged backward launch's slab blocks) plan with this */
+int tsgnn_panel_blocks(int64_t rows) {
+  if (rows <= 0) return 0;
+  static int ncu = 0;
+  if (ncu == 0) {
+    int dev = 0, v = 0;
+    ncu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+  }
+  int nf = 0, un = 16;
+  return (int)panel_split(rows, ncu, &nf, &un);
 }
 
 int tsgnn_gather_rowgemm_f32(const int* ell, int ell_w, const int* tail_ptr, const int* tail_col, const float* x, int64_t ldx, const float* b, int64_t ldb, int trans_b,

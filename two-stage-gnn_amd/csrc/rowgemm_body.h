@@ -4,6 +4,7 @@
 #pragma once
 #include "common.h"
 #include <type_traits>
+#include <cstdlib>
 
 namespace {
 
@@ -43,7 +44,33 @@ struct RowGemmArgs {
   //   carries the slot beside the row:  entry = slot << 20 | row  (GraphBatch.ell_slots()).
   const int* st_row_slot; unsigned long long* st_sums; float* st_ghost;
   const unsigned long long* bn_sums; const float* bn_ghost; const int* bn_slot_count; int bn_B, bn_nslots, bn_F;
+  // HALF PANELS (round 4; 0: every block is a 32-row panel).  n_full > 0: blocks [0, n_full) are 32-row panels of rows [0, 32 n_full), the
+  // blocks behind them 16-ROW panels of the remaining rows (then the filler block).  A batch of a few more panels than CUs puts a second
+  // panel on some CUs, and a CU with two panels decides the launch (1.3-1.4 x): with one full panel per CU and the overflow in 16-row
+  // (or 8-row) units the busiest CU gathers 40-48 rows instead of 64 (panel_split() below).
+  int n_full;
+  int unit;                           // rows per unit of the blocks behind the full panels (16 or 8: panel_unit_rows())
 };
+
+// blocks of a panel launch of `rows` rows on `ncu` compute units: n_full (0: plain 32-row panels) and the total number of panel blocks
+// rows per unit behind the full panels: 8 while the overflow is small (up to ncu / 16 panels: the extra blocks — each reads all of W and
+// runs a whole MFMA chain — stay few), 16 above.  Measured on the DD batches of seeds 0-7 (ms per step, units of 32 = plain / 16 / 8):
+// 266-271 panels 0.1395-0.1437 / 0.1381-0.1420 / 0.1371-0.1414; 288 panels 0.1406 / 0.1378 / 0.1410.  TSGNN_PANEL_UNIT forces 8 or 16.
+inline int panel_unit_rows(int64_t rows, int ncu) {
+  static const int forced = [] { const char* e = getenv("TSGNN_PANEL_UNIT"); const int v = e ? atoi(e) : 0; return (v == 8 || v == 16) ? v : 0; }();
+  if (forced) return forced;
+  return ((rows + 31) / 32 - ncu) <= ncu / 16 ? 8 : 16;
+}
+inline unsigned panel_split(int64_t rows, int ncu, int* n_full, int* unit) {
+  static const bool on = [] { const char* e = getenv("TSGNN_HALF_PANELS"); return e ? atoi(e) != 0 : true; }();
+  const int64_t P = (rows + 31) / 32;
+  *n_full = 0; *unit = 16;
+  if (!on || ncu < 8 || P <= ncu || P - ncu > ncu / 2) return (unsigned)P;
+  const int nf = ncu & ~7;                               // (a multiple of 8: the XCD-aware order of the full panels)
+  *n_full = nf;
+  const int u = *unit = panel_unit_rows(rows, ncu);
+  return (unsigned)nf + (unsigned)((rows - 32 * (int64_t)nf + u - 1) / u);
+}
 
 constexpr int BN_TAB = 1024;                  // slots the LDS table of (mean, rstd) holds
 constexpr float BN_FWD_EPS = 1e-5f;
@@ -95,7 +122,17 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem_a
   // that the neighbour rows gathered by adjacent panels (same graph) are fetched into one L2 only.  The filler block
   // (last) keeps its index.
   const unsigned npanels = (unsigned)((g.rows + 31) / 32);
-  const int64_t m0 = (bid < npanels ? (int64_t)xcd_remap(bid, npanels) : (int64_t)bid) * 32;
+  int64_t m0, rows_hi;                                   // this block's rows [m0, rows_hi)
+  if (g.n_full > 0) {
+    const int un = g.unit == 8 ? 8 : 16;
+    const unsigned nfull = (unsigned)g.n_full, nhalf = (unsigned)((g.rows - 32 * (int64_t)nfull + un - 1) / un);
+    if (bid < nfull) { m0 = (int64_t)xcd_remap(bid, nfull) * 32; rows_hi = m0 + 32; }
+    else if (bid < nfull + nhalf) { m0 = 32 * (int64_t)nfull + un * (int64_t)(bid - nfull); rows_hi = min(m0 + un, g.rows); }
+    else { m0 = (int64_t)npanels * 32; rows_hi = m0; }   // the filler block
+  } else {
+    m0 = (bid < npanels ? (int64_t)xcd_remap(bid, npanels) : (int64_t)bid) * 32;
+    rows_hi = min(m0 + 32, g.rows);
+  }
   TR(0);
   if (m0 >= g.rows) {
     // filler block (launched after the panels when fill_rows > 0): every fill row = [normalised] bias
@@ -145,7 +182,7 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem_a
   if constexpr (READOUT) {
     if (g.ro_packed) {
       ro_gf = g.ro_row_graph[m0];
-      ro_gl = g.ro_row_graph[min(m0 + 31, g.rows - 1)];
+      ro_gl = g.ro_row_graph[rows_hi - 1];
     }
   }
 
@@ -154,7 +191,7 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem_a
   // Loads are unconditional from clamped (always mapped) addresses; validity is applied when the registers
   // are written to LDS, so nothing waits on a load before the MFMAs of the current chunk.
   const int am = tid >> 3, ak4 = tid & 7;
-  const bool a_row_ok = (m0 + am) < g.rows;
+  const bool a_row_ok = (m0 + am) < rows_hi;
   const float* ap = g.a + ((a_row_ok && !GATHER) ? (m0 + am) : 0) * g.lda + 4 * ak4 + (GATHER ? 0 : kb);
   const float* bp[BV];
   int b_k[BV];                                         // k (or first k of the float4) inside the chunk
@@ -184,7 +221,7 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem_a
     unsigned b_valid;                                  // bit q: rb[q] valid
     bool plain;                                        // uniform: no masking needed
   };
-  const bool panel_full = (m0 + 32) <= g.rows && g.N == NP;   // uniform: every row and column of the panel exists
+  const bool panel_full = (m0 + 32) <= rows_hi && g.N == NP;   // uniform: every row and column of the panel exists
   auto fetch = [&](Staged& s, int k0) {                // G(c): global -> registers
     s.plain = panel_full && (k0 + KC) <= Kv;
     s.a_valid = 0;
@@ -296,7 +333,7 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem_a
 #pragma unroll
       for (int q = 0; q < GN / 4; ++q) {
         int4 v = make_int4(-1, -1, -1, -1);
-        if (row < g.rows && 4 * q < g.ell_w) v = *reinterpret_cast<const int4*>(g.ell + row * g.ell_w + 4 * q);
+        if (row < rows_hi && 4 * q < g.ell_w) v = *reinterpret_cast<const int4*>(g.ell + row * g.ell_w + 4 * q);
         ids[p][4 * q] = v.x; ids[p][4 * q + 1] = v.y; ids[p][4 * q + 2] = v.z; ids[p][4 * q + 3] = v.w;
       }
     }
@@ -318,7 +355,7 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem_a
   }
   int st_slot = -1;                                    // STATS: the slot of row m0 + lane (wave 0, lanes < 32), used last
   if constexpr (STATS) {
-    if (g.st_sums && wid == 0 && grp == 0 && lane < 32 && (m0 + lane) < g.rows) st_slot = g.st_row_slot[m0 + lane];
+    if (g.st_sums && wid == 0 && grp == 0 && lane < 32 && (m0 + lane) < rows_hi) st_slot = g.st_row_slot[m0 + lane];
   }
 #pragma unroll
   for (int c = 0; c < NS; ++c)
@@ -398,7 +435,7 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem_a
           }
         }
       }
-      if (colok && g.tail_ptr && row < g.rows && table_full) {   // lists longer than the table continue in the CSR tail (a handful
+      if (colok && g.tail_ptr && row < rows_hi && table_full) {   // lists longer than the table continue in the CSR tail (a handful
                                                                  // of rows per batch: asking every row with >= GN neighbours for its
                                                                  // tail range was a dependent round trip for 7 % of the rows)
         for (int e = g.tail_ptr[row]; e < g.tail_ptr[row + 1]; ++e) {
@@ -416,7 +453,7 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem_a
         const int pr = 8 * KS * p + rsub;
         *reinterpret_cast<float4*>(Apanel + pr * LDA_F + 4 * (c4 ^ (pr & 7))) = va;
       }
-      if (g.zout && colok && row < g.rows) st_out(reinterpret_cast<float4*>(g.zout + row * g.ldz + 4 * c4), va);
+      if (g.zout && colok && row < rows_hi) st_out(reinterpret_cast<float4*>(g.zout + row * g.ldz + 4 * c4), va);
     }
   }
   float bias_v[TPW];                                   // fetched now, used in the epilogue
@@ -536,7 +573,7 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem_a
         const float4 p = *reinterpret_cast<const float4*>(red + lane * 4);
         const float rs = fminf(__builtin_amdgcn_rsqf((p.x + p.y) + (p.z + p.w)), 1.0f / NORM_EPS);
         inv[lane] = rs;
-        if (g.rinv && wid == 0 && (m0 + lane) < g.rows) g.rinv[m0 + lane] = rs;
+        if (g.rinv && wid == 0 && (m0 + lane) < rows_hi) g.rinv[m0 + lane] = rs;
         if constexpr (STATS) {
           if (g.st_sums && wid == 0 && st_slot >= 0) {
             const float4 a = *reinterpret_cast<const float4*>(redq + lane * 4), b = *reinterpret_cast<const float4*>(redq + 128 + lane * 4);
@@ -568,7 +605,7 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem_a
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int64_t gm = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          if (gm < g.rows && cn < g.N) cp[(int64_t)((r & 3) + 8 * (r >> 2)) * g.ldc] = acc[t][r] * scale[r];
+          if (gm < rows_hi && cn < g.N) cp[(int64_t)((r & 3) + 8 * (r >> 2)) * g.ldc] = acc[t][r] * scale[r];
         }
       }
     }
@@ -579,7 +616,7 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem_a
       // the wave, one 64-bit atomicMax per (graph, column) and panel.  Values are the stored ones (acc * scale), so the
       // readout is bitwise what a pass over c would find; ties go to the smallest row (~row in the low word).
       const int cn = wid * 32 + i;
-      const int64_t last = min(m0 + 31, g.rows - 1);
+      const int64_t last = rows_hi - 1;
       for (int b = ro_gf; b <= ro_gl; ++b) {
         int64_t lo = m0, hi = last + 1;
         if (ro_gf != ro_gl) { lo = max(lo, (int64_t)g.ro_graph_ptr[b]); hi = min(hi, (int64_t)g.ro_graph_ptr[b + 1]); }

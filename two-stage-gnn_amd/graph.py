@@ -14,6 +14,7 @@ Row layouts
             drop-in ``GraphConv.forward(x[B,N,F], adj[B,N,N])`` whose output must be padded too).
 Feature matrices have ``total_rows = n_rows + n_ghost`` rows; ghost rows have empty neighbour lists.
 """
+import os
 import numpy as np
 import torch
 
@@ -306,6 +307,9 @@ class GraphBatch:
             ch, ng = int(ch[0]), int(ng[0])
             chunks = -(-int(nslots) // ch)
             npan = -(-self.n_rows // 32)
+            ncu = torch.cuda.get_device_properties(self.device).multi_processor_count
+            if npan > ncu and npan - ncu <= ncu // 2 and os.environ.get("TSGNN_HALF_PANELS", "1") != "0":
+                npan = ncu & ~7            # (rowgemm_body.h panel_split: the full panels; the rows behind them go as 16-row units on any XCD)
             q, r = divmod(npan, 8)
             start = np.zeros(9, dtype=np.int64)
             for x in range(8):

@@ -93,7 +93,7 @@ def _slabs_beside_panels(nslab, rps, need, rows, K, N, dev):
     ncu = _ncu.get(dev)
     if ncu is None:
         ncu = _ncu[dev] = torch.cuda.get_device_properties(dev).multi_processor_count
-    npan = (rows + 31) // 32
+    npan = int(nat.lib().tsgnn_panel_blocks(int(rows)))         # (32-row panels, or 16-row units for the rows beyond one panel per CU)
     if npan <= ncu or 2 * nslab + npan <= 2 * ncu:
         return nslab, rps, need
     cap = max(32, (2 * ncu - npan) // 2)
