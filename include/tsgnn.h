@@ -294,6 +294,10 @@ int tsgnn_rowgemm_f32(const float* a, int64_t lda, const float* b, int64_t ldb, 
  * full panels decided the launch: 1.3-1.4 x).  For callers that size a co-resident role of the same launch (encoders.py:33-40 backward:
  * the weight-gradient slab blocks beside the input-gradient panels). */
 int tsgnn_panel_blocks(int64_t rows);
+/* on = 0: the fused layer launches issued by this process keep plain 32-row panels until on = 1 again (process-wide, not per thread: a
+ * backward's launches come from autograd's thread).  For capacity-padded batches — ingest.IngestPipeline captures its steps under it: the
+ * rows beyond one panel per unit are mostly padding there.  Not for concurrent use by two trainers of one process. */
+int tsgnn_panel_split_hint(int on);
 /* Aggregation fused into the product (GraphConv.forward lines encoders.py:33-40 in one launch; and its input gradient
  * dX = (A dU) W^T for a symmetric A): the A operand of tsgnn_rowgemm_f32 is replaced by
  *   z[r,:] = sum_k x[ell[r*ell_w + k], :K]      (ell = fixed-width neighbour table of tsgnn_csr_to_ell, entries < 0 skipped,

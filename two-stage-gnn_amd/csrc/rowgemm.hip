@@ -20,6 +20,8 @@
 #include <cstdlib>
 #include "rowgemm_body.h"
 #include "ingest_rider.h"
+
+int tsgnn_panel_split_on_ = 1;
 #include "rowgemm_big_body.h"
 
 namespace {
@@ -306,6 +308,12 @@ int tsgnn_gather_rowgemm_st_f32(const int* ell, int ell_w, const int* tail_ptr, 
     rowgemm_gather_st_kernel<<<nblk + pr.blocks, 256, rowgemm_lds_bytes<4, false, true>(), stream>>>(g, pr, nblk);
   }
   TSGNN_CHECK_LAUNCH();
+  return TSGNN_OK;
+}
+
+/* on = 0: the fused layer launches of this PROCESS keep plain 32-row panels until it is switched back on (default on) */
+int tsgnn_panel_split_hint(int on) {
+  tsgnn_panel_split_on_ = on ? 1 : 0;
   return TSGNN_OK;
 }
 

@@ -4,6 +4,8 @@
 #pragma once
 #include "common.h"
 #include <type_traits>
+
+extern int tsgnn_panel_split_on_;                       // rowgemm.hip; see panel_split() below
 #include <cstdlib>
 
 namespace {
@@ -61,11 +63,14 @@ inline int panel_unit_rows(int64_t rows, int ncu) {
   if (forced) return forced;
   return ((rows + 31) / 32 - ncu) <= ncu / 16 ? 8 : 16;
 }
+// 0: launches keep plain 32-row panels (tsgnn_panel_split_hint; process-wide — a backward's launches are issued by autograd's own
+// thread, so a thread-local switch would miss them: capacity-padded batches, whose rows beyond one panel
+// per CU are mostly PADDING — cut into units they cost a block's fixed work each and gather nothing: the ingest step 0.1494 -> 0.1541 ms)
 inline unsigned panel_split(int64_t rows, int ncu, int* n_full, int* unit) {
   static const bool on = [] { const char* e = getenv("TSGNN_HALF_PANELS"); return e ? atoi(e) != 0 : true; }();
   const int64_t P = (rows + 31) / 32;
   *n_full = 0; *unit = 16;
-  if (!on || ncu < 8 || P <= ncu || P - ncu > ncu / 2) return (unsigned)P;
+  if (!on || !tsgnn_panel_split_on_ || ncu < 8 || P <= ncu || P - ncu > ncu / 2) return (unsigned)P;
   const int nf = ncu & ~7;                               // (a multiple of 8: the XCD-aware order of the full panels)
   *n_full = nf;
   const int u = *unit = panel_unit_rows(rows, ncu);

@@ -311,9 +311,15 @@ class IngestPipeline:
                     nat.call("ingest_flush_pull_rider")       # (a model without such a launch: the riders as launches of their own)
                     return out
                 return loss
-        for p, s in enumerate(self.slots):
-            fn = make_loss_ride(s, self.slots[(p + 1) % depth]) if self.ride else make_loss(s)
-            self.steps.append(GraphedStep(trainer, fn, warmup=2, stream=self.compute))
+        # capacity-padded batches keep plain 32-row panels: their rows beyond one panel per CU are mostly padding (csrc/rowgemm_body.h,
+        # panel_split; the decision is taken when the launches are captured)
+        nat.call_nostream("panel_split_hint", 0)
+        try:
+            for p, s in enumerate(self.slots):
+                fn = make_loss_ride(s, self.slots[(p + 1) % depth]) if self.ride else make_loss(s)
+                self.steps.append(GraphedStep(trainer, fn, warmup=2, stream=self.compute))
+        finally:
+            nat.call_nostream("panel_split_hint", 1)
 
     def run(self, schedule=None, workers=2, ticks=None):
         """enqueue one step per entry of the schedule; returns after the last step is enqueued (caller synchronises).
