@@ -69,8 +69,11 @@ inline int panel_unit_rows(int64_t rows, int ncu) {
 inline unsigned panel_split(int64_t rows, int ncu, int* n_full, int* unit) {
   static const bool on = [] { const char* e = getenv("TSGNN_HALF_PANELS"); return e ? atoi(e) != 0 : true; }();
   const int64_t P = (rows + 31) / 32;
-  *n_full = 0; *unit = 16;
-  if (!on || !tsgnn_panel_split_on_ || ncu < 8 || P <= ncu || P - ncu > ncu / 2) return (unsigned)P;
+  *n_full = 0; *unit = 32;
+  if (!on || !tsgnn_panel_split_on_ || ncu < 8) return (unsigned)P;
+  // (small batches — PROTEINS b64: 77 panels — cut entirely into 16- or 8-row units to occupy more CUs: 116.9 -> 117.2 / 125.4 us per
+  // step, measured and left out: a block's fixed work — all of W, a whole MFMA chain — does not shrink with its rows)
+  if (P <= ncu || P - ncu > ncu / 2) return (unsigned)P;
   const int nf = ncu & ~7;                               // (a multiple of 8: the XCD-aware order of the full panels)
   *n_full = nf;
   const int u = *unit = panel_unit_rows(rows, ncu);
@@ -128,11 +131,11 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem_a
   // (last) keeps its index.
   const unsigned npanels = (unsigned)((g.rows + 31) / 32);
   int64_t m0, rows_hi;                                   // this block's rows [m0, rows_hi)
-  if (g.n_full > 0) {
-    const int un = g.unit == 8 ? 8 : 16;
+  if (g.unit == 8 || g.unit == 16) {
+    const int un = g.unit;
     const unsigned nfull = (unsigned)g.n_full, nhalf = (unsigned)((g.rows - 32 * (int64_t)nfull + un - 1) / un);
     if (bid < nfull) { m0 = (int64_t)xcd_remap(bid, nfull) * 32; rows_hi = m0 + 32; }
-    else if (bid < nfull + nhalf) { m0 = 32 * (int64_t)nfull + un * (int64_t)(bid - nfull); rows_hi = min(m0 + un, g.rows); }
+    else if (bid < nfull + nhalf) { m0 = 32 * (int64_t)nfull + un * (int64_t)xcd_remap(bid - nfull, nhalf); rows_hi = min(m0 + un, g.rows); }
     else { m0 = (int64_t)npanels * 32; rows_hi = m0; }   // the filler block
   } else {
     m0 = (bid < npanels ? (int64_t)xcd_remap(bid, npanels) : (int64_t)bid) * 32;
