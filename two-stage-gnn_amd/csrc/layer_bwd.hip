@@ -15,11 +15,11 @@
 namespace {
 
 // PANELS_FIRST: the row panels take the low block indices (dispatched first), the slab blocks follow
-template <bool PANELS_FIRST>
+template <bool PANELS_FIRST, bool UNITS = false>
 __global__ __launch_bounds__(256) void sage_layer_bwd_kernel(RowGemmArgs ga, TnArgs gt, unsigned n_tn, unsigned nslab, unsigned n_pan, int slab_delay) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (PANELS_FIRST) {
-    if (blockIdx.x < n_pan) rowgemm_body<4, true, true>(ga, smem, blockIdx.x);
+    if (blockIdx.x < n_pan) rowgemm_body<4, true, true, 1, false, false, false, UNITS>(ga, smem, blockIdx.x);
     else {
       // the slab blocks finish well before the row panels (whose gather prologue is two dependent round trips): let the panels'
       // requests go first instead of competing with the slabs' 64 KB per block for the same first microseconds
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void sage_layer_bwd_kernel(RowGemmArgs ga, TnA
     }
   } else {
     if (blockIdx.x < n_tn) tn_rows_body<4, 4, 2>(gt, smem, blockIdx.x % nslab, blockIdx.x / nslab, nslab);
-    else rowgemm_body<4, true, true>(ga, smem, blockIdx.x - n_tn);
+    else rowgemm_body<4, true, true, 1, false, false, false, UNITS>(ga, smem, blockIdx.x - n_tn);
   }
 }
 
@@ -69,7 +69,10 @@ int tsgnn_sage_layer_bwd_f32(const int* ell, int ell_w, const int* tail_ptr, con
   static const int slab_delay_env = [] { const char* e = getenv("TSGNN_SLAB_DELAY"); return e ? atoi(e) : -1; }();
   const int slab_delay = slab_delay_env >= 0 ? slab_delay_env : ((int64_t)n_pan <= (int64_t)ncu ? 2 : 0);
   TSGNN_KNAME(panels_first ? "sage_layer_bwd_kernel<true>" : "sage_layer_bwd_kernel<false>");
-  if (panels_first) sage_layer_bwd_kernel<true><<<n_tn + n_pan, 256, la > lt ? la : lt, stream>>>(ga, gt, n_tn, (unsigned)nslab, n_pan, slab_delay);
+  const bool units = ga.unit == 8 || ga.unit == 16;
+  if (panels_first && units) sage_layer_bwd_kernel<true, true><<<n_tn + n_pan, 256, la > lt ? la : lt, stream>>>(ga, gt, n_tn, (unsigned)nslab, n_pan, slab_delay);
+  else if (panels_first) sage_layer_bwd_kernel<true><<<n_tn + n_pan, 256, la > lt ? la : lt, stream>>>(ga, gt, n_tn, (unsigned)nslab, n_pan, slab_delay);
+  else if (units) sage_layer_bwd_kernel<false, true><<<n_tn + n_pan, 256, la > lt ? la : lt, stream>>>(ga, gt, n_tn, (unsigned)nslab, n_pan, slab_delay);
   else sage_layer_bwd_kernel<false><<<n_tn + n_pan, 256, la > lt ? la : lt, stream>>>(ga, gt, n_tn, (unsigned)nslab, n_pan, slab_delay);
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;

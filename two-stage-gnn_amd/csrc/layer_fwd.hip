@@ -34,13 +34,13 @@ __global__ __launch_bounds__(256) void sage_layer_fwd_kernel(RowGemmArgs ga, Slo
 // The same launch for a layer whose INPUT's slot batch-norm was not materialised (rowgemm_body.h BNIN / STATS, readout_body.h):
 // x = the previous layer's v; the gather and the readout partial form y = BN(relu(v)) on the fly from the previous layer's integer
 // sums.  ST: this layer is followed by a batch-norm too (statistics epilogue); RO: it is the last one (readout epilogue).
-template <bool RO, bool ST>
+template <bool RO, bool ST, bool UNITS = false>
 __global__ __launch_bounds__(256, 2) void sage_layer_fwd_bn_kernel(RowGemmArgs ga, SlotArgs sa, BnReadArgs bn, unsigned n_gemm, unsigned ro_gx,
                                                                 int ro_ch, int F4, unsigned long long* __restrict__ packed, unsigned n_main,
                                                                 PullRider pr, const int* __restrict__ ro_map) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (blockIdx.x < n_gemm) {
-    rowgemm_body<4, false, true, 1, RO, true, ST>(ga, smem, blockIdx.x);
+    rowgemm_body<4, false, true, 1, RO, true, ST, UNITS>(ga, smem, blockIdx.x);
   } else if (blockIdx.x < n_main) {
     // ro_map (nullable): which (graph, chunk) this block scans — chosen on the host so that the block sits on the XCD whose row
     // panels gather that graph's rows (blocks b, b + 8, ... share an XCD): the rows are in that L2 already instead of being
@@ -122,16 +122,23 @@ int tsgnn_sage_layer_fwd_bn_f32(const int* ell, int ell_w, const int* tail_ptr, 
   if (lds < lro) lds = lro;
   const unsigned n_main = n_gemm + ro_gx * (unsigned)B;
   const PullRider pr = take_pull_rider();
+  const bool units = ga.unit == 8 || ga.unit == 16;     // (rows beyond one panel per CU as 16- / 8-row units: the UNITS build of the kernels)
+#define TSGNN_FWD_BN(RO_, ST_)                                                                                                              \
+  do {                                                                                                                                      \
+    if (units) sage_layer_fwd_bn_kernel<RO_, ST_, true><<<n_main + pr.blocks, 256, lds, stream>>>(ga, sa, bn, n_gemm, ro_gx, ro_ch, K / 4, packed, n_main, pr, ro_map); \
+    else sage_layer_fwd_bn_kernel<RO_, ST_><<<n_main + pr.blocks, 256, lds, stream>>>(ga, sa, bn, n_gemm, ro_gx, ro_ch, K / 4, packed, n_main, pr, ro_map);             \
+  } while (0)
   if (packed_out) {
     TSGNN_KNAME("sage_layer_fwd_bn_kernel<true,false>");
-    sage_layer_fwd_bn_kernel<true, false><<<n_main + pr.blocks, 256, lds, stream>>>(ga, sa, bn, n_gemm, ro_gx, ro_ch, K / 4, packed, n_main, pr, ro_map);
+    TSGNN_FWD_BN(true, false);
   } else if (row_slot) {
     TSGNN_KNAME("sage_layer_fwd_bn_kernel<false,true>");
-    sage_layer_fwd_bn_kernel<false, true><<<n_main + pr.blocks, 256, lds, stream>>>(ga, sa, bn, n_gemm, ro_gx, ro_ch, K / 4, packed, n_main, pr, ro_map);
+    TSGNN_FWD_BN(false, true);
   } else {
     TSGNN_KNAME("sage_layer_fwd_bn_kernel<false,false>");
-    sage_layer_fwd_bn_kernel<false, false><<<n_main + pr.blocks, 256, lds, stream>>>(ga, sa, bn, n_gemm, ro_gx, ro_ch, K / 4, packed, n_main, pr, ro_map);
+    TSGNN_FWD_BN(false, false);
   }
+#undef TSGNN_FWD_BN
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;
 }

@@ -62,10 +62,11 @@ __global__ __launch_bounds__(512) void rowgemm_gather_ks2_kernel(RowGemmArgs g) 
 
 // the same two kernels with the statistics epilogue (rowgemm_body.h, STATS): the layer in front of a slot batch-norm that has no
 // launch of its own (tsgnn_gather_rowgemm_st_f32)
+template <bool UNITS>
 __global__ __launch_bounds__(256) void rowgemm_gather_st_kernel(RowGemmArgs g, PullRider pr, unsigned nblk) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (blockIdx.x >= nblk) { pull_rider_body(pr, blockIdx.x - nblk); return; }    // passengers, as below
-  rowgemm_body<4, false, true, 1, false, false, true>(g, smem, blockIdx.x);
+  rowgemm_body<4, false, true, 1, false, false, true, UNITS>(g, smem, blockIdx.x);
 }
 // pr: passengers (csrc/ingest_rider.h) — a share of the NEXT mini-batch's staging buffer -> its mirror as the launch's last workgroups
 __global__ __launch_bounds__(512) void rowgemm_gather_ks2_st_kernel(RowGemmArgs g, PullRider pr, unsigned nblk) {
@@ -305,7 +306,8 @@ int tsgnn_gather_rowgemm_st_f32(const int* ell, int ell_w, const int* tail_ptr, 
   } else {
     const PullRider pr = take_pull_rider(256);
     TSGNN_KNAME("rowgemm_gather_st_kernel");
-    rowgemm_gather_st_kernel<<<nblk + pr.blocks, 256, rowgemm_lds_bytes<4, false, true>(), stream>>>(g, pr, nblk);
+    if (g.unit == 8 || g.unit == 16) rowgemm_gather_st_kernel<true><<<nblk + pr.blocks, 256, rowgemm_lds_bytes<4, false, true>(), stream>>>(g, pr, nblk);
+    else rowgemm_gather_st_kernel<false><<<nblk + pr.blocks, 256, rowgemm_lds_bytes<4, false, true>(), stream>>>(g, pr, nblk);
   }
   TSGNN_CHECK_LAUNCH();
   return TSGNN_OK;

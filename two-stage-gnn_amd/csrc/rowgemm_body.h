@@ -100,7 +100,7 @@ constexpr int LDA_F = 128;            // row stride of the gathered full-K A pan
 // epilogue), so a CU idles through every memory wait; with two wave groups the gather prologue is shared by twice the
 // lanes (half the rows per lane), each group runs half of the K chunks on its own LDS stages while the other group's
 // waits are covered, and group 1 hands its accumulators to group 0 through LDS before the (unchanged) epilogue.
-template <int NT, bool TRANS_B, bool GATHER, int KS = 1, bool READOUT = false, bool BNIN = false, bool STATS = false>
+template <int NT, bool TRANS_B, bool GATHER, int KS = 1, bool READOUT = false, bool BNIN = false, bool STATS = false, bool UNITS = false>
 __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem_all, unsigned bid) {
   static_assert(KS == 1 || (KS == 2 && GATHER && NT <= 4), "the split-K variant is built for the gather kernel, widths <= 128");
   static_assert(!READOUT || (NT <= 4 && KS == 1), "the readout epilogue is built for one column tile per wave");
@@ -130,16 +130,18 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem_a
   // that the neighbour rows gathered by adjacent panels (same graph) are fetched into one L2 only.  The filler block
   // (last) keeps its index.
   const unsigned npanels = (unsigned)((g.rows + 31) / 32);
-  int64_t m0, rows_hi;                                   // this block's rows [m0, rows_hi)
-  if (g.unit == 8 || g.unit == 16) {
-    const int un = g.unit;
+  // UNITS (compile time: the plain path keeps its code — the same checks against a per-block row bound cost every panel kernel
+  // 0.2-0.6 us when they were decided at run time): this block's rows are [m0, rows_hi); plain: rows_hi = the batch's row count
+  int64_t m0, rows_hi;
+  if constexpr (UNITS) {
+    const int un = g.unit == 8 ? 8 : 16;
     const unsigned nfull = (unsigned)g.n_full, nhalf = (unsigned)((g.rows - 32 * (int64_t)nfull + un - 1) / un);
     if (bid < nfull) { m0 = (int64_t)xcd_remap(bid, nfull) * 32; rows_hi = m0 + 32; }
     else if (bid < nfull + nhalf) { m0 = 32 * (int64_t)nfull + un * (int64_t)xcd_remap(bid - nfull, nhalf); rows_hi = min(m0 + un, g.rows); }
     else { m0 = (int64_t)npanels * 32; rows_hi = m0; }   // the filler block
   } else {
     m0 = (bid < npanels ? (int64_t)xcd_remap(bid, npanels) : (int64_t)bid) * 32;
-    rows_hi = min(m0 + 32, g.rows);
+    rows_hi = g.rows;
   }
   TR(0);
   if (m0 >= g.rows) {
@@ -190,7 +192,7 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem_a
   if constexpr (READOUT) {
     if (g.ro_packed) {
       ro_gf = g.ro_row_graph[m0];
-      ro_gl = g.ro_row_graph[rows_hi - 1];
+      ro_gl = g.ro_row_graph[min(m0 + 31, rows_hi - 1)];
     }
   }
 
@@ -624,7 +626,7 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs& g, float* smem_a
       // the wave, one 64-bit atomicMax per (graph, column) and panel.  Values are the stored ones (acc * scale), so the
       // readout is bitwise what a pass over c would find; ties go to the smallest row (~row in the low word).
       const int cn = wid * 32 + i;
-      const int64_t last = rows_hi - 1;
+      const int64_t last = min(m0 + 31, rows_hi - 1);
       for (int b = ro_gf; b <= ro_gl; ++b) {
         int64_t lo = m0, hi = last + 1;
         if (ro_gf != ro_gl) { lo = max(lo, (int64_t)g.ro_graph_ptr[b]); hi = min(hi, (int64_t)g.ro_graph_ptr[b + 1]); }
