@@ -68,8 +68,8 @@ int tsgnn_sage_layer_bwd_f32(const int* ell, int ell_w, const int* tail_ptr, con
   // one-panel-per-CU launches delay.  TSGNN_SLAB_DELAY overrides.
   static const int slab_delay_env = [] { const char* e = getenv("TSGNN_SLAB_DELAY"); return e ? atoi(e) : -1; }();
   const int slab_delay = slab_delay_env >= 0 ? slab_delay_env : ((int64_t)n_pan <= (int64_t)ncu ? 2 : 0);
-  TSGNN_KNAME(panels_first ? "sage_layer_bwd_kernel<true>" : "sage_layer_bwd_kernel<false>");
   const bool units = ga.unit == 8 || ga.unit == 16;
+  TSGNN_KNAME("sage_layer_bwd_kernel<%s,%s>", panels_first ? "true" : "false", units ? "true" : "false");   // (the demangled name, without blanks)
   if (panels_first && units) sage_layer_bwd_kernel<true, true><<<n_tn + n_pan, 256, la > lt ? la : lt, stream>>>(ga, gt, n_tn, (unsigned)nslab, n_pan, slab_delay);
   else if (panels_first) sage_layer_bwd_kernel<true><<<n_tn + n_pan, 256, la > lt ? la : lt, stream>>>(ga, gt, n_tn, (unsigned)nslab, n_pan, slab_delay);
   else if (units) sage_layer_bwd_kernel<false, true><<<n_tn + n_pan, 256, la > lt ? la : lt, stream>>>(ga, gt, n_tn, (unsigned)nslab, n_pan, slab_delay);

@@ -129,13 +129,13 @@ int tsgnn_sage_layer_fwd_bn_f32(const int* ell, int ell_w, const int* tail_ptr, 
     else sage_layer_fwd_bn_kernel<RO_, ST_><<<n_main + pr.blocks, 256, lds, stream>>>(ga, sa, bn, n_gemm, ro_gx, ro_ch, K / 4, packed, n_main, pr, ro_map);             \
   } while (0)
   if (packed_out) {
-    TSGNN_KNAME("sage_layer_fwd_bn_kernel<true,false>");
+    TSGNN_KNAME("sage_layer_fwd_bn_kernel<true,false,%s>", units ? "true" : "false");
     TSGNN_FWD_BN(true, false);
   } else if (row_slot) {
-    TSGNN_KNAME("sage_layer_fwd_bn_kernel<false,true>");
+    TSGNN_KNAME("sage_layer_fwd_bn_kernel<false,true,%s>", units ? "true" : "false");
     TSGNN_FWD_BN(false, true);
   } else {
-    TSGNN_KNAME("sage_layer_fwd_bn_kernel<false,false>");
+    TSGNN_KNAME("sage_layer_fwd_bn_kernel<false,false,%s>", units ? "true" : "false");
     TSGNN_FWD_BN(false, false);
   }
 #undef TSGNN_FWD_BN

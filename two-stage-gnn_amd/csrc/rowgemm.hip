@@ -305,7 +305,7 @@ int tsgnn_gather_rowgemm_st_f32(const int* ell, int ell_w, const int* tail_ptr, 
     rowgemm_gather_ks2_st_kernel<<<nblk + pr.blocks, 512, lds2, stream>>>(g, pr, nblk);
   } else {
     const PullRider pr = take_pull_rider(256);
-    TSGNN_KNAME("rowgemm_gather_st_kernel");
+    TSGNN_KNAME("rowgemm_gather_st_kernel<%s>", (g.unit == 8 || g.unit == 16) ? "true" : "false");
     if (g.unit == 8 || g.unit == 16) rowgemm_gather_st_kernel<true><<<nblk + pr.blocks, 256, rowgemm_lds_bytes<4, false, true>(), stream>>>(g, pr, nblk);
     else rowgemm_gather_st_kernel<false><<<nblk + pr.blocks, 256, rowgemm_lds_bytes<4, false, true>(), stream>>>(g, pr, nblk);
   }
