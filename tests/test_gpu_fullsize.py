@@ -100,10 +100,51 @@ def _run(model, loss_fn, forward32, forward64, lr, clip=2.0, steps=3, defer_loss
     return report
 
 
+def test_panel_units_equal_plain_panels():
+    """rows beyond one 32-row panel per compute unit as 16- / 8-row units (csrc/rowgemm_body.h panel_split; the first layer's product, the
+    fused forward launches, the merged backward launches) against plain panels on the SAME batches (switched per process with
+    tsgnn_panel_split_hint): a row's arithmetic does not depend on the block that owns it, so logits, loss and the input-side results
+    are BITWISE equal; the weight gradients are sums over differently cut slabs (the slab count follows the panel blocks) and agree to
+    rounding.  Batches of 271 (8-row units) and 288 panels (16-row units)."""
+    from two_stage_gnn_amd import dense_encoders as E, synthetic, _native as nat
+    dev = torch.device("cuda")
+
+    class A:
+        bias = True
+    for seed, want_unit in ((3, 8), (6, 16)):
+        hb = synthetic.host_batch(seed=seed, B=32, shape="DD", nmax=1000)
+        g, x, label = synthetic.to_device(hb, dev)
+        npan = -(-g.n_rows // 32)
+        ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+        if not (ncu < npan <= ncu + ncu // 2):
+            pytest.skip("this device hosts every panel of the batch at once")
+        blocks = int(nat.lib().tsgnn_panel_blocks(int(g.n_rows)))
+        assert blocks == (ncu & ~7) + -(-(g.n_rows - 32 * (ncu & ~7)) // want_unit), (blocks, npan)
+        out = []
+        for on in (1, 0):
+            nat.call_nostream("panel_split_hint", on)
+            try:
+                assert (int(nat.lib().tsgnn_panel_blocks(int(g.n_rows))) == npan) == (on == 0)
+                torch.manual_seed(11)
+                m = E.GcnEncoderGraph(89, 128, 128, 2, 3, bn=True, args=A(), final_dim="number_classes").to(dev)
+                g2, x2, _ = synthetic.to_device(hb, dev)              # (a fresh batch object: no cached launch plans)
+                logits = m(x2, g2)[1]
+                loss = m.loss(logits, label)
+                loss.backward()
+                torch.cuda.synchronize()
+                out.append((logits.detach().clone(), float(loss.detach()), [p.grad.detach().clone() for p in m.parameters() if p.grad is not None]))
+            finally:
+                nat.call_nostream("panel_split_hint", 1)
+        assert torch.equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]
+        for a, b in zip(out[0][2], out[1][2]):
+            torch.testing.assert_close(a, b, rtol=2e-5, atol=1e-7 * float(b.abs().max() + 1e-30) + 1e-9)
+
+
 # ------------------------------------------------------------------------------------------------ GraphSage stack (bench.py)
 @pytest.mark.parametrize("shape,B,nmax,layers,hid,seed", [
     ("DD", 32, 1000, 3, 128, 0),          # the headline batch: 8,151 rows = 255 row panels (bench.py, rank 0)
-    ("DD", 32, 1000, 3, 128, 6),          # bench.py's rank 6: 9,191 rows = 288 row panels (more panels than compute units)
+    ("DD", 32, 1000, 3, 128, 6),          # bench.py's rank 6: 9,191 rows = 288 row panels (more panels than compute units: 16-row units)
+    ("DD", 32, 1000, 3, 128, 3),          # rank 3: 8,662 rows = 271 panels (a small overflow: 8-row units behind one panel per unit)
     ("PROTEINS", 64, 620, 3, 128, 1),     # BASELINE config 2 (scripts/config_bench.py)
     ("MUTAG", 32, 40, 2, 64, 0),          # BASELINE config 1
 ])
